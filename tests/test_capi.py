@@ -1,0 +1,51 @@
+"""CPU: the C-ABI library loads (no GPU needed) and exports every symbol include/voxactb_hip.h declares."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'voxactb_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(vxb_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_library_exports_all_declared_symbols():
+    from voxactb_amd.csrc import build
+    build.build(verbose=False)
+    from voxactb_amd import _lib
+    L = _lib.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 3
+    missing = [s for s in syms if not hasattr(L, s)]
+    assert not missing, missing
+    assert L.vxb_abi_version() >= 1
+
+
+def test_workspace_size_query():
+    from voxactb_amd import _lib
+    n = _lib.lib().vxb_voxelize_workspace_bytes(16, 65536, 100)
+    assert n == (16 * 100 ** 3 + 16 + 7 * 16 * 65536) * 4
+    assert _lib.lib().vxb_voxelize_workspace_bytes(0, 1, 1) == 0
+
+
+def test_product_never_imports_oracle():
+    bad = []
+    for d, _, fs in os.walk(os.path.join(ROOT, 'voxactb_amd')):
+        for f in fs:
+            if f.endswith('.py'):
+                s = open(os.path.join(d, f)).read()
+                if re.search(r'^\s*(from|import)\s+oracle\b', s, flags=re.M):
+                    bad.append(os.path.join(d, f))
+    assert not bad, bad
+
+
+def test_cpu_tensor_is_refused():
+    import pytest
+    import torch
+    from voxactb_amd import _lib
+    from voxactb_amd.voxel.voxel_grid import VoxelGrid
+    vg = VoxelGrid([0, 0, 0, 1, 1, 1], 4, 'cpu', 1, 3, 8)
+    with pytest.raises(_lib.VoxactbHipError):
+        vg.coords_to_bounding_voxel_grid(torch.zeros(1, 8, 3), torch.zeros(1, 8, 3))

@@ -1,0 +1,122 @@
+"""GPU parity: HIP voxelizer (through the C ABI) vs golden fixtures and the oracle.  Bit-exact in ALL channels."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import voxel_grid as ovox
+from voxactb_amd import synthetic
+from voxactb_amd.voxel.voxel_grid import VoxelGrid
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def same(a, b):
+    return torch.equal(torch.nan_to_num(a.cpu()), torch.nan_to_num(b.cpu()))
+
+
+def run(coords, feats, bounds, V):
+    B, N, _ = coords.shape
+    vg = VoxelGrid(bounds[0].tolist(), V, DEV, B, 0 if feats is None else feats.shape[-1], N)
+    out = vg.coords_to_bounding_voxel_grid(coords.to(DEV), None if feats is None else feats.to(DEV), bounds.to(DEV))
+    torch.cuda.synchronize()
+    # self-cleaning invariant: the cell table must be all-zero again
+    assert int(vg._ws[:B * V ** 3].abs().sum()) == 0
+    return out, vg
+
+
+def test_golden_kats(golden):
+    g = golden('f1_voxel_kats')
+    out, _ = run(T(g['kat_coords']), T(g['kat_feats']), T(g['kat_bounds']), int(g['kat_V']))
+    assert same(out, T(g['kat_grid']))
+    for c in range(int(g['n_cases'])):
+        out, _ = run(T(g['c%d_coords' % c]), T(g['c%d_feats' % c]), T(g['c%d_bounds' % c]), int(g['c%d_V' % c]))
+        ref = T(g['c%d_grid' % c])
+        assert same(out[..., -1], ref[..., -1]), 'occupancy case %d' % c
+        assert same(out, ref), 'case %d' % c
+
+
+def cams_batch(B, cams, H, W, V, seed):
+    rs = synthetic.make_replay_sample(B, cams, (H, W), V, 4, seed=seed)
+    pcd = [rs['%s_point_cloud' % c][:, 0] for c in cams]
+    rgb = [(rs['%s_rgb' % c][:, 0] / 255.0) * 2.0 - 1.0 for c in cams]
+    return pcd, rgb
+
+
+def test_c1_fixture_and_camera_path(golden):
+    g = golden('f3_encoder_c1')
+    pcd, rgb = cams_batch(1, ['front'], 64, 64, 32, seed=1)
+    bounds = torch.tensor([synthetic.SCENE_BOUNDS])
+    vg = VoxelGrid(synthetic.SCENE_BOUNDS, 32, DEV, 1, 3, 64 * 64)
+    out = vg.voxelize_cameras([p.to(DEV) for p in pcd], [r.to(DEV) for r in rgb], bounds.to(DEV))
+    assert same(out, T(g['grid']))
+    out2 = vg.voxelize_cameras([p.to(DEV) for p in pcd], [r.to(DEV) for r in rgb])   # default bounds, 2nd call
+    assert same(out2, T(g['grid']))
+
+
+@pytest.mark.parametrize('B,ncam,HW,V,per_sample', [(2, 2, 16, 8, False), (3, 4, 32, 50, True), (16, 4, 128, 100, False),
+                                                     (2, 3, 48, 25, True)])
+def test_vs_oracle(B, ncam, HW, V, per_sample):
+    cams = synthetic.CAMERAS4[:ncam]
+    pcd, rgb = cams_batch(B, cams, HW, HW, V, seed=7)
+    if per_sample:
+        g = np.random.default_rng(3)
+        c = np.array(synthetic.SCENE_BOUNDS[:3]) + g.uniform(0.3, 0.7, (B, 3))
+        bounds = torch.tensor(np.concatenate([c - 0.3, c + 0.3], 1), dtype=torch.float32)
+    else:
+        bounds = torch.tensor([synthetic.SCENE_BOUNDS])
+    coords, feats = ovox.flatten_cameras(pcd, rgb)
+    ref = ovox.voxelize(coords, feats, bounds, V)
+    vg = VoxelGrid(synthetic.SCENE_BOUNDS, V, DEV, B, 3, ncam * HW * HW)
+    out = vg.voxelize_cameras([p.to(DEV) for p in pcd], [r.to(DEV) for r in rgb], bounds.to(DEV))
+    assert same(out[..., -1], ref[..., -1]), 'occupancy'
+    assert same(out[..., 6:9], ref[..., 6:9]), 'index channels'
+    assert same(out, ref), 'mean channels'
+    out_flat, _ = run(coords, feats, bounds, V)
+    assert same(out_flat, ref)
+    # run-to-run determinism
+    out3 = vg.voxelize_cameras([p.to(DEV) for p in pcd], [r.to(DEV) for r in rgb], bounds.to(DEV))
+    assert torch.equal(out, out3)
+
+
+def test_edge_cases():
+    V = 16
+    bounds = torch.tensor([[0., 0., 0., 1., 1., 1.]])
+    # (a) nothing inside -> all cells empty
+    p = torch.full((2, 100, 3), 5.0)
+    out, _ = run(p, torch.ones(2, 100, 3), bounds, V)
+    assert same(out, ovox.voxelize(p, torch.ones(2, 100, 3), bounds, V)) and float(out[..., -1].sum()) == 0
+    # (b) every point in ONE cell (long path, count >> 16), order-sensitive values
+    g = np.random.default_rng(0)
+    p = torch.from_numpy((0.5 + 0.01 * g.uniform(0, 1, (1, 5000, 3))).astype(np.float32))
+    f = torch.from_numpy((g.standard_normal((1, 5000, 3)) * 10 ** g.uniform(-3, 3, (1, 5000, 1))).astype(np.float32))
+    out, _ = run(p, f, bounds, V)
+    assert same(out, ovox.voxelize(p, f, bounds, V))
+    # (c) counts straddling the short/long threshold (15, 16, 17, 18 points per cell) + no features
+    pts = []
+    for i, cnt in enumerate((1, 2, 3, 15, 16, 17, 18, 33, 64, 65)):
+        base = np.array([0.03 + 0.0625 * i, 0.5, 0.5], np.float32)
+        pts.append(base + 0.01 * g.uniform(0, 1, (cnt, 3)).astype(np.float32))
+    p = torch.from_numpy(np.concatenate(pts)[None])
+    perm = torch.from_numpy(g.permutation(p.shape[1]))
+    p = p[:, perm]
+    f = torch.from_numpy(g.standard_normal((1, p.shape[1], 3)).astype(np.float32))
+    out, _ = run(p, f, bounds, V)
+    assert same(out, ovox.voxelize(p, f, bounds, V))
+    out, _ = run(p, None, bounds, V)
+    assert same(out, ovox.voxelize(p, torch.zeros(1, p.shape[1], 0), bounds, V))
+    # (d) odd V (scalar fill path) and feature_size 1
+    out, _ = run(p, f[..., :1], bounds, 7)
+    assert same(out, ovox.voxelize(p, f[..., :1], bounds, 7))
+
+
+def test_errors():
+    from voxactb_amd import _lib
+    vg = VoxelGrid([0, 0, 0, 1, 1, 1], 8, DEV, 2, 3, 16)
+    with pytest.raises(_lib.VoxactbHipError):
+        vg.coords_to_bounding_voxel_grid(torch.zeros(2, 16, 3, device=DEV), torch.zeros(2, 16, 3, device=DEV),
+                                         torch.zeros(3, 6, device=DEV))   # bounds rows not in {1, B}

@@ -1,0 +1,63 @@
+"""Build libvoxactb_hip.so (all gfx950 kernels + the C ABI) in-tree with hipcc.
+
+    python -m voxactb_amd.csrc.build [--force]
+
+hipcc cross-compiles for gfx950 without a GPU.  The .so is git-ignored but travels to the GPU
+box with the gpurun snapshot.  Objects are rebuilt only when their source (or a header) is newer.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, 'libvoxactb_hip.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
+         '-fhip-fp32-correctly-rounded-divide-sqrt', '-Wno-unused-result']
+
+
+def sources():
+    return sorted(f for f in os.listdir(HERE) if f.endswith('.hip'))
+
+
+def _headers_mtime():
+    hs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith('.h')]
+    hs.append(os.path.join(HERE, '..', '..', 'include', 'voxactb_hip.h'))
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def _compile(src, force):
+    obj = os.path.join(HERE, src[:-4] + '.o')
+    s = os.path.join(HERE, src)
+    if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(s)
+            and os.path.getmtime(obj) > _headers_mtime()):
+        return obj, False
+    cmd = [HIPCC] + FLAGS + ['-c', s, '-o', obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, r.stdout, r.stderr))
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj, True
+
+
+def build(force=False, verbose=True):
+    srcs = sources()
+    with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+        res = list(ex.map(lambda s: _compile(s, force), srcs))
+    objs = [o for o, _ in res]
+    if force or any(c for _, c in res) or not os.path.exists(LIB):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))
+        if verbose:
+            print('built %s from %d sources' % (LIB, len(srcs)))
+    elif verbose:
+        print('%s up to date' % LIB)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

@@ -1,0 +1,433 @@
+// Deterministic multi-view point-cloud -> voxel-grid builder for gfx950 (MI355X).
+//
+// Replaces VoxelGrid.coords_to_bounding_voxel_grid (reference peract/voxel/voxel_grid.py:148-198,
+// scatter-mean :106-146) and the per-camera flatten of QFunction.forward
+// (peract/agents/peract_bc/qattention_peract_bc_agent.py:85-93).
+//
+// The reference zero-fills two dense B*(V+2)^3*7 accumulators, scatter-adds into both, divides,
+// crops and concatenates: ~2.9 GB of traffic at B=16, V=100.  Here the dense grid is written exactly
+// once and everything irregular happens on compact, L2-resident structures:
+//
+//   fill    pure 16-byte store stream: every cell written as "empty" (zeros | idx/V | 0)
+//   count   1 thread / point: cell id, rank = atomicAdd(table[cell], 1); first toucher registers
+//           the cell in a compact occupied-cell list               (int32 table, B*V^3*4 bytes)
+//   alloc   1 thread / occupied cell: bump-allocate a segment of `count` ids, table[cell] = base
+//   place   1 thread / point: seg[base + rank] = point id
+//   reduce  1 thread / occupied cell (count <= 16): sort ids in registers (bitonic network), sum the
+//           points IN ASCENDING POINT ID -- the order scatter_add_ uses on CPU -- divide, store the
+//           cell's 10 floats, reset table[cell] = 0
+//   reduce_long  1 wave / cell with count > 16: ids -> LDS bitmap (sorting by construction), expand,
+//           batched gathers, sequential fp32 adds in id order
+//
+// Integer atomics only => run-to-run deterministic, and bit-identical to the CPU reference in all
+// channels.  fp32 semantics follow the reference op for op (true division, the two +1e-12 terms).
+#include "common.h"
+#include <limits.h>
+
+namespace {
+
+constexpr int VOX_MAX_SRC = 8;
+constexpr int VOX_MAX_F = 8;
+constexpr int VOX_SHORT = 16;     // cells with <= this many points are reduced by one thread
+constexpr int VOX_CHUNK = 2048;   // ids expanded per bitmap sweep in the long path (64 words x 32 bits)
+
+struct VoxSrc {
+    const float* c[VOX_MAX_SRC];
+    const float* f[VOX_MAX_SRC];
+};
+struct VoxGeom {
+    int B, n_src, pps, N, F, V, bounds_rows;
+    long long cb, cc, cp, fb, fc, fp;
+};
+struct VoxWs {
+    int *table, *ctr, *cellid, *rank, *occ_cell, *occ_cnt, *occ_base, *seg, *longl;
+};
+
+__host__ __device__ inline size_t vox_ws_ints(long long B, long long N, long long V) {
+    return (size_t)(B * V * V * V + 16 + 7 * B * N);
+}
+
+__host__ inline VoxWs vox_ws_carve(void* ws, long long B, long long N, long long V) {
+    VoxWs w;
+    int* p = (int*)ws;
+    w.table = p;     p += B * V * V * V;
+    w.ctr = p;       p += 16;
+    w.cellid = p;    p += B * N;
+    w.rank = p;      p += B * N;
+    w.occ_cell = p;  p += B * N;
+    w.occ_cnt = p;   p += B * N;
+    w.occ_base = p;  p += B * N;
+    w.seg = p;       p += B * N;
+    w.longl = p;
+    return w;
+}
+
+// voxel_grid.py:153-163 for one axis; returns the index in the (V+2)-grid, clamped to [0, V+1].
+__device__ __forceinline__ int vox_axis_index(float p, float mn, float mx, int V) {
+    const float Vf = __fadd_rn((float)V, 1e-12f);          // dims_orig.float() + MIN_DENOMINATOR
+    const float res = __fdiv_rn(__fsub_rn(mx, mn), Vf);    // :157
+    const float den = __fadd_rn(res, 1e-12f);              // :158
+    const float org = __fsub_rn(mn, res);                  // :160
+    const float q = floorf(__fdiv_rn(__fsub_rn(p, org), den));
+    // .int() then min/max (:161-164).  NaN / huge values end in a border cell (0 or V+1) on CPU
+    // and here alike; border cells are cropped (:184), so only "is it a border" matters for them.
+    int iv;
+    if (!(q >= 0.0f)) iv = 0;
+    else if (q > (float)(V + 1)) iv = V + 1;
+    else iv = (int)q;
+    return iv;
+}
+
+__device__ __forceinline__ const float* vox_point_ptr(const float* const* src, int n, int pps, int b,
+                                                      long long bs, long long ps) {
+    const int s = n / pps;
+    const int i = n - s * pps;
+    return src[s] + (long long)b * bs + (long long)i * ps;
+}
+
+__global__ void __launch_bounds__(256) vox_count_kernel(VoxSrc src, VoxGeom g, const float* __restrict__ bounds,
+                                                        VoxWs w) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)g.B * g.N) return;
+    const int b = (int)(t / g.N);
+    const int n = (int)(t - (long long)b * g.N);
+    const float* cp = vox_point_ptr(src.c, n, g.pps, b, g.cb, g.cp);
+    const float* bd = bounds + (g.bounds_rows > 1 ? b * 6 : 0);
+    int idx[3];
+    bool inside = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int iv = vox_axis_index(cp[a * g.cc], bd[a], bd[3 + a], g.V);
+        inside = inside && (iv >= 1) && (iv <= g.V);
+        idx[a] = iv - 1;
+    }
+    int cell = -1, r = 0;
+    if (inside) {
+        cell = (idx[0] * g.V + idx[1]) * g.V + idx[2];
+        const int gc = b * g.V * g.V * g.V + cell;
+        r = atomicAdd(&w.table[gc], 1);
+        if (r == 0) {
+            const int slot = atomicAdd(&w.ctr[0], 1);
+            w.occ_cell[slot] = gc;
+        }
+    }
+    w.cellid[t] = cell;
+    w.rank[t] = r;
+}
+
+__global__ void __launch_bounds__(256) vox_alloc_kernel(VoxWs w) {
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    if (slot >= w.ctr[0]) return;
+    const int gc = w.occ_cell[slot];
+    const int L = w.table[gc];
+    const int base = atomicAdd(&w.ctr[1], L);
+    w.table[gc] = base;
+    w.occ_cnt[slot] = L;
+    w.occ_base[slot] = base;
+    if (L > VOX_SHORT) {
+        const int li = atomicAdd(&w.ctr[2], 1);
+        w.longl[li] = slot;
+    }
+}
+
+__global__ void __launch_bounds__(256) vox_place_kernel(VoxGeom g, VoxWs w) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)g.B * g.N) return;
+    const int cell = w.cellid[t];
+    if (cell < 0) return;
+    const int b = (int)(t / g.N);
+    const int n = (int)(t - (long long)b * g.N);
+    const int base = w.table[b * g.V * g.V * g.V + cell];
+    w.seg[base + w.rank[t]] = n;
+}
+
+#define VOX_CSWAP(x, y)            \
+    {                              \
+        const int lo_ = min(x, y); \
+        const int hi_ = max(x, y); \
+        x = lo_;                   \
+        y = hi_;                   \
+    }
+
+__device__ __forceinline__ void vox_sort16(int (&a)[16]) {
+    // bitonic network, fully unrolled so that a[] stays in registers
+#pragma unroll
+    for (int k = 2; k <= 16; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    if ((i & k) == 0) { VOX_CSWAP(a[i], a[l]); }
+                    else { VOX_CSWAP(a[l], a[i]); }
+                }
+            }
+        }
+    }
+}
+
+template <int F>
+__device__ __forceinline__ void vox_store_cell(float* __restrict__ out, int gc, int V, const float (&acc)[3 + F], int L) {
+    constexpr int C = 3 + F + 4;
+    const int V3 = V * V * V;
+    const int cell = gc % V3;
+    const int x = cell / (V * V);
+    const int y = (cell / V) % V;
+    const int z = cell % V;
+    float* o = out + (size_t)gc * C;
+    const float Lf = (float)L;                       // clamp_(1) is a no-op for occupied cells (:121)
+#pragma unroll
+    for (int c = 0; c < 3 + F; ++c) o[c] = __fdiv_rn(acc[c], Lf);
+    const float Vf = (float)V;                       // self._voxel_d (:197)
+    o[3 + F + 0] = __fdiv_rn((float)x, Vf);
+    o[3 + F + 1] = __fdiv_rn((float)y, Vf);
+    o[3 + F + 2] = __fdiv_rn((float)z, Vf);
+    o[3 + F + 3] = 1.0f;                             // (count/count > 0).float()  (:192)
+}
+
+template <int F>
+__global__ void __launch_bounds__(256) vox_reduce_short_kernel(VoxSrc src, VoxGeom g, VoxWs w, float* __restrict__ out) {
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    if (slot >= w.ctr[0]) return;
+    const int L = w.occ_cnt[slot];
+    if (L > VOX_SHORT) return;
+    const int gc = w.occ_cell[slot];
+    const int base = w.occ_base[slot];
+    const int b = gc / (g.V * g.V * g.V);
+    int a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = (i < L) ? w.seg[base + i] : INT_MAX;
+    if (L == 2) {
+        VOX_CSWAP(a[0], a[1]);
+    } else if (L > 2) {
+        vox_sort16(a);
+    }
+    float acc[3 + F];
+#pragma unroll
+    for (int c = 0; c < 3 + F; ++c) acc[c] = 0.0f;     // zeros_like(self._flat_output) (:145)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i < L) {
+            const float* cp = vox_point_ptr(src.c, a[i], g.pps, b, g.cb, g.cp);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] = __fadd_rn(acc[c], cp[c * g.cc]);
+            if (F > 0) {
+                const float* fp = vox_point_ptr(src.f, a[i], g.pps, b, g.fb, g.fp);
+#pragma unroll
+                for (int c = 0; c < F; ++c) acc[3 + c] = __fadd_rn(acc[3 + c], fp[c * g.fc]);
+            }
+        }
+    }
+    vox_store_cell<F>(out, gc, g.V, acc, L);
+    w.table[gc] = 0;
+}
+
+template <int F>
+__global__ void __launch_bounds__(64) vox_reduce_long_kernel(VoxSrc src, VoxGeom g, VoxWs w, float* __restrict__ out,
+                                                            int n_words) {
+    constexpr int NC = 3 + F;
+    constexpr int C = NC + 4;
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    unsigned* bm = (unsigned*)smem;
+    int* chunk = smem + ((n_words + 63) & ~63);
+    float* stage = (float*)(chunk + VOX_CHUNK);
+    const int lane = threadIdx.x;
+    const int n_long = w.ctr[2];
+    const int V3 = g.V * g.V * g.V;
+    for (int li = blockIdx.x; li < n_long; li += gridDim.x) {
+        const int slot = w.longl[li];
+        const int gc = w.occ_cell[slot];
+        const int L = w.occ_cnt[slot];
+        const int base = w.occ_base[slot];
+        const int b = gc / V3;
+        for (int i = lane; i < n_words; i += 64) bm[i] = 0u;
+        __syncthreads();
+        for (int i = lane; i < L; i += 64) {
+            const int id = w.seg[base + i];
+            atomicOr(&bm[id >> 5], 1u << (id & 31));
+        }
+        __syncthreads();
+        float acc = 0.0f;                     // lane c < NC accumulates channel c
+        for (int w0 = 0; w0 < n_words; w0 += 64) {
+            const int wi = w0 + lane;
+            unsigned word = (wi < n_words) ? bm[wi] : 0u;
+            const int cnt = __popc(word);
+            int incl = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            const int total = __shfl(incl, 63, 64);
+            if (total == 0) continue;          // wave-uniform
+            int pos = incl - cnt;
+            while (word) {
+                const int bit = __ffs(word) - 1;
+                chunk[pos++] = (wi << 5) + bit;
+                word &= word - 1;
+            }
+            __syncthreads();
+            for (int k0 = 0; k0 < total; k0 += 64) {
+                const int m = min(64, total - k0);
+                if (lane < m) {
+                    const int n = chunk[k0 + lane];
+                    const float* cp = vox_point_ptr(src.c, n, g.pps, b, g.cb, g.cp);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) stage[lane * NC + c] = cp[c * g.cc];
+                    if (F > 0) {
+                        const float* fp = vox_point_ptr(src.f, n, g.pps, b, g.fb, g.fp);
+#pragma unroll
+                        for (int c = 0; c < F; ++c) stage[lane * NC + 3 + c] = fp[c * g.fc];
+                    }
+                }
+                __syncthreads();
+                if (lane < NC) {
+                    for (int j = 0; j < m; ++j) acc = __fadd_rn(acc, stage[j * NC + lane]);
+                }
+                __syncthreads();
+            }
+        }
+        const int cell = gc % V3;
+        float* o = out + (size_t)gc * C;
+        const float Vf = (float)g.V;
+        if (lane < NC) o[lane] = __fdiv_rn(acc, (float)L);
+        else if (lane == NC) o[lane] = __fdiv_rn((float)(cell / (g.V * g.V)), Vf);
+        else if (lane == NC + 1) o[lane] = __fdiv_rn((float)((cell / g.V) % g.V), Vf);
+        else if (lane == NC + 2) o[lane] = __fdiv_rn((float)(cell % g.V), Vf);
+        else if (lane == NC + 3) o[lane] = 1.0f;
+        if (lane == 0) w.table[gc] = 0;
+        __syncthreads();
+    }
+}
+
+// Every cell as "empty": channels [0, NC) = 0, idx/V, occupancy 0 (voxel_grid.py:192-198 for count == 0).
+// One z-row (V*C floats) per block iteration, 16-byte stores; the (z, channel) of a thread's four
+// floats do not depend on the row, so they are decoded once.
+__global__ void __launch_bounds__(256) vox_fill_kernel(float* __restrict__ out, int rows, int V, int C) {
+    const int NC = C - 4;
+    const int q4 = (V * C) >> 2;                 // float4 per row
+    const float Vf = (float)V;
+    for (int j = threadIdx.x; j < q4; j += 256) {
+        int sel[4];
+        float zv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int f = 4 * j + e;
+            const int z = f / C;
+            const int ch = f - z * C;
+            sel[e] = ch - NC;                      // 0 -> x/V, 1 -> y/V, 2 -> z/V, else 0
+            zv[e] = __fdiv_rn((float)z, Vf);
+        }
+        for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+            const int xy = row % (V * V);
+            const float xv = __fdiv_rn((float)(xy / V), Vf);
+            const float yv = __fdiv_rn((float)(xy % V), Vf);
+            float4 v;
+            v.x = sel[0] == 0 ? xv : sel[0] == 1 ? yv : sel[0] == 2 ? zv[0] : 0.0f;
+            v.y = sel[1] == 0 ? xv : sel[1] == 1 ? yv : sel[1] == 2 ? zv[1] : 0.0f;
+            v.z = sel[2] == 0 ? xv : sel[2] == 1 ? yv : sel[2] == 2 ? zv[2] : 0.0f;
+            v.w = sel[3] == 0 ? xv : sel[3] == 1 ? yv : sel[3] == 2 ? zv[3] : 0.0f;
+            reinterpret_cast<float4*>(out + (size_t)row * V * C)[j] = v;
+        }
+    }
+}
+
+// generic fallback when V*C is not a multiple of 4 (odd V): one float per thread iteration
+__global__ void __launch_bounds__(256) vox_fill_scalar_kernel(float* __restrict__ out, long long total, int V, int C) {
+    const int NC = C - 4;
+    const float Vf = (float)V;
+    for (long long f = (long long)blockIdx.x * 256 + threadIdx.x; f < total; f += (long long)gridDim.x * 256) {
+        const long long cellg = f / C;
+        const int ch = (int)(f - cellg * C);
+        const int cell = (int)(cellg % ((long long)V * V * V));
+        float v = 0.0f;
+        if (ch == NC) v = __fdiv_rn((float)(cell / (V * V)), Vf);
+        else if (ch == NC + 1) v = __fdiv_rn((float)((cell / V) % V), Vf);
+        else if (ch == NC + 2) v = __fdiv_rn((float)(cell % V), Vf);
+        out[f] = v;
+    }
+}
+
+template <int F>
+int vox_launch_reduce(const VoxSrc& src, const VoxGeom& g, const VoxWs& w, float* out, hipStream_t st) {
+    const long long BN = (long long)g.B * g.N;
+    hipLaunchKernelGGL(vox_reduce_short_kernel<F>, dim3(vxb_cdiv(BN, 256)), dim3(256), 0, st, src, g, w, out);
+    const int n_words = (g.N + 31) / 32;
+    const size_t lds = (size_t)(((n_words + 63) & ~63) + VOX_CHUNK) * 4 + (size_t)64 * (3 + F) * 4;
+    if (lds > 160 * 1024) return VXB_ESIZE;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)vox_reduce_long_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return VXB_ELAUNCH;
+    }
+    const int grid = (int)(BN / (VOX_SHORT + 1) < 1 ? 1 : (BN / (VOX_SHORT + 1) > 2048 ? 2048 : BN / (VOX_SHORT + 1)));
+    hipLaunchKernelGGL(vox_reduce_long_kernel<F>, dim3(grid), dim3(64), lds, st, src, g, w, out, n_words);
+    return VXB_OK;
+}
+
+}  // namespace
+
+extern "C" int vxb_abi_version(void) { return 1; }
+
+extern "C" size_t vxb_voxelize_workspace_bytes(int B, int n_points, int V) {
+    if (B <= 0 || n_points <= 0 || V <= 0) return 0;
+    return vox_ws_ints(B, n_points, V) * sizeof(int);
+}
+
+extern "C" int vxb_voxelize_f32(const float* const* coord_src, const float* const* feat_src, int n_src,
+                                int B, int pts_per_src, int F,
+                                int64_t coord_bstride, int64_t coord_cstride, int64_t coord_pstride,
+                                int64_t feat_bstride, int64_t feat_cstride, int64_t feat_pstride,
+                                const float* bounds, int bounds_rows, int V,
+                                float* out, void* workspace, size_t workspace_bytes, vxb_stream_t stream) {
+    if (!coord_src || !bounds || !out || !workspace) return VXB_EARG;
+    if (n_src < 1 || n_src > VOX_MAX_SRC || B < 1 || pts_per_src < 1 || V < 1) return VXB_EARG;
+    if (F < 0 || F > VOX_MAX_F || (F > 0 && !feat_src)) return VXB_EARG;
+    if (bounds_rows != 1 && bounds_rows != B) return VXB_EARG;
+    const long long N = (long long)n_src * pts_per_src;
+    const long long V3 = (long long)V * V * V;
+    if ((long long)B * V3 >= INT_MAX || (long long)B * N >= INT_MAX) return VXB_ESIZE;
+    if (workspace_bytes < vox_ws_ints(B, N, V) * sizeof(int)) return VXB_EWS;
+    hipStream_t st = (hipStream_t)stream;
+    VoxSrc src;
+    for (int s = 0; s < VOX_MAX_SRC; ++s) {
+        src.c[s] = s < n_src ? coord_src[s] : nullptr;
+        src.f[s] = (s < n_src && F > 0) ? feat_src[s] : nullptr;
+        if (s < n_src && (!src.c[s] || (F > 0 && !src.f[s]))) return VXB_EARG;
+    }
+    VoxGeom g;
+    g.B = B; g.n_src = n_src; g.pps = pts_per_src; g.N = (int)N; g.F = F; g.V = V; g.bounds_rows = bounds_rows;
+    g.cb = coord_bstride; g.cc = coord_cstride; g.cp = coord_pstride;
+    g.fb = feat_bstride; g.fc = feat_cstride; g.fp = feat_pstride;
+    VoxWs w = vox_ws_carve(workspace, B, N, V);
+    const int C = 3 + F + 4;
+    const long long BN = (long long)B * N;
+
+    if (hipMemsetAsync(w.ctr, 0, 16 * sizeof(int), st) != hipSuccess) return VXB_ELAUNCH;
+    if (((V * C) & 3) == 0 && (((uintptr_t)out) & 15) == 0) {
+        const int rows = B * V * V;
+        hipLaunchKernelGGL(vox_fill_kernel, dim3(rows < 4096 ? rows : 4096), dim3(256), 0, st, out, rows, V, C);
+    } else {
+        hipLaunchKernelGGL(vox_fill_scalar_kernel, dim3(2048), dim3(256), 0, st, out, (long long)B * V3 * C, V, C);
+    }
+    hipLaunchKernelGGL(vox_count_kernel, dim3(vxb_cdiv(BN, 256)), dim3(256), 0, st, src, g, bounds, w);
+    hipLaunchKernelGGL(vox_alloc_kernel, dim3(vxb_cdiv(BN, 256)), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(vox_place_kernel, dim3(vxb_cdiv(BN, 256)), dim3(256), 0, st, g, w);
+    int rc = VXB_OK;
+    switch (F) {
+        case 0: rc = vox_launch_reduce<0>(src, g, w, out, st); break;
+        case 1: rc = vox_launch_reduce<1>(src, g, w, out, st); break;
+        case 2: rc = vox_launch_reduce<2>(src, g, w, out, st); break;
+        case 3: rc = vox_launch_reduce<3>(src, g, w, out, st); break;
+        case 4: rc = vox_launch_reduce<4>(src, g, w, out, st); break;
+        case 5: rc = vox_launch_reduce<5>(src, g, w, out, st); break;
+        case 6: rc = vox_launch_reduce<6>(src, g, w, out, st); break;
+        case 7: rc = vox_launch_reduce<7>(src, g, w, out, st); break;
+        case 8: rc = vox_launch_reduce<8>(src, g, w, out, st); break;
+        default: return VXB_EARG;
+    }
+    if (rc != VXB_OK) return rc;
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}

@@ -1,0 +1,105 @@
+"""Seeded synthetic replay batches with the schema `launch_utils.create_replay`
+declares (reference: peract/agents/peract_bc/launch_utils.py:56-145; shapes after
+`offline_train_runner.py:140`: every element is (B, 1, *shape)).
+
+There is no RLBench data on the GPU box, so bench.py / tests / smoke() draw their
+inputs from here: per camera an RGB image uniform in
+[0, 255] and a point cloud that mimics RGB-D geometry -- 70 % of the pixels on
+three planes and two boxes inside the scene bounds, 20 % clustered inside a 5 cm
+ball (wrist-camera contention on a few voxels), 10 % outside the bounds (dropped
+by the voxelizer's border crop).  numpy Philox keyed by (seed, name) so that the
+same batch can be regenerated anywhere.
+"""
+import zlib
+import numpy as np
+import torch
+
+SCENE_BOUNDS = [-0.3, -0.5, 0.6, 0.7, 0.5, 1.6]   # peract/conf/config.yaml:15
+CAMERAS4 = ['front', 'left_shoulder', 'right_shoulder', 'wrist']
+
+
+def _rng(seed, name):
+    return np.random.Generator(np.random.Philox(key=(zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0xFFFFFFFF))
+
+
+def synthetic_point_cloud(g, B, H, W, bounds):
+    """[B,3,H,W] float32 world-metre point cloud."""
+    lo = np.asarray(bounds[:3], np.float64)
+    hi = np.asarray(bounds[3:], np.float64)
+    ext = hi - lo
+    n = H * W
+    pts = np.empty((B, n, 3), np.float64)
+    for b in range(B):
+        kind = g.uniform(0, 1, n)
+        u = g.uniform(0, 1, (n, 3))
+        p = lo + u * ext
+        # three planes (table z, back wall x, side wall y)
+        m = kind < 0.30
+        p[m, 2] = lo[2] + 0.15 * ext[2] + 0.002 * g.standard_normal(m.sum())
+        m = (kind >= 0.30) & (kind < 0.42)
+        p[m, 0] = hi[0] - 0.05 * ext[0] + 0.002 * g.standard_normal(m.sum())
+        m = (kind >= 0.42) & (kind < 0.52)
+        p[m, 1] = lo[1] + 0.08 * ext[1] + 0.002 * g.standard_normal(m.sum())
+        # two boxes
+        m = (kind >= 0.52) & (kind < 0.62)
+        p[m] = lo + (0.3 + 0.12 * u[m]) * ext
+        m = (kind >= 0.62) & (kind < 0.70)
+        p[m] = lo + (0.6 + 0.08 * u[m]) * ext
+        # cluster within a 5 cm ball
+        m = (kind >= 0.70) & (kind < 0.90)
+        c = lo + g.uniform(0.25, 0.75, 3) * ext
+        d = g.standard_normal((m.sum(), 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True) + 1e-9
+        p[m] = c + d * (0.05 * g.uniform(0, 1, (m.sum(), 1)) ** (1 / 3))
+        # outside the bounds
+        m = kind >= 0.90
+        side = g.integers(0, 2, (m.sum(), 3))
+        off = g.uniform(0.01, 0.5, (m.sum(), 3)) * ext
+        p[m] = np.where(side == 0, lo - off, hi + off)
+        pts[b] = p
+    return np.ascontiguousarray(pts.astype(np.float32).transpose(0, 2, 1).reshape(B, 3, H, W))
+
+
+def make_replay_sample(batch_size=16, cameras=CAMERAS4, image_size=(128, 128), voxel_size=100,
+                       low_dim_size=4, seed=0, scene_bounds=SCENE_BOUNDS, arm_pred_loss=False,
+                       crop_target_obj_voxel=False, crop_radius=0.3, n_depths=1):
+    """dict[str -> torch tensor (B,1,...)] as handed to PreprocessAgent.update()."""
+    B = batch_size
+    H, W = image_size
+    out = {}
+    lo = np.asarray(scene_bounds[:3], np.float32)
+    hi = np.asarray(scene_bounds[3:], np.float32)
+    for cam in cameras:
+        g = _rng(seed, cam)
+        rgb = g.integers(0, 256, (B, 3, H, W)).astype(np.float32)
+        pcd = synthetic_point_cloud(g, B, H, W, scene_bounds)
+        out['%s_rgb' % cam] = torch.from_numpy(rgb).unsqueeze(1)
+        out['%s_point_cloud' % cam] = torch.from_numpy(pcd).unsqueeze(1)
+        out['%s_camera_extrinsics' % cam] = torch.eye(4).repeat(B, 1, 1, 1)
+        out['%s_camera_intrinsics' % cam] = torch.eye(3).repeat(B, 1, 1, 1)
+    g = _rng(seed, 'labels')
+    out['trans_action_indicies'] = torch.from_numpy(
+        g.integers(0, voxel_size, (B, 1, 3 * n_depths)).astype(np.int32))
+    rg = np.concatenate([g.integers(0, 72, (B, 1, 3)), g.integers(0, 2, (B, 1, 1))], -1)
+    out['rot_grip_action_indicies'] = torch.from_numpy(rg.astype(np.int32))
+    out['ignore_collisions'] = torch.from_numpy(g.integers(0, 2, (B, 1, 1)).astype(np.int32))
+    pos = lo + g.uniform(0.3, 0.7, (B, 3)).astype(np.float32) * (hi - lo)
+    q = g.standard_normal((B, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    out['gripper_pose'] = torch.from_numpy(np.concatenate([pos, q], 1)).unsqueeze(1)
+    out['lang_goal_emb'] = torch.from_numpy(g.standard_normal((B, 1, 1024)).astype(np.float32))
+    out['lang_token_embs'] = torch.from_numpy(g.standard_normal((B, 1, 77, 512)).astype(np.float32))
+    out['low_dim_state'] = torch.from_numpy(g.uniform(0, 1, (B, 1, low_dim_size)).astype(np.float32))
+    if arm_pred_loss:
+        out['label'] = torch.from_numpy(g.integers(0, 2, (B, 1, 1)).astype(np.int32))
+    if crop_target_obj_voxel:
+        c = lo + g.uniform(0.35, 0.65, (B, 3)).astype(np.float32) * (hi - lo)
+        tb = np.concatenate([c - crop_radius, c + crop_radius], 1).astype(np.float32)
+        out['target_object_scene_bounds'] = torch.from_numpy(tb).unsqueeze(1)
+    out['action'] = torch.zeros(B, 1, 8)
+    out['reward'] = torch.zeros(B, 1)
+    out['terminal'] = torch.zeros(B, 1, dtype=torch.int8)
+    out['timeout'] = torch.zeros(B, 1, dtype=torch.bool)
+    out['indices'] = torch.arange(B, dtype=torch.int32).unsqueeze(1)
+    out['demo'] = torch.ones(B, dtype=torch.bool)
+    return out
