@@ -12,6 +12,8 @@
  *     small, -4 HIP launch error (hipGetLastError != hipSuccess).  Python raises RuntimeError.
  *   - all tensors fp32 unless the name says otherwise; activations are channels-last
  *     ([B, D, H, W, C] / [B, N, C]); one host thread per process drives one stream.
+ *   - "ACCUMULATED" outputs are += (parameter gradients); everything else is overwritten unless an
+ *     `accumulate` flag says otherwise.
  */
 #ifndef VOXACTB_HIP_H
 #define VOXACTB_HIP_H
@@ -47,6 +49,113 @@ int vxb_voxelize_f32(const float* const* coord_src, const float* const* feat_src
                      int64_t feat_bstride, int64_t feat_cstride, int64_t feat_pstride,
                      const float* bounds, int bounds_rows, int V,
                      float* out, void* workspace, size_t workspace_bytes, vxb_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * fp32 matrix-core GEMM (v_mfma_f32_32x32x2_f32).  Replaces nn.Linear / einsum in Attention,
+ * FeedForward, lang_preprocess (perceiver_lang_io.py:80-132, :417).
+ *   C[z] (+)= act(alpha * A[z] @ B[z] + bias) (+ residual[z]),  z in [0,batch): offsets (z/H)*b?1 + (z%H)*b?2
+ * A(m,k) at A[m*sAm + k*sAk], B(k,n) at B[k*sBk + n*sBn]; one stride of each operand must be 1 and the
+ * other a multiple of 4 (16-byte loads).  act: 0 none, 1 LeakyReLU(slope). */
+int vxb_gemm_f32(const float* A, const float* B, float* C, const float* bias, const float* residual,
+                 int M, int N, int K, int64_t sAm, int64_t sAk, int64_t sBk, int64_t sBn, int64_t ldc,
+                 int batch, int H, int64_t bA1, int64_t bA2, int64_t bB1, int64_t bB2, int64_t bC1,
+                 int64_t bC2, float alpha, int act, float slope, int accumulate, vxb_stream_t stream);
+/* same contract, one thread per output element: for the tiny layers (proprio 4|7|8 -> 64, MLP heads). */
+int vxb_naive_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                       int64_t sAm, int64_t sAk, int64_t sBk, int64_t sBn, int64_t ldc, int act, float slope,
+                       int accumulate, vxb_stream_t stream);
+
+/* Implicit-GEMM conv3d over channels-last cubes.  Replaces Conv3DBlock.forward
+ * (peract/helpers/network_utils.py:166-170; replicate padding :135-137) and, with flipped weights and
+ * zero padding, its data gradient.  rows m=(b,d,h,w) over S_out^3; src voxel = o*stride + tap + off per axis
+ * (replicate: clamped, else zero outside); K = kext^3*(C0+C1) ordered (tap, channel) with the channels of
+ * src0 then src1 (torch.cat([d0,u0],1) without the cat, perceiver_lang_io.py:462); wt: [K][N].
+ * d2s_s > 0: depth-to-space output -- column n=(phase, co), written to a (S_out*d2s_s)^3 x d2s_C grid. */
+int vxb_conv3d_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
+                   int stride, int kext, int off, int replicate, const float* wt, int N,
+                   const float* bias, float* out, int64_t ldc, int act, float slope, int accumulate,
+                   int d2s_s, int d2s_C, vxb_stream_t stream);
+/* Weight gradient of the same conv: part[z][K][N] = gather(src)^T @ dY over the z-th slice of positions
+ * (reduce with vxb_sum_splits_f32).  d2s_s > 0: dY is the fine grid of a depth-to-space output. */
+int vxb_conv3d_wgrad_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
+                         int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
+                         int d2s_s, int d2s_C, float* part, int nsplit, vxb_stream_t stream);
+/* Adjoint of replicate padding after a data-gradient conv: dst[b,j,c] (+)= sum of src[b,i,c0+c] over the padded
+ * positions i that clamp to j; optionally times LeakyReLU'(lrelu_of[b,j,c]) (the producer's activation). */
+int vxb_fold_pad_f32(const float* src, int Sp, int Cs, int c0, float* dst, const float* lrelu_of, int B, int S,
+                     int C, int pad, int accumulate, float slope, vxb_stream_t stream);
+/* Polyphase form of Upsample(x s, trilinear, align_corners=False) followed by Conv3d(k) (network_utils.py:245-250):
+ * Weff[(j3*Cin+ci)][(r3*Cout+co)] = sum_t W[co][ci][t] * L[r][t][j] per axis; and its adjoint (dW ACCUMULATED). */
+int vxb_polyphase_weights_f32(const float* W, const float* L, float* Weff, int Cin, int Cout, int k, int s, int kl,
+                              vxb_stream_t stream);
+int vxb_polyphase_weights_bwd_f32(const float* dWeff, const float* L, float* dW, int Cin, int Cout, int k, int s, int kl,
+                                  vxb_stream_t stream);
+
+/* 1x1x1 input conv 10 -> 64 + LeakyReLU (perceiver_lang_io.py:357) and its parameter gradients (ACCUMULATED). */
+int vxb_pointwise_fwd_f32(const float* x, const float* W, const float* bias, float* y, int64_t nvox, int Cin,
+                          int Cout, float slope, vxb_stream_t stream);
+int vxb_pointwise_wgrad_f32(const float* x, const float* y, const float* dy, float* dW, float* db, float* part_ws,
+                            int64_t nvox, int Cin, int Cout, float slope, vxb_stream_t stream);
+
+/* 3x3x3 conv with one output channel = trans_decoder (perceiver_lang_io.py:465): forward, data gradient
+ * (replicate adjoint folded in, optional LeakyReLU' of the producer), parameter gradients (ACCUMULATED). */
+int vxb_conv3_c1_fwd_f32(const float* u, const float* w, const float* bias, float* q, int B, int S, int C,
+                         vxb_stream_t stream);
+int vxb_conv3_c1_dgrad_f32(const float* dq, const float* w, const float* u, float* du, int B, int S, int C,
+                           int accumulate, int apply_lrelu_mask, float slope, vxb_stream_t stream);
+int vxb_conv3_c1_wgrad_f32(const float* u, const float* dq, float* dw, float* db, float* part_ws, int B, int S, int C,
+                           vxb_stream_t stream);
+
+/* SpatialSoftmax3D (T=0.01, meshgrid 'xy' quirk) + AdaptiveMaxPool3d(1) in one streaming pass
+ * (network_utils.py:773-809; perceiver_lang_io.py:360,:451,:470), and the backward of both. */
+int vxb_ss3d_max_fwd_f32(const float* x, int64_t bs, int B, int S, int C, const float* lin, float* part_ws,
+                         float* out_ss, float* out_max, float* stats, int32_t* argmax, vxb_stream_t stream);
+int vxb_ss3d_max_bwd_f32(const float* x, int64_t bs, int B, int S, int C, const float* lin, const float* stats,
+                         const float* out_ss, const int32_t* argmax, const float* g_ss, const float* g_max,
+                         float* dx, int64_t dbs, int accumulate, vxb_stream_t stream);
+
+/* PreNorm LayerNorm (perceiver_lang_io.py:56-71), eps 1e-5.  bwd: dgamma/dbeta ACCUMULATED. */
+int vxb_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                          float* rstd, int64_t rows, int D, float eps, vxb_stream_t stream);
+int vxb_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean,
+                          const float* rstd, float* dx, float* dgamma, float* dbeta, float* part_ws,
+                          int64_t rows, int D, int accumulate_dx, vxb_stream_t stream);
+
+/* attention softmax + dropout (perceiver_lang_io.py:124-128), counter-based keep mask (seed,row,col). */
+int vxb_softmax_rows_f32(float* S, float* P_drop, int64_t rows, int cols, int64_t ld, float dropout_p,
+                         uint32_t seed, vxb_stream_t stream);
+int vxb_softmax_bwd_rows_f32(const float* P, float* dP_inout, int64_t rows, int cols, int64_t ld, float scale,
+                             float dropout_p, uint32_t seed, vxb_stream_t stream);
+
+/* GEGLU x * gelu_erf(gates) (perceiver_lang_io.py:74-77); LeakyReLU backward; y += alpha*x. */
+int vxb_geglu_fwd_f32(const float* h, float* out, int64_t rows, int F, vxb_stream_t stream);
+int vxb_geglu_bwd_f32(const float* h, const float* dout, float* dh, int64_t rows, int F, vxb_stream_t stream);
+int vxb_lrelu_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, float slope, vxb_stream_t stream);
+int vxb_axpy_f32(float* dst, const float* src, int64_t n, float alpha, vxb_stream_t stream);
+
+/* deterministic reductions: dst (+)= alpha * sum_s part[s][:];  out (+)= column sums of x[rows,N]. */
+int vxb_sum_splits_f32(const float* part, int nsplit, int64_t n, float* dst, int accumulate, float alpha,
+                       vxb_stream_t stream);
+int vxb_colsum_f32(const float* x, int64_t rows, int N, int64_t ld, float* part_ws, float* out, int accumulate,
+                   vxb_stream_t stream);
+
+/* context assembly cat(lang, cat(patch, proprio)) + pos_encoding (perceiver_lang_io.py:370-422) and its adjoint. */
+int vxb_ctx_build_f32(const float* lang, const float* patch, const float* pp, const float* pos, float* ctx, int B,
+                      int T0, int T1, int C, vxb_stream_t stream);
+int vxb_ctx_bwd_f32(const float* dctx, float* dlang, float* dpatch, float* dpp, float* dpos, float* part_ws, int B,
+                    int T0, int T1, int C, vxb_stream_t stream);
+
+/* cross-entropy (agent :517-578) + argmax (agent :57-80): one 10^6-way head, and up to 8 small heads per row. */
+int vxb_ce_big_f32(const float* x, int64_t P, int B, const int32_t* label, float* part_ws, float* lse, float* loss,
+                   int32_t* argmax, float* dx, float gscale, vxb_stream_t stream);
+int vxb_ce_rows_f32(const float* logits, int64_t ld, int rows, int nseg, const int32_t* col0, const int32_t* ncls,
+                    const int32_t* labels, float* loss, int32_t* pred, float* dlogits, float gscale,
+                    vxb_stream_t stream);
+
+/* Fused multi-tensor LAMB (peract/helpers/optim/lamb.py:94-122; no bias correction, ||w|| clamp 10). */
+int vxb_lamb_step_f32(float* w, const float* g, float* m, float* v, float* upd, const int32_t* chunks, int nchunks,
+                      const int32_t* first, int ntensors, float* part, float* trust, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, vxb_stream_t stream);
 
 #ifdef __cplusplus
 }

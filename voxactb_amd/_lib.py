@@ -3,20 +3,47 @@
 There is deliberately NO fallback: if the library is missing or a kernel returns an error the
 caller gets an exception.  torch is imported first so that the HIP runtime the library resolves
 (`libamdhip64.so.7`) is the one torch already loaded -- device pointers and streams are then shared.
+Prototypes are parsed from the header itself, so the binding cannot drift from the ABI.
 """
 import ctypes
 import os
+import re
 
 import torch  # noqa: F401  (must precede the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libvoxactb_hip.so')
+HEADER = os.path.join(_HERE, '..', 'include', 'voxactb_hip.h')
 
 _ERR = {-1: 'bad argument', -2: 'unsupported size', -3: 'workspace too small', -4: 'HIP launch error'}
 
 
 class VoxactbHipError(RuntimeError):
     pass
+
+
+_CT = {'int': ctypes.c_int, 'int64_t': ctypes.c_int64, 'size_t': ctypes.c_size_t, 'float': ctypes.c_float,
+       'uint32_t': ctypes.c_uint32, 'int32_t': ctypes.c_int32, 'vxb_stream_t': ctypes.c_void_p, 'void': None}
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [argtypes])} for every `vxb_*` prototype in the header."""
+    txt = open(path).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    protos = {}
+    for m in re.finditer(r'\b(int|size_t)\s+(vxb_[a-z0-9_]+)\s*\(([^)]*)\)\s*;', txt, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        argtypes = []
+        for a in [x.strip() for x in args.split(',') if x.strip()]:
+            if a == 'void':
+                continue
+            if '*' in a:
+                argtypes.append(ctypes.c_void_p)
+            else:
+                t = a.replace('const', '').split()[0]
+                argtypes.append(_CT[t])
+        protos[name] = (_CT[ret], argtypes)
+    return protos
 
 
 _lib = None
@@ -29,14 +56,32 @@ def lib():
             raise VoxactbHipError(
                 'HIP extension %s not found: run `python -m voxactb_amd.csrc.build` '
                 '(there is no CPU fallback for the product path)' % LIB_PATH)
-        _lib = ctypes.CDLL(LIB_PATH)
-        _declare(_lib)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in parse_header().items():
+            fn = getattr(L, name)       # AttributeError here == header/library mismatch: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
     return _lib
 
 
 def check(rc, what):
     if rc != 0:
         raise VoxactbHipError('%s failed: %s (code %d)' % (what, _ERR.get(rc, 'unknown'), rc))
+
+
+def call(name, *args):
+    """Call a C-ABI entry point; tensors are passed as device pointers, None as NULL; the current stream is appended."""
+    conv = []
+    for a in args:
+        if torch.is_tensor(a):
+            conv.append(ctypes.c_void_p(a.data_ptr()))
+        elif a is None:
+            conv.append(ctypes.c_void_p(0))
+        else:
+            conv.append(a)
+    rc = getattr(lib(), name)(*conv, stream_ptr())
+    check(rc, name)
 
 
 def stream_ptr(device=None):
@@ -52,31 +97,3 @@ def require_cuda(*tensors):
         if t is not None and not t.is_cuda:
             raise VoxactbHipError('voxactb_amd kernels need tensors on a HIP device (got %s); '
                                   'there is no CPU fallback' % t.device)
-
-
-c_int, c_i64, c_sz, c_f, c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float, ctypes.c_void_p
-
-
-def _declare(L):
-    L.vxb_abi_version.restype = c_int
-    L.vxb_voxelize_workspace_bytes.restype = c_sz
-    L.vxb_voxelize_workspace_bytes.argtypes = [c_int, c_int, c_int]
-    L.vxb_voxelize_f32.restype = c_int
-    L.vxb_voxelize_f32.argtypes = [c_p, c_p, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
-                                   c_p, c_int, c_int, c_p, c_p, c_sz, c_p]
-    for name, (res, args) in _EXTRA_DECLS.items():
-        fn = getattr(L, name)
-        fn.restype = res
-        fn.argtypes = args
-
-
-# filled by the op modules (voxactb_amd/ops_*.py) before first use of lib()
-_EXTRA_DECLS = {}
-
-
-def declare(name, restype, argtypes):
-    _EXTRA_DECLS[name] = (restype, argtypes)
-    if _lib is not None:
-        fn = getattr(_lib, name)
-        fn.restype = restype
-        fn.argtypes = argtypes

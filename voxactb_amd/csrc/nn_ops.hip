@@ -1,0 +1,451 @@
+// Normalisation / activation / softmax / small-GEMM kernels of the PerceiverIO Q-function (fp32).
+// Reference ops: PreNorm LayerNorm (perceiver_lang_io.py:56-71), GEGLU (:74-77), attention softmax +
+// dropout (:124-128), LeakyReLU(0.02) of Conv3DBlock / DenseBlock (network_utils.py:12-27,166-170,285-289).
+// All kernels are HBM-bound streaming passes: 16-byte accesses where the layout allows, one wave per
+// row for the row-wise ops (64-lane shuffles, no LDS), deterministic two-stage column reductions.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+// counter-based keep mask: same (seed, row, col) -> same decision in forward and backward
+__device__ __forceinline__ bool keep_elem(unsigned seed, unsigned row, unsigned col, float p) {
+    const unsigned h = hash32(hash32(row * 0x9E3779B1U + seed) ^ (col * 0x85EBCA77U + 0xC2B2AE3DU));
+    return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm
+// one wave per row; D <= 64*16
+template <int VPL>   // values per lane
+__global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                                     long long rows, int D, float eps) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + row * D;
+    float v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < D ? xr[c] : 0.f;
+        s += v[i];
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = lane + 64 * i;
+        const float d = c < D ? v[i] - mu : 0.f;
+        q += d * d;
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+    float* yr = y + row * D;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D) yr[c] = (v[i] - mu) * rs * gamma[c] + beta[c];
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// dx (+)= rstd*(dy*g - mean(dy*g) - xhat*mean(dy*g*xhat)); per-block partial dgamma/dbeta -> part[blk][2][D]
+template <int VPL>
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, float* __restrict__ dx,
+                                                     float* __restrict__ part, long long rows, int D,
+                                                     int rows_per_block, int accumulate) {
+    __shared__ float sg[4][VPL * 64], sb[4][VPL * 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float ag[VPL], ab[VPL], gm[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        ag[i] = 0.f; ab[i] = 0.f;
+        const int c = lane + 64 * i;
+        gm[i] = c < D ? gamma[c] : 0.f;
+    }
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    for (int rr = wid; rr < rows_per_block; rr += 4) {
+        const long long row = r0 + rr;
+        if (row >= rows) break;
+        const float mu = mean[row], rs = rstd[row];
+        float xh[VPL], dg[VPL];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = lane + 64 * i;
+            const float xv = c < D ? x[row * D + c] : 0.f;
+            const float dv = c < D ? dy[row * D + c] : 0.f;
+            xh[i] = c < D ? (xv - mu) * rs : 0.f;
+            dg[i] = dv * gm[i];
+            s1 += dg[i];
+            s2 += dg[i] * xh[i];
+            ag[i] += dv * xh[i];
+            ab[i] += dv;
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D) {
+                const float v = rs * (dg[i] - s1 - xh[i] * s2);
+                if (accumulate) dx[row * D + c] += v; else dx[row * D + c] = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { sg[wid][lane + 64 * i] = ag[i]; sb[wid][lane + 64 * i] = ab[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        part[((long long)blockIdx.x * 2 + 0) * D + c] = sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c];
+        part[((long long)blockIdx.x * 2 + 1) * D + c] = sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c];
+    }
+}
+
+// dst[i] (+)= alpha * sum_s part[s][i]
+__global__ void __launch_bounds__(256) sum_splits_kernel(const float* __restrict__ part, int nsplit, long long n,
+                                                         float* __restrict__ dst, int accumulate, float alpha) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += part[(long long)k * n + i];
+        s *= alpha;
+        if (accumulate) dst[i] += s; else dst[i] = s;
+    }
+}
+
+// column sums, stage 1: part[blk][N] over a slab of rows
+__global__ void __launch_bounds__(256) colsum_part_kernel(const float* __restrict__ x, long long rows, int N, long long ld,
+                                                          int rows_per_block, float* __restrict__ part) {
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(rows, r0 + rows_per_block);
+    for (int c = threadIdx.x; c < N; c += 256) {
+        float s = 0.f;
+        for (long long r = r0; r < r1; ++r) s += x[r * ld + c];
+        part[(long long)blockIdx.x * N + c] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ softmax rows
+// in place: S[row, :cols] -> P; optional second output Pd = P * keep / (1-p)
+__global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ S, float* __restrict__ Pd, int cols,
+                                                           long long ld, float p, unsigned seed) {
+    __shared__ float red[4];
+    const long long row = blockIdx.x;
+    float* s = S + row * ld;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float m = -INFINITY;
+    for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, s[c]);
+    m = wave_max(m);
+    if (lane == 0) red[wid] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float e = expf(s[c] - m);
+        s[c] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wid] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    const float keep_scale = 1.0f / (1.0f - p);
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float pv = s[c] * inv;
+        s[c] = pv;
+        if (Pd) Pd[row * ld + c] = keep_elem(seed, (unsigned)row, (unsigned)c, p) ? pv * keep_scale : 0.f;
+    }
+    // zero the row padding (ld is rounded up to 4 so that the GEMMs may read it with 16-byte loads)
+    for (int c = cols + threadIdx.x; c < ld; c += 256) { s[c] = 0.f; if (Pd) Pd[row * ld + c] = 0.f; }
+}
+
+// dS = scale * P * (dP - sum(dP*P)),  dP = dPd * keep/(1-p); written over dPd
+__global__ void __launch_bounds__(256) softmax_bwd_rows_kernel(const float* __restrict__ P, float* __restrict__ dPd, int cols,
+                                                               long long ld, float scale, float p, unsigned seed) {
+    __shared__ float red[4];
+    const long long row = blockIdx.x;
+    const float* pr = P + row * ld;
+    float* d = dPd + row * ld;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const float ks = 1.0f / (1.0f - p);
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        float g = d[c];
+        if (p > 0.f) g = keep_elem(seed, (unsigned)row, (unsigned)c, p) ? g * ks : 0.f;
+        acc += g * pr[c];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) red[wid] = acc;
+    __syncthreads();
+    const float tot = red[0] + red[1] + red[2] + red[3];
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        float g = d[c];
+        if (p > 0.f) g = keep_elem(seed, (unsigned)row, (unsigned)c, p) ? g * ks : 0.f;
+        d[c] = scale * pr[c] * (g - tot);
+    }
+    for (int c = cols + threadIdx.x; c < ld; c += 256) d[c] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------ GEGLU / lrelu
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+__global__ void __launch_bounds__(256) geglu_fwd_kernel(const float* __restrict__ h, float* __restrict__ out, long long rows, int F) {
+    const long long n = rows * F;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long r = i / F;
+        const int c = (int)(i - r * F);
+        out[i] = h[r * 2 * F + c] * gelu_erf(h[r * 2 * F + F + c]);
+    }
+}
+__global__ void __launch_bounds__(256) geglu_bwd_kernel(const float* __restrict__ h, const float* __restrict__ dout,
+                                                        float* __restrict__ dh, long long rows, int F) {
+    const long long n = rows * F;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long r = i / F;
+        const int c = (int)(i - r * F);
+        const float a = h[r * 2 * F + c], g = h[r * 2 * F + F + c], d = dout[i];
+        dh[r * 2 * F + c] = d * gelu_erf(g);
+        dh[r * 2 * F + F + c] = d * a * gelu_erf_grad(g);
+    }
+}
+__global__ void __launch_bounds__(256) lrelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                        float* __restrict__ dx, long long n, float slope) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        dx[i] = y[i] > 0.f ? dy[i] : dy[i] * slope;
+}
+__global__ void __launch_bounds__(256) add_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n, float alpha) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] += alpha * src[i];
+}
+
+// ------------------------------------------------------------------------------------------ naive GEMM (tiny layers)
+// C[m,n] (+)= act(sum_k A[m*sAm + k*sAk] * B[k*sBk + n*sBn] + bias[n])
+__global__ void __launch_bounds__(256) naive_gemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                         float* __restrict__ C, const float* __restrict__ bias, int M, int N,
+                                                         int K, long long sAm, long long sAk, long long sBk, long long sBn,
+                                                         long long ldc, int act, float slope, int accumulate) {
+    const long long total = (long long)M * N;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s = fmaf(A[m * sAm + k * sAk], B[k * sBk + n * sBn], s);
+        if (bias) s += bias[n];
+        if (act == 1) s = s > 0.f ? s : s * slope;
+        if (accumulate) C[m * ldc + n] += s; else C[m * ldc + n] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ context assembly
+// ctx[b, t, :] = (t < T0 ? lang[b,t,:] : cat(patch[b,t-T0,:C], pp[b,:C])) + pos[t,:]     (perceiver_lang_io.py:370-422)
+__global__ void __launch_bounds__(256) ctx_build_kernel(const float* __restrict__ lang, const float* __restrict__ patch,
+                                                        const float* __restrict__ pp, const float* __restrict__ pos,
+                                                        float* __restrict__ ctx, int B, int T0, int T1, int C) {
+    const int Cx = 2 * C;
+    const long long n = (long long)B * (T0 + T1) * Cx;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % Cx);
+        const long long bt = i / Cx;
+        const int t = (int)(bt % (T0 + T1));
+        const int b = (int)(bt / (T0 + T1));
+        float v;
+        if (t < T0) v = lang[((long long)b * T0 + t) * Cx + c];
+        else if (c < C) v = patch[((long long)b * T1 + (t - T0)) * C + c];
+        else v = pp[b * C + (c - C)];
+        ctx[i] = v + pos[(long long)t * Cx + c];
+    }
+}
+// adjoint: dlang, dpatch written; dpos[t,c] = sum_b dctx; dpp[b,c] = sum_t dctx[b, T0+t, C+c]
+__global__ void __launch_bounds__(256) ctx_bwd_kernel(const float* __restrict__ dctx, float* __restrict__ dlang,
+                                                      float* __restrict__ dpatch, float* __restrict__ dpos, int B, int T0,
+                                                      int T1, int C) {
+    const int Cx = 2 * C;
+    const long long n = (long long)(T0 + T1) * Cx;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % Cx);
+        const int t = (int)(i / Cx);
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float v = dctx[((long long)b * (T0 + T1) + t) * Cx + c];
+            s += v;
+            if (t < T0) dlang[((long long)b * T0 + t) * Cx + c] = v;
+            else if (c < C) dpatch[((long long)b * T1 + (t - T0)) * C + c] = v;
+        }
+        dpos[i] += s;
+    }
+}
+// dpp[b,c] = sum_t dctx[b, T0+t, C+c]: stage 1 per (b, chunk) -> part[b][chunk][C]; stage 2 sums the chunks
+__global__ void __launch_bounds__(256) ctx_bwd_pp_kernel(const float* __restrict__ dctx, float* __restrict__ part, int T0,
+                                                         int T1, int C, int nchunk) {
+    __shared__ float red[256];
+    const int b = blockIdx.x, ch = blockIdx.y;
+    const int Cx = 2 * C;
+    const int per = (T1 + nchunk - 1) / nchunk;
+    const int t0 = ch * per, t1 = min(T1, t0 + per);
+    const int nstripe = 256 / C;                 // C in {64, 128}
+    const int c = threadIdx.x % C, sidx = threadIdx.x / C;
+    float s = 0.f;
+    for (int t = t0 + sidx; t < t1; t += nstripe) s += dctx[((long long)b * (T0 + T1) + T0 + t) * Cx + C + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float v = 0.f;
+        for (int k = 0; k < nstripe; ++k) v += red[k * C + threadIdx.x];
+        part[((long long)b * nchunk + ch) * C + threadIdx.x] = v;
+    }
+}
+__global__ void __launch_bounds__(256) ctx_bwd_pp2_kernel(const float* __restrict__ part, float* __restrict__ dpp, int B, int C, int nchunk) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i % C;
+    float s = 0.f;
+    for (int k = 0; k < nchunk; ++k) s += part[((long long)b * nchunk + k) * C + c];
+    dpp[i] = s;
+}
+
+inline int grid_for(long long n) {
+    long long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace
+
+extern "C" int vxb_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                     float* rstd, int64_t rows, int D, float eps, vxb_stream_t stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || rows < 1 || D < 1) return VXB_EARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = vxb_cdiv(rows, 4);
+    if (D <= 128) hipLaunchKernelGGL(ln_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, rows, D, eps);
+    else if (D <= 512) hipLaunchKernelGGL(ln_fwd_kernel<8>, dim3(grid), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, rows, D, eps);
+    else if (D <= 1024) hipLaunchKernelGGL(ln_fwd_kernel<16>, dim3(grid), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, rows, D, eps);
+    else return VXB_ESIZE;
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+// part_ws: at least 2*D*ceil(rows/64) floats.  dgamma/dbeta are ACCUMULATED (+=).
+extern "C" int vxb_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean,
+                                     const float* rstd, float* dx, float* dgamma, float* dbeta, float* part_ws,
+                                     int64_t rows, int D, int accumulate_dx, vxb_stream_t stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !part_ws || rows < 1 || D < 1) return VXB_EARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int rpb = 64;
+    const int grid = vxb_cdiv(rows, rpb);
+    if (D <= 128) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(grid), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, part_ws, rows, D, rpb, accumulate_dx);
+    else if (D <= 512) hipLaunchKernelGGL(ln_bwd_kernel<8>, dim3(grid), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, part_ws, rows, D, rpb, accumulate_dx);
+    else return VXB_ESIZE;
+    // part layout [grid][2][D] -> two strided reductions via a [grid] x [2D] view
+    hipLaunchKernelGGL(colsum_part_kernel, dim3(1), dim3(256), 0, st, part_ws, (long long)grid, 2 * D, (long long)2 * D, grid,
+                       part_ws + (size_t)grid * 2 * D);
+    hipLaunchKernelGGL(add_kernel, dim3(1), dim3(256), 0, st, dgamma, part_ws + (size_t)grid * 2 * D, (long long)D, 1.0f);
+    hipLaunchKernelGGL(add_kernel, dim3(1), dim3(256), 0, st, dbeta, part_ws + (size_t)grid * 2 * D + D, (long long)D, 1.0f);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+extern "C" int vxb_sum_splits_f32(const float* part, int nsplit, int64_t n, float* dst, int accumulate, float alpha,
+                                  vxb_stream_t stream) {
+    if (!part || !dst || nsplit < 1 || n < 1) return VXB_EARG;
+    hipLaunchKernelGGL(sum_splits_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, part, nsplit, (long long)n, dst, accumulate, alpha);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+// out[N] (+)= column sums of x[rows, N] (row stride ld).  part_ws: ceil(rows/rpb)*N floats with rpb = max(64, rows/1024).
+extern "C" int vxb_colsum_f32(const float* x, int64_t rows, int N, int64_t ld, float* part_ws, float* out, int accumulate,
+                              vxb_stream_t stream) {
+    if (!x || !part_ws || !out || rows < 1 || N < 1) return VXB_EARG;
+    hipStream_t st = (hipStream_t)stream;
+    long long rpb = rows / 1024;
+    if (rpb < 64) rpb = 64;
+    const int nb = vxb_cdiv(rows, rpb);
+    hipLaunchKernelGGL(colsum_part_kernel, dim3(nb), dim3(256), 0, st, x, (long long)rows, N, (long long)ld, (int)rpb, part_ws);
+    hipLaunchKernelGGL(sum_splits_kernel, dim3(grid_for(N)), dim3(256), 0, st, part_ws, nb, (long long)N, out, accumulate, 1.0f);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+extern "C" int vxb_softmax_rows_f32(float* S, float* P_drop, int64_t rows, int cols, int64_t ld, float dropout_p,
+                                    uint32_t seed, vxb_stream_t stream) {
+    if (!S || rows < 1 || cols < 1 || dropout_p < 0.f || dropout_p >= 1.f) return VXB_EARG;
+    if (rows >= INT32_MAX) return VXB_ESIZE;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, S,
+                       dropout_p > 0.f ? P_drop : nullptr, cols, (long long)ld, dropout_p, seed);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+extern "C" int vxb_softmax_bwd_rows_f32(const float* P, float* dP_inout, int64_t rows, int cols, int64_t ld, float scale,
+                                        float dropout_p, uint32_t seed, vxb_stream_t stream) {
+    if (!P || !dP_inout || rows < 1 || cols < 1) return VXB_EARG;
+    if (rows >= INT32_MAX) return VXB_ESIZE;
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, P, dP_inout, cols,
+                       (long long)ld, scale, dropout_p, seed);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+extern "C" int vxb_geglu_fwd_f32(const float* h, float* out, int64_t rows, int F, vxb_stream_t stream) {
+    if (!h || !out || rows < 1 || F < 1) return VXB_EARG;
+    hipLaunchKernelGGL(geglu_fwd_kernel, dim3(grid_for(rows * F)), dim3(256), 0, (hipStream_t)stream, h, out, (long long)rows, F);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+extern "C" int vxb_geglu_bwd_f32(const float* h, const float* dout, float* dh, int64_t rows, int F, vxb_stream_t stream) {
+    if (!h || !dout || !dh || rows < 1 || F < 1) return VXB_EARG;
+    hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid_for(rows * F)), dim3(256), 0, (hipStream_t)stream, h, dout, dh, (long long)rows, F);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+extern "C" int vxb_lrelu_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, float slope, vxb_stream_t stream) {
+    if (!dy || !y || !dx || n < 1) return VXB_EARG;
+    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, (long long)n, slope);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+extern "C" int vxb_axpy_f32(float* dst, const float* src, int64_t n, float alpha, vxb_stream_t stream) {
+    if (!dst || !src || n < 1) return VXB_EARG;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dst, src, (long long)n, alpha);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+extern "C" int vxb_naive_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                                  int64_t sAm, int64_t sAk, int64_t sBk, int64_t sBn, int64_t ldc, int act, float slope,
+                                  int accumulate, vxb_stream_t stream) {
+    if (!A || !B || !C || M < 1 || N < 1 || K < 1) return VXB_EARG;
+    hipLaunchKernelGGL(naive_gemm_kernel, dim3(grid_for((long long)M * N)), dim3(256), 0, (hipStream_t)stream, A, B, C, bias, M, N, K,
+                       (long long)sAm, (long long)sAk, (long long)sBk, (long long)sBn, (long long)ldc, act, slope, accumulate);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+extern "C" int vxb_ctx_build_f32(const float* lang, const float* patch, const float* pp, const float* pos, float* ctx, int B,
+                                 int T0, int T1, int C, vxb_stream_t stream) {
+    if (!lang || !patch || !pp || !pos || !ctx || B < 1 || T0 < 0 || T1 < 1 || C < 1) return VXB_EARG;
+    hipLaunchKernelGGL(ctx_build_kernel, dim3(grid_for((long long)B * (T0 + T1) * 2 * C)), dim3(256), 0, (hipStream_t)stream, lang, patch, pp,
+                       pos, ctx, B, T0, T1, C);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+// dlang [B,T0,2C], dpatch [B,T1,C], dpp [B,C] are WRITTEN; dpos [T0+T1,2C] is ACCUMULATED.
+extern "C" int vxb_ctx_bwd_f32(const float* dctx, float* dlang, float* dpatch, float* dpp, float* dpos, float* part_ws, int B,
+                               int T0, int T1, int C, vxb_stream_t stream) {
+    if (!dctx || !dlang || !dpatch || !dpp || !dpos || !part_ws || B < 1 || T1 < 1 || C < 1) return VXB_EARG;
+    if (C > 256 || (256 % C)) return VXB_ESIZE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = 32;     // part_ws: B*32*C floats
+    hipLaunchKernelGGL(ctx_bwd_kernel, dim3(grid_for((long long)(T0 + T1) * 2 * C)), dim3(256), 0, st, dctx, dlang, dpatch, dpos, B, T0, T1, C);
+    hipLaunchKernelGGL(ctx_bwd_pp_kernel, dim3(B, nchunk), dim3(256), 0, st, dctx, part_ws, T0, T1, C, nchunk);
+    hipLaunchKernelGGL(ctx_bwd_pp2_kernel, dim3(vxb_cdiv((long long)B * C, 256)), dim3(256), 0, st, part_ws, dpp, B, C, nchunk);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}

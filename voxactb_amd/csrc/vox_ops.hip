@@ -1,0 +1,782 @@
+// Voxel-grid-sized streaming kernels of the Q-function (fp32, channels-last [B, S^3, C]):
+//   * 1x1x1 input conv (10 -> 64) + LeakyReLU and its weight gradient    (perceiver_lang_io.py:357)
+//   * SpatialSoftmax3D + global max pool, forward and backward           (network_utils.py:773-809; perceiver :360,:451,:470)
+//   * 3x3x3 conv with ONE output channel (trans_decoder), fwd / dgrad / wgrad   (perceiver :465)
+//   * replicate-padding adjoint ("fold") used after every implicit-GEMM data gradient
+//   * cross-entropy over 10^6 voxel logits + small heads, with argmax    (agent :57-80, :517-578)
+//   * polyphase weight transform of upsample(x s, trilinear) o conv(k)   (network_utils.py:245-250) and its adjoint
+//   * fused multi-tensor LAMB                                            (helpers/optim/lamb.py:60-124)
+// All are HBM/L2-bound; none is reshaped into a GEMM.
+#include "common.h"
+
+namespace {
+
+inline int grid_for(long long n) {
+    long long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+// =====================================================================================================
+// pointwise conv  y[v, co] = lrelu(sum_ci x[v, ci] * W[co, ci] + b[co]),  Cin <= 16, Cout % 4 == 0, Cout <= 128
+// =====================================================================================================
+__global__ void __launch_bounds__(256) pw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, float* __restrict__ y,
+                                                     long long nvox, int Cin, int Cout, float slope) {
+    __shared__ float sw[16 * 128];     // [ci][co]
+    __shared__ float sb[128];
+    for (int i = threadIdx.x; i < Cin * Cout; i += 256) {
+        const int co = i / Cin, ci = i % Cin;
+        sw[ci * Cout + co] = W[i];
+    }
+    for (int i = threadIdx.x; i < Cout; i += 256) sb[i] = bias[i];
+    __syncthreads();
+    const int q = Cout >> 2;
+    const long long total = nvox * q;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long v = i / q;
+        const int c4 = (int)(i - v * q) * 4;
+        float a0 = sb[c4], a1 = sb[c4 + 1], a2 = sb[c4 + 2], a3 = sb[c4 + 3];
+        const float* xr = x + v * Cin;
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float xv = xr[ci];
+            const float* wr = sw + ci * Cout + c4;
+            a0 = fmaf(xv, wr[0], a0); a1 = fmaf(xv, wr[1], a1); a2 = fmaf(xv, wr[2], a2); a3 = fmaf(xv, wr[3], a3);
+        }
+        float4 o;
+        o.x = a0 > 0.f ? a0 : a0 * slope; o.y = a1 > 0.f ? a1 : a1 * slope;
+        o.z = a2 > 0.f ? a2 : a2 * slope; o.w = a3 > 0.f ? a3 : a3 * slope;
+        *reinterpret_cast<float4*>(y + v * Cout + c4) = o;
+    }
+}
+
+// partW[blk][co*Cin + ci], partB[blk][co] from dpre = dy * lrelu'(y); Cout == 64
+__global__ void __launch_bounds__(256) pw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                       const float* __restrict__ dy, float* __restrict__ partW,
+                                                       float* __restrict__ partB, long long nvox, int Cin, int vox_per_block,
+                                                       float slope) {
+    __shared__ float red[256 * 17];
+    const int co = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    float acc[16], accb = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const long long v0 = (long long)blockIdx.x * vox_per_block;
+    const long long v1 = min(nvox, v0 + vox_per_block);
+    for (long long v = v0 + grp; v < v1; v += 4) {
+        const float yv = y[v * 64 + co];
+        float d = dy[v * 64 + co];
+        d = yv > 0.f ? d : d * slope;
+        accb += d;
+        const float* xr = x + v * Cin;
+#pragma unroll
+        for (int ci = 0; ci < 16; ++ci)
+            if (ci < Cin) acc[ci] = fmaf(d, xr[ci], acc[ci]);
+    }
+#pragma unroll
+    for (int ci = 0; ci < 16; ++ci) red[threadIdx.x * 17 + ci] = acc[ci];
+    red[threadIdx.x * 17 + 16] = accb;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        for (int ci = 0; ci < Cin; ++ci) {
+            float s = 0.f;
+            for (int g = 0; g < 4; ++g) s += red[(g * 64 + threadIdx.x) * 17 + ci];
+            partW[(long long)blockIdx.x * 64 * Cin + threadIdx.x * Cin + ci] = s;
+        }
+        float s = 0.f;
+        for (int g = 0; g < 4; ++g) s += red[(g * 64 + threadIdx.x) * 17 + 16];
+        partB[(long long)blockIdx.x * 64 + threadIdx.x] = s;
+    }
+}
+
+// =====================================================================================================
+// SpatialSoftmax3D (T = 0.01) + global max.   x: [B, S^3, C] (batch stride bs), C in {64, 128}
+// stage 1: per (b, row-chunk) online-softmax partials part[b][chunk][c][7] = {m, s, sx, sy, sz, xmax, argmax}
+// =====================================================================================================
+struct SsPart { float m, s, sx, sy, sz, xmax; int arg; };
+
+__device__ __forceinline__ void ss_merge(SsPart& a, const SsPart& b) {
+    if (b.s > 0.f || b.m > -INFINITY) {
+        const float m = fmaxf(a.m, b.m);
+        const float fa = a.m > -INFINITY ? expf(a.m - m) : 0.f;
+        const float fb = b.m > -INFINITY ? expf(b.m - m) : 0.f;
+        a.s = a.s * fa + b.s * fb;
+        a.sx = a.sx * fa + b.sx * fb;
+        a.sy = a.sy * fa + b.sy * fb;
+        a.sz = a.sz * fa + b.sz * fb;
+        a.m = m;
+    }
+    if (b.xmax > a.xmax || (b.xmax == a.xmax && b.arg < a.arg)) { a.xmax = b.xmax; a.arg = b.arg; }
+}
+
+__global__ void __launch_bounds__(256) ss_part_kernel(const float* __restrict__ x, long long bs, int S, int C,
+                                                      const float* __restrict__ lin, int rows_per_chunk,
+                                                      SsPart* __restrict__ part, int nchunk, float T) {
+    __shared__ SsPart red[256];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int c = threadIdx.x % C, pl = threadIdx.x / C, npl = 256 / C;
+    const float* xb = x + (long long)b * bs;
+    SsPart a;
+    a.m = -INFINITY; a.s = 0.f; a.sx = 0.f; a.sy = 0.f; a.sz = 0.f; a.xmax = -INFINITY; a.arg = 0x7fffffff;
+    const int row0 = chunk * rows_per_chunk, row1 = min(S * S, row0 + rows_per_chunk);
+    for (int row = row0; row < row1; ++row) {
+        const int i = row / S, j = row - i * S;
+        const float wy = lin[i], wx = lin[j];        // meshgrid 'xy' quirk: pos_x follows axis 1, pos_y axis 0
+        for (int k = pl; k < S; k += npl) {
+            const int p = row * S + k;
+            const float xv = xb[(long long)p * C + c];
+            const float l = __fdiv_rn(xv, T);
+            if (xv > a.xmax) { a.xmax = xv; a.arg = p; }
+            if (l > a.m) {
+                const float f = a.m > -INFINITY ? expf(a.m - l) : 0.f;
+                a.s *= f; a.sx *= f; a.sy *= f; a.sz *= f;
+                a.m = l;
+            }
+            const float e = expf(l - a.m);
+            a.s += e; a.sx = fmaf(e, wx, a.sx); a.sy = fmaf(e, wy, a.sy); a.sz = fmaf(e, lin[k], a.sz);
+        }
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        SsPart r = red[threadIdx.x];
+        for (int g = 1; g < npl; ++g) ss_merge(r, red[g * C + threadIdx.x]);
+        part[((long long)b * nchunk + chunk) * C + threadIdx.x] = r;
+    }
+}
+
+// stage 2: combine chunks -> out_ss[b][3c + {x,y,z}], out_max[b][c], stats[b][c] = {m, s}, argmax[b][c]
+__global__ void __launch_bounds__(256) ss_final_kernel(const SsPart* __restrict__ part, int nchunk, int B, int C,
+                                                       float* __restrict__ out_ss, float* __restrict__ out_max,
+                                                       float* __restrict__ stats, int* __restrict__ argmax) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i % C;
+    SsPart r = part[((long long)b * nchunk) * C + c];
+    for (int k = 1; k < nchunk; ++k) ss_merge(r, part[((long long)b * nchunk + k) * C + c]);
+    out_ss[(long long)b * 3 * C + 3 * c + 0] = r.sx / r.s;
+    out_ss[(long long)b * 3 * C + 3 * c + 1] = r.sy / r.s;
+    out_ss[(long long)b * 3 * C + 3 * c + 2] = r.sz / r.s;
+    out_max[i] = r.xmax;
+    stats[2 * i] = r.m;
+    stats[2 * i + 1] = r.s;
+    argmax[i] = r.arg;
+}
+
+// backward: dx[b,p,c] (+)= a_p/T * (gx*(lin[j]-ex) + gy*(lin[i]-ey) + gz*(lin[k]-ez)) + (p == argmax) * gmax
+__global__ void __launch_bounds__(256) ss_bwd_kernel(const float* __restrict__ x, long long bs, int S, int C,
+                                                     const float* __restrict__ lin, const float* __restrict__ stats,
+                                                     const float* __restrict__ out_ss, const int* __restrict__ argmax,
+                                                     const float* __restrict__ g_ss, const float* __restrict__ g_max,
+                                                     float* __restrict__ dx, long long dbs, int rows_per_chunk, float T,
+                                                     int accumulate) {
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int c = threadIdx.x % C, pl = threadIdx.x / C, npl = 256 / C;
+    const float* xb = x + (long long)b * bs;
+    float* db = dx + (long long)b * dbs;
+    const int bc = b * C + c;
+    const float m = stats[2 * bc], inv_s = 1.0f / stats[2 * bc + 1];
+    const float ex = out_ss[(long long)b * 3 * C + 3 * c], ey = out_ss[(long long)b * 3 * C + 3 * c + 1],
+                ez = out_ss[(long long)b * 3 * C + 3 * c + 2];
+    const float gx = g_ss[(long long)b * 3 * C + 3 * c], gy = g_ss[(long long)b * 3 * C + 3 * c + 1],
+                gz = g_ss[(long long)b * 3 * C + 3 * c + 2];
+    const float gm = g_max[bc];
+    const int am = argmax[bc];
+    const int row0 = chunk * rows_per_chunk, row1 = min(S * S, row0 + rows_per_chunk);
+    for (int row = row0; row < row1; ++row) {
+        const int i = row / S, j = row - i * S;
+        const float base = gx * (lin[j] - ex) + gy * (lin[i] - ey);
+        for (int k = pl; k < S; k += npl) {
+            const int p = row * S + k;
+            const long long o = (long long)p * C + c;
+            const float l = __fdiv_rn(xb[o], T);
+            const float a = expf(l - m) * inv_s;
+            float g = __fdiv_rn(a * (base + gz * (lin[k] - ez)), T);
+            if (p == am) g += gm;
+            if (accumulate) db[o] += g; else db[o] = g;
+        }
+    }
+}
+
+// =====================================================================================================
+// 3x3x3 conv, ONE output channel, replicate padding; lane = input channel (C == 64)
+// =====================================================================================================
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// q[b, p] = bias + sum_t sum_c u[clamp(p + t - 1)][c] * w[c][t];  one wave handles runs of voxels along w
+__global__ void __launch_bounds__(256) c1_fwd_kernel(const float* __restrict__ u, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ q, int B, int S) {
+    const int lane = threadIdx.x & 63;
+    float wr[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) wr[t] = w[lane * 27 + t];
+    const float bv = bias[0];
+    const long long nrows = (long long)B * S * S;
+    for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < nrows; row += (long long)gridDim.x * 4) {
+        const int h = (int)(row % S);
+        const int d = (int)((row / S) % S);
+        const int b = (int)(row / ((long long)S * S));
+        const float* ub = u + (long long)b * S * S * S * 64;
+        const float* rp[9];
+#pragma unroll
+        for (int dd = 0; dd < 3; ++dd)
+#pragma unroll
+            for (int hh = 0; hh < 3; ++hh)
+                rp[dd * 3 + hh] = ub + ((long long)clampi(d + dd - 1, 0, S - 1) * S + clampi(h + hh - 1, 0, S - 1)) * S * 64 + lane;
+        float win[9][3];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            win[r][1] = rp[r][0];                                  // w = 0 (and its replicate copy at w = -1)
+            win[r][0] = win[r][1];
+            win[r][2] = rp[r][(long long)clampi(1, 0, S - 1) * 64];
+        }
+        for (int x = 0; x < S; ++x) {
+            float acc = 0.f;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                acc = fmaf(win[r][0], wr[r * 3 + 0], acc);
+                acc = fmaf(win[r][1], wr[r * 3 + 1], acc);
+                acc = fmaf(win[r][2], wr[r * 3 + 2], acc);
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) q[row * S + x] = acc + bv;
+            const int nx = clampi(x + 2, 0, S - 1);
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                win[r][0] = win[r][1];
+                win[r][1] = win[r][2];
+                win[r][2] = rp[r][(long long)nx * 64];
+            }
+        }
+    }
+}
+
+// du[j][c] = (du_in[j][c] + sum_{27 (o,t) pairs} dq[o] * w[c][t]) * (mask ? lrelu'(u[j][c]) : 1)
+// per axis, pair k in {0,1,2}: o = j + 1 - k, t = k; o < 0 -> (0, t=0); o > S-1 -> (S-1, t=2)   (replicate adjoint)
+__global__ void __launch_bounds__(256) c1_dgrad_kernel(const float* __restrict__ dq, const float* __restrict__ w,
+                                                       const float* __restrict__ u, float* __restrict__ du, int B, int S,
+                                                       int accumulate, int mask, float slope) {
+    const int lane = threadIdx.x & 63;
+    __shared__ float sw[27 * 64];          // [t][c]: runtime tap index at the borders -> LDS, not registers
+    for (int i = threadIdx.x; i < 27 * 64; i += 256) sw[(i % 27) * 64 + i / 27] = w[i];
+    __syncthreads();
+    const long long nvox = (long long)B * S * S * S;
+    for (long long v = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); v < nvox; v += (long long)gridDim.x * 4) {
+        const int x = (int)(v % S);
+        const int h = (int)((v / S) % S);
+        const int d = (int)((v / ((long long)S * S)) % S);
+        const long long b = v / ((long long)S * S * S);
+        const float* dqb = dq + b * S * S * S;
+        int od[3], td[3], oh[3], th[3], ox[3], tx[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int o = d + 1 - k; td[k] = o < 0 ? 0 : (o > S - 1 ? 2 : k); od[k] = clampi(o, 0, S - 1);
+            o = h + 1 - k;     th[k] = o < 0 ? 0 : (o > S - 1 ? 2 : k); oh[k] = clampi(o, 0, S - 1);
+            o = x + 1 - k;     tx[k] = o < 0 ? 0 : (o > S - 1 ? 2 : k); ox[k] = clampi(o, 0, S - 1);
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    const float g = dqb[((long long)od[a] * S + oh[bb]) * S + ox[cc]];
+                    const int t = (td[a] * 3 + th[bb]) * 3 + tx[cc];
+                    acc = fmaf(g, sw[t * 64 + lane], acc);
+                }
+        const long long o = v * 64 + lane;
+        float r = acc + (accumulate ? du[o] : 0.f);
+        if (mask) r = u[o] > 0.f ? r : r * slope;
+        du[o] = r;
+    }
+}
+
+// part[blk][c*27 + t] = sum over the block's rows of dq[o] * u[clamp(o + t - 1)][c];  partB[blk] = sum dq
+__global__ void __launch_bounds__(256) c1_wgrad_kernel(const float* __restrict__ u, const float* __restrict__ dq,
+                                                       float* __restrict__ part, float* __restrict__ partB, int B, int S,
+                                                       int rows_per_block) {
+    __shared__ float red[4][64 * 27];
+    __shared__ float redb[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = 0.f;
+    float accb = 0.f;
+    const long long nrows = (long long)B * S * S;
+    const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(nrows, r0 + rows_per_block);
+    for (long long row = r0 + wid; row < r1; row += 4) {
+        const int h = (int)(row % S);
+        const int d = (int)((row / S) % S);
+        const int b = (int)(row / ((long long)S * S));
+        const float* ub = u + (long long)b * S * S * S * 64;
+        const float* rp[9];
+#pragma unroll
+        for (int dd = 0; dd < 3; ++dd)
+#pragma unroll
+            for (int hh = 0; hh < 3; ++hh)
+                rp[dd * 3 + hh] = ub + ((long long)clampi(d + dd - 1, 0, S - 1) * S + clampi(h + hh - 1, 0, S - 1)) * S * 64 + lane;
+        float win[9][3];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            win[r][1] = rp[r][0];
+            win[r][0] = win[r][1];
+            win[r][2] = rp[r][(long long)clampi(1, 0, S - 1) * 64];
+        }
+        for (int x = 0; x < S; ++x) {
+            const float g = dq[row * S + x];
+            accb += g;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                acc[r * 3 + 0] = fmaf(g, win[r][0], acc[r * 3 + 0]);
+                acc[r * 3 + 1] = fmaf(g, win[r][1], acc[r * 3 + 1]);
+                acc[r * 3 + 2] = fmaf(g, win[r][2], acc[r * 3 + 2]);
+            }
+            const int nx = clampi(x + 2, 0, S - 1);
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                win[r][0] = win[r][1];
+                win[r][1] = win[r][2];
+                win[r][2] = rp[r][(long long)nx * 64];
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 27; ++t) red[wid][lane * 27 + t] = acc[t];
+    if (lane == 0) redb[wid] = accb;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 27; i += 256)
+        part[(long long)blockIdx.x * 64 * 27 + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    if (threadIdx.x == 0) partB[blockIdx.x] = redb[0] + redb[1] + redb[2] + redb[3];
+}
+
+// =====================================================================================================
+// fold: adjoint of replicate padding.  src [B, Sp^3, Cs] (valid extent S + 2*pad per axis), channels [c0, c0+C)
+// dst[b, j, c] (+)= sum_{i : clamp(i - pad, 0, S-1) == j} src[b, i, c0 + c]   (* lrelu'(y[b,j,c]) if y)
+// =====================================================================================================
+__global__ void __launch_bounds__(256) fold_kernel(const float* __restrict__ src, int Sp, int Cs, int c0,
+                                                   float* __restrict__ dst, const float* __restrict__ y, int B, int S, int C,
+                                                   int pad, int accumulate, float slope) {
+    const int q = C >> 2;
+    const long long total = (long long)B * S * S * S * q;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c4 = (int)(i % q) * 4;
+        long long v = i / q;
+        const int x = (int)(v % S); v /= S;
+        const int h = (int)(v % S); v /= S;
+        const int d = (int)(v % S); v /= S;
+        const long long b = v;
+        const int d0 = d == 0 ? 0 : d + pad, d1 = d == S - 1 ? S - 1 + 2 * pad : d + pad;
+        const int h0 = h == 0 ? 0 : h + pad, h1 = h == S - 1 ? S - 1 + 2 * pad : h + pad;
+        const int x0 = x == 0 ? 0 : x + pad, x1 = x == S - 1 ? S - 1 + 2 * pad : x + pad;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int dd = d0; dd <= d1; ++dd)
+            for (int hh = h0; hh <= h1; ++hh)
+                for (int xx = x0; xx <= x1; ++xx) {
+                    const float4 s = *reinterpret_cast<const float4*>(
+                        src + ((((long long)b * Sp + dd) * Sp + hh) * Sp + xx) * Cs + c0 + c4);
+                    a.x += s.x; a.y += s.y; a.z += s.z; a.w += s.w;
+                }
+        const long long o = ((((long long)b * S + d) * S + h) * S + x) * C + c4;
+        if (accumulate) {
+            const float4 p = *reinterpret_cast<const float4*>(dst + o);
+            a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+        }
+        if (y) {
+            const float4 yy = *reinterpret_cast<const float4*>(y + o);
+            a.x = yy.x > 0.f ? a.x : a.x * slope; a.y = yy.y > 0.f ? a.y : a.y * slope;
+            a.z = yy.z > 0.f ? a.z : a.z * slope; a.w = yy.w > 0.f ? a.w : a.w * slope;
+        }
+        *reinterpret_cast<float4*>(dst + o) = a;
+    }
+}
+
+// =====================================================================================================
+// cross entropy over one huge class axis (q_trans: [B, P], P = V^3) + argmax
+// =====================================================================================================
+struct CePart { float m, s, xmax; int arg; };
+
+__global__ void __launch_bounds__(256) ce_part_kernel(const float* __restrict__ x, long long P, int per_chunk, int nchunk,
+                                                      CePart* __restrict__ part) {
+    __shared__ CePart red[256];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const float* xb = x + (long long)b * P;
+    const long long p0 = (long long)chunk * per_chunk, p1 = min(P, p0 + per_chunk);
+    float m = -INFINITY, s = 0.f;
+    int arg = 0x7fffffff;
+    for (long long p = p0 + threadIdx.x; p < p1; p += 256) {
+        const float v = xb[p];
+        if (v > m) { s = s * expf(m - v) + 1.0f; m = v; arg = (int)p; }
+        else s += expf(v - m);
+    }
+    CePart a; a.m = m; a.s = s; a.xmax = m; a.arg = arg;
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            CePart l = red[threadIdx.x], r = red[threadIdx.x + o];
+            const float mm = fmaxf(l.m, r.m);
+            const float fl = l.m > -INFINITY ? expf(l.m - mm) : 0.f, fr = r.m > -INFINITY ? expf(r.m - mm) : 0.f;
+            CePart z;
+            z.m = mm; z.s = l.s * fl + r.s * fr;
+            if (r.xmax > l.xmax || (r.xmax == l.xmax && r.arg < l.arg)) { z.xmax = r.xmax; z.arg = r.arg; }
+            else { z.xmax = l.xmax; z.arg = l.arg; }
+            red[threadIdx.x] = z;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[(long long)b * nchunk + chunk] = red[0];
+}
+
+// one thread per b: lse, loss = lse - x[label], argmax
+__global__ void ce_final_kernel(const float* __restrict__ x, long long P, const CePart* __restrict__ part, int nchunk,
+                                const int* __restrict__ label, int B, float* __restrict__ lse, float* __restrict__ loss,
+                                int* __restrict__ argmax) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float m = -INFINITY, s = 0.f, xm = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int k = 0; k < nchunk; ++k) {
+        const CePart r = part[(long long)b * nchunk + k];
+        const float mm = fmaxf(m, r.m);
+        s = s * (m > -INFINITY ? expf(m - mm) : 0.f) + r.s * (r.m > -INFINITY ? expf(r.m - mm) : 0.f);
+        m = mm;
+        if (r.xmax > xm || (r.xmax == xm && r.arg < arg)) { xm = r.xmax; arg = r.arg; }
+    }
+    const float l = m + logf(s);
+    lse[b] = l;
+    loss[b] = l - x[(long long)b * P + label[b]];
+    argmax[b] = arg;
+}
+
+__global__ void __launch_bounds__(256) ce_grad_kernel(const float* __restrict__ x, long long P, const float* __restrict__ lse,
+                                                      const int* __restrict__ label, float* __restrict__ dx, int B, float gscale) {
+    const long long total = (long long)B * P;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / P);
+        const long long p = i - (long long)b * P;
+        float g = expf(x[i] - lse[b]);
+        if (p == label[b]) g -= 1.0f;
+        dx[i] = g * gscale;
+    }
+}
+
+// small heads: one wave per (row, segment); logits [rows, ld]; segment s covers columns [col0[s], col0[s]+ncls[s])
+struct CeSegs { int n; int col0[8]; int ncls[8]; };
+__global__ void __launch_bounds__(64) ce_rows_kernel(const float* __restrict__ logits, long long ld, CeSegs segs,
+                                                     const int* __restrict__ labels, float* __restrict__ loss,
+                                                     int* __restrict__ pred, float* __restrict__ dlogits, float gscale) {
+    const int row = blockIdx.x, sg = blockIdx.y, lane = threadIdx.x;
+    const float* x = logits + (long long)row * ld + segs.col0[sg];
+    const int n = segs.ncls[sg];
+    float m = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int c = lane; c < n; c += 64) {
+        const float v = x[c];
+        if (v > m) { m = v; arg = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, 64);
+        const int oa = __shfl_xor(arg, o, 64);
+        if (om > m || (om == m && oa < arg)) { m = om; arg = oa; }
+    }
+    float s = 0.f;
+    for (int c = lane; c < n; c += 64) s += expf(x[c] - m);
+    s = wave_sum(s);
+    const float l = m + logf(s);
+    const int lab = labels[row * segs.n + sg];
+    if (lane == 0) {
+        loss[row * segs.n + sg] = l - x[lab];
+        pred[row * segs.n + sg] = arg;
+    }
+    if (dlogits) {
+        float* d = dlogits + (long long)row * ld + segs.col0[sg];
+        for (int c = lane; c < n; c += 64) d[c] = (expf(x[c] - l) - (c == lab ? 1.0f : 0.0f)) * gscale;
+    }
+}
+
+// =====================================================================================================
+// polyphase weights:  Weff[(j3*Cin + ci)][(r3*Cout + co)] = sum_t W[co][ci][t3] * L[rd][td][jd] L[rh][th][jh] L[rw][tw][jw]
+// =====================================================================================================
+__global__ void __launch_bounds__(256) weff_fwd_kernel(const float* __restrict__ W, const float* __restrict__ L, float* __restrict__ Weff,
+                                                       int Cin, int Cout, int k, int s, int kl) {
+    extern __shared__ float sL[];          // [s][k][kl]
+    for (int i = threadIdx.x; i < s * k * kl; i += 256) sL[i] = L[i];
+    __syncthreads();
+    const int T = k * k * k;
+    const long long ncol = (long long)s * s * s * Cout;
+    const long long total = (long long)kl * kl * kl * Cin * ncol;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long col = i % ncol, row = i / ncol;
+        const int co = (int)(col % Cout), r3 = (int)(col / Cout);
+        const int ci = (int)(row % Cin), j3 = (int)(row / Cin);
+        const int rw = r3 % s, rh = (r3 / s) % s, rd = r3 / (s * s);
+        const int jw = j3 % kl, jh = (j3 / kl) % kl, jd = j3 / (kl * kl);
+        const float* w = W + ((long long)co * Cin + ci) * T;
+        float acc = 0.f;
+        for (int td = 0; td < k; ++td) {
+            const float ld = sL[(rd * k + td) * kl + jd];
+            if (ld == 0.f) continue;
+            for (int th = 0; th < k; ++th) {
+                const float lh = ld * sL[(rh * k + th) * kl + jh];
+                if (lh == 0.f) continue;
+                for (int tw = 0; tw < k; ++tw) acc = fmaf(w[(td * k + th) * k + tw], lh * sL[(rw * k + tw) * kl + jw], acc);
+            }
+        }
+        Weff[i] = acc;
+    }
+}
+// adjoint: dW[co][ci][t3] += sum_{r3, j3} dWeff[(j3*Cin+ci)][(r3*Cout+co)] * L3
+__global__ void __launch_bounds__(256) weff_bwd_kernel(const float* __restrict__ dWeff, const float* __restrict__ L, float* __restrict__ dW,
+                                                       int Cin, int Cout, int k, int s, int kl) {
+    extern __shared__ float sL[];
+    for (int i = threadIdx.x; i < s * k * kl; i += 256) sL[i] = L[i];
+    __syncthreads();
+    const int T = k * k * k;
+    const long long ncol = (long long)s * s * s * Cout;
+    const long long total = (long long)Cout * Cin * T;
+    // thread order: co fastest so that dWeff reads are coalesced
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int co = (int)(i % Cout);
+        const int ci = (int)((i / Cout) % Cin);
+        const int t3 = (int)(i / ((long long)Cout * Cin));
+        const int tw = t3 % k, th = (t3 / k) % k, td = t3 / (k * k);
+        float acc = 0.f;
+        for (int rd = 0; rd < s; ++rd)
+            for (int jd = 0; jd < kl; ++jd) {
+                const float ld = sL[(rd * k + td) * kl + jd];
+                if (ld == 0.f) continue;
+                for (int rh = 0; rh < s; ++rh)
+                    for (int jh = 0; jh < kl; ++jh) {
+                        const float lh = ld * sL[(rh * k + th) * kl + jh];
+                        if (lh == 0.f) continue;
+                        for (int rw = 0; rw < s; ++rw)
+                            for (int jw = 0; jw < kl; ++jw) {
+                                const float lw = lh * sL[(rw * k + tw) * kl + jw];
+                                if (lw == 0.f) continue;
+                                const long long row = (long long)((jd * kl + jh) * kl + jw) * Cin + ci;
+                                const long long col = (long long)((rd * s + rh) * s + rw) * Cout + co;
+                                acc = fmaf(dWeff[row * ncol + col], lw, acc);
+                            }
+                    }
+            }
+        dW[((long long)co * Cin + ci) * T + t3] += acc;
+    }
+}
+
+// =====================================================================================================
+// LAMB (lamb.py:94-122), multi-tensor over flat buffers.  chunk table: {tensor id, start, len} per chunk
+// =====================================================================================================
+__global__ void __launch_bounds__(256) lamb_stage1_kernel(const float* __restrict__ w, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v, float* __restrict__ upd,
+                                                          const int* __restrict__ chunks, float* __restrict__ part, float beta1,
+                                                          float beta2, float eps, float wd) {
+    __shared__ float r1[4], r2[4];
+    const int* ch = chunks + 3 * blockIdx.x;
+    const long long start = ch[1];
+    const int len = ch[2];
+    float sw = 0.f, su = 0.f;
+    for (int i = threadIdx.x; i < len; i += 256) {
+        const long long o = start + i;
+        const float gv = g[o], wv = w[o];
+        const float mv = m[o] * beta1 + (1.0f - beta1) * gv;
+        const float vv = v[o] * beta2 + (1.0f - beta2) * gv * gv;
+        m[o] = mv; v[o] = vv;
+        float u = mv / (sqrtf(vv) + eps);
+        if (wd != 0.f) u += wd * wv;
+        upd[o] = u;
+        sw = fmaf(wv, wv, sw);
+        su = fmaf(u, u, su);
+    }
+    sw = wave_sum(sw); su = wave_sum(su);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { r1[wid] = sw; r2[wid] = su; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = r1[0] + r1[1] + r1[2] + r1[3];
+        part[2 * blockIdx.x + 1] = r2[0] + r2[1] + r2[2] + r2[3];
+    }
+}
+// one thread per tensor: trust ratio from the partial sums of its chunks [first[t], first[t+1])
+__global__ void lamb_stage2_kernel(const float* __restrict__ part, const int* __restrict__ first, int ntensors,
+                                   float* __restrict__ trust) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntensors) return;
+    float sw = 0.f, su = 0.f;
+    for (int c = first[t]; c < first[t + 1]; ++c) { sw += part[2 * c]; su += part[2 * c + 1]; }
+    float wn = sqrtf(sw);
+    wn = fminf(fmaxf(wn, 0.f), 10.f);
+    const float an = sqrtf(su);
+    trust[t] = (wn == 0.f || an == 0.f) ? 1.0f : wn / an;
+}
+__global__ void __launch_bounds__(256) lamb_stage3_kernel(float* __restrict__ w, const float* __restrict__ upd,
+                                                          const int* __restrict__ chunks, const float* __restrict__ trust, float lr) {
+    const int* ch = chunks + 3 * blockIdx.x;
+    const long long start = ch[1];
+    const int len = ch[2];
+    const float alpha = -(lr * trust[ch[0]]);
+    for (int i = threadIdx.x; i < len; i += 256) w[start + i] = fmaf(alpha, upd[start + i], w[start + i]);
+}
+
+}  // namespace
+
+extern "C" int vxb_pointwise_fwd_f32(const float* x, const float* W, const float* bias, float* y, int64_t nvox, int Cin,
+                                     int Cout, float slope, vxb_stream_t stream) {
+    if (!x || !W || !bias || !y || nvox < 1 || Cin < 1 || Cin > 16 || Cout < 4 || Cout > 128 || (Cout & 3)) return VXB_EARG;
+    hipLaunchKernelGGL(pw_fwd_kernel, dim3(grid_for(nvox * (Cout / 4))), dim3(256), 0, (hipStream_t)stream, x, W, bias, y,
+                       (long long)nvox, Cin, Cout, slope);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+// part_ws: nblk*(64*Cin + 64) floats with nblk = ceil(nvox / 4096).  dW [64][Cin] and db [64] are ACCUMULATED.
+extern "C" int vxb_pointwise_wgrad_f32(const float* x, const float* y, const float* dy, float* dW, float* db, float* part_ws,
+                                       int64_t nvox, int Cin, int Cout, float slope, vxb_stream_t stream);
+extern "C" int vxb_sum_splits_f32(const float* part, int nsplit, int64_t n, float* dst, int accumulate, float alpha, vxb_stream_t stream);
+
+extern "C" int vxb_pointwise_wgrad_f32(const float* x, const float* y, const float* dy, float* dW, float* db, float* part_ws,
+                                       int64_t nvox, int Cin, int Cout, float slope, vxb_stream_t stream) {
+    if (!x || !y || !dy || !dW || !db || !part_ws || nvox < 1 || Cin < 1 || Cin > 16 || Cout != 64) return VXB_EARG;
+    const int vpb = 4096;
+    const int nb = vxb_cdiv(nvox, vpb);
+    float* pW = part_ws;
+    float* pB = part_ws + (size_t)nb * 64 * Cin;
+    hipLaunchKernelGGL(pw_wgrad_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, y, dy, pW, pB, (long long)nvox, Cin, vpb, slope);
+    VXB_CHECK_LAUNCH();
+    int rc = vxb_sum_splits_f32(pW, nb, 64 * Cin, dW, 1, 1.0f, stream);
+    if (rc) return rc;
+    return vxb_sum_splits_f32(pB, nb, 64, db, 1, 1.0f, stream);
+}
+
+// x: [B, S^3, C] with batch stride bs (elements).  part_ws: B*nchunk*C*7 floats, nchunk = ceil(S*S / rows_per_chunk),
+// rows_per_chunk = max(1, S*S/64).  Outputs: out_ss [B,3C], out_max [B,C], stats [B,C,2], argmax [B,C] (int32).
+extern "C" int vxb_ss3d_max_fwd_f32(const float* x, int64_t bs, int B, int S, int C, const float* lin, float* part_ws,
+                                    float* out_ss, float* out_max, float* stats, int32_t* argmax, vxb_stream_t stream) {
+    if (!x || !lin || !part_ws || !out_ss || !out_max || !stats || !argmax || B < 1 || S < 1) return VXB_EARG;
+    if (C != 64 && C != 128) return VXB_ESIZE;
+    hipStream_t st = (hipStream_t)stream;
+    const int rpc = (S * S / 64) < 1 ? 1 : S * S / 64;
+    const int nchunk = vxb_cdiv(S * S, rpc);
+    hipLaunchKernelGGL(ss_part_kernel, dim3(nchunk, B), dim3(256), 0, st, x, (long long)bs, S, C, lin, rpc, (SsPart*)part_ws, nchunk, 0.01f);
+    hipLaunchKernelGGL(ss_final_kernel, dim3(vxb_cdiv(B * C, 256)), dim3(256), 0, st, (const SsPart*)part_ws, nchunk, B, C, out_ss,
+                       out_max, stats, argmax);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+extern "C" int vxb_ss3d_max_bwd_f32(const float* x, int64_t bs, int B, int S, int C, const float* lin, const float* stats,
+                                    const float* out_ss, const int32_t* argmax, const float* g_ss, const float* g_max,
+                                    float* dx, int64_t dbs, int accumulate, vxb_stream_t stream) {
+    if (!x || !lin || !stats || !out_ss || !argmax || !g_ss || !g_max || !dx || B < 1 || S < 1) return VXB_EARG;
+    if (C != 64 && C != 128) return VXB_ESIZE;
+    const int rpc = (S * S / 256) < 1 ? 1 : S * S / 256;
+    const int nchunk = vxb_cdiv(S * S, rpc);
+    hipLaunchKernelGGL(ss_bwd_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, (long long)bs, S, C, lin, stats, out_ss,
+                       argmax, g_ss, g_max, dx, (long long)dbs, rpc, 0.01f, accumulate);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+extern "C" int vxb_conv3_c1_fwd_f32(const float* u, const float* w, const float* bias, float* q, int B, int S, int C,
+                                    vxb_stream_t stream) {
+    if (!u || !w || !bias || !q || B < 1 || S < 1) return VXB_EARG;
+    if (C != 64) return VXB_ESIZE;
+    const long long nrows = (long long)B * S * S;
+    const int grid = (int)((nrows + 3) / 4 > 8192 ? 8192 : (nrows + 3) / 4);
+    hipLaunchKernelGGL(c1_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, u, w, bias, q, B, S);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+extern "C" int vxb_conv3_c1_dgrad_f32(const float* dq, const float* w, const float* u, float* du, int B, int S, int C,
+                                      int accumulate, int apply_lrelu_mask, float slope, vxb_stream_t stream) {
+    if (!dq || !w || !du || (apply_lrelu_mask && !u) || B < 1 || S < 1) return VXB_EARG;
+    if (C != 64) return VXB_ESIZE;
+    const long long nvox = (long long)B * S * S * S;
+    const int grid = (int)((nvox + 3) / 4 > 32768 ? 32768 : (nvox + 3) / 4);
+    hipLaunchKernelGGL(c1_dgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dq, w, u, du, B, S, accumulate, apply_lrelu_mask, slope);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+// part_ws: nblk*(64*27 + 1) floats, nblk = ceil(B*S*S / 64).  dw [1][64][27] and db [1] are ACCUMULATED.
+extern "C" int vxb_conv3_c1_wgrad_f32(const float* u, const float* dq, float* dw, float* db, float* part_ws, int B, int S, int C,
+                                      vxb_stream_t stream) {
+    if (!u || !dq || !dw || !db || !part_ws || B < 1 || S < 1) return VXB_EARG;
+    if (C != 64) return VXB_ESIZE;
+    const long long nrows = (long long)B * S * S;
+    const int rpb = 64;
+    const int nb = vxb_cdiv(nrows, rpb);
+    float* pW = part_ws;
+    float* pB = part_ws + (size_t)nb * 64 * 27;
+    hipLaunchKernelGGL(c1_wgrad_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, u, dq, pW, pB, B, S, rpb);
+    VXB_CHECK_LAUNCH();
+    int rc = vxb_sum_splits_f32(pW, nb, 64 * 27, dw, 1, 1.0f, stream);
+    if (rc) return rc;
+    return vxb_sum_splits_f32(pB, nb, 1, db, 1, 1.0f, stream);
+}
+
+extern "C" int vxb_fold_pad_f32(const float* src, int Sp, int Cs, int c0, float* dst, const float* lrelu_of, int B, int S,
+                                int C, int pad, int accumulate, float slope, vxb_stream_t stream) {
+    if (!src || !dst || B < 1 || S < 1 || C < 4 || (C & 3) || (Cs & 3) || (c0 & 3) || pad < 0 || Sp < S + 2 * pad) return VXB_EARG;
+    hipLaunchKernelGGL(fold_kernel, dim3(grid_for((long long)B * S * S * S * (C / 4))), dim3(256), 0, (hipStream_t)stream, src, Sp, Cs,
+                       c0, dst, lrelu_of, B, S, C, pad, accumulate, slope);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+// part_ws: B*nchunk*4 floats (nchunk = ceil(P / 65536)).  Outputs per sample: lse, loss, argmax; dx = gscale*(softmax - onehot).
+extern "C" int vxb_ce_big_f32(const float* x, int64_t P, int B, const int32_t* label, float* part_ws, float* lse, float* loss,
+                              int32_t* argmax, float* dx, float gscale, vxb_stream_t stream) {
+    if (!x || !label || !part_ws || !lse || !loss || !argmax || B < 1 || P < 1 || P >= INT32_MAX) return VXB_EARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int per = 65536;
+    const int nchunk = vxb_cdiv(P, per);
+    hipLaunchKernelGGL(ce_part_kernel, dim3(nchunk, B), dim3(256), 0, st, x, (long long)P, per, nchunk, (CePart*)part_ws);
+    hipLaunchKernelGGL(ce_final_kernel, dim3(vxb_cdiv(B, 64)), dim3(64), 0, st, x, (long long)P, (const CePart*)part_ws, nchunk, label, B,
+                       lse, loss, argmax);
+    if (dx) hipLaunchKernelGGL(ce_grad_kernel, dim3(grid_for((long long)B * P)), dim3(256), 0, st, x, (long long)P, lse, label, dx, B, gscale);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+// logits [rows, ld]; nseg <= 8 segments (col0, ncls); labels [rows, nseg] int32; loss, pred [rows, nseg]; dlogits may be null.
+extern "C" int vxb_ce_rows_f32(const float* logits, int64_t ld, int rows, int nseg, const int32_t* col0, const int32_t* ncls,
+                               const int32_t* labels, float* loss, int32_t* pred, float* dlogits, float gscale,
+                               vxb_stream_t stream) {
+    if (!logits || !col0 || !ncls || !labels || !loss || !pred || rows < 1 || nseg < 1 || nseg > 8) return VXB_EARG;
+    CeSegs s;
+    s.n = nseg;
+    for (int i = 0; i < 8; ++i) { s.col0[i] = i < nseg ? col0[i] : 0; s.ncls[i] = i < nseg ? ncls[i] : 0; }
+    hipLaunchKernelGGL(ce_rows_kernel, dim3(rows, nseg), dim3(64), 0, (hipStream_t)stream, logits, (long long)ld, s, labels, loss, pred,
+                       dlogits, gscale);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+extern "C" int vxb_polyphase_weights_f32(const float* W, const float* L, float* Weff, int Cin, int Cout, int k, int s, int kl,
+                                         vxb_stream_t stream) {
+    if (!W || !L || !Weff || Cin < 1 || Cout < 1 || k < 1 || s < 1 || kl < 1 || s * k * kl > 8192) return VXB_EARG;
+    const long long total = (long long)kl * kl * kl * Cin * s * s * s * Cout;
+    hipLaunchKernelGGL(weff_fwd_kernel, dim3(grid_for(total)), dim3(256), s * k * kl * sizeof(float), (hipStream_t)stream, W, L, Weff, Cin,
+                       Cout, k, s, kl);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+extern "C" int vxb_polyphase_weights_bwd_f32(const float* dWeff, const float* L, float* dW, int Cin, int Cout, int k, int s, int kl,
+                                             vxb_stream_t stream) {
+    if (!dWeff || !L || !dW || Cin < 1 || Cout < 1 || k < 1 || s < 1 || kl < 1 || s * k * kl > 8192) return VXB_EARG;
+    const long long total = (long long)Cout * Cin * k * k * k;
+    hipLaunchKernelGGL(weff_bwd_kernel, dim3(grid_for(total)), dim3(256), s * k * kl * sizeof(float), (hipStream_t)stream, dWeff, L, dW, Cin,
+                       Cout, k, s, kl);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+// chunks: int32 [nchunks][3] = {tensor id, start, len} (device); first: int32 [ntensors+1] (device);
+// upd: scratch of the same length as w; part: 2*nchunks floats; trust: ntensors floats (kept for inspection).
+extern "C" int vxb_lamb_step_f32(float* w, const float* g, float* m, float* v, float* upd, const int32_t* chunks, int nchunks,
+                                 const int32_t* first, int ntensors, float* part, float* trust, float lr, float beta1, float beta2,
+                                 float eps, float weight_decay, vxb_stream_t stream) {
+    if (!w || !g || !m || !v || !upd || !chunks || !first || !part || !trust || nchunks < 1 || ntensors < 1) return VXB_EARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(lamb_stage1_kernel, dim3(nchunks), dim3(256), 0, st, w, g, m, v, upd, chunks, part, beta1, beta2, eps, weight_decay);
+    hipLaunchKernelGGL(lamb_stage2_kernel, dim3(vxb_cdiv(ntensors, 64)), dim3(64), 0, st, part, first, ntensors, trust);
+    hipLaunchKernelGGL(lamb_stage3_kernel, dim3(nchunks), dim3(256), 0, st, w, upd, chunks, trust, lr);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}

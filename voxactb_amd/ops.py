@@ -1,0 +1,348 @@
+"""Thin tensor-level wrappers over the C ABI (include/voxactb_hip.h).  Every function launches hand-written
+gfx950 kernels on the current torch stream; torch is used for allocation and views only.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call
+
+LRELU_SLOPE = 0.02   # reference: peract/helpers/network_utils.py:12
+ACT_NONE, ACT_LRELU = 0, 1
+_NAIVE_MACS = 1 << 22
+
+
+def _f32c(*ts):
+    for t in ts:
+        if t is not None:
+            if not t.is_cuda:
+                raise _lib.VoxactbHipError('tensor on %s: the kernels need a HIP device (no CPU fallback)' % t.device)
+            assert t.dtype == torch.float32, t.dtype
+
+
+def gemm(A, B, C, M, N, K, sAm, sAk, sBk, sBn, ldc, bias=None, residual=None, batch=1, H=1,
+         bA=(0, 0), bB=(0, 0), bC=(0, 0), alpha=1.0, act=ACT_NONE, accumulate=False):
+    _f32c(A, B, C, bias, residual)
+    call('vxb_gemm_f32', A, B, C, bias, residual, M, N, K, sAm, sAk, sBk, sBn, ldc, batch, H,
+         bA[0], bA[1], bB[0], bB[1], bC[0], bC[1], float(alpha), act, LRELU_SLOPE, int(accumulate))
+
+
+def naive_gemm(A, B, C, M, N, K, sAm, sAk, sBk, sBn, ldc, bias=None, act=ACT_NONE, accumulate=False):
+    _f32c(A, B, C, bias)
+    call('vxb_naive_gemm_f32', A, B, C, bias, M, N, K, sAm, sAk, sBk, sBn, ldc, act, LRELU_SLOPE, int(accumulate))
+
+
+def _small(M, N, K):
+    return M * N * K <= _NAIVE_MACS or (K % 4) or (N % 4)
+
+
+def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None):
+    """out[M,N] = act(x[M,K] @ W[N,K]^T + bias) (+ residual).  nn.Linear / DenseBlock forward."""
+    M, K = x.shape
+    N = W.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    if _small(M, N, K):
+        assert residual is None
+        naive_gemm(x, W, out, M, N, K, x.stride(0), 1, 1, W.stride(0), out.stride(0), bias, act)
+    else:
+        gemm(x, W, out, M, N, K, x.stride(0), 1, 1, W.stride(0), out.stride(0), bias=bias, residual=residual, act=act)
+    return out
+
+
+def linear_bwd(x, W, dy, dW, db=None, dx=None, dx_accumulate=False, ws=None):
+    """dW[N,K] += dy^T x ; db[N] += colsum(dy) ; dx[M,K] (+)= dy @ W   (dy already includes the activation')."""
+    M, K = x.shape
+    N = W.shape[0]
+    if _small(M, N, K) or (dy.stride(0) % 4):
+        naive_gemm(dy, x, dW, N, K, M, 1, dy.stride(0), x.stride(0), 1, dW.stride(0), accumulate=True)
+        if dx is not None:
+            naive_gemm(dy, W, dx, M, K, N, dy.stride(0), 1, W.stride(0), 1, dx.stride(0), accumulate=dx_accumulate)
+    else:
+        gemm(dy, x, dW, N, K, M, 1, dy.stride(0), x.stride(0), 1, dW.stride(0), accumulate=True)
+        if dx is not None:
+            gemm(dy, W, dx, M, K, N, dy.stride(0), 1, W.stride(0), 1, dx.stride(0), accumulate=dx_accumulate)
+    if db is not None:
+        colsum(dy, db, accumulate=True)
+
+
+def colsum(x, out, accumulate=False):
+    rows, N = x.shape
+    rpb = max(64, rows // 1024)
+    ws = torch.empty(((rows + rpb - 1) // rpb) * N, dtype=torch.float32, device=x.device)
+    call('vxb_colsum_f32', x, rows, N, x.stride(0), ws, out, int(accumulate))
+
+
+def sum_splits(part, nsplit, n, dst, accumulate=False, alpha=1.0):
+    call('vxb_sum_splits_f32', part, nsplit, n, dst, int(accumulate), float(alpha))
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5):
+    rows, D = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    call('vxb_layernorm_fwd_f32', x, gamma, beta, y, mean, rstd, rows, D, float(eps))
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_dx=False):
+    rows, D = x.shape
+    if dx is None:
+        dx = torch.empty_like(x)
+    nblk = (rows + 63) // 64
+    ws = torch.empty(nblk * 2 * D + 2 * D, dtype=torch.float32, device=x.device)
+    call('vxb_layernorm_bwd_f32', dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, rows, D, int(accumulate_dx))
+    return dx
+
+
+def softmax_rows(S, rows, cols, ld, p=0.0, seed=0):
+    """in place S -> P; returns P_drop (== S itself when p == 0)."""
+    Pd = torch.empty_like(S) if p > 0 else None
+    call('vxb_softmax_rows_f32', S, Pd, rows, cols, ld, float(p), int(seed) & 0xFFFFFFFF)
+    return Pd if p > 0 else S
+
+
+def softmax_bwd_rows(P, dP, rows, cols, ld, scale, p=0.0, seed=0):
+    call('vxb_softmax_bwd_rows_f32', P, dP, rows, cols, ld, float(scale), float(p), int(seed) & 0xFFFFFFFF)
+    return dP
+
+
+def geglu_fwd(h):
+    rows, F2 = h.shape
+    out = torch.empty((rows, F2 // 2), dtype=torch.float32, device=h.device)
+    call('vxb_geglu_fwd_f32', h, out, rows, F2 // 2)
+    return out
+
+
+def geglu_bwd(h, dout):
+    dh = torch.empty_like(h)
+    call('vxb_geglu_bwd_f32', h, dout, dh, h.shape[0], h.shape[1] // 2)
+    return dh
+
+
+def lrelu_bwd_(dy, y):
+    call('vxb_lrelu_bwd_f32', dy, y, dy, dy.numel(), LRELU_SLOPE)
+    return dy
+
+
+def axpy_(dst, src, alpha=1.0):
+    call('vxb_axpy_f32', dst, src, dst.numel(), float(alpha))
+    return dst
+
+
+# --------------------------------------------------------------------------------------------- conv family
+def conv_weight_fwd(W):
+    """[Co,Ci,k,k,k] -> [(tap, ci)][co]  (tiny re-layout, done with torch views + one copy)."""
+    Co, Ci = W.shape[:2]
+    return W.reshape(Co, Ci, -1).permute(2, 1, 0).reshape(-1, Co).contiguous()
+
+
+def conv_weight_dgrad(W):
+    """[Co,Ci,k,k,k] -> [(flipped tap, co)][ci]: weights of the data-gradient conv (stride 1)."""
+    Co, Ci = W.shape[:2]
+    return W.flip(2, 3, 4).reshape(Co, Ci, -1).permute(2, 0, 1).reshape(-1, Ci).contiguous()
+
+
+def conv3d(src0, wt, N, B, S_in, S_out, kext, off, stride=1, replicate=True, bias=None, act=ACT_NONE, src1=None,
+           out=None, ldc=None, accumulate=False, d2s=(0, 0)):
+    C0 = src0.shape[-1]
+    C1 = src1.shape[-1] if src1 is not None else 0
+    if out is None:
+        if d2s[0] > 0:
+            Vf = S_out * d2s[0]
+            out = torch.empty((B, Vf, Vf, Vf, d2s[1]), dtype=torch.float32, device=src0.device)
+        else:
+            out = torch.empty((B, S_out, S_out, S_out, N), dtype=torch.float32, device=src0.device)
+    _f32c(src0, src1, wt, bias, out)
+    call('vxb_conv3d_f32', src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, int(replicate), wt, N, bias, out,
+         ldc if ldc is not None else N, act, LRELU_SLOPE, int(accumulate), d2s[0], d2s[1])
+    return out
+
+
+def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=True, src1=None, ldy=None, d2s=(0, 0),
+                 nsplit=None):
+    """returns dWt [(tap, ci)][N] (fp32, deterministic split reduction)."""
+    C0 = src0.shape[-1]
+    C1 = src1.shape[-1] if src1 is not None else 0
+    K = kext ** 3 * (C0 + C1)
+    P = B * S_out ** 3
+    if nsplit is None:
+        tiles = ((K + 127) // 128) * ((N + 127) // 128 if N > 64 else 1)
+        nsplit = max(1, min(64, 1024 // max(tiles, 1), (P + 4095) // 4096))
+    part = torch.empty((nsplit, K, N), dtype=torch.float32, device=src0.device)
+    call('vxb_conv3d_wgrad_f32', src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, int(replicate), dy, N,
+         ldy if ldy is not None else N, d2s[0], d2s[1], part, nsplit)
+    if nsplit == 1:
+        return part[0]
+    out = torch.empty((K, N), dtype=torch.float32, device=src0.device)
+    sum_splits(part, nsplit, K * N, out)
+    return out
+
+
+def fold_pad(src, Sp, Cs, c0, dst, B, S, C, pad, accumulate=False, lrelu_of=None):
+    call('vxb_fold_pad_f32', src, Sp, Cs, c0, dst, lrelu_of, B, S, C, pad, int(accumulate), LRELU_SLOPE)
+    return dst
+
+
+def polyphase_tables(k, s):
+    """Per-axis matrices of upsample(x s, trilinear, align_corners=False) o conv(k, replicate pad k//2):
+    fine output s*q + r, tap t reads fine position Y = r + t - k//2 (relative to s*q), which interpolates the
+    low-res cells floor(src), floor(src)+1 with src = (Y + 0.5)/s - 0.5 (network_utils.py:245-250; replicate
+    extension of the low-res grid reproduces both the border clamp of the interpolation and the conv padding).
+    Returns (L [s][k][kl] float32, R) with kl = 2R+1 low-res taps, j = cell offset + R."""
+    p = k // 2
+    ent = []
+    for r in range(s):
+        for t in range(k):
+            Y = r + t - p
+            src = (Y + 0.5) / s - 0.5
+            i0 = int(np.floor(src))
+            lam = src - i0
+            ent.append((r, t, i0, 1.0 - lam))
+            ent.append((r, t, i0 + 1, lam))
+    R = max(abs(e[2]) for e in ent if e[3] != 0.0)
+    kl = 2 * R + 1
+    L = np.zeros((s, k, kl), np.float64)
+    for r, t, j, w in ent:
+        if w != 0.0:
+            L[r, t, j + R] += w
+    return L.astype(np.float32), R
+
+
+def polyphase_weights(W, L, s, kl):
+    Co, Ci, k = W.shape[0], W.shape[1], W.shape[2]
+    Weff = torch.empty((kl ** 3 * Ci, s ** 3 * Co), dtype=torch.float32, device=W.device)
+    call('vxb_polyphase_weights_f32', W, L, Weff, Ci, Co, k, s, kl)
+    return Weff
+
+
+def polyphase_weights_bwd(dWeff, L, dW, s, kl):
+    Co, Ci, k = dW.shape[0], dW.shape[1], dW.shape[2]
+    call('vxb_polyphase_weights_bwd_f32', dWeff, L, dW, Ci, Co, k, s, kl)
+
+
+def polyphase_dgrad_weights(Weff, Ci, Co, s, kl):
+    """[(j3, ci)][(r3, co)] -> [(t'3, co)][ci] with t' = s*(kl-1-j) + r per axis (stride-s, zero-pad data-gradient conv)."""
+    w = Weff.view(kl, kl, kl, Ci, s, s, s, Co).flip(0, 1, 2)
+    return w.permute(0, 4, 1, 5, 2, 6, 7, 3).reshape((s * kl) ** 3 * Co, Ci).contiguous()
+
+
+def strided_dgrad_weights(W, s):
+    """Data gradient of a stride-s conv as a stride-1 conv on the coarse grid with s^3 output phases:
+    W [Co,Ci,k,k,k] -> wt [(u''3, co)][(r3, ci)], U = ceil(k/s) taps/axis, element = W[co,ci,t = s*(U-1-u'') + r] (0 if t >= k)."""
+    Co, Ci, k = W.shape[0], W.shape[1], W.shape[2]
+    U = (k + s - 1) // s
+    Wp = torch.zeros((Co, Ci, U * s, U * s, U * s), dtype=W.dtype, device=W.device)
+    Wp[:, :, :k, :k, :k] = W
+    Wp = Wp.view(Co, Ci, U, s, U, s, U, s).flip(2, 4, 6)          # u'' = U-1-u
+    return Wp.permute(2, 4, 6, 0, 3, 5, 7, 1).reshape(U ** 3 * Co, s ** 3 * Ci).contiguous(), U
+
+
+# --------------------------------------------------------------------------------------------- voxel-sized ops
+def pointwise_fwd(x, W, bias):
+    nvox = x.numel() // x.shape[-1]
+    Cout = W.shape[0]
+    y = torch.empty(x.shape[:-1] + (Cout,), dtype=torch.float32, device=x.device)
+    call('vxb_pointwise_fwd_f32', x, W, bias, y, nvox, x.shape[-1], Cout, LRELU_SLOPE)
+    return y
+
+
+def pointwise_wgrad(x, y, dy, dW, db):
+    nvox = x.numel() // x.shape[-1]
+    Cin = x.shape[-1]
+    nb = (nvox + 4095) // 4096
+    ws = torch.empty(nb * (64 * Cin + 64), dtype=torch.float32, device=x.device)
+    call('vxb_pointwise_wgrad_f32', x, y, dy, dW, db, ws, nvox, Cin, y.shape[-1], LRELU_SLOPE)
+
+
+_LIN = {}
+
+
+def lin_table(S, device):
+    key = (S, str(device))
+    if key not in _LIN:
+        # network_utils.py:782-792: np.linspace in float64, then .float()
+        _LIN[key] = torch.from_numpy(np.linspace(-1., 1., S)).float().to(device)
+    return _LIN[key]
+
+
+def ss3d_max_fwd(x, bs, B, S, C):
+    dev = x.device
+    rpc = max(1, S * S // 64)
+    nchunk = (S * S + rpc - 1) // rpc
+    ws = torch.empty(B * nchunk * C * 7, dtype=torch.float32, device=dev)
+    out_ss = torch.empty((B, 3 * C), dtype=torch.float32, device=dev)
+    out_max = torch.empty((B, C), dtype=torch.float32, device=dev)
+    stats = torch.empty((B, C, 2), dtype=torch.float32, device=dev)
+    argmax = torch.empty((B, C), dtype=torch.int32, device=dev)
+    call('vxb_ss3d_max_fwd_f32', x, bs, B, S, C, lin_table(S, dev), ws, out_ss, out_max, stats, argmax)
+    return out_ss, out_max, stats, argmax
+
+
+def ss3d_max_bwd(x, bs, B, S, C, stats, out_ss, argmax, g_ss, g_max, dx, dbs, accumulate=False):
+    call('vxb_ss3d_max_bwd_f32', x, bs, B, S, C, lin_table(S, x.device), stats, out_ss, argmax, g_ss, g_max, dx, dbs,
+         int(accumulate))
+    return dx
+
+
+def conv3_c1_fwd(u, w, bias, B, S):
+    q = torch.empty((B, S, S, S), dtype=torch.float32, device=u.device)
+    call('vxb_conv3_c1_fwd_f32', u, w, bias, q, B, S, 64)
+    return q
+
+
+def conv3_c1_dgrad(dq, w, u, du, B, S, accumulate=True, mask=True):
+    call('vxb_conv3_c1_dgrad_f32', dq, w, u, du, B, S, 64, int(accumulate), int(mask), LRELU_SLOPE)
+    return du
+
+
+def conv3_c1_wgrad(u, dq, dw, db, B, S):
+    nb = (B * S * S + 63) // 64
+    ws = torch.empty(nb * (64 * 27 + 1), dtype=torch.float32, device=u.device)
+    call('vxb_conv3_c1_wgrad_f32', u, dq, dw, db, ws, B, S, 64)
+
+
+def ctx_build(lang, patch, pp, pos, B, T0, T1, C):
+    ctx = torch.empty((B, T0 + T1, 2 * C), dtype=torch.float32, device=lang.device)
+    call('vxb_ctx_build_f32', lang, patch, pp, pos, ctx, B, T0, T1, C)
+    return ctx
+
+
+def ctx_bwd(dctx, dpos, B, T0, T1, C):
+    dev = dctx.device
+    dlang = torch.empty((B * T0, 2 * C), dtype=torch.float32, device=dev)
+    dpatch = torch.empty((B * T1, C), dtype=torch.float32, device=dev)
+    dpp = torch.empty((B, C), dtype=torch.float32, device=dev)
+    ws = torch.empty(B * 32 * C, dtype=torch.float32, device=dev)
+    call('vxb_ctx_bwd_f32', dctx, dlang, dpatch, dpp, dpos, ws, B, T0, T1, C)
+    return dlang, dpatch, dpp
+
+
+def ce_big(x, label, dx=None, gscale=1.0):
+    """x [B, P] logits, label [B] int32 -> (loss [B], lse [B], argmax [B] int32); dx = gscale*(softmax - onehot)."""
+    B, P = x.shape
+    dev = x.device
+    nchunk = (P + 65535) // 65536
+    ws = torch.empty(B * nchunk * 4, dtype=torch.float32, device=dev)
+    lse = torch.empty(B, dtype=torch.float32, device=dev)
+    loss = torch.empty(B, dtype=torch.float32, device=dev)
+    arg = torch.empty(B, dtype=torch.int32, device=dev)
+    call('vxb_ce_big_f32', x, P, B, label, ws, lse, loss, arg, dx, float(gscale))
+    return loss, lse, arg
+
+
+def ce_rows(logits, segs, labels, dlogits=None, gscale=1.0):
+    """logits [rows, ld]; segs = [(col0, ncls), ...]; labels [rows, nseg] int32 -> (loss [rows,nseg], pred [rows,nseg])."""
+    import ctypes
+    rows = logits.shape[0]
+    n = len(segs)
+    dev = logits.device
+    loss = torch.empty((rows, n), dtype=torch.float32, device=dev)
+    pred = torch.empty((rows, n), dtype=torch.int32, device=dev)
+    c0 = (ctypes.c_int32 * n)(*[s[0] for s in segs])
+    nc = (ctypes.c_int32 * n)(*[s[1] for s in segs])
+    rc = _lib.lib().vxb_ce_rows_f32(_lib.ptr(logits), logits.stride(0), rows, n, c0, nc, _lib.ptr(labels), _lib.ptr(loss),
+                                    _lib.ptr(pred), _lib.ptr(dlogits), float(gscale), _lib.stream_ptr())
+    _lib.check(rc, 'vxb_ce_rows_f32')
+    return loss, pred
