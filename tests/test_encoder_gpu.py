@@ -1,0 +1,134 @@
+"""GPU parity of the whole Q-function (HIP engine) against golden fixtures captured from the reference and against the
+oracle run live: forward within 1e-4 (BASELINE.json north_star), gradients within 2e-3 relative of each tensor's max."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import agent as oagent, perceiver as operc, weights as ow
+from voxactb_amd import synthetic
+from voxactb_amd.agents.peract_bc.perceiver_lang_io import PerceiverVoxelLangEncoder
+from voxactb_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+TOL_Q = 1e-4
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def build_encoder(g, arm):
+    enc = PerceiverVoxelLangEncoder(
+        depth=int(g['cfg_depth']), iterations=1, voxel_size=int(g['cfg_V']), initial_dim=10, low_dim_size=int(g['cfg_low_dim']),
+        num_latents=int(g['cfg_latents']), voxel_patch_size=int(g['cfg_k']), voxel_patch_stride=int(g['cfg_s']),
+        activation='lrelu', input_dropout=0.0, attn_dropout=0.0, decoder_dropout=0.0, arm_pred_loss=arm)
+    shapes = {n: tuple(p.shape) for n, p in enc.named_parameters()}
+    sd = ow.hashed_state_dict(shapes, 0)
+    enc.load_state_dict(sd, strict=False)
+    return enc.to(DEV), sd
+
+
+def batch(g, cams):
+    B, H, W, V = int(g['cfg_B']), int(g['cfg_H']), int(g['cfg_W']), int(g['cfg_V'])
+    rs = synthetic.make_replay_sample(B, cams, (H, W), V, int(g['cfg_low_dim']), seed=1, arm_pred_loss=bool(g['cfg_arm']))
+    rs = {k: (v[:, 0] if v.dim() > 2 else v) for k, v in rs.items()}
+    return {k: ((v.float() / 255.0) * 2.0 - 1.0 if 'rgb' in k else v.float()) for k, v in rs.items()}
+
+
+def maxerr(a, b):
+    return float((a.detach().float().cpu() - b.detach().float().cpu()).abs().max())
+
+
+def run_fixture(g, cams):
+    arm = bool(g['cfg_arm'])
+    enc, sd = build_encoder(g, arm)
+    rs = batch(g, cams)
+    V = int(g['cfg_V'])
+    B = int(g['cfg_B'])
+    grid = T(g['grid']).to(DEV)
+    eng = enc.engine()
+    outs, cache = eng.forward(grid, rs['low_dim_state'].to(DEV), rs['lang_token_embs'].to(DEV), training=False, save=True)
+    # intermediates first: a failure here localises the broken stage
+    for name, mine in (('int_z1', cache['z1'].permute(0, 4, 1, 2, 3)), ('int_feats', cache['feats'])):
+        e = maxerr(mine, T(g[name]))
+        assert e < 5e-4, (name, e)
+    ez = maxerr(cache['z'][:, 77:].reshape(B, -1, cache['z'].shape[-1]).permute(0, 2, 1), T(g['int_z']).reshape(B, cache['z'].shape[-1], -1))
+    assert ez < 5e-4, ('z', ez)
+    assert abs(float(cache['d0'].double().sum()) - float(g['int_d0_sum'])) < 1e-3 * abs(float(g['int_d0_sum'])) + 1e-2
+    assert abs(float(cache['u0'].double().sum()) - float(g['int_u0_sum'])) < 1e-3 * abs(float(g['int_u0_sum'])) + 1e-2
+    assert abs(float(cache['u'].double().sum()) - float(g['int_u_sum'])) < 1e-3 * abs(float(g['int_u_sum'])) + 1e-2
+    e_q = maxerr(outs[0], T(g['q_trans']))
+    e_r = maxerr(outs[1], T(g['rot_grip']))
+    e_c = maxerr(outs[2], T(g['collision']))
+    print('forward max-abs: q_trans %.2e rot_grip %.2e collision %.2e' % (e_q, e_r, e_c))
+    assert e_q < TOL_Q and e_r < TOL_Q and e_c < TOL_Q
+    if arm:
+        assert maxerr(outs[3], T(g['arm_out'])) < TOL_Q
+    # loss + backward
+    at = rs['trans_action_indicies'].long()
+    lab = ((at[:, 0] * V + at[:, 1]) * V + at[:, 2]).int().to(DEV)
+    dq = torch.empty((B, V ** 3), device=DEV)
+    l_t, _, _ = ops.ce_big(outs[0].view(B, -1), lab, dq, 1.0 / B)
+    labs = torch.cat([rs['rot_grip_action_indicies'].int(), rs['ignore_collisions'].int()[:, :1]], 1).to(DEV).contiguous()
+    d_o = torch.empty_like(cache['o'])
+    l_h, _ = ops.ce_rows(cache['o'], [(0, 72), (72, 72), (144, 72), (216, 2), (218, 2)], labs, d_o, 1.0 / B)
+    total = l_t + l_h.sum(1)
+    d_arm = None
+    if arm:
+        d_arm = torch.empty_like(outs[3])
+        la, _ = ops.ce_rows(outs[3], [(0, 2)], rs['label'].int()[:, :1].to(DEV).contiguous(), d_arm, 1.0 / B)
+        total = total + la[:, 0]
+    loss = float(total.mean())
+    assert abs(loss - float(g['loss'])) < 1e-4, (loss, float(g['loss']))
+    for p in enc.parameters():
+        p.grad = None
+    eng.backward(cache, dq, d_o, d_arm)
+    names = [str(n) for n in g['grad_names']]
+    ref_norms = T(g['grad_norms'])
+    P = dict(enc.named_parameters())
+    bad = []
+    for n, rn in zip(names, ref_norms):
+        gn = float(P[n].grad.norm())
+        if abs(gn - float(rn)) > 3e-3 * float(rn) + 1e-5:   # +1e-5: grads that are mathematically 0 (trans bias)
+            bad.append((n, gn, float(rn)))
+        key = 'grad__' + n
+        if key in g.files:
+            ref = T(g[key])
+            e = maxerr(P[n].grad, ref)
+            if e > 3e-3 * float(ref.abs().max()) + 1e-5:
+                bad.append((n, 'full', e, float(ref.abs().max())))
+    assert not bad, bad
+
+
+def test_encoder_tiny_fixture(golden):
+    run_fixture(golden('f3_encoder_tiny'), ['front', 'wrist'])
+
+
+def test_encoder_c1_fixture(golden):
+    run_fixture(golden('f3_encoder_c1'), ['front'])
+
+
+def test_dropout_training_mode_runs_and_is_reproducible(golden):
+    g = golden('f3_encoder_tiny')
+    enc, _ = build_encoder(g, True)
+    enc.input_dropout, enc.attn_dropout = 0.1, 0.1
+    rs = batch(g, ['front', 'wrist'])
+    grid = T(g['grid']).to(DEV)
+    eng = enc.engine()
+    a, _ = eng.forward(grid, rs['low_dim_state'].to(DEV), rs['lang_token_embs'].to(DEV), training=True, save=False, seed=7)
+    b, _ = eng.forward(grid, rs['low_dim_state'].to(DEV), rs['lang_token_embs'].to(DEV), training=True, save=False, seed=7)
+    c, _ = eng.forward(grid, rs['low_dim_state'].to(DEV), rs['lang_token_embs'].to(DEV), training=True, save=False, seed=8)
+    assert torch.equal(a[0], b[0]) and not torch.equal(a[0], c[0])
+    assert maxerr(a[0], T(g['q_trans'])) < 0.5      # dropout perturbs, but stays in the same ballpark
+
+
+def test_module_forward_api(golden):
+    """PerceiverVoxelLangEncoder.forward(ins [B,10,V,V,V], ...) as QFunction calls it (agent :107-133)."""
+    g = golden('f3_encoder_tiny')
+    enc, _ = build_encoder(g, True)
+    rs = batch(g, ['front', 'wrist'])
+    grid = T(g['grid']).to(DEV)
+    ins = grid.permute(0, 4, 1, 2, 3)
+    outs = enc(ins, rs['low_dim_state'].to(DEV), rs['lang_goal_emb'].to(DEV), rs['lang_token_embs'].to(DEV), None, None, None)
+    assert maxerr(outs[0], T(g['q_trans'])) < TOL_Q and len(outs) == 4

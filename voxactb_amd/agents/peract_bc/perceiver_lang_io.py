@@ -1,0 +1,588 @@
+"""PerceiverVoxelLangEncoder -- drop-in for the reference class of the same name
+(reference: peract/agents/peract_bc/perceiver_lang_io.py:135-485) for the configuration the VoxAct-B
+single-arm / acting / stabilizing policies use (lang_fusion_type='seq', pos_encoding_with_lang=True,
+no ablation flags; launch_utils.py:744-774).
+
+Same constructor arguments, same parameter / buffer names and shapes (so reference checkpoints load with
+`load_state_dict`), same `forward(ins, proprio, lang_goal_emb, lang_token_embs, prev_layer_voxel_grid,
+bounds, prev_layer_bounds, mask=None)` outputs.  The arithmetic does NOT run through torch.nn: parameters
+are plain storage, and forward/backward are explicit sequences of hand-written gfx950 kernels
+(voxactb_amd/csrc/*.hip through the C ABI), orchestrated by `PerceiverEngine` below:
+
+  * channels-last activations end to end (the voxelizer already emits [B,V,V,V,10]);
+  * every Conv3DBlock is an implicit GEMM on the matrix cores with replicate padding done by address
+    clamping; data gradients are zero-padded convs followed by the padding adjoint ("fold");
+  * `Upsample(x s, trilinear) -> Conv3d(k)` of Conv3DUpsampleBlock (network_utils.py:245-250) is evaluated in
+    polyphase form: a (2R+1)^3 replicate-padded conv on the LOW-res grid with s^3*64 phase channels and a
+    depth-to-space store -- 4.6x fewer FLOPs at k=s=5 and the 4.1 GB upsampled tensor is never materialised;
+  * no autograd graph: the backward pass is written out, parameter gradients accumulate into views of one
+    flat buffer (one RCCL all-reduce, one fused LAMB launch sequence).
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from ... import ops
+from ..._lib import VoxactbHipError, require_cuda
+
+LRELU_SLOPE = 0.02
+LANG_FEAT_DIM, LANG_EMB_DIM, LANG_MAX_SEQ_LEN = 1024, 512, 77
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# parameter holders: same attribute paths as the reference modules, same initialisation, no forward()
+# ----------------------------------------------------------------------------------------------------------------------
+def _init_like_reference(weight, bias, activation):
+    """network_utils.py:140-154 / :263-276."""
+    if activation is None:
+        nn.init.xavier_uniform_(weight, gain=nn.init.calculate_gain('linear'))
+    elif activation == 'tanh':
+        nn.init.xavier_uniform_(weight, gain=nn.init.calculate_gain('tanh'))
+    elif activation == 'lrelu':
+        nn.init.kaiming_uniform_(weight, a=LRELU_SLOPE, nonlinearity='leaky_relu')
+    elif activation == 'relu':
+        nn.init.kaiming_uniform_(weight, nonlinearity='relu')
+    else:
+        raise ValueError()
+    nn.init.zeros_(bias)
+
+
+class _Holder(nn.Module):
+    def forward(self, *a, **k):
+        raise VoxactbHipError('parameter holder: the arithmetic runs in PerceiverEngine (HIP kernels), not torch.nn')
+
+
+class Conv3DBlock(_Holder):
+    """storage twin of network_utils.Conv3DBlock (:128-170)."""
+
+    def __init__(self, in_channels, out_channels, kernel_sizes=3, strides=1, norm=None, activation=None):
+        super().__init__()
+        if norm is not None:
+            raise NotImplementedError('Norm not implemented.')
+        self.conv3d = nn.Conv3d(in_channels, out_channels, kernel_sizes, strides, padding=kernel_sizes // 2,
+                                padding_mode='replicate')
+        _init_like_reference(self.conv3d.weight, self.conv3d.bias, activation)
+        self.activation = activation
+        self.out_channels = out_channels
+
+
+class Conv3DUpsampleBlock(_Holder):
+    """storage twin of network_utils.Conv3DUpsampleBlock (:237-254): conv_up.0, [Upsample = conv_up.1], conv_up.2."""
+
+    def __init__(self, in_channels, out_channels, strides, kernel_sizes=3, norm=None, activation=None):
+        super().__init__()
+        layer = [Conv3DBlock(in_channels, out_channels, kernel_sizes, 1, norm, activation)]
+        if strides > 1:
+            layer.append(nn.Upsample(scale_factor=strides, mode='trilinear', align_corners=False))
+        layer.append(Conv3DBlock(out_channels, out_channels, kernel_sizes, 1, norm, activation))
+        self.conv_up = nn.Sequential(*layer)
+
+
+class DenseBlock(_Holder):
+    def __init__(self, in_features, out_features, norm=None, activation=None):
+        super().__init__()
+        self.linear = nn.Linear(in_features, out_features)
+        _init_like_reference(self.linear.weight, self.linear.bias, activation)
+        self.activation = activation
+
+
+class SpatialSoftmax3D(_Holder):
+    """only the registered buffers (state_dict compatibility, network_utils.py:780-795)."""
+
+    def __init__(self, depth, height, width, channel):
+        super().__init__()
+        self.temperature = 0.01
+        px, py, pz = np.meshgrid(np.linspace(-1., 1., depth), np.linspace(-1., 1., height), np.linspace(-1., 1., width))
+        for n, a in (('pos_x', px), ('pos_y', py), ('pos_z', pz)):
+            self.register_buffer(n, torch.from_numpy(a.reshape(depth * height * width)).float())
+
+
+class Attention(_Holder):
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.0):
+        super().__init__()
+        inner = dim_head * heads
+        context_dim = query_dim if context_dim is None else context_dim
+        self.scale = dim_head ** -0.5
+        self.heads = heads
+        self.dim_head = dim_head
+        self.to_q = nn.Linear(query_dim, inner, bias=False)
+        self.to_kv = nn.Linear(context_dim, inner * 2, bias=False)
+        self.to_out = nn.Linear(inner, query_dim)
+        self.dropout_p = dropout
+
+
+class GEGLU(_Holder):
+    pass
+
+
+class FeedForward(_Holder):
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(dim, dim * mult * 2), GEGLU(), nn.Linear(dim * mult, dim))
+
+
+class PreNorm(_Holder):
+    def __init__(self, dim, fn, context_dim=None):
+        super().__init__()
+        self.fn = fn
+        self.norm = nn.LayerNorm(dim)
+        self.norm_context = nn.LayerNorm(context_dim) if context_dim is not None else None
+
+
+class PerceiverVoxelLangEncoder(nn.Module):
+
+    def __init__(self, depth, iterations, voxel_size, initial_dim, low_dim_size, layer=0, num_rotation_classes=72,
+                 num_grip_classes=2, num_collision_classes=2, input_axis=3, num_latents=512, im_channels=64,
+                 latent_dim=512, cross_heads=1, latent_heads=8, cross_dim_head=64, latent_dim_head=64, activation='relu',
+                 weight_tie_layers=False, pos_encoding_with_lang=True, input_dropout=0.1, attn_dropout=0.1,
+                 decoder_dropout=0.0, lang_fusion_type='seq', voxel_patch_size=9, voxel_patch_stride=8,
+                 no_skip_connection=False, no_perceiver=False, no_language=False, final_dim=64, arm_pred_loss=False):
+        super().__init__()
+        if lang_fusion_type != 'seq' or not pos_encoding_with_lang or no_skip_connection or no_perceiver \
+                or weight_tie_layers or iterations != 1 or activation != 'lrelu' or low_dim_size <= 0 \
+                or num_rotation_classes <= 0:
+            raise NotImplementedError(
+                'voxactb_amd covers the configuration VoxAct-B trains (launch_utils.py:744-774, PERACT_BC.yaml): '
+                "lang_fusion_type='seq', pos_encoding_with_lang, activation='lrelu', iterations=1, no ablations")
+        if im_channels != 64 or final_dim != 64 or int(initial_dim) > 16:
+            raise NotImplementedError('kernels are specialised for im_channels = final_dim = 64, initial_dim <= 16')
+        if voxel_size % voxel_patch_stride or voxel_patch_size % 2 == 0:
+            raise ValueError('voxel_patch_size must be odd and voxel_patch_stride must divide voxel_size '
+                             '(the reference fails at perceiver_lang_io.py:422 otherwise)')
+        self.depth, self.layer, self.init_dim, self.iterations = depth, layer, int(initial_dim), iterations
+        self.input_axis, self.voxel_size, self.low_dim_size, self.im_channels = input_axis, voxel_size, low_dim_size, im_channels
+        self.pos_encoding_with_lang, self.lang_fusion_type = pos_encoding_with_lang, lang_fusion_type
+        self.voxel_patch_size, self.voxel_patch_stride = voxel_patch_size, voxel_patch_stride
+        self.num_rotation_classes, self.num_grip_classes = num_rotation_classes, num_grip_classes
+        self.num_collision_classes, self.final_dim = num_collision_classes, final_dim
+        self.input_dropout, self.attn_dropout, self.decoder_dropout = input_dropout, attn_dropout, decoder_dropout
+        self.no_skip_connection, self.no_perceiver, self.no_language = no_skip_connection, no_perceiver, no_language
+        self.arm_pred_loss = arm_pred_loss
+        self.cross_heads, self.latent_heads = cross_heads, latent_heads
+        self.cross_dim_head, self.latent_dim_head = cross_dim_head, latent_dim_head
+        self.num_latents, self.latent_dim = num_latents, latent_dim
+
+        spatial_size = voxel_size // voxel_patch_stride
+        self.input_dim_before_seq = im_channels * 2
+        self.pos_encoding = nn.Parameter(torch.randn(1, LANG_MAX_SEQ_LEN + spatial_size ** 3, self.input_dim_before_seq))
+        self.input_preprocess = Conv3DBlock(self.init_dim, im_channels, kernel_sizes=1, strides=1, activation=activation)
+        self.patchify = Conv3DBlock(im_channels, im_channels, kernel_sizes=voxel_patch_size, strides=voxel_patch_stride,
+                                    activation=activation)
+        self.lang_preprocess = nn.Linear(LANG_EMB_DIM, im_channels * 2)
+        self.proprio_preprocess = DenseBlock(low_dim_size, im_channels, None, activation)
+        self.ss0 = SpatialSoftmax3D(voxel_size, voxel_size, voxel_size, im_channels)
+        flat_size = im_channels * 4
+        self.latents = nn.Parameter(torch.randn(num_latents, latent_dim))
+        self.cross_attend_blocks = nn.ModuleList([
+            PreNorm(latent_dim, Attention(latent_dim, self.input_dim_before_seq, heads=cross_heads, dim_head=cross_dim_head,
+                                          dropout=input_dropout), context_dim=self.input_dim_before_seq),
+            PreNorm(latent_dim, FeedForward(latent_dim))])
+        self.layers = nn.ModuleList([])
+        for _ in range(depth):
+            self.layers.append(nn.ModuleList([
+                PreNorm(latent_dim, Attention(latent_dim, heads=latent_heads, dim_head=latent_dim_head, dropout=attn_dropout)),
+                PreNorm(latent_dim, FeedForward(latent_dim))]))
+        self.decoder_cross_attn = PreNorm(self.input_dim_before_seq,
+                                          Attention(self.input_dim_before_seq, latent_dim, heads=cross_heads,
+                                                    dim_head=cross_dim_head, dropout=decoder_dropout),
+                                          context_dim=latent_dim)
+        self.up0 = Conv3DUpsampleBlock(self.input_dim_before_seq, final_dim, kernel_sizes=voxel_patch_size,
+                                       strides=voxel_patch_stride, activation=activation)
+        self.ss1 = SpatialSoftmax3D(spatial_size, spatial_size, spatial_size, self.input_dim_before_seq)
+        flat_size += self.input_dim_before_seq * 4
+        self.final = Conv3DBlock(im_channels * 2, im_channels, kernel_sizes=3, strides=1, activation=activation)
+        self.trans_decoder = Conv3DBlock(final_dim, 1, kernel_sizes=3, strides=1, activation=None)
+        self.ss_final = SpatialSoftmax3D(voxel_size, voxel_size, voxel_size, im_channels)
+        flat_size += im_channels * 4
+        self.dense0 = DenseBlock(flat_size, 256, None, activation)
+        self.dense1 = DenseBlock(256, final_dim, None, activation)
+        self.rot_grip_collision_ff = DenseBlock(final_dim, num_rotation_classes * 3 + num_grip_classes + num_collision_classes,
+                                                None, None)
+        if arm_pred_loss:
+            self.dense2 = DenseBlock(flat_size, final_dim, None, activation)
+            self.arm_ff = DenseBlock(final_dim, 2, None, None)
+        self._engine = None
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def engine(self):
+        if self._engine is None:
+            self._engine = PerceiverEngine(self)
+        return self._engine
+
+    def forward(self, ins, proprio, lang_goal_emb, lang_token_embs, prev_layer_voxel_grid, bounds, prev_layer_bounds,
+                mask=None):
+        """ins: [B,10,V,V,V] (the channels-first VIEW QFunction passes, agent :100) or channels-last [B,V,V,V,10].
+        `lang_goal_emb`, `prev_layer_*`, `bounds` are dead inputs for lang_fusion_type='seq' (perceiver :345-354)."""
+        if mask is not None:
+            raise NotImplementedError('attention mask is never passed by the agent')
+        eng = self.engine()
+        outs, _ = eng.forward(eng.to_channels_last(ins), proprio, lang_token_embs, training=False, save=False)
+        return outs
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def _r4(n):
+    return (n + 3) & ~3
+
+
+class PerceiverEngine:
+    """Explicit forward / backward of the encoder on HIP kernels.  Parameter storage = the module's Parameters."""
+
+    def __init__(self, module: PerceiverVoxelLangEncoder):
+        self.m = module
+        self.P = dict(module.named_parameters())
+        k, s = module.voxel_patch_size, module.voxel_patch_stride
+        self.k, self.s = k, s
+        self.V = module.voxel_size
+        self.G = self.V // s
+        self.C = module.im_channels
+        self.Cx = 2 * self.C
+        self.D = module.latent_dim
+        self.L = module.num_latents
+        self.T0 = LANG_MAX_SEQ_LEN
+        if s > 1:
+            Lt, self.R = ops.polyphase_tables(k, s)
+            self.kl = 2 * self.R + 1
+            self._Lt_host = Lt
+        self._Lt = None
+        self.step_seed = 0
+
+    # -------------------------------------------------------------------------------------------------- helpers
+    def p(self, name):
+        return self.P[name].data
+
+    def g(self, name):
+        prm = self.P[name]
+        if prm.grad is None:
+            prm.grad = torch.zeros_like(prm.data)
+        return prm.grad
+
+    def Lt(self, dev):
+        if self._Lt is None or self._Lt.device != dev:
+            self._Lt = torch.from_numpy(self._Lt_host).to(dev)
+        return self._Lt
+
+    def to_channels_last(self, ins):
+        require_cuda(ins)
+        V = self.V
+        if ins.dim() != 5:
+            raise VoxactbHipError('voxel grid must be 5-D')
+        if ins.shape[-1] == self.m.init_dim and ins.shape[1] == V:
+            return ins.contiguous()
+        x = ins.permute(0, 2, 3, 4, 1)        # channels-first view of an NDHWC buffer -> zero-copy
+        return x.contiguous()
+
+    # -------------------------------------------------------------------------------------------------- attention
+    def _attn_fwd(self, pre, xq, ctxn, H, d, p, seed, residual, save):
+        """xq [B,Nq,Dq], ctxn [B,Nk,Dc] (already normalised).  Returns out [B*Nq, Dout], cache."""
+        B, Nq, Dq = xq.shape
+        Nk = ctxn.shape[1]
+        Wq, Wkv = self.p(pre + '.fn.to_q.weight'), self.p(pre + '.fn.to_kv.weight')
+        Wo, bo = self.p(pre + '.fn.to_out.weight'), self.p(pre + '.fn.to_out.bias')
+        inner = H * d
+        q = ops.linear(xq.view(B * Nq, Dq), Wq)
+        kv = ops.linear(ctxn.reshape(B * Nk, ctxn.shape[2]), Wkv)
+        ld = _r4(Nk)
+        S = torch.empty((B * H, Nq, ld), dtype=torch.float32, device=xq.device)
+        ops.gemm(q, kv, S, Nq, Nk, d, inner, 1, 1, 2 * inner, ld, batch=B * H, H=H, bA=(Nq * inner, d),
+                 bB=(Nk * 2 * inner, d), bC=(H * Nq * ld, Nq * ld), alpha=d ** -0.5)
+        Pd = ops.softmax_rows(S, B * H * Nq, Nk, ld, p, seed)
+        O = torch.empty((B * Nq, inner), dtype=torch.float32, device=xq.device)
+        ops.gemm(Pd, kv[:, inner:], O, Nq, d, Nk, ld, 1, 2 * inner, 1, inner, batch=B * H, H=H,
+                 bA=(H * Nq * ld, Nq * ld), bB=(Nk * 2 * inner, d), bC=(Nq * inner, d))
+        out = ops.linear(O, Wo, bo, residual=residual)
+        cache = dict(q=q, kv=kv, P=S, Pd=Pd, O=O, dims=(B, Nq, Nk, H, d, ld), p=p, seed=seed) if save else None
+        return out, cache
+
+    def _attn_bwd(self, pre, c, dout, xq2d, ctx2d, same_src):
+        """dout [B*Nq, Dout] -> (dxq [B*Nq,Dq], dctx [B*Nk,Dc] or None if same_src (added into dxq))."""
+        B, Nq, Nk, H, d, ld = c['dims']
+        inner = H * d
+        Wq, Wkv, Wo = self.p(pre + '.fn.to_q.weight'), self.p(pre + '.fn.to_kv.weight'), self.p(pre + '.fn.to_out.weight')
+        dev = dout.device
+        dO = torch.empty((B * Nq, inner), dtype=torch.float32, device=dev)
+        ops.linear_bwd(c['O'], Wo, dout, self.g(pre + '.fn.to_out.weight'), self.g(pre + '.fn.to_out.bias'), dO)
+        kv, q, P, Pd = c['kv'], c['q'], c['P'], c['Pd']
+        dkv = torch.empty_like(kv)
+        # dV[j,:] = sum_i Pd[i,j] dO[i,:]
+        ops.gemm(Pd, dO, dkv[:, inner:], Nk, d, Nq, 1, ld, inner, 1, 2 * inner, batch=B * H, H=H,
+                 bA=(H * Nq * ld, Nq * ld), bB=(Nq * inner, d), bC=(Nk * 2 * inner, d))
+        # dPd[i,j] = sum_d dO[i,d] V[j,d]
+        dP = Pd if c['p'] > 0 else torch.empty_like(P)
+        ops.gemm(dO, kv[:, inner:], dP, Nq, Nk, d, inner, 1, 1, 2 * inner, ld, batch=B * H, H=H, bA=(Nq * inner, d),
+                 bB=(Nk * 2 * inner, d), bC=(H * Nq * ld, Nq * ld))
+        dS = ops.softmax_bwd_rows(P, dP, B * H * Nq, Nk, ld, d ** -0.5, c['p'], c['seed'])
+        dq = torch.empty_like(q)
+        ops.gemm(dS, kv, dq, Nq, d, Nk, ld, 1, 2 * inner, 1, inner, batch=B * H, H=H, bA=(H * Nq * ld, Nq * ld),
+                 bB=(Nk * 2 * inner, d), bC=(Nq * inner, d))
+        ops.gemm(dS, q, dkv, Nk, d, Nq, 1, ld, inner, 1, 2 * inner, batch=B * H, H=H, bA=(H * Nq * ld, Nq * ld),
+                 bB=(Nq * inner, d), bC=(Nk * 2 * inner, d))
+        dxq = torch.empty_like(xq2d)
+        ops.linear_bwd(xq2d, Wq, dq, self.g(pre + '.fn.to_q.weight'), None, dxq)
+        if same_src:
+            ops.linear_bwd(ctx2d, Wkv, dkv, self.g(pre + '.fn.to_kv.weight'), None, dxq, dx_accumulate=True)
+            return dxq, None
+        dctx = torch.empty_like(ctx2d)
+        ops.linear_bwd(ctx2d, Wkv, dkv, self.g(pre + '.fn.to_kv.weight'), None, dctx)
+        return dxq, dctx
+
+    def _ff_fwd(self, pre, x2d, save):
+        xn, mean, rstd = ops.layernorm_fwd(x2d, self.p(pre + '.norm.weight'), self.p(pre + '.norm.bias'))
+        h = ops.linear(xn, self.p(pre + '.fn.net.0.weight'), self.p(pre + '.fn.net.0.bias'))
+        gg = ops.geglu_fwd(h)
+        out = ops.linear(gg, self.p(pre + '.fn.net.2.weight'), self.p(pre + '.fn.net.2.bias'), residual=x2d)
+        return out, (dict(x=x2d, mean=mean, rstd=rstd, xn=xn, h=h, gg=gg) if save else None)
+
+    def _ff_bwd(self, pre, c, dx):
+        """dx: gradient wrt the block output (also the residual path); updated in place to the input gradient."""
+        dgg = torch.empty_like(c['gg'])
+        ops.linear_bwd(c['gg'], self.p(pre + '.fn.net.2.weight'), dx, self.g(pre + '.fn.net.2.weight'),
+                       self.g(pre + '.fn.net.2.bias'), dgg)
+        dh = ops.geglu_bwd(c['h'], dgg)
+        dxn = torch.empty_like(c['xn'])
+        ops.linear_bwd(c['xn'], self.p(pre + '.fn.net.0.weight'), dh, self.g(pre + '.fn.net.0.weight'),
+                       self.g(pre + '.fn.net.0.bias'), dxn)
+        ops.layernorm_bwd(dxn, c['x'], self.p(pre + '.norm.weight'), c['mean'], c['rstd'], self.g(pre + '.norm.weight'),
+                          self.g(pre + '.norm.bias'), dx=dx, accumulate_dx=True)
+        return dx
+
+    # -------------------------------------------------------------------------------------------------- forward
+    def forward(self, vox, proprio, lang_token_embs, training=False, save=True, seed=None):
+        """vox [B,V,V,V,10] channels-last.  Returns ((trans [B,1,V,V,V], rot_and_grip, collision[, arm]), cache)."""
+        require_cuda(vox, proprio, lang_token_embs)
+        m = self.m
+        B = vox.shape[0]
+        V, G, C, Cx, D, L, T0, k, s = self.V, self.G, self.C, self.Cx, self.D, self.L, self.T0, self.k, self.s
+        T1 = G ** 3
+        Nctx = T0 + T1
+        dev = vox.device
+        if seed is None:
+            self.step_seed += 1
+            seed = self.step_seed
+        p_in = m.input_dropout if training else 0.0
+        p_at = m.attn_dropout if training else 0.0
+        p_de = m.decoder_dropout if training else 0.0
+        proprio = proprio.float().contiguous()
+        lang = lang_token_embs.float().contiguous().view(B * T0, LANG_EMB_DIM)
+        c = {}
+        # 1. input 1x1x1 conv + lrelu (perceiver :357)
+        d0 = ops.pointwise_fwd(vox, self.p('input_preprocess.conv3d.weight').view(C, -1), self.p('input_preprocess.conv3d.bias'))
+        # 2. SpatialSoftmax3D + max (perceiver :360)
+        ss0 = ops.ss3d_max_fwd(d0, V ** 3 * C, B, V, C)
+        # 3. patchify (perceiver :363)
+        patch = ops.conv3d(d0, ops.conv_weight_fwd(self.p('patchify.conv3d.weight')), C, B, V, G, k, -(k // 2), stride=s,
+                           bias=self.p('patchify.conv3d.bias'), act=ops.ACT_LRELU)
+        # 4-6. proprio, language, context assembly (perceiver :370-422)
+        pp = ops.linear(proprio, self.p('proprio_preprocess.linear.weight'), self.p('proprio_preprocess.linear.bias'), ops.ACT_LRELU)
+        lg = ops.linear(lang, self.p('lang_preprocess.weight'), self.p('lang_preprocess.bias'))
+        ctx = ops.ctx_build(lg, patch, pp, self.p('pos_encoding'), B, T0, T1, C)
+        ctx2d = ctx.view(B * Nctx, Cx)
+        # 7. latents
+        x = self.p('latents').unsqueeze(0).expand(B, L, D).contiguous().view(B * L, D)
+        # 8. cross attention block (perceiver :431-432)
+        pre = 'cross_attend_blocks.0'
+        xn, xm, xr = ops.layernorm_fwd(x, self.p(pre + '.norm.weight'), self.p(pre + '.norm.bias'))
+        cn, cm, cr = ops.layernorm_fwd(ctx2d, self.p(pre + '.norm_context.weight'), self.p(pre + '.norm_context.bias'))
+        x1, ca = self._attn_fwd(pre, xn.view(B, L, D), cn.view(B, Nctx, Cx), m.cross_heads, m.cross_dim_head, p_in,
+                                seed * 131 + 1, x, save)
+        if save:
+            c['cross'] = dict(x=x, xn=xn, xm=xm, xr=xr, cn=cn, cm=cm, cr=cr, attn=ca)
+        x, c['cross_ff'] = self._ff_fwd('cross_attend_blocks.1', x1, save)
+        # self attention stack (perceiver :435-437)
+        c['layers'] = []
+        for i in range(m.depth):
+            pre = 'layers.%d.0' % i
+            xn, xm, xr = ops.layernorm_fwd(x, self.p(pre + '.norm.weight'), self.p(pre + '.norm.bias'))
+            x1, sa = self._attn_fwd(pre, xn.view(B, L, D), xn.view(B, L, D), m.latent_heads, m.latent_dim_head, p_at,
+                                    seed * 131 + 2 + i, x, save)
+            x2, fc = self._ff_fwd('layers.%d.1' % i, x1, save)
+            if save:
+                c['layers'].append(dict(x=x, xn=xn, xm=xm, xr=xr, attn=sa, ff=fc))
+            x = x2
+        # decoder cross attention (perceiver :440-448): queries = all context tokens, no residual
+        pre = 'decoder_cross_attn'
+        qn, qm, qr = ops.layernorm_fwd(ctx2d, self.p(pre + '.norm.weight'), self.p(pre + '.norm.bias'))
+        ln, lm, lr = ops.layernorm_fwd(x, self.p(pre + '.norm_context.weight'), self.p(pre + '.norm_context.bias'))
+        z, da = self._attn_fwd(pre, qn.view(B, Nctx, Cx), ln.view(B, L, D), m.cross_heads, m.cross_dim_head, p_de,
+                               seed * 131 + 100, None, save)
+        z = z.view(B, Nctx, Cx)
+        zv = z[:, T0:]                                   # [B, G^3, Cx] view, batch stride Nctx*Cx
+        ss1 = ops.ss3d_max_fwd(zv, Nctx * Cx, B, G, Cx)  # perceiver :451
+        zc = zv.contiguous().view(B, G, G, G, Cx)
+        # up0 = conv(k) -> upsample(s) -> conv(k)   (perceiver :454; network_utils :242-250)
+        z1 = ops.conv3d(zc, ops.conv_weight_fwd(self.p('up0.conv_up.0.conv3d.weight')), C, B, G, G, k, -(k // 2),
+                        bias=self.p('up0.conv_up.0.conv3d.bias'), act=ops.ACT_LRELU)
+        up2 = 'up0.conv_up.%d.conv3d' % (2 if s > 1 else 1)
+        if s > 1:
+            Weff = ops.polyphase_weights(self.p(up2 + '.weight'), self.Lt(dev), s, self.kl)
+            u0 = ops.conv3d(z1, Weff, s ** 3 * C, B, G, G, self.kl, -self.R, bias=self.p(up2 + '.bias').repeat(s ** 3),
+                            act=ops.ACT_LRELU, d2s=(s, C))
+        else:
+            Weff = None
+            u0 = ops.conv3d(z1, ops.conv_weight_fwd(self.p(up2 + '.weight')), C, B, G, G, k, -(k // 2),
+                            bias=self.p(up2 + '.bias'), act=ops.ACT_LRELU)
+        # final conv over cat([d0, u0]) without the cat (perceiver :462)
+        u = ops.conv3d(d0, ops.conv_weight_fwd(self.p('final.conv3d.weight')), C, B, V, V, 3, -1,
+                       bias=self.p('final.conv3d.bias'), act=ops.ACT_LRELU, src1=u0)
+        # translation head (perceiver :465) and pooled features (:470)
+        q_trans = ops.conv3_c1_fwd(u, self.p('trans_decoder.conv3d.weight'), self.p('trans_decoder.conv3d.bias'), B, V)
+        ss2 = ops.ss3d_max_fwd(u, V ** 3 * C, B, V, C)
+        feats = torch.cat([ss0[0], ss0[1], ss1[0], ss1[1], ss2[0], ss2[1]], dim=1)
+        h0 = ops.linear(feats, self.p('dense0.linear.weight'), self.p('dense0.linear.bias'), ops.ACT_LRELU)
+        h1 = ops.linear(h0, self.p('dense1.linear.weight'), self.p('dense1.linear.bias'), ops.ACT_LRELU)
+        o = ops.linear(h1, self.p('rot_grip_collision_ff.linear.weight'), self.p('rot_grip_collision_ff.linear.bias'))
+        nc = m.num_collision_classes
+        outs = (q_trans.view(B, 1, V, V, V), o[:, :-nc], o[:, -nc:])
+        h2 = None
+        if m.arm_pred_loss:
+            h2 = ops.linear(feats, self.p('dense2.linear.weight'), self.p('dense2.linear.bias'), ops.ACT_LRELU)
+            outs = outs + (ops.linear(h2, self.p('arm_ff.linear.weight'), self.p('arm_ff.linear.bias')),)
+        if save:
+            c.update(B=B, vox=vox, proprio=proprio, lang=lang, d0=d0, ss0=ss0, patch=patch, pp=pp, ctx2d=ctx2d,
+                     dec=dict(qn=qn, qm=qm, qr=qr, ln=ln, lm=lm, lr=lr, x=x, attn=da), z=z, ss1=ss1, zc=zc, z1=z1,
+                     Weff=Weff, u0=u0, u=u, ss2=ss2, feats=feats, h0=h0, h1=h1, h2=h2, o=o)
+        return outs, (c if save else None)
+
+    # -------------------------------------------------------------------------------------------------- backward
+    def backward(self, c, dq_trans, d_o, d_arm=None):
+        """dq_trans [B,V,V,V] (or [B,1,V,V,V]), d_o [B, 3*rot+grip+coll] (grad of the concatenated MLP head output),
+        d_arm [B,2] or None.  Accumulates into every parameter's .grad."""
+        m = self.m
+        B = c['B']
+        V, G, C, Cx, D, L, T0, k, s = self.V, self.G, self.C, self.Cx, self.D, self.L, self.T0, self.k, self.s
+        T1 = G ** 3
+        Nctx = T0 + T1
+        dev = dq_trans.device
+        dq_trans = dq_trans.contiguous().view(B, V, V, V)
+
+        def E(*shape):
+            return torch.empty(shape, dtype=torch.float32, device=dev)
+
+        # ---- MLP heads (perceiver :472-483)
+        dh1 = E(B, c['h1'].shape[1])
+        ops.linear_bwd(c['h1'], self.p('rot_grip_collision_ff.linear.weight'), d_o.contiguous(),
+                       self.g('rot_grip_collision_ff.linear.weight'), self.g('rot_grip_collision_ff.linear.bias'), dh1)
+        ops.lrelu_bwd_(dh1, c['h1'])
+        dh0 = E(B, 256)
+        ops.linear_bwd(c['h0'], self.p('dense1.linear.weight'), dh1, self.g('dense1.linear.weight'), self.g('dense1.linear.bias'), dh0)
+        ops.lrelu_bwd_(dh0, c['h0'])
+        dfe = E(B, c['feats'].shape[1])
+        ops.linear_bwd(c['feats'], self.p('dense0.linear.weight'), dh0, self.g('dense0.linear.weight'), self.g('dense0.linear.bias'), dfe)
+        if m.arm_pred_loss and d_arm is not None:
+            dh2 = E(B, C)
+            ops.linear_bwd(c['h2'], self.p('arm_ff.linear.weight'), d_arm.contiguous(), self.g('arm_ff.linear.weight'),
+                           self.g('arm_ff.linear.bias'), dh2)
+            ops.lrelu_bwd_(dh2, c['h2'])
+            ops.linear_bwd(c['feats'], self.p('dense2.linear.weight'), dh2, self.g('dense2.linear.weight'),
+                           self.g('dense2.linear.bias'), dfe, dx_accumulate=True)
+        o0 = 0
+        gs = []
+        for width in (3 * C, C, 3 * Cx, Cx, 3 * C, C):
+            gs.append(dfe[:, o0:o0 + width].contiguous())
+            o0 += width
+        # ---- u: ss_final/max + trans_decoder
+        u, d0, u0 = c['u'], c['d0'], c['u0']
+        du = E(B, V, V, V, C)
+        ss, mx, st, am = c['ss2']
+        ops.ss3d_max_bwd(u, V ** 3 * C, B, V, C, st, ss, am, gs[4], gs[5], du, V ** 3 * C)
+        wt = self.p('trans_decoder.conv3d.weight')
+        ops.conv3_c1_wgrad(u, dq_trans, self.g('trans_decoder.conv3d.weight'), self.g('trans_decoder.conv3d.bias'), B, V)
+        ops.conv3_c1_dgrad(dq_trans, wt, u, du, B, V, accumulate=True, mask=True)      # du is now d(pre-activation of `final`)
+        # ---- final conv (two sources)
+        Wf = self.p('final.conv3d.weight')
+        dWt = ops.conv3d_wgrad(d0, du, C, B, V, V, 3, -1, src1=u0)
+        self.g('final.conv3d.weight').add_(dWt.view(27, 2 * C, C).permute(2, 1, 0).reshape(Wf.shape))
+        ops.colsum(du.view(-1, C), self.g('final.conv3d.bias'), accumulate=True)
+        dcat = ops.conv3d(du, ops.conv_weight_dgrad(Wf), 2 * C, B, V, V + 2, 3, -2, replicate=False)
+        del du
+        dd0 = E(B, V, V, V, C)
+        ss, mx, st, am = c['ss0']
+        ops.ss3d_max_bwd(d0, V ** 3 * C, B, V, C, st, ss, am, gs[0], gs[1], dd0, V ** 3 * C)
+        ops.fold_pad(dcat, V + 2, 2 * C, 0, dd0, B, V, C, 1, accumulate=True)
+        du0 = E(B, V, V, V, C)
+        ops.fold_pad(dcat, V + 2, 2 * C, C, du0, B, V, C, 1, lrelu_of=u0)             # d(pre-activation of up0's last conv)
+        del dcat
+        # ---- up0: second conv (polyphase) -> first conv
+        z1, zc = c['z1'], c['zc']
+        up2 = 'up0.conv_up.%d.conv3d' % (2 if s > 1 else 1)
+        W2 = self.p(up2 + '.weight')
+        ops.colsum(du0.view(-1, C), self.g(up2 + '.bias'), accumulate=True)
+        dz1 = E(B, G, G, G, C)
+        if s > 1:
+            kl, R = self.kl, self.R
+            dWeff = ops.conv3d_wgrad(z1, du0, s ** 3 * C, B, G, G, kl, -R, d2s=(s, C))
+            ops.polyphase_weights_bwd(dWeff, self.Lt(dev), self.g(up2 + '.weight'), s, kl)
+            wd = ops.polyphase_dgrad_weights(c['Weff'], C, C, s, kl)
+            Sp = G + 2 * R
+            dzp = ops.conv3d(du0, wd, C, B, V, Sp, s * kl, -s * (kl - 1), stride=s, replicate=False)
+            ops.fold_pad(dzp, Sp, C, 0, dz1, B, G, C, R, lrelu_of=z1)
+        else:
+            dWt = ops.conv3d_wgrad(z1, du0, C, B, G, G, k, -(k // 2))
+            self.g(up2 + '.weight').add_(dWt.view(k ** 3, C, C).permute(2, 1, 0).reshape(W2.shape))
+            dzp = ops.conv3d(du0, ops.conv_weight_dgrad(W2), C, B, G, G + 2 * (k // 2), k, -(k - 1), replicate=False)
+            ops.fold_pad(dzp, G + 2 * (k // 2), C, 0, dz1, B, G, C, k // 2, lrelu_of=z1)
+        del du0, dzp
+        W1 = self.p('up0.conv_up.0.conv3d.weight')
+        dWt = ops.conv3d_wgrad(zc, dz1, C, B, G, G, k, -(k // 2))
+        self.g('up0.conv_up.0.conv3d.weight').add_(dWt.view(k ** 3, Cx, C).permute(2, 1, 0).reshape(W1.shape))
+        ops.colsum(dz1.view(-1, C), self.g('up0.conv_up.0.conv3d.bias'), accumulate=True)
+        pk = k // 2
+        dzp = ops.conv3d(dz1, ops.conv_weight_dgrad(W1), Cx, B, G, G + 2 * pk, k, -(k - 1), replicate=False)
+        dzv = E(B, T1, Cx)
+        ss, mx, st, am = c['ss1']
+        ops.ss3d_max_bwd(c['z'][:, T0:], Nctx * Cx, B, G, Cx, st, ss, am, gs[2], gs[3], dzv, T1 * Cx)
+        ops.fold_pad(dzp, G + 2 * pk, Cx, 0, dzv, B, G, Cx, pk, accumulate=True)
+        dz = torch.zeros((B, Nctx, Cx), dtype=torch.float32, device=dev)
+        dz[:, T0:] = dzv
+        # ---- decoder cross attention
+        dc = c['dec']
+        pre = 'decoder_cross_attn'
+        dqn, dln = self._attn_bwd(pre, dc['attn'], dz.view(B * Nctx, Cx), dc['qn'], dc['ln'], False)
+        dctx = ops.layernorm_bwd(dqn, c['ctx2d'], self.p(pre + '.norm.weight'), dc['qm'], dc['qr'], self.g(pre + '.norm.weight'),
+                                 self.g(pre + '.norm.bias'))
+        dx = ops.layernorm_bwd(dln, dc['x'], self.p(pre + '.norm_context.weight'), dc['lm'], dc['lr'],
+                               self.g(pre + '.norm_context.weight'), self.g(pre + '.norm_context.bias'))
+        # ---- self-attention stack, reversed
+        for i in reversed(range(m.depth)):
+            lc = c['layers'][i]
+            dx = self._ff_bwd('layers.%d.1' % i, lc['ff'], dx)
+            pre = 'layers.%d.0' % i
+            dxn, _ = self._attn_bwd(pre, lc['attn'], dx, lc['xn'], lc['xn'], True)
+            ops.layernorm_bwd(dxn, lc['x'], self.p(pre + '.norm.weight'), lc['xm'], lc['xr'], self.g(pre + '.norm.weight'),
+                              self.g(pre + '.norm.bias'), dx=dx, accumulate_dx=True)
+        # ---- cross-attention block
+        dx = self._ff_bwd('cross_attend_blocks.1', c['cross_ff'], dx)
+        cc = c['cross']
+        pre = 'cross_attend_blocks.0'
+        dxn, dcn = self._attn_bwd(pre, cc['attn'], dx, cc['xn'], cc['cn'], False)
+        ops.layernorm_bwd(dxn, cc['x'], self.p(pre + '.norm.weight'), cc['xm'], cc['xr'], self.g(pre + '.norm.weight'),
+                          self.g(pre + '.norm.bias'), dx=dx, accumulate_dx=True)
+        ops.layernorm_bwd(dcn, c['ctx2d'], self.p(pre + '.norm_context.weight'), cc['cm'], cc['cr'],
+                          self.g(pre + '.norm_context.weight'), self.g(pre + '.norm_context.bias'), dx=dctx, accumulate_dx=True)
+        ops.sum_splits(dx, B, L * D, self.g('latents'), accumulate=True)
+        # ---- context assembly, language, proprio
+        dlang, dpatch, dpp = ops.ctx_bwd(dctx, self.g('pos_encoding'), B, T0, T1, C)
+        ops.linear_bwd(c['lang'], self.p('lang_preprocess.weight'), dlang, self.g('lang_preprocess.weight'),
+                       self.g('lang_preprocess.bias'))
+        ops.lrelu_bwd_(dpp, c['pp'])
+        ops.linear_bwd(c['proprio'], self.p('proprio_preprocess.linear.weight'), dpp, self.g('proprio_preprocess.linear.weight'),
+                       self.g('proprio_preprocess.linear.bias'))
+        # ---- patchify
+        ops.lrelu_bwd_(dpatch, c['patch'])
+        Wp = self.p('patchify.conv3d.weight')
+        dWt = ops.conv3d_wgrad(d0, dpatch, C, B, V, G, k, -pk, stride=s)
+        self.g('patchify.conv3d.weight').add_(dWt.view(k ** 3, C, C).permute(2, 1, 0).reshape(Wp.shape))
+        ops.colsum(dpatch, self.g('patchify.conv3d.bias'), accumulate=True)
+        if s > 1:
+            wtp, U = ops.strided_dgrad_weights(Wp, s)
+            Gp = (V + 2 * pk + s - 1) // s
+            dxp = ops.conv3d(dpatch, wtp, s ** 3 * C, B, G, Gp, U, -(U - 1), replicate=False, d2s=(s, C))
+            ops.fold_pad(dxp, Gp * s, C, 0, dd0, B, V, C, pk, accumulate=True)
+        else:
+            dxp = ops.conv3d(dpatch, ops.conv_weight_dgrad(Wp), C, B, G, V + 2 * pk, k, -(k - 1), replicate=False)
+            ops.fold_pad(dxp, V + 2 * pk, C, 0, dd0, B, V, C, pk, accumulate=True)
+        # ---- input conv (its LeakyReLU' is applied inside the weight-gradient kernel)
+        ops.pointwise_wgrad(c['vox'], d0, dd0, self.g('input_preprocess.conv3d.weight').view(C, -1),
+                            self.g('input_preprocess.conv3d.bias'))

@@ -43,8 +43,9 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None):
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
     if _small(M, N, K):
-        assert residual is None
         naive_gemm(x, W, out, M, N, K, x.stride(0), 1, 1, W.stride(0), out.stride(0), bias, act)
+        if residual is not None:
+            axpy_(out, residual)
     else:
         gemm(x, W, out, M, N, K, x.stride(0), 1, 1, W.stride(0), out.stride(0), bias=bias, residual=residual, act=act)
     return out
