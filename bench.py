@@ -1,0 +1,179 @@
+#!/usr/bin/env python
+"""bench.py -- voxel-policy train steps/s at BASELINE.json config 2 (100^3 grid, 4 cams 128x128, B=16 per GPU).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = QAttentionPerActBCAgent.update() through the agent stack (PreprocessAgent -> QAttentionStackAgent ->
+QAttentionPerActBCAgent): SE(3) augmentation, voxelize, Q-network forward, 6 CE losses, backward, gradient
+all-reduce (RCCL, N > 1), fused LAMB, and the runner's `.item()` on the loss (offline_train_runner.py:94) -- on a
+synthetic replay batch that is already resident in HBM.  Weak scaling: every rank owns its own B=16 shard
+(task_uniform_replay_buffer.py:103-108 semantics), the only exchange is the gradient all-reduce.
+
+Rank 0 prints ONE JSON line (metric/value/... + `roofline` for the dominant kernel + `cpu_baseline`).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
+PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured achievable)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--voxel-size', type=int, default=100)
+    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--image', type=int, default=128)
+    ap.add_argument('--depth', type=int, default=6)
+    ap.add_argument('--latents', type=int, default=2048)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-voxel-size', type=int, default=0, help='debug: smaller grid for the CPU baseline leg')
+    ap.add_argument('--kernel-table', action='store_true', help='print the per-kernel timing table to stderr')
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)      # backend "nccl" == RCCL on ROCm
+    assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % a.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    from voxactb_amd import _lib, synthetic
+    from voxactb_amd.agents.peract_bc import launch_utils as lu
+
+    V, B, HW = a.voxel_size, a.batch, a.image
+    patch = 5 if V % 5 == 0 else 4
+    cfg = lu.default_cfg(method__voxel_sizes=[V], method__voxel_patch_size=5, method__voxel_patch_stride=patch,
+                         method__transformer_depth=a.depth, method__num_latents=a.latents, replay__batch_size=B,
+                         rlbench__camera_resolution=[HW, HW], ddp__num_devices=world)
+    torch.manual_seed(1234)           # identical initial weights on every rank (DDP broadcasts rank 0's upstream)
+    agent = lu.create_agent(cfg)
+    agent.build(training=True, device=local_rank)
+    n_params = sum(p.numel() for p in agent._pose_agent._qattention_agents[0]._q.parameters())
+    batches = [{k: v.to(dev) for k, v in synthetic.make_replay_sample(
+        B, cfg.rlbench.cameras, (HW, HW), V, 4, seed=100 * rank + j).items()} for j in range(2)]
+
+    def step(i):
+        out = agent.update(i, batches[i % 2])
+        return float(out['total_losses'])          # the runner's .item() (device sync every step)
+
+    torch.manual_seed(1000 + rank)    # augmentation draws differ per rank, as they would with per-rank replay shards
+    for i in range(a.warmup):
+        step(i)
+    timer = _lib.KernelTimer()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    _lib.TIMER = timer
+    t0 = time.perf_counter()
+    loss = None
+    for i in range(a.steps):
+        loss = step(a.warmup + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.TIMER = None
+    tt = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt[0])
+    agg = timer.summary()
+
+    if rank == 0:
+        ms_per_step = dt / a.steps * 1e3
+        value = world * a.steps / dt
+        # dominant kernel group = largest share of device time
+        tot_ms = sum(d['ms'] for d in agg.values())
+        dom_label, dom = max(agg.items(), key=lambda kv: kv[1]['ms'])
+        groups = {}
+        for label, d in agg.items():
+            key = 'conv3d (all implicit-GEMM launches)' if label.startswith('conv3d') else \
+                  ('gemm (linear layers)' if label == 'gemm' else label)
+            gd = groups.setdefault(key, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+            for f in ('calls', 'ms', 'flops', 'bytes'):
+                gd[f] += d[f]
+        dom_key, domg = max(groups.items(), key=lambda kv: kv[1]['ms'])
+        roofline = {'kernel': dom_key, 'bound': 'mfma', 'achieved': domg['flops'] / (domg['ms'] * 1e-3) / 1e12,
+                    'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'traffic': None,
+                    'launches': domg['calls'], 'avg_launch_ms': domg['ms'] / max(domg['calls'], 1),
+                    'share_of_device_time': domg['ms'] / tot_ms}
+        roofline['frac'] = roofline['achieved'] / roofline['peak']
+        extra = {}
+        if 'voxelize' in agg:
+            v = agg['voxelize']
+            gbps = v['bytes'] / (v['ms'] * 1e-3) / 1e9
+            extra['voxel_scatter'] = {'bound': 'hbm', 'achieved': gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+                                      'frac': gbps / PEAK_HBM_GBPS, 'avg_launch_ms': v['ms'] / v['calls'], 'traffic': None}
+        if 'attn_core' in agg:
+            v = agg['attn_core']
+            tf = v['flops'] / (v['ms'] * 1e-3) / 1e12
+            extra['attention_qk_pv'] = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                        'frac': tf / PEAK_FP32_MFMA_TFLOPS, 'dtype': 'f32', 'share_of_device_time': v['ms'] / tot_ms}
+        if a.kernel_table:
+            for label, d in sorted(agg.items(), key=lambda kv: -kv[1]['ms']):
+                sys.stderr.write('%-44s calls %5d  %9.2f ms/step  %7.2f TF/s\n' % (
+                    label, d['calls'] // a.steps, d['ms'] / a.steps, d['flops'] / max(d['ms'], 1e-9) / 1e9))
+        cpu = None
+        if not a.no_cpu_baseline:
+            cpu = cpu_baseline(a, cfg)
+        out = {
+            'metric': 'voxel-policy train steps/sec (100^3 grid, 4 cams, B=16)', 'value': value, 'unit': 'steps/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE.json configs[1]: QAttentionPerActBCAgent.update(), V=%d, %d cams %dx%d, '
+                                   'B=%d per GPU, PerceiverIO depth %d, %d latents, SE(3) aug + dropout on, LAMB'
+                                   % (V, len(cfg.rlbench.cameras), HW, HW, B, a.depth, a.latents),
+                       'global_batch': B * world, 'parallelism': 'dp%d' % world, 'params': n_params},
+            'samples_per_s': value * B, 'final_loss': loss, 'device_time_ms_per_step': tot_ms / a.steps,
+            'roofline': roofline, 'rooflines_other': extra, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, cfg):
+    """The oracle (CPU restatement of the reference path, kind 'port') timed on this host: ONE sample (B=1) of the same
+    workload through voxelize + forward + losses + backward + LAMB; a B=16 step is 16x that."""
+    import torch
+    from oracle import agent as oagent, perceiver as operc, weights as ow
+    from voxactb_amd import synthetic
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    V = a.cpu_voxel_size or a.voxel_size
+    s = 5 if V % 5 == 0 else 4
+    shapes = operc.param_shapes(a.depth, V, 4, num_latents=a.latents, voxel_patch_size=5, voxel_patch_stride=s)
+    P = ow.hashed_state_dict(shapes, 0)
+    rs = synthetic.make_replay_sample(1, cfg.rlbench.cameras, (a.image, a.image), V, 4, seed=7)
+    r = {k: (v[:, 0] if v.dim() > 2 else v) for k, v in rs.items()}
+    r = {k: ((v.float() / 255.0) * 2.0 - 1.0 if 'rgb' in k else v.float()) for k, v in r.items()}
+    bt = dict(pcd=[r['%s_point_cloud' % c] for c in cfg.rlbench.cameras], rgb=[r['%s_rgb' % c] for c in cfg.rlbench.cameras],
+              proprio=r['low_dim_state'], lang_token_embs=r['lang_token_embs'], bounds=torch.tensor([synthetic.SCENE_BOUNDS]),
+              trans=r['trans_action_indicies'], rot_grip=r['rot_grip_action_indicies'], ignore_collisions=r['ignore_collisions'])
+    t0 = time.perf_counter()
+    oagent.train_steps(P, [bt], V, 1, depth=a.depth, voxel_patch_stride=s)
+    dt = time.perf_counter() - t0
+    return {'value': 1.0 / (dt * a.batch), 'unit': 'steps/s', 'cores': ncores, 'kind': 'port',
+            'sample': 'one replay sample (B=1) of the same workload through the CPU oracle (voxelize + fwd + 6 CE + bwd + LAMB) '
+                      'took %.1f s; a B=%d step is %dx that' % (dt, a.batch, a.batch), 'seconds_per_sample': dt}
+
+
+if __name__ == '__main__':
+    main()

@@ -70,8 +70,51 @@ def check(rc, what):
         raise VoxactbHipError('%s failed: %s (code %d)' % (what, _ERR.get(rc, 'unknown'), rc))
 
 
+class KernelTimer:
+    """Optional per-entry-point timing with HIP events recorded on the launching stream (bench.py uses it to price
+    the dominant kernel against its roofline).  `meta` = (label, flops, bytes) supplied by the ops wrappers."""
+
+    def __init__(self):
+        self.records = []          # (label, name, start_event, stop_event, flops, bytes)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for label, name, e0, e1, fl, by in self.records:
+            d = agg.setdefault(label, dict(entry=name, calls=0, ms=0.0, flops=0.0, bytes=0.0))
+            d['calls'] += 1
+            d['ms'] += e0.elapsed_time(e1)
+            d['flops'] += fl
+            d['bytes'] += by
+        return agg
+
+
+TIMER = None          # set to a KernelTimer to enable
+_META = None
+
+
+def set_meta(label, flops=0.0, nbytes=0.0):
+    global _META
+    _META = (label, float(flops), float(nbytes))
+
+
 def call(name, *args):
     """Call a C-ABI entry point; tensors are passed as device pointers, None as NULL; the current stream is appended."""
+    global _META
+    meta, _META = _META, None
+    if TIMER is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _call(name, *args)
+        e1.record()
+        label, fl, by = meta if meta is not None else (name, 0.0, 0.0)
+        TIMER.records.append((label, name, e0, e1, fl, by))
+        return
+    _call(name, *args)
+
+
+def _call(name, *args):
     conv = []
     for a in args:
         if torch.is_tensor(a):

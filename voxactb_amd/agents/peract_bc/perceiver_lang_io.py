@@ -287,11 +287,11 @@ class PerceiverEngine:
         ld = _r4(Nk)
         S = torch.empty((B * H, Nq, ld), dtype=torch.float32, device=xq.device)
         ops.gemm(q, kv, S, Nq, Nk, d, inner, 1, 1, 2 * inner, ld, batch=B * H, H=H, bA=(Nq * inner, d),
-                 bB=(Nk * 2 * inner, d), bC=(H * Nq * ld, Nq * ld), alpha=d ** -0.5)
+                 bB=(Nk * 2 * inner, d), bC=(H * Nq * ld, Nq * ld), alpha=d ** -0.5, label='attn_core')
         Pd = ops.softmax_rows(S, B * H * Nq, Nk, ld, p, seed)
         O = torch.empty((B * Nq, inner), dtype=torch.float32, device=xq.device)
         ops.gemm(Pd, kv[:, inner:], O, Nq, d, Nk, ld, 1, 2 * inner, 1, inner, batch=B * H, H=H,
-                 bA=(H * Nq * ld, Nq * ld), bB=(Nk * 2 * inner, d), bC=(Nq * inner, d))
+                 bA=(H * Nq * ld, Nq * ld), bB=(Nk * 2 * inner, d), bC=(Nq * inner, d), label='attn_core')
         out = ops.linear(O, Wo, bo, residual=residual)
         cache = dict(q=q, kv=kv, P=S, Pd=Pd, O=O, dims=(B, Nq, Nk, H, d, ld), p=p, seed=seed) if save else None
         return out, cache
@@ -308,17 +308,17 @@ class PerceiverEngine:
         dkv = torch.empty_like(kv)
         # dV[j,:] = sum_i Pd[i,j] dO[i,:]
         ops.gemm(Pd, dO, dkv[:, inner:], Nk, d, Nq, 1, ld, inner, 1, 2 * inner, batch=B * H, H=H,
-                 bA=(H * Nq * ld, Nq * ld), bB=(Nq * inner, d), bC=(Nk * 2 * inner, d))
+                 bA=(H * Nq * ld, Nq * ld), bB=(Nq * inner, d), bC=(Nk * 2 * inner, d), label='attn_core')
         # dPd[i,j] = sum_d dO[i,d] V[j,d]
         dP = Pd if c['p'] > 0 else torch.empty_like(P)
         ops.gemm(dO, kv[:, inner:], dP, Nq, Nk, d, inner, 1, 1, 2 * inner, ld, batch=B * H, H=H, bA=(Nq * inner, d),
-                 bB=(Nk * 2 * inner, d), bC=(H * Nq * ld, Nq * ld))
+                 bB=(Nk * 2 * inner, d), bC=(H * Nq * ld, Nq * ld), label='attn_core')
         dS = ops.softmax_bwd_rows(P, dP, B * H * Nq, Nk, ld, d ** -0.5, c['p'], c['seed'])
         dq = torch.empty_like(q)
         ops.gemm(dS, kv, dq, Nq, d, Nk, ld, 1, 2 * inner, 1, inner, batch=B * H, H=H, bA=(H * Nq * ld, Nq * ld),
-                 bB=(Nk * 2 * inner, d), bC=(Nq * inner, d))
+                 bB=(Nk * 2 * inner, d), bC=(Nq * inner, d), label='attn_core')
         ops.gemm(dS, q, dkv, Nk, d, Nq, 1, ld, inner, 1, 2 * inner, batch=B * H, H=H, bA=(H * Nq * ld, Nq * ld),
-                 bB=(Nq * inner, d), bC=(Nk * 2 * inner, d))
+                 bB=(Nq * inner, d), bC=(Nk * 2 * inner, d), label='attn_core')
         dxq = torch.empty_like(xq2d)
         ops.linear_bwd(xq2d, Wq, dq, self.g(pre + '.fn.to_q.weight'), None, dxq)
         if same_src:

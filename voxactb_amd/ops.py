@@ -21,8 +21,9 @@ def _f32c(*ts):
 
 
 def gemm(A, B, C, M, N, K, sAm, sAk, sBk, sBn, ldc, bias=None, residual=None, batch=1, H=1,
-         bA=(0, 0), bB=(0, 0), bC=(0, 0), alpha=1.0, act=ACT_NONE, accumulate=False):
+         bA=(0, 0), bB=(0, 0), bC=(0, 0), alpha=1.0, act=ACT_NONE, accumulate=False, label=None):
     _f32c(A, B, C, bias, residual)
+    _lib.set_meta(label or 'gemm', 2.0 * M * N * K * batch)
     call('vxb_gemm_f32', A, B, C, bias, residual, M, N, K, sAm, sAk, sBk, sBn, ldc, batch, H,
          bA[0], bA[1], bB[0], bB[1], bC[0], bC[1], float(alpha), act, LRELU_SLOPE, int(accumulate))
 
@@ -146,7 +147,7 @@ def conv_weight_dgrad(W):
 
 
 def conv3d(src0, wt, N, B, S_in, S_out, kext, off, stride=1, replicate=True, bias=None, act=ACT_NONE, src1=None,
-           out=None, ldc=None, accumulate=False, d2s=(0, 0)):
+           out=None, ldc=None, accumulate=False, d2s=(0, 0), label=None):
     C0 = src0.shape[-1]
     C1 = src1.shape[-1] if src1 is not None else 0
     if out is None:
@@ -156,13 +157,15 @@ def conv3d(src0, wt, N, B, S_in, S_out, kext, off, stride=1, replicate=True, bia
         else:
             out = torch.empty((B, S_out, S_out, S_out, N), dtype=torch.float32, device=src0.device)
     _f32c(src0, src1, wt, bias, out)
+    _lib.set_meta(label or 'conv3d[k%d s%d %d->%d S%d%s]' % (kext, stride, C0 + C1, N, S_out, '' if replicate else ' dgrad'),
+                  2.0 * B * S_out ** 3 * N * kext ** 3 * (C0 + C1))
     call('vxb_conv3d_f32', src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, int(replicate), wt, N, bias, out,
          ldc if ldc is not None else N, act, LRELU_SLOPE, int(accumulate), d2s[0], d2s[1])
     return out
 
 
 def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=True, src1=None, ldy=None, d2s=(0, 0),
-                 nsplit=None):
+                 nsplit=None, label=None):
     """returns dWt [(tap, ci)][N] (fp32, deterministic split reduction)."""
     C0 = src0.shape[-1]
     C1 = src1.shape[-1] if src1 is not None else 0
@@ -172,6 +175,7 @@ def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
         tiles = ((K + 127) // 128) * ((N + 127) // 128 if N > 64 else 1)
         nsplit = max(1, min(64, 1024 // max(tiles, 1), (P + 4095) // 4096))
     part = torch.empty((nsplit, K, N), dtype=torch.float32, device=src0.device)
+    _lib.set_meta(label or 'conv3d_wgrad[k%d s%d %d->%d S%d]' % (kext, stride, C0 + C1, N, S_out), 2.0 * P * N * K)
     call('vxb_conv3d_wgrad_f32', src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, int(replicate), dy, N,
          ldy if ldy is not None else N, d2s[0], d2s[1], part, nsplit)
     if nsplit == 1:

@@ -70,9 +70,18 @@ class VoxelGrid(nn.Module):
         ws = self._workspace(B, n_src * pps, device)
         cp = (ctypes.c_void_p * n_src)(*coord_ptrs)
         fp = (ctypes.c_void_p * n_src)(*feat_ptrs) if F > 0 else None
+        timer = _lib.TIMER
+        if timer is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         rc = _lib.lib().vxb_voxelize_f32(cp, fp, n_src, B, pps, F, cs[0], cs[1], cs[2], fs[0], fs[1], fs[2],
                                          _lib.ptr(bounds), bounds.shape[0], V, _lib.ptr(out), _lib.ptr(ws),
                                          ws.numel() * 4, _lib.stream_ptr(device))
+        if timer is not None:
+            e1.record()
+            # algorithmic bytes: read N*(3+F)*4 per sample, write V^3*(3+F+4)*4 per sample
+            nbytes = B * (n_src * pps * (3 + F) * 4 + V ** 3 * (3 + F + 4) * 4)
+            timer.records.append(('voxelize', 'vxb_voxelize_f32', e0, e1, 0.0, float(nbytes)))
         if rc != 0:
             ws.zero_()   # restore the "table is zero" invariant after a failed call
         _lib.check(rc, 'vxb_voxelize_f32')
