@@ -123,12 +123,23 @@ __global__ void __launch_bounds__(256) sum_splits_kernel(const float* __restrict
 // column sums, stage 1: part[blk][N] over a slab of rows
 __global__ void __launch_bounds__(256) colsum_part_kernel(const float* __restrict__ x, long long rows, int N, long long ld,
                                                           int rows_per_block, float* __restrict__ part) {
+    // 64 column lanes x 4 row lanes: a wave reads 256 contiguous bytes of one row
+    __shared__ float red[256];
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = min(rows, r0 + rows_per_block);
-    for (int c = threadIdx.x; c < N; c += 256) {
-        float s = 0.f;
-        for (long long r = r0; r < r1; ++r) s += x[r * ld + c];
-        part[(long long)blockIdx.x * N + c] = s;
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < N; c0 += 64) {
+        const int c = c0 + cl;
+        float s0 = 0.f, s1 = 0.f;
+        if (c < N) {
+            long long r = r0 + rl;
+            for (; r + 4 < r1; r += 8) { s0 += x[r * ld + c]; s1 += x[(r + 4) * ld + c]; }
+            for (; r < r1; r += 4) s0 += x[r * ld + c];
+        }
+        red[threadIdx.x] = s0 + s1;
+        __syncthreads();
+        if (rl == 0 && c < N) part[(long long)blockIdx.x * N + c] = red[cl] + red[64 + cl] + red[128 + cl] + red[192 + cl];
+        __syncthreads();
     }
 }
 

@@ -48,7 +48,8 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None):
         if residual is not None:
             axpy_(out, residual)
     else:
-        gemm(x, W, out, M, N, K, x.stride(0), 1, 1, W.stride(0), out.stride(0), bias=bias, residual=residual, act=act)
+        gemm(x, W, out, M, N, K, x.stride(0), 1, 1, W.stride(0), out.stride(0), bias=bias, residual=residual, act=act,
+             label='gemm_fwd %dx%dx%d' % (M, N, K))
     return out
 
 
@@ -61,9 +62,24 @@ def linear_bwd(x, W, dy, dW, db=None, dx=None, dx_accumulate=False, ws=None):
         if dx is not None:
             naive_gemm(dy, W, dx, M, K, N, dy.stride(0), 1, W.stride(0), 1, dx.stride(0), accumulate=dx_accumulate)
     else:
-        gemm(dy, x, dW, N, K, M, 1, dy.stride(0), x.stride(0), 1, dW.stride(0), accumulate=True)
+        # dW = dy^T x reduces over M rows: few output tiles, so split the reduction across workgroups (batch = split)
+        tiles = ((N + 127) // 128) * ((K + 127) // 128 if K > 64 else 1)
+        ns = 1
+        if tiles < 512 and dW.is_contiguous():
+            cands = [d for d in range(1, 65) if M % d == 0 and (M // d) >= 256]
+            ok = [d for d in cands if tiles * d >= 512]
+            ns = min(ok) if ok else (max(cands) if cands else 1)
+        if ns > 1:
+            rc = M // ns
+            part = torch.empty((ns, N, K), dtype=torch.float32, device=x.device)
+            gemm(dy, x, part, N, K, rc, 1, dy.stride(0), x.stride(0), 1, K, batch=ns, H=1, bA=(rc * dy.stride(0), 0),
+                 bB=(rc * x.stride(0), 0), bC=(N * K, 0), label='gemm_wgrad %dx%dx%d' % (N, K, M))
+            sum_splits(part, ns, N * K, dW, accumulate=True)
+        else:
+            gemm(dy, x, dW, N, K, M, 1, dy.stride(0), x.stride(0), 1, dW.stride(0), accumulate=True, label='gemm_wgrad %dx%dx%d' % (N, K, M))
         if dx is not None:
-            gemm(dy, W, dx, M, K, N, dy.stride(0), 1, W.stride(0), 1, dx.stride(0), accumulate=dx_accumulate)
+            gemm(dy, W, dx, M, K, N, dy.stride(0), 1, W.stride(0), 1, dx.stride(0), accumulate=dx_accumulate,
+                 label='gemm_dgrad %dx%dx%d' % (M, K, N))
     if db is not None:
         colsum(dy, db, accumulate=True)
 
