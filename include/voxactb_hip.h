@@ -84,6 +84,20 @@ int vxb_conv3d_wgrad_f32(const float* src0, const float* src1, int C0, int C1, i
  * positions i that clamp to j; optionally times LeakyReLU'(lrelu_of[b,j,c]) (the producer's activation). */
 int vxb_fold_pad_f32(const float* src, int Sp, int Cs, int c0, float* dst, const float* lrelu_of, int B, int S,
                      int C, int pad, int accumulate, float slope, vxb_stream_t stream);
+/* bf16 matrix-core twins ("throughput mode", v_mfma_f32_32x32x16_bf16, fp32 accumulate): the fp32 A operand is rounded
+ * to bf16 (RNE) while it is staged into LDS; weights come as bf16 [N][K] (K contiguous, K % 8 == 0; C0, C1 % 32 == 0). */
+int vxb_gemm_bf16w_f32(const float* A, int64_t lda, const void* Bw, float* C, int64_t ldc, const float* bias,
+                       const float* residual, int M, int N, int K, int act, float slope, int accumulate,
+                       vxb_stream_t stream);
+int vxb_conv3d_bf16w_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
+                         int stride, int kext, int off, int replicate, const void* wt_bf16, int N,
+                         const float* bias, float* out, int64_t ldc, int act, float slope, int accumulate,
+                         int d2s_s, int d2s_C, vxb_stream_t stream);
+/* bf16 matrix-core weight gradient (same contract as vxb_conv3d_wgrad_f32): both operands are staged position-major and
+ * transposed for the matrix cores by ds_read_b64_tr_b16. */
+int vxb_conv3d_wgrad_bf16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
+                              int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
+                              int d2s_s, int d2s_C, float* part, int nsplit, vxb_stream_t stream);
 /* Polyphase form of Upsample(x s, trilinear, align_corners=False) followed by Conv3d(k) (network_utils.py:245-250):
  * Weff[(j3*Cin+ci)][(r3*Cout+co)] = sum_t W[co][ci][t] * L[r][t][j] per axis; and its adjoint (dW ACCUMULATED). */
 int vxb_polyphase_weights_f32(const float* W, const float* L, float* Weff, int Cin, int Cout, int k, int s, int kl,

@@ -326,3 +326,59 @@ def test_ctx_and_ce():
     close(loss, ref, 1e-5, 'ce rows')
     close(dl, lg.grad, 1e-6, 'ce rows grad')
     assert pred.cpu().tolist() == [[int(lg[r, c0:c0 + n].argmax()) for (c0, n) in segs] for r in range(4)]
+
+
+# ------------------------------------------------------------------------------------------------ bf16 matrix-core mode
+def bf(x):
+    return x.bfloat16().float()
+
+
+@pytest.mark.parametrize('M,N,K', [(256, 128, 64), (300, 72, 96), (1000, 512, 2048), (77, 64, 512)])
+def test_gemm_bf16w(M, N, K):
+    x, W, b, r = rnd(M, K), rnd(N, K, seed=1), rnd(N, seed=2), rnd(M, N, seed=3)
+    out = ops.gemm_bf16w(x.to(DEV), W.to(DEV).to(torch.bfloat16), bias=b.to(DEV), act=ops.ACT_LRELU, residual=r.to(DEV))
+    # the kernel must equal an fp32 GEMM of the bf16-ROUNDED operands (fp32 accumulate) ...
+    close(out, F.leaky_relu(bf(x) @ bf(W).t() + b, 0.02) + r, 2e-5, 'bf16 gemm (rounded-operand reference)')
+    # ... and stay within bf16 rounding of the true fp32 result
+    close(out, F.leaky_relu(x @ W.t() + b, 0.02) + r, 2e-2, 'bf16 gemm vs fp32')
+
+
+@pytest.mark.parametrize('Cin,Cout,k,s,S', [(64, 64, 3, 1, 6), (128, 64, 5, 1, 5), (64, 64, 5, 5, 10), (64, 128, 3, 1, 4)])
+def test_conv3d_bf16w(Cin, Cout, k, s, S):
+    B = 2
+    x = rnd(B, Cin, S, S, S)
+    W = rnd(Cout, Cin, k, k, k, seed=1, scale=0.1)
+    b = rnd(Cout, seed=2)
+    ref = F.leaky_relu(ref_conv(bf(x), bf(W), b, s), 0.02)
+    G = ref.shape[-1]
+    wb = ops.to_bf16_nk(ops.conv_weight_fwd(W.to(DEV)))
+    y = ops.conv3d_bf16w(cl(x).to(DEV), wb, Cout, B, S, G, k, -(k // 2), stride=s, bias=b.to(DEV), act=ops.ACT_LRELU)
+    close(y, cl(ref), 3e-5, 'bf16 conv fwd')
+    # data gradient through the same kernel (zero padding, flipped weights) + two-source + depth-to-space variants
+    if s == 1:
+        dy = rnd(B, Cout, G, G, G, seed=3)
+        wd = ops.to_bf16_nk(ops.conv_weight_dgrad(W.to(DEV)))
+        p = k // 2
+        dxp = ops.conv3d_bf16w(cl(dy).to(DEV), wd, Cin, B, G, S + 2 * p, k, -(k - 1), replicate=False)
+        dxp_ref = ops.conv3d(cl(bf(dy)).to(DEV), ops.conv_weight_dgrad(bf(W).to(DEV)), Cin, B, G, S + 2 * p, k, -(k - 1), replicate=False)
+        close(dxp, dxp_ref, 3e-5, 'bf16 conv dgrad')
+
+
+def test_conv3d_bf16w_two_sources_and_d2s():
+    B, S = 2, 5
+    a, c = rnd(B, 64, S, S, S), rnd(B, 64, S, S, S, seed=5)
+    W, b = rnd(64, 128, 3, 3, 3, seed=1, scale=0.1), rnd(64, seed=2)
+    ref = F.leaky_relu(ref_conv(torch.cat([bf(a), bf(c)], 1), bf(W), b), 0.02)
+    y = ops.conv3d_bf16w(cl(a).to(DEV), ops.to_bf16_nk(ops.conv_weight_fwd(W.to(DEV))), 64, B, S, S, 3, -1, bias=b.to(DEV),
+                         act=ops.ACT_LRELU, src1=cl(c).to(DEV))
+    close(y, cl(ref), 3e-5, 'bf16 two-source')
+    # polyphase forward in bf16 == fp32 kernel on rounded operands
+    k, s, G = 5, 5, 3
+    z1 = rnd(B, 64, G, G, G, seed=7)
+    W2 = rnd(64, 64, k, k, k, seed=8, scale=0.1)
+    L, R = ops.polyphase_tables(k, s)
+    kl = 2 * R + 1
+    Weff = ops.polyphase_weights(W2.to(DEV), torch.from_numpy(L).to(DEV), s, kl)
+    u_ref = ops.conv3d(cl(bf(z1)).to(DEV), bf(Weff), s ** 3 * 64, B, G, G, kl, -R, d2s=(s, 64))
+    u = ops.conv3d_bf16w(cl(z1).to(DEV), ops.to_bf16_nk(Weff), s ** 3 * 64, B, G, G, kl, -R, d2s=(s, 64))
+    close(u, u_ref, 3e-5, 'bf16 polyphase d2s')

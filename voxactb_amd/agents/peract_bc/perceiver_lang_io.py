@@ -248,6 +248,12 @@ class PerceiverEngine:
             self._Lt_host = Lt
         self._Lt = None
         self.step_seed = 0
+        # 'fp32': exact fp32 matrix cores everywhere (parity mode).  'bf16': forward / data-gradient convs and large
+        # linears on bf16 matrix cores with fp32 accumulation (throughput mode; see ops.PRECISION).
+        import os
+        self.precision = os.environ.get('VOXACTB_PRECISION', 'fp32')
+        if self.precision not in ('fp32', 'bf16'):
+            raise ValueError('VOXACTB_PRECISION must be fp32 or bf16')
 
     # -------------------------------------------------------------------------------------------------- helpers
     def p(self, name):
@@ -352,6 +358,14 @@ class PerceiverEngine:
     def forward(self, vox, proprio, lang_token_embs, training=False, save=True, seed=None):
         """vox [B,V,V,V,10] channels-last.  Returns ((trans [B,1,V,V,V], rot_and_grip, collision[, arm]), cache)."""
         require_cuda(vox, proprio, lang_token_embs)
+        ops.new_step()
+        ops.PRECISION = self.precision
+        try:
+            return self._forward(vox, proprio, lang_token_embs, training, save, seed)
+        finally:
+            ops.PRECISION = 'fp32'
+
+    def _forward(self, vox, proprio, lang_token_embs, training, save, seed):
         m = self.m
         B = vox.shape[0]
         V, G, C, Cx, D, L, T0, k, s = self.V, self.G, self.C, self.Cx, self.D, self.L, self.T0, self.k, self.s
@@ -449,6 +463,13 @@ class PerceiverEngine:
     def backward(self, c, dq_trans, d_o, d_arm=None):
         """dq_trans [B,V,V,V] (or [B,1,V,V,V]), d_o [B, 3*rot+grip+coll] (grad of the concatenated MLP head output),
         d_arm [B,2] or None.  Accumulates into every parameter's .grad."""
+        ops.PRECISION = self.precision
+        try:
+            return self._backward(c, dq_trans, d_o, d_arm)
+        finally:
+            ops.PRECISION = 'fp32'
+
+    def _backward(self, c, dq_trans, d_o, d_arm=None):
         m = self.m
         B = c['B']
         V, G, C, Cx, D, L, T0, k, s = self.V, self.G, self.C, self.Cx, self.D, self.L, self.T0, self.k, self.s

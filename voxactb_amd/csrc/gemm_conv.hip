@@ -482,3 +482,245 @@ extern "C" int vxb_conv3d_wgrad_f32(const float* src0, const float* src1, int C0
     if (hipGetLastError() != hipSuccess) return VXB_ELAUNCH;
     return VXB_OK;
 }
+
+// =====================================================================================================================
+// bf16 matrix-core variant ("throughput mode"): C = act(A @ Bw^T + bias).
+//   A  : fp32 in HBM (activations / gradients), K-contiguous rows or the conv gather; rounded to bf16 (RNE) while being
+//        staged into LDS, so the surrounding fp32 kernels and buffers are unchanged.
+//   Bw : bf16 weights [N][K] (K contiguous), prepared once per step.
+//   acc: fp32 (v_mfma_f32_32x32x16_bf16, 16x the fp32-MFMA rate).
+// LDS tiles are [row][32 k] bf16 with an 80-byte row stride: a fragment read is one ds_read_b128 per lane and the 16
+// lanes of a read group hit 16 distinct 16-byte bank slots.  Both operands use the same (lane>>5, j) -> k placement, so
+// the k-permutation inside one instruction cancels in the dot product.
+// =====================================================================================================================
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    // round-to-nearest-even fp32 -> bf16, two values per dword
+    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
+    a += 0x7fffu + ((a >> 16) & 1u);
+    b += 0x7fffu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xffff0000u);
+}
+
+constexpr int BK16 = 32;
+constexpr int LDS16 = 40;      // bf16 elements per LDS row (32 + 8 pad) = 80 bytes
+
+template <int AMODE, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs g, const u16* __restrict__ Bw) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_F4 = BM * BK16 / 4 / 256;        // fp32 float4 loads per thread (4 for BM = 128)
+    constexpr int B_V8 = BN * BK16 / 8 / 256;        // 16-byte bf16 loads per thread (2 for BN = 128, 1 for 64)
+    __shared__ __attribute__((aligned(16))) u16 As[BM * LDS16];
+    __shared__ __attribute__((aligned(16))) u16 Bs[BN * LDS16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const float* __restrict__ A = g.A;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    int a_b[A_F4], a_d[A_F4], a_h[A_F4], a_w[A_F4];
+    bool a_rowok[A_F4];
+    if (AMODE == A_CONV) {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int m = m0 + (tid >> 3) + 32 * i;
+            a_rowok[i] = m < g.M;
+            const int S = g.cg.S_out;
+            int r = a_rowok[i] ? m : 0;
+            a_w[i] = r % S; r /= S;
+            a_h[i] = r % S; r /= S;
+            a_d[i] = r % S; r /= S;
+            a_b[i] = r;
+        }
+    }
+    float4 ra[A_F4];
+    uint4 rb[B_V8];
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK16;
+        if (AMODE == A_KCONTIG) {
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const int m = m0 + (tid >> 3) + 32 * i;
+                const int k = k0 + (tid & 7) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < g.M && k < g.K) v = *reinterpret_cast<const float4*>(A + (long long)m * g.sAm + k);
+                ra[i] = v;
+            }
+        } else {
+            const ConvGeom& c = g.cg;
+            const int Ct = c.C0 + c.C1;
+            const int tap = k0 / Ct;
+            const int cc = k0 - tap * Ct + (tid & 7) * 4;
+            const int tw = tap % c.kext, th = (tap / c.kext) % c.kext, td = tap / (c.kext * c.kext);
+            const bool second = cc >= c.C0;
+            const float* src = second ? c.src1 : c.src0;
+            const int Cs = second ? c.C1 : c.C0;
+            const int ch = second ? cc - c.C0 : cc;
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                int id = a_d[i] * c.stride + td + c.off;
+                int ih = a_h[i] * c.stride + th + c.off;
+                int iw = a_w[i] * c.stride + tw + c.off;
+                bool ok = a_rowok[i] && (k0 < g.K);
+                if (c.replicate) {
+                    id = min(max(id, 0), c.S_in - 1);
+                    ih = min(max(ih, 0), c.S_in - 1);
+                    iw = min(max(iw, 0), c.S_in - 1);
+                } else {
+                    ok = ok && id >= 0 && id < c.S_in && ih >= 0 && ih < c.S_in && iw >= 0 && iw < c.S_in;
+                }
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) {
+                    const long long vox = (((long long)a_b[i] * c.S_in + id) * c.S_in + ih) * c.S_in + iw;
+                    v = *reinterpret_cast<const float4*>(src + vox * Cs + ch);
+                }
+                ra[i] = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_V8; ++i) {
+            const int n = n0 + (tid >> 2) + 64 * i;
+            const int k = k0 + (tid & 3) * 8;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (n < g.N && k < g.K) v = *reinterpret_cast<const uint4*>(Bw + (long long)n * g.K + k);
+            rb[i] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int r = (tid >> 3) + 32 * i, kq = (tid & 7) * 4;
+            uint2 p;
+            p.x = pack_bf16(ra[i].x, ra[i].y);
+            p.y = pack_bf16(ra[i].z, ra[i].w);
+            *reinterpret_cast<uint2*>(&As[r * LDS16 + kq]) = p;
+        }
+#pragma unroll
+        for (int i = 0; i < B_V8; ++i) {
+            const int r = (tid >> 2) + 64 * i, kq = (tid & 3) * 8;
+            *reinterpret_cast<uint4*>(&Bs[r * LDS16 + kq]) = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nkt = (g.K + BK16 - 1) / BK16;
+    load_tile(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        const int lk = (lane >> 5) * 8, lm = lane & 31;
+#pragma unroll
+        for (int kk = 0; kk < BK16; kk += 16) {
+            bf16x8 av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                av[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * (BM / WM) + i * 32 + lm) * LDS16 + kk + lk]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bv[j] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * (BN / WN) + j * 32 + lm) * LDS16 + kk + lk]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    float* __restrict__ C = g.C;
+    const float* __restrict__ R = g.residual;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+            if (n >= g.N) continue;
+            const float bsv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= g.M) continue;
+                float v = g.alpha * acc[i][j][r] + bsv;
+                if (g.act == ACT_LRELU) v = v > 0.f ? v : v * g.slope;
+                long long off;
+                if (g.d2s_s > 0) {
+                    const int s = g.d2s_s, G = g.d2s_G, Cc = g.d2s_C;
+                    const int ph = n / Cc, co = n - ph * Cc;
+                    const int rw = ph % s, rh = (ph / s) % s, rd = ph / (s * s);
+                    int q = m;
+                    const int qw = q % G; q /= G;
+                    const int qh = q % G; q /= G;
+                    const int qd = q % G; q /= G;
+                    const long long Vv = (long long)G * s;
+                    off = ((((long long)q * Vv + qd * s + rd) * Vv + qh * s + rh) * Vv + qw * s + rw) * Cc + co;
+                } else {
+                    off = (long long)m * g.ldc + n;
+                }
+                if (R) v += R[off];
+                if (g.accumulate) v += C[off];
+                C[off] = v;
+            }
+        }
+    }
+}
+
+template <int AMODE>
+int launch_gemm_bf16(const GemmArgs& g, const u16* Bw, hipStream_t st) {
+    if (g.N > 64) {
+        dim3 grid(vxb_cdiv(g.N, 128), vxb_cdiv(g.M, 128), 1);
+        hipLaunchKernelGGL((gemm_bf16_kernel<AMODE, 128, 128, 2, 2>), grid, dim3(256), 0, st, g, Bw);
+    } else {
+        dim3 grid(vxb_cdiv(g.N, 64), vxb_cdiv(g.M, 128), 1);
+        hipLaunchKernelGGL((gemm_bf16_kernel<AMODE, 128, 64, 2, 2>), grid, dim3(256), 0, st, g, Bw);
+    }
+    if (hipGetLastError() != hipSuccess) return VXB_ELAUNCH;
+    return VXB_OK;
+}
+
+}  // namespace
+
+// C[M,N] (+)= act(A[M,K] (fp32, row stride lda, rounded to bf16) @ Bw[N,K]^T (bf16) + bias) (+ residual); K % 8 == 0.
+extern "C" int vxb_gemm_bf16w_f32(const float* A, int64_t lda, const void* Bw, float* C, int64_t ldc, const float* bias,
+                                  const float* residual, int M, int N, int K, int act, float slope, int accumulate,
+                                  vxb_stream_t stream) {
+    if (!A || !Bw || !C || M < 1 || N < 1 || K < 8) return VXB_EARG;
+    if ((K & 7) || (lda & 3) || !aligned16(A) || !aligned16(Bw)) return VXB_ESIZE;
+    GemmArgs g = {};
+    g.A = A; g.C = C; g.bias = bias; g.residual = residual; g.M = M; g.N = N; g.K = K; g.sAm = lda; g.sAk = 1; g.ldc = ldc;
+    g.H = 1; g.alpha = 1.f; g.act = act; g.slope = slope; g.accumulate = accumulate;
+    return launch_gemm_bf16<A_KCONTIG>(g, (const u16*)Bw, (hipStream_t)stream);
+}
+
+// bf16-matrix-core twin of vxb_conv3d_f32: same geometry, weights as bf16 [N][K = kext^3*(C0+C1)]; C0, C1 multiples of 32.
+extern "C" int vxb_conv3d_bf16w_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
+                                    int stride, int kext, int off, int replicate, const void* wt_bf16, int N,
+                                    const float* bias, float* out, int64_t ldc, int act, float slope, int accumulate,
+                                    int d2s_s, int d2s_C, vxb_stream_t stream) {
+    if (!src0 || !wt_bf16 || !out || B < 1 || S_in < 1 || S_out < 1 || kext < 1 || stride < 1 || N < 1) return VXB_EARG;
+    if ((C0 & 31) || (C1 & 31) || C0 < 32 || (C1 > 0 && !src1)) return VXB_ESIZE;
+    if (!aligned16(src0) || !aligned16(wt_bf16) || (src1 && !aligned16(src1))) return VXB_ESIZE;
+    const long long M = (long long)B * S_out * S_out * S_out;
+    const long long K = (long long)kext * kext * kext * (C0 + C1);
+    if (M >= INT32_MAX || K >= INT32_MAX) return VXB_ESIZE;
+    GemmArgs g = {};
+    g.A = src0; g.C = out; g.bias = bias; g.M = (int)M; g.N = N; g.K = (int)K; g.ldc = ldc; g.H = 1;
+    g.alpha = 1.f; g.act = act; g.slope = slope; g.accumulate = accumulate;
+    g.d2s_s = d2s_s; g.d2s_G = S_out; g.d2s_C = d2s_C;
+    g.cg.src0 = src0; g.cg.src1 = src1; g.cg.C0 = C0; g.cg.C1 = C1; g.cg.S_in = S_in; g.cg.S_out = S_out;
+    g.cg.stride = stride; g.cg.kext = kext; g.cg.off = off; g.cg.replicate = replicate;
+    if (d2s_s > 0 && (d2s_C < 1 || N % d2s_C)) return VXB_EARG;
+    return launch_gemm_bf16<A_CONV>(g, (const u16*)wt_bf16, (hipStream_t)stream);
+}

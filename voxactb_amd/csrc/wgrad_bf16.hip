@@ -1,0 +1,276 @@
+// bf16 matrix-core weight gradient of the implicit-GEMM conv3d ("throughput mode" twin of vxb_conv3d_wgrad_f32):
+//     part[z][(tap, ci)][n] = sum over the z-th slice of positions p of  gather(src)[p][(tap, ci)] * dY[p][n]
+// Both operands reduce over POSITIONS, but live in HBM position-major ([p][channel], fp32).  They are staged into LDS
+// in that natural layout (rounded to bf16, 8-byte stores) and fed to v_mfma_f32_32x32x16_bf16 through the gfx950
+// transpose read ds_read_b64_tr_b16, whose semantics were measured on hardware (tools/ubench/trprobe.hip):
+//     within a 16-lane group, lane i receives  in[4j + (i >> 2)][i & 3]  for j = 0..3
+// where in[t][s] is the s-th b16 at lane t's address.  Pointing lane t at LDS[(p0 + (t >> 2))][c0 + 4 (t & 3)] therefore
+// hands lane i channel c0 + i at positions p0 .. p0+3: a [4 pos][16 ch] block, transposed for free.
+// LDS row strides are = 16 (mod 64) dwords, which makes the 32 lanes served per LDS cycle hit 64 distinct banks.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+struct WgArgs {
+    const float* src0;
+    const float* src1;
+    const float* dy;
+    float* part;
+    int C0, C1, S_in, S_out, stride, kext, off, replicate;
+    int Krows;           // kext^3 * (C0 + C1)
+    int N;               // output channels (columns)
+    long long P;         // positions = B * S_out^3
+    long long ldy;       // dY row stride (row-major mode)
+    int d2s_s, d2s_C;    // > 0: dY is a fine grid [B, (S_out*s)^3, d2s_C], column n = (phase, co)
+    int tiles_per_split;
+};
+
+__device__ __forceinline__ unsigned pack_bf16_2(float lo, float hi) {
+    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
+    a += 0x7fffu + ((a >> 16) & 1u);
+    b += 0x7fffu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xffff0000u);
+}
+
+__device__ __forceinline__ unsigned long long ds_read_tr16(unsigned addr) {
+    unsigned long long v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
+constexpr int BP = 32;      // positions per K-tile
+
+template <int BN>
+__global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
+    constexpr int BM = 128;                       // (tap, ci) rows per block
+    constexpr int LDA = BM + 32;                  // 160 bf16 = 80 dwords  (= 16 mod 64)
+    constexpr int LDB = BN == 128 ? 160 : 96;     // 80 / 48 dwords        (= 16 / 48 mod 64)
+    constexpr int WN = BN == 128 ? 2 : 1, WM = 4 / WN;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_F4 = BP * BM / 4 / 256;       // 4
+    constexpr int B_F4 = BP * BN / 4 / 256;       // 4 or 2
+    __shared__ __attribute__((aligned(16))) u16 As[BP * LDA];
+    __shared__ __attribute__((aligned(16))) u16 Bs[BP * LDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int S = g.S_out;
+    const int Ct = g.C0 + g.C1;
+
+    // ---- A: thread-constant (tap, channel) part; e = tid + 256 i -> pos = e / 32, row4 = (e % 32) * 4 = (tid % 32) * 4
+    const int kr = m0 + (tid & 31) * 4;
+    const bool a_ok = kr < g.Krows;
+    int a_td = 0, a_th = 0, a_tw = 0, a_ch = 0, a_Cs = g.C0;
+    const float* a_src = g.src0;
+    if (a_ok) {
+        const int tap = kr / Ct;
+        const int cc = kr - tap * Ct;
+        a_tw = tap % g.kext; a_th = (tap / g.kext) % g.kext; a_td = tap / (g.kext * g.kext);
+        if (cc >= g.C0) { a_src = g.src1; a_Cs = g.C1; a_ch = cc - g.C0; } else { a_ch = cc; }
+    }
+    // ---- B: thread-constant column part
+    const int bn = n0 + (tid % (BN / 4)) * 4;
+    const bool b_ok = bn < g.N;
+    int b_rd = 0, b_rh = 0, b_rw = 0, b_co = 0;
+    if (g.d2s_s > 0 && b_ok) {
+        const int ph = bn / g.d2s_C;
+        b_co = bn - ph * g.d2s_C;
+        b_rw = ph % g.d2s_s; b_rh = (ph / g.d2s_s) % g.d2s_s; b_rd = ph / (g.d2s_s * g.d2s_s);
+    }
+
+    long long nkt = (g.P + BP - 1) / BP;
+    long long kt_begin = (long long)blockIdx.z * g.tiles_per_split;
+    if (nkt > kt_begin + g.tiles_per_split) nkt = kt_begin + g.tiles_per_split;
+
+    // position coordinates of the 8-row sub-slot this thread loads for A (pos = k0 + tid/32 + 8 i) and for B
+    // (pos = k0 + tid/(BN/4) + (256/(BN/4)) i): decoded once, advanced incrementally by 32 per tile
+    int aw[A_F4], ah[A_F4], ad[A_F4], ab[A_F4];
+    int bw[B_F4], bh[B_F4], bd[B_F4], bb[B_F4];
+    auto decode = [&](long long pos, int& w, int& h, int& d, int& b) {
+        long long r = pos;
+        w = (int)(r % S); r /= S;
+        h = (int)(r % S); r /= S;
+        d = (int)(r % S); r /= S;
+        b = (int)r;
+    };
+    auto advance = [&](int& w, int& h, int& d, int& b) {
+        if (S == 1) { b += BP; return; }       // plain GEMM (linear-layer weight gradient): rows are the positions
+        w += BP;
+        if (w >= S) {
+            const int c1 = w / S;
+            w -= c1 * S;
+            h += c1;
+            if (h >= S) {
+                const int c2 = h / S;
+                h -= c2 * S;
+                d += c2;
+                if (d >= S) { const int c3 = d / S; d -= c3 * S; b += c3; }
+            }
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) decode(kt_begin * BP + (tid >> 5) + 8 * i, aw[i], ah[i], ad[i], ab[i]);
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) decode(kt_begin * BP + tid / (BN / 4) + (256 / (BN / 4)) * i, bw[i], bh[i], bd[i], bb[i]);
+
+    float4 ra[A_F4], rb[B_F4];
+    auto load_tile = [&](long long kt) {
+        const long long k0 = kt * BP;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const long long pos = k0 + (tid >> 5) + 8 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a_ok && pos < g.P) {
+                int id = ad[i] * g.stride + a_td + g.off;
+                int ih = ah[i] * g.stride + a_th + g.off;
+                int iw = aw[i] * g.stride + a_tw + g.off;
+                bool ok = true;
+                if (g.replicate) {
+                    id = min(max(id, 0), g.S_in - 1); ih = min(max(ih, 0), g.S_in - 1); iw = min(max(iw, 0), g.S_in - 1);
+                } else {
+                    ok = id >= 0 && id < g.S_in && ih >= 0 && ih < g.S_in && iw >= 0 && iw < g.S_in;
+                }
+                if (ok) {
+                    const long long vox = (((long long)ab[i] * g.S_in + id) * g.S_in + ih) * g.S_in + iw;
+                    v = *reinterpret_cast<const float4*>(a_src + vox * a_Cs + a_ch);
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const long long pos = k0 + tid / (BN / 4) + (256 / (BN / 4)) * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b_ok && pos < g.P) {
+                if (g.d2s_s > 0) {
+                    const int s = g.d2s_s;
+                    const long long Vv = (long long)S * s;
+                    const long long o = ((((long long)bb[i] * Vv + bd[i] * s + b_rd) * Vv + bh[i] * s + b_rh) * Vv + bw[i] * s + b_rw) * g.d2s_C + b_co;
+                    v = *reinterpret_cast<const float4*>(g.dy + o);
+                } else {
+                    v = *reinterpret_cast<const float4*>(g.dy + pos * g.ldy + bn);
+                }
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            uint2 p;
+            p.x = pack_bf16_2(ra[i].x, ra[i].y); p.y = pack_bf16_2(ra[i].z, ra[i].w);
+            *reinterpret_cast<uint2*>(&As[((tid >> 5) + 8 * i) * LDA + (tid & 31) * 4]) = p;
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            uint2 p;
+            p.x = pack_bf16_2(rb[i].x, rb[i].y); p.y = pack_bf16_2(rb[i].z, rb[i].w);
+            *reinterpret_cast<uint2*>(&Bs[(tid / (BN / 4) + (256 / (BN / 4)) * i) * LDB + (tid % (BN / 4)) * 4]) = p;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addressing (see header): group gq = lane >> 4, t = lane & 15
+    const int gq = lane >> 4, t = lane & 15;
+    const int f_pos = 8 * (gq >> 1) + (t >> 2);          // + kk + 4 r
+    const int f_ch = 16 * (gq & 1) + 4 * (t & 3);        // + 32 * tile + wave offset
+    const unsigned a_base = (unsigned)(size_t)(&As[0]) + 2u * (unsigned)(f_pos * LDA + wm * (BM / WM) + f_ch);
+    const unsigned b_base = (unsigned)(size_t)(&Bs[0]) + 2u * (unsigned)(f_pos * LDB + wn * (BN / WN) + f_ch);
+
+    if (kt_begin < nkt) load_tile(kt_begin);
+    for (long long kt = kt_begin; kt < nkt; ++kt) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < nkt) {
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) advance(aw[i], ah[i], ad[i], ab[i]);
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) advance(bw[i], bh[i], bd[i], bb[i]);
+            load_tile(kt + 1);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BP; kk += 16) {
+            unsigned long long a0[TM], a1[TM], b0[TN], b1[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                a0[i] = ds_read_tr16(a_base + 2u * (unsigned)((kk + 0) * LDA + i * 32));
+                a1[i] = ds_read_tr16(a_base + 2u * (unsigned)((kk + 4) * LDA + i * 32));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                b0[j] = ds_read_tr16(b_base + 2u * (unsigned)((kk + 0) * LDB + j * 32));
+                b1[j] = ds_read_tr16(b_base + 2u * (unsigned)((kk + 4) * LDB + j * 32));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                union { unsigned long long u[2]; bf16x8 v; } fa;
+                fa.u[0] = a0[i]; fa.u[1] = a1[i];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    union { unsigned long long u[2]; bf16x8 v; } fb;
+                    fb.u[0] = b0[j]; fb.u[1] = b1[j];
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    float* __restrict__ C = g.part + (long long)blockIdx.z * g.Krows * g.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+            if (n >= g.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < g.Krows) C[(long long)m * g.N + n] = acc[i][j][r];
+            }
+        }
+}
+
+}  // namespace
+
+// Same contract as vxb_conv3d_wgrad_f32 (include/voxactb_hip.h); operands are rounded to bf16 while staged, fp32 accumulate.
+extern "C" int vxb_conv3d_wgrad_bf16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
+                                         int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
+                                         int d2s_s, int d2s_C, float* part, int nsplit, vxb_stream_t stream) {
+    if (!src0 || !dy || !part || B < 1 || S_in < 1 || S_out < 1 || kext < 1 || stride < 1 || N < 1 || nsplit < 1) return VXB_EARG;
+    if ((C0 & 3) || (C1 & 3) || C0 < 4 || (C1 > 0 && !src1) || (N & 3)) return VXB_ESIZE;
+    if (d2s_s > 0 && (d2s_C < 4 || (d2s_C & 3) || N % d2s_C)) return VXB_EARG;
+    if (d2s_s <= 0 && (ldy & 3)) return VXB_ESIZE;
+    WgArgs g;
+    g.src0 = src0; g.src1 = src1; g.dy = dy; g.part = part;
+    g.C0 = C0; g.C1 = C1; g.S_in = S_in; g.S_out = S_out; g.stride = stride; g.kext = kext; g.off = off; g.replicate = replicate;
+    const long long K = (long long)kext * kext * kext * (C0 + C1);
+    if (K >= INT32_MAX) return VXB_ESIZE;
+    g.Krows = (int)K; g.N = N; g.P = (long long)B * S_out * S_out * S_out; g.ldy = ldy; g.d2s_s = d2s_s; g.d2s_C = d2s_C;
+    const long long nkt = (g.P + BP - 1) / BP;
+    g.tiles_per_split = (int)((nkt + nsplit - 1) / nsplit);
+    hipStream_t st = (hipStream_t)stream;
+    if (N > 64) {
+        dim3 grid(vxb_cdiv(N, 128), vxb_cdiv(K, 128), nsplit);
+        hipLaunchKernelGGL(wgrad_bf16_kernel<128>, grid, dim3(256), 0, st, g);
+    } else {
+        dim3 grid(vxb_cdiv(N, 64), vxb_cdiv(K, 128), nsplit);
+        hipLaunchKernelGGL(wgrad_bf16_kernel<64>, grid, dim3(256), 0, st, g);
+    }
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}

@@ -11,6 +11,26 @@ LRELU_SLOPE = 0.02   # reference: peract/helpers/network_utils.py:12
 ACT_NONE, ACT_LRELU = 0, 1
 _NAIVE_MACS = 1 << 22
 
+# Compute precision of the matrix-core kernels: 'fp32' = exact fp32 MFMA everywhere (parity mode, the default);
+# 'bf16' = forward + data-gradient convs and large linears on bf16 MFMA with fp32 accumulation (throughput mode;
+# weight gradients, attention softmax path and every streaming kernel stay fp32).  Set by PerceiverEngine per call.
+PRECISION = 'fp32'
+_WCACHE = {}
+
+
+def new_step():
+    """weights change every optimizer step: drop the per-step bf16 weight copies."""
+    _WCACHE.clear()
+
+
+def _bf16_weight(W, transposed):
+    key = (W.data_ptr(), tuple(W.shape), transposed)
+    wb = _WCACHE.get(key)
+    if wb is None:
+        wb = (W.t().contiguous() if transposed else W.contiguous()).to(torch.bfloat16)
+        _WCACHE[key] = wb
+    return wb
+
 
 def _f32c(*ts):
     for t in ts:
@@ -47,6 +67,8 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None):
         naive_gemm(x, W, out, M, N, K, x.stride(0), 1, 1, W.stride(0), out.stride(0), bias, act)
         if residual is not None:
             axpy_(out, residual)
+    elif PRECISION == 'bf16' and K % 8 == 0 and W.is_contiguous():
+        gemm_bf16w(x, _bf16_weight(W, False), out, bias, act, residual, label='gemm_fwd %dx%dx%d' % (M, N, K))
     else:
         gemm(x, W, out, M, N, K, x.stride(0), 1, 1, W.stride(0), out.stride(0), bias=bias, residual=residual, act=act,
              label='gemm_fwd %dx%dx%d' % (M, N, K))
@@ -69,7 +91,12 @@ def linear_bwd(x, W, dy, dW, db=None, dx=None, dx_accumulate=False, ws=None):
             cands = [d for d in range(1, 65) if M % d == 0 and (M // d) >= 256]
             ok = [d for d in cands if tiles * d >= 512]
             ns = min(ok) if ok else (max(cands) if cands else 1)
-        if ns > 1:
+        if PRECISION == 'bf16' and dW.is_contiguous() and dy.stride(0) == N:
+            # both operands are row(position)-major -> the transposed-read bf16 kernel (a 1x1x1 "conv" over M positions)
+            nsb = max(1, min(64, (512 + tiles - 1) // tiles, M // 256))
+            res = conv3d_wgrad(dy, x, K, M, 1, 1, 1, 0, ldy=x.stride(0), nsplit=nsb, label='gemm_wgrad %dx%dx%d' % (N, K, M))
+            axpy_(dW, res)
+        elif ns > 1:
             rc = M // ns
             part = torch.empty((ns, N, K), dtype=torch.float32, device=x.device)
             gemm(dy, x, part, N, K, rc, 1, dy.stride(0), x.stride(0), 1, K, batch=ns, H=1, bA=(rc * dy.stride(0), 0),
@@ -77,7 +104,9 @@ def linear_bwd(x, W, dy, dW, db=None, dx=None, dx_accumulate=False, ws=None):
             sum_splits(part, ns, N * K, dW, accumulate=True)
         else:
             gemm(dy, x, dW, N, K, M, 1, dy.stride(0), x.stride(0), 1, dW.stride(0), accumulate=True, label='gemm_wgrad %dx%dx%d' % (N, K, M))
-        if dx is not None:
+        if dx is not None and PRECISION == 'bf16' and N % 8 == 0 and W.is_contiguous():
+            gemm_bf16w(dy, _bf16_weight(W, True), dx, accumulate=dx_accumulate, label='gemm_dgrad %dx%dx%d' % (M, K, N))
+        elif dx is not None:
             gemm(dy, W, dx, M, K, N, dy.stride(0), 1, W.stride(0), 1, dx.stride(0), accumulate=dx_accumulate,
                  label='gemm_dgrad %dx%dx%d' % (M, K, N))
     if db is not None:
@@ -166,6 +195,9 @@ def conv3d(src0, wt, N, B, S_in, S_out, kext, off, stride=1, replicate=True, bia
            out=None, ldc=None, accumulate=False, d2s=(0, 0), label=None):
     C0 = src0.shape[-1]
     C1 = src1.shape[-1] if src1 is not None else 0
+    if PRECISION == 'bf16' and C0 % 32 == 0 and C1 % 32 == 0 and wt.dtype == torch.float32:
+        return conv3d_bf16w(src0, to_bf16_nk(wt), N, B, S_in, S_out, kext, off, stride, replicate, bias, act, src1, out, ldc,
+                            accumulate, d2s, label)
     if out is None:
         if d2s[0] > 0:
             Vf = S_out * d2s[0]
@@ -181,7 +213,7 @@ def conv3d(src0, wt, N, B, S_in, S_out, kext, off, stride=1, replicate=True, bia
 
 
 def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=True, src1=None, ldy=None, d2s=(0, 0),
-                 nsplit=None, label=None):
+                 nsplit=None, label=None, force_bf16=False):
     """returns dWt [(tap, ci)][N] (fp32, deterministic split reduction)."""
     C0 = src0.shape[-1]
     C1 = src1.shape[-1] if src1 is not None else 0
@@ -192,7 +224,8 @@ def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
         nsplit = max(1, min(64, 1024 // max(tiles, 1), (P + 4095) // 4096))
     part = torch.empty((nsplit, K, N), dtype=torch.float32, device=src0.device)
     _lib.set_meta(label or 'conv3d_wgrad[k%d s%d %d->%d S%d]' % (kext, stride, C0 + C1, N, S_out), 2.0 * P * N * K)
-    call('vxb_conv3d_wgrad_f32', src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, int(replicate), dy, N,
+    call('vxb_conv3d_wgrad_bf16_f32' if (PRECISION == 'bf16' or force_bf16) else 'vxb_conv3d_wgrad_f32',
+         src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, int(replicate), dy, N,
          ldy if ldy is not None else N, d2s[0], d2s[1], part, nsplit)
     if nsplit == 1:
         return part[0]
@@ -367,3 +400,41 @@ def ce_rows(logits, segs, labels, dlogits=None, gscale=1.0):
                                     _lib.ptr(pred), _lib.ptr(dlogits), float(gscale), _lib.stream_ptr())
     _lib.check(rc, 'vxb_ce_rows_f32')
     return loss, pred
+
+
+# --------------------------------------------------------------------------------------------- bf16 matrix-core mode
+def gemm_bf16w(x, Wb, out=None, bias=None, act=ACT_NONE, residual=None, accumulate=False, label=None):
+    """out[M,N] = act(x[M,K] (fp32 -> bf16 on the fly) @ Wb[N,K]^T (bf16) + bias) (+ residual), fp32 accumulate."""
+    M, K = x.shape
+    N = Wb.shape[0]
+    assert Wb.dtype == torch.bfloat16 and Wb.is_contiguous() and Wb.shape[1] == K
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _lib.set_meta(label or 'gemm_bf16 %dx%dx%d' % (M, N, K), 2.0 * M * N * K)
+    call('vxb_gemm_bf16w_f32', x, x.stride(0), Wb, out, out.stride(0), bias, residual, M, N, K, act, LRELU_SLOPE,
+         int(accumulate))
+    return out
+
+
+def conv3d_bf16w(src0, wb, N, B, S_in, S_out, kext, off, stride=1, replicate=True, bias=None, act=ACT_NONE, src1=None,
+                 out=None, ldc=None, accumulate=False, d2s=(0, 0), label=None):
+    """same contract as conv3d(), weights wb = bf16 [N][(tap, ci)]."""
+    C0 = src0.shape[-1]
+    C1 = src1.shape[-1] if src1 is not None else 0
+    assert wb.dtype == torch.bfloat16 and wb.is_contiguous()
+    if out is None:
+        if d2s[0] > 0:
+            Vf = S_out * d2s[0]
+            out = torch.empty((B, Vf, Vf, Vf, d2s[1]), dtype=torch.float32, device=src0.device)
+        else:
+            out = torch.empty((B, S_out, S_out, S_out, N), dtype=torch.float32, device=src0.device)
+    _lib.set_meta(label or 'conv3d_bf16[k%d s%d %d->%d S%d%s]' % (kext, stride, C0 + C1, N, S_out, '' if replicate else ' dgrad'),
+                  2.0 * B * S_out ** 3 * N * kext ** 3 * (C0 + C1))
+    call('vxb_conv3d_bf16w_f32', src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, int(replicate), wb, N, bias, out,
+         ldc if ldc is not None else N, act, LRELU_SLOPE, int(accumulate), d2s[0], d2s[1])
+    return out
+
+
+def to_bf16_nk(wt_kn):
+    """[K][N] fp32 weight layout of the fp32 kernels -> bf16 [N][K] (one small transposing copy per step)."""
+    return wt_kn.t().contiguous().to(torch.bfloat16)
