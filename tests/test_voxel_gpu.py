@@ -112,6 +112,16 @@ def test_edge_cases():
     # (d) odd V (scalar fill path) and feature_size 1
     out, _ = run(p, f[..., :1], bounds, 7)
     assert same(out, ovox.voxelize(p, f[..., :1], bounds, 7))
+    # (e) a slab too large for LDS whose cells end exactly on / straddle the 4096-pair chunk boundary
+    for n0 in (4095, 4096, 4097):
+        pa = 0.51 + 0.001 * g.uniform(0, 1, (n0, 3))
+        pb = pa[:1500] + np.array([0.0, 0.0625, 0.0])
+        pc = pa[:700] + np.array([0.0, 0.0, 0.0625])
+        p = torch.from_numpy(np.concatenate([pa, pb, pc])[None].astype(np.float32))
+        p = p[:, torch.from_numpy(g.permutation(p.shape[1]))]
+        f = torch.from_numpy(g.standard_normal((1, p.shape[1], 3)).astype(np.float32))
+        out, _ = run(p, f, bounds, V)
+        assert same(out, ovox.voxelize(p, f, bounds, V)), n0
 
 
 def test_errors():
