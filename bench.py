@@ -40,6 +40,7 @@ def main():
     ap.add_argument('--depth', type=int, default=6)
     ap.add_argument('--latents', type=int, default=2048)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-bf16-mode', action='store_true', help='skip the secondary bf16 throughput-mode measurement')
     ap.add_argument('--cpu-voxel-size', type=int, default=0, help='debug: smaller grid for the CPU baseline leg')
     ap.add_argument('--kernel-table', action='store_true', help='print the per-kernel timing table to stderr')
     a = ap.parse_args()
@@ -96,6 +97,41 @@ def main():
     dt = float(tt[0])
     agg = timer.summary()
 
+    # secondary measurement, same workload: bf16 matrix-core throughput mode (never the headline `value`)
+    bf16 = None
+    if not a.no_bf16_mode:
+        eng = agent._pose_agent._qattention_agents[0]._q.encoder.engine()
+        eng.precision = 'bf16'
+        step(a.warmup + a.steps)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        timer2 = _lib.KernelTimer()
+        _lib.TIMER = timer2
+        t1 = time.perf_counter()
+        for i in range(a.steps):
+            step(a.warmup + a.steps + 1 + i)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t2 = torch.tensor([time.perf_counter() - t1], device=dev)
+        if world > 1:
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        eng.precision = 'fp32'
+        _lib.TIMER = None
+        agg2 = timer2.summary()
+        bf_roof = {}
+        for key, pref in (('attention_flash_fwd_bwd', 'attn_core'), ('conv3d', 'conv3d'), ('linear_gemms', 'gemm')):
+            ms = sum(d['ms'] for l, d in agg2.items() if l.startswith(pref))
+            fl = sum(d['flops'] for l, d in agg2.items() if l.startswith(pref))
+            if ms > 0:
+                bf_roof[key] = {'bound': 'mfma', 'achieved': fl / (ms * 1e-3) / 1e12, 'peak': 2500.0, 'unit': 'TFLOP/s',
+                                'frac': fl / (ms * 1e-3) / 1e12 / 2500.0, 'ms_per_step': ms / a.steps}
+        bf16 = {'rooflines': bf_roof,'value': world * a.steps / float(t2[0]), 'unit': 'steps/s', 'ms_per_step': float(t2[0]) / a.steps * 1e3,
+                'dtype': 'bf16 matrix cores (fp32 accumulate) for conv fwd/dgrad/wgrad + large linears; everything else f32',
+                'note': 'not held to the 1e-4 Q-value bound (tests/test_bf16_mode_gpu.py: 4e-3 on q_trans); '
+                        'the headline value above is the fp32 parity mode'}
+
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         value = world * a.steps / dt
@@ -142,7 +178,7 @@ def main():
                                    % (V, len(cfg.rlbench.cameras), HW, HW, B, a.depth, a.latents),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world, 'params': n_params},
             'samples_per_s': value * B, 'final_loss': loss, 'device_time_ms_per_step': tot_ms / a.steps,
-            'roofline': roofline, 'rooflines_other': extra, 'cpu_baseline': cpu,
+            'roofline': roofline, 'rooflines_other': extra, 'cpu_baseline': cpu, 'throughput_mode_bf16': bf16,
         }
         print(json.dumps(out))
     if world > 1:

@@ -141,6 +141,16 @@ int vxb_softmax_rows_f32(float* S, float* P_drop, int64_t rows, int cols, int64_
 int vxb_softmax_bwd_rows_f32(const float* P, float* dP_inout, int64_t rows, int cols, int64_t ld, float scale,
                              float dropout_p, uint32_t seed, vxb_stream_t stream);
 
+/* Fused attention on the bf16 matrix cores (throughput mode): O = dropout(softmax(scale q k^T)) v per (b, h) without
+ * materialising the score tensor (perceiver_lang_io.py:116-130).  q [B,Nq,H*64], kv [B,Nk,2*H*64] (k | v halves), fp32;
+ * lse [B*H, Nq] = log-sum-exp of the scaled scores (kept for the backward pass).  head_dim must be 64. */
+int vxb_flash_attn_fwd_bf16(const float* q, const float* kv, float* o, float* lse, int B, int H, int Nq, int Nk,
+                            int head_dim, float scale, float dropout_p, uint32_t seed, vxb_stream_t stream);
+
+int vxb_flash_attn_bwd_bf16(const float* q, const float* kv, const float* o, const float* d_o, const float* lse,
+                            float* dq, float* dkv, float* dsum_ws, int B, int H, int Nq, int Nk, int head_dim,
+                            float scale, float dropout_p, uint32_t seed, vxb_stream_t stream);
+
 /* GEGLU x * gelu_erf(gates) (perceiver_lang_io.py:74-77); LeakyReLU backward; y += alpha*x. */
 int vxb_geglu_fwd_f32(const float* h, float* out, int64_t rows, int F, vxb_stream_t stream);
 int vxb_geglu_bwd_f32(const float* h, const float* dout, float* dh, int64_t rows, int F, vxb_stream_t stream);

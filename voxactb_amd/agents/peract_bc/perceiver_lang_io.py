@@ -24,7 +24,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from ... import ops
+from ... import flash, ops
 from ..._lib import VoxactbHipError, require_cuda
 
 LRELU_SLOPE = 0.02
@@ -290,6 +290,12 @@ class PerceiverEngine:
         inner = H * d
         q = ops.linear(xq.view(B * Nq, Dq), Wq)
         kv = ops.linear(ctxn.reshape(B * Nk, ctxn.shape[2]), Wkv)
+        if self.precision == 'bf16' and d == 64:
+            # throughput mode: fused attention on the bf16 matrix cores, no [B*h, i, j] tensor (csrc/flash_attn.hip)
+            O, lse = flash.flash_attn_fwd(q, kv, B, H, Nq, Nk, d ** -0.5, p, seed)
+            out = ops.linear(O, Wo, bo, residual=residual)
+            cache = dict(q=q, kv=kv, O=O, lse=lse, flash=True, dims=(B, Nq, Nk, H, d, 0), p=p, seed=seed) if save else None
+            return out, cache
         ld = _r4(Nk)
         S = torch.empty((B * H, Nq, ld), dtype=torch.float32, device=xq.device)
         ops.gemm(q, kv, S, Nq, Nk, d, inner, 1, 1, 2 * inner, ld, batch=B * H, H=H, bA=(Nq * inner, d),
@@ -310,6 +316,9 @@ class PerceiverEngine:
         dev = dout.device
         dO = torch.empty((B * Nq, inner), dtype=torch.float32, device=dev)
         ops.linear_bwd(c['O'], Wo, dout, self.g(pre + '.fn.to_out.weight'), self.g(pre + '.fn.to_out.bias'), dO)
+        if c.get('flash'):
+            dq, dkv = flash.flash_attn_bwd(c['q'], c['kv'], c['O'], dO, c['lse'], B, H, Nq, Nk, d ** -0.5, c['p'], c['seed'])
+            return self._attn_bwd_proj(pre, dq, dkv, xq2d, ctx2d, same_src)
         kv, q, P, Pd = c['kv'], c['q'], c['P'], c['Pd']
         dkv = torch.empty_like(kv)
         # dV[j,:] = sum_i Pd[i,j] dO[i,:]
@@ -325,6 +334,10 @@ class PerceiverEngine:
                  bB=(Nk * 2 * inner, d), bC=(Nq * inner, d), label='attn_core')
         ops.gemm(dS, q, dkv, Nk, d, Nq, 1, ld, inner, 1, 2 * inner, batch=B * H, H=H, bA=(H * Nq * ld, Nq * ld),
                  bB=(Nq * inner, d), bC=(Nk * 2 * inner, d), label='attn_core')
+        return self._attn_bwd_proj(pre, dq, dkv, xq2d, ctx2d, same_src)
+
+    def _attn_bwd_proj(self, pre, dq, dkv, xq2d, ctx2d, same_src):
+        Wq, Wkv = self.p(pre + '.fn.to_q.weight'), self.p(pre + '.fn.to_kv.weight')
         dxq = torch.empty_like(xq2d)
         ops.linear_bwd(xq2d, Wq, dq, self.g(pre + '.fn.to_q.weight'), None, dxq)
         if same_src:

@@ -58,14 +58,16 @@ struct GemmArgs {
     ConvGeom cg;
 };
 
-template <int AMODE, int BMODE, int BM, int BN, int WM, int WN>
+template <int AMODE, int BMODE, int BM, int BN, int WM, int WN, int BKT>
 __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int LDA = BM + 4, LDB = BN + 4;
-    constexpr int A_F4 = BM * BK / 4 / 256;      // float4 loads per thread for the A tile
-    constexpr int B_F4 = BN * BK / 4 / 256;
-    __shared__ __attribute__((aligned(16))) float As[BK * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+    constexpr int KQ = BKT / 4;                  // float4 per tile row
+    constexpr int RPP = 256 / KQ;                // rows covered per pass of the 256 threads
+    constexpr int A_F4 = BM * BKT / 4 / 256;      // float4 loads per thread for the A tile
+    constexpr int B_F4 = BN * BKT / 4 / 256;
+    __shared__ __attribute__((aligned(16))) float As[BKT * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[BKT * LDB];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
@@ -73,7 +75,20 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
     const long long zo1 = z / g.H, zo2 = z % g.H;
     const float* __restrict__ A = g.A + zo1 * g.bA1 + zo2 * g.bA2;
     const float* __restrict__ Bp = g.B + zo1 * g.bB1 + zo2 * g.bB2;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: the dispatcher places linear block id b on XCD b % 8 (each XCD has a private 4 MB L2), so
+    // give every XCD a CONTIGUOUS range of tiles -- neighbouring conv tiles share their tap windows through that L2.
+    // Bijective for any grid size; a different hardware placement would only change speed, never results.
+    int tile_x, tile_y;
+    {
+        const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+        const int lid = blockIdx.y * gx + blockIdx.x;
+        const int xcd = lid & 7, slot = lid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int lid2 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        tile_x = lid2 % gx;
+        tile_y = lid2 / gx;
+    }
+    const int m0 = tile_y * BM, n0 = tile_x * BN;
 
     // ---------------------------------------------------------------- per-thread load descriptors
     // A, K-contiguous / conv: thread -> (row = tid/4 + 64*i, kq = tid%4); M-contiguous: (k = tid/(BM/4)+..., mq)
@@ -82,7 +97,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
     if (AMODE == A_CONV) {
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
-            const int m = m0 + (tid >> 2) + 64 * i;
+            const int m = m0 + (tid / KQ) + RPP * i;
             a_rowok[i] = m < g.M;
             const int S = g.cg.S_out;
             int r = a_rowok[i] ? m : 0;
@@ -95,13 +110,13 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
     float4 ra[A_F4], rb[B_F4];
 
     auto load_tile = [&](int kt) {
-        const int k0 = kt * BK;
+        const int k0 = kt * BKT;
         // ---- A
         if (AMODE == A_KCONTIG) {
 #pragma unroll
             for (int i = 0; i < A_F4; ++i) {
-                const int m = m0 + (tid >> 2) + 64 * i;
-                const int k = k0 + (tid & 3) * 4;
+                const int m = m0 + (tid / KQ) + RPP * i;
+                const int k = k0 + (tid % KQ) * 4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (m < g.M && k < g.K) v = *reinterpret_cast<const float4*>(A + (long long)m * g.sAm + k);
                 ra[i] = v;
@@ -169,7 +184,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
             const ConvGeom& c = g.cg;
             const int Ct = c.C0 + c.C1;
             const int tap = k0 / Ct;
-            const int cc = k0 - tap * Ct + (tid & 3) * 4;     // channel within the concatenated sources
+            const int cc = k0 - tap * Ct + (tid % KQ) * 4;     // channel within the concatenated sources
             const int tw = tap % c.kext, th = (tap / c.kext) % c.kext, td = tap / (c.kext * c.kext);
             const bool second = cc >= c.C0;
             const float* src = second ? c.src1 : c.src0;
@@ -240,8 +255,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
         } else {
 #pragma unroll
             for (int i = 0; i < B_F4; ++i) {
-                const int n = n0 + (tid >> 2) + 64 * i;
-                const int k = k0 + (tid & 3) * 4;
+                const int n = n0 + (tid / KQ) + RPP * i;
+                const int k = k0 + (tid % KQ) * 4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (n < g.N && k < g.K) v = *reinterpret_cast<const float4*>(Bp + (long long)n * g.sBn + k);
                 rb[i] = v;
@@ -259,7 +274,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
         } else {
 #pragma unroll
             for (int i = 0; i < A_F4; ++i) {
-                const int r = (tid >> 2) + 64 * i, kq = (tid & 3) * 4;
+                const int r = (tid / KQ) + RPP * i, kq = (tid % KQ) * 4;
                 As[(kq + 0) * LDA + r] = ra[i].x;
                 As[(kq + 1) * LDA + r] = ra[i].y;
                 As[(kq + 2) * LDA + r] = ra[i].z;
@@ -275,7 +290,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
         } else {
 #pragma unroll
             for (int i = 0; i < B_F4; ++i) {
-                const int r = (tid >> 2) + 64 * i, kq = (tid & 3) * 4;
+                const int r = (tid / KQ) + RPP * i, kq = (tid % KQ) * 4;
                 Bs[(kq + 0) * LDB + r] = rb[i].x;
                 Bs[(kq + 1) * LDB + r] = rb[i].y;
                 Bs[(kq + 2) * LDB + r] = rb[i].z;
@@ -292,7 +307,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    int nkt = (g.K + BK - 1) / BK;
+    int nkt = (g.K + BKT - 1) / BKT;
     int kt_begin = 0;
     if (g.tiles_per_split > 0) {
         kt_begin = blockIdx.z * g.tiles_per_split;
@@ -305,18 +320,23 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
         __syncthreads();
         if (kt + 1 < nkt) load_tile(kt + 1);
         const int lk = lane >> 5, lm = lane & 31;
+        // issue every LDS fragment read of the tile first: the matrix pipe then never waits for an LDS round trip
+        // (a read-then-multiply loop left ~100 cycles of LDS latency exposed per 256-cycle MFMA group)
+        float av[BKT / 2][TM], bv[BKT / 2][TN];
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float av[TM], bv[TN];
+        for (int kk = 0; kk < BKT; kk += 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = As[(kk + lk) * LDA + wm * (BM / WM) + i * 32 + lm];
+            for (int i = 0; i < TM; ++i) av[kk / 2][i] = As[(kk + lk) * LDA + wm * (BM / WM) + i * 32 + lm];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = Bs[(kk + lk) * LDB + wn * (BN / WN) + j * 32 + lm];
+            for (int j = 0; j < TN; ++j) bv[kk / 2][j] = Bs[(kk + lk) * LDB + wn * (BN / WN) + j * 32 + lm];
+        }
+#pragma unroll
+        for (int kk = 0; kk < BKT; kk += 2) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk / 2][i], bv[kk / 2][j], acc[i][j], 0, 0, 0);
         }
     }
 
@@ -358,17 +378,26 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
     }
 }
 
-template <int AMODE, int BMODE>
-int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
+template <int AMODE, int BMODE, int BKT>
+int launch_gemm_bk(const GemmArgs& g, int batch, hipStream_t st) {
     if (g.N > 64) {
         dim3 grid(vxb_cdiv(g.N, 128), vxb_cdiv(g.M, 128), batch);
-        hipLaunchKernelGGL((gemm_kernel<AMODE, BMODE, 128, 128, 2, 2>), grid, dim3(256), 0, st, g);
+        hipLaunchKernelGGL((gemm_kernel<AMODE, BMODE, 128, 128, 2, 2, BKT>), grid, dim3(256), 0, st, g);
     } else {
         dim3 grid(vxb_cdiv(g.N, 64), vxb_cdiv(g.M, 128), batch);
-        hipLaunchKernelGGL((gemm_kernel<AMODE, BMODE, 128, 64, 2, 2>), grid, dim3(256), 0, st, g);
+        hipLaunchKernelGGL((gemm_kernel<AMODE, BMODE, 128, 64, 2, 2, BKT>), grid, dim3(256), 0, st, g);
     }
     if (hipGetLastError() != hipSuccess) return VXB_ELAUNCH;
     return VXB_OK;
+}
+
+// K tile of 32 (fewer barriers per FLOP) whenever a tile cannot straddle a tap / source boundary, else 16
+template <int AMODE, int BMODE>
+int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
+    const bool conv = AMODE == A_CONV || AMODE == A_CONVT;
+    const bool wide = conv ? ((g.cg.C0 & 31) == 0 && (g.cg.C1 & 31) == 0) : true;
+    if (AMODE == A_CONVT) return launch_gemm_bk<AMODE, BMODE, 16>(g, batch, st);   // reduction runs over positions: keep 16
+    return wide ? launch_gemm_bk<AMODE, BMODE, 32>(g, batch, st) : launch_gemm_bk<AMODE, BMODE, 16>(g, batch, st);
 }
 
 template <int AMODE>
@@ -464,19 +493,19 @@ extern "C" int vxb_conv3d_wgrad_f32(const float* src0, const float* src1, int C0
         gg.d2s_s = -d2s_s;   // negative: "d2s for the B operand only"
         if (N > 64) {
             dim3 grid(vxb_cdiv(N, 128), vxb_cdiv(K, 128), nsplit);
-            hipLaunchKernelGGL((gemm_kernel<A_CONVT, B_D2S, 128, 128, 2, 2>), grid, dim3(256), 0, st, gg);
+            hipLaunchKernelGGL((gemm_kernel<A_CONVT, B_D2S, 128, 128, 2, 2, BK>), grid, dim3(256), 0, st, gg);
         } else {
             dim3 grid(vxb_cdiv(N, 64), vxb_cdiv(K, 128), nsplit);
-            hipLaunchKernelGGL((gemm_kernel<A_CONVT, B_D2S, 128, 64, 2, 2>), grid, dim3(256), 0, st, gg);
+            hipLaunchKernelGGL((gemm_kernel<A_CONVT, B_D2S, 128, 64, 2, 2, BK>), grid, dim3(256), 0, st, gg);
         }
     } else {
         if (ldy & 3) return VXB_ESIZE;
         if (N > 64) {
             dim3 grid(vxb_cdiv(N, 128), vxb_cdiv(K, 128), nsplit);
-            hipLaunchKernelGGL((gemm_kernel<A_CONVT, B_NCONTIG, 128, 128, 2, 2>), grid, dim3(256), 0, st, g);
+            hipLaunchKernelGGL((gemm_kernel<A_CONVT, B_NCONTIG, 128, 128, 2, 2, BK>), grid, dim3(256), 0, st, g);
         } else {
             dim3 grid(vxb_cdiv(N, 64), vxb_cdiv(K, 128), nsplit);
-            hipLaunchKernelGGL((gemm_kernel<A_CONVT, B_NCONTIG, 128, 64, 2, 2>), grid, dim3(256), 0, st, g);
+            hipLaunchKernelGGL((gemm_kernel<A_CONVT, B_NCONTIG, 128, 64, 2, 2, BK>), grid, dim3(256), 0, st, g);
         }
     }
     if (hipGetLastError() != hipSuccess) return VXB_ELAUNCH;
@@ -520,7 +549,20 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs g, const u16* _
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const float* __restrict__ A = g.A;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: the dispatcher places linear block id b on XCD b % 8 (each XCD has a private 4 MB L2), so
+    // give every XCD a CONTIGUOUS range of tiles -- neighbouring conv tiles share their tap windows through that L2.
+    // Bijective for any grid size; a different hardware placement would only change speed, never results.
+    int tile_x, tile_y;
+    {
+        const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+        const int lid = blockIdx.y * gx + blockIdx.x;
+        const int xcd = lid & 7, slot = lid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int lid2 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        tile_x = lid2 % gx;
+        tile_y = lid2 / gx;
+    }
+    const int m0 = tile_y * BM, n0 = tile_x * BN;
 
     int a_b[A_F4], a_d[A_F4], a_h[A_F4], a_w[A_F4];
     bool a_rowok[A_F4];
