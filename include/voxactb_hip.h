@@ -93,6 +93,30 @@ int vxb_conv3d_bf16w_f32(const float* src0, const float* src1, int C0, int C1, i
                          int stride, int kext, int off, int replicate, const void* wt_bf16, int N,
                          const float* bias, float* out, int64_t ldc, int act, float slope, int accumulate,
                          int d2s_s, int d2s_C, vxb_stream_t stream);
+/* "bf16x3" split-product twins of the three entries above and below: each fp32 operand value a is used as
+ * hi = bf16(a), lo = bf16(a - hi) and a product is evaluated as hi*hi + hi*lo + lo*hi on the bf16 matrix cores with fp32
+ * accumulation -- dropped terms <= 2^-16 relative per product, 3 MFMAs at 16x the fp32-MFMA rate.  Weights come
+ * pre-split as bf16 planes [2][N][K] (hi plane, then lo plane). */
+int vxb_gemm_bf16x3_f32(const float* A, int64_t lda, const void* Bw, float* C, int64_t ldc, const float* bias,
+                        const float* residual, int M, int N, int K, int act, float slope, int accumulate,
+                        vxb_stream_t stream);
+int vxb_conv3d_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
+                          int stride, int kext, int off, int replicate, const void* wt_bf16, int N,
+                          const float* bias, float* out, int64_t ldc, int act, float slope, int accumulate,
+                          int d2s_s, int d2s_C, vxb_stream_t stream);
+int vxb_conv3d_wgrad_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
+                                int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
+                                int d2s_s, int d2s_C, float* part, int nsplit, vxb_stream_t stream);
+/* LDS-halo specialisation of vxb_conv3d_bf16w_f32 for kext == 3, stride == 1 (the `final` conv of the Q-function,
+ * perceiver_lang_io.py:462-466, and its data gradient): a 4x8x8 block of output voxels stages its 6x10x10 input halo
+ * once instead of once per tap.  C0, C1 % 32 == 0, N in {64, 128}; out [B, S_out^3, N] is overwritten.  The x3 entry
+ * takes the hi/lo weight planes [2][N][K] of the bf16x3 split. */
+int vxb_conv3_halo_bf16w_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
+                             int off, int replicate, const void* wt_bf16, int N, const float* bias, float* out,
+                             int act, float slope, vxb_stream_t stream);
+int vxb_conv3_halo_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
+                              int off, int replicate, const void* wt_bf16, int N, const float* bias, float* out,
+                              int act, float slope, vxb_stream_t stream);
 /* bf16 matrix-core weight gradient (same contract as vxb_conv3d_wgrad_f32): both operands are staged position-major and
  * transposed for the matrix cores by ds_read_b64_tr_b16. */
 int vxb_conv3d_wgrad_bf16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,

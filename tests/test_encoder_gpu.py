@@ -40,7 +40,7 @@ def maxerr(a, b):
     return float((a.detach().float().cpu() - b.detach().float().cpu()).abs().max())
 
 
-def run_fixture(g, cams):
+def run_fixture(g, cams, precision='fp32'):
     arm = bool(g['cfg_arm'])
     enc, sd = build_encoder(g, arm)
     rs = batch(g, cams)
@@ -48,6 +48,7 @@ def run_fixture(g, cams):
     B = int(g['cfg_B'])
     grid = T(g['grid']).to(DEV)
     eng = enc.engine()
+    eng.precision = precision
     outs, cache = eng.forward(grid, rs['low_dim_state'].to(DEV), rs['lang_token_embs'].to(DEV), training=False, save=True)
     # intermediates first: a failure here localises the broken stage
     for name, mine in (('int_z1', cache['z1'].permute(0, 4, 1, 2, 3)), ('int_feats', cache['feats'])):
@@ -107,6 +108,12 @@ def test_encoder_tiny_fixture(golden):
 
 def test_encoder_c1_fixture(golden):
     run_fixture(golden('f3_encoder_c1'), ['front'])
+
+
+def test_encoder_fixtures_bf16x3_split_mode(golden):
+    """'bf16x3' (hi/lo split products on the bf16 matrix cores) is held to the SAME bounds as the exact-fp32 mode."""
+    run_fixture(golden('f3_encoder_tiny'), ['front', 'wrist'], precision='bf16x3')
+    run_fixture(golden('f3_encoder_c1'), ['front'], precision='bf16x3')
 
 
 def test_dropout_training_mode_runs_and_is_reproducible(golden):

@@ -249,11 +249,13 @@ class PerceiverEngine:
         self._Lt = None
         self.step_seed = 0
         # 'fp32': exact fp32 matrix cores everywhere (parity mode).  'bf16': forward / data-gradient convs and large
-        # linears on bf16 matrix cores with fp32 accumulation (throughput mode; see ops.PRECISION).
+        # linears on bf16 matrix cores with fp32 accumulation (throughput mode; see ops.PRECISION).  'bf16x3': the same
+        # kernels with every fp32 operand split into hi + lo bf16 halves and three MFMAs per product (fp32-faithful to
+        # ~2^-16 per product; attention core stays on the exact fp32 matrix cores).
         import os
         self.precision = os.environ.get('VOXACTB_PRECISION', 'fp32')
-        if self.precision not in ('fp32', 'bf16'):
-            raise ValueError('VOXACTB_PRECISION must be fp32 or bf16')
+        if self.precision not in ('fp32', 'bf16', 'bf16x3'):
+            raise ValueError('VOXACTB_PRECISION must be fp32, bf16x3 or bf16')
 
     # -------------------------------------------------------------------------------------------------- helpers
     def p(self, name):

@@ -1,0 +1,281 @@
+// LDS-halo 3x3x3 stride-1 conv3d on the bf16 matrix cores -- the `final` conv of the Q-function
+// (perceiver_lang_io.py:462, 442 GF/sample forward) and its data gradient, in the 'bf16' and 'bf16x3' precisions.
+//
+// The generic implicit-GEMM kernel (gemm_conv.hip) re-fetches every input voxel once per tap (27x) through L2, which
+// bounds it at ~250-400 TF/s in bf16.  Here one workgroup owns a 4x8x8 block of output voxels:
+//   * the 6x10x10 input halo of one channel chunk is staged ONCE into LDS (fp32 -> bf16 on the way, replicate padding
+//     by clamping / zero padding by predication): 2.3x amplification instead of 27x;
+//   * per tap only the [N][chunk] weight slice is streamed (double-buffered in LDS) and the A operand of
+//     v_mfma_f32_32x32x16_bf16 is read straight out of the halo at a shifted address.
+// A chunk is 32 bf16 per voxel: 32 channels ('bf16') or 16 channels as hi|lo halves ('bf16x3': hi = bf16(a),
+// lo = bf16(a - hi), products hi*hi + hi*lo + lo*hi).  That keeps a workgroup at 68-78 KB of LDS and <= 256 VGPRs, so
+// TWO workgroups share a CU and one's halo fetch hides behind the other's MFMAs (global loads retire in order, so
+// prefetching the next halo inside one wave would stall on the per-tap weight loads instead).
+// LDS layout: halo[(d*10 + h)*12 + w][40 bf16]: with 80-byte voxels and a padded row length of 12 the 8(h) x 4(w)
+// patch of voxels that forms one 32-row MFMA tile is conflict-free for ds_read_b128 (brute-forced over the four
+// 16-lane service groups of that instruction).  Output: C[row = voxel][col = channel] -> 128-byte stores per voxel.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+constexpr int TD = 4, TH = 8, TW = 8;                 // output tile
+constexpr int HDp = TD + 2, HHp = TH + 2, HWp = 12;   // halo extents (w padded 10 -> 12)
+constexpr int HW_USED = TW + 2;
+constexpr int NPOS = HDp * HHp * HW_USED;             // 600 staged voxels
+constexpr int SP = 40;                                // bf16 per halo voxel (32 + 8 pad)
+constexpr int LDW = 40;                               // bf16 per weight row (32 + 8 pad)
+constexpr int HALO_SLOTS = HDp * HHp * HWp;           // 720
+
+struct HaloArgs {
+    const float* src0;
+    const float* src1;
+    int C0, C1;
+    int B, S_in, S_out, off, replicate;
+    const u16* wb;          // bf16 [N][K] (x3: planes [2][N][K]), K = 27 * (C0 + C1), k = tap * (C0 + C1) + channel
+    int N, K;
+    const float* bias;
+    float* out;             // [B, S_out^3, N]
+    int act;
+    float slope;
+    int ntd, nth, ntw;
+};
+
+__device__ __forceinline__ unsigned hb_pack2(float lo, float hi) {
+    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
+    a += 0x7fffu + ((a >> 16) & 1u);
+    b += 0x7fffu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xffff0000u);
+}
+
+template <int NT, int X3>     // NT = N / 32 column tiles per wave (2 or 4)
+__global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {
+    extern __shared__ __attribute__((aligned(16))) u16 smem[];
+    u16* halo = smem;                               // [HALO_SLOTS][SP]
+    u16* wsm = smem + HALO_SLOTS * SP;              // [2][N][LDW]
+    constexpr int N = NT * 32;
+    constexpr int CPC = X3 ? 16 : 32;               // channels per chunk
+    constexpr int F4P = CPC / 4;                    // float4 per voxel per chunk
+    constexpr int NLD = (NPOS * F4P + 255) / 256;   // halo float4 loads per thread per chunk (10 / 19)
+    constexpr int W_V8 = N * 4 / 256;               // 16-byte weight loads per thread per tap (1 / 2)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int hi = lane >> 5, lq = lane & 31;
+    int t = blockIdx.x;
+    const int tw = t % g.ntw; t /= g.ntw;
+    const int th = t % g.nth; t /= g.nth;
+    const int td = t % g.ntd; t /= g.ntd;
+    const int b = t;
+    const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
+    const int Ct = g.C0 + g.C1;
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // A-operand base slots of this wave's two M tiles: tile mt = wid*2 + i -> d = mt >> 1, w half = mt & 1;
+    // lane row: h = lq >> 2, w = (mt & 1) * 4 + (lq & 3)
+    int abase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int mt = wid * 2 + i;
+        abase[i] = (((mt >> 1) * HHp + (lq >> 2)) * HWp + (mt & 1) * 4 + (lq & 3)) * SP + 8 * hi;
+    }
+    const int wrow = lq * LDW + 8 * hi;            // B-operand row of this lane inside a weight tile (+ nt*32*LDW)
+
+    // halo staging slots of this thread: element e = tid + 256 i -> voxel e / F4P, channel quad e % F4P
+    int st_goff[NLD];      // voxel offset in the source cube (in voxels), -1 = zero fill / unused
+    int st_soff[NLD];      // LDS offset (u16)
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = tid + 256 * i;
+        int p = e / F4P;
+        const int c4 = (e % F4P) * 4;
+        st_goff[i] = -1;
+        st_soff[i] = 0;
+        if (p < NPOS) {
+            const int pw = p % HW_USED; p /= HW_USED;
+            const int ph = p % HHp; p /= HHp;
+            const int pd = p;
+            int id = d0 + pd + g.off, ih = h0 + ph + g.off, iw = w0 + pw + g.off;
+            bool ok = true;
+            if (g.replicate) {
+                id = min(max(id, 0), g.S_in - 1); ih = min(max(ih, 0), g.S_in - 1); iw = min(max(iw, 0), g.S_in - 1);
+            } else {
+                ok = id >= 0 && id < g.S_in && ih >= 0 && ih < g.S_in && iw >= 0 && iw < g.S_in;
+            }
+            st_soff[i] = ((pd * HHp + ph) * HWp + pw) * SP + c4;
+            if (ok) st_goff[i] = (id * g.S_in + ih) * g.S_in + iw;
+            else st_goff[i] = -2;                   // staged as zeros
+        }
+    }
+    const long long bvox = (long long)b * g.S_in * g.S_in * g.S_in;
+
+    uint4 rw[W_V8];
+    const int nchunk = Ct / CPC;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int cb = ch * CPC;
+        const bool second = cb >= g.C0;
+        const float* src = second ? g.src1 : g.src0;
+        const int Cs = second ? g.C1 : g.C0;
+        const int c0 = second ? cb - g.C0 : cb;
+        // ---- fetch the halo of this chunk (all loads in flight together), then convert + store
+        float4 hv[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            hv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (st_goff[i] >= 0)
+                hv[i] = *reinterpret_cast<const float4*>(src + (bvox + st_goff[i]) * Cs + c0 + (((tid + 256 * i) % F4P) * 4));
+        }
+        // weights of tap 0 (tile [N][32 u16]: bf16 -> 32 channels; x3 -> hi 16 | lo 16)
+#define HB_LOAD_W(tap_)                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < W_V8; ++i) {                                                                \
+        const int e = tid + 256 * i;                                                                                 \
+        const int n = e >> 2, q = e & 3;                                                                             \
+        const u16* wp = X3 ? g.wb + (long long)(q >> 1) * N * g.K + (long long)n * g.K + (tap_) * Ct + cb + (q & 1) * 8 \
+                           : g.wb + (long long)n * g.K + (tap_) * Ct + cb + q * 8;                                   \
+        rw[i] = *reinterpret_cast<const uint4*>(wp);                                                                 \
+    }
+#define HB_STORE_W(buf_)                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < W_V8; ++i) {                                                                \
+        const int e = tid + 256 * i;                                                                                 \
+        *reinterpret_cast<uint4*>(&wsm[(buf_) * N * LDW + (e >> 2) * LDW + (e & 3) * 8]) = rw[i];                     \
+    }
+        HB_LOAD_W(0)
+        __syncthreads();                            // every wave is done with the previous chunk's halo / weights
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            if (st_goff[i] != -1) {
+                uint2 pk;
+                pk.x = hb_pack2(hv[i].x, hv[i].y); pk.y = hb_pack2(hv[i].z, hv[i].w);
+                *reinterpret_cast<uint2*>(&halo[st_soff[i]]) = pk;
+                if (X3) {
+                    uint2 q;
+                    q.x = hb_pack2(hv[i].x - __uint_as_float(pk.x << 16), hv[i].y - __uint_as_float(pk.x & 0xffff0000u));
+                    q.y = hb_pack2(hv[i].z - __uint_as_float(pk.y << 16), hv[i].w - __uint_as_float(pk.y & 0xffff0000u));
+                    *reinterpret_cast<uint2*>(&halo[st_soff[i] + 16]) = q;
+                }
+            }
+        }
+        HB_STORE_W(0)
+        __syncthreads();
+        for (int tap = 0; tap < 27; ++tap) {
+            const int cur = tap & 1;
+            if (tap + 1 < 27) { HB_LOAD_W(tap + 1) }
+            const int tdz = tap / 9, thy = (tap / 3) % 3, twx = tap % 3;
+            const int toff = ((tdz * HHp + thy) * HWp + twx) * SP;
+            const u16* wcur = wsm + cur * N * LDW;
+            if (X3) {
+                bf16x8 ah[2], al[2], bh[NT], bl[NT];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ah[i] = *reinterpret_cast<const bf16x8*>(&halo[abase[i] + toff]);
+                    al[i] = *reinterpret_cast<const bf16x8*>(&halo[abase[i] + toff + 16]);
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    bh[j] = *reinterpret_cast<const bf16x8*>(&wcur[j * 32 * LDW + wrow]);
+                    bl[j] = *reinterpret_cast<const bf16x8*>(&wcur[j * 32 * LDW + wrow + 16]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 a[2], bb[NT];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(&halo[abase[i] + toff + 16 * ks]);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bb[j] = *reinterpret_cast<const bf16x8*>(&wcur[j * 32 * LDW + wrow + 16 * ks]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);
+                }
+            }
+            if (tap + 1 < 27) { HB_STORE_W(cur ^ 1) }     // other buffer: last read one tap ago, a barrier has passed since
+            __syncthreads();
+        }
+    }
+    // ---- epilogue: acc[i][j][r] = C[voxel row (r&3) + 8*(r>>2) + 4*hi of M tile i][channel j*32 + lq]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int mt = wid * 2 + i;
+        const int od = d0 + (mt >> 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int oh = h0 + (m >> 2), ow = w0 + (mt & 1) * 4 + (m & 3);
+            if (od < g.S_out && oh < g.S_out && ow < g.S_out) {
+                float* op = g.out + ((((long long)b * g.S_out + od) * g.S_out + oh) * g.S_out + ow) * N;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int n = j * 32 + lq;
+                    float v = acc[i][j][r] + (g.bias ? g.bias[n] : 0.f);
+                    if (g.act == 1) v = v > 0.f ? v : v * g.slope;
+                    op[n] = v;
+                }
+            }
+        }
+    }
+}
+
+inline bool hb_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+template <int NT, int X3>
+int hb_launch(const HaloArgs& g, long long nblk, hipStream_t st) {
+    const size_t lds = (size_t)(HALO_SLOTS * SP + 2 * NT * 32 * LDW) * sizeof(u16);
+    if (hipFuncSetAttribute((const void*)conv3_halo_kernel<NT, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return VXB_ELAUNCH;
+    hipLaunchKernelGGL((conv3_halo_kernel<NT, X3>), dim3((unsigned)nblk), dim3(256), lds, st, g);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+int hb_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out, int off, int replicate,
+            const void* wt_bf16, int N, const float* bias, float* out, int act, float slope, vxb_stream_t stream) {
+    if (!src0 || !wt_bf16 || !out || B < 1 || S_in < 1 || S_out < 1) return VXB_EARG;
+    if ((C0 & 31) || (C1 & 31) || C0 < 32 || (C1 > 0 && !src1) || (N != 64 && N != 128)) return VXB_ESIZE;
+    if (!hb_aligned16(src0) || !hb_aligned16(wt_bf16) || (src1 && !hb_aligned16(src1))) return VXB_ESIZE;
+    if ((long long)S_in * S_in * S_in >= INT32_MAX) return VXB_ESIZE;
+    HaloArgs g;
+    g.src0 = src0; g.src1 = src1; g.C0 = C0; g.C1 = C1; g.B = B; g.S_in = S_in; g.S_out = S_out; g.off = off;
+    g.replicate = replicate; g.wb = (const u16*)wt_bf16; g.N = N; g.K = 27 * (C0 + C1); g.bias = bias; g.out = out;
+    g.act = act; g.slope = slope;
+    g.ntd = vxb_cdiv(S_out, TD); g.nth = vxb_cdiv(S_out, TH); g.ntw = vxb_cdiv(S_out, TW);
+    const long long nblk = (long long)B * g.ntd * g.nth * g.ntw;
+    if (nblk >= INT32_MAX) return VXB_ESIZE;
+    hipStream_t st = (hipStream_t)stream;
+    if (N == 64) return x3 ? hb_launch<2, 1>(g, nblk, st) : hb_launch<2, 0>(g, nblk, st);
+    return x3 ? hb_launch<4, 1>(g, nblk, st) : hb_launch<4, 0>(g, nblk, st);
+}
+
+}  // namespace
+
+// 3x3x3, stride-1 twin of vxb_conv3d_bf16w_f32 (same weights layout bf16 [N][27*(C0+C1)], same padding semantics:
+// src voxel = out + tap + off per axis); C0, C1 multiples of 32, N in {64, 128}.  out [B, S_out^3, N] is overwritten.
+extern "C" int vxb_conv3_halo_bf16w_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
+                                        int off, int replicate, const void* wt_bf16, int N, const float* bias, float* out,
+                                        int act, float slope, vxb_stream_t stream) {
+    return hb_impl(0, src0, src1, C0, C1, B, S_in, S_out, off, replicate, wt_bf16, N, bias, out, act, slope, stream);
+}
+
+// 'bf16x3' twin (weights = planes [2][N][K], see vxb_conv3d_bf16x3_f32).
+extern "C" int vxb_conv3_halo_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
+                                         int off, int replicate, const void* wt_bf16, int N, const float* bias, float* out,
+                                         int act, float slope, vxb_stream_t stream) {
+    return hb_impl(1, src0, src1, C0, C1, B, S_in, S_out, off, replicate, wt_bf16, N, bias, out, act, slope, stream);
+}

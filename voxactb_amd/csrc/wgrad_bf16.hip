@@ -44,7 +44,8 @@ __device__ __forceinline__ unsigned long long ds_read_tr16(unsigned addr) {
 
 constexpr int BP = 32;      // positions per K-tile
 
-template <int BN>
+// X3 = 1: "bf16x3" split products (see gemm_conv.hip): both operands are staged as hi/lo bf16 planes, 3 MFMAs per product.
+template <int BN, int X3>
 __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
     constexpr int BM = 128;                       // (tap, ci) rows per block
     constexpr int LDA = BM + 32;                  // 160 bf16 = 80 dwords  (= 16 mod 64)
@@ -53,8 +54,8 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_F4 = BP * BM / 4 / 256;       // 4
     constexpr int B_F4 = BP * BN / 4 / 256;       // 4 or 2
-    __shared__ __attribute__((aligned(16))) u16 As[BP * LDA];
-    __shared__ __attribute__((aligned(16))) u16 Bs[BP * LDB];
+    __shared__ __attribute__((aligned(16))) u16 As[(1 + X3) * BP * LDA];
+    __shared__ __attribute__((aligned(16))) u16 Bs[(1 + X3) * BP * LDB];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
@@ -165,12 +166,24 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
             uint2 p;
             p.x = pack_bf16_2(ra[i].x, ra[i].y); p.y = pack_bf16_2(ra[i].z, ra[i].w);
             *reinterpret_cast<uint2*>(&As[((tid >> 5) + 8 * i) * LDA + (tid & 31) * 4]) = p;
+            if (X3) {
+                uint2 q;
+                q.x = pack_bf16_2(ra[i].x - __uint_as_float(p.x << 16), ra[i].y - __uint_as_float(p.x & 0xffff0000u));
+                q.y = pack_bf16_2(ra[i].z - __uint_as_float(p.y << 16), ra[i].w - __uint_as_float(p.y & 0xffff0000u));
+                *reinterpret_cast<uint2*>(&As[BP * LDA + ((tid >> 5) + 8 * i) * LDA + (tid & 31) * 4]) = q;
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             uint2 p;
             p.x = pack_bf16_2(rb[i].x, rb[i].y); p.y = pack_bf16_2(rb[i].z, rb[i].w);
             *reinterpret_cast<uint2*>(&Bs[(tid / (BN / 4) + (256 / (BN / 4)) * i) * LDB + (tid % (BN / 4)) * 4]) = p;
+            if (X3) {
+                uint2 q;
+                q.x = pack_bf16_2(rb[i].x - __uint_as_float(p.x << 16), rb[i].y - __uint_as_float(p.x & 0xffff0000u));
+                q.y = pack_bf16_2(rb[i].z - __uint_as_float(p.y << 16), rb[i].w - __uint_as_float(p.y & 0xffff0000u));
+                *reinterpret_cast<uint2*>(&Bs[BP * LDB + (tid / (BN / 4) + (256 / (BN / 4)) * i) * LDB + (tid % (BN / 4)) * 4]) = q;
+            }
         }
     };
 
@@ -204,18 +217,43 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
 #pragma unroll
         for (int kk = 0; kk < BP; kk += 16) {
             unsigned long long a0[TM], a1[TM], b0[TN], b1[TN];
+            unsigned long long al0[TM], al1[TM], bl0[TN], bl1[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 a0[i] = ds_read_tr16(a_base + 2u * (unsigned)((kk + 0) * LDA + i * 32));
                 a1[i] = ds_read_tr16(a_base + 2u * (unsigned)((kk + 4) * LDA + i * 32));
+                if (X3) {
+                    al0[i] = ds_read_tr16(a_base + 2u * (unsigned)(BP * LDA + (kk + 0) * LDA + i * 32));
+                    al1[i] = ds_read_tr16(a_base + 2u * (unsigned)(BP * LDA + (kk + 4) * LDA + i * 32));
+                }
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 b0[j] = ds_read_tr16(b_base + 2u * (unsigned)((kk + 0) * LDB + j * 32));
                 b1[j] = ds_read_tr16(b_base + 2u * (unsigned)((kk + 4) * LDB + j * 32));
+                if (X3) {
+                    bl0[j] = ds_read_tr16(b_base + 2u * (unsigned)(BP * LDB + (kk + 0) * LDB + j * 32));
+                    bl1[j] = ds_read_tr16(b_base + 2u * (unsigned)(BP * LDB + (kk + 4) * LDB + j * 32));
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            if (X3) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    union { unsigned long long u[2]; bf16x8 v; } fa, fl;
+                    fa.u[0] = a0[i]; fa.u[1] = a1[i];
+                    fl.u[0] = al0[i]; fl.u[1] = al1[i];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        union { unsigned long long u[2]; bf16x8 v; } fb, fm;
+                        fb.u[0] = b0[j]; fb.u[1] = b1[j];
+                        fm.u[0] = bl0[j]; fm.u[1] = bl1[j];
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl.v, fb.v, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fm.v, acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 union { unsigned long long u[2]; bf16x8 v; } fa;
@@ -247,10 +285,9 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
 
 }  // namespace
 
-// Same contract as vxb_conv3d_wgrad_f32 (include/voxactb_hip.h); operands are rounded to bf16 while staged, fp32 accumulate.
-extern "C" int vxb_conv3d_wgrad_bf16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
-                                         int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
-                                         int d2s_s, int d2s_C, float* part, int nsplit, vxb_stream_t stream) {
+static int wgrad_bf16_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
+                          int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
+                          int d2s_s, int d2s_C, float* part, int nsplit, vxb_stream_t stream) {
     if (!src0 || !dy || !part || B < 1 || S_in < 1 || S_out < 1 || kext < 1 || stride < 1 || N < 1 || nsplit < 1) return VXB_EARG;
     if ((C0 & 3) || (C1 & 3) || C0 < 4 || (C1 > 0 && !src1) || (N & 3)) return VXB_ESIZE;
     if (d2s_s > 0 && (d2s_C < 4 || (d2s_C & 3) || N % d2s_C)) return VXB_EARG;
@@ -266,11 +303,29 @@ extern "C" int vxb_conv3d_wgrad_bf16_f32(const float* src0, const float* src1, i
     hipStream_t st = (hipStream_t)stream;
     if (N > 64) {
         dim3 grid(vxb_cdiv(N, 128), vxb_cdiv(K, 128), nsplit);
-        hipLaunchKernelGGL(wgrad_bf16_kernel<128>, grid, dim3(256), 0, st, g);
+        if (x3) hipLaunchKernelGGL((wgrad_bf16_kernel<128, 1>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((wgrad_bf16_kernel<128, 0>), grid, dim3(256), 0, st, g);
     } else {
         dim3 grid(vxb_cdiv(N, 64), vxb_cdiv(K, 128), nsplit);
-        hipLaunchKernelGGL(wgrad_bf16_kernel<64>, grid, dim3(256), 0, st, g);
+        if (x3) hipLaunchKernelGGL((wgrad_bf16_kernel<64, 1>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((wgrad_bf16_kernel<64, 0>), grid, dim3(256), 0, st, g);
     }
     VXB_CHECK_LAUNCH();
     return VXB_OK;
+}
+
+// Same contract as vxb_conv3d_wgrad_f32 (include/voxactb_hip.h); operands are rounded to bf16 while staged, fp32 accumulate.
+extern "C" int vxb_conv3d_wgrad_bf16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
+                                         int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
+                                         int d2s_s, int d2s_C, float* part, int nsplit, vxb_stream_t stream) {
+    return wgrad_bf16_impl(0, src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, replicate, dy, N, ldy, d2s_s, d2s_C, part,
+                           nsplit, stream);
+}
+
+// "bf16x3" twin: both operands split into hi/lo bf16 planes while staged; hi*hi + hi*lo + lo*hi, fp32 accumulate.
+extern "C" int vxb_conv3d_wgrad_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
+                                           int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
+                                           int d2s_s, int d2s_C, float* part, int nsplit, vxb_stream_t stream) {
+    return wgrad_bf16_impl(1, src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, replicate, dy, N, ldy, d2s_s, d2s_C, part,
+                           nsplit, stream);
 }

@@ -15,6 +15,7 @@ _NAIVE_MACS = 1 << 22
 # 'bf16' = forward + data-gradient convs and large linears on bf16 MFMA with fp32 accumulation (throughput mode;
 # weight gradients, attention softmax path and every streaming kernel stay fp32).  Set by PerceiverEngine per call.
 PRECISION = 'fp32'
+HALO_CONV = True     # 3x3x3 stride-1 bf16 convs go through the LDS-halo kernel (conv_halo_bf16.hip)
 _WCACHE = {}
 
 
@@ -23,11 +24,26 @@ def new_step():
     _WCACHE.clear()
 
 
+def split_bf16(w, x3=None):
+    """fp32 [N][K] -> bf16 [N][K] ('bf16') or the hi/lo planes [2][N][K] of the 'bf16x3' split (lo = bf16(w - hi))."""
+    if x3 is None:
+        x3 = PRECISION == 'bf16x3'
+    hi = w.to(torch.bfloat16)
+    if not x3:
+        return hi
+    return torch.stack((hi, (w - hi.float()).to(torch.bfloat16)))
+
+
+def _mm():
+    """matrix-core mode of the large GEMMs / convs: False = fp32 MFMA, True = bf16 MFMA (plain or x3 split)."""
+    return PRECISION in ('bf16', 'bf16x3')
+
+
 def _bf16_weight(W, transposed):
-    key = (W.data_ptr(), tuple(W.shape), transposed)
+    key = (W.data_ptr(), tuple(W.shape), transposed, PRECISION)
     wb = _WCACHE.get(key)
     if wb is None:
-        wb = (W.t().contiguous() if transposed else W.contiguous()).to(torch.bfloat16)
+        wb = split_bf16(W.t().contiguous() if transposed else W.contiguous())
         _WCACHE[key] = wb
     return wb
 
@@ -67,7 +83,7 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None):
         naive_gemm(x, W, out, M, N, K, x.stride(0), 1, 1, W.stride(0), out.stride(0), bias, act)
         if residual is not None:
             axpy_(out, residual)
-    elif PRECISION == 'bf16' and K % 8 == 0 and W.is_contiguous():
+    elif _mm() and K % 8 == 0 and W.is_contiguous():
         gemm_bf16w(x, _bf16_weight(W, False), out, bias, act, residual, label='gemm_fwd %dx%dx%d' % (M, N, K))
     else:
         gemm(x, W, out, M, N, K, x.stride(0), 1, 1, W.stride(0), out.stride(0), bias=bias, residual=residual, act=act,
@@ -91,7 +107,7 @@ def linear_bwd(x, W, dy, dW, db=None, dx=None, dx_accumulate=False, ws=None):
             cands = [d for d in range(1, 65) if M % d == 0 and (M // d) >= 256]
             ok = [d for d in cands if tiles * d >= 512]
             ns = min(ok) if ok else (max(cands) if cands else 1)
-        if PRECISION == 'bf16' and dW.is_contiguous() and dy.stride(0) == N:
+        if _mm() and dW.is_contiguous() and dy.stride(0) == N:
             # both operands are row(position)-major -> the transposed-read bf16 kernel (a 1x1x1 "conv" over M positions)
             nsb = max(1, min(64, (512 + tiles - 1) // tiles, M // 256))
             res = conv3d_wgrad(dy, x, K, M, 1, 1, 1, 0, ldy=x.stride(0), nsplit=nsb, label='gemm_wgrad %dx%dx%d' % (N, K, M))
@@ -104,7 +120,7 @@ def linear_bwd(x, W, dy, dW, db=None, dx=None, dx_accumulate=False, ws=None):
             sum_splits(part, ns, N * K, dW, accumulate=True)
         else:
             gemm(dy, x, dW, N, K, M, 1, dy.stride(0), x.stride(0), 1, dW.stride(0), accumulate=True, label='gemm_wgrad %dx%dx%d' % (N, K, M))
-        if dx is not None and PRECISION == 'bf16' and N % 8 == 0 and W.is_contiguous():
+        if dx is not None and _mm() and N % 8 == 0 and W.is_contiguous():
             gemm_bf16w(dy, _bf16_weight(W, True), dx, accumulate=dx_accumulate, label='gemm_dgrad %dx%dx%d' % (M, K, N))
         elif dx is not None:
             gemm(dy, W, dx, M, K, N, dy.stride(0), 1, W.stride(0), 1, dx.stride(0), accumulate=dx_accumulate,
@@ -195,7 +211,7 @@ def conv3d(src0, wt, N, B, S_in, S_out, kext, off, stride=1, replicate=True, bia
            out=None, ldc=None, accumulate=False, d2s=(0, 0), label=None):
     C0 = src0.shape[-1]
     C1 = src1.shape[-1] if src1 is not None else 0
-    if PRECISION == 'bf16' and C0 % 32 == 0 and C1 % 32 == 0 and wt.dtype == torch.float32:
+    if _mm() and C0 % 32 == 0 and C1 % 32 == 0 and wt.dtype == torch.float32:
         return conv3d_bf16w(src0, to_bf16_nk(wt), N, B, S_in, S_out, kext, off, stride, replicate, bias, act, src1, out, ldc,
                             accumulate, d2s, label)
     if out is None:
@@ -224,8 +240,9 @@ def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
         nsplit = max(1, min(64, 1024 // max(tiles, 1), (P + 4095) // 4096))
     part = torch.empty((nsplit, K, N), dtype=torch.float32, device=src0.device)
     _lib.set_meta(label or 'conv3d_wgrad[k%d s%d %d->%d S%d]' % (kext, stride, C0 + C1, N, S_out), 2.0 * P * N * K)
-    call('vxb_conv3d_wgrad_bf16_f32' if (PRECISION == 'bf16' or force_bf16) else 'vxb_conv3d_wgrad_f32',
-         src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, int(replicate), dy, N,
+    entry = {'bf16': 'vxb_conv3d_wgrad_bf16_f32', 'bf16x3': 'vxb_conv3d_wgrad_bf16x3_f32'}.get(
+        force_bf16 if isinstance(force_bf16, str) else ('bf16' if force_bf16 else PRECISION), 'vxb_conv3d_wgrad_f32')
+    call(entry, src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, int(replicate), dy, N,
          ldy if ldy is not None else N, d2s[0], d2s[1], part, nsplit)
     if nsplit == 1:
         return part[0]
@@ -406,12 +423,13 @@ def ce_rows(logits, segs, labels, dlogits=None, gscale=1.0):
 def gemm_bf16w(x, Wb, out=None, bias=None, act=ACT_NONE, residual=None, accumulate=False, label=None):
     """out[M,N] = act(x[M,K] (fp32 -> bf16 on the fly) @ Wb[N,K]^T (bf16) + bias) (+ residual), fp32 accumulate."""
     M, K = x.shape
-    N = Wb.shape[0]
-    assert Wb.dtype == torch.bfloat16 and Wb.is_contiguous() and Wb.shape[1] == K
+    x3 = Wb.dim() == 3          # hi/lo planes of the bf16x3 split
+    N = Wb.shape[-2]
+    assert Wb.dtype == torch.bfloat16 and Wb.is_contiguous() and Wb.shape[-1] == K
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
     _lib.set_meta(label or 'gemm_bf16 %dx%dx%d' % (M, N, K), 2.0 * M * N * K)
-    call('vxb_gemm_bf16w_f32', x, x.stride(0), Wb, out, out.stride(0), bias, residual, M, N, K, act, LRELU_SLOPE,
+    call('vxb_gemm_bf16x3_f32' if x3 else 'vxb_gemm_bf16w_f32', x, x.stride(0), Wb, out, out.stride(0), bias, residual, M, N, K, act, LRELU_SLOPE,
          int(accumulate))
     return out
 
@@ -430,11 +448,18 @@ def conv3d_bf16w(src0, wb, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
             out = torch.empty((B, S_out, S_out, S_out, N), dtype=torch.float32, device=src0.device)
     _lib.set_meta(label or 'conv3d_bf16[k%d s%d %d->%d S%d%s]' % (kext, stride, C0 + C1, N, S_out, '' if replicate else ' dgrad'),
                   2.0 * B * S_out ** 3 * N * kext ** 3 * (C0 + C1))
-    call('vxb_conv3d_bf16w_f32', src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, int(replicate), wb, N, bias, out,
+    x3 = wb.dim() == 3
+    if (HALO_CONV and kext == 3 and stride == 1 and d2s[0] == 0 and not accumulate and N in (64, 128)
+            and (ldc is None or ldc == N) and S_out >= 16):
+        call('vxb_conv3_halo_bf16x3_f32' if x3 else 'vxb_conv3_halo_bf16w_f32', src0, src1, C0, C1, B, S_in, S_out, off, int(replicate), wb, N, bias, out,
+             act, LRELU_SLOPE)
+        return out
+    call('vxb_conv3d_bf16x3_f32' if x3 else 'vxb_conv3d_bf16w_f32', src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, int(replicate), wb, N, bias, out,
          ldc if ldc is not None else N, act, LRELU_SLOPE, int(accumulate), d2s[0], d2s[1])
     return out
 
 
 def to_bf16_nk(wt_kn):
-    """[K][N] fp32 weight layout of the fp32 kernels -> bf16 [N][K] (one small transposing copy per step)."""
-    return wt_kn.t().contiguous().to(torch.bfloat16)
+    """[K][N] fp32 weight layout of the fp32 kernels -> bf16 [N][K] (one small transposing copy per step); in 'bf16x3'
+    mode the hi/lo planes [2][N][K]."""
+    return split_bf16(wt_kn.t().contiguous())
