@@ -117,6 +117,14 @@ int vxb_conv3_halo_bf16w_f32(const float* src0, const float* src1, int C0, int C
 int vxb_conv3_halo_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                               int off, int replicate, const void* wt_bf16, int N, const float* bias, float* out,
                               int act, float slope, vxb_stream_t stream);
+/* LDS-halo weight gradient of the same 3x3x3 stride-1 convs (contract of vxb_conv3d_wgrad_f32 with kext = 3, stride = 1;
+ * the z slices of part[z][K][N] are runs of 2x8x8 voxel tiles).  C0, C1 % 16 == 0, N % 64 == 0; d2s needs d2s_C == 64. */
+int vxb_conv3_wgrad_halo_bf16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
+                                  int off, int replicate, const float* dy, int N, int64_t ldy, int d2s_s, int d2s_C,
+                                  float* part, int nsplit, vxb_stream_t stream);
+int vxb_conv3_wgrad_halo_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
+                                    int off, int replicate, const float* dy, int N, int64_t ldy, int d2s_s, int d2s_C,
+                                    float* part, int nsplit, vxb_stream_t stream);
 /* bf16 matrix-core weight gradient (same contract as vxb_conv3d_wgrad_f32): both operands are staged position-major and
  * transposed for the matrix cores by ds_read_b64_tr_b16. */
 int vxb_conv3d_wgrad_bf16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,

@@ -1,0 +1,68 @@
+"""LDS-halo 3x3x3 weight-gradient kernel (wgrad_halo.hip): 'bf16' against the generic transposed-read bf16 kernel (same
+rounded operands, different fp32 summation order) and 'bf16x3' against a float64 PyTorch reference at the bound of the
+exact-fp32 kernels; ragged edges (S not a multiple of the 2x8x8 tile), two sources, zero padding and the
+depth-to-space dY gather of the polyphase up-conv."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from voxactb_amd import ops
+from .test_ops_gpu import rnd, close, cl, ref_conv, DEV
+
+pytestmark = pytest.mark.gpu
+
+
+def _generic(fn):
+    ops.HALO_CONV = False
+    try:
+        return fn()
+    finally:
+        ops.HALO_CONV = True
+
+
+@pytest.mark.parametrize('C0,C1,N,S,B', [(64, 64, 64, 19, 2), (16, 0, 128, 17, 1), (32, 0, 64, 16, 3)])
+def test_wgrad_halo_bf16_matches_generic(C0, C1, N, S, B):
+    a = cl(rnd(B, C0, S, S, S)).to(DEV)
+    c = cl(rnd(B, C1, S, S, S, seed=5)).to(DEV) if C1 else None
+    dy = cl(rnd(B, N, S, S, S, seed=3)).to(DEV)
+    ref = _generic(lambda: ops.conv3d_wgrad(a, dy, N, B, S, S, 3, -1, src1=c, force_bf16=True))
+    got = ops.conv3d_wgrad(a, dy, N, B, S, S, 3, -1, src1=c, force_bf16=True)
+    close(got, ref, 3e-5, 'halo wgrad bf16 vs generic')
+    # explicit split counts, including one that does not divide the tile count
+    for ns in (1, 7):
+        close(ops.conv3d_wgrad(a, dy, N, B, S, S, 3, -1, src1=c, force_bf16=True, nsplit=ns), ref, 3e-5, 'nsplit %d' % ns)
+
+
+@pytest.mark.parametrize('C0,C1,N,S', [(64, 64, 64, 18), (32, 0, 64, 21)])
+def test_wgrad_halo_x3_matches_fp64(C0, C1, N, S):
+    B = 2
+    a, c = rnd(B, C0, S, S, S), (rnd(B, C1, S, S, S, seed=5) if C1 else None)
+    dy = rnd(B, N, S, S, S, seed=3)
+    xin = torch.cat([a, c], 1) if C1 else a
+    W = torch.zeros(N, C0 + C1, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    ref_conv(xin.double(), W, None).backward(dy.double())
+    got = ops.conv3d_wgrad(cl(a).to(DEV), cl(dy).to(DEV), N, B, S, S, 3, -1, src1=cl(c).to(DEV) if C1 else None,
+                           force_bf16='bf16x3')
+    close(got, ops.conv_weight_fwd(W.grad.float()), 2e-5, 'halo wgrad x3 vs fp64')
+
+
+def test_wgrad_halo_zero_padding_dgrad_geometry():
+    """zero padding with S_out = S_in + 2, off = -2 (the geometry a data-gradient conv's own weight gradient would use)."""
+    B, C, N, S = 2, 32, 64, 16
+    a = cl(rnd(B, C, S, S, S)).to(DEV)
+    dy = cl(rnd(B, N, S + 2, S + 2, S + 2, seed=3)).to(DEV)
+    ref = _generic(lambda: ops.conv3d_wgrad(a, dy, N, B, S, S + 2, 3, -2, replicate=False, force_bf16=True))
+    got = ops.conv3d_wgrad(a, dy, N, B, S, S + 2, 3, -2, replicate=False, force_bf16=True)
+    close(got, ref, 3e-5, 'halo wgrad zero pad')
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'bf16x3'])
+def test_wgrad_halo_depth_to_space_dy(mode):
+    """dY gathered from the fine grid of a depth-to-space output (polyphase up-conv): N = s^3 * 64 columns."""
+    B, C, G, s = 1, 32, 16, 2
+    z = cl(rnd(B, C, G, G, G)).to(DEV)
+    dyf = cl(rnd(B, 64, G * s, G * s, G * s, seed=3)).to(DEV)
+    N = s ** 3 * 64
+    ref = _generic(lambda: ops.conv3d_wgrad(z, dyf, N, B, G, G, 3, -1, d2s=(s, 64), force_bf16=mode))
+    got = ops.conv3d_wgrad(z, dyf, N, B, G, G, 3, -1, d2s=(s, 64), force_bf16=mode)
+    close(got, ref, 3e-5, 'halo wgrad d2s ' + mode)

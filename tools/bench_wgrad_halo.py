@@ -1,0 +1,36 @@
+"""Micro-benchmark: LDS-halo 3x3x3 weight gradient vs the generic transposed-read kernel at the `final` conv's size."""
+import sys
+import os
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from voxactb_amd import ops  # noqa: E402
+from tools.bench_halo import timeit  # noqa: E402
+
+
+def main():
+    dev = 'cuda:0'
+    B, S = 4, 100
+    x0 = torch.randn(B, S, S, S, 64, device=dev)
+    x1 = torch.randn(B, S, S, S, 64, device=dev)
+    dy = torch.randn(B, S, S, S, 64, device=dev)
+    fl = 2.0 * B * S ** 3 * 64 * 27 * 128
+    for mode in ('bf16', 'bf16x3'):
+        for halo in (False, True):
+            ops.HALO_CONV = halo
+            t = timeit(lambda: ops.conv3d_wgrad(x0, dy, 64, B, S, S, 3, -1, src1=x1, force_bf16=mode), n=3)
+            print('%-7s wgrad 128->64 S100  halo=%d  %.3f ms  %.1f TF/s' % (mode, halo, t, fl / t * 1e-9))
+    # polyphase up-conv weight gradient: low-res 20^3 x 64 -> 125 * 64 phase channels, dY on the 100^3 fine grid
+    G, s = 20, 5
+    z = torch.randn(B, G, G, G, 64, device=dev)
+    dyf = torch.randn(B, G * s, G * s, G * s, 64, device=dev)
+    fl = 2.0 * B * G ** 3 * 8000 * 27 * 64
+    for mode in ('bf16', 'bf16x3'):
+        for halo in (False, True):
+            ops.HALO_CONV = halo
+            t = timeit(lambda: ops.conv3d_wgrad(z, dyf, 8000, B, G, G, 3, -1, d2s=(s, 64), force_bf16=mode), n=3)
+            print('%-7s wgrad 64->8000 S20 d2s  halo=%d  %.3f ms  %.1f TF/s' % (mode, halo, t, fl / t * 1e-9))
+
+
+if __name__ == '__main__':
+    main()

@@ -63,7 +63,18 @@ __global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {
     constexpr int W_V8 = N * 4 / 256;               // 16-byte weight loads per thread per tap (1 / 2)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int hi = lane >> 5, lq = lane & 31;
-    int t = blockIdx.x;
+    // XCD-aware order (workgroup id b runs on XCD b % 8, each with a private L2): give every XCD a contiguous run of
+    // tiles so that neighbouring tiles share their halo overlap through one L2.  Bijective for any grid size.
+    int t;
+    {
+        const int nwg = gridDim.x, lid = blockIdx.x;
+        const int xcd = lid & 7, slot = lid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int nnb = g.N / N;                       // column blocks of one voxel tile are neighbours in launch order
+    const int n0 = (t % nnb) * N;                   // this workgroup's 64 output channels
+    t /= nnb;
     const int tw = t % g.ntw; t /= g.ntw;
     const int th = t % g.nth; t /= g.nth;
     const int td = t % g.ntd; t /= g.ntd;
@@ -117,7 +128,60 @@ __global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {
     }
     const long long bvox = (long long)b * g.S_in * g.S_in * g.S_in;
 
-    uint4 rw[W_V8];
+    // Weight tiles travel global -> registers -> LDS two taps ahead of their use (two register sets, two LDS buffers),
+    // so an L2 round trip has two taps of MFMAs to hide behind; the A fragments of the next tap are read from the halo
+    // before the barrier that publishes its weights.
+    uint4 rw0[W_V8], rw1[W_V8];
+    bf16x8 afr[2][2];       // [M tile][k half]: bf16 -> channels 0-15 | 16-31 of the chunk; x3 -> hi | lo of its 16 channels
+#define HB_LOAD_W(R, tap_)                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < W_V8; ++i) {                                                                \
+        const int e = tid + 256 * i;                                                                                 \
+        const int n = e >> 2, q = e & 3;                                                                             \
+        const u16* wp = X3 ? g.wb + ((long long)(q >> 1) * g.N + n0 + n) * g.K + (tap_) * Ct + cb + (q & 1) * 8       \
+                           : g.wb + (long long)(n0 + n) * g.K + (tap_) * Ct + cb + q * 8;                            \
+        R[i] = *reinterpret_cast<const uint4*>(wp);                                                                  \
+    }
+#define HB_STORE_W(R, buf_)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < W_V8; ++i) {                                                                \
+        const int e = tid + 256 * i;                                                                                 \
+        *reinterpret_cast<uint4*>(&wsm[(buf_) * N * LDW + (e >> 2) * LDW + (e & 3) * 8]) = R[i];                      \
+    }
+#define HB_READ_A(tap_)                                                                                              \
+    {                                                                                                                \
+        const int tp_ = (tap_);                                                                                      \
+        const int toff_ = (((tp_ / 9) * HHp + (tp_ / 3) % 3) * HWp + tp_ % 3) * SP;                                  \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                               \
+            afr[i][0] = *reinterpret_cast<const bf16x8*>(&halo[abase[i] + toff_]);                                   \
+            afr[i][1] = *reinterpret_cast<const bf16x8*>(&halo[abase[i] + toff_ + 16]);                              \
+        }                                                                                                            \
+    }
+#define HB_TAP(tap_, RL, RS)                                                                                         \
+    {                                                                                                                \
+        const int tap = (tap_);                                                                                      \
+        if (tap + 2 < 27) { HB_LOAD_W(RL, tap + 2) }                                                                 \
+        const u16* wcur = wsm + (tap & 1) * N * LDW;                                                                 \
+        bf16x8 bfr[NT][2];                                                                                           \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                              \
+            bfr[j][0] = *reinterpret_cast<const bf16x8*>(&wcur[j * 32 * LDW + wrow]);                                \
+            bfr[j][1] = *reinterpret_cast<const bf16x8*>(&wcur[j * 32 * LDW + wrow + 16]);                           \
+        }                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                 \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                              \
+            if (X3) {                                                                                                \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i][1], bfr[j][0], acc[i][j], 0, 0, 0);       \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i][0], bfr[j][1], acc[i][j], 0, 0, 0);       \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i][0], bfr[j][0], acc[i][j], 0, 0, 0);       \
+            } else {                                                                                                 \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i][0], bfr[j][0], acc[i][j], 0, 0, 0);       \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i][1], bfr[j][1], acc[i][j], 0, 0, 0);       \
+            }                                                                                                        \
+        }                                                                                                            \
+        if (tap + 1 < 27) {                                                                                          \
+            HB_STORE_W(RS, (tap + 1) & 1)                                                                            \
+            HB_READ_A(tap + 1)                                                                                       \
+        }                                                                                                            \
+        __syncthreads();                                                                                             \
+    }
     const int nchunk = Ct / CPC;
     for (int ch = 0; ch < nchunk; ++ch) {
         const int cb = ch * CPC;
@@ -133,22 +197,9 @@ __global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {
             if (st_goff[i] >= 0)
                 hv[i] = *reinterpret_cast<const float4*>(src + (bvox + st_goff[i]) * Cs + c0 + (((tid + 256 * i) % F4P) * 4));
         }
-        // weights of tap 0 (tile [N][32 u16]: bf16 -> 32 channels; x3 -> hi 16 | lo 16)
-#define HB_LOAD_W(tap_)                                                                                              \
-    _Pragma("unroll") for (int i = 0; i < W_V8; ++i) {                                                                \
-        const int e = tid + 256 * i;                                                                                 \
-        const int n = e >> 2, q = e & 3;                                                                             \
-        const u16* wp = X3 ? g.wb + (long long)(q >> 1) * N * g.K + (long long)n * g.K + (tap_) * Ct + cb + (q & 1) * 8 \
-                           : g.wb + (long long)n * g.K + (tap_) * Ct + cb + q * 8;                                   \
-        rw[i] = *reinterpret_cast<const uint4*>(wp);                                                                 \
-    }
-#define HB_STORE_W(buf_)                                                                                             \
-    _Pragma("unroll") for (int i = 0; i < W_V8; ++i) {                                                                \
-        const int e = tid + 256 * i;                                                                                 \
-        *reinterpret_cast<uint4*>(&wsm[(buf_) * N * LDW + (e >> 2) * LDW + (e & 3) * 8]) = rw[i];                     \
-    }
-        HB_LOAD_W(0)
-        __syncthreads();                            // every wave is done with the previous chunk's halo / weights
+        HB_LOAD_W(rw0, 0)
+        HB_LOAD_W(rw1, 1)
+        // (the barrier that ended the previous chunk's last tap already freed the halo and both weight buffers)
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             if (st_goff[i] != -1) {
@@ -163,52 +214,14 @@ __global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {
                 }
             }
         }
-        HB_STORE_W(0)
+        HB_STORE_W(rw0, 0)
         __syncthreads();
-        for (int tap = 0; tap < 27; ++tap) {
-            const int cur = tap & 1;
-            if (tap + 1 < 27) { HB_LOAD_W(tap + 1) }
-            const int tdz = tap / 9, thy = (tap / 3) % 3, twx = tap % 3;
-            const int toff = ((tdz * HHp + thy) * HWp + twx) * SP;
-            const u16* wcur = wsm + cur * N * LDW;
-            if (X3) {
-                bf16x8 ah[2], al[2], bh[NT], bl[NT];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    ah[i] = *reinterpret_cast<const bf16x8*>(&halo[abase[i] + toff]);
-                    al[i] = *reinterpret_cast<const bf16x8*>(&halo[abase[i] + toff + 16]);
-                }
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    bh[j] = *reinterpret_cast<const bf16x8*>(&wcur[j * 32 * LDW + wrow]);
-                    bl[j] = *reinterpret_cast<const bf16x8*>(&wcur[j * 32 * LDW + wrow + 16]);
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    }
-            } else {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    bf16x8 a[2], bb[NT];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(&halo[abase[i] + toff + 16 * ks]);
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) bb[j] = *reinterpret_cast<const bf16x8*>(&wcur[j * 32 * LDW + wrow + 16 * ks]);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);
-                }
-            }
-            if (tap + 1 < 27) { HB_STORE_W(cur ^ 1) }     // other buffer: last read one tap ago, a barrier has passed since
-            __syncthreads();
+        HB_READ_A(0)
+        for (int tp = 0; tp < 26; tp += 2) {
+            HB_TAP(tp, rw0, rw1)
+            HB_TAP(tp + 1, rw1, rw0)
         }
+        HB_TAP(26, rw0, rw1)
     }
     // ---- epilogue: acc[i][j][r] = C[voxel row (r&3) + 8*(r>>2) + 4*hi of M tile i][channel j*32 + lq]
 #pragma unroll
@@ -220,10 +233,10 @@ __global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {
             const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
             const int oh = h0 + (m >> 2), ow = w0 + (mt & 1) * 4 + (m & 3);
             if (od < g.S_out && oh < g.S_out && ow < g.S_out) {
-                float* op = g.out + ((((long long)b * g.S_out + od) * g.S_out + oh) * g.S_out + ow) * N;
+                float* op = g.out + ((((long long)b * g.S_out + od) * g.S_out + oh) * g.S_out + ow) * g.N;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    const int n = j * 32 + lq;
+                    const int n = n0 + j * 32 + lq;
                     float v = acc[i][j][r] + (g.bias ? g.bias[n] : 0.f);
                     if (g.act == 1) v = v > 0.f ? v : v * g.slope;
                     op[n] = v;
@@ -240,7 +253,7 @@ int hb_launch(const HaloArgs& g, long long nblk, hipStream_t st) {
     const size_t lds = (size_t)(HALO_SLOTS * SP + 2 * NT * 32 * LDW) * sizeof(u16);
     if (hipFuncSetAttribute((const void*)conv3_halo_kernel<NT, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VXB_ELAUNCH;
-    hipLaunchKernelGGL((conv3_halo_kernel<NT, X3>), dim3((unsigned)nblk), dim3(256), lds, st, g);
+    hipLaunchKernelGGL((conv3_halo_kernel<NT, X3>), dim3((unsigned)(nblk * (g.N / (NT * 32)))), dim3(256), lds, st, g);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
@@ -259,8 +272,9 @@ int hb_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B,
     const long long nblk = (long long)B * g.ntd * g.nth * g.ntw;
     if (nblk >= INT32_MAX) return VXB_ESIZE;
     hipStream_t st = (hipStream_t)stream;
-    if (N == 64) return x3 ? hb_launch<2, 1>(g, nblk, st) : hb_launch<2, 0>(g, nblk, st);
-    return x3 ? hb_launch<4, 1>(g, nblk, st) : hb_launch<4, 0>(g, nblk, st);
+    // 64 output channels per workgroup (162-225 VGPRs -> two workgroups per CU); N = 128 runs two column blocks that each
+    // stage the halo -- cheaper than the register spills of a 128-wide accumulator tile.
+    return x3 ? hb_launch<2, 1>(g, nblk, st) : hb_launch<2, 0>(g, nblk, st);
 }
 
 }  // namespace

@@ -1,0 +1,273 @@
+// LDS-halo weight gradient of a 3x3x3 stride-1 conv3d on the bf16 matrix cores ('bf16' and 'bf16x3' precisions):
+//     part[z][(tap, ci)][n] = sum over the z-th slice of voxel tiles of  x[clamp(pos + tap + off)][ci] * dY[pos][n]
+// (the `final` conv of the Q-function, perceiver_lang_io.py:462, and the polyphase form of the decoder's up-conv,
+// network_utils.py:245-250, whose dY is gathered from the fine grid by space-to-depth).
+//
+// The generic transposed-read kernel (wgrad_bf16.hip) gathers x once per tap (27x through L2) and sits at ~100 TF/s in
+// bf16x3.  Here a workgroup owns 16 input channels x 64 output channels x ALL 27 taps and streams over 2x8x8 voxel
+// tiles: per tile the 4x10x10 halo of x and the 128 dY rows are staged once (fp32 -> bf16 hi[/lo] planes), and every
+// tap reads its A operand from the halo at a shifted address.  The reduction runs over voxels, so both operands go
+// through ds_read_b64_tr_b16 (voxel-major LDS -> k-major fragments) into v_mfma_f32_16x16x32_bf16.
+//   * wave w owns taps w, w+4, ... (7/7/7/6): 7 x 4 accumulator tiles of 16x16 = 112 VGPRs; the four dY fragments of
+//     a k-step are read once and reused by all of a wave's taps.
+//   * k-step = 32 voxels = 4 h-rows x 8 w of one d-plane; lane group q (16 lanes) holds h = hb + 2(q>>1) + r,
+//     w = 4(q&1) + 0..3 for read r -- the 32 lanes served per LDS cycle then touch 8 consecutive voxels, which with
+//     32-byte halo voxels and 160-byte dY rows hit 64 distinct banks (no padding of the halo needed).
+//   * the next tile's global loads are issued before the current tile's MFMAs (15 float4 per thread in flight) --
+//     there are no other global loads in the loop, so in-order retirement does not get in the way.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+constexpr int WTD = 2, WTH = 8, WTW = 8;              // voxel tile
+constexpr int XH = WTH + 2, XW = WTW + 2;             // halo h, w extents (10, 10); d extent WTD + 2 = 4
+constexpr int XSLOTS = (WTD + 2) * XH * XW;           // 400
+constexpr int XPL = XSLOTS * 16;                      // u16 per x plane
+constexpr int DLD = 80;                               // u16 per dY row (64 + 16 pad): 40 dwords, 8 rows -> 8 bank octets
+constexpr int DPL = WTD * WTH * WTW * DLD;            // u16 per dY plane
+constexpr int NXL = (XSLOTS * 4 + 255) / 256;         // 7 float4 x loads per thread per tile
+constexpr int NDL = WTD * WTH * WTW * 16 / 256;       // 8 float4 dY loads per thread per tile
+
+struct WhArgs {
+    const float* src0;
+    const float* src1;
+    const float* dy;
+    float* part;
+    int C0, C1, B, S_in, S_out, off, replicate;
+    int N, Krows;
+    long long ldy;
+    int d2s_s, d2s_C;
+    int ntd, nth, ntw;
+    long long ntiles;
+    int tiles_per_split;
+};
+
+__device__ __forceinline__ unsigned wh_pack2(float lo, float hi) {
+    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
+    a += 0x7fffu + ((a >> 16) & 1u);
+    b += 0x7fffu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xffff0000u);
+}
+
+__device__ __forceinline__ bf16x8 wh_frag(const u16* p0, const u16* p1) {
+    union { s16x4 s[2]; bf16x8 v; } u;
+    u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0));
+    u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p1));
+    return u.v;
+}
+
+template <int X3>
+__global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
+    extern __shared__ __attribute__((aligned(16))) u16 smem[];
+    u16* xs = smem;                                   // [1 + X3][XSLOTS][16]
+    u16* ds = smem + (1 + X3) * XPL;                  // [1 + X3][128][DLD]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int Ct = g.C0 + g.C1;
+    const int cb = blockIdx.x * 16;                   // this workgroup's 16 input channels
+    const int n0 = blockIdx.y * 64;                   // ... and 64 output channels
+    const bool second = cb >= g.C0;
+    const float* __restrict__ src = second ? g.src1 : g.src0;
+    const int Cs = second ? g.C1 : g.C0;
+    const int c0 = second ? cb - g.C0 : cb;
+    const int S = g.S_out;
+    // dY of a depth-to-space output: column block nb is one phase (d2s_C == 64) of the fine grid
+    int rd = 0, rh = 0, rw = 0;
+    if (g.d2s_s > 0) { const int ph = blockIdx.y; rw = ph % g.d2s_s; rh = (ph / g.d2s_s) % g.d2s_s; rd = ph / (g.d2s_s * g.d2s_s); }
+
+    f32x4 acc[7][4];
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    long long t_begin = (long long)blockIdx.z * g.tiles_per_split;
+    long long t_end = t_begin + g.tiles_per_split;
+    if (t_end > g.ntiles) t_end = g.ntiles;
+
+    float4 px[NXL], pd[NDL];
+    auto issue = [&](long long tile) {
+        long long t = tile;
+        const int tw = (int)(t % g.ntw); t /= g.ntw;
+        const int th = (int)(t % g.nth); t /= g.nth;
+        const int td = (int)(t % g.ntd); t /= g.ntd;
+        const int b = (int)t;
+        const int d0 = td * WTD, h0 = th * WTH, w0 = tw * WTW;
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) {
+            const int e = tid + 256 * i;
+            int p = e >> 2;
+            const int c4 = (e & 3) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < XSLOTS) {
+                const int hw = p % XW; p /= XW;
+                const int hh = p % XH; p /= XH;
+                int id = d0 + p + g.off, ih = h0 + hh + g.off, iw = w0 + hw + g.off;
+                bool ok = true;
+                if (g.replicate) {
+                    id = min(max(id, 0), g.S_in - 1); ih = min(max(ih, 0), g.S_in - 1); iw = min(max(iw, 0), g.S_in - 1);
+                } else {
+                    ok = id >= 0 && id < g.S_in && ih >= 0 && ih < g.S_in && iw >= 0 && iw < g.S_in;
+                }
+                if (ok) v = *reinterpret_cast<const float4*>(src + ((((long long)b * g.S_in + id) * g.S_in + ih) * g.S_in + iw) * Cs + c0 + c4);
+            }
+            px[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NDL; ++i) {
+            const int e = tid + 256 * i;
+            const int pos = e >> 4, n4 = (e & 15) * 4;
+            const int od = d0 + (pos >> 6), oh = h0 + ((pos >> 3) & 7), ow = w0 + (pos & 7);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (od < S && oh < S && ow < S) {
+                if (g.d2s_s > 0) {
+                    const int s = g.d2s_s;
+                    const long long Vf = (long long)S * s;
+                    v = *reinterpret_cast<const float4*>(g.dy + ((((long long)b * Vf + od * s + rd) * Vf + oh * s + rh) * Vf + ow * s + rw) * g.d2s_C + n4);
+                } else {
+                    v = *reinterpret_cast<const float4*>(g.dy + ((((long long)b * S + od) * S + oh) * S + ow) * g.ldy + n0 + n4);
+                }
+            }
+            pd[i] = v;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) {
+            const int e = tid + 256 * i;
+            if ((e >> 2) < XSLOTS) {
+                uint2 pk;
+                pk.x = wh_pack2(px[i].x, px[i].y); pk.y = wh_pack2(px[i].z, px[i].w);
+                *reinterpret_cast<uint2*>(&xs[(e >> 2) * 16 + (e & 3) * 4]) = pk;
+                if (X3) {
+                    uint2 q;
+                    q.x = wh_pack2(px[i].x - __uint_as_float(pk.x << 16), px[i].y - __uint_as_float(pk.x & 0xffff0000u));
+                    q.y = wh_pack2(px[i].z - __uint_as_float(pk.y << 16), px[i].w - __uint_as_float(pk.y & 0xffff0000u));
+                    *reinterpret_cast<uint2*>(&xs[XPL + (e >> 2) * 16 + (e & 3) * 4]) = q;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NDL; ++i) {
+            const int e = tid + 256 * i;
+            uint2 pk;
+            pk.x = wh_pack2(pd[i].x, pd[i].y); pk.y = wh_pack2(pd[i].z, pd[i].w);
+            *reinterpret_cast<uint2*>(&ds[(e >> 4) * DLD + (e & 15) * 4]) = pk;
+            if (X3) {
+                uint2 q;
+                q.x = wh_pack2(pd[i].x - __uint_as_float(pk.x << 16), pd[i].y - __uint_as_float(pk.x & 0xffff0000u));
+                q.y = wh_pack2(pd[i].z - __uint_as_float(pk.y << 16), pd[i].w - __uint_as_float(pk.y & 0xffff0000u));
+                *reinterpret_cast<uint2*>(&ds[DPL + (e >> 4) * DLD + (e & 15) * 4]) = q;
+            }
+        }
+    };
+
+    // fragment addressing: lane group q = lane >> 4, t = lane & 15 -> voxel (h = hb + 2(q>>1) + r, w = 4(q&1) + (t>>2)),
+    // channel quad t & 3 (ds_read_b64_tr_b16 then hands lane i channel i at the group's 4 voxels)
+    const int q = lane >> 4, tl = lane & 15;
+    const int fh = 2 * (q >> 1), fw = 4 * (q & 1) + (tl >> 2), fc = 4 * (tl & 3);
+
+    if (t_begin < t_end) issue(t_begin);
+    for (long long tile = t_begin; tile < t_end; ++tile) {
+        __syncthreads();                 // every wave is done reading the previous tile
+        stage();
+        __syncthreads();
+        if (tile + 1 < t_end) issue(tile + 1);
+#pragma unroll 1
+        for (int ks = 0; ks < 4; ++ks) {
+            const int dd = ks >> 1, hb = (ks & 1) * 4;
+            const u16* xa0 = xs + ((dd * XH + hb + fh) * XW + fw) * 16 + fc;        // read r = 0 (tap offset added later)
+            const u16* xa1 = xa0 + XW * 16;                                          // r = 1: next h row
+            const u16* db0 = ds + ((dd * WTH + hb + fh) * WTW + fw) * DLD + fc;
+            const u16* db1 = db0 + WTW * DLD;
+            bf16x8 bh[4], bl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bh[j] = wh_frag(db0 + 16 * j, db1 + 16 * j);
+                if (X3) bl[j] = wh_frag(db0 + DPL + 16 * j, db1 + DPL + 16 * j);
+            }
+#pragma unroll
+            for (int ti = 0; ti < 7; ++ti) {
+                const int tap = wid + 4 * ti;
+                if (tap < 27) {
+                    const int toff = (((tap / 9) * XH + (tap / 3) % 3) * XW + tap % 3) * 16;
+                    const bf16x8 ah = wh_frag(xa0 + toff, xa1 + toff);
+                    if (X3) {
+                        const bf16x8 al = wh_frag(xa0 + XPL + toff, xa1 + XPL + toff);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[ti][j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[ti][j], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[ti][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // D tile (16 ci x 16 n): lane l holds column n = l & 15, rows 4 (l >> 4) + r
+    float* __restrict__ C = g.part + (long long)blockIdx.z * g.Krows * g.N;
+#pragma unroll
+    for (int ti = 0; ti < 7; ++ti) {
+        const int tap = wid + 4 * ti;
+        if (tap < 27) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = tap * Ct + cb + 4 * q + r;
+                    C[(long long)row * g.N + n0 + 16 * j + tl] = acc[ti][j][r];
+                }
+        }
+    }
+}
+
+}  // namespace
+
+static int wgrad_halo_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out, int off,
+                           int replicate, const float* dy, int N, int64_t ldy, int d2s_s, int d2s_C, float* part, int nsplit,
+                           vxb_stream_t stream) {
+    if (!src0 || !dy || !part || B < 1 || S_in < 1 || S_out < 1 || N < 1 || nsplit < 1) return VXB_EARG;
+    if ((C0 & 15) || (C1 & 15) || C0 < 16 || (C1 > 0 && !src1) || (N & 63)) return VXB_ESIZE;
+    if (d2s_s > 0 && d2s_C != 64) return VXB_ESIZE;
+    if (d2s_s <= 0 && (ldy & 3)) return VXB_ESIZE;
+    WhArgs g;
+    g.src0 = src0; g.src1 = src1; g.dy = dy; g.part = part; g.C0 = C0; g.C1 = C1; g.B = B; g.S_in = S_in; g.S_out = S_out;
+    g.off = off; g.replicate = replicate; g.N = N; g.Krows = 27 * (C0 + C1); g.ldy = ldy; g.d2s_s = d2s_s; g.d2s_C = d2s_C;
+    g.ntd = vxb_cdiv(S_out, WTD); g.nth = vxb_cdiv(S_out, WTH); g.ntw = vxb_cdiv(S_out, WTW);
+    g.ntiles = (long long)B * g.ntd * g.nth * g.ntw;
+    g.tiles_per_split = (int)((g.ntiles + nsplit - 1) / nsplit);
+    if (nsplit > 65535 || N / 64 > 65535) return VXB_ESIZE;
+    const size_t lds = (size_t)(1 + (x3 ? 1 : 0)) * (XPL + DPL) * sizeof(u16);
+    dim3 grid((C0 + C1) / 16, N / 64, nsplit);
+    hipStream_t st = (hipStream_t)stream;
+    if (x3) {
+        if (hipFuncSetAttribute((const void*)wgrad_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
+        hipLaunchKernelGGL(wgrad_halo_kernel<1>, grid, dim3(256), lds, st, g);
+    } else {
+        if (hipFuncSetAttribute((const void*)wgrad_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
+        hipLaunchKernelGGL(wgrad_halo_kernel<0>, grid, dim3(256), lds, st, g);
+    }
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+// 3x3x3 stride-1 specialisation of vxb_conv3d_wgrad_bf16_f32 / _bf16x3_f32 (same contract and part[z][K][N] layout;
+// the z slices are runs of 2x8x8 voxel tiles).  C0, C1 % 16 == 0, N % 64 == 0; d2s: d2s_C == 64.
+extern "C" int vxb_conv3_wgrad_halo_bf16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
+                                             int off, int replicate, const float* dy, int N, int64_t ldy, int d2s_s,
+                                             int d2s_C, float* part, int nsplit, vxb_stream_t stream) {
+    return wgrad_halo_impl(0, src0, src1, C0, C1, B, S_in, S_out, off, replicate, dy, N, ldy, d2s_s, d2s_C, part, nsplit, stream);
+}
+
+extern "C" int vxb_conv3_wgrad_halo_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
+                                               int off, int replicate, const float* dy, int N, int64_t ldy, int d2s_s,
+                                               int d2s_C, float* part, int nsplit, vxb_stream_t stream) {
+    return wgrad_halo_impl(1, src0, src1, C0, C1, B, S_in, S_out, off, replicate, dy, N, ldy, d2s_s, d2s_C, part, nsplit, stream);
+}

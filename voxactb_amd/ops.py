@@ -235,6 +235,21 @@ def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
     C1 = src1.shape[-1] if src1 is not None else 0
     K = kext ** 3 * (C0 + C1)
     P = B * S_out ** 3
+    mode = force_bf16 if isinstance(force_bf16, str) else ('bf16' if force_bf16 else PRECISION)
+    if (HALO_CONV and mode in ('bf16', 'bf16x3') and kext == 3 and stride == 1 and C0 % 16 == 0 and C1 % 16 == 0
+            and N % 64 == 0 and (d2s[0] == 0 or d2s[1] == 64) and S_out >= 16 and (ldy is None or ldy % 4 == 0)):
+        blocks = ((C0 + C1) // 16) * (N // 64)
+        ntiles = B * ((S_out + 1) // 2) * ((S_out + 7) // 8) ** 2
+        ns = nsplit if nsplit is not None else max(1, min(256, (1024 + blocks - 1) // blocks, ntiles // 8))
+        part = torch.empty((ns, K, N), dtype=torch.float32, device=src0.device)
+        _lib.set_meta(label or 'conv3d_wgrad[k%d s%d %d->%d S%d]' % (kext, stride, C0 + C1, N, S_out), 2.0 * P * N * K)
+        call('vxb_conv3_wgrad_halo_bf16x3_f32' if mode == 'bf16x3' else 'vxb_conv3_wgrad_halo_bf16_f32', src0, src1, C0, C1,
+             B, S_in, S_out, off, int(replicate), dy, N, ldy if ldy is not None else N, d2s[0], d2s[1], part, ns)
+        if ns == 1:
+            return part[0]
+        out = torch.empty((K, N), dtype=torch.float32, device=src0.device)
+        sum_splits(part, ns, K * N, out)
+        return out
     if nsplit is None:
         tiles = ((K + 127) // 128) * ((N + 127) // 128 if N > 64 else 1)
         nsplit = max(1, min(64, 1024 // max(tiles, 1), (P + 4095) // 4096))
