@@ -109,14 +109,16 @@ int vxb_conv3d_wgrad_bf16x3_f32(const float* src0, const float* src1, int C0, in
                                 int d2s_s, int d2s_C, float* part, int nsplit, vxb_stream_t stream);
 /* LDS-halo specialisation of vxb_conv3d_bf16w_f32 for kext == 3, stride == 1 (the `final` conv of the Q-function,
  * perceiver_lang_io.py:462-466, and its data gradient): a 4x8x8 block of output voxels stages its 6x10x10 input halo
- * once instead of once per tap.  C0, C1 % 32 == 0, N in {64, 128}; out [B, S_out^3, N] is overwritten.  The x3 entry
- * takes the hi/lo weight planes [2][N][K] of the bf16x3 split. */
+ * once instead of once per tap.  C0, C1 % 32 == 0, N % 64 == 0; out [B, S_out^3, N] is overwritten.  The x3 entry
+ * takes the hi/lo weight planes [2][N][K] of the bf16x3 split.
+ * s2d_s > 0: src0 is a fine grid [B, (S_in*s2d_s)^3, s2d_C] read by space-to-depth (input channel = (phase, co)) -- the
+ * data gradient of the polyphase up-conv.  d2s_s > 0: depth-to-space output, 64 channels per phase (its forward). */
 int vxb_conv3_halo_bf16w_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                              int off, int replicate, const void* wt_bf16, int N, const float* bias, float* out,
-                             int act, float slope, vxb_stream_t stream);
+                             int act, float slope, int s2d_s, int s2d_C, int d2s_s, vxb_stream_t stream);
 int vxb_conv3_halo_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                               int off, int replicate, const void* wt_bf16, int N, const float* bias, float* out,
-                              int act, float slope, vxb_stream_t stream);
+                              int act, float slope, int s2d_s, int s2d_C, int d2s_s, vxb_stream_t stream);
 /* LDS-halo weight gradient of the same 3x3x3 stride-1 convs (contract of vxb_conv3d_wgrad_f32 with kext = 3, stride = 1;
  * the z slices of part[z][K][N] are runs of 2x8x8 voxel tiles).  C0, C1 % 16 == 0, N % 64 == 0; d2s needs d2s_C == 64. */
 int vxb_conv3_wgrad_halo_bf16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,

@@ -550,9 +550,14 @@ class PerceiverEngine:
             kl, R = self.kl, self.R
             dWeff = ops.conv3d_wgrad(z1, du0, s ** 3 * C, B, G, G, kl, -R, d2s=(s, C))
             ops.polyphase_weights_bwd(dWeff, self.Lt(dev), self.g(up2 + '.weight'), s, kl)
-            wd = ops.polyphase_dgrad_weights(c['Weff'], C, C, s, kl)
             Sp = G + 2 * R
-            dzp = ops.conv3d(du0, wd, C, B, V, Sp, s * kl, -s * (kl - 1), stride=s, replicate=False)
+            if ops.s2d_halo_ok(kl, C, C):
+                # same gradient as a 3^3 conv over the low-res grid reading the fine dY by space-to-depth (LDS-halo kernel)
+                wd = ops.polyphase_dgrad_weights_lowres(c['Weff'], C, C, s, kl)
+                dzp = ops.conv3_s2d(du0, wd, C, B, G, Sp, -(kl - 1), s, C)
+            else:
+                wd = ops.polyphase_dgrad_weights(c['Weff'], C, C, s, kl)
+                dzp = ops.conv3d(du0, wd, C, B, V, Sp, s * kl, -s * (kl - 1), stride=s, replicate=False)
             ops.fold_pad(dzp, Sp, C, 0, dz1, B, G, C, R, lrelu_of=z1)
         else:
             dWt = ops.conv3d_wgrad(z1, du0, C, B, G, G, k, -(k // 2))

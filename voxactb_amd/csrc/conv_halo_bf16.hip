@@ -42,6 +42,8 @@ struct HaloArgs {
     int act;
     float slope;
     int ntd, nth, ntw;
+    int s2d_s, s2d_C;       // > 0: src0 is a fine grid [B, (S_in*s)^3, s2d_C], input channel = (phase, co)
+    int d2s_s;              // > 0: out is a fine grid [B, (S_out*s)^3, 64], output column = (phase, co)
 };
 
 __device__ __forceinline__ unsigned hb_pack2(float lo, float hi) {
@@ -101,7 +103,11 @@ __global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {
     const int wrow = lq * LDW + 8 * hi;            // B-operand row of this lane inside a weight tile (+ nt*32*LDW)
 
     // halo staging slots of this thread: element e = tid + 256 i -> voxel e / F4P, channel quad e % F4P
-    int st_goff[NLD];      // voxel offset in the source cube (in voxels), -1 = zero fill / unused
+    // space-to-depth source (s2d_s > 0): the input "channels" are (phase, co) of a fine grid [B, (S_in*s)^3, s2d_C];
+    // voxel (id, ih, iw), phase (rd, rh, rw) lives at fine voxel (id*s + rd, ...).
+    const int sm = g.s2d_s > 0 ? g.s2d_s : 1;
+    const int Vin = g.S_in * sm;
+    int st_goff[NLD];      // voxel offset in the source cube (in voxels, phase 0), -1 = unused, -2 = zero fill
     int st_soff[NLD];      // LDS offset (u16)
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -122,11 +128,11 @@ __global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {
                 ok = id >= 0 && id < g.S_in && ih >= 0 && ih < g.S_in && iw >= 0 && iw < g.S_in;
             }
             st_soff[i] = ((pd * HHp + ph) * HWp + pw) * SP + c4;
-            if (ok) st_goff[i] = (id * g.S_in + ih) * g.S_in + iw;
+            if (ok) st_goff[i] = ((id * sm) * Vin + ih * sm) * Vin + iw * sm;
             else st_goff[i] = -2;                   // staged as zeros
         }
     }
-    const long long bvox = (long long)b * g.S_in * g.S_in * g.S_in;
+    const long long bvox = (long long)b * Vin * Vin * Vin;
 
     // Weight tiles travel global -> registers -> LDS two taps ahead of their use (two register sets, two LDS buffers),
     // so an L2 round trip has two taps of MFMAs to hide behind; the A fragments of the next tap are read from the halo
@@ -187,15 +193,22 @@ __global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {
         const int cb = ch * CPC;
         const bool second = cb >= g.C0;
         const float* src = second ? g.src1 : g.src0;
-        const int Cs = second ? g.C1 : g.C0;
-        const int c0 = second ? cb - g.C0 : cb;
+        int Cs = second ? g.C1 : g.C0;
+        int c0 = second ? cb - g.C0 : cb;
+        long long vbase = bvox;
+        if (g.s2d_s > 0) {
+            const int ph = cb / g.s2d_C;
+            c0 = cb - ph * g.s2d_C;
+            Cs = g.s2d_C;
+            vbase += ((long long)(ph / (sm * sm)) * Vin + (ph / sm) % sm) * Vin + ph % sm;
+        }
         // ---- fetch the halo of this chunk (all loads in flight together), then convert + store
         float4 hv[NLD];
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             hv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (st_goff[i] >= 0)
-                hv[i] = *reinterpret_cast<const float4*>(src + (bvox + st_goff[i]) * Cs + c0 + (((tid + 256 * i) % F4P) * 4));
+                hv[i] = *reinterpret_cast<const float4*>(src + (vbase + st_goff[i]) * Cs + c0 + (((tid + 256 * i) % F4P) * 4));
         }
         HB_LOAD_W(rw0, 0)
         HB_LOAD_W(rw1, 1)
@@ -233,7 +246,15 @@ __global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {
             const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
             const int oh = h0 + (m >> 2), ow = w0 + (mt & 1) * 4 + (m & 3);
             if (od < g.S_out && oh < g.S_out && ow < g.S_out) {
-                float* op = g.out + ((((long long)b * g.S_out + od) * g.S_out + oh) * g.S_out + ow) * g.N;
+                float* op;
+                if (g.d2s_s > 0) {
+                    // depth-to-space output: this workgroup's 64 columns are one phase of the fine grid
+                    const int s = g.d2s_s, ph = n0 / N;
+                    const long long Vf = (long long)g.S_out * s;
+                    op = g.out + ((((long long)b * Vf + od * s + ph / (s * s)) * Vf + oh * s + (ph / s) % s) * Vf + ow * s + ph % s) * N - n0;
+                } else {
+                    op = g.out + ((((long long)b * g.S_out + od) * g.S_out + oh) * g.S_out + ow) * g.N;
+                }
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const int n = n0 + j * 32 + lq;
@@ -259,12 +280,16 @@ int hb_launch(const HaloArgs& g, long long nblk, hipStream_t st) {
 }
 
 int hb_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out, int off, int replicate,
-            const void* wt_bf16, int N, const float* bias, float* out, int act, float slope, vxb_stream_t stream) {
+            const void* wt_bf16, int N, const float* bias, float* out, int act, float slope, int s2d_s, int s2d_C,
+            int d2s_s, vxb_stream_t stream) {
     if (!src0 || !wt_bf16 || !out || B < 1 || S_in < 1 || S_out < 1) return VXB_EARG;
-    if ((C0 & 31) || (C1 & 31) || C0 < 32 || (C1 > 0 && !src1) || (N != 64 && N != 128)) return VXB_ESIZE;
+    if ((C0 & 31) || (C1 & 31) || C0 < 32 || (C1 > 0 && !src1) || N < 64 || (N & 63)) return VXB_ESIZE;
     if (!hb_aligned16(src0) || !hb_aligned16(wt_bf16) || (src1 && !hb_aligned16(src1))) return VXB_ESIZE;
-    if ((long long)S_in * S_in * S_in >= INT32_MAX) return VXB_ESIZE;
+    if (s2d_s > 0 && (C1 != 0 || s2d_C < 32 || (s2d_C & 31) || C0 != s2d_s * s2d_s * s2d_s * s2d_C)) return VXB_EARG;
+    const long long Vin = (long long)S_in * (s2d_s > 0 ? s2d_s : 1);
+    if (Vin * Vin * Vin >= INT32_MAX) return VXB_ESIZE;
     HaloArgs g;
+    g.s2d_s = s2d_s; g.s2d_C = s2d_C; g.d2s_s = d2s_s;
     g.src0 = src0; g.src1 = src1; g.C0 = C0; g.C1 = C1; g.B = B; g.S_in = S_in; g.S_out = S_out; g.off = off;
     g.replicate = replicate; g.wb = (const u16*)wt_bf16; g.N = N; g.K = 27 * (C0 + C1); g.bias = bias; g.out = out;
     g.act = act; g.slope = slope;
@@ -280,16 +305,21 @@ int hb_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B,
 }  // namespace
 
 // 3x3x3, stride-1 twin of vxb_conv3d_bf16w_f32 (same weights layout bf16 [N][27*(C0+C1)], same padding semantics:
-// src voxel = out + tap + off per axis); C0, C1 multiples of 32, N in {64, 128}.  out [B, S_out^3, N] is overwritten.
+// src voxel = out + tap + off per axis); C0, C1 multiples of 32, N a multiple of 64.  out [B, S_out^3, N] is overwritten.
+// s2d_s > 0: src0 is a fine grid [B, (S_in*s2d_s)^3, s2d_C] read by space-to-depth (input channel = (phase, co), C0 =
+// s^3 * s2d_C) -- the data gradient of the polyphase up-conv.  d2s_s > 0: depth-to-space output with 64 channels per
+// phase (N = d2s_s^3 * 64), out = fine grid [B, (S_out*d2s_s)^3, 64] -- the polyphase up-conv forward.
 extern "C" int vxb_conv3_halo_bf16w_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                                         int off, int replicate, const void* wt_bf16, int N, const float* bias, float* out,
-                                        int act, float slope, vxb_stream_t stream) {
-    return hb_impl(0, src0, src1, C0, C1, B, S_in, S_out, off, replicate, wt_bf16, N, bias, out, act, slope, stream);
+                                        int act, float slope, int s2d_s, int s2d_C, int d2s_s, vxb_stream_t stream) {
+    return hb_impl(0, src0, src1, C0, C1, B, S_in, S_out, off, replicate, wt_bf16, N, bias, out, act, slope, s2d_s, s2d_C, d2s_s,
+                   stream);
 }
 
 // 'bf16x3' twin (weights = planes [2][N][K], see vxb_conv3d_bf16x3_f32).
 extern "C" int vxb_conv3_halo_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                                          int off, int replicate, const void* wt_bf16, int N, const float* bias, float* out,
-                                         int act, float slope, vxb_stream_t stream) {
-    return hb_impl(1, src0, src1, C0, C1, B, S_in, S_out, off, replicate, wt_bf16, N, bias, out, act, slope, stream);
+                                         int act, float slope, int s2d_s, int s2d_C, int d2s_s, vxb_stream_t stream) {
+    return hb_impl(1, src0, src1, C0, C1, B, S_in, S_out, off, replicate, wt_bf16, N, bias, out, act, slope, s2d_s, s2d_C, d2s_s,
+                   stream);
 }

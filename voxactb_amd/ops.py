@@ -16,6 +16,8 @@ _NAIVE_MACS = 1 << 22
 # weight gradients, attention softmax path and every streaming kernel stay fp32).  Set by PerceiverEngine per call.
 PRECISION = 'fp32'
 HALO_CONV = True     # 3x3x3 stride-1 bf16 convs go through the LDS-halo kernel (conv_halo_bf16.hip)
+HALO_D2S = False     # ... also the depth-to-space forward of the polyphase up-conv: measured 21.0 ms vs 19.3 ms generic at
+                     # 20^3 x 8000 columns (the 4x8x8 tile wastes 44 % on a 20^3 grid and the halo is re-staged per column block)
 _WCACHE = {}
 
 
@@ -314,6 +316,30 @@ def polyphase_dgrad_weights(Weff, Ci, Co, s, kl):
     return w.permute(0, 4, 1, 5, 2, 6, 7, 3).reshape((s * kl) ** 3 * Co, Ci).contiguous()
 
 
+def polyphase_dgrad_weights_lowres(Weff, Ci, Co, s, kl):
+    """[(j3, ci)][(r3, co)] -> [(j''3, (r3, co))][ci] with j'' = kl-1-j per axis: the same data gradient written as a
+    stride-1 zero-pad conv over the LOW-RES grid whose input channels are the s^3 phases x co of the fine dY
+    (read in place by space-to-depth, see conv3_s2d)."""
+    w = Weff.view(kl, kl, kl, Ci, s, s, s, Co).flip(0, 1, 2)
+    return w.permute(0, 1, 2, 4, 5, 6, 7, 3).reshape(kl ** 3 * s ** 3 * Co, Ci).contiguous()
+
+
+def s2d_halo_ok(kl, C, N):
+    return HALO_CONV and _mm() and kl == 3 and C % 32 == 0 and N % 64 == 0
+
+
+def conv3_s2d(src_fine, wt, N, B, G, S_out, off, s, Cf, label=None):
+    """out[B, S_out^3, N] = 3x3x3 zero-pad conv over the low-res grid G^3 whose input channel (phase, co) is read from
+    src_fine [B, (G*s)^3, Cf] at fine voxel (q*s + r); wt fp32 [(tap, phase, co)][N].  LDS-halo kernel only (bf16 modes)."""
+    wb = to_bf16_nk(wt)
+    out = torch.empty((B, S_out, S_out, S_out, N), dtype=torch.float32, device=src_fine.device)
+    C0 = s ** 3 * Cf
+    _lib.set_meta(label or 'conv3_s2d[k3 %d->%d S%d dgrad]' % (C0, N, S_out), 2.0 * B * S_out ** 3 * N * 27 * C0)
+    call('vxb_conv3_halo_bf16x3_f32' if wb.dim() == 3 else 'vxb_conv3_halo_bf16w_f32', src_fine, None, C0, 0, B, G, S_out, off,
+         0, wb, N, None, out, ACT_NONE, LRELU_SLOPE, s, Cf, 0)
+    return out
+
+
 def strided_dgrad_weights(W, s):
     """Data gradient of a stride-s conv as a stride-1 conv on the coarse grid with s^3 output phases:
     W [Co,Ci,k,k,k] -> wt [(u''3, co)][(r3, ci)], U = ceil(k/s) taps/axis, element = W[co,ci,t = s*(U-1-u'') + r] (0 if t >= k)."""
@@ -464,10 +490,10 @@ def conv3d_bf16w(src0, wb, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
     _lib.set_meta(label or 'conv3d_bf16[k%d s%d %d->%d S%d%s]' % (kext, stride, C0 + C1, N, S_out, '' if replicate else ' dgrad'),
                   2.0 * B * S_out ** 3 * N * kext ** 3 * (C0 + C1))
     x3 = wb.dim() == 3
-    if (HALO_CONV and kext == 3 and stride == 1 and d2s[0] == 0 and not accumulate and N in (64, 128)
+    if (HALO_CONV and kext == 3 and stride == 1 and (d2s[0] == 0 or (d2s[1] == 64 and HALO_D2S)) and not accumulate and N % 64 == 0
             and (ldc is None or ldc == N) and S_out >= 16):
-        call('vxb_conv3_halo_bf16x3_f32' if x3 else 'vxb_conv3_halo_bf16w_f32', src0, src1, C0, C1, B, S_in, S_out, off, int(replicate), wb, N, bias, out,
-             act, LRELU_SLOPE)
+        call('vxb_conv3_halo_bf16x3_f32' if x3 else 'vxb_conv3_halo_bf16w_f32', src0, src1, C0, C1, B, S_in, S_out, off,
+             int(replicate), wb, N, bias, out, act, LRELU_SLOPE, 0, 0, d2s[0])
         return out
     call('vxb_conv3d_bf16x3_f32' if x3 else 'vxb_conv3d_bf16w_f32', src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, int(replicate), wb, N, bias, out,
          ldc if ldc is not None else N, act, LRELU_SLOPE, int(accumulate), d2s[0], d2s[1])
