@@ -184,6 +184,13 @@ int vxb_flash_attn_fwd_bf16(const float* q, const float* kv, float* o, float* ls
 int vxb_flash_attn_bwd_bf16(const float* q, const float* kv, const float* o, const float* d_o, const float* lse,
                             float* dq, float* dkv, float* dsum_ws, int B, int H, int Nq, int Nk, int head_dim,
                             float scale, float dropout_p, uint32_t seed, vxb_stream_t stream);
+/* 'bf16x3' twins: q, k, v, dO and the probabilities / score gradients are all carried as hi + lo bf16 halves, three
+ * MFMAs per product -- the fused kernels then stay inside the 1e-4 Q-value bound of the exact-fp32 attention path. */
+int vxb_flash_attn_fwd_bf16x3(const float* q, const float* kv, float* o, float* lse, int B, int H, int Nq, int Nk,
+                              int head_dim, float scale, float dropout_p, uint32_t seed, vxb_stream_t stream);
+int vxb_flash_attn_bwd_bf16x3(const float* q, const float* kv, const float* o, const float* d_o, const float* lse,
+                              float* dq, float* dkv, float* dsum_ws, int B, int H, int Nq, int Nk, int head_dim,
+                              float scale, float dropout_p, uint32_t seed, vxb_stream_t stream);
 
 /* GEGLU x * gelu_erf(gates) (perceiver_lang_io.py:74-77); LeakyReLU backward; y += alpha*x. */
 int vxb_geglu_fwd_f32(const float* h, float* out, int64_t rows, int F, vxb_stream_t stream);

@@ -256,6 +256,7 @@ class PerceiverEngine:
         self.precision = os.environ.get('VOXACTB_PRECISION', 'fp32')
         if self.precision not in ('fp32', 'bf16', 'bf16x3'):
             raise ValueError('VOXACTB_PRECISION must be fp32, bf16x3 or bf16')
+        self.fused_attention = os.environ.get('VOXACTB_FUSED_ATTENTION', '1') != '0'   # bf16 / bf16x3 modes, head dim 64
 
     # -------------------------------------------------------------------------------------------------- helpers
     def p(self, name):
@@ -292,11 +293,13 @@ class PerceiverEngine:
         inner = H * d
         q = ops.linear(xq.view(B * Nq, Dq), Wq)
         kv = ops.linear(ctxn.reshape(B * Nk, ctxn.shape[2]), Wkv)
-        if self.precision == 'bf16' and d == 64:
-            # throughput mode: fused attention on the bf16 matrix cores, no [B*h, i, j] tensor (csrc/flash_attn.hip)
-            O, lse = flash.flash_attn_fwd(q, kv, B, H, Nq, Nk, d ** -0.5, p, seed)
+        if self.precision in ('bf16', 'bf16x3') and d == 64 and self.fused_attention:
+            # fused attention on the bf16 matrix cores, no [B*h, i, j] tensor (csrc/flash_attn.hip); 'bf16x3' carries
+            # q, k, v, dO, P and dS as hi + lo halves
+            x3 = self.precision == 'bf16x3'
+            O, lse = flash.flash_attn_fwd(q, kv, B, H, Nq, Nk, d ** -0.5, p, seed, x3=x3)
             out = ops.linear(O, Wo, bo, residual=residual)
-            cache = dict(q=q, kv=kv, O=O, lse=lse, flash=True, dims=(B, Nq, Nk, H, d, 0), p=p, seed=seed) if save else None
+            cache = dict(q=q, kv=kv, O=O, lse=lse, flash=True, x3=x3, dims=(B, Nq, Nk, H, d, 0), p=p, seed=seed) if save else None
             return out, cache
         ld = _r4(Nk)
         S = torch.empty((B * H, Nq, ld), dtype=torch.float32, device=xq.device)
@@ -319,7 +322,8 @@ class PerceiverEngine:
         dO = torch.empty((B * Nq, inner), dtype=torch.float32, device=dev)
         ops.linear_bwd(c['O'], Wo, dout, self.g(pre + '.fn.to_out.weight'), self.g(pre + '.fn.to_out.bias'), dO)
         if c.get('flash'):
-            dq, dkv = flash.flash_attn_bwd(c['q'], c['kv'], c['O'], dO, c['lse'], B, H, Nq, Nk, d ** -0.5, c['p'], c['seed'])
+            dq, dkv = flash.flash_attn_bwd(c['q'], c['kv'], c['O'], dO, c['lse'], B, H, Nq, Nk, d ** -0.5, c['p'], c['seed'],
+                                           x3=c['x3'])
             return self._attn_bwd_proj(pre, dq, dkv, xq2d, ctx2d, same_src)
         kv, q, P, Pd = c['kv'], c['q'], c['P'], c['Pd']
         dkv = torch.empty_like(kv)

@@ -1,4 +1,4 @@
-// Fused ("flash") attention for the Perceiver blocks on the bf16 matrix cores (throughput mode).
+// Fused ("flash") attention for the Perceiver blocks on the bf16 matrix cores ('bf16' and 'bf16x3' precisions).
 // Replaces, without ever materialising the [B*h, i, j] score tensor (perceiver_lang_io.py:116-130):
 //     sim = q k^T * scale ; attn = softmax(sim) ; attn = dropout(attn) ; out = attn v
 // for the three attention shapes of the model: cross (2048 x 8077, 1 head), self (2048 x 2048, 8 heads), decoder
@@ -15,6 +15,10 @@
 //                           round trip for P (any k-permutation inside one MFMA cancels as long as A and B agree)
 // One workgroup = 4 waves x 32 queries; K/V tiles of 64 keys, register-prefetched one tile ahead.
 // Dropout uses a counter-based hash of (seed, row, key pair): the backward kernels regenerate the same mask.
+//
+// X3 = 1 ('bf16x3'): every matrix-core operand -- q, k, v, dO and also the probabilities P and score gradients dS -- is
+// carried as hi = bf16(a), lo = bf16(a - hi) and each product is evaluated as hi*hi + hi*lo + lo*hi (fp32 accumulate),
+// which keeps the fused kernels inside the 1e-4 Q-value bound of the exact-fp32 attention path.
 #include "common.h"
 
 namespace {
@@ -28,6 +32,8 @@ constexpr int BQ = 128;         // queries per workgroup (4 waves x 32)
 constexpr int BKV = 64;         // keys per tile
 constexpr int LDK = 72;         // Ks row stride in bf16 (36 dwords: conflict-free ds_read_b128)
 constexpr int LDV = 96;         // Vs row stride in bf16 (48 dwords: conflict-free ds_read_b64_tr_b16)
+constexpr int KPL = BKV * LDK;  // u16 per b128-layout plane
+constexpr int VPL = BKV * LDV;  // u16 per transposed-read-layout plane
 constexpr float LOG2E = 1.4426950408889634f;
 
 struct AttnArgs {
@@ -54,15 +60,69 @@ __device__ __forceinline__ unsigned fa_pack2(float lo, float hi) {
     b += 0x7fffu + ((b >> 16) & 1u);
     return (a >> 16) | (b & 0xffff0000u);
 }
+// hi/lo split of a value pair: ph = bf16 pair, pl = bf16 pair of the (exact) residuals
+__device__ __forceinline__ void fa_split2(float a, float b, unsigned& ph, unsigned& pl) {
+    ph = fa_pack2(a, b);
+    pl = fa_pack2(a - __uint_as_float(ph << 16), b - __uint_as_float(ph & 0xffff0000u));
+}
 __device__ __forceinline__ unsigned long long fa_tr16(unsigned addr) {
     unsigned long long v;
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
     return v;
 }
+// acc += A B with A = ah + al, B = bh + bl (X3) or A = ah, B = bh
+template <int X3>
+__device__ __forceinline__ f32x16 fa_mma(const bf16x8 ah, const bf16x8 al, const bf16x8 bh, const bf16x8 bl, f32x16 c) {
+    if (X3) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+}
+// 8 consecutive fp32 (two float4) -> one bf16x8 fragment (+ residual fragment), optionally pre-scaled
+template <int X3>
+__device__ __forceinline__ void fa_frag8(const float* p, float s, bf16x8& fh, bf16x8& fl) {
+    union { unsigned u[4]; bf16x8 v; } h, l;
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 c = *reinterpret_cast<const float4*>(p + 4);
+    if (X3) {
+        fa_split2(a.x * s, a.y * s, h.u[0], l.u[0]); fa_split2(a.z * s, a.w * s, h.u[1], l.u[1]);
+        fa_split2(c.x * s, c.y * s, h.u[2], l.u[2]); fa_split2(c.z * s, c.w * s, h.u[3], l.u[3]);
+        fl = l.v;
+    } else {
+        h.u[0] = fa_pack2(a.x * s, a.y * s); h.u[1] = fa_pack2(a.z * s, a.w * s);
+        h.u[2] = fa_pack2(c.x * s, c.y * s); h.u[3] = fa_pack2(c.z * s, c.w * s);
+        fl = h.v;
+    }
+    fh = h.v;
+}
+// one float4 -> 8-byte bf16 store into a plane (and its residual into the lo plane PL u16 further)
+template <int X3>
+__device__ __forceinline__ void fa_store4(u16* dst, int PL, const float4 v, float s) {
+    uint2 ph, pl;
+    if (X3) {
+        fa_split2(v.x * s, v.y * s, ph.x, pl.x); fa_split2(v.z * s, v.w * s, ph.y, pl.y);
+        *reinterpret_cast<uint2*>(dst + PL) = pl;
+    } else {
+        ph.x = fa_pack2(v.x * s, v.y * s); ph.y = fa_pack2(v.z * s, v.w * s);
+    }
+    *reinterpret_cast<uint2*>(dst) = ph;
+}
+__device__ __forceinline__ bf16x8 fa_join(unsigned long long a, unsigned long long b) {
+    union { unsigned long long u[2]; bf16x8 v; } t;
+    t.u[0] = a; t.u[1] = b;
+    return t.v;
+}
+__device__ __forceinline__ bf16x8 fa_from4(const unsigned* p) {
+    union { unsigned u[4]; bf16x8 v; } t;
+    t.u[0] = p[0]; t.u[1] = p[1]; t.u[2] = p[2]; t.u[3] = p[3];
+    return t.v;
+}
 
+template <int X3>
 __global__ void __launch_bounds__(256) flash_fwd_kernel(AttnArgs g) {
-    __shared__ __attribute__((aligned(16))) u16 Ks[BKV * LDK];
-    __shared__ __attribute__((aligned(16))) u16 Vs[BKV * LDV];
+    __shared__ __attribute__((aligned(16))) u16 Ks[(1 + X3) * KPL];
+    __shared__ __attribute__((aligned(16))) u16 Vs[(1 + X3) * VPL];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int hi = lane >> 5, lq = lane & 31;
     const int bh = blockIdx.y, b = bh / g.H, h = bh - b * g.H;
@@ -76,16 +136,9 @@ __global__ void __launch_bounds__(256) flash_fwd_kernel(AttnArgs g) {
     const float qs = g.scale * LOG2E;                          // scores live in the log2 domain
 
     // Q^T fragments: lane (q, hi) holds q[16 ks + 8 hi .. +8] for ks = 0..3
-    bf16x8 qf[4];
+    bf16x8 qfh[4], qfl[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        union { unsigned u[4]; bf16x8 v; } t;
-        const float4 a = *reinterpret_cast<const float4*>(qp + 16 * ks + 8 * hi);
-        const float4 c = *reinterpret_cast<const float4*>(qp + 16 * ks + 8 * hi + 4);
-        t.u[0] = fa_pack2(a.x * qs, a.y * qs); t.u[1] = fa_pack2(a.z * qs, a.w * qs);
-        t.u[2] = fa_pack2(c.x * qs, c.y * qs); t.u[3] = fa_pack2(c.z * qs, c.w * qs);
-        qf[ks] = t.v;
-    }
+    for (int ks = 0; ks < 4; ++ks) fa_frag8<X3>(qp + 16 * ks + 8 * hi, qs, qfh[ks], qfl[ks]);
     f32x16 oacc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -114,11 +167,8 @@ __global__ void __launch_bounds__(256) flash_fwd_kernel(AttnArgs g) {
         for (int i = 0; i < 4; ++i) {
             const int e = tid + 256 * i;
             const int r = e >> 4, c4 = (e & 15) * 4;
-            uint2 pk, pv;
-            pk.x = fa_pack2(rk[i].x, rk[i].y); pk.y = fa_pack2(rk[i].z, rk[i].w);
-            pv.x = fa_pack2(rv[i].x, rv[i].y); pv.y = fa_pack2(rv[i].z, rv[i].w);
-            *reinterpret_cast<uint2*>(&Ks[r * LDK + c4]) = pk;
-            *reinterpret_cast<uint2*>(&Vs[r * LDV + c4]) = pv;
+            fa_store4<X3>(&Ks[r * LDK + c4], KPL, rk[i], 1.f);
+            fa_store4<X3>(&Vs[r * LDV + c4], VPL, rv[i], 1.f);
         }
     };
 
@@ -145,8 +195,10 @@ __global__ void __launch_bounds__(256) flash_fwd_kernel(AttnArgs g) {
             for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Ks[(kb * 32 + lq) * LDK + 16 * ks + 8 * hi]);
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], sacc[kb], 0, 0, 0);
+                const u16* kp = &Ks[(kb * 32 + lq) * LDK + 16 * ks + 8 * hi];
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(kp);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(kp + X3 * KPL);
+                sacc[kb] = fa_mma<X3>(ah, al, qfh[ks], qfl[ks], sacc[kb]);
             }
         }
         // sacc[kb][r] = score(key = kt*64 + kb*32 + (r&3) + 8*(r>>2) + 4*hi, q = this lane's query), log2 domain
@@ -165,7 +217,7 @@ __global__ void __launch_bounds__(256) flash_fwd_kernel(AttnArgs g) {
         const float alpha = exp2f(m_run - m_new);            // 0 on the first tile (m_run = -inf)
         m_run = m_new;
         float psum = 0.f;
-        unsigned pb[2][8];                                     // P^T fragments (bf16 pairs): [key block][4 dwords x 2 k-steps]
+        unsigned pbh[2][8], pbl[2][8];                         // P^T fragments (bf16 pairs): [key block][4 dwords x 2 k-steps]
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -178,7 +230,8 @@ __global__ void __launch_bounds__(256) flash_fwd_kernel(AttnArgs g) {
                     p0 = (hsh & 0xffffu) >= thr ? p0 * keep_scale : 0.f;
                     p1 = (hsh >> 16) >= thr ? p1 * keep_scale : 0.f;
                 }
-                pb[kb][r >> 1] = fa_pack2(p0, p1);
+                if (X3) fa_split2(p0, p1, pbh[kb][r >> 1], pbl[kb][r >> 1]);
+                else pbh[kb][r >> 1] = fa_pack2(p0, p1);
             }
         l_run = l_run * alpha + psum;
 #pragma unroll
@@ -190,22 +243,26 @@ __global__ void __launch_bounds__(256) flash_fwd_kernel(AttnArgs g) {
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                union { unsigned u[4]; bf16x8 v; } pf;
-                pf.u[0] = pb[kb][4 * ks]; pf.u[1] = pb[kb][4 * ks + 1]; pf.u[2] = pb[kb][4 * ks + 2]; pf.u[3] = pb[kb][4 * ks + 3];
-                unsigned long long va[2][2];
+                const bf16x8 pfh = fa_from4(&pbh[kb][4 * ks]);
+                const bf16x8 pfl = X3 ? fa_from4(&pbl[kb][4 * ks]) : pfh;
+                unsigned long long va[2][2], vl[2][2];
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
                     const unsigned ad = v_base + 2u * (unsigned)((kb * 32 + 16 * ks) * LDV + db * 32);
                     va[db][0] = fa_tr16(ad);
                     va[db][1] = fa_tr16(ad + 2u * (unsigned)(8 * LDV));
+                    if (X3) {
+                        vl[db][0] = fa_tr16(ad + 2u * (unsigned)VPL);
+                        vl[db][1] = fa_tr16(ad + 2u * (unsigned)(VPL + 8 * LDV));
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    union { unsigned long long u[2]; bf16x8 v; } vf;
-                    vf.u[0] = va[db][0]; vf.u[1] = va[db][1];
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, oacc[db], 0, 0, 0);
+                    const bf16x8 vfh = fa_join(va[db][0], va[db][1]);
+                    const bf16x8 vfl = X3 ? fa_join(vl[db][0], vl[db][1]) : vfh;
+                    oacc[db] = fa_mma<X3>(vfh, vfl, pfh, pfl, oacc[db]);
                 }
             }
     }
@@ -267,10 +324,11 @@ __global__ void __launch_bounds__(256) flash_rowdot_kernel(const float* __restri
 // dQ: same swapped structure as the forward pass (lane = query).  Per K/V tile:
 //   S^T = K Q^T (K via ds_read_b128), P = exp2(S^T - lse);  dP^T = V dO^T (V via ds_read_b128);
 //   dS^T = scale * P * (dP * keep/(1-p) - D);  dQ^T += K^T dS^T (K^T via ds_read_b64_tr_b16, dS^T packed from registers)
+template <int X3>
 __global__ void __launch_bounds__(256) flash_bwd_dq_kernel(AttnBwdArgs g) {
-    __shared__ __attribute__((aligned(16))) u16 Kb[BKV * LDK];     // K, b128-friendly stride
-    __shared__ __attribute__((aligned(16))) u16 Kt[BKV * LDV];     // K, transposed-read-friendly stride
-    __shared__ __attribute__((aligned(16))) u16 Vb[BKV * LDK];     // V, b128-friendly stride
+    __shared__ __attribute__((aligned(16))) u16 Kb[(1 + X3) * KPL];     // K, b128-friendly stride
+    __shared__ __attribute__((aligned(16))) u16 Kt[(1 + X3) * VPL];     // K, transposed-read-friendly stride
+    __shared__ __attribute__((aligned(16))) u16 Vb[(1 + X3) * KPL];     // V, b128-friendly stride
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int hi = lane >> 5, lq = lane & 31;
     const int bh = blockIdx.y, b = bh / g.H, h = bh - b * g.H;
@@ -281,19 +339,11 @@ __global__ void __launch_bounds__(256) flash_bwd_dq_kernel(AttnBwdArgs g) {
     const float* kbase = g.kv + (long long)b * g.Nk * 2 * inner + h * HD;
     const float* vbase = kbase + inner;
     const float qs = g.scale * LOG2E;
-    bf16x8 qf[4], dof[4];
+    bf16x8 qfh[4], qfl[4], dofh[4], dofl[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        union { unsigned u[4]; bf16x8 v; } t, u;
-        const float4 a = *reinterpret_cast<const float4*>(g.q + qoff + 16 * ks + 8 * hi);
-        const float4 c = *reinterpret_cast<const float4*>(g.q + qoff + 16 * ks + 8 * hi + 4);
-        t.u[0] = fa_pack2(a.x * qs, a.y * qs); t.u[1] = fa_pack2(a.z * qs, a.w * qs);
-        t.u[2] = fa_pack2(c.x * qs, c.y * qs); t.u[3] = fa_pack2(c.z * qs, c.w * qs);
-        qf[ks] = t.v;
-        const float4 e = *reinterpret_cast<const float4*>(g.d_o + qoff + 16 * ks + 8 * hi);
-        const float4 f = *reinterpret_cast<const float4*>(g.d_o + qoff + 16 * ks + 8 * hi + 4);
-        u.u[0] = fa_pack2(e.x, e.y); u.u[1] = fa_pack2(e.z, e.w); u.u[2] = fa_pack2(f.x, f.y); u.u[3] = fa_pack2(f.z, f.w);
-        dof[ks] = u.v;
+        fa_frag8<X3>(g.q + qoff + 16 * ks + 8 * hi, qs, qfh[ks], qfl[ks]);
+        fa_frag8<X3>(g.d_o + qoff + 16 * ks + 8 * hi, 1.f, dofh[ks], dofl[ks]);
     }
     const float lse2 = q_ok ? g.lse[(long long)bh * g.Nq + qrow] * LOG2E : 0.f;
     const float dsum = q_ok ? g.dsum[(long long)bh * g.Nq + qrow] : 0.f;
@@ -323,12 +373,9 @@ __global__ void __launch_bounds__(256) flash_bwd_dq_kernel(AttnBwdArgs g) {
         for (int i = 0; i < 4; ++i) {
             const int e = tid + 256 * i;
             const int r = e >> 4, c4 = (e & 15) * 4;
-            uint2 pk, pv;
-            pk.x = fa_pack2(rk[i].x, rk[i].y); pk.y = fa_pack2(rk[i].z, rk[i].w);
-            pv.x = fa_pack2(rv[i].x, rv[i].y); pv.y = fa_pack2(rv[i].z, rv[i].w);
-            *reinterpret_cast<uint2*>(&Kb[r * LDK + c4]) = pk;
-            *reinterpret_cast<uint2*>(&Kt[r * LDV + c4]) = pk;
-            *reinterpret_cast<uint2*>(&Vb[r * LDK + c4]) = pv;
+            fa_store4<X3>(&Kb[r * LDK + c4], KPL, rk[i], 1.f);
+            fa_store4<X3>(&Kt[r * LDV + c4], VPL, rk[i], 1.f);
+            fa_store4<X3>(&Vb[r * LDK + c4], KPL, rv[i], 1.f);
         }
     };
     const unsigned thr = (unsigned)(g.p_drop * 65536.0f);
@@ -351,14 +398,16 @@ __global__ void __launch_bounds__(256) flash_bwd_dq_kernel(AttnBwdArgs g) {
             for (int r = 0; r < 16; ++r) { sacc[kb][r] = 0.f; pacc[kb][r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Kb[(kb * 32 + lq) * LDK + 16 * ks + 8 * hi]);
-                const bf16x8 c = *reinterpret_cast<const bf16x8*>(&Vb[(kb * 32 + lq) * LDK + 16 * ks + 8 * hi]);
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], sacc[kb], 0, 0, 0);
-                pacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c, dof[ks], pacc[kb], 0, 0, 0);
+                const u16* kp = &Kb[(kb * 32 + lq) * LDK + 16 * ks + 8 * hi];
+                const u16* vp = &Vb[(kb * 32 + lq) * LDK + 16 * ks + 8 * hi];
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(kp), al = *reinterpret_cast<const bf16x8*>(kp + X3 * KPL);
+                const bf16x8 ch = *reinterpret_cast<const bf16x8*>(vp), cl = *reinterpret_cast<const bf16x8*>(vp + X3 * KPL);
+                sacc[kb] = fa_mma<X3>(ah, al, qfh[ks], qfl[ks], sacc[kb]);
+                pacc[kb] = fa_mma<X3>(ch, cl, dofh[ks], dofl[ks], pacc[kb]);
             }
         }
         const int kbase_t = kt * BKV;
-        unsigned sb[2][8];
+        unsigned sbh[2][8], sbl[2][8];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -372,28 +421,34 @@ __global__ void __launch_bounds__(256) flash_bwd_dq_kernel(AttnBwdArgs g) {
                     d0 = (hsh & 0xffffu) >= thr ? d0 * keep_scale : 0.f;
                     d1 = (hsh >> 16) >= thr ? d1 * keep_scale : 0.f;
                 }
-                sb[kb][r >> 1] = fa_pack2(g.scale * p0 * (d0 - dsum), g.scale * p1 * (d1 - dsum));
+                const float s0 = g.scale * p0 * (d0 - dsum), s1 = g.scale * p1 * (d1 - dsum);
+                if (X3) fa_split2(s0, s1, sbh[kb][r >> 1], sbl[kb][r >> 1]);
+                else sbh[kb][r >> 1] = fa_pack2(s0, s1);
             }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                union { unsigned u[4]; bf16x8 v; } sf;
-                sf.u[0] = sb[kb][4 * ks]; sf.u[1] = sb[kb][4 * ks + 1]; sf.u[2] = sb[kb][4 * ks + 2]; sf.u[3] = sb[kb][4 * ks + 3];
-                unsigned long long ka[2][2];
+                const bf16x8 sfh = fa_from4(&sbh[kb][4 * ks]);
+                const bf16x8 sfl = X3 ? fa_from4(&sbl[kb][4 * ks]) : sfh;
+                unsigned long long ka[2][2], kl[2][2];
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
                     const unsigned ad = k_base + 2u * (unsigned)((kb * 32 + 16 * ks) * LDV + db * 32);
                     ka[db][0] = fa_tr16(ad);
                     ka[db][1] = fa_tr16(ad + 2u * (unsigned)(8 * LDV));
+                    if (X3) {
+                        kl[db][0] = fa_tr16(ad + 2u * (unsigned)VPL);
+                        kl[db][1] = fa_tr16(ad + 2u * (unsigned)(VPL + 8 * LDV));
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    union { unsigned long long u[2]; bf16x8 v; } kf;
-                    kf.u[0] = ka[db][0]; kf.u[1] = ka[db][1];
-                    dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.v, sf.v, dqacc[db], 0, 0, 0);
+                    const bf16x8 kfh = fa_join(ka[db][0], ka[db][1]);
+                    const bf16x8 kfl = X3 ? fa_join(kl[db][0], kl[db][1]) : kfh;
+                    dqacc[db] = fa_mma<X3>(kfh, kfl, sfh, sfl, dqacc[db]);
                 }
             }
     }
@@ -413,11 +468,12 @@ __global__ void __launch_bounds__(256) flash_bwd_dq_kernel(AttnBwdArgs g) {
 //   S = Q K^T, dP = dO V^T   : A = Q / dO rows from LDS (ds_read_b128), B = K^T / V^T fragments in registers
 //   P = exp2(S - lse[q]), dS = scale * P * (dP * keep/(1-p) - D[q])      (lse / D per register row, from LDS)
 //   dV += Pd^T dO, dK += dS^T Q : A = the P / dS registers packed to bf16, B = dO / Q via ds_read_b64_tr_b16
+template <int X3>
 __global__ void __launch_bounds__(256) flash_bwd_dkv_kernel(AttnBwdArgs g) {
-    __shared__ __attribute__((aligned(16))) u16 Qb[BKV * LDK];
-    __shared__ __attribute__((aligned(16))) u16 Qt[BKV * LDV];
-    __shared__ __attribute__((aligned(16))) u16 Ob[BKV * LDK];
-    __shared__ __attribute__((aligned(16))) u16 Ot[BKV * LDV];
+    __shared__ __attribute__((aligned(16))) u16 Qb[(1 + X3) * KPL];
+    __shared__ __attribute__((aligned(16))) u16 Qt[(1 + X3) * VPL];
+    __shared__ __attribute__((aligned(16))) u16 Ob[(1 + X3) * KPL];
+    __shared__ __attribute__((aligned(16))) u16 Ot[(1 + X3) * VPL];
     __shared__ float s_lse[BKV], s_dsum[BKV];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int hi = lane >> 5, lk = lane & 31;
@@ -429,18 +485,11 @@ __global__ void __launch_bounds__(256) flash_bwd_dkv_kernel(AttnBwdArgs g) {
     const float* qbase = g.q + (long long)b * g.Nq * inner + h * HD;
     const float* dobase = g.d_o + (long long)b * g.Nq * inner + h * HD;
     const float qs = g.scale * LOG2E;
-    bf16x8 kf[4], vf[4];                 // K^T / V^T fragments: lane (key, hi) holds k[16 ks + 8 hi .. +8]
+    bf16x8 kfh[4], kfl[4], vfh[4], vfl[4];     // K^T / V^T fragments: lane (key, hi) holds k[16 ks + 8 hi .. +8]
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        union { unsigned u[4]; bf16x8 v; } t, u;
-        const float4 a = *reinterpret_cast<const float4*>(g.kv + koff + 16 * ks + 8 * hi);
-        const float4 c = *reinterpret_cast<const float4*>(g.kv + koff + 16 * ks + 8 * hi + 4);
-        t.u[0] = fa_pack2(a.x, a.y); t.u[1] = fa_pack2(a.z, a.w); t.u[2] = fa_pack2(c.x, c.y); t.u[3] = fa_pack2(c.z, c.w);
-        kf[ks] = t.v;
-        const float4 e = *reinterpret_cast<const float4*>(g.kv + koff + inner + 16 * ks + 8 * hi);
-        const float4 f = *reinterpret_cast<const float4*>(g.kv + koff + inner + 16 * ks + 8 * hi + 4);
-        u.u[0] = fa_pack2(e.x, e.y); u.u[1] = fa_pack2(e.z, e.w); u.u[2] = fa_pack2(f.x, f.y); u.u[3] = fa_pack2(f.z, f.w);
-        vf[ks] = u.v;
+        fa_frag8<X3>(g.kv + koff + 16 * ks + 8 * hi, 1.f, kfh[ks], kfl[ks]);
+        fa_frag8<X3>(g.kv + koff + inner + 16 * ks + 8 * hi, 1.f, vfh[ks], vfl[ks]);
     }
     f32x16 dkacc[2], dvacc[2];
 #pragma unroll
@@ -474,13 +523,10 @@ __global__ void __launch_bounds__(256) flash_bwd_dkv_kernel(AttnBwdArgs g) {
         for (int i = 0; i < 4; ++i) {
             const int e = tid + 256 * i;
             const int r = e >> 4, c4 = (e & 15) * 4;
-            uint2 pq, po;
-            pq.x = fa_pack2(rq[i].x * qs, rq[i].y * qs); pq.y = fa_pack2(rq[i].z * qs, rq[i].w * qs);
-            po.x = fa_pack2(ro[i].x, ro[i].y); po.y = fa_pack2(ro[i].z, ro[i].w);
-            *reinterpret_cast<uint2*>(&Qb[r * LDK + c4]) = pq;
-            *reinterpret_cast<uint2*>(&Qt[r * LDV + c4]) = pq;
-            *reinterpret_cast<uint2*>(&Ob[r * LDK + c4]) = po;
-            *reinterpret_cast<uint2*>(&Ot[r * LDV + c4]) = po;
+            fa_store4<X3>(&Qb[r * LDK + c4], KPL, rq[i], qs);
+            fa_store4<X3>(&Qt[r * LDV + c4], VPL, rq[i], qs);
+            fa_store4<X3>(&Ob[r * LDK + c4], KPL, ro[i], 1.f);
+            fa_store4<X3>(&Ot[r * LDV + c4], VPL, ro[i], 1.f);
         }
         if (tid < BKV) { s_lse[tid] = rl; s_dsum[tid] = rd; }
     };
@@ -506,14 +552,16 @@ __global__ void __launch_bounds__(256) flash_bwd_dkv_kernel(AttnBwdArgs g) {
             for (int r = 0; r < 16; ++r) { sacc[qb][r] = 0.f; pacc[qb][r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Qb[(qb * 32 + lk) * LDK + 16 * ks + 8 * hi]);
-                const bf16x8 c = *reinterpret_cast<const bf16x8*>(&Ob[(qb * 32 + lk) * LDK + 16 * ks + 8 * hi]);
-                sacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[ks], sacc[qb], 0, 0, 0);
-                pacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c, vf[ks], pacc[qb], 0, 0, 0);
+                const u16* qp = &Qb[(qb * 32 + lk) * LDK + 16 * ks + 8 * hi];
+                const u16* op = &Ob[(qb * 32 + lk) * LDK + 16 * ks + 8 * hi];
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(qp), al = *reinterpret_cast<const bf16x8*>(qp + X3 * KPL);
+                const bf16x8 ch = *reinterpret_cast<const bf16x8*>(op), cl = *reinterpret_cast<const bf16x8*>(op + X3 * KPL);
+                sacc[qb] = fa_mma<X3>(ah, al, kfh[ks], kfl[ks], sacc[qb]);
+                pacc[qb] = fa_mma<X3>(ch, cl, vfh[ks], vfl[ks], pacc[qb]);
             }
         }
         // sacc[qb][r] = S[q = qt*64 + qb*32 + (r&3) + 8*(r>>2) + 4*hi][key = this lane's key]
-        unsigned pb[2][8], sb[2][8];
+        unsigned pbh[2][8], pbl[2][8], sbh[2][8], sbl[2][8];
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
@@ -532,18 +580,23 @@ __global__ void __launch_bounds__(256) flash_bwd_dkv_kernel(AttnBwdArgs g) {
                     d0 = k0 ? d0 * keep_scale : 0.f; d1 = k1 ? d1 * keep_scale : 0.f;
                     pd0 = k0 ? p0 * keep_scale : 0.f; pd1 = k1 ? p1 * keep_scale : 0.f;
                 }
-                pb[qb][r >> 1] = fa_pack2(pd0, pd1);
-                sb[qb][r >> 1] = fa_pack2(g.scale * p0 * (d0 - s_dsum[ql]), g.scale * p1 * (d1 - s_dsum[ql + 1]));
+                const float s0 = g.scale * p0 * (d0 - s_dsum[ql]), s1 = g.scale * p1 * (d1 - s_dsum[ql + 1]);
+                if (X3) {
+                    fa_split2(pd0, pd1, pbh[qb][r >> 1], pbl[qb][r >> 1]);
+                    fa_split2(s0, s1, sbh[qb][r >> 1], sbl[qb][r >> 1]);
+                } else {
+                    pbh[qb][r >> 1] = fa_pack2(pd0, pd1);
+                    sbh[qb][r >> 1] = fa_pack2(s0, s1);
+                }
             }
         // dV += Pd^T dO ; dK += dS^T Q : contraction over the 64 queries = 2 q-blocks x 2 k-steps of 16
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                union { unsigned u[4]; bf16x8 v; } pf, sf;
-#pragma unroll
-                for (int w4 = 0; w4 < 4; ++w4) { pf.u[w4] = pb[qb][4 * ks + w4]; sf.u[w4] = sb[qb][4 * ks + w4]; }
-                unsigned long long oa[2][2], qa[2][2];
+                const bf16x8 pfh = fa_from4(&pbh[qb][4 * ks]), sfh = fa_from4(&sbh[qb][4 * ks]);
+                const bf16x8 pfl = X3 ? fa_from4(&pbl[qb][4 * ks]) : pfh, sfl = X3 ? fa_from4(&sbl[qb][4 * ks]) : sfh;
+                unsigned long long oa[2][2], qa[2][2], ol[2][2], ql2[2][2];
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
                     const unsigned ro2 = 2u * (unsigned)((qb * 32 + 16 * ks) * LDV + db * 32);
@@ -551,16 +604,21 @@ __global__ void __launch_bounds__(256) flash_bwd_dkv_kernel(AttnBwdArgs g) {
                     oa[db][1] = fa_tr16(o_base + ro2 + 2u * (unsigned)(8 * LDV));
                     qa[db][0] = fa_tr16(q_base + ro2);
                     qa[db][1] = fa_tr16(q_base + ro2 + 2u * (unsigned)(8 * LDV));
+                    if (X3) {
+                        ol[db][0] = fa_tr16(o_base + ro2 + 2u * (unsigned)VPL);
+                        ol[db][1] = fa_tr16(o_base + ro2 + 2u * (unsigned)(VPL + 8 * LDV));
+                        ql2[db][0] = fa_tr16(q_base + ro2 + 2u * (unsigned)VPL);
+                        ql2[db][1] = fa_tr16(q_base + ro2 + 2u * (unsigned)(VPL + 8 * LDV));
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    union { unsigned long long u[2]; bf16x8 v; } of, qf2;
-                    of.u[0] = oa[db][0]; of.u[1] = oa[db][1];
-                    qf2.u[0] = qa[db][0]; qf2.u[1] = qa[db][1];
-                    dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf.v, of.v, dvacc[db], 0, 0, 0);
-                    dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sf.v, qf2.v, dkacc[db], 0, 0, 0);
+                    const bf16x8 ofh = fa_join(oa[db][0], oa[db][1]), q2h = fa_join(qa[db][0], qa[db][1]);
+                    const bf16x8 ofl = X3 ? fa_join(ol[db][0], ol[db][1]) : ofh, q2l = X3 ? fa_join(ql2[db][0], ql2[db][1]) : q2h;
+                    dvacc[db] = fa_mma<X3>(pfh, pfl, ofh, ofl, dvacc[db]);
+                    dkacc[db] = fa_mma<X3>(sfh, sfl, q2h, q2l, dkacc[db]);
                 }
             }
     }
@@ -579,26 +637,23 @@ __global__ void __launch_bounds__(256) flash_bwd_dkv_kernel(AttnBwdArgs g) {
         }
 }
 
-}  // namespace
-
-// O = dropout(softmax(scale * Q K^T)) V per (b, h), head dim 64; lse[b*H + h][q] = log sum exp of the scaled scores.
-extern "C" int vxb_flash_attn_fwd_bf16(const float* q, const float* kv, float* o, float* lse, int B, int H, int Nq, int Nk,
-                                       int head_dim, float scale, float dropout_p, uint32_t seed, vxb_stream_t stream) {
+int fa_fwd_impl(int x3, const float* q, const float* kv, float* o, float* lse, int B, int H, int Nq, int Nk, int head_dim,
+                float scale, float dropout_p, uint32_t seed, vxb_stream_t stream) {
     if (!q || !kv || !o || !lse || B < 1 || H < 1 || Nq < 1 || Nk < 1) return VXB_EARG;
     if (head_dim != HD || dropout_p < 0.f || dropout_p >= 1.f) return VXB_ESIZE;
     AttnArgs g;
     g.q = q; g.kv = kv; g.o = o; g.lse = lse; g.B = B; g.H = H; g.Nq = Nq; g.Nk = Nk;
     g.scale = scale; g.p_drop = dropout_p; g.seed = seed;
-    hipLaunchKernelGGL(flash_fwd_kernel, dim3(vxb_cdiv(Nq, BQ), B * H), dim3(256), 0, (hipStream_t)stream, g);
+    const dim3 grid(vxb_cdiv(Nq, BQ), B * H);
+    if (x3) hipLaunchKernelGGL(flash_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(flash_fwd_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, g);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
 
-// Backward of the fused attention: dq [B,Nq,H*64] and dkv [B,Nk,2*H*64] are WRITTEN.  o / lse come from the forward call;
-// dsum_ws: B*H*Nq floats of scratch.  Same (seed, dropout_p) as the forward call.
-extern "C" int vxb_flash_attn_bwd_bf16(const float* q, const float* kv, const float* o, const float* d_o, const float* lse,
-                                       float* dq, float* dkv, float* dsum_ws, int B, int H, int Nq, int Nk, int head_dim,
-                                       float scale, float dropout_p, uint32_t seed, vxb_stream_t stream) {
+int fa_bwd_impl(int x3, const float* q, const float* kv, const float* o, const float* d_o, const float* lse, float* dq,
+                float* dkv, float* dsum_ws, int B, int H, int Nq, int Nk, int head_dim, float scale, float dropout_p,
+                uint32_t seed, vxb_stream_t stream) {
     if (!q || !kv || !o || !d_o || !lse || !dq || !dkv || !dsum_ws || B < 1 || H < 1 || Nq < 1 || Nk < 1) return VXB_EARG;
     if (head_dim != HD || dropout_p < 0.f || dropout_p >= 1.f) return VXB_ESIZE;
     hipStream_t st = (hipStream_t)stream;
@@ -607,8 +662,38 @@ extern "C" int vxb_flash_attn_bwd_bf16(const float* q, const float* kv, const fl
     AttnBwdArgs g;
     g.q = q; g.kv = kv; g.d_o = d_o; g.lse = lse; g.dsum = dsum_ws; g.dq = dq; g.dkv = dkv;
     g.B = B; g.H = H; g.Nq = Nq; g.Nk = Nk; g.scale = scale; g.p_drop = dropout_p; g.seed = seed;
-    hipLaunchKernelGGL(flash_bwd_dq_kernel, dim3(vxb_cdiv(Nq, BQ), B * H), dim3(256), 0, st, g);
-    hipLaunchKernelGGL(flash_bwd_dkv_kernel, dim3(vxb_cdiv(Nk, BQ), B * H), dim3(256), 0, st, g);
+    if (x3) {
+        hipLaunchKernelGGL(flash_bwd_dq_kernel<1>, dim3(vxb_cdiv(Nq, BQ), B * H), dim3(256), 0, st, g);
+        hipLaunchKernelGGL(flash_bwd_dkv_kernel<1>, dim3(vxb_cdiv(Nk, BQ), B * H), dim3(256), 0, st, g);
+    } else {
+        hipLaunchKernelGGL(flash_bwd_dq_kernel<0>, dim3(vxb_cdiv(Nq, BQ), B * H), dim3(256), 0, st, g);
+        hipLaunchKernelGGL(flash_bwd_dkv_kernel<0>, dim3(vxb_cdiv(Nk, BQ), B * H), dim3(256), 0, st, g);
+    }
     VXB_CHECK_LAUNCH();
     return VXB_OK;
+}
+
+}  // namespace
+
+// O = dropout(softmax(scale * Q K^T)) V per (b, h), head dim 64; lse[b*H + h][q] = log sum exp of the scaled scores.
+extern "C" int vxb_flash_attn_fwd_bf16(const float* q, const float* kv, float* o, float* lse, int B, int H, int Nq, int Nk,
+                                       int head_dim, float scale, float dropout_p, uint32_t seed, vxb_stream_t stream) {
+    return fa_fwd_impl(0, q, kv, o, lse, B, H, Nq, Nk, head_dim, scale, dropout_p, seed, stream);
+}
+extern "C" int vxb_flash_attn_fwd_bf16x3(const float* q, const float* kv, float* o, float* lse, int B, int H, int Nq, int Nk,
+                                         int head_dim, float scale, float dropout_p, uint32_t seed, vxb_stream_t stream) {
+    return fa_fwd_impl(1, q, kv, o, lse, B, H, Nq, Nk, head_dim, scale, dropout_p, seed, stream);
+}
+
+// Backward of the fused attention: dq [B,Nq,H*64] and dkv [B,Nk,2*H*64] are WRITTEN.  o / lse come from the forward call;
+// dsum_ws: B*H*Nq floats of scratch.  Same (seed, dropout_p) as the forward call.
+extern "C" int vxb_flash_attn_bwd_bf16(const float* q, const float* kv, const float* o, const float* d_o, const float* lse,
+                                       float* dq, float* dkv, float* dsum_ws, int B, int H, int Nq, int Nk, int head_dim,
+                                       float scale, float dropout_p, uint32_t seed, vxb_stream_t stream) {
+    return fa_bwd_impl(0, q, kv, o, d_o, lse, dq, dkv, dsum_ws, B, H, Nq, Nk, head_dim, scale, dropout_p, seed, stream);
+}
+extern "C" int vxb_flash_attn_bwd_bf16x3(const float* q, const float* kv, const float* o, const float* d_o, const float* lse,
+                                         float* dq, float* dkv, float* dsum_ws, int B, int H, int Nq, int Nk, int head_dim,
+                                         float scale, float dropout_p, uint32_t seed, vxb_stream_t stream) {
+    return fa_bwd_impl(1, q, kv, o, d_o, lse, dq, dkv, dsum_ws, B, H, Nq, Nk, head_dim, scale, dropout_p, seed, stream);
 }
