@@ -26,6 +26,7 @@ import torch
 import torch.distributed as dist
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (no sparsity)
 PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured achievable)
 
 
@@ -40,7 +41,8 @@ def main():
     ap.add_argument('--depth', type=int, default=6)
     ap.add_argument('--latents', type=int, default=2048)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-bf16-mode', action='store_true', help='skip the secondary bf16 throughput-mode measurement')
+    ap.add_argument('--no-other-modes', '--no-bf16-mode', dest='no_other_modes', action='store_true',
+                    help='skip the secondary measurements in the other precisions and the parity probe')
     ap.add_argument('--cpu-voxel-size', type=int, default=0, help='debug: smaller grid for the CPU baseline leg')
     ap.add_argument('--kernel-table', action='store_true', help='print the per-kernel timing table to stderr')
     a = ap.parse_args()
@@ -70,98 +72,90 @@ def main():
     batches = [{k: v.to(dev) for k, v in synthetic.make_replay_sample(
         B, cfg.rlbench.cameras, (HW, HW), V, 4, seed=100 * rank + j).items()} for j in range(2)]
 
-    def step(i):
+    eng = agent._pose_agent._qattention_agents[0]._q.encoder.engine()
+    headline_mode = eng.precision          # 'bf16x3' unless VOXACTB_PRECISION overrides it
+    counter = [0]
+
+    def step():
+        i = counter[0]
+        counter[0] += 1
         out = agent.update(i, batches[i % 2])
         return float(out['total_losses'])          # the runner's .item() (device sync every step)
 
-    torch.manual_seed(1000 + rank)    # augmentation draws differ per rank, as they would with per-rank replay shards
-    for i in range(a.warmup):
-        step(i)
-    timer = _lib.KernelTimer()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    _lib.TIMER = timer
-    t0 = time.perf_counter()
-    loss = None
-    for i in range(a.steps):
-        loss = step(a.warmup + i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    _lib.TIMER = None
-    tt = torch.tensor([dt], device=dev)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt[0])
-    agg = timer.summary()
-
-    # secondary measurement, same workload: bf16 matrix-core throughput mode (never the headline `value`)
-    bf16 = None
-    if not a.no_bf16_mode:
-        eng = agent._pose_agent._qattention_agents[0]._q.encoder.engine()
-        eng.precision = 'bf16'
-        step(a.warmup + a.steps)
+    def measure(mode, steps, warmup):
+        """W untimed + exactly K timed update() steps in `mode`, bracketed by barrier + synchronize; max over ranks."""
+        eng.precision = mode
+        for _ in range(warmup):
+            step()
+        timer = _lib.KernelTimer()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        timer2 = _lib.KernelTimer()
-        _lib.TIMER = timer2
-        t1 = time.perf_counter()
-        for i in range(a.steps):
-            step(a.warmup + a.steps + 1 + i)
+        _lib.TIMER = timer
+        t0 = time.perf_counter()
+        loss = None
+        for _ in range(steps):
+            loss = step()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        t2 = torch.tensor([time.perf_counter() - t1], device=dev)
-        if world > 1:
-            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
-        eng.precision = 'fp32'
+        dt = time.perf_counter() - t0
         _lib.TIMER = None
-        agg2 = timer2.summary()
-        bf_roof = {}
-        for key, pref in (('attention_flash_fwd_bwd', 'attn_core'), ('conv3d', 'conv3d'), ('linear_gemms', 'gemm')):
-            ms = sum(d['ms'] for l, d in agg2.items() if l.startswith(pref))
-            fl = sum(d['flops'] for l, d in agg2.items() if l.startswith(pref))
-            if ms > 0:
-                bf_roof[key] = {'bound': 'mfma', 'achieved': fl / (ms * 1e-3) / 1e12, 'peak': 2500.0, 'unit': 'TFLOP/s',
-                                'frac': fl / (ms * 1e-3) / 1e12 / 2500.0, 'ms_per_step': ms / a.steps}
-        bf16 = {'rooflines': bf_roof,'value': world * a.steps / float(t2[0]), 'unit': 'steps/s', 'ms_per_step': float(t2[0]) / a.steps * 1e3,
-                'dtype': 'bf16 matrix cores (fp32 accumulate) for conv fwd/dgrad/wgrad + large linears; everything else f32',
-                'note': 'not held to the 1e-4 Q-value bound (tests/test_bf16_mode_gpu.py: 4e-3 on q_trans); '
-                        'the headline value above is the fp32 parity mode'}
+        tt = torch.tensor([dt], device=dev)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        eng.precision = headline_mode
+        return float(tt[0]), loss, timer.summary()
+
+    torch.manual_seed(1000 + rank)    # augmentation draws differ per rank, as they would with per-rank replay shards
+    dt, loss, agg = measure(headline_mode, a.steps, a.warmup)
+
+    # secondary measurements of the same workload in the other precisions (never the headline `value`)
+    others = {}
+    if not a.no_other_modes:
+        for mode in ('fp32', 'bf16x3', 'bf16'):
+            if mode == headline_mode:
+                continue
+            dt2, _, agg2 = measure(mode, a.steps, 1)
+            others[mode] = {'value': world * a.steps / dt2, 'unit': 'steps/s', 'ms_per_step': dt2 / a.steps * 1e3,
+                            'dtype': MODE_DTYPE[mode], 'rooflines': group_rooflines(agg2, mode, a.steps),
+                            'note': MODE_NOTE[mode]}
+
+    # how far the headline precision is from the exact-fp32 matrix-core path on THIS workload (forward, eval mode, B=2)
+    probe = None
+    if rank == 0 and headline_mode != 'fp32' and not a.no_other_modes:
+        g = torch.Generator(device='cpu').manual_seed(5)
+        grid = (torch.rand(2, V, V, V, 10, generator=g) * (torch.rand(2, V, V, V, 1, generator=g) < 0.05)).to(dev)
+        prop = batches[0]['low_dim_state'][:2, 0].float() if batches[0]['low_dim_state'].dim() > 2 else batches[0]['low_dim_state'][:2].float()
+        lang = batches[0]['lang_token_embs'][:2, 0].float() if batches[0]['lang_token_embs'].dim() > 3 else batches[0]['lang_token_embs'][:2].float()
+        qs = {}
+        for mode in (headline_mode, 'fp32'):
+            eng.precision = mode
+            outs, _ = eng.forward(grid, prop, lang, training=False, save=False)
+            qs[mode] = [o.float().clone() for o in outs[:3]]
+        eng.precision = headline_mode
+        probe = {'what': 'max |Q(%s) - Q(exact fp32 MFMA)| over q_trans / rot_grip / collision, V=%d forward, B=2, eval' % (headline_mode, V),
+                 'q_trans': float((qs[headline_mode][0] - qs['fp32'][0]).abs().max()),
+                 'rot_grip': float((qs[headline_mode][1] - qs['fp32'][1]).abs().max()),
+                 'collision': float((qs[headline_mode][2] - qs['fp32'][2]).abs().max()),
+                 'q_trans_abs_max': float(qs['fp32'][0].abs().max()), 'bound': 1e-4}
 
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         value = world * a.steps / dt
-        # dominant kernel group = largest share of device time
         tot_ms = sum(d['ms'] for d in agg.values())
-        dom_label, dom = max(agg.items(), key=lambda kv: kv[1]['ms'])
-        groups = {}
-        for label, d in agg.items():
-            key = 'conv3d (all implicit-GEMM launches)' if label.startswith('conv3d') else \
-                  ('gemm (linear layers)' if label.startswith('gemm') else label)
-            gd = groups.setdefault(key, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
-            for f in ('calls', 'ms', 'flops', 'bytes'):
-                gd[f] += d[f]
-        dom_key, domg = max(groups.items(), key=lambda kv: kv[1]['ms'])
-        roofline = {'kernel': dom_key, 'bound': 'mfma', 'achieved': domg['flops'] / (domg['ms'] * 1e-3) / 1e12,
-                    'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'traffic': None,
-                    'launches': domg['calls'], 'avg_launch_ms': domg['ms'] / max(domg['calls'], 1),
-                    'share_of_device_time': domg['ms'] / tot_ms}
-        roofline['frac'] = roofline['achieved'] / roofline['peak']
-        extra = {}
+        roofs = group_rooflines(agg, headline_mode, a.steps)
+        dom_key = max(roofs, key=lambda k: roofs[k]['ms_per_step'])
+        roofline = dict(roofs[dom_key])
+        roofline['kernel'] = dom_key
+        roofline['traffic'] = None
+        roofline['share_of_device_time'] = roofline['ms_per_step'] * a.steps / tot_ms
+        extra = {k: v for k, v in roofs.items() if k != dom_key}
         if 'voxelize' in agg:
             v = agg['voxelize']
             gbps = v['bytes'] / (v['ms'] * 1e-3) / 1e9
             extra['voxel_scatter'] = {'bound': 'hbm', 'achieved': gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
                                       'frac': gbps / PEAK_HBM_GBPS, 'avg_launch_ms': v['ms'] / v['calls'], 'traffic': None}
-        if 'attn_core' in agg:
-            v = agg['attn_core']
-            tf = v['flops'] / (v['ms'] * 1e-3) / 1e12
-            extra['attention_qk_pv'] = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                                        'frac': tf / PEAK_FP32_MFMA_TFLOPS, 'dtype': 'f32', 'share_of_device_time': v['ms'] / tot_ms}
         if a.kernel_table:
             for label, d in sorted(agg.items(), key=lambda kv: -kv[1]['ms']):
                 sys.stderr.write('%-44s calls %5d  %9.2f ms/step  %7.2f TF/s\n' % (
@@ -172,17 +166,52 @@ def main():
         out = {
             'metric': 'voxel-policy train steps/sec (100^3 grid, 4 cams, B=16)', 'value': value, 'unit': 'steps/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': MODE_DTYPE[headline_mode], 'data': 'synthetic',
             'config': {'workload': 'BASELINE.json configs[1]: QAttentionPerActBCAgent.update(), V=%d, %d cams %dx%d, '
                                    'B=%d per GPU, PerceiverIO depth %d, %d latents, SE(3) aug + dropout on, LAMB'
                                    % (V, len(cfg.rlbench.cameras), HW, HW, B, a.depth, a.latents),
-                       'global_batch': B * world, 'parallelism': 'dp%d' % world, 'params': n_params},
+                       'global_batch': B * world, 'parallelism': 'dp%d' % world, 'params': n_params,
+                       'precision': headline_mode},
             'samples_per_s': value * B, 'final_loss': loss, 'device_time_ms_per_step': tot_ms / a.steps,
-            'roofline': roofline, 'rooflines_other': extra, 'cpu_baseline': cpu, 'throughput_mode_bf16': bf16,
+            'roofline': roofline, 'rooflines_other': extra, 'cpu_baseline': cpu, 'precision_note': MODE_NOTE[headline_mode],
+            'parity_probe': probe, 'other_precisions': others,
         }
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+MODE_DTYPE = {
+    'fp32': 'f32 (v_mfma_f32_32x32x2_f32 everywhere)',
+    'bf16x3': 'f32 storage / accumulate; matrix products as bf16x3 split (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16)',
+    'bf16': 'bf16 matrix cores (fp32 accumulate) for convs, large linears and fused attention; everything else f32',
+}
+MODE_NOTE = {
+    'fp32': 'exact fp32 matrix cores: the reference-parity mode of the first measurements (tests/test_encoder_gpu.py, 1e-4)',
+    'bf16x3': 'held to the same 1e-4 Q-value / 2e-5 per-op bounds as the exact-fp32 mode (tests/test_encoder_gpu.py::'
+              'test_encoder_fixtures_bf16x3_split_mode, test_bf16x3_gpu.py, test_flash_x3_gpu.py); 3 MFMAs per product',
+    'bf16': 'throughput mode, NOT held to the 1e-4 Q-value bound (tests/test_bf16_mode_gpu.py: ~4e-3 on q_trans)',
+}
+# matrix-core roof per algorithmic FLOP: fp32 MFMA; bf16 dense MFMA / 3 instructions per product; bf16 dense MFMA
+MODE_PEAK = {'fp32': PEAK_FP32_MFMA_TFLOPS, 'bf16x3': PEAK_BF16_MFMA_TFLOPS / 3.0, 'bf16': PEAK_BF16_MFMA_TFLOPS}
+
+
+def group_rooflines(agg, mode, steps):
+    """conv / linear / attention kernel groups: algorithmic TFLOP/s against the matrix-core roof of the precision."""
+    out = {}
+    for key, pref in (('conv3d (implicit-GEMM + LDS-halo launches)', 'conv3'), ('gemm (linear layers)', 'gemm'),
+                      ('attention (QK^T, PV and their gradients)', 'attn_core')):
+        ms = sum(d['ms'] for l, d in agg.items() if l.startswith(pref))
+        fl = sum(d['flops'] for l, d in agg.items() if l.startswith(pref))
+        calls = sum(d['calls'] for l, d in agg.items() if l.startswith(pref))
+        if ms > 0:
+            peak = MODE_PEAK[mode]
+            tf = fl / (ms * 1e-3) / 1e12
+            out[key] = {'bound': 'mfma', 'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak,
+                        'peak_basis': {'fp32': 'fp32 MFMA 157.3', 'bf16x3': 'bf16 dense MFMA 2500 / 3 MFMAs per product',
+                                       'bf16': 'bf16 dense MFMA 2500'}[mode],
+                        'launches': calls // steps, 'avg_launch_ms': ms / max(calls, 1), 'ms_per_step': ms / steps}
+    return out
 
 
 def cpu_baseline(a, cfg):

@@ -248,12 +248,14 @@ class PerceiverEngine:
             self._Lt_host = Lt
         self._Lt = None
         self.step_seed = 0
-        # 'fp32': exact fp32 matrix cores everywhere (parity mode).  'bf16': forward / data-gradient convs and large
-        # linears on bf16 matrix cores with fp32 accumulation (throughput mode; see ops.PRECISION).  'bf16x3': the same
-        # kernels with every fp32 operand split into hi + lo bf16 halves and three MFMAs per product (fp32-faithful to
-        # ~2^-16 per product; attention core stays on the exact fp32 matrix cores).
+        # Precision of the matrix-core kernels (tensors, accumulators, softmax / norm statistics are fp32 in every mode):
+        #   'bf16x3' (default): every fp32 operand is used as hi + lo bf16 halves, three bf16 MFMAs per product
+        #             (hi*hi + hi*lo + lo*hi, <= 2^-16 relative per product) -- convs, linears and the fused attention;
+        #             held to the same 1e-4 Q-value bound as 'fp32' (tests/test_encoder_gpu.py)
+        #   'fp32'  : exact fp32 matrix cores (v_mfma_f32_32x32x2_f32) everywhere, unfused attention
+        #   'bf16'  : plain bf16 operands (throughput mode, ~4e-3 on Q-values)
         import os
-        self.precision = os.environ.get('VOXACTB_PRECISION', 'fp32')
+        self.precision = os.environ.get('VOXACTB_PRECISION', 'bf16x3')
         if self.precision not in ('fp32', 'bf16', 'bf16x3'):
             raise ValueError('VOXACTB_PRECISION must be fp32, bf16x3 or bf16')
         self.fused_attention = os.environ.get('VOXACTB_FUSED_ATTENTION', '1') != '0'   # bf16 / bf16x3 modes, head dim 64
