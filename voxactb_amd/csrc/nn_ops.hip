@@ -120,7 +120,62 @@ __global__ void __launch_bounds__(256) sum_splits_kernel(const float* __restrict
     }
 }
 
-// column sums, stage 1: part[blk][N] over a slab of rows
+// column sums of a DENSE [rows, N] matrix whose row length divides 1024 floats (N = 64 ... 1024, the bias gradients of
+// the voxel-sized convs): the slab is streamed as one flat array with float4 loads -- thread t always lands on the same
+// 4 columns, so it keeps 4 running sums and the block folds the 1024 / N threads of a column group at the end.
+// Fixed summation order -> deterministic.
+__global__ void __launch_bounds__(256) colsum_flat_kernel(const float* __restrict__ x, long long rows, int N,
+                                                          int rows_per_block, float* __restrict__ part) {
+    __shared__ float4 red[256];
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(rows, r0 + rows_per_block);
+    const float4* __restrict__ p = reinterpret_cast<const float4*>(x + r0 * N);
+    const long long n4 = (r1 - r0) * N / 4;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    long long i = threadIdx.x;
+    for (; i + 768 < n4; i += 1024) {
+        const float4 a = p[i], b = p[i + 256], c = p[i + 512], d = p[i + 768];
+        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+        s2.x += c.x; s2.y += c.y; s2.z += c.z; s2.w += c.w;
+        s3.x += d.x; s3.y += d.y; s3.z += d.z; s3.w += d.w;
+    }
+    for (; i < n4; i += 256) { const float4 a = p[i]; s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w; }
+    s0.x += s1.x + (s2.x + s3.x); s0.y += s1.y + (s2.y + s3.y); s0.z += s1.z + (s2.z + s3.z); s0.w += s1.w + (s2.w + s3.w);
+    red[threadIdx.x] = s0;
+    __syncthreads();
+    const int q = N / 4;                       // threads t, t + q, t + 2q, ... share columns 4 (t % q) .. +3
+    if ((int)threadIdx.x < q) {
+        float4 a = red[threadIdx.x];
+        for (int j = threadIdx.x + q; j < 256; j += q) { const float4 b = red[j]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+        *reinterpret_cast<float4*>(part + (long long)blockIdx.x * N + 4 * threadIdx.x) = a;
+    }
+}
+
+// stage 2 of the column sums: out[c] (+)= sum over nb partial rows; 64 columns x 4 row lanes per block
+__global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ part, int nb, int N,
+                                                           float* __restrict__ out, int accumulate) {
+    __shared__ float red[256];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < N) {
+        int r = rl;
+        for (; r + 12 < nb; r += 16) {
+            s0 += part[(long long)r * N + c]; s1 += part[(long long)(r + 4) * N + c];
+            s2 += part[(long long)(r + 8) * N + c]; s3 += part[(long long)(r + 12) * N + c];
+        }
+        for (; r < nb; r += 4) s0 += part[(long long)r * N + c];
+    }
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rl == 0 && c < N) {
+        const float s = (red[cl] + red[64 + cl]) + (red[128 + cl] + red[192 + cl]);
+        out[c] = accumulate ? out[c] + s : s;
+    }
+}
+
+// column sums, stage 1 (general N / row stride): part[blk][N] over a slab of rows
 __global__ void __launch_bounds__(256) colsum_part_kernel(const float* __restrict__ x, long long rows, int N, long long ld,
                                                           int rows_per_block, float* __restrict__ part) {
     // 64 column lanes x 4 row lanes: a wave reads 256 contiguous bytes of one row
@@ -380,8 +435,11 @@ extern "C" int vxb_colsum_f32(const float* x, int64_t rows, int N, int64_t ld, f
     long long rpb = rows / 1024;
     if (rpb < 64) rpb = 64;
     const int nb = vxb_cdiv(rows, rpb);
-    hipLaunchKernelGGL(colsum_part_kernel, dim3(nb), dim3(256), 0, st, x, (long long)rows, N, (long long)ld, (int)rpb, part_ws);
-    hipLaunchKernelGGL(sum_splits_kernel, dim3(grid_for(N)), dim3(256), 0, st, part_ws, nb, (long long)N, out, accumulate, 1.0f);
+    if (ld == N && N >= 4 && N <= 1024 && 1024 % N == 0 && ((uintptr_t)x & 15) == 0)
+        hipLaunchKernelGGL(colsum_flat_kernel, dim3(nb), dim3(256), 0, st, x, (long long)rows, N, (int)rpb, part_ws);
+    else
+        hipLaunchKernelGGL(colsum_part_kernel, dim3(nb), dim3(256), 0, st, x, (long long)rows, N, (long long)ld, (int)rpb, part_ws);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(vxb_cdiv(N, 64)), dim3(256), 0, st, part_ws, nb, N, out, accumulate);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
