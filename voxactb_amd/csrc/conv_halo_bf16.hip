@@ -138,7 +138,9 @@ __global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {
     // so an L2 round trip has two taps of MFMAs to hide behind; the A fragments of the next tap are read from the halo
     // before the barrier that publishes its weights.
     uint4 rw0[W_V8], rw1[W_V8];
-    bf16x8 afr[2][2];       // [M tile][k half]: bf16 -> channels 0-15 | 16-31 of the chunk; x3 -> hi | lo of its 16 channels
+    // A fragments, two register sets (current tap / next tap): [M tile][k half]; bf16 -> channels 0-15 | 16-31 of the
+    // chunk, x3 -> hi | lo of its 16 channels
+    bf16x8 afa[2][2], afb[2][2];
 #define HB_LOAD_W(R, tap_)                                                                                           \
     _Pragma("unroll") for (int i = 0; i < W_V8; ++i) {                                                                \
         const int e = tid + 256 * i;                                                                                 \
@@ -152,40 +154,44 @@ __global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {
         const int e = tid + 256 * i;                                                                                 \
         *reinterpret_cast<uint4*>(&wsm[(buf_) * N * LDW + (e >> 2) * LDW + (e & 3) * 8]) = R[i];                      \
     }
-#define HB_READ_A(tap_)                                                                                              \
+#define HB_READ_A(AF, tap_)                                                                                          \
     {                                                                                                                \
         const int tp_ = (tap_);                                                                                      \
         const int toff_ = (((tp_ / 9) * HHp + (tp_ / 3) % 3) * HWp + tp_ % 3) * SP;                                  \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                               \
-            afr[i][0] = *reinterpret_cast<const bf16x8*>(&halo[abase[i] + toff_]);                                   \
-            afr[i][1] = *reinterpret_cast<const bf16x8*>(&halo[abase[i] + toff_ + 16]);                              \
+            AF[i][0] = *reinterpret_cast<const bf16x8*>(&halo[abase[i] + toff_]);                                    \
+            AF[i][1] = *reinterpret_cast<const bf16x8*>(&halo[abase[i] + toff_ + 16]);                               \
         }                                                                                                            \
     }
-#define HB_TAP(tap_, RL, RS)                                                                                         \
+    // one tap: issue everything the NEXT taps need (weight load two taps ahead, weight tile of tap+1 into the other LDS
+    // buffer, A fragments of tap+1) before this tap's MFMAs, so that it all runs under them; one barrier per tap.
+#define HB_TAP(tap_, RL, RS, AC, AN)                                                                                 \
     {                                                                                                                \
         const int tap = (tap_);                                                                                      \
         if (tap + 2 < 27) { HB_LOAD_W(RL, tap + 2) }                                                                 \
+        __builtin_amdgcn_sched_barrier(0);   /* keep the load at the top of the tap: it must stay two taps ahead */  \
         const u16* wcur = wsm + (tap & 1) * N * LDW;                                                                 \
         bf16x8 bfr[NT][2];                                                                                           \
         _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                              \
             bfr[j][0] = *reinterpret_cast<const bf16x8*>(&wcur[j * 32 * LDW + wrow]);                                \
             bfr[j][1] = *reinterpret_cast<const bf16x8*>(&wcur[j * 32 * LDW + wrow + 16]);                           \
         }                                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                 \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                              \
-            if (X3) {                                                                                                \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i][1], bfr[j][0], acc[i][j], 0, 0, 0);       \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i][0], bfr[j][1], acc[i][j], 0, 0, 0);       \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i][0], bfr[j][0], acc[i][j], 0, 0, 0);       \
-            } else {                                                                                                 \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i][0], bfr[j][0], acc[i][j], 0, 0, 0);       \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i][1], bfr[j][1], acc[i][j], 0, 0, 0);       \
-            }                                                                                                        \
-        }                                                                                                            \
         if (tap + 1 < 27) {                                                                                          \
             HB_STORE_W(RS, (tap + 1) & 1)                                                                            \
-            HB_READ_A(tap + 1)                                                                                       \
+            HB_READ_A(AN, tap + 1)                                                                                   \
         }                                                                                                            \
+        /* term-major order: consecutive MFMAs hit different accumulators (no back-to-back dependent issue) */       \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                 \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][1], bfr[j][X3 ? 0 : 1], acc[i][j], 0, 0, 0);   \
+        if (X3) {                                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                             \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][0], bfr[j][1], acc[i][j], 0, 0, 0);        \
+        }                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                 \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][0], bfr[j][0], acc[i][j], 0, 0, 0);            \
         __syncthreads();                                                                                             \
     }
     const int nchunk = Ct / CPC;
@@ -229,12 +235,12 @@ __global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {
         }
         HB_STORE_W(rw0, 0)
         __syncthreads();
-        HB_READ_A(0)
+        HB_READ_A(afa, 0)
         for (int tp = 0; tp < 26; tp += 2) {
-            HB_TAP(tp, rw0, rw1)
-            HB_TAP(tp + 1, rw1, rw0)
+            HB_TAP(tp, rw0, rw1, afa, afb)
+            HB_TAP(tp + 1, rw1, rw0, afb, afa)
         }
-        HB_TAP(26, rw0, rw1)
+        HB_TAP(26, rw0, rw1, afa, afb)
     }
     // ---- epilogue: acc[i][j][r] = C[voxel row (r&3) + 8*(r>>2) + 4*hi of M tile i][channel j*32 + lq]
 #pragma unroll
