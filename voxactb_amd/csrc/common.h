@@ -20,6 +20,16 @@ static inline int vxb_cdiv(long long a, long long b) { return (int)((a + b - 1) 
 
 constexpr int WAVE = 64;
 
+// two fp32 -> packed bf16 pair (low half = first value), round-to-nearest-even: one v_cvt_pk_bf16_f32 on gfx950
+typedef __bf16 vxb_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float vxb_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned vxb_pack_bf16(float lo, float hi) {
+    const vxb_f32x2 v = {lo, hi};
+    union { vxb_bf16x2 b; unsigned u; } t;
+    t.b = __builtin_convertvector(v, vxb_bf16x2);
+    return t.u;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -46,12 +46,7 @@ struct HaloArgs {
     int d2s_s;              // > 0: out is a fine grid [B, (S_out*s)^3, 64], output column = (phase, co)
 };
 
-__device__ __forceinline__ unsigned hb_pack2(float lo, float hi) {
-    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
-    a += 0x7fffu + ((a >> 16) & 1u);
-    b += 0x7fffu + ((b >> 16) & 1u);
-    return (a >> 16) | (b & 0xffff0000u);
-}
+__device__ __forceinline__ unsigned hb_pack2(float lo, float hi) { return vxb_pack_bf16(lo, hi); }
 
 template <int NT, int X3>     // NT = N / 32 column tiles per wave (2 or 4)
 __global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {

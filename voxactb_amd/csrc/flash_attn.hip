@@ -54,12 +54,7 @@ __device__ __forceinline__ unsigned fa_hash(unsigned x) {
 __device__ __forceinline__ unsigned fa_keep_pair(unsigned seed, unsigned row, unsigned colpair) {
     return fa_hash((row * 0x9E3779B1U + seed) ^ (colpair * 0x85EBCA77U + 0xC2B2AE3DU));
 }
-__device__ __forceinline__ unsigned fa_pack2(float lo, float hi) {
-    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
-    a += 0x7fffu + ((a >> 16) & 1u);
-    b += 0x7fffu + ((b >> 16) & 1u);
-    return (a >> 16) | (b & 0xffff0000u);
-}
+__device__ __forceinline__ unsigned fa_pack2(float lo, float hi) { return vxb_pack_bf16(lo, hi); }
 // hi/lo split of a value pair: ph = bf16 pair, pl = bf16 pair of the (exact) residuals
 __device__ __forceinline__ void fa_split2(float a, float b, unsigned& ph, unsigned& pl) {
     ph = fa_pack2(a, b);

@@ -529,10 +529,7 @@ typedef unsigned short u16;
 
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     // round-to-nearest-even fp32 -> bf16, two values per dword
-    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
-    a += 0x7fffu + ((a >> 16) & 1u);
-    b += 0x7fffu + ((b >> 16) & 1u);
-    return (a >> 16) | (b & 0xffff0000u);
+    return vxb_pack_bf16(lo, hi);
 }
 
 constexpr int BK16 = 32;

@@ -29,12 +29,7 @@ struct WgArgs {
     int tiles_per_split;
 };
 
-__device__ __forceinline__ unsigned pack_bf16_2(float lo, float hi) {
-    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
-    a += 0x7fffu + ((a >> 16) & 1u);
-    b += 0x7fffu + ((b >> 16) & 1u);
-    return (a >> 16) | (b & 0xffff0000u);
-}
+__device__ __forceinline__ unsigned pack_bf16_2(float lo, float hi) { return vxb_pack_bf16(lo, hi); }
 
 __device__ __forceinline__ unsigned long long ds_read_tr16(unsigned addr) {
     unsigned long long v;

@@ -48,12 +48,7 @@ struct WhArgs {
     int tiles_per_split;
 };
 
-__device__ __forceinline__ unsigned wh_pack2(float lo, float hi) {
-    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
-    a += 0x7fffu + ((a >> 16) & 1u);
-    b += 0x7fffu + ((b >> 16) & 1u);
-    return (a >> 16) | (b & 0xffff0000u);
-}
+__device__ __forceinline__ unsigned wh_pack2(float lo, float hi) { return vxb_pack_bf16(lo, hi); }
 
 __device__ __forceinline__ bf16x8 wh_frag(const u16* p0, const u16* p1) {
     union { s16x4 s[2]; bf16x8 v; } u;
