@@ -688,6 +688,7 @@ extern "C" int vxb_conv3_c1_dgrad_f32(const float* dq, const float* w, const flo
                                       int accumulate, int apply_lrelu_mask, float slope, vxb_stream_t stream) {
     if (!dq || !w || !du || (apply_lrelu_mask && !u) || B < 1 || S < 1) return VXB_EARG;
     if (C != 64) return VXB_ESIZE;
+    if ((S & 3) == 0) return vxb_c1_dgrad4_launch(dq, w, u, du, B, S, accumulate, apply_lrelu_mask, slope, (hipStream_t)stream);
     const long long nvox = (long long)B * S * S * S;
     const int grid = (int)((nvox + 3) / 4 > 32768 ? 32768 : (nvox + 3) / 4);
     hipLaunchKernelGGL(c1_dgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dq, w, u, du, B, S, accumulate, apply_lrelu_mask, slope);
@@ -699,6 +700,7 @@ extern "C" int vxb_conv3_c1_wgrad_f32(const float* u, const float* dq, float* dw
                                       vxb_stream_t stream) {
     if (!u || !dq || !dw || !db || !part_ws || B < 1 || S < 1) return VXB_EARG;
     if (C != 64) return VXB_ESIZE;
+    if ((S & 3) == 0) return vxb_c1_wgrad4_launch(u, dq, dw, db, part_ws, B, S, (hipStream_t)stream);
     const long long nrows = (long long)B * S * S;
     const int rpb = 64;
     const int nb = vxb_cdiv(nrows, rpb);
