@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256) colsum_flat_kernel(const float* __restric
 }
 
 // stage 2 of the column sums: out[c] (+)= sum over nb partial rows; 64 columns x 4 row lanes per block
-__global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ part, int nb, int N,
+__global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ part, int nb, int N, long long ld,
                                                            float* __restrict__ out, int accumulate) {
     __shared__ float red[256];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -162,10 +162,10 @@ __global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restri
     if (c < N) {
         int r = rl;
         for (; r + 12 < nb; r += 16) {
-            s0 += part[(long long)r * N + c]; s1 += part[(long long)(r + 4) * N + c];
-            s2 += part[(long long)(r + 8) * N + c]; s3 += part[(long long)(r + 12) * N + c];
+            s0 += part[(long long)r * ld + c]; s1 += part[(long long)(r + 4) * ld + c];
+            s2 += part[(long long)(r + 8) * ld + c]; s3 += part[(long long)(r + 12) * ld + c];
         }
-        for (; r < nb; r += 4) s0 += part[(long long)r * N + c];
+        for (; r < nb; r += 4) s0 += part[(long long)r * ld + c];
     }
     red[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
@@ -410,11 +410,9 @@ extern "C" int vxb_layernorm_bwd_f32(const float* dy, const float* x, const floa
     if (D <= 128) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(grid), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, part_ws, rows, D, rpb, accumulate_dx);
     else if (D <= 512) hipLaunchKernelGGL(ln_bwd_kernel<8>, dim3(grid), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, part_ws, rows, D, rpb, accumulate_dx);
     else return VXB_ESIZE;
-    // part layout [grid][2][D] -> two strided reductions via a [grid] x [2D] view
-    hipLaunchKernelGGL(colsum_part_kernel, dim3(1), dim3(256), 0, st, part_ws, (long long)grid, 2 * D, (long long)2 * D, grid,
-                       part_ws + (size_t)grid * 2 * D);
-    hipLaunchKernelGGL(add_kernel, dim3(1), dim3(256), 0, st, dgamma, part_ws + (size_t)grid * 2 * D, (long long)D, 1.0f);
-    hipLaunchKernelGGL(add_kernel, dim3(1), dim3(256), 0, st, dbeta, part_ws + (size_t)grid * 2 * D + D, (long long)D, 1.0f);
+    // part layout [grid][2][D]: dgamma += column sums of the first half, dbeta += of the second (parallel over columns)
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(vxb_cdiv(D, 64)), dim3(256), 0, st, part_ws, grid, D, (long long)2 * D, dgamma, 1);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(vxb_cdiv(D, 64)), dim3(256), 0, st, part_ws + D, grid, D, (long long)2 * D, dbeta, 1);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
@@ -422,7 +420,11 @@ extern "C" int vxb_layernorm_bwd_f32(const float* dy, const float* x, const floa
 extern "C" int vxb_sum_splits_f32(const float* part, int nsplit, int64_t n, float* dst, int accumulate, float alpha,
                                   vxb_stream_t stream) {
     if (!part || !dst || nsplit < 1 || n < 1) return VXB_EARG;
-    hipLaunchKernelGGL(sum_splits_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, part, nsplit, (long long)n, dst, accumulate, alpha);
+    if (nsplit >= 32 && n < (1 << 20) && alpha == 1.0f)   // many partials of a short vector: 4 row lanes x 4-way ILP per column
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(vxb_cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream, part, nsplit, (int)n,
+                           (long long)n, dst, accumulate);
+    else
+        hipLaunchKernelGGL(sum_splits_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, part, nsplit, (long long)n, dst, accumulate, alpha);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
@@ -439,7 +441,7 @@ extern "C" int vxb_colsum_f32(const float* x, int64_t rows, int N, int64_t ld, f
         hipLaunchKernelGGL(colsum_flat_kernel, dim3(nb), dim3(256), 0, st, x, (long long)rows, N, (int)rpb, part_ws);
     else
         hipLaunchKernelGGL(colsum_part_kernel, dim3(nb), dim3(256), 0, st, x, (long long)rows, N, (long long)ld, (int)rpb, part_ws);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(vxb_cdiv(N, 64)), dim3(256), 0, st, part_ws, nb, N, out, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(vxb_cdiv(N, 64)), dim3(256), 0, st, part_ws, nb, N, (long long)N, out, accumulate);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
