@@ -171,6 +171,58 @@ __global__ void __launch_bounds__(256) c1_wgrad4_kernel(const float* __restrict_
     }
 }
 
+// q[o] = bias + sum_t sum_c u[clamp(o + t - 1)][c] * w[c][t]: 16 threads (4 channels each) walk one (b, d, h) row with a
+// sliding 3x3x3 window of float4, weights as float4 from LDS, 4 cross-lane steps fold the 16 partial dots per voxel.
+__global__ void __launch_bounds__(256) c1_fwd4_kernel(const float* __restrict__ u, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ q, int B, int S) {
+    __shared__ float sw[27 * 64];          // [t][c]
+    for (int i = threadIdx.x; i < 27 * 64; i += 256) sw[(i % 27) * 64 + i / 27] = w[i];
+    __syncthreads();
+    const int c4 = (threadIdx.x & 15) * 4, gl = threadIdx.x >> 4;
+    const float bv = bias[0];
+    const long long nrows = (long long)B * S * S;
+    for (long long row = (long long)blockIdx.x * 16 + gl; row < nrows; row += (long long)gridDim.x * 16) {
+        const int h = (int)(row % S);
+        const int d = (int)((row / S) % S);
+        const long long b = row / ((long long)S * S);
+        const float* ub = u + b * S * S * S * 64 + c4;
+        long long ro[9];
+#pragma unroll
+        for (int dd = 0; dd < 3; ++dd)
+#pragma unroll
+            for (int hh = 0; hh < 3; ++hh)
+                ro[dd * 3 + hh] = ((long long)c1_clampi(d + dd - 1, 0, S - 1) * S + c1_clampi(h + hh - 1, 0, S - 1)) * S * 64;
+        float4 win[9][3];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            win[r][1] = *reinterpret_cast<const float4*>(ub + ro[r]);
+            win[r][0] = win[r][1];
+            win[r][2] = *reinterpret_cast<const float4*>(ub + ro[r] + (long long)c1_clampi(1, 0, S - 1) * 64);
+        }
+        for (int x = 0; x < S; ++x) {
+            float acc = 0.f;
+#pragma unroll
+            for (int r = 0; r < 9; ++r)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float4 wv = *reinterpret_cast<const float4*>(&sw[(r * 3 + k) * 64 + c4]);
+                    const float4 a = win[r][k];
+                    acc = fmaf(a.x, wv.x, acc); acc = fmaf(a.y, wv.y, acc); acc = fmaf(a.z, wv.z, acc); acc = fmaf(a.w, wv.w, acc);
+                }
+            acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64);
+            acc += __shfl_xor(acc, 4, 64); acc += __shfl_xor(acc, 8, 64);
+            if ((threadIdx.x & 15) == 0) q[row * S + x] = acc + bv;
+            const int nx = c1_clampi(x + 2, 0, S - 1);
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                win[r][0] = win[r][1];
+                win[r][1] = win[r][2];
+                win[r][2] = *reinterpret_cast<const float4*>(ub + ro[r] + (long long)nx * 64);
+            }
+        }
+    }
+}
+
 // dst[i] += sum_k part[k][i] over nb partial rows, i < n: 64 columns x 4 row lanes per block (fixed order)
 __global__ void __launch_bounds__(256) c1_reduce_kernel(const float* __restrict__ part, int nb, int n, float* __restrict__ dst) {
     __shared__ float red[256];
@@ -188,6 +240,13 @@ __global__ void __launch_bounds__(256) c1_reduce_kernel(const float* __restrict_
 }
 
 }  // namespace
+
+int vxb_c1_fwd4_launch(const float* u, const float* w, const float* bias, float* q, int B, int S, hipStream_t st) {
+    const long long nrows = (long long)B * S * S;
+    const int grid = (int)((nrows + 15) / 16 > 8192 ? 8192 : (nrows + 15) / 16);
+    hipLaunchKernelGGL(c1_fwd4_kernel, dim3(grid), dim3(256), 0, st, u, w, bias, q, B, S);
+    return hipGetLastError() == hipSuccess ? VXB_OK : VXB_ELAUNCH;
+}
 
 // launchers used by the C entry points in vox_ops.hip when S % 4 == 0
 int vxb_c1_dgrad4_launch(const float* dq, const float* w, const float* u, float* du, int B, int S, int accumulate, int mask,

@@ -19,6 +19,7 @@
 static inline int vxb_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // float4 variants of the Cout = 1 conv kernels (c1_conv.hip), used by the C entry points in vox_ops.hip when S % 4 == 0
+int vxb_c1_fwd4_launch(const float* u, const float* w, const float* bias, float* q, int B, int S, hipStream_t st);
 int vxb_c1_dgrad4_launch(const float* dq, const float* w, const float* u, float* du, int B, int S, int accumulate, int mask,
                          float slope, hipStream_t st);
 int vxb_c1_wgrad4_launch(const float* u, const float* dq, float* dw, float* db, float* part_ws, int B, int S, hipStream_t st);

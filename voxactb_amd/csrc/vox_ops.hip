@@ -87,6 +87,67 @@ __global__ void __launch_bounds__(256) pw_wgrad_kernel(const float* __restrict__
     }
 }
 
+// float4 variant: a thread owns 4 output channels (16 threads per voxel, 16 voxels per pass, two passes in flight)
+__global__ void __launch_bounds__(256) pw_wgrad4_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                        const float* __restrict__ dy, float* __restrict__ partW,
+                                                        float* __restrict__ partB, long long nvox, int Cin, int vox_per_block,
+                                                        float slope) {
+    __shared__ float red[4][64 * 17];
+    const int c4 = (threadIdx.x & 15) * 4, gl = threadIdx.x >> 4, wid = threadIdx.x >> 6;
+    float acc[4][16], accb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        accb[e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[e][i] = 0.f;
+    }
+    const long long v0 = (long long)blockIdx.x * vox_per_block;
+    const long long v1 = min(nvox, v0 + vox_per_block);
+    for (long long vb = v0 + gl; vb < v1; vb += 32) {
+        float4 yy[2], dd[2];
+        float xr[2][16];
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) {
+            const long long v = vb + 16 * uu;
+            const bool ok = v < v1;
+            yy[uu] = ok ? *reinterpret_cast<const float4*>(y + v * 64 + c4) : make_float4(1.f, 1.f, 1.f, 1.f);
+            dd[uu] = ok ? *reinterpret_cast<const float4*>(dy + v * 64 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int ci = 0; ci < 16; ++ci) xr[uu][ci] = (ok && ci < Cin) ? x[v * Cin + ci] : 0.f;
+        }
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) {
+            const float d[4] = {yy[uu].x > 0.f ? dd[uu].x : dd[uu].x * slope, yy[uu].y > 0.f ? dd[uu].y : dd[uu].y * slope,
+                                yy[uu].z > 0.f ? dd[uu].z : dd[uu].z * slope, yy[uu].w > 0.f ? dd[uu].w : dd[uu].w * slope};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                accb[e] += d[e];
+#pragma unroll
+                for (int ci = 0; ci < 16; ++ci) acc[e][ci] = fmaf(d[e], xr[uu][ci], acc[e][ci]);
+            }
+        }
+    }
+    // fold the 4 voxel groups of a wave (lanes l, l^16, l^32, l^48), then the 4 waves through LDS
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int ci = 0; ci < 17; ++ci) {
+            float v = ci < 16 ? acc[e][ci] : accb[e];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if ((threadIdx.x & 63) < 16) red[wid][(c4 + e) * 17 + ci] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int co = threadIdx.x;
+        for (int ci = 0; ci < Cin; ++ci)
+            partW[(long long)blockIdx.x * 64 * Cin + co * Cin + ci] =
+                (red[0][co * 17 + ci] + red[1][co * 17 + ci]) + (red[2][co * 17 + ci] + red[3][co * 17 + ci]);
+        partB[(long long)blockIdx.x * 64 + co] = (red[0][co * 17 + 16] + red[1][co * 17 + 16]) + (red[2][co * 17 + 16] + red[3][co * 17 + 16]);
+    }
+}
+
 // =====================================================================================================
 // SpatialSoftmax3D (T = 0.01) + global max.   x: [B, S^3, C] (batch stride bs), C in {64, 128}
 // stage 1: per (b, row-chunk) online-softmax partials part[b][chunk][c][7] = {m, s, sx, sy, sz, xmax, argmax}
@@ -143,6 +204,66 @@ __global__ void __launch_bounds__(256) ss_part_kernel(const float* __restrict__ 
     }
 }
 
+// float4 variant of stage 1 (16-byte aligned rows): a thread owns 4 channels, C/4 threads cover a voxel, and four voxels
+// per thread are loaded before any of them is consumed -- the scalar kernel keeps one 256-byte row per wave in flight,
+// far too little to cover HBM latency on 256 CUs.
+__device__ __forceinline__ void ss_update(SsPart& a, float xv, int p, float wx, float wy, float wz, float T) {
+    const float l = __fdiv_rn(xv, T);
+    if (xv > a.xmax) { a.xmax = xv; a.arg = p; }
+    if (l > a.m) {
+        const float f = a.m > -INFINITY ? expf(a.m - l) : 0.f;
+        a.s *= f; a.sx *= f; a.sy *= f; a.sz *= f;
+        a.m = l;
+    }
+    const float e = expf(l - a.m);
+    a.s += e; a.sx = fmaf(e, wx, a.sx); a.sy = fmaf(e, wy, a.sy); a.sz = fmaf(e, wz, a.sz);
+}
+
+__global__ void __launch_bounds__(256) ss_part4_kernel(const float* __restrict__ x, long long bs, int S, int C,
+                                                       const float* __restrict__ lin, int rows_per_chunk,
+                                                       SsPart* __restrict__ part, int nchunk, float T) {
+    __shared__ SsPart red[256 * 4];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int q = C >> 2;
+    const int cq = threadIdx.x % q, pl = threadIdx.x / q, npl = 256 / q;
+    const float* xb = x + (long long)b * bs + 4 * cq;
+    SsPart a[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e].m = -INFINITY; a[e].s = 0.f; a[e].sx = 0.f; a[e].sy = 0.f; a[e].sz = 0.f; a[e].xmax = -INFINITY; a[e].arg = 0x7fffffff; }
+    const int row0 = chunk * rows_per_chunk, row1 = min(S * S, row0 + rows_per_chunk);
+    for (int row = row0; row < row1; ++row) {
+        const int i = row / S, j = row - i * S;
+        const float wy = lin[i], wx = lin[j];        // meshgrid 'xy' quirk: pos_x follows axis 1, pos_y axis 0
+        for (int k0 = pl; k0 < S; k0 += 4 * npl) {
+            float4 v[4];
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) {
+                const int k = k0 + uu * npl;
+                v[uu] = k < S ? *reinterpret_cast<const float4*>(xb + (long long)(row * S + k) * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) {
+                const int k = k0 + uu * npl;
+                if (k < S) {
+                    const int p = row * S + k;
+                    const float wz = lin[k];
+                    ss_update(a[0], v[uu].x, p, wx, wy, wz, T); ss_update(a[1], v[uu].y, p, wx, wy, wz, T);
+                    ss_update(a[2], v[uu].z, p, wx, wy, wz, T); ss_update(a[3], v[uu].w, p, wx, wy, wz, T);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[threadIdx.x * 4 + e] = a[e];
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        const int tq = threadIdx.x >> 2, e = threadIdx.x & 3;      // channel c = threadIdx.x = 4 tq + e
+        SsPart r = red[tq * 4 + e];
+        for (int g = 1; g < npl; ++g) ss_merge(r, red[(g * q + tq) * 4 + e]);
+        part[((long long)b * nchunk + chunk) * C + threadIdx.x] = r;
+    }
+}
+
 // stage 2: combine chunks -> out_ss[b][3c + {x,y,z}], out_max[b][c], stats[b][c] = {m, s}, argmax[b][c]
 __global__ void __launch_bounds__(256) ss_final_kernel(const SsPart* __restrict__ part, int nchunk, int B, int C,
                                                        float* __restrict__ out_ss, float* __restrict__ out_max,
@@ -159,6 +280,66 @@ __global__ void __launch_bounds__(256) ss_final_kernel(const SsPart* __restrict_
     stats[2 * i] = r.m;
     stats[2 * i + 1] = r.s;
     argmax[i] = r.arg;
+}
+
+// float4 variant of the backward pass below (same formula per element; 4 channels per thread, 4 voxels in flight)
+__global__ void __launch_bounds__(256) ss_bwd4_kernel(const float* __restrict__ x, long long bs, int S, int C,
+                                                      const float* __restrict__ lin, const float* __restrict__ stats,
+                                                      const float* __restrict__ out_ss, const int* __restrict__ argmax,
+                                                      const float* __restrict__ g_ss, const float* __restrict__ g_max,
+                                                      float* __restrict__ dx, long long dbs, int rows_per_chunk, float T,
+                                                      int accumulate) {
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int q = C >> 2;
+    const int cq = threadIdx.x % q, pl = threadIdx.x / q, npl = 256 / q;
+    const float* xb = x + (long long)b * bs + 4 * cq;
+    float* db = dx + (long long)b * dbs + 4 * cq;
+    float m[4], inv_s[4], ex[4], ey[4], ez[4], gx[4], gy[4], gz[4], gm[4];
+    int am[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = 4 * cq + e, bc = b * C + c;
+        m[e] = stats[2 * bc]; inv_s[e] = 1.0f / stats[2 * bc + 1];
+        ex[e] = out_ss[(long long)b * 3 * C + 3 * c]; ey[e] = out_ss[(long long)b * 3 * C + 3 * c + 1]; ez[e] = out_ss[(long long)b * 3 * C + 3 * c + 2];
+        gx[e] = g_ss[(long long)b * 3 * C + 3 * c]; gy[e] = g_ss[(long long)b * 3 * C + 3 * c + 1]; gz[e] = g_ss[(long long)b * 3 * C + 3 * c + 2];
+        gm[e] = g_max[bc]; am[e] = argmax[bc];
+    }
+    const int row0 = chunk * rows_per_chunk, row1 = min(S * S, row0 + rows_per_chunk);
+    for (int row = row0; row < row1; ++row) {
+        const int i = row / S, j = row - i * S;
+        float base[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) base[e] = gx[e] * (lin[j] - ex[e]) + gy[e] * (lin[i] - ey[e]);
+        for (int k0 = pl; k0 < S; k0 += 4 * npl) {
+            float4 v[4], old[4];
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) {
+                const int k = k0 + uu * npl;
+                const long long o = (long long)(row * S + k) * C;
+                v[uu] = k < S ? *reinterpret_cast<const float4*>(xb + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+                old[uu] = (k < S && accumulate) ? *reinterpret_cast<const float4*>(db + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) {
+                const int k = k0 + uu * npl;
+                if (k < S) {
+                    const int p = row * S + k;
+                    const float lk = lin[k];
+                    const float xs[4] = {v[uu].x, v[uu].y, v[uu].z, v[uu].w};
+                    float r[4] = {old[uu].x, old[uu].y, old[uu].z, old[uu].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float l = __fdiv_rn(xs[e], T);
+                        const float a = expf(l - m[e]) * inv_s[e];
+                        float g = __fdiv_rn(a * (base[e] + gz[e] * (lk - ez[e])), T);
+                        if (p == am[e]) g += gm[e];
+                        r[e] = accumulate ? r[e] + g : g;
+                    }
+                    *reinterpret_cast<float4*>(db + (long long)p * C) = make_float4(r[0], r[1], r[2], r[3]);
+                }
+            }
+        }
+    }
 }
 
 // backward: dx[b,p,c] (+)= a_p/T * (gx*(lin[j]-ex) + gy*(lin[i]-ey) + gz*(lin[k]-ez)) + (p == argmax) * gmax
@@ -639,7 +820,10 @@ extern "C" int vxb_pointwise_wgrad_f32(const float* x, const float* y, const flo
     const int nb = vxb_cdiv(nvox, vpb);
     float* pW = part_ws;
     float* pB = part_ws + (size_t)nb * 64 * Cin;
-    hipLaunchKernelGGL(pw_wgrad_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, y, dy, pW, pB, (long long)nvox, Cin, vpb, slope);
+    if (((((uintptr_t)y) | ((uintptr_t)dy)) & 15) == 0)
+        hipLaunchKernelGGL(pw_wgrad4_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, y, dy, pW, pB, (long long)nvox, Cin, vpb, slope);
+    else
+        hipLaunchKernelGGL(pw_wgrad_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, y, dy, pW, pB, (long long)nvox, Cin, vpb, slope);
     VXB_CHECK_LAUNCH();
     int rc = vxb_sum_splits_f32(pW, nb, 64 * Cin, dW, 1, 1.0f, stream);
     if (rc) return rc;
@@ -655,7 +839,10 @@ extern "C" int vxb_ss3d_max_fwd_f32(const float* x, int64_t bs, int B, int S, in
     hipStream_t st = (hipStream_t)stream;
     const int rpc = (S * S / 64) < 1 ? 1 : S * S / 64;
     const int nchunk = vxb_cdiv(S * S, rpc);
-    hipLaunchKernelGGL(ss_part_kernel, dim3(nchunk, B), dim3(256), 0, st, x, (long long)bs, S, C, lin, rpc, (SsPart*)part_ws, nchunk, 0.01f);
+    if ((bs & 3) == 0 && (((uintptr_t)x) & 15) == 0)
+        hipLaunchKernelGGL(ss_part4_kernel, dim3(nchunk, B), dim3(256), 0, st, x, (long long)bs, S, C, lin, rpc, (SsPart*)part_ws, nchunk, 0.01f);
+    else
+        hipLaunchKernelGGL(ss_part_kernel, dim3(nchunk, B), dim3(256), 0, st, x, (long long)bs, S, C, lin, rpc, (SsPart*)part_ws, nchunk, 0.01f);
     hipLaunchKernelGGL(ss_final_kernel, dim3(vxb_cdiv(B * C, 256)), dim3(256), 0, st, (const SsPart*)part_ws, nchunk, B, C, out_ss,
                        out_max, stats, argmax);
     VXB_CHECK_LAUNCH();
@@ -668,8 +855,12 @@ extern "C" int vxb_ss3d_max_bwd_f32(const float* x, int64_t bs, int B, int S, in
     if (C != 64 && C != 128) return VXB_ESIZE;
     const int rpc = (S * S / 256) < 1 ? 1 : S * S / 256;
     const int nchunk = vxb_cdiv(S * S, rpc);
-    hipLaunchKernelGGL(ss_bwd_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, (long long)bs, S, C, lin, stats, out_ss,
-                       argmax, g_ss, g_max, dx, (long long)dbs, rpc, 0.01f, accumulate);
+    if ((bs & 3) == 0 && (dbs & 3) == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)dx) & 15) == 0)
+        hipLaunchKernelGGL(ss_bwd4_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, (long long)bs, S, C, lin, stats,
+                           out_ss, argmax, g_ss, g_max, dx, (long long)dbs, rpc, 0.01f, accumulate);
+    else
+        hipLaunchKernelGGL(ss_bwd_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, (long long)bs, S, C, lin, stats, out_ss,
+                           argmax, g_ss, g_max, dx, (long long)dbs, rpc, 0.01f, accumulate);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
@@ -678,6 +869,7 @@ extern "C" int vxb_conv3_c1_fwd_f32(const float* u, const float* w, const float*
                                     vxb_stream_t stream) {
     if (!u || !w || !bias || !q || B < 1 || S < 1) return VXB_EARG;
     if (C != 64) return VXB_ESIZE;
+    if ((((uintptr_t)u) & 15) == 0) return vxb_c1_fwd4_launch(u, w, bias, q, B, S, (hipStream_t)stream);
     const long long nrows = (long long)B * S * S;
     const int grid = (int)((nrows + 3) / 4 > 8192 ? 8192 : (nrows + 3) / 4);
     hipLaunchKernelGGL(c1_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, u, w, bias, q, B, S);
