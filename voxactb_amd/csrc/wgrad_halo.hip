@@ -62,7 +62,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* xs = smem;                                   // [1 + X3][XSLOTS][16]
     u16* ds = smem + (1 + X3) * XPL;                  // [1 + X3][128][DLD]
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform (scalar register)
     const int Ct = g.C0 + g.C1;
     const int cb = blockIdx.x * 16;                   // this workgroup's 16 input channels
     const int n0 = blockIdx.y * 64;                   // ... and 64 output channels
@@ -167,6 +168,13 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
     const int q = lane >> 4, tl = lane & 15;
     const int fh = 2 * (q >> 1), fw = 4 * (q & 1) + (tl >> 2), fc = 4 * (tl & 3);
 
+    int toffs[7];                        // halo offsets (u16) of this wave's taps; wave-uniform
+#pragma unroll
+    for (int ti = 0; ti < 7; ++ti) {
+        const int tap = min(wid + 4 * ti, 26);
+        toffs[ti] = (((tap / 9) * XH + (tap / 3) % 3) * XW + tap % 3) * 16;
+    }
+
     if (t_begin < t_end) issue(t_begin);
     for (long long tile = t_begin; tile < t_end; ++tile) {
         __syncthreads();                 // every wave is done reading the previous tile
@@ -186,22 +194,26 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
                 bh[j] = wh_frag(db0 + 16 * j, db1 + 16 * j);
                 if (X3) bl[j] = wh_frag(db0 + DPL + 16 * j, db1 + DPL + 16 * j);
             }
+            // the A fragments of tap ti+1 are read while the 12 MFMAs of tap ti run (wave 3's seventh slot re-reads tap 26
+            // and its accumulator is never stored: no branch in the loop)
+            bf16x8 ah = wh_frag(xa0 + toffs[0], xa1 + toffs[0]);
+            bf16x8 al = X3 ? wh_frag(xa0 + XPL + toffs[0], xa1 + XPL + toffs[0]) : ah;
 #pragma unroll
             for (int ti = 0; ti < 7; ++ti) {
-                const int tap = wid + 4 * ti;
-                if (tap < 27) {
-                    const int toff = (((tap / 9) * XH + (tap / 3) % 3) * XW + tap % 3) * 16;
-                    const bf16x8 ah = wh_frag(xa0 + toff, xa1 + toff);
-                    if (X3) {
-                        const bf16x8 al = wh_frag(xa0 + XPL + toff, xa1 + XPL + toff);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[ti][j], 0, 0, 0);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[ti][j], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[ti][j], 0, 0, 0);
+                bf16x8 ahn = ah, aln = al;
+                if (ti + 1 < 7) {
+                    ahn = wh_frag(xa0 + toffs[ti + 1], xa1 + toffs[ti + 1]);
+                    if (X3) aln = wh_frag(xa0 + XPL + toffs[ti + 1], xa1 + XPL + toffs[ti + 1]);
                 }
+                if (X3) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[ti][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[ti][j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[ti][j], 0, 0, 0);
+                ah = ahn; al = aln;
             }
         }
     }
