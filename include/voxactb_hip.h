@@ -107,6 +107,19 @@ int vxb_conv3d_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, 
 int vxb_conv3d_wgrad_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                                 int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
                                 int d2s_s, int d2s_C, float* part, int nsplit, vxb_stream_t stream);
+/* Direct-to-LDS variants (global_load_lds_dwordx4, no register round trip): BOTH operands are bf16 planes in HBM.
+ * vxb_split_bf16_f32 makes the activation planes [nplanes][rows][cols] (plane 0 = bf16(x), plane 1 = bf16(x - plane 0));
+ * weights are the same [nplanes][N][K] planes as above.  nplanes = 1 ('bf16') or 2 ('bf16x3').  K % 32 == 0 (conv:
+ * Cin % 32 == 0, one source).  zeros: >= 16 bytes of device zeros, fetched for zero-padded taps. */
+int vxb_split_bf16_f32(const float* src, int64_t ld, int64_t rows, int cols, void* dst_planes, int nplanes,
+                       vxb_stream_t stream);
+int vxb_gemm_dl_f32(const void* A_planes, const void* Bw_planes, int nplanes, float* C, int64_t ldc, const float* bias,
+                    const float* residual, int M, int N, int K, int act, float slope, int accumulate,
+                    vxb_stream_t stream);
+int vxb_conv3d_dl_f32(const void* src_planes, int Cin, int B, int S_in, int S_out, int stride, int kext, int off,
+                      int replicate, const void* wt_planes, int nplanes, int N, const float* bias, float* out,
+                      int64_t ldc, int act, float slope, int accumulate, int d2s_s, int d2s_C, const void* zeros,
+                      vxb_stream_t stream);
 /* LDS-halo specialisation of vxb_conv3d_bf16w_f32 for kext == 3, stride == 1 (the `final` conv of the Q-function,
  * perceiver_lang_io.py:462-466, and its data gradient): a 4x8x8 block of output voxels stages its 6x10x10 input halo
  * once instead of once per tap.  C0, C1 % 32 == 0, N % 64 == 0; out [B, S_out^3, N] is overwritten.  The x3 entry

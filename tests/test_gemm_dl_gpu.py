@@ -1,0 +1,83 @@
+"""GPU: direct-to-LDS GEMM / conv kernels (gemm_dl.hip: both operands as bf16 planes, global_load_lds, XOR-swizzled
+tiles) against the register-staged kernels on the same operands -- identical products, different fp32 summation order
+(3e-5) -- and, in bf16x3, against float64 references at the bound of the exact-fp32 kernels (2e-5)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from voxactb_amd import ops
+from .test_ops_gpu import rnd, close, cl, ref_conv, DEV
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(fn):
+    ops.DL_GEMM = False
+    try:
+        ref = fn()
+    finally:
+        ops.DL_GEMM = 'force'
+    try:
+        return ref, fn()
+    finally:
+        ops.DL_GEMM = True
+
+
+@pytest.mark.parametrize('x3', [False, True])
+@pytest.mark.parametrize('M,N,K', [(256, 128, 64), (300, 72, 96), (1000, 512, 2048), (131, 64, 512), (4096, 1000, 32)])
+def test_gemm_dl_matches_register_staged(M, N, K, x3):
+    x, W, b, r = rnd(M, K), rnd(N, K, seed=1), rnd(N, seed=2), rnd(M, N, seed=3)
+    wb = ops.split_bf16(W.to(DEV), x3)
+    ref, got = _both(lambda: ops.gemm_bf16w(x.to(DEV), wb, bias=b.to(DEV), act=ops.ACT_LRELU, residual=r.to(DEV)))
+    close(got, ref, 3e-5, 'dl gemm vs staged')
+    if x3:
+        close(got, F.leaky_relu(x.double() @ W.double().t() + b.double(), 0.02).float() + r, 2e-5, 'dl gemm x3 vs fp64')
+    # accumulate into an existing output, strided input rows
+    xx = rnd(M, K + 32, seed=5).to(DEV)
+    base = rnd(M, N, seed=6).to(DEV)
+    o1, o2 = base.clone(), base.clone()
+    ops.DL_GEMM = False
+    ops.gemm_bf16w(xx[:, :K], wb, out=o1, accumulate=True)
+    ops.DL_GEMM = 'force'
+    ops.gemm_bf16w(xx[:, :K], wb, out=o2, accumulate=True)
+    ops.DL_GEMM = True
+    close(o2, o1, 3e-5, 'dl gemm accumulate / strided rows')
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'bf16x3'])
+@pytest.mark.parametrize('Cin,Cout,k,s,S', [(64, 64, 5, 1, 6), (64, 64, 5, 5, 10), (32, 128, 3, 1, 5), (64, 64, 3, 2, 8)])
+def test_conv_dl_matches_register_staged(mode, Cin, Cout, k, s, S):
+    B = 2
+    x = cl(rnd(B, Cin, S, S, S)).to(DEV)
+    W = rnd(Cout, Cin, k, k, k, seed=1, scale=0.1).to(DEV)
+    b = rnd(Cout, seed=2).to(DEV)
+    G = (S + 2 * (k // 2) - k) // s + 1
+    ops.PRECISION = mode
+    ops.HALO_CONV = False           # isolate the generic paths
+    try:
+        ref, got = _both(lambda: ops.conv3d(x, ops.conv_weight_fwd(W), Cout, B, S, G, k, -(k // 2), stride=s, bias=b, act=ops.ACT_LRELU))
+        close(got, ref, 3e-5, 'dl conv fwd ' + mode)
+        if s == 1:      # zero-padded data-gradient geometry: taps outside the cube fetch the zero page
+            dy = cl(rnd(B, Cout, G, G, G, seed=3)).to(DEV)
+            p = k // 2
+            ref, got = _both(lambda: ops.conv3d(dy, ops.conv_weight_dgrad(W), Cin, B, G, S + 2 * p, k, -(k - 1), replicate=False))
+            close(got, ref, 3e-5, 'dl conv dgrad ' + mode)
+    finally:
+        ops.PRECISION = 'fp32'
+        ops.HALO_CONV = True
+
+
+def test_conv_dl_depth_to_space_polyphase_forward():
+    B, C, G, s = 2, 64, 6, 5
+    z = cl(rnd(B, C, G, G, G)).to(DEV)
+    Weff = rnd(27 * C, s ** 3 * 64, seed=1, scale=0.05).to(DEV)
+    bias = rnd(s ** 3 * 64, seed=2).to(DEV)
+    ops.PRECISION = 'bf16x3'
+    try:
+        ref, got = _both(lambda: ops.conv3d(z, Weff, s ** 3 * 64, B, G, G, 3, -1, bias=bias, act=ops.ACT_LRELU, d2s=(s, 64)))
+    finally:
+        ops.PRECISION = 'fp32'
+    assert got.shape == (B, G * s, G * s, G * s, 64)
+    close(got, ref, 3e-5, 'dl conv d2s')
+    exact = ops.conv3d(z, Weff, s ** 3 * 64, B, G, G, 3, -1, bias=bias, act=ops.ACT_LRELU, d2s=(s, 64))     # fp32 matrix cores
+    close(got, exact, 2e-5, 'dl conv d2s x3 vs exact fp32')

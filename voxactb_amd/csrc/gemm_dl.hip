@@ -1,0 +1,314 @@
+// Direct-to-LDS GEMM / implicit-GEMM conv on the bf16 matrix cores ('bf16' and 'bf16x3' precisions).
+//
+// The generic kernels in gemm_conv.hip stage fp32 operands global -> VGPR -> (convert / split) -> ds_write -> LDS; per
+// 32-deep k-tile that costs ~200 VALU and 12 wide ds_write instructions per thread next to 24 MFMAs, and it is what
+// bounds them at 150-300 TF/s.  Here BOTH operands are bf16 planes in HBM already (weights are pre-split once per step,
+// activations by one streaming pass, vxb_split_bf16_f32) and travel global -> LDS with `global_load_lds_dwordx4`:
+// no VGPRs, no conversion, no ds_write; the loads of k-tile t+1 are in flight while the MFMAs of k-tile t run
+// (two LDS stages, ONE barrier per k-tile).
+//
+// A wave-level direct load writes lane l's 16 bytes to LDS[base + 16 l] (measured: tools/ubench/ldsload_probe.hip), but
+// every lane may fetch from any global address.  A 128-row x 32-bf16 operand tile is 512 slots of 16 bytes, slot
+// (row, chunk) at index row*4 + (chunk ^ ((row >> 2) & 3)): one instruction fills 16 consecutive rows, and the XOR
+// swizzle makes the fragment reads (ds_read_b128, 32 rows x one chunk per half-wave) conflict-free without padding --
+// the swizzle is applied on the SOURCE side (which global chunk a lane fetches), since the destination is fixed.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+constexpr int DL_A_KCONTIG = 0, DL_A_CONV = 1;
+constexpr int DTILE = 128 * 32;            // u16 per operand plane tile (8 KB)
+
+struct DlArgs {
+    const u16* A;            // KCONTIG: bf16 [M][lda] plane(s); CONV: bf16 [B, S_in^3, C] plane(s)
+    long long a_plane;       // u16 between the hi and the lo plane of A
+    long long lda;
+    const u16* Bw;           // bf16 [N][K] plane(s)
+    long long b_plane;
+    const u16* zeros;        // >= 16 bytes of zeros (source of zero-padded conv taps)
+    float* C;
+    const float* bias;
+    const float* residual;
+    int M, N, K;
+    long long ldc;
+    int act;
+    float slope;
+    int accumulate;
+    int d2s_s, d2s_G, d2s_C;
+    int Cin, S_in, S_out, stride, kext, off, replicate;
+};
+
+__device__ __forceinline__ void dl_load16(const u16* src, u16* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int AMODE, int X3>
+__global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
+    extern __shared__ __attribute__((aligned(16))) u16 smem[];
+    constexpr int NPL = 1 + X3;
+    constexpr int STAGE = 2 * NPL * DTILE;     // [A planes][B planes]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    // XCD-aware tile order (see gemm_conv.hip)
+    int tile_x, tile_y;
+    {
+        const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+        const int lid = blockIdx.y * gx + blockIdx.x;
+        const int xcd = lid & 7, slot = lid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int lid2 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        tile_x = lid2 % gx;
+        tile_y = lid2 / gx;
+    }
+    const int m0 = tile_y * 128, n0 = tile_x * 128;
+
+    // ---- load slots of this lane: instruction (wid, i) fills rows (2 wid + i) * 16 .. +15; lane -> row + (lane >> 2),
+    //      destination chunk position lane & 3, i.e. source chunk (lane & 3) ^ ((row >> 2) & 3)
+    int lrow[2], lchunk[2];
+    long long a_off[2], b_off[2];
+    int a_b[2], a_d[2], a_h[2], a_w[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        lrow[i] = (2 * wid + i) * 16 + (lane >> 2);
+        lchunk[i] = (lane & 3) ^ ((lrow[i] >> 2) & 3);
+        const int m = min(m0 + lrow[i], g.M - 1);
+        const int n = min(n0 + lrow[i], g.N - 1);
+        b_off[i] = (long long)n * g.K + lchunk[i] * 8;
+        if (AMODE == DL_A_KCONTIG) {
+            a_off[i] = (long long)m * g.lda + lchunk[i] * 8;
+        } else {
+            int r = m;
+            const int S = g.S_out;
+            a_w[i] = r % S; r /= S;
+            a_h[i] = r % S; r /= S;
+            a_d[i] = r % S; r /= S;
+            a_b[i] = r;
+            a_off[i] = 0;
+        }
+    }
+
+    auto issue = [&](int stage, int kt) {
+        const int k0 = kt * 32;
+        u16* sb = smem + stage * STAGE;
+        const u16* asrc[2];
+        if (AMODE == DL_A_KCONTIG) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) asrc[i] = g.A + a_off[i] + k0;
+        } else {
+            const int tap = k0 / g.Cin;
+            const int cc = k0 - tap * g.Cin;
+            const int tw = tap % g.kext, th = (tap / g.kext) % g.kext, td = tap / (g.kext * g.kext);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int id = a_d[i] * g.stride + td + g.off;
+                int ih = a_h[i] * g.stride + th + g.off;
+                int iw = a_w[i] * g.stride + tw + g.off;
+                bool ok = true;
+                if (g.replicate) {
+                    id = min(max(id, 0), g.S_in - 1); ih = min(max(ih, 0), g.S_in - 1); iw = min(max(iw, 0), g.S_in - 1);
+                } else {
+                    ok = id >= 0 && id < g.S_in && ih >= 0 && ih < g.S_in && iw >= 0 && iw < g.S_in;
+                }
+                const long long vox = (((long long)a_b[i] * g.S_in + id) * g.S_in + ih) * g.S_in + iw;
+                asrc[i] = ok ? g.A + vox * g.Cin + cc + lchunk[i] * 8 : nullptr;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const u16* s = asrc[i] ? asrc[i] + p * g.a_plane : g.zeros;
+                dl_load16(s, sb + p * DTILE + (2 * wid + i) * 512);
+                dl_load16(g.Bw + p * g.b_plane + b_off[i] + k0, sb + (NPL + p) * DTILE + (2 * wid + i) * 512);
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment slots: lane (row = lane & 31, hi = lane >> 5) of tile t reads chunk 2 ks + hi of its row
+    const int lm = lane & 31, hi = lane >> 5;
+    int fa[2], fb[2], fx[2];                    // row * 32 u16 base and the row's swizzle key, per 32-row tile
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ra = wm * 64 + t * 32 + lm, rb = wn * 64 + t * 32 + lm;
+        fa[t] = ra * 32; fb[t] = rb * 32;
+        fx[t] = (lm >> 2) & 3;                  // (row >> 2) & 3: the tile bases are multiples of 32, so only lm matters
+    }
+
+    const int nkt = g.K / 32;
+    issue(0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of k-tile kt have landed in LDS
+        __syncthreads();                                      // ... everyone's have; and everyone finished k-tile kt-1
+        if (kt + 1 < nkt) issue((kt + 1) & 1, kt + 1);
+        const u16* sb = smem + (kt & 1) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int co = ((2 * ks + hi) ^ fx[t]) * 8;
+                ah[t] = *reinterpret_cast<const bf16x8*>(sb + fa[t] + co);
+                bh[t] = *reinterpret_cast<const bf16x8*>(sb + NPL * DTILE + fb[t] + co);
+                if (X3) {
+                    al[t] = *reinterpret_cast<const bf16x8*>(sb + DTILE + fa[t] + co);
+                    bl[t] = *reinterpret_cast<const bf16x8*>(sb + (NPL + 1) * DTILE + fb[t] + co);
+                }
+            }
+            if (X3) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    float* __restrict__ C = g.C;
+    const float* __restrict__ R = g.residual;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (n >= g.N) continue;
+            const float bsv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= g.M) continue;
+                float v = acc[i][j][r] + bsv;
+                if (g.act == 1) v = v > 0.f ? v : v * g.slope;
+                long long off;
+                if (g.d2s_s > 0) {
+                    const int s = g.d2s_s, G = g.d2s_G, Cc = g.d2s_C;
+                    const int ph = n / Cc, co = n - ph * Cc;
+                    const int rw = ph % s, rh = (ph / s) % s, rd = ph / (s * s);
+                    int q = m;
+                    const int qw = q % G; q /= G;
+                    const int qh = q % G; q /= G;
+                    const int qd = q % G; q /= G;
+                    const long long Vv = (long long)G * s;
+                    off = ((((long long)q * Vv + qd * s + rd) * Vv + qh * s + rh) * Vv + qw * s + rw) * Cc + co;
+                } else {
+                    off = (long long)m * g.ldc + n;
+                }
+                if (R) v += R[off];
+                if (g.accumulate) v += C[off];
+                C[off] = v;
+            }
+        }
+    }
+}
+
+// fp32 [rows][cols] (row stride ld) -> bf16 planes: hi [rows][cols] and, when lo != nullptr, the residual plane
+__global__ void __launch_bounds__(256) split_bf16_kernel(const float* __restrict__ src, long long ld, long long rows, int cols,
+                                                         u16* __restrict__ hi, u16* __restrict__ lo) {
+    const int q = cols >> 2;
+    const long long total = rows * q;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / q;
+        const int c4 = (int)(i - r * q) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(src + r * ld + c4);
+        uint2 ph;
+        ph.x = vxb_pack_bf16(v.x, v.y); ph.y = vxb_pack_bf16(v.z, v.w);
+        *reinterpret_cast<uint2*>(hi + r * cols + c4) = ph;
+        if (lo) {
+            uint2 pl;
+            pl.x = vxb_pack_bf16(v.x - __uint_as_float(ph.x << 16), v.y - __uint_as_float(ph.x & 0xffff0000u));
+            pl.y = vxb_pack_bf16(v.z - __uint_as_float(ph.y << 16), v.w - __uint_as_float(ph.y & 0xffff0000u));
+            *reinterpret_cast<uint2*>(lo + r * cols + c4) = pl;
+        }
+    }
+}
+
+template <int AMODE>
+int dl_launch(const DlArgs& g, int x3, hipStream_t st) {
+    const dim3 grid(vxb_cdiv(g.N, 128), vxb_cdiv(g.M, 128));
+    const size_t lds = (size_t)2 * 2 * (x3 ? 2 : 1) * DTILE * sizeof(u16);
+    if (x3) {
+        if (hipFuncSetAttribute((const void*)gemm_dl_kernel<AMODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
+        hipLaunchKernelGGL((gemm_dl_kernel<AMODE, 1>), grid, dim3(256), lds, st, g);
+    } else {
+        hipLaunchKernelGGL((gemm_dl_kernel<AMODE, 0>), grid, dim3(256), lds, st, g);
+    }
+    return hipGetLastError() == hipSuccess ? VXB_OK : VXB_ELAUNCH;
+}
+
+inline bool dl_al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+// dst planes [nplanes (1 or 2)][rows][cols] bf16 <- src fp32 [rows][cols] (row stride ld): plane 0 = bf16(src) (RNE),
+// plane 1 = bf16(src - plane 0): the operand format of the direct-to-LDS kernels.  cols % 4 == 0.
+extern "C" int vxb_split_bf16_f32(const float* src, int64_t ld, int64_t rows, int cols, void* dst_planes, int nplanes,
+                                  vxb_stream_t stream) {
+    if (!src || !dst_planes || rows < 1 || cols < 4 || (nplanes != 1 && nplanes != 2)) return VXB_EARG;
+    if ((cols & 3) || (ld & 3) || !dl_al16(src) || !dl_al16(dst_planes)) return VXB_ESIZE;
+    u16* hi = (u16*)dst_planes;
+    u16* lo = nplanes == 2 ? hi + rows * cols : nullptr;
+    const long long total = rows * (cols >> 2);
+    const int grid = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+    hipLaunchKernelGGL(split_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (long long)ld, (long long)rows, cols, hi, lo);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+// C[M,N] (+)= act(A @ Bw^T + bias) (+ residual) with BOTH operands as bf16 planes: A_planes [nplanes][M][K] (from
+// vxb_split_bf16_f32), Bw_planes [nplanes][N][K]; nplanes = 1 ('bf16') or 2 ('bf16x3': hi*hi + hi*lo + lo*hi).  K % 32 == 0.
+extern "C" int vxb_gemm_dl_f32(const void* A_planes, const void* Bw_planes, int nplanes, float* C, int64_t ldc,
+                               const float* bias, const float* residual, int M, int N, int K, int act, float slope,
+                               int accumulate, vxb_stream_t stream) {
+    if (!A_planes || !Bw_planes || !C || M < 1 || N < 1 || K < 32 || (nplanes != 1 && nplanes != 2)) return VXB_EARG;
+    if ((K & 31) || !dl_al16(A_planes) || !dl_al16(Bw_planes)) return VXB_ESIZE;
+    DlArgs g = {};
+    g.A = (const u16*)A_planes; g.a_plane = (long long)M * K; g.lda = K;
+    g.Bw = (const u16*)Bw_planes; g.b_plane = (long long)N * K; g.zeros = (const u16*)Bw_planes;
+    g.C = C; g.bias = bias; g.residual = residual; g.M = M; g.N = N; g.K = K; g.ldc = ldc; g.act = act; g.slope = slope;
+    g.accumulate = accumulate;
+    return dl_launch<DL_A_KCONTIG>(g, nplanes == 2, (hipStream_t)stream);
+}
+
+// Implicit-GEMM conv3d twin of vxb_conv3d_bf16w/bf16x3_f32 for ONE source whose activations were pre-split:
+// src_planes [nplanes][B, S_in^3, Cin] bf16; weights [nplanes][N][K = kext^3 * Cin]; Cin % 32 == 0.
+// zeros: >= 16 bytes of zeros in device memory (fetched for zero-padded taps).
+extern "C" int vxb_conv3d_dl_f32(const void* src_planes, int Cin, int B, int S_in, int S_out, int stride, int kext, int off,
+                                 int replicate, const void* wt_planes, int nplanes, int N, const float* bias, float* out,
+                                 int64_t ldc, int act, float slope, int accumulate, int d2s_s, int d2s_C, const void* zeros,
+                                 vxb_stream_t stream) {
+    if (!src_planes || !wt_planes || !out || !zeros || B < 1 || S_in < 1 || S_out < 1 || kext < 1 || stride < 1 || N < 1) return VXB_EARG;
+    if ((nplanes != 1 && nplanes != 2) || (Cin & 31) || Cin < 32) return VXB_ESIZE;
+    if (!dl_al16(src_planes) || !dl_al16(wt_planes) || !dl_al16(zeros)) return VXB_ESIZE;
+    const long long M = (long long)B * S_out * S_out * S_out;
+    const long long K = (long long)kext * kext * kext * Cin;
+    if (M >= INT32_MAX || K >= INT32_MAX) return VXB_ESIZE;
+    if (d2s_s > 0 && (d2s_C < 1 || N % d2s_C)) return VXB_EARG;
+    DlArgs g = {};
+    g.A = (const u16*)src_planes; g.a_plane = (long long)B * S_in * S_in * S_in * Cin;
+    g.Bw = (const u16*)wt_planes; g.b_plane = (long long)N * K; g.zeros = (const u16*)zeros;
+    g.C = out; g.bias = bias; g.M = (int)M; g.N = N; g.K = (int)K; g.ldc = ldc; g.act = act; g.slope = slope;
+    g.accumulate = accumulate; g.d2s_s = d2s_s; g.d2s_G = S_out; g.d2s_C = d2s_C;
+    g.Cin = Cin; g.S_in = S_in; g.S_out = S_out; g.stride = stride; g.kext = kext; g.off = off; g.replicate = replicate;
+    return dl_launch<DL_A_CONV>(g, nplanes == 2, (hipStream_t)stream);
+}

@@ -461,6 +461,26 @@ def ce_rows(logits, segs, labels, dlogits=None, gscale=1.0):
 
 
 # --------------------------------------------------------------------------------------------- bf16 matrix-core mode
+DL_GEMM = True       # direct-to-LDS kernels (gemm_dl.hip) for K % 32 == 0 GEMMs / single-source convs in the bf16 modes:
+                     # True = where the split pass pays (rules below), 'force' = wherever legal (tests), False = never
+_ZEROS = {}
+
+
+def _zeros16(dev):
+    z = _ZEROS.get(dev)
+    if z is None:
+        z = _ZEROS[dev] = torch.zeros(64, dtype=torch.bfloat16, device=dev)
+    return z
+
+
+def split_planes(x2d, nplanes):
+    """fp32 [rows][cols] (row stride free) -> bf16 planes [nplanes][rows][cols]: hi (and lo = bf16(x - hi))."""
+    rows, cols = x2d.shape
+    planes = torch.empty((nplanes, rows, cols), dtype=torch.bfloat16, device=x2d.device)
+    call('vxb_split_bf16_f32', x2d, x2d.stride(0), rows, cols, planes, nplanes)
+    return planes
+
+
 def gemm_bf16w(x, Wb, out=None, bias=None, act=ACT_NONE, residual=None, accumulate=False, label=None):
     """out[M,N] = act(x[M,K] (fp32 -> bf16 on the fly) @ Wb[N,K]^T (bf16) + bias) (+ residual), fp32 accumulate."""
     M, K = x.shape
@@ -470,6 +490,18 @@ def gemm_bf16w(x, Wb, out=None, bias=None, act=ACT_NONE, residual=None, accumula
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
     _lib.set_meta(label or 'gemm_bf16 %dx%dx%d' % (M, N, K), 2.0 * M * N * K)
+    # the split pass costs M*K*(6|8) bytes of HBM traffic; it pays when every A tile is reused by many column tiles
+    # (measured at M = 32768 in bf16x3: N x K = 4096x512 5.3 -> 4.6 ms, 2048x512 2.65 -> 2.40, but 512x4096 3.2 -> 4.4)
+    if (DL_GEMM and K % 32 == 0 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and M >= 128
+            and (DL_GEMM == 'force' or not x3 or N >= 2 * K)):
+        # both operands as bf16 planes, global -> LDS without a register round trip (one streaming split pass for x,
+        # timed under the same label with zero FLOPs)
+        _lib.set_meta(label or 'gemm_bf16 %dx%dx%d' % (M, N, K), 0.0)
+        planes = split_planes(x, 2 if x3 else 1)
+        _lib.set_meta(label or 'gemm_bf16 %dx%dx%d' % (M, N, K), 2.0 * M * N * K)
+        call('vxb_gemm_dl_f32', planes, Wb, 2 if x3 else 1, out, out.stride(0), bias, residual, M, N, K, act, LRELU_SLOPE,
+             int(accumulate))
+        return out
     call('vxb_gemm_bf16x3_f32' if x3 else 'vxb_gemm_bf16w_f32', x, x.stride(0), Wb, out, out.stride(0), bias, residual, M, N, K, act, LRELU_SLOPE,
          int(accumulate))
     return out
@@ -494,6 +526,18 @@ def conv3d_bf16w(src0, wb, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
             and (ldc is None or ldc == N) and S_out >= 16):
         call('vxb_conv3_halo_bf16x3_f32' if x3 else 'vxb_conv3_halo_bf16w_f32', src0, src1, C0, C1, B, S_in, S_out, off,
              int(replicate), wb, N, bias, out, act, LRELU_SLOPE, 0, 0, d2s[0])
+        return out
+    # ... same trade for convs: every input voxel must feed enough products ((kext/stride)^3 * N per channel) to amortise
+    # the split pass (up-conv forward 17.7 -> 15.3 ms; the stride-5 patchify would lose 1.5 ms and stays register-staged)
+    if (DL_GEMM and src1 is None and C0 % 32 == 0 and src0.is_contiguous() and B * S_out ** 3 >= 128
+            and (DL_GEMM == 'force' or (kext / float(stride)) ** 3 * N >= 512)):
+        lbl = label or 'conv3d_bf16[k%d s%d %d->%d S%d%s]' % (kext, stride, C0, N, S_out, '' if replicate else ' dgrad')
+        npl = 2 if x3 else 1
+        _lib.set_meta(lbl, 0.0)
+        planes = split_planes(src0.view(-1, C0), npl)
+        _lib.set_meta(lbl, 2.0 * B * S_out ** 3 * N * kext ** 3 * C0)
+        call('vxb_conv3d_dl_f32', planes, C0, B, S_in, S_out, stride, kext, off, int(replicate), wb, npl, N, bias, out,
+             ldc if ldc is not None else N, act, LRELU_SLOPE, int(accumulate), d2s[0], d2s[1], _zeros16(src0.device))
         return out
     call('vxb_conv3d_bf16x3_f32' if x3 else 'vxb_conv3d_bf16w_f32', src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, int(replicate), wb, N, bias, out,
          ldc if ldc is not None else N, act, LRELU_SLOPE, int(accumulate), d2s[0], d2s[1])
