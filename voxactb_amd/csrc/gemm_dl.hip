@@ -93,6 +93,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
         }
     }
 
+    int it_cc = 0, it_tw = 0, it_th = 0, it_td = 0;       // conv gather iterator of the NEXT k-tile to be issued
     auto issue = [&](int stage, int kt) {
         const int k0 = kt * 32;
         u16* sb = smem + stage * STAGE;
@@ -101,22 +102,30 @@ __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) asrc[i] = g.A + a_off[i] + k0;
         } else {
-            const int tap = k0 / g.Cin;
-            const int cc = k0 - tap * g.Cin;
-            const int tw = tap % g.kext, th = (tap / g.kext) % g.kext, td = tap / (g.kext * g.kext);
+            // k-tiles are issued in order: (tap, channel offset) advance incrementally, and the gathered voxel of a row
+            // is recomputed only when the tap changes (every Cin / 32 k-tiles) -- no divisions in the loop
+            if (it_cc == 0) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int id = a_d[i] * g.stride + td + g.off;
-                int ih = a_h[i] * g.stride + th + g.off;
-                int iw = a_w[i] * g.stride + tw + g.off;
-                bool ok = true;
-                if (g.replicate) {
-                    id = min(max(id, 0), g.S_in - 1); ih = min(max(ih, 0), g.S_in - 1); iw = min(max(iw, 0), g.S_in - 1);
-                } else {
-                    ok = id >= 0 && id < g.S_in && ih >= 0 && ih < g.S_in && iw >= 0 && iw < g.S_in;
+                for (int i = 0; i < 2; ++i) {
+                    int id = a_d[i] * g.stride + it_td + g.off;
+                    int ih = a_h[i] * g.stride + it_th + g.off;
+                    int iw = a_w[i] * g.stride + it_tw + g.off;
+                    bool ok = true;
+                    if (g.replicate) {
+                        id = min(max(id, 0), g.S_in - 1); ih = min(max(ih, 0), g.S_in - 1); iw = min(max(iw, 0), g.S_in - 1);
+                    } else {
+                        ok = id >= 0 && id < g.S_in && ih >= 0 && ih < g.S_in && iw >= 0 && iw < g.S_in;
+                    }
+                    const long long vox = (((long long)a_b[i] * g.S_in + id) * g.S_in + ih) * g.S_in + iw;
+                    a_off[i] = ok ? vox * g.Cin + lchunk[i] * 8 : -1;
                 }
-                const long long vox = (((long long)a_b[i] * g.S_in + id) * g.S_in + ih) * g.S_in + iw;
-                asrc[i] = ok ? g.A + vox * g.Cin + cc + lchunk[i] * 8 : nullptr;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) asrc[i] = a_off[i] >= 0 ? g.A + a_off[i] + it_cc : nullptr;
+            it_cc += 32;
+            if (it_cc == g.Cin) {
+                it_cc = 0;
+                if (++it_tw == g.kext) { it_tw = 0; if (++it_th == g.kext) { it_th = 0; ++it_td; } }
             }
         }
 #pragma unroll
