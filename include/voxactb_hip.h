@@ -205,6 +205,18 @@ int vxb_flash_attn_bwd_bf16x3(const float* q, const float* kv, const float* o, c
                               float* dq, float* dkv, float* dsum_ws, int B, int H, int Nq, int Nk, int head_dim,
                               float scale, float dropout_p, uint32_t seed, vxb_stream_t stream);
 
+/* Forward with k | v as bf16 planes [nplanes][B*Nk][2*H*64] (vxb_split_bf16_f32 of the to_kv output): K/V tiles go
+ * global -> LDS directly (double-buffered, one barrier per 64-key tile).  Same outputs / dropout mask as the entries above. */
+int vxb_flash_attn_fwd_dl(const float* q, const void* kv_planes, int nplanes, float* o, float* lse, int B, int H, int Nq,
+                          int Nk, int head_dim, float scale, float dropout_p, uint32_t seed, vxb_stream_t stream);
+
+/* Backward twin: q, dO and k | v tiles from bf16 planes (kv_planes as above; q_planes / do_planes [nplanes][B*Nq][H*64]),
+ * one LDS copy per tile serving row and transposed fragment reads.  dq / dkv WRITTEN; dsum_ws: B*H*Nq floats. */
+int vxb_flash_attn_bwd_dl(const float* q, const float* kv, const float* o, const float* d_o, const float* lse,
+                          const void* kv_planes, const void* q_planes, const void* do_planes, int nplanes, float* dq,
+                          float* dkv, float* dsum_ws, int B, int H, int Nq, int Nk, int head_dim, float scale,
+                          float dropout_p, uint32_t seed, vxb_stream_t stream);
+
 /* GEGLU x * gelu_erf(gates) (perceiver_lang_io.py:74-77); LeakyReLU backward; y += alpha*x. */
 int vxb_geglu_fwd_f32(const float* h, float* out, int64_t rows, int F, vxb_stream_t stream);
 int vxb_geglu_bwd_f32(const float* h, const float* dout, float* dh, int64_t rows, int F, vxb_stream_t stream);

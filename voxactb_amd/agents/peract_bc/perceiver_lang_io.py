@@ -299,9 +299,9 @@ class PerceiverEngine:
             # fused attention on the bf16 matrix cores, no [B*h, i, j] tensor (csrc/flash_attn.hip); 'bf16x3' carries
             # q, k, v, dO, P and dS as hi + lo halves
             x3 = self.precision == 'bf16x3'
-            O, lse = flash.flash_attn_fwd(q, kv, B, H, Nq, Nk, d ** -0.5, p, seed, x3=x3)
+            O, lse, kvp = flash.flash_attn_fwd_dl(q, kv, B, H, Nq, Nk, d ** -0.5, p, seed, x3=x3, return_planes=True)
             out = ops.linear(O, Wo, bo, residual=residual)
-            cache = dict(q=q, kv=kv, O=O, lse=lse, flash=True, x3=x3, dims=(B, Nq, Nk, H, d, 0), p=p, seed=seed) if save else None
+            cache = dict(q=q, kv=kv, kvp=kvp, O=O, lse=lse, flash=True, x3=x3, dims=(B, Nq, Nk, H, d, 0), p=p, seed=seed) if save else None
             return out, cache
         ld = _r4(Nk)
         S = torch.empty((B * H, Nq, ld), dtype=torch.float32, device=xq.device)
@@ -324,8 +324,8 @@ class PerceiverEngine:
         dO = torch.empty((B * Nq, inner), dtype=torch.float32, device=dev)
         ops.linear_bwd(c['O'], Wo, dout, self.g(pre + '.fn.to_out.weight'), self.g(pre + '.fn.to_out.bias'), dO)
         if c.get('flash'):
-            dq, dkv = flash.flash_attn_bwd(c['q'], c['kv'], c['O'], dO, c['lse'], B, H, Nq, Nk, d ** -0.5, c['p'], c['seed'],
-                                           x3=c['x3'])
+            dq, dkv = flash.flash_attn_bwd_dl(c['q'], c['kv'], c['O'], dO, c['lse'], B, H, Nq, Nk, d ** -0.5, c['p'], c['seed'],
+                                              x3=c['x3'], kv_planes=c['kvp'])
             return self._attn_bwd_proj(pre, dq, dkv, xq2d, ctx2d, same_src)
         kv, q, P, Pd = c['kv'], c['q'], c['P'], c['Pd']
         dkv = torch.empty_like(kv)

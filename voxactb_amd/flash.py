@@ -14,6 +14,45 @@ def flash_attn_fwd(q, kv, B, H, Nq, Nk, scale, p=0.0, seed=0, x3=False):
     return o, lse
 
 
+def flash_attn_fwd_dl(q, kv, B, H, Nq, Nk, scale, p=0.0, seed=0, x3=False, return_planes=False):
+    """same result as flash_attn_fwd; k | v are first split into bf16 planes (one streaming pass) and then loaded
+    global -> LDS directly by the kernel (csrc/flash_fwd_dl.hip)."""
+    npl = 2 if x3 else 1
+    planes = torch.empty((npl,) + tuple(kv.shape), dtype=torch.bfloat16, device=kv.device)
+    set_meta('attn_core', 0.0)
+    call('vxb_split_bf16_f32', kv, kv.stride(0), kv.shape[0], kv.shape[1], planes, npl)
+    o = torch.empty_like(q)
+    lse = torch.empty((B * H, Nq), dtype=torch.float32, device=q.device)
+    set_meta('attn_core', 4.0 * B * H * Nq * Nk * 64)
+    call('vxb_flash_attn_fwd_dl', q, planes, npl, o, lse, B, H, Nq, Nk, 64, float(scale), float(p), int(seed) & 0xFFFFFFFF)
+    if return_planes:
+        return o, lse, planes
+    return o, lse
+
+
+def _planes(x, npl):
+    out = torch.empty((npl,) + tuple(x.shape), dtype=torch.bfloat16, device=x.device)
+    set_meta('attn_core', 0.0)
+    call('vxb_split_bf16_f32', x, x.stride(0), x.shape[0], x.shape[1], out, npl)
+    return out
+
+
+def flash_attn_bwd_dl(q, kv, o, d_o, lse, B, H, Nq, Nk, scale, p=0.0, seed=0, x3=False, kv_planes=None):
+    """flash_attn_bwd with q, dO and k | v tiles loaded global -> LDS directly from bf16 planes (csrc/flash_bwd_dl.hip);
+    kv_planes: the planes made by flash_attn_fwd_dl(..., return_planes=True), recomputed when None."""
+    npl = 2 if x3 else 1
+    if kv_planes is None:
+        kv_planes = _planes(kv, npl)
+    qp, dop = _planes(q, npl), _planes(d_o, npl)
+    dq = torch.empty_like(q)
+    dkv = torch.empty_like(kv)
+    ws = torch.empty(B * H * Nq, dtype=torch.float32, device=q.device)
+    set_meta('attn_core', 10.0 * B * H * Nq * Nk * 64)
+    call('vxb_flash_attn_bwd_dl', q, kv, o, d_o, lse, kv_planes, qp, dop, npl, dq, dkv, ws, B, H, Nq, Nk, 64, float(scale),
+         float(p), int(seed) & 0xFFFFFFFF)
+    return dq, dkv
+
+
 def flash_attn_bwd(q, kv, o, d_o, lse, B, H, Nq, Nk, scale, p=0.0, seed=0, x3=False):
     """-> (dq [B*Nq, H*64], dkv [B*Nk, 2*H*64]); same (p, seed) as the forward call."""
     dq = torch.empty_like(q)
