@@ -65,8 +65,24 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform (scalar register)
     const int Ct = g.C0 + g.C1;
-    const int cb = blockIdx.x * 16;                   // this workgroup's 16 input channels
-    const int n0 = blockIdx.y * 64;                   // ... and 64 output channels
+    // Workgroup -> (channel chunk bx, column block by, tile slice bz).  The chunk blocks of one (by, bz) read the SAME dY
+    // tiles; hardware places linear workgroup id L on XCD L % 8, so when the number of (by, bz) pairs is a multiple of 8
+    // the ids are permuted to put all chunks of a pair on one XCD (same L2) and next to each other in launch order:
+    // L = xcd + 8 * (chunk + G * pj)  <->  pair = pj * 8 + xcd.  Bijective; only speed depends on the placement.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const int G = gridDim.x, P = gridDim.y * gridDim.z;
+        if ((P & 7) == 0) {
+            const int L = blockIdx.x + G * (blockIdx.y + gridDim.y * blockIdx.z);
+            const int xcd = L & 7, j = L >> 3;
+            bx = j % G;
+            const int pair = (j / G) * 8 + xcd;
+            by = pair % gridDim.y;
+            bz = pair / gridDim.y;
+        }
+    }
+    const int cb = bx * 16;                           // this workgroup's 16 input channels
+    const int n0 = by * 64;                           // ... and 64 output channels
     const bool second = cb >= g.C0;
     const float* __restrict__ src = second ? g.src1 : g.src0;
     const int Cs = second ? g.C1 : g.C0;
@@ -74,7 +90,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
     const int S = g.S_out;
     // dY of a depth-to-space output: column block nb is one phase (d2s_C == 64) of the fine grid
     int rd = 0, rh = 0, rw = 0;
-    if (g.d2s_s > 0) { const int ph = blockIdx.y; rw = ph % g.d2s_s; rh = (ph / g.d2s_s) % g.d2s_s; rd = ph / (g.d2s_s * g.d2s_s); }
+    if (g.d2s_s > 0) { const int ph = by; rw = ph % g.d2s_s; rh = (ph / g.d2s_s) % g.d2s_s; rd = ph / (g.d2s_s * g.d2s_s); }
 
     f32x4 acc[7][4];
 #pragma unroll
@@ -82,7 +98,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    long long t_begin = (long long)blockIdx.z * g.tiles_per_split;
+    long long t_begin = (long long)bz * g.tiles_per_split;
     long long t_end = t_begin + g.tiles_per_split;
     if (t_end > g.ntiles) t_end = g.ntiles;
 
@@ -219,7 +235,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
     }
 
     // D tile (16 ci x 16 n): lane l holds column n = l & 15, rows 4 (l >> 4) + r
-    float* __restrict__ C = g.part + (long long)blockIdx.z * g.Krows * g.N;
+    float* __restrict__ C = g.part + (long long)bz * g.Krows * g.N;
 #pragma unroll
     for (int ti = 0; ti < 7; ++ti) {
         const int tap = wid + 4 * ti;

@@ -243,6 +243,12 @@ def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
         blocks = ((C0 + C1) // 16) * (N // 64)
         ntiles = B * ((S_out + 1) // 2) * ((S_out + 7) // 8) ** 2
         ns = nsplit if nsplit is not None else max(1, min(256, (1024 + blocks - 1) // blocks, ntiles // 8))
+        if nsplit is None:
+            # (column blocks x slices) a multiple of 8 lets the kernel co-locate the channel-chunk blocks that share dY
+            # tiles on one XCD (see wgrad_halo.hip)
+            import math
+            step = 8 // math.gcd(N // 64, 8)
+            ns = min(((ns + step - 1) // step) * step, max(step, (ntiles // step) * step))
         part = torch.empty((ns, K, N), dtype=torch.float32, device=src0.device)
         _lib.set_meta(label or 'conv3d_wgrad[k%d s%d %d->%d S%d]' % (kext, stride, C0 + C1, N, S_out), 2.0 * P * N * K)
         call('vxb_conv3_wgrad_halo_bf16x3_f32' if mode == 'bf16x3' else 'vxb_conv3_wgrad_halo_bf16_f32', src0, src1, C0, C1,
