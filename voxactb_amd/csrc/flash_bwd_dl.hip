@@ -98,7 +98,7 @@ __device__ __forceinline__ void bd_frag8(const float* p, float s, bf16x8& fh, bf
 // lane = query (swapped form).  Per K/V tile: S^T = K Q^T, P = exp2(S^T - lse); dP^T = V dO^T;
 // dS^T = scale * P * (dP * keep/(1-p) - D); dQ^T += K^T dS^T (K^T by transposed reads of the same K tile).
 template <int X3>
-__global__ void __launch_bounds__(256) flash_bwd_dq_dl_kernel(BdArgs g) {
+__global__ void __launch_bounds__(256, 2) flash_bwd_dq_dl_kernel(BdArgs g) {
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     constexpr int NPL = 1 + X3;
     constexpr int STAGE = 2 * NPL * TILE;           // [K planes][V planes]
@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(256) flash_bwd_dq_dl_kernel(BdArgs g) {
 //   P = exp2(S - lse[q]), dS = scale * P * (dP * keep/(1-p) - D[q])
 //   dV += Pd^T dO, dK += dS^T Q : A = the P / dS registers packed to bf16, B = dO / Q by transposed reads of the same tiles
 template <int X3>
-__global__ void __launch_bounds__(256) flash_bwd_dkv_dl_kernel(BdArgs g) {
+__global__ void __launch_bounds__(256, 2) flash_bwd_dkv_dl_kernel(BdArgs g) {
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     constexpr int NPL = 1 + X3;
     constexpr int STAGE = 2 * NPL * TILE;           // [Q planes][dO planes]
@@ -293,9 +293,6 @@ __global__ void __launch_bounds__(256) flash_bwd_dkv_dl_kernel(BdArgs g) {
     };
     const unsigned thr = (unsigned)(g.p_drop * 65536.0f);
     const float keep_scale = 1.0f / (1.0f - g.p_drop);
-    int rbase[2], rkey[2];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) { const int row = qb * 32 + lk; rbase[qb] = row * 64; rkey[qb] = bd_swz(row); }
     const int t16 = lane & 15, gq = lane >> 4;
     const int trow0 = 4 * (gq >> 1) + (t16 >> 2);
     const int tchunk0 = 2 * (gq & 1) + ((t16 & 3) >> 1), thalf = (t16 & 1) * 4;
@@ -308,31 +305,33 @@ __global__ void __launch_bounds__(256) flash_bwd_dkv_dl_kernel(BdArgs g) {
         if (qt + 1 < nqt) issue((qt + 1) & 1, qt + 1);
         const int st = qt & 1;
         const u16* sb = smem + st * STAGE;
-        f32x16 sacc[2], pacc[2];
-#pragma unroll
+        const unsigned q_addr = (unsigned)(size_t)sb, o_addr = (unsigned)(size_t)(sb + NPL * TILE);
+        // the two 32-query blocks of the tile one after the other (a real loop): only one block's S / dP / P / dS
+        // registers are live at a time, which is what lets two waves share a SIMD
+#pragma unroll 1
         for (int qb = 0; qb < 2; ++qb) {
+            f32x16 sacc, pacc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { sacc[qb][r] = 0.f; pacc[qb][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+            const int arow = qb * 32 + lk;
+            const int abase = arow * 64, akey = bd_swz(arow);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int co = rbase[qb] + ((2 * ks + hi) ^ rkey[qb]) * 8;
+                const int co = abase + ((2 * ks + hi) ^ akey) * 8;
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(sb + co), al = *reinterpret_cast<const bf16x8*>(sb + X3 * TILE + co);
                 const bf16x8 ch = *reinterpret_cast<const bf16x8*>(sb + NPL * TILE + co);
                 const bf16x8 cl = *reinterpret_cast<const bf16x8*>(sb + (NPL + X3) * TILE + co);
-                sacc[qb] = bd_mma<X3>(ah, al, kfh[ks], kfl[ks], sacc[qb]);
-                pacc[qb] = bd_mma<X3>(ch, cl, vfh[ks], vfl[ks], pacc[qb]);
+                sacc = bd_mma<X3>(ah, al, kfh[ks], kfl[ks], sacc);
+                pacc = bd_mma<X3>(ch, cl, vfh[ks], vfl[ks], pacc);
             }
-        }
-        // sacc[qb][r] = S[q = qt*64 + qb*32 + (r&3) + 8*(r>>2) + 4*hi][key = this lane's key]
-        unsigned pbh[2][8], pbl[2][8], sbh[2][8], sbl[2][8];
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
+            // sacc[r] = S[q = qt*64 + qb*32 + (r&3) + 8*(r>>2) + 4*hi][key = this lane's key]
+            unsigned pbh[8], pbl[8], sbh[8], sbl[8];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const int ql = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;          // local query row of reg r (r+1 -> ql+1)
-                float p0 = k_ok ? __builtin_amdgcn_exp2f(sacc[qb][r] - s_lse[st][ql]) : 0.f;
-                float p1 = k_ok ? __builtin_amdgcn_exp2f(sacc[qb][r + 1] - s_lse[st][ql + 1]) : 0.f;
-                float d0 = pacc[qb][r], d1 = pacc[qb][r + 1];
+                float p0 = k_ok ? __builtin_amdgcn_exp2f(sacc[r] - s_lse[st][ql]) : 0.f;
+                float p1 = k_ok ? __builtin_amdgcn_exp2f(sacc[r + 1] - s_lse[st][ql + 1]) : 0.f;
+                float d0 = pacc[r], d1 = pacc[r + 1];
                 float pd0 = p0, pd1 = p1;
                 if (thr > 0u) {
                     const unsigned row0 = (unsigned)bh * (unsigned)g.Nq + (unsigned)(qt * BT + ql);
@@ -345,21 +344,18 @@ __global__ void __launch_bounds__(256) flash_bwd_dkv_dl_kernel(BdArgs g) {
                 }
                 const float s0 = g.scale * p0 * (d0 - s_dsum[st][ql]), s1 = g.scale * p1 * (d1 - s_dsum[st][ql + 1]);
                 if (X3) {
-                    bd_split2(pd0, pd1, pbh[qb][r >> 1], pbl[qb][r >> 1]);
-                    bd_split2(s0, s1, sbh[qb][r >> 1], sbl[qb][r >> 1]);
+                    bd_split2(pd0, pd1, pbh[r >> 1], pbl[r >> 1]);
+                    bd_split2(s0, s1, sbh[r >> 1], sbl[r >> 1]);
                 } else {
-                    pbh[qb][r >> 1] = vxb_pack_bf16(pd0, pd1);
-                    sbh[qb][r >> 1] = vxb_pack_bf16(s0, s1);
+                    pbh[r >> 1] = vxb_pack_bf16(pd0, pd1);
+                    sbh[r >> 1] = vxb_pack_bf16(s0, s1);
                 }
             }
-        // dV += Pd^T dO ; dK += dS^T Q : contraction over the 64 queries = 2 q-blocks x 2 k-steps of 16
-        const unsigned q_addr = (unsigned)(size_t)sb, o_addr = (unsigned)(size_t)(sb + NPL * TILE);
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
+            // dV += Pd^T dO ; dK += dS^T Q : contraction over this block's 32 queries = 2 k-steps of 16
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 pfh = bd_from4(&pbh[qb][4 * ks]), sfh = bd_from4(&sbh[qb][4 * ks]);
-                const bf16x8 pfl = X3 ? bd_from4(&pbl[qb][4 * ks]) : pfh, sfl = X3 ? bd_from4(&sbl[qb][4 * ks]) : sfh;
+                const bf16x8 pfh = bd_from4(&pbh[4 * ks]), sfh = bd_from4(&sbh[4 * ks]);
+                const bf16x8 pfl = X3 ? bd_from4(&pbl[4 * ks]) : pfh, sfl = X3 ? bd_from4(&sbl[4 * ks]) : sfh;
                 unsigned long long oa[2][2], qa[2][2], ol[2][2], ql2[2][2];
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
@@ -384,6 +380,7 @@ __global__ void __launch_bounds__(256) flash_bwd_dkv_dl_kernel(BdArgs g) {
                     dkacc[db] = bd_mma<X3>(sfh, sfl, q2h, q2l, dkacc[db]);
                 }
             }
+        }
     }
     // accumulators: C[i = key (row, regs)][j = d (lane)]: row = (r&3) + 8*(r>>2) + 4*hi of the wave's 32 keys, col = db*32 + (lane & 31)
     const int kw0 = blockIdx.x * BQ + wid * 32;
