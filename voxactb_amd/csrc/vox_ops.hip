@@ -678,21 +678,27 @@ __global__ void __launch_bounds__(64) ce_rows_kernel(const float* __restrict__ l
 // =====================================================================================================
 // polyphase weights:  Weff[(j3*Cin + ci)][(r3*Cout + co)] = sum_t W[co][ci][t3] * L[rd][td][jd] L[rh][th][jh] L[rw][tw][jw]
 // =====================================================================================================
+// one workgroup per output row (j3, ci): the 27 x Cout weights W[:, ci, :] it needs are staged once in LDS ([t][co], so the
+// Cout-contiguous threads read consecutive words) instead of being fetched 27 times per element with a Cin*27-float stride
 __global__ void __launch_bounds__(256) weff_fwd_kernel(const float* __restrict__ W, const float* __restrict__ L, float* __restrict__ Weff,
                                                        int Cin, int Cout, int k, int s, int kl) {
-    extern __shared__ float sL[];          // [s][k][kl]
-    for (int i = threadIdx.x; i < s * k * kl; i += 256) sL[i] = L[i];
-    __syncthreads();
+    extern __shared__ float sm[];          // sL [s][k][kl], then sW [T][Cout]
+    float* sL = sm;
+    float* sW = sm + s * k * kl;
     const int T = k * k * k;
-    const long long ncol = (long long)s * s * s * Cout;
-    const long long total = (long long)kl * kl * kl * Cin * ncol;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long col = i % ncol, row = i / ncol;
-        const int co = (int)(col % Cout), r3 = (int)(col / Cout);
-        const int ci = (int)(row % Cin), j3 = (int)(row / Cin);
+    const int row = blockIdx.x;            // j3 * Cin + ci
+    const int ci = row % Cin, j3 = row / Cin;
+    for (int i = threadIdx.x; i < s * k * kl; i += 256) sL[i] = L[i];
+    for (int i = threadIdx.x; i < T * Cout; i += 256) {
+        const int co = i / T, t = i - co * T;
+        sW[t * Cout + co] = W[((long long)co * Cin + ci) * T + t];
+    }
+    __syncthreads();
+    const int jw = j3 % kl, jh = (j3 / kl) % kl, jd = j3 / (kl * kl);
+    const int ncol = s * s * s * Cout;
+    for (int col = threadIdx.x; col < ncol; col += 256) {
+        const int co = col % Cout, r3 = col / Cout;
         const int rw = r3 % s, rh = (r3 / s) % s, rd = r3 / (s * s);
-        const int jw = j3 % kl, jh = (j3 / kl) % kl, jd = j3 / (kl * kl);
-        const float* w = W + ((long long)co * Cin + ci) * T;
         float acc = 0.f;
         for (int td = 0; td < k; ++td) {
             const float ld = sL[(rd * k + td) * kl + jd];
@@ -700,10 +706,11 @@ __global__ void __launch_bounds__(256) weff_fwd_kernel(const float* __restrict__
             for (int th = 0; th < k; ++th) {
                 const float lh = ld * sL[(rh * k + th) * kl + jh];
                 if (lh == 0.f) continue;
-                for (int tw = 0; tw < k; ++tw) acc = fmaf(w[(td * k + th) * k + tw], lh * sL[(rw * k + tw) * kl + jw], acc);
+                for (int tw = 0; tw < k; ++tw)
+                    acc = fmaf(sW[((td * k + th) * k + tw) * Cout + co], lh * sL[(rw * k + tw) * kl + jw], acc);
             }
         }
-        Weff[i] = acc;
+        Weff[(long long)row * ncol + col] = acc;
     }
 }
 // adjoint: dW[co][ci][t3] += sum_{r3, j3} dWeff[(j3*Cin+ci)][(r3*Cout+co)] * L3
@@ -945,9 +952,9 @@ extern "C" int vxb_ce_rows_f32(const float* logits, int64_t ld, int rows, int ns
 extern "C" int vxb_polyphase_weights_f32(const float* W, const float* L, float* Weff, int Cin, int Cout, int k, int s, int kl,
                                          vxb_stream_t stream) {
     if (!W || !L || !Weff || Cin < 1 || Cout < 1 || k < 1 || s < 1 || kl < 1 || s * k * kl > 8192) return VXB_EARG;
-    const long long total = (long long)kl * kl * kl * Cin * s * s * s * Cout;
-    hipLaunchKernelGGL(weff_fwd_kernel, dim3(grid_for(total)), dim3(256), s * k * kl * sizeof(float), (hipStream_t)stream, W, L, Weff, Cin,
-                       Cout, k, s, kl);
+    const size_t lds = (size_t)(s * k * kl + k * k * k * Cout) * sizeof(float);
+    if (lds > 64 * 1024) return VXB_ESIZE;
+    hipLaunchKernelGGL(weff_fwd_kernel, dim3(kl * kl * kl * Cin), dim3(256), lds, (hipStream_t)stream, W, L, Weff, Cin, Cout, k, s, kl);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
