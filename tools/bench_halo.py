@@ -21,6 +21,9 @@ def timeit(fn, n=5):
 
 def main():
     dev = 'cuda:0'
+    if os.environ.get('HALO_WAVES'):
+        from voxactb_amd import _lib
+        _lib.lib().vxb_debug_set_halo_waves(int(os.environ['HALO_WAVES']))
     B, S = 4, 100
     x0 = torch.randn(B, S, S, S, 64, device=dev)
     x1 = torch.randn(B, S, S, S, 64, device=dev)

@@ -46,18 +46,29 @@ struct HaloArgs {
     int d2s_s;              // > 0: out is a fine grid [B, (S_out*s)^3, 64], output column = (phase, co)
 };
 
-__device__ __forceinline__ unsigned hb_pack2(float lo, float hi) { return vxb_pack_bf16(lo, hi); }
+// bf16 pair from two fp32 (RNE).  Both forms give identical bits; which one is FASTER was measured per precision on the
+// 128->64 forward (4 waves x 2 M tiles): the integer form 765 TF/s vs v_cvt_pk_bf16_f32 590 TF/s in 'bf16', but 351 vs 365
+// TF/s in 'bf16x3' -- the cheaper conversion bunches the two resident workgroups' ds_write bursts together.
+template <int X3>
+__device__ __forceinline__ unsigned hb_pack2(float lo, float hi) {
+    if (X3) return vxb_pack_bf16(lo, hi);
+    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
+    a += 0x7fffu + ((a >> 16) & 1u);
+    b += 0x7fffu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xffff0000u);
+}
 
-template <int NT, int X3>     // NT = N / 32 column tiles per wave (2 or 4)
-__global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {
+template <int NT, int X3, int NW>     // NT = N / 32 column tiles per wave; NW waves share the 8 M tiles (4 -> 2 each, 8 -> 1 each)
+__global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
+    constexpr int NTH = NW * 64, MTW = 8 / NW;
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* halo = smem;                               // [HALO_SLOTS][SP]
     u16* wsm = smem + HALO_SLOTS * SP;              // [2][N][LDW]
     constexpr int N = NT * 32;
     constexpr int CPC = X3 ? 16 : 32;               // channels per chunk
     constexpr int F4P = CPC / 4;                    // float4 per voxel per chunk
-    constexpr int NLD = (NPOS * F4P + 255) / 256;   // halo float4 loads per thread per chunk (10 / 19)
-    constexpr int W_V8 = N * 4 / 256;               // 16-byte weight loads per thread per tap (1 / 2)
+    constexpr int NLD = (NPOS * F4P + NTH - 1) / NTH;   // halo float4 loads per thread per chunk (10 / 19)
+    constexpr int W_V8 = (N * 4 + NTH - 1) / NTH;              // 16-byte weight loads per thread per tap (1 / 2)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int hi = lane >> 5, lq = lane & 31;
     // XCD-aware order (workgroup id b runs on XCD b % 8, each with a private L2): give every XCD a contiguous run of
@@ -79,9 +90,9 @@ __global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {
     const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
     const int Ct = g.C0 + g.C1;
 
-    f32x16 acc[2][NT];
+    f32x16 acc[MTW][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MTW; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -89,10 +100,10 @@ __global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {
 
     // A-operand base slots of this wave's two M tiles: tile mt = wid*2 + i -> d = mt >> 1, w half = mt & 1;
     // lane row: h = lq >> 2, w = (mt & 1) * 4 + (lq & 3)
-    int abase[2];
+    int abase[MTW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int mt = wid * 2 + i;
+    for (int i = 0; i < MTW; ++i) {
+        const int mt = wid * MTW + i;
         abase[i] = (((mt >> 1) * HHp + (lq >> 2)) * HWp + (mt & 1) * 4 + (lq & 3)) * SP + 8 * hi;
     }
     const int wrow = lq * LDW + 8 * hi;            // B-operand row of this lane inside a weight tile (+ nt*32*LDW)
@@ -106,7 +117,7 @@ __global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {
     int st_soff[NLD];      // LDS offset (u16)
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-        const int e = tid + 256 * i;
+        const int e = tid + NTH * i;
         int p = e / F4P;
         const int c4 = (e % F4P) * 4;
         st_goff[i] = -1;
@@ -135,25 +146,25 @@ __global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {
     uint4 rw0[W_V8], rw1[W_V8];
     // A fragments, two register sets (current tap / next tap): [M tile][k half]; bf16 -> channels 0-15 | 16-31 of the
     // chunk, x3 -> hi | lo of its 16 channels
-    bf16x8 afa[2][2], afb[2][2];
+    bf16x8 afa[MTW][2], afb[MTW][2];
 #define HB_LOAD_W(R, tap_)                                                                                           \
     _Pragma("unroll") for (int i = 0; i < W_V8; ++i) {                                                                \
-        const int e = tid + 256 * i;                                                                                 \
+        const int e = tid + NTH * i;                                                                                 \
         const int n = e >> 2, q = e & 3;                                                                             \
         const u16* wp = X3 ? g.wb + ((long long)(q >> 1) * g.N + n0 + n) * g.K + (tap_) * Ct + cb + (q & 1) * 8       \
                            : g.wb + (long long)(n0 + n) * g.K + (tap_) * Ct + cb + q * 8;                            \
-        R[i] = *reinterpret_cast<const uint4*>(wp);                                                                  \
+        if (N * 4 >= NTH || e < N * 4) R[i] = *reinterpret_cast<const uint4*>(wp);                                    \
     }
 #define HB_STORE_W(R, buf_)                                                                                          \
     _Pragma("unroll") for (int i = 0; i < W_V8; ++i) {                                                                \
-        const int e = tid + 256 * i;                                                                                 \
-        *reinterpret_cast<uint4*>(&wsm[(buf_) * N * LDW + (e >> 2) * LDW + (e & 3) * 8]) = R[i];                      \
+        const int e = tid + NTH * i;                                                                                 \
+        if (N * 4 >= NTH || e < N * 4) *reinterpret_cast<uint4*>(&wsm[(buf_) * N * LDW + (e >> 2) * LDW + (e & 3) * 8]) = R[i]; \
     }
 #define HB_READ_A(AF, tap_)                                                                                          \
     {                                                                                                                \
         const int tp_ = (tap_);                                                                                      \
         const int toff_ = (((tp_ / 9) * HHp + (tp_ / 3) % 3) * HWp + tp_ % 3) * SP;                                  \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                               \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i) {                                                               \
             AF[i][0] = *reinterpret_cast<const bf16x8*>(&halo[abase[i] + toff_]);                                    \
             AF[i][1] = *reinterpret_cast<const bf16x8*>(&halo[abase[i] + toff_ + 16]);                               \
         }                                                                                                            \
@@ -176,15 +187,15 @@ __global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {
             HB_READ_A(AN, tap + 1)                                                                                   \
         }                                                                                                            \
         /* term-major order: consecutive MFMAs hit different accumulators (no back-to-back dependent issue) */       \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                 \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                                 \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][1], bfr[j][X3 ? 0 : 1], acc[i][j], 0, 0, 0);   \
         if (X3) {                                                                                                    \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                             \
+            _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                             \
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][0], bfr[j][1], acc[i][j], 0, 0, 0);        \
         }                                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                 \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                                 \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][0], bfr[j][0], acc[i][j], 0, 0, 0);            \
         __syncthreads();                                                                                             \
@@ -209,7 +220,7 @@ __global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {
         for (int i = 0; i < NLD; ++i) {
             hv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (st_goff[i] >= 0)
-                hv[i] = *reinterpret_cast<const float4*>(src + (vbase + st_goff[i]) * Cs + c0 + (((tid + 256 * i) % F4P) * 4));
+                hv[i] = *reinterpret_cast<const float4*>(src + (vbase + st_goff[i]) * Cs + c0 + (((tid + NTH * i) % F4P) * 4));
         }
         HB_LOAD_W(rw0, 0)
         HB_LOAD_W(rw1, 1)
@@ -218,12 +229,12 @@ __global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {
         for (int i = 0; i < NLD; ++i) {
             if (st_goff[i] != -1) {
                 uint2 pk;
-                pk.x = hb_pack2(hv[i].x, hv[i].y); pk.y = hb_pack2(hv[i].z, hv[i].w);
+                pk.x = hb_pack2<X3>(hv[i].x, hv[i].y); pk.y = hb_pack2<X3>(hv[i].z, hv[i].w);
                 *reinterpret_cast<uint2*>(&halo[st_soff[i]]) = pk;
                 if (X3) {
                     uint2 q;
-                    q.x = hb_pack2(hv[i].x - __uint_as_float(pk.x << 16), hv[i].y - __uint_as_float(pk.x & 0xffff0000u));
-                    q.y = hb_pack2(hv[i].z - __uint_as_float(pk.y << 16), hv[i].w - __uint_as_float(pk.y & 0xffff0000u));
+                    q.x = hb_pack2<X3>(hv[i].x - __uint_as_float(pk.x << 16), hv[i].y - __uint_as_float(pk.x & 0xffff0000u));
+                    q.y = hb_pack2<X3>(hv[i].z - __uint_as_float(pk.y << 16), hv[i].w - __uint_as_float(pk.y & 0xffff0000u));
                     *reinterpret_cast<uint2*>(&halo[st_soff[i] + 16]) = q;
                 }
             }
@@ -239,8 +250,8 @@ __global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {
     }
     // ---- epilogue: acc[i][j][r] = C[voxel row (r&3) + 8*(r>>2) + 4*hi of M tile i][channel j*32 + lq]
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int mt = wid * 2 + i;
+    for (int i = 0; i < MTW; ++i) {
+        const int mt = wid * MTW + i;
         const int od = d0 + (mt >> 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -270,12 +281,14 @@ __global__ void __launch_bounds__(256, 2) conv3_halo_kernel(HaloArgs g) {
 
 inline bool hb_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-template <int NT, int X3>
+int g_halo_waves = 4;        // experiment knob (vxb_debug_set_halo_waves): 4 waves x 2 M tiles or 8 waves x 1 M tile per workgroup
+
+template <int NT, int X3, int NW>
 int hb_launch(const HaloArgs& g, long long nblk, hipStream_t st) {
     const size_t lds = (size_t)(HALO_SLOTS * SP + 2 * NT * 32 * LDW) * sizeof(u16);
-    if (hipFuncSetAttribute((const void*)conv3_halo_kernel<NT, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv3_halo_kernel<NT, X3, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VXB_ELAUNCH;
-    hipLaunchKernelGGL((conv3_halo_kernel<NT, X3>), dim3((unsigned)(nblk * (g.N / (NT * 32)))), dim3(256), lds, st, g);
+    hipLaunchKernelGGL((conv3_halo_kernel<NT, X3, NW>), dim3((unsigned)(nblk * (g.N / (NT * 32)))), dim3(NW * 64), lds, st, g);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
@@ -300,10 +313,13 @@ int hb_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B,
     hipStream_t st = (hipStream_t)stream;
     // 64 output channels per workgroup (162-225 VGPRs -> two workgroups per CU); N = 128 runs two column blocks that each
     // stage the halo -- cheaper than the register spills of a 128-wide accumulator tile.
-    return x3 ? hb_launch<2, 1>(g, nblk, st) : hb_launch<2, 0>(g, nblk, st);
+    if (g_halo_waves == 8) return x3 ? hb_launch<2, 1, 8>(g, nblk, st) : hb_launch<2, 0, 8>(g, nblk, st);
+    return x3 ? hb_launch<2, 1, 4>(g, nblk, st) : hb_launch<2, 0, 4>(g, nblk, st);
 }
 
 }  // namespace
+
+extern "C" void vxb_debug_set_halo_waves(int nw) { g_halo_waves = nw == 8 ? 8 : 4; }
 
 // 3x3x3, stride-1 twin of vxb_conv3d_bf16w_f32 (same weights layout bf16 [N][27*(C0+C1)], same padding semantics:
 // src voxel = out + tap + off per axis); C0, C1 multiples of 32, N a multiple of 64.  out [B, S_out^3, N] is overwritten.
