@@ -1,0 +1,52 @@
+"""GPU: data gradient of a 3x3x3 replicate-padded conv fused with the adjoint of its padding (vxb_conv3_dgrad_fold_f32)
+against the two-kernel path (zero-padded conv on the padded domain + vxb_fold_pad_f32) and against autograd of the
+PyTorch conv (float64) in bf16x3."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from voxactb_amd import ops
+from .test_ops_gpu import rnd, close, cl, ref_conv, DEV
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'bf16x3'])
+@pytest.mark.parametrize('S,B', [(16, 2), (20, 1), (34, 1)])
+def test_dgrad_fold_matches_two_kernel_path(mode, S, B):
+    C, N = 64, 128
+    dy = cl(rnd(B, C, S, S, S, seed=3)).to(DEV)
+    W = rnd(C, N, 3, 3, 3, seed=1, scale=0.1).to(DEV)              # conv N -> C, so its data gradient has N columns
+    y1 = cl(rnd(B, 64, S, S, S, seed=5)).to(DEV)
+    base0 = cl(rnd(B, 64, S, S, S, seed=6)).to(DEV)
+    ops.PRECISION = mode
+    try:
+        assert ops.dgrad_fold_ok(C, N, S)
+        wd = ops.conv_weight_dgrad(W)
+        dcat = ops.conv3d(dy, wd, N, B, S, S + 2, 3, -2, replicate=False)
+        r0 = base0.clone()
+        ops.fold_pad(dcat, S + 2, N, 0, r0, B, S, 64, 1, accumulate=True)
+        r1 = torch.empty(B, S, S, S, 64, device=DEV)
+        ops.fold_pad(dcat, S + 2, N, 64, r1, B, S, 64, 1, lrelu_of=y1)
+        g0 = base0.clone()
+        g1 = torch.full((B, S, S, S, 64), 3.0, device=DEV)
+        ops.conv3_dgrad_fold(dy, wd, B, S, N, [(g0, True, None), (g1, False, y1)])
+    finally:
+        ops.PRECISION = 'fp32'
+    close(g0, r0, 3e-5, 'fused fold, accumulate block ' + mode)
+    close(g1, r1, 3e-5, 'fused fold, lrelu block ' + mode)
+
+
+def test_dgrad_fold_x3_vs_autograd():
+    B, S, C, N = 1, 16, 64, 64
+    x = rnd(B, N, S, S, S, seed=2).double().requires_grad_(True)
+    W = rnd(C, N, 3, 3, 3, seed=1, scale=0.1)
+    dy = rnd(B, C, S, S, S, seed=3)
+    ref_conv(x, W.double(), None).backward(dy.double())
+    out = torch.zeros(B, S, S, S, 64, device=DEV)
+    ops.PRECISION = 'bf16x3'
+    try:
+        ops.conv3_dgrad_fold(cl(dy).to(DEV), ops.conv_weight_dgrad(W.to(DEV)), B, S, N, [(out, False, None)])
+    finally:
+        ops.PRECISION = 'fp32'
+    close(out, cl(x.grad.float()), 2e-5, 'fused dgrad + fold vs autograd')

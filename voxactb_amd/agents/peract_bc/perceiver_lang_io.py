@@ -537,15 +537,20 @@ class PerceiverEngine:
         dWt = ops.conv3d_wgrad(d0, du, C, B, V, V, 3, -1, src1=u0)
         self.g('final.conv3d.weight').add_(dWt.view(27, 2 * C, C).permute(2, 1, 0).reshape(Wf.shape))
         ops.colsum(du.view(-1, C), self.g('final.conv3d.bias'), accumulate=True)
-        dcat = ops.conv3d(du, ops.conv_weight_dgrad(Wf), 2 * C, B, V, V + 2, 3, -2, replicate=False)
-        del du
         dd0 = E(B, V, V, V, C)
         ss, mx, st, am = c['ss0']
         ops.ss3d_max_bwd(d0, V ** 3 * C, B, V, C, st, ss, am, gs[0], gs[1], dd0, V ** 3 * C)
-        ops.fold_pad(dcat, V + 2, 2 * C, 0, dd0, B, V, C, 1, accumulate=True)
         du0 = E(B, V, V, V, C)
-        ops.fold_pad(dcat, V + 2, 2 * C, C, du0, B, V, C, 1, lrelu_of=u0)             # d(pre-activation of up0's last conv)
-        del dcat
+        if C == 64 and ops.dgrad_fold_ok(C, 2 * C, V):
+            # data gradient and the adjoint of the replicate padding in one kernel: the first 64 columns add into dd0,
+            # the other 64 become d(pre-activation of up0's last conv) through u0's LeakyReLU'
+            ops.conv3_dgrad_fold(du, ops.conv_weight_dgrad(Wf), B, V, 2 * C, [(dd0, True, None), (du0, False, u0)])
+        else:
+            dcat = ops.conv3d(du, ops.conv_weight_dgrad(Wf), 2 * C, B, V, V + 2, 3, -2, replicate=False)
+            ops.fold_pad(dcat, V + 2, 2 * C, 0, dd0, B, V, C, 1, accumulate=True)
+            ops.fold_pad(dcat, V + 2, 2 * C, C, du0, B, V, C, 1, lrelu_of=u0)         # d(pre-activation of up0's last conv)
+            del dcat
+        del du
         # ---- up0: second conv (polyphase) -> first conv
         z1, zc = c['z1'], c['zc']
         up2 = 'up0.conv_up.%d.conv3d' % (2 if s > 1 else 1)

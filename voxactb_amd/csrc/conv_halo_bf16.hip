@@ -44,6 +44,12 @@ struct HaloArgs {
     int ntd, nth, ntw;
     int s2d_s, s2d_C;       // > 0: src0 is a fine grid [B, (S_in*s)^3, s2d_C], input channel = (phase, co)
     int d2s_s;              // > 0: out is a fine grid [B, (S_out*s)^3, 64], output column = (phase, co)
+    // fold mode (fold_pad > 0): the conv is a data gradient on the padded domain S_out = fold_S + 2 fold_pad; instead of
+    // storing it, column block nb adds the replicate-padding adjoint into fold_dst[nb] [B, fold_S^3, 64]
+    int fold_pad, fold_S;
+    float* fold_dst[2];
+    const float* fold_y[2];  // != nullptr: multiply by LeakyReLU'(y) (the producer's activation)
+    int fold_acc[2];         // 1: dst += ..., 0: dst = ...
 };
 
 // bf16 pair from two fp32 (RNE).  Both forms give identical bits; which one is FASTER was measured per precision on the
@@ -248,6 +254,61 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
         }
         HB_TAP(26, rw0, rw1, afa, afb)
     }
+    if (g.fold_pad > 0) {
+        // ---- fused adjoint of the replicate padding (vxb_fold_pad_f32 without the round trip through HBM): the tile goes
+        // to LDS as fp32 [256 voxels][64 ch] (the halo / weight buffers are free now); the voxel that is the first of the
+        // padded voxels clamping to an output voxel sums its (pad+1)-wide border group -- the host checked that every
+        // group lies inside one tile -- and updates the destination
+        float* ft = reinterpret_cast<float*>(smem);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            const int mt = wid * MTW + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int pos = ((mt >> 1) * TH + (m >> 2)) * TW + (mt & 1) * 4 + (m & 3);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) ft[pos * 64 + j * 32 + lq] = acc[i][j][r];
+            }
+        }
+        __syncthreads();
+        const int nb = n0 / N, P = g.fold_pad, S = g.fold_S;
+        float* __restrict__ dst = g.fold_dst[nb];
+        const float* __restrict__ yv = g.fold_y[nb];
+        const int facc = g.fold_acc[nb];
+        for (int item = tid; item < TD * TH * TW * 16; item += NTH) {
+            const int c4 = (item & 15) * 4, pos = item >> 4;
+            const int wl = pos % TW, hl = (pos / TW) % TH, dl = pos / (TW * TH);
+            const int id = d0 + dl, ih = h0 + hl, iw = w0 + wl;
+            if (id >= g.S_out || ih >= g.S_out || iw >= g.S_out) continue;
+            // owner test and group span per axis: i in [1, P] belongs to the group of i = 0; i > S-1+P to that of S-1+P
+            if ((id >= 1 && id <= P) || id > S - 1 + P || (ih >= 1 && ih <= P) || ih > S - 1 + P || (iw >= 1 && iw <= P) || iw > S - 1 + P) continue;
+            const int nd = (id == 0 || id == S - 1 + P) ? P + 1 : 1;
+            const int nh = (ih == 0 || ih == S - 1 + P) ? P + 1 : 1;
+            const int nw = (iw == 0 || iw == S - 1 + P) ? P + 1 : 1;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int dd = 0; dd < nd; ++dd)
+                for (int hh = 0; hh < nh; ++hh)
+                    for (int ww = 0; ww < nw; ++ww) {
+                        const float4 v = *reinterpret_cast<const float4*>(&ft[(((dl + dd) * TH + hl + hh) * TW + wl + ww) * 64 + c4]);
+                        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+                    }
+            const int jd = min(max(id - P, 0), S - 1), jh = min(max(ih - P, 0), S - 1), jw = min(max(iw - P, 0), S - 1);
+            const long long o = ((((long long)b * S + jd) * S + jh) * S + jw) * 64 + c4;
+            if (facc) {
+                const float4 pv = *reinterpret_cast<const float4*>(dst + o);
+                a.x += pv.x; a.y += pv.y; a.z += pv.z; a.w += pv.w;
+            }
+            if (yv) {
+                const float4 yy = *reinterpret_cast<const float4*>(yv + o);
+                a.x = yy.x > 0.f ? a.x : a.x * g.slope; a.y = yy.y > 0.f ? a.y : a.y * g.slope;
+                a.z = yy.z > 0.f ? a.z : a.z * g.slope; a.w = yy.w > 0.f ? a.w : a.w * g.slope;
+            }
+            *reinterpret_cast<float4*>(dst + o) = a;
+        }
+        return;
+    }
     // ---- epilogue: acc[i][j][r] = C[voxel row (r&3) + 8*(r>>2) + 4*hi of M tile i][channel j*32 + lq]
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
@@ -295,8 +356,8 @@ int hb_launch(const HaloArgs& g, long long nblk, hipStream_t st) {
 
 int hb_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out, int off, int replicate,
             const void* wt_bf16, int N, const float* bias, float* out, int act, float slope, int s2d_s, int s2d_C,
-            int d2s_s, vxb_stream_t stream) {
-    if (!src0 || !wt_bf16 || !out || B < 1 || S_in < 1 || S_out < 1) return VXB_EARG;
+            int d2s_s, vxb_stream_t stream, const HaloArgs* fold = nullptr) {
+    if (!src0 || !wt_bf16 || (!out && !fold) || B < 1 || S_in < 1 || S_out < 1) return VXB_EARG;
     if ((C0 & 31) || (C1 & 31) || C0 < 32 || (C1 > 0 && !src1) || N < 64 || (N & 63)) return VXB_ESIZE;
     if (!hb_aligned16(src0) || !hb_aligned16(wt_bf16) || (src1 && !hb_aligned16(src1))) return VXB_ESIZE;
     if (s2d_s > 0 && (C1 != 0 || s2d_C < 32 || (s2d_C & 31) || C0 != s2d_s * s2d_s * s2d_s * s2d_C)) return VXB_EARG;
@@ -304,6 +365,12 @@ int hb_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B,
     if (Vin * Vin * Vin >= INT32_MAX) return VXB_ESIZE;
     HaloArgs g;
     g.s2d_s = s2d_s; g.s2d_C = s2d_C; g.d2s_s = d2s_s;
+    g.fold_pad = 0; g.fold_S = 0; g.fold_dst[0] = g.fold_dst[1] = nullptr; g.fold_y[0] = g.fold_y[1] = nullptr;
+    g.fold_acc[0] = g.fold_acc[1] = 0;
+    if (fold) {
+        g.fold_pad = fold->fold_pad; g.fold_S = fold->fold_S;
+        for (int i = 0; i < 2; ++i) { g.fold_dst[i] = fold->fold_dst[i]; g.fold_y[i] = fold->fold_y[i]; g.fold_acc[i] = fold->fold_acc[i]; }
+    }
     g.src0 = src0; g.src1 = src1; g.C0 = C0; g.C1 = C1; g.B = B; g.S_in = S_in; g.S_out = S_out; g.off = off;
     g.replicate = replicate; g.wb = (const u16*)wt_bf16; g.N = N; g.K = 27 * (C0 + C1); g.bias = bias; g.out = out;
     g.act = act; g.slope = slope;
@@ -339,4 +406,22 @@ extern "C" int vxb_conv3_halo_bf16x3_f32(const float* src0, const float* src1, i
                                          int act, float slope, int s2d_s, int s2d_C, int d2s_s, vxb_stream_t stream) {
     return hb_impl(1, src0, src1, C0, C1, B, S_in, S_out, off, replicate, wt_bf16, N, bias, out, act, slope, s2d_s, s2d_C, d2s_s,
                    stream);
+}
+
+// Data gradient of a 3x3x3 replicate-padded conv fused with the adjoint of its padding (vxb_conv3_halo_* followed by
+// vxb_fold_pad_f32, without writing the padded-domain gradient): dy [B, S^3, C0] -> for each 64-column block nb of the
+// N <= 128 input channels, dst_nb [B, S^3, 64] (+)= fold(conv_zero_pad(dy, wt_dgrad)) (* LeakyReLU'(y_nb) when y_nb is
+// given).  x3 != 0: weights are the [2][N][K] planes ('bf16x3').  pad = 1.
+extern "C" int vxb_conv3_dgrad_fold_f32(const float* dy, int C0, int B, int S, const void* wt_bf16, int x3, int N, float* dst0,
+                                        float* dst1, const float* y0, const float* y1, int acc0, int acc1, float slope,
+                                        vxb_stream_t stream) {
+    if (!dy || !wt_bf16 || !dst0 || (N > 64 && !dst1) || N > 128 || S < 2) return VXB_EARG;
+    const int pad = 1, S_out = S + 2 * pad;
+    // every border group {0..pad} / {S-1+pad..S-1+2 pad} must lie inside one tile
+    if ((S_out - 1 - pad) / TD != (S_out - 1) / TD || (S_out - 1 - pad) / TH != (S_out - 1) / TH || (S_out - 1 - pad) / TW != (S_out - 1) / TW)
+        return VXB_ESIZE;
+    HaloArgs f;
+    f.fold_pad = pad; f.fold_S = S; f.fold_dst[0] = dst0; f.fold_dst[1] = dst1; f.fold_y[0] = y0; f.fold_y[1] = y1;
+    f.fold_acc[0] = acc0; f.fold_acc[1] = acc1;
+    return hb_impl(x3, dy, nullptr, C0, 0, B, S, S_out, -2 * pad, 0, wt_bf16, N, nullptr, nullptr, 0, slope, 0, 0, 0, stream, &f);
 }

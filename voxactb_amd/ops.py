@@ -330,6 +330,25 @@ def polyphase_dgrad_weights_lowres(Weff, Ci, Co, s, kl):
     return w.permute(0, 1, 2, 4, 5, 6, 7, 3).reshape(kl ** 3 * s ** 3 * Co, Ci).contiguous()
 
 
+def dgrad_fold_ok(C_dy, N, S):
+    """the fused data-gradient + fold kernel: bf16 modes, 3x3x3 / pad 1, border groups inside one 4x8x8 tile."""
+    So = S + 2
+    return (HALO_CONV and _mm() and C_dy % 32 == 0 and N in (64, 128) and S >= 16
+            and (So - 2) // 4 == (So - 1) // 4 and (So - 2) // 8 == (So - 1) // 8)
+
+
+def conv3_dgrad_fold(dy, wt_dgrad, B, S, N, dsts, label=None):
+    """fold_pad(conv3d(dy, wt_dgrad, zero pad, S+2), pad=1) without the padded tensor: dsts = [(dst [B,S,S,S,64],
+    accumulate, lrelu_of or None)] per 64-column block (1 or 2 entries)."""
+    C0 = dy.shape[-1]
+    wb = to_bf16_nk(wt_dgrad)
+    x3 = wb.dim() == 3
+    d0, a0, y0 = dsts[0]
+    d1, a1, y1 = dsts[1] if len(dsts) > 1 else (None, False, None)
+    _lib.set_meta(label or 'conv3d_bf16[k3 s1 %d->%d S%d dgrad+fold]' % (C0, N, S + 2), 2.0 * B * (S + 2) ** 3 * N * 27 * C0)
+    call('vxb_conv3_dgrad_fold_f32', dy, C0, B, S, wb, int(x3), N, d0, d1, y0, y1, int(a0), int(a1), LRELU_SLOPE)
+
+
 def s2d_halo_ok(kl, C, N):
     return HALO_CONV and _mm() and kl == 3 and C % 32 == 0 and N % 64 == 0
 
