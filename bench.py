@@ -33,8 +33,8 @@ PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=4)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--voxel-size', type=int, default=100)
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--image', type=int, default=128)
