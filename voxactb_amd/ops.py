@@ -11,9 +11,9 @@ LRELU_SLOPE = 0.02   # reference: peract/helpers/network_utils.py:12
 ACT_NONE, ACT_LRELU = 0, 1
 _NAIVE_MACS = 1 << 22
 
-# Compute precision of the matrix-core kernels: 'fp32' = exact fp32 MFMA everywhere (parity mode, the default);
-# 'bf16' = forward + data-gradient convs and large linears on bf16 MFMA with fp32 accumulation (throughput mode;
-# weight gradients, attention softmax path and every streaming kernel stay fp32).  Set by PerceiverEngine per call.
+# Compute precision of the matrix-core kernels, set by PerceiverEngine per call (its default is bf16x3):
+# "fp32" = exact fp32 MFMA everywhere; "bf16x3" = hi/lo split products on the bf16 matrix cores (same parity bounds);
+# "bf16" = plain bf16 operands (throughput mode).  Accumulators and every streaming kernel are fp32 in all modes.
 PRECISION = 'fp32'
 HALO_CONV = True     # 3x3x3 stride-1 bf16 convs go through the LDS-halo kernel (conv_halo_bf16.hip)
 HALO_D2S = False     # ... also the depth-to-space forward of the polyphase up-conv: measured 21.0 ms vs 19.3 ms generic at
