@@ -128,17 +128,20 @@ int vxb_conv3d_dl_f32(const void* src_planes, int Cin, int B, int S_in, int S_ou
  * data gradient of the polyphase up-conv.  d2s_s > 0: depth-to-space output, 64 channels per phase (its forward). */
 int vxb_conv3_halo_bf16w_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                              int off, int replicate, const void* wt_bf16, int N, const float* bias, float* out,
-                             int act, float slope, int s2d_s, int s2d_C, int d2s_s, vxb_stream_t stream);
+                             int act, float slope, int s2d_s, int s2d_C, int d2s_s, const void* wfrag, vxb_stream_t stream);
 int vxb_conv3_halo_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                               int off, int replicate, const void* wt_bf16, int N, const float* bias, float* out,
-                              int act, float slope, int s2d_s, int s2d_C, int d2s_s, vxb_stream_t stream);
-/* Data gradient of a 3x3x3 replicate-padded conv fused with vxb_fold_pad_f32 (the padded-domain gradient never reaches
+                              int act, float slope, int s2d_s, int s2d_C, int d2s_s, const void* wfrag, vxb_stream_t stream);
+/* wfrag (optional, NULL = weights staged through LDS per tap): the same weights pre-shuffled into MFMA fragment order,
+ * [N/64][chunk][tap][column tile 2][k half or plane 2][lane 64][8 bf16] with chunk = 32 channels ('bf16') or 16 ('bf16x3');
+ * the kernel then loads its B fragments straight from global memory and the 27-tap loop has no barrier.
+ * Data gradient of a 3x3x3 replicate-padded conv fused with vxb_fold_pad_f32 (the padded-domain gradient never reaches
  * HBM): dy [B, S^3, C0]; wt_bf16 = data-gradient weights [N][27*C0] (x3 != 0: planes [2][N][K]); for each 64-column block
  * nb of the N <= 128 columns: dst_nb [B, S^3, 64] (+)= fold(...) (* LeakyReLU'(y_nb) when y_nb != NULL).
  * Replaces the pair at perceiver_lang_io.py:462 (backward of `final` into d0 and u0). */
 int vxb_conv3_dgrad_fold_f32(const float* dy, int C0, int B, int S, const void* wt_bf16, int x3, int N, float* dst0,
                              float* dst1, const float* y0, const float* y1, int acc0, int acc1, float slope,
-                             vxb_stream_t stream);
+                             const void* wfrag, vxb_stream_t stream);
 /* LDS-halo weight gradient of the same 3x3x3 stride-1 convs (contract of vxb_conv3d_wgrad_f32 with kext = 3, stride = 1;
  * the z slices of part[z][K][N] are runs of 2x8x8 voxel tiles).  C0, C1 % 16 == 0, N % 64 == 0; d2s needs d2s_C == 64. */
 int vxb_conv3_wgrad_halo_bf16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,

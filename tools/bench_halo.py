@@ -21,6 +21,8 @@ def timeit(fn, n=5):
 
 def main():
     dev = 'cuda:0'
+    if os.environ.get('HALO_WD') == '0':
+        ops.HALO_WD = False
     if os.environ.get('HALO_WAVES'):
         from voxactb_amd import _lib
         _lib.lib().vxb_debug_set_halo_waves(int(os.environ['HALO_WAVES']))

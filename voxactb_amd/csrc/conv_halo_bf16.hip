@@ -46,6 +46,7 @@ struct HaloArgs {
     int d2s_s;              // > 0: out is a fine grid [B, (S_out*s)^3, 64], output column = (phase, co)
     // fold mode (fold_pad > 0): the conv is a data gradient on the padded domain S_out = fold_S + 2 fold_pad; instead of
     // storing it, column block nb adds the replicate-padding adjoint into fold_dst[nb] [B, fold_S^3, 64]
+    const u16* wfrag;        // WD kernels: weights pre-shuffled into fragment order (ops.halo_wfrag)
     int fold_pad, fold_S;
     float* fold_dst[2];
     const float* fold_y[2];  // != nullptr: multiply by LeakyReLU'(y) (the producer's activation)
@@ -64,7 +65,8 @@ __device__ __forceinline__ unsigned hb_pack2(float lo, float hi) {
     return (a >> 16) | (b & 0xffff0000u);
 }
 
-template <int NT, int X3, int NW>     // NT = N / 32 column tiles per wave; NW waves share the 8 M tiles (4 -> 2 each, 8 -> 1 each)
+template <int NT, int X3, int NW, int WD>     // NT = N / 32 column tiles per wave; NW waves share the 8 M tiles (4 -> 2 each,
+                                              // 8 -> 1 each); WD: B fragments straight from global (pre-shuffled weights)
 __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
     constexpr int NTH = NW * 64, MTW = 8 / NW;
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
@@ -206,7 +208,34 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][0], bfr[j][0], acc[i][j], 0, 0, 0);            \
         __syncthreads();                                                                                             \
     }
+    // ---- WD variant: the B fragments of a tap come straight from global memory (weights pre-shuffled on the host into
+    // fragment order: 1 KB per (tap, column tile, k half / plane), lane-contiguous -> fully coalesced, L1-shared by the
+    // waves of the CU), two taps ahead in three rotating register sets.  No weight traffic through LDS and NO barrier
+    // inside the 27-tap loop.
+    bf16x8 bq0[NT][2], bq1[NT][2], bq2[NT][2];
     const int nchunk = Ct / CPC;
+#define HD_LOADB(BQ, tap_)                                                                                           \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                    \
+    _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                     \
+        BQ[j][f] = *reinterpret_cast<const bf16x8*>(g.wfrag + ((((long long)(n0 / N) * nchunk + ch) * 27 + (tap_)) * (NT * 2) + j * 2 + f) * 512 + lane * 8);
+#define HD_TAP(tap_, BC, BL, AC, AN)                                                                                 \
+    {                                                                                                                \
+        const int tap = (tap_);                                                                                      \
+        if (tap + 2 < 27) { HD_LOADB(BL, tap + 2) }                                                                  \
+        if (tap + 1 < 27) { HB_READ_A(AN, tap + 1) }                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                               \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][1], BC[j][X3 ? 0 : 1], acc[i][j], 0, 0, 0);    \
+        if (X3) {                                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                           \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][0], BC[j][1], acc[i][j], 0, 0, 0);         \
+        }                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                               \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][0], BC[j][0], acc[i][j], 0, 0, 0);             \
+    }
     for (int ch = 0; ch < nchunk; ++ch) {
         const int cb = ch * CPC;
         const bool second = cb >= g.C0;
@@ -228,9 +257,15 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
             if (st_goff[i] >= 0)
                 hv[i] = *reinterpret_cast<const float4*>(src + (vbase + st_goff[i]) * Cs + c0 + (((tid + NTH * i) % F4P) * 4));
         }
-        HB_LOAD_W(rw0, 0)
-        HB_LOAD_W(rw1, 1)
-        // (the barrier that ended the previous chunk's last tap already freed the halo and both weight buffers)
+        if (!WD) {
+            HB_LOAD_W(rw0, 0)
+            HB_LOAD_W(rw1, 1)
+            // (the barrier that ended the previous chunk's last tap already freed the halo and both weight buffers)
+        } else {
+            HD_LOADB(bq0, 0)
+            HD_LOADB(bq1, 1)
+            __syncthreads();                        // no per-tap barriers here: every wave must be done with the old halo
+        }
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             if (st_goff[i] != -1) {
@@ -245,14 +280,28 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
                 }
             }
         }
-        HB_STORE_W(rw0, 0)
+        if (!WD) { HB_STORE_W(rw0, 0) }
         __syncthreads();
         HB_READ_A(afa, 0)
-        for (int tp = 0; tp < 26; tp += 2) {
-            HB_TAP(tp, rw0, rw1, afa, afb)
-            HB_TAP(tp + 1, rw1, rw0, afb, afa)
+        if (!WD) {
+            for (int tp = 0; tp < 26; tp += 2) {
+                HB_TAP(tp, rw0, rw1, afa, afb)
+                HB_TAP(tp + 1, rw1, rw0, afb, afa)
+            }
+            HB_TAP(26, rw0, rw1, afa, afb)
+        } else {
+            for (int tp = 0; tp < 24; tp += 6) {
+                HD_TAP(tp, bq0, bq2, afa, afb)
+                HD_TAP(tp + 1, bq1, bq0, afb, afa)
+                HD_TAP(tp + 2, bq2, bq1, afa, afb)
+                HD_TAP(tp + 3, bq0, bq2, afb, afa)
+                HD_TAP(tp + 4, bq1, bq0, afa, afb)
+                HD_TAP(tp + 5, bq2, bq1, afb, afa)
+            }
+            HD_TAP(24, bq0, bq2, afa, afb)
+            HD_TAP(25, bq1, bq0, afb, afa)
+            HD_TAP(26, bq2, bq1, afa, afb)
         }
-        HB_TAP(26, rw0, rw1, afa, afb)
     }
     if (g.fold_pad > 0) {
         // ---- fused adjoint of the replicate padding (vxb_fold_pad_f32 without the round trip through HBM): the tile goes
@@ -344,19 +393,20 @@ inline bool hb_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 int g_halo_waves = 4;        // experiment knob (vxb_debug_set_halo_waves): 4 waves x 2 M tiles or 8 waves x 1 M tile per workgroup
 
-template <int NT, int X3, int NW>
+template <int NT, int X3, int NW, int WD>
 int hb_launch(const HaloArgs& g, long long nblk, hipStream_t st) {
+    // (the fold epilogue re-uses the buffer as an fp32 [256][64] tile: keep the full size in every variant)
     const size_t lds = (size_t)(HALO_SLOTS * SP + 2 * NT * 32 * LDW) * sizeof(u16);
-    if (hipFuncSetAttribute((const void*)conv3_halo_kernel<NT, X3, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv3_halo_kernel<NT, X3, NW, WD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VXB_ELAUNCH;
-    hipLaunchKernelGGL((conv3_halo_kernel<NT, X3, NW>), dim3((unsigned)(nblk * (g.N / (NT * 32)))), dim3(NW * 64), lds, st, g);
+    hipLaunchKernelGGL((conv3_halo_kernel<NT, X3, NW, WD>), dim3((unsigned)(nblk * (g.N / (NT * 32)))), dim3(NW * 64), lds, st, g);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
 
 int hb_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out, int off, int replicate,
             const void* wt_bf16, int N, const float* bias, float* out, int act, float slope, int s2d_s, int s2d_C,
-            int d2s_s, vxb_stream_t stream, const HaloArgs* fold = nullptr) {
+            int d2s_s, vxb_stream_t stream, const HaloArgs* fold = nullptr, const void* wfrag = nullptr) {
     if (!src0 || !wt_bf16 || (!out && !fold) || B < 1 || S_in < 1 || S_out < 1) return VXB_EARG;
     if ((C0 & 31) || (C1 & 31) || C0 < 32 || (C1 > 0 && !src1) || N < 64 || (N & 63)) return VXB_ESIZE;
     if (!hb_aligned16(src0) || !hb_aligned16(wt_bf16) || (src1 && !hb_aligned16(src1))) return VXB_ESIZE;
@@ -364,7 +414,7 @@ int hb_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B,
     const long long Vin = (long long)S_in * (s2d_s > 0 ? s2d_s : 1);
     if (Vin * Vin * Vin >= INT32_MAX) return VXB_ESIZE;
     HaloArgs g;
-    g.s2d_s = s2d_s; g.s2d_C = s2d_C; g.d2s_s = d2s_s;
+    g.s2d_s = s2d_s; g.s2d_C = s2d_C; g.d2s_s = d2s_s; g.wfrag = (const u16*)wfrag;
     g.fold_pad = 0; g.fold_S = 0; g.fold_dst[0] = g.fold_dst[1] = nullptr; g.fold_y[0] = g.fold_y[1] = nullptr;
     g.fold_acc[0] = g.fold_acc[1] = 0;
     if (fold) {
@@ -380,8 +430,9 @@ int hb_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B,
     hipStream_t st = (hipStream_t)stream;
     // 64 output channels per workgroup (162-225 VGPRs -> two workgroups per CU); N = 128 runs two column blocks that each
     // stage the halo -- cheaper than the register spills of a 128-wide accumulator tile.
-    if (g_halo_waves == 8) return x3 ? hb_launch<2, 1, 8>(g, nblk, st) : hb_launch<2, 0, 8>(g, nblk, st);
-    return x3 ? hb_launch<2, 1, 4>(g, nblk, st) : hb_launch<2, 0, 4>(g, nblk, st);
+    if (g.wfrag) return x3 ? hb_launch<2, 1, 4, 1>(g, nblk, st) : hb_launch<2, 0, 4, 1>(g, nblk, st);
+    if (g_halo_waves == 8) return x3 ? hb_launch<2, 1, 8, 0>(g, nblk, st) : hb_launch<2, 0, 8, 0>(g, nblk, st);
+    return x3 ? hb_launch<2, 1, 4, 0>(g, nblk, st) : hb_launch<2, 0, 4, 0>(g, nblk, st);
 }
 
 }  // namespace
@@ -395,17 +446,17 @@ extern "C" void vxb_debug_set_halo_waves(int nw) { g_halo_waves = nw == 8 ? 8 : 
 // phase (N = d2s_s^3 * 64), out = fine grid [B, (S_out*d2s_s)^3, 64] -- the polyphase up-conv forward.
 extern "C" int vxb_conv3_halo_bf16w_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                                         int off, int replicate, const void* wt_bf16, int N, const float* bias, float* out,
-                                        int act, float slope, int s2d_s, int s2d_C, int d2s_s, vxb_stream_t stream) {
+                                        int act, float slope, int s2d_s, int s2d_C, int d2s_s, const void* wfrag, vxb_stream_t stream) {
     return hb_impl(0, src0, src1, C0, C1, B, S_in, S_out, off, replicate, wt_bf16, N, bias, out, act, slope, s2d_s, s2d_C, d2s_s,
-                   stream);
+                   stream, nullptr, wfrag);
 }
 
 // 'bf16x3' twin (weights = planes [2][N][K], see vxb_conv3d_bf16x3_f32).
 extern "C" int vxb_conv3_halo_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                                          int off, int replicate, const void* wt_bf16, int N, const float* bias, float* out,
-                                         int act, float slope, int s2d_s, int s2d_C, int d2s_s, vxb_stream_t stream) {
+                                         int act, float slope, int s2d_s, int s2d_C, int d2s_s, const void* wfrag, vxb_stream_t stream) {
     return hb_impl(1, src0, src1, C0, C1, B, S_in, S_out, off, replicate, wt_bf16, N, bias, out, act, slope, s2d_s, s2d_C, d2s_s,
-                   stream);
+                   stream, nullptr, wfrag);
 }
 
 // Data gradient of a 3x3x3 replicate-padded conv fused with the adjoint of its padding (vxb_conv3_halo_* followed by
@@ -414,7 +465,7 @@ extern "C" int vxb_conv3_halo_bf16x3_f32(const float* src0, const float* src1, i
 // given).  x3 != 0: weights are the [2][N][K] planes ('bf16x3').  pad = 1.
 extern "C" int vxb_conv3_dgrad_fold_f32(const float* dy, int C0, int B, int S, const void* wt_bf16, int x3, int N, float* dst0,
                                         float* dst1, const float* y0, const float* y1, int acc0, int acc1, float slope,
-                                        vxb_stream_t stream) {
+                                        const void* wfrag, vxb_stream_t stream) {
     if (!dy || !wt_bf16 || !dst0 || (N > 64 && !dst1) || N > 128 || S < 2) return VXB_EARG;
     const int pad = 1, S_out = S + 2 * pad;
     // every border group {0..pad} / {S-1+pad..S-1+2 pad} must lie inside one tile
@@ -423,5 +474,5 @@ extern "C" int vxb_conv3_dgrad_fold_f32(const float* dy, int C0, int B, int S, c
     HaloArgs f;
     f.fold_pad = pad; f.fold_S = S; f.fold_dst[0] = dst0; f.fold_dst[1] = dst1; f.fold_y[0] = y0; f.fold_y[1] = y1;
     f.fold_acc[0] = acc0; f.fold_acc[1] = acc1;
-    return hb_impl(x3, dy, nullptr, C0, 0, B, S, S_out, -2 * pad, 0, wt_bf16, N, nullptr, nullptr, 0, slope, 0, 0, 0, stream, &f);
+    return hb_impl(x3, dy, nullptr, C0, 0, B, S, S_out, -2 * pad, 0, wt_bf16, N, nullptr, nullptr, 0, slope, 0, 0, 0, stream, &f, wfrag);
 }

@@ -330,6 +330,24 @@ def polyphase_dgrad_weights_lowres(Weff, Ci, Co, s, kl):
     return w.permute(0, 1, 2, 4, 5, 6, 7, 3).reshape(kl ** 3 * s ** 3 * Co, Ci).contiguous()
 
 
+HALO_WD = True       # halo conv: B fragments straight from global memory (pre-shuffled weights), no barrier in the tap loop
+
+
+def halo_wfrag(wb, Ct):
+    """weights bf16 [N][27*Ct] ('bf16') or planes [2][N][27*Ct] ('bf16x3') -> the same values in MFMA fragment order
+    [N/64][chunk][tap][column tile 2][k half | plane 2][lane = hi*32 + lq][8]: lane (lq, hi) of column tile j finds its
+    8 k-values of tap t, chunk c at a lane-contiguous 16-byte slot (one coalesced 1 KB load per fragment)."""
+    if not HALO_WD:
+        return None
+    if wb.dim() == 3:       # x3: chunk = 16 channels, second fragment = lo plane
+        N = wb.shape[1]
+        v = wb.view(2, N // 64, 2, 32, 27, Ct // 16, 2, 8)              # (p, nb, j, lq, tap, ch, hi, e)
+        return v.permute(1, 5, 4, 2, 0, 6, 3, 7).contiguous()             # (nb, ch, tap, j, p, hi, lq, e)
+    N = wb.shape[0]
+    v = wb.view(N // 64, 2, 32, 27, Ct // 32, 2, 2, 8)                  # (nb, j, lq, tap, ch, f, hi, e)
+    return v.permute(0, 4, 3, 1, 5, 6, 2, 7).contiguous()                 # (nb, ch, tap, j, f, hi, lq, e)
+
+
 def dgrad_fold_ok(C_dy, N, S):
     """the fused data-gradient + fold kernel: bf16 modes, 3x3x3 / pad 1, border groups inside one 4x8x8 tile."""
     So = S + 2
@@ -346,7 +364,9 @@ def conv3_dgrad_fold(dy, wt_dgrad, B, S, N, dsts, label=None):
     d0, a0, y0 = dsts[0]
     d1, a1, y1 = dsts[1] if len(dsts) > 1 else (None, False, None)
     _lib.set_meta(label or 'conv3d_bf16[k3 s1 %d->%d S%d dgrad+fold]' % (C0, N, S + 2), 2.0 * B * (S + 2) ** 3 * N * 27 * C0)
-    call('vxb_conv3_dgrad_fold_f32', dy, C0, B, S, wb, int(x3), N, d0, d1, y0, y1, int(a0), int(a1), LRELU_SLOPE)
+    wf = halo_wfrag(wb, C0)
+    _lib.set_meta(label or 'conv3d_bf16[k3 s1 %d->%d S%d dgrad+fold]' % (C0, N, S + 2), 2.0 * B * (S + 2) ** 3 * N * 27 * C0)
+    call('vxb_conv3_dgrad_fold_f32', dy, C0, B, S, wb, int(x3), N, d0, d1, y0, y1, int(a0), int(a1), LRELU_SLOPE, wf)
 
 
 def s2d_halo_ok(kl, C, N):
@@ -360,8 +380,10 @@ def conv3_s2d(src_fine, wt, N, B, G, S_out, off, s, Cf, label=None):
     out = torch.empty((B, S_out, S_out, S_out, N), dtype=torch.float32, device=src_fine.device)
     C0 = s ** 3 * Cf
     _lib.set_meta(label or 'conv3_s2d[k3 %d->%d S%d dgrad]' % (C0, N, S_out), 2.0 * B * S_out ** 3 * N * 27 * C0)
+    wf = halo_wfrag(wb, C0)
+    _lib.set_meta(label or 'conv3_s2d[k3 %d->%d S%d dgrad]' % (C0, N, S_out), 2.0 * B * S_out ** 3 * N * 27 * C0)
     call('vxb_conv3_halo_bf16x3_f32' if wb.dim() == 3 else 'vxb_conv3_halo_bf16w_f32', src_fine, None, C0, 0, B, G, S_out, off,
-         0, wb, N, None, out, ACT_NONE, LRELU_SLOPE, s, Cf, 0)
+         0, wb, N, None, out, ACT_NONE, LRELU_SLOPE, s, Cf, 0, wf)
     return out
 
 
@@ -549,8 +571,11 @@ def conv3d_bf16w(src0, wb, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
     x3 = wb.dim() == 3
     if (HALO_CONV and kext == 3 and stride == 1 and (d2s[0] == 0 or (d2s[1] == 64 and HALO_D2S)) and not accumulate and N % 64 == 0
             and (ldc is None or ldc == N) and S_out >= 16):
+        wf = halo_wfrag(wb, C0 + C1)
+        _lib.set_meta(label or 'conv3d_bf16[k%d s%d %d->%d S%d%s]' % (kext, stride, C0 + C1, N, S_out, '' if replicate else ' dgrad'),
+                      2.0 * B * S_out ** 3 * N * kext ** 3 * (C0 + C1))
         call('vxb_conv3_halo_bf16x3_f32' if x3 else 'vxb_conv3_halo_bf16w_f32', src0, src1, C0, C1, B, S_in, S_out, off,
-             int(replicate), wb, N, bias, out, act, LRELU_SLOPE, 0, 0, d2s[0])
+             int(replicate), wb, N, bias, out, act, LRELU_SLOPE, 0, 0, d2s[0], wf)
         return out
     # ... same trade for convs: every input voxel must feed enough products ((kext/stride)^3 * N per channel) to amortise
     # the split pass (up-conv forward 17.7 -> 15.3 ms; the stride-5 patchify would lose 1.5 ms and stays register-staged)
