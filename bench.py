@@ -140,6 +140,29 @@ def main():
                  'collision': float((qs[headline_mode][2] - qs['fp32'][2]).abs().max()),
                  'q_trans_abs_max': float(qs['fp32'][0].abs().max()), 'bound': 1e-4}
 
+    # act() latency: eval agent, B=1 observation with precomputed language embeddings (the CLIP text
+    # encoder's weights are not in either tree), 1 voxelize + 1 forward + argmax + the D2H copy of the 9-vector action
+    act_lat = None
+    if rank == 0 and not a.no_other_modes:
+        ev = lu.create_agent(cfg)
+        ev.build(training=False, device=local_rank)
+        rs = synthetic.make_replay_sample(1, cfg.rlbench.cameras, (HW, HW), V, 4, seed=3)
+        obs = {k: v.to(dev) for k, v in rs.items() if k.endswith(('_rgb', '_point_cloud')) or k == 'low_dim_state'}
+        obs = {k: v.unsqueeze(0) if v.dim() < 5 and k != 'low_dim_state' else v for k, v in obs.items()}
+        obs['low_dim_state'] = rs['low_dim_state'].to(dev)
+        obs['lang_goal_emb'] = rs['lang_goal_emb'][0].to(dev)
+        obs['lang_token_embs'] = rs['lang_token_embs'][0].to(dev)
+        for i in range(3):
+            ev.act(i, dict(obs), deterministic=True)      # act() annotates the dict it is given
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(10):
+            ev.act(i, dict(obs), deterministic=True)      # act() annotates the dict it is given
+        torch.cuda.synchronize()
+        act_lat = {'ms_per_act': (time.perf_counter() - t0) / 10 * 1e3, 'precision': ev._pose_agent._qattention_agents[0]._q.encoder.engine().precision,
+                   'what': 'QAttentionPerActBCAgent.act(): B=1, V=%d, %d cams %dx%d, language embeddings given' % (V, len(cfg.rlbench.cameras), HW, HW)}
+        del ev
+
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         value = world * a.steps / dt
@@ -184,7 +207,7 @@ def main():
                        'precision': headline_mode},
             'samples_per_s': value * B, 'final_loss': loss, 'device_time_ms_per_step': tot_ms / a.steps,
             'roofline': roofline, 'rooflines_other': extra, 'cpu_baseline': cpu, 'precision_note': MODE_NOTE[headline_mode],
-            'parity_probe': probe, 'other_precisions': others,
+            'parity_probe': probe, 'act_latency': act_lat, 'other_precisions': others,
         }
         print(json.dumps(out))
     if world > 1:
