@@ -5,8 +5,12 @@
 // bounds it at ~250-400 TF/s in bf16.  Here one workgroup owns a 4x8x8 block of output voxels:
 //   * the 6x10x10 input halo of one channel chunk is staged ONCE into LDS (fp32 -> bf16 on the way, replicate padding
 //     by clamping / zero padding by predication): 2.3x amplification instead of 27x;
-//   * per tap only the [N][chunk] weight slice is streamed (double-buffered in LDS) and the A operand of
-//     v_mfma_f32_32x32x16_bf16 is read straight out of the halo at a shifted address.
+//   * the A operand of v_mfma_f32_32x32x16_bf16 is read straight out of the halo at a shifted address per tap;
+//   * the weights of a tap (B operand) come either from global memory in MFMA fragment order (pre-shuffled by
+//     ops.halo_wfrag; every wave loads its own fragments two taps ahead, no barrier in the 27-tap loop -- the default)
+//     or, without that copy, as the [N][chunk] slice staged per tap through a double-buffered LDS tile.
+// Variants: two concatenated sources, zero padding (data gradients), space-to-depth input, depth-to-space output, and a
+// "fold" epilogue that applies the adjoint of the replicate padding in place of the padded-domain store.
 // A chunk is 32 bf16 per voxel: 32 channels ('bf16') or 16 channels as hi|lo halves ('bf16x3': hi = bf16(a),
 // lo = bf16(a - hi), products hi*hi + hi*lo + lo*hi).  That keeps a workgroup at 68-78 KB of LDS and <= 256 VGPRs, so
 // TWO workgroups share a CU and one's halo fetch hides behind the other's MFMAs (global loads retire in order, so
