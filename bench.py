@@ -200,7 +200,9 @@ def main():
             'metric': 'voxel-policy train steps/sec (100^3 grid, 4 cams, B=16)', 'value': value, 'unit': 'steps/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': MODE_DTYPE[headline_mode], 'data': 'synthetic',
-            'config': {'workload': 'BASELINE.json configs[1]: QAttentionPerActBCAgent.update(), V=%d, %d cams %dx%d, '
+            'config': {'workload': ('BASELINE.json configs[1]' if (V, B, HW) == (100, 16, 128) else
+                                    'BASELINE.json configs[4] shape (per GPU)' if (V, B) == (200, 8) else 'custom size') +
+                                   ': QAttentionPerActBCAgent.update(), V=%d, %d cams %dx%d, '
                                    'B=%d per GPU, PerceiverIO depth %d, %d latents, SE(3) aug + dropout on, LAMB'
                                    % (V, len(cfg.rlbench.cameras), HW, HW, B, a.depth, a.latents),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world, 'params': n_params,
