@@ -41,11 +41,12 @@ struct VoxGeom {
 };
 struct VoxWs {
     int *table, *ctr, *occ_n, *cellid, *rank, *occ_cell, *occ_cnt, *occ_base, *seg, *longl;
+    float* pdata;        // [B*N][8]: xyz, up to 4 features, point id (int bits) of every placed point, segment order
 };
 constexpr int VOX_PB = 1024;      // points (and occupied-cell slots) per block in count / alloc / reduce
 
 __host__ __device__ inline size_t vox_ws_ints(long long B, long long N, long long V) {
-    return (size_t)(B * V * V * V + 16 + ((B * N + VOX_PB - 1) / VOX_PB + 16) + 7 * B * N);
+    return (size_t)(B * V * V * V + 16 + ((B * N + VOX_PB - 1) / VOX_PB + 16) + 7 * B * N + 4 + 8 * B * N);
 }
 
 __host__ inline VoxWs vox_ws_carve(void* ws, long long B, long long N, long long V) {
@@ -60,7 +61,8 @@ __host__ inline VoxWs vox_ws_carve(void* ws, long long B, long long N, long long
     w.occ_cnt = p;   p += B * N;
     w.occ_base = p;  p += B * N;
     w.seg = p;       p += B * N;
-    w.longl = p;
+    w.longl = p;     p += B * N;
+    w.pdata = (float*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
     return w;
 }
 
@@ -266,6 +268,76 @@ __global__ void __launch_bounds__(256) vox_reduce_short_kernel(VoxSrc src, VoxGe
     w.table[gc] = 0;
 }
 
+// ---- data-carrying variant (F <= 4, N < 2^27): `place` also copies the point's coordinates / features / id into its
+// 32-byte slot of the cell's segment (coalesced reads, fire-and-forget scatter stores), so that the reduction streams
+// contiguous 32-byte records instead of gathering 3 + F scattered words per point.  Same ascending-id summation order.
+template <int F>
+__global__ void __launch_bounds__(256) vox_place_data_kernel(VoxSrc src, VoxGeom g, VoxWs w) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)g.B * g.N) return;
+    const int cell = w.cellid[t];
+    if (cell < 0) return;
+    const int b = (int)(t / g.N);
+    const int n = (int)(t - (long long)b * g.N);
+    const int slot = w.table[b * g.V * g.V * g.V + cell] + w.rank[t];
+    w.seg[slot] = n;
+    const float* cp = vox_point_ptr(src.c, n, g.pps, b, g.cb, g.cp);
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = cp[c * g.cc];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[3 + c] = 0.f;
+    if (F > 0) {
+        const float* fp = vox_point_ptr(src.f, n, g.pps, b, g.fb, g.fp);
+#pragma unroll
+        for (int c = 0; c < F; ++c) v[3 + c] = fp[c * g.fc];
+    }
+    v[7] = __int_as_float(n);
+    float4* pd = reinterpret_cast<float4*>(w.pdata + (size_t)slot * 8);
+    pd[0] = make_float4(v[0], v[1], v[2], v[3]);
+    pd[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+template <int F>
+__global__ void __launch_bounds__(256) vox_reduce_short_pd_kernel(VoxGeom g, VoxWs w, float* __restrict__ out) {
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    if ((slot % VOX_PB) >= w.occ_n[slot / VOX_PB]) return;
+    const int L = w.occ_cnt[slot];
+    if (L > VOX_SHORT) return;
+    const int gc = w.occ_cell[slot];
+    const float4* pd = reinterpret_cast<const float4*>(w.pdata + (size_t)w.occ_base[slot] * 8);
+    float acc[3 + F];
+#pragma unroll
+    for (int c = 0; c < 3 + F; ++c) acc[c] = 0.0f;     // zeros_like(self._flat_output) (:145)
+    if (L == 1) {
+        const float4 a0 = pd[0], a1 = pd[1];
+        const float r[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int c = 0; c < 3 + F; ++c) acc[c] = __fadd_rn(acc[c], r[c]);
+    } else {
+        int a[16];                                     // (id << 4) | record index: sorting the keys sorts by id
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = (i < L) ? ((__float_as_int(pd[2 * i + 1].w) << 4) | i) : INT_MAX;
+        if (L == 2) {
+            VOX_CSWAP(a[0], a[1]);
+        } else {
+            vox_sort16(a);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (i < L) {
+                const int k = a[i] & 15;
+                const float4 a0 = pd[2 * k], a1 = pd[2 * k + 1];
+                const float r[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                for (int c = 0; c < 3 + F; ++c) acc[c] = __fadd_rn(acc[c], r[c]);
+            }
+        }
+    }
+    vox_store_cell<F>(out, gc, g.V, acc, L);
+    w.table[gc] = 0;
+}
+
 template <int F>
 __global__ void __launch_bounds__(64) vox_reduce_long_kernel(VoxSrc src, VoxGeom g, VoxWs w, float* __restrict__ out,
                                                             int n_words) {
@@ -401,9 +473,10 @@ __global__ void __launch_bounds__(256) vox_fill_scalar_kernel(float* __restrict_
 }
 
 template <int F>
-int vox_launch_reduce(const VoxSrc& src, const VoxGeom& g, const VoxWs& w, float* out, hipStream_t st) {
+int vox_launch_reduce(const VoxSrc& src, const VoxGeom& g, const VoxWs& w, float* out, hipStream_t st, bool use_pd) {
     const long long BN = (long long)g.B * g.N;
-    hipLaunchKernelGGL(vox_reduce_short_kernel<F>, dim3(vxb_cdiv(BN, 256)), dim3(256), 0, st, src, g, w, out);
+    if (use_pd && F <= 4) hipLaunchKernelGGL(vox_reduce_short_pd_kernel<(F <= 4 ? F : 0)>, dim3(vxb_cdiv(BN, 256)), dim3(256), 0, st, g, w, out);
+    else hipLaunchKernelGGL(vox_reduce_short_kernel<F>, dim3(vxb_cdiv(BN, 256)), dim3(256), 0, st, src, g, w, out);
     const int n_words = (g.N + 31) / 32;
     const size_t lds = (size_t)(((n_words + 63) & ~63) + VOX_CHUNK) * 4 + (size_t)64 * (3 + F) * 4;
     if (lds > 160 * 1024) return VXB_ESIZE;
@@ -477,19 +550,30 @@ extern "C" int vxb_voxelize_f32(const float* const* coord_src, const float* cons
     }
     hipLaunchKernelGGL(vox_count_kernel, dim3(vxb_cdiv(BN, VOX_PB)), dim3(VOX_PB), 0, st, src, g, bounds, w);
     hipLaunchKernelGGL(vox_alloc_kernel, dim3(vxb_cdiv(BN, VOX_PB)), dim3(VOX_PB), 0, st, w);
-    hipLaunchKernelGGL(vox_place_kernel, dim3(vxb_cdiv(BN, 256)), dim3(256), 0, st, g, w);
+    const bool use_pd = F <= 4 && N < (1ll << 27);     // records of 8 floats; (id << 4 | index) sort keys
+    if (use_pd) {
+        switch (F) {
+            case 0: hipLaunchKernelGGL(vox_place_data_kernel<0>, dim3(vxb_cdiv(BN, 256)), dim3(256), 0, st, src, g, w); break;
+            case 1: hipLaunchKernelGGL(vox_place_data_kernel<1>, dim3(vxb_cdiv(BN, 256)), dim3(256), 0, st, src, g, w); break;
+            case 2: hipLaunchKernelGGL(vox_place_data_kernel<2>, dim3(vxb_cdiv(BN, 256)), dim3(256), 0, st, src, g, w); break;
+            case 3: hipLaunchKernelGGL(vox_place_data_kernel<3>, dim3(vxb_cdiv(BN, 256)), dim3(256), 0, st, src, g, w); break;
+            default: hipLaunchKernelGGL(vox_place_data_kernel<4>, dim3(vxb_cdiv(BN, 256)), dim3(256), 0, st, src, g, w); break;
+        }
+    } else {
+        hipLaunchKernelGGL(vox_place_kernel, dim3(vxb_cdiv(BN, 256)), dim3(256), 0, st, g, w);
+    }
     if (hipEventRecord(ev_join, fs) != hipSuccess || hipStreamWaitEvent(st, ev_join, 0) != hipSuccess) return VXB_ELAUNCH;
     int rc = VXB_OK;
     switch (F) {
-        case 0: rc = vox_launch_reduce<0>(src, g, w, out, st); break;
-        case 1: rc = vox_launch_reduce<1>(src, g, w, out, st); break;
-        case 2: rc = vox_launch_reduce<2>(src, g, w, out, st); break;
-        case 3: rc = vox_launch_reduce<3>(src, g, w, out, st); break;
-        case 4: rc = vox_launch_reduce<4>(src, g, w, out, st); break;
-        case 5: rc = vox_launch_reduce<5>(src, g, w, out, st); break;
-        case 6: rc = vox_launch_reduce<6>(src, g, w, out, st); break;
-        case 7: rc = vox_launch_reduce<7>(src, g, w, out, st); break;
-        case 8: rc = vox_launch_reduce<8>(src, g, w, out, st); break;
+        case 0: rc = vox_launch_reduce<0>(src, g, w, out, st, use_pd); break;
+        case 1: rc = vox_launch_reduce<1>(src, g, w, out, st, use_pd); break;
+        case 2: rc = vox_launch_reduce<2>(src, g, w, out, st, use_pd); break;
+        case 3: rc = vox_launch_reduce<3>(src, g, w, out, st, use_pd); break;
+        case 4: rc = vox_launch_reduce<4>(src, g, w, out, st, use_pd); break;
+        case 5: rc = vox_launch_reduce<5>(src, g, w, out, st, use_pd); break;
+        case 6: rc = vox_launch_reduce<6>(src, g, w, out, st, use_pd); break;
+        case 7: rc = vox_launch_reduce<7>(src, g, w, out, st, use_pd); break;
+        case 8: rc = vox_launch_reduce<8>(src, g, w, out, st, use_pd); break;
         default: return VXB_EARG;
     }
     if (rc != VXB_OK) return rc;
