@@ -194,7 +194,7 @@ def main():
                 sys.stderr.write('%-44s calls %5d  %9.2f ms/step  %7.2f TF/s\n' % (
                     label, d['calls'] // a.steps, d['ms'] / a.steps, d['flops'] / max(d['ms'], 1e-9) / 1e9))
         cpu = None
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only
             cpu = cpu_baseline(a, cfg)
         out = {
             'metric': 'voxel-policy train steps/sec (100^3 grid, 4 cams, B=16)', 'value': value, 'unit': 'steps/s',
