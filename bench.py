@@ -213,6 +213,7 @@ def main():
         }
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()                   # rank 0 did the rank-0-only extras; leave together
         dist.destroy_process_group()
 
 

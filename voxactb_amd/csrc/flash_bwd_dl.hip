@@ -163,6 +163,7 @@ __global__ void __launch_bounds__(256, 2) flash_bwd_dq_dl_kernel(BdArgs g) {
         if (kt + 1 < nkt) issue((kt + 1) & 1, kt + 1);
         const u16* sb = smem + (kt & 1) * STAGE;
         f32x16 sacc[2], pacc[2];
+        __builtin_amdgcn_s_setprio(1);              // favour the wave that has matrix work to issue
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -177,6 +178,7 @@ __global__ void __launch_bounds__(256, 2) flash_bwd_dq_dl_kernel(BdArgs g) {
                 pacc[kb] = bd_mma<X3>(ch, cl, dofh[ks], dofl[ks], pacc[kb]);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         const int kbase_t = kt * BT;
         unsigned sbh[2][8], sbl[2][8];
 #pragma unroll
@@ -311,6 +313,7 @@ __global__ void __launch_bounds__(256, 2) flash_bwd_dkv_dl_kernel(BdArgs g) {
 #pragma unroll 1
         for (int qb = 0; qb < 2; ++qb) {
             f32x16 sacc, pacc;
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
             const int arow = qb * 32 + lk;
@@ -324,6 +327,7 @@ __global__ void __launch_bounds__(256, 2) flash_bwd_dkv_dl_kernel(BdArgs g) {
                 sacc = bd_mma<X3>(ah, al, kfh[ks], kfl[ks], sacc);
                 pacc = bd_mma<X3>(ch, cl, vfh[ks], vfl[ks], pacc);
             }
+            __builtin_amdgcn_s_setprio(0);
             // sacc[r] = S[q = qt*64 + qb*32 + (r&3) + 8*(r>>2) + 4*hi][key = this lane's key]
             unsigned pbh[8], pbl[8], sbh[8], sbl[8];
 #pragma unroll

@@ -156,6 +156,7 @@ __global__ void __launch_bounds__(256) flash_fwd_dl_kernel(FdArgs g) {
 
         // ---- S^T = K Q^T for the two 32-key blocks
         f32x16 sacc[2];
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -168,6 +169,7 @@ __global__ void __launch_bounds__(256) flash_fwd_dl_kernel(FdArgs g) {
                 sacc[kb] = fd_mma<X3>(ah, al, qfh[ks], qfl[ks], sacc[kb]);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         const int kbase_t = kt * BKV;
         float mt = -INFINITY;
         if (kbase_t + BKV > g.Nk) {                      // only the last tile can hold keys >= Nk
