@@ -473,7 +473,9 @@ __global__ void __launch_bounds__(256) vox_fill_scalar_kernel(float* __restrict_
 }
 
 template <int F>
-int vox_launch_reduce(const VoxSrc& src, const VoxGeom& g, const VoxWs& w, float* out, hipStream_t st, bool use_pd) {
+int vox_launch_reduce(const VoxSrc& src, const VoxGeom& g, const VoxWs& w, float* out, hipStream_t st, hipStream_t st_long,
+                      bool use_pd) {
+    // short cells on `st`, the few long cells (one wave each, latency-bound) on `st_long`: they write disjoint cells
     const long long BN = (long long)g.B * g.N;
     if (use_pd && F <= 4) hipLaunchKernelGGL(vox_reduce_short_pd_kernel<(F <= 4 ? F : 0)>, dim3(vxb_cdiv(BN, 256)), dim3(256), 0, st, g, w, out);
     else hipLaunchKernelGGL(vox_reduce_short_kernel<F>, dim3(vxb_cdiv(BN, 256)), dim3(256), 0, st, src, g, w, out);
@@ -486,7 +488,7 @@ int vox_launch_reduce(const VoxSrc& src, const VoxGeom& g, const VoxWs& w, float
             return VXB_ELAUNCH;
     }
     const int grid = (int)(BN / (VOX_SHORT + 1) < 1 ? 1 : (BN / (VOX_SHORT + 1) > 2048 ? 2048 : BN / (VOX_SHORT + 1)));
-    hipLaunchKernelGGL(vox_reduce_long_kernel<F>, dim3(grid), dim3(64), lds, st, src, g, w, out, n_words);
+    hipLaunchKernelGGL(vox_reduce_long_kernel<F>, dim3(grid), dim3(64), lds, st_long, src, g, w, out, n_words);
     return VXB_OK;
 }
 
@@ -532,15 +534,17 @@ extern "C" int vxb_voxelize_f32(const float* const* coord_src, const float* cons
     // chain (count/alloc/place are latency-bound on L2-resident tables), so it runs on a side stream and
     // joins before the first kernel that writes occupied cells into `out`.
     static hipStream_t side = nullptr;
-    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    static hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_placed = nullptr, ev_long = nullptr;
     if (!side) {
         if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return VXB_ELAUNCH;
         if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return VXB_ELAUNCH;
         if (hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) return VXB_ELAUNCH;
+        if (hipEventCreateWithFlags(&ev_placed, hipEventDisableTiming) != hipSuccess) return VXB_ELAUNCH;
+        if (hipEventCreateWithFlags(&ev_long, hipEventDisableTiming) != hipSuccess) return VXB_ELAUNCH;
     }
     hipStream_t fs = side;
-    if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(fs, ev_fork, 0) != hipSuccess) return VXB_ELAUNCH;
     if (hipMemsetAsync(w.ctr, 0, 16 * sizeof(int), st) != hipSuccess) return VXB_ELAUNCH;
+    if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(fs, ev_fork, 0) != hipSuccess) return VXB_ELAUNCH;
     if (((V * C) & 3) == 0 && (((uintptr_t)out) & 15) == 0) {
         const int rows = B * V * V;
         const int groups = (rows + 7) / 8;
@@ -548,6 +552,7 @@ extern "C" int vxb_voxelize_f32(const float* const* coord_src, const float* cons
     } else {
         hipLaunchKernelGGL(vox_fill_scalar_kernel, dim3(2048), dim3(256), 0, fs, out, (long long)B * V3 * C, V, C);
     }
+    // (forking only after count was measured too: 328 vs 319 us -- count and fill slow each other down either way)
     hipLaunchKernelGGL(vox_count_kernel, dim3(vxb_cdiv(BN, VOX_PB)), dim3(VOX_PB), 0, st, src, g, bounds, w);
     hipLaunchKernelGGL(vox_alloc_kernel, dim3(vxb_cdiv(BN, VOX_PB)), dim3(VOX_PB), 0, st, w);
     const bool use_pd = F <= 4 && N < (1ll << 27);     // records of 8 floats; (id << 4 | index) sort keys
@@ -562,21 +567,24 @@ extern "C" int vxb_voxelize_f32(const float* const* coord_src, const float* cons
     } else {
         hipLaunchKernelGGL(vox_place_kernel, dim3(vxb_cdiv(BN, 256)), dim3(256), 0, st, g, w);
     }
-    if (hipEventRecord(ev_join, fs) != hipSuccess || hipStreamWaitEvent(st, ev_join, 0) != hipSuccess) return VXB_ELAUNCH;
+    // the side stream (fill done) also runs the long-cell reduction once the segments are placed
+    if (hipEventRecord(ev_placed, st) != hipSuccess || hipEventRecord(ev_join, fs) != hipSuccess) return VXB_ELAUNCH;
+    if (hipStreamWaitEvent(st, ev_join, 0) != hipSuccess || hipStreamWaitEvent(fs, ev_placed, 0) != hipSuccess) return VXB_ELAUNCH;
     int rc = VXB_OK;
     switch (F) {
-        case 0: rc = vox_launch_reduce<0>(src, g, w, out, st, use_pd); break;
-        case 1: rc = vox_launch_reduce<1>(src, g, w, out, st, use_pd); break;
-        case 2: rc = vox_launch_reduce<2>(src, g, w, out, st, use_pd); break;
-        case 3: rc = vox_launch_reduce<3>(src, g, w, out, st, use_pd); break;
-        case 4: rc = vox_launch_reduce<4>(src, g, w, out, st, use_pd); break;
-        case 5: rc = vox_launch_reduce<5>(src, g, w, out, st, use_pd); break;
-        case 6: rc = vox_launch_reduce<6>(src, g, w, out, st, use_pd); break;
-        case 7: rc = vox_launch_reduce<7>(src, g, w, out, st, use_pd); break;
-        case 8: rc = vox_launch_reduce<8>(src, g, w, out, st, use_pd); break;
+        case 0: rc = vox_launch_reduce<0>(src, g, w, out, st, fs, use_pd); break;
+        case 1: rc = vox_launch_reduce<1>(src, g, w, out, st, fs, use_pd); break;
+        case 2: rc = vox_launch_reduce<2>(src, g, w, out, st, fs, use_pd); break;
+        case 3: rc = vox_launch_reduce<3>(src, g, w, out, st, fs, use_pd); break;
+        case 4: rc = vox_launch_reduce<4>(src, g, w, out, st, fs, use_pd); break;
+        case 5: rc = vox_launch_reduce<5>(src, g, w, out, st, fs, use_pd); break;
+        case 6: rc = vox_launch_reduce<6>(src, g, w, out, st, fs, use_pd); break;
+        case 7: rc = vox_launch_reduce<7>(src, g, w, out, st, fs, use_pd); break;
+        case 8: rc = vox_launch_reduce<8>(src, g, w, out, st, fs, use_pd); break;
         default: return VXB_EARG;
     }
     if (rc != VXB_OK) return rc;
+    if (hipEventRecord(ev_long, fs) != hipSuccess || hipStreamWaitEvent(st, ev_long, 0) != hipSuccess) return VXB_ELAUNCH;
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
