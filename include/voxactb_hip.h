@@ -119,7 +119,10 @@ int vxb_gemm_dl_f32(const void* A_planes, const void* Bw_planes, int nplanes, fl
 int vxb_conv3d_dl_f32(const void* src_planes, int Cin, int B, int S_in, int S_out, int stride, int kext, int off,
                       int replicate, const void* wt_planes, int nplanes, int N, const float* bias, float* out,
                       int64_t ldc, int act, float slope, int accumulate, int d2s_s, int d2s_C, const void* zeros,
-                      vxb_stream_t stream);
+                      const uint32_t* tapmask, const int32_t* d2s_perm, vxb_stream_t stream);
+/* (tapmask / d2s_perm, both optional: block-sparse weights of the polyphase up-conv, network_utils.py:245-250 -- a fine
+ * phase only sees the low-res taps its trilinear footprint reaches.  tapmask[column tile] bit t set <=> tap t has
+ * non-zero weights in that 128-column tile; d2s_perm[p] = fine-grid phase held by 64-column block p.) */
 /* LDS-halo specialisation of vxb_conv3d_bf16w_f32 for kext == 3, stride == 1 (the `final` conv of the Q-function,
  * perceiver_lang_io.py:462-466, and its data gradient): a 4x8x8 block of output voxels stages its 6x10x10 input halo
  * once instead of once per tap.  C0, C1 % 32 == 0, N % 64 == 0; out [B, S_out^3, N] is overwritten.  The x3 entry

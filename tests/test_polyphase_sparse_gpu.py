@@ -1,0 +1,58 @@
+"""GPU: the block-sparse evaluation of the polyphase up-conv (network_utils.py:245-250: a fine phase only reaches the
+low-res taps under its trilinear footprint, 17.6 of 27 weight blocks on average) against the dense evaluation of the
+same weights.  The skipped products are exact zeros and the surviving ones keep their order: bit-identical."""
+import numpy as np
+import pytest
+import torch
+
+from voxactb_amd import ops
+from .test_ops_gpu import rnd, cl, DEV
+
+pytestmark = pytest.mark.gpu
+
+
+def _weff(C, k, s, seed=1):
+    W = rnd(C, C, k, k, k, seed=seed, scale=0.05).to(DEV)
+    Lh, R = ops.polyphase_tables(k, s)
+    Lt = torch.from_numpy(Lh).to(DEV)
+    return ops.polyphase_weights(W, Lt, s, 2 * R + 1), Lt, R
+
+
+def test_structure_matches_the_weights():
+    """every block the structure calls zero IS zero in W_eff, and the non-zero fraction is 2.6^3 / 27 for k = s = 5."""
+    C, k, s = 64, 5, 5
+    Weff, _, R = _weff(C, k, s)
+    kl = 2 * R + 1
+    st = ops.polyphase_structure(k, s, DEV)
+    blk = Weff.view(kl ** 3, C, s ** 3, C).abs().amax(dim=(1, 3)).cpu().numpy()          # [tap][phase]
+    for ph in range(s ** 3):
+        for tap in range(kl ** 3):
+            if not (st['phase_mask'][ph] >> tap) & 1:
+                assert blk[tap, ph] == 0.0, (tap, ph)
+    assert abs(st['frac'] - 2.6 ** 3 / 27.0) < 1e-9
+    assert sorted(st['order']) == list(range(s ** 3))
+    tm = st['tile_mask'].cpu().tolist()
+    for i, m in enumerate(tm):
+        want = st['phase_mask'][st['order'][2 * i]] | (st['phase_mask'][st['order'][2 * i + 1]] if 2 * i + 1 < s ** 3 else 0)
+        assert m == want and m != 0
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'bf16x3'])
+@pytest.mark.parametrize('k,s,G', [(5, 5, 6), (3, 2, 9)])
+def test_sparse_forward_is_bit_identical_to_dense(mode, k, s, G):
+    B, C = 2, 64
+    Weff, _, R = _weff(C, k, s)
+    kl = 2 * R + 1
+    z = cl(rnd(B, C, G, G, G, seed=4)).to(DEV)
+    bias = rnd(C, seed=2).to(DEV).repeat(s ** 3)
+    ops.PRECISION = mode
+    try:
+        assert ops.polyphase_fwd_ok(C, C, kl, B, G)
+        got = ops.conv3_polyphase_fwd(z, Weff, C, B, G, k, s, bias, act=ops.ACT_LRELU)
+        ops.HALO_CONV = False
+        ref = ops.conv3d(z, Weff, s ** 3 * C, B, G, G, kl, -R, bias=bias, act=ops.ACT_LRELU, d2s=(s, C))
+    finally:
+        ops.PRECISION = 'fp32'
+        ops.HALO_CONV = True
+    assert got.shape == ref.shape == (B, G * s, G * s, G * s, C)
+    assert torch.equal(got, ref)

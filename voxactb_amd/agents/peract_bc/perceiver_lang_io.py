@@ -452,8 +452,11 @@ class PerceiverEngine:
         up2 = 'up0.conv_up.%d.conv3d' % (2 if s > 1 else 1)
         if s > 1:
             Weff = ops.polyphase_weights(self.p(up2 + '.weight'), self.Lt(dev), s, self.kl)
-            u0 = ops.conv3d(z1, Weff, s ** 3 * C, B, G, G, self.kl, -self.R, bias=self.p(up2 + '.bias').repeat(s ** 3),
-                            act=ops.ACT_LRELU, d2s=(s, C))
+            if ops.polyphase_fwd_ok(C, C, self.kl, B, G):
+                u0 = ops.conv3_polyphase_fwd(z1, Weff, C, B, G, k, s, self.p(up2 + '.bias').repeat(s ** 3), act=ops.ACT_LRELU)
+            else:
+                u0 = ops.conv3d(z1, Weff, s ** 3 * C, B, G, G, self.kl, -self.R, bias=self.p(up2 + '.bias').repeat(s ** 3),
+                                act=ops.ACT_LRELU, d2s=(s, C))
         else:
             Weff = None
             u0 = ops.conv3d(z1, ops.conv_weight_fwd(self.p(up2 + '.weight')), C, B, G, G, k, -(k // 2),

@@ -40,6 +40,9 @@ struct DlArgs {
     int accumulate;
     int d2s_s, d2s_G, d2s_C;
     int Cin, S_in, S_out, stride, kext, off, replicate;
+    const unsigned* tapmask; // CONV, kext^3 <= 32: bit t of tapmask[column tile] clear -> the tile's weights of tap t are all zero
+    unsigned d2s_magic;      // floor(2^32 / d2s_G) + 1 when M * d2s_G < 2^32 (exact multiply-high division), else 0
+    const int* d2s_perm;     // d2s: column block p holds fine-grid phase d2s_perm[p] (nullptr = identity)
 };
 
 __device__ __forceinline__ void dl_load16(const u16* src, u16* lds_wave_base) {
@@ -94,8 +97,14 @@ __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
     }
 
     int it_cc = 0, it_tw = 0, it_th = 0, it_td = 0;       // conv gather iterator of the NEXT k-tile to be issued
+    // block-sparse weights (polyphase up-conv: a phase only sees the low-res taps its interpolation footprint reaches):
+    // the k loop visits only the taps whose bit is set in this column tile's mask
+    unsigned it_rem = 0xffffffffu;
+    int it_kt = 0;
+    if (AMODE == DL_A_CONV && g.tapmask) it_rem = g.tapmask[tile_x];
+    const bool masked = AMODE == DL_A_CONV && g.tapmask != nullptr;
     auto issue = [&](int stage, int kt) {
-        const int k0 = kt * 32;
+        int k0 = kt * 32;
         u16* sb = smem + stage * STAGE;
         const u16* asrc[2];
         if (AMODE == DL_A_KCONTIG) {
@@ -104,6 +113,13 @@ __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
         } else {
             // k-tiles are issued in order: (tap, channel offset) advance incrementally, and the gathered voxel of a row
             // is recomputed only when the tap changes (every Cin / 32 k-tiles) -- no divisions in the loop
+            if (masked && it_cc == 0) {
+                const int tap = __builtin_ctz(it_rem);
+                it_rem &= it_rem - 1;
+                it_tw = tap % g.kext; it_th = (tap / g.kext) % g.kext; it_td = tap / (g.kext * g.kext);
+                it_kt = tap * (g.Cin >> 5);
+            }
+            if (masked) k0 = (it_kt + (it_cc >> 5)) * 32;
             if (it_cc == 0) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -125,7 +141,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
             it_cc += 32;
             if (it_cc == g.Cin) {
                 it_cc = 0;
-                if (++it_tw == g.kext) { it_tw = 0; if (++it_th == g.kext) { it_th = 0; ++it_td; } }
+                if (!masked) { if (++it_tw == g.kext) { it_tw = 0; if (++it_th == g.kext) { it_th = 0; ++it_td; } } }
             }
         }
 #pragma unroll
@@ -157,7 +173,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
         fx[t] = (lm >> 2) & 3;                  // (row >> 2) & 3: the tile bases are multiples of 32, so only lm matters
     }
 
-    const int nkt = g.K / 32;
+    const int nkt = masked ? __builtin_popcount(it_rem) * (g.Cin >> 5) : g.K / 32;
     issue(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of k-tile kt have landed in LDS
@@ -196,6 +212,54 @@ __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
 
     float* __restrict__ C = g.C;
     const float* __restrict__ R = g.residual;
+    if (g.d2s_s > 0) {
+        // depth-to-space store: offset = row part (low-res voxel of row m) + column part (phase, channel of column n);
+        // both are decoded once per row / per column tile, the row with multiply-high divisions (host-checked range)
+        const int s = g.d2s_s, G = g.d2s_G, Cc = g.d2s_C;
+        const long long Vv = (long long)G * s;
+        long long coloff[2];
+        float bsv[2];
+        bool cok[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            cok[j] = n < g.N;
+            const int nn = cok[j] ? n : 0;
+            int ph = nn / Cc;
+            const int co = nn - ph * Cc;
+            if (g.d2s_perm) ph = g.d2s_perm[ph];
+            const int rw = ph % s, rh = (ph / s) % s, rd = ph / (s * s);
+            coloff[j] = (((long long)rd * Vv + rh) * Vv + rw) * Cc + co;
+            bsv[j] = g.bias ? g.bias[nn] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= g.M) continue;
+                unsigned q1, q2, q3;
+                if (g.d2s_magic) {
+                    q1 = __umulhi((unsigned)m, g.d2s_magic); q2 = __umulhi(q1, g.d2s_magic); q3 = __umulhi(q2, g.d2s_magic);
+                } else {
+                    q1 = (unsigned)m / G; q2 = q1 / G; q3 = q2 / G;
+                }
+                const int qw = m - q1 * G, qh = q1 - q2 * G, qd = q2 - q3 * G;
+                const long long rowoff = ((((long long)q3 * Vv + qd * s) * Vv + qh * s) * Vv + qw * s) * Cc;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (!cok[j]) continue;
+                    float v = acc[i][j][r] + bsv[j];
+                    if (g.act == 1) v = v > 0.f ? v : v * g.slope;
+                    const long long off = rowoff + coloff[j];
+                    if (R) v += R[off];
+                    if (g.accumulate) v += C[off];
+                    C[off] = v;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -209,20 +273,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
                 if (m >= g.M) continue;
                 float v = acc[i][j][r] + bsv;
                 if (g.act == 1) v = v > 0.f ? v : v * g.slope;
-                long long off;
-                if (g.d2s_s > 0) {
-                    const int s = g.d2s_s, G = g.d2s_G, Cc = g.d2s_C;
-                    const int ph = n / Cc, co = n - ph * Cc;
-                    const int rw = ph % s, rh = (ph / s) % s, rd = ph / (s * s);
-                    int q = m;
-                    const int qw = q % G; q /= G;
-                    const int qh = q % G; q /= G;
-                    const int qd = q % G; q /= G;
-                    const long long Vv = (long long)G * s;
-                    off = ((((long long)q * Vv + qd * s + rd) * Vv + qh * s + rh) * Vv + qw * s + rw) * Cc + co;
-                } else {
-                    off = (long long)m * g.ldc + n;
-                }
+                const long long off = (long long)m * g.ldc + n;
                 if (R) v += R[off];
                 if (g.accumulate) v += C[off];
                 C[off] = v;
@@ -302,10 +353,13 @@ extern "C" int vxb_gemm_dl_f32(const void* A_planes, const void* Bw_planes, int 
 // Implicit-GEMM conv3d twin of vxb_conv3d_bf16w/bf16x3_f32 for ONE source whose activations were pre-split:
 // src_planes [nplanes][B, S_in^3, Cin] bf16; weights [nplanes][N][K = kext^3 * Cin]; Cin % 32 == 0.
 // zeros: >= 16 bytes of zeros in device memory (fetched for zero-padded taps).
+// tapmask (optional, kext^3 <= 32): one word per 128-column tile, bit t set <=> tap t has non-zero weights in that tile
+// (never all-zero); the other taps are skipped.  d2s_perm (optional, d2s_C == 64): column block p of the weights / output
+// is phase d2s_perm[p] of the fine grid -- lets the host pair phases with the same tap footprint in one column tile.
 extern "C" int vxb_conv3d_dl_f32(const void* src_planes, int Cin, int B, int S_in, int S_out, int stride, int kext, int off,
                                  int replicate, const void* wt_planes, int nplanes, int N, const float* bias, float* out,
                                  int64_t ldc, int act, float slope, int accumulate, int d2s_s, int d2s_C, const void* zeros,
-                                 vxb_stream_t stream) {
+                                 const uint32_t* tapmask, const int32_t* d2s_perm, vxb_stream_t stream) {
     if (!src_planes || !wt_planes || !out || !zeros || B < 1 || S_in < 1 || S_out < 1 || kext < 1 || stride < 1 || N < 1) return VXB_EARG;
     if ((nplanes != 1 && nplanes != 2) || (Cin & 31) || Cin < 32) return VXB_ESIZE;
     if (!dl_al16(src_planes) || !dl_al16(wt_planes) || !dl_al16(zeros)) return VXB_ESIZE;
@@ -313,11 +367,15 @@ extern "C" int vxb_conv3d_dl_f32(const void* src_planes, int Cin, int B, int S_i
     const long long K = (long long)kext * kext * kext * Cin;
     if (M >= INT32_MAX || K >= INT32_MAX) return VXB_ESIZE;
     if (d2s_s > 0 && (d2s_C < 1 || N % d2s_C)) return VXB_EARG;
+    if (tapmask && kext * kext * kext > 32) return VXB_ESIZE;
+    if (d2s_perm && (d2s_s <= 0 || d2s_C != 64)) return VXB_EARG;      // a permuted phase must not straddle column tiles
     DlArgs g = {};
+    g.tapmask = tapmask; g.d2s_perm = d2s_perm;
     g.A = (const u16*)src_planes; g.a_plane = (long long)B * S_in * S_in * S_in * Cin;
     g.Bw = (const u16*)wt_planes; g.b_plane = (long long)N * K; g.zeros = (const u16*)zeros;
     g.C = out; g.bias = bias; g.M = (int)M; g.N = N; g.K = (int)K; g.ldc = ldc; g.act = act; g.slope = slope;
     g.accumulate = accumulate; g.d2s_s = d2s_s; g.d2s_G = S_out; g.d2s_C = d2s_C;
+    g.d2s_magic = (d2s_s > 0 && S_out > 1 && M * S_out < (1ll << 32)) ? (unsigned)((1ull << 32) / (unsigned)S_out) + 1u : 0u;
     g.Cin = Cin; g.S_in = S_in; g.S_out = S_out; g.stride = stride; g.kext = kext; g.off = off; g.replicate = replicate;
     return dl_launch<DL_A_CONV>(g, nplanes == 2, (hipStream_t)stream);
 }

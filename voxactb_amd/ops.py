@@ -330,6 +330,91 @@ def polyphase_dgrad_weights_lowres(Weff, Ci, Co, s, kl):
     return w.permute(0, 1, 2, 4, 5, 6, 7, 3).reshape(kl ** 3 * s ** 3 * Co, Ci).contiguous()
 
 
+_POLY = {}
+
+
+def polyphase_structure(k, s, dev):
+    """Zero structure of the polyphase weights (network_utils.py:245-250): along one axis fine phase r only reaches the
+    low-res offsets j with L[r][:, j] != 0 (k = s = 5: r = 0 -> {-1, 0}, r = 1..3 -> {-1, 0, 1}, r = 4 -> {0, 1}), so only
+    17.6 of the 27 (tap, phase) weight blocks are non-zero on average.  Returns
+      phase_mask [s^3] int : bit (jd*kl + jh)*kl + jw set <=> phase (rd, rh, rw) has weights at that low-res tap
+      perm [s^3] int32     : column-block order that pairs phases with (nearly) the same footprint in one 128-column tile
+      tile_mask int32      : union of the two phase masks per 128-column tile of that order
+      frac                 : non-zero fraction of the kl^3 * s^3 blocks (the algorithmic flops of the polyphase form)."""
+    key = (k, s, str(dev))
+    st = _POLY.get(key)
+    if st is not None:
+        return st
+    L, R = polyphase_tables(k, s)
+    kl = 2 * R + 1
+    reach = (L != 0).any(axis=1)                                   # [s][kl]
+    nph = s ** 3
+    pm = []
+    for ph in range(nph):
+        rd, rh, rw = ph // (s * s), (ph // s) % s, ph % s
+        m = 0
+        for jd in range(kl):
+            for jh in range(kl):
+                for jw in range(kl):
+                    if reach[rd, jd] and reach[rh, jh] and reach[rw, jw]:
+                        m |= 1 << ((jd * kl + jh) * kl + jw)
+        pm.append(m)
+    # pair equal footprints first, then the left-overs greedily by the size of the union
+    groups = {}
+    for ph, m in enumerate(pm):
+        groups.setdefault(m, []).append(ph)
+    order, left = [], []
+    for m in sorted(groups):
+        l = list(groups[m])
+        while len(l) >= 2:
+            order += [l.pop(0), l.pop(0)]
+        left += l
+    pc = lambda x: bin(x).count('1')
+    while len(left) >= 2:
+        a = left.pop(0)
+        b = min(left, key=lambda c: 2 * pc(pm[a] | pm[c]) - pc(pm[a]) - pc(pm[c]))
+        left.remove(b)
+        order += [a, b]
+    order += left
+    tm = [pm[order[i]] | (pm[order[i + 1]] if i + 1 < nph else 0) for i in range(0, nph, 2)]
+    st = dict(kl=kl, R=R, phase_mask=pm, order=order,
+              perm=torch.tensor(order, dtype=torch.int32, device=dev), perm_long=torch.tensor(order, dtype=torch.int64, device=dev),
+              tile_mask=torch.tensor(tm, dtype=torch.int32, device=dev),
+              frac=sum(pc(m) for m in pm) / float(nph * kl ** 3), tile_frac=sum(pc(m) for m in tm) * 2 / float(2 * len(tm) * kl ** 3))
+    _POLY[key] = st
+    return st
+
+
+POLY_SPARSE = True       # skip the structurally zero (tap, phase) blocks of the polyphase up-conv
+
+
+def polyphase_fwd_ok(C, Cout, kl, B, G):
+    return (POLY_SPARSE and DL_GEMM and _mm() and C % 32 == 0 and Cout == 64 and kl ** 3 <= 32 and B * G ** 3 >= 128)
+
+
+def conv3_polyphase_fwd(z, Weff, Cout, B, G, k, s, bias, act=ACT_NONE, label=None):
+    """upsample(x s, trilinear) -> conv(k, replicate) as the low-res kl^3 conv with s^3 * Cout phase columns and a
+    depth-to-space store (conv3d(z, Weff, ..., d2s=(s, Cout))), visiting only the non-zero (tap, phase) weight blocks:
+    direct-to-LDS implicit GEMM with a tap mask per 128-column tile.  Bit-identical to the dense evaluation (the skipped
+    products are exact zeros)."""
+    C = z.shape[-1]
+    st = polyphase_structure(k, s, z.device)
+    kl, R = st['kl'], st['R']
+    N, K = s ** 3 * Cout, kl ** 3 * C
+    npl = 2 if PRECISION == 'bf16x3' else 1
+    lbl = label or 'conv3_polyphase[k%d s%d %d->%d G%d]' % (k, s, C, Cout, G)
+    _lib.set_meta(lbl, 0.0)
+    wt = Weff.t().view(s ** 3, Cout, K).index_select(0, st['perm_long']).view(N, K)      # [(phase in tile order, co)][K]
+    wb = split_planes(wt, npl)
+    _lib.set_meta(lbl, 0.0)
+    planes = split_planes(z.reshape(-1, C), npl)
+    out = torch.empty((B, G * s, G * s, G * s, Cout), dtype=torch.float32, device=z.device)
+    _lib.set_meta(lbl, 2.0 * B * G ** 3 * N * kl ** 3 * C * st['frac'])
+    call('vxb_conv3d_dl_f32', planes, C, B, G, G, 1, kl, -R, 1, wb, npl, N, bias, out, N, act, LRELU_SLOPE, 0, s, Cout,
+         _zeros16(z.device), st['tile_mask'], st['perm'])
+    return out
+
+
 HALO_WD = True       # halo conv: B fragments straight from global memory (pre-shuffled weights), no barrier in the tap loop
 
 
@@ -587,7 +672,7 @@ def conv3d_bf16w(src0, wb, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
         planes = split_planes(src0.view(-1, C0), npl)
         _lib.set_meta(lbl, 2.0 * B * S_out ** 3 * N * kext ** 3 * C0)
         call('vxb_conv3d_dl_f32', planes, C0, B, S_in, S_out, stride, kext, off, int(replicate), wb, npl, N, bias, out,
-             ldc if ldc is not None else N, act, LRELU_SLOPE, int(accumulate), d2s[0], d2s[1], _zeros16(src0.device))
+             ldc if ldc is not None else N, act, LRELU_SLOPE, int(accumulate), d2s[0], d2s[1], _zeros16(src0.device), None, None)
         return out
     call('vxb_conv3d_bf16x3_f32' if x3 else 'vxb_conv3d_bf16w_f32', src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, int(replicate), wb, N, bias, out,
          ldc if ldc is not None else N, act, LRELU_SLOPE, int(accumulate), d2s[0], d2s[1])
