@@ -129,12 +129,19 @@ int vxb_conv3d_dl_f32(const void* src_planes, int Cin, int B, int S_in, int S_ou
  * takes the hi/lo weight planes [2][N][K] of the bf16x3 split.
  * s2d_s > 0: src0 is a fine grid [B, (S_in*s2d_s)^3, s2d_C] read by space-to-depth (input channel = (phase, co)) -- the
  * data gradient of the polyphase up-conv.  d2s_s > 0: depth-to-space output, 64 channels per phase (its forward). */
+/* taptab / ncls / tap_total (optional; s2d input + wfrag only): block-sparse weights of the polyphase up-conv's data
+ * gradient.  taptab = ncls footprint classes x 32 ints (entries 0..26: LDS offset, in bf16 units, of the n-th listed tap =
+ * ((td*10 + th)*12 + tw)*40; entry 31: list length, a multiple of 3, padded with zero-weight taps) followed by
+ * (class, number of taps listed before the phase's first chunk) for each of the s2d_s^3 phases; wfrag then holds only
+ * the listed taps, [column block][tap_total][...]. */
 int vxb_conv3_halo_bf16w_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                              int off, int replicate, const void* wt_bf16, int N, const float* bias, float* out,
-                             int act, float slope, int s2d_s, int s2d_C, int d2s_s, const void* wfrag, vxb_stream_t stream);
+                             int act, float slope, int s2d_s, int s2d_C, int d2s_s, const void* wfrag, const int32_t* taptab,
+                              int ncls, int tap_total, vxb_stream_t stream);
 int vxb_conv3_halo_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                               int off, int replicate, const void* wt_bf16, int N, const float* bias, float* out,
-                              int act, float slope, int s2d_s, int s2d_C, int d2s_s, const void* wfrag, vxb_stream_t stream);
+                              int act, float slope, int s2d_s, int s2d_C, int d2s_s, const void* wfrag, const int32_t* taptab,
+                              int ncls, int tap_total, vxb_stream_t stream);
 /* wfrag (optional, NULL = weights staged through LDS per tap): the same weights pre-shuffled into MFMA fragment order,
  * [N/64][chunk][tap][column tile 2][k half or plane 2][lane 64][8 bf16] with chunk = 32 channels ('bf16') or 16 ('bf16x3');
  * the kernel then loads its B fragments straight from global memory and the 27-tap loop has no barrier.
@@ -146,13 +153,18 @@ int vxb_conv3_dgrad_fold_f32(const float* dy, int C0, int B, int S, const void* 
                              float* dst1, const float* y0, const float* y1, int acc0, int acc1, float slope,
                              const void* wfrag, vxb_stream_t stream);
 /* LDS-halo weight gradient of the same 3x3x3 stride-1 convs (contract of vxb_conv3d_wgrad_f32 with kext = 3, stride = 1;
- * the z slices of part[z][K][N] are runs of 2x8x8 voxel tiles).  C0, C1 % 16 == 0, N % 64 == 0; d2s needs d2s_C == 64. */
+ * the z slices of part[z][K][N] are runs of 128-voxel tiles, 2x8x8 or 4x4x8 -- chosen by the voxels wasted on the
+ * edge of an S_out^3 grid; vxb_conv3_wgrad_halo_tiles returns their number).  C0, C1 % 16 == 0, N % 64 == 0; d2s needs
+ * d2s_C == 64.  phase_mask (optional, d2s only: the polyphase up-conv, network_utils.py:245-250): one word per 64-column
+ * block (= fine-grid phase), bit t set <=> weight block (tap t, phase) is not structurally zero; the other blocks are
+ * neither computed nor stored (the caller zero-fills `part`). */
 int vxb_conv3_wgrad_halo_bf16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                                   int off, int replicate, const float* dy, int N, int64_t ldy, int d2s_s, int d2s_C,
-                                  float* part, int nsplit, vxb_stream_t stream);
+                                  float* part, int nsplit, const uint32_t* phase_mask, vxb_stream_t stream);
 int vxb_conv3_wgrad_halo_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                                     int off, int replicate, const float* dy, int N, int64_t ldy, int d2s_s, int d2s_C,
-                                    float* part, int nsplit, vxb_stream_t stream);
+                                    float* part, int nsplit, const uint32_t* phase_mask, vxb_stream_t stream);
+size_t vxb_conv3_wgrad_halo_tiles(int B, int S_out, int x3);
 /* bf16 matrix-core weight gradient (same contract as vxb_conv3d_wgrad_f32): both operands are staged position-major and
  * transposed for the matrix cores by ds_read_b64_tr_b16. */
 int vxb_conv3d_wgrad_bf16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,

@@ -56,3 +56,52 @@ def test_sparse_forward_is_bit_identical_to_dense(mode, k, s, G):
         ops.HALO_CONV = True
     assert got.shape == ref.shape == (B, G * s, G * s, G * s, C)
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'bf16x3'])
+def test_sparse_weight_gradient_matches_dense_on_the_nonzero_blocks(mode):
+    """the masked LDS-halo weight gradient returns the dense result on every structurally non-zero (tap, phase) block
+    (same tiles, same order: bit-identical) and zeros elsewhere -- which is all polyphase_weights_bwd reads."""
+    B, C, k, s, G = 1, 64, 5, 5, 16          # (the LDS-halo kernel takes grids of 16^3 and up)
+    st = ops.polyphase_structure(k, s, DEV)
+    kl, R = st['kl'], st['R']
+    z = cl(rnd(B, C, G, G, G, seed=4)).to(DEV)
+    dy = cl(rnd(B, C, G * s, G * s, G * s, seed=6)).to(DEV)
+    dense = ops.conv3d_wgrad(z, dy, s ** 3 * C, B, G, G, kl, -R, d2s=(s, C), force_bf16=mode, nsplit=2)
+    got = ops.conv3d_wgrad(z, dy, s ** 3 * C, B, G, G, kl, -R, d2s=(s, C), force_bf16=mode, nsplit=2,
+                           phase_mask=st['phase_mask_t'], flops_frac=st['frac'])
+    keep = torch.tensor([[(m >> t) & 1 for m in st['phase_mask']] for t in range(kl ** 3)], dtype=torch.bool, device=DEV)
+    keep = keep[:, None, :, None].expand(kl ** 3, C, s ** 3, C).reshape(kl ** 3 * C, s ** 3 * C)
+    assert torch.equal(got[keep], dense[keep])
+    assert float(got[~keep].abs().max()) == 0.0
+    # and through the adjoint of the weight construction: identical parameter gradients
+    Lh, _ = ops.polyphase_tables(k, s)
+    Lt = torch.from_numpy(Lh).to(DEV)
+    dW0 = torch.zeros(C, C, k, k, k, device=DEV)
+    dW1 = torch.zeros(C, C, k, k, k, device=DEV)
+    ops.polyphase_weights_bwd(dense, Lt, dW0, s, kl)
+    ops.polyphase_weights_bwd(got, Lt, dW1, s, kl)
+    assert float((dW0 - dW1).abs().max()) <= 1e-6 * float(dW0.abs().max())
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'bf16x3'])
+def test_sparse_data_gradient_is_bit_identical_to_dense(mode):
+    """space-to-depth LDS-halo conv with per-phase tap lists (only the non-zero blocks of the flipped weights, lists
+    padded to a multiple of three with zero-weight taps) against the same kernel visiting all 27 taps."""
+    B, C, k, s, G = 2, 64, 5, 5, 6
+    Weff, _, R = _weff(C, k, s)
+    kl = 2 * R + 1
+    du = cl(rnd(B, C, G * s, G * s, G * s, seed=3)).to(DEV)
+    Sp = G + 2 * R
+    ops.PRECISION = mode
+    try:
+        wd = ops.polyphase_dgrad_weights_lowres(Weff, C, C, s, kl)
+        assert ops.s2d_halo_ok(kl, C, C)
+        dense = ops.conv3_s2d(du, wd, C, B, G, Sp, -(kl - 1), s, C)
+        got = ops.conv3_s2d(du, wd, C, B, G, Sp, -(kl - 1), s, C, poly_k=k)
+    finally:
+        ops.PRECISION = 'fp32'
+    assert torch.equal(got, dense)
+    tt, ncls, total, rows = ops.s2d_taptab(k, s, DEV, 16, 4)
+    assert ncls == 27 and total == rows.numel() and total % 3 == 0
+    assert total == 4 * (8 * 9 + 36 * 12 + 54 * 18 + 27 * 27)          # 8-tap lists padded to 9

@@ -562,13 +562,15 @@ class PerceiverEngine:
         dz1 = E(B, G, G, G, C)
         if s > 1:
             kl, R = self.kl, self.R
-            dWeff = ops.conv3d_wgrad(z1, du0, s ** 3 * C, B, G, G, kl, -R, d2s=(s, C))
+            pst = ops.polyphase_structure(k, s, dev) if ops.POLY_SPARSE else None
+            dWeff = ops.conv3d_wgrad(z1, du0, s ** 3 * C, B, G, G, kl, -R, d2s=(s, C),
+                                     phase_mask=pst['phase_mask_t'] if pst else None, flops_frac=pst['frac'] if pst else 1.0)
             ops.polyphase_weights_bwd(dWeff, self.Lt(dev), self.g(up2 + '.weight'), s, kl)
             Sp = G + 2 * R
             if ops.s2d_halo_ok(kl, C, C):
                 # same gradient as a 3^3 conv over the low-res grid reading the fine dY by space-to-depth (LDS-halo kernel)
                 wd = ops.polyphase_dgrad_weights_lowres(c['Weff'], C, C, s, kl)
-                dzp = ops.conv3_s2d(du0, wd, C, B, G, Sp, -(kl - 1), s, C)
+                dzp = ops.conv3_s2d(du0, wd, C, B, G, Sp, -(kl - 1), s, C, poly_k=k)
             else:
                 wd = ops.polyphase_dgrad_weights(c['Weff'], C, C, s, kl)
                 dzp = ops.conv3d(du0, wd, C, B, V, Sp, s * kl, -s * (kl - 1), stride=s, replicate=False)

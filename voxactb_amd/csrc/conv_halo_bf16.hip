@@ -51,6 +51,13 @@ struct HaloArgs {
     // fold mode (fold_pad > 0): the conv is a data gradient on the padded domain S_out = fold_S + 2 fold_pad; instead of
     // storing it, column block nb adds the replicate-padding adjoint into fold_dst[nb] [B, fold_S^3, 64]
     const u16* wfrag;        // WD kernels: weights pre-shuffled into fragment order (ops.halo_wfrag)
+    // TL kernels (space-to-depth input with block-sparse weights, the polyphase up-conv's data gradient): every phase of
+    // the fine grid belongs to a footprint class with its own list of non-zero taps; wfrag then holds only those taps
+    // ([column block][tap_total][...], a chunk's taps consecutive).  taptab = ncls lists of 32 ints (entries 0..26: LDS
+    // offset of the n-th listed tap, entry 31: list length, a multiple of 3 -- padded with zero-weight taps) followed by
+    // (class, taps listed before this phase's first chunk) per phase.
+    const int* taptab;
+    int ncls, nphase, tap_total;
     int fold_pad, fold_S;
     float* fold_dst[2];
     const float* fold_y[2];  // != nullptr: multiply by LeakyReLU'(y) (the producer's activation)
@@ -69,8 +76,9 @@ __device__ __forceinline__ unsigned hb_pack2(float lo, float hi) {
     return (a >> 16) | (b & 0xffff0000u);
 }
 
-template <int NT, int X3, int NW, int WD>     // NT = N / 32 column tiles per wave; NW waves share the 8 M tiles (4 -> 2 each,
-                                              // 8 -> 1 each); WD: B fragments straight from global (pre-shuffled weights)
+template <int NT, int X3, int NW, int WD, int TL = 0>   // NT = N / 32 column tiles per wave; NW waves share the 8 M tiles (4 -> 2
+                                              // each, 8 -> 1 each); WD: B fragments straight from global (pre-shuffled
+                                              // weights); TL: per-chunk tap lists (block-sparse weights, WD only)
 __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
     constexpr int NTH = NW * 64, MTW = 8 / NW;
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
@@ -218,10 +226,44 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
     // inside the 27-tap loop.
     bf16x8 bq0[NT][2], bq1[NT][2], bq2[NT][2];
     const int nchunk = Ct / CPC;
+    int tapbase = 0, ntap = 27, taplist = 0;      // TL: first row of this chunk in wfrag, its tap count, lane n = n-th tap's LDS offset
+    const long long wf_rows = TL ? g.tap_total : (long long)nchunk * 27;
 #define HD_LOADB(BQ, tap_)                                                                                           \
     _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                    \
     _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                     \
-        BQ[j][f] = *reinterpret_cast<const bf16x8*>(g.wfrag + ((((long long)(n0 / N) * nchunk + ch) * 27 + (tap_)) * (NT * 2) + j * 2 + f) * 512 + lane * 8);
+        BQ[j][f] = *reinterpret_cast<const bf16x8*>(g.wfrag + (((long long)(n0 / N) * wf_rows + (TL ? tapbase : ch * 27) + (tap_)) * (NT * 2) + j * 2 + f) * 512 + lane * 8);
+#define HB_READ_A_OFF(AF, off_)                                                                                      \
+    {                                                                                                                \
+        const int toff_ = (off_);                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i) {                                                             \
+            AF[i][0] = *reinterpret_cast<const bf16x8*>(&halo[abase[i] + toff_]);                                    \
+            AF[i][1] = *reinterpret_cast<const bf16x8*>(&halo[abase[i] + toff_ + 16]);                               \
+        }                                                                                                            \
+    }
+    // TL tap n of the chunk's list: same pipeline as HD_TAP, with the list position instead of the tap number
+#define HT_TAP(n_, BC, BL, AC, AN)                                                                                   \
+    {                                                                                                                \
+        const int ln_ = (n_);                                                                                        \
+        if (ln_ + 2 < ntap) { HD_LOADB(BL, ln_ + 2) }                                                                \
+        if (ln_ + 1 < ntap) { HB_READ_A_OFF(AN, __builtin_amdgcn_readlane(taplist, ln_ + 1)) }                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                               \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][1], BC[j][X3 ? 0 : 1], acc[i][j], 0, 0, 0);    \
+        if (X3) {                                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                           \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][0], BC[j][1], acc[i][j], 0, 0, 0);         \
+        }                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                               \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][0], BC[j][0], acc[i][j], 0, 0, 0);             \
+    }
+    int* ttab = reinterpret_cast<int*>(wsm);        // TL: the tap table lives in the (otherwise unused) weight buffers
+    if (TL) {
+        for (int i = tid; i < g.ncls * 32 + g.nphase * 2; i += NTH) ttab[i] = g.taptab[i];
+        __syncthreads();
+    }
 #define HD_TAP(tap_, BC, BL, AC, AN)                                                                                 \
     {                                                                                                                \
         const int tap = (tap_);                                                                                      \
@@ -252,6 +294,14 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
             c0 = cb - ph * g.s2d_C;
             Cs = g.s2d_C;
             vbase += ((long long)(ph / (sm * sm)) * Vin + (ph / sm) % sm) * Vin + ph % sm;
+        }
+        if (TL) {
+            const int ph = cb / g.s2d_C;
+            const int cls = __builtin_amdgcn_readfirstlane(ttab[g.ncls * 32 + 2 * ph]);
+            const int pre = __builtin_amdgcn_readfirstlane(ttab[g.ncls * 32 + 2 * ph + 1]);
+            taplist = ttab[cls * 32 + (lane & 31)];
+            ntap = __builtin_amdgcn_readlane(taplist, 31);
+            tapbase = pre + (ch - ph * (g.s2d_C / CPC)) * ntap;
         }
         // ---- fetch the halo of this chunk (all loads in flight together), then convert + store
         float4 hv[NLD];
@@ -286,6 +336,25 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
         }
         if (!WD) { HB_STORE_W(rw0, 0) }
         __syncthreads();
+        if (TL) {
+            HB_READ_A_OFF(afa, __builtin_amdgcn_readlane(taplist, 0))
+            int n = 0;
+#pragma unroll 1
+            for (; n + 6 <= ntap; n += 6) {
+                HT_TAP(n, bq0, bq2, afa, afb)
+                HT_TAP(n + 1, bq1, bq0, afb, afa)
+                HT_TAP(n + 2, bq2, bq1, afa, afb)
+                HT_TAP(n + 3, bq0, bq2, afb, afa)
+                HT_TAP(n + 4, bq1, bq0, afa, afb)
+                HT_TAP(n + 5, bq2, bq1, afb, afa)
+            }
+            if (n < ntap) {          // list lengths are multiples of 3
+                HT_TAP(n, bq0, bq2, afa, afb)
+                HT_TAP(n + 1, bq1, bq0, afb, afa)
+                HT_TAP(n + 2, bq2, bq1, afa, afb)
+            }
+            continue;
+        }
         HB_READ_A(afa, 0)
         if (!WD) {
             for (int tp = 0; tp < 26; tp += 2) {
@@ -397,27 +466,31 @@ inline bool hb_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 int g_halo_waves = 4;        // experiment knob (vxb_debug_set_halo_waves): 4 waves x 2 M tiles or 8 waves x 1 M tile per workgroup
 
-template <int NT, int X3, int NW, int WD>
+template <int NT, int X3, int NW, int WD, int TL = 0>
 int hb_launch(const HaloArgs& g, long long nblk, hipStream_t st) {
     // (the fold epilogue re-uses the buffer as an fp32 [256][64] tile: keep the full size in every variant)
     const size_t lds = (size_t)(HALO_SLOTS * SP + 2 * NT * 32 * LDW) * sizeof(u16);
-    if (hipFuncSetAttribute((const void*)conv3_halo_kernel<NT, X3, NW, WD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (TL && (size_t)(g.ncls * 32 + g.nphase * 2) * sizeof(int) > (size_t)2 * NT * 32 * LDW * sizeof(u16)) return VXB_ESIZE;
+    if (hipFuncSetAttribute((const void*)conv3_halo_kernel<NT, X3, NW, WD, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VXB_ELAUNCH;
-    hipLaunchKernelGGL((conv3_halo_kernel<NT, X3, NW, WD>), dim3((unsigned)(nblk * (g.N / (NT * 32)))), dim3(NW * 64), lds, st, g);
+    hipLaunchKernelGGL((conv3_halo_kernel<NT, X3, NW, WD, TL>), dim3((unsigned)(nblk * (g.N / (NT * 32)))), dim3(NW * 64), lds, st, g);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
 
 int hb_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out, int off, int replicate,
             const void* wt_bf16, int N, const float* bias, float* out, int act, float slope, int s2d_s, int s2d_C,
-            int d2s_s, vxb_stream_t stream, const HaloArgs* fold = nullptr, const void* wfrag = nullptr) {
+            int d2s_s, vxb_stream_t stream, const HaloArgs* fold = nullptr, const void* wfrag = nullptr,
+            const int32_t* taptab = nullptr, int ncls = 0, int nphase = 0, int tap_total = 0) {
     if (!src0 || !wt_bf16 || (!out && !fold) || B < 1 || S_in < 1 || S_out < 1) return VXB_EARG;
     if ((C0 & 31) || (C1 & 31) || C0 < 32 || (C1 > 0 && !src1) || N < 64 || (N & 63)) return VXB_ESIZE;
     if (!hb_aligned16(src0) || !hb_aligned16(wt_bf16) || (src1 && !hb_aligned16(src1))) return VXB_ESIZE;
     if (s2d_s > 0 && (C1 != 0 || s2d_C < 32 || (s2d_C & 31) || C0 != s2d_s * s2d_s * s2d_s * s2d_C)) return VXB_EARG;
     const long long Vin = (long long)S_in * (s2d_s > 0 ? s2d_s : 1);
     if (Vin * Vin * Vin >= INT32_MAX) return VXB_ESIZE;
+    if (taptab && (!wfrag || s2d_s <= 0 || fold || ncls < 1 || tap_total < 3 || nphase != s2d_s * s2d_s * s2d_s)) return VXB_EARG;
     HaloArgs g;
+    g.taptab = taptab; g.ncls = ncls; g.nphase = nphase; g.tap_total = tap_total;
     g.s2d_s = s2d_s; g.s2d_C = s2d_C; g.d2s_s = d2s_s; g.wfrag = (const u16*)wfrag;
     g.fold_pad = 0; g.fold_S = 0; g.fold_dst[0] = g.fold_dst[1] = nullptr; g.fold_y[0] = g.fold_y[1] = nullptr;
     g.fold_acc[0] = g.fold_acc[1] = 0;
@@ -434,6 +507,7 @@ int hb_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B,
     hipStream_t st = (hipStream_t)stream;
     // 64 output channels per workgroup (162-225 VGPRs -> two workgroups per CU); N = 128 runs two column blocks that each
     // stage the halo -- cheaper than the register spills of a 128-wide accumulator tile.
+    if (g.taptab) return x3 ? hb_launch<2, 1, 4, 1, 1>(g, nblk, st) : hb_launch<2, 0, 4, 1, 1>(g, nblk, st);
     if (g.wfrag) return x3 ? hb_launch<2, 1, 4, 1>(g, nblk, st) : hb_launch<2, 0, 4, 1>(g, nblk, st);
     if (g_halo_waves == 8) return x3 ? hb_launch<2, 1, 8, 0>(g, nblk, st) : hb_launch<2, 0, 8, 0>(g, nblk, st);
     return x3 ? hb_launch<2, 1, 4, 0>(g, nblk, st) : hb_launch<2, 0, 4, 0>(g, nblk, st);
@@ -446,21 +520,24 @@ extern "C" void vxb_debug_set_halo_waves(int nw) { g_halo_waves = nw == 8 ? 8 : 
 // 3x3x3, stride-1 twin of vxb_conv3d_bf16w_f32 (same weights layout bf16 [N][27*(C0+C1)], same padding semantics:
 // src voxel = out + tap + off per axis); C0, C1 multiples of 32, N a multiple of 64.  out [B, S_out^3, N] is overwritten.
 // s2d_s > 0: src0 is a fine grid [B, (S_in*s2d_s)^3, s2d_C] read by space-to-depth (input channel = (phase, co), C0 =
-// s^3 * s2d_C) -- the data gradient of the polyphase up-conv.  d2s_s > 0: depth-to-space output with 64 channels per
+// s^3 * s2d_C) -- the data gradient of the polyphase up-conv.  With taptab (s2d + wfrag only) the weights are block-sparse:
+// see HaloArgs::taptab; wfrag then lists only the non-zero taps of every chunk (ops.halo_wfrag_sparse).  d2s_s > 0: depth-to-space output with 64 channels per
 // phase (N = d2s_s^3 * 64), out = fine grid [B, (S_out*d2s_s)^3, 64] -- the polyphase up-conv forward.
 extern "C" int vxb_conv3_halo_bf16w_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                                         int off, int replicate, const void* wt_bf16, int N, const float* bias, float* out,
-                                        int act, float slope, int s2d_s, int s2d_C, int d2s_s, const void* wfrag, vxb_stream_t stream) {
+                                        int act, float slope, int s2d_s, int s2d_C, int d2s_s, const void* wfrag, const int32_t* taptab,
+                                         int ncls, int tap_total, vxb_stream_t stream) {
     return hb_impl(0, src0, src1, C0, C1, B, S_in, S_out, off, replicate, wt_bf16, N, bias, out, act, slope, s2d_s, s2d_C, d2s_s,
-                   stream, nullptr, wfrag);
+                   stream, nullptr, wfrag, taptab, ncls, s2d_s * s2d_s * s2d_s, tap_total);
 }
 
 // 'bf16x3' twin (weights = planes [2][N][K], see vxb_conv3d_bf16x3_f32).
 extern "C" int vxb_conv3_halo_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                                          int off, int replicate, const void* wt_bf16, int N, const float* bias, float* out,
-                                         int act, float slope, int s2d_s, int s2d_C, int d2s_s, const void* wfrag, vxb_stream_t stream) {
+                                         int act, float slope, int s2d_s, int s2d_C, int d2s_s, const void* wfrag, const int32_t* taptab,
+                                         int ncls, int tap_total, vxb_stream_t stream) {
     return hb_impl(1, src0, src1, C0, C1, B, S_in, S_out, off, replicate, wt_bf16, N, bias, out, act, slope, s2d_s, s2d_C, d2s_s,
-                   stream, nullptr, wfrag);
+                   stream, nullptr, wfrag, taptab, ncls, s2d_s * s2d_s * s2d_s, tap_total);
 }
 
 // Data gradient of a 3x3x3 replicate-padded conv fused with the adjoint of its padding (vxb_conv3_halo_* followed by

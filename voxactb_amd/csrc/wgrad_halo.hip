@@ -25,14 +25,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
-constexpr int WTD = 2, WTH = 8, WTW = 8;              // voxel tile
-constexpr int XH = WTH + 2, XW = WTW + 2;             // halo h, w extents (10, 10); d extent WTD + 2 = 4
-constexpr int XSLOTS = (WTD + 2) * XH * XW;           // 400
-constexpr int XPL = XSLOTS * 16;                      // u16 per x plane
+// voxel tile WTD x WTH x 8 = 128 voxels: 2x8x8 or 4x4x8 (the host picks the one that wastes fewer voxels on the grid edge:
+// S = 100 -> 100x100x104 instead of 100x104x104, S = 20 -> 20x20x24 instead of 20x24x24)
+constexpr int WTW = 8, XW = WTW + 2;
 constexpr int DLD = 80;                               // u16 per dY row (64 + 16 pad): 40 dwords, 8 rows -> 8 bank octets
-constexpr int DPL = WTD * WTH * WTW * DLD;            // u16 per dY plane
-constexpr int NXL = (XSLOTS * 4 + 255) / 256;         // 7 float4 x loads per thread per tile
-constexpr int NDL = WTD * WTH * WTW * 16 / 256;       // 8 float4 dY loads per thread per tile
+constexpr int DPL = 128 * DLD;                        // u16 per dY plane
+constexpr int NDL = 128 * 16 / 256;                   // 8 float4 dY loads per thread per tile
 
 struct WhArgs {
     const float* src0;
@@ -46,6 +44,8 @@ struct WhArgs {
     int ntd, nth, ntw;
     long long ntiles;
     int tiles_per_split;
+    const unsigned* phase_mask;   // d2s: bit t of phase_mask[column block] clear -> that (tap, phase) weight block is
+                                  // structurally zero (polyphase up-conv) and is neither computed nor stored
 };
 
 __device__ __forceinline__ unsigned wh_pack2(float lo, float hi) { return vxb_pack_bf16(lo, hi); }
@@ -57,8 +57,13 @@ __device__ __forceinline__ bf16x8 wh_frag(const u16* p0, const u16* p1) {
     return u.v;
 }
 
-template <int X3>
+template <int X3, int WTD, int WTH>
 __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
+    constexpr int XH = WTH + 2;                           // halo h extent; d extent WTD + 2, w extent 10
+    constexpr int XSLOTS = (WTD + 2) * XH * XW;           // 400 / 360
+    constexpr int XPL = XSLOTS * 16;                      // u16 per x plane
+    constexpr int NXL = (XSLOTS * 4 + 255) / 256;         // 7 / 6 float4 x loads per thread per tile
+    constexpr int HB = WTH / 4;                           // k-steps (4 h-rows x 8 w) per d-plane
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* xs = smem;                                   // [1 + X3][XSLOTS][16]
     u16* ds = smem + (1 + X3) * XPL;                  // [1 + X3][128][DLD]
@@ -134,7 +139,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
         for (int i = 0; i < NDL; ++i) {
             const int e = tid + 256 * i;
             const int pos = e >> 4, n4 = (e & 15) * 4;
-            const int od = d0 + (pos >> 6), oh = h0 + ((pos >> 3) & 7), ow = w0 + (pos & 7);
+            const int od = d0 + pos / (WTH * 8), oh = h0 + ((pos >> 3) % WTH), ow = w0 + (pos & 7);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (od < S && oh < S && ow < S) {
                 if (g.d2s_s > 0) {
@@ -184,10 +189,20 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
     const int q = lane >> 4, tl = lane & 15;
     const int fh = 2 * (q >> 1), fw = 4 * (q & 1) + (tl >> 2), fc = 4 * (tl & 3);
 
+    // this wave's taps: the (wid + 4 ti)-th ACTIVE tap of the column block (all 27, or the phase's footprint); slots past
+    // the end repeat the last active tap and are never stored
+    const unsigned tmask = (g.phase_mask && g.d2s_s > 0) ? (g.phase_mask[by] & 0x7ffffffu) : 0x7ffffffu;
+    const int nact = __builtin_popcount(tmask);
+    const int nti = (nact + 3) >> 2;     // tap slots every wave runs (workgroup-uniform)
     int toffs[7];                        // halo offsets (u16) of this wave's taps; wave-uniform
+    int wtap[7];
 #pragma unroll
     for (int ti = 0; ti < 7; ++ti) {
-        const int tap = min(wid + 4 * ti, 26);
+        int idx = min(wid + 4 * ti, nact - 1);
+        unsigned m = tmask;
+        for (int z = 0; z < idx; ++z) m &= m - 1;
+        const int tap = __builtin_ctz(m);
+        wtap[ti] = (wid + 4 * ti < nact) ? tap : -1;
         toffs[ti] = (((tap / 9) * XH + (tap / 3) % 3) * XW + tap % 3) * 16;
     }
 
@@ -199,7 +214,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
         if (tile + 1 < t_end) issue(tile + 1);
 #pragma unroll 1
         for (int ks = 0; ks < 4; ++ks) {
-            const int dd = ks >> 1, hb = (ks & 1) * 4;
+            const int dd = ks / HB, hb = (ks % HB) * 4;
             const u16* xa0 = xs + ((dd * XH + hb + fh) * XW + fw) * 16 + fc;        // read r = 0 (tap offset added later)
             const u16* xa1 = xa0 + XW * 16;                                          // r = 1: next h row
             const u16* db0 = ds + ((dd * WTH + hb + fh) * WTW + fw) * DLD + fc;
@@ -210,12 +225,13 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
                 bh[j] = wh_frag(db0 + 16 * j, db1 + 16 * j);
                 if (X3) bl[j] = wh_frag(db0 + DPL + 16 * j, db1 + DPL + 16 * j);
             }
-            // the A fragments of tap ti+1 are read while the 12 MFMAs of tap ti run (wave 3's seventh slot re-reads tap 26
-            // and its accumulator is never stored: no branch in the loop)
+            // the A fragments of tap ti+1 are read while the 12 MFMAs of tap ti run (a wave's slot past the end re-reads the
+            // last active tap and its accumulator is never stored)
             bf16x8 ah = wh_frag(xa0 + toffs[0], xa1 + toffs[0]);
             bf16x8 al = X3 ? wh_frag(xa0 + XPL + toffs[0], xa1 + XPL + toffs[0]) : ah;
 #pragma unroll
             for (int ti = 0; ti < 7; ++ti) {
+                if (ti >= nti) break;    // uniform: a phase with 8 / 12 / 18 active taps runs 2 / 3 / 5 slots
                 bf16x8 ahn = ah, aln = al;
                 if (ti + 1 < 7) {
                     ahn = wh_frag(xa0 + toffs[ti + 1], xa1 + toffs[ti + 1]);
@@ -238,8 +254,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
     float* __restrict__ C = g.part + (long long)bz * g.Krows * g.N;
 #pragma unroll
     for (int ti = 0; ti < 7; ++ti) {
-        const int tap = wid + 4 * ti;
-        if (tap < 27) {
+        const int tap = wtap[ti];
+        if (tap >= 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -253,44 +269,68 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
 
 }  // namespace
 
-static int wgrad_halo_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out, int off,
-                           int replicate, const float* dy, int N, int64_t ldy, int d2s_s, int d2s_C, float* part, int nsplit,
-                           vxb_stream_t stream) {
-    if (!src0 || !dy || !part || B < 1 || S_in < 1 || S_out < 1 || N < 1 || nsplit < 1) return VXB_EARG;
-    if ((C0 & 15) || (C1 & 15) || C0 < 16 || (C1 > 0 && !src1) || (N & 63)) return VXB_ESIZE;
-    if (d2s_s > 0 && d2s_C != 64) return VXB_ESIZE;
-    if (d2s_s <= 0 && (ldy & 3)) return VXB_ESIZE;
-    WhArgs g;
-    g.src0 = src0; g.src1 = src1; g.dy = dy; g.part = part; g.C0 = C0; g.C1 = C1; g.B = B; g.S_in = S_in; g.S_out = S_out;
-    g.off = off; g.replicate = replicate; g.N = N; g.Krows = 27 * (C0 + C1); g.ldy = ldy; g.d2s_s = d2s_s; g.d2s_C = d2s_C;
-    g.ntd = vxb_cdiv(S_out, WTD); g.nth = vxb_cdiv(S_out, WTH); g.ntw = vxb_cdiv(S_out, WTW);
-    g.ntiles = (long long)B * g.ntd * g.nth * g.ntw;
+static int g_wh_shape = -1;       // experiment knob (vxb_debug_set_wgrad_halo_shape): -1 = choose per grid, 0 / 1 = force
+
+// tile shape for a grid of extent S: 1 -> 4x4x8, 0 -> 2x8x8.  Measured at B = 4 (tools/bench_wgrad_halo.py): per tile the
+// 4x4x8 kernel is as fast in 'bf16' but ~10 % slower in 'bf16x3', so it is taken when it saves any edge voxels in bf16 and
+// only when it saves more than 10 % of them in x3 (S = 20: 20x20x24 vs 20x24x24 yes; S = 100: 100x100x104 vs 100x104x104 no).
+static inline int wgrad_halo_shape(int S, int x3) {
+    if (g_wh_shape >= 0) return g_wh_shape;
+    const long long a = (long long)vxb_cdiv(S, 2) * 2 * vxb_cdiv(S, 8) * 8, b = (long long)vxb_cdiv(S, 4) * 4 * vxb_cdiv(S, 4) * 4;
+    return x3 ? (b * 10 < a * 9) : (b < a);
+}
+
+template <int X3, int TD, int TH>
+static int wgrad_halo_launch(WhArgs& g, int nsplit, hipStream_t st) {
+    g.ntd = vxb_cdiv(g.S_out, TD); g.nth = vxb_cdiv(g.S_out, TH); g.ntw = vxb_cdiv(g.S_out, WTW);
+    g.ntiles = (long long)g.B * g.ntd * g.nth * g.ntw;
     g.tiles_per_split = (int)((g.ntiles + nsplit - 1) / nsplit);
-    if (nsplit > 65535 || N / 64 > 65535) return VXB_ESIZE;
-    const size_t lds = (size_t)(1 + (x3 ? 1 : 0)) * (XPL + DPL) * sizeof(u16);
-    dim3 grid((C0 + C1) / 16, N / 64, nsplit);
-    hipStream_t st = (hipStream_t)stream;
-    if (x3) {
-        if (hipFuncSetAttribute((const void*)wgrad_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
-        hipLaunchKernelGGL(wgrad_halo_kernel<1>, grid, dim3(256), lds, st, g);
-    } else {
-        if (hipFuncSetAttribute((const void*)wgrad_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
-        hipLaunchKernelGGL(wgrad_halo_kernel<0>, grid, dim3(256), lds, st, g);
-    }
+    const size_t lds = (size_t)(1 + X3) * ((TD + 2) * (TH + 2) * XW * 16 + DPL) * sizeof(u16);
+    dim3 grid((g.C0 + g.C1) / 16, g.N / 64, nsplit);
+    if (hipFuncSetAttribute((const void*)wgrad_halo_kernel<X3, TD, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
+    hipLaunchKernelGGL((wgrad_halo_kernel<X3, TD, TH>), grid, dim3(256), lds, st, g);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
 
+static int wgrad_halo_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out, int off,
+                           int replicate, const float* dy, int N, int64_t ldy, int d2s_s, int d2s_C, float* part, int nsplit,
+                           const uint32_t* phase_mask, vxb_stream_t stream) {
+    if (!src0 || !dy || !part || B < 1 || S_in < 1 || S_out < 1 || N < 1 || nsplit < 1) return VXB_EARG;
+    if ((C0 & 15) || (C1 & 15) || C0 < 16 || (C1 > 0 && !src1) || (N & 63)) return VXB_ESIZE;
+    if (d2s_s > 0 && d2s_C != 64) return VXB_ESIZE;
+    if (d2s_s <= 0 && ((ldy & 3) || phase_mask)) return VXB_ESIZE;
+    WhArgs g;
+    g.src0 = src0; g.src1 = src1; g.dy = dy; g.part = part; g.C0 = C0; g.C1 = C1; g.B = B; g.S_in = S_in; g.S_out = S_out;
+    g.off = off; g.replicate = replicate; g.N = N; g.Krows = 27 * (C0 + C1); g.ldy = ldy; g.d2s_s = d2s_s; g.d2s_C = d2s_C;
+    g.phase_mask = phase_mask;
+    if (nsplit > 65535 || N / 64 > 65535) return VXB_ESIZE;
+    hipStream_t st = (hipStream_t)stream;
+    if (wgrad_halo_shape(S_out, x3)) return x3 ? wgrad_halo_launch<1, 4, 4>(g, nsplit, st) : wgrad_halo_launch<0, 4, 4>(g, nsplit, st);
+    return x3 ? wgrad_halo_launch<1, 2, 8>(g, nsplit, st) : wgrad_halo_launch<0, 2, 8>(g, nsplit, st);
+}
+
 // 3x3x3 stride-1 specialisation of vxb_conv3d_wgrad_bf16_f32 / _bf16x3_f32 (same contract and part[z][K][N] layout;
-// the z slices are runs of 2x8x8 voxel tiles).  C0, C1 % 16 == 0, N % 64 == 0; d2s: d2s_C == 64.
+// the z slices are runs of 128-voxel tiles, 2x8x8 or 4x4x8 -- vxb_conv3_wgrad_halo_tiles gives their number).
+// C0, C1 % 16 == 0, N % 64 == 0; d2s: d2s_C == 64.  phase_mask (optional, d2s only): one word per 64-column block, bit t
+// set <=> the (tap t, phase) weight block is not structurally zero; the other blocks of `part` are left untouched.
 extern "C" int vxb_conv3_wgrad_halo_bf16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                                              int off, int replicate, const float* dy, int N, int64_t ldy, int d2s_s,
-                                             int d2s_C, float* part, int nsplit, vxb_stream_t stream) {
-    return wgrad_halo_impl(0, src0, src1, C0, C1, B, S_in, S_out, off, replicate, dy, N, ldy, d2s_s, d2s_C, part, nsplit, stream);
+                                             int d2s_C, float* part, int nsplit, const uint32_t* phase_mask, vxb_stream_t stream) {
+    return wgrad_halo_impl(0, src0, src1, C0, C1, B, S_in, S_out, off, replicate, dy, N, ldy, d2s_s, d2s_C, part, nsplit, phase_mask, stream);
 }
 
 extern "C" int vxb_conv3_wgrad_halo_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                                                int off, int replicate, const float* dy, int N, int64_t ldy, int d2s_s,
-                                               int d2s_C, float* part, int nsplit, vxb_stream_t stream) {
-    return wgrad_halo_impl(1, src0, src1, C0, C1, B, S_in, S_out, off, replicate, dy, N, ldy, d2s_s, d2s_C, part, nsplit, stream);
+                                               int d2s_C, float* part, int nsplit, const uint32_t* phase_mask, vxb_stream_t stream) {
+    return wgrad_halo_impl(1, src0, src1, C0, C1, B, S_in, S_out, off, replicate, dy, N, ldy, d2s_s, d2s_C, part, nsplit, phase_mask, stream);
 }
+
+// number of voxel tiles the two entries above split into z slices (for choosing nsplit)
+extern "C" size_t vxb_conv3_wgrad_halo_tiles(int B, int S_out, int x3) {
+    if (B < 1 || S_out < 1) return 0;
+    const int sh = wgrad_halo_shape(S_out, x3);
+    return (size_t)B * vxb_cdiv(S_out, sh ? 4 : 2) * vxb_cdiv(S_out, sh ? 4 : 8) * vxb_cdiv(S_out, 8);
+}
+
+extern "C" void vxb_debug_set_wgrad_halo_shape(int shape) { g_wh_shape = shape < 0 ? -1 : (shape ? 1 : 0); }

@@ -231,8 +231,9 @@ def conv3d(src0, wt, N, B, S_in, S_out, kext, off, stride=1, replicate=True, bia
 
 
 def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=True, src1=None, ldy=None, d2s=(0, 0),
-                 nsplit=None, label=None, force_bf16=False):
-    """returns dWt [(tap, ci)][N] (fp32, deterministic split reduction)."""
+                 nsplit=None, label=None, force_bf16=False, phase_mask=None, flops_frac=1.0):
+    """returns dWt [(tap, ci)][N] (fp32, deterministic split reduction).  phase_mask (LDS-halo kernel, d2s only): int32
+    [N / 64] tap masks of the polyphase structure -- the structurally zero (tap, phase) blocks come back as zeros."""
     C0 = src0.shape[-1]
     C1 = src1.shape[-1] if src1 is not None else 0
     K = kext ** 3 * (C0 + C1)
@@ -241,7 +242,7 @@ def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
     if (HALO_CONV and mode in ('bf16', 'bf16x3') and kext == 3 and stride == 1 and C0 % 16 == 0 and C1 % 16 == 0
             and N % 64 == 0 and (d2s[0] == 0 or d2s[1] == 64) and S_out >= 16 and (ldy is None or ldy % 4 == 0)):
         blocks = ((C0 + C1) // 16) * (N // 64)
-        ntiles = B * ((S_out + 1) // 2) * ((S_out + 7) // 8) ** 2
+        ntiles = int(_lib.lib().vxb_conv3_wgrad_halo_tiles(B, S_out, int(mode == 'bf16x3')))
         ns = nsplit if nsplit is not None else max(1, min(256, (1024 + blocks - 1) // blocks, ntiles // 8))
         if nsplit is None:
             # (column blocks x slices) a multiple of 8 lets the kernel co-locate the channel-chunk blocks that share dY
@@ -249,10 +250,13 @@ def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
             import math
             step = 8 // math.gcd(N // 64, 8)
             ns = min(((ns + step - 1) // step) * step, max(step, (ntiles // step) * step))
-        part = torch.empty((ns, K, N), dtype=torch.float32, device=src0.device)
-        _lib.set_meta(label or 'conv3d_wgrad[k%d s%d %d->%d S%d]' % (kext, stride, C0 + C1, N, S_out), 2.0 * P * N * K)
+        if phase_mask is not None and d2s[0] > 0:
+            part = torch.zeros((ns, K, N), dtype=torch.float32, device=src0.device)      # skipped blocks stay zero
+        else:
+            part, phase_mask, flops_frac = torch.empty((ns, K, N), dtype=torch.float32, device=src0.device), None, 1.0
+        _lib.set_meta(label or 'conv3d_wgrad[k%d s%d %d->%d S%d]' % (kext, stride, C0 + C1, N, S_out), 2.0 * P * N * K * flops_frac)
         call('vxb_conv3_wgrad_halo_bf16x3_f32' if mode == 'bf16x3' else 'vxb_conv3_wgrad_halo_bf16_f32', src0, src1, C0, C1,
-             B, S_in, S_out, off, int(replicate), dy, N, ldy if ldy is not None else N, d2s[0], d2s[1], part, ns)
+             B, S_in, S_out, off, int(replicate), dy, N, ldy if ldy is not None else N, d2s[0], d2s[1], part, ns, phase_mask)
         if ns == 1:
             return part[0]
         out = torch.empty((K, N), dtype=torch.float32, device=src0.device)
@@ -379,7 +383,7 @@ def polyphase_structure(k, s, dev):
     tm = [pm[order[i]] | (pm[order[i + 1]] if i + 1 < nph else 0) for i in range(0, nph, 2)]
     st = dict(kl=kl, R=R, phase_mask=pm, order=order,
               perm=torch.tensor(order, dtype=torch.int32, device=dev), perm_long=torch.tensor(order, dtype=torch.int64, device=dev),
-              tile_mask=torch.tensor(tm, dtype=torch.int32, device=dev),
+              tile_mask=torch.tensor(tm, dtype=torch.int32, device=dev), phase_mask_t=torch.tensor(pm, dtype=torch.int32, device=dev),
               frac=sum(pc(m) for m in pm) / float(nph * kl ** 3), tile_frac=sum(pc(m) for m in tm) * 2 / float(2 * len(tm) * kl ** 3))
     _POLY[key] = st
     return st
@@ -458,17 +462,65 @@ def s2d_halo_ok(kl, C, N):
     return HALO_CONV and _mm() and kl == 3 and C % 32 == 0 and N % 64 == 0
 
 
-def conv3_s2d(src_fine, wt, N, B, G, S_out, off, s, Cf, label=None):
+def s2d_taptab(k, s, dev, cpc, chunks_per_phase):
+    """tap lists of the polyphase DATA gradient for the LDS-halo kernel (see voxactb_hip.h, taptab): the gradient's tap t''
+    is the forward tap kl^3 - 1 - t'' (all three axes flipped).  Returns (table int32, ncls, tap_total, rows) with rows =
+    index into the dense [chunk][27] fragment blocks of every listed tap, chunk by chunk."""
+    key = ('tt', k, s, str(dev), cpc, chunks_per_phase)
+    r = _POLY.get(key)
+    if r is not None:
+        return r
+    st = polyphase_structure(k, s, dev)
+    kl = st['kl']
+    assert kl == 3
+    nt = kl ** 3
+    lists, cls_of, table, phase_rows = {}, [], [], []
+    for ph, m in enumerate(st['phase_mask']):
+        dm = sum(1 << (nt - 1 - t) for t in range(nt) if (m >> t) & 1)
+        if dm not in lists:
+            taps = [t for t in range(nt) if (dm >> t) & 1]
+            pad = [t for t in range(nt) if not (dm >> t) & 1][:(-len(taps)) % 3]     # zero-weight taps of this footprint
+            lists[dm] = (len(lists), taps + pad)
+        cls_of.append(lists[dm][0])
+    ncls = len(lists)
+    for dm, (ci, taps) in sorted(lists.items(), key=lambda kv: kv[1][0]):
+        ent = [(((t // 9) * 10 + (t // 3) % 3) * 12 + t % 3) * 40 for t in taps] + [0] * (32 - len(taps))
+        ent[31] = len(taps)
+        table += ent
+    by_cls = {ci: taps for ci, taps in lists.values()}
+    total, rows = 0, []
+    for ph in range(s ** 3):
+        taps = by_cls[cls_of[ph]]
+        table += [cls_of[ph], total]
+        for c in range(chunks_per_phase):
+            rows += [(ph * chunks_per_phase + c) * nt + t for t in taps]
+        total += chunks_per_phase * len(taps)
+    r = (torch.tensor(table, dtype=torch.int32, device=dev), ncls, total, torch.tensor(rows, dtype=torch.int64, device=dev))
+    _POLY[key] = r
+    return r
+
+
+def conv3_s2d(src_fine, wt, N, B, G, S_out, off, s, Cf, label=None, poly_k=None):
     """out[B, S_out^3, N] = 3x3x3 zero-pad conv over the low-res grid G^3 whose input channel (phase, co) is read from
-    src_fine [B, (G*s)^3, Cf] at fine voxel (q*s + r); wt fp32 [(tap, phase, co)][N].  LDS-halo kernel only (bf16 modes)."""
+    src_fine [B, (G*s)^3, Cf] at fine voxel (q*s + r); wt fp32 [(tap, phase, co)][N].  LDS-halo kernel only (bf16 modes).
+    poly_k: wt is the data gradient of the polyphase up-conv of a k^3 kernel -- only its non-zero (tap, phase) blocks are
+    visited (POLY_SPARSE)."""
     wb = to_bf16_nk(wt)
     out = torch.empty((B, S_out, S_out, S_out, N), dtype=torch.float32, device=src_fine.device)
     C0 = s ** 3 * Cf
-    _lib.set_meta(label or 'conv3_s2d[k3 %d->%d S%d dgrad]' % (C0, N, S_out), 2.0 * B * S_out ** 3 * N * 27 * C0)
+    x3 = wb.dim() == 3
+    lbl = label or 'conv3_s2d[k3 %d->%d S%d dgrad]' % (C0, N, S_out)
+    _lib.set_meta(lbl, 0.0)
     wf = halo_wfrag(wb, C0)
-    _lib.set_meta(label or 'conv3_s2d[k3 %d->%d S%d dgrad]' % (C0, N, S_out), 2.0 * B * S_out ** 3 * N * 27 * C0)
-    call('vxb_conv3_halo_bf16x3_f32' if wb.dim() == 3 else 'vxb_conv3_halo_bf16w_f32', src_fine, None, C0, 0, B, G, S_out, off,
-         0, wb, N, None, out, ACT_NONE, LRELU_SLOPE, s, Cf, 0, wf)
+    tt, ncls, total, frac = None, 0, 0, 1.0
+    if poly_k is not None and POLY_SPARSE and wf is not None:
+        cpc = 16 if x3 else 32
+        tt, ncls, total, rows = s2d_taptab(poly_k, s, src_fine.device, cpc, Cf // cpc)
+        wf = wf.view(wf.shape[0], wf.shape[1] * 27, -1).index_select(1, rows).contiguous()
+        frac = polyphase_structure(poly_k, s, src_fine.device)['frac']
+    _lib.set_meta(lbl, 2.0 * B * S_out ** 3 * N * 27 * C0 * frac)
+    call('vxb_conv3_halo_bf16x3_f32' if x3 else 'vxb_conv3_halo_bf16w_f32', src_fine, None, C0, 0, B, G, S_out, off,
+         0, wb, N, None, out, ACT_NONE, LRELU_SLOPE, s, Cf, 0, wf, tt, ncls, total)
     return out
 
 
@@ -660,7 +712,7 @@ def conv3d_bf16w(src0, wb, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
         _lib.set_meta(label or 'conv3d_bf16[k%d s%d %d->%d S%d%s]' % (kext, stride, C0 + C1, N, S_out, '' if replicate else ' dgrad'),
                       2.0 * B * S_out ** 3 * N * kext ** 3 * (C0 + C1))
         call('vxb_conv3_halo_bf16x3_f32' if x3 else 'vxb_conv3_halo_bf16w_f32', src0, src1, C0, C1, B, S_in, S_out, off,
-             int(replicate), wb, N, bias, out, act, LRELU_SLOPE, 0, 0, d2s[0], wf)
+             int(replicate), wb, N, bias, out, act, LRELU_SLOPE, 0, 0, d2s[0], wf, None, 0, 0)
         return out
     # ... same trade for convs: every input voxel must feed enough products ((kext/stride)^3 * N per channel) to amortise
     # the split pass (up-conv forward 17.7 -> 15.3 ms; the stride-5 patchify would lose 1.5 ms and stays register-staged)
