@@ -113,13 +113,17 @@ int vxb_conv3d_wgrad_bf16x3_f32(const float* src0, const float* src1, int C0, in
  * Cin % 32 == 0, one source).  zeros: >= 16 bytes of device zeros, fetched for zero-padded taps. */
 int vxb_split_bf16_f32(const float* src, int64_t ld, int64_t rows, int cols, void* dst_planes, int nplanes,
                        vxb_stream_t stream);
-int vxb_gemm_dl_f32(const void* A_planes, const void* Bw_planes, int nplanes, float* C, int64_t ldc, const float* bias,
+int vxb_gemm_dl_f32(const void* A_planes, const void* Bw_planes, const void* Bw_frag, int nplanes, float* C, int64_t ldc, const float* bias,
                     const float* residual, int M, int N, int K, int act, float slope, int accumulate,
                     vxb_stream_t stream);
 int vxb_conv3d_dl_f32(const void* src_planes, int Cin, int B, int S_in, int S_out, int stride, int kext, int off,
-                      int replicate, const void* wt_planes, int nplanes, int N, const float* bias, float* out,
+                      int replicate, const void* wt_planes, const void* wt_frag, int nplanes, int N, const float* bias, float* out,
                       int64_t ldc, int act, float slope, int accumulate, int d2s_s, int d2s_C, const void* zeros,
                       const uint32_t* tapmask, const int32_t* d2s_perm, vxb_stream_t stream);
+/* (Bw_frag / wt_frag, optional: the same weights, rows zero-padded to a multiple of 128, in MFMA fragment order
+ * [ceil(N/128)*4][K/16][nplanes][64 lanes][8]
+ * -- lane (col = lane & 31, half = lane >> 5) of column tile t, k-step ks holds W[32 t + col][16 ks + 8 half .. + 7]; the
+ * kernel then reads its B fragments straight from global memory, one k-tile ahead, and only A goes through LDS.) */
 /* (tapmask / d2s_perm, both optional: block-sparse weights of the polyphase up-conv, network_utils.py:245-250 -- a fine
  * phase only sees the low-res taps its trilinear footprint reaches.  tapmask[column tile] bit t set <=> tap t has
  * non-zero weights in that 128-column tile; d2s_perm[p] = fine-grid phase held by 64-column block p.) */

@@ -81,3 +81,27 @@ def test_conv_dl_depth_to_space_polyphase_forward():
     close(got, ref, 3e-5, 'dl conv d2s')
     exact = ops.conv3d(z, Weff, s ** 3 * 64, B, G, G, 3, -1, bias=bias, act=ops.ACT_LRELU, d2s=(s, 64))     # fp32 matrix cores
     close(got, exact, 2e-5, 'dl conv d2s x3 vs exact fp32')
+
+
+@pytest.mark.parametrize('x3', [False, True])
+@pytest.mark.parametrize('M,N,K', [(300, 72, 96), (1000, 512, 2048), (4096, 1000, 32), (256, 128, 64)])
+def test_weight_fragments_from_global_are_bit_identical(M, N, K, x3):
+    """B fragments read straight from global memory (ops.gemm_wfrag order, one k-tile ahead in registers) or through the
+    LDS tile: same products, same order."""
+    x, W, b = rnd(M, K).to(DEV), rnd(N, K, seed=1).to(DEV), rnd(N, seed=2).to(DEV)
+    wb = ops.split_bf16(W, x3)
+    outs = []
+    ops.DL_GEMM = 'force'
+    try:
+        for bd in (False, True):
+            ops.GEMM_BD = bd
+            ops.new_step()
+            outs.append(ops.gemm_bf16w(x, wb, bias=b, act=ops.ACT_LRELU))
+    finally:
+        ops.DL_GEMM, ops.GEMM_BD = True, True
+    assert torch.equal(outs[0], outs[1])
+    f = ops.gemm_wfrag(wb)
+    Np = (N + 127) // 128 * 128
+    assert f.shape == (Np // 32, K // 16, 2 if x3 else 1, 2, 32, 8)
+    w3 = wb if x3 else wb.unsqueeze(0)
+    assert torch.equal(f[1, 0, 0, 1, 5], w3[0, 32 + 5, 8:16])

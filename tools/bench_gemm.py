@@ -1,0 +1,33 @@
+"""Micro-benchmark: the linear-layer GEMMs of the Perceiver stack (M = B * latents = 32768) in bf16x3 / bf16 --
+register-staged kernel vs direct-to-LDS kernel (with and without weight fragments from global memory)."""
+import sys
+import os
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from voxactb_amd import ops  # noqa: E402
+from tools.bench_halo import timeit  # noqa: E402
+
+
+def main():
+    dev = 'cuda:0'
+    M = 32768
+    for x3 in (True, False):
+        for N, K in [(4096, 512), (512, 4096), (2048, 512), (512, 2048), (512, 512), (1024, 512), (512, 1024)]:
+            x = torch.randn(M, K, device=dev)
+            W = torch.randn(N, K, device=dev) * 0.05
+            wb = ops.split_bf16(W, x3)
+            out = torch.empty(M, N, device=dev)
+            fl = 2.0 * M * N * K
+            res = []
+            for name, dl, bd in (('staged', False, False), ('dl', 'force', False), ('dl+bfrag', 'force', True)):
+                ops.DL_GEMM, ops.GEMM_BD = dl, bd
+                ops.new_step()
+                t = timeit(lambda: ops.gemm_bf16w(x, wb, out=out), n=10)
+                res.append('%s %.3f ms %5.0f TF/s' % (name, t, fl / t * 1e-9))
+            ops.DL_GEMM, ops.GEMM_BD = True, True
+            print('%s  %5d x %5d x %5d   %s' % ('bf16x3' if x3 else 'bf16  ', M, N, K, '   '.join(res)))
+
+
+if __name__ == '__main__':
+    main()

@@ -51,3 +51,21 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global memory (s_waitcnt vmcnt(0)), which
+// drains every global load a wave has in flight -- fatal for kernels that keep operand prefetches (register loads or
+// direct-to-LDS loads, tracked by hand with s_waitcnt vmcnt(n)) running across the barrier.
+__device__ __forceinline__ void vxb_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// Bare s_barrier for kernels whose LDS is written ONLY by direct-to-LDS loads that the code tracks itself with
+// s_waitcnt vmcnt(n): even the LDS-only fence above waits for every outstanding direct load (they are LDS writes), i.e.
+// for the tiles deliberately left in flight.  The asm clobbers keep the compiler from moving LDS reads across it.
+__device__ __forceinline__ void vxb_raw_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}

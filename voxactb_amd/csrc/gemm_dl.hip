@@ -29,6 +29,7 @@ struct DlArgs {
     long long lda;
     const u16* Bw;           // bf16 [N][K] plane(s)
     long long b_plane;
+    const u16* Bfrag;        // BD kernels: the same weights in MFMA fragment order [N/32][K/16][plane][lane 64][8] (ops.gemm_wfrag)
     const u16* zeros;        // >= 16 bytes of zeros (source of zero-padded conv taps)
     float* C;
     const float* bias;
@@ -50,11 +51,15 @@ __device__ __forceinline__ void dl_load16(const u16* src, u16* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int AMODE, int X3>
+// BD: the B (weight) fragments come straight from global memory in fragment order, one k-tile ahead in two alternating
+// register sets -- no weight traffic through LDS.  With both operands in LDS the 2x2-tile waves of the x3 kernel need
+// 16 ds_read_b128 + 8 KB of direct loads per 24 MFMAs, which saturates the CU's 128 B/clk; the B half of that moves to
+// the L1/L2 path (weights are shared by every workgroup) and the A stages shrink to 16 KB.
+template <int AMODE, int X3, int BD>
 __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     constexpr int NPL = 1 + X3;
-    constexpr int STAGE = 2 * NPL * DTILE;     // [A planes][B planes]
+    constexpr int STAGE = (BD ? 1 : 2) * NPL * DTILE;     // [A planes][B planes]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
@@ -103,6 +108,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
     int it_kt = 0;
     if (AMODE == DL_A_CONV && g.tapmask) it_rem = g.tapmask[tile_x];
     const bool masked = AMODE == DL_A_CONV && g.tapmask != nullptr;
+    int k0_issued = 0;                      // weight k offset of the k-tile issued last (the BD fragment loads follow it)
     auto issue = [&](int stage, int kt) {
         int k0 = kt * 32;
         u16* sb = smem + stage * STAGE;
@@ -144,13 +150,14 @@ __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
                 if (!masked) { if (++it_tw == g.kext) { it_tw = 0; if (++it_th == g.kext) { it_th = 0; ++it_td; } } }
             }
         }
+        k0_issued = k0;
 #pragma unroll
         for (int p = 0; p < NPL; ++p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const u16* s = asrc[i] ? asrc[i] + p * g.a_plane : g.zeros;
                 dl_load16(s, sb + p * DTILE + (2 * wid + i) * 512);
-                dl_load16(g.Bw + p * g.b_plane + b_off[i] + k0, sb + (NPL + p) * DTILE + (2 * wid + i) * 512);
+                if (!BD) dl_load16(g.Bw + p * g.b_plane + b_off[i] + k0, sb + (NPL + p) * DTILE + (2 * wid + i) * 512);
             }
         }
     };
@@ -174,6 +181,68 @@ __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
     }
 
     const int nkt = masked ? __builtin_popcount(it_rem) * (g.Cin >> 5) : g.K / 32;
+    if (BD) {
+        // B fragments of tile t (32 columns), k-step ks, plane p: 1 KB at ((ntile * K/16 + k0/16 + ks) * NPL + p) * 512 + lane * 8
+        bf16x8 b0[2][2][NPL], b1[2][2][NPL];
+        const long long nks = g.K >> 4;
+        const u16* bfb = g.Bfrag + ((long long)((n0 + wn * 64) >> 5) * nks * NPL) * 512 + lane * 8;
+        // The fragment loads are inline asm on purpose: the compiler's waitcnt pass cannot count register loads and
+        // direct-to-LDS loads on one in-order counter and drains vmcnt to 0 before the first use of a loaded register --
+        // i.e. it would wait for the A tiles deliberately left in flight.  Hidden from it, the loads are covered by the
+        // hand-placed s_waitcnt at the top of the next k-tile (they are issued BEFORE that tile's direct loads).
+#define DL_LOADB(SET, k0_)                                                                                            \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                \
+            const u16* bp_ = bfb + (((long long)t * nks + ((k0_) >> 4)) * NPL) * 512;                                  \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                           \
+            _Pragma("unroll") for (int p = 0; p < NPL; ++p)                                                            \
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(SET[t][ks][p]) : "v"(bp_), "n"((ks * NPL + p) * 1024) : "memory"); \
+        }
+        // one k-tile.  Loads retire in order, so they are issued as  B(kt+1) -> registers,  then  A(kt+2) -> LDS stage
+        // (kt+2) % 3:  at the top of tile kt only the 2*NPL direct loads of A(kt+1) may still be in flight -- A gets two
+        // tiles of MFMAs to arrive (HBM / fabric latency), B (L2-resident weights) one.
+#define DL_KTILE(kt_, CUR, NXT)                                                                                       \
+        {                                                                                                             \
+            const int kt = (kt_);                                                                                     \
+            if (kt + 1 < nkt) { if (X3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); } \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
+            vxb_raw_barrier();                                                                                        \
+            if (kt + 1 < nkt) { DL_LOADB(NXT, k0_next) }                                                              \
+            if (kt + 2 < nkt) { issue((kt + 2) % 3, kt + 2); }                                                        \
+            const u16* sb = smem + (kt % 3) * STAGE;                                                                  \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                         \
+                bf16x8 ah[2], al[2];                                                                                  \
+                _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                        \
+                    const int co = ((2 * ks + hi) ^ fx[t]) * 8;                                                       \
+                    ah[t] = *reinterpret_cast<const bf16x8*>(sb + fa[t] + co);                                        \
+                    if (X3) al[t] = *reinterpret_cast<const bf16x8*>(sb + DTILE + fa[t] + co);                        \
+                }                                                                                                     \
+                if (X3) {                                                                                             \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                      \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], CUR[j][ks][0], acc[i][j], 0, 0, 0); \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                      \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], CUR[j][ks][NPL - 1], acc[i][j], 0, 0, 0); \
+                }                                                                                                     \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], CUR[j][ks][0], acc[i][j], 0, 0, 0);     \
+            }                                                                                                         \
+            k0_next = k0_issued;                                                                                      \
+        }
+        // k0_next: weight k offset of tile kt + 1 (the A issue runs one tile further ahead than the B loads)
+        issue(0, 0);
+        DL_LOADB(b0, k0_issued)
+        int k0_next = 0;
+        if (nkt > 1) { issue(1, 1); k0_next = k0_issued; }
+        int kt2 = 0;
+#pragma unroll 1
+        for (; kt2 + 2 <= nkt; kt2 += 2) {
+            DL_KTILE(kt2, b0, b1)
+            DL_KTILE(kt2 + 1, b1, b0)
+        }
+        if (kt2 < nkt) DL_KTILE(kt2, b0, b1)
+    } else {
     issue(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of k-tile kt have landed in LDS
@@ -208,6 +277,8 @@ __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
+    }
+
     }
 
     float* __restrict__ C = g.C;
@@ -303,17 +374,20 @@ __global__ void __launch_bounds__(256) split_bf16_kernel(const float* __restrict
     }
 }
 
+template <int AMODE, int X3, int BD>
+int dl_launch2(const DlArgs& g, hipStream_t st) {
+    const dim3 grid(vxb_cdiv(g.N, 128), vxb_cdiv(g.M, 128));
+    const size_t lds = (size_t)(BD ? 3 : 2 * 2) * (1 + X3) * DTILE * sizeof(u16);     // BD: three A stages; else 2 x (A + B)
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute((const void*)gemm_dl_kernel<AMODE, X3, BD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
+    hipLaunchKernelGGL((gemm_dl_kernel<AMODE, X3, BD>), grid, dim3(256), lds, st, g);
+    return hipGetLastError() == hipSuccess ? VXB_OK : VXB_ELAUNCH;
+}
+
 template <int AMODE>
 int dl_launch(const DlArgs& g, int x3, hipStream_t st) {
-    const dim3 grid(vxb_cdiv(g.N, 128), vxb_cdiv(g.M, 128));
-    const size_t lds = (size_t)2 * 2 * (x3 ? 2 : 1) * DTILE * sizeof(u16);
-    if (x3) {
-        if (hipFuncSetAttribute((const void*)gemm_dl_kernel<AMODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
-        hipLaunchKernelGGL((gemm_dl_kernel<AMODE, 1>), grid, dim3(256), lds, st, g);
-    } else {
-        hipLaunchKernelGGL((gemm_dl_kernel<AMODE, 0>), grid, dim3(256), lds, st, g);
-    }
-    return hipGetLastError() == hipSuccess ? VXB_OK : VXB_ELAUNCH;
+    if (g.Bfrag) return x3 ? dl_launch2<AMODE, 1, 1>(g, st) : dl_launch2<AMODE, 0, 1>(g, st);
+    return x3 ? dl_launch2<AMODE, 1, 0>(g, st) : dl_launch2<AMODE, 0, 0>(g, st);
 }
 
 inline bool dl_al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -337,12 +411,18 @@ extern "C" int vxb_split_bf16_f32(const float* src, int64_t ld, int64_t rows, in
 
 // C[M,N] (+)= act(A @ Bw^T + bias) (+ residual) with BOTH operands as bf16 planes: A_planes [nplanes][M][K] (from
 // vxb_split_bf16_f32), Bw_planes [nplanes][N][K]; nplanes = 1 ('bf16') or 2 ('bf16x3': hi*hi + hi*lo + lo*hi).  K % 32 == 0.
-extern "C" int vxb_gemm_dl_f32(const void* A_planes, const void* Bw_planes, int nplanes, float* C, int64_t ldc,
+// Bw_frag (optional): the same weights, rows zero-padded to a multiple of 128, in fragment order
+// [ceil(N/128)*4][K/16][nplanes][64 lanes][8 bf16] -- lane
+// (col = lane & 31, half = lane >> 5) of column tile t, k-step ks holds Bw[32 t + col][16 ks + 8 half .. + 7]; the kernel
+// then reads its B fragments straight from global memory (no weight traffic through LDS).
+extern "C" int vxb_gemm_dl_f32(const void* A_planes, const void* Bw_planes, const void* Bw_frag, int nplanes, float* C, int64_t ldc,
                                const float* bias, const float* residual, int M, int N, int K, int act, float slope,
                                int accumulate, vxb_stream_t stream) {
     if (!A_planes || !Bw_planes || !C || M < 1 || N < 1 || K < 32 || (nplanes != 1 && nplanes != 2)) return VXB_EARG;
     if ((K & 31) || !dl_al16(A_planes) || !dl_al16(Bw_planes)) return VXB_ESIZE;
+    if (Bw_frag && !dl_al16(Bw_frag)) return VXB_ESIZE;
     DlArgs g = {};
+    g.Bfrag = (const u16*)Bw_frag;
     g.A = (const u16*)A_planes; g.a_plane = (long long)M * K; g.lda = K;
     g.Bw = (const u16*)Bw_planes; g.b_plane = (long long)N * K; g.zeros = (const u16*)Bw_planes;
     g.C = C; g.bias = bias; g.residual = residual; g.M = M; g.N = N; g.K = K; g.ldc = ldc; g.act = act; g.slope = slope;
@@ -353,11 +433,12 @@ extern "C" int vxb_gemm_dl_f32(const void* A_planes, const void* Bw_planes, int 
 // Implicit-GEMM conv3d twin of vxb_conv3d_bf16w/bf16x3_f32 for ONE source whose activations were pre-split:
 // src_planes [nplanes][B, S_in^3, Cin] bf16; weights [nplanes][N][K = kext^3 * Cin]; Cin % 32 == 0.
 // zeros: >= 16 bytes of zeros in device memory (fetched for zero-padded taps).
+// wt_frag (optional): the weights in fragment order, see vxb_gemm_dl_f32.
 // tapmask (optional, kext^3 <= 32): one word per 128-column tile, bit t set <=> tap t has non-zero weights in that tile
 // (never all-zero); the other taps are skipped.  d2s_perm (optional, d2s_C == 64): column block p of the weights / output
 // is phase d2s_perm[p] of the fine grid -- lets the host pair phases with the same tap footprint in one column tile.
 extern "C" int vxb_conv3d_dl_f32(const void* src_planes, int Cin, int B, int S_in, int S_out, int stride, int kext, int off,
-                                 int replicate, const void* wt_planes, int nplanes, int N, const float* bias, float* out,
+                                 int replicate, const void* wt_planes, const void* wt_frag, int nplanes, int N, const float* bias, float* out,
                                  int64_t ldc, int act, float slope, int accumulate, int d2s_s, int d2s_C, const void* zeros,
                                  const uint32_t* tapmask, const int32_t* d2s_perm, vxb_stream_t stream) {
     if (!src_planes || !wt_planes || !out || !zeros || B < 1 || S_in < 1 || S_out < 1 || kext < 1 || stride < 1 || N < 1) return VXB_EARG;
@@ -369,7 +450,9 @@ extern "C" int vxb_conv3d_dl_f32(const void* src_planes, int Cin, int B, int S_i
     if (d2s_s > 0 && (d2s_C < 1 || N % d2s_C)) return VXB_EARG;
     if (tapmask && kext * kext * kext > 32) return VXB_ESIZE;
     if (d2s_perm && (d2s_s <= 0 || d2s_C != 64)) return VXB_EARG;      // a permuted phase must not straddle column tiles
+    if (wt_frag && !dl_al16(wt_frag)) return VXB_ESIZE;
     DlArgs g = {};
+    g.Bfrag = (const u16*)wt_frag;
     g.tapmask = tapmask; g.d2s_perm = d2s_perm;
     g.A = (const u16*)src_planes; g.a_plane = (long long)B * S_in * S_in * S_in * Cin;
     g.Bw = (const u16*)wt_planes; g.b_plane = (long long)N * K; g.zeros = (const u16*)zeros;

@@ -21,9 +21,33 @@ HALO_D2S = False     # ... also the depth-to-space forward of the polyphase up-c
 _WCACHE = {}
 
 
+_FCACHE = {}
+GEMM_BD = True       # direct-to-LDS GEMMs read their weight fragments straight from global memory (no B tile in LDS)
+
+
+def gemm_wfrag(wb):
+    """bf16 weights [N][K] or planes [2][N][K] -> MFMA fragment order [N/32][K/16][planes][half 2][col 32][8] (cached per
+    weight tensor until new_step()): the B operand of the direct-to-LDS kernels without a trip through LDS."""
+    if not GEMM_BD or wb.shape[-1] % 16:
+        return None
+    key = (wb.data_ptr(), tuple(wb.shape))
+    f = _FCACHE.get(key)
+    if f is None:
+        w3 = wb if wb.dim() == 3 else wb.unsqueeze(0)
+        P, N, K = w3.shape
+        if N % 128:                      # the kernel's column tiles are 128 wide: zero rows up to the next multiple
+            w3 = torch.cat((w3, w3.new_zeros((P, 128 - N % 128, K))), dim=1)
+            N = w3.shape[1]
+        f = w3.view(P, N // 32, 32, K // 16, 2, 8).permute(1, 3, 0, 4, 2, 5).contiguous()
+        _FCACHE[key] = (f, wb)           # (keeps wb alive: the key is its address)
+        return f
+    return f[0]
+
+
 def new_step():
     """weights change every optimizer step: drop the per-step bf16 weight copies."""
     _WCACHE.clear()
+    _FCACHE.clear()
 
 
 def split_bf16(w, x3=None):
@@ -414,7 +438,7 @@ def conv3_polyphase_fwd(z, Weff, Cout, B, G, k, s, bias, act=ACT_NONE, label=Non
     planes = split_planes(z.reshape(-1, C), npl)
     out = torch.empty((B, G * s, G * s, G * s, Cout), dtype=torch.float32, device=z.device)
     _lib.set_meta(lbl, 2.0 * B * G ** 3 * N * kl ** 3 * C * st['frac'])
-    call('vxb_conv3d_dl_f32', planes, C, B, G, G, 1, kl, -R, 1, wb, npl, N, bias, out, N, act, LRELU_SLOPE, 0, s, Cout,
+    call('vxb_conv3d_dl_f32', planes, C, B, G, G, 1, kl, -R, 1, wb, gemm_wfrag(wb), npl, N, bias, out, N, act, LRELU_SLOPE, 0, s, Cout,
          _zeros16(z.device), st['tile_mask'], st['perm'])
     return out
 
@@ -683,8 +707,8 @@ def gemm_bf16w(x, Wb, out=None, bias=None, act=ACT_NONE, residual=None, accumula
         _lib.set_meta(label or 'gemm_bf16 %dx%dx%d' % (M, N, K), 0.0)
         planes = split_planes(x, 2 if x3 else 1)
         _lib.set_meta(label or 'gemm_bf16 %dx%dx%d' % (M, N, K), 2.0 * M * N * K)
-        call('vxb_gemm_dl_f32', planes, Wb, 2 if x3 else 1, out, out.stride(0), bias, residual, M, N, K, act, LRELU_SLOPE,
-             int(accumulate))
+        call('vxb_gemm_dl_f32', planes, Wb, gemm_wfrag(Wb), 2 if x3 else 1, out, out.stride(0), bias, residual, M, N, K, act,
+             LRELU_SLOPE, int(accumulate))
         return out
     call('vxb_gemm_bf16x3_f32' if x3 else 'vxb_gemm_bf16w_f32', x, x.stride(0), Wb, out, out.stride(0), bias, residual, M, N, K, act, LRELU_SLOPE,
          int(accumulate))
@@ -723,7 +747,7 @@ def conv3d_bf16w(src0, wb, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
         _lib.set_meta(lbl, 0.0)
         planes = split_planes(src0.view(-1, C0), npl)
         _lib.set_meta(lbl, 2.0 * B * S_out ** 3 * N * kext ** 3 * C0)
-        call('vxb_conv3d_dl_f32', planes, C0, B, S_in, S_out, stride, kext, off, int(replicate), wb, npl, N, bias, out,
+        call('vxb_conv3d_dl_f32', planes, C0, B, S_in, S_out, stride, kext, off, int(replicate), wb, gemm_wfrag(wb), npl, N, bias, out,
              ldc if ldc is not None else N, act, LRELU_SLOPE, int(accumulate), d2s[0], d2s[1], _zeros16(src0.device), None, None)
         return out
     call('vxb_conv3d_bf16x3_f32' if x3 else 'vxb_conv3d_bf16w_f32', src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, int(replicate), wb, N, bias, out,
