@@ -195,6 +195,16 @@ int vxb_conv3_c1_dgrad_f32(const float* dq, const float* w, const float* u, floa
                            int accumulate, int apply_lrelu_mask, float slope, vxb_stream_t stream);
 int vxb_conv3_c1_wgrad_f32(const float* u, const float* dq, float* dw, float* db, float* part_ws, int B, int S, int C,
                            vxb_stream_t stream);
+/* Matrix-core versions of the two entries above for the 'bf16x3' / 'bf16' precisions (bf16x3 products, fp32 accumulate):
+ * the 27 taps are the MFMA column dimension -- forward P[v'][t] = u[v'] . w[:, t] on the tile's halo, then
+ * q[v] = bias + sum_t P[v + t - 1][t]; weight gradient dW = u^T Bq with Bq[v'][t] = the dq of the outputs whose tap t
+ * reads u[v'] (trans_decoder, perceiver_lang_io.py:316-321 / :466).  C = 64.  wfrag_ws: 8 KB of device scratch;
+ * part_ws: vxb_conv3_c1_wgrad_mfma_blocks(B, S) * (64*27 + 1) floats. */
+int vxb_conv3_c1_fwd_mfma(const float* u, const float* w, const float* bias, float* q, int B, int S, void* wfrag_ws,
+                          vxb_stream_t stream);
+int vxb_conv3_c1_wgrad_mfma(const float* u, const float* dq, float* dw, float* db, float* part_ws, int B, int S,
+                            vxb_stream_t stream);
+size_t vxb_conv3_c1_wgrad_mfma_blocks(int B, int S);
 
 /* SpatialSoftmax3D (T=0.01, meshgrid 'xy' quirk) + AdaptiveMaxPool3d(1) in one streaming pass
  * (network_utils.py:773-809; perceiver_lang_io.py:360,:451,:470), and the backward of both. */

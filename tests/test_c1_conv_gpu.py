@@ -36,3 +36,33 @@ def test_c1_forward_dgrad_wgrad(B, S):
     dw2, db2 = torch.zeros_like(dw), torch.zeros_like(dbb)
     ops.conv3_c1_wgrad(ud, dq.to(DEV), dw2, db2, B, S)
     assert torch.equal(dw, dw2) and torch.equal(dbb, db2)        # deterministic split reduction
+
+
+@pytest.mark.parametrize('mode', ['bf16x3', 'bf16'])
+@pytest.mark.parametrize('B,S', [(2, 12), (1, 16), (3, 4), (2, 7), (1, 21), (1, 2)])
+def test_c1_matrix_core_forward_and_wgrad(B, S, mode):
+    """taps as the MFMA column dimension (c1_mfma.hip): forward P = u w then a 27-point gather; weight gradient u^T Bq with
+    the clamped-tap adjoint folded into Bq.  bf16x3 products: same 2e-5 / 3e-5 bounds as the exact kernels."""
+    u = rnd(B, 64, S, S, S, seed=4).requires_grad_(True)
+    w1, b1 = rnd(1, 64, 3, 3, 3, seed=5, scale=0.1).requires_grad_(True), rnd(1, seed=6).requires_grad_(True)
+    q_ref = ref_conv(u.double(), w1.double(), b1.double())
+    dq = rnd(B, S, S, S, seed=7)
+    (q_ref[:, 0] * dq.double()).sum().backward()
+    ud = cl(u.detach()).to(DEV)
+    ops.PRECISION = mode
+    try:
+        assert ops.C1_MFMA
+        q = ops.conv3_c1_fwd(ud, w1.detach().to(DEV), b1.detach().to(DEV), B, S)
+        dw, dbb = torch.zeros(1, 64, 3, 3, 3, device=DEV), torch.zeros(1, device=DEV)
+        ops.conv3_c1_wgrad(ud, dq.to(DEV), dw, dbb, B, S)
+        dw2, db2 = torch.zeros_like(dw), torch.zeros_like(dbb)
+        ops.conv3_c1_wgrad(ud, dq.to(DEV), dw2, db2, B, S)
+        ops.C1_MFMA = False
+        q_exact = ops.conv3_c1_fwd(ud, w1.detach().to(DEV), b1.detach().to(DEV), B, S)
+    finally:
+        ops.PRECISION, ops.C1_MFMA = 'fp32', True
+    close(q, q_ref[:, 0].float(), 2e-5, 'c1 mfma fwd')
+    close(q, q_exact, 2e-5, 'c1 mfma fwd vs exact kernel')
+    close(dw, w1.grad.float(), 3e-5, 'c1 mfma wgrad')
+    close(dbb, b1.grad.float(), 3e-5, 'c1 mfma db')
+    assert torch.equal(dw, dw2) and torch.equal(dbb, db2)

@@ -606,8 +606,16 @@ def ss3d_max_bwd(x, bs, B, S, C, stats, out_ss, argmax, g_ss, g_max, dx, dbs, ac
     return dx
 
 
+C1_MFMA = True       # Cout = 1 conv of the translation head on the matrix cores in the bf16 / bf16x3 precisions
+
+
 def conv3_c1_fwd(u, w, bias, B, S):
     q = torch.empty((B, S, S, S), dtype=torch.float32, device=u.device)
+    if C1_MFMA and _mm() and u.shape[-1] == 64:
+        ws = torch.empty(4096, dtype=torch.bfloat16, device=u.device)
+        _lib.set_meta('vxb_conv3_c1_fwd_mfma', 0.0)
+        call('vxb_conv3_c1_fwd_mfma', u, w, bias, q, B, S, ws)
+        return q
     call('vxb_conv3_c1_fwd_f32', u, w, bias, q, B, S, 64)
     return q
 
@@ -618,6 +626,12 @@ def conv3_c1_dgrad(dq, w, u, du, B, S, accumulate=True, mask=True):
 
 
 def conv3_c1_wgrad(u, dq, dw, db, B, S):
+    if C1_MFMA and _mm() and u.shape[-1] == 64:
+        nb = int(_lib.lib().vxb_conv3_c1_wgrad_mfma_blocks(B, S))
+        ws = torch.empty(nb * (64 * 27 + 1), dtype=torch.float32, device=u.device)
+        _lib.set_meta('vxb_conv3_c1_wgrad_mfma', 0.0)
+        call('vxb_conv3_c1_wgrad_mfma', u, dq, dw, db, ws, B, S)
+        return
     nb = (B * S * S + 63) // 64
     ws = torch.empty(nb * (64 * 27 + 1), dtype=torch.float32, device=u.device)
     call('vxb_conv3_c1_wgrad_f32', u, dq, dw, db, ws, B, S, 64)
