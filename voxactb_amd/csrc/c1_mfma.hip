@@ -223,7 +223,25 @@ __global__ void __launch_bounds__(256, 2) c1_wgrad_mfma_kernel(const float* __re
         }
         __syncthreads();
         if (tile + 1 < t_end) issue(tile + 1);
-        // ---- Bq[v'][t]: 128 x 27 entries (columns 27..31 stay zero from the first tile on)
+        // ---- Bq[v'][t]: 128 x 27 entries (columns 27..31 are written as zeros).  A thread keeps its tap (tid & 31) and its
+        // w position ((tid >> 5) & 7) for all 16 entries; tiles that touch no face of the cube read one dq per entry at a
+        // compile-time offset from a per-thread base
+        const bool interior = d0 >= 1 && d0 + GT_D <= S - 1 && h0 >= 1 && h0 + GT_H <= S - 1 && w0 >= 1 && w0 + GT_W <= S - 1;
+        if (interior) {
+            const int tp = tid & 31, lw = tid >> 5;
+            const int tpc = tp < 27 ? tp : 0;
+            const float* dbase = dqh + ((2 - tpc / 9) * QH_H + 2 - (tpc / 3) % 3) * QH_W + 2 - tpc % 3 + lw;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int pos = lw + 8 * i;                         // lh = i & 7, ld = i >> 3
+                const float v = tp < 27 ? dbase[((i >> 3) * QH_H + (i & 7)) * QH_W] : 0.f;
+                const unsigned hb = __float_as_uint(v);
+                const unsigned h16 = (hb + 0x7fffu + ((hb >> 16) & 1u)) >> 16;
+                const unsigned rb = __float_as_uint(v - __uint_as_float(h16 << 16));
+                bs[pos * BLD + tp] = (u16)h16;
+                bs[BPL + pos * BLD + tp] = (u16)((rb + 0x7fffu + ((rb >> 16) & 1u)) >> 16);
+            }
+        } else
         for (int e = tid; e < 128 * 32; e += 256) {
             const int pos = e >> 5, tp = e & 31;
             float v = 0.f;
