@@ -26,7 +26,8 @@ def test_library_exports_all_declared_symbols():
 def test_workspace_size_query():
     from voxactb_amd import _lib
     n = _lib.lib().vxb_voxelize_workspace_bytes(16, 65536, 100)
-    assert n == (16 * 100 ** 3 + 16 + (16 * 65536 // 1024 + 16) + 7 * 16 * 65536) * 4
+    # count table + counters + per-block occupied counts + 7 per-point int arrays + the 8-float records of `place`
+    assert n == (16 * 100 ** 3 + 16 + (16 * 65536 // 1024 + 16) + 7 * 16 * 65536 + 4 + 8 * 16 * 65536) * 4
     assert _lib.lib().vxb_voxelize_workspace_bytes(0, 1, 1) == 0
 
 
