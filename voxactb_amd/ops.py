@@ -54,6 +54,10 @@ def split_bf16(w, x3=None):
     """fp32 [N][K] -> bf16 [N][K] ('bf16') or the hi/lo planes [2][N][K] of the 'bf16x3' split (lo = bf16(w - hi))."""
     if x3 is None:
         x3 = PRECISION == 'bf16x3'
+    if (w.is_cuda and w.dim() == 2 and w.dtype == torch.float32 and w.shape[1] % 4 == 0 and w.stride(1) == 1
+            and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0):
+        planes = split_planes(w, 2 if x3 else 1)          # one pass (vxb_split_bf16_f32) instead of five torch kernels
+        return planes if x3 else planes[0]
     hi = w.to(torch.bfloat16)
     if not x3:
         return hi
