@@ -84,6 +84,10 @@ int vxb_conv3d_wgrad_f32(const float* src0, const float* src1, int C0, int C1, i
  * positions i that clamp to j; optionally times LeakyReLU'(lrelu_of[b,j,c]) (the producer's activation). */
 int vxb_fold_pad_f32(const float* src, int Sp, int Cs, int c0, float* dst, const float* lrelu_of, int B, int S,
                      int C, int pad, int accumulate, float slope, vxb_stream_t stream);
+/* Rigid transform of a channels-first point cloud [B, 3, n] (apply_se3_augmentation / perturb_se3,
+ * peract/voxel/augmentation.py:36-57): dst[b, :, i] = (src[b, :, i] - t_b) R_b + c_b with points as ROW vectors;
+ * xf [B][15] = R_b (row-major 3x3), t_b (gripper position), c_b (new, clamped centre). */
+int vxb_se3_points_f32(const float* src, float* dst, const float* xf, int B, int64_t n, vxb_stream_t stream);
 /* bf16 matrix-core twins ("throughput mode", v_mfma_f32_32x32x16_bf16, fp32 accumulate): the fp32 A operand is rounded
  * to bf16 (RNE) while it is staged into LDS; weights come as bf16 [N][K] (K contiguous, K % 8 == 0; C0, C1 % 32 == 0). */
 int vxb_gemm_bf16w_f32(const float* A, int64_t lda, const void* Bw, float* C, int64_t ldc, const float* bias,

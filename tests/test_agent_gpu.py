@@ -106,3 +106,24 @@ def test_se3_augmentation_path_runs(golden):
     torch.manual_seed(0)
     l0 = float(agent.update(0, raw_batch(g, 'a', 10))['total_losses'])
     assert np.isfinite(l0) and 5.0 < l0 < 40.0
+
+
+def test_se3_point_transform_kernel_matches_the_row_vector_formula():
+    """vxb_se3_points_f32 against reference augmentation.py:36-57 evaluated with torch on the host: p' = (p - t) R + c,
+    points as row vectors, centre clamped to the batch-wide bounds; pose matrices on the host, clouds on the device."""
+    from voxactb_amd.voxel import augmentation as aug
+    torch.manual_seed(3)
+    bs, H, W = 5, 16, 12
+    pcd = [torch.randn(bs, 3, H, W), torch.randn(bs, 3, H, W) * 0.3 + 0.2]
+    eye = torch.eye(4).unsqueeze(0).repeat(bs, 1, 1)
+    tr, rot, grip = eye.clone(), eye.clone(), eye.clone()
+    tr[:, :3, 3] = torch.randn(bs, 3) * 0.1
+    rot[:, :3, :3] = aug.euler_angles_to_matrix(torch.randn(bs, 3), 'XYZ')
+    grip[:, :3, :3] = aug.euler_angles_to_matrix(torch.randn(bs, 3), 'XYZ')
+    grip[:, :3, 3] = torch.rand(bs, 3) * 0.5
+    bounds = torch.tensor([[-0.3, -0.5, 0.6, 0.7, 0.5, 1.6]])
+    want = aug.perturb_se3(pcd, tr, rot, grip, bounds)                       # host tensors: the torch formula
+    got = aug.perturb_se3([p.to('cuda:0') for p in pcd], tr, rot, grip, bounds)
+    for w_, g_ in zip(want, got):
+        assert g_.is_cuda and g_.shape == w_.shape
+        assert float((g_.cpu() - w_).abs().max()) < 2e-6

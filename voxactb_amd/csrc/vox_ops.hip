@@ -981,3 +981,33 @@ extern "C" int vxb_lamb_step_f32(float* w, const float* g, float* m, float* v, f
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
+
+// ---- rigid transform of a channels-first point cloud (SE(3) augmentation, peract/voxel/augmentation.py:36-57):
+//      dst[b, j, n] = sum_k (src[b, k, n] - xf[b][9 + k]) * xf[b][3 k + j] + xf[b][12 + j]
+// xf [B][15] = rotation R (row-major; points are rotated as ROW vectors, p' = p R), gripper position, new centre.
+// Replaces the reshape / subtract / bmm / transpose / add chain (five kernels and a K = 3 batched GEMM per camera).
+namespace {
+__global__ void __launch_bounds__(256) se3_points_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                         const float* __restrict__ xf, long long n) {
+    const int b = blockIdx.y;
+    const float* x = xf + b * 15;
+    const float r00 = x[0], r01 = x[1], r02 = x[2], r10 = x[3], r11 = x[4], r12 = x[5], r20 = x[6], r21 = x[7], r22 = x[8];
+    const float t0 = x[9], t1 = x[10], t2 = x[11], c0 = x[12], c1 = x[13], c2 = x[14];
+    const float* s = src + (long long)b * 3 * n;
+    float* d = dst + (long long)b * 3 * n;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float p0 = s[i] - t0, p1 = s[n + i] - t1, p2 = s[2 * n + i] - t2;
+        d[i] = fmaf(p2, r20, fmaf(p1, r10, p0 * r00)) + c0;
+        d[n + i] = fmaf(p2, r21, fmaf(p1, r11, p0 * r01)) + c1;
+        d[2 * n + i] = fmaf(p2, r22, fmaf(p1, r12, p0 * r02)) + c2;
+    }
+}
+}  // namespace
+
+extern "C" int vxb_se3_points_f32(const float* src, float* dst, const float* xf, int B, int64_t n, vxb_stream_t stream) {
+    if (!src || !dst || !xf || B < 1 || n < 1) return VXB_EARG;
+    const int gx = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+    hipLaunchKernelGGL(se3_points_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, src, dst, xf, (long long)n);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}

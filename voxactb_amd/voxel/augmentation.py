@@ -7,9 +7,9 @@ every sample is discretised with `bounds[0]` when layer == 0 (:161-162), points 
 any translation index is negative (:116), at most 100 attempts (:119-120).
 
 The three pytorch3d==0.3.0 helpers the reference imports (not vendored upstream) are restated from their published
-definition -- see oracle/se3.py for the pinning caveat.  The 4x4 / label arithmetic is host-side exactly as upstream
-(B tiny float64 numpy evaluations); the point transform runs on the device.  Fusing the rigid transform into the
-voxelizer's point load is the first "next" row of SURVEY.md section 8(f).
+definition -- see oracle/se3.py for the pinning caveat.  The 4x4 / label arithmetic runs on the host (B tiny
+evaluations, one device -> host copy of the poses); the point transform is one fused HIP kernel per camera.  Fusing it
+into the voxelizer's point load is the first "next" row of SURVEY.md section 8(f).
 """
 import numpy as np
 import torch
@@ -86,7 +86,10 @@ def matrix_to_quaternion(m):
 
 
 def perturb_se3(pcd, trans_shift_4x4, rot_shift_4x4, action_gripper_4x4, bounds):
-    """reference :7-65.  pcd: list of [bs,3,H,W]."""
+    """reference :7-65.  pcd: list of [bs,3,H,W].  The pose matrices / bounds may live on the host (that is where
+    apply_se3_augmentation does its B tiny 4x4 evaluations) while the clouds are on the device: rotation, gripper position
+    and the clamped new centre go up as ONE [bs, 15] tensor and every camera is transformed by one fused kernel
+    (vxb_se3_points_f32) instead of a reshape / subtract / bmm / transpose / add chain."""
     bs = pcd[0].shape[0]
     if bounds.shape[0] != bs:
         bounds = bounds.repeat(bs, 1)
@@ -95,6 +98,16 @@ def perturb_se3(pcd, trans_shift_4x4, rot_shift_4x4, action_gripper_4x4, bounds)
     t_grip = action_gripper_4x4[:, 0:3, 3]
     centre = torch.max(torch.min(t_grip + trans_shift_4x4[:, 0:3, 3], hi), lo)
     R = rot_shift_4x4[:, :3, :3]
+    if pcd[0].is_cuda:
+        from .._lib import call
+        xf = torch.cat([R.reshape(bs, 9), t_grip, centre], dim=1).float().contiguous().to(pcd[0].device)
+        out = []
+        for p in pcd:
+            pc = p.float().contiguous()
+            o = torch.empty_like(pc)
+            call('vxb_se3_points_f32', pc, o, xf, bs, pc.numel() // (bs * 3))
+            out.append(o)
+        return out
     out = []
     for p in pcd:
         flat = p.reshape(bs, 3, -1) - t_grip.unsqueeze(-1)
@@ -105,37 +118,42 @@ def perturb_se3(pcd, trans_shift_4x4, rot_shift_4x4, action_gripper_4x4, bounds)
 
 def apply_se3_augmentation(pcd, action_gripper_pose, action_trans, action_rot_grip, bounds, layer, trans_aug_range,
                            rot_aug_range, rot_aug_resolution, voxel_size, rot_resolution, device):
-    """reference :68-185."""
+    """reference :68-185.  The pose / label arithmetic (B 4x4 matrices, one scipy call per sample) runs on the HOST --
+    upstream evaluates it with ~80 tiny device kernels and several device->host copies per attempt, which on this path
+    was 5 ms of an otherwise idle GPU at the start of every step; the random streams were host-side already.  Only the
+    point clouds are touched on the device."""
     bs = pcd[0].shape[0]
-    identity_4x4 = torch.eye(4).unsqueeze(0).repeat(bs, 1, 1).to(device=device)
-    action_gripper_trans = action_gripper_pose[:, :3]
-    q_wxyz = torch.cat((action_gripper_pose[:, 6].unsqueeze(1), action_gripper_pose[:, 3:6]), dim=1)
+    host = torch.device('cpu')
+    pose_h = action_gripper_pose.detach().to(host).float()
+    bounds_h = bounds.detach().to(host).float()
+    grip_np = action_rot_grip.detach().cpu().numpy()
+    identity_4x4 = torch.eye(4).unsqueeze(0).repeat(bs, 1, 1)
+    q_wxyz = torch.cat((pose_h[:, 6].unsqueeze(1), pose_h[:, 3:6]), dim=1)
     action_gripper_4x4 = identity_4x4.detach().clone()
     action_gripper_4x4[:, :3, :3] = quaternion_to_matrix(q_wxyz)
-    action_gripper_4x4[:, 0:3, 3] = action_gripper_trans
-    perturbed_trans = torch.full_like(action_trans, -1.)
-    perturbed_rot_grip = torch.full_like(action_rot_grip, -1.)
-    bounds_np = bounds.detach().cpu().numpy()
-    grip_np = action_rot_grip.detach().cpu().numpy()
+    action_gripper_4x4[:, 0:3, 3] = pose_h[:, :3]
+    perturbed_trans = torch.full(tuple(action_trans.shape), -1.)
+    perturbed_rot_grip = torch.full(tuple(action_rot_grip.shape), -1.)
+    bounds_np = bounds_h.numpy()
     attempts = 0
     while torch.any(perturbed_trans < 0):
         attempts += 1
         if attempts > 100:
             raise Exception('Failing to perturb action and keep it within bounds.')
-        trans_range = (bounds[:, 3:] - bounds[:, :3]) * trans_aug_range.to(device=device)
-        trans_shift = trans_range * rand_dist((bs, 3)).to(device=device)
+        trans_range = (bounds_h[:, 3:] - bounds_h[:, :3]) * trans_aug_range.to(host)
+        trans_shift = trans_range * rand_dist((bs, 3))
         trans_shift_4x4 = identity_4x4.detach().clone()
         trans_shift_4x4[:, 0:3, 3] = trans_shift
         steps = [int(r // rot_aug_resolution) for r in rot_aug_range]
         rpy = [rand_discrete((bs, 1), min=-n, max=n) * np.deg2rad(rot_aug_resolution) for n in steps]
-        rot_shift_3x3 = euler_angles_to_matrix(torch.cat(rpy, dim=1), "XYZ")
+        rot_shift_3x3 = euler_angles_to_matrix(torch.cat(rpy, dim=1).float(), "XYZ")
         rot_shift_4x4 = identity_4x4.detach().clone()
         rot_shift_4x4[:, :3, :3] = rot_shift_3x3
         perturbed = torch.bmm(action_gripper_4x4, rot_shift_4x4)
         perturbed[:, 0:3, 3] += trans_shift
-        p_trans = perturbed[:, 0:3, 3].cpu().numpy()
+        p_trans = perturbed[:, 0:3, 3].numpy()
         q = matrix_to_quaternion(perturbed[:, :3, :3])
-        q_xyzw = torch.cat([q[:, 1:], q[:, 0].unsqueeze(1)], dim=1).cpu().numpy()
+        q_xyzw = torch.cat([q[:, 1:], q[:, 0].unsqueeze(1)], dim=1).numpy()
         trans_idx, rot_grip_idx = [], []
         for b in range(bs):
             bnp = bounds_np[b if layer > 0 else 0]
@@ -144,7 +162,7 @@ def apply_se3_augmentation(pcd, action_gripper_pose, action_trans, action_rot_gr
             if quat[-1] < 0:
                 quat = -quat
             rot_grip_idx.append(quaternion_to_discrete_euler(quat, rot_resolution).tolist() + [int(grip_np[b, 3])])
-        perturbed_trans = torch.from_numpy(np.array(trans_idx)).to(device=device)
-        perturbed_rot_grip = torch.from_numpy(np.array(rot_grip_idx)).to(device=device)
-    pcd = perturb_se3(pcd, trans_shift_4x4, rot_shift_4x4, action_gripper_4x4, bounds)
-    return perturbed_trans, perturbed_rot_grip, pcd
+        perturbed_trans = torch.from_numpy(np.array(trans_idx))
+        perturbed_rot_grip = torch.from_numpy(np.array(rot_grip_idx))
+    pcd = perturb_se3(pcd, trans_shift_4x4, rot_shift_4x4, action_gripper_4x4, bounds_h)
+    return perturbed_trans.to(device=device), perturbed_rot_grip.to(device=device), pcd
