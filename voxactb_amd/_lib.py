@@ -114,17 +114,34 @@ def call(name, *args):
     _call(name, *args)
 
 
+_FNS = {}
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _call(name, *args):
+    # (hot: ~550 calls per training step -- plain ints for pointers, the raw current-stream handle of the first tensor's
+    # device; ctypes converts them through the argtypes parsed from the header)
+    fn = _FNS.get(name)
+    if fn is None:
+        fn = _FNS[name] = getattr(lib(), name)
     conv = []
+    dev = -1
     for a in args:
-        if torch.is_tensor(a):
-            conv.append(ctypes.c_void_p(a.data_ptr()))
+        if isinstance(a, torch.Tensor):
+            if not a.is_cuda:
+                raise VoxactbHipError('%s: tensor on %s -- the kernels need a HIP device (no CPU fallback)' % (name, a.device))
+            conv.append(a.data_ptr())
+            if dev < 0:
+                dev = a.get_device()
         elif a is None:
-            conv.append(ctypes.c_void_p(0))
+            conv.append(0)
         else:
             conv.append(a)
-    rc = getattr(lib(), name)(*conv, stream_ptr())
-    check(rc, name)
+    if _raw_stream is not None and dev >= 0:
+        st = _raw_stream(dev)
+    else:
+        st = torch.cuda.current_stream(dev if dev >= 0 else None).cuda_stream
+    check(fn(*conv, st), name)
 
 
 def stream_ptr(device=None):
