@@ -50,12 +50,12 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % a.gpus
+    torch.cuda.set_device(local_rank)          # one process per GPU; bind before the communicator is created
+    dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world)      # backend "nccl" == RCCL on ROCm
-    assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % a.gpus
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
 
     from voxactb_amd import _lib, synthetic
     from voxactb_amd.agents.peract_bc import launch_utils as lu

@@ -1,0 +1,98 @@
+"""GPU, BASELINE.json config-2 geometry (100^3 voxels, 4 cameras 128x128, PerceiverIO depth 6 / 2048 latents) at B = 2:
+size-independent properties of the whole path through the C ABI.  The reference cannot run here and the CPU oracle
+needs ~6 s per sample at this size, so the checks are (a) two independent kernel families agreeing -- the default
+'bf16x3' precision against the exact-fp32 matrix-core kernels -- inside the 1e-4 north-star bound on every Q head and
+inside 1e-2 (max and L2, relative) on every parameter gradient -- activation-mask flips, see below, (b) run-to-run determinism, (c) occupancy bookkeeping
+of the voxel grid that feeds it."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+V, B, HW = 100, 2, 128
+
+
+@pytest.fixture(scope='module')
+def rig():
+    from voxactb_amd import synthetic
+    from voxactb_amd.agents.peract_bc import launch_utils as lu
+    cfg = lu.default_cfg(method__voxel_sizes=[V], method__voxel_patch_size=5, method__voxel_patch_stride=5,
+                         method__transformer_depth=6, method__num_latents=2048, replay__batch_size=B,
+                         rlbench__camera_resolution=[HW, HW], ddp__num_devices=1)
+    torch.manual_seed(77)
+    agent = lu.create_agent(cfg)
+    agent.build(training=True, device=0)
+    qa = agent._pose_agent._qattention_agents[0]
+    rs = {k: v.to(DEV) for k, v in synthetic.make_replay_sample(B, cfg.rlbench.cameras, (HW, HW), V, 4, seed=11).items()}
+    pcd = [rs['%s_point_cloud' % c][:, 0] for c in cfg.rlbench.cameras]
+    rgb = [(rs['%s_rgb' % c][:, 0].float() / 255.0) * 2.0 - 1.0 for c in cfg.rlbench.cameras]     # PreprocessAgent's normalisation
+    grid = qa._q.voxelize([[r, p] for r, p in zip(rgb, pcd)], pcd, qa._coordinate_bounds.to(DEV))
+    prop = rs['low_dim_state'][:, 0].float() if rs['low_dim_state'].dim() > 2 else rs['low_dim_state'].float()
+    lang = rs['lang_token_embs'][:, 0].float() if rs['lang_token_embs'].dim() > 3 else rs['lang_token_embs'].float()
+    return dict(agent=agent, qa=qa, eng=qa._q.encoder.engine(), grid=grid, prop=prop, lang=lang, pcd=pcd, rgb=rgb)
+
+
+def test_voxel_grid_bookkeeping(rig):
+    g = rig['grid']
+    assert g.shape == (B, V, V, V, 10)
+    occ = g[..., 9]
+    assert set(torch.unique(occ).tolist()) <= {0.0, 1.0}
+    n_occ = int(occ.sum())
+    assert 0 < n_occ <= B * 4 * HW * HW
+    # empty cells: zero features; every cell carries its own index / V in channels 6..8 (voxel_grid.py:192-198)
+    assert float(g[..., :6][occ == 0].abs().max()) == 0.0
+    idx = (torch.arange(V, dtype=torch.float32) / V).to(DEV)          # IEEE division on the host, as the reference's CPU path
+    assert torch.equal(g[0, :, 0, 0, 6], idx) and torch.equal(g[1, 0, :, 0, 7], idx) and torch.equal(g[0, 0, 0, :, 8], idx)
+    again = rig['qa']._q.voxelize([[r, p] for r, p in zip(rig['rgb'], rig['pcd'])], rig['pcd'], rig['qa']._coordinate_bounds.to(DEV))
+    assert torch.equal(again, g)                                    # deterministic, bit for bit
+
+
+def _run(eng, rig, mode, backward):
+    eng.precision = mode
+    outs, cache = eng.forward(rig['grid'], rig['prop'], rig['lang'], training=False, save=backward)
+    outs = [o.float().clone() for o in outs[:3]]
+    grads = None
+    if backward:
+        arena = rig['qa']._arena
+        arena.zero_grad()
+        torch.manual_seed(5)
+        dq = (torch.randn(B, V ** 3, device=DEV) * 1e-3).contiguous()
+        d_o = torch.randn_like(cache['o']) * 1e-1
+        eng.backward(cache, dq, d_o, None)
+        grads = {n: p.grad.clone() for n, p in rig['qa']._q.named_parameters()}
+    return outs, grads
+
+
+def test_q_values_and_gradients_agree_across_kernel_families(rig):
+    eng = rig['eng']
+    keep = eng.precision
+    try:
+        o3, g3 = _run(eng, rig, 'bf16x3', True)
+        o3b, _ = _run(eng, rig, 'bf16x3', False)
+        o1, g1 = _run(eng, rig, 'fp32', True)
+    finally:
+        eng.precision = keep
+    for a, b in zip(o3, o3b):
+        assert torch.equal(a, b)                                    # run-to-run deterministic
+    for name, a, b in zip(('q_trans', 'rot_grip', 'collision'), o3, o1):
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) < 1e-4 * max(1.0, float(b.abs().max())), name      # the north-star bound, at full size
+    worst = 0.0
+    report = []
+    for n in g1:
+        ref = g1[n]
+        den = float(ref.abs().max())
+        if den == 0.0:
+            assert float(g3[n].abs().max()) == 0.0, n
+            continue
+        err = float((g3[n] - ref).abs().max()) / den
+        l2 = float((g3[n] - ref).norm() / ref.norm())
+        worst = max(worst, err)
+        report.append((err, l2, n))
+    report.sort(reverse=True)
+    print('\n'.join('%.2e max-rel  %.2e l2-rel  %s' % r for r in report[:12]))
+    # 1e-5 differences in the forward flip the LeakyReLU mask / max-pool winner of the ~1e-5 fraction of activations that sit
+    # that close to the kink; each flip changes a gradient term by O(1), i.e. ~sqrt(1e-5) = 3e-3 in relative L2 -- the same
+    # effect bounds the fixture-based gradient tests (tests/test_encoder_gpu.py, 3e-3 at small sizes)
+    assert report[0][0] < 1e-2 and max(r[1] for r in report) < 1e-2, report[0]
+    assert worst > 0.0                                              # (two different kernel families really ran)
