@@ -211,7 +211,9 @@ int vxb_conv3_c1_wgrad_mfma(const float* u, const float* dq, float* dw, float* d
 size_t vxb_conv3_c1_wgrad_mfma_blocks(int B, int S);
 
 /* SpatialSoftmax3D (T=0.01, meshgrid 'xy' quirk) + AdaptiveMaxPool3d(1) in one streaming pass
- * (network_utils.py:773-809; perceiver_lang_io.py:360,:451,:470), and the backward of both. */
+ * (network_utils.py:773-809; perceiver_lang_io.py:360,:451,:470), and the backward of both.
+ * part_ws: B * nchunk * C * 7 floats with nchunk = ceil(S^2 / max(1, S^2 / want)), want = max(64, ceil(1024 / B))
+ * (the (d, h) rows of a sample are cut into >= 1024 / B chunks so that small batches still fill the chip). */
 int vxb_ss3d_max_fwd_f32(const float* x, int64_t bs, int B, int S, int C, const float* lin, float* part_ws,
                          float* out_ss, float* out_max, float* stats, int32_t* argmax, vxb_stream_t stream);
 int vxb_ss3d_max_bwd_f32(const float* x, int64_t bs, int B, int S, int C, const float* lin, const float* stats,
@@ -228,6 +230,10 @@ int vxb_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, c
 /* attention softmax + dropout (perceiver_lang_io.py:124-128), counter-based keep mask (seed,row,col). */
 int vxb_softmax_rows_f32(float* S, float* P_drop, int64_t rows, int cols, int64_t ld, float dropout_p,
                          uint32_t seed, vxb_stream_t stream);
+/* In-place softmax of a few very long rows (the V^3-wide translation softmax of act(),
+ * qattention_peract_bc_agent.py:705-707): rows are cut into 8192-column chunks over many workgroups.
+ * ws: rows * ceil(cols / 8192) * 2 floats of scratch. */
+int vxb_softmax_long_rows_f32(float* S, float* ws, int64_t rows, int cols, int64_t ld, vxb_stream_t stream);
 int vxb_softmax_bwd_rows_f32(const float* P, float* dP_inout, int64_t rows, int cols, int64_t ld, float scale,
                              float dropout_p, uint32_t seed, vxb_stream_t stream);
 

@@ -28,3 +28,18 @@ def test_colsum_strided_rows_take_the_general_path():
     out = torch.empty(64, device=DEV)
     ops.colsum(x.to(DEV)[:, 64:128], out)
     close(out, x[:, 64:128].double().sum(0).float(), 2e-5, 'colsum strided')
+
+
+@pytest.mark.parametrize('rows,cols', [(1, 1000000), (3, 70001), (2, 65536)])
+def test_softmax_long_rows_matches_torch(rows, cols):
+    """the multi-workgroup softmax of a few very long rows (act(): B x V^3) against torch's softmax in float64."""
+    import torch
+    from voxactb_amd import ops
+    ld = (cols + 3) & ~3
+    x = torch.randn(rows, ld, device='cuda:0') * 3.0
+    want = torch.softmax(x[:, :cols].double(), dim=1)
+    got = ops.softmax_rows(x.clone(), rows, cols, ld)
+    assert float((got[:, :cols].double() - want).abs().max()) < 1e-9 + 2e-6 * float(want.max())
+    assert abs(float(got[:, :cols].double().sum(1).max()) - 1.0) < 1e-5
+    if ld > cols:
+        assert float(got[:, cols:].abs().max()) == 0.0

@@ -233,6 +233,54 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ S
     for (int c = cols + threadIdx.x; c < ld; c += 256) { s[c] = 0.f; if (Pd) Pd[row * ld + c] = 0.f; }
 }
 
+// ---- long rows (the V^3-wide translation softmax of act(), qattention_peract_bc_agent.py:705): one workgroup per row
+// takes 1.9 ms for 10^6 columns at B = 1; here a row is cut into 8192-column chunks -- pass 1 leaves (max, sum exp) per
+// chunk, pass 2 lets every chunk's workgroup combine the row's partials (fixed order) and normalise its own columns.
+constexpr int SM_CHUNK = 8192;
+__global__ void __launch_bounds__(256) softmax_long_part_kernel(const float* __restrict__ S, float2* __restrict__ part, int cols,
+                                                                long long ld, int nchunk) {
+    __shared__ float red[4];
+    const int row = blockIdx.y, ch = blockIdx.x;
+    const float* s = S + (long long)row * ld;
+    const int c0 = ch * SM_CHUNK, c1 = min(cols, c0 + SM_CHUNK);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float m = -INFINITY;
+    for (int c = c0 + threadIdx.x; c < c1; c += 256) m = fmaxf(m, s[c]);
+    m = wave_max(m);
+    if (lane == 0) red[wid] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int c = c0 + threadIdx.x; c < c1; c += 256) sum += expf(s[c] - m);
+    sum = wave_sum(sum);
+    if (lane == 0) red[wid] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(long long)row * nchunk + ch] = make_float2(m, (red[0] + red[1]) + (red[2] + red[3]));
+}
+__global__ void __launch_bounds__(256) softmax_long_norm_kernel(float* __restrict__ S, const float2* __restrict__ part, int cols,
+                                                                long long ld, int nchunk) {
+    __shared__ float s_m, s_inv;
+    const int row = blockIdx.y, ch = blockIdx.x;
+    const float2* pr = part + (long long)row * nchunk;
+    if (threadIdx.x < 64) {
+        float m = -INFINITY;
+        for (int i = threadIdx.x; i < nchunk; i += 64) m = fmaxf(m, pr[i].x);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int i = threadIdx.x; i < nchunk; i += 64) sum += pr[i].y * expf(pr[i].x - m);
+        sum = wave_sum(sum);
+        if (threadIdx.x == 0) { s_m = m; s_inv = 1.0f / sum; }
+    }
+    __syncthreads();
+    const float m = s_m, inv = s_inv;
+    float* s = S + (long long)row * ld;
+    const int c0 = ch * SM_CHUNK, c1 = min(cols, c0 + SM_CHUNK);
+    for (int c = c0 + threadIdx.x; c < c1; c += 256) s[c] = expf(s[c] - m) * inv;
+    if (ch == nchunk - 1)
+        for (long long c = cols + threadIdx.x; c < ld; c += 256) s[c] = 0.f;
+}
+
 // dS = scale * P * (dP - sum(dP*P)),  dP = dPd * keep/(1-p); written over dPd
 __global__ void __launch_bounds__(256) softmax_bwd_rows_kernel(const float* __restrict__ P, float* __restrict__ dPd, int cols,
                                                                long long ld, float scale, float p, unsigned seed) {
@@ -452,6 +500,19 @@ extern "C" int vxb_softmax_rows_f32(float* S, float* P_drop, int64_t rows, int c
     if (rows >= INT32_MAX) return VXB_ESIZE;
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, S,
                        dropout_p > 0.f ? P_drop : nullptr, cols, (long long)ld, dropout_p, seed);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+// in-place softmax of a few very long rows (no dropout): ws = rows * ceil(cols / 8192) * 2 floats of scratch
+extern "C" int vxb_softmax_long_rows_f32(float* S, float* ws, int64_t rows, int cols, int64_t ld, vxb_stream_t stream) {
+    if (!S || !ws || rows < 1 || cols < 1 || ld < cols) return VXB_EARG;
+    if (rows > 65535) return VXB_ESIZE;
+    const int nchunk = (cols + SM_CHUNK - 1) / SM_CHUNK;
+    hipLaunchKernelGGL(softmax_long_part_kernel, dim3(nchunk, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, S, (float2*)ws,
+                       cols, (long long)ld, nchunk);
+    hipLaunchKernelGGL(softmax_long_norm_kernel, dim3(nchunk, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, S,
+                       (const float2*)ws, cols, (long long)ld, nchunk);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }

@@ -282,6 +282,34 @@ __global__ void __launch_bounds__(256) ss_final_kernel(const SsPart* __restrict_
     argmax[i] = r.arg;
 }
 
+// stage 2 for many chunks (small batches cut a sample into up to 1024 chunks): one workgroup per (b, c), threads merge a
+// strided subset of the chunks, then a fixed-order tree over the 256 partial results
+__global__ void __launch_bounds__(256) ss_final_wide_kernel(const SsPart* __restrict__ part, int nchunk, int B, int C,
+                                                            float* __restrict__ out_ss, float* __restrict__ out_max,
+                                                            float* __restrict__ stats, int* __restrict__ argmax) {
+    __shared__ SsPart red[256];
+    const int i = blockIdx.x, b = i / C, c = i % C;
+    SsPart r;
+    r.m = -INFINITY; r.s = 0.f; r.sx = 0.f; r.sy = 0.f; r.sz = 0.f; r.xmax = -INFINITY; r.arg = 0x7fffffff;
+    for (int k = threadIdx.x; k < nchunk; k += 256) ss_merge(r, part[((long long)b * nchunk + k) * C + c]);
+    red[threadIdx.x] = r;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { SsPart a = red[threadIdx.x]; ss_merge(a, red[threadIdx.x + o]); red[threadIdx.x] = a; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        r = red[0];
+        out_ss[(long long)b * 3 * C + 3 * c + 0] = r.sx / r.s;
+        out_ss[(long long)b * 3 * C + 3 * c + 1] = r.sy / r.s;
+        out_ss[(long long)b * 3 * C + 3 * c + 2] = r.sz / r.s;
+        out_max[i] = r.xmax;
+        stats[2 * i] = r.m;
+        stats[2 * i + 1] = r.s;
+        argmax[i] = r.arg;
+    }
+}
+
 // float4 variant of the backward pass below (same formula per element; 4 channels per thread, 4 voxels in flight)
 __global__ void __launch_bounds__(256) ss_bwd4_kernel(const float* __restrict__ x, long long bs, int S, int C,
                                                       const float* __restrict__ lin, const float* __restrict__ stats,
@@ -839,19 +867,27 @@ extern "C" int vxb_pointwise_wgrad_f32(const float* x, const float* y, const flo
 
 // x: [B, S^3, C] with batch stride bs (elements).  part_ws: B*nchunk*C*7 floats, nchunk = ceil(S*S / rows_per_chunk),
 // rows_per_chunk = max(1, S*S/64).  Outputs: out_ss [B,3C], out_max [B,C], stats [B,C,2], argmax [B,C] (int32).
+static inline int vxb_ss3d_chunks(int B) { const int w = (1024 + B - 1) / B; return w < 64 ? 64 : w; }
+
 extern "C" int vxb_ss3d_max_fwd_f32(const float* x, int64_t bs, int B, int S, int C, const float* lin, float* part_ws,
                                     float* out_ss, float* out_max, float* stats, int32_t* argmax, vxb_stream_t stream) {
     if (!x || !lin || !part_ws || !out_ss || !out_max || !stats || !argmax || B < 1 || S < 1) return VXB_EARG;
     if (C != 64 && C != 128) return VXB_ESIZE;
     hipStream_t st = (hipStream_t)stream;
-    const int rpc = (S * S / 64) < 1 ? 1 : S * S / 64;
+    // >= 1024 workgroups per launch: 64 chunks of (d, h) rows per sample at B >= 16, more for small batches (act(): B = 1)
+    const int want = vxb_ss3d_chunks(B);
+    const int rpc = (S * S / want) < 1 ? 1 : S * S / want;
     const int nchunk = vxb_cdiv(S * S, rpc);
     if ((bs & 3) == 0 && (((uintptr_t)x) & 15) == 0)
         hipLaunchKernelGGL(ss_part4_kernel, dim3(nchunk, B), dim3(256), 0, st, x, (long long)bs, S, C, lin, rpc, (SsPart*)part_ws, nchunk, 0.01f);
     else
         hipLaunchKernelGGL(ss_part_kernel, dim3(nchunk, B), dim3(256), 0, st, x, (long long)bs, S, C, lin, rpc, (SsPart*)part_ws, nchunk, 0.01f);
-    hipLaunchKernelGGL(ss_final_kernel, dim3(vxb_cdiv(B * C, 256)), dim3(256), 0, st, (const SsPart*)part_ws, nchunk, B, C, out_ss,
-                       out_max, stats, argmax);
+    if (nchunk > 128)
+        hipLaunchKernelGGL(ss_final_wide_kernel, dim3(B * C), dim3(256), 0, st, (const SsPart*)part_ws, nchunk, B, C, out_ss,
+                           out_max, stats, argmax);
+    else
+        hipLaunchKernelGGL(ss_final_kernel, dim3(vxb_cdiv(B * C, 256)), dim3(256), 0, st, (const SsPart*)part_ws, nchunk, B, C, out_ss,
+                           out_max, stats, argmax);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }

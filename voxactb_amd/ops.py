@@ -191,6 +191,11 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_d
 
 def softmax_rows(S, rows, cols, ld, p=0.0, seed=0):
     """in place S -> P; returns P_drop (== S itself when p == 0)."""
+    if p == 0 and cols >= 65536 and rows <= 1024:
+        # a handful of very long rows (act(): B x V^3): many workgroups per row instead of one
+        ws = torch.empty(rows * ((cols + 8191) // 8192) * 2, dtype=torch.float32, device=S.device)
+        call('vxb_softmax_long_rows_f32', S, ws, rows, cols, ld)
+        return S
     Pd = torch.empty_like(S) if p > 0 else None
     call('vxb_softmax_rows_f32', S, Pd, rows, cols, ld, float(p), int(seed) & 0xFFFFFFFF)
     return Pd if p > 0 else S
@@ -593,7 +598,8 @@ def lin_table(S, device):
 
 def ss3d_max_fwd(x, bs, B, S, C):
     dev = x.device
-    rpc = max(1, S * S // 64)
+    want = max(64, (1024 + B - 1) // B)            # same rule as vxb_ss3d_max_fwd_f32: >= 1024 workgroups per launch
+    rpc = max(1, S * S // want)
     nchunk = (S * S + rpc - 1) // rpc
     ws = torch.empty(B * nchunk * C * 7, dtype=torch.float32, device=dev)
     out_ss = torch.empty((B, 3 * C), dtype=torch.float32, device=dev)
