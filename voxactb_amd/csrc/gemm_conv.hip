@@ -751,7 +751,11 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs g, const u16* _
 
 template <int AMODE, int X3>
 int launch_gemm_bf16(const GemmArgs& g, const u16* Bw, hipStream_t st) {
-    if (g.N > 64) {
+    if (AMODE == 0 && g.N > 64 && (long long)vxb_cdiv(g.N, 128) * vxb_cdiv(g.M, 128) < 192) {
+        // few rows (act(): M = 2048 latents): 64 x 64 tiles fill the chip four times better; same k order, same sums
+        dim3 grid(vxb_cdiv(g.N, 64), vxb_cdiv(g.M, 64), 1);
+        hipLaunchKernelGGL((gemm_bf16_kernel<AMODE == 0 ? 0 : AMODE, 64, 64, 2, 2, X3>), grid, dim3(256), 0, st, g, Bw);
+    } else if (g.N > 64) {
         dim3 grid(vxb_cdiv(g.N, 128), vxb_cdiv(g.M, 128), 1);
         hipLaunchKernelGGL((gemm_bf16_kernel<AMODE, 128, 128, 2, 2, X3>), grid, dim3(256), 0, st, g, Bw);
     } else {
