@@ -96,3 +96,40 @@ def test_q_values_and_gradients_agree_across_kernel_families(rig):
     # effect bounds the fixture-based gradient tests (tests/test_encoder_gpu.py, 3e-3 at small sizes)
     assert report[0][0] < 1e-2 and max(r[1] for r in report) < 1e-2, report[0]
     assert worst > 0.0                                              # (two different kernel families really ran)
+
+
+def test_largest_grid_forward_agrees_across_kernel_families():
+    """BASELINE.json configs[4] geometry (200^3 voxels, 40^3 patches, 8.0e6 voxels per sample) at B = 1, forward only:
+    the default 'bf16x3' kernels (LDS-halo convs, tap-list polyphase, fused attention, matrix-core Cout = 1 conv) against
+    the exact-fp32 generic kernels -- 32-bit index arithmetic and tile edge handling at the maximum size."""
+    from voxactb_amd import synthetic
+    from voxactb_amd.agents.peract_bc import launch_utils as lu
+    V2, HW2 = 200, 128
+    cfg = lu.default_cfg(method__voxel_sizes=[V2], method__voxel_patch_size=5, method__voxel_patch_stride=5,
+                         method__transformer_depth=2, method__num_latents=512, replay__batch_size=1,
+                         rlbench__camera_resolution=[HW2, HW2], ddp__num_devices=1)
+    torch.manual_seed(78)
+    agent = lu.create_agent(cfg)
+    agent.build(training=False, device=0)
+    qa = agent._pose_agent._qattention_agents[0]
+    rs = {k: v.to(DEV) for k, v in synthetic.make_replay_sample(1, cfg.rlbench.cameras, (HW2, HW2), V2, 4, seed=12).items()}
+    pcd = [rs['%s_point_cloud' % c][:, 0] for c in cfg.rlbench.cameras]
+    rgb = [(rs['%s_rgb' % c][:, 0].float() / 255.0) * 2.0 - 1.0 for c in cfg.rlbench.cameras]
+    grid = qa._q.voxelize([[r, p] for r, p in zip(rgb, pcd)], pcd, qa._coordinate_bounds.to(DEV))
+    assert grid.shape == (1, V2, V2, V2, 10) and 0 < int(grid[..., 9].sum()) <= 4 * HW2 * HW2
+    prop = rs['low_dim_state'][:, 0].float()
+    lang = rs['lang_token_embs'][:, 0].float()
+    eng = qa._q.encoder.engine()
+    keep = eng.precision
+    outs = {}
+    try:
+        for mode in ('bf16x3', 'fp32'):
+            eng.precision = mode
+            o, _ = eng.forward(grid, prop, lang, training=False, save=False)
+            outs[mode] = [t.float().clone() for t in o[:3]]
+    finally:
+        eng.precision = keep
+    for name, a, b in zip(('q_trans', 'rot_grip', 'collision'), outs['bf16x3'], outs['fp32']):
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) < 1e-4 * max(1.0, float(b.abs().max())), name
+    assert outs['fp32'][0].shape[-3:] == (V2, V2, V2)
