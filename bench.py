@@ -51,11 +51,15 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % a.gpus
-    torch.cuda.set_device(local_rank)          # one process per GPU; bind before the communicator is created
-    dev = torch.device('cuda', local_rank)
+    # one process per GPU; bind before the communicator is created.  (Debug only: VOXACTB_BENCH_BACKEND=gloo lets several
+    # ranks share one GPU -- RCCL refuses that -- to exercise the N > 1 control flow on a single-GPU box.)
+    backend = os.environ.get('VOXACTB_BENCH_BACKEND', 'nccl')
+    dev_index = local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)      # backend "nccl" == RCCL on ROCm
+        dist.init_process_group(backend, rank=rank, world_size=world)      # backend "nccl" == RCCL on ROCm
 
     from voxactb_amd import _lib, synthetic
     from voxactb_amd.agents.peract_bc import launch_utils as lu
@@ -67,7 +71,7 @@ def main():
                          rlbench__camera_resolution=[HW, HW], ddp__num_devices=world)
     torch.manual_seed(1234)           # identical initial weights on every rank (DDP broadcasts rank 0's upstream)
     agent = lu.create_agent(cfg)
-    agent.build(training=True, device=local_rank)
+    agent.build(training=True, device=dev_index)
     n_params = sum(p.numel() for p in agent._pose_agent._qattention_agents[0]._q.parameters())
     batches = [{k: v.to(dev) for k, v in synthetic.make_replay_sample(
         B, cfg.rlbench.cameras, (HW, HW), V, 4, seed=100 * rank + j).items()} for j in range(2)]
@@ -145,7 +149,7 @@ def main():
     act_lat = None
     if rank == 0 and not a.no_other_modes:
         ev = lu.create_agent(cfg)
-        ev.build(training=False, device=local_rank)
+        ev.build(training=False, device=dev_index)
         rs = synthetic.make_replay_sample(1, cfg.rlbench.cameras, (HW, HW), V, 4, seed=3)
         obs = {k: v.to(dev) for k, v in rs.items() if k.endswith(('_rgb', '_point_cloud')) or k == 'low_dim_state'}
         obs = {k: v.unsqueeze(0) if v.dim() < 5 and k != 'low_dim_state' else v for k, v in obs.items()}
