@@ -456,6 +456,32 @@ __global__ void __launch_bounds__(256) vox_fill_kernel(float* __restrict__ out, 
     }
 }
 
+// C = 10 (xyz, rgb, index, occupancy), V even: the same values as one FLAT, 16-byte aligned store stream per sample
+// (every wave instruction writes one aligned 1 KB run; the row-wise kernel above starts a row every 4000 bytes and ends
+// each on a partial wave: 5.0 vs 5.9-6.4 TB/s in tools/ubench/storebw.hip).  The pattern repeats every 20 floats = two
+// cells = five float4: j = 0, 3 are all zero, j = 1 carries (x, y)/V of the first cell, j = 2 its z/V, j = 4 the second
+// cell's (x, y, z)/V.  k/V comes from an LDS table (IEEE division once per block), the cell coordinates from
+// multiply-high divisions (cell * V < 2^32, checked by the host).
+__global__ void __launch_bounds__(256) vox_fill_flat10_kernel(float* __restrict__ out, unsigned n4, int V, unsigned magicV) {
+    extern __shared__ float vtab[];
+    for (int k = threadIdx.x; k < V; k += 256) vtab[k] = __fdiv_rn((float)k, (float)V);
+    __syncthreads();
+    float4* __restrict__ o = reinterpret_cast<float4*>(out + (size_t)blockIdx.y * n4 * 4);
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+        const unsigned grp = i / 5u, j = i - 5u * grp;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j == 1u || j == 2u || j == 4u) {
+            const unsigned cell = 2u * grp + (j == 4u ? 1u : 0u);
+            const unsigned xy = __umulhi(cell, magicV), z = cell - xy * (unsigned)V;
+            const unsigned x = __umulhi(xy, magicV), y = xy - x * (unsigned)V;
+            if (j == 1u) { v.z = vtab[x]; v.w = vtab[y]; }
+            else if (j == 2u) { v.x = vtab[z]; }
+            else { v.x = vtab[x]; v.y = vtab[y]; v.z = vtab[z]; }
+        }
+        o[i] = v;
+    }
+}
+
 // generic fallback when V*C is not a multiple of 4 (odd V): one float per thread iteration
 __global__ void __launch_bounds__(256) vox_fill_scalar_kernel(float* __restrict__ out, long long total, int V, int C) {
     const int NC = C - 4;
@@ -545,7 +571,12 @@ extern "C" int vxb_voxelize_f32(const float* const* coord_src, const float* cons
     hipStream_t fs = side;
     if (hipMemsetAsync(w.ctr, 0, 16 * sizeof(int), st) != hipSuccess) return VXB_ELAUNCH;
     if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(fs, ev_fork, 0) != hipSuccess) return VXB_ELAUNCH;
-    if (((V * C) & 3) == 0 && (((uintptr_t)out) & 15) == 0) {
+    if (C == 10 && (V & 1) == 0 && V >= 2 && V <= 1024 && (((uintptr_t)out) & 15) == 0 && V3 * V < (1ll << 32)) {
+        const unsigned n4 = (unsigned)(V3 * 10 / 4);                    // float4 per sample
+        const unsigned magicV = (unsigned)((1ull << 32) / (unsigned)V) + 1u;
+        const unsigned gx = (n4 + 255) / 256;       // one float4 per thread: many short blocks sustain 6.4 TB/s, few long ones 4.7
+        hipLaunchKernelGGL(vox_fill_flat10_kernel, dim3(gx, B), dim3(256), V * sizeof(float), fs, out, n4, V, magicV);
+    } else if (((V * C) & 3) == 0 && (((uintptr_t)out) & 15) == 0) {
         const int rows = B * V * V;
         const int groups = (rows + 7) / 8;
         hipLaunchKernelGGL(vox_fill_kernel, dim3(groups), dim3(256), 0, fs, out, rows, V, C);
