@@ -205,6 +205,10 @@ __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
             const int kt = (kt_);                                                                                     \
             if (kt + 1 < nkt) { if (X3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); } \
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
+            /* tie the fragments to the wait: the compiler must not move an MFMA that reads them above it */          \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                              \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                           \
+            _Pragma("unroll") for (int p = 0; p < NPL; ++p) asm volatile("" : "+v"(CUR[t][ks][p]));                    \
             vxb_raw_barrier();                                                                                        \
             if (kt + 1 < nkt) { DL_LOADB(NXT, k0_next) }                                                              \
             if (kt + 2 < nkt) { issue((kt + 2) % 3, kt + 2); }                                                        \
