@@ -17,6 +17,19 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=o
          '-fhip-fp32-correctly-rounded-divide-sqrt', '-Wno-unused-result']
 
 
+# scheduler choice per source, measured on the kernels' own micro-benchmarks (tools/bench_*.py)
+_MINREG = ['-mllvm', '-amdgpu-sched-strategy=iterative-minreg']
+PER_FILE_FLAGS = {
+    # bf16x3, B = 4, S = 100: weight gradient 2x8x8 tiles 278 -> 301 TF/s (19 instead of 24 spilled VGPRs; 26.5 -> 24.2 ms
+    # in the step); the 4x4x8 tiles (wgrad_halo_t44.hip) lose 5 % with it and keep the default.  conv_halo_bf16.hip: + 1-2 %
+    # on the dense kernels but - 5 % on the tap-list variant -> default.  max-ilp: c1_conv.hip - 9 %, others neutral.
+    'wgrad_halo.hip': _MINREG,
+}
+
+
+INCLUDES_SOURCE = {'wgrad_halo_t44.hip': ['wgrad_halo.hip']}      # translation units that #include another source
+
+
 def sources():
     return sorted(f for f in os.listdir(HERE) if f.endswith('.hip'))
 
@@ -30,10 +43,11 @@ def _headers_mtime():
 def _compile(src, force):
     obj = os.path.join(HERE, src[:-4] + '.o')
     s = os.path.join(HERE, src)
-    if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(s)
+    src_mtime = max([os.path.getmtime(s)] + [os.path.getmtime(os.path.join(HERE, d)) for d in INCLUDES_SOURCE.get(src, [])])
+    if (not force and os.path.exists(obj) and os.path.getmtime(obj) > src_mtime
             and os.path.getmtime(obj) > _headers_mtime()):
         return obj, False
-    cmd = [HIPCC] + FLAGS + ['-c', s, '-o', obj]
+    cmd = [HIPCC] + FLAGS + PER_FILE_FLAGS.get(src, []) + os.environ.get('VXB_EXTRA_FLAGS', '').split() + ['-c', s, '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, r.stdout, r.stderr))

@@ -32,7 +32,12 @@ constexpr int DLD = 80;                               // u16 per dY row (64 + 16
 constexpr int DPL = 128 * DLD;                        // u16 per dY plane
 constexpr int NDL = 128 * 16 / 256;                   // 8 float4 dY loads per thread per tile
 
-struct WhArgs {
+}  // namespace
+
+// (shared by the two translation units of this kernel: wgrad_halo.hip holds the 2x8x8 tiles and the C entries,
+// wgrad_halo_t44.hip -- this file again under WH_T44_UNIT -- the 4x4x8 tiles; each is compiled with the instruction
+// scheduler that measured faster for it, see build.py)
+struct VxbWhArgs {
     const float* src0;
     const float* src1;
     const float* dy;
@@ -47,6 +52,9 @@ struct WhArgs {
     const unsigned* phase_mask;   // d2s: bit t of phase_mask[column block] clear -> that (tap, phase) weight block is
                                   // structurally zero (polyphase up-conv) and is neither computed nor stored
 };
+typedef VxbWhArgs WhArgs;
+
+namespace {
 
 __device__ __forceinline__ unsigned wh_pack2(float lo, float hi) { return vxb_pack_bf16(lo, hi); }
 
@@ -269,17 +277,6 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
 
 }  // namespace
 
-static int g_wh_shape = -1;       // experiment knob (vxb_debug_set_wgrad_halo_shape): -1 = choose per grid, 0 / 1 = force
-
-// tile shape for a grid of extent S: 1 -> 4x4x8, 0 -> 2x8x8.  Measured at B = 4 (tools/bench_wgrad_halo.py): per tile the
-// 4x4x8 kernel is as fast in 'bf16' but ~10 % slower in 'bf16x3', so it is taken when it saves any edge voxels in bf16 and
-// only when it saves more than 10 % of them in x3 (S = 20: 20x20x24 vs 20x24x24 yes; S = 100: 100x100x104 vs 100x104x104 no).
-static inline int wgrad_halo_shape(int S, int x3) {
-    if (g_wh_shape >= 0) return g_wh_shape;
-    const long long a = (long long)vxb_cdiv(S, 2) * 2 * vxb_cdiv(S, 8) * 8, b = (long long)vxb_cdiv(S, 4) * 4 * vxb_cdiv(S, 4) * 4;
-    return x3 ? (b * 10 < a * 9) : (b < a);
-}
-
 template <int X3, int TD, int TH>
 static int wgrad_halo_launch(WhArgs& g, int nsplit, hipStream_t st) {
     g.ntd = vxb_cdiv(g.S_out, TD); g.nth = vxb_cdiv(g.S_out, TH); g.ntw = vxb_cdiv(g.S_out, WTW);
@@ -291,6 +288,24 @@ static int wgrad_halo_launch(WhArgs& g, int nsplit, hipStream_t st) {
     hipLaunchKernelGGL((wgrad_halo_kernel<X3, TD, TH>), grid, dim3(256), lds, st, g);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
+}
+
+#ifdef WH_T44_UNIT
+int vxb_wgrad_halo_launch_t44(VxbWhArgs& g, int x3, int nsplit, hipStream_t st) {
+    return x3 ? wgrad_halo_launch<1, 4, 4>(g, nsplit, st) : wgrad_halo_launch<0, 4, 4>(g, nsplit, st);
+}
+#else
+int vxb_wgrad_halo_launch_t44(VxbWhArgs& g, int x3, int nsplit, hipStream_t st);
+
+static int g_wh_shape = -1;       // experiment knob (vxb_debug_set_wgrad_halo_shape): -1 = choose per grid, 0 / 1 = force
+
+// tile shape for a grid of extent S: 1 -> 4x4x8, 0 -> 2x8x8.  Measured at B = 4 (tools/bench_wgrad_halo.py): per tile the
+// 4x4x8 kernel is as fast in 'bf16' but ~10 % slower in 'bf16x3', so it is taken when it saves any edge voxels in bf16 and
+// only when it saves more than 10 % of them in x3 (S = 20: 20x20x24 vs 20x24x24 yes; S = 100: 100x100x104 vs 100x104x104 no).
+static inline int wgrad_halo_shape(int S, int x3) {
+    if (g_wh_shape >= 0) return g_wh_shape;
+    const long long a = (long long)vxb_cdiv(S, 2) * 2 * vxb_cdiv(S, 8) * 8, b = (long long)vxb_cdiv(S, 4) * 4 * vxb_cdiv(S, 4) * 4;
+    return x3 ? (b * 10 < a * 9) : (b < a);
 }
 
 static int wgrad_halo_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out, int off,
@@ -306,7 +321,7 @@ static int wgrad_halo_impl(int x3, const float* src0, const float* src1, int C0,
     g.phase_mask = phase_mask;
     if (nsplit > 65535 || N / 64 > 65535) return VXB_ESIZE;
     hipStream_t st = (hipStream_t)stream;
-    if (wgrad_halo_shape(S_out, x3)) return x3 ? wgrad_halo_launch<1, 4, 4>(g, nsplit, st) : wgrad_halo_launch<0, 4, 4>(g, nsplit, st);
+    if (wgrad_halo_shape(S_out, x3)) return vxb_wgrad_halo_launch_t44(g, x3, nsplit, st);
     return x3 ? wgrad_halo_launch<1, 2, 8>(g, nsplit, st) : wgrad_halo_launch<0, 2, 8>(g, nsplit, st);
 }
 
@@ -334,3 +349,4 @@ extern "C" size_t vxb_conv3_wgrad_halo_tiles(int B, int S_out, int x3) {
 }
 
 extern "C" void vxb_debug_set_wgrad_halo_shape(int shape) { g_wh_shape = shape < 0 ? -1 : (shape ? 1 : 0); }
+#endif   // WH_T44_UNIT
