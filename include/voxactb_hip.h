@@ -39,15 +39,20 @@ int vxb_abi_version(void);
  * bounds: [bounds_rows (1 or B), 6] = (min xyz, max xyz).  out: [B, V, V, V, 3+F+3+1].
  * Results equal the reference's CPU path bit-for-bit in all channels (sums are accumulated in
  * ascending point id, as scatter_add_ does on CPU).
- * Workspace: vxb_voxelize_workspace_bytes(); its first B*V^3 int32 must be ZERO on entry (zero the
- * whole workspace once after allocation); every successful call leaves them zero again.
+ * xform: NULL, or [B][15] = R_b (row-major 3x3), t_b, c_b: every point is replaced by (p - t_b) R_b + c_b (row-vector
+ * convention) as it is loaded -- the SE(3) augmentation's perturb_se3 (peract/voxel/augmentation.py:36-62) folded into
+ * the voxelizer, same operation order as vxb_se3_points_f32 (so both routes give the same grid, bit for bit).
+ * Workspace: vxb_voxelize_workspace_bytes() bytes, contents arbitrary on entry (nothing to pre-zero).
  */
 size_t vxb_voxelize_workspace_bytes(int B, int n_points, int V);
+/* Point chain used by vxb_voxelize_f32: 0 = automatic (tile-routed chain when F <= 4, V <= 200, N < 2^20; otherwise the
+ * table-based chain), 1 = always the table-based chain (A/B measurements, tests).  Both produce identical grids. */
+int vxb_voxelize_select_chain(int which);
 int vxb_voxelize_f32(const float* const* coord_src, const float* const* feat_src, int n_src,
                      int B, int pts_per_src, int F,
                      int64_t coord_bstride, int64_t coord_cstride, int64_t coord_pstride,
                      int64_t feat_bstride, int64_t feat_cstride, int64_t feat_pstride,
-                     const float* bounds, int bounds_rows, int V,
+                     const float* bounds, int bounds_rows, int V, const float* xform,
                      float* out, void* workspace, size_t workspace_bytes, vxb_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -88,6 +93,20 @@ int vxb_fold_pad_f32(const float* src, int Sp, int Cs, int c0, float* dst, const
  * peract/voxel/augmentation.py:36-57): dst[b, :, i] = (src[b, :, i] - t_b) R_b + c_b with points as ROW vectors;
  * xf [B][15] = R_b (row-major 3x3), t_b (gripper position), c_b (new, clamped centre). */
 int vxb_se3_points_f32(const float* src, float* dst, const float* xf, int B, int64_t n, vxb_stream_t stream);
+/* Pose / label half of apply_se3_augmentation (peract/voxel/augmentation.py:98-177 with helpers/utils.py:63-64, 92-97,
+ * 104-116), on the device and without a host round trip.  For attempt k = 0 .. K-1 and sample b: shift = (bounds_max -
+ * bounds_min) * aug_xyz * shift_unit[k][b] (float64, as the reference's float64 `trans_aug_range` makes it), rotation
+ * Rx Ry Rz of rpy_steps[k][b] * rot_aug_resolution degrees, T' = T_grip R with T'[:3,3] += shift, translation index =
+ * min(floor((t' - min) / (res + 1e-12)), V - 1) in float64 with the bounds row of sample b (row 0 when layer == 0,
+ * :161-162), rotation index = round((euler_xyz(T') + 180) / rot_resolution) mod (360 / rot_resolution).  The FIRST
+ * attempt whose translation indices are >= 0 for the whole batch wins (:116); none in K: status[0] = -1 and the labels
+ * are -1 (the caller raises, :119-120).  Outputs of the winning attempt: trans_idx [B][3], rot_grip_idx [B][4] (grip bit
+ * copied from rot_grip_in), xf [B][15] = R (row-major), t_grip, clamp(t_grip + shift, batch-wide bounds) -- the operand of
+ * vxb_voxelize_f32 / vxb_se3_points_f32; status[0] = winning attempt.  pose [B][7] = xyz + quaternion (x, y, z, w). */
+int vxb_se3_relabel_f32(const float* pose, const int32_t* rot_grip_in, const float* bounds, int bounds_rows, int layer,
+                        const float* shift_unit, const int32_t* rpy_steps, int K, int B, double aug_x, double aug_y,
+                        double aug_z, float rot_aug_resolution, int V, float rot_resolution, int32_t* trans_idx,
+                        int32_t* rot_grip_idx, float* xf, int32_t* status, vxb_stream_t stream);
 /* bf16 matrix-core twins ("throughput mode", v_mfma_f32_32x32x16_bf16, fp32 accumulate): the fp32 A operand is rounded
  * to bf16 (RNE) while it is staged into LDS; weights come as bf16 [N][K] (K contiguous, K % 8 == 0; C0, C1 % 32 == 0). */
 int vxb_gemm_bf16w_f32(const float* A, int64_t lda, const void* Bw, float* C, int64_t ldc, const float* bias,

@@ -112,14 +112,17 @@ def augment(pcd_list, gripper_pose, rot_grip, bounds, shift_unit, rpy_steps,
     q_wxyz = torch.cat([gripper_pose[:, 6:7], gripper_pose[:, 3:6]], 1)
     T[:, :3, :3] = quaternion_to_matrix(q_wxyz)                         # :106
     T[:, :3, 3] = gripper_pose[:, :3]
-    trans_range = (bounds[:, 3:] - bounds[:, :3]) * torch.as_tensor(trans_aug_range, dtype=torch.float32)
-    shift = trans_range * shift_unit                                    # :123-124
+    # `trans_aug_range` is a float64 tensor upstream (agent :186, torch.from_numpy(np.array(...))): the range and the shift
+    # are float64 (type promotion), the 4x4 that carries the shift to perturb_se3 is float32 again
+    trans_range = (bounds[:, 3:] - bounds[:, :3]) * torch.as_tensor(trans_aug_range, dtype=torch.float64)
+    shift64 = trans_range * shift_unit                                  # :123-124
+    shift = shift64.float()                                             # :125-126 (assignment into the fp32 identity)
     ang = rpy_steps.float() * np.deg2rad(rot_aug_resolution)           # :133-141
     R3 = euler_angles_to_matrix(ang, 'XYZ')                              # :142
     R4 = torch.eye(4).repeat(bs, 1, 1)
     R4[:, :3, :3] = R3
     Tp = torch.bmm(T, R4)                                               # :147
-    Tp[:, :3, 3] += shift                                               # :148
+    Tp[:, :3, 3] += shift64                                             # :148 (computed in float64, stored as fp32)
     tr = Tp[:, :3, 3].numpy()
     qw = matrix_to_quaternion(Tp[:, :3, :3])                            # :152
     q_xyzw = torch.cat([qw[:, 1:], qw[:, 0:1]], 1).numpy()

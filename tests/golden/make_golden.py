@@ -113,6 +113,13 @@ CFG_TINY = dict(V=8, k=3, s=2, depth=1, latents=16, low_dim=4, B=2, cams=['front
 CFG_C1 = dict(V=32, k=5, s=4, depth=1, latents=64, low_dim=4, B=1, cams=['front'], H=64, W=64)
 CFG_UPD = dict(V=16, k=3, s=4, depth=2, latents=32, low_dim=7, B=3, cams=['front', 'wrist'], H=16, W=16)
 CFG_C2 = dict(V=100, k=5, s=5, depth=6, latents=2048, low_dim=4, B=1, cams=synthetic.CAMERAS4, H=128, W=128)
+# BASELINE.json configs[2] shape of ONE of the twin agents (acting / stabilizing): low_dim 7, arm-prediction loss,
+# per-sample crop bounds (scripts/train_open_jar_ours_vlm_10_demos_v2_11_acting.sh:22-24); B = 2 so that the two samples
+# really use different bounds rows
+CFG_C3 = dict(V=100, k=5, s=5, depth=6, latents=2048, low_dim=7, B=2, cams=synthetic.CAMERAS4, H=128, W=128)
+# BASELINE.json configs[4] shape: 200^3 voxels, depth 6 (forward digest only: the autograd graph of the reference at this
+# size does not fit the build container's memory budget comfortably)
+CFG_C5 = dict(V=200, k=5, s=5, depth=6, latents=2048, low_dim=4, B=1, cams=synthetic.CAMERAS4, H=128, W=128)
 
 
 def make_ref_encoder(cfg, arm=False, seed=0):
@@ -142,15 +149,16 @@ def enc_kw(cfg, arm=False):
     return dict(depth=cfg['depth'], voxel_patch_stride=cfg['s'], arm_pred_loss=arm)
 
 
-def encoder_fixture(name, cfg, arm=False, with_grads=True, digest=False):
+def encoder_fixture(name, cfg, arm=False, with_grads=True, digest=False, crop=False, check_oracle=True):
     enc, sd = make_ref_encoder(cfg, arm)
-    rs = batch_for(cfg, seed=1, arm=arm)
+    rs = batch_for(cfg, seed=1, arm=arm, crop=crop)
     pcd = [rs['%s_point_cloud' % c] for c in cfg['cams']]
     rgb = [rs['%s_rgb' % c] for c in cfg['cams']]
-    bounds = torch.tensor([synthetic.SCENE_BOUNDS])
+    bounds = rs['target_object_scene_bounds'] if crop else torch.tensor([synthetic.SCENE_BOUNDS])
     coords, feats = ovox.flatten_cameras(pcd, rgb)
     grid = ref_voxelize(coords, feats, bounds, cfg['V'], cfg['B'])
-    assert torch.equal(grid, ovox.voxelize(coords, feats, bounds, cfg['V']))
+    if check_oracle:
+        assert torch.equal(grid, ovox.voxelize(coords, feats, bounds, cfg['V']))
     ins = grid.permute(0, 4, 1, 2, 3).detach()
     t0 = time.time()
     for p in enc.parameters():
@@ -158,15 +166,19 @@ def encoder_fixture(name, cfg, arm=False, with_grads=True, digest=False):
     with torch.set_grad_enabled(with_grads):
         outs = enc(ins, rs['low_dim_state'], rs['lang_goal_emb'], rs['lang_token_embs'], None, bounds, None)
     print('%s: reference forward %.1fs' % (name, time.time() - t0))
-    with torch.no_grad():
-        o_outs, inter = operc.forward({k: v for k, v in sd.items()}, ins, rs['low_dim_state'],
-                                      rs['lang_token_embs'], return_intermediates=True, **enc_kw(cfg, arm))
-    errs = [float((a.detach() - b).abs().max()) for a, b in zip(outs, o_outs)]
-    print('%s: oracle vs reference max-abs %s' % (name, errs))
-    assert max(errs) < 2e-5, errs
+    inter = None
+    if check_oracle:
+        with torch.no_grad():
+            o_outs, inter = operc.forward({k: v for k, v in sd.items()}, ins, rs['low_dim_state'],
+                                          rs['lang_token_embs'], return_intermediates=True, **enc_kw(cfg, arm))
+        errs = [float((a.detach() - b).abs().max()) for a, b in zip(outs, o_outs)]
+        print('%s: oracle vs reference max-abs %s' % (name, errs))
+        assert max(errs) < 2e-5, errs
+        if digest:
+            inter = None
     arrs = dict(cfg_V=cfg['V'], cfg_k=cfg['k'], cfg_s=cfg['s'], cfg_depth=cfg['depth'], cfg_latents=cfg['latents'],
                 cfg_low_dim=cfg['low_dim'], cfg_B=cfg['B'], cfg_H=cfg['H'], cfg_W=cfg['W'], cfg_ncam=len(cfg['cams']),
-                cfg_arm=int(arm), rot_grip=outs[1], collision=outs[2])
+                cfg_arm=int(arm), cfg_crop=int(crop), rot_grip=outs[1], collision=outs[2])
     if arm:
         arrs['arm_out'] = outs[3]
     qt = outs[0].detach()
@@ -323,12 +335,138 @@ def f8_se3():
          trans_idx=ti, rot_grip_idx=ri, pcd_out=pp[0], ok=int(ok))
 
 
+# ----------------------------------------------------------------------------- F9: act() through the whole agent stack
+class _StubTextEncoder:
+    """Stands in for CLIP RN50 (weights `data/clip_rn50.pth` are in neither tree): a deterministic
+    function of the tokens with CLIP's output shapes (helpers/clip/core/clip.py:426-440)."""
+
+    def __init__(self):
+        self.table = ow.hashed_normal('clip_stub_table', (997, 512))
+        self.proj = ow.hashed_normal('clip_stub_proj', (512, 1024)) * 0.05
+
+    def float(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    def encode_text_with_embeddings(self, tokens):
+        emb = self.table[tokens.long() % 997]                       # [1,77,512]
+        return emb.mean(1) @ self.proj, emb
+
+
+def _act_observation(cfg, seed):
+    """the observation dict RolloutGenerator hands to PreprocessAgent.act (rollout_generator.py:146-152): every
+    element [1, 1, ...]; rgb still 0..255."""
+    rs = synthetic.make_replay_sample(1, cfg['cams'], (cfg['H'], cfg['W']), cfg['V'], cfg['low_dim'], seed=seed)
+    obs = {}
+    g = np.random.Generator(np.random.Philox(key=4242 + seed))
+    for c in cfg['cams']:
+        obs['%s_rgb' % c] = rs['%s_rgb' % c].clone()
+        obs['%s_point_cloud' % c] = rs['%s_point_cloud' % c].clone()
+        # a plausible pinhole camera looking at the scene centre (values only need to be shared by both sides)
+        from scipy.spatial.transform import Rotation
+        ext = np.eye(4)
+        ext[:3, :3] = Rotation.from_euler('xyz', g.uniform(-0.6, 0.6, 3)).as_matrix()
+        ext[:3, 3] = np.array([0.2, 0.0, 1.1]) + g.uniform(-1.5, 1.5, 3)
+        f = -cfg['W'] / (2 * np.tan(np.deg2rad(30)))
+        K = np.array([[f, 0, cfg['W'] / 2], [0, f, cfg['H'] / 2], [0, 0, 1.0]])
+        obs['%s_camera_extrinsics' % c] = torch.from_numpy(ext).float().view(1, 1, 4, 4)
+        obs['%s_camera_intrinsics' % c] = torch.from_numpy(K).float().view(1, 1, 3, 3)
+    obs['low_dim_state'] = rs['low_dim_state'].clone()
+    obs['lang_goal_tokens'] = torch.from_numpy(g.integers(0, 49408, (1, 1, 77))).long()
+    return obs
+
+
+def f9_act():
+    stub_modules()
+    import types
+    ref_agent = load('ref_agent', 'agents/peract_bc/qattention_peract_bc_agent.py')
+    ref_agent.load_clip = lambda *a, **k: (MagicMock(), None)
+    ref_agent.build_model = lambda sd: _StubTextEncoder()
+    # the stack agent does `from helpers import utils` / `from agents.peract_bc.qattention_peract_bc_agent import ...`;
+    # importing the `agents.peract_bc` package would pull launch_utils -> rlbench (SURVEY.md 8c), so the package
+    # levels are empty namespaces and the two modules are the path-loaded ones
+    for pkg in ('agents', 'agents.peract_bc'):
+        if pkg not in sys.modules:
+            sys.modules[pkg] = types.ModuleType(pkg)
+            sys.modules[pkg].__path__ = []
+    sys.modules['agents.peract_bc.qattention_peract_bc_agent'] = ref_agent
+    ref_stack = load('ref_stack', 'agents/peract_bc/qattention_stack_agent.py')
+    ref_prep = load('ref_prep', 'helpers/preprocess_agent.py')
+    out = {}
+    for tag, cfg in (('s', dict(CFG_UPD, low_dim=4, B=1)), ('c2', CFG_C2)):
+        enc, sd = make_ref_encoder(cfg, False)
+        qa = ref_agent.QAttentionPerActBCAgent(
+            layer=0, coordinate_bounds=synthetic.SCENE_BOUNDS, perceiver_encoder=enc, camera_names=cfg['cams'],
+            batch_size=1, voxel_size=cfg['V'], bounds_offset=None, voxel_feature_size=3, image_crop_size=64,
+            num_rotation_classes=72, rotation_resolution=5, lr=5e-4, include_low_dim_state=True,
+            image_resolution=[cfg['H'], cfg['W']], lambda_weight_l2=1e-6, transform_augmentation=False,
+            optimizer_type='lamb')
+        agent = ref_prep.PreprocessAgent(ref_stack.QAttentionStackAgent([qa], 5, cfg['cams']))
+        agent.build(training=False, device=torch.device('cpu'))
+        obs = _act_observation(cfg, seed=21)
+        with torch.no_grad():
+            emb, tok = _StubTextEncoder().encode_text_with_embeddings(obs['lang_goal_tokens'][0])
+        t0 = time.time()
+        with torch.no_grad():
+            res = agent.act(0, {k: v.clone() for k, v in obs.items()}, deterministic=True)
+        print('f9 %s: reference act() %.1fs' % (tag, time.time() - t0))
+        qt = res.info['q_depth0'].reshape(1, -1)
+        pre = 'f9%s_' % tag
+        out.update({pre + 'cfg_' + k: cfg[k] for k in ('V', 'k', 's', 'depth', 'latents', 'low_dim', 'H', 'W')})
+        out[pre + 'cfg_ncam'] = len(cfg['cams'])
+        out[pre + 'lang_goal_tokens'] = obs['lang_goal_tokens']
+        out[pre + 'lang_goal_emb'], out[pre + 'lang_token_embs'] = emb, tok
+        for c in cfg['cams']:
+            out[pre + c + '_ext'] = obs['%s_camera_extrinsics' % c]
+            out[pre + c + '_int'] = obs['%s_camera_intrinsics' % c]
+            out[pre + c + '_pixel_coord'] = np.array(res.observation_elements['%s_pixel_coord' % c], dtype=np.float64)
+        out[pre + 'continuous_action'] = np.asarray(res.action, dtype=np.float64)
+        out[pre + 'attention_coordinate'] = res.observation_elements['attention_coordinate_layer_0']
+        out[pre + 'trans_action_indicies'] = res.observation_elements['trans_action_indicies']
+        out[pre + 'rot_grip_action_indicies'] = res.observation_elements['rot_grip_action_indicies']
+        out[pre + 'coords'] = res.info['voxel_idx_depth0']
+        top = qt.topk(16, dim=1)
+        sidx = ow.hashed_int('digest', (4096,), 0, qt.shape[1])
+        out[pre + 'q_top_vals'], out[pre + 'q_top_idx'] = top.values, top.indices
+        out[pre + 'q_sample_idx'], out[pre + 'q_sample'] = sidx, qt[:, sidx]
+        out[pre + 'q_sum'] = qt.double().sum()
+        # the softmaxed rotation / grip / collision heads are not returned by act(); recompute them the way act() does
+        # (agent :394-416) from the reference Q-function on the same preprocessed observation
+        o2 = {k: ((v.float() / 255.0) * 2.0 - 1.0 if 'rgb' in k else v.float()) for k, v in obs.items()}
+        ob = [[o2['%s_rgb' % c][0], o2['%s_point_cloud' % c][0]] for c in cfg['cams']]
+        pc = [o2['%s_point_cloud' % c][0] for c in cfg['cams']]
+        with torch.no_grad():
+            q_t, q_rg, q_c, vox = qa._q(ob, o2['low_dim_state'][0], pc, emb, tok, qa._coordinate_bounds, None, None)
+            out[pre + 'q_rot_grip_softmax'] = qa._softmax_q_rot_grip(q_rg)
+            out[pre + 'q_collision_softmax'] = qa._softmax_ignore_collision(q_c)
+            # oracle agreement (pins oracle.agent.softmax_heads / attention_coordinate / choose_highest_action)
+            P = {k: v for k, v in sd.items()}
+            oo = oagent.qfunction_forward(P, pc, [o[0] for o in ob], o2['low_dim_state'][0], tok,
+                                          torch.tensor([synthetic.SCENE_BOUNDS]), cfg['V'], **enc_kw(cfg))
+            sqt, sqr, sqc = oagent.softmax_heads(oo[0], oo[1], oo[2])
+            co, rg, ic = oagent.choose_highest_action(sqt, sqr, sqc)
+            assert torch.equal(co.int(), res.info['voxel_idx_depth0'].int()), (co, res.info['voxel_idx_depth0'])
+            assert float((sqr - out[pre + 'q_rot_grip_softmax']).abs().max()) < 1e-5
+            ac = oagent.attention_coordinate(torch.tensor([synthetic.SCENE_BOUNDS]), co, cfg['V'])
+            assert float((ac[0] - torch.from_numpy(np.asarray(out[pre + 'attention_coordinate']))).abs().max()) < 1e-6
+    save('f9_act', **out)
+
+
 SECTIONS = {
     'f1': f1_voxel_kats,
     'f3tiny': lambda: encoder_fixture('f3_encoder_tiny', CFG_TINY, arm=True),
     'f3c1': lambda: encoder_fixture('f3_encoder_c1', CFG_C1),
     'f5': lambda: encoder_fixture('f5_encoder_c2_digest', CFG_C2, with_grads=False, digest=True),
+    'f5g': lambda: encoder_fixture('f5g_encoder_c2_grads', CFG_C2, with_grads=True, digest=True),
+    'f5c3': lambda: encoder_fixture('f5c3_encoder_c3_digest', CFG_C3, arm=True, with_grads=True, digest=True, crop=True),
+    'f5v200': lambda: encoder_fixture('f5v200_encoder_c5_digest', CFG_C5, with_grads=False, digest=True),
     'f6': f6_update_traces,
+    'f9': f9_act,
     'f7': f7_lamb,
     'f8': f8_se3,
 }
@@ -341,7 +479,7 @@ if __name__ == '__main__':
     todo = [s for s in a.only.split(',') if s] or list(SECTIONS)
     torch.manual_seed(0)
     for s in todo:
-        if s == 'f5' and a.skip_c2:
+        if s in ('f5', 'f5g', 'f5c3', 'f5v200') and a.skip_c2:
             continue
         print('==', s)
         SECTIONS[s]()

@@ -1,0 +1,153 @@
+"""GPU parity AT THE HEADLINE SIZES against digests the REFERENCE produced (tests/golden/make_golden.py, sections
+f5 / f5g / f5c3 / f5v200): BASELINE.json configs[1] geometry (V=100, 4 cameras 128x128, depth 6, 2048 latents), the
+configs[2] twin-agent shape (low_dim 7, arm-prediction head, per-sample crop bounds, B=2) and the configs[4] grid (V=200,
+depth 6) -- each in the exact-'fp32' AND the default 'bf16x3' precision, i.e. both kernel families are pinned to the
+reference itself, not to each other.
+
+Checked per fixture: voxel occupancy list bit-exact + per-channel sums, q_trans argmax / top-16 / 4096 sampled logits /
+log-sum-exp and every rot_grip / collision (/ arm) logit within 1e-4 (BASELINE.json north_star), and -- where the
+reference's backward was captured -- the loss within 1e-4 and every parameter-gradient norm within 3e-3 relative."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import weights as ow
+from voxactb_amd import ops, synthetic
+from voxactb_amd.agents.peract_bc.perceiver_lang_io import PerceiverVoxelLangEncoder
+from voxactb_amd.voxel.voxel_grid import VoxelGrid
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+TOL_Q = 1e-4
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _setup(g):
+    arm, crop = bool(g['cfg_arm']), bool(g['cfg_crop']) if 'cfg_crop' in g.files else False
+    V, B, H, W = int(g['cfg_V']), int(g['cfg_B']), int(g['cfg_H']), int(g['cfg_W'])
+    cams = synthetic.CAMERAS4[:int(g['cfg_ncam'])]
+    enc = PerceiverVoxelLangEncoder(
+        depth=int(g['cfg_depth']), iterations=1, voxel_size=V, initial_dim=10, low_dim_size=int(g['cfg_low_dim']),
+        num_latents=int(g['cfg_latents']), voxel_patch_size=int(g['cfg_k']), voxel_patch_stride=int(g['cfg_s']),
+        activation='lrelu', input_dropout=0.0, attn_dropout=0.0, decoder_dropout=0.0, arm_pred_loss=arm)
+    enc.load_state_dict(ow.hashed_state_dict({n: tuple(p.shape) for n, p in enc.named_parameters()}, 0), strict=False)
+    enc = enc.to(DEV)
+    rs = synthetic.make_replay_sample(B, cams, (H, W), V, int(g['cfg_low_dim']), seed=1, arm_pred_loss=arm,
+                                      crop_target_obj_voxel=crop)
+    rs = {k: (v[:, 0] if v.dim() > 2 else v) for k, v in rs.items()}
+    rs = {k: ((v.float() / 255.0) * 2.0 - 1.0 if 'rgb' in k else v.float()) for k, v in rs.items()}
+    bounds = rs['target_object_scene_bounds'] if crop else torch.tensor([synthetic.SCENE_BOUNDS])
+    vg = VoxelGrid(synthetic.SCENE_BOUNDS, V, DEV, B, 3, H * W * len(cams))
+    grid = vg.voxelize_cameras([rs['%s_point_cloud' % c].to(DEV) for c in cams], [rs['%s_rgb' % c].to(DEV) for c in cams],
+                               bounds.to(DEV))
+    return enc, rs, grid, arm, V, B
+
+
+def _check_grid(g, grid):
+    occ = grid[..., -1] > 0
+    flat = torch.nonzero(occ.reshape(-1))[:, 0].int().cpu()
+    ref = T(g['grid_occ_flat'])
+    assert flat.numel() == int(g['grid_occ_count']) and torch.equal(flat, ref)          # occupancy indices: bit-exact
+    sums = grid.double().sum(dim=(0, 1, 2, 3)).cpu()
+    rs = T(g['grid_channel_sums'])
+    assert float(((sums - rs).abs() / (rs.abs() + 1.0)).max()) < 1e-9, (sums, rs)         # same floats, summed in double
+
+
+def _check_forward(g, outs, arm, tag):
+    B = outs[0].shape[0]
+    flat = outs[0].reshape(B, -1).float().cpu()
+    assert torch.equal(flat.argmax(1), T(g['q_trans_argmax'])), tag
+    sidx = T(g['q_trans_sample_idx']).long()
+    e_s = float((flat[:, sidx] - T(g['q_trans_sample'])).abs().max())
+    tv, ti = T(g['q_trans_top_vals']), T(g['q_trans_top_idx']).long()
+    e_t = float((torch.gather(flat, 1, ti) - tv).abs().max())                            # reference's top-16 positions
+    mine_top = flat.topk(16, dim=1)
+    e_tv = float((mine_top.values - tv).abs().max())                                       # and our own top-16 values
+    e_l = float((torch.logsumexp(flat.double(), 1) - T(g['q_trans_lse'])).abs().max())
+    e_r = float((outs[1].float().cpu() - T(g['rot_grip'])).abs().max())
+    e_c = float((outs[2].float().cpu() - T(g['collision'])).abs().max())
+    print('%s: q_trans samples %.2e top16 %.2e/%.2e lse %.2e | rot_grip %.2e collision %.2e (|q|max %.2f)'
+          % (tag, e_s, e_t, e_tv, e_l, e_r, e_c, float(flat.abs().max())))
+    assert max(e_s, e_t, e_tv, e_l, e_r, e_c) < TOL_Q, tag
+    if arm:
+        assert float((outs[3].float().cpu() - T(g['arm_out'])).abs().max()) < TOL_Q, tag
+    return dict(q_samples=e_s, q_top=e_t, lse=e_l, rot_grip=e_r, collision=e_c)
+
+
+def _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, tag):
+    at = rs['trans_action_indicies'].long()
+    lab = ((at[:, 0] * V + at[:, 1]) * V + at[:, 2]).int().to(DEV)
+    dq = torch.empty((B, V ** 3), device=DEV)
+    l_t, _, _ = ops.ce_big(outs[0].view(B, -1), lab, dq, 1.0 / B)
+    labs = torch.cat([rs['rot_grip_action_indicies'].int(), rs['ignore_collisions'].int()[:, :1]], 1).to(DEV).contiguous()
+    d_o = torch.empty_like(cache['o'])
+    l_h, _ = ops.ce_rows(cache['o'], [(0, 72), (72, 72), (144, 72), (216, 2), (218, 2)], labs, d_o, 1.0 / B)
+    total = l_t + l_h.sum(1)
+    d_arm = None
+    if arm:
+        d_arm = torch.empty_like(outs[3])
+        la, _ = ops.ce_rows(outs[3], [(0, 2)], rs['label'].int()[:, :1].to(DEV).contiguous(), d_arm, 1.0 / B)
+        total = total + la[:, 0]
+    loss = float(total.mean())
+    assert abs(loss - float(g['loss'])) < 1e-4, (tag, loss, float(g['loss']))
+    for p in enc.parameters():
+        p.grad = None
+    eng.backward(cache, dq, d_o, d_arm)
+    P = dict(enc.named_parameters())
+    bad, worst = [], 0.0
+    for n, rn in zip([str(n) for n in g['grad_names']], T(g['grad_norms'])):
+        gn, rn = float(P[n].grad.norm()), float(rn)
+        rel = abs(gn - rn) / (rn + 1e-12)
+        if abs(gn - rn) > 3e-3 * rn + 1e-5:          # + 1e-5: gradients that are mathematically zero (trans_decoder bias)
+            bad.append((n, gn, rn))
+        elif rn > 1e-4:
+            worst = max(worst, rel)
+        key = 'grad__' + n
+        if key in g.files:
+            ref = T(g[key])
+            e = float((P[n].grad.float().cpu() - ref).abs().max())
+            if e > 3e-3 * float(ref.abs().max()) + 1e-5:
+                bad.append((n, 'full', e, float(ref.abs().max())))
+    print('%s: loss %.6f (reference %.6f), worst grad-norm rel. error %.2e' % (tag, loss, float(g['loss']), worst))
+    assert not bad, (tag, bad)
+
+
+def _run(g, precision, tag, backward):
+    enc, rs, grid, arm, V, B = _setup(g)
+    _check_grid(g, grid)
+    eng = enc.engine()
+    eng.precision = precision
+    outs, cache = eng.forward(grid, rs['low_dim_state'].to(DEV), rs['lang_token_embs'].to(DEV), training=False, save=backward)
+    errs = _check_forward(g, outs, arm, '%s/%s' % (tag, precision))
+    if backward:
+        _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, '%s/%s' % (tag, precision))
+    del cache, outs
+    torch.cuda.empty_cache()
+    return errs
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_c2_forward_digest_f5(golden, precision):
+    """V=100, depth 6, 2048 latents, B=1 -- forward (reference perceiver_lang_io.py:345-485)."""
+    _run(golden('f5_encoder_c2_digest'), precision, 'f5', backward=False)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_c2_forward_backward_digest(golden, precision):
+    """the same configuration with the reference's loss and per-parameter gradient norms (fwd + bwd of the reference)."""
+    _run(golden('f5g_encoder_c2_grads'), precision, 'f5g', backward=True)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_c3_twin_agent_shape_digest(golden, precision):
+    """BASELINE.json configs[2] shape of one twin agent: low_dim 7, arm head, per-sample crop bounds, B=2, fwd + bwd."""
+    _run(golden('f5c3_encoder_c3_digest'), precision, 'f5c3', backward=True)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_c5_v200_forward_digest(golden, precision):
+    """BASELINE.json configs[4] grid: V=200 (40^3 patches, 64 077 context tokens), depth 6, 2048 latents, forward."""
+    _run(golden('f5v200_encoder_c5_digest'), precision, 'f5v200', backward=False)

@@ -1,0 +1,101 @@
+"""GPU: the SE(3) augmentation on the device (csrc/se3_relabel.hip + the voxelizer's fused point transform) against the
+oracle's restatement of reference peract/voxel/augmentation.py:68-185 (oracle/se3.py) and its fixture F8
+(tests/golden/f8_se3.npz: explicit random draws -> labels + transformed points; pytorch3d helpers unpinned upstream)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import se3 as ose3
+from voxactb_amd import synthetic
+from voxactb_amd.voxel import augmentation as aug
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _plan(pose, rot_grip, bounds, unit, steps, layer=0, V=100):
+    return aug.se3_augmentation_plan(pose.to(DEV), rot_grip.to(DEV), bounds.to(DEV), layer, torch.tensor([0.125] * 3, dtype=torch.float64),
+                                     [0.0, 0.0, 45.0], 5, V, 5, DEV, draws=(unit, steps))
+
+
+def test_f8_fixture(golden):
+    g = golden('f8_se3')
+    pose, rg, bounds = T(g['pose']), T(g['rot_grip']), T(g['bounds'])
+    ti, ri, xf, status = _plan(pose, rg, bounds, T(g['shift_unit'])[None], T(g['rpy_steps'])[None].int())
+    assert int(status.item()) == 0
+    assert torch.equal(ti.cpu().long(), T(g['trans_idx']).long())
+    assert torch.equal(ri.cpu().long(), T(g['rot_grip_idx']).long())
+    moved = aug.transform_point_clouds([T(g['pcd']).to(DEV)], xf)[0]
+    assert float((moved.cpu() - T(g['pcd_out'])).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize('per_sample,layer', [(False, 0), (True, 0), (True, 1)])
+def test_randomised_against_oracle(per_sample, layer):
+    B, V = 16, 100
+    for seed in range(6):
+        rs = synthetic.make_replay_sample(B, ['front'], (8, 8), V, 4, seed=40 + seed, crop_target_obj_voxel=per_sample, crop_radius=0.45)
+        pose, rg = rs['gripper_pose'][:, 0], rs['rot_grip_action_indicies'][:, 0]
+        bounds = rs['target_object_scene_bounds'][:, 0] if per_sample else torch.tensor([synthetic.SCENE_BOUNDS])
+        gen = torch.Generator().manual_seed(seed)
+        unit = 2 * torch.rand((1, B, 3), generator=gen) - 1
+        steps = torch.cat([torch.zeros(1, B, 2, dtype=torch.int32), torch.randint(-9, 10, (1, B, 1), generator=gen, dtype=torch.int32)], 2)
+        want_t, want_r, want_p, ok = ose3.augment([rs['front_point_cloud'][:, 0]], pose, rg, bounds, unit[0], steps[0].long(),
+                                                  [0.125] * 3, 5, V, 5, layer=layer)
+        ti, ri, xf, status = _plan(pose, rg, bounds, unit, steps, layer=layer)
+        if not ok:
+            assert int(status.item()) == -1 and int(ti.max()) == -1
+            continue
+        assert int(status.item()) == 0
+        assert torch.equal(ti.cpu().long(), want_t.long()), seed
+        assert torch.equal(ri.cpu().long(), want_r.long()), seed
+        moved = aug.transform_point_clouds([rs['front_point_cloud'][:, 0].to(DEV)], xf)[0]
+        assert float((moved.cpu() - want_p[0]).abs().max()) < 2e-6
+
+
+def test_retry_picks_the_first_attempt_that_keeps_the_whole_batch_inside():
+    B, V = 4, 100
+    rs = synthetic.make_replay_sample(B, ['front'], (8, 8), V, 4, seed=3)
+    pose, rg = rs['gripper_pose'][:, 0].clone(), rs['rot_grip_action_indicies'][:, 0]
+    bounds = torch.tensor([synthetic.SCENE_BOUNDS])
+    pose[2, :3] = torch.tensor(synthetic.SCENE_BOUNDS[:3]) + 0.01          # sample 2 sits in a corner of the scene
+    unit = torch.zeros(4, B, 3)
+    unit[0, 2] = -1.0                 # attempt 0 pushes sample 2 out of the lower bound -> the whole batch is re-drawn
+    unit[1, 2] = -0.9                 # attempt 1 as well
+    unit[2] = 0.05                    # attempt 2 keeps everyone inside
+    unit[3] = 0.5
+    steps = torch.zeros(4, B, 3, dtype=torch.int32)
+    steps[2, :, 2] = 3
+    ti, ri, xf, status = _plan(pose, rg, bounds, unit, steps)
+    assert int(status.item()) == 2
+    want_t, want_r, _, ok = ose3.augment([rs['front_point_cloud'][:, 0]], pose, rg, bounds, unit[2], steps[2].long(), [0.125] * 3, 5, V, 5)
+    assert ok and torch.equal(ti.cpu().long(), want_t.long()) and torch.equal(ri.cpu().long(), want_r.long())
+    # no attempt succeeds: flagged, labels poisoned
+    ti, ri, xf, status = _plan(pose, rg, bounds, unit[:2], steps[:2])
+    assert int(status.item()) == -1 and int(ti.max()) == -1 and int(ri.max()) == -1
+
+
+def test_reference_signature_wrapper_and_failure_raises():
+    B, V = 3, 50
+    rs = synthetic.make_replay_sample(B, ['front', 'wrist'], (8, 8), V, 4, seed=9)
+    pcd = [rs['front_point_cloud'][:, 0].to(DEV), rs['wrist_point_cloud'][:, 0].to(DEV)]
+    pose = rs['gripper_pose'][:, 0].to(DEV)
+    torch.manual_seed(0)
+    at, ar, out = aug.apply_se3_augmentation(pcd, pose, rs['trans_action_indicies'][:, 0].to(DEV), rs['rot_grip_action_indicies'][:, 0].to(DEV),
+                                             torch.tensor([synthetic.SCENE_BOUNDS], device=DEV), 0, torch.tensor([0.125] * 3, dtype=torch.float64),
+                                             [0.0, 0.0, 45.0], 5, V, 5, DEV)
+    assert at.shape == (B, 3) and ar.shape == (B, 4) and int(at.min()) >= 0 and int(at.max()) < V
+    assert torch.equal(ar[:, 3].cpu().long(), rs['rot_grip_action_indicies'][:, 0, 3].long())
+    assert len(out) == 2 and out[0].shape == pcd[0].shape
+    # rigid: pairwise distances preserved
+    a, b = pcd[0].reshape(B, 3, -1)[:, :, :40], out[0].reshape(B, 3, -1)[:, :, :40]
+    assert torch.allclose((a[:, :, :, None] - a[:, :, None, :]).norm(dim=1), (b[:, :, :, None] - b[:, :, None, :]).norm(dim=1), atol=1e-5)
+    pose_out = pose.clone()
+    pose_out[:, :3] = -50.0            # far outside: every attempt fails
+    with pytest.raises(Exception, match='Failing to perturb'):
+        aug.apply_se3_augmentation(pcd, pose_out, rs['trans_action_indicies'][:, 0].to(DEV), rs['rot_grip_action_indicies'][:, 0].to(DEV),
+                                   torch.tensor([synthetic.SCENE_BOUNDS], device=DEV), 0, torch.tensor([0.125] * 3, dtype=torch.float64),
+                                   [0.0, 0.0, 45.0], 5, V, 5, DEV)

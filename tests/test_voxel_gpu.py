@@ -11,6 +11,15 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
+@pytest.fixture(params=['tiles', 'table'], autouse=True)
+def chain(request):
+    """every test runs on both point chains: the tile-routed one (default) and the table-based fallback"""
+    from voxactb_amd import _lib
+    assert _lib.lib().vxb_voxelize_select_chain(1 if request.param == 'table' else 0) == 0
+    yield request.param
+    _lib.lib().vxb_voxelize_select_chain(0)
+
+
 def T(a):
     return torch.from_numpy(np.asarray(a))
 
@@ -24,8 +33,6 @@ def run(coords, feats, bounds, V):
     vg = VoxelGrid(bounds[0].tolist(), V, DEV, B, 0 if feats is None else feats.shape[-1], N)
     out = vg.coords_to_bounding_voxel_grid(coords.to(DEV), None if feats is None else feats.to(DEV), bounds.to(DEV))
     torch.cuda.synchronize()
-    # self-cleaning invariant: the cell table must be all-zero again
-    assert int(vg._ws[:B * V ** 3].abs().sum()) == 0
     return out, vg
 
 
@@ -122,6 +129,59 @@ def test_edge_cases():
         f = torch.from_numpy(g.standard_normal((1, p.shape[1], 3)).astype(np.float32))
         out, _ = run(p, f, bounds, V)
         assert same(out, ovox.voxelize(p, f, bounds, V)), n0
+
+
+def test_tile_chain_edges():
+    """sizes around the tile-routed chain's units: chunks of 2048 points, tiles of 8 x 8 x 16 cells, one heavy cell that
+    holds a whole sample, a grid smaller than one tile, point counts that are not a multiple of anything"""
+    g = np.random.default_rng(11)
+    bounds = torch.tensor([[0., 0., 0., 1., 1., 1.]])
+    for V, N in ((4, 1), (6, 63), (8, 2047), (16, 2048), (16, 2049), (24, 6000), (40, 4097)):
+        p = torch.from_numpy(g.uniform(-0.05, 1.05, (2, N, 3)).astype(np.float32))
+        f = torch.from_numpy(g.standard_normal((2, N, 3)).astype(np.float32))
+        out, _ = run(p, f, bounds, V)
+        assert same(out, ovox.voxelize(p, f, bounds, V)), (V, N)
+    # a whole 4-camera sample (65 536 points) in ONE cell next to a second sample spread over the grid
+    V, N = 20, 65536
+    p = torch.from_numpy(g.uniform(0.0, 1.0, (2, N, 3)).astype(np.float32))
+    p[0] = 0.5125 + 0.02 * p[0]
+    f = torch.from_numpy((g.standard_normal((2, N, 3)) * 10 ** g.uniform(-2, 2, (2, N, 1))).astype(np.float32))
+    out, _ = run(p, f, bounds, V)
+    assert same(out, ovox.voxelize(p, f, bounds, V))
+    # features: 0 .. 4 on the tile chain, 5 falls back to the table chain
+    p = torch.from_numpy(g.uniform(0.0, 1.0, (1, 3000, 3)).astype(np.float32))
+    for F in (0, 1, 2, 4, 5):
+        f = torch.from_numpy(g.standard_normal((1, 3000, F)).astype(np.float32))
+        out, _ = run(p, f if F else None, bounds, 12)
+        assert same(out, ovox.voxelize(p, f, bounds, 12)), F
+
+
+def test_fused_rigid_transform_equals_transform_then_voxelize():
+    """`xform` of vxb_voxelize_f32 (the SE(3) augmentation folded into the point load) against vxb_se3_points_f32 followed
+    by a plain voxelization, and against the oracle's perturb_points (reference augmentation.py:36-62)."""
+    from oracle import se3 as ose3
+    from voxactb_amd.voxel import augmentation as aug
+    B, H, W, V = 3, 24, 20, 20
+    cams = ['front', 'wrist']
+    pcd, rgb = cams_batch(B, cams, H, W, V, seed=5)
+    g = np.random.default_rng(2)
+    ang = torch.from_numpy(g.uniform(-0.8, 0.8, (B, 3)).astype(np.float32))
+    R = ose3.euler_angles_to_matrix(ang, 'XYZ')
+    t = torch.from_numpy((np.array(synthetic.SCENE_BOUNDS[:3]) + g.uniform(0.3, 0.7, (B, 3))).astype(np.float32))
+    c = t + torch.from_numpy(g.uniform(-0.1, 0.1, (B, 3)).astype(np.float32))
+    xf = torch.cat([R.reshape(B, 9), t, c], 1).contiguous().to(DEV)
+    bounds = torch.tensor([synthetic.SCENE_BOUNDS])
+    vg = VoxelGrid(synthetic.SCENE_BOUNDS, V, DEV, B, 3, len(cams) * H * W)
+    fused = vg.voxelize_cameras([p.to(DEV) for p in pcd], [r.to(DEV) for r in rgb], bounds.to(DEV), xform=xf)
+    moved = aug.transform_point_clouds([p.to(DEV) for p in pcd], xf)
+    plain = vg.voxelize_cameras(moved, [r.to(DEV) for r in rgb], bounds.to(DEV))
+    assert torch.equal(fused, plain)
+    # the kernel's points vs the reference formula (p - t) R + c evaluated by the oracle on the host
+    want = ose3.perturb_points(pcd, c - t, R, t, torch.tensor([[-10., -10., -10., 10., 10., 10.]]))
+    for w_, m_ in zip(want, moved):
+        assert float((m_.cpu() - w_).abs().max()) < 2e-6
+    ref = ovox.voxelize(*ovox.flatten_cameras([m.cpu() for m in moved], rgb), bounds, V)
+    assert same(fused, ref)
 
 
 def test_errors():

@@ -23,7 +23,7 @@ class VoxactbHipError(RuntimeError):
 
 
 _CT = {'int': ctypes.c_int, 'int64_t': ctypes.c_int64, 'size_t': ctypes.c_size_t, 'float': ctypes.c_float,
-       'uint32_t': ctypes.c_uint32, 'int32_t': ctypes.c_int32, 'vxb_stream_t': ctypes.c_void_p, 'void': None}
+       'double': ctypes.c_double, 'uint32_t': ctypes.c_uint32, 'int32_t': ctypes.c_int32, 'vxb_stream_t': ctypes.c_void_p, 'void': None}
 
 
 def parse_header(path=HEADER):
@@ -137,11 +137,43 @@ def _call(name, *args):
             conv.append(0)
         else:
             conv.append(a)
+    if dev >= 0 and dev != _current_device():
+        # a kernel launch goes to the CURRENT device (the null stream is per device, and a stream handle of another device
+        # is an invalid resource): make the tensors' device current for the launch.  Agents call torch.cuda.set_device in
+        # build(), so this branch is the safety net for callers that hold tensors on several devices in one process.
+        with torch.cuda.device(dev):
+            check(fn(*conv, _stream_of(dev)), name)
+        return
+    check(fn(*conv, _stream_of(dev)), name)
+
+
+_current_device = torch.cuda.current_device
+
+
+def _stream_of(dev):
     if _raw_stream is not None and dev >= 0:
-        st = _raw_stream(dev)
-    else:
-        st = torch.cuda.current_stream(dev if dev >= 0 else None).cuda_stream
-    check(fn(*conv, st), name)
+        return _raw_stream(dev)
+    return torch.cuda.current_stream(dev if dev >= 0 else None).cuda_stream
+
+
+class on_device:
+    """`with on_device(tensor_or_device):` -- make that HIP device current for raw C-ABI launches (no-op when it already is)."""
+
+    def __init__(self, where):
+        dev = where.device if isinstance(where, torch.Tensor) else torch.device(where)
+        self._idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        self._ctx = None
+
+    def __enter__(self):
+        if self._idx != torch.cuda.current_device():
+            self._ctx = torch.cuda.device(self._idx)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+        return False
 
 
 def stream_ptr(device=None):

@@ -1,16 +1,22 @@
-"""LaunchUtils API -- `create_agent(cfg)` and the replay schema of `create_replay(...)`
-(reference: peract/agents/peract_bc/launch_utils.py:37-164 and :663-829).
+"""LaunchUtils API -- `create_replay`, `fill_replay`, `fill_multi_task_replay`, `create_agent`
+(reference: peract/agents/peract_bc/launch_utils.py:37-164, :167-228, :301-488, :491-660, :663-829), the four calls
+`run_seed_fn.py:107-129` makes for `method.name == 'PERACT_BC'`.
 
 `create_agent` accepts any object with the attribute paths hydra's DictConfig exposes upstream (cfg.method.*,
 cfg.rlbench.*, cfg.replay.batch_size, cfg.ddp.num_devices, cfg.framework.*), see `default_cfg()`.
-`create_replay` builds YARR's TaskUniformReplayBuffer when `yarr` is importable (the replay store is a "next" row of
-SURVEY.md section 8f, not rebuilt here); `replay_schema` returns the element list without YARR.
-Demo loading (`fill_replay`, :491-660) needs RLBench data and is out of scope.
+`create_replay` builds YARR's TaskUniformReplayBuffer when `yarr` is importable, else the built-in shard store
+(voxactb_amd/replay.py); `replay_schema` returns the element list either way.
+`fill_replay` / `_add_keypoints_to_replay` / `_get_action` do the label arithmetic here (helpers/rotation.py) and reach the
+simulator-side pieces -- stored-demo loading, keypoint discovery, observation extraction, CLIP tokenizer / text encoder --
+through `UPSTREAM`, a table of callables that resolves to the reference's own modules when they are importable (the
+drop-in runs inside the reference tree) and can be replaced for tests or other data sources (`set_upstream(...)`).
 """
+import logging
 from types import SimpleNamespace
 
 import numpy as np
 
+from ...helpers import rotation
 from ...helpers.preprocess_agent import PreprocessAgent
 from .perceiver_lang_io import PerceiverVoxelLangEncoder
 from .qattention_peract_bc_agent import QAttentionPerActBCAgent
@@ -19,6 +25,7 @@ from .qattention_stack_agent import QAttentionStackAgent
 REWARD_SCALE = 100.0
 LOW_DIM_DOMINANT_ASSISTIVE_SIZE = 7
 LOW_DIM_SIZE = 4
+SINGLE_ARM = ['right', 'left']
 
 
 def _ns(d):
@@ -145,3 +152,263 @@ def create_agent(cfg):
     rotation_agent = QAttentionStackAgent(qattention_agents=agents, rotation_resolution=cfg.method.rotation_resolution,
                                           camera_names=cfg.rlbench.cameras)
     return PreprocessAgent(pose_agent=rotation_agent)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# replay fill (reference :167-228 _get_action, :301-488 _add_keypoints_to_replay, :491-595 fill_replay, :598-660 fill_multi_task_replay)
+# ----------------------------------------------------------------------------------------------------------------------
+class _Upstream:
+    """Simulator-side callables the fill needs.  Unset entries are looked up in the reference tree on first use:
+        get_stored_demos            rlbench.utils.get_stored_demos                       (launch_utils.py:534-542)
+        get_stored_real_world_demos rlbench.utils.get_stored_real_world_demos            (:524-532)
+        keypoint_discovery          helpers.demo_loading_utils.keypoint_discovery        (:574-578)
+        keypoint_discovery_no_duplicate  helpers.demo_loading_utils.keypoint_discovery_no_duplicate (:572)
+        extract_obs                 helpers.utils.extract_obs                            (:373-392)
+        extract_left_and_right_arm_instruction  helpers.utils....                        (:366)
+        get_new_scene_bounds_based_on_crop      helpers.utils....                        (:343-347)
+        tokenize / load_clip / build_model      helpers.clip.core.clip                   (:393, :511-514)
+    """
+    _WHERE = {
+        'get_stored_demos': ('rlbench.utils', 'get_stored_demos'),
+        'get_stored_real_world_demos': ('rlbench.utils', 'get_stored_real_world_demos'),
+        'keypoint_discovery': ('helpers.demo_loading_utils', 'keypoint_discovery'),
+        'keypoint_discovery_no_duplicate': ('helpers.demo_loading_utils', 'keypoint_discovery_no_duplicate'),
+        'extract_obs': ('helpers.utils', 'extract_obs'),
+        'extract_left_and_right_arm_instruction': ('helpers.utils', 'extract_left_and_right_arm_instruction'),
+        'get_new_scene_bounds_based_on_crop': ('helpers.utils', 'get_new_scene_bounds_based_on_crop'),
+        'tokenize': ('helpers.clip.core.clip', 'tokenize'),
+        'load_clip': ('helpers.clip.core.clip', 'load_clip'),
+        'build_model': ('helpers.clip.core.clip', 'build_model'),
+    }
+
+    def __init__(self):
+        self._fn = {}
+
+    def set(self, **fns):
+        for k, v in fns.items():
+            if k not in self._WHERE:
+                raise KeyError('unknown upstream hook %r (known: %s)' % (k, ', '.join(sorted(self._WHERE))))
+            self._fn[k] = v
+
+    def __getattr__(self, name):
+        if name.startswith('_') or name not in self._WHERE:
+            raise AttributeError(name)
+        if name not in self._fn:
+            mod, attr = self._WHERE[name]
+            try:
+                import importlib
+                self._fn[name] = getattr(importlib.import_module(mod), attr)
+            except Exception as e:  # noqa: BLE001
+                raise ImportError('fill_replay needs %s.%s from the VoxAct-B tree (RLBench demos / CLIP are not part of '
+                                  'voxactb_amd); put the reference on sys.path or inject it with '
+                                  'launch_utils.set_upstream(%s=...)' % (mod, attr, name)) from e
+        return self._fn[name]
+
+
+UPSTREAM = _Upstream()
+
+
+def set_upstream(**fns):
+    UPSTREAM.set(**fns)
+
+
+def _acting_side(which_arm, keypoint_label, dominant_assistive_arm):
+    """which gripper a keyframe's action belongs to (reference :178-198, :404-412)."""
+    if which_arm == 'right' or dominant_assistive_arm == 'right':
+        return 'right'
+    if which_arm == 'left' or dominant_assistive_arm == 'left':
+        return 'left'
+    if which_arm == 'multiarm':
+        if keypoint_label == 0:
+            return 'right'
+        if keypoint_label == 1:
+            return 'left'
+    raise NotImplementedError('which_arm=%r label=%r' % (which_arm, keypoint_label))
+
+
+def _get_action(obs_tp1, obs_tm1, rlbench_scene_bounds, voxel_sizes, bounds_offset, rotation_resolution, crop_augmentation,
+                which_arm, keypoint_label, dominant_assistive_arm=''):
+    """-> (trans_indicies, rot_and_grip_indicies, ignore_collisions, action[8], attention_coordinates)   (reference :167-228)."""
+    if not (which_arm in SINGLE_ARM or which_arm in ('multiarm', 'dominant', 'assistive')):
+        raise NotImplementedError("which_arm=%r: the two-gripper action belongs to the one_policy_more_heads baseline "
+                                  "(SURVEY.md a25)" % (which_arm,))
+    side = _acting_side(which_arm, keypoint_label, dominant_assistive_arm)
+    gripper_pose = getattr(obs_tp1, 'gripper_%s_pose' % side)
+    gripper_open = getattr(obs_tp1, 'gripper_%s_open' % side)
+    quat = rotation.normalize_quaternion(gripper_pose[3:])
+    if quat[-1] < 0:
+        quat = -quat
+    disc_rot = rotation.quaternion_to_discrete_euler(quat, rotation_resolution)
+    attention_coordinate = gripper_pose[:3]          # a VIEW upstream too: the crop jitter below shifts the pose itself
+    trans_indicies, attention_coordinates = [], []
+    bounds = np.array(rlbench_scene_bounds)
+    ignore_collisions = int(obs_tm1.ignore_collisions)
+    for depth, vox_size in enumerate(voxel_sizes):   # PerAct uses a single voxelization level
+        if depth > 0:
+            if crop_augmentation:
+                shift = bounds_offset[depth - 1] * 0.75
+                attention_coordinate += np.random.uniform(-shift, shift, size=(3,))
+            bounds = np.concatenate([attention_coordinate - bounds_offset[depth - 1],
+                                     attention_coordinate + bounds_offset[depth - 1]])
+        index = rotation.point_to_voxel_index(gripper_pose[:3], vox_size, bounds)
+        trans_indicies.extend(index.tolist())
+        res = (bounds[3:] - bounds[:3]) / vox_size
+        attention_coordinate = bounds[:3] + res * index
+        attention_coordinates.append(attention_coordinate)
+    rot_and_grip_indicies = disc_rot.tolist() + [int(gripper_open)]
+    action = np.concatenate([gripper_pose, np.array([float(gripper_open)])])
+    return trans_indicies, rot_and_grip_indicies, ignore_collisions, action, attention_coordinates
+
+
+def _per_task(value, task_idx):
+    """cfg entries that are a scalar for one task and a list for multi-task runs (:320-334)."""
+    if isinstance(value, (float, int, str)):
+        return value
+    return value[task_idx]
+
+
+def _add_keypoints_to_replay(cfg, task, task_idx, replay, inital_obs, demo, episode_keypoints, cameras, rlbench_scene_bounds,
+                             voxel_sizes, bounds_offset, rotation_resolution, crop_augmentation, description='',
+                             clip_model=None, device='cpu', labels=None, dominant_assistive_arm=''):
+    """One replay transition per remaining keyframe of the episode, then the terminal observation (reference :301-488)."""
+    import torch
+    m = cfg.method
+    if m.which_arm == 'both':
+        raise NotImplementedError("which_arm='both' belongs to the one_policy_more_heads baseline (SURVEY.md a25)")
+    scene_bounds = rlbench_scene_bounds if type(rlbench_scene_bounds[0]) is float else rlbench_scene_bounds[task_idx]
+    crop_radius = _per_task(m.crop_radius, task_idx)
+    obs = inital_obs
+    final_obs, obs_dict_tp1_kw = None, None
+    sentence_emb = token_embs = None
+    for k, keypoint in enumerate(episode_keypoints):
+        obs_tp1 = demo[keypoint]
+        obs_tm1 = demo[max(0, keypoint - 1)]
+        if m.crop_target_obj_voxel:                  # the grid follows the target object (:339-347)
+            radius = obs_tp1.auto_crop_radius if (crop_radius == 'auto' and obs_tp1.auto_crop_radius != 0.0) else crop_radius
+            scene_bounds = UPSTREAM.get_new_scene_bounds_based_on_crop(radius, obs_tp1.target_object_pos)
+        keypoint_label = labels[k] if labels is not None else -1
+        trans_indicies, rot_grip_indicies, ignore_collisions, action, _ = _get_action(
+            obs_tp1, obs_tm1, scene_bounds, voxel_sizes, bounds_offset, rotation_resolution, crop_augmentation, m.which_arm,
+            keypoint_label, dominant_assistive_arm)
+        terminal = (k == len(episode_keypoints) - 1)
+        reward = float(terminal) * REWARD_SCALE if terminal else 0
+        which_arm, text = m.which_arm, description
+        extra = {}
+        if m.which_arm == 'multiarm':
+            left_text, right_text = UPSTREAM.extract_left_and_right_arm_instruction(description)
+            which_arm = _acting_side('multiarm', keypoint_label, '')
+            text = right_text if which_arm == 'right' else left_text
+            if getattr(m, 'arm_pred_input', False):
+                extra['keypoint_label'] = keypoint_label
+        elif m.arm_id_to_proprio:
+            extra['keypoint_label'] = keypoint_label
+        obs_dict_tp1_kw = dict(cameras=cameras, episode_length=cfg.rlbench.episode_length, which_arm=which_arm, **extra)
+        obs_dict = UPSTREAM.extract_obs(obs, t=k, **obs_dict_tp1_kw)
+        tokens = torch.from_numpy(np.asarray(UPSTREAM.tokenize([text]))).to(device)
+        sentence_emb, token_embs = clip_model.encode_text_with_embeddings(tokens)
+        obs_dict['lang_goal_emb'] = sentence_emb[0].float().detach().cpu().numpy()
+        obs_dict['lang_token_embs'] = token_embs[0].float().detach().cpu().numpy()
+        side = _acting_side(m.which_arm, keypoint_label, dominant_assistive_arm)
+        if m.crop_target_obj_voxel:
+            obs_dict['target_object_scene_bounds'] = scene_bounds
+        final_obs = {'trans_action_indicies': trans_indicies, 'rot_grip_action_indicies': rot_grip_indicies,
+                     'gripper_pose': getattr(obs_tp1, 'gripper_%s_pose' % side), 'task': task,
+                     'lang_goal': np.array([text], dtype=object)}
+        if m.arm_pred_loss:
+            final_obs['label'] = [labels[k]]
+        others = {'demo': True}
+        others.update(final_obs)
+        others.update(obs_dict)
+        replay.add(action, reward, terminal, False, **others)
+        obs = obs_tp1
+    if final_obs is None:
+        return
+    # terminal observation of the episode (:462-488)
+    obs_dict_tp1 = UPSTREAM.extract_obs(obs_tp1, t=k + 1, **obs_dict_tp1_kw)
+    obs_dict_tp1['lang_goal_emb'] = sentence_emb[0].float().detach().cpu().numpy()
+    obs_dict_tp1['lang_token_embs'] = token_embs[0].float().detach().cpu().numpy()
+    if m.crop_target_obj_voxel:
+        obs_dict_tp1['target_object_scene_bounds'] = scene_bounds
+    obs_dict_tp1.pop('wrist_world_to_cam', None)
+    obs_dict_tp1.update(final_obs)
+    replay.add_final(**obs_dict_tp1)
+
+
+def _dominant_assistive_side(which_arm, d_idx, num_demos):
+    """the stored demos are half-and-half: the first half has the LEFT arm acting / the RIGHT arm stabilizing (:551-568)."""
+    first_half = num_demos == 1 or d_idx < int(num_demos / 2)
+    if which_arm == 'dominant':
+        return 'left' if first_half else 'right'
+    if which_arm == 'assistive':
+        return 'right' if first_half else 'left'
+    return ''
+
+
+def fill_replay(cfg, obs_config, rank, replay, task, task_idx, num_demos, demo_augmentation, demo_augmentation_every_n,
+                cameras, rlbench_scene_bounds, voxel_sizes, bounds_offset, rotation_resolution, crop_augmentation,
+                clip_model=None, device='cpu', keypoint_method='heuristic'):
+    """Stored demos of one task -> keyframe transitions in `replay` (reference :491-595)."""
+    m = cfg.method
+    logging.getLogger().setLevel(cfg.framework.logging_level)
+    if clip_model is None:
+        model, _ = UPSTREAM.load_clip('RN50', jit=False, device=device)
+        clip_model = UPSTREAM.build_model(model.state_dict())
+        clip_model.to(device)
+        del model
+    logging.debug('Filling %s replay ...' % task)
+    loader = UPSTREAM.get_stored_real_world_demos if getattr(m, 'is_real_robot', False) else UPSTREAM.get_stored_demos
+    for d_idx in range(num_demos):
+        demo = loader(amount=1, image_paths=False, dataset_root=cfg.rlbench.demo_path, variation_number=-1, task_name=task,
+                      obs_config=obs_config, random_selection=False, from_episode_number=d_idx, which_arm=m.which_arm)[0]
+        descs = demo._observations[0].misc['descriptions']
+        side = _dominant_assistive_side(m.which_arm, d_idx, num_demos)
+        kp_kw = dict(which_arm=m.which_arm, method=keypoint_method, saved_every_last_inserted=m.saved_every_last_inserted)
+        two_arm_kw = dict(dominant_assistive_arm=side,
+                          use_default_stopped_buffer_timesteps=m.use_default_stopped_buffer_timesteps,
+                          stopped_buffer_timesteps_overwrite=m.stopped_buffer_timesteps_overwrite)
+        labels = None
+        if m.keypoint_discovery_no_duplicate:
+            episode_keypoints, labels = UPSTREAM.keypoint_discovery_no_duplicate(demo, **kp_kw, **two_arm_kw)
+        elif m.which_arm in ('both', 'multiarm', 'dominant', 'assistive'):
+            episode_keypoints, labels = UPSTREAM.keypoint_discovery(demo, **kp_kw, **two_arm_kw)
+        else:
+            episode_keypoints = UPSTREAM.keypoint_discovery(demo, **kp_kw)
+        if rank == 0:
+            logging.info('Loading Demo(%d) - found %d keypoints - %s' % (d_idx, len(episode_keypoints), task))
+        for i in range(len(demo) - 1):
+            if not demo_augmentation and i > 0:
+                break
+            if i % demo_augmentation_every_n != 0:
+                continue
+            # keyframes the starting point has already passed are dropped (:585-588); `labels` stays unsliced upstream as
+            # well, i.e. labels[k] keeps referring to the ORIGINAL keyframe list (:349)
+            while len(episode_keypoints) > 0 and i >= episode_keypoints[0]:
+                episode_keypoints = episode_keypoints[1:]
+            if len(episode_keypoints) == 0:
+                break
+            _add_keypoints_to_replay(cfg, task, task_idx, replay, demo[i], demo, episode_keypoints, cameras, rlbench_scene_bounds,
+                                     voxel_sizes, bounds_offset, rotation_resolution, crop_augmentation, description=descs[0],
+                                     clip_model=clip_model, device=device, labels=labels, dominant_assistive_arm=side)
+    logging.debug('Replay %s filled with demos.' % task)
+
+
+def fill_multi_task_replay(cfg, obs_config, rank, replay, tasks, num_demos, demo_augmentation, demo_augmentation_every_n,
+                           cameras, rlbench_scene_bounds, voxel_sizes, bounds_offset, rotation_resolution, crop_augmentation,
+                           clip_model=None, keypoint_method='heuristic'):
+    """Every task's demos into one task-uniform replay (reference :598-660).  Upstream forks one process per task over a
+    multiprocessing.Manager store; the fill is a start-up cost outside the hot path, so the tasks are filled in turn, in
+    this process, with one text encoder shared by all of them -- same transitions, same order within a task."""
+    import torch
+    if getattr(cfg.ddp, 'cpu', False) or not torch.cuda.is_available():
+        model_device = torch.device('cpu')
+    else:
+        model_device = torch.device('cuda:%d' % torch.cuda.current_device())
+    if clip_model is None:
+        model, _ = UPSTREAM.load_clip('RN50', jit=False, device=model_device)
+        clip_model = UPSTREAM.build_model(model.state_dict())
+        clip_model.to(model_device)
+        del model
+    for task_idx, task in enumerate(tasks):
+        fill_replay(cfg, obs_config, rank, replay, task, int(task_idx), num_demos, demo_augmentation, demo_augmentation_every_n,
+                    cameras, rlbench_scene_bounds, voxel_sizes, bounds_offset, rotation_resolution, crop_augmentation,
+                    clip_model, model_device, keypoint_method)

@@ -227,6 +227,17 @@ def _r4(n):
     return (n + 3) & ~3
 
 
+def _mix32(a, b):
+    """two-round 32-bit finaliser of (a, b): per-layer / per-rank dropout seeds that share no low-bit structure."""
+    x = (int(a) * 0x9E3779B1 + int(b) * 0x85EBCA77 + 0xC2B2AE3D) & 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
 class PerceiverEngine:
     """Explicit forward / backward of the encoder on HIP kernels.  Parameter storage = the module's Parameters."""
 
@@ -261,6 +272,17 @@ class PerceiverEngine:
         self.fused_attention = os.environ.get('VOXACTB_FUSED_ATTENTION', '1') != '0'   # bf16 / bf16x3 modes, head dim 64
 
     # -------------------------------------------------------------------------------------------------- helpers
+    def _draw_seed(self):
+        """One 32-bit dropout seed per training step, drawn from torch's default CPU generator (so `torch.manual_seed`
+        governs it and a resumed run does not replay the first steps' masks) and mixed with the data-parallel rank (the
+        reference's nn.Dropout draws independent masks on every rank, perceiver :124-128).  A CPU draw: no device sync."""
+        s = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        rank = 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank = torch.distributed.get_rank()
+        self.step_seed = _mix32(s, 0x51ED27 + rank)
+        return self.step_seed
+
     def p(self, name):
         return self.P[name].data
 
@@ -394,8 +416,7 @@ class PerceiverEngine:
         Nctx = T0 + T1
         dev = vox.device
         if seed is None:
-            self.step_seed += 1
-            seed = self.step_seed
+            seed = self._draw_seed() if training else 0
         p_in = m.input_dropout if training else 0.0
         p_at = m.attn_dropout if training else 0.0
         p_de = m.decoder_dropout if training else 0.0
@@ -421,7 +442,7 @@ class PerceiverEngine:
         xn, xm, xr = ops.layernorm_fwd(x, self.p(pre + '.norm.weight'), self.p(pre + '.norm.bias'))
         cn, cm, cr = ops.layernorm_fwd(ctx2d, self.p(pre + '.norm_context.weight'), self.p(pre + '.norm_context.bias'))
         x1, ca = self._attn_fwd(pre, xn.view(B, L, D), cn.view(B, Nctx, Cx), m.cross_heads, m.cross_dim_head, p_in,
-                                seed * 131 + 1, x, save)
+                                _mix32(seed, 1), x, save)
         if save:
             c['cross'] = dict(x=x, xn=xn, xm=xm, xr=xr, cn=cn, cm=cm, cr=cr, attn=ca)
         x, c['cross_ff'] = self._ff_fwd('cross_attend_blocks.1', x1, save)
@@ -431,7 +452,7 @@ class PerceiverEngine:
             pre = 'layers.%d.0' % i
             xn, xm, xr = ops.layernorm_fwd(x, self.p(pre + '.norm.weight'), self.p(pre + '.norm.bias'))
             x1, sa = self._attn_fwd(pre, xn.view(B, L, D), xn.view(B, L, D), m.latent_heads, m.latent_dim_head, p_at,
-                                    seed * 131 + 2 + i, x, save)
+                                    _mix32(seed, 2 + i), x, save)
             x2, fc = self._ff_fwd('layers.%d.1' % i, x1, save)
             if save:
                 c['layers'].append(dict(x=x, xn=xn, xm=xm, xr=xr, attn=sa, ff=fc))
@@ -441,7 +462,7 @@ class PerceiverEngine:
         qn, qm, qr = ops.layernorm_fwd(ctx2d, self.p(pre + '.norm.weight'), self.p(pre + '.norm.bias'))
         ln, lm, lr = ops.layernorm_fwd(x, self.p(pre + '.norm_context.weight'), self.p(pre + '.norm_context.bias'))
         z, da = self._attn_fwd(pre, qn.view(B, Nctx, Cx), ln.view(B, L, D), m.cross_heads, m.cross_dim_head, p_de,
-                               seed * 131 + 100, None, save)
+                               _mix32(seed, 100), None, save)
         z = z.view(B, Nctx, Cx)
         zv = z[:, T0:]                                   # [B, G^3, Cx] view, batch stride Nctx*Cx
         ss1 = ops.ss3d_max_fwd(zv, Nctx * Cx, B, G, Cx)  # perceiver :451

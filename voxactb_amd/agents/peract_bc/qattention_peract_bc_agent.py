@@ -26,7 +26,7 @@ from ... import ops
 from ..._lib import VoxactbHipError
 from ...flat_params import FlatParams
 from ...helpers.optim.lamb import Lamb
-from ...voxel.augmentation import apply_se3_augmentation
+from ...voxel.augmentation import se3_augmentation_plan
 from ...voxel.voxel_grid import VoxelGrid
 from ...yarr_agent import Agent, ActResult, ScalarSummary, HistogramSummary, Summary
 
@@ -88,10 +88,11 @@ class QFunction(nn.Module):
             ignore_collision = predc.long()
         return coords, rot_and_grip_indicies, ignore_collision
 
-    def voxelize(self, rgb_pcd, pcd, bounds):
-        """agent :85-100: flatten cameras + VoxelGrid, fused.  Returns the channels-last grid [B,V,V,V,10]."""
+    def voxelize(self, rgb_pcd, pcd, bounds, xform=None):
+        """agent :85-100: flatten cameras + VoxelGrid, fused (and, with `xform`, the SE(3) augmentation's rigid transform
+        of the clouds, augmentation.py:36-62).  Returns the channels-last grid [B,V,V,V,10]."""
         rgb = [rp[0] for rp in rgb_pcd]
-        return self._voxelizer.voxelize_cameras(pcd, rgb, bounds)
+        return self._voxelizer.voxelize_cameras(pcd, rgb, bounds, xform)
 
     def forward(self, rgb_pcd, proprio, pcd, lang_goal_emb, lang_token_embs, bounds=None, prev_bounds=None,
                 prev_layer_voxel_grid=None):
@@ -174,6 +175,9 @@ class QAttentionPerActBCAgent(Agent):
         if dev.type != 'cuda':
             raise VoxactbHipError('voxactb_amd agents run on a HIP device only (got %s); there is no CPU fallback' % dev)
         self._dev = dev
+        # the C-ABI launches go to the CURRENT HIP device: run_seed_fn.py / OfflineTrainRunner pass `device=rank` and never
+        # call set_device themselves (reference modules follow their tensors; raw launches do not)
+        torch.cuda.set_device(dev)
         self._voxelizer = VoxelGrid(coord_bounds=self._coordinate_bounds, voxel_size=self._voxel_size, device=dev,
                                     batch_size=self._batch_size if training else 1, feature_size=self._voxel_feature_size,
                                     max_num_coords=int(np.prod(self._image_resolution)) * self._num_cameras)
@@ -182,6 +186,7 @@ class QAttentionPerActBCAgent(Agent):
         self._coordinate_bounds = torch.tensor(self._coordinate_bounds, device=dev).unsqueeze(0)
         if self._training:
             self._arena = FlatParams(self._q, dev)
+            self._arena.broadcast_weights(0)            # DDP's wrap-time parameter broadcast (agent :50-54)
             if self._optimizer_type == 'lamb':
                 self._optimizer = Lamb(self._q.parameters(), lr=self._lr, weight_decay=self._lambda_weight_l2,
                                        betas=(0.9, 0.999), adam=False)
@@ -239,6 +244,15 @@ class QAttentionPerActBCAgent(Agent):
         ops.softmax_rows(buf, buf.shape[0], 2, 4)
         return buf[:, :2]
 
+    def _check_se3_status(self):
+        """augmentation.py:119-120 raises after 100 failed attempts; the device kernel flags the same condition (and poisons
+        that step's labels, so its loss is NaN) -- surfaced here, at the start of the next update(), without a mid-step sync."""
+        st = getattr(self, '_se3_status', None)
+        if st is not None:
+            self._se3_status = None
+            if int(st.item()) < 0:
+                raise Exception('Failing to perturb action and keep it within bounds.')
+
     # ------------------------------------------------------------------------------------------------------------ update
     def update(self, step: int, replay_sample: dict) -> dict:
         action_trans = replay_sample['trans_action_indicies'][:, self._layer * 3:self._layer * 3 + 3].int()
@@ -267,14 +281,17 @@ class QAttentionPerActBCAgent(Agent):
         obs, pcd = self._preprocess_inputs(replay_sample)
         bs = pcd[0].shape[0]
 
+        xform = None
         if self._transform_augmentation:                                       # agent :469-483
-            action_trans, action_rot_grip, pcd = apply_se3_augmentation(
-                pcd, action_gripper_pose, action_trans, action_rot_grip, bounds, self._layer,
+            self._check_se3_status()               # last step's retry budget (no sync: that step has long finished)
+            action_trans, action_rot_grip, xform, self._se3_status = se3_augmentation_plan(
+                action_gripper_pose.to(device), action_rot_grip.to(device), bounds, self._layer,
                 self._transform_augmentation_xyz, self._transform_augmentation_rpy,
                 self._transform_augmentation_rot_resolution, self._voxel_size, self._rotation_resolution, device)
 
-        # forward (agent :486-508): voxelize + encoder, keeping the backward cache
-        grid = self._q.voxelize(obs, pcd, bounds)
+        # forward (agent :486-508): voxelize (the augmentation's rigid transform rides on the point load) + encoder,
+        # keeping the backward cache
+        grid = self._q.voxelize(obs, pcd, bounds, xform)
         voxel_grid = grid.permute(0, 4, 1, 2, 3).detach()
         eng = self._q.encoder.engine()
         outs, cache = eng.forward(grid, proprio, lang_token_embs, training=True, save=True)
@@ -433,6 +450,8 @@ class QAttentionPerActBCAgent(Agent):
             elif '_voxelizer' not in k:
                 logging.warning("key %s not found in checkpoint" % k)
         self._q.load_state_dict(merged)
+        if self._training:
+            self._arena.broadcast_weights(0)            # every rank resumes from rank 0's file contents
 
     def load_weights(self, savedir: str):
         weight_file = os.path.join(savedir, '%s.pt' % self._name)

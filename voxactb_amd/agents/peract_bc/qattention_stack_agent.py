@@ -5,7 +5,7 @@ from typing import List
 import numpy as np
 import torch
 
-from ...voxel.augmentation import discrete_euler_to_quaternion
+from ...helpers.rotation import discrete_euler_to_quaternion, point_to_pixel_index
 from ...yarr_agent import Agent, ActResult, Summary
 
 NAME = 'QAttentionStackAgent'
@@ -25,6 +25,10 @@ class QAttentionStackAgent(Agent):
         self._device = device
         for qa in self._qattention_agents:
             qa.build(training, device)
+
+    def _pixel_device(self):
+        d = self._device
+        return torch.device('cuda:%d' % d) if isinstance(d, int) else (torch.device('cpu') if d is None else torch.device(d))
 
     def update(self, step: int, replay_sample: dict) -> dict:
         total_losses = 0.
@@ -52,6 +56,13 @@ class QAttentionStackAgent(Agent):
             observation['attention_coordinate'] = act_results.observation_elements['attention_coordinate']
             observation['prev_layer_voxel_grid'] = act_results.observation_elements['prev_layer_voxel_grid']
             observation['prev_layer_bounds'] = act_results.observation_elements['prev_layer_bounds']
+            if not is_real_robot:          # where the chosen voxel projects into every camera (stack agent :62-70)
+                for n in self._camera_names:
+                    px, py = point_to_pixel_index(attention_coordinate[0],
+                                                  observation['%s_camera_extrinsics' % n][0, 0].cpu().numpy(),
+                                                  observation['%s_camera_intrinsics' % n][0, 0].cpu().numpy())
+                    observation['%s_pixel_coord' % n] = torch.tensor([[[py, px]]], dtype=torch.float32, device=self._pixel_device())
+                    observation_elements['%s_pixel_coord' % n] = [py, px]
             infos.update(act_results.info)
         rgai = torch.cat(rot_grip, 1)[0].cpu().numpy()
         ignore_collisions = float(torch.cat(coll, 1)[0].cpu().numpy())

@@ -652,7 +652,10 @@ __global__ void ce_final_kernel(const float* __restrict__ x, long long P, const 
     }
     const float l = m + logf(s);
     lse[b] = l;
-    loss[b] = l - x[(long long)b * P + label[b]];
+    // a label outside [0, P) (a corrupt replay entry) must not become an out-of-bounds read: the loss of that sample is NaN,
+    // which surfaces at the runner's `.item()` (the reference raises an indexing error at the same place, agent :519-545)
+    const int lab = label[b];
+    loss[b] = ((unsigned)lab < (unsigned long long)P) ? l - x[(long long)b * P + lab] : NAN;
     argmax[b] = arg;
 }
 
@@ -663,7 +666,9 @@ __global__ void __launch_bounds__(256) ce_grad_kernel(const float* __restrict__ 
         const int b = (int)(i / P);
         const long long p = i - (long long)b * P;
         float g = expf(x[i] - lse[b]);
-        if (p == label[b]) g -= 1.0f;
+        const int lab = label[b];
+        if (p == lab) g -= 1.0f;
+        if ((unsigned)lab >= (unsigned long long)P) g = NAN;          // invalid label: poison the row, see ce_final_kernel
         dx[i] = g * gscale;
     }
 }
@@ -693,13 +698,14 @@ __global__ void __launch_bounds__(64) ce_rows_kernel(const float* __restrict__ l
     s = wave_sum(s);
     const float l = m + logf(s);
     const int lab = labels[row * segs.n + sg];
+    const bool lab_ok = (unsigned)lab < (unsigned)n;                  // invalid label -> NaN loss / gradient, never an OOB read
     if (lane == 0) {
-        loss[row * segs.n + sg] = l - x[lab];
+        loss[row * segs.n + sg] = lab_ok ? l - x[lab] : NAN;
         pred[row * segs.n + sg] = arg;
     }
     if (dlogits) {
         float* d = dlogits + (long long)row * ld + segs.col0[sg];
-        for (int c = lane; c < n; c += 64) d[c] = (expf(x[c] - l) - (c == lab ? 1.0f : 0.0f)) * gscale;
+        for (int c = lane; c < n; c += 64) d[c] = lab_ok ? (expf(x[c] - l) - (c == lab ? 1.0f : 0.0f)) * gscale : NAN;
     }
 }
 

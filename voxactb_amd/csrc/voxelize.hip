@@ -21,24 +21,23 @@
 //
 // Integer atomics only => run-to-run deterministic, and bit-identical to the CPU reference in all
 // channels.  fp32 semantics follow the reference op for op (true division, the two +1e-12 terms).
-#include "common.h"
+//
+// Since round 2 the chain above is the FALLBACK (F > 4 features, V > 200, N >= 2^20): the default point chain is the
+// tile-routed one in voxelize_tiles.hip (no dense table, no sort, stable ballot ranks), which runs on a side stream next
+// to the `fill` store stream of this file and patches the occupied cells in afterwards.
+#include "voxelize.h"
 #include <limits.h>
+#include <stdlib.h>
 
 namespace {
 
-constexpr int VOX_MAX_SRC = 8;
-constexpr int VOX_MAX_F = 8;
+using VoxSrc = vox::Src;
+using VoxGeom = vox::Geom;
+constexpr int VOX_MAX_SRC = vox::MAX_SRC;
+constexpr int VOX_MAX_F = vox::MAX_F;
 constexpr int VOX_SHORT = 16;     // cells with <= this many points are reduced by one thread
 constexpr int VOX_CHUNK = 2048;   // ids expanded per bitmap sweep in the long path (64 words x 32 bits)
 
-struct VoxSrc {
-    const float* c[VOX_MAX_SRC];
-    const float* f[VOX_MAX_SRC];
-};
-struct VoxGeom {
-    int B, n_src, pps, N, F, V, bounds_rows;
-    long long cb, cc, cp, fb, fc, fp;
-};
 struct VoxWs {
     int *table, *ctr, *occ_n, *cellid, *rank, *occ_cell, *occ_cnt, *occ_base, *seg, *longl;
     float* pdata;        // [B*N][8]: xyz, up to 4 features, point id (int bits) of every placed point, segment order
@@ -66,27 +65,9 @@ __host__ inline VoxWs vox_ws_carve(void* ws, long long B, long long N, long long
     return w;
 }
 
-// voxel_grid.py:153-163 for one axis; returns the index in the (V+2)-grid, clamped to [0, V+1].
-__device__ __forceinline__ int vox_axis_index(float p, float mn, float mx, int V) {
-    const float Vf = __fadd_rn((float)V, 1e-12f);          // dims_orig.float() + MIN_DENOMINATOR
-    const float res = __fdiv_rn(__fsub_rn(mx, mn), Vf);    // :157
-    const float den = __fadd_rn(res, 1e-12f);              // :158
-    const float org = __fsub_rn(mn, res);                  // :160
-    const float q = floorf(__fdiv_rn(__fsub_rn(p, org), den));
-    // .int() then min/max (:161-164).  NaN / huge values end in a border cell (0 or V+1) on CPU
-    // and here alike; border cells are cropped (:184), so only "is it a border" matters for them.
-    int iv;
-    if (!(q >= 0.0f)) iv = 0;
-    else if (q > (float)(V + 1)) iv = V + 1;
-    else iv = (int)q;
-    return iv;
-}
-
-__device__ __forceinline__ const float* vox_point_ptr(const float* const* src, int n, int pps, int b,
-                                                      long long bs, long long ps) {
-    const int s = n / pps;
-    const int i = n - s * pps;
-    return src[s] + (long long)b * bs + (long long)i * ps;
+__device__ __forceinline__ int vox_axis_index(float p, float mn, float mx, int V) { return vox::axis_index(p, mn, mx, V); }
+__device__ __forceinline__ const float* vox_point_ptr(const float* const* src, int n, int pps, int b, long long bs, long long ps) {
+    return vox::point_ptr(src, n, pps, b, bs, ps);
 }
 
 // Same-address global atomics serialise at ~12 ns each on this chip (MI355X_MICROARCH "fanin"), so the
@@ -102,13 +83,14 @@ __global__ void __launch_bounds__(VOX_PB) vox_count_kernel(VoxSrc src, VoxGeom g
     if (live) {
         const int b = (int)(t / g.N);
         const int n = (int)(t - (long long)b * g.N);
-        const float* cp = vox_point_ptr(src.c, n, g.pps, b, g.cb, g.cp);
+        float pc[3];
+        vox::load_coords(src, g, b, n, pc);
         const float* bd = bounds + (g.bounds_rows > 1 ? b * 6 : 0);
         int idx[3];
         bool inside = true;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const int iv = vox_axis_index(cp[a * g.cc], bd[a], bd[3 + a], g.V);
+            const int iv = vox_axis_index(pc[a], bd[a], bd[3 + a], g.V);
             inside = inside && (iv >= 1) && (iv <= g.V);
             idx[a] = iv - 1;
         }
@@ -254,9 +236,10 @@ __global__ void __launch_bounds__(256) vox_reduce_short_kernel(VoxSrc src, VoxGe
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         if (i < L) {
-            const float* cp = vox_point_ptr(src.c, a[i], g.pps, b, g.cb, g.cp);
+            float pc[3];
+            vox::load_coords(src, g, b, a[i], pc);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) acc[c] = __fadd_rn(acc[c], cp[c * g.cc]);
+            for (int c = 0; c < 3; ++c) acc[c] = __fadd_rn(acc[c], pc[c]);
             if (F > 0) {
                 const float* fp = vox_point_ptr(src.f, a[i], g.pps, b, g.fb, g.fp);
 #pragma unroll
@@ -281,10 +264,13 @@ __global__ void __launch_bounds__(256) vox_place_data_kernel(VoxSrc src, VoxGeom
     const int n = (int)(t - (long long)b * g.N);
     const int slot = w.table[b * g.V * g.V * g.V + cell] + w.rank[t];
     w.seg[slot] = n;
-    const float* cp = vox_point_ptr(src.c, n, g.pps, b, g.cb, g.cp);
     float v[8];
+    {
+        float pc[3];
+        vox::load_coords(src, g, b, n, pc);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) v[c] = cp[c * g.cc];
+        for (int c = 0; c < 3; ++c) v[c] = pc[c];
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) v[3 + c] = 0.f;
     if (F > 0) {
@@ -387,9 +373,10 @@ __global__ void __launch_bounds__(64) vox_reduce_long_kernel(VoxSrc src, VoxGeom
                 const int m = min(64, total - k0);
                 if (lane < m) {
                     const int n = chunk[k0 + lane];
-                    const float* cp = vox_point_ptr(src.c, n, g.pps, b, g.cb, g.cp);
+                    float pc[3];
+                    vox::load_coords(src, g, b, n, pc);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) stage[lane * NC + c] = cp[c * g.cc];
+                    for (int c = 0; c < 3; ++c) stage[lane * NC + c] = pc[c];
                     if (F > 0) {
                         const float* fp = vox_point_ptr(src.f, n, g.pps, b, g.fb, g.fp);
 #pragma unroll
@@ -520,57 +507,41 @@ int vox_launch_reduce(const VoxSrc& src, const VoxGeom& g, const VoxWs& w, float
 
 }  // namespace
 
-extern "C" int vxb_abi_version(void) { return 1; }
+extern "C" int vxb_abi_version(void) { return 2; }
 
-extern "C" size_t vxb_voxelize_workspace_bytes(int B, int n_points, int V) {
-    if (B <= 0 || n_points <= 0 || V <= 0) return 0;
-    return vox_ws_ints(B, n_points, V) * sizeof(int);
+namespace {
+struct VoxStreams {
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_placed = nullptr, ev_long = nullptr;
+};
+// one set per device (a process normally drives one GPU; the table keeps a multi-device process correct)
+int vox_streams(VoxStreams** out) {
+    static VoxStreams tab[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VXB_ELAUNCH;
+    VoxStreams& s = tab[dev];
+    if (!s.side) {
+        if (hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking) != hipSuccess) return VXB_ELAUNCH;
+        if (hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming) != hipSuccess) return VXB_ELAUNCH;
+        if (hipEventCreateWithFlags(&s.ev_join, hipEventDisableTiming) != hipSuccess) return VXB_ELAUNCH;
+        if (hipEventCreateWithFlags(&s.ev_placed, hipEventDisableTiming) != hipSuccess) return VXB_ELAUNCH;
+        if (hipEventCreateWithFlags(&s.ev_long, hipEventDisableTiming) != hipSuccess) return VXB_ELAUNCH;
+    }
+    *out = &s;
+    return VXB_OK;
 }
 
-extern "C" int vxb_voxelize_f32(const float* const* coord_src, const float* const* feat_src, int n_src,
-                                int B, int pts_per_src, int F,
-                                int64_t coord_bstride, int64_t coord_cstride, int64_t coord_pstride,
-                                int64_t feat_bstride, int64_t feat_cstride, int64_t feat_pstride,
-                                const float* bounds, int bounds_rows, int V,
-                                float* out, void* workspace, size_t workspace_bytes, vxb_stream_t stream) {
-    if (!coord_src || !bounds || !out || !workspace) return VXB_EARG;
-    if (n_src < 1 || n_src > VOX_MAX_SRC || B < 1 || pts_per_src < 1 || V < 1) return VXB_EARG;
-    if (F < 0 || F > VOX_MAX_F || (F > 0 && !feat_src)) return VXB_EARG;
-    if (bounds_rows != 1 && bounds_rows != B) return VXB_EARG;
-    const long long N = (long long)n_src * pts_per_src;
-    const long long V3 = (long long)V * V * V;
-    if ((long long)B * V3 >= INT_MAX || (long long)B * N >= INT_MAX) return VXB_ESIZE;
-    if (workspace_bytes < vox_ws_ints(B, N, V) * sizeof(int)) return VXB_EWS;
-    hipStream_t st = (hipStream_t)stream;
-    VoxSrc src;
-    for (int s = 0; s < VOX_MAX_SRC; ++s) {
-        src.c[s] = s < n_src ? coord_src[s] : nullptr;
-        src.f[s] = (s < n_src && F > 0) ? feat_src[s] : nullptr;
-        if (s < n_src && (!src.c[s] || (F > 0 && !src.f[s]))) return VXB_EARG;
+int g_vox_chain = -1;        // -1: not decided yet (environment), 0: automatic, 1: always the table-based chain
+bool vox_force_table_chain() {
+    if (g_vox_chain < 0) {
+        const char* e = getenv("VXB_VOXELIZE_TABLE");       // debugging / A-B switch: "1" = always the table-based chain
+        g_vox_chain = (e && e[0] == '1') ? 1 : 0;
     }
-    VoxGeom g;
-    g.B = B; g.n_src = n_src; g.pps = pts_per_src; g.N = (int)N; g.F = F; g.V = V; g.bounds_rows = bounds_rows;
-    g.cb = coord_bstride; g.cc = coord_cstride; g.cp = coord_pstride;
-    g.fb = feat_bstride; g.fc = feat_cstride; g.fp = feat_pstride;
-    VoxWs w = vox_ws_carve(workspace, B, N, V);
-    const int C = 3 + F + 4;
-    const long long BN = (long long)B * N;
+    return g_vox_chain == 1;
+}
 
-    // fork: the dense "empty grid" store stream is bandwidth-bound and independent of the point-side
-    // chain (count/alloc/place are latency-bound on L2-resident tables), so it runs on a side stream and
-    // joins before the first kernel that writes occupied cells into `out`.
-    static hipStream_t side = nullptr;
-    static hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_placed = nullptr, ev_long = nullptr;
-    if (!side) {
-        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return VXB_ELAUNCH;
-        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return VXB_ELAUNCH;
-        if (hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) return VXB_ELAUNCH;
-        if (hipEventCreateWithFlags(&ev_placed, hipEventDisableTiming) != hipSuccess) return VXB_ELAUNCH;
-        if (hipEventCreateWithFlags(&ev_long, hipEventDisableTiming) != hipSuccess) return VXB_ELAUNCH;
-    }
-    hipStream_t fs = side;
-    if (hipMemsetAsync(w.ctr, 0, 16 * sizeof(int), st) != hipSuccess) return VXB_ELAUNCH;
-    if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(fs, ev_fork, 0) != hipSuccess) return VXB_ELAUNCH;
+void vox_launch_fill(float* out, int B, int V, int C, hipStream_t fs) {
+    const long long V3 = (long long)V * V * V;
     if (C == 10 && (V & 1) == 0 && V >= 2 && V <= 1024 && (((uintptr_t)out) & 15) == 0 && V3 * V < (1ll << 32)) {
         const unsigned n4 = (unsigned)(V3 * 10 / 4);                    // float4 per sample
         const unsigned magicV = (unsigned)((1ull << 32) / (unsigned)V) + 1u;
@@ -583,7 +554,69 @@ extern "C" int vxb_voxelize_f32(const float* const* coord_src, const float* cons
     } else {
         hipLaunchKernelGGL(vox_fill_scalar_kernel, dim3(2048), dim3(256), 0, fs, out, (long long)B * V3 * C, V, C);
     }
-    // (forking only after count was measured too: 328 vs 319 us -- count and fill slow each other down either way)
+}
+}  // namespace
+
+extern "C" int vxb_voxelize_select_chain(int which) {
+    if (which != 0 && which != 1) return VXB_EARG;
+    g_vox_chain = which;
+    return VXB_OK;
+}
+
+extern "C" size_t vxb_voxelize_workspace_bytes(int B, int n_points, int V) {
+    if (B <= 0 || n_points <= 0 || V <= 0) return 0;
+    const size_t table = vox_ws_ints(B, n_points, V) * sizeof(int);
+    const size_t tiles = vox_tiles_ws_bytes(B, n_points, V);
+    return table > tiles ? table : tiles;
+}
+
+extern "C" int vxb_voxelize_f32(const float* const* coord_src, const float* const* feat_src, int n_src,
+                                int B, int pts_per_src, int F,
+                                int64_t coord_bstride, int64_t coord_cstride, int64_t coord_pstride,
+                                int64_t feat_bstride, int64_t feat_cstride, int64_t feat_pstride,
+                                const float* bounds, int bounds_rows, int V, const float* xform,
+                                float* out, void* workspace, size_t workspace_bytes, vxb_stream_t stream) {
+    if (!coord_src || !bounds || !out || !workspace) return VXB_EARG;
+    if (n_src < 1 || n_src > VOX_MAX_SRC || B < 1 || pts_per_src < 1 || V < 1) return VXB_EARG;
+    if (F < 0 || F > VOX_MAX_F || (F > 0 && !feat_src)) return VXB_EARG;
+    if (bounds_rows != 1 && bounds_rows != B) return VXB_EARG;
+    const long long N = (long long)n_src * pts_per_src;
+    const long long V3 = (long long)V * V * V;
+    if ((long long)B * V3 >= INT_MAX || (long long)B * N >= INT_MAX) return VXB_ESIZE;
+    if (workspace_bytes < vxb_voxelize_workspace_bytes(B, (int)N, V)) return VXB_EWS;
+    hipStream_t st = (hipStream_t)stream;
+    VoxSrc src;
+    for (int s = 0; s < VOX_MAX_SRC; ++s) {
+        src.c[s] = s < n_src ? coord_src[s] : nullptr;
+        src.f[s] = (s < n_src && F > 0) ? feat_src[s] : nullptr;
+        if (s < n_src && (!src.c[s] || (F > 0 && !src.f[s]))) return VXB_EARG;
+    }
+    VoxGeom g;
+    g.B = B; g.n_src = n_src; g.pps = pts_per_src; g.N = (int)N; g.F = F; g.V = V; g.bounds_rows = bounds_rows;
+    g.cb = coord_bstride; g.cc = coord_cstride; g.cp = coord_pstride;
+    g.fb = feat_bstride; g.fc = feat_cstride; g.fp = feat_pstride;
+    g.xf = xform;
+    const int C = 3 + F + 4;
+    const long long BN = (long long)B * N;
+    VoxStreams* vs = nullptr;
+    if (vox_streams(&vs) != VXB_OK) return VXB_ELAUNCH;
+    hipStream_t fs = vs->side;
+
+    if (vox_tiles_supported(B, N, V, F) && !vox_force_table_chain()) {
+        // fork: the point chain (route -> tile) runs on the side stream next to the dense "empty grid" store stream; it only
+        // touches a few bytes per point, so the two barely compete.  Join, then the occupied cells are patched in.
+        if (hipEventRecord(vs->ev_fork, st) != hipSuccess || hipStreamWaitEvent(fs, vs->ev_fork, 0) != hipSuccess) return VXB_ELAUNCH;
+        vox_launch_fill(out, B, V, C, st);
+        return vox_tiles_launch(src, g, bounds, out, workspace, st, fs, vs->ev_join);
+    }
+
+    // ---- table-based fallback chain
+    VoxWs w = vox_ws_carve(workspace, B, N, V);
+    // the count table must be zero on entry (the chain leaves it zero, but the workspace is shared with the tile chain)
+    if (hipMemsetAsync(w.table, 0, (size_t)B * V3 * sizeof(int), st) != hipSuccess) return VXB_ELAUNCH;
+    if (hipMemsetAsync(w.ctr, 0, 16 * sizeof(int), st) != hipSuccess) return VXB_ELAUNCH;
+    if (hipEventRecord(vs->ev_fork, st) != hipSuccess || hipStreamWaitEvent(fs, vs->ev_fork, 0) != hipSuccess) return VXB_ELAUNCH;
+    vox_launch_fill(out, B, V, C, fs);
     hipLaunchKernelGGL(vox_count_kernel, dim3(vxb_cdiv(BN, VOX_PB)), dim3(VOX_PB), 0, st, src, g, bounds, w);
     hipLaunchKernelGGL(vox_alloc_kernel, dim3(vxb_cdiv(BN, VOX_PB)), dim3(VOX_PB), 0, st, w);
     const bool use_pd = F <= 4 && N < (1ll << 27);     // records of 8 floats; (id << 4 | index) sort keys
@@ -599,8 +632,8 @@ extern "C" int vxb_voxelize_f32(const float* const* coord_src, const float* cons
         hipLaunchKernelGGL(vox_place_kernel, dim3(vxb_cdiv(BN, 256)), dim3(256), 0, st, g, w);
     }
     // the side stream (fill done) also runs the long-cell reduction once the segments are placed
-    if (hipEventRecord(ev_placed, st) != hipSuccess || hipEventRecord(ev_join, fs) != hipSuccess) return VXB_ELAUNCH;
-    if (hipStreamWaitEvent(st, ev_join, 0) != hipSuccess || hipStreamWaitEvent(fs, ev_placed, 0) != hipSuccess) return VXB_ELAUNCH;
+    if (hipEventRecord(vs->ev_placed, st) != hipSuccess || hipEventRecord(vs->ev_join, fs) != hipSuccess) return VXB_ELAUNCH;
+    if (hipStreamWaitEvent(st, vs->ev_join, 0) != hipSuccess || hipStreamWaitEvent(fs, vs->ev_placed, 0) != hipSuccess) return VXB_ELAUNCH;
     int rc = VXB_OK;
     switch (F) {
         case 0: rc = vox_launch_reduce<0>(src, g, w, out, st, fs, use_pd); break;
@@ -615,7 +648,7 @@ extern "C" int vxb_voxelize_f32(const float* const* coord_src, const float* cons
         default: return VXB_EARG;
     }
     if (rc != VXB_OK) return rc;
-    if (hipEventRecord(ev_long, fs) != hipSuccess || hipStreamWaitEvent(st, ev_long, 0) != hipSuccess) return VXB_ELAUNCH;
+    if (hipEventRecord(vs->ev_long, fs) != hipSuccess || hipStreamWaitEvent(st, vs->ev_long, 0) != hipSuccess) return VXB_ELAUNCH;
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }

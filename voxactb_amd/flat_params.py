@@ -32,6 +32,13 @@ class FlatParams:
     def zero_grad(self):
         self.flat_g.zero_()
 
+    def broadcast_weights(self, src=0):
+        """Rank `src`'s parameters to every rank -- what DistributedDataParallel does implicitly when it wraps the module
+        (agent :50-54): run_seed_fn.py never seeds torch, so without it every replica would start from its own init."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.broadcast(self.flat_w, src=src)
+
     def all_reduce_grads(self):
         """sum over ranks (the 1/world factor is folded into the loss scale, see QAttentionPerActBCAgent.update)."""
         import torch.distributed as dist

@@ -4,6 +4,8 @@ Same constructor / `step()` / `state` layout semantics (per-parameter `exp_avg`,
 `weight_norm`-style trust ratio, no bias correction, ||w|| clamped to [0, 10]), but ONE fused multi-tensor
 launch sequence (3 kernels, no host sync) over flat buffers instead of 118 x (2 reductions + a
 tensor->bool sync).  Parameters must live in a `FlatParams` arena (see flat_params.py); the agent arranges that.
+Every arena parameter has a gradient view (zero when nothing flowed into it), so none is skipped the way the reference
+skips `p.grad is None` (lamb.py:75-76); on this path the engine writes a gradient for every parameter it declares.
 """
 import numpy as np
 import torch
@@ -60,10 +62,14 @@ class Lamb(Optimizer):
         loss = closure() if closure is not None else None
         if self._arena is None:
             raise VoxactbHipError('Lamb.step(): parameters are not in a FlatParams arena (call attach())')
+        if len(self.param_groups) != 1:
+            raise VoxactbHipError('Lamb: the fused step covers exactly one parameter group (the agent creates one, agent :243-249)')
         g = self.param_groups[0]
         a = self._arena
         call('vxb_lamb_step_f32', a.flat_w, a.flat_g, self.exp_avg, self.exp_avg_sq, self._upd, self._chunks, self._nchunks,
              self._first, self._ntensors, self._part, self.trust_ratio, float(g['lr']), float(g['betas'][0]),
              float(g['betas'][1]), float(g['eps']), float(g['weight_decay']))
         self.steps += 1
+        for p in a.params:                   # per-parameter step counter, as the reference keeps it (lamb.py:90)
+            self.state[p]['step'] = self.steps
         return loss

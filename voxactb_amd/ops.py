@@ -686,8 +686,9 @@ def ce_rows(logits, segs, labels, dlogits=None, gscale=1.0):
     pred = torch.empty((rows, n), dtype=torch.int32, device=dev)
     c0 = (ctypes.c_int32 * n)(*[s[0] for s in segs])
     nc = (ctypes.c_int32 * n)(*[s[1] for s in segs])
-    rc = _lib.lib().vxb_ce_rows_f32(_lib.ptr(logits), logits.stride(0), rows, n, c0, nc, _lib.ptr(labels), _lib.ptr(loss),
-                                    _lib.ptr(pred), _lib.ptr(dlogits), float(gscale), _lib.stream_ptr())
+    with _lib.on_device(logits):
+        rc = _lib.lib().vxb_ce_rows_f32(_lib.ptr(logits), logits.stride(0), rows, n, c0, nc, _lib.ptr(labels), _lib.ptr(loss),
+                                        _lib.ptr(pred), _lib.ptr(dlogits), float(gscale), _lib.stream_ptr(dev))
     _lib.check(rc, 'vxb_ce_rows_f32')
     return loss, pred
 

@@ -46,7 +46,7 @@ class VoxelGrid(nn.Module):
             nbytes = _lib.lib().vxb_voxelize_workspace_bytes(B, N, self._voxel_size)
             if nbytes == 0:
                 raise _lib.VoxactbHipError('bad voxelizer geometry B=%d N=%d V=%d' % (B, N, self._voxel_size))
-            self._ws = torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=device)
+            self._ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=device)      # nothing to pre-zero
             self._ws_key = key
         return self._ws
 
@@ -61,11 +61,15 @@ class VoxelGrid(nn.Module):
         b = b.to(device=device, dtype=torch.float32).reshape(-1, 6).contiguous()
         return b
 
-    def _run(self, coord_ptrs, feat_ptrs, B, pps, F, cs, fs, bounds, device):
+    def _run(self, coord_ptrs, feat_ptrs, B, pps, F, cs, fs, bounds, device, xform=None):
         V = self._voxel_size
         n_src = len(coord_ptrs)
         if bounds.shape[0] not in (1, B):
             raise _lib.VoxactbHipError('coord_bounds must have 1 or B rows, got %d' % bounds.shape[0])
+        if xform is not None:
+            _lib.require_cuda(xform)
+            if tuple(xform.shape) != (B, 15) or xform.dtype != torch.float32 or not xform.is_contiguous():
+                raise _lib.VoxactbHipError('xform must be a contiguous float32 [B, 15] tensor (R row-major, t, c)')
         out = torch.empty((B, V, V, V, 3 + F + 4), dtype=torch.float32, device=device)
         ws = self._workspace(B, n_src * pps, device)
         cp = (ctypes.c_void_p * n_src)(*coord_ptrs)
@@ -74,23 +78,23 @@ class VoxelGrid(nn.Module):
         if timer is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        rc = _lib.lib().vxb_voxelize_f32(cp, fp, n_src, B, pps, F, cs[0], cs[1], cs[2], fs[0], fs[1], fs[2],
-                                         _lib.ptr(bounds), bounds.shape[0], V, _lib.ptr(out), _lib.ptr(ws),
-                                         ws.numel() * 4, _lib.stream_ptr(device))
+        with _lib.on_device(device):        # raw launch: the tensors' device must be the current one (rank >= 1 of a DDP job)
+            rc = _lib.lib().vxb_voxelize_f32(cp, fp, n_src, B, pps, F, cs[0], cs[1], cs[2], fs[0], fs[1], fs[2],
+                                             _lib.ptr(bounds), bounds.shape[0], V, _lib.ptr(xform), _lib.ptr(out), _lib.ptr(ws),
+                                             ws.numel() * 4, _lib.stream_ptr(device))
         if timer is not None:
             e1.record()
             # algorithmic bytes: read N*(3+F)*4 per sample, write V^3*(3+F+4)*4 per sample
             nbytes = B * (n_src * pps * (3 + F) * 4 + V ** 3 * (3 + F + 4) * 4)
             timer.records.append(('voxelize', 'vxb_voxelize_f32', e0, e1, 0.0, float(nbytes)))
-        if rc != 0:
-            ws.zero_()   # restore the "table is zero" invariant after a failed call
         _lib.check(rc, 'vxb_voxelize_f32')
         return out
 
     # ------------------------------------------------------------------ reference API
-    def coords_to_bounding_voxel_grid(self, coords, coord_features=None, coord_bounds=None):
+    def coords_to_bounding_voxel_grid(self, coords, coord_features=None, coord_bounds=None, xform=None):
         """coords [B,N,3], coord_features [B,N,F] or None, coord_bounds [1|B,6] or None
-        -> [B,V,V,V,3+F+3+1]  (reference voxel_grid.py:148-198)."""
+        -> [B,V,V,V,3+F+3+1]  (reference voxel_grid.py:148-198).  `xform` [B,15] (not in the reference signature): rigid
+        transform applied to every point as it is loaded, see voxel/augmentation.py."""
         _lib.require_cuda(coords, coord_features)
         coords = coords.float().contiguous()
         B, N, _ = coords.shape
@@ -101,10 +105,10 @@ class VoxelGrid(nn.Module):
             F = feats.shape[-1]
         bounds = self._bounds(coord_bounds, coords.device)
         return self._run([coords.data_ptr()], [feats.data_ptr()] if F else [], B, N, F,
-                         (N * 3, 1, 3), (N * F, 1, F), bounds, coords.device)
+                         (N * 3, 1, 3), (N * F, 1, F), bounds, coords.device, xform)
 
     # ------------------------------------------------------------------ fused camera path
-    def voxelize_cameras(self, pcd, rgb, coord_bounds=None):
+    def voxelize_cameras(self, pcd, rgb, coord_bounds=None, xform=None):
         """pcd, rgb: lists (one per camera) of [B,3,H,W] / [B,F,H,W]; same result as flattening the
         cameras (agent :85-93) and calling coords_to_bounding_voxel_grid."""
         _lib.require_cuda(*pcd, *rgb)
@@ -118,4 +122,4 @@ class VoxelGrid(nn.Module):
         bounds = self._bounds(coord_bounds, pcd[0].device)
         self._keep = (pcd, rgb)
         return self._run([p.data_ptr() for p in pcd], [r.data_ptr() for r in rgb], B, H * W, F,
-                         (3 * H * W, H * W, 1), (F * H * W, H * W, 1), bounds, pcd[0].device)
+                         (3 * H * W, H * W, 1), (F * H * W, H * W, 1), bounds, pcd[0].device, xform)
