@@ -42,18 +42,26 @@ int vxb_abi_version(void);
  * xform: NULL, or [B][15] = R_b (row-major 3x3), t_b, c_b: every point is replaced by (p - t_b) R_b + c_b (row-vector
  * convention) as it is loaded -- the SE(3) augmentation's perturb_se3 (peract/voxel/augmentation.py:36-62) folded into
  * the voxelizer, same operation order as vxb_se3_points_f32 (so both routes give the same grid, bit for bit).
- * Workspace: vxb_voxelize_workspace_bytes() bytes, contents arbitrary on entry (nothing to pre-zero).
+ * out_state: 0 = `out` holds anything (every cell is written).  1 / 2 = INCREMENTAL: `out` and `workspace` are untouched
+ * since the previous successful call with the same B, N, V, F that used this very pair, and that call was made with
+ * out_state 0 or 2 (-> pass 1) or with out_state 1 (-> pass 2): the workspace keeps two lists of occupied cells and the
+ * value says which one the previous call wrote.  The empty-cell pattern does not depend on the input, so only the cells
+ * occupied then are reset and the cells occupied now are written (~80 bytes per occupied cell instead of 40 bytes per cell
+ * of the grid).  Same result, bit for bit.  Ignored (treated as 0) by the table chain.
+ * Workspace: vxb_voxelize_workspace_bytes() bytes, contents arbitrary on entry for out_state 0 (nothing to pre-zero).
  */
 size_t vxb_voxelize_workspace_bytes(int B, int n_points, int V);
-/* Point chain used by vxb_voxelize_f32: 0 = automatic (tile-routed chain when F <= 4, V <= 200, N < 2^20; otherwise the
- * table-based chain), 1 = always the table-based chain (A/B measurements, tests).  Both produce identical grids. */
+/* Point chain used by vxb_voxelize_f32: 0 = automatic (tile-routed chain when F <= 4, V <= 200, N < 2^20, all kernels in
+ * order on the caller's stream; otherwise the table-based chain), 1 = always the table-based chain, 3 / 5 = tile-routed
+ * chain with the empty-grid fill overlapped on a side stream (3: after the route kernel, 5: from the start) -- kept for A/B
+ * measurements.  All produce identical grids. */
 int vxb_voxelize_select_chain(int which);
 int vxb_voxelize_f32(const float* const* coord_src, const float* const* feat_src, int n_src,
                      int B, int pts_per_src, int F,
                      int64_t coord_bstride, int64_t coord_cstride, int64_t coord_pstride,
                      int64_t feat_bstride, int64_t feat_cstride, int64_t feat_pstride,
                      const float* bounds, int bounds_rows, int V, const float* xform,
-                     float* out, void* workspace, size_t workspace_bytes, vxb_stream_t stream);
+                     float* out, int out_state, void* workspace, size_t workspace_bytes, vxb_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * fp32 matrix-core GEMM (v_mfma_f32_32x32x2_f32).  Replaces nn.Linear / einsum in Attention,
@@ -310,9 +318,10 @@ int vxb_ce_rows_f32(const float* logits, int64_t ld, int rows, int nseg, const i
                     const int32_t* labels, float* loss, int32_t* pred, float* dlogits, float gscale,
                     vxb_stream_t stream);
 
-/* Fused multi-tensor LAMB (peract/helpers/optim/lamb.py:94-122; no bias correction, ||w|| clamp 10). */
+/* Fused multi-tensor LAMB (peract/helpers/optim/lamb.py:94-122; no bias correction, ||w|| clamp 10).  The betas come as
+ * doubles: 1 - beta is evaluated in double and then rounded to fp32, as Python evaluates `alpha=1 - beta1` upstream. */
 int vxb_lamb_step_f32(float* w, const float* g, float* m, float* v, float* upd, const int32_t* chunks, int nchunks,
-                      const int32_t* first, int ntensors, float* part, float* trust, float lr, float beta1, float beta2,
+                      const int32_t* first, int ntensors, float* part, float* trust, float lr, double beta1, double beta2,
                       float eps, float weight_decay, vxb_stream_t stream);
 
 #ifdef __cplusplus

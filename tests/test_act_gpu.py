@@ -48,6 +48,7 @@ def test_act_matches_reference_fixture(golden, tag):
         obs['%s_camera_intrinsics' % cam] = T(g[pre + cam + '_int']).to(DEV)
     obs['low_dim_state'] = rs['low_dim_state'].to(DEV)
     obs['lang_goal_tokens'] = T(g[pre + 'lang_goal_tokens']).to(DEV)
+    raw = {k: v.clone() for k, v in obs.items()}          # act() normalises the rgb entries of the dict it is given, in place
     res = agent.act(0, obs, deterministic=True)
     assert torch.equal(seen['tokens'].long().reshape(-1), T(g[pre + 'lang_goal_tokens']).long().reshape(-1))
     # discrete outputs: identical
@@ -72,7 +73,7 @@ def test_act_matches_reference_fixture(golden, tag):
     # rotation / grip / collision heads, softmaxed the way act() does (agent :394-416)
     vox = res.info['voxel_grid_depth0']
     assert vox.shape == (1, 10, c['V'], c['V'], c['V'])
-    o2 = {k: ((v.float() / 255.0) * 2.0 - 1.0 if 'rgb' in k else v.float()) for k, v in obs.items() if torch.is_tensor(v)}
+    o2 = {k: ((v.float() / 255.0) * 2.0 - 1.0 if 'rgb' in k else v.float()) for k, v in raw.items() if torch.is_tensor(v)}
     ob = [[o2['%s_rgb' % cam][0], o2['%s_point_cloud' % cam][0]] for cam in cams]
     pc = [o2['%s_point_cloud' % cam][0] for cam in cams]
     q_t, q_rg, q_c, _ = qa._q(ob, o2['low_dim_state'][0], pc, emb, tok, qa._coordinate_bounds, None, None)

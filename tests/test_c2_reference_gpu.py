@@ -109,7 +109,12 @@ def _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, tag):
         if key in g.files:
             ref = T(g[key])
             e = float((P[n].grad.float().cpu() - ref).abs().max())
-            if e > 3e-3 * float(ref.abs().max()) + 1e-5:
+            # the tensors stored in full are mostly conv biases: sums of dY over 10^6 voxels per channel.  A forward difference
+            # of 1e-6 flips the LeakyReLU mask of the ~1e-5 fraction of pre-activations that sit that close to zero, and each
+            # flip moves one term of such a sum by its full size: 0.4-0.9 % of the largest entry at this size (measured, both
+            # precisions) against 0.3 % at the small sizes of tests/test_encoder_gpu.py.  Entries that are mathematically
+            # zero (trans_decoder bias: sum(softmax - onehot)) are rounding noise of ~6e-5 on both sides.
+            if e > 1.5e-2 * float(ref.abs().max()) + 2e-4:
                 bad.append((n, 'full', e, float(ref.abs().max())))
     print('%s: loss %.6f (reference %.6f), worst grad-norm rel. error %.2e' % (tag, loss, float(g['loss']), worst))
     assert not bad, (tag, bad)

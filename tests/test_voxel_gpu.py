@@ -184,6 +184,43 @@ def test_fused_rigid_transform_equals_transform_then_voxelize():
     assert same(fused, ref)
 
 
+def test_persistent_buffers_are_updated_in_place_to_the_same_grids():
+    """VoxelGrid(persistent=2): results of five calls with different clouds, colours and per-sample bounds equal the
+    fresh-buffer results (incremental update = reset the cells occupied two calls ago + write the new ones)."""
+    B, H, W, V = 3, 32, 32, 40
+    cams = ['front', 'wrist']
+    fresh = VoxelGrid(synthetic.SCENE_BOUNDS, V, DEV, B, 3, len(cams) * H * W)
+    pers = VoxelGrid(synthetic.SCENE_BOUNDS, V, DEV, B, 3, len(cams) * H * W, persistent=2)
+    g = np.random.default_rng(4)
+    seen = []
+    for it in range(5):
+        pcd, rgb = cams_batch(B, cams, H, W, V, seed=20 + it)
+        c = np.array(synthetic.SCENE_BOUNDS[:3]) + g.uniform(0.3, 0.7, (B, 3))
+        bounds = torch.tensor(np.concatenate([c - 0.35, c + 0.35], 1), dtype=torch.float32).to(DEV)
+        pcd, rgb = [p.to(DEV) for p in pcd], [r.to(DEV) for r in rgb]
+        want = fresh.voxelize_cameras(pcd, rgb, bounds)
+        got = pers.voxelize_cameras(pcd, rgb, bounds)
+        assert torch.equal(got, want), it
+        seen.append(got.data_ptr())
+    assert len(set(seen)) == 2 and seen[0] == seen[2] == seen[4] and seen[1] == seen[3]      # two buffers, used in turn
+    # an empty cloud after a full one: every previously occupied cell is reset
+    far = [torch.full((B, 3, H, W), 9.0, device=DEV) for _ in cams]
+    for _ in range(2):
+        got = pers.voxelize_cameras(far, rgb, bounds)
+        assert torch.equal(got, fresh.voxelize_cameras(far, rgb, bounds)) and float(got[..., -1].sum()) == 0
+
+
+def test_overlapped_launch_orders_give_the_same_grid():
+    from voxactb_amd import _lib
+    pcd, rgb = cams_batch(2, ['front', 'wrist'], 64, 64, 50, seed=8)
+    pcd, rgb = [p.to(DEV) for p in pcd], [r.to(DEV) for r in rgb]
+    vg = VoxelGrid(synthetic.SCENE_BOUNDS, 50, DEV, 2, 3, 2 * 64 * 64)
+    ref = vg.voxelize_cameras(pcd, rgb)
+    for order in (3, 5):
+        assert _lib.lib().vxb_voxelize_select_chain(order) == 0
+        assert torch.equal(vg.voxelize_cameras(pcd, rgb), ref), order
+
+
 def test_errors():
     from voxactb_amd import _lib
     vg = VoxelGrid([0, 0, 0, 1, 1, 1], 8, DEV, 2, 3, 16)

@@ -180,7 +180,10 @@ class QAttentionPerActBCAgent(Agent):
         torch.cuda.set_device(dev)
         self._voxelizer = VoxelGrid(coord_bounds=self._coordinate_bounds, voxel_size=self._voxel_size, device=dev,
                                     batch_size=self._batch_size if training else 1, feature_size=self._voxel_feature_size,
-                                    max_num_coords=int(np.prod(self._image_resolution)) * self._num_cameras)
+                                    max_num_coords=int(np.prod(self._image_resolution)) * self._num_cameras,
+                                    # training: the grid lives for one step (it is returned in `prev_layer_voxel_grid` and
+                                    # read by update_summaries), so two buffers updated in place in turn are enough
+                                    persistent=2 if training else 0)
         self._q = QFunction(self._perceiver_encoder, self._voxelizer, self._bounds_offset, self._rotation_resolution, dev,
                             training, self._arm_pred_loss).to(dev).train(training)
         self._coordinate_bounds = torch.tensor(self._coordinate_bounds, device=dev).unsqueeze(0)

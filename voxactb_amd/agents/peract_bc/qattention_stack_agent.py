@@ -65,7 +65,7 @@ class QAttentionStackAgent(Agent):
                     observation_elements['%s_pixel_coord' % n] = [py, px]
             infos.update(act_results.info)
         rgai = torch.cat(rot_grip, 1)[0].cpu().numpy()
-        ignore_collisions = float(torch.cat(coll, 1)[0].cpu().numpy())
+        ignore_collisions = float(torch.cat(coll, 1)[0, 0].cpu().numpy())
         observation_elements['trans_action_indicies'] = torch.cat(trans, 1)[0].cpu().numpy()
         observation_elements['rot_grip_action_indicies'] = rgai
         quat = discrete_euler_to_quaternion(rgai[-4:-1], self._rotation_resolution)

@@ -791,7 +791,7 @@ __global__ void __launch_bounds__(256) weff_bwd_kernel(const float* __restrict__
 __global__ void __launch_bounds__(256) lamb_stage1_kernel(const float* __restrict__ w, const float* __restrict__ g,
                                                           float* __restrict__ m, float* __restrict__ v, float* __restrict__ upd,
                                                           const int* __restrict__ chunks, float* __restrict__ part, float beta1,
-                                                          float beta2, float eps, float wd) {
+                                                          float beta2, float omb1, float omb2, float eps, float wd) {
     __shared__ float r1[4], r2[4];
     const int* ch = chunks + 3 * blockIdx.x;
     const long long start = ch[1];
@@ -800,8 +800,10 @@ __global__ void __launch_bounds__(256) lamb_stage1_kernel(const float* __restric
     for (int i = threadIdx.x; i < len; i += 256) {
         const long long o = start + i;
         const float gv = g[o], wv = w[o];
-        const float mv = m[o] * beta1 + (1.0f - beta1) * gv;
-        const float vv = v[o] * beta2 + (1.0f - beta2) * gv * gv;
+        // omb = 1 - beta evaluated in DOUBLE on the host and then rounded, as Python does for `alpha=1 - beta1` /
+        // `value=1 - beta2` (lamb.py:99-101): 1.0f - 0.999f is 1.3e-5 away from float(0.001)
+        const float mv = m[o] * beta1 + omb1 * gv;
+        const float vv = v[o] * beta2 + omb2 * gv * gv;
         m[o] = mv; v[o] = vv;
         float u = mv / (sqrtf(vv) + eps);
         if (wd != 0.f) u += wd * wv;
@@ -836,7 +838,8 @@ __global__ void __launch_bounds__(256) lamb_stage3_kernel(float* __restrict__ w,
     const long long start = ch[1];
     const int len = ch[2];
     const float alpha = -(lr * trust[ch[0]]);
-    for (int i = threadIdx.x; i < len; i += 256) w[start + i] = fmaf(alpha, upd[start + i], w[start + i]);
+    // p.data.add_(adam_step, alpha=...) rounds the product and the sum separately on the CPU path (lamb.py:122)
+    for (int i = threadIdx.x; i < len; i += 256) w[start + i] = __fadd_rn(w[start + i], __fmul_rn(alpha, upd[start + i]));
 }
 
 }  // namespace
@@ -1013,11 +1016,12 @@ extern "C" int vxb_polyphase_weights_bwd_f32(const float* dWeff, const float* L,
 // chunks: int32 [nchunks][3] = {tensor id, start, len} (device); first: int32 [ntensors+1] (device);
 // upd: scratch of the same length as w; part: 2*nchunks floats; trust: ntensors floats (kept for inspection).
 extern "C" int vxb_lamb_step_f32(float* w, const float* g, float* m, float* v, float* upd, const int32_t* chunks, int nchunks,
-                                 const int32_t* first, int ntensors, float* part, float* trust, float lr, float beta1, float beta2,
+                                 const int32_t* first, int ntensors, float* part, float* trust, float lr, double beta1, double beta2,
                                  float eps, float weight_decay, vxb_stream_t stream) {
     if (!w || !g || !m || !v || !upd || !chunks || !first || !part || !trust || nchunks < 1 || ntensors < 1) return VXB_EARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(lamb_stage1_kernel, dim3(nchunks), dim3(256), 0, st, w, g, m, v, upd, chunks, part, beta1, beta2, eps, weight_decay);
+    hipLaunchKernelGGL(lamb_stage1_kernel, dim3(nchunks), dim3(256), 0, st, w, g, m, v, upd, chunks, part, (float)beta1, (float)beta2,
+                       (float)(1.0 - beta1), (float)(1.0 - beta2), eps, weight_decay);
     hipLaunchKernelGGL(lamb_stage2_kernel, dim3(vxb_cdiv(ntensors, 64)), dim3(64), 0, st, part, first, ntensors, trust);
     hipLaunchKernelGGL(lamb_stage3_kernel, dim3(nchunks), dim3(256), 0, st, w, upd, chunks, trust, lr);
     VXB_CHECK_LAUNCH();

@@ -63,7 +63,10 @@ __device__ __forceinline__ void load_coords(const Src& src, const Geom& g, int b
 // tile-routed chain (voxelize_tiles.hip)
 bool vox_tiles_supported(long long B, long long N, int V, int F);
 size_t vox_tiles_ws_bytes(long long B, long long N, int V);
-// enqueue: [side] memset + route + tile-reduce, [st] join + patch.  The caller has already forked `side` after the inputs
-// were ready on `st` and launched the empty-grid fill on `st`.
+// enqueue the empty-grid fill (or, order 4, the reset of the previously occupied cells) and the point chain; `order`: see
+// vt_launch.  The compact cell lists are double-buffered inside the workspace: this call writes list `list_out` (0 / 1) and,
+// in incremental mode, resets the cells of list `list_in`.
 int vox_tiles_launch(const vox::Src& src, const vox::Geom& g, const float* bounds, float* out, void* ws, hipStream_t st,
-                     hipStream_t side, hipEvent_t ev_join);
+                     hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_mid, hipEvent_t ev_join, int order, int list_in,
+                     int list_out);
+void vox_launch_fill(float* out, int B, int V, int C, hipStream_t fs);

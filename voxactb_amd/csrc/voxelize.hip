@@ -521,7 +521,10 @@ int vox_streams(VoxStreams** out) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VXB_ELAUNCH;
     VoxStreams& s = tab[dev];
     if (!s.side) {
-        if (hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking) != hipSuccess) return VXB_ELAUNCH;
+        // highest priority: the point chain's few small workgroups must not queue behind the 156 k workgroups of the fill
+        int prio_lo = 0, prio_hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_hi = 0;
+        if (hipStreamCreateWithPriority(&s.side, hipStreamNonBlocking, prio_hi) != hipSuccess) return VXB_ELAUNCH;
         if (hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming) != hipSuccess) return VXB_ELAUNCH;
         if (hipEventCreateWithFlags(&s.ev_join, hipEventDisableTiming) != hipSuccess) return VXB_ELAUNCH;
         if (hipEventCreateWithFlags(&s.ev_placed, hipEventDisableTiming) != hipSuccess) return VXB_ELAUNCH;
@@ -531,15 +534,16 @@ int vox_streams(VoxStreams** out) {
     return VXB_OK;
 }
 
-int g_vox_chain = -1;        // -1: not decided yet (environment), 0: automatic, 1: always the table-based chain
+int g_vox_chain = -1;        // -1: not decided yet (environment), 0: automatic, 1: always the table-based chain, 3 / 5: see header
 bool vox_force_table_chain() {
     if (g_vox_chain < 0) {
-        const char* e = getenv("VXB_VOXELIZE_TABLE");       // debugging / A-B switch: "1" = always the table-based chain
-        g_vox_chain = (e && e[0] == '1') ? 1 : 0;
+        const char* e = getenv("VXB_VOXELIZE_TABLE");       // debugging / A-B switch, same values as vxb_voxelize_select_chain
+        g_vox_chain = (e && (e[0] == '1' || e[0] == '3' || e[0] == '5')) ? e[0] - '0' : 0;
     }
     return g_vox_chain == 1;
 }
 
+}  // namespace
 void vox_launch_fill(float* out, int B, int V, int C, hipStream_t fs) {
     const long long V3 = (long long)V * V * V;
     if (C == 10 && (V & 1) == 0 && V >= 2 && V <= 1024 && (((uintptr_t)out) & 15) == 0 && V3 * V < (1ll << 32)) {
@@ -555,10 +559,9 @@ void vox_launch_fill(float* out, int B, int V, int C, hipStream_t fs) {
         hipLaunchKernelGGL(vox_fill_scalar_kernel, dim3(2048), dim3(256), 0, fs, out, (long long)B * V3 * C, V, C);
     }
 }
-}  // namespace
 
 extern "C" int vxb_voxelize_select_chain(int which) {
-    if (which != 0 && which != 1) return VXB_EARG;
+    if (which != 0 && which != 1 && which != 3 && which != 5) return VXB_EARG;
     g_vox_chain = which;
     return VXB_OK;
 }
@@ -575,11 +578,12 @@ extern "C" int vxb_voxelize_f32(const float* const* coord_src, const float* cons
                                 int64_t coord_bstride, int64_t coord_cstride, int64_t coord_pstride,
                                 int64_t feat_bstride, int64_t feat_cstride, int64_t feat_pstride,
                                 const float* bounds, int bounds_rows, int V, const float* xform,
-                                float* out, void* workspace, size_t workspace_bytes, vxb_stream_t stream) {
+                                float* out, int out_state, void* workspace, size_t workspace_bytes, vxb_stream_t stream) {
     if (!coord_src || !bounds || !out || !workspace) return VXB_EARG;
     if (n_src < 1 || n_src > VOX_MAX_SRC || B < 1 || pts_per_src < 1 || V < 1) return VXB_EARG;
     if (F < 0 || F > VOX_MAX_F || (F > 0 && !feat_src)) return VXB_EARG;
     if (bounds_rows != 1 && bounds_rows != B) return VXB_EARG;
+    if (out_state < 0 || out_state > 2) return VXB_EARG;
     const long long N = (long long)n_src * pts_per_src;
     const long long V3 = (long long)V * V * V;
     if ((long long)B * V3 >= INT_MAX || (long long)B * N >= INT_MAX) return VXB_ESIZE;
@@ -603,11 +607,16 @@ extern "C" int vxb_voxelize_f32(const float* const* coord_src, const float* cons
     hipStream_t fs = vs->side;
 
     if (vox_tiles_supported(B, N, V, F) && !vox_force_table_chain()) {
-        // fork: the point chain (route -> tile) runs on the side stream next to the dense "empty grid" store stream; it only
-        // touches a few bytes per point, so the two barely compete.  Join, then the occupied cells are patched in.
-        if (hipEventRecord(vs->ev_fork, st) != hipSuccess || hipStreamWaitEvent(fs, vs->ev_fork, 0) != hipSuccess) return VXB_ELAUNCH;
-        vox_launch_fill(out, B, V, C, st);
-        return vox_tiles_launch(src, g, bounds, out, workspace, st, fs, vs->ev_join);
+        // the point chain (route -> light / heavy tiles) runs on the side stream next to the dense "empty grid" store
+        // stream, joins, and the occupied cells are patched in
+        // out_state 1 / 2: `out` and `workspace` are exactly as the previous successful call with the same geometry left them
+        // -> incremental update (no fill).  Orders 0 / 3 overlap the fill with the point chain; measured on MI355X that
+        // overlap buys nothing (the store stream stretches the latency-bound chain by what it hides), so a stateless call
+        // runs the fill after the chain.
+        const int order = out_state != 0 ? 4 : (g_vox_chain == 5 ? 0 : (g_vox_chain == 3 ? 3 : 2));
+        // out_state 0 / 2 -> this call writes cell list 0, out_state 1 -> list 1 (and resets the cells of the other one)
+        return vox_tiles_launch(src, g, bounds, out, workspace, st, fs, vs->ev_fork, vs->ev_placed, vs->ev_join, order,
+                                out_state == 1 ? 0 : (out_state == 2 ? 1 : -1), out_state == 1 ? 1 : 0);
     }
 
     // ---- table-based fallback chain

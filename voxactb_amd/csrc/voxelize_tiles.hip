@@ -5,22 +5,24 @@
 // :159-182): sums per cell are taken in ASCENDING POINT ID, the order scatter_add_ uses on the CPU, so all channels are
 // bit-identical to the reference and run-to-run deterministic.
 //
-// The V^3 cells of a sample are cut into tiles of 8 x 8 x 16 cells (1024 cells: a tile's per-cell counters fit in 16 KB
-// of LDS).  Three kernels, the first two on a side stream next to the 640 MB empty-grid store stream:
+// The V^3 cells of a sample are cut into tiles of 8 x 8 x 16 cells (1024 cells: a tile's per-cell counters fit in a few KB
+// of LDS).  Four kernels, the first three on a high-priority side stream next to the 640 MB empty-grid store stream:
 //
 //   route   one workgroup per 2048-point chunk (ids ascending inside a wave): cell index with the reference's fp32
 //           arithmetic (optionally after the SE(3) transform of the augmentation), border points dropped, then a STABLE
 //           partition of the chunk by tile -- ranks from wave ballots ("which lower lanes hold the same tile"), wave-
-//           private LDS histograms, no atomics on the data path -- writes (cell | id) keys and 32-byte point records
-//           sorted by tile, a [chunk][tile] offset table (uint16) and a worklist of non-empty (sample, tile) pairs.
-//   tile    one workgroup per non-empty tile: walks the tile's segments of all chunks in chunk order (= id order),
-//           stable counting sort by cell (same ballot ranks, 4 wave-private counter rows), records moved to their cell
-//           segment, then one thread per cell adds its records front to back -- ascending id by construction -- and emits
-//           a compact (means, cell address) record per occupied cell.
-//   patch   after the fill has finished: occupied cells overwrite their 40 bytes of the dense grid.
+//           private LDS histograms, no atomics -- writes 32-byte point records (xyz, features, cell | id key) sorted by
+//           tile and a tile-major [tile][chunk] offset table (uint16).
+//   light   ONE WAVE per tile, no barriers: reads the tile's two offset rows, leaves if the tile is empty, hands tiles
+//           with more than 256 points to the heavy list; otherwise holds the tile's records in registers (chunk order = id
+//           order), ranks them per cell with the same ballots (stable counting sort), parks them in LDS in (cell, id) order
+//           and lets each lane add the records of its cells front to back -- ascending id by construction.
+//   heavy   one 256-thread workgroup per listed tile: the same algorithm with four wave-private counter rows and the
+//           sorted records in an L2-resident scratch.
+//   patch   after the fill has finished: a flat pass over the compact (means, cell address) records of every sample
+//           overwrites the occupied cells' 40 bytes of the dense grid.
 //
-// All intermediate buffers are a few bytes per point (L2 / MALL resident); nothing needs zero-initialising except a
-// B * tiles counter array (one small memset per call).
+// All intermediate buffers are a few bytes per point (L2 / MALL resident); a per-call memset clears B + 1 counters.
 #include "voxelize.h"
 #include <limits.h>
 
@@ -35,16 +37,20 @@ constexpr int ID_BITS = 20;                     // key = cell-in-tile << 20 | po
 constexpr int MAX_TILES = 8191;                 // 13-bit tile field in the route kernel's per-point word
 constexpr int MAX_NC = 512;                     // chunks per sample
 
+constexpr int LIGHT = 256;                      // tiles with at most this many points are reduced by a single wave
+
 struct TileWs {
-    int* ctr;                // [16]   ctr[0] = worklist length
-    int* tile_total;         // [B * NT] points per tile (only its zero / non-zero transition is used: worklist append)
-    int* worklist;           // [B * NT] b * NT + tile of every non-empty tile
-    int2* tinfo;             // [B * NT] (first slot of the tile inside its sample's NP-slot scratch, occupied cells)
-    unsigned short* off;     // [B][NC][NT + 1] start of tile t inside chunk c's sorted run
-    unsigned* keys;          // [B][NC * CHUNK]
-    float4* recs;            // [B][NC * CHUNK][2]  xyz, features (<= 4), key bits
-    float4* sorted;          // same shape: records in (tile, cell, id) order
-    float4* res;             // same shape: per occupied cell: means (<= 7), cell address bits
+    int* ctr;                // [64 + 32 B]  ctr[0] = light-list length, ctr[32] = heavy-list length, ctr[64 + 32 b] = occupied
+                             // cells of sample b emitted so far (one 128-byte line per counter: same-line atomics serialise
+                             // at ~12 ns each)
+    const int* ctr_prev;     // the same counters of the previous call on this workspace (incremental mode), or null
+    int* light;              // [B * NT]  b * NT + tile of every tile with 1 .. LIGHT points
+    int* heavy;              // [B * NT]  ... with more than LIGHT points
+    unsigned short* off;     // [B][NT + 1][NC]  start of tile t inside chunk c's sorted run (row NT = points kept of chunk c)
+    float4* recs;            // [B][NC * CHUNK][2]  xyz, features (<= 4), key bits; sorted by tile inside a chunk
+    float4* sorted;          // same shape: heavy tiles' records in (cell, id) order
+    float4* res;             // same shape: per occupied cell: means (<= 7), cell address bits; dense from slot 0 per sample
+    const float4* res_prev;  // the cell list the previous call on this workspace left (incremental mode), or null
     int NT, Tx, Ty, Tz, NC, tile_bits;
     long long NP;            // NC * CHUNK slots per sample
 };
@@ -158,31 +164,25 @@ __global__ void __launch_bounds__(256) vt_route_kernel(Src src, Geom g, const fl
     for (int t = t0; t < t1; ++t) sum += s_hist[t] + s_hist[NT + t] + s_hist[2 * NT + t] + s_hist[3 * NT + t];
     int total;
     int run = block_excl_scan(sum, s_red, &total);
-    unsigned short* offp = w.off + ((size_t)b * w.NC + chunk) * (NT + 1);
+    unsigned short* offp = w.off + (size_t)b * (NT + 1) * w.NC + chunk;       // [tile][chunk]: a tile's row is contiguous
     for (int t = t0; t < t1; ++t) {
         const int h0 = s_hist[t], h1 = s_hist[NT + t], h2 = s_hist[2 * NT + t], h3 = s_hist[3 * NT + t];
-        offp[t] = (unsigned short)run;
+        offp[(size_t)t * w.NC] = (unsigned short)run;
         s_hist[t] = (unsigned short)run;
         s_hist[NT + t] = (unsigned short)(run + h0);
         s_hist[2 * NT + t] = (unsigned short)(run + h0 + h1);
         s_hist[3 * NT + t] = (unsigned short)(run + h0 + h1 + h2);
-        const int s = h0 + h1 + h2 + h3;
-        run += s;
-        if (s > 0) {
-            const int old = atomicAdd(&w.tile_total[b * NT + t], s);
-            if (old == 0) w.worklist[atomicAdd(&w.ctr[0], 1)] = b * NT + t;
-        }
+        run += h0 + h1 + h2 + h3;
     }
-    if (tid == 255) offp[NT] = (unsigned short)total;
+    if (tid == 255) offp[(size_t)NT * w.NC] = (unsigned short)total;
     __syncthreads();
-    const size_t slot0 = ((size_t)b * w.NC + chunk) * CHUNK;
+    const size_t slot0 = (size_t)b * w.NP + (size_t)chunk * CHUNK;
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
         if ((validmask >> j) & 1u) {
             const unsigned tile = tilecell[j] & 0x1FFFu, cell = tilecell[j] >> 13;
             const size_t dst = slot0 + myh[tile] + pos_in_wave[j];
             const unsigned key = (cell << ID_BITS) | (unsigned)(n0 + j * 64);
-            w.keys[dst] = key;
             float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 3 + F; ++c) v[c] = pv[j][c];
@@ -193,29 +193,215 @@ __global__ void __launch_bounds__(256) vt_route_kernel(Src src, Geom g, const fl
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------ tile
+// one compact record per occupied cell: means of the 3 + F channels, address of the cell inside the sample
 template <int F>
-__global__ void __launch_bounds__(256) vt_tile_kernel(Geom g, TileWs w) {
+__device__ __forceinline__ void emit_cell(float4* __restrict__ res, size_t slot, const float (&acc)[7], int cnt, int gc) {
+    const float Lf = (float)cnt;                                    // clamp_(1) is a no-op for occupied cells (:121)
+    float mean[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3 + F; ++c) mean[c] = __fdiv_rn(acc[c], Lf);
+    res[slot * 2] = make_float4(mean[0], mean[1], mean[2], mean[3]);
+    res[slot * 2 + 1] = make_float4(mean[4], mean[5], mean[6], __int_as_float(gc));
+}
+
+// ------------------------------------------------------------------------------------------------------------ light
+// One wave per (sample, tile); wave-synchronous (LDS traffic of one wave is processed in program order, the fences only
+// stop the compiler from moving accesses across them).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// one thread per (sample, tile): points in the tile = sum over the chunks of the segment lengths (two contiguous rows of the
+// tile-major offset table) -> compact lists of the light and of the heavy tiles (empty tiles are never visited again)
+__global__ void __launch_bounds__(256) vt_classify_kernel(Geom g, TileWs w) {
+    __shared__ int s_red[4];
+    __shared__ int s_base[2];
+    const int NT = w.NT, NC = w.NC;
+    const int bt = blockIdx.x * 256 + threadIdx.x;
+    int n = 0;
+    if (bt < g.B * NT) {
+        const int b = bt / NT, tile = bt - b * NT;
+        const unsigned short* row = w.off + ((size_t)b * (NT + 1) + tile) * NC;
+        for (int c = 0; c < NC; ++c) n += (int)row[NC + c] - (int)row[c];
+    }
+    const bool is_heavy = n > LIGHT || (n > 0 && NC > 64);
+    const bool is_light = n > 0 && !is_heavy;
+    int tot;
+    const int ex = block_excl_scan((is_light ? 1 : 0) | (is_heavy ? 1 << 16 : 0), s_red, &tot);
+    if (threadIdx.x == 0) {
+        s_base[0] = (tot & 0xFFFF) ? atomicAdd(&w.ctr[0], tot & 0xFFFF) : 0;
+        s_base[1] = (tot >> 16) ? atomicAdd(&w.ctr[32], tot >> 16) : 0;
+    }
+    __syncthreads();
+    if (is_light) w.light[s_base[0] + (ex & 0xFFFF)] = bt;
+    if (is_heavy) w.heavy[s_base[1] + (ex >> 16)] = bt;
+}
+
+template <int F>
+__global__ void __launch_bounds__(64) vt_light_kernel(Geom g, TileWs w) {
+    __shared__ unsigned short s_cnt[CELLS];                 // points per cell, then first slot of the cell
+    __shared__ int s_segs[64], s_segp[65];                  // per chunk: start of the tile's segment, exclusive prefix of lengths
+    __shared__ float4 s_rec[LIGHT * 2];                     // the tile's records in (cell, id) order
+    const int lane = threadIdx.x;
+    const int NT = w.NT, NC = w.NC;
+    const int nlight = w.ctr[0];
+  for (int e = blockIdx.x; e < nlight; e += gridDim.x) {
+    const int bt = w.light[e];
+    const int b = bt / NT, tile = bt - b * NT;
+    const unsigned short* row = w.off + ((size_t)b * (NT + 1) + tile) * NC;
+    int s = 0, len = 0;
+    if (lane < NC) {
+        s = row[lane];
+        len = (int)row[NC + lane] - s;                      // next tile's row: where this tile's segment ends
+    }
+    int incl = len;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    const int n = __shfl(incl, 63, 64);
+    wave_sync();                                            // (LDS of the previous tile of this wave is no longer read)
+    s_segs[lane] = s;
+    s_segp[lane] = incl - len;
+    if (lane == 63) s_segp[64] = n;
+    for (int i = lane; i < CELLS / 2; i += 64) reinterpret_cast<unsigned*>(s_cnt)[i] = 0u;
+    wave_sync();
+    // the tile's records, stream position j = lane + 64 k (chunk order = ascending point id)
+    constexpr int K = LIGHT / 64;
+    float4 ra[K], rb[K];
+    unsigned cell[K], pos[K];
+    const size_t rec0 = (size_t)b * w.NP;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int j = lane + 64 * k;
+        cell[k] = 0;
+        if (j < n) {
+            int lo = 0, hi = 64;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_segp[mid] <= j) lo = mid; else hi = mid;
+            }
+            const size_t idx = rec0 + (size_t)lo * CHUNK + s_segs[lo] + (j - s_segp[lo]);
+            ra[k] = w.recs[idx * 2];
+            rb[k] = w.recs[idx * 2 + 1];
+            cell[k] = __float_as_uint(rb[k].w) >> ID_BITS;
+        }
+    }
+    // stable rank inside the cell: earlier batches first, lower lanes first
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const bool valid = lane + 64 * k < n;
+        const unsigned long long m = match_bits(cell[k], 10, valid);
+        const int rank = lanes_below(m), cnt = __popcll(m);
+        const unsigned before = valid ? s_cnt[cell[k]] : 0u;
+        if (valid && rank == 0) s_cnt[cell[k]] = (unsigned short)(before + cnt);
+        pos[k] = before + rank;
+        wave_sync();
+    }
+    // cell starts: lane L owns the z-column of cells 16 L .. 16 L + 15
+    int cnt16[16], start16[16];
+    int tot = 0, occ = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        cnt16[i] = s_cnt[16 * lane + i];
+        tot += cnt16[i];
+        occ += cnt16[i] > 0 ? 1 : 0;
+    }
+    int packed = (occ << 16) | tot, pincl = packed;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(pincl, o, 64);
+        if (lane >= o) pincl += t;
+    }
+    const int nocc = __shfl(pincl, 63, 64) >> 16;
+    int run = (pincl - packed) & 0xFFFF;
+    const int occ_before = (pincl - packed) >> 16;
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        start16[i] = run;
+        s_cnt[16 * lane + i] = (unsigned short)run;
+        run += cnt16[i];
+    }
+    // dense slots of this sample's compact list (order across tiles is arbitrary: every record carries its cell address)
+    int rbase = 0;
+    if (lane == 0) rbase = atomicAdd(&w.ctr[64 + 32 * b], nocc);
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (lane + 64 * k < n) {
+            const int p = s_cnt[cell[k]] + pos[k];
+            s_rec[2 * p] = ra[k];
+            s_rec[2 * p + 1] = rb[k];
+        }
+    }
+    wave_sync();
+    rbase = __shfl(rbase, 0, 64);
+    const int tz = tile % w.Tz, ty = (tile / w.Tz) % w.Ty, tx = tile / (w.Tz * w.Ty);
+    float4* res = w.res + (size_t)b * w.NP * 2;
+    int slot = rbase + occ_before;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int cnt = cnt16[i];
+        if (cnt > 0) {
+            float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                // zeros_like(self._flat_output) (:145)
+            for (int k = 0; k < cnt; ++k) {
+                const float4 a = s_rec[2 * (start16[i] + k)], c4 = s_rec[2 * (start16[i] + k) + 1];
+                const float r[7] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z};
+#pragma unroll
+                for (int c = 0; c < 3 + F; ++c) acc[c] = __fadd_rn(acc[c], r[c]);
+            }
+            const int cellid = 16 * lane + i;
+            const int X = tx * TX + (cellid >> 7), Y = ty * TY + ((cellid >> 4) & 7), Z = tz * TZ + (cellid & 15);
+            emit_cell<F>(res, (size_t)slot, acc, cnt, (X * g.V + Y) * g.V + Z);
+            ++slot;
+        }
+    }
+  }
+}
+
+// slot (inside the sample's record array) of stream position s of a tile: chunk by binary search over the prefix of the
+// segment lengths, then the offset inside that chunk's segment
+__device__ __forceinline__ size_t locate(const int* s_segp, const int* s_segs, int NC, int s) {
+    int lo = 0, hi = NC;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_segp[mid] <= s) lo = mid; else hi = mid;
+    }
+    return (size_t)lo * CHUNK + s_segs[lo] + (s - s_segp[lo]);
+}
+
+// ------------------------------------------------------------------------------------------------------------ heavy
+constexpr int HB = 4;                                   // 64-record batches a wave keeps in flight in the heavy kernel
+// (keeping the sorted records of tiles up to 3584 points in 112 KB of LDS, with 8 batches in flight, was measured: 64 us
+// instead of 53 for the kernel -- the reduction is not what it waits for)
+
+template <int F>
+__global__ void __launch_bounds__(256) vt_heavy_kernel(Geom g, TileWs w, int all_tiles) {
     __shared__ unsigned s_hist[4 * CELLS];              // per wave: count, then write cursor, of every cell
     __shared__ unsigned s_cell[CELLS + 1];              // occupied cells before this one << 20 | first slot of the cell
     __shared__ int s_segs[MAX_NC];                      // start of the tile's segment inside chunk c
     __shared__ int s_segp[MAX_NC + 1];                  // exclusive prefix of the segment lengths
     __shared__ int s_red[4];
+    __shared__ int s_rbase;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int NT = w.NT, NC = w.NC;
-    const int nwork = w.ctr[0];
+    const int nwork = all_tiles ? g.B * NT : w.ctr[32];
     for (int e = blockIdx.x; e < nwork; e += gridDim.x) {
-        const int bt = w.worklist[e];
+        const int bt = all_tiles ? e : w.heavy[e];
         const int b = bt / NT, tile = bt - b * NT;
         // 1. the tile's segments, chunk by chunk (= ascending point id)
+        const unsigned short* row = w.off + ((size_t)b * (NT + 1) + tile) * NC;
         int n = 0, base_part = 0;
         for (int c0 = 0; c0 < NC; c0 += 256) {
             const int c = c0 + tid;
             int s = 0, len = 0;
             if (c < NC) {
-                const unsigned short* offp = w.off + ((size_t)b * NC + c) * (NT + 1) + tile;
-                s = offp[0];
-                len = (int)offp[1] - s;
+                s = row[c];
+                len = (int)row[NC + c] - s;
                 s_segs[c] = s;
             }
             int tot;
@@ -224,6 +410,7 @@ __global__ void __launch_bounds__(256) vt_tile_kernel(Geom g, TileWs w) {
             n += tot;
             base_part += s;
         }
+        if (n == 0) { __syncthreads(); continue; }      // (only reachable with all_tiles)
         if (tid == 0) s_segp[NC] = n;
         int base;                                       // points of this sample in lower-numbered tiles
         block_excl_scan(base_part, s_red, &base);
@@ -233,22 +420,24 @@ __global__ void __launch_bounds__(256) vt_tile_kernel(Geom g, TileWs w) {
         const int q = (((n + 3) >> 2) + 63) & ~63;
         const int r0 = min(n, wv * q), r1 = min(n, r0 + q);
         unsigned* myh = s_hist + wv * CELLS;
-        const size_t key0 = (size_t)b * w.NP;
-        for (int s0 = r0; s0 < r1; s0 += 64) {
-            const int s = s0 + lane;
-            const bool valid = s < r1;
-            unsigned cell = 0;
-            if (valid) {
-                int lo = 0, hi = NC;
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_segp[mid] <= s) lo = mid; else hi = mid;
-                }
-                cell = w.keys[key0 + (size_t)lo * CHUNK + s_segs[lo] + (s - s_segp[lo])] >> ID_BITS;
+        const size_t rec0 = (size_t)b * w.NP;
+        for (int s0 = r0; s0 < r1; s0 += 64 * HB) {         // HB batches of 64 in flight, ranked in stream order
+            unsigned cell[HB];
+            bool valid[HB];
+#pragma unroll
+            for (int u = 0; u < HB; ++u) {
+                const int s = s0 + 64 * u + lane;
+                valid[u] = s < r1;
+                cell[u] = 0;
+                if (valid[u]) cell[u] = __float_as_uint(w.recs[(rec0 + locate(s_segp, s_segs, NC, s)) * 2 + 1].w) >> ID_BITS;
             }
-            const unsigned long long m = match_bits(cell, 10, valid);
-            const int rank = lanes_below(m), cnt = __popcll(m);
-            if (valid && rank == 0) myh[cell] += (unsigned)cnt;
+#pragma unroll
+            for (int u = 0; u < HB; ++u) {
+                if (s0 + 64 * u >= r1) break;                   // (wave-uniform)
+                const unsigned long long m = match_bits(cell[u], 10, valid[u]);
+                const int rank = lanes_below(m), cnt = __popcll(m);
+                if (valid[u] && rank == 0) myh[cell[u]] += (unsigned)cnt;
+            }
         }
         __syncthreads();
         // 3. cell starts: cells in order, waves in order inside a cell
@@ -277,41 +466,49 @@ __global__ void __launch_bounds__(256) vt_tile_kernel(Geom g, TileWs w) {
                 s_hist[3 * CELLS + cellid] = start + h[i][0] + h[i][1] + h[i][2];
                 run += (cs[i] > 0 ? (1u << 20) : 0u) + (unsigned)cs[i];
             }
-            if (tid == 255) s_cell[CELLS] = run;
+            if (tid == 255) {
+                s_cell[CELLS] = run;
+                s_rbase = atomicAdd(&w.ctr[64 + 32 * b], (int)(run >> 20));
+            }
         }
         __syncthreads();
         // 4. move every record to its cell segment (stable: stream order = id order)
         float4* sorted = w.sorted + ((size_t)b * w.NP + base) * 2;
-        for (int s0 = r0; s0 < r1; s0 += 64) {
-            const int s = s0 + lane;
-            const bool valid = s < r1;
-            unsigned cell = 0;
-            float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
-            if (valid) {
-                int lo = 0, hi = NC;
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_segp[mid] <= s) lo = mid; else hi = mid;
+        for (int s0 = r0; s0 < r1; s0 += 64 * HB) {
+            float4 ra[HB], rb[HB];
+            bool valid[HB];
+#pragma unroll
+            for (int u = 0; u < HB; ++u) {
+                const int s = s0 + 64 * u + lane;
+                valid[u] = s < r1;
+                ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[u] = ra[u];
+                if (valid[u]) {
+                    const size_t idx = rec0 + locate(s_segp, s_segs, NC, s);
+                    ra[u] = w.recs[idx * 2];
+                    rb[u] = w.recs[idx * 2 + 1];
                 }
-                const size_t idx = key0 + (size_t)lo * CHUNK + s_segs[lo] + (s - s_segp[lo]);
-                ra = w.recs[idx * 2];
-                rb = w.recs[idx * 2 + 1];
-                cell = __float_as_uint(rb.w) >> ID_BITS;
             }
-            const unsigned long long m = match_bits(cell, 10, valid);
-            const int rank = lanes_below(m), cnt = __popcll(m);
-            const unsigned before = valid ? myh[cell] : 0u;
-            if (valid && rank == 0) myh[cell] = before + (unsigned)cnt;
-            if (valid) {
-                const size_t pos = before + rank;
-                sorted[pos * 2] = ra;
-                sorted[pos * 2 + 1] = rb;
+#pragma unroll
+            for (int u = 0; u < HB; ++u) {
+                if (s0 + 64 * u >= r1) break;                   // (wave-uniform)
+                const unsigned cell = __float_as_uint(rb[u].w) >> ID_BITS;
+                const unsigned long long m = match_bits(cell, 10, valid[u]);
+                const int rank = lanes_below(m), cnt = __popcll(m);
+                const unsigned before = valid[u] ? myh[cell] : 0u;
+                if (valid[u] && rank == 0) myh[cell] = before + (unsigned)cnt;
+                if (valid[u]) {
+                    const size_t pos = before + rank;
+                    sorted[pos * 2] = ra[u];
+                    sorted[pos * 2 + 1] = rb[u];
+                }
             }
         }
         __syncthreads();
         // 5. one thread per cell: add the records front to back (ascending id), emit a compact record per occupied cell
         const int tz = tile % w.Tz, ty = (tile / w.Tz) % w.Ty, tx = tile / (w.Tz * w.Ty);
-        float4* res = w.res + ((size_t)b * w.NP + base) * 2;
+        float4* res = w.res + (size_t)b * w.NP * 2;
+        const int rbase = s_rbase;
 #pragma unroll 1
         for (int i = 0; i < 4; ++i) {
             const int cellid = i * 256 + tid;
@@ -338,19 +535,43 @@ __global__ void __launch_bounds__(256) vt_tile_kernel(Geom g, TileWs w) {
 #pragma unroll
                     for (int c = 0; c < 3 + F; ++c) acc[c] = __fadd_rn(acc[c], r[c]);
                 }
-                const float Lf = (float)cnt;                                // clamp_(1) is a no-op for occupied cells (:121)
-                float mean[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int c = 0; c < 3 + F; ++c) mean[c] = __fdiv_rn(acc[c], Lf);
                 const int X = tx * TX + (cellid >> 7), Y = ty * TY + ((cellid >> 4) & 7), Z = tz * TZ + (cellid & 15);
-                const int gc = (X * g.V + Y) * g.V + Z;
-                const size_t o = (size_t)(info >> 20) * 2;
-                res[o] = make_float4(mean[0], mean[1], mean[2], mean[3]);
-                res[o + 1] = make_float4(mean[4], mean[5], mean[6], __int_as_float(gc));
+                emit_cell<F>(res, (size_t)(rbase + (int)(info >> 20)), acc, cnt, (X * g.V + Y) * g.V + Z);
             }
         }
-        if (tid == 0) w.tinfo[bt] = make_int2(base, (int)(s_cell[CELLS] >> 20));
         __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ unpatch
+// Incremental mode: `out` still holds the grid of the previous call that used this workspace, whose compact cell list is
+// still in `res` / `ctr`.  The empty-cell pattern does not depend on the input, so instead of re-writing all V^3 cells the
+// previously occupied ones are reset to "empty" (zeros | idx/V | 0, voxel_grid.py:192-198 for count == 0) before the new
+// ones are patched in: ~2 x 40 bytes per occupied cell of traffic instead of 40 bytes per cell of the grid.
+template <int F>
+__global__ void __launch_bounds__(256) vt_unpatch_kernel(Geom g, TileWs w, float* __restrict__ out) {
+    constexpr int C = 3 + F + 4;
+    const int b = blockIdx.y, V = g.V;
+    const int nocc = w.ctr_prev[64 + 32 * b];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= nocc) return;
+    const size_t V3 = (size_t)V * V * V;
+    const float Vf = (float)V;
+    const int gc = __float_as_int(w.res_prev[((size_t)b * w.NP + j) * 2 + 1].w);
+    const int x = gc / (V * V), y = (gc / V) % V, z = gc % V;
+    float v[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[c] = 0.0f;
+    v[3 + F + 0] = __fdiv_rn((float)x, Vf);
+    v[3 + F + 1] = __fdiv_rn((float)y, Vf);
+    v[3 + F + 2] = __fdiv_rn((float)z, Vf);
+    float* o = out + ((size_t)b * V3 + gc) * C;
+    if ((C & 1) == 0 && ((reinterpret_cast<uintptr_t>(out) & 7) == 0)) {
+#pragma unroll
+        for (int c = 0; c < C; c += 2) *reinterpret_cast<float2*>(o + c) = make_float2(v[c], v[c + 1]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) o[c] = v[c];
     }
 }
 
@@ -358,43 +579,39 @@ __global__ void __launch_bounds__(256) vt_tile_kernel(Geom g, TileWs w) {
 template <int F>
 __global__ void __launch_bounds__(256) vt_patch_kernel(Geom g, TileWs w, float* __restrict__ out) {
     constexpr int C = 3 + F + 4;
-    const int NT = w.NT, V = g.V;
+    const int b = blockIdx.y, V = g.V;
+    const int nocc = w.ctr[64 + 32 * b];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= nocc) return;
     const size_t V3 = (size_t)V * V * V;
     const float Vf = (float)V;                           // self._voxel_d (:197)
-    const int nwork = w.ctr[0];
-    for (int e = blockIdx.x; e < nwork; e += gridDim.x) {
-        const int bt = w.worklist[e];
-        const int b = bt / NT;
-        const int2 ti = w.tinfo[bt];
-        const float4* res = w.res + ((size_t)b * w.NP + ti.x) * 2;
-        for (int j = threadIdx.x; j < ti.y; j += 256) {
-            const float4 ra = res[j * 2], rb = res[j * 2 + 1];
-            const int gc = __float_as_int(rb.w);
-            const int x = gc / (V * V), y = (gc / V) % V, z = gc % V;
-            const float m[7] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z};
-            float v[C];
+    const float4* res = w.res + (size_t)b * w.NP * 2;
+    const float4 ra = res[(size_t)j * 2], rb = res[(size_t)j * 2 + 1];
+    const int gc = __float_as_int(rb.w);
+    const int x = gc / (V * V), y = (gc / V) % V, z = gc % V;
+    const float m[7] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z};
+    float v[C];
 #pragma unroll
-            for (int c = 0; c < 3 + F; ++c) v[c] = m[c];
-            v[3 + F + 0] = __fdiv_rn((float)x, Vf);
-            v[3 + F + 1] = __fdiv_rn((float)y, Vf);
-            v[3 + F + 2] = __fdiv_rn((float)z, Vf);
-            v[3 + F + 3] = 1.0f;                         // (count/count > 0).float()  (:192)
-            float* o = out + ((size_t)b * V3 + gc) * C;
-            if ((C & 1) == 0 && ((reinterpret_cast<uintptr_t>(out) & 7) == 0)) {
+    for (int c = 0; c < 3 + F; ++c) v[c] = m[c];
+    v[3 + F + 0] = __fdiv_rn((float)x, Vf);
+    v[3 + F + 1] = __fdiv_rn((float)y, Vf);
+    v[3 + F + 2] = __fdiv_rn((float)z, Vf);
+    v[3 + F + 3] = 1.0f;                                 // (count/count > 0).float()  (:192)
+    float* o = out + ((size_t)b * V3 + gc) * C;
+    if ((C & 1) == 0 && ((reinterpret_cast<uintptr_t>(out) & 7) == 0)) {
 #pragma unroll
-                for (int c = 0; c < C; c += 2) *reinterpret_cast<float2*>(o + c) = make_float2(v[c], v[c + 1]);
-            } else {
+        for (int c = 0; c < C; c += 2) *reinterpret_cast<float2*>(o + c) = make_float2(v[c], v[c + 1]);
+    } else {
 #pragma unroll
-                for (int c = 0; c < C; ++c) o[c] = v[c];
-            }
-        }
+        for (int c = 0; c < C; ++c) o[c] = v[c];
     }
 }
 
 struct Layout {
-    size_t ctr, tile_total, worklist, tinfo, off, keys, recs, sorted, res, total;
+    size_t ctr[2], light, heavy, off, recs, sorted, res[2], total;
     int NT, Tx, Ty, Tz, NC;
 };
+constexpr size_t CTR_INTS(long long B) { return 64 + 32 * (size_t)B; }
 
 Layout vt_layout(long long B, long long N, int V) {
     Layout L;
@@ -403,35 +620,57 @@ Layout vt_layout(long long B, long long N, int V) {
     L.NC = (int)((N + CHUNK - 1) / CHUNK);
     size_t p = 0;
     auto take = [&p](size_t bytes) { const size_t at = p; p += (bytes + 255) & ~(size_t)255; return at; };
-    L.ctr = take(16 * sizeof(int));
-    L.tile_total = take((size_t)B * L.NT * sizeof(int));      // (contiguous with ctr: one memset covers both)
-    L.worklist = take((size_t)B * L.NT * sizeof(int));
-    L.tinfo = take((size_t)B * L.NT * sizeof(int2));
-    L.off = take((size_t)B * L.NC * (L.NT + 1) * sizeof(unsigned short));
+    L.ctr[0] = take(CTR_INTS(B) * sizeof(int));
+    L.ctr[1] = take(CTR_INTS(B) * sizeof(int));
+    L.light = take((size_t)B * L.NT * sizeof(int));
+    L.heavy = take((size_t)B * L.NT * sizeof(int));
+    L.off = take((size_t)B * (L.NT + 1) * L.NC * sizeof(unsigned short));
     const size_t slots = (size_t)B * L.NC * CHUNK;
-    L.keys = take(slots * sizeof(unsigned));
     L.recs = take(slots * 32);
     L.sorted = take(slots * 32);
-    L.res = take(slots * 32);
+    L.res[0] = take(slots * 32);            // the compact cell lists are double-buffered: in incremental mode the previous
+    L.res[1] = take(slots * 32);            // call's list is still being read (unpatch) while the new one is written
     L.total = p;
     return L;
 }
 
 template <int F>
 int vt_launch(const Src& src, const Geom& g, const float* bounds, float* out, const TileWs& w, hipStream_t st, hipStream_t side,
-              hipEvent_t ev_join, size_t zero_bytes) {
-    if (hipMemsetAsync(w.ctr, 0, zero_bytes, side) != hipSuccess) return VXB_ELAUNCH;
+              hipEvent_t ev_fork, hipEvent_t ev_mid, hipEvent_t ev_join, int order, int C) {
+    // order 2: fresh buffer.   route, classify, heavy, light, fill, patch          -- all in order on `st`: no side stream, no
+    // order 4: incremental.    unpatch, route, classify, heavy, light, patch         events, capturable in a hipGraph
+    // orders 0 / 3 (A/B measurements): the fill on the side stream, from the start / after the classify kernel.
+    // Every attempt to run two of these kernels side by side (fill || chain, light || heavy, unpatch || route) ended LATER
+    // than running them back to back on MI355X: they are all bound by memory latency, and sharing the memory system
+    // stretches each by about what the overlap would have hidden (profiles/r02_voxel_*.txt).
+    const long long cap = (long long)g.N < (long long)g.V * g.V * g.V ? g.N : (long long)g.V * g.V * g.V;   // occupied cells per sample
+    const bool forked = order == 0 || order == 3;       // only the A/B orders use the side stream
+    if (forked && (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess)) return VXB_ELAUNCH;
+    if (order == 4) hipLaunchKernelGGL(vt_unpatch_kernel<F>, dim3((unsigned)((cap + 255) / 256), g.B), dim3(256), 0, st, g, w, out);
+    if (order == 0) vox_launch_fill(out, g.B, g.V, C, side);
+    if (hipMemsetAsync(w.ctr, 0, CTR_INTS(g.B) * sizeof(int), st) != hipSuccess) return VXB_ELAUNCH;
     const size_t lds = (size_t)4 * w.NT * sizeof(unsigned short);
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute((const void*)vt_route_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return VXB_ELAUNCH;
     }
-    hipLaunchKernelGGL(vt_route_kernel<F>, dim3(w.NC, g.B), dim3(256), lds, side, src, g, bounds, w);
+    hipLaunchKernelGGL(vt_route_kernel<F>, dim3(w.NC, g.B), dim3(256), lds, st, src, g, bounds, w);
     const long long tiles = (long long)g.B * w.NT;
-    const int grid = (int)(tiles < 2048 ? tiles : 2048);
-    hipLaunchKernelGGL(vt_tile_kernel<F>, dim3(grid), dim3(256), 0, side, g, w);
-    if (hipEventRecord(ev_join, side) != hipSuccess || hipStreamWaitEvent(st, ev_join, 0) != hipSuccess) return VXB_ELAUNCH;
-    hipLaunchKernelGGL(vt_patch_kernel<F>, dim3(grid), dim3(256), 0, st, g, w, out);
+    const size_t heavy_lds = 0;
+    if (w.NC <= 64) {
+        hipLaunchKernelGGL(vt_classify_kernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, st, g, w);
+        // (light and heavy tiles on two streams were measured: the heavy kernel stretches from 53 to 75 us next to the
+        // light one and the pair ends later than back to back)
+        if (order == 3) vox_launch_fill(out, g.B, g.V, C, side);
+        hipLaunchKernelGGL(vt_heavy_kernel<F>, dim3(512), dim3(256), heavy_lds, st, g, w, 0);
+        hipLaunchKernelGGL(vt_light_kernel<F>, dim3((unsigned)(tiles < 4096 ? tiles : 4096)), dim3(64), 0, st, g, w);
+    } else {                                                    // more than 64 chunks per sample: every tile by the workgroup kernel
+        if (order == 3) vox_launch_fill(out, g.B, g.V, C, side);
+        hipLaunchKernelGGL(vt_heavy_kernel<F>, dim3((unsigned)(tiles < 4096 ? tiles : 4096)), dim3(256), heavy_lds, st, g, w, 1);
+    }
+    if (order == 2) vox_launch_fill(out, g.B, g.V, C, st);
+    if (forked && (hipEventRecord(ev_join, side) != hipSuccess || hipStreamWaitEvent(st, ev_join, 0) != hipSuccess)) return VXB_ELAUNCH;
+    hipLaunchKernelGGL(vt_patch_kernel<F>, dim3((unsigned)((cap + 255) / 256), g.B), dim3(256), 0, st, g, w, out);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
@@ -452,31 +691,32 @@ size_t vox_tiles_ws_bytes(long long B, long long N, int V) {
 }
 
 int vox_tiles_launch(const Src& src, const Geom& g, const float* bounds, float* out, void* ws, hipStream_t st, hipStream_t side,
-                     hipEvent_t ev_join) {
+                     hipEvent_t ev_fork, hipEvent_t ev_mid, hipEvent_t ev_join, int order, int list_in, int list_out) {
+    const int C = 3 + g.F + 4;
     const Layout L = vt_layout(g.B, g.N, g.V);
     char* p = (char*)ws;
     TileWs w;
-    w.ctr = (int*)(p + L.ctr);
-    w.tile_total = (int*)(p + L.tile_total);
-    w.worklist = (int*)(p + L.worklist);
-    w.tinfo = (int2*)(p + L.tinfo);
+    w.ctr = (int*)(p + L.ctr[list_out]);
+    w.ctr_prev = list_in >= 0 ? (const int*)(p + L.ctr[list_in]) : nullptr;
+    w.light = (int*)(p + L.light);
+    w.heavy = (int*)(p + L.heavy);
     w.off = (unsigned short*)(p + L.off);
-    w.keys = (unsigned*)(p + L.keys);
     w.recs = (float4*)(p + L.recs);
     w.sorted = (float4*)(p + L.sorted);
-    w.res = (float4*)(p + L.res);
+    w.res = (float4*)(p + L.res[list_out]);
+    w.res_prev = list_in >= 0 ? (const float4*)(p + L.res[list_in]) : nullptr;
     w.NT = L.NT; w.Tx = L.Tx; w.Ty = L.Ty; w.Tz = L.Tz; w.NC = L.NC;
     w.NP = (long long)L.NC * CHUNK;
     int bits = 1;
     while ((1 << bits) < L.NT) ++bits;
     w.tile_bits = bits;
-    const size_t zero_bytes = L.worklist;               // ctr + tile_total
+    if (order == 4 && list_in < 0) return VXB_EARG;
     switch (g.F) {
-        case 0: return vt_launch<0>(src, g, bounds, out, w, st, side, ev_join, zero_bytes);
-        case 1: return vt_launch<1>(src, g, bounds, out, w, st, side, ev_join, zero_bytes);
-        case 2: return vt_launch<2>(src, g, bounds, out, w, st, side, ev_join, zero_bytes);
-        case 3: return vt_launch<3>(src, g, bounds, out, w, st, side, ev_join, zero_bytes);
-        case 4: return vt_launch<4>(src, g, bounds, out, w, st, side, ev_join, zero_bytes);
+        case 0: return vt_launch<0>(src, g, bounds, out, w, st, side, ev_fork, ev_mid, ev_join, order, C);
+        case 1: return vt_launch<1>(src, g, bounds, out, w, st, side, ev_fork, ev_mid, ev_join, order, C);
+        case 2: return vt_launch<2>(src, g, bounds, out, w, st, side, ev_fork, ev_mid, ev_join, order, C);
+        case 3: return vt_launch<3>(src, g, bounds, out, w, st, side, ev_fork, ev_mid, ev_join, order, C);
+        case 4: return vt_launch<4>(src, g, bounds, out, w, st, side, ev_fork, ev_mid, ev_join, order, C);
         default: return VXB_EARG;
     }
 }
