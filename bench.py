@@ -11,6 +11,10 @@ all-reduce (RCCL, N > 1), fused LAMB, and the runner's `.item()` on the loss (of
 synthetic replay batch that is already resident in HBM.  Weak scaling: every rank owns its own B=16 shard
 (task_uniform_replay_buffer.py:103-108 semantics), the only exchange is the gradient all-reduce.
 
+    python bench.py --agents 2 --aug-copies 4        # BASELINE.json configs[2] / [3]: the acting + stabilizing twin agents
+(low_dim 7, arm-prediction loss, per-sample crop bounds), both resident on every GPU; one step = each agent updating on 4
+independently SE(3)-perturbed copies of its 16 replay samples (4 update() calls per agent, 128 voxel grids per step).
+
 Rank 0 prints ONE JSON line (metric/value/... + `roofline` for the dominant kernel + `cpu_baseline`).
 """
 import argparse
@@ -40,6 +44,10 @@ def main():
     ap.add_argument('--image', type=int, default=128)
     ap.add_argument('--depth', type=int, default=6)
     ap.add_argument('--latents', type=int, default=2048)
+    ap.add_argument('--agents', type=int, default=1, choices=(1, 2),
+                    help='2 = the acting + stabilizing twin agents of BASELINE.json configs[2] / [3]')
+    ap.add_argument('--aug-copies', type=int, default=1,
+                    help='SE(3)-perturbed copies of every replay sample per step (update() calls per agent and step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-modes', '--no-bf16-mode', dest='no_other_modes', action='store_true',
                     help='skip the secondary measurements in the other precisions and the parity probe')
@@ -66,29 +74,51 @@ def main():
 
     V, B, HW = a.voxel_size, a.batch, a.image
     patch = 5 if V % 5 == 0 else 4
-    cfg = lu.default_cfg(method__voxel_sizes=[V], method__voxel_patch_size=5, method__voxel_patch_stride=patch,
-                         method__transformer_depth=a.depth, method__num_latents=a.latents, replay__batch_size=B,
-                         rlbench__camera_resolution=[HW, HW], ddp__num_devices=world)
-    torch.manual_seed(1234)           # identical initial weights on every rank (DDP broadcasts rank 0's upstream)
-    agent = lu.create_agent(cfg)
-    agent.build(training=True, device=dev_index)
+    twin = a.agents == 2
+    over = dict(method__voxel_sizes=[V], method__voxel_patch_size=5, method__voxel_patch_stride=patch,
+                method__transformer_depth=a.depth, method__num_latents=a.latents, replay__batch_size=B,
+                rlbench__camera_resolution=[HW, HW], ddp__num_devices=world)
+    # twin agents: `which_arm` dominant (acting) / assistive (stabilizing), 7-dim proprioception, arm-prediction head,
+    # grid cropped around the target object (scripts/train_open_jar_ours_vlm_10_demos_v2_11_{acting,stabilizing}.sh:22-24)
+    arms = ['dominant', 'assistive'] if twin else ['right']
+    agents, cfgs = [], []
+    torch.manual_seed(1234)           # (the agent broadcasts rank 0's weights at build(), as DDP does upstream)
+    for arm in arms:
+        cfg = lu.default_cfg(**over) if not twin else lu.default_cfg(
+            method__which_arm=arm, method__arm_pred_loss=True, method__crop_target_obj_voxel=True, **over)
+        ag = lu.create_agent(cfg)
+        ag.build(training=True, device=dev_index)
+        agents.append(ag)
+        cfgs.append(cfg)
+    cfg, agent = cfgs[0], agents[0]
+    low_dim = 7 if twin else 4
     n_params = sum(p.numel() for p in agent._pose_agent._qattention_agents[0]._q.parameters())
-    batches = [{k: v.to(dev) for k, v in synthetic.make_replay_sample(
-        B, cfg.rlbench.cameras, (HW, HW), V, 4, seed=100 * rank + j).items()} for j in range(2)]
+    # open_jar-like / open_drawer-like scene bounds for the two halves of the ranks
+    scene = synthetic.SCENE_BOUNDS if (not twin or rank % 2 == 0) else [-0.8, -1.0, 0.1, 1.2, 1.0, 2.8]
+    batches = [[{k: v.to(dev) for k, v in synthetic.make_replay_sample(
+        B, cfg.rlbench.cameras, (HW, HW), V, low_dim, seed=100 * rank + 10 * ai + j, scene_bounds=scene, arm_pred_loss=twin,
+        crop_target_obj_voxel=twin, crop_radius=0.3 if ai == 0 else 0.4, keyframes_near_target=twin).items()} for j in range(2)] for ai in range(len(agents))]
 
-    eng = agent._pose_agent._qattention_agents[0]._q.encoder.engine()
+    engines = [ag._pose_agent._qattention_agents[0]._q.encoder.engine() for ag in agents]
+    eng = engines[0]
     headline_mode = eng.precision          # 'bf16x3' unless VOXACTB_PRECISION overrides it
     counter = [0]
+    updates_per_step = len(agents) * a.aug_copies
 
     def step():
         i = counter[0]
         counter[0] += 1
-        out = agent.update(i, batches[i % 2])
-        return float(out['total_losses'])          # the runner's .item() (device sync every step)
+        loss = 0.0
+        for ai, ag in enumerate(agents):           # the twin agents are stepped back to back on this GPU's shard
+            for _ in range(a.aug_copies):          # every call draws a fresh SE(3) perturbation of the same replay samples
+                out = ag.update(i, dict(batches[ai][i % 2]))
+                loss = float(out['total_losses'])  # the runner's .item() (device sync every update)
+        return loss
 
     def measure(mode, steps, warmup):
-        """W untimed + exactly K timed update() steps in `mode`, bracketed by barrier + synchronize; max over ranks."""
-        eng.precision = mode
+        """W untimed + exactly K timed steps in `mode`, bracketed by barrier + synchronize; max over ranks."""
+        for e_ in engines:
+            e_.precision = mode
         for _ in range(warmup):
             step()
         timer = _lib.KernelTimer()
@@ -108,7 +138,8 @@ def main():
         tt = torch.tensor([dt], device=dev)
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        eng.precision = headline_mode
+        for e_ in engines:
+            e_.precision = headline_mode
         return float(tt[0]), loss, timer.summary()
 
     torch.manual_seed(1000 + rank)    # augmentation draws differ per rank, as they would with per-rank replay shards
@@ -125,24 +156,12 @@ def main():
                             'dtype': MODE_DTYPE[mode], 'rooflines': group_rooflines(agg2, mode, a.steps),
                             'note': MODE_NOTE[mode]}
 
-    # how far the headline precision is from the exact-fp32 matrix-core path on THIS workload (forward, eval mode, B=2)
+    # parity of the headline precision against the REFERENCE at this geometry: the digest the reference produced for a
+    # seeded batch with name-hashed weights (tests/golden/f5_encoder_c2_digest.npz, generated by make_golden.py from the
+    # reference's own modules; the same check runs as tests/test_c2_reference_gpu.py in both precisions)
     probe = None
-    if rank == 0 and headline_mode != 'fp32' and not a.no_other_modes:
-        g = torch.Generator(device='cpu').manual_seed(5)
-        grid = (torch.rand(2, V, V, V, 10, generator=g) * (torch.rand(2, V, V, V, 1, generator=g) < 0.05)).to(dev)
-        prop = batches[0]['low_dim_state'][:2, 0].float() if batches[0]['low_dim_state'].dim() > 2 else batches[0]['low_dim_state'][:2].float()
-        lang = batches[0]['lang_token_embs'][:2, 0].float() if batches[0]['lang_token_embs'].dim() > 3 else batches[0]['lang_token_embs'][:2].float()
-        qs = {}
-        for mode in (headline_mode, 'fp32'):
-            eng.precision = mode
-            outs, _ = eng.forward(grid, prop, lang, training=False, save=False)
-            qs[mode] = [o.float().clone() for o in outs[:3]]
-        eng.precision = headline_mode
-        probe = {'what': 'max |Q(%s) - Q(exact fp32 MFMA)| over q_trans / rot_grip / collision, V=%d forward, B=2, eval' % (headline_mode, V),
-                 'q_trans': float((qs[headline_mode][0] - qs['fp32'][0]).abs().max()),
-                 'rot_grip': float((qs[headline_mode][1] - qs['fp32'][1]).abs().max()),
-                 'collision': float((qs[headline_mode][2] - qs['fp32'][2]).abs().max()),
-                 'q_trans_abs_max': float(qs['fp32'][0].abs().max()), 'bound': 1e-4}
+    if rank == 0 and not a.no_other_modes:
+        probe = reference_digest_check(dev, headline_mode, V, a.depth, a.latents, HW)
 
     # act() latency: eval agent, B=1 observation with precomputed language embeddings (the CLIP text
     # encoder's weights are not in either tree), 1 voxelize + 1 forward + argmax + the D2H copy of the 9-vector action
@@ -151,9 +170,10 @@ def main():
         ev = lu.create_agent(cfg)
         ev.build(training=False, device=dev_index)
         rs = synthetic.make_replay_sample(1, cfg.rlbench.cameras, (HW, HW), V, 4, seed=3)
-        obs = {k: v.to(dev) for k, v in rs.items() if k.endswith(('_rgb', '_point_cloud')) or k == 'low_dim_state'}
-        obs = {k: v.unsqueeze(0) if v.dim() < 5 and k != 'low_dim_state' else v for k, v in obs.items()}
-        obs['low_dim_state'] = rs['low_dim_state'].to(dev)
+        obs = {k: v.to(dev) for k, v in rs.items()
+               if k.endswith(('_rgb', '_point_cloud', '_camera_extrinsics', '_camera_intrinsics')) or k == 'low_dim_state'}
+        for cam in cfg.rlbench.cameras:
+            obs['%s_camera_extrinsics' % cam][0, 0, 2, 3] = -1.0             # (a camera 1 m off the scene origin)
         obs['lang_goal_emb'] = rs['lang_goal_emb'][0].to(dev)
         obs['lang_token_embs'] = rs['lang_token_embs'][0].to(dev)
         for i in range(3):
@@ -172,28 +192,38 @@ def main():
         value = world * a.steps / dt
         tot_ms = sum(d['ms'] for d in agg.values())
         roofs = group_rooflines(agg, headline_mode, a.steps)
-        dom_key = max(roofs, key=lambda k: roofs[k]['ms_per_step'])
-        roofline = dict(roofs[dom_key])
-        roofline['kernel'] = dom_key
-        roofline['traffic'] = None
-        if headline_mode == 'bf16x3' and V == 100 and B == 16 and dom_key.startswith('conv3d'):
-            # HBM bytes per launch of the dominant kernel of this group (conv3_halo_kernel<2,1,4,1,0>: final fwd and final
-            # dgrad + fused padding adjoint), from the committed PMC passes of this same command (profiles/
-            # r01_pmc_*_v8.txt; separate --pmc FETCH_SIZE / WRITE_SIZE runs, KiB units).  FETCH_SIZE doubled as
-            # MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950; WRITE_SIZE is exact (4.0 GiB forward,
-            # 2 x 4.0 GiB for the two gradients of the fused dgrad -> mean 6.0M KiB).
-            roofline['traffic'] = (2 * 8605105.3 + 6000000.0) * 1024.0
-            roofline['traffic_note'] = ('conv3_halo_kernel<2,1,4,1,0> mean per launch: FETCH_SIZE 8.81 GB raw (x2 = 17.6 GB) + '
-                                        'WRITE_SIZE 6.14 GB (exactly the outputs); compulsory reads are 8.2 GB (fwd: two 64-channel '
-                                        'sources) and 4.1 + 8.2 GB (dgrad: dY once per 64-column block + the two accumulate / mask '
-                                        'operands); 23.8 GB / 19.9 ms = 1.2 TB/s, i.e. the kernel is matrix-core-bound, not HBM-bound')
+        # the dominant KERNEL = the timer label (one C-ABI entry point at one shape) with the largest share of device time;
+        # the conv / linear / attention GROUP figures stay in `rooflines_other`
+        dom_label = max((l for l in agg if agg[l]['flops'] > 0), key=lambda l: agg[l]['ms'])
+        d = agg[dom_label]
+        tf = d['flops'] / (d['ms'] * 1e-3) / 1e12
+        roofline = {'bound': 'mfma', 'achieved': tf, 'peak': MODE_PEAK[headline_mode], 'unit': 'TFLOP/s',
+                    'frac': tf / MODE_PEAK[headline_mode], 'frac_of_bf16_dense_peak': tf / PEAK_BF16_MFMA_TFLOPS,
+                    'peak_basis': {'fp32': 'fp32 MFMA 157.3', 'bf16x3': 'bf16 dense MFMA 2500 / 3 MFMAs per product',
+                                   'bf16': 'bf16 dense MFMA 2500'}[headline_mode],
+                    'kernel': dom_label, 'entry': d['entry'], 'launches': d['calls'] // a.steps,
+                    'avg_launch_ms': d['ms'] / max(d['calls'], 1), 'ms_per_step': d['ms'] / a.steps,
+                    'algorithmic_flops_per_launch': d['flops'] / max(d['calls'], 1), 'traffic': None}
+        dom_key = dom_label
+        if headline_mode == 'bf16x3' and (V, B) == (100, 16):
+            for pref, (nbytes, note) in PMC_TRAFFIC_C2.items():
+                if dom_label.startswith(pref):
+                    roofline['traffic'] = nbytes
+                    roofline['traffic_note'] = note
         roofline['share_of_device_time'] = roofline['ms_per_step'] * a.steps / tot_ms
-        extra = {k: v for k, v in roofs.items() if k != dom_key}
+        extra = dict(roofs)
         if 'voxelize' in agg:
             v = agg['voxelize']
             gbps = v['bytes'] / (v['ms'] * 1e-3) / 1e9
             extra['voxel_scatter'] = {'bound': 'hbm', 'achieved': gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
-                                      'frac': gbps / PEAK_HBM_GBPS, 'avg_launch_ms': v['ms'] / v['calls'], 'traffic': None}
+                                      'frac': gbps / PEAK_HBM_GBPS, 'avg_launch_ms': v['ms'] / v['calls'], 'traffic': None,
+                                      'algorithmic_bytes_per_launch': v['bytes'] / v['calls'],
+                                      'note': 'training path: the grid lives in two persistent buffers that are UPDATED (cells '
+                                              'occupied two steps ago reset, new ones written: ~80 B per occupied cell) instead '
+                                              'of re-written (40 B per cell); `achieved` prices the launch against the bytes of '
+                                              'the full read-points + write-grid formulation (SURVEY.md 8d), so it can exceed '
+                                              'what a full rewrite could reach.  Full-rewrite (stateless) call: '
+                                              'profiles/r02_voxel_fresh_kernel_stats.txt'}
         if a.kernel_table:
             for label, d in sorted(agg.items(), key=lambda kv: -kv[1]['ms']):
                 sys.stderr.write('%-44s calls %5d  %9.2f ms/step  %7.2f TF/s\n' % (
@@ -205,22 +235,38 @@ def main():
             'metric': 'voxel-policy train steps/sec (100^3 grid, 4 cams, B=16)', 'value': value, 'unit': 'steps/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': MODE_DTYPE[headline_mode], 'data': 'synthetic',
-            'config': {'workload': ('BASELINE.json configs[1]' if (V, B, HW) == (100, 16, 128) else
+            'config': {'workload': ('BASELINE.json configs[2] / [3] (twin acting + stabilizing agents, low_dim 7, arm loss, crop bounds; '
+                                    'one step = %d agents x %d SE(3)-perturbed copies = %d update() calls of B=%d; ' % (
+                                        len(agents), a.aug_copies, updates_per_step, B) if twin else '') +
+                                   ('BASELINE.json configs[1]' if (V, B, HW) == (100, 16, 128) else
                                     'BASELINE.json configs[4] shape (per GPU)' if (V, B) == (200, 8) else 'custom size') +
                                    ': QAttentionPerActBCAgent.update(), V=%d, %d cams %dx%d, '
                                    'B=%d per GPU, PerceiverIO depth %d, %d latents, SE(3) aug + dropout on, LAMB'
                                    % (V, len(cfg.rlbench.cameras), HW, HW, B, a.depth, a.latents),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world, 'params': n_params,
                        'precision': headline_mode},
-            'samples_per_s': value * B, 'final_loss': loss, 'device_time_ms_per_step': tot_ms / a.steps,
+            'samples_per_s': value * B * updates_per_step, 'updates_per_step': updates_per_step, 'final_loss': loss, 'device_time_ms_per_step': tot_ms / a.steps,
             'roofline': roofline, 'rooflines_other': extra, 'cpu_baseline': cpu, 'precision_note': MODE_NOTE[headline_mode],
-            'parity_probe': probe, 'act_latency': act_lat, 'other_precisions': others,
+            'parity_vs_reference': probe, 'act_latency': act_lat, 'other_precisions': others,
         }
         print(json.dumps(out))
     if world > 1:
         dist.barrier()                   # rank 0 did the rank-0-only extras; leave together
         dist.destroy_process_group()
 
+
+# HBM bytes per launch from the committed PMC passes of this command at configs[1] (separate --pmc FETCH_SIZE / WRITE_SIZE
+# runs, KiB units; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950, WRITE_SIZE exact)
+PMC_TRAFFIC_C2 = {
+    'conv3d_wgrad[k3 s1 128->64 S100]': (
+        33.8e9, 'wgrad_halo_kernel<1,2,8> (final conv weight gradient): 33.8 GB fetched per launch (FETCH_SIZE x2) for 12.3 GB '
+                'compulsory (x 4.1 GB + dY 4.1 GB + the second source 4.1 GB), output 1.8 MB; profiles/r01_pmc_fetch_size_v8.txt'),
+    'conv3d_bf16[k3 s1 128->64 S100': (
+        (2 * 8605105.3 + 6000000.0) * 1024.0,
+        'conv3_halo_kernel<2,1,4,1,0> (final conv forward / data gradient + padding adjoint), mean per launch: FETCH_SIZE 8.81 GB '
+        'raw (x2 = 17.6 GB) + WRITE_SIZE 6.14 GB; 23.8 GB / 19.9 ms = 1.2 TB/s: matrix-core-bound, not HBM-bound; '
+        'profiles/r01_pmc_*_v8.txt'),
+}
 
 MODE_DTYPE = {
     'fp32': 'f32 (v_mfma_f32_32x32x2_f32 everywhere)',
@@ -255,6 +301,54 @@ def group_rooflines(agg, mode, steps):
     return out
 
 
+def reference_digest_check(dev, mode, V, depth, latents, HW):
+    """Forward of the engine in precision `mode` on the seeded batch of fixture F5 (BASELINE.json configs[1] geometry, B=1) with
+    name-hashed weights, against the numbers the REFERENCE produced for it.  None when the bench runs at another size."""
+    import numpy as np
+    from voxactb_amd import synthetic
+    from voxactb_amd.agents.peract_bc.perceiver_lang_io import PerceiverVoxelLangEncoder
+    from voxactb_amd.voxel.voxel_grid import VoxelGrid
+    path = os.path.join(ROOT, 'tests', 'golden', 'f5_encoder_c2_digest.npz')
+    if not os.path.exists(path):
+        return None
+    g = np.load(path, allow_pickle=False)
+    if (V, depth, latents, HW) != (int(g['cfg_V']), int(g['cfg_depth']), int(g['cfg_latents']), int(g['cfg_H'])):
+        return None
+    T = lambda x: torch.from_numpy(np.asarray(x))       # noqa: E731
+    cams = synthetic.CAMERAS4[:int(g['cfg_ncam'])]
+    enc = PerceiverVoxelLangEncoder(depth=depth, iterations=1, voxel_size=V, initial_dim=10, low_dim_size=int(g['cfg_low_dim']),
+                                    num_latents=latents, voxel_patch_size=int(g['cfg_k']), voxel_patch_stride=int(g['cfg_s']),
+                                    activation='lrelu', input_dropout=0.0, attn_dropout=0.0, decoder_dropout=0.0)
+    enc.load_state_dict(synthetic.hashed_state_dict({n: tuple(p.shape) for n, p in enc.named_parameters()}, 0), strict=False)
+    enc = enc.to(dev)
+    rs = synthetic.make_replay_sample(1, cams, (HW, HW), V, int(g['cfg_low_dim']), seed=1)
+    rs = {k: (v[:, 0] if v.dim() > 2 else v) for k, v in rs.items()}
+    rs = {k: ((v.float() / 255.0) * 2.0 - 1.0 if 'rgb' in k else v.float()) for k, v in rs.items()}
+    vg = VoxelGrid(synthetic.SCENE_BOUNDS, V, dev, 1, 3, HW * HW * len(cams))
+    grid = vg.voxelize_cameras([rs['%s_point_cloud' % c].to(dev) for c in cams], [rs['%s_rgb' % c].to(dev) for c in cams])
+    occ = torch.nonzero((grid[..., -1] > 0).reshape(-1))[:, 0].int().cpu()
+    eng = enc.engine()
+    eng.precision = mode
+    outs, _ = eng.forward(grid, rs['low_dim_state'].to(dev), rs['lang_token_embs'].to(dev), training=False, save=False)
+    flat = outs[0].reshape(1, -1).float().cpu()
+    sidx = T(g['q_trans_sample_idx']).long()
+    res = {'what': 'engine forward in %s vs the reference digest tests/golden/f5_encoder_c2_digest.npz (V=%d, depth %d, %d latents, '
+                   'B=1, name-hashed weights): max abs error' % (mode, V, depth, latents),
+           'voxel_occupancy_bit_exact': bool(torch.equal(occ, T(g['grid_occ_flat']))),
+           'q_trans_argmax_equal': bool(torch.equal(flat.argmax(1), T(g['q_trans_argmax']))),
+           'q_trans_4096_samples': float((flat[:, sidx] - T(g['q_trans_sample'])).abs().max()),
+           'q_trans_top16': float((torch.gather(flat, 1, T(g['q_trans_top_idx']).long()) - T(g['q_trans_top_vals'])).abs().max()),
+           'q_trans_logsumexp': float((torch.logsumexp(flat.double(), 1) - T(g['q_trans_lse'])).abs().max()),
+           'rot_grip': float((outs[1].float().cpu() - T(g['rot_grip'])).abs().max()),
+           'collision': float((outs[2].float().cpu() - T(g['collision'])).abs().max()),
+           'q_trans_abs_max': float(flat.abs().max()), 'bound': 1e-4}
+    res['within_bound'] = bool(max(res[k] for k in ('q_trans_4096_samples', 'q_trans_top16', 'q_trans_logsumexp', 'rot_grip',
+                                                    'collision')) < 1e-4 and res['voxel_occupancy_bit_exact'])
+    del enc, eng, outs, grid
+    torch.cuda.empty_cache()
+    return res
+
+
 def cpu_baseline(a, cfg):
     """The oracle (CPU restatement of the reference path, kind 'port') timed on this host: ONE sample (B=1) of the same
     workload through voxelize + forward + losses + backward + LAMB; a B=16 step is 16x that."""
@@ -275,12 +369,19 @@ def cpu_baseline(a, cfg):
     bt = dict(pcd=[r['%s_point_cloud' % c] for c in cfg.rlbench.cameras], rgb=[r['%s_rgb' % c] for c in cfg.rlbench.cameras],
               proprio=r['low_dim_state'], lang_token_embs=r['lang_token_embs'], bounds=torch.tensor([synthetic.SCENE_BOUNDS]),
               trans=r['trans_action_indicies'], rot_grip=r['rot_grip_action_indicies'], ignore_collisions=r['ignore_collisions'])
+    from oracle import voxel_grid as ovox
+    t0 = time.perf_counter()
+    ovox.voxelize(*ovox.flatten_cameras(bt['pcd'], bt['rgb']), bt['bounds'], V)       # the voxelizer leg on its own
+    dt_vox = time.perf_counter() - t0
     t0 = time.perf_counter()
     oagent.train_steps(P, [bt], V, 1, depth=a.depth, voxel_patch_stride=s)
     dt = time.perf_counter() - t0
-    return {'value': 1.0 / (dt * a.batch), 'unit': 'steps/s', 'cores': ncores, 'kind': 'port',
+    return {'value': 1.0 / (dt * a.batch), 'unit': 'steps/s', 'cores': ncores, 'kind': 'port', 'extrapolated': True,
             'sample': 'one replay sample (B=1) of the same workload through the CPU oracle (voxelize + fwd + 6 CE + bwd + LAMB) '
-                      'took %.1f s; a B=%d step is %dx that' % (dt, a.batch, a.batch), 'seconds_per_sample': dt}
+                      'took %.1f s; `value` EXTRAPOLATES a B=%d step as %dx that (the B=%d autograd graph needs ~40 GB and minutes)'
+                      % (dt, a.batch, a.batch, a.batch),
+            'seconds_per_sample': dt, 'voxelize_seconds_per_sample': dt_vox,
+            'voxelize_note': 'scatter-mean voxelization of one sample (4 x 128 x 128 points -> %d^3 grid) on the same threads' % V}
 
 
 if __name__ == '__main__':

@@ -149,7 +149,7 @@ def enc_kw(cfg, arm=False):
     return dict(depth=cfg['depth'], voxel_patch_stride=cfg['s'], arm_pred_loss=arm)
 
 
-def encoder_fixture(name, cfg, arm=False, with_grads=True, digest=False, crop=False, check_oracle=True):
+def encoder_fixture(name, cfg, arm=False, with_grads=True, digest=False, crop=False, check_oracle=True, f64_grads=False):
     enc, sd = make_ref_encoder(cfg, arm)
     rs = batch_for(cfg, seed=1, arm=arm, crop=crop)
     pcd = [rs['%s_point_cloud' % c] for c in cfg['cams']]
@@ -163,6 +163,19 @@ def encoder_fixture(name, cfg, arm=False, with_grads=True, digest=False, crop=Fa
     t0 = time.time()
     for p in enc.parameters():
         p.requires_grad_(with_grads)
+    dy_sums = {}
+    hooks = []
+    if f64_grads and with_grads:
+        # bias gradients of the grid convs are sums of dY over up to 10^6 voxels per channel; the reference adds them up in
+        # fp32.  The same dY values added up in float64 (a backward hook on every conv output) separate the reference's own
+        # summation error from real differences.
+        def tap(name):
+            def fwd_hook(mod, inp, out):
+                out.register_hook(lambda gr: dy_sums.__setitem__(name, gr.double().sum(dim=(0, 2, 3, 4))))
+            return fwd_hook
+        for n, m in enc.named_modules():
+            if isinstance(m, torch.nn.Conv3d):
+                hooks.append(m.register_forward_hook(tap(n)))
     with torch.set_grad_enabled(with_grads):
         outs = enc(ins, rs['low_dim_state'], rs['lang_goal_emb'], rs['lang_token_embs'], None, bounds, None)
     print('%s: reference forward %.1fs' % (name, time.time() - t0))
@@ -212,6 +225,12 @@ def encoder_fixture(name, cfg, arm=False, with_grads=True, digest=False, crop=Fa
         for n, p in enc.named_parameters():
             if p.numel() <= 20000 and not n.startswith(('pos_encoding', 'latents')):
                 arrs['grad__' + n] = p.grad
+        for n, v in dy_sums.items():
+            arrs['dysum64__' + n + '.bias'] = v
+            print('%s: %s.bias  fp32-summed vs float64-summed dY: %.2e (max |grad| %.2e)' % (
+                name, n, float((dict(enc.named_parameters())[n + '.bias'].grad.double() - v).abs().max()), float(v.abs().max())))
+    for h in hooks:
+        h.remove()
     save(name, **arrs)
 
 
@@ -462,8 +481,8 @@ SECTIONS = {
     'f3tiny': lambda: encoder_fixture('f3_encoder_tiny', CFG_TINY, arm=True),
     'f3c1': lambda: encoder_fixture('f3_encoder_c1', CFG_C1),
     'f5': lambda: encoder_fixture('f5_encoder_c2_digest', CFG_C2, with_grads=False, digest=True),
-    'f5g': lambda: encoder_fixture('f5g_encoder_c2_grads', CFG_C2, with_grads=True, digest=True),
-    'f5c3': lambda: encoder_fixture('f5c3_encoder_c3_digest', CFG_C3, arm=True, with_grads=True, digest=True, crop=True),
+    'f5g': lambda: encoder_fixture('f5g_encoder_c2_grads', CFG_C2, with_grads=True, digest=True, f64_grads=True),
+    'f5c3': lambda: encoder_fixture('f5c3_encoder_c3_digest', CFG_C3, arm=True, with_grads=True, digest=True, crop=True, f64_grads=True),
     'f5v200': lambda: encoder_fixture('f5v200_encoder_c5_digest', CFG_C5, with_grads=False, digest=True),
     'f6': f6_update_traces,
     'f9': f9_act,

@@ -100,8 +100,22 @@ def _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, tag):
     bad, worst = [], 0.0
     for n, rn in zip([str(n) for n in g['grad_names']], T(g['grad_norms'])):
         gn, rn = float(P[n].grad.norm()), float(rn)
+        key64 = 'dysum64__' + n
+        if key64 in g.files:
+            # bias of a grid conv = sum of dY over up to 10^6 voxels per channel.  The fixture also holds the reference's dY
+            # added up in FLOAT64 (a backward hook in make_golden.py); the reference's own fp32 sum is off from that by
+            # 5.8e-3 (final), 4.4e-3 (up0.conv_up.2), 1.2e-3 (input_preprocess) at this size, and its trans_decoder bias
+            # gradient (mathematically sum(softmax - onehot) = 0) is 5.9e-5 of pure rounding noise -- so the float64 sums
+            # are the yardstick for these six tensors, not the fp32 ones
+            ref = T(g[key64])
+            e = float((P[n].grad.double().cpu() - ref).abs().max())
+            ref32 = float((T(g['grad__' + n]).double() - ref).abs().max()) if ('grad__' + n) in g.files else float('nan')
+            print('   %-34s |ours - f64 sum| %.2e   |reference fp32 - f64 sum| %.2e   (max |grad| %.2e)' % (n, e, ref32, float(ref.abs().max())))
+            if e > 2e-3 * float(ref.abs().max()) + 2e-5:
+                bad.append((n, 'vs float64 dY sum', e, float(ref.abs().max())))
+            continue
         rel = abs(gn - rn) / (rn + 1e-12)
-        if abs(gn - rn) > 3e-3 * rn + 1e-5:          # + 1e-5: gradients that are mathematically zero (trans_decoder bias)
+        if abs(gn - rn) > 3e-3 * rn + 1e-5:
             bad.append((n, gn, rn))
         elif rn > 1e-4:
             worst = max(worst, rel)
@@ -109,12 +123,7 @@ def _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, tag):
         if key in g.files:
             ref = T(g[key])
             e = float((P[n].grad.float().cpu() - ref).abs().max())
-            # the tensors stored in full are mostly conv biases: sums of dY over 10^6 voxels per channel.  A forward difference
-            # of 1e-6 flips the LeakyReLU mask of the ~1e-5 fraction of pre-activations that sit that close to zero, and each
-            # flip moves one term of such a sum by its full size: 0.4-0.9 % of the largest entry at this size (measured, both
-            # precisions) against 0.3 % at the small sizes of tests/test_encoder_gpu.py.  Entries that are mathematically
-            # zero (trans_decoder bias: sum(softmax - onehot)) are rounding noise of ~6e-5 on both sides.
-            if e > 1.5e-2 * float(ref.abs().max()) + 2e-4:
+            if e > 3e-3 * float(ref.abs().max()) + 1e-5:
                 bad.append((n, 'full', e, float(ref.abs().max())))
     print('%s: loss %.6f (reference %.6f), worst grad-norm rel. error %.2e' % (tag, loss, float(g['loss']), worst))
     assert not bad, (tag, bad)

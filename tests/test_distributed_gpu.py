@@ -1,0 +1,102 @@
+"""GPU, two ranks on ONE device over gloo (RCCL refuses two ranks per GPU; the code path is the same `torch.distributed`
+calls the 8-GPU run makes with backend "nccl"): the real `update()` step under data parallelism.
+
+  (a) ranks that initialise their networks from DIFFERENT seeds hold bit-identical weights after build() (rank 0's are
+      broadcast, as DistributedDataParallel does when it wraps the module, reference agent :50-54) and after two update()s
+      on different shards;
+  (b) the exchanged gradient equals the gradient of ONE process on the concatenated batch (loss = mean over the global batch,
+      agent :578), and so does the LAMB step taken from it;
+  (c) every bucket of the overlapped exchange is reduced exactly once per step.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(method__voxel_sizes=[16], method__voxel_patch_size=3, method__voxel_patch_stride=4, method__transformer_depth=2,
+           method__num_latents=32, method__input_dropout=0.0, method__attn_dropout=0.0,
+           rlbench__cameras=['front', 'wrist'], rlbench__camera_resolution=[16, 16])
+B = 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_agent(batch, seed):
+    from voxactb_amd.agents.peract_bc import launch_utils as lu
+    cfg = lu.default_cfg(replay__batch_size=batch, **CFG)
+    cfg.method.transform_augmentation.apply_se3 = False
+    torch.manual_seed(seed)
+    agent = lu.create_agent(cfg)
+    agent.build(training=True, device=0)
+    return agent, agent._pose_agent._qattention_agents[0]
+
+
+def _shard(rank):
+    from voxactb_amd import synthetic
+    return synthetic.make_replay_sample(B, CFG['rlbench__cameras'], (16, 16), 16, 4, seed=50 + rank)
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    agent, qa = _make_agent(B, seed=1000 + 17 * rank)              # a different initialisation on every rank
+    w_build = qa._arena.flat_w.clone()
+    calls = []
+    orig = qa._arena.reduce_bucket
+    qa._arena.reduce_bucket = lambda name: (calls.append(name), orig(name))[1]
+    losses = []
+    grads = None
+    for step in range(2):
+        rs = {k: v.to('cuda:0') for k, v in _shard(rank if step == 0 else 1 - rank).items()}
+        losses.append(float(agent.update(step, rs)['total_losses']))
+        if step == 0:
+            grads = qa._arena.flat_g.clone()
+            w_step0 = qa._arena.flat_w.clone()
+    torch.save(dict(w_build=w_build.cpu(), w_step0=w_step0.cpu(), w_final=qa._arena.flat_w.cpu(), grads=grads.cpu(), losses=losses,
+                    calls=calls, buckets=list(qa._arena._buckets)), os.path.join(out_dir, 'rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_update_matches_one_process_on_the_concatenated_batch(tmp_path):
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), 'rank%d.pt' % r)) for r in range(world))
+    # (a) one model: identical after build (although the ranks seeded differently) and after every step
+    assert torch.equal(r0['w_build'], r1['w_build'])
+    assert torch.equal(r0['w_step0'], r1['w_step0']) and torch.equal(r0['w_final'], r1['w_final'])
+    assert torch.equal(r0['grads'], r1['grads'])                    # the summed gradient is the same tensor on both ranks
+    assert not torch.equal(r0['w_build'], r0['w_final'])
+    # (c) every bucket once per step, backward order: tail, layers high -> low, head
+    assert r0['calls'] == r0['buckets'] * 2 and r0['buckets'][0] == 'tail' and r0['buckets'][-1] == 'head'
+    # (b) one process, global batch = the two shards concatenated, starting from the broadcast weights
+    agent, qa = _make_agent(2 * B, seed=1)
+    qa._arena.flat_w.copy_(r0['w_build'].to('cuda:0'))
+    s0, s1 = _shard(0), _shard(1)
+    rs = {k: torch.cat([s0[k], s1[k]], 0).to('cuda:0') for k in s0}
+    loss = float(agent.update(0, rs)['total_losses'])
+    g1 = qa._arena.flat_g.cpu()
+    den = float(g1.abs().max())
+    assert float((g1 - r0['grads']).abs().max()) < 2e-5 * den + 1e-7, (float((g1 - r0['grads']).abs().max()), den)
+    assert abs(loss - 0.5 * (r0['losses'][0] + r1['losses'][0])) < 1e-5          # mean over the global batch
+    dw = (qa._arena.flat_w.cpu() - r0['w_step0']).abs().max()
+    assert float(dw) < 5e-6, float(dw)

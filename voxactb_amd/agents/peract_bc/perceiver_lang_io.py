@@ -258,6 +258,7 @@ class PerceiverEngine:
             self.kl = 2 * self.R + 1
             self._Lt_host = Lt
         self._Lt = None
+        self._on_bucket = None
         self.step_seed = 0
         # Precision of the matrix-core kernels (tensors, accumulators, softmax / norm statistics are fp32 in every mode):
         #   'bf16x3' (default): every fp32 operand is used as hi + lo bf16 halves, three bf16 MFMAs per product
@@ -505,10 +506,22 @@ class PerceiverEngine:
         return outs, (c if save else None)
 
     # -------------------------------------------------------------------------------------------------- backward
-    def backward(self, c, dq_trans, d_o, d_arm=None):
+    # parameter-name prefixes of the gradient-exchange buckets, in the order the backward pass completes them (= from the end of
+    # the module's registration order towards its start, so every bucket is one contiguous slice of the flat gradient buffer)
+    def grad_buckets(self):
+        out = [('tail', ['decoder_cross_attn.', 'up0.', 'final.', 'trans_decoder.', 'dense0.', 'dense1.',
+                         'rot_grip_collision_ff.', 'dense2.', 'arm_ff.'])]
+        out += [('layers.%d' % i, ['layers.%d.' % i]) for i in reversed(range(self.m.depth))]
+        out.append(('head', ['pos_encoding', 'latents', 'input_preprocess.', 'patchify.', 'lang_preprocess.',
+                             'proprio_preprocess.', 'cross_attend_blocks.']))
+        return out
+
+    def backward(self, c, dq_trans, d_o, d_arm=None, on_bucket_ready=None):
         """dq_trans [B,V,V,V] (or [B,1,V,V,V]), d_o [B, 3*rot+grip+coll] (grad of the concatenated MLP head output),
-        d_arm [B,2] or None.  Accumulates into every parameter's .grad."""
+        d_arm [B,2] or None.  Accumulates into every parameter's .grad.  `on_bucket_ready(name)` is called as soon as the
+        last kernel that writes gradients of bucket `name` (see grad_buckets) has been enqueued."""
         ops.PRECISION = self.precision
+        self._on_bucket = on_bucket_ready
         try:
             return self._backward(c, dq_trans, d_o, d_arm)
         finally:
@@ -622,6 +635,7 @@ class PerceiverEngine:
                                  self.g(pre + '.norm.bias'))
         dx = ops.layernorm_bwd(dln, dc['x'], self.p(pre + '.norm_context.weight'), dc['lm'], dc['lr'],
                                self.g(pre + '.norm_context.weight'), self.g(pre + '.norm_context.bias'))
+        self._bucket_ready('tail')                  # heads, trans_decoder, final, up0, decoder cross attention: complete
         # ---- self-attention stack, reversed
         for i in reversed(range(m.depth)):
             lc = c['layers'][i]
@@ -630,6 +644,7 @@ class PerceiverEngine:
             dxn, _ = self._attn_bwd(pre, lc['attn'], dx, lc['xn'], lc['xn'], True)
             ops.layernorm_bwd(dxn, lc['x'], self.p(pre + '.norm.weight'), lc['xm'], lc['xr'], self.g(pre + '.norm.weight'),
                               self.g(pre + '.norm.bias'), dx=dx, accumulate_dx=True)
+            self._bucket_ready('layers.%d' % i)
         # ---- cross-attention block
         dx = self._ff_bwd('cross_attend_blocks.1', c['cross_ff'], dx)
         cc = c['cross']
@@ -664,3 +679,8 @@ class PerceiverEngine:
         # ---- input conv (its LeakyReLU' is applied inside the weight-gradient kernel)
         ops.pointwise_wgrad(c['vox'], d0, dd0, self.g('input_preprocess.conv3d.weight').view(C, -1),
                             self.g('input_preprocess.conv3d.bias'))
+        self._bucket_ready('head')
+
+    def _bucket_ready(self, name):
+        if self._on_bucket is not None:
+            self._on_bucket(name)

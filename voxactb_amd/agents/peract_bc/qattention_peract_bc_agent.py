@@ -190,6 +190,14 @@ class QAttentionPerActBCAgent(Agent):
         if self._training:
             self._arena = FlatParams(self._q, dev)
             self._arena.broadcast_weights(0)            # DDP's wrap-time parameter broadcast (agent :50-54)
+            # gradient-exchange buckets: slices of the flat gradient buffer in the order backward completes them
+            shim = '_qnet.module.'
+            for bname, prefixes in self._q.encoder.engine().grad_buckets():
+                present = [shim + p for p in prefixes if any(n.startswith(shim + p) for n in self._arena.names)]
+                if present:
+                    self._arena.bucket(bname, present)
+            if not self._arena.buckets_cover_everything():
+                raise VoxactbHipError('gradient buckets do not tile the parameter arena')
             if self._optimizer_type == 'lamb':
                 self._optimizer = Lamb(self._q.parameters(), lr=self._lr, weight_decay=self._lambda_weight_l2,
                                        betas=(0.9, 0.999), adam=False)
@@ -334,8 +342,10 @@ class QAttentionPerActBCAgent(Agent):
 
         # backward + exchange + optimizer (agent :580-582)
         self._arena.zero_grad()
-        eng.backward(cache, dq, d_o, d_arm)
-        self._arena.all_reduce_grads()
+        # every bucket's all-reduce (RCCL over xGMI) starts the moment backward has enqueued its last gradient kernel and runs
+        # next to the rest of the backward pass; the optimizer waits for all of them (DDP's bucketed overlap, agent :50-54)
+        eng.backward(cache, dq, d_o, d_arm, on_bucket_ready=self._arena.reduce_bucket)
+        self._arena.finish_reduce()
         self._optimizer.step()
 
         coords = torch.stack([torch.div(torch.div(amax, V, rounding_mode='trunc'), V, rounding_mode='trunc'),

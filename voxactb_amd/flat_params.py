@@ -2,8 +2,16 @@
 
 The reference lets DDP bucket 118 gradient tensors (25 MB buckets over gloo, qattention_peract_bc_agent.py:50-54)
 and LAMB loop over them one by one.  Here every Parameter's `.data` and `.grad` are views into two flat buffers, so
-the data-parallel exchange is ONE in-place RCCL all-reduce over xGMI and the optimizer is one fused launch.
-`named_parameters()`, `state_dict()`, `load_state_dict()`, `param.grad` (update_summaries, agent :814-821) keep working.
+the data-parallel exchange is a handful of in-place RCCL all-reduces over contiguous slices of ONE buffer and the
+optimizer is one fused launch.  `named_parameters()`, `state_dict()`, `load_state_dict()`, `param.grad`
+(update_summaries, agent :814-821) keep working.
+
+Overlap with the backward pass: the arena follows the module's registration order, and the backward pass finishes
+gradients from the END of that order towards its start (heads, decoder, the self-attention layers 5 .. 0, then the
+input side).  `bucket(prefixes)` names a contiguous slice by parameter-name prefixes; the engine calls
+`reduce_bucket(name)` as soon as the last kernel writing into that slice has been enqueued, which starts an
+asynchronous all-reduce (RCCL runs it on its own stream behind an event on the compute stream) while the backward
+pass continues; `finish_reduce()` makes the compute stream wait for all of them before the optimizer.
 """
 import torch
 
@@ -29,8 +37,58 @@ class FlatParams:
             self.segments.append((off, n))
         self.total = total
 
+        self._buckets = {}
+        self._pending = []
+        self._done = set()
+
     def zero_grad(self):
         self.flat_g.zero_()
+        self._done.clear()
+
+    # ------------------------------------------------------------------ buckets of the gradient exchange
+    def bucket(self, name, prefixes):
+        """Declare the slice of the flat buffers that holds every parameter whose name starts with one of `prefixes`
+        (must be contiguous in registration order).  Returns (first float, end float)."""
+        idx = [i for i, n in enumerate(self.names) if n.startswith(tuple(prefixes))]
+        if not idx:
+            raise ValueError('no parameter matches %r' % (prefixes,))
+        if idx != list(range(idx[0], idx[-1] + 1)):
+            raise ValueError('parameters matching %r are not contiguous in the arena' % (prefixes,))
+        lo = self.segments[idx[0]][0]
+        hi = self.total if idx[-1] + 1 == len(self.segments) else self.segments[idx[-1] + 1][0]
+        self._buckets[name] = (lo, hi)
+        return lo, hi
+
+    def buckets_cover_everything(self):
+        spans = sorted(self._buckets.values())
+        return bool(spans) and spans[0][0] == 0 and spans[-1][1] == self.total and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+    @staticmethod
+    def _world():
+        import torch.distributed as dist
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def reduce_bucket(self, name):
+        """Start the sum over ranks of one bucket (no-op for a single rank).  The 1/world factor is folded into the loss
+        scale, see QAttentionPerActBCAgent.update."""
+        if name in self._done:
+            raise RuntimeError('bucket %r reduced twice in one step' % name)
+        self._done.add(name)
+        if self._world() > 1:
+            import torch.distributed as dist
+            lo, hi = self._buckets[name]
+            self._pending.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish_reduce(self):
+        """Every bucket that has not been started yet goes out now; then the compute stream waits for all of them."""
+        for name in self._buckets:
+            if name not in self._done:
+                self.reduce_bucket(name)
+        if not self._buckets:
+            self.all_reduce_grads()
+        for w in self._pending:
+            w.wait()
+        self._pending = []
 
     def broadcast_weights(self, src=0):
         """Rank `src`'s parameters to every rank -- what DistributedDataParallel does implicitly when it wraps the module

@@ -62,7 +62,7 @@ def synthetic_point_cloud(g, B, H, W, bounds):
 
 def make_replay_sample(batch_size=16, cameras=CAMERAS4, image_size=(128, 128), voxel_size=100,
                        low_dim_size=4, seed=0, scene_bounds=SCENE_BOUNDS, arm_pred_loss=False,
-                       crop_target_obj_voxel=False, crop_radius=0.3, n_depths=1):
+                       crop_target_obj_voxel=False, crop_radius=0.3, n_depths=1, keyframes_near_target=False):
     """dict[str -> torch tensor (B,1,...)] as handed to PreprocessAgent.update()."""
     B = batch_size
     H, W = image_size
@@ -94,6 +94,13 @@ def make_replay_sample(batch_size=16, cameras=CAMERAS4, image_size=(128, 128), v
         out['label'] = torch.from_numpy(g.integers(0, 2, (B, 1, 1)).astype(np.int32))
     if crop_target_obj_voxel:
         c = lo + g.uniform(0.35, 0.65, (B, 3)).astype(np.float32) * (hi - lo)
+        if keyframes_near_target:
+            # one task: the target object sits at about the same place in every sample and the keyframe gripper poses are
+            # within 10 cm of it -- what the SE(3) augmentation needs to succeed under crop bounds (it discretises EVERY
+            # sample with the first sample's bounds, reference augmentation.py:161-162)
+            c = (c[:1] + g.uniform(-0.05, 0.05, (B, 3))).astype(np.float32)
+            pos = (c + g.uniform(-0.1, 0.1, (B, 3))).astype(np.float32)
+            out['gripper_pose'] = torch.from_numpy(np.concatenate([pos, q], 1)).unsqueeze(1)
         tb = np.concatenate([c - crop_radius, c + crop_radius], 1).astype(np.float32)
         out['target_object_scene_bounds'] = torch.from_numpy(tb).unsqueeze(1)
     out['action'] = torch.zeros(B, 1, 8)
@@ -103,3 +110,66 @@ def make_replay_sample(batch_size=16, cameras=CAMERAS4, image_size=(128, 128), v
     out['indices'] = torch.arange(B, dtype=torch.int32).unsqueeze(1)
     out['demo'] = torch.ones(B, dtype=torch.bool)
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Name-hashed parameter generator: fixtures cannot ship 133 MB of weights, so the fixture generator (which loads them into
+# the REFERENCE module), the tests and bench.py's reference-digest check derive every tensor from (parameter name, seed)
+# with numpy's Philox counter RNG.  Magnitudes follow the reference's init families so activations stay O(1)
+# (perceiver_lang_io.py:197-205,234; network_utils.py:140-154,263-276): conv / dense with lrelu: kaiming-uniform bound
+# sqrt(6 / ((1 + a^2) fan_in)); plain nn.Linear: 1 / sqrt(fan_in); LayerNorm: weight 1 + 0.1 u, bias 0.1 u (perturbed on
+# purpose so the affine paths are exercised); biases: small non-zero values; latents / pos_encoding: N(0, 1).
+# ----------------------------------------------------------------------------------------------------------------------
+LRELU_SLOPE = 0.02  # network_utils.py:12
+
+
+def _hrng(name: str, seed: int):
+    key = zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1 & 0xFFFFFFFF)
+    return np.random.Generator(np.random.Philox(key=key))
+
+def hashed_tensor(name: str, shape, seed: int = 0) -> torch.Tensor:
+    shape = tuple(int(s) for s in shape)
+    g = _hrng(name, seed)
+    n = int(np.prod(shape)) if len(shape) else 1
+    leaf = name.split('.')[-1]
+    if name in ('latents', 'pos_encoding'):
+        a = g.standard_normal(n)
+    elif '.norm' in name or name.startswith('norm'):
+        u = g.uniform(-1.0, 1.0, n)
+        a = (1.0 + 0.1 * u) if leaf == 'weight' else 0.1 * u
+    elif leaf == 'weight':
+        fan_in = int(np.prod(shape[1:]))
+        if 'conv3d' in name or name.endswith('linear.weight'):
+            bound = np.sqrt(6.0 / ((1.0 + LRELU_SLOPE ** 2) * fan_in))
+        else:
+            bound = 1.0 / np.sqrt(fan_in)
+        a = g.uniform(-bound, bound, n)
+    elif leaf == 'bias':
+        a = 0.05 * g.uniform(-1.0, 1.0, n)
+    else:
+        a = g.uniform(-1.0, 1.0, n)
+    return torch.from_numpy(a.astype(np.float32).reshape(shape))
+
+
+def hashed_state_dict(shapes: dict, seed: int = 0) -> dict:
+    """shapes: {param_name: shape}.  Returns {param_name: fp32 tensor}."""
+    return {k: hashed_tensor(k, v, seed) for k, v in shapes.items()}
+
+
+def hashed_uniform(name: str, shape, lo=0.0, hi=1.0, seed: int = 0) -> torch.Tensor:
+    g = _hrng('u:' + name, seed)
+    a = g.uniform(lo, hi, int(np.prod(shape)))
+    return torch.from_numpy(a.astype(np.float32).reshape(tuple(shape)))
+
+
+def hashed_normal(name: str, shape, seed: int = 0) -> torch.Tensor:
+    g = _hrng('n:' + name, seed)
+    a = g.standard_normal(int(np.prod(shape)))
+    return torch.from_numpy(a.astype(np.float32).reshape(tuple(shape)))
+
+
+def hashed_int(name: str, shape, lo: int, hi: int, seed: int = 0) -> torch.Tensor:
+    """integers in [lo, hi)."""
+    g = _hrng('i:' + name, seed)
+    a = g.integers(lo, hi, int(np.prod(shape)))
+    return torch.from_numpy(a.astype(np.int64).reshape(tuple(shape)))
