@@ -33,6 +33,9 @@ def _free_port():
 
 
 def _make_agent(batch, seed):
+    # exact-fp32 matrix cores: two batch compositions then differ by summation order only (~1e-6); the default bf16x3
+    # split products add ~1e-4 of the largest gradient entry, which would blur check (b)
+    os.environ['VOXACTB_PRECISION'] = 'fp32'
     from voxactb_amd.agents.peract_bc import launch_utils as lu
     cfg = lu.default_cfg(replay__batch_size=batch, **CFG)
     cfg.method.transform_augmentation.apply_se3 = False
@@ -71,7 +74,8 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_update_matches_one_process_on_the_concatenated_batch(tmp_path):
+def test_two_rank_update_matches_one_process_on_the_concatenated_batch(tmp_path, monkeypatch):
+    monkeypatch.setenv('VOXACTB_PRECISION', 'fp32')
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]

@@ -1,0 +1,207 @@
+"""CPU: the shard replay store (voxactb_amd/replay.py) -- add / add_final / task-uniform sampling semantics of yarr's
+TaskUniformReplayBuffer as PerAct configures it (uniform_replay_buffer.py:322-386, :639-756; task_uniform_replay_buffer.py:
+66-131), in RAM and memory-mapped, and the launch_utils call sequence of run_seed_fn.py:107-129 against stub demos."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from voxactb_amd import replay as R
+from voxactb_amd.agents import peract_bc
+
+
+def _buffer(save_dir=None, rank=0, world=1, batch=4):
+    obs = [R.ObservationElement('low_dim_state', (4,), np.float32), R.ObservationElement('front_rgb', (3, 4, 4), np.float32),
+           R.ReplayElement('trans_action_indicies', (3,), np.int32), R.ReplayElement('task', (), str)]
+    return R.ShardReplayBuffer(batch_size=batch, timesteps=1, replay_capacity=1000, action_shape=(8,), action_dtype=np.float32,
+                               observation_elements=obs, extra_replay_elements=[R.ReplayElement('demo', (), bool)], save_dir=save_dir, rank=rank, num_replicas=world, rows_per_shard=7)
+
+
+def _fill(buf, tasks=('open_jar', 'open_drawer'), episodes=3, steps=4):
+    rows = {}
+    n = 0
+    for ti, task in enumerate(tasks):
+        for ep in range(episodes):
+            for k in range(steps):
+                val = 100 * ti + 10 * ep + k
+                buf.add(np.full(8, val, np.float32), 1.0 if k == steps - 1 else 0.0, k == steps - 1, False,
+                        low_dim_state=np.full(4, val, np.float32), front_rgb=np.full((3, 4, 4), val, np.float32),
+                        trans_action_indicies=np.array([val, val + 1, val + 2], np.int32), demo=True, task=task)
+                rows.setdefault(task, []).append(n)
+                n += 1
+            buf.add_final(low_dim_state=np.full(4, 100 * ti + 10 * ep + steps, np.float32),
+                          front_rgb=np.full((3, 4, 4), 100 * ti + 10 * ep + steps, np.float32),
+                          trans_action_indicies=np.zeros(3, np.int32), task=task)
+            rows[task].append(-n)                # the final observation is a row of the task's list too (upstream `_add` registers
+            n += 1                               # every row), it only never comes out of the sampler
+    return rows
+
+
+@pytest.mark.parametrize('disk', [False, True])
+def test_add_sample_semantics(tmp_path, disk):
+    buf = _buffer(str(tmp_path / 'replay') if disk else None)
+    _fill(buf)
+    buf.seed(0)
+    assert int(buf.add_count) == 2 * 3 * 5 and not buf.is_empty() and not buf.is_full()
+    seen_tasks = set()
+    for _ in range(30):
+        b = buf.sample_transition_batch()
+        assert 'task' not in b and 'task_tp1' not in b and set(b) >= {'action', 'reward', 'terminal', 'timeout', 'indices', 'low_dim_state',
+                                               'low_dim_state_tp1', 'front_rgb', 'front_rgb_tp1', 'trans_action_indicies', 'demo'}
+        assert b['front_rgb'].shape == (4, 1, 3, 4, 4) and b['action'].shape == (4, 1, 8) and b['demo'].shape == (4,)
+        assert b['terminal'].dtype == np.int8 and b['indices'].dtype == np.int32 and b['trans_action_indicies'].dtype == np.int32
+        v = b['low_dim_state'][:, 0, 0]
+        # every element of a transition comes from the same row; its _tp1 twin from the next row (also across the episode end,
+        # where the next row is the add_final observation)
+        assert np.array_equal(b['action'][:, 0, 0], v) and np.array_equal(b['front_rgb'][:, 0, 0, 0, 0], v)
+        assert np.array_equal(b['low_dim_state_tp1'][:, 0, 0], v + 1)
+        assert np.array_equal(b['terminal'][:, 0], (v % 10 == 3).astype(np.int8)) and np.array_equal(b['reward'][:, 0], (v % 10 == 3))
+        assert np.all(v % 10 != 4)                                   # the final observations are never sampled as transitions
+        seen_tasks |= set((v // 100).astype(int).tolist())
+    assert seen_tasks == {0, 1}
+    if disk:
+        files = sorted(os.listdir(str(tmp_path / 'replay')))
+        assert 'front_rgb.00000.bin' in files and not any(f.endswith('.replay') for f in files)      # binary columns, no pickles
+        buf.shutdown()
+        assert os.listdir(str(tmp_path / 'replay')) == []
+
+
+def test_rank_stride_of_every_task_and_uniform_tasks():
+    bufs = [_buffer(rank=r, world=2, batch=64) for r in range(2)]
+    rows = None
+    for b in bufs:
+        rows = _fill(b)
+        b.seed(5 + b._rank)
+    got = [set(), set()]
+    counts = np.zeros(2)
+    for _ in range(20):
+        for r, b in enumerate(bufs):
+            idx = b.sample_transition_batch()['indices'][:, 0]
+            got[r] |= set(idx.tolist())
+            counts += np.bincount((np.asarray(idx) >= 15).astype(int), minlength=2)
+    for r in range(2):                                                 # task_idxs[task][rank::world], terminal = -1 rows excluded
+        allowed = set()
+        for task_rows in rows.values():
+            allowed |= set(x for x in task_rows[r::2] if x >= 0)
+        assert got[r] <= allowed and len(got[r]) >= len(allowed) - 1
+    assert got[0].isdisjoint(got[1])
+    assert abs(counts[0] - counts[1]) < 0.15 * counts.sum()            # tasks drawn uniformly
+
+
+def test_errors():
+    buf = _buffer()
+    with pytest.raises(RuntimeError):
+        buf.sample_transition_batch()
+    with pytest.raises(ValueError):
+        buf.add(np.zeros(8, np.float32), 0.0, False, False, low_dim_state=np.zeros(5, np.float32), front_rgb=np.zeros((3, 4, 4), np.float32),
+                trans_action_indicies=np.zeros(3, np.int32), demo=True, task='t')
+    with pytest.raises(NotImplementedError):
+        R.ShardReplayBuffer(timesteps=2, rank=0, num_replicas=1)
+
+
+# ------------------------------------------------------------------------------------------------ drop-in call sequence
+class _Obs(SimpleNamespace):
+    pass
+
+
+def _demo(n=12, side='right'):
+    g = np.random.default_rng(0)
+    obs = []
+    for i in range(n):
+        q = g.standard_normal(4)
+        q /= np.linalg.norm(q)
+        pose = np.concatenate([np.array([0.2, 0.0, 1.1]) + 0.05 * g.standard_normal(3), q])
+        o = _Obs(ignore_collisions=float(i % 2), misc={'descriptions': ['open the jar']}, auto_crop_radius=0.0,
+                 target_object_pos=np.array([0.2, 0.0, 1.0]), index=i)
+        setattr(o, 'gripper_%s_pose' % side, pose)
+        setattr(o, 'gripper_%s_open' % side, float(i % 3 != 0))
+        obs.append(o)
+    return SimpleNamespace(_observations=obs, __getitem__=None, obs=obs)
+
+
+class _Demo(list):
+    @property
+    def _observations(self):
+        return list(self)
+
+
+def test_run_seed_call_sequence_with_stub_demos(tmp_path):
+    """`peract_bc.launch_utils.create_replay` -> `fill_multi_task_replay` -> `create_agent` exactly as run_seed_fn.py:107-129
+    calls them, with the simulator-side pieces (stored demos, keypoints, observation extraction, CLIP) injected."""
+    lu = peract_bc.launch_utils
+    cams, V, HW = ['front', 'wrist'], 16, 8
+    cfg = lu.default_cfg(method__voxel_sizes=[V], method__voxel_patch_size=3, method__voxel_patch_stride=4, method__transformer_depth=1,
+                         method__num_latents=16, rlbench__cameras=cams, rlbench__camera_resolution=[HW, HW], replay__batch_size=3)
+    cfg.method.keypoint_discovery_no_duplicate = False
+    cfg.method.saved_every_last_inserted = 0
+    cfg.method.use_default_stopped_buffer_timesteps = True
+    cfg.method.stopped_buffer_timesteps_overwrite = 0
+    cfg.method.crop_radius = 0.0
+    cfg.method.is_real_robot = False
+    cfg.method.demo_augmentation, cfg.method.demo_augmentation_every_n = True, 5
+    cfg.method.crop_augmentation, cfg.method.keypoint_method = True, 'heuristic'
+    cfg.rlbench.demo_path, cfg.rlbench.episode_length, cfg.rlbench.demos, cfg.rlbench.tasks = 'unused', 10, 2, ['open_jar', 'open_drawer']
+    cfg.framework.logging_level = 20
+    cfg.replay.timesteps, cfg.replay.prioritisation, cfg.replay.task_uniform, cfg.replay.use_disk = 1, False, True, True
+    cfg.replay.max_parallel_processes = 1
+    cfg.ddp.cpu = True
+    demos = {d: _Demo(_demo(12).obs) for d in range(2)}
+
+    def get_stored_demos(amount, image_paths, dataset_root, variation_number, task_name, obs_config, random_selection,
+                         from_episode_number, which_arm):
+        return [demos[from_episode_number]]
+
+    def keypoint_discovery(demo, which_arm='right', method='heuristic', saved_every_last_inserted=0):
+        return [3, 7, 11]
+
+    def extract_obs(obs, t, cameras, episode_length, which_arm):
+        d = {'low_dim_state': np.full(4, obs.index, np.float32),
+             'ignore_collisions': np.array([obs.ignore_collisions], dtype=np.float32)}     # (helpers/utils.py:595)
+        for c in cameras:
+            d['%s_rgb' % c] = np.full((3, HW, HW), obs.index, np.float32)
+            d['%s_point_cloud' % c] = np.full((3, HW, HW), 0.5, np.float32)
+            d['%s_camera_extrinsics' % c] = np.eye(4, dtype=np.float32)
+            d['%s_camera_intrinsics' % c] = np.eye(3, dtype=np.float32)
+        return d
+
+    class Clip:
+        def encode_text_with_embeddings(self, tokens):
+            return torch.ones(1, 1024), torch.ones(1, 77, 512)
+
+    lu.set_upstream(get_stored_demos=get_stored_demos, keypoint_discovery=keypoint_discovery, extract_obs=extract_obs,
+                    tokenize=lambda texts: np.zeros((1, 77), np.int64))
+    replay_path = str(tmp_path / 'replay')
+    replay_buffer = lu.create_replay(cfg.replay.batch_size, cfg.replay.timesteps, cfg.replay.prioritisation, cfg.replay.task_uniform,
+                                     replay_path if cfg.replay.use_disk else None, cams, cfg.method.voxel_sizes,
+                                     cfg.rlbench.camera_resolution, which_arm=cfg.method.which_arm,
+                                     crop_target_obj_voxel=cfg.method.crop_target_obj_voxel, arm_pred_loss=cfg.method.arm_pred_loss,
+                                     arm_id_to_proprio=cfg.method.arm_id_to_proprio)
+    lu.fill_multi_task_replay(cfg, None, 0, replay_buffer, cfg.rlbench.tasks, cfg.rlbench.demos, cfg.method.demo_augmentation,
+                              cfg.method.demo_augmentation_every_n, cams, cfg.rlbench.scene_bounds, cfg.method.voxel_sizes,
+                              cfg.method.bounds_offset, cfg.method.rotation_resolution, cfg.method.crop_augmentation,
+                              clip_model=Clip(), keypoint_method=cfg.method.keypoint_method)
+    # per demo: start points i = 0, 5, 10 -> keyframes left (3, 7, 11), (7, 11), (11) -> 6 transitions + 3 finals
+    assert int(replay_buffer.add_count) == 2 * 2 * 9
+    agent = lu.create_agent(cfg)
+    assert type(agent).__name__ == 'PreprocessAgent'
+    wrapped = R.BatchStreamReplayBuffer(replay_buffer, num_workers=0)
+    batch = next(iter(wrapped.dataset()))
+    for name, shape, dt in lu.replay_schema(cams, [V], (HW, HW)):
+        if name in ('task', 'lang_goal'):
+            assert name not in batch
+            continue
+        assert tuple(batch[name].shape) == (3, 1) + tuple(shape), name
+        assert tuple(batch[name + '_tp1'].shape) == (3, 1) + tuple(shape), name      # every observation element has its twin
+    # labels are the discretised keyframe poses (helpers/rotation.py), keyframe 3 / 7 / 11 of demo 0
+    from voxactb_amd.helpers import rotation
+    o = demos[0][3]
+    want_t = rotation.point_to_voxel_index(o.gripper_right_pose[:3], V, np.array(cfg.rlbench.scene_bounds))
+    q = rotation.normalize_quaternion(o.gripper_right_pose[3:])
+    want_r = rotation.quaternion_to_discrete_euler(q if q[-1] >= 0 else -q, 5).tolist() + [int(o.gripper_right_open)]
+    first = replay_buffer.sample_transition_batch(1, indices=[0])
+    assert first['trans_action_indicies'][0, 0].tolist() == want_t.tolist()
+    assert first['rot_grip_action_indicies'][0, 0].tolist() == want_r
+    assert first['front_rgb'][0, 0, 0, 0, 0] == 0 and first['front_rgb_tp1'][0, 0, 0, 0, 0] == 3      # obs at the start point, tp1 = keyframe
+    replay_buffer.shutdown()

@@ -86,24 +86,20 @@ def create_replay(batch_size, timesteps, prioritisation, task_uniform, save_dir,
                   arm_pred_loss=False, arm_id_to_proprio=False):
     if which_arm == 'both':
         raise NotImplementedError("which_arm='both' belongs to the one_policy_more_heads baseline (SURVEY.md a25)")
-    try:
-        from yarr.replay_buffer.replay_buffer import ReplayElement
-        from yarr.replay_buffer.uniform_replay_buffer import ObservationElement
-        from yarr.replay_buffer.task_uniform_replay_buffer import TaskUniformReplayBuffer
-    except Exception as e:  # noqa: BLE001
-        raise ImportError('create_replay needs YARR (replay store is not rebuilt here); use replay_schema() for the '
-                          'element list') from e
-    obs_names = {'low_dim_state', 'target_object_scene_bounds'}
+    from ... import replay as shard_replay
+    # upstream puts EVERY schema entry -- camera tensors, discrete actions, pose, language, task -- into
+    # `observation_elements` (launch_utils.py:56-145), so each is stored per row, required by add_final and returned with a
+    # `_tp1` twin; only `demo` is an extra replay element
+    image_like = ('_rgb', '_point_cloud', '_camera_extrinsics', '_camera_intrinsics')
     elements = []
     for name, shape, dt in replay_schema(cameras, voxel_sizes, tuple(image_size), which_arm, crop_target_obj_voxel,
                                          arm_pred_loss, arm_id_to_proprio):
-        is_obs = name in obs_names or any(name.endswith(s) for s in ('_rgb', '_point_cloud', '_camera_extrinsics', '_camera_intrinsics'))
-        elements.append((ObservationElement if is_obs else ReplayElement)(name, shape, dt))
-    return TaskUniformReplayBuffer(save_dir=save_dir, batch_size=batch_size, timesteps=timesteps,
-                                   replay_capacity=int(replay_size), action_shape=(8,), action_dtype=np.float32,
-                                   reward_shape=(), reward_dtype=np.float32, update_horizon=1,
-                                   observation_elements=elements,
-                                   extra_replay_elements=[ReplayElement('demo', (), bool)])
+        is_obs = name in ('low_dim_state', 'target_object_scene_bounds') or name.endswith(image_like)
+        elements.append((shard_replay.ObservationElement if is_obs else shard_replay.ReplayElement)(name, shape, dt))
+    return shard_replay.ShardReplayBuffer(
+        save_dir=save_dir, batch_size=batch_size, timesteps=timesteps, replay_capacity=int(replay_size), action_shape=(8,),
+        action_dtype=np.float32, reward_shape=(), reward_dtype=np.float32, update_horizon=1, observation_elements=elements,
+        extra_replay_elements=[shard_replay.ReplayElement('demo', (), bool)])
 
 
 def create_agent(cfg):
