@@ -1,10 +1,21 @@
+# per-round evidence: bench JSON (default + twin-agent workload), rocprofv3 kernel stats and HBM traffic counters of the same command
+# usage (on the GPU box, from the repo root):  bash tools/profile_round.sh r02 v1
+R=${1:-r02}; V=${2:-v1}; O=gpurun_out/$R$V; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_v8 -o v8 -- python bench.py --no-cpu-baseline --no-other-modes --steps 3 --warmup 1 > gpurun_out/prof_v8.log 2>&1
-python tools/prof_summary.py gpurun_out/prof_v8/v8_results.db 60 > gpurun_out/prof_v8_summary.txt
+python bench.py --steps 10 --warmup 3 > $O/bench.json 2> $O/bench.err
+python bench.py --agents 2 --aug-copies 4 --steps 2 --warmup 1 --no-cpu-baseline --no-other-modes > $O/bench_twin.json 2> $O/bench_twin.err
+rocprofv3 --kernel-trace --stats -d $O/prof -o p -- python bench.py --no-cpu-baseline --no-other-modes --steps 3 --warmup 1 > $O/prof.log 2>&1
+python tools/prof_summary.py $O/prof/p_results.db 70 > $O/step_kernel_stats.txt
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc8_$c -- python bench.py --no-cpu-baseline --no-other-modes --steps 2 --warmup 1 > gpurun_out/pmc8_$c.log 2>&1
-  python tools/pmc_summary.py gpurun_out/pmc8_$c 30 > gpurun_out/pmc8_${c}_summary.txt
-  rm -rf gpurun_out/pmc8_$c
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python bench.py --no-cpu-baseline --no-other-modes --steps 2 --warmup 1 > $O/pmc_$c.log 2>&1
+  python tools/pmc_summary.py $O/pmc_$c 30 > $O/pmc_${c}_summary.txt
+  rm -rf $O/pmc_$c
 done
-head -12 gpurun_out/prof_v8_summary.txt | cut -c1-150
-head -8 gpurun_out/pmc8_FETCH_SIZE_summary.txt | cut -c1-150
+rm -rf $O/prof
+head -14 $O/step_kernel_stats.txt | cut -c1-150
+head -8 $O/pmc_FETCH_SIZE_summary.txt | cut -c1-150
+python -c "
+import json
+for f in ('bench.json', 'bench_twin.json'):
+    d = json.load(open('$O/' + f)); print(f, d['value'], d['ms_per_step'], d.get('samples_per_s'), d['roofline']['kernel'], round(d['roofline']['frac'], 3), d['rooflines_other'].get('voxel_scatter', {}).get('frac'))
+"
