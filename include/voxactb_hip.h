@@ -63,6 +63,17 @@ int vxb_voxelize_f32(const float* const* coord_src, const float* const* feat_src
                      const float* bounds, int bounds_rows, int V, const float* xform,
                      float* out, int out_state, void* workspace, size_t workspace_bytes, vxb_stream_t stream);
 
+/* RGB-D input: the same voxelizer fed with DEPTH images [B][H][W] instead of stored point clouds; the
+ * world point of pixel (h, w) of camera s is computed in the point load exactly as PyRep builds the stored clouds
+ * (PyRep/pyrep/objects/vision_sensor.py:155-175, RLBench/rlbench/utils.py:205-256): pc = (w d, h d, d) in fp32,
+ * world = M (pc, 1) in float64, rounded to fp32.  proj [B][n_src][14] doubles = the three rows of
+ * M = inv([K [R^T | -R^T C]; 0 0 0 1])[0:3], then near, far; depth_normalised != 0: d = near + depth (far - near) in fp32
+ * first (a 0..1 depth buffer), else the images are in metres.  Point id = s*H*W + h*W + w.  Everything else as above. */
+int vxb_voxelize_depth_f32(const float* const* depth_src, const float* const* feat_src, int n_src, int B, int H, int W, int F,
+                           int64_t feat_bstride, int64_t feat_cstride, int64_t feat_pstride, const double* proj,
+                           int depth_normalised, const float* bounds, int bounds_rows, int V, const float* xform, float* out,
+                           int out_state, void* workspace, size_t workspace_bytes, vxb_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * fp32 matrix-core GEMM (v_mfma_f32_32x32x2_f32).  Replaces nn.Linear / einsum in Attention,
  * FeedForward, lang_preprocess (perceiver_lang_io.py:80-132, :417).
@@ -323,6 +334,11 @@ int vxb_ce_rows_f32(const float* logits, int64_t ld, int rows, int nseg, const i
 int vxb_lamb_step_f32(float* w, const float* g, float* m, float* v, float* upd, const int32_t* chunks, int nchunks,
                       const int32_t* first, int ntensors, float* part, float* trust, float lr, double beta1, double beta2,
                       float eps, float weight_decay, vxb_stream_t stream);
+
+/* torch.optim.Adam step over a flat parameter buffer (the reference's `optimizer: adam` alternative, agent :263-268):
+ * L2 weight decay folded into the gradient, bias correction with `step` (1-based), eps 1e-8 by default upstream. */
+int vxb_adam_step_f32(float* w, const float* g, float* m, float* v, int64_t n, float lr, double beta1, double beta2, float eps,
+                      float weight_decay, int64_t step, vxb_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -65,3 +65,25 @@ def voxelize(coords: torch.Tensor, feats: torch.Tensor, bounds: torch.Tensor, V:
 def occupied_cells(grid: torch.Tensor) -> torch.Tensor:
     """[B,V,V,V,C] -> int64 [n,4] (b,x,y,z) of occupied cells, lexicographic."""
     return torch.nonzero(grid[..., -1] > 0)
+
+
+def depth_to_point_cloud(depth, extrinsics, intrinsics, near=None, far=None):
+    """RGB-D input path (PyRep/pyrep/objects/vision_sensor.py:155-175, :381-412; RLBench/rlbench/utils.py:205-207).
+    depth [H,W] float32 (metres, or a 0..1 buffer when near / far are given), extrinsics [4,4] camera-to-world, intrinsics
+    [3,3]  ->  world points [H,W,3] float32, exactly as the stored `<cam>_point_cloud` observations are produced:
+    pixel grid (x = column, y = row) times depth in float32, then the inverse projection in float64."""
+    import numpy as np
+    depth = np.asarray(depth, dtype=np.float32)
+    if near is not None:
+        depth = (np.float32(near) + depth * np.float32(far - near)).astype(np.float32)          # utils.py:205-207 (fp32 array math)
+    H, W = depth.shape
+    xs = np.tile(np.arange(W, dtype=np.float32), (H, 1))
+    ys = np.tile(np.arange(H, dtype=np.float32)[:, None], (1, W))
+    pc = np.stack([xs * depth, ys * depth, depth], -1)                                            # :163-164 (float32)
+    extrinsics = np.asarray(extrinsics, dtype=np.float64)
+    R_inv = extrinsics[:3, :3].T                                                                  # :165-167
+    R_inv_C = R_inv @ extrinsics[:3, 3:4]
+    proj = np.asarray(intrinsics, dtype=np.float64) @ np.concatenate((R_inv, -R_inv_C), -1)        # :168-169
+    inv = np.linalg.inv(np.concatenate([proj, [[0, 0, 0, 1]]]))[0:3]                                # :170-172
+    homo = np.concatenate([pc.astype(np.float64), np.ones((H, W, 1))], -1).reshape(H * W, 4).T      # :406-409
+    return (inv @ homo).T.reshape(H, W, 3).astype(np.float32), inv

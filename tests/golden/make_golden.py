@@ -476,6 +476,45 @@ def f9_act():
     save('f9_act', **out)
 
 
+# ----------------------------------------------------------------------------- F10: RGB-D -> point cloud (PyRep)
+def f10_depth():
+    """PyRep's VisionSensor module cannot be imported (it loads the CoppeliaSim backend), but the point-cloud code is
+    pure numpy: the three module-level helpers and the static method are compiled FROM the reference file where it lies
+    (ast-selected definitions, executed in a namespace that only holds numpy) and run here."""
+    import ast
+    path = REF + '/PyRep/pyrep/objects/vision_sensor.py'
+    tree = ast.parse(open(path).read())
+    want = {'_create_uniform_pixel_coords_image', '_transform', '_pixel_to_world_coords'}
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == 'VisionSensor'][0]
+    fn = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == 'pointcloud_from_depth_and_camera_params'][0]
+    fn.decorator_list = []
+    ns = {'np': np}
+    exec(compile(ast.Module(body=body + [fn], type_ignores=[]), path, 'exec'), ns)
+    ref_fn = ns['pointcloud_from_depth_and_camera_params']
+    from scipy.spatial.transform import Rotation
+    g = np.random.Generator(np.random.Philox(key=77))
+    B, H, W, cams = 2, 24, 20, 2
+    out = dict(cfg_B=B, cfg_H=H, cfg_W=W, cfg_ncam=cams)
+    near, far = 0.01, 4.5
+    for b in range(B):
+        for c in range(cams):
+            ext = np.eye(4)
+            ext[:3, :3] = Rotation.from_euler('xyz', g.uniform(-2.5, 2.5, 3)).as_matrix()
+            ext[:3, 3] = np.array([0.2, 0.0, 1.1]) + g.uniform(-1.0, 1.0, 3)
+            f = -W / (2 * np.tan(np.deg2rad(g.uniform(25, 40))))
+            K = np.array([[f, 0, W / 2], [0, f * g.uniform(0.9, 1.1), H / 2], [0, 0, 1.0]])
+            d01 = g.uniform(0.05, 0.6, (H, W)).astype(np.float32)                      # a 0..1 depth buffer
+            depth_m = (np.float32(near) + d01 * np.float32(far - near)).astype(np.float32)
+            cloud = ref_fn(depth_m, ext, K).astype(np.float32)                         # stored as float32 observations
+            mine, inv = ovox.depth_to_point_cloud(d01, ext, K, near, far)
+            assert np.array_equal(mine, cloud), (b, c, np.abs(mine - cloud).max())
+            tag = 'b%d_c%d_' % (b, c)
+            out[tag + 'depth01'], out[tag + 'ext'], out[tag + 'int'], out[tag + 'cloud'] = d01, ext, K, cloud
+    out['near'], out['far'] = near, far
+    save('f10_depth_clouds', **out)
+
+
 SECTIONS = {
     'f1': f1_voxel_kats,
     'f3tiny': lambda: encoder_fixture('f3_encoder_tiny', CFG_TINY, arm=True),
@@ -486,6 +525,7 @@ SECTIONS = {
     'f5v200': lambda: encoder_fixture('f5v200_encoder_c5_digest', CFG_C5, with_grads=False, digest=True),
     'f6': f6_update_traces,
     'f9': f9_act,
+    'f10': f10_depth,
     'f7': f7_lamb,
     'f8': f8_se3,
 }

@@ -102,3 +102,14 @@ def test_se3_fixture(golden):
     da = (a[:, :, :50, None] - a[:, :, None, :50]).norm(dim=1)
     db = (b[:, :, :50, None] - b[:, :, None, :50]).norm(dim=1)
     assert torch.allclose(da, db, atol=1e-5)
+
+
+def test_depth_to_point_cloud_fixture(golden):
+    """F10: clouds produced by PyRep's own pointcloud_from_depth_and_camera_params (compiled from the reference file by
+    make_golden.py) for seeded depth buffers / cameras."""
+    g = golden('f10_depth_clouds')
+    for b in range(int(g['cfg_B'])):
+        for c in range(int(g['cfg_ncam'])):
+            tag = 'b%d_c%d_' % (b, c)
+            mine, _ = ovox.depth_to_point_cloud(g[tag + 'depth01'], g[tag + 'ext'], g[tag + 'int'], float(g['near']), float(g['far']))
+            assert np.array_equal(mine, g[tag + 'cloud'])

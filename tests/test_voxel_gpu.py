@@ -221,6 +221,31 @@ def test_overlapped_launch_orders_give_the_same_grid():
         assert torch.equal(vg.voxelize_cameras(pcd, rgb), ref), order
 
 
+def test_depth_images_give_the_grid_of_the_reference_point_clouds(golden):
+    """RGB-D input: voxelize_depth(depth buffers, cameras) == voxelize(point clouds PyRep computed from them) -- fixture F10
+    holds clouds from PyRep's own code -- bit for bit, for a 0..1 depth buffer with near / far and for metres."""
+    g = golden('f10_depth_clouds')
+    B, H, W, nc = int(g['cfg_B']), int(g['cfg_H']), int(g['cfg_W']), int(g['cfg_ncam'])
+    near, far = float(g['near']), float(g['far'])
+    d01 = [torch.stack([T(g['b%d_c%d_depth01' % (b, c)]) for b in range(B)]).to(DEV) for c in range(nc)]
+    clouds = [torch.stack([T(g['b%d_c%d_cloud' % (b, c)]).permute(2, 0, 1) for b in range(B)]).contiguous().to(DEV) for c in range(nc)]
+    ext = torch.stack([torch.stack([T(g['b%d_c%d_ext' % (b, c)]) for c in range(nc)]) for b in range(B)])
+    K = torch.stack([torch.stack([T(g['b%d_c%d_int' % (b, c)]) for c in range(nc)]) for b in range(B)])
+    rgb = [torch.rand(B, 3, H, W, device=DEV) for _ in range(nc)]
+    lo = torch.stack([c.amin(dim=(0, 2, 3)) for c in clouds]).amin(0).cpu()
+    hi = torch.stack([c.amax(dim=(0, 2, 3)) for c in clouds]).amax(0).cpu()
+    bounds = torch.cat([lo + 0.1 * (hi - lo), hi - 0.1 * (hi - lo)]).unsqueeze(0).to(DEV)
+    V = 24
+    vg = VoxelGrid(bounds[0].tolist(), V, DEV, B, 3, nc * H * W)
+    want = vg.voxelize_cameras(clouds, rgb, bounds)
+    assert float(want[..., -1].sum()) > 50
+    got = vg.voxelize_depth(d01, rgb, ext, K, bounds, near_far=(near, far))
+    assert torch.equal(got, want)
+    metres = [(np.float32(near) + d.cpu().numpy() * np.float32(far - near)).astype(np.float32) for d in d01]
+    got_m = vg.voxelize_depth([torch.from_numpy(m).to(DEV) for m in metres], rgb, ext, K, bounds)
+    assert torch.equal(got_m, want)
+
+
 def test_errors():
     from voxactb_amd import _lib
     vg = VoxelGrid([0, 0, 0, 1, 1, 1], 8, DEV, 2, 3, 16)

@@ -25,7 +25,9 @@ import torch.nn as nn
 from ... import ops
 from ..._lib import VoxactbHipError
 from ...flat_params import FlatParams
+from ...helpers.optim.adam import Adam
 from ...helpers.optim.lamb import Lamb
+from ...helpers.optim.schedule import CosineWithHardRestarts
 from ...voxel.augmentation import se3_augmentation_plan
 from ...voxel.voxel_grid import VoxelGrid
 from ...yarr_agent import Agent, ActResult, ScalarSummary, HistogramSummary, Summary
@@ -162,8 +164,6 @@ class QAttentionPerActBCAgent(Agent):
             self._loss_weights = (trans_loss_weight, rot_loss_weight, grip_loss_weight, collision_loss_weight, arm_loss_weight)
         else:
             self._loss_weights = None
-        if lr_scheduler:
-            raise NotImplementedError('lr_scheduler=True (off in PERACT_BC.yaml:33) is not built')
 
     # ------------------------------------------------------------------------------------------------------------ build
     def build(self, training: bool, device: torch.device = None):
@@ -202,11 +202,15 @@ class QAttentionPerActBCAgent(Agent):
                 self._optimizer = Lamb(self._q.parameters(), lr=self._lr, weight_decay=self._lambda_weight_l2,
                                        betas=(0.9, 0.999), adam=False)
                 self._optimizer.attach(self._arena)
-            elif self._optimizer_type == 'adam':
-                raise NotImplementedError("optimizer 'adam' is the non-default upstream alternative (agent :263-268); "
-                                          "only the default 'lamb' (PERACT_BC.yaml:34) has a fused HIP kernel")
+            elif self._optimizer_type == 'adam':                        # agent :263-268
+                self._optimizer = Adam(self._q.parameters(), lr=self._lr, weight_decay=self._lambda_weight_l2)
+                self._optimizer.attach(self._arena)
             else:
                 raise Exception('Unknown optimizer type')
+            if self._lr_scheduler:                                      # agent :273-279
+                self._scheduler = CosineWithHardRestarts(self._optimizer, num_warmup_steps=self._num_warmup_steps,
+                                                         num_training_steps=self._training_iterations,
+                                                         num_cycles=self._training_iterations // 10000)
             logging.info('# Q Params: %d' % sum(p.numel() for name, p in self._q.named_parameters()
                                                  if p.requires_grad and 'clip' not in name))
         else:
@@ -359,6 +363,9 @@ class QAttentionPerActBCAgent(Agent):
         }
         if self._arm_pred_loss:
             self._summaries['losses/arm_loss'] = q_arm_loss.mean()
+        if self._lr_scheduler:                                          # agent :595-597
+            self._scheduler.step()
+            self._summaries['learning_rate'] = self._scheduler.get_last_lr()[0]
         self._vis_voxel_grid = voxel_grid[0]
         self._vis_translation_qvalue = None          # computed lazily in update_summaries (softmax over V^3)
         self._vis_q_trans0 = q_trans[0:1]

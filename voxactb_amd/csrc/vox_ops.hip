@@ -842,7 +842,35 @@ __global__ void __launch_bounds__(256) lamb_stage3_kernel(float* __restrict__ w,
     for (int i = threadIdx.x; i < len; i += 256) w[start + i] = __fadd_rn(w[start + i], __fmul_rn(alpha, upd[start + i]));
 }
 
+// torch.optim.Adam (the reference's alternative optimizer, agent :263-268), single-tensor formulas of torch/optim/adam.py
+// applied to the flat arena: g += wd * w; m = lerp(m, g, 1 - beta1); v = v * beta2 + (1 - beta2) g g;
+// w -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n, float beta2, float omb1, float omb2, float eps,
+                                                   float wd, float step_size, float bc2_sqrt) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float gv = g[i];
+        const float wv = w[i];
+        if (wd != 0.f) gv = __fadd_rn(gv, __fmul_rn(wd, wv));
+        const float mv = __fadd_rn(m[i], __fmul_rn(omb1, __fsub_rn(gv, m[i])));          // exp_avg.lerp_(grad, 1 - beta1)
+        const float vv = __fadd_rn(__fmul_rn(v[i], beta2), __fmul_rn(__fmul_rn(omb2, gv), gv));
+        m[i] = mv; v[i] = vv;
+        const float denom = __fadd_rn(__fdiv_rn(sqrtf(vv), bc2_sqrt), eps);
+        w[i] = __fadd_rn(wv, __fmul_rn(-step_size, __fdiv_rn(mv, denom)));              // addcdiv_(exp_avg, denom, value=-step_size)
+    }
+}
+
 }  // namespace
+
+extern "C" int vxb_adam_step_f32(float* w, const float* g, float* m, float* v, int64_t n, float lr, double beta1, double beta2,
+                                 float eps, float weight_decay, int64_t step, vxb_stream_t stream) {
+    if (!w || !g || !m || !v || n < 1 || step < 1) return VXB_EARG;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, (long long)n, (float)beta2,
+                       (float)(1.0 - beta1), (float)(1.0 - beta2), eps, weight_decay, (float)((double)lr / bc1), (float)sqrt(bc2));
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
 
 extern "C" int vxb_pointwise_fwd_f32(const float* x, const float* W, const float* bias, float* y, int64_t nvox, int Cin,
                                      int Cout, float slope, vxb_stream_t stream) {

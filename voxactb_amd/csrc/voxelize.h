@@ -16,6 +16,10 @@ struct Geom {
     int B, n_src, pps, N, F, V, bounds_rows;
     long long cb, cc, cp, fb, fc, fp;
     const float* xf;      // optional [B, 15] rigid transform applied to every point as it is loaded (R row-major 9, t 3, c 3)
+    // depth mode (proj != nullptr): source s holds a DEPTH image [B][H * W] instead of coordinates and the world point of
+    // pixel (h, w) is computed here.  proj [B][n_src][14] doubles: rows of the inverse camera projection (3 x 4), near, far
+    const double* proj;
+    int img_w, depth_norm;
 };
 
 // voxel_grid.py:153-163 for one axis; returns the index in the (V+2)-grid, clamped to [0, V+1].
@@ -50,11 +54,32 @@ __device__ __forceinline__ void xform_point(const float* __restrict__ x, float (
     p[2] = fmaf(p2, x[8], fmaf(p1, x[5], p0 * x[2])) + x[14];
 }
 
+// RGB-D input: world point of pixel (h, w) from its depth, as PyRep computes the stored clouds
+// (PyRep/pyrep/objects/vision_sensor.py:155-175: pc = (w d, h d, d) in fp32, world = inv(K [R^T | -R^T C])[0:3] (pc, 1) in
+// float64, stored as fp32; RLBench/rlbench/utils.py:205-207 for a normalised depth: d = near + depth (far - near) in fp32)
+__device__ __forceinline__ void depth_to_point(const Src& src, const Geom& g, int b, int n, float (&p)[3]) {
+    const int s = n / g.pps, i = n - s * g.pps;
+    const float d = src.c[s][(long long)b * g.cb + (long long)i * g.cp];
+    const double* P = g.proj + ((long long)b * g.n_src + s) * 14;
+    float dm = d;
+    if (g.depth_norm) dm = __fadd_rn((float)P[12], __fmul_rn(d, (float)(P[13] - P[12])));
+    const int h = i / g.img_w, w = i - h * g.img_w;
+    const double px = (double)__fmul_rn((float)w, dm), py = (double)__fmul_rn((float)h, dm), pz = (double)dm;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        p[a] = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(P[4 * a], px), __dmul_rn(P[4 * a + 1], py)), __dmul_rn(P[4 * a + 2], pz)),
+                                P[4 * a + 3]);
+}
+
 // coordinates of point n of sample b, after the optional rigid transform
 __device__ __forceinline__ void load_coords(const Src& src, const Geom& g, int b, int n, float (&p)[3]) {
-    const float* cp = point_ptr(src.c, n, g.pps, b, g.cb, g.cp);
+    if (g.proj) {
+        depth_to_point(src, g, b, n, p);
+    } else {
+        const float* cp = point_ptr(src.c, n, g.pps, b, g.cb, g.cp);
 #pragma unroll
-    for (int a = 0; a < 3; ++a) p[a] = cp[a * g.cc];
+        for (int a = 0; a < 3; ++a) p[a] = cp[a * g.cc];
+    }
     if (g.xf) xform_point(g.xf + b * 15, p);
 }
 

@@ -573,12 +573,12 @@ extern "C" size_t vxb_voxelize_workspace_bytes(int B, int n_points, int V) {
     return table > tiles ? table : tiles;
 }
 
-extern "C" int vxb_voxelize_f32(const float* const* coord_src, const float* const* feat_src, int n_src,
-                                int B, int pts_per_src, int F,
-                                int64_t coord_bstride, int64_t coord_cstride, int64_t coord_pstride,
-                                int64_t feat_bstride, int64_t feat_cstride, int64_t feat_pstride,
-                                const float* bounds, int bounds_rows, int V, const float* xform,
-                                float* out, int out_state, void* workspace, size_t workspace_bytes, vxb_stream_t stream) {
+static int vox_run(const float* const* coord_src, const float* const* feat_src, int n_src,
+                   int B, int pts_per_src, int F,
+                   int64_t coord_bstride, int64_t coord_cstride, int64_t coord_pstride,
+                   int64_t feat_bstride, int64_t feat_cstride, int64_t feat_pstride,
+                   const float* bounds, int bounds_rows, int V, const float* xform, const double* proj, int img_w, int depth_norm,
+                   float* out, int out_state, void* workspace, size_t workspace_bytes, vxb_stream_t stream) {
     if (!coord_src || !bounds || !out || !workspace) return VXB_EARG;
     if (n_src < 1 || n_src > VOX_MAX_SRC || B < 1 || pts_per_src < 1 || V < 1) return VXB_EARG;
     if (F < 0 || F > VOX_MAX_F || (F > 0 && !feat_src)) return VXB_EARG;
@@ -600,6 +600,7 @@ extern "C" int vxb_voxelize_f32(const float* const* coord_src, const float* cons
     g.cb = coord_bstride; g.cc = coord_cstride; g.cp = coord_pstride;
     g.fb = feat_bstride; g.fc = feat_cstride; g.fp = feat_pstride;
     g.xf = xform;
+    g.proj = proj; g.img_w = img_w; g.depth_norm = depth_norm;
     const int C = 3 + F + 4;
     const long long BN = (long long)B * N;
     VoxStreams* vs = nullptr;
@@ -660,4 +661,24 @@ extern "C" int vxb_voxelize_f32(const float* const* coord_src, const float* cons
     if (hipEventRecord(vs->ev_long, fs) != hipSuccess || hipStreamWaitEvent(st, vs->ev_long, 0) != hipSuccess) return VXB_ELAUNCH;
     VXB_CHECK_LAUNCH();
     return VXB_OK;
+}
+
+extern "C" int vxb_voxelize_f32(const float* const* coord_src, const float* const* feat_src, int n_src,
+                                int B, int pts_per_src, int F,
+                                int64_t coord_bstride, int64_t coord_cstride, int64_t coord_pstride,
+                                int64_t feat_bstride, int64_t feat_cstride, int64_t feat_pstride,
+                                const float* bounds, int bounds_rows, int V, const float* xform,
+                                float* out, int out_state, void* workspace, size_t workspace_bytes, vxb_stream_t stream) {
+    return vox_run(coord_src, feat_src, n_src, B, pts_per_src, F, coord_bstride, coord_cstride, coord_pstride, feat_bstride,
+                   feat_cstride, feat_pstride, bounds, bounds_rows, V, xform, nullptr, 0, 0, out, out_state, workspace,
+                   workspace_bytes, stream);
+}
+
+extern "C" int vxb_voxelize_depth_f32(const float* const* depth_src, const float* const* feat_src, int n_src, int B, int H, int W,
+                                      int F, int64_t feat_bstride, int64_t feat_cstride, int64_t feat_pstride, const double* proj,
+                                      int depth_normalised, const float* bounds, int bounds_rows, int V, const float* xform,
+                                      float* out, int out_state, void* workspace, size_t workspace_bytes, vxb_stream_t stream) {
+    if (!proj || H < 1 || W < 1) return VXB_EARG;
+    return vox_run(depth_src, feat_src, n_src, B, H * W, F, (int64_t)H * W, 0, 1, feat_bstride, feat_cstride, feat_pstride, bounds,
+                   bounds_rows, V, xform, proj, W, depth_normalised ? 1 : 0, out, out_state, workspace, workspace_bytes, stream);
 }

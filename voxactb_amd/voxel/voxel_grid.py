@@ -72,7 +72,7 @@ class VoxelGrid(nn.Module):
         b = b.to(device=device, dtype=torch.float32).reshape(-1, 6).contiguous()
         return b
 
-    def _run(self, coord_ptrs, feat_ptrs, B, pps, F, cs, fs, bounds, device, xform=None):
+    def _run(self, coord_ptrs, feat_ptrs, B, pps, F, cs, fs, bounds, device, xform=None, depth=None):
         V = self._voxel_size
         n_src = len(coord_ptrs)
         if bounds.shape[0] not in (1, B):
@@ -103,15 +103,21 @@ class VoxelGrid(nn.Module):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         with _lib.on_device(device):        # raw launch: the tensors' device must be the current one (rank >= 1 of a DDP job)
-            rc = _lib.lib().vxb_voxelize_f32(cp, fp, n_src, B, pps, F, cs[0], cs[1], cs[2], fs[0], fs[1], fs[2],
-                                             _lib.ptr(bounds), bounds.shape[0], V, _lib.ptr(xform), _lib.ptr(out), state, _lib.ptr(ws),
-                                             ws.numel() * 4, _lib.stream_ptr(device))
+            if depth is None:
+                rc = _lib.lib().vxb_voxelize_f32(cp, fp, n_src, B, pps, F, cs[0], cs[1], cs[2], fs[0], fs[1], fs[2],
+                                                 _lib.ptr(bounds), bounds.shape[0], V, _lib.ptr(xform), _lib.ptr(out), state,
+                                                 _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr(device))
+            else:
+                H, W, proj, normalised = depth
+                rc = _lib.lib().vxb_voxelize_depth_f32(cp, fp, n_src, B, H, W, F, fs[0], fs[1], fs[2], _lib.ptr(proj),
+                                                       int(normalised), _lib.ptr(bounds), bounds.shape[0], V, _lib.ptr(xform),
+                                                       _lib.ptr(out), state, _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr(device))
         if timer is not None:
             e1.record()
             # algorithmic bytes: read N*(3+F)*4 per sample, write V^3*(3+F+4)*4 per sample
             nbytes = B * (n_src * pps * (3 + F) * 4 + V ** 3 * (3 + F + 4) * 4)
             timer.records.append(('voxelize', 'vxb_voxelize_f32', e0, e1, 0.0, float(nbytes)))
-        _lib.check(rc, 'vxb_voxelize_f32')
+        _lib.check(rc, 'vxb_voxelize_f32' if depth is None else 'vxb_voxelize_depth_f32')
         if slot is not None:
             slot[2] = 2 if state == 1 else 1     # complete result in place: the next use may be incremental (the value names
                                                  # which of the workspace's two cell lists this call wrote, see the C header)
@@ -150,3 +156,38 @@ class VoxelGrid(nn.Module):
         self._keep = (pcd, rgb)
         return self._run([p.data_ptr() for p in pcd], [r.data_ptr() for r in rgb], B, H * W, F,
                          (3 * H * W, H * W, 1), (F * H * W, H * W, 1), bounds, pcd[0].device, xform)
+
+    # ------------------------------------------------------------------ RGB-D input (SURVEY.md 8f row 2)
+    @staticmethod
+    def inverse_projections(extrinsics, intrinsics, near_far=None):
+        """[B, n_cam, 14] float64: rows of inv([K [R^T | -R^T C]; 0 0 0 1])[0:3] per camera (the matrix PyRep applies to
+        (x d, y d, d, 1), vision_sensor.py:165-172), then near and far.  Host numpy in float64, as upstream."""
+        import numpy as np
+        ext = np.asarray(extrinsics.detach().cpu() if torch.is_tensor(extrinsics) else extrinsics, dtype=np.float64)
+        K = np.asarray(intrinsics.detach().cpu() if torch.is_tensor(intrinsics) else intrinsics, dtype=np.float64)
+        R_inv = np.swapaxes(ext[..., :3, :3], -1, -2)
+        R_inv_C = R_inv @ ext[..., :3, 3:4]
+        proj = K @ np.concatenate((R_inv, -R_inv_C), -1)
+        homo = np.concatenate([proj, np.broadcast_to(np.array([0, 0, 0, 1.0]), proj.shape[:-2] + (1, 4))], -2)
+        inv = np.linalg.inv(homo)[..., 0:3, :].reshape(ext.shape[:-2] + (12,))
+        nf = np.zeros(ext.shape[:-2] + (2,)) if near_far is None else np.broadcast_to(np.asarray(near_far, np.float64), ext.shape[:-2] + (2,))
+        return np.ascontiguousarray(np.concatenate([inv, nf], -1))
+
+    def voxelize_depth(self, depth, rgb, extrinsics, intrinsics, coord_bounds=None, near_far=None, xform=None):
+        """depth: list (one per camera) of [B,H,W] (or [B,1,H,W]) depth images -- metres, or a 0..1 depth buffer when
+        `near_far` = (near, far) per camera [n_cam, 2] / [B, n_cam, 2] is given; rgb: list of [B,F,H,W]; extrinsics
+        [B,n_cam,4,4] camera-to-world, intrinsics [B,n_cam,3,3].  Same grid as voxelizing the point clouds PyRep would have
+        stored for these images (vision_sensor.py:155-175), without ever materialising them: one float per pixel of input
+        instead of three."""
+        _lib.require_cuda(*depth, *rgb)
+        depth = [d.float().reshape(d.shape[0], d.shape[-2], d.shape[-1]).contiguous() for d in depth]
+        B, H, W = depth[0].shape
+        F = rgb[0].shape[1] if rgb else 0
+        rgb = [r.float().contiguous() for r in rgb]
+        proj = torch.from_numpy(self.inverse_projections(extrinsics, intrinsics, near_far)).to(depth[0].device)
+        if tuple(proj.shape) != (B, len(depth), 14):
+            raise _lib.VoxactbHipError('extrinsics / intrinsics must be [B, n_cam, 4, 4] / [B, n_cam, 3, 3]')
+        bounds = self._bounds(coord_bounds, depth[0].device)
+        self._keep = (depth, rgb, proj)
+        return self._run([d.data_ptr() for d in depth], [r.data_ptr() for r in rgb], B, H * W, F, (H * W, 0, 1),
+                         (F * H * W, H * W, 1), bounds, depth[0].device, xform, depth=(H, W, proj, near_far is not None))
