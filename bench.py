@@ -102,6 +102,7 @@ def main():
     engines = [ag._pose_agent._qattention_agents[0]._q.encoder.engine() for ag in agents]
     eng = engines[0]
     headline_mode = eng.precision          # 'bf16x3' unless VOXACTB_PRECISION overrides it
+    headline_bwd = eng.bwd_precision       # '' (= same as the forward) unless VOXACTB_BWD_PRECISION overrides it
     counter = [0]
     updates_per_step = len(agents) * a.aug_copies
 
@@ -118,7 +119,7 @@ def main():
     def measure(mode, steps, warmup):
         """W untimed + exactly K timed steps in `mode`, bracketed by barrier + synchronize; max over ranks."""
         for e_ in engines:
-            e_.precision = mode
+            e_.precision, _, e_.bwd_precision = mode.partition('/')      # 'bf16x3/bf16' = forward bf16x3, backward products bf16
         for _ in range(warmup):
             step()
         timer = _lib.KernelTimer()
@@ -139,7 +140,7 @@ def main():
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         for e_ in engines:
-            e_.precision = headline_mode
+            e_.precision, e_.bwd_precision = headline_mode, headline_bwd
         return float(tt[0]), loss, timer.summary()
 
     torch.manual_seed(1000 + rank)    # augmentation draws differ per rank, as they would with per-rank replay shards
@@ -148,12 +149,12 @@ def main():
     # secondary measurements of the same workload in the other precisions (never the headline `value`)
     others = {}
     if not a.no_other_modes:
-        for mode in ('fp32', 'bf16x3', 'bf16'):
-            if mode == headline_mode:
+        for mode in ('fp32', 'bf16x3', 'bf16x3/bf16', 'bf16'):
+            if mode == headline_mode and not headline_bwd:
                 continue
             dt2, _, agg2 = measure(mode, a.steps, 1)
             others[mode] = {'value': world * a.steps / dt2, 'unit': 'steps/s', 'ms_per_step': dt2 / a.steps * 1e3,
-                            'dtype': MODE_DTYPE[mode], 'rooflines': group_rooflines(agg2, mode, a.steps),
+                            'dtype': MODE_DTYPE[mode], 'rooflines': group_rooflines(agg2, mode.partition('/')[0], a.steps),
                             'note': MODE_NOTE[mode]}
 
     # parity of the headline precision against the REFERENCE at this geometry: the digest the reference produced for a
@@ -272,12 +273,15 @@ MODE_DTYPE = {
     'fp32': 'f32 (v_mfma_f32_32x32x2_f32 everywhere)',
     'bf16x3': 'f32 storage / accumulate; matrix products as bf16x3 split (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16)',
     'bf16': 'bf16 matrix cores (fp32 accumulate) for convs, large linears and fused attention; everything else f32',
+    'bf16x3/bf16': 'forward as bf16x3 (Q-values inside 1e-4 of the reference), matrix products of the BACKWARD pass on plain bf16',
 }
 MODE_NOTE = {
     'fp32': 'exact fp32 matrix cores: the reference-parity mode of the first measurements (tests/test_encoder_gpu.py, 1e-4)',
     'bf16x3': 'held to the same 1e-4 Q-value / 2e-5 per-op bounds as the exact-fp32 mode (tests/test_encoder_gpu.py::'
               'test_encoder_fixtures_bf16x3_split_mode, test_bf16x3_gpu.py, test_flash_x3_gpu.py); 3 MFMAs per product',
     'bf16': 'throughput mode, NOT held to the 1e-4 Q-value bound (tests/test_bf16_mode_gpu.py: ~4e-3 on q_trans)',
+    'bf16x3/bf16': 'mixed mode (VOXACTB_BWD_PRECISION=bf16): the forward keeps the 1e-4 Q-value bound, parameter gradients are '
+                   'within 0.5 % of the reference (norms within 4e-3) instead of 0.2 % -- not the default',
 }
 # matrix-core roof per algorithmic FLOP: fp32 MFMA; bf16 dense MFMA / 3 instructions per product; bf16 dense MFMA
 MODE_PEAK = {'fp32': PEAK_FP32_MFMA_TFLOPS, 'bf16x3': PEAK_BF16_MFMA_TFLOPS / 3.0, 'bf16': PEAK_BF16_MFMA_TFLOPS}

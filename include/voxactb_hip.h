@@ -335,6 +335,13 @@ int vxb_lamb_step_f32(float* w, const float* g, float* m, float* v, float* upd, 
                       const int32_t* first, int ntensors, float* part, float* trust, float lr, double beta1, double beta2,
                       float eps, float weight_decay, vxb_stream_t stream);
 
+/* 256 x 256-tile GEMM for the big linear layers (nn.Linear forward / data gradient at M = B * 2048 latent rows,
+ * perceiver_lang_io.py:80-132): C[M][N] (+)= act(A[M][K] @ W[N][K]^T + bias) (+ residual).  Both operands are bf16 planes
+ * (nplanes = 1: 'bf16'; 2: hi then lo, 'bf16x3'): A_planes [nplanes][M][lda], W_planes [nplanes][N][K]; K % 32 == 0,
+ * lda % 8 == 0, 16-byte aligned bases. */
+int vxb_gemm256_f32(const void* A_planes, int64_t lda, const void* W_planes, int nplanes, float* C, int64_t ldc, const float* bias,
+                    const float* residual, int M, int N, int K, int act, float slope, int accumulate, vxb_stream_t stream);
+
 /* torch.optim.Adam step over a flat parameter buffer (the reference's `optimizer: adam` alternative, agent :263-268):
  * L2 weight decay folded into the gradient, bias correction with `step` (1-based), eps 1e-8 by default upstream. */
 int vxb_adam_step_f32(float* w, const float* g, float* m, float* v, int64_t n, float lr, double beta1, double beta2, float eps,

@@ -40,7 +40,7 @@ def maxerr(a, b):
     return float((a.detach().float().cpu() - b.detach().float().cpu()).abs().max())
 
 
-def run_fixture(g, cams, precision='fp32'):
+def run_fixture(g, cams, precision='fp32', bwd_precision='', grad_tol=3e-3):
     arm = bool(g['cfg_arm'])
     enc, sd = build_encoder(g, arm)
     rs = batch(g, cams)
@@ -48,7 +48,7 @@ def run_fixture(g, cams, precision='fp32'):
     B = int(g['cfg_B'])
     grid = T(g['grid']).to(DEV)
     eng = enc.engine()
-    eng.precision = precision
+    eng.precision, eng.bwd_precision = precision, bwd_precision
     outs, cache = eng.forward(grid, rs['low_dim_state'].to(DEV), rs['lang_token_embs'].to(DEV), training=False, save=True)
     # intermediates first: a failure here localises the broken stage
     for name, mine in (('int_z1', cache['z1'].permute(0, 4, 1, 2, 3)), ('int_feats', cache['feats'])):
@@ -91,13 +91,13 @@ def run_fixture(g, cams, precision='fp32'):
     bad = []
     for n, rn in zip(names, ref_norms):
         gn = float(P[n].grad.norm())
-        if abs(gn - float(rn)) > 3e-3 * float(rn) + 1e-5:   # +1e-5: grads that are mathematically 0 (trans bias)
+        if abs(gn - float(rn)) > grad_tol * float(rn) + 1e-5:   # +1e-5: grads that are mathematically 0 (trans bias)
             bad.append((n, gn, float(rn)))
         key = 'grad__' + n
         if key in g.files:
             ref = T(g[key])
             e = maxerr(P[n].grad, ref)
-            if e > 3e-3 * float(ref.abs().max()) + 1e-5:
+            if e > grad_tol * float(ref.abs().max()) + 1e-5:
                 bad.append((n, 'full', e, float(ref.abs().max())))
     assert not bad, bad
 
@@ -114,6 +114,13 @@ def test_encoder_fixtures_bf16x3_split_mode(golden):
     """'bf16x3' (hi/lo split products on the bf16 matrix cores) is held to the SAME bounds as the exact-fp32 mode."""
     run_fixture(golden('f3_encoder_tiny'), ['front', 'wrist'], precision='bf16x3')
     run_fixture(golden('f3_encoder_c1'), ['front'], precision='bf16x3')
+
+
+def test_mixed_mode_forward_bf16x3_backward_bf16(golden):
+    """VOXACTB_BWD_PRECISION=bf16 (optional, not the default): the forward -- and with it the 1e-4 Q-value bound -- is untouched,
+    the products of the backward pass run on plain bf16 operands: gradients within 1 % of the reference's instead of 0.3 %."""
+    run_fixture(golden('f3_encoder_tiny'), ['front', 'wrist'], precision='bf16x3', bwd_precision='bf16', grad_tol=1e-2)
+    run_fixture(golden('f3_encoder_c1'), ['front'], precision='bf16x3', bwd_precision='bf16', grad_tol=1e-2)
 
 
 def test_dropout_training_mode_runs_and_is_reproducible(golden):

@@ -20,12 +20,17 @@ def main():
             out = torch.empty(M, N, device=dev)
             fl = 2.0 * M * N * K
             res = []
-            for name, dl, bd in (('staged', False, False), ('dl', 'force', False), ('dl+bfrag', 'force', True)):
-                ops.DL_GEMM, ops.GEMM_BD = dl, bd
+            ref = None
+            for name, g256, dl, bd in (('staged', False, False, False), ('dl', False, 'force', False), ('dl+bfrag', False, 'force', True),
+                                       ('gemm256', True, True, True)):
+                ops.GEMM256, ops.DL_GEMM, ops.GEMM_BD = g256, dl, bd
                 ops.new_step()
                 t = timeit(lambda: ops.gemm_bf16w(x, wb, out=out), n=10)
-                res.append('%s %.3f ms %5.0f TF/s' % (name, t, fl / t * 1e-9))
-            ops.DL_GEMM, ops.GEMM_BD = True, True
+                if ref is None:
+                    ref = out.clone()
+                err = float((out - ref).abs().max())
+                res.append('%s %.3f ms %5.0f TF/s (|d| %.1e)' % (name, t, fl / t * 1e-9, err))
+            ops.GEMM256, ops.DL_GEMM, ops.GEMM_BD = True, True, True
             print('%s  %5d x %5d x %5d   %s' % ('bf16x3' if x3 else 'bf16  ', M, N, K, '   '.join(res)))
 
 

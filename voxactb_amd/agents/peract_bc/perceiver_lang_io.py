@@ -275,6 +275,9 @@ class PerceiverEngine:
         # every other product stays bf16x3 -- measured against the reference digest in DESIGN.md section 6 (it does NOT hold
         # the 1e-4 bound, so it is not a shipped mode)
         self.attn_precision = os.environ.get('VOXACTB_ATTN_PRECISION', '')
+        # precision of the matrix products of the BACKWARD pass ('' = same as the forward); see DESIGN.md section 4a
+        self.bwd_precision = os.environ.get('VOXACTB_BWD_PRECISION', '')
+        self.attn_bwd_precision = os.environ.get('VOXACTB_ATTN_BWD_PRECISION', '')
 
     # -------------------------------------------------------------------------------------------------- helpers
     def _draw_seed(self):
@@ -351,8 +354,9 @@ class PerceiverEngine:
         dO = torch.empty((B * Nq, inner), dtype=torch.float32, device=dev)
         ops.linear_bwd(c['O'], Wo, dout, self.g(pre + '.fn.to_out.weight'), self.g(pre + '.fn.to_out.bias'), dO)
         if c.get('flash'):
+            bp = self.attn_bwd_precision or self.bwd_precision or self.precision
             dq, dkv = flash.flash_attn_bwd_dl(c['q'], c['kv'], c['O'], dO, c['lse'], B, H, Nq, Nk, d ** -0.5, c['p'], c['seed'],
-                                              x3=c['x3'], kv_planes=c['kvp'])
+                                              x3=c['x3'] and bp == 'bf16x3', kv_planes=c['kvp'])
             return self._attn_bwd_proj(pre, dq, dkv, xq2d, ctx2d, same_src)
         kv, q, P, Pd = c['kv'], c['q'], c['P'], c['Pd']
         dkv = torch.empty_like(kv)
@@ -524,7 +528,7 @@ class PerceiverEngine:
         """dq_trans [B,V,V,V] (or [B,1,V,V,V]), d_o [B, 3*rot+grip+coll] (grad of the concatenated MLP head output),
         d_arm [B,2] or None.  Accumulates into every parameter's .grad.  `on_bucket_ready(name)` is called as soon as the
         last kernel that writes gradients of bucket `name` (see grad_buckets) has been enqueued."""
-        ops.PRECISION = self.precision
+        ops.PRECISION = self.bwd_precision or self.precision
         self._on_bucket = on_bucket_ready
         try:
             return self._backward(c, dq_trans, d_o, d_arm)

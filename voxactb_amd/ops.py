@@ -2,6 +2,8 @@
 gfx950 kernels on the current torch stream; torch is used for allocation and views only.
 """
 import numpy as np
+import os
+
 import torch
 
 from . import _lib
@@ -694,6 +696,7 @@ def ce_rows(logits, segs, labels, dlogits=None, gscale=1.0):
 
 
 # --------------------------------------------------------------------------------------------- bf16 matrix-core mode
+GEMM256 = os.environ.get('VOXACTB_GEMM256', '1') != '0'      # 256 x 256-tile kernel for the big linear layers (A/B switch)
 DL_GEMM = True       # direct-to-LDS kernels (gemm_dl.hip) for K % 32 == 0 GEMMs / single-source convs in the bf16 modes:
                      # True = where the split pass pays (rules below), 'force' = wherever legal (tests), False = never
 _ZEROS = {}
@@ -722,6 +725,14 @@ def gemm_bf16w(x, Wb, out=None, bias=None, act=ACT_NONE, residual=None, accumula
     assert Wb.dtype == torch.bfloat16 and Wb.is_contiguous() and Wb.shape[-1] == K
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    if GEMM256 and K % 32 == 0 and N % 256 == 0 and M >= 2048 and x.stride(1) == 1 and x.stride(0) % 4 == 0:
+        # big linear layers: 256 x 256 tiles, 8 waves, both operands as bf16 planes through direct-to-LDS loads (gemm256.hip)
+        npl = 2 if x3 else 1
+        _lib.set_meta(label or 'gemm_bf16 %dx%dx%d' % (M, N, K), 0.0)
+        planes = split_planes(x, npl)
+        _lib.set_meta(label or 'gemm_bf16 %dx%dx%d' % (M, N, K), 2.0 * M * N * K)
+        call('vxb_gemm256_f32', planes, K, Wb, npl, out, out.stride(0), bias, residual, M, N, K, act, LRELU_SLOPE, int(accumulate))
+        return out
     _lib.set_meta(label or 'gemm_bf16 %dx%dx%d' % (M, N, K), 2.0 * M * N * K)
     # the split pass costs M*K*(6|8) bytes of HBM traffic; it pays when every A tile is reused by many column tiles
     # (measured at M = 32768 in bf16x3: N x K = 4096x512 5.3 -> 4.6 ms, 2048x512 2.65 -> 2.40, but 512x4096 3.2 -> 4.4)
