@@ -105,3 +105,25 @@ def test_weight_fragments_from_global_are_bit_identical(M, N, K, x3):
     assert f.shape == (Np // 32, K // 16, 2 if x3 else 1, 2, 32, 8)
     w3 = wb if x3 else wb.unsqueeze(0)
     assert torch.equal(f[1, 0, 0, 1, 5], w3[0, 32 + 5, 8:16])
+
+
+@pytest.mark.parametrize('M,N,K', [(2048, 256, 64), (4096, 4096, 512), (2300, 512, 96), (2048, 768, 32)])
+def test_gemm256_matches_float64_and_the_128_tile_kernels(M, N, K):
+    """gemm256.hip (256 x 256 tiles, 8 waves) in bf16x3: ragged M, every epilogue option, against float64 (2e-5, the bound of
+    the exact-fp32 kernels) and against the register-staged kernel (same products, same k order)."""
+    x, W, b, r = rnd(M, K), rnd(N, K, seed=1), rnd(N, seed=2), rnd(M, N, seed=3)
+    wb = ops.split_bf16(W.to(DEV), True)
+    keep = ops.GEMM256
+    try:
+        ops.GEMM256 = False
+        ref = ops.gemm_bf16w(x.to(DEV), wb, bias=b.to(DEV), act=ops.ACT_LRELU, residual=r.to(DEV))
+        ops.GEMM256 = 'force'
+        got = ops.gemm_bf16w(x.to(DEV), wb, bias=b.to(DEV), act=ops.ACT_LRELU, residual=r.to(DEV))
+        base = rnd(M, N, seed=6).to(DEV)
+        acc = base.clone()
+        ops.gemm_bf16w(x.to(DEV), wb, out=acc, accumulate=True)
+    finally:
+        ops.GEMM256 = keep
+    close(got, ref, 3e-5, 'gemm256 vs 128-tile kernel')
+    close(got, F.leaky_relu(x.double() @ W.double().t() + b.double(), 0.02).float() + r, 2e-5, 'gemm256 vs fp64')
+    close(acc, (base.cpu().double() + x.double() @ W.double().t()).float(), 2e-5, 'gemm256 accumulate')

@@ -22,7 +22,7 @@ def main():
             res = []
             ref = None
             for name, g256, dl, bd in (('staged', False, False, False), ('dl', False, 'force', False), ('dl+bfrag', False, 'force', True),
-                                       ('gemm256', True, True, True)):
+                                       ('gemm256', 'force', True, True)):
                 ops.GEMM256, ops.DL_GEMM, ops.GEMM_BD = g256, dl, bd
                 ops.new_step()
                 t = timeit(lambda: ops.gemm_bf16w(x, wb, out=out), n=10)

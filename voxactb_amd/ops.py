@@ -725,7 +725,10 @@ def gemm_bf16w(x, Wb, out=None, bias=None, act=ACT_NONE, residual=None, accumula
     assert Wb.dtype == torch.bfloat16 and Wb.is_contiguous() and Wb.shape[-1] == K
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
-    if GEMM256 and K % 32 == 0 and N % 256 == 0 and M >= 2048 and x.stride(1) == 1 and x.stride(0) % 4 == 0:
+    # measured at M = 32768 in bf16x3 (tools/bench_gemm.py): N x K = 4096 x 512: 239 TF/s vs 217 (direct-to-LDS 128^2 + weight
+    # fragments) / 174 (register-staged); at N <= 2048 the 128^2 kernels win (270 vs 244 at 2048 x 512, 283 vs 257 at 512 x 4096)
+    if (GEMM256 and x3 and K % 32 == 0 and N % 256 == 0 and (N >= 4096 or GEMM256 == 'force') and M >= 2048 and x.stride(1) == 1
+            and x.stride(0) % 4 == 0):
         # big linear layers: 256 x 256 tiles, 8 waves, both operands as bf16 planes through direct-to-LDS loads (gemm256.hip)
         npl = 2 if x3 else 1
         _lib.set_meta(label or 'gemm_bf16 %dx%dx%d' % (M, N, K), 0.0)
