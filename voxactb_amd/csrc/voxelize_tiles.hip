@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(256) vt_classify_kernel(Geom g, TileWs w) {
 }
 
 template <int F>
-__global__ void __launch_bounds__(64) vt_light_kernel(Geom g, TileWs w) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) vt_light_kernel(Geom g, TileWs w) {
     __shared__ unsigned short s_cnt[CELLS];                 // points per cell, then first slot of the cell
     __shared__ int s_segs[64], s_segp[65];                  // per chunk: start of the tile's segment, exclusive prefix of lengths
     __shared__ float4 s_rec[LIGHT * 2];                     // the tile's records in (cell, id) order
@@ -279,11 +279,10 @@ __global__ void __launch_bounds__(64) vt_light_kernel(Geom g, TileWs w) {
         const int j = lane + 64 * k;
         cell[k] = 0;
         if (j < n) {
-            int lo = 0, hi = 64;
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (s_segp[mid] <= j) lo = mid; else hi = mid;
-            }
+            int lo = 0;                                     // largest chunk whose prefix is <= j (prefixes beyond NC equal n)
+#pragma unroll
+            for (int st = 32; st > 0; st >>= 1)
+                if (s_segp[lo + st] <= j) lo += st;
             const size_t idx = rec0 + (size_t)lo * CHUNK + s_segs[lo] + (j - s_segp[lo]);
             ra[k] = w.recs[idx * 2];
             rb[k] = w.recs[idx * 2 + 1];
@@ -301,14 +300,14 @@ __global__ void __launch_bounds__(64) vt_light_kernel(Geom g, TileWs w) {
         pos[k] = before + rank;
         wave_sync();
     }
-    // cell starts: lane L owns the z-column of cells 16 L .. 16 L + 15
-    int cnt16[16], start16[16];
+    // cell starts: lane L owns the z-column of cells 16 L .. 16 L + 15 (counts are re-read from LDS instead of being kept in
+    // register arrays: indexed arrays end up in scratch memory)
     int tot = 0, occ = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        cnt16[i] = s_cnt[16 * lane + i];
-        tot += cnt16[i];
-        occ += cnt16[i] > 0 ? 1 : 0;
+        const int c = s_cnt[16 * lane + i];
+        tot += c;
+        occ += c > 0 ? 1 : 0;
     }
     int packed = (occ << 16) | tot, pincl = packed;
 #pragma unroll
@@ -317,14 +316,17 @@ __global__ void __launch_bounds__(64) vt_light_kernel(Geom g, TileWs w) {
         if (lane >= o) pincl += t;
     }
     const int nocc = __shfl(pincl, 63, 64) >> 16;
-    int run = (pincl - packed) & 0xFFFF;
+    const int lane_start = (pincl - packed) & 0xFFFF;
     const int occ_before = (pincl - packed) >> 16;
     wave_sync();
+    {
+        int run = lane_start;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        start16[i] = run;
-        s_cnt[16 * lane + i] = (unsigned short)run;
-        run += cnt16[i];
+        for (int i = 0; i < 16; ++i) {
+            const int c = s_cnt[16 * lane + i];
+            s_cnt[16 * lane + i] = (unsigned short)run;
+            run += c;
+        }
     }
     // dense slots of this sample's compact list (order across tiles is arbitrary: every record carries its cell address)
     int rbase = 0;
@@ -343,13 +345,15 @@ __global__ void __launch_bounds__(64) vt_light_kernel(Geom g, TileWs w) {
     const int tz = tile % w.Tz, ty = (tile / w.Tz) % w.Ty, tx = tile / (w.Tz * w.Ty);
     float4* res = w.res + (size_t)b * w.NP * 2;
     int slot = rbase + occ_before;
-#pragma unroll
+    const int lane_end = lane_start + tot;
+#pragma unroll 1
     for (int i = 0; i < 16; ++i) {
-        const int cnt = cnt16[i];
+        const int st = s_cnt[16 * lane + i];
+        const int cnt = (i < 15 ? (int)s_cnt[16 * lane + i + 1] : lane_end) - st;
         if (cnt > 0) {
             float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                // zeros_like(self._flat_output) (:145)
             for (int k = 0; k < cnt; ++k) {
-                const float4 a = s_rec[2 * (start16[i] + k)], c4 = s_rec[2 * (start16[i] + k) + 1];
+                const float4 a = s_rec[2 * (st + k)], c4 = s_rec[2 * (st + k) + 1];
                 const float r[7] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z};
 #pragma unroll
                 for (int c = 0; c < 3 + F; ++c) acc[c] = __fadd_rn(acc[c], r[c]);
@@ -518,12 +522,12 @@ __global__ void __launch_bounds__(256) vt_heavy_kernel(Geom g, TileWs w, int all
                 float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // zeros_like(self._flat_output) (:145)
                 const float4* sp = sorted + (size_t)start * 2;
                 int k = 0;
-                for (; k + 4 <= cnt; k += 4) {                              // four records in flight, added in order
-                    float4 a[4], c4[4];
+                for (; k + 8 <= cnt; k += 8) {                              // eight records in flight, added in order
+                    float4 a[8], c4[8];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) { a[u] = sp[(k + u) * 2]; c4[u] = sp[(k + u) * 2 + 1]; }
+                    for (int u = 0; u < 8; ++u) { a[u] = sp[(k + u) * 2]; c4[u] = sp[(k + u) * 2 + 1]; }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < 8; ++u) {
                         const float r[7] = {a[u].x, a[u].y, a[u].z, a[u].w, c4[u].x, c4[u].y, c4[u].z};
 #pragma unroll
                         for (int c = 0; c < 3 + F; ++c) acc[c] = __fadd_rn(acc[c], r[c]);
