@@ -20,11 +20,11 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=o
 # scheduler choice per source, measured on the kernels' own micro-benchmarks (tools/bench_*.py)
 _MINREG = ['-mllvm', '-amdgpu-sched-strategy=iterative-minreg']
 PER_FILE_FLAGS = {
-    # bf16x3, B = 4, S = 100: weight gradient 2x8x8 tiles 278 -> 301 TF/s (19 instead of 24 spilled VGPRs; 26.5 -> 24.2 ms
-    # in the step); the 4x4x8 tiles (wgrad_halo_t44.hip) lose 5 % with it and keep the default.  conv_halo_bf16.hip: + 1-2 %
-    # on the dense kernels but - 5 % on the tap-list variant -> default.  max-ilp: c1_conv.hip - 9 %, others neutral.
+    # weight gradient, 2x8x8 tiles: the same register count with either scheduler since round 2 (no spills); minreg kept.
+    # The 4x4x8 unit (wgrad_halo_t44.hip) spills 2 VGPRs with minreg and none with the default scheduler -- and a scratch
+    # reload in the prefetch section is an s_waitcnt vmcnt(0), see wgrad_halo.hip -- so it takes the default.
+    # conv_halo_bf16.hip: + 1-2 % on the dense kernels but - 5 % on the tap-list variant -> default.  max-ilp: c1_conv.hip - 9 %.
     'wgrad_halo.hip': _MINREG,
-    'wgrad_halo_t44.hip': _MINREG,      # in the step (B = 16, tap lists): 13.65 -> 12.8 ms, although the B = 4 micro-benchmark lost 5 %
 }
 
 

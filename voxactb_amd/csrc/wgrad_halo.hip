@@ -111,61 +111,65 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    long long t_begin = (long long)bz * g.tiles_per_split;
-    long long t_end = t_begin + g.tiles_per_split;
-    if (t_end > g.ntiles) t_end = g.ntiles;
+    const int t_begin = bz * g.tiles_per_split;
+    const int t_end = (int)min((long long)t_begin + g.tiles_per_split, g.ntiles);
 
     float4 px[NXL], pd[NDL];
-    auto issue = [&](long long tile) {
-        long long t = tile;
-        const int tw = (int)(t % g.ntw); t /= g.ntw;
-        const int th = (int)(t % g.nth); t /= g.nth;
-        const int td = (int)(t % g.ntd); t /= g.ntd;
-        const int b = (int)t;
+    unsigned okm = 0;                  // bit i: x load i is real data (not zero padding / a slot past the halo); bit 8 + i: dY load i
+    // dY addressing without a branch on the layout: fine-grid extent, voxel step and phase offsets (1 / 0 without d2s)
+    const int ds_ = g.d2s_s > 0 ? g.d2s_s : 1;
+    const int Vf = S * ds_;
+    const long long dy_row = g.d2s_s > 0 ? (long long)g.d2s_C : g.ldy;
+    const float* __restrict__ dyb = g.dy + (g.d2s_s > 0 ? 0 : n0);
+    const int Sm = g.S_in - 1;
+    // Every load is unconditional (clamped address + a mask bit) and the per-thread slot decomposition is recomputed from an
+    // opaque copy of the thread id on every call.  As loop invariants the ~40 values were hoisted out of the tile loop, kept
+    // live across it and spilled -- and every scratch reload in here is an s_waitcnt vmcnt(0) that drains the prefetch
+    // loads issued before it: the 15 loads of a tile arrived one at a time (half of the kernel's time was that wait).
+    auto issue = [&](int tile) {
+        int t = tile;
+        const int tw = t % g.ntw; t /= g.ntw;
+        const int th = t % g.nth; t /= g.nth;
+        const int td = t % g.ntd; t /= g.ntd;
+        const int b = t;
         const int d0 = td * WTD, h0 = th * WTH, w0 = tw * WTW;
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));
+        unsigned m = 0;
 #pragma unroll
         for (int i = 0; i < NXL; ++i) {
-            const int e = tid + 256 * i;
+            const int e = tid_ + 256 * i;
             int p = e >> 2;
             const int c4 = (e & 3) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p < XSLOTS) {
-                const int hw = p % XW; p /= XW;
-                const int hh = p % XH; p /= XH;
-                int id = d0 + p + g.off, ih = h0 + hh + g.off, iw = w0 + hw + g.off;
-                bool ok = true;
-                if (g.replicate) {
-                    id = min(max(id, 0), g.S_in - 1); ih = min(max(ih, 0), g.S_in - 1); iw = min(max(iw, 0), g.S_in - 1);
-                } else {
-                    ok = id >= 0 && id < g.S_in && ih >= 0 && ih < g.S_in && iw >= 0 && iw < g.S_in;
-                }
-                if (ok) v = *reinterpret_cast<const float4*>(src + ((((long long)b * g.S_in + id) * g.S_in + ih) * g.S_in + iw) * Cs + c0 + c4);
-            }
-            px[i] = v;
+            bool ok = p < XSLOTS;
+            p = min(p, XSLOTS - 1);
+            const int hw = p % XW; p /= XW;
+            const int hh = p % XH; p /= XH;
+            const int id = d0 + p + g.off, ih = h0 + hh + g.off, iw = w0 + hw + g.off;
+            const int cd = min(max(id, 0), Sm), ch = min(max(ih, 0), Sm), cw = min(max(iw, 0), Sm);
+            ok = ok && (g.replicate || (cd == id && ch == ih && cw == iw));
+            m |= (ok ? 1u : 0u) << i;
+            const int vox = ((b * g.S_in + cd) * g.S_in + ch) * g.S_in + cw;
+            px[i] = *reinterpret_cast<const float4*>(src + (long long)vox * Cs + c0 + c4);
         }
 #pragma unroll
         for (int i = 0; i < NDL; ++i) {
-            const int e = tid + 256 * i;
+            const int e = tid_ + 256 * i;
             const int pos = e >> 4, n4 = (e & 15) * 4;
             const int od = d0 + pos / (WTH * 8), oh = h0 + ((pos >> 3) % WTH), ow = w0 + (pos & 7);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (od < S && oh < S && ow < S) {
-                if (g.d2s_s > 0) {
-                    const int s = g.d2s_s;
-                    const long long Vf = (long long)S * s;
-                    v = *reinterpret_cast<const float4*>(g.dy + ((((long long)b * Vf + od * s + rd) * Vf + oh * s + rh) * Vf + ow * s + rw) * g.d2s_C + n4);
-                } else {
-                    v = *reinterpret_cast<const float4*>(g.dy + ((((long long)b * S + od) * S + oh) * S + ow) * g.ldy + n0 + n4);
-                }
-            }
-            pd[i] = v;
+            const bool ok = od < S && oh < S && ow < S;
+            m |= (ok ? 1u : 0u) << (8 + i);
+            const int vox = ((b * Vf + min(od, S - 1) * ds_ + rd) * Vf + min(oh, S - 1) * ds_ + rh) * Vf + min(ow, S - 1) * ds_ + rw;
+            pd[i] = *reinterpret_cast<const float4*>(dyb + (long long)vox * dy_row + n4);
         }
+        okm = m;
     };
     auto stage = [&]() {
 #pragma unroll
         for (int i = 0; i < NXL; ++i) {
             const int e = tid + 256 * i;
             if ((e >> 2) < XSLOTS) {
+                if (!((okm >> i) & 1u)) px[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 uint2 pk;
                 pk.x = wh_pack2(px[i].x, px[i].y); pk.y = wh_pack2(px[i].z, px[i].w);
                 *reinterpret_cast<uint2*>(&xs[(e >> 2) * 16 + (e & 3) * 4]) = pk;
@@ -180,6 +184,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
 #pragma unroll
         for (int i = 0; i < NDL; ++i) {
             const int e = tid + 256 * i;
+            if (!((okm >> (8 + i)) & 1u)) pd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             uint2 pk;
             pk.x = wh_pack2(pd[i].x, pd[i].y); pk.y = wh_pack2(pd[i].z, pd[i].w);
             *reinterpret_cast<uint2*>(&ds[(e >> 4) * DLD + (e & 15) * 4]) = pk;
@@ -215,7 +220,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
     }
 
     if (t_begin < t_end) issue(t_begin);
-    for (long long tile = t_begin; tile < t_end; ++tile) {
+    for (int tile = t_begin; tile < t_end; ++tile) {
         __syncthreads();                 // every wave is done reading the previous tile
         stage();
         __syncthreads();
@@ -233,27 +238,32 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
                 bh[j] = wh_frag(db0 + 16 * j, db1 + 16 * j);
                 if (X3) bl[j] = wh_frag(db0 + DPL + 16 * j, db1 + DPL + 16 * j);
             }
-            // the A fragments of tap ti+1 are read while the 12 MFMAs of tap ti run (a wave's slot past the end re-reads the
-            // last active tap and its accumulator is never stored)
+            // The A fragments of tap ti+1 are read while the MFMAs of tap ti run (a wave's slot past the end re-reads the last
+            // active tap and its accumulator is never stored): the hi fragment into a second register set before the tap's
+            // first MFMA, the lo fragment back into its own registers as soon as the tap's four lo * hi products have issued
+            // -- 12 / 8 MFMAs of cover for the LDS round trip at 4 extra VGPRs (a full second set of both does not fit in 256
+            // without spilling; without the barriers the scheduler sinks the reads below the MFMAs and every tap starts on
+            // s_waitcnt lgkmcnt(0)).
             bf16x8 ah = wh_frag(xa0 + toffs[0], xa1 + toffs[0]);
             bf16x8 al = X3 ? wh_frag(xa0 + XPL + toffs[0], xa1 + XPL + toffs[0]) : ah;
 #pragma unroll
             for (int ti = 0; ti < 7; ++ti) {
                 if (ti >= nti) break;    // uniform: a phase with 8 / 12 / 18 active taps runs 2 / 3 / 5 slots
-                bf16x8 ahn = ah, aln = al;
-                if (ti + 1 < 7) {
-                    ahn = wh_frag(xa0 + toffs[ti + 1], xa1 + toffs[ti + 1]);
-                    if (X3) aln = wh_frag(xa0 + XPL + toffs[ti + 1], xa1 + XPL + toffs[ti + 1]);
-                }
+                bf16x8 ahn = ah;
+                if (ti + 1 < 7) ahn = wh_frag(xa0 + toffs[ti + 1], xa1 + toffs[ti + 1]);
+                __builtin_amdgcn_sched_barrier(0);
                 if (X3) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[ti][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ti + 1 < 7) al = wh_frag(xa0 + XPL + toffs[ti + 1], xa1 + XPL + toffs[ti + 1]);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[ti][j], 0, 0, 0);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[ti][j], 0, 0, 0);
-                ah = ahn; al = aln;
+                ah = ahn;
             }
         }
     }
@@ -281,6 +291,7 @@ template <int X3, int TD, int TH>
 static int wgrad_halo_launch(WhArgs& g, int nsplit, hipStream_t st) {
     g.ntd = vxb_cdiv(g.S_out, TD); g.nth = vxb_cdiv(g.S_out, TH); g.ntw = vxb_cdiv(g.S_out, WTW);
     g.ntiles = (long long)g.B * g.ntd * g.nth * g.ntw;
+    if (g.ntiles >= INT32_MAX) return VXB_ESIZE;
     g.tiles_per_split = (int)((g.ntiles + nsplit - 1) / nsplit);
     const size_t lds = (size_t)(1 + X3) * ((TD + 2) * (TH + 2) * XW * 16 + DPL) * sizeof(u16);
     dim3 grid((g.C0 + g.C1) / 16, g.N / 64, nsplit);
@@ -299,13 +310,14 @@ int vxb_wgrad_halo_launch_t44(VxbWhArgs& g, int x3, int nsplit, hipStream_t st);
 
 static int g_wh_shape = -1;       // experiment knob (vxb_debug_set_wgrad_halo_shape): -1 = choose per grid, 0 / 1 = force
 
-// tile shape for a grid of extent S: 1 -> 4x4x8, 0 -> 2x8x8.  Measured at B = 4 (tools/bench_wgrad_halo.py): per tile the
-// 4x4x8 kernel is as fast in 'bf16' but ~10 % slower in 'bf16x3', so it is taken when it saves any edge voxels in bf16 and
-// only when it saves more than 10 % of them in x3 (S = 20: 20x20x24 vs 20x24x24 yes; S = 100: 100x100x104 vs 100x104x104 no).
+// tile shape for a grid of extent S: 1 -> 4x4x8, 0 -> 2x8x8.  Per tile the 4x4x8 kernel is the faster one in both precisions
+// (its halo is 360 instead of 400 voxels; B = 4, S = 100, tools/bench_wgrad_halo.py: 378 vs 348 TF/s in 'bf16x3', 694 vs 601 in
+// 'bf16'), so it is taken unless it pads the grid more (S = 100: 100x100x104 vs 100x104x104, S = 20: 20x20x24 vs 20x24x24).
 static inline int wgrad_halo_shape(int S, int x3) {
+    (void)x3;
     if (g_wh_shape >= 0) return g_wh_shape;
     const long long a = (long long)vxb_cdiv(S, 2) * 2 * vxb_cdiv(S, 8) * 8, b = (long long)vxb_cdiv(S, 4) * 4 * vxb_cdiv(S, 4) * 4;
-    return x3 ? (b * 10 < a * 9) : (b < a);
+    return b <= a;
 }
 
 static int wgrad_halo_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out, int off,
@@ -320,6 +332,10 @@ static int wgrad_halo_impl(int x3, const float* src0, const float* src1, int C0,
     g.off = off; g.replicate = replicate; g.N = N; g.Krows = 27 * (C0 + C1); g.ldy = ldy; g.d2s_s = d2s_s; g.d2s_C = d2s_C;
     g.phase_mask = phase_mask;
     if (nsplit > 65535 || N / 64 > 65535) return VXB_ESIZE;
+    {   // voxel indices are 32-bit inside the kernel
+        const long long vf = (long long)S_out * (d2s_s > 0 ? d2s_s : 1);
+        if ((long long)B * S_in * S_in * S_in >= INT32_MAX || (long long)B * vf * vf * vf >= INT32_MAX) return VXB_ESIZE;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (wgrad_halo_shape(S_out, x3)) return vxb_wgrad_halo_launch_t44(g, x3, nsplit, st);
     return x3 ? wgrad_halo_launch<1, 2, 8>(g, nsplit, st) : wgrad_halo_launch<0, 2, 8>(g, nsplit, st);
