@@ -26,7 +26,13 @@ def main():
     if os.environ.get('HALO_WAVES'):
         from voxactb_amd import _lib
         _lib.lib().vxb_debug_set_halo_waves(int(os.environ['HALO_WAVES']))
-    B, S = 4, 100
+    if os.environ.get('HALO_DBG'):      # timing experiments (results are wrong): 1 = stage the first chunk only, 2 = B fragments of 3 taps only
+        from voxactb_amd import _lib
+        _lib.lib().vxb_debug_set_halo_experiment(int(os.environ['HALO_DBG']))
+    if os.environ.get('HALO_WN'):
+        from voxactb_amd import _lib
+        _lib.lib().vxb_debug_set_halo_wn(int(os.environ['HALO_WN']))
+    B, S = int(os.environ.get('HALO_B', 4)), 100
     x0 = torch.randn(B, S, S, S, 64, device=dev)
     x1 = torch.randn(B, S, S, S, 64, device=dev)
     wf32 = torch.randn(64, 27 * 128, device=dev) * 0.05

@@ -62,6 +62,7 @@ struct HaloArgs {
     float* fold_dst[2];
     const float* fold_y[2];  // != nullptr: multiply by LeakyReLU'(y) (the producer's activation)
     int fold_acc[2];         // 1: dst += ..., 0: dst = ...
+    int dbg;                 // timing experiments only (vxb_debug_set_halo_experiment): results are WRONG when != 0
 };
 
 // bf16 pair from two fp32 (RNE).  Both forms give identical bits; which one is FASTER was measured per precision on the
@@ -76,21 +77,25 @@ __device__ __forceinline__ unsigned hb_pack2(float lo, float hi) {
     return (a >> 16) | (b & 0xffff0000u);
 }
 
-template <int NT, int X3, int NW, int WD, int TL = 0>   // NT = N / 32 column tiles per wave; NW waves share the 8 M tiles (4 -> 2
-                                              // each, 8 -> 1 each); WD: B fragments straight from global (pre-shuffled
-                                              // weights); TL: per-chunk tap lists (block-sparse weights, WD only)
+template <int NTG, int X3, int NW, int WD, int TL = 0, int WN = 1>
+                                              // NTG = N / 32 column tiles per workgroup; the NW waves form a (NW / WN) x WN grid over
+                                              // (8 M tiles) x (NTG column tiles): 4 x 1 -> 2 M tiles x 2 column tiles per wave,
+                                              // 2 x 2 -> 4 x 1 (half the B-fragment traffic per MFMA, twice the A reads from LDS),
+                                              // 8 x 1 -> 1 x 2; WD: B fragments straight from global (pre-shuffled weights); TL:
+                                              // per-chunk tap lists (block-sparse weights, WD only)
 __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
-    constexpr int NTH = NW * 64, MTW = 8 / NW;
+    constexpr int NTH = NW * 64, MTW = 8 / (NW / WN), NT = NTG / WN;
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* halo = smem;                               // [HALO_SLOTS][SP]
     u16* wsm = smem + HALO_SLOTS * SP;              // [2][N][LDW]
-    constexpr int N = NT * 32;
+    constexpr int N = NTG * 32;
     constexpr int CPC = X3 ? 16 : 32;               // channels per chunk
     constexpr int F4P = CPC / 4;                    // float4 per voxel per chunk
     constexpr int NLD = (NPOS * F4P + NTH - 1) / NTH;   // halo float4 loads per thread per chunk (10 / 19)
     constexpr int W_V8 = (N * 4 + NTH - 1) / NTH;              // 16-byte weight loads per thread per tap (1 / 2)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int hi = lane >> 5, lq = lane & 31;
+    const int wm = wid / WN, wn = wid % WN;          // this wave's row of M tiles / its first column tile is wn * NT
     // XCD-aware order (workgroup id b runs on XCD b % 8, each with a private L2): give every XCD a contiguous run of
     // tiles so that neighbouring tiles share their halo overlap through one L2.  Bijective for any grid size.
     int t;
@@ -123,7 +128,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
     int abase[MTW];
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
-        const int mt = wid * MTW + i;
+        const int mt = wm * MTW + i;
         abase[i] = (((mt >> 1) * HHp + (lq >> 2)) * HWp + (mt & 1) * 4 + (lq & 3)) * SP + 8 * hi;
     }
     const int wrow = lq * LDW + 8 * hi;            // B-operand row of this lane inside a weight tile (+ nt*32*LDW)
@@ -199,8 +204,8 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
         const u16* wcur = wsm + (tap & 1) * N * LDW;                                                                 \
         bf16x8 bfr[NT][2];                                                                                           \
         _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                              \
-            bfr[j][0] = *reinterpret_cast<const bf16x8*>(&wcur[j * 32 * LDW + wrow]);                                \
-            bfr[j][1] = *reinterpret_cast<const bf16x8*>(&wcur[j * 32 * LDW + wrow + 16]);                           \
+            bfr[j][0] = *reinterpret_cast<const bf16x8*>(&wcur[(wn * NT + j) * 32 * LDW + wrow]);                                \
+            bfr[j][1] = *reinterpret_cast<const bf16x8*>(&wcur[(wn * NT + j) * 32 * LDW + wrow + 16]);                           \
         }                                                                                                            \
         if (tap + 1 < 27) {                                                                                          \
             HB_STORE_W(RS, (tap + 1) & 1)                                                                            \
@@ -229,9 +234,10 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
     int tapbase = 0, ntap = 27, taplist = 0;      // TL: first row of this chunk in wfrag, its tap count, lane n = n-th tap's LDS offset
     const long long wf_rows = TL ? g.tap_total : (long long)nchunk * 27;
 #define HD_LOADB(BQ, tap_)                                                                                           \
+    if (!(g.dbg & 2) || (tap_) < 3)                                                                                   \
     _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                    \
     _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                     \
-        BQ[j][f] = *reinterpret_cast<const bf16x8*>(g.wfrag + (((long long)(n0 / N) * wf_rows + (TL ? tapbase : ch * 27) + (tap_)) * (NT * 2) + j * 2 + f) * 512 + lane * 8);
+        BQ[j][f] = *reinterpret_cast<const bf16x8*>(g.wfrag + (((long long)(n0 / N) * wf_rows + (TL ? tapbase : ch * 27) + (tap_)) * (NTG * 2) + (wn * NT + j) * 2 + f) * 512 + lane * 8);
 #define HB_READ_A_OFF(AF, off_)                                                                                      \
     {                                                                                                                \
         const int toff_ = (off_);                                                                                    \
@@ -282,19 +288,36 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][0], BC[j][0], acc[i][j], 0, 0, 0);             \
     }
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const int cb = ch * CPC;
-        const bool second = cb >= g.C0;
+    // (Measured and rejected, round 2: fetching the halo of chunk ch + 1 into registers during the taps of chunk ch -- 40 more
+    // VGPRs in 'bf16x3', no spills -- is 3.6 % SLOWER.  The vector L1 returns data in request order for the whole CU, so HBM-latency
+    // halo loads in the middle of a tap loop hold up the L2-hit B-fragment loads of both resident workgroups.)
+    constexpr bool PF = false;
+    float4 hv[NLD];
+    auto halo_issue = [&](int ch_) {
+        const int cb_ = ch_ * CPC;
+        const bool second = cb_ >= g.C0;
         const float* src = second ? g.src1 : g.src0;
         int Cs = second ? g.C1 : g.C0;
-        int c0 = second ? cb - g.C0 : cb;
+        int c0 = second ? cb_ - g.C0 : cb_;
         long long vbase = bvox;
         if (g.s2d_s > 0) {
-            const int ph = cb / g.s2d_C;
-            c0 = cb - ph * g.s2d_C;
+            const int ph = cb_ / g.s2d_C;
+            c0 = cb_ - ph * g.s2d_C;
             Cs = g.s2d_C;
             vbase += ((long long)(ph / (sm * sm)) * Vin + (ph / sm) % sm) * Vin + ph % sm;
         }
+        const bool dbg_skip_stage = (g.dbg & 1) && ch_ > 0;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            hv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (st_goff[i] >= 0 && !dbg_skip_stage)
+                hv[i] = *reinterpret_cast<const float4*>(src + (vbase + st_goff[i]) * Cs + c0 + (((tid + NTH * i) % F4P) * 4));
+        }
+    };
+    if (PF) halo_issue(0);
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int cb = ch * CPC;
+        const bool dbg_skip_stage = (g.dbg & 1) && ch > 0;
         if (TL) {
             const int ph = cb / g.s2d_C;
             const int cls = __builtin_amdgcn_readfirstlane(ttab[g.ncls * 32 + 2 * ph]);
@@ -304,13 +327,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
             tapbase = pre + (ch - ph * (g.s2d_C / CPC)) * ntap;
         }
         // ---- fetch the halo of this chunk (all loads in flight together), then convert + store
-        float4 hv[NLD];
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            hv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (st_goff[i] >= 0)
-                hv[i] = *reinterpret_cast<const float4*>(src + (vbase + st_goff[i]) * Cs + c0 + (((tid + NTH * i) % F4P) * 4));
-        }
+        if (!PF) halo_issue(ch);
         if (!WD) {
             HB_LOAD_W(rw0, 0)
             HB_LOAD_W(rw1, 1)
@@ -322,7 +339,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
         }
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            if (st_goff[i] != -1) {
+            if (st_goff[i] != -1 && !dbg_skip_stage) {
                 uint2 pk;
                 pk.x = hb_pack2<X3>(hv[i].x, hv[i].y); pk.y = hb_pack2<X3>(hv[i].z, hv[i].w);
                 *reinterpret_cast<uint2*>(&halo[st_soff[i]]) = pk;
@@ -366,6 +383,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
             for (int tp = 0; tp < 24; tp += 6) {
                 HD_TAP(tp, bq0, bq2, afa, afb)
                 HD_TAP(tp + 1, bq1, bq0, afb, afa)
+                if (PF && tp == 0 && ch + 1 < nchunk) halo_issue(ch + 1);
                 HD_TAP(tp + 2, bq2, bq1, afa, afb)
                 HD_TAP(tp + 3, bq0, bq2, afb, afa)
                 HD_TAP(tp + 4, bq1, bq0, afa, afb)
@@ -385,13 +403,13 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
-            const int mt = wid * MTW + i;
+            const int mt = wm * MTW + i;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
                 const int pos = ((mt >> 1) * TH + (m >> 2)) * TW + (mt & 1) * 4 + (m & 3);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) ft[pos * 64 + j * 32 + lq] = acc[i][j][r];
+                for (int j = 0; j < NT; ++j) ft[pos * 64 + (wn * NT + j) * 32 + lq] = acc[i][j][r];
             }
         }
         __syncthreads();
@@ -434,7 +452,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
     // ---- epilogue: acc[i][j][r] = C[voxel row (r&3) + 8*(r>>2) + 4*hi of M tile i][channel j*32 + lq]
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
-        const int mt = wid * MTW + i;
+        const int mt = wm * MTW + i;
         const int od = d0 + (mt >> 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -452,7 +470,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
                 }
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    const int n = n0 + j * 32 + lq;
+                    const int n = n0 + (wn * NT + j) * 32 + lq;
                     float v = acc[i][j][r] + (g.bias ? g.bias[n] : 0.f);
                     if (g.act == 1) v = v > 0.f ? v : v * g.slope;
                     op[n] = v;
@@ -464,16 +482,19 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
 
 inline bool hb_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-int g_halo_waves = 4;        // experiment knob (vxb_debug_set_halo_waves): 4 waves x 2 M tiles or 8 waves x 1 M tile per workgroup
+int g_halo_waves = 4;
+int g_halo_dbg = 0;
+int g_halo_wn = 0;         // experiment knob (vxb_debug_set_halo_wn): waves along N in the WD kernels, 1 or 2; 0 = default (2 in
+                          // 'bf16x3': B = 16, S = 100 forward 21.1 -> 19.9 ms, data gradient 21.8 -> 21.1 ms; 1 in 'bf16': no difference)        // experiment knob (vxb_debug_set_halo_waves): 4 waves x 2 M tiles or 8 waves x 1 M tile per workgroup
 
-template <int NT, int X3, int NW, int WD, int TL = 0>
+template <int NT, int X3, int NW, int WD, int TL = 0, int WN = 1>
 int hb_launch(const HaloArgs& g, long long nblk, hipStream_t st) {
     // (the fold epilogue re-uses the buffer as an fp32 [256][64] tile: keep the full size in every variant)
     const size_t lds = (size_t)(HALO_SLOTS * SP + 2 * NT * 32 * LDW) * sizeof(u16);
     if (TL && (size_t)(g.ncls * 32 + g.nphase * 2) * sizeof(int) > (size_t)2 * NT * 32 * LDW * sizeof(u16)) return VXB_ESIZE;
-    if (hipFuncSetAttribute((const void*)conv3_halo_kernel<NT, X3, NW, WD, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv3_halo_kernel<NT, X3, NW, WD, TL, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VXB_ELAUNCH;
-    hipLaunchKernelGGL((conv3_halo_kernel<NT, X3, NW, WD, TL>), dim3((unsigned)(nblk * (g.N / (NT * 32)))), dim3(NW * 64), lds, st, g);
+    hipLaunchKernelGGL((conv3_halo_kernel<NT, X3, NW, WD, TL, WN>), dim3((unsigned)(nblk * (g.N / (NT * 32)))), dim3(NW * 64), lds, st, g);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
@@ -492,6 +513,7 @@ int hb_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B,
     HaloArgs g;
     g.taptab = taptab; g.ncls = ncls; g.nphase = nphase; g.tap_total = tap_total;
     g.s2d_s = s2d_s; g.s2d_C = s2d_C; g.d2s_s = d2s_s; g.wfrag = (const u16*)wfrag;
+    g.dbg = g_halo_dbg;
     g.fold_pad = 0; g.fold_S = 0; g.fold_dst[0] = g.fold_dst[1] = nullptr; g.fold_y[0] = g.fold_y[1] = nullptr;
     g.fold_acc[0] = g.fold_acc[1] = 0;
     if (fold) {
@@ -507,7 +529,10 @@ int hb_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B,
     hipStream_t st = (hipStream_t)stream;
     // 64 output channels per workgroup (162-225 VGPRs -> two workgroups per CU); N = 128 runs two column blocks that each
     // stage the halo -- cheaper than the register spills of a 128-wide accumulator tile.
+    const int wn = g_halo_wn ? g_halo_wn : (x3 ? 2 : 1);
+    if (g.taptab && wn == 2) return x3 ? hb_launch<2, 1, 4, 1, 1, 2>(g, nblk, st) : hb_launch<2, 0, 4, 1, 1, 2>(g, nblk, st);
     if (g.taptab) return x3 ? hb_launch<2, 1, 4, 1, 1>(g, nblk, st) : hb_launch<2, 0, 4, 1, 1>(g, nblk, st);
+    if (g.wfrag && wn == 2) return x3 ? hb_launch<2, 1, 4, 1, 0, 2>(g, nblk, st) : hb_launch<2, 0, 4, 1, 0, 2>(g, nblk, st);
     if (g.wfrag) return x3 ? hb_launch<2, 1, 4, 1>(g, nblk, st) : hb_launch<2, 0, 4, 1>(g, nblk, st);
     if (g_halo_waves == 8) return x3 ? hb_launch<2, 1, 8, 0>(g, nblk, st) : hb_launch<2, 0, 8, 0>(g, nblk, st);
     return x3 ? hb_launch<2, 1, 4, 0>(g, nblk, st) : hb_launch<2, 0, 4, 0>(g, nblk, st);
@@ -516,6 +541,8 @@ int hb_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B,
 }  // namespace
 
 extern "C" void vxb_debug_set_halo_waves(int nw) { g_halo_waves = nw == 8 ? 8 : 4; }
+extern "C" void vxb_debug_set_halo_experiment(int bits) { g_halo_dbg = bits; }
+extern "C" void vxb_debug_set_halo_wn(int wn) { g_halo_wn = (wn == 1 || wn == 2) ? wn : 0; }
 
 // 3x3x3, stride-1 twin of vxb_conv3d_bf16w_f32 (same weights layout bf16 [N][27*(C0+C1)], same padding semantics:
 // src voxel = out + tap + off per axis); C0, C1 multiples of 32, N a multiple of 64.  out [B, S_out^3, N] is overwritten.
