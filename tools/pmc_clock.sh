@@ -8,5 +8,5 @@ for grp in "GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAI
     rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/$b-$tag -- python tools/bench_$b.py > $O/$b-$tag.log 2>&1
   done
 done
-python tools/pmc_clock.py $O > $O/summary.txt 2>&1
+python tools/pmc_clock.py $O 14 -v > $O/summary.txt 2>&1
 rm -rf $O/*/ ; tail -60 $O/summary.txt

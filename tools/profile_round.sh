@@ -12,6 +12,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmc_$c
 done
 rm -rf $O/prof
+# SQ counters of the same command: effective clock, matrix-pipe duty, issue / wait split per kernel
+for grp in "GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA"; do
+  tag=$(echo $grp | tr ' ' '_')
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/sq/$tag -- python bench.py --no-cpu-baseline --no-other-modes --steps 2 --warmup 1 > $O/sq_$tag.log 2>&1
+done
+python tools/pmc_clock.py $O/sq 24 > $O/sq_summary.txt 2>&1
+rm -rf $O/sq $O/sq_*.log
 head -14 $O/step_kernel_stats.txt | cut -c1-150
 head -8 $O/pmc_FETCH_SIZE_summary.txt | cut -c1-150
 python -c "

@@ -229,7 +229,9 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
     // fragment order: 1 KB per (tap, column tile, k half / plane), lane-contiguous -> fully coalesced, L1-shared by the
     // waves of the CU), two taps ahead in three rotating register sets.  No weight traffic through LDS and NO barrier
     // inside the 27-tap loop.
+    constexpr int BD = (WD && !TL && WN == 2) ? 4 : 2;      // B-fragment prefetch distance in taps
     bf16x8 bq0[NT][2], bq1[NT][2], bq2[NT][2];
+    bf16x8 bqr[BD + 1][NT][2];
     const int nchunk = Ct / CPC;
     int tapbase = 0, ntap = 27, taplist = 0;      // TL: first row of this chunk in wfrag, its tap count, lane n = n-th tap's LDS offset
     const long long wf_rows = TL ? g.tap_total : (long long)nchunk * 27;
@@ -269,6 +271,20 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
     if (TL) {
         for (int i = tid; i < g.ncls * 32 + g.nphase * 2; i += NTH) ttab[i] = g.taptab[i];
         __syncthreads();
+    }
+#define HD_MFMA(AC, BC)                                                                                              \
+    {                                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                               \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][1], BC[j][X3 ? 0 : 1], acc[i][j], 0, 0, 0);    \
+        if (X3) {                                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                           \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][0], BC[j][1], acc[i][j], 0, 0, 0);         \
+        }                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                               \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][0], BC[j][0], acc[i][j], 0, 0, 0);             \
     }
 #define HD_TAP(tap_, BC, BL, AC, AN)                                                                                 \
     {                                                                                                                \
@@ -333,8 +349,13 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
             HB_LOAD_W(rw1, 1)
             // (the barrier that ended the previous chunk's last tap already freed the halo and both weight buffers)
         } else {
-            HD_LOADB(bq0, 0)
-            HD_LOADB(bq1, 1)
+            if (BD == 2) {
+                HD_LOADB(bq0, 0)
+                HD_LOADB(bq1, 1)
+            } else {
+#pragma unroll
+                for (int t0 = 0; t0 < BD; ++t0) { HD_LOADB(bqr[t0], t0) }
+            }
             __syncthreads();                        // no per-tap barriers here: every wave must be done with the old halo
         }
 #pragma unroll
@@ -379,11 +400,10 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
                 HB_TAP(tp + 1, rw1, rw0, afb, afa)
             }
             HB_TAP(26, rw0, rw1, afa, afb)
-        } else {
+        } else if (BD == 2) {
             for (int tp = 0; tp < 24; tp += 6) {
                 HD_TAP(tp, bq0, bq2, afa, afb)
                 HD_TAP(tp + 1, bq1, bq0, afb, afa)
-                if (PF && tp == 0 && ch + 1 < nchunk) halo_issue(ch + 1);
                 HD_TAP(tp + 2, bq2, bq1, afa, afb)
                 HD_TAP(tp + 3, bq0, bq2, afb, afa)
                 HD_TAP(tp + 4, bq1, bq0, afa, afb)
@@ -392,6 +412,21 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
             HD_TAP(24, bq0, bq2, afa, afb)
             HD_TAP(25, bq1, bq0, afb, afa)
             HD_TAP(26, bq2, bq1, afa, afb)
+        } else {
+            // deeper B pipeline (2 x 2 wave layout: a set is 8 VGPRs): fragments arrive BD taps ahead in BD + 1 rotating sets
+#pragma unroll
+            for (int tp = 0; tp < 27; ++tp) {
+                if (tp + BD < 27) { HD_LOADB(bqr[(tp + BD) % (BD + 1)], tp + BD) }
+                if (tp & 1) {
+                    if (tp + 1 < 27) { HB_READ_A(afa, tp + 1) }
+                    __builtin_amdgcn_sched_barrier(0);
+                    HD_MFMA(afb, bqr[tp % (BD + 1)])
+                } else {
+                    if (tp + 1 < 27) { HB_READ_A(afb, tp + 1) }
+                    __builtin_amdgcn_sched_barrier(0);
+                    HD_MFMA(afa, bqr[tp % (BD + 1)])
+                }
+            }
         }
     }
     if (g.fold_pad > 0) {
