@@ -16,6 +16,8 @@ def main():
     dy = torch.randn(B, S, S, S, 64, device=dev)
     fl = 2.0 * B * S ** 3 * 64 * 27 * 128
     from voxactb_amd import _lib
+    if os.environ.get('WH_DBG'):       # timing experiments (wrong results): 1 = stage / prefetch the first tile only, 2 = no MFMA loop
+        _lib.lib().vxb_debug_set_wgrad_halo_experiment(int(os.environ['WH_DBG']))
     for mode in ('bf16', 'bf16x3'):
         for halo, shape in ((False, -1), (True, 0), (True, 1)):
             ops.HALO_CONV = halo

@@ -49,6 +49,7 @@ struct VxbWhArgs {
     int ntd, nth, ntw;
     long long ntiles;
     int tiles_per_split;
+    int dbg;                      // timing experiments only (vxb_debug_set_wgrad_halo_experiment); results are WRONG when != 0
     const unsigned* phase_mask;   // d2s: bit t of phase_mask[column block] clear -> that (tap, phase) weight block is
                                   // structurally zero (polyphase up-conv) and is neither computed nor stored
 };
@@ -219,12 +220,18 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
         toffs[ti] = (((tap / 9) * XH + (tap / 3) % 3) * XW + tap % 3) * 16;
     }
 
+    // (Timing experiments, round 2, B = 4, S = 100, 4x4x8 tiles, 'bf16x3': 4.75 ms as is; 3.25 ms with the staging of all but the
+    // first tile removed (g.dbg & 1: 545 TF/s, the ceiling of this MFMA loop); 1.70 ms with the MFMA loop removed (g.dbg & 2).
+    // The VALU work of issue() + stage() (~650 instructions per thread and tile) is not hidden behind the other resident
+    // workgroup's MFMAs -- the times add.  Delaying every second workgroup by 1-8 thousand cycles to break a possible
+    // lockstep of the two changed nothing.)
     if (t_begin < t_end) issue(t_begin);
     for (int tile = t_begin; tile < t_end; ++tile) {
         __syncthreads();                 // every wave is done reading the previous tile
-        stage();
+        if (!(g.dbg & 1) || tile == t_begin) stage();
         __syncthreads();
-        if (tile + 1 < t_end) issue(tile + 1);
+        if (tile + 1 < t_end && !(g.dbg & 1)) issue(tile + 1);
+        if (g.dbg & 2) continue;
 #pragma unroll 1
         for (int ks = 0; ks < 4; ++ks) {
             const int dd = ks / HB, hb = (ks % HB) * 4;
@@ -308,6 +315,7 @@ int vxb_wgrad_halo_launch_t44(VxbWhArgs& g, int x3, int nsplit, hipStream_t st) 
 #else
 int vxb_wgrad_halo_launch_t44(VxbWhArgs& g, int x3, int nsplit, hipStream_t st);
 
+static int g_wh_dbg = 0;
 static int g_wh_shape = -1;       // experiment knob (vxb_debug_set_wgrad_halo_shape): -1 = choose per grid, 0 / 1 = force
 
 // tile shape for a grid of extent S: 1 -> 4x4x8, 0 -> 2x8x8.  Per tile the 4x4x8 kernel is the faster one in both precisions
@@ -331,6 +339,7 @@ static int wgrad_halo_impl(int x3, const float* src0, const float* src1, int C0,
     g.src0 = src0; g.src1 = src1; g.dy = dy; g.part = part; g.C0 = C0; g.C1 = C1; g.B = B; g.S_in = S_in; g.S_out = S_out;
     g.off = off; g.replicate = replicate; g.N = N; g.Krows = 27 * (C0 + C1); g.ldy = ldy; g.d2s_s = d2s_s; g.d2s_C = d2s_C;
     g.phase_mask = phase_mask;
+    g.dbg = g_wh_dbg;
     if (nsplit > 65535 || N / 64 > 65535) return VXB_ESIZE;
     {   // voxel indices are 32-bit inside the kernel
         const long long vf = (long long)S_out * (d2s_s > 0 ? d2s_s : 1);
@@ -364,5 +373,6 @@ extern "C" size_t vxb_conv3_wgrad_halo_tiles(int B, int S_out, int x3) {
     return (size_t)B * vxb_cdiv(S_out, sh ? 4 : 2) * vxb_cdiv(S_out, sh ? 4 : 8) * vxb_cdiv(S_out, 8);
 }
 
+extern "C" void vxb_debug_set_wgrad_halo_experiment(int bits) { g_wh_dbg = bits; }
 extern "C" void vxb_debug_set_wgrad_halo_shape(int shape) { g_wh_shape = shape < 0 ? -1 : (shape ? 1 : 0); }
 #endif   // WH_T44_UNIT
