@@ -316,11 +316,13 @@ int vxb_sum_splits_f32(const float* part, int nsplit, int64_t n, float* dst, int
 int vxb_colsum_f32(const float* x, int64_t rows, int N, int64_t ld, float* part_ws, float* out, int accumulate,
                    vxb_stream_t stream);
 
-/* context assembly cat(lang, cat(patch, proprio)) + pos_encoding (perceiver_lang_io.py:370-422) and its adjoint. */
+/* context assembly cat(lang, cat(patch, proprio)) + pos_encoding (perceiver_lang_io.py:370-422) and its adjoint.  pp is
+   [B, Cp]: Cp = C for one proprio vector, 2 C for the right | left pair of the 2Robots encoder (perceiver_lang_io.py:721-727);
+   the context is C + Cp wide. */
 int vxb_ctx_build_f32(const float* lang, const float* patch, const float* pp, const float* pos, float* ctx, int B,
-                      int T0, int T1, int C, vxb_stream_t stream);
+                      int T0, int T1, int C, int Cp, vxb_stream_t stream);
 int vxb_ctx_bwd_f32(const float* dctx, float* dlang, float* dpatch, float* dpp, float* dpos, float* part_ws, int B,
-                    int T0, int T1, int C, vxb_stream_t stream);
+                    int T0, int T1, int C, int Cp, vxb_stream_t stream);
 
 /* cross-entropy (agent :517-578) + argmax (agent :57-80): one 10^6-way head, and up to 8 small heads per row. */
 int vxb_ce_big_f32(const float* x, int64_t P, int B, const int32_t* label, float* part_ws, float* lse, float* loss,

@@ -234,6 +234,53 @@ def encoder_fixture(name, cfg, arm=False, with_grads=True, digest=False, crop=Fa
     save(name, **arrs)
 
 
+
+# ----------------------------------------------------------------------------- F11: the 2Robots (one_policy_more_heads) encoder
+def encoder2_fixture(name, cfg):
+    """reference PerceiverVoxelLang2RobotsEncoder (perceiver_lang_io.py:488-860) forward + backward of the summed two-arm loss
+    (agent :1283-1363) on hashed weights: six outputs, loss, every parameter gradient's norm (small ones in full)."""
+    enc = ref_pl.PerceiverVoxelLang2RobotsEncoder(
+        depth=cfg['depth'], iterations=1, voxel_size=cfg['V'], initial_dim=10, low_dim_size=cfg['low_dim'],
+        num_latents=cfg['latents'], voxel_patch_size=cfg['k'], voxel_patch_stride=cfg['s'],
+        activation='lrelu', input_dropout=0.0, attn_dropout=0.0, decoder_dropout=0.0)
+    shapes = {n: tuple(p.shape) for n, p in enc.named_parameters()}
+    from voxactb_amd.agents.peract_bc.perceiver_lang_io import PerceiverVoxelLang2RobotsEncoder as Mine
+    mine = Mine(depth=cfg['depth'], iterations=1, voxel_size=cfg['V'], initial_dim=10, low_dim_size=cfg['low_dim'],
+                num_latents=cfg['latents'], voxel_patch_size=cfg['k'], voxel_patch_stride=cfg['s'], activation='lrelu',
+                input_dropout=0.0, attn_dropout=0.0, decoder_dropout=0.0)
+    assert [(n, tuple(p.shape)) for n, p in mine.named_parameters()] == list(shapes.items())      # names, shapes AND order
+    enc.load_state_dict(ow.hashed_state_dict(shapes, 0), strict=False)
+    enc.eval()
+    rs = batch_for(cfg, seed=1)
+    B, V = cfg['B'], cfg['V']
+    pcd = [rs['%s_point_cloud' % c] for c in cfg['cams']]
+    rgb = [rs['%s_rgb' % c] for c in cfg['cams']]
+    bounds = torch.tensor([synthetic.SCENE_BOUNDS])
+    coords, feats = ovox.flatten_cameras(pcd, rgb)
+    grid = ref_voxelize(coords, feats, bounds, V, B)
+    ins = grid.permute(0, 4, 1, 2, 3).detach()
+    proprio_left = ow.hashed_uniform('f11.proprio_left', (B, cfg['low_dim']), 0.0, 1.0)
+    trans_left = ow.hashed_int('f11.trans_left', (B, 3), 0, V)
+    rot_left = torch.cat((ow.hashed_int('f11.rot_left', (B, 3), 0, 72), ow.hashed_int('f11.grip_left', (B, 1), 0, 2)), 1)
+    outs = enc(ins, rs['low_dim_state'], proprio_left, rs['lang_goal_emb'], rs['lang_token_embs'], None, bounds, None)
+    tr, _ = oagent.losses(outs[0], outs[1], outs[2], rs['trans_action_indicies'], rs['rot_grip_action_indicies'], rs['ignore_collisions'])
+    tl, _ = oagent.losses(outs[3], outs[4], outs[5], trans_left, rot_left, rs['ignore_collisions'])
+    total = tr + tl              # mean over B of the sum of both arms' heads (agent :1365-1369)
+    total.backward()
+    arrs = dict(cfg_V=V, cfg_k=cfg['k'], cfg_s=cfg['s'], cfg_depth=cfg['depth'], cfg_latents=cfg['latents'],
+                cfg_low_dim=cfg['low_dim'], cfg_B=B, cfg_H=cfg['H'], cfg_W=cfg['W'], cfg_ncam=len(cfg['cams']),
+                grid=grid, proprio_left=proprio_left, trans_left=trans_left, rot_grip_left=rot_left,
+                q_trans_right=outs[0].detach(), rot_grip_right=outs[1], collision_right=outs[2],
+                q_trans_left=outs[3].detach(), rot_grip_left_out=outs[4], collision_left=outs[5], loss=total.detach())
+    arrs['grad_names'] = np.array([n for n, _ in enc.named_parameters()])
+    arrs['grad_norms'] = torch.stack([p.grad.norm() for _, p in enc.named_parameters()])
+    for n, p in enc.named_parameters():
+        if p.numel() <= 20000 and not n.startswith(('pos_encoding', 'latents')):
+            arrs['grad__' + n] = p.grad
+    print('%s: loss %.6f' % (name, float(total)))
+    save(name, **arrs)
+
+
 # ----------------------------------------------------------------------------- F6 / F9: agent-level
 def stub_modules():
     for name in ['torchvision', 'torchvision.transforms', 'pytorch3d', 'pytorch3d.transforms', 'pyrender',
@@ -523,6 +570,8 @@ SECTIONS = {
     'f5g': lambda: encoder_fixture('f5g_encoder_c2_grads', CFG_C2, with_grads=True, digest=True, f64_grads=True),
     'f5c3': lambda: encoder_fixture('f5c3_encoder_c3_digest', CFG_C3, arm=True, with_grads=True, digest=True, crop=True, f64_grads=True),
     'f5v200': lambda: encoder_fixture('f5v200_encoder_c5_digest', CFG_C5, with_grads=False, digest=True),
+    'f11tiny': lambda: encoder2_fixture('f11_encoder_2robots_tiny', CFG_TINY),
+    'f11c1': lambda: encoder2_fixture('f11_encoder_2robots_c1', CFG_C1),
     'f6': f6_update_traces,
     'f9': f9_act,
     'f10': f10_depth,

@@ -138,7 +138,8 @@ class PerceiverVoxelLangEncoder(nn.Module):
                  latent_dim=512, cross_heads=1, latent_heads=8, cross_dim_head=64, latent_dim_head=64, activation='relu',
                  weight_tie_layers=False, pos_encoding_with_lang=True, input_dropout=0.1, attn_dropout=0.1,
                  decoder_dropout=0.0, lang_fusion_type='seq', voxel_patch_size=9, voxel_patch_stride=8,
-                 no_skip_connection=False, no_perceiver=False, no_language=False, final_dim=64, arm_pred_loss=False):
+                 no_skip_connection=False, no_perceiver=False, no_language=False, final_dim=64, arm_pred_loss=False,
+                 _two_robots=False):
         super().__init__()
         if lang_fusion_type != 'seq' or not pos_encoding_with_lang or no_skip_connection or no_perceiver \
                 or weight_tie_layers or iterations != 1 or activation != 'lrelu' or low_dim_size <= 0 \
@@ -160,17 +161,19 @@ class PerceiverVoxelLangEncoder(nn.Module):
         self.input_dropout, self.attn_dropout, self.decoder_dropout = input_dropout, attn_dropout, decoder_dropout
         self.no_skip_connection, self.no_perceiver, self.no_language = no_skip_connection, no_perceiver, no_language
         self.arm_pred_loss = arm_pred_loss
+        self.two_robots = bool(_two_robots)       # one_policy_more_heads baseline (reference class PerceiverVoxelLang2RobotsEncoder)
         self.cross_heads, self.latent_heads = cross_heads, latent_heads
         self.cross_dim_head, self.latent_dim_head = cross_dim_head, latent_dim_head
         self.num_latents, self.latent_dim = num_latents, latent_dim
 
         spatial_size = voxel_size // voxel_patch_stride
-        self.input_dim_before_seq = im_channels * 2
+        # context width: patch features + one proprio embedding, or + the right and the left arm's (perceiver :547, :721-727)
+        self.input_dim_before_seq = im_channels * (3 if self.two_robots else 2)
         self.pos_encoding = nn.Parameter(torch.randn(1, LANG_MAX_SEQ_LEN + spatial_size ** 3, self.input_dim_before_seq))
         self.input_preprocess = Conv3DBlock(self.init_dim, im_channels, kernel_sizes=1, strides=1, activation=activation)
         self.patchify = Conv3DBlock(im_channels, im_channels, kernel_sizes=voxel_patch_size, strides=voxel_patch_stride,
                                     activation=activation)
-        self.lang_preprocess = nn.Linear(LANG_EMB_DIM, im_channels * 2)
+        self.lang_preprocess = nn.Linear(LANG_EMB_DIM, self.input_dim_before_seq)
         self.proprio_preprocess = DenseBlock(low_dim_size, im_channels, None, activation)
         self.ss0 = SpatialSoftmax3D(voxel_size, voxel_size, voxel_size, im_channels)
         flat_size = im_channels * 4
@@ -203,6 +206,14 @@ class PerceiverVoxelLangEncoder(nn.Module):
         if arm_pred_loss:
             self.dense2 = DenseBlock(flat_size, final_dim, None, activation)
             self.arm_ff = DenseBlock(final_dim, 2, None, None)
+        if self.two_robots:
+            # second head set on the same trunk (perceiver :668-690, same registration order)
+            self.trans_decoder_left_arm = Conv3DBlock(final_dim, 1, kernel_sizes=3, strides=1, activation=None)
+            self.ss_final_left_arm = SpatialSoftmax3D(voxel_size, voxel_size, voxel_size, im_channels)
+            self.dense0_left_arm = DenseBlock(flat_size, 256, None, activation)
+            self.dense1_left_arm = DenseBlock(256, final_dim, None, activation)
+            self.rot_grip_collision_ff_left_arm = DenseBlock(
+                final_dim, num_rotation_classes * 3 + num_grip_classes + num_collision_classes, None, None)
         self._engine = None
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -219,6 +230,35 @@ class PerceiverVoxelLangEncoder(nn.Module):
             raise NotImplementedError('attention mask is never passed by the agent')
         eng = self.engine()
         outs, _ = eng.forward(eng.to_channels_last(ins), proprio, lang_token_embs, training=False, save=False)
+        return outs
+
+
+class PerceiverVoxelLang2RobotsEncoder(PerceiverVoxelLangEncoder):
+    """The `one_policy_more_heads` baseline (reference perceiver_lang_io.py:488-860): one trunk for both arms -- context
+    tokens carry the patch features and BOTH arms' proprio embeddings (192 wide; `proprio_preprocess` is shared), and the
+    translation / rotation-gripper-collision heads exist twice (`*_left_arm`).  Same parameter names as the reference."""
+
+    def __init__(self, depth, iterations, voxel_size, initial_dim, low_dim_size, layer=0, num_rotation_classes=72,
+                 num_grip_classes=2, num_collision_classes=2, input_axis=3, num_latents=512, im_channels=64,
+                 latent_dim=512, cross_heads=1, latent_heads=8, cross_dim_head=64, latent_dim_head=64, activation='relu',
+                 weight_tie_layers=False, pos_encoding_with_lang=True, input_dropout=0.1, attn_dropout=0.1,
+                 decoder_dropout=0.0, lang_fusion_type='seq', voxel_patch_size=9, voxel_patch_stride=8,
+                 no_skip_connection=False, no_perceiver=False, no_language=False, final_dim=64):
+        super().__init__(depth, iterations, voxel_size, initial_dim, low_dim_size, layer, num_rotation_classes,
+                         num_grip_classes, num_collision_classes, input_axis, num_latents, im_channels, latent_dim,
+                         cross_heads, latent_heads, cross_dim_head, latent_dim_head, activation, weight_tie_layers,
+                         pos_encoding_with_lang, input_dropout, attn_dropout, decoder_dropout, lang_fusion_type,
+                         voxel_patch_size, voxel_patch_stride, no_skip_connection, no_perceiver, no_language, final_dim,
+                         arm_pred_loss=False, _two_robots=True)
+
+    def forward(self, ins, proprio_right, proprio_left, lang_goal_emb, lang_token_embs, prev_layer_voxel_grid, bounds,
+                prev_layer_bounds, mask=None):
+        """-> (trans_right, rot_and_grip_right, collision_right, trans_left, rot_and_grip_left, collision_left) (:860)."""
+        if mask is not None:
+            raise NotImplementedError('attention mask is never passed by the agent')
+        eng = self.engine()
+        outs, _ = eng.forward(eng.to_channels_last(ins), proprio_right, lang_token_embs, training=False, save=False,
+                              proprio_left=proprio_left)
         return outs
 
 
@@ -249,7 +289,8 @@ class PerceiverEngine:
         self.V = module.voxel_size
         self.G = self.V // s
         self.C = module.im_channels
-        self.Cx = 2 * self.C
+        self.Cx = module.input_dim_before_seq
+        self.two = bool(getattr(module, 'two_robots', False))
         self.D = module.latent_dim
         self.L = module.num_latents
         self.T0 = LANG_MAX_SEQ_LEN
@@ -407,17 +448,21 @@ class PerceiverEngine:
         return dx
 
     # -------------------------------------------------------------------------------------------------- forward
-    def forward(self, vox, proprio, lang_token_embs, training=False, save=True, seed=None):
-        """vox [B,V,V,V,10] channels-last.  Returns ((trans [B,1,V,V,V], rot_and_grip, collision[, arm]), cache)."""
+    def forward(self, vox, proprio, lang_token_embs, training=False, save=True, seed=None, proprio_left=None):
+        """vox [B,V,V,V,10] channels-last.  Returns ((trans [B,1,V,V,V], rot_and_grip, collision[, arm]), cache); for the
+        2Robots encoder `proprio` is the right arm's, `proprio_left` the left arm's, and the outputs are (trans_right,
+        rot_and_grip_right, collision_right, trans_left, rot_and_grip_left, collision_left)."""
         require_cuda(vox, proprio, lang_token_embs)
+        if self.two != (proprio_left is not None):
+            raise VoxactbHipError('proprio_left is given exactly for the 2Robots encoder')
         ops.new_step()
         ops.PRECISION = self.precision
         try:
-            return self._forward(vox, proprio, lang_token_embs, training, save, seed)
+            return self._forward(vox, proprio, lang_token_embs, training, save, seed, proprio_left)
         finally:
             ops.PRECISION = 'fp32'
 
-    def _forward(self, vox, proprio, lang_token_embs, training, save, seed):
+    def _forward(self, vox, proprio, lang_token_embs, training, save, seed, proprio_left=None):
         m = self.m
         B = vox.shape[0]
         V, G, C, Cx, D, L, T0, k, s = self.V, self.G, self.C, self.Cx, self.D, self.L, self.T0, self.k, self.s
@@ -430,6 +475,9 @@ class PerceiverEngine:
         p_at = m.attn_dropout if training else 0.0
         p_de = m.decoder_dropout if training else 0.0
         proprio = proprio.float().contiguous()
+        if self.two:
+            # both arms go through the ONE proprio_preprocess block (perceiver :721-727): rows [right | left]
+            proprio = torch.cat((proprio, proprio_left.float().contiguous()), dim=0)
         lang = lang_token_embs.float().contiguous().view(B * T0, LANG_EMB_DIM)
         c = {}
         # 1. input 1x1x1 conv + lrelu (perceiver :357)
@@ -442,7 +490,8 @@ class PerceiverEngine:
         # 4-6. proprio, language, context assembly (perceiver :370-422)
         pp = ops.linear(proprio, self.p('proprio_preprocess.linear.weight'), self.p('proprio_preprocess.linear.bias'), ops.ACT_LRELU)
         lg = ops.linear(lang, self.p('lang_preprocess.weight'), self.p('lang_preprocess.bias'))
-        ctx = ops.ctx_build(lg, patch, pp, self.p('pos_encoding'), B, T0, T1, C)
+        ppc = torch.cat((pp[:B], pp[B:]), dim=1) if self.two else pp          # [B, C] or [B, right C | left C]
+        ctx = ops.ctx_build(lg, patch, ppc, self.p('pos_encoding'), B, T0, T1, C)
         ctx2d = ctx.view(B * Nctx, Cx)
         # 7. latents
         x = self.p('latents').unsqueeze(0).expand(B, L, D).contiguous().view(B * L, D)
@@ -503,6 +552,16 @@ class PerceiverEngine:
         o = ops.linear(h1, self.p('rot_grip_collision_ff.linear.weight'), self.p('rot_grip_collision_ff.linear.bias'))
         nc = m.num_collision_classes
         outs = (q_trans.view(B, 1, V, V, V), o[:, :-nc], o[:, -nc:])
+        left = None
+        if self.two:
+            # left arm: its own translation conv and MLP head over the SAME pooled features (ss_final_left_arm(u) is
+            # ss_final(u): SpatialSoftmax3D has no parameters; perceiver :845-858)
+            q_left = ops.conv3_c1_fwd(u, self.p('trans_decoder_left_arm.conv3d.weight'), self.p('trans_decoder_left_arm.conv3d.bias'), B, V)
+            h0l = ops.linear(feats, self.p('dense0_left_arm.linear.weight'), self.p('dense0_left_arm.linear.bias'), ops.ACT_LRELU)
+            h1l = ops.linear(h0l, self.p('dense1_left_arm.linear.weight'), self.p('dense1_left_arm.linear.bias'), ops.ACT_LRELU)
+            ol = ops.linear(h1l, self.p('rot_grip_collision_ff_left_arm.linear.weight'), self.p('rot_grip_collision_ff_left_arm.linear.bias'))
+            outs = outs + (q_left.view(B, 1, V, V, V), ol[:, :-nc], ol[:, -nc:])
+            left = dict(h0=h0l, h1=h1l, o=ol)
         h2 = None
         if m.arm_pred_loss:
             h2 = ops.linear(feats, self.p('dense2.linear.weight'), self.p('dense2.linear.bias'), ops.ACT_LRELU)
@@ -510,7 +569,7 @@ class PerceiverEngine:
         if save:
             c.update(B=B, vox=vox, proprio=proprio, lang=lang, d0=d0, ss0=ss0, patch=patch, pp=pp, ctx2d=ctx2d,
                      dec=dict(qn=qn, qm=qm, qr=qr, ln=ln, lm=lm, lr=lr, x=x, attn=da), z=z, ss1=ss1, zc=zc, z1=z1,
-                     Weff=Weff, u0=u0, u=u, ss2=ss2, feats=feats, h0=h0, h1=h1, h2=h2, o=o)
+                     Weff=Weff, u0=u0, u=u, ss2=ss2, feats=feats, h0=h0, h1=h1, h2=h2, o=o, left=left)
         return outs, (c if save else None)
 
     # -------------------------------------------------------------------------------------------------- backward
@@ -518,24 +577,25 @@ class PerceiverEngine:
     # the module's registration order towards its start, so every bucket is one contiguous slice of the flat gradient buffer)
     def grad_buckets(self):
         out = [('tail', ['decoder_cross_attn.', 'up0.', 'final.', 'trans_decoder.', 'dense0.', 'dense1.',
-                         'rot_grip_collision_ff.', 'dense2.', 'arm_ff.'])]
+                         'rot_grip_collision_ff.', 'dense2.', 'arm_ff.', 'trans_decoder_left_arm.', 'dense0_left_arm.',
+                         'dense1_left_arm.', 'rot_grip_collision_ff_left_arm.'])]
         out += [('layers.%d' % i, ['layers.%d.' % i]) for i in reversed(range(self.m.depth))]
         out.append(('head', ['pos_encoding', 'latents', 'input_preprocess.', 'patchify.', 'lang_preprocess.',
                              'proprio_preprocess.', 'cross_attend_blocks.']))
         return out
 
-    def backward(self, c, dq_trans, d_o, d_arm=None, on_bucket_ready=None):
+    def backward(self, c, dq_trans, d_o, d_arm=None, on_bucket_ready=None, dq_trans_left=None, d_o_left=None):
         """dq_trans [B,V,V,V] (or [B,1,V,V,V]), d_o [B, 3*rot+grip+coll] (grad of the concatenated MLP head output),
         d_arm [B,2] or None.  Accumulates into every parameter's .grad.  `on_bucket_ready(name)` is called as soon as the
         last kernel that writes gradients of bucket `name` (see grad_buckets) has been enqueued."""
         ops.PRECISION = self.bwd_precision or self.precision
         self._on_bucket = on_bucket_ready
         try:
-            return self._backward(c, dq_trans, d_o, d_arm)
+            return self._backward(c, dq_trans, d_o, d_arm, dq_trans_left, d_o_left)
         finally:
             ops.PRECISION = 'fp32'
 
-    def _backward(self, c, dq_trans, d_o, d_arm=None):
+    def _backward(self, c, dq_trans, d_o, d_arm=None, dq_trans_left=None, d_o_left=None):
         m = self.m
         B = c['B']
         V, G, C, Cx, D, L, T0, k, s = self.V, self.G, self.C, self.Cx, self.D, self.L, self.T0, self.k, self.s
@@ -564,6 +624,20 @@ class PerceiverEngine:
             ops.lrelu_bwd_(dh2, c['h2'])
             ops.linear_bwd(c['feats'], self.p('dense2.linear.weight'), dh2, self.g('dense2.linear.weight'),
                            self.g('dense2.linear.bias'), dfe, dx_accumulate=True)
+        if self.two:
+            if dq_trans_left is None or d_o_left is None:
+                raise VoxactbHipError('the 2Robots encoder needs the left arm\'s loss gradients')
+            cl = c['left']
+            dh1l = E(B, cl['h1'].shape[1])
+            ops.linear_bwd(cl['h1'], self.p('rot_grip_collision_ff_left_arm.linear.weight'), d_o_left.contiguous(),
+                           self.g('rot_grip_collision_ff_left_arm.linear.weight'), self.g('rot_grip_collision_ff_left_arm.linear.bias'), dh1l)
+            ops.lrelu_bwd_(dh1l, cl['h1'])
+            dh0l = E(B, 256)
+            ops.linear_bwd(cl['h0'], self.p('dense1_left_arm.linear.weight'), dh1l, self.g('dense1_left_arm.linear.weight'),
+                           self.g('dense1_left_arm.linear.bias'), dh0l)
+            ops.lrelu_bwd_(dh0l, cl['h0'])
+            ops.linear_bwd(c['feats'], self.p('dense0_left_arm.linear.weight'), dh0l, self.g('dense0_left_arm.linear.weight'),
+                           self.g('dense0_left_arm.linear.bias'), dfe, dx_accumulate=True)
         o0 = 0
         gs = []
         for width in (3 * C, C, 3 * Cx, Cx, 3 * C, C):
@@ -576,6 +650,10 @@ class PerceiverEngine:
         ops.ss3d_max_bwd(u, V ** 3 * C, B, V, C, st, ss, am, gs[4], gs[5], du, V ** 3 * C)
         wt = self.p('trans_decoder.conv3d.weight')
         ops.conv3_c1_wgrad(u, dq_trans, self.g('trans_decoder.conv3d.weight'), self.g('trans_decoder.conv3d.bias'), B, V)
+        if self.two:
+            dql = dq_trans_left.contiguous().view(B, V, V, V)
+            ops.conv3_c1_wgrad(u, dql, self.g('trans_decoder_left_arm.conv3d.weight'), self.g('trans_decoder_left_arm.conv3d.bias'), B, V)
+            ops.conv3_c1_dgrad(dql, self.p('trans_decoder_left_arm.conv3d.weight'), u, du, B, V, accumulate=True, mask=False)
         ops.conv3_c1_dgrad(dq_trans, wt, u, du, B, V, accumulate=True, mask=True)      # du is now d(pre-activation of `final`)
         # ---- final conv (two sources)
         Wf = self.p('final.conv3d.weight')
@@ -664,7 +742,9 @@ class PerceiverEngine:
                           self.g(pre + '.norm_context.weight'), self.g(pre + '.norm_context.bias'), dx=dctx, accumulate_dx=True)
         ops.sum_splits(dx, B, L * D, self.g('latents'), accumulate=True)
         # ---- context assembly, language, proprio
-        dlang, dpatch, dpp = ops.ctx_bwd(dctx, self.g('pos_encoding'), B, T0, T1, C)
+        dlang, dpatch, dpp = ops.ctx_bwd(dctx, self.g('pos_encoding'), B, T0, T1, C, Cx - C)
+        if self.two:
+            dpp = torch.cat((dpp[:, :C], dpp[:, C:]), dim=0).contiguous()      # rows [right | left], as c['proprio'] / c['pp']
         ops.linear_bwd(c['lang'], self.p('lang_preprocess.weight'), dlang, self.g('lang_preprocess.weight'),
                        self.g('lang_preprocess.bias'))
         ops.lrelu_bwd_(dpp, c['pp'])

@@ -361,11 +361,12 @@ __global__ void __launch_bounds__(256) naive_gemm_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------ context assembly
-// ctx[b, t, :] = (t < T0 ? lang[b,t,:] : cat(patch[b,t-T0,:C], pp[b,:C])) + pos[t,:]     (perceiver_lang_io.py:370-422)
+// ctx[b, t, :] = (t < T0 ? lang[b,t,:] : cat(patch[b,t-T0,:C], pp[b,:Cp])) + pos[t,:]     (perceiver_lang_io.py:370-422;
+// Cp = C for one proprio vector, 2 C for the right | left pair of the 2Robots encoder, :721-727)
 __global__ void __launch_bounds__(256) ctx_build_kernel(const float* __restrict__ lang, const float* __restrict__ patch,
                                                         const float* __restrict__ pp, const float* __restrict__ pos,
-                                                        float* __restrict__ ctx, int B, int T0, int T1, int C) {
-    const int Cx = 2 * C;
+                                                        float* __restrict__ ctx, int B, int T0, int T1, int C, int Cp) {
+    const int Cx = C + Cp;
     const long long n = (long long)B * (T0 + T1) * Cx;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % Cx);
@@ -375,15 +376,15 @@ __global__ void __launch_bounds__(256) ctx_build_kernel(const float* __restrict_
         float v;
         if (t < T0) v = lang[((long long)b * T0 + t) * Cx + c];
         else if (c < C) v = patch[((long long)b * T1 + (t - T0)) * C + c];
-        else v = pp[b * C + (c - C)];
+        else v = pp[b * Cp + (c - C)];
         ctx[i] = v + pos[(long long)t * Cx + c];
     }
 }
 // adjoint: dlang, dpatch written; dpos[t,c] = sum_b dctx; dpp[b,c] = sum_t dctx[b, T0+t, C+c]
 __global__ void __launch_bounds__(256) ctx_bwd_kernel(const float* __restrict__ dctx, float* __restrict__ dlang,
                                                       float* __restrict__ dpatch, float* __restrict__ dpos, int B, int T0,
-                                                      int T1, int C) {
-    const int Cx = 2 * C;
+                                                      int T1, int C, int Cp) {
+    const int Cx = C + Cp;
     const long long n = (long long)(T0 + T1) * Cx;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % Cx);
@@ -398,24 +399,24 @@ __global__ void __launch_bounds__(256) ctx_bwd_kernel(const float* __restrict__ 
         dpos[i] += s;
     }
 }
-// dpp[b,c] = sum_t dctx[b, T0+t, C+c]: stage 1 per (b, chunk) -> part[b][chunk][C]; stage 2 sums the chunks
+// dpp[b,c] = sum_t dctx[b, T0+t, C+c], c < Cp: stage 1 per (b, chunk) -> part[b][chunk][Cp]; stage 2 sums the chunks
 __global__ void __launch_bounds__(256) ctx_bwd_pp_kernel(const float* __restrict__ dctx, float* __restrict__ part, int T0,
-                                                         int T1, int C, int nchunk) {
+                                                         int T1, int C, int Cp, int nchunk) {
     __shared__ float red[256];
     const int b = blockIdx.x, ch = blockIdx.y;
-    const int Cx = 2 * C;
+    const int Cx = C + Cp;
     const int per = (T1 + nchunk - 1) / nchunk;
     const int t0 = ch * per, t1 = min(T1, t0 + per);
-    const int nstripe = 256 / C;                 // C in {64, 128}
-    const int c = threadIdx.x % C, sidx = threadIdx.x / C;
+    const int nstripe = 256 / Cp;                // Cp in {64, 128}
+    const int c = threadIdx.x % Cp, sidx = threadIdx.x / Cp;
     float s = 0.f;
     for (int t = t0 + sidx; t < t1; t += nstripe) s += dctx[((long long)b * (T0 + T1) + T0 + t) * Cx + C + c];
     red[threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.x < C) {
+    if (threadIdx.x < Cp) {
         float v = 0.f;
-        for (int k = 0; k < nstripe; ++k) v += red[k * C + threadIdx.x];
-        part[((long long)b * nchunk + ch) * C + threadIdx.x] = v;
+        for (int k = 0; k < nstripe; ++k) v += red[k * Cp + threadIdx.x];
+        part[((long long)b * nchunk + ch) * Cp + threadIdx.x] = v;
     }
 }
 __global__ void __launch_bounds__(256) ctx_bwd_pp2_kernel(const float* __restrict__ part, float* __restrict__ dpp, int B, int C, int nchunk) {
@@ -561,23 +562,23 @@ extern "C" int vxb_naive_gemm_f32(const float* A, const float* B, float* C, cons
     return VXB_OK;
 }
 extern "C" int vxb_ctx_build_f32(const float* lang, const float* patch, const float* pp, const float* pos, float* ctx, int B,
-                                 int T0, int T1, int C, vxb_stream_t stream) {
-    if (!lang || !patch || !pp || !pos || !ctx || B < 1 || T0 < 0 || T1 < 1 || C < 1) return VXB_EARG;
-    hipLaunchKernelGGL(ctx_build_kernel, dim3(grid_for((long long)B * (T0 + T1) * 2 * C)), dim3(256), 0, (hipStream_t)stream, lang, patch, pp,
-                       pos, ctx, B, T0, T1, C);
+                                 int T0, int T1, int C, int Cp, vxb_stream_t stream) {
+    if (!lang || !patch || !pp || !pos || !ctx || B < 1 || T0 < 0 || T1 < 1 || C < 1 || Cp < 1) return VXB_EARG;
+    hipLaunchKernelGGL(ctx_build_kernel, dim3(grid_for((long long)B * (T0 + T1) * (C + Cp))), dim3(256), 0, (hipStream_t)stream, lang, patch, pp,
+                       pos, ctx, B, T0, T1, C, Cp);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
-// dlang [B,T0,2C], dpatch [B,T1,C], dpp [B,C] are WRITTEN; dpos [T0+T1,2C] is ACCUMULATED.
+// dlang [B,T0,C+Cp], dpatch [B,T1,C], dpp [B,Cp] are WRITTEN; dpos [T0+T1,C+Cp] is ACCUMULATED.
 extern "C" int vxb_ctx_bwd_f32(const float* dctx, float* dlang, float* dpatch, float* dpp, float* dpos, float* part_ws, int B,
-                               int T0, int T1, int C, vxb_stream_t stream) {
-    if (!dctx || !dlang || !dpatch || !dpp || !dpos || !part_ws || B < 1 || T1 < 1 || C < 1) return VXB_EARG;
-    if (C > 256 || (256 % C)) return VXB_ESIZE;
+                               int T0, int T1, int C, int Cp, vxb_stream_t stream) {
+    if (!dctx || !dlang || !dpatch || !dpp || !dpos || !part_ws || B < 1 || T1 < 1 || C < 1 || Cp < 1) return VXB_EARG;
+    if (Cp > 256 || (256 % Cp)) return VXB_ESIZE;
     hipStream_t st = (hipStream_t)stream;
-    const int nchunk = 32;     // part_ws: B*32*C floats
-    hipLaunchKernelGGL(ctx_bwd_kernel, dim3(grid_for((long long)(T0 + T1) * 2 * C)), dim3(256), 0, st, dctx, dlang, dpatch, dpos, B, T0, T1, C);
-    hipLaunchKernelGGL(ctx_bwd_pp_kernel, dim3(B, nchunk), dim3(256), 0, st, dctx, part_ws, T0, T1, C, nchunk);
-    hipLaunchKernelGGL(ctx_bwd_pp2_kernel, dim3(vxb_cdiv((long long)B * C, 256)), dim3(256), 0, st, part_ws, dpp, B, C, nchunk);
+    const int nchunk = 32;     // part_ws: B*32*Cp floats
+    hipLaunchKernelGGL(ctx_bwd_kernel, dim3(grid_for((long long)(T0 + T1) * (C + Cp))), dim3(256), 0, st, dctx, dlang, dpatch, dpos, B, T0, T1, C, Cp);
+    hipLaunchKernelGGL(ctx_bwd_pp_kernel, dim3(B, nchunk), dim3(256), 0, st, dctx, part_ws, T0, T1, C, Cp, nchunk);
+    hipLaunchKernelGGL(ctx_bwd_pp2_kernel, dim3(vxb_cdiv((long long)B * Cp, 256)), dim3(256), 0, st, part_ws, dpp, B, Cp, nchunk);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }

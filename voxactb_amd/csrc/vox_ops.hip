@@ -168,7 +168,7 @@ __device__ __forceinline__ void ss_merge(SsPart& a, const SsPart& b) {
     if (b.xmax > a.xmax || (b.xmax == a.xmax && b.arg < a.arg)) { a.xmax = b.xmax; a.arg = b.arg; }
 }
 
-__global__ void __launch_bounds__(256) ss_part_kernel(const float* __restrict__ x, long long bs, int S, int C,
+__global__ void __launch_bounds__(256) ss_part_kernel(const float* __restrict__ x, long long bs, int S, int C, int ld,
                                                       const float* __restrict__ lin, int rows_per_chunk,
                                                       SsPart* __restrict__ part, int nchunk, float T) {
     __shared__ SsPart red[256];
@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256) ss_part_kernel(const float* __restrict__ 
         const float wy = lin[i], wx = lin[j];        // meshgrid 'xy' quirk: pos_x follows axis 1, pos_y axis 0
         for (int k = pl; k < S; k += npl) {
             const int p = row * S + k;
-            const float xv = xb[(long long)p * C + c];
+            const float xv = xb[(long long)p * ld + c];
             const float l = __fdiv_rn(xv, T);
             if (xv > a.xmax) { a.xmax = xv; a.arg = p; }
             if (l > a.m) {
@@ -219,7 +219,7 @@ __device__ __forceinline__ void ss_update(SsPart& a, float xv, int p, float wx, 
     a.s += e; a.sx = fmaf(e, wx, a.sx); a.sy = fmaf(e, wy, a.sy); a.sz = fmaf(e, wz, a.sz);
 }
 
-__global__ void __launch_bounds__(256) ss_part4_kernel(const float* __restrict__ x, long long bs, int S, int C,
+__global__ void __launch_bounds__(256) ss_part4_kernel(const float* __restrict__ x, long long bs, int S, int C, int ld,
                                                        const float* __restrict__ lin, int rows_per_chunk,
                                                        SsPart* __restrict__ part, int nchunk, float T) {
     __shared__ SsPart red[256 * 4];
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256) ss_part4_kernel(const float* __restrict__
 #pragma unroll
             for (int uu = 0; uu < 4; ++uu) {
                 const int k = k0 + uu * npl;
-                v[uu] = k < S ? *reinterpret_cast<const float4*>(xb + (long long)(row * S + k) * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[uu] = k < S ? *reinterpret_cast<const float4*>(xb + (long long)(row * S + k) * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int uu = 0; uu < 4; ++uu) {
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(256) ss_part4_kernel(const float* __restrict__
 }
 
 // stage 2: combine chunks -> out_ss[b][3c + {x,y,z}], out_max[b][c], stats[b][c] = {m, s}, argmax[b][c]
-__global__ void __launch_bounds__(256) ss_final_kernel(const SsPart* __restrict__ part, int nchunk, int B, int C,
+__global__ void __launch_bounds__(256) ss_final_kernel(const SsPart* __restrict__ part, int nchunk, int B, int C, int Ct, int c0,
                                                        float* __restrict__ out_ss, float* __restrict__ out_max,
                                                        float* __restrict__ stats, int* __restrict__ argmax) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -273,18 +273,19 @@ __global__ void __launch_bounds__(256) ss_final_kernel(const SsPart* __restrict_
     const int b = i / C, c = i % C;
     SsPart r = part[((long long)b * nchunk) * C + c];
     for (int k = 1; k < nchunk; ++k) ss_merge(r, part[((long long)b * nchunk + k) * C + c]);
-    out_ss[(long long)b * 3 * C + 3 * c + 0] = r.sx / r.s;
-    out_ss[(long long)b * 3 * C + 3 * c + 1] = r.sy / r.s;
-    out_ss[(long long)b * 3 * C + 3 * c + 2] = r.sz / r.s;
-    out_max[i] = r.xmax;
-    stats[2 * i] = r.m;
-    stats[2 * i + 1] = r.s;
-    argmax[i] = r.arg;
+    const int o = b * Ct + c0 + c;                    // channel c of this slab is channel c0 + c of the Ct-wide tensor
+    out_ss[3LL * o + 0] = r.sx / r.s;
+    out_ss[3LL * o + 1] = r.sy / r.s;
+    out_ss[3LL * o + 2] = r.sz / r.s;
+    out_max[o] = r.xmax;
+    stats[2 * o] = r.m;
+    stats[2 * o + 1] = r.s;
+    argmax[o] = r.arg;
 }
 
 // stage 2 for many chunks (small batches cut a sample into up to 1024 chunks): one workgroup per (b, c), threads merge a
 // strided subset of the chunks, then a fixed-order tree over the 256 partial results
-__global__ void __launch_bounds__(256) ss_final_wide_kernel(const SsPart* __restrict__ part, int nchunk, int B, int C,
+__global__ void __launch_bounds__(256) ss_final_wide_kernel(const SsPart* __restrict__ part, int nchunk, int B, int C, int Ct, int c0,
                                                             float* __restrict__ out_ss, float* __restrict__ out_max,
                                                             float* __restrict__ stats, int* __restrict__ argmax) {
     __shared__ SsPart red[256];
@@ -300,18 +301,19 @@ __global__ void __launch_bounds__(256) ss_final_wide_kernel(const SsPart* __rest
     }
     if (threadIdx.x == 0) {
         r = red[0];
-        out_ss[(long long)b * 3 * C + 3 * c + 0] = r.sx / r.s;
-        out_ss[(long long)b * 3 * C + 3 * c + 1] = r.sy / r.s;
-        out_ss[(long long)b * 3 * C + 3 * c + 2] = r.sz / r.s;
-        out_max[i] = r.xmax;
-        stats[2 * i] = r.m;
-        stats[2 * i + 1] = r.s;
-        argmax[i] = r.arg;
+        const int o = b * Ct + c0 + c;
+        out_ss[3LL * o + 0] = r.sx / r.s;
+        out_ss[3LL * o + 1] = r.sy / r.s;
+        out_ss[3LL * o + 2] = r.sz / r.s;
+        out_max[o] = r.xmax;
+        stats[2 * o] = r.m;
+        stats[2 * o + 1] = r.s;
+        argmax[o] = r.arg;
     }
 }
 
 // float4 variant of the backward pass below (same formula per element; 4 channels per thread, 4 voxels in flight)
-__global__ void __launch_bounds__(256) ss_bwd4_kernel(const float* __restrict__ x, long long bs, int S, int C,
+__global__ void __launch_bounds__(256) ss_bwd4_kernel(const float* __restrict__ x, long long bs, int S, int C, int ld, int Ct, int c0,
                                                       const float* __restrict__ lin, const float* __restrict__ stats,
                                                       const float* __restrict__ out_ss, const int* __restrict__ argmax,
                                                       const float* __restrict__ g_ss, const float* __restrict__ g_max,
@@ -326,10 +328,10 @@ __global__ void __launch_bounds__(256) ss_bwd4_kernel(const float* __restrict__ 
     int am[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const int c = 4 * cq + e, bc = b * C + c;
+        const int c = 4 * cq + e, bc = b * Ct + c0 + c;
         m[e] = stats[2 * bc]; inv_s[e] = 1.0f / stats[2 * bc + 1];
-        ex[e] = out_ss[(long long)b * 3 * C + 3 * c]; ey[e] = out_ss[(long long)b * 3 * C + 3 * c + 1]; ez[e] = out_ss[(long long)b * 3 * C + 3 * c + 2];
-        gx[e] = g_ss[(long long)b * 3 * C + 3 * c]; gy[e] = g_ss[(long long)b * 3 * C + 3 * c + 1]; gz[e] = g_ss[(long long)b * 3 * C + 3 * c + 2];
+        ex[e] = out_ss[3LL * bc]; ey[e] = out_ss[3LL * bc + 1]; ez[e] = out_ss[3LL * bc + 2];
+        gx[e] = g_ss[3LL * bc]; gy[e] = g_ss[3LL * bc + 1]; gz[e] = g_ss[3LL * bc + 2];
         gm[e] = g_max[bc]; am[e] = argmax[bc];
     }
     const int row0 = chunk * rows_per_chunk, row1 = min(S * S, row0 + rows_per_chunk);
@@ -343,7 +345,7 @@ __global__ void __launch_bounds__(256) ss_bwd4_kernel(const float* __restrict__ 
 #pragma unroll
             for (int uu = 0; uu < 4; ++uu) {
                 const int k = k0 + uu * npl;
-                const long long o = (long long)(row * S + k) * C;
+                const long long o = (long long)(row * S + k) * ld;
                 v[uu] = k < S ? *reinterpret_cast<const float4*>(xb + o) : make_float4(0.f, 0.f, 0.f, 0.f);
                 old[uu] = (k < S && accumulate) ? *reinterpret_cast<const float4*>(db + o) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -363,7 +365,7 @@ __global__ void __launch_bounds__(256) ss_bwd4_kernel(const float* __restrict__ 
                         if (p == am[e]) g += gm[e];
                         r[e] = accumulate ? r[e] + g : g;
                     }
-                    *reinterpret_cast<float4*>(db + (long long)p * C) = make_float4(r[0], r[1], r[2], r[3]);
+                    *reinterpret_cast<float4*>(db + (long long)p * ld) = make_float4(r[0], r[1], r[2], r[3]);
                 }
             }
         }
@@ -371,7 +373,7 @@ __global__ void __launch_bounds__(256) ss_bwd4_kernel(const float* __restrict__ 
 }
 
 // backward: dx[b,p,c] (+)= a_p/T * (gx*(lin[j]-ex) + gy*(lin[i]-ey) + gz*(lin[k]-ez)) + (p == argmax) * gmax
-__global__ void __launch_bounds__(256) ss_bwd_kernel(const float* __restrict__ x, long long bs, int S, int C,
+__global__ void __launch_bounds__(256) ss_bwd_kernel(const float* __restrict__ x, long long bs, int S, int C, int ld, int Ct, int c0,
                                                      const float* __restrict__ lin, const float* __restrict__ stats,
                                                      const float* __restrict__ out_ss, const int* __restrict__ argmax,
                                                      const float* __restrict__ g_ss, const float* __restrict__ g_max,
@@ -381,12 +383,10 @@ __global__ void __launch_bounds__(256) ss_bwd_kernel(const float* __restrict__ x
     const int c = threadIdx.x % C, pl = threadIdx.x / C, npl = 256 / C;
     const float* xb = x + (long long)b * bs;
     float* db = dx + (long long)b * dbs;
-    const int bc = b * C + c;
+    const int bc = b * Ct + c0 + c;
     const float m = stats[2 * bc], inv_s = 1.0f / stats[2 * bc + 1];
-    const float ex = out_ss[(long long)b * 3 * C + 3 * c], ey = out_ss[(long long)b * 3 * C + 3 * c + 1],
-                ez = out_ss[(long long)b * 3 * C + 3 * c + 2];
-    const float gx = g_ss[(long long)b * 3 * C + 3 * c], gy = g_ss[(long long)b * 3 * C + 3 * c + 1],
-                gz = g_ss[(long long)b * 3 * C + 3 * c + 2];
+    const float ex = out_ss[3LL * bc], ey = out_ss[3LL * bc + 1], ez = out_ss[3LL * bc + 2];
+    const float gx = g_ss[3LL * bc], gy = g_ss[3LL * bc + 1], gz = g_ss[3LL * bc + 2];
     const float gm = g_max[bc];
     const int am = argmax[bc];
     const int row0 = chunk * rows_per_chunk, row1 = min(S * S, row0 + rows_per_chunk);
@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(256) ss_bwd_kernel(const float* __restrict__ x
         const float base = gx * (lin[j] - ex) + gy * (lin[i] - ey);
         for (int k = pl; k < S; k += npl) {
             const int p = row * S + k;
-            const long long o = (long long)p * C + c;
+            const long long o = (long long)p * ld + c;
             const float l = __fdiv_rn(xb[o], T);
             const float a = expf(l - m) * inv_s;
             float g = __fdiv_rn(a * (base + gz * (lin[k] - ez)), T);
@@ -909,22 +909,27 @@ static inline int vxb_ss3d_chunks(int B) { const int w = (1024 + B - 1) / B; ret
 extern "C" int vxb_ss3d_max_fwd_f32(const float* x, int64_t bs, int B, int S, int C, const float* lin, float* part_ws,
                                     float* out_ss, float* out_max, float* stats, int32_t* argmax, vxb_stream_t stream) {
     if (!x || !lin || !part_ws || !out_ss || !out_max || !stats || !argmax || B < 1 || S < 1) return VXB_EARG;
-    if (C != 64 && C != 128) return VXB_ESIZE;
+    if (C != 64 && C != 128 && C != 192) return VXB_ESIZE;
     hipStream_t st = (hipStream_t)stream;
     // >= 1024 workgroups per launch: 64 chunks of (d, h) rows per sample at B >= 16, more for small batches (act(): B = 1)
     const int want = vxb_ss3d_chunks(B);
     const int rpc = (S * S / want) < 1 ? 1 : S * S / want;
     const int nchunk = vxb_cdiv(S * S, rpc);
-    if ((bs & 3) == 0 && (((uintptr_t)x) & 15) == 0)
-        hipLaunchKernelGGL(ss_part4_kernel, dim3(nchunk, B), dim3(256), 0, st, x, (long long)bs, S, C, lin, rpc, (SsPart*)part_ws, nchunk, 0.01f);
-    else
-        hipLaunchKernelGGL(ss_part_kernel, dim3(nchunk, B), dim3(256), 0, st, x, (long long)bs, S, C, lin, rpc, (SsPart*)part_ws, nchunk, 0.01f);
-    if (nchunk > 128)
-        hipLaunchKernelGGL(ss_final_wide_kernel, dim3(B * C), dim3(256), 0, st, (const SsPart*)part_ws, nchunk, B, C, out_ss,
-                           out_max, stats, argmax);
-    else
-        hipLaunchKernelGGL(ss_final_kernel, dim3(vxb_cdiv(B * C, 256)), dim3(256), 0, st, (const SsPart*)part_ws, nchunk, B, C, out_ss,
-                           out_max, stats, argmax);
+    // the kernels spread 64 or 128 channels over a workgroup: a 192-wide tensor (2Robots context) runs as the slabs 128 + 64
+    for (int c0 = 0; c0 < C; c0 += 128) {
+        const int Cs = C - c0 < 128 ? C - c0 : 128;
+        const float* xs = x + c0;
+        if ((bs & 3) == 0 && (((uintptr_t)xs) & 15) == 0 && (C & 3) == 0)
+            hipLaunchKernelGGL(ss_part4_kernel, dim3(nchunk, B), dim3(256), 0, st, xs, (long long)bs, S, Cs, C, lin, rpc, (SsPart*)part_ws, nchunk, 0.01f);
+        else
+            hipLaunchKernelGGL(ss_part_kernel, dim3(nchunk, B), dim3(256), 0, st, xs, (long long)bs, S, Cs, C, lin, rpc, (SsPart*)part_ws, nchunk, 0.01f);
+        if (nchunk > 128)
+            hipLaunchKernelGGL(ss_final_wide_kernel, dim3(B * Cs), dim3(256), 0, st, (const SsPart*)part_ws, nchunk, B, Cs, C, c0, out_ss,
+                               out_max, stats, argmax);
+        else
+            hipLaunchKernelGGL(ss_final_kernel, dim3(vxb_cdiv(B * Cs, 256)), dim3(256), 0, st, (const SsPart*)part_ws, nchunk, B, Cs, C, c0,
+                               out_ss, out_max, stats, argmax);
+    }
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
@@ -932,15 +937,20 @@ extern "C" int vxb_ss3d_max_bwd_f32(const float* x, int64_t bs, int B, int S, in
                                     const float* out_ss, const int32_t* argmax, const float* g_ss, const float* g_max,
                                     float* dx, int64_t dbs, int accumulate, vxb_stream_t stream) {
     if (!x || !lin || !stats || !out_ss || !argmax || !g_ss || !g_max || !dx || B < 1 || S < 1) return VXB_EARG;
-    if (C != 64 && C != 128) return VXB_ESIZE;
+    if (C != 64 && C != 128 && C != 192) return VXB_ESIZE;
     const int rpc = (S * S / 256) < 1 ? 1 : S * S / 256;
     const int nchunk = vxb_cdiv(S * S, rpc);
-    if ((bs & 3) == 0 && (dbs & 3) == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)dx) & 15) == 0)
-        hipLaunchKernelGGL(ss_bwd4_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, (long long)bs, S, C, lin, stats,
-                           out_ss, argmax, g_ss, g_max, dx, (long long)dbs, rpc, 0.01f, accumulate);
-    else
-        hipLaunchKernelGGL(ss_bwd_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, (long long)bs, S, C, lin, stats, out_ss,
-                           argmax, g_ss, g_max, dx, (long long)dbs, rpc, 0.01f, accumulate);
+    for (int c0 = 0; c0 < C; c0 += 128) {
+        const int Cs = C - c0 < 128 ? C - c0 : 128;
+        const float* xs = x + c0;
+        float* ds = dx + c0;
+        if ((bs & 3) == 0 && (dbs & 3) == 0 && (((uintptr_t)xs) & 15) == 0 && (((uintptr_t)ds) & 15) == 0)
+            hipLaunchKernelGGL(ss_bwd4_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, xs, (long long)bs, S, Cs, C, C, c0, lin, stats,
+                               out_ss, argmax, g_ss, g_max, ds, (long long)dbs, rpc, 0.01f, accumulate);
+        else
+            hipLaunchKernelGGL(ss_bwd_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, xs, (long long)bs, S, Cs, C, C, c0, lin, stats,
+                               out_ss, argmax, g_ss, g_max, ds, (long long)dbs, rpc, 0.01f, accumulate);
+    }
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }

@@ -650,18 +650,21 @@ def conv3_c1_wgrad(u, dq, dw, db, B, S):
 
 
 def ctx_build(lang, patch, pp, pos, B, T0, T1, C):
-    ctx = torch.empty((B, T0 + T1, 2 * C), dtype=torch.float32, device=lang.device)
-    call('vxb_ctx_build_f32', lang, patch, pp, pos, ctx, B, T0, T1, C)
+    """pp [B, Cp]: one proprio embedding (Cp = C) or the right | left pair of the 2Robots encoder (Cp = 2 C)."""
+    Cp = pp.shape[1]
+    ctx = torch.empty((B, T0 + T1, C + Cp), dtype=torch.float32, device=lang.device)
+    call('vxb_ctx_build_f32', lang, patch, pp, pos, ctx, B, T0, T1, C, Cp)
     return ctx
 
 
-def ctx_bwd(dctx, dpos, B, T0, T1, C):
+def ctx_bwd(dctx, dpos, B, T0, T1, C, Cp=None):
     dev = dctx.device
-    dlang = torch.empty((B * T0, 2 * C), dtype=torch.float32, device=dev)
+    Cp = C if Cp is None else Cp
+    dlang = torch.empty((B * T0, C + Cp), dtype=torch.float32, device=dev)
     dpatch = torch.empty((B * T1, C), dtype=torch.float32, device=dev)
-    dpp = torch.empty((B, C), dtype=torch.float32, device=dev)
-    ws = torch.empty(B * 32 * C, dtype=torch.float32, device=dev)
-    call('vxb_ctx_bwd_f32', dctx, dlang, dpatch, dpp, dpos, ws, B, T0, T1, C)
+    dpp = torch.empty((B, Cp), dtype=torch.float32, device=dev)
+    ws = torch.empty(B * 32 * Cp, dtype=torch.float32, device=dev)
+    call('vxb_ctx_bwd_f32', dctx, dlang, dpatch, dpp, dpos, ws, B, T0, T1, C, Cp)
     return dlang, dpatch, dpp
 
 
