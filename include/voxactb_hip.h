@@ -126,6 +126,15 @@ int vxb_se3_relabel_f32(const float* pose, const int32_t* rot_grip_in, const flo
                         const float* shift_unit, const int32_t* rpy_steps, int K, int B, double aug_x, double aug_y,
                         double aug_z, float rot_aug_resolution, int V, float rot_resolution, int32_t* trans_idx,
                         int32_t* rot_grip_idx, float* xf, int32_t* status, vxb_stream_t stream);
+/* Two arms under ONE perturbation (apply_se3_augmentation_2Robots, peract/voxel/augmentation.py:187-348, the
+ * one_policy_more_heads baseline): both poses use the same draws, an attempt wins only when BOTH arms' translation indices
+ * are >= 0 for the whole batch (:237), xf is centred on the RIGHT arm's pose (:346).  Otherwise as vxb_se3_relabel_f32. */
+int vxb_se3_relabel_pair_f32(const float* pose_right, const int32_t* rot_grip_right, const float* pose_left,
+                             const int32_t* rot_grip_left, const float* bounds, int bounds_rows, int layer,
+                             const float* shift_unit, const int32_t* rpy_steps, int K, int B, double aug_x, double aug_y,
+                             double aug_z, float rot_aug_resolution, int V, float rot_resolution, int32_t* trans_idx_right,
+                             int32_t* rot_grip_idx_right, int32_t* trans_idx_left, int32_t* rot_grip_idx_left, float* xf,
+                             int32_t* status, vxb_stream_t stream);
 /* bf16 matrix-core twins ("throughput mode", v_mfma_f32_32x32x16_bf16, fp32 accumulate): the fp32 A operand is rounded
  * to bf16 (RNE) while it is staged into LDS; weights come as bf16 [N][K] (K contiguous, K % 8 == 0; C0, C1 % 32 == 0). */
 int vxb_gemm_bf16w_f32(const float* A, int64_t lda, const void* Bw, float* C, int64_t ldc, const float* bias,

@@ -99,3 +99,44 @@ def test_reference_signature_wrapper_and_failure_raises():
         aug.apply_se3_augmentation(pcd, pose_out, rs['trans_action_indicies'][:, 0].to(DEV), rs['rot_grip_action_indicies'][:, 0].to(DEV),
                                    torch.tensor([synthetic.SCENE_BOUNDS], device=DEV), 0, torch.tensor([0.125] * 3, dtype=torch.float64),
                                    [0.0, 0.0, 45.0], 5, V, 5, DEV)
+
+
+def test_two_arms_share_one_perturbation():
+    """apply_se3_augmentation_2Robots (reference augmentation.py:187-348): the same draws for both arms' poses, an attempt is
+    kept only if BOTH arms stay inside the grid, the clouds turn about the RIGHT arm.  Per arm the arithmetic is the
+    single-arm one, so the oracle's `augment` is the yardstick for each."""
+    B, V = 8, 100
+    bounds = torch.tensor([synthetic.SCENE_BOUNDS])
+    for seed in range(4):
+        rs_r = synthetic.make_replay_sample(B, ['front'], (8, 8), V, 4, seed=70 + seed)
+        rs_l = synthetic.make_replay_sample(B, ['front'], (8, 8), V, 4, seed=170 + seed)
+        pose_r, rg_r = rs_r['gripper_pose'][:, 0].clone(), rs_r['rot_grip_action_indicies'][:, 0]
+        pose_l, rg_l = rs_l['gripper_pose'][:, 0].clone(), rs_l['rot_grip_action_indicies'][:, 0]
+        pcd = rs_r['front_point_cloud'][:, 0]
+        gen = torch.Generator().manual_seed(seed)
+        unit = 2 * torch.rand((3, B, 3), generator=gen) - 1
+        steps = torch.cat([torch.zeros(3, B, 2, dtype=torch.int32), torch.randint(-9, 10, (3, B, 1), generator=gen, dtype=torch.int32)], 2)
+        if seed == 1:      # attempt 0: only the LEFT arm leaves the grid -> the whole batch is re-drawn for both arms
+            pose_l[3, :3] = torch.tensor(synthetic.SCENE_BOUNDS[:3]) + 0.01
+            unit[0, 3] = -1.0
+            unit[1, 3] = 0.2
+        want = None
+        for k in range(3):
+            tr, rr, pts, ok_r = ose3.augment([pcd], pose_r, rg_r, bounds, unit[k], steps[k].long(), [0.125] * 3, 5, V, 5)
+            tl, rl, _, ok_l = ose3.augment([pcd], pose_l, rg_l, bounds, unit[k], steps[k].long(), [0.125] * 3, 5, V, 5)
+            if ok_r and ok_l:
+                want = (k, tr, rr, tl, rl, pts)
+                break
+        out = aug.se3_augmentation_plan_2robots(pose_r.to(DEV), rg_r.to(DEV), pose_l.to(DEV), rg_l.to(DEV), bounds.to(DEV), 0,
+                                                torch.tensor([0.125] * 3, dtype=torch.float64), [0.0, 0.0, 45.0], 5, V, 5, DEV,
+                                                draws=(unit, steps))
+        if want is None:
+            assert int(out[5].item()) == -1 and int(out[0].max()) == -1 and int(out[2].max()) == -1
+            continue
+        assert int(out[5].item()) == want[0], seed
+        if seed == 1:
+            assert want[0] >= 1
+        for got, ref in zip(out[:4], want[1:5]):
+            assert torch.equal(got.cpu().long(), ref.long()), seed
+        moved = aug.transform_point_clouds([pcd.to(DEV)], out[4])[0]
+        assert float((moved.cpu() - want[5][0]).abs().max()) < 2e-6

@@ -16,6 +16,13 @@
 namespace {
 
 struct RelabelArgs {
+    // arm 0 = the (right) arm whose pose is the centre of the point-cloud transform; arm 1 (optional, 2Robots baseline,
+    // augmentation.py:187-348): shares every random draw, the retry vote covers both arms' translation indices (:237)
+    int n_arms;
+    const float* pose2;
+    const int32_t* rot_grip_in2;
+    int32_t* trans_idx2;
+    int32_t* rot_grip_idx2;
     const float* pose;
     const int32_t* rot_grip_in;
     const float* bounds;
@@ -81,25 +88,30 @@ __global__ void se3_relabel_kernel(RelabelArgs A) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], A.bounds[r * 6 + a]); hi[a] = fmaxf(hi[a], A.bounds[r * 6 + 3 + a]); }
 
-    float T[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
+    float T[2][9] = {{1, 0, 0, 0, 1, 0, 0, 0, 1}, {1, 0, 0, 0, 1, 0, 0, 0, 1}}, t[2][3] = {{0, 0, 0}, {0, 0, 0}};
     const float* bd_range = A.bounds;                               // row whose extent scales the shift (broadcast [1|B, 3])
     const float* bd_label = A.bounds;                               // row used for the translation label (:161-162)
     if (live) {
-        const float* p = A.pose + b * 7;
-        t[0] = p[0]; t[1] = p[1]; t[2] = p[2];
-        const float i = p[3], j = p[4], k = p[5], r = p[6];         // pytorch3d order is (r, i, j, k) = (w, x, y, z)
-        const float ss = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(r, r), __fmul_rn(i, i)), __fmul_rn(j, j)), __fmul_rn(k, k));
-        const float two_s = __fdiv_rn(2.0f, ss);
-        T[0] = 1.0f - two_s * (j * j + k * k); T[1] = two_s * (i * j - k * r);        T[2] = two_s * (i * k + j * r);
-        T[3] = two_s * (i * j + k * r);        T[4] = 1.0f - two_s * (i * i + k * k); T[5] = two_s * (j * k - i * r);
-        T[6] = two_s * (i * k - j * r);        T[7] = two_s * (j * k + i * r);        T[8] = 1.0f - two_s * (i * i + j * j);
+#pragma unroll
+        for (int arm = 0; arm < 2; ++arm) {
+            if (arm >= A.n_arms) break;
+            const float* p = (arm ? A.pose2 : A.pose) + b * 7;
+            t[arm][0] = p[0]; t[arm][1] = p[1]; t[arm][2] = p[2];
+            const float i = p[3], j = p[4], k = p[5], r = p[6];     // pytorch3d order is (r, i, j, k) = (w, x, y, z)
+            const float ss = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(r, r), __fmul_rn(i, i)), __fmul_rn(j, j)), __fmul_rn(k, k));
+            const float two_s = __fdiv_rn(2.0f, ss);
+            float* Ta = T[arm];
+            Ta[0] = 1.0f - two_s * (j * j + k * k); Ta[1] = two_s * (i * j - k * r);        Ta[2] = two_s * (i * k + j * r);
+            Ta[3] = two_s * (i * j + k * r);        Ta[4] = 1.0f - two_s * (i * i + k * k); Ta[5] = two_s * (j * k - i * r);
+            Ta[6] = two_s * (i * k - j * r);        Ta[7] = two_s * (j * k + i * r);        Ta[8] = 1.0f - two_s * (i * i + j * j);
+        }
         if (A.bounds_rows > 1) bd_range = A.bounds + b * 6;
         if (A.bounds_rows > 1 && A.layer > 0) bd_label = A.bounds + b * 6;
     }
     const float step_rad = (float)(A.rot_aug_resolution * (M_PI / 180.0));          // np.deg2rad(...), cast by the f32 product
     for (int k = 0; k < A.K; ++k) {
-        int tidx[3] = {0, 0, 0};
-        float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, M[9], centre[3] = {0, 0, 0};
+        int tidx[2][3] = {{0, 0, 0}, {0, 0, 0}};
+        float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, M[2][9], centre[3] = {0, 0, 0};
         bool ok = true;
         if (live) {
             const float* su = A.shift_unit + ((size_t)k * A.B + b) * 3;
@@ -111,52 +123,63 @@ __global__ void se3_relabel_kernel(RelabelArgs A) {
             Rz[0] = cosf(az); Rz[1] = -sinf(az); Rz[3] = sinf(az); Rz[4] = cosf(az);
             mat3_mul(Rx, Ry, Rxy);
             mat3_mul(Rxy, Rz, R);                                   // euler_angles_to_matrix(., "XYZ") (:142)
-            mat3_mul(T, R, M);                                      // rotation block of bmm(T_grip, R) (:147)
-            float tp[3];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const double range = (double)__fsub_rn(bd_range[3 + a], bd_range[a]) * A.aug[a];    // f32 extent * f64 range (:123)
-                const double shift = range * (double)su[a];                                          // (:124)
-                tp[a] = (float)((double)t[a] + shift);                                               // in-place += (:148)
-                centre[a] = fminf(fmaxf(__fadd_rn(t[a], (float)shift), lo[a]), hi[a]);               // (:49-57)
-                // point_to_voxel_index (helpers/utils.py:104-116): float64, clipped from above only
-                const double res = (double)__fsub_rn(bd_label[3 + a], bd_label[a]) / ((double)A.V + 1e-12);
-                const double q = floor((double)__fsub_rn(tp[a], bd_label[a]) / (res + 1e-12));
-                int iv = (q >= -2147483648.0 && q <= 2147483647.0) ? (int)q : INT32_MIN;             // NaN / overflow -> invalid
-                iv = iv < A.V - 1 ? iv : A.V - 1;
-                tidx[a] = iv;
-                ok = ok && iv >= 0;
+            for (int arm = 0; arm < 2; ++arm) {
+                if (arm >= A.n_arms) break;
+                mat3_mul(T[arm], R, M[arm]);                        // rotation block of bmm(T_grip, R) (:147)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const double range = (double)__fsub_rn(bd_range[3 + a], bd_range[a]) * A.aug[a];    // f32 extent * f64 range (:123)
+                    const double shift = range * (double)su[a];                                          // (:124)
+                    const float tp = (float)((double)t[arm][a] + shift);                                 // in-place += (:148)
+                    if (arm == 0) centre[a] = fminf(fmaxf(__fadd_rn(t[0][a], (float)shift), lo[a]), hi[a]);   // (:49-57)
+                    // point_to_voxel_index (helpers/utils.py:104-116): float64, clipped from above only
+                    const double res = (double)__fsub_rn(bd_label[3 + a], bd_label[a]) / ((double)A.V + 1e-12);
+                    const double q = floor((double)__fsub_rn(tp, bd_label[a]) / (res + 1e-12));
+                    int iv = (q >= -2147483648.0 && q <= 2147483647.0) ? (int)q : INT32_MIN;             // NaN / overflow -> invalid
+                    iv = iv < A.V - 1 ? iv : A.V - 1;
+                    tidx[arm][a] = iv;
+                    ok = ok && iv >= 0;
+                }
             }
         }
         const int all_ok = __syncthreads_and(ok ? 1 : 0);
         if (all_ok) {
             if (live) {
-                // matrix_to_quaternion (pytorch3d 0.3.0), fp32, (w, x, y, z)
-                const float m00 = M[0], m11 = M[4], m22 = M[8];
-                const float qw = 0.5f * sqrtf(fmaxf(0.0f, 1.0f + m00 + m11 + m22));
-                float qx = 0.5f * sqrtf(fmaxf(0.0f, 1.0f + m00 - m11 - m22));
-                float qy = 0.5f * sqrtf(fmaxf(0.0f, 1.0f - m00 + m11 - m22));
-                float qz = 0.5f * sqrtf(fmaxf(0.0f, 1.0f - m00 - m11 + m22));
-                qx = copysignf(qx, M[7] - M[5]);
-                qy = copysignf(qy, M[2] - M[6]);
-                qz = copysignf(qz, M[3] - M[1]);
-                // normalize_quaternion (utils.py:63-64) in fp32, then force w >= 0 (:167-171)
-                const float nrm = sqrtf(qx * qx + qy * qy + qz * qz + qw * qw);
-                float x = qx / nrm, y = qy / nrm, z = qz / nrm, w = qw / nrm;
-                if (w < 0.0f) { x = -x; y = -y; z = -z; w = -w; }
-                int disc[3];
-                discrete_euler((double)x, (double)y, (double)z, (double)w, (double)A.rot_resolution, disc);
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    A.trans_idx[b * 3 + a] = tidx[a];
-                    A.rot_grip_idx[b * 4 + a] = disc[a];
+                for (int arm = 0; arm < 2; ++arm) {
+                    if (arm >= A.n_arms) break;
+                    const float* Ma = M[arm];
+                    // matrix_to_quaternion (pytorch3d 0.3.0), fp32, (w, x, y, z)
+                    const float m00 = Ma[0], m11 = Ma[4], m22 = Ma[8];
+                    const float qw = 0.5f * sqrtf(fmaxf(0.0f, 1.0f + m00 + m11 + m22));
+                    float qx = 0.5f * sqrtf(fmaxf(0.0f, 1.0f + m00 - m11 - m22));
+                    float qy = 0.5f * sqrtf(fmaxf(0.0f, 1.0f - m00 + m11 - m22));
+                    float qz = 0.5f * sqrtf(fmaxf(0.0f, 1.0f - m00 - m11 + m22));
+                    qx = copysignf(qx, Ma[7] - Ma[5]);
+                    qy = copysignf(qy, Ma[2] - Ma[6]);
+                    qz = copysignf(qz, Ma[3] - Ma[1]);
+                    // normalize_quaternion (utils.py:63-64) in fp32, then force w >= 0 (:167-171)
+                    const float nrm = sqrtf(qx * qx + qy * qy + qz * qz + qw * qw);
+                    float x = qx / nrm, y = qy / nrm, z = qz / nrm, w = qw / nrm;
+                    if (w < 0.0f) { x = -x; y = -y; z = -z; w = -w; }
+                    int disc[3];
+                    discrete_euler((double)x, (double)y, (double)z, (double)w, (double)A.rot_resolution, disc);
+                    int32_t* ti = arm ? A.trans_idx2 : A.trans_idx;
+                    int32_t* ri = arm ? A.rot_grip_idx2 : A.rot_grip_idx;
+                    const int32_t* rin = arm ? A.rot_grip_in2 : A.rot_grip_in;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        ti[b * 3 + a] = tidx[arm][a];
+                        ri[b * 4 + a] = disc[a];
+                    }
+                    ri[b * 4 + 3] = rin[b * 4 + 3];                 // the gripper bit is carried over (:172)
                 }
-                A.rot_grip_idx[b * 4 + 3] = A.rot_grip_in[b * 4 + 3];   // the gripper bit is carried over (:172)
                 float* x15 = A.xf + b * 15;
 #pragma unroll
                 for (int a = 0; a < 9; ++a) x15[a] = R[a];
 #pragma unroll
-                for (int a = 0; a < 3; ++a) { x15[9 + a] = t[a]; x15[12 + a] = centre[a]; }
+                for (int a = 0; a < 3; ++a) { x15[9 + a] = t[0][a]; x15[12 + a] = centre[a]; }
             }
             if (b == 0) A.status[0] = k;
             return;
@@ -169,6 +192,12 @@ __global__ void se3_relabel_kernel(RelabelArgs A) {
         for (int a = 0; a < 3; ++a) A.trans_idx[b * 3 + a] = -1;
 #pragma unroll
         for (int a = 0; a < 4; ++a) A.rot_grip_idx[b * 4 + a] = -1;
+        if (A.n_arms > 1) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) A.trans_idx2[b * 3 + a] = -1;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) A.rot_grip_idx2[b * 4 + a] = -1;
+        }
         float* x15 = A.xf + b * 15;
         for (int a = 0; a < 15; ++a) x15[a] = (a == 0 || a == 4 || a == 8) ? 1.0f : 0.0f;
     }
@@ -177,14 +206,17 @@ __global__ void se3_relabel_kernel(RelabelArgs A) {
 
 }  // namespace
 
-extern "C" int vxb_se3_relabel_f32(const float* pose, const int32_t* rot_grip_in, const float* bounds, int bounds_rows, int layer,
-                                   const float* shift_unit, const int32_t* rpy_steps, int K, int B, double aug_x, double aug_y,
-                                   double aug_z, float rot_aug_resolution, int V, float rot_resolution, int32_t* trans_idx,
-                                   int32_t* rot_grip_idx, float* xf, int32_t* status, vxb_stream_t stream) {
+static int se3_relabel_launch(int n_arms, const float* pose, const int32_t* rot_grip_in, const float* pose2, const int32_t* rot_grip_in2,
+                              const float* bounds, int bounds_rows, int layer, const float* shift_unit, const int32_t* rpy_steps, int K,
+                              int B, double aug_x, double aug_y, double aug_z, float rot_aug_resolution, int V, float rot_resolution,
+                              int32_t* trans_idx, int32_t* rot_grip_idx, int32_t* trans_idx2, int32_t* rot_grip_idx2, float* xf,
+                              int32_t* status, vxb_stream_t stream) {
     if (!pose || !rot_grip_in || !bounds || !shift_unit || !rpy_steps || !trans_idx || !rot_grip_idx || !xf || !status) return VXB_EARG;
+    if (n_arms == 2 && (!pose2 || !rot_grip_in2 || !trans_idx2 || !rot_grip_idx2)) return VXB_EARG;
     if (K < 1 || B < 1 || V < 1 || (bounds_rows != 1 && bounds_rows != B) || !(rot_resolution > 0.f)) return VXB_EARG;
     if (B > 1024) return VXB_ESIZE;
     RelabelArgs A;
+    A.n_arms = n_arms; A.pose2 = pose2; A.rot_grip_in2 = rot_grip_in2; A.trans_idx2 = trans_idx2; A.rot_grip_idx2 = rot_grip_idx2;
     A.pose = pose; A.rot_grip_in = rot_grip_in; A.bounds = bounds; A.bounds_rows = bounds_rows; A.layer = layer;
     A.shift_unit = shift_unit; A.rpy_steps = rpy_steps; A.K = K; A.B = B;
     A.aug[0] = aug_x; A.aug[1] = aug_y; A.aug[2] = aug_z;
@@ -194,4 +226,26 @@ extern "C" int vxb_se3_relabel_f32(const float* pose, const int32_t* rot_grip_in
     hipLaunchKernelGGL(se3_relabel_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, A);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
+}
+
+extern "C" int vxb_se3_relabel_f32(const float* pose, const int32_t* rot_grip_in, const float* bounds, int bounds_rows, int layer,
+                                   const float* shift_unit, const int32_t* rpy_steps, int K, int B, double aug_x, double aug_y,
+                                   double aug_z, float rot_aug_resolution, int V, float rot_resolution, int32_t* trans_idx,
+                                   int32_t* rot_grip_idx, float* xf, int32_t* status, vxb_stream_t stream) {
+    return se3_relabel_launch(1, pose, rot_grip_in, nullptr, nullptr, bounds, bounds_rows, layer, shift_unit, rpy_steps, K, B, aug_x, aug_y,
+                              aug_z, rot_aug_resolution, V, rot_resolution, trans_idx, rot_grip_idx, nullptr, nullptr, xf, status, stream);
+}
+
+// Two arms under ONE perturbation (apply_se3_augmentation_2Robots, augmentation.py:187-348): same draws for both poses, the
+// attempt is kept only when BOTH arms' translation indices stay inside the grid (:237), and the point-cloud transform xf is
+// centred on the RIGHT arm's pose (:346).
+extern "C" int vxb_se3_relabel_pair_f32(const float* pose_right, const int32_t* rot_grip_right, const float* pose_left,
+                                        const int32_t* rot_grip_left, const float* bounds, int bounds_rows, int layer,
+                                        const float* shift_unit, const int32_t* rpy_steps, int K, int B, double aug_x, double aug_y,
+                                        double aug_z, float rot_aug_resolution, int V, float rot_resolution, int32_t* trans_idx_right,
+                                        int32_t* rot_grip_idx_right, int32_t* trans_idx_left, int32_t* rot_grip_idx_left, float* xf,
+                                        int32_t* status, vxb_stream_t stream) {
+    return se3_relabel_launch(2, pose_right, rot_grip_right, pose_left, rot_grip_left, bounds, bounds_rows, layer, shift_unit, rpy_steps,
+                              K, B, aug_x, aug_y, aug_z, rot_aug_resolution, V, rot_resolution, trans_idx_right, rot_grip_idx_right,
+                              trans_idx_left, rot_grip_idx_left, xf, status, stream);
 }

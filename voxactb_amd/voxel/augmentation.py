@@ -23,6 +23,7 @@ import torch
 from .._lib import VoxactbHipError, call, require_cuda
 
 MAX_ATTEMPTS = 100        # augmentation.py:119
+MAX_ATTEMPTS_2ROBOTS = 400        # augmentation.py:239
 
 
 def _draws(bs, rot_aug_range, rot_aug_resolution, attempts):
@@ -88,3 +89,44 @@ def apply_se3_augmentation(pcd, action_gripper_pose, action_trans, action_rot_gr
         raise Exception('Failing to perturb action and keep it within bounds.')
     return trans_idx.to(action_trans.dtype if action_trans.dtype in (torch.int32, torch.int64) else torch.int64), \
         rot_idx.to(torch.int64), transform_point_clouds([p.to(device) for p in pcd], xform)
+
+
+def se3_augmentation_plan_2robots(pose_right, rot_grip_right, pose_left, rot_grip_left, bounds, layer, trans_aug_range,
+                                  rot_aug_range, rot_aug_resolution, voxel_size, rot_resolution, device,
+                                  attempts=MAX_ATTEMPTS_2ROBOTS, draws=None):
+    """Both arms of the `one_policy_more_heads` baseline under ONE perturbation (reference :187-348): the same shift and
+    rotation for both keyframe poses, re-drawn while either arm's translation label leaves the grid, the cloud transform
+    centred on the right arm.  -> (trans_right, rot_grip_right, trans_left, rot_grip_left, xform [B,15], status [1])."""
+    require_cuda(pose_right, rot_grip_right, pose_left, rot_grip_left, bounds)
+    bs = pose_right.shape[0]
+    dev = pose_right.device
+    if draws is None:
+        draws = _draws(bs, rot_aug_range, rot_aug_resolution, attempts)
+    unit = draws[0].to(device=dev, dtype=torch.float32).contiguous()
+    steps = draws[1].to(device=dev, dtype=torch.int32).contiguous()
+    bnd = bounds.float().reshape(-1, 6).contiguous()
+    if bnd.shape[0] not in (1, bs):
+        raise VoxactbHipError('bounds must have 1 or B rows')
+    aug = [float(v) for v in torch.as_tensor(trans_aug_range, dtype=torch.float64).reshape(-1)[:3]]
+    out = [torch.empty((bs, n), dtype=torch.int32, device=dev) for n in (3, 4, 3, 4)]
+    xform = torch.empty((bs, 15), dtype=torch.float32, device=dev)
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    call('vxb_se3_relabel_pair_f32', pose_right.float().contiguous(), rot_grip_right.to(torch.int32).contiguous(),
+         pose_left.float().contiguous(), rot_grip_left.to(torch.int32).contiguous(), bnd, bnd.shape[0], int(layer), unit, steps,
+         unit.shape[0], bs, aug[0], aug[1], aug[2], float(rot_aug_resolution), int(voxel_size), float(rot_resolution),
+         out[0], out[1], out[2], out[3], xform, status)
+    return out[0], out[1], out[2], out[3], xform, status
+
+
+def apply_se3_augmentation_2Robots(pcd, action_gripper_pose_right, action_trans_right, action_rot_grip_right,
+                                   action_gripper_pose_left, action_trans_left, action_rot_grip_left, bounds, layer,
+                                   trans_aug_range, rot_aug_range, rot_aug_resolution, voxel_size, rot_resolution, device):
+    """Reference signature and return values (:187-201, :348)."""
+    tr, rr, tl, rl, xform, status = se3_augmentation_plan_2robots(
+        action_gripper_pose_right.to(device), action_rot_grip_right.to(device), action_gripper_pose_left.to(device),
+        action_rot_grip_left.to(device), bounds.to(device), layer, trans_aug_range, rot_aug_range, rot_aug_resolution,
+        voxel_size, rot_resolution, device)
+    if int(status.item()) < 0:
+        raise Exception('Failing to perturb action and keep it within bounds.')
+    return tr.to(torch.int64), rr.to(torch.int64), tl.to(torch.int64), rl.to(torch.int64), \
+        transform_point_clouds([p.to(device) for p in pcd], xform)
