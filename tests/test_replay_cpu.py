@@ -205,3 +205,69 @@ def test_run_seed_call_sequence_with_stub_demos(tmp_path):
     assert first['rot_grip_action_indicies'][0, 0].tolist() == want_r
     assert first['front_rgb'][0, 0, 0, 0, 0] == 0 and first['front_rgb_tp1'][0, 0, 0, 0, 0] == 3      # obs at the start point, tp1 = keyframe
     replay_buffer.shutdown()
+
+
+def test_two_arm_fill_for_the_one_policy_more_heads_baseline(tmp_path):
+    """which_arm='both' (SURVEY 8a row a25): `_get_action` returns both arms' labels (reference launch_utils.py:229-298),
+    `_add_keypoints_to_replay` stores them under the `_right` / `_left` names QAttentionPerActBCAgent2Robots.update reads
+    (agent :1227-1233), `create_agent` builds the 2Robots stack."""
+    lu = peract_bc.launch_utils
+    cams, V, HW = ['front'], 16, 8
+    cfg = lu.default_cfg(method__voxel_sizes=[V], method__voxel_patch_size=3, method__voxel_patch_stride=4, method__transformer_depth=1,
+                         method__num_latents=16, rlbench__cameras=cams, rlbench__camera_resolution=[HW, HW], replay__batch_size=2,
+                         method__which_arm='both', method__variant='one_policy_more_heads')
+    cfg.method.keypoint_discovery_no_duplicate = False
+    cfg.method.saved_every_last_inserted = 0
+    cfg.method.crop_radius = 0.0
+    cfg.method.is_real_robot = False
+    cfg.rlbench.demo_path, cfg.rlbench.episode_length = 'unused', 10
+    cfg.framework.logging_level = 20
+    cfg.method.use_default_stopped_buffer_timesteps, cfg.method.stopped_buffer_timesteps_overwrite = True, 0
+    right, left = _demo(12, 'right').obs, _demo(12, 'left').obs
+    for o, l in zip(right, left):
+        o.gripper_left_pose = l.gripper_left_pose + np.array([0.1, 0.05, 0.0, 0, 0, 0, 0])
+        o.gripper_left_open = 1.0 - o.gripper_right_open
+    demo = _Demo(right)
+
+    def extract_obs(obs, t, cameras, episode_length, which_arm):
+        assert which_arm == 'both'
+        d = {'low_dim_state_right_arm': np.full(4, obs.index, np.float32), 'low_dim_state_left_arm': np.full(4, -obs.index, np.float32),
+             'ignore_collisions': np.array([obs.ignore_collisions], dtype=np.float32)}
+        for c in cameras:
+            d['%s_rgb' % c] = np.full((3, HW, HW), obs.index, np.float32)
+            d['%s_point_cloud' % c] = np.full((3, HW, HW), 0.5, np.float32)
+            d['%s_camera_extrinsics' % c] = np.eye(4, dtype=np.float32)
+            d['%s_camera_intrinsics' % c] = np.eye(3, dtype=np.float32)
+        return d
+
+    class Clip:
+        def encode_text_with_embeddings(self, tokens):
+            return torch.ones(1, 1024), torch.ones(1, 77, 512)
+
+    lu.set_upstream(get_stored_demos=lambda **kw: [demo], keypoint_discovery=lambda demo, **kw: ([3, 7, 11], [0, 1, 0]),
+                    extract_obs=extract_obs, tokenize=lambda texts: np.zeros((1, 77), np.int64))
+    rb = lu.create_replay(2, 1, False, True, str(tmp_path / 'replay'), cams, [V], [HW, HW], which_arm='both')
+    lu.fill_replay(cfg, None, 0, rb, 'open_jar', 0, 1, False, 5, cams, cfg.rlbench.scene_bounds, [V], cfg.method.bounds_offset,
+                   cfg.method.rotation_resolution, False, clip_model=Clip(), keypoint_method='heuristic')
+    assert int(rb.add_count) == 4                                        # 3 transitions + the terminal observation
+    from voxactb_amd.helpers import rotation
+    row = rb.sample_transition_batch(1, indices=[0])
+    o = demo[3]
+    for side in ('right', 'left'):
+        pose = getattr(o, 'gripper_%s_pose' % side)
+        want_t = rotation.point_to_voxel_index(pose[:3], V, np.array(cfg.rlbench.scene_bounds))
+        q = rotation.normalize_quaternion(pose[3:])
+        want_r = rotation.quaternion_to_discrete_euler(q if q[-1] >= 0 else -q, 5).tolist() + [int(getattr(o, 'gripper_%s_open' % side))]
+        assert row['trans_action_indicies_%s' % side][0, 0].tolist() == want_t.tolist()
+        assert row['rot_grip_action_indicies_%s' % side][0, 0].tolist() == want_r
+        assert np.allclose(row['gripper_pose_%s' % side][0, 0], pose)
+    assert row['low_dim_state_left_arm'][0, 0, 0] == 0 and row['low_dim_state_left_arm_tp1'][0, 0, 0] == -3
+    assert row['label'][0, 0, 0] == 0
+    # nine-tuple of the two-arm action (launch_utils.py:296-298)
+    got = lu._get_action(o, demo[2], cfg.rlbench.scene_bounds, [V], cfg.method.bounds_offset, 5, False, 'both', 0)
+    assert len(got) == 9 and got[3].shape == (8,) and got[7].shape == (8,)
+    agent = lu.create_agent(cfg)
+    assert type(agent._pose_agent).__name__ == 'QAttentionStackAgent2Robots'
+    assert type(agent._pose_agent._qattention_agents[0]).__name__ == 'QAttentionPerActBCAgent2Robots'
+    assert type(agent._pose_agent._qattention_agents[0]._perceiver_encoder).__name__ == 'PerceiverVoxelLang2RobotsEncoder'
+    rb.shutdown()

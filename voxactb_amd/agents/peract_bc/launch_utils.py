@@ -18,9 +18,9 @@ import numpy as np
 
 from ...helpers import rotation
 from ...helpers.preprocess_agent import PreprocessAgent
-from .perceiver_lang_io import PerceiverVoxelLangEncoder
-from .qattention_peract_bc_agent import QAttentionPerActBCAgent
-from .qattention_stack_agent import QAttentionStackAgent
+from .perceiver_lang_io import PerceiverVoxelLangEncoder, PerceiverVoxelLang2RobotsEncoder
+from .qattention_peract_bc_agent import QAttentionPerActBCAgent, QAttentionPerActBCAgent2Robots
+from .qattention_stack_agent import QAttentionStackAgent, QAttentionStackAgent2Robots
 
 REWARD_SCALE = 100.0
 LOW_DIM_DOMINANT_ASSISTIVE_SIZE = 7
@@ -67,10 +67,23 @@ def replay_schema(cameras, voxel_sizes, image_size=(128, 128), which_arm='right'
         low = LOW_DIM_DOMINANT_ASSISTIVE_SIZE + (1 if arm_id_to_proprio else 0)
     else:
         low = LOW_DIM_SIZE
-    el = [('low_dim_state', (low,), np.float32)]
+    if which_arm == 'both':     # one_policy_more_heads: one proprio vector per arm (:58-62)
+        el = [('low_dim_state_right_arm', (low,), np.float32), ('low_dim_state_left_arm', (low,), np.float32)]
+    else:
+        el = [('low_dim_state', (low,), np.float32)]
     for c in cameras:
         el += [('%s_rgb' % c, (3, *image_size), np.float32), ('%s_point_cloud' % c, (3, *image_size), np.float32),
                ('%s_camera_extrinsics' % c, (4, 4), np.float32), ('%s_camera_intrinsics' % c, (3, 3), np.float32)]
+    if which_arm == 'both':
+        # the names QAttentionPerActBCAgent2Robots.update reads (agent :1227-1233) and _add_keypoints_to_replay writes
+        # (:419-430).  Upstream's own declaration of this branch (:90-117) lists `rot_grip_action_indicies` / `gripper_pose`
+        # for the left arm and `ignore_collisions` twice -- names its fill never provides; the coherent set is declared here.
+        el += [('trans_action_indicies_right', (3 * len(voxel_sizes),), np.int32), ('rot_grip_action_indicies_right', (4,), np.int32),
+               ('gripper_pose_right', (7,), np.float32), ('trans_action_indicies_left', (3 * len(voxel_sizes),), np.int32),
+               ('rot_grip_action_indicies_left', (4,), np.int32), ('gripper_pose_left', (7,), np.float32),
+               ('ignore_collisions', (1,), np.int32), ('lang_goal_emb', (1024,), np.float32),
+               ('lang_token_embs', (77, 512), np.float32), ('task', (), str), ('lang_goal', (1,), object), ('label', (1,), np.int32)]
+        return el
     el += [('trans_action_indicies', (3 * len(voxel_sizes),), np.int32), ('rot_grip_action_indicies', (4,), np.int32),
            ('ignore_collisions', (1,), np.int32), ('gripper_pose', (7,), np.float32), ('lang_goal_emb', (1024,), np.float32),
            ('lang_token_embs', (77, 512), np.float32), ('task', (), str), ('lang_goal', (1,), object)]
@@ -84,8 +97,6 @@ def replay_schema(cameras, voxel_sizes, image_size=(128, 128), which_arm='right'
 def create_replay(batch_size, timesteps, prioritisation, task_uniform, save_dir, cameras, voxel_sizes,
                   image_size=[128, 128], replay_size=3e5, which_arm='right', crop_target_obj_voxel=False,
                   arm_pred_loss=False, arm_id_to_proprio=False):
-    if which_arm == 'both':
-        raise NotImplementedError("which_arm='both' belongs to the one_policy_more_heads baseline (SURVEY.md a25)")
     from ... import replay as shard_replay
     # upstream puts EVERY schema entry -- camera tensors, discrete actions, pose, language, task -- into
     # `observation_elements` (launch_utils.py:56-145), so each is stored per row, required by add_final and returned with a
@@ -94,7 +105,8 @@ def create_replay(batch_size, timesteps, prioritisation, task_uniform, save_dir,
     elements = []
     for name, shape, dt in replay_schema(cameras, voxel_sizes, tuple(image_size), which_arm, crop_target_obj_voxel,
                                          arm_pred_loss, arm_id_to_proprio):
-        is_obs = name in ('low_dim_state', 'target_object_scene_bounds') or name.endswith(image_like)
+        is_obs = name in ('low_dim_state', 'low_dim_state_right_arm', 'low_dim_state_left_arm',
+                          'target_object_scene_bounds') or name.endswith(image_like)
         elements.append((shard_replay.ObservationElement if is_obs else shard_replay.ReplayElement)(name, shape, dt))
     return shard_replay.ShardReplayBuffer(
         save_dir=save_dir, batch_size=batch_size, timesteps=timesteps, replay_capacity=int(replay_size), action_shape=(8,),
@@ -103,10 +115,9 @@ def create_replay(batch_size, timesteps, prioritisation, task_uniform, save_dir,
 
 
 def create_agent(cfg):
-    """reference :663-829 (variant 'two_policies': the single-arm / acting / stabilizing policies)."""
-    if cfg.method.variant == 'one_policy_more_heads':
-        raise NotImplementedError('one_policy_more_heads (PerceiverVoxelLang2RobotsEncoder) is the upstream baseline, '
-                                  'not the VoxAct-B method (SURVEY.md section 8a row a25)')
+    """reference :663-829: variant 'two_policies' (the single-arm / acting / stabilizing policies) or
+    'one_policy_more_heads' (the baseline with one trunk and a head set per arm, :673-735, :814-820)."""
+    two_robots = cfg.method.variant == 'one_policy_more_heads'
     depth_0bounds = cfg.rlbench.scene_bounds
     cam_resolution = cfg.rlbench.camera_resolution
     num_rotation_classes = int(360. // cfg.method.rotation_resolution)
@@ -118,6 +129,33 @@ def create_agent(cfg):
         else:
             low_dim_size = LOW_DIM_SIZE
         m = cfg.method
+        if two_robots:
+            enc = PerceiverVoxelLang2RobotsEncoder(
+                depth=m.transformer_depth, iterations=m.transformer_iterations, voxel_size=vox_size, initial_dim=3 + 3 + 1 + 3,
+                low_dim_size=LOW_DIM_SIZE, layer=depth, num_rotation_classes=num_rotation_classes if last else 0,
+                num_grip_classes=2 if last else 0, num_collision_classes=2 if last else 0, input_axis=3,
+                num_latents=m.num_latents, latent_dim=m.latent_dim, cross_heads=m.cross_heads, latent_heads=m.latent_heads,
+                cross_dim_head=m.cross_dim_head, latent_dim_head=m.latent_dim_head, weight_tie_layers=False,
+                activation=m.activation, pos_encoding_with_lang=m.pos_encoding_with_lang, input_dropout=m.input_dropout,
+                attn_dropout=m.attn_dropout, decoder_dropout=m.decoder_dropout, lang_fusion_type=m.lang_fusion_type,
+                voxel_patch_size=m.voxel_patch_size, voxel_patch_stride=m.voxel_patch_stride,
+                no_skip_connection=m.no_skip_connection, no_perceiver=m.no_perceiver, no_language=m.no_language,
+                final_dim=m.final_dim)
+            agents.append(QAttentionPerActBCAgent2Robots(
+                layer=depth, coordinate_bounds=depth_0bounds, perceiver_encoder=enc, camera_names=cfg.rlbench.cameras,
+                voxel_size=vox_size, bounds_offset=m.bounds_offset[depth - 1] if depth > 0 else None,
+                image_crop_size=m.image_crop_size, lr=m.lr, training_iterations=cfg.framework.training_iterations,
+                lr_scheduler=m.lr_scheduler, num_warmup_steps=m.num_warmup_steps, trans_loss_weight=m.trans_loss_weight,
+                rot_loss_weight=m.rot_loss_weight, grip_loss_weight=m.grip_loss_weight,
+                collision_loss_weight=m.collision_loss_weight, include_low_dim_state=True, image_resolution=cam_resolution,
+                batch_size=cfg.replay.batch_size, voxel_feature_size=3, lambda_weight_l2=m.lambda_weight_l2,
+                num_rotation_classes=num_rotation_classes, rotation_resolution=m.rotation_resolution,
+                transform_augmentation=m.transform_augmentation.apply_se3,
+                transform_augmentation_xyz=m.transform_augmentation.aug_xyz,
+                transform_augmentation_rpy=m.transform_augmentation.aug_rpy,
+                transform_augmentation_rot_resolution=m.transform_augmentation.aug_rot_resolution,
+                optimizer_type=m.optimizer, num_devices=cfg.ddp.num_devices, wandb_run=cfg.framework.wandb_logging))
+            continue
         enc = PerceiverVoxelLangEncoder(
             depth=m.transformer_depth, iterations=m.transformer_iterations, voxel_size=vox_size, initial_dim=3 + 3 + 1 + 3,
             low_dim_size=low_dim_size, layer=depth, num_rotation_classes=num_rotation_classes if last else 0,
@@ -145,8 +183,9 @@ def create_agent(cfg):
             optimizer_type=m.optimizer, num_devices=cfg.ddp.num_devices, crop_target_obj_voxel=m.crop_target_obj_voxel,
             wandb_run=cfg.framework.wandb_logging, arm_pred_loss=m.arm_pred_loss,
             randomizations_crop_point=m.randomizations_crop_point))
-    rotation_agent = QAttentionStackAgent(qattention_agents=agents, rotation_resolution=cfg.method.rotation_resolution,
-                                          camera_names=cfg.rlbench.cameras)
+    stack = QAttentionStackAgent2Robots if two_robots else QAttentionStackAgent
+    rotation_agent = stack(qattention_agents=agents, rotation_resolution=cfg.method.rotation_resolution,
+                           camera_names=cfg.rlbench.cameras)
     return PreprocessAgent(pose_agent=rotation_agent)
 
 
@@ -224,10 +263,17 @@ def _acting_side(which_arm, keypoint_label, dominant_assistive_arm):
 
 def _get_action(obs_tp1, obs_tm1, rlbench_scene_bounds, voxel_sizes, bounds_offset, rotation_resolution, crop_augmentation,
                 which_arm, keypoint_label, dominant_assistive_arm=''):
-    """-> (trans_indicies, rot_and_grip_indicies, ignore_collisions, action[8], attention_coordinates)   (reference :167-228)."""
+    """-> (trans_indicies, rot_and_grip_indicies, ignore_collisions, action[8], attention_coordinates)   (reference :167-228);
+    which_arm == 'both' (one_policy_more_heads, :229-298): (trans_right, rot_grip_right, ignore_collisions, action_right,
+    attention_right, trans_left, rot_grip_left, action_left, attention_left)."""
+    if which_arm == 'both':
+        r = _get_action(obs_tp1, obs_tm1, rlbench_scene_bounds, voxel_sizes, bounds_offset, rotation_resolution,
+                        crop_augmentation, 'right', keypoint_label)
+        le = _get_action(obs_tp1, obs_tm1, rlbench_scene_bounds, voxel_sizes, bounds_offset, rotation_resolution,
+                         crop_augmentation, 'left', keypoint_label)
+        return r[0], r[1], r[2], r[3], r[4], le[0], le[1], le[3], le[4]
     if not (which_arm in SINGLE_ARM or which_arm in ('multiarm', 'dominant', 'assistive')):
-        raise NotImplementedError("which_arm=%r: the two-gripper action belongs to the one_policy_more_heads baseline "
-                                  "(SURVEY.md a25)" % (which_arm,))
+        raise NotImplementedError('which_arm=%r' % (which_arm,))
     side = _acting_side(which_arm, keypoint_label, dominant_assistive_arm)
     gripper_pose = getattr(obs_tp1, 'gripper_%s_pose' % side)
     gripper_open = getattr(obs_tp1, 'gripper_%s_open' % side)
@@ -269,8 +315,7 @@ def _add_keypoints_to_replay(cfg, task, task_idx, replay, inital_obs, demo, epis
     """One replay transition per remaining keyframe of the episode, then the terminal observation (reference :301-488)."""
     import torch
     m = cfg.method
-    if m.which_arm == 'both':
-        raise NotImplementedError("which_arm='both' belongs to the one_policy_more_heads baseline (SURVEY.md a25)")
+    both = m.which_arm == 'both'
     scene_bounds = rlbench_scene_bounds if type(rlbench_scene_bounds[0]) is float else rlbench_scene_bounds[task_idx]
     crop_radius = _per_task(m.crop_radius, task_idx)
     obs = inital_obs
@@ -283,9 +328,9 @@ def _add_keypoints_to_replay(cfg, task, task_idx, replay, inital_obs, demo, epis
             radius = obs_tp1.auto_crop_radius if (crop_radius == 'auto' and obs_tp1.auto_crop_radius != 0.0) else crop_radius
             scene_bounds = UPSTREAM.get_new_scene_bounds_based_on_crop(radius, obs_tp1.target_object_pos)
         keypoint_label = labels[k] if labels is not None else -1
-        trans_indicies, rot_grip_indicies, ignore_collisions, action, _ = _get_action(
-            obs_tp1, obs_tm1, scene_bounds, voxel_sizes, bounds_offset, rotation_resolution, crop_augmentation, m.which_arm,
-            keypoint_label, dominant_assistive_arm)
+        got = _get_action(obs_tp1, obs_tm1, scene_bounds, voxel_sizes, bounds_offset, rotation_resolution, crop_augmentation,
+                          m.which_arm, keypoint_label, dominant_assistive_arm)
+        trans_indicies, rot_grip_indicies, ignore_collisions, action = got[0], got[1], got[2], got[3]
         terminal = (k == len(episode_keypoints) - 1)
         reward = float(terminal) * REWARD_SCALE if terminal else 0
         which_arm, text = m.which_arm, description
@@ -304,13 +349,19 @@ def _add_keypoints_to_replay(cfg, task, task_idx, replay, inital_obs, demo, epis
         sentence_emb, token_embs = clip_model.encode_text_with_embeddings(tokens)
         obs_dict['lang_goal_emb'] = sentence_emb[0].float().detach().cpu().numpy()
         obs_dict['lang_token_embs'] = token_embs[0].float().detach().cpu().numpy()
-        side = _acting_side(m.which_arm, keypoint_label, dominant_assistive_arm)
         if m.crop_target_obj_voxel:
             obs_dict['target_object_scene_bounds'] = scene_bounds
-        final_obs = {'trans_action_indicies': trans_indicies, 'rot_grip_action_indicies': rot_grip_indicies,
-                     'gripper_pose': getattr(obs_tp1, 'gripper_%s_pose' % side), 'task': task,
-                     'lang_goal': np.array([text], dtype=object)}
-        if m.arm_pred_loss:
+        if both:                                     # :419-430 (the stored `action` is the right arm's, :457-459)
+            final_obs = {'trans_action_indicies_right': got[0], 'rot_grip_action_indicies_right': got[1],
+                         'gripper_pose_right': obs_tp1.gripper_right_pose, 'trans_action_indicies_left': got[5],
+                         'rot_grip_action_indicies_left': got[6], 'gripper_pose_left': obs_tp1.gripper_left_pose,
+                         'task': task, 'lang_goal': np.array([text], dtype=object), 'label': [labels[k]]}
+        else:
+            side = _acting_side(m.which_arm, keypoint_label, dominant_assistive_arm)
+            final_obs = {'trans_action_indicies': trans_indicies, 'rot_grip_action_indicies': rot_grip_indicies,
+                         'gripper_pose': getattr(obs_tp1, 'gripper_%s_pose' % side), 'task': task,
+                         'lang_goal': np.array([text], dtype=object)}
+        if m.arm_pred_loss and not both:
             final_obs['label'] = [labels[k]]
         others = {'demo': True}
         others.update(final_obs)

@@ -28,7 +28,7 @@ from ...flat_params import FlatParams
 from ...helpers.optim.adam import Adam
 from ...helpers.optim.lamb import Lamb
 from ...helpers.optim.schedule import CosineWithHardRestarts
-from ...voxel.augmentation import se3_augmentation_plan
+from ...voxel.augmentation import se3_augmentation_plan, se3_augmentation_plan_2robots
 from ...voxel.voxel_grid import VoxelGrid
 from ...yarr_agent import Agent, ActResult, ScalarSummary, HistogramSummary, Summary
 
@@ -184,8 +184,7 @@ class QAttentionPerActBCAgent(Agent):
                                     # training: the grid lives for one step (it is returned in `prev_layer_voxel_grid` and
                                     # read by update_summaries), so two buffers updated in place in turn are enough
                                     persistent=2 if training else 0)
-        self._q = QFunction(self._perceiver_encoder, self._voxelizer, self._bounds_offset, self._rotation_resolution, dev,
-                            training, self._arm_pred_loss).to(dev).train(training)
+        self._q = self._make_q(dev, training).to(dev).train(training)
         self._coordinate_bounds = torch.tensor(self._coordinate_bounds, device=dev).unsqueeze(0)
         if self._training:
             self._arena = FlatParams(self._q, dev)
@@ -216,6 +215,10 @@ class QAttentionPerActBCAgent(Agent):
         else:
             for param in self._q.parameters():
                 param.requires_grad = False
+
+    def _make_q(self, dev, training):
+        return QFunction(self._perceiver_encoder, self._voxelizer, self._bounds_offset, self._rotation_resolution, dev,
+                         training, self._arm_pred_loss)
 
     def set_text_encoder(self, fn):
         """fn(tokens [77] long) -> (lang_goal_emb [1,1024], lang_token_embs [1,77,512]).  Upstream loads CLIP RN50 here
@@ -484,3 +487,194 @@ class QAttentionPerActBCAgent(Agent):
 
     def save_weights(self, savedir: str):
         torch.save(self._q.state_dict(), os.path.join(savedir, '%s.pt' % self._name))
+
+
+# ======================================================================================================================
+# one_policy_more_heads baseline: ONE policy predicts both arms' actions from both arms' proprioception
+# ======================================================================================================================
+class QFunction2Robots(QFunction):
+    """reference agent :882-964."""
+
+    def __init__(self, perceiver_encoder: nn.Module, voxelizer: VoxelGrid, bounds_offset: float, rotation_resolution: float,
+                 device, training):
+        super().__init__(perceiver_encoder, voxelizer, bounds_offset, rotation_resolution, device, training, False)
+
+    def forward(self, rgb_pcd, proprio_right, proprio_left, pcd, lang_goal_emb, lang_token_embs, bounds=None, prev_bounds=None,
+                prev_layer_voxel_grid=None):
+        """-> (q_trans_right, q_rot_grip_right, q_collision_right, voxel_grid, q_trans_left, q_rot_grip_left,
+        q_collision_left)   (agent :924-964)."""
+        grid = self.voxelize(rgb_pcd, pcd, bounds)
+        voxel_grid = grid.permute(0, 4, 1, 2, 3).detach()
+        outs, _ = self.encoder.engine().forward(grid, proprio_right, lang_token_embs, training=False, save=False,
+                                                proprio_left=proprio_left)
+        return outs[0], outs[1], outs[2], voxel_grid, outs[3], outs[4], outs[5]
+
+
+class QAttentionPerActBCAgent2Robots(QAttentionPerActBCAgent):
+    """reference agent :966-1672.  Same constructor as upstream (no crop / arm-prediction options)."""
+
+    def __init__(self, layer: int, coordinate_bounds: list, perceiver_encoder: nn.Module, camera_names: list,
+                 batch_size: int, voxel_size: int, bounds_offset: float, voxel_feature_size: int, image_crop_size: int,
+                 num_rotation_classes: int, rotation_resolution: float, lr: float = 0.0001, lr_scheduler: bool = False,
+                 training_iterations: int = 100000, num_warmup_steps: int = 20000, trans_loss_weight: float = 1.0,
+                 rot_loss_weight: float = 1.0, grip_loss_weight: float = 1.0, collision_loss_weight: float = 1.0,
+                 include_low_dim_state: bool = False, image_resolution: list = None, lambda_weight_l2: float = 0.0,
+                 transform_augmentation: bool = True, transform_augmentation_xyz: list = [0.0, 0.0, 0.0],
+                 transform_augmentation_rpy: list = [0.0, 0.0, 180.0], transform_augmentation_rot_resolution: int = 5,
+                 optimizer_type: str = 'adam', num_devices: int = 1, wandb_run=None):
+        super().__init__(layer, coordinate_bounds, perceiver_encoder, camera_names, batch_size, voxel_size, bounds_offset,
+                         voxel_feature_size, image_crop_size, num_rotation_classes, rotation_resolution, lr, lr_scheduler,
+                         training_iterations, num_warmup_steps, trans_loss_weight, rot_loss_weight, grip_loss_weight,
+                         collision_loss_weight, include_low_dim_state, image_resolution, lambda_weight_l2,
+                         transform_augmentation, transform_augmentation_xyz, transform_augmentation_rpy,
+                         transform_augmentation_rot_resolution, optimizer_type, num_devices, wandb_run=wandb_run)
+
+    def _make_q(self, dev, training):
+        return QFunction2Robots(self._perceiver_encoder, self._voxelizer, self._bounds_offset, self._rotation_resolution, dev,
+                                training)
+
+    def _arm_losses(self, q_trans, o, action_trans, action_rot_grip, action_ignore_collisions, gscale):
+        """the five cross entropies of one arm (agent :1283-1363) and their gradients."""
+        device, V, n = self._dev, self._voxel_size, self._num_rotation_classes
+        bs = q_trans.shape[0]
+        w = self._loss_weights or (1.0, 1.0, 1.0, 1.0, 1.0)
+        at = action_trans.to(device).long()
+        flat_label = ((at[:, 0] * V + at[:, 1]) * V + at[:, 2]).int()
+        dq = torch.empty((bs, V ** 3), dtype=torch.float32, device=device)
+        l_trans, _, amax = ops.ce_big(q_trans.view(bs, -1), flat_label, dq, gscale * w[0])
+        labs = torch.cat([action_rot_grip.to(device).int(), action_ignore_collisions.to(device).int()[:, :1]], dim=1).contiguous()
+        d_o = torch.empty_like(o)
+        l_heads, pred = ops.ce_rows(o, [(0, n), (n, n), (2 * n, n), (3 * n, 2), (3 * n + 2, 2)], labs, d_o, gscale)
+        if self._loss_weights is not None:
+            d_o[:, :3 * n] *= w[1]
+            d_o[:, 3 * n:3 * n + 2] *= w[2]
+            d_o[:, 3 * n + 2:] *= w[3]
+        rot = l_heads[:, 0] + l_heads[:, 1] + l_heads[:, 2]
+        return dict(trans=l_trans, rot=rot, grip=l_heads[:, 3], coll=l_heads[:, 4], dq=dq, d_o=d_o, amax=amax, pred=pred,
+                    combined=l_trans * w[0] + rot * w[1] + l_heads[:, 3] * w[2] + l_heads[:, 4] * w[3])
+
+    def update(self, step: int, replay_sample: dict) -> dict:
+        L = self._layer
+        action_trans_right = replay_sample['trans_action_indicies_right'][:, L * 3:L * 3 + 3].int()
+        action_rot_grip_right = replay_sample['rot_grip_action_indicies_right'].int()
+        action_gripper_pose_right = replay_sample['gripper_pose_right']
+        action_trans_left = replay_sample['trans_action_indicies_left'][:, L * 3:L * 3 + 3].int()
+        action_rot_grip_left = replay_sample['rot_grip_action_indicies_left'].int()
+        action_gripper_pose_left = replay_sample['gripper_pose_left']
+        action_ignore_collisions = replay_sample['ignore_collisions'].int()
+        lang_token_embs = replay_sample['lang_token_embs'].float()
+        prev_layer_voxel_grid = replay_sample.get('prev_layer_voxel_grid', None)
+        prev_layer_bounds = replay_sample.get('prev_layer_bounds', None)
+        device = self._dev
+        bounds = self._coordinate_bounds.to(device)
+        if L > 0:
+            cp = replay_sample['attention_coordinate_layer_%d' % (L - 1)]
+            bounds = torch.cat([cp - self._bounds_offset, cp + self._bounds_offset], dim=1)
+        proprio_right = proprio_left = None
+        if self._include_low_dim_state:
+            proprio_right = replay_sample['low_dim_state_right_arm']
+            proprio_left = replay_sample['low_dim_state_left_arm']
+        obs, pcd = self._preprocess_inputs(replay_sample)
+        bs = pcd[0].shape[0]
+
+        xform = None
+        if self._transform_augmentation:                                       # agent :1260-1281
+            self._check_se3_status()
+            action_trans_right, action_rot_grip_right, action_trans_left, action_rot_grip_left, xform, self._se3_status = \
+                se3_augmentation_plan_2robots(
+                    action_gripper_pose_right.to(device), action_rot_grip_right.to(device), action_gripper_pose_left.to(device),
+                    action_rot_grip_left.to(device), bounds, L, self._transform_augmentation_xyz,
+                    self._transform_augmentation_rpy, self._transform_augmentation_rot_resolution, self._voxel_size,
+                    self._rotation_resolution, device)
+
+        grid = self._q.voxelize(obs, pcd, bounds, xform)
+        voxel_grid = grid.permute(0, 4, 1, 2, 3).detach()
+        eng = self._q.encoder.engine()
+        outs, cache = eng.forward(grid, proprio_right, lang_token_embs, training=True, save=True, proprio_left=proprio_left)
+
+        world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            world = torch.distributed.get_world_size()
+        gscale = 1.0 / (bs * world)
+        r = self._arm_losses(outs[0], cache['o'], action_trans_right, action_rot_grip_right, action_ignore_collisions, gscale)
+        l = self._arm_losses(outs[3], cache['left']['o'], action_trans_left, action_rot_grip_left, action_ignore_collisions, gscale)
+        total_loss = (r['combined'] + l['combined']).mean()                   # agent :1365-1369
+
+        self._arena.zero_grad()
+        eng.backward(cache, r['dq'], r['d_o'], None, on_bucket_ready=self._arena.reduce_bucket, dq_trans_left=l['dq'],
+                     d_o_left=l['d_o'])
+        self._arena.finish_reduce()
+        self._optimizer.step()
+
+        V = self._voxel_size
+
+        def coords_of(amax):
+            return torch.stack([torch.div(torch.div(amax, V, rounding_mode='trunc'), V, rounding_mode='trunc'),
+                                torch.div(amax, V, rounding_mode='trunc') % V, amax % V], 1).long()
+        self._summaries = {
+            'losses/total_loss': total_loss,
+            'losses/trans_loss': (r['trans'] + l['trans']).mean(),
+            'losses/rot_loss': (r['rot'] + l['rot']).mean(),
+            'losses/grip_loss': (r['grip'] + l['grip']).mean(),
+            'losses/collision_loss': (r['coll'] + l['coll']).mean(),
+        }
+        if self._lr_scheduler:
+            self._scheduler.step()
+            self._summaries['learning_rate'] = self._scheduler.get_last_lr()[0]
+        self._vis_voxel_grid = voxel_grid[0]
+        self._vis_max_coordinate_right, self._vis_gt_coordinate_right = coords_of(r['amax'])[0], action_trans_right[0]
+        self._vis_max_coordinate_left, self._vis_gt_coordinate_left = coords_of(l['amax'])[0], action_trans_left[0]
+        self._last_pred = (coords_of(r['amax']), r['pred'], coords_of(l['amax']), l['pred'])
+        prev_layer_voxel_grid = [voxel_grid] if prev_layer_voxel_grid is None else prev_layer_voxel_grid + [voxel_grid]
+        if prev_layer_bounds is None:
+            prev_layer_bounds = [self._coordinate_bounds.repeat(bs, 1)]
+        else:
+            prev_layer_bounds = prev_layer_bounds + [bounds]
+        return {'total_loss': total_loss, 'prev_layer_voxel_grid': prev_layer_voxel_grid,
+                'prev_layer_bounds': prev_layer_bounds}
+
+    def act(self, step: int, observation: dict, deterministic=False) -> ActResult:
+        """agent :1457-1582: both arms' actions from one forward."""
+        bounds = self._coordinate_bounds
+        prev_layer_voxel_grid = observation.get('prev_layer_voxel_grid', None)
+        prev_layer_bounds = observation.get('prev_layer_bounds', None)
+        if 'lang_token_embs' in observation:
+            lang_goal_emb = observation['lang_goal_emb']
+            lang_token_embs = observation['lang_token_embs']
+            while lang_token_embs.dim() > 3:
+                lang_token_embs = lang_token_embs[0]
+        else:
+            if self._text_encoder is None:
+                raise VoxactbHipError('act(): no text encoder set (set_text_encoder) and no precomputed lang_token_embs '
+                                      'in the observation; upstream loads CLIP RN50 weights that are not in the tree')
+            tokens = observation.get('lang_goal_tokens', None).long()
+            with torch.no_grad():
+                lang_goal_emb, lang_token_embs = self._text_encoder(tokens[0].to(self._dev))
+        res = (bounds[:, 3:] - bounds[:, :3]) / self._voxel_size
+        obs, pcd = self._act_preprocess_inputs(observation)
+        obs = [[o[0][0].to(self._dev), o[1][0].to(self._dev)] for o in obs]
+        proprio_right = observation['low_dim_state_right_arm'][0].to(self._dev)
+        proprio_left = observation['low_dim_state_left_arm'][0].to(self._dev)
+        pcd = [p[0].to(self._dev) for p in pcd]
+        lang_token_embs = lang_token_embs.to(self._dev).float()
+        bounds = torch.as_tensor(bounds, device=self._dev)
+        qtr, qrr, qcr, vox_grid, qtl, qrl, qcl = self._q(obs, proprio_right, proprio_left, pcd, lang_goal_emb, lang_token_embs,
+                                                        bounds, prev_layer_bounds, prev_layer_voxel_grid)
+        out = {}
+        for side, qt, qr, qc in (('right', qtr, qrr, qcr), ('left', qtl, qrl, qcl)):
+            qt = self._softmax_q_trans(qt)
+            coords, rot_grip, coll = self._q.choose_highest_action(qt, self._softmax_q_rot_grip(qr), self._softmax_ignore_collision(qc))
+            coords = coords.int()
+            out[side] = (qt, coords, rot_grip, coll.int(), bounds[:, :3] + res * coords + res / 2)
+        prev_layer_voxel_grid = [vox_grid] if prev_layer_voxel_grid is None else prev_layer_voxel_grid + [vox_grid]
+        prev_layer_bounds = [bounds] if prev_layer_bounds is None else prev_layer_bounds + [bounds]
+        observation_elements = {'attention_coordinate_right': out['right'][4], 'attention_coordinate_left': out['left'][4],
+                                'prev_layer_voxel_grid': prev_layer_voxel_grid, 'prev_layer_bounds': prev_layer_bounds}
+        info = {'voxel_grid_depth%d' % self._layer: vox_grid,
+                'q_depth_right%d' % self._layer: out['right'][0], 'voxel_idx_depth_right%d' % self._layer: out['right'][1],
+                'q_depth_left%d' % self._layer: out['left'][0], 'voxel_idx_depth_left%d' % self._layer: out['left'][1]}
+        self._act_voxel_grid = vox_grid[0]
+        self._act_max_coordinate_right, self._act_qvalues_right = out['right'][1][0], out['right'][0][0].detach()
+        self._act_max_coordinate_left, self._act_qvalues_left = out['left'][1][0], out['left'][0][0].detach()
+        return ActResult((out['right'][1], out['right'][2], out['right'][3], out['left'][1], out['left'][2], out['left'][3]),
+                         observation_elements=observation_elements, info=info)

@@ -100,3 +100,46 @@ class QAttentionStackAgent(Agent):
     def save_weights(self, savedir: str):
         for qa in self._qattention_agents:
             qa.save_weights(savedir)
+
+
+class QAttentionStackAgent2Robots(QAttentionStackAgent):
+    """reference qattention_stack_agent.py:127-276: the per-depth agents return both arms' actions; `which_arm` picks the one
+    that is turned into the continuous action."""
+
+    def act(self, step: int, observation: dict, deterministic=False, which_arm=None, new_scene_bounds=None, *_ignored,
+            **_ignored_kw) -> ActResult:
+        # (upstream's signature ends at new_scene_bounds, :153-154; PreprocessAgent passes the single-arm extras positionally)
+        if which_arm not in ('right', 'left'):
+            raise NotImplementedError
+        key = 'attention_coordinate_' + which_arm
+        observation_elements, infos = {}, {}
+        trans, rot_grip, coll = [], [], []
+        for depth, qagent in enumerate(self._qattention_agents):
+            act_results = qagent.act(step, observation, deterministic)
+            attention_coordinate = act_results.observation_elements[key].cpu().numpy()
+            observation_elements['attention_coordinate_layer_%d' % depth] = attention_coordinate[0]
+            a = act_results.action
+            t, r, c = (a[0], a[1], a[2]) if which_arm == 'right' else (a[3], a[4], a[5])
+            trans.append(t)
+            if r is not None:
+                rot_grip.append(r)
+            if c is not None:
+                coll.append(c)
+            observation['attention_coordinate'] = act_results.observation_elements[key]
+            observation['prev_layer_voxel_grid'] = act_results.observation_elements['prev_layer_voxel_grid']
+            observation['prev_layer_bounds'] = act_results.observation_elements['prev_layer_bounds']
+            for n in self._camera_names:
+                px, py = point_to_pixel_index(attention_coordinate[0],
+                                              observation['%s_camera_extrinsics' % n][0, 0].cpu().numpy(),
+                                              observation['%s_camera_intrinsics' % n][0, 0].cpu().numpy())
+                observation['%s_pixel_coord' % n] = torch.tensor([[[py, px]]], dtype=torch.float32, device=self._pixel_device())
+                observation_elements['%s_pixel_coord' % n] = [py, px]
+            infos.update(act_results.info)
+        rgai = torch.cat(rot_grip, 1)[0].cpu().numpy()
+        ignore_collisions = float(torch.cat(coll, 1)[0, 0].cpu().numpy())
+        observation_elements['trans_action_indicies'] = torch.cat(trans, 1)[0].cpu().numpy()
+        observation_elements['rot_grip_action_indicies'] = rgai
+        continuous_action = np.concatenate([act_results.observation_elements[key].cpu().numpy()[0],
+                                            discrete_euler_to_quaternion(rgai[-4:-1], self._rotation_resolution), rgai[-1:],
+                                            [ignore_collisions]])
+        return ActResult(continuous_action, observation_elements=observation_elements, info=infos)
