@@ -164,8 +164,9 @@ def main():
     if rank == 0 and not a.no_other_modes:
         probe = reference_digest_check(dev, headline_mode, V, a.depth, a.latents, HW)
 
-    # act() latency: eval agent, B=1 observation with precomputed language embeddings (the CLIP text
-    # encoder's weights are not in either tree), 1 voxelize + 1 forward + argmax + the D2H copy of the 9-vector action
+    # act() latency: eval agent, B=1 observation, 1 voxelize + 1 forward + argmax + the D2H copy of the 9-vector
+    # action -- with precomputed language embeddings, and with the CLIP text transformer in front (helpers/clip_text.py; the RN50
+    # checkpoint is in neither tree, so its text half runs on name-hashed weights of the same shapes)
     act_lat = None
     if rank == 0 and not a.no_other_modes:
         ev = lu.create_agent(cfg)
@@ -186,7 +187,22 @@ def main():
         torch.cuda.synchronize()
         act_lat = {'ms_per_act': (time.perf_counter() - t0) / 10 * 1e3, 'precision': ev._pose_agent._qattention_agents[0]._q.encoder.engine().precision,
                    'what': 'QAttentionPerActBCAgent.act(): B=1, V=%d, %d cams %dx%d, language embeddings given' % (V, len(cfg.rlbench.cameras), HW, HW)}
-        del ev
+        from voxactb_amd.helpers.clip_text import ClipTextEncoder
+        text = ClipTextEncoder(synthetic.hashed_clip_text_state_dict(), dev)
+        ev._pose_agent._qattention_agents[0].set_text_encoder(text.for_agent())
+        obs_t = {k: v for k, v in obs.items() if k not in ('lang_goal_emb', 'lang_token_embs')}
+        tok = torch.zeros((1, 1, 77), dtype=torch.long, device=dev)
+        tok[0, 0, :5] = torch.tensor([49406, 1000, 2000, 3000, 49407])
+        obs_t['lang_goal_tokens'] = tok
+        for i in range(3):
+            ev.act(i, dict(obs_t), deterministic=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(10):
+            ev.act(i, dict(obs_t), deterministic=True)
+        torch.cuda.synchronize()
+        act_lat['ms_per_act_with_text_encoder'] = (time.perf_counter() - t0) / 10 * 1e3
+        del ev, text
 
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3

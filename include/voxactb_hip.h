@@ -325,6 +325,15 @@ int vxb_sum_splits_f32(const float* part, int nsplit, int64_t n, float* dst, int
 int vxb_colsum_f32(const float* x, int64_t rows, int N, int64_t ld, float* part_ws, float* out, int accumulate,
                    vxb_stream_t stream);
 
+/* CLIP text transformer pieces of the act() path (reference peract/helpers/clip/core/clip.py:426-440
+ * encode_text_with_embeddings, :224-245 ResidualAttentionBlock, :219-221 QuickGELU): token + positional embedding (or a
+ * plain row gather with pos == NULL), x * sigmoid(1.702 x) in place, and the causal multi-head self-attention of n short
+ * sequences (L <= 128, heads of 64; qkv = nn.MultiheadAttention's in_proj output q | k | v). */
+int vxb_embed_rows_f32(const int32_t* idx, const float* table, const float* pos, float* out, int64_t rows, int L, int D,
+                       int64_t table_rows, vxb_stream_t stream);
+int vxb_quick_gelu_f32(float* x, int64_t n, vxb_stream_t stream);
+int vxb_attn_causal_small_f32(const float* qkv, float* out, int n, int L, int H, vxb_stream_t stream);
+
 /* context assembly cat(lang, cat(patch, proprio)) + pos_encoding (perceiver_lang_io.py:370-422) and its adjoint.  pp is
    [B, Cp]: Cp = C for one proprio vector, 2 C for the right | left pair of the 2Robots encoder (perceiver_lang_io.py:721-727);
    the context is C + Cp wide. */

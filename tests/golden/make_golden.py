@@ -281,6 +281,37 @@ def encoder2_fixture(name, cfg):
     save(name, **arrs)
 
 
+
+# ----------------------------------------------------------------------------- F12: CLIP text encoder (act() path)
+F12_SENTENCES = ['open the jar', 'open the drawer', 'put the cube in the drawer with the left arm',
+                 "Don't spill: hold the jar's lid, then twist 2 times!"]
+
+
+def f12_clip_text():
+    """reference CLIP class (helpers/clip/core/clip.py:289-440) with name-hashed TEXT weights, fp32, on sentences tokenized by
+    the reference tokenizer (simple_tokenizer.py + its BPE vocabulary): token ids, sentence features, token embeddings."""
+    stub_modules()
+    sys.modules['ftfy'].fix_text = lambda t: t            # ftfy is not installed here; identity on these ASCII sentences
+    sys.path.insert(0, os.path.join(REF, 'peract'))
+    # clip.py uses a relative import of its tokenizer: load it as the submodule of a stand-in package
+    import types
+    pkg = types.ModuleType('ref_clip_pkg')
+    pkg.__path__ = [os.path.join(REF, 'peract', 'helpers', 'clip', 'core')]
+    sys.modules['ref_clip_pkg'] = pkg
+    clip = importlib.import_module('ref_clip_pkg.clip')
+    model = clip.CLIP(1024, 224, (3, 4, 6, 3), 64, None, 77, 49408, 512, 8, 12).float().eval()
+    sd = synthetic.hashed_clip_text_state_dict()
+    missing = model.load_state_dict(sd, strict=False)
+    assert not [k for k in missing.missing_keys if not k.startswith('visual.') and k != 'logit_scale'], missing.missing_keys
+    assert not missing.unexpected_keys
+    tokens = clip.tokenize(F12_SENTENCES)
+    with torch.no_grad():
+        feat, emb = model.encode_text_with_embeddings(tokens)
+    save('f12_clip_text', tokens=tokens, feat=feat, emb=emb, sentences=np.array(F12_SENTENCES))
+    print('f12: |feat| max %.3f, |emb| max %.3f, %d tokens in the longest sentence' % (
+        float(feat.abs().max()), float(emb.abs().max()), int((tokens != 0).sum(1).max())))
+
+
 # ----------------------------------------------------------------------------- F6 / F9: agent-level
 def stub_modules():
     for name in ['torchvision', 'torchvision.transforms', 'pytorch3d', 'pytorch3d.transforms', 'pyrender',
@@ -572,6 +603,7 @@ SECTIONS = {
     'f5v200': lambda: encoder_fixture('f5v200_encoder_c5_digest', CFG_C5, with_grads=False, digest=True),
     'f11tiny': lambda: encoder2_fixture('f11_encoder_2robots_tiny', CFG_TINY),
     'f11c1': lambda: encoder2_fixture('f11_encoder_2robots_c1', CFG_C1),
+    'f12': f12_clip_text,
     'f6': f6_update_traces,
     'f9': f9_act,
     'f10': f10_depth,

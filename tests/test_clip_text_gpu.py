@@ -1,0 +1,71 @@
+"""GPU: the CLIP text encoder of the act() path (voxactb_amd/helpers/clip_text.py) against fixture F12 --
+the reference CLIP class (helpers/clip/core/clip.py:426-440) run in fp32 with name-hashed text weights on sentences
+tokenized by the reference tokenizer."""
+import numpy as np
+import pytest
+import torch
+
+from voxactb_amd import synthetic
+from voxactb_amd.helpers.clip_text import ClipTextEncoder
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope='module')
+def encoder():
+    return ClipTextEncoder(synthetic.hashed_clip_text_state_dict(), DEV)
+
+
+def test_features_and_token_embeddings_match_the_reference(golden, encoder):
+    g = golden('f12_clip_text')
+    feat, emb = encoder.encode_text_with_embeddings(T(g['tokens']))
+    e_f = float((feat.cpu() - T(g['feat'])).abs().max())
+    e_e = float((emb.cpu() - T(g['emb'])).abs().max())
+    print('CLIP text: sentence features %.2e, token embeddings %.2e (|feat| max %.2f)' % (e_f, e_e, float(T(g['feat']).abs().max())))
+    assert emb.shape == (4, 77, 512) and feat.shape == (4, 1024)
+    assert e_f < 5e-5 and e_e < 5e-5
+    # one sequence at a time (what act() passes: tokens[0]) gives the same rows
+    f1, e1 = encoder.encode_text_with_embeddings(T(g['tokens'])[2])
+    assert float((f1 - feat[2:3]).abs().max()) < 1e-5 and float((e1 - emb[2:3]).abs().max()) < 1e-5
+
+
+def test_half_precision_checkpoint_is_widened(encoder):
+    sd = {k: v.half() for k, v in synthetic.hashed_clip_text_state_dict(layers=1).items()}
+    sd['visual.conv1.weight'] = torch.zeros(4, 3, 3, 3).half()         # the visual half of a checkpoint is ignored
+    enc = ClipTextEncoder(sd, DEV)
+    tok = torch.zeros(1, 77, dtype=torch.long)
+    tok[0, :3] = torch.tensor([49406, 320, 49407])
+    feat, emb = enc.encode_text_with_embeddings(tok)
+    assert feat.dtype == torch.float32 and torch.isfinite(feat).all() and torch.isfinite(emb).all()
+
+
+def test_agent_act_uses_the_text_encoder(golden, encoder):
+    """act() without precomputed language embeddings: tokens -> ClipTextEncoder -> Q-function (agent :661-664)."""
+    from oracle import weights as ow
+    from voxactb_amd.agents.peract_bc import launch_utils as lu
+    g = golden('f12_clip_text')
+    cams = ['front', 'wrist']
+    cfg = lu.default_cfg(method__voxel_sizes=[8], method__voxel_patch_size=3, method__voxel_patch_stride=2, method__transformer_depth=1,
+                         method__num_latents=16, replay__batch_size=1, rlbench__cameras=cams, rlbench__camera_resolution=[16, 16])
+    agent = lu.create_agent(cfg)
+    enc = agent._pose_agent._qattention_agents[0]._perceiver_encoder
+    enc.load_state_dict(ow.hashed_state_dict({n: tuple(p.shape) for n, p in enc.named_parameters()}, 0), strict=False)
+    agent.build(training=False, device=0)
+    qa = agent._pose_agent._qattention_agents[0]
+    qa.set_text_encoder(encoder.for_agent())
+    rs = synthetic.make_replay_sample(1, cams, (16, 16), 8, 4, seed=3)
+    obs = {k: v.to(DEV) for k, v in rs.items() if k not in ('lang_goal_emb', 'lang_token_embs')}
+    obs['lang_goal_tokens'] = T(g['tokens'])[0:1][None].to(DEV)            # [1, 1, 77] as the rollout generator stacks it
+    a = agent.act(0, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in obs.items()})
+    # the same observation with the reference's embeddings of that sentence precomputed
+    obs2 = dict(obs)
+    obs2.pop('lang_goal_tokens')
+    obs2['lang_goal_emb'] = T(g['feat'])[0:1].to(DEV)
+    obs2['lang_token_embs'] = T(g['emb'])[0:1].to(DEV)
+    b = agent.act(0, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in obs2.items()})
+    assert np.allclose(a.action, b.action) and a.action.shape == (9,)

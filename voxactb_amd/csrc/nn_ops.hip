@@ -428,6 +428,72 @@ __global__ void __launch_bounds__(256) ctx_bwd_pp2_kernel(const float* __restric
     dpp[i] = s;
 }
 
+
+// ------------------------------------------------------------------------------------------ CLIP text transformer (act() path)
+// Pieces of the language encoder the reference runs once per act() (helpers/clip/core/clip.py:426-440 encode_text_with_embeddings,
+// :224-245 ResidualAttentionBlock): tiny shapes (n x 77 tokens x 512), latency not throughput -- the linear layers and
+// LayerNorms reuse the kernels above, these three fill the gaps.
+// out[r][:] = table[idx[r]][:] (+ pos[r % L][:]): token embedding + positional embedding, or a plain row gather (pos = nullptr)
+__global__ void __launch_bounds__(256) embed_rows_kernel(const int* __restrict__ idx, const float* __restrict__ table,
+                                                         const float* __restrict__ pos, float* __restrict__ out, long long rows,
+                                                         int L, int D, long long table_rows) {
+    const long long n = rows * D;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long r = i / D;
+        const int c = (int)(i - r * D);
+        long long t = idx[r];
+        t = t < 0 ? 0 : (t >= table_rows ? table_rows - 1 : t);
+        float v = table[t * D + c];
+        if (pos) v += pos[(r % L) * D + c];
+        out[i] = v;
+    }
+}
+// QuickGELU (clip.py:219-221): x * sigmoid(1.702 x), in place
+__global__ void __launch_bounds__(256) quick_gelu_kernel(float* __restrict__ x, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = x[i];
+        x[i] = v / (1.0f + expf(-1.702f * v));
+    }
+}
+// causal multi-head self-attention of a short sequence (nn.MultiheadAttention with the upper-triangular -inf mask,
+// clip.py:396-402): qkv [n * L][3 * H * 64] = in_proj output (q | k | v, head h at columns 64 h), out [n * L][H * 64].
+// One workgroup per (head, sequence); thread i owns query i: K and V of the head sit in LDS, scores of keys j <= i go
+// through a running-max softmax in fp32.
+__global__ void __launch_bounds__(128) attn_causal_small_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L, int H) {
+    extern __shared__ float smem[];
+    float* Ks = smem;                 // [L][65]
+    float* Vs = smem + L * 65;        // [L][64]
+    const int h = blockIdx.x, b = blockIdx.y, i = threadIdx.x;
+    const int D = H * 64;
+    const float* base = qkv + (long long)b * L * 3 * D;
+    for (int e = threadIdx.x; e < L * 64; e += 128) {
+        const int j = e >> 6, c = e & 63;
+        Ks[j * 65 + c] = base[(long long)j * 3 * D + D + h * 64 + c];
+        Vs[j * 64 + c] = base[(long long)j * 3 * D + 2 * D + h * 64 + c];
+    }
+    __syncthreads();
+    if (i >= L) return;
+    float q[64], acc[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) { q[c] = base[(long long)i * 3 * D + h * 64 + c] * 0.125f; acc[c] = 0.f; }     // q / sqrt(64) first (torch)
+    float m = -INFINITY, ssum = 0.f;
+    for (int j = 0; j <= i; ++j) {
+        float sc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) sc = fmaf(q[c], Ks[j * 65 + c], sc);
+        const float mn = fmaxf(m, sc);
+        const float f = expf(m - mn), p = expf(sc - mn);
+        ssum = ssum * f + p;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) acc[c] = fmaf(p, Vs[j * 64 + c], acc[c] * f);
+        m = mn;
+    }
+    const float inv = 1.0f / ssum;
+    float* o = out + ((long long)b * L + i) * D + h * 64;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) o[c] = acc[c] * inv;
+}
+
 inline int grid_for(long long n) {
     long long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -579,6 +645,32 @@ extern "C" int vxb_ctx_bwd_f32(const float* dctx, float* dlang, float* dpatch, f
     hipLaunchKernelGGL(ctx_bwd_kernel, dim3(grid_for((long long)(T0 + T1) * (C + Cp))), dim3(256), 0, st, dctx, dlang, dpatch, dpos, B, T0, T1, C, Cp);
     hipLaunchKernelGGL(ctx_bwd_pp_kernel, dim3(B, nchunk), dim3(256), 0, st, dctx, part_ws, T0, T1, C, Cp, nchunk);
     hipLaunchKernelGGL(ctx_bwd_pp2_kernel, dim3(vxb_cdiv((long long)B * Cp, 256)), dim3(256), 0, st, part_ws, dpp, B, Cp, nchunk);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+// out[r][:] = table[idx[r]][:] (+ pos[r % L][:] when pos != nullptr); idx is clamped to [0, table_rows).
+extern "C" int vxb_embed_rows_f32(const int32_t* idx, const float* table, const float* pos, float* out, int64_t rows, int L, int D,
+                                  int64_t table_rows, vxb_stream_t stream) {
+    if (!idx || !table || !out || rows < 1 || L < 1 || D < 1 || table_rows < 1) return VXB_EARG;
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream, idx, table, pos, out,
+                       (long long)rows, L, D, (long long)table_rows);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+extern "C" int vxb_quick_gelu_f32(float* x, int64_t n, vxb_stream_t stream) {
+    if (!x || n < 1) return VXB_EARG;
+    hipLaunchKernelGGL(quick_gelu_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, (long long)n);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+// causal self-attention of n sequences of L <= 128 tokens, H heads of 64: qkv [n * L][3 * H * 64] -> out [n * L][H * 64]
+extern "C" int vxb_attn_causal_small_f32(const float* qkv, float* out, int n, int L, int H, vxb_stream_t stream) {
+    if (!qkv || !out || n < 1 || L < 1 || H < 1) return VXB_EARG;
+    if (L > 128) return VXB_ESIZE;
+    const size_t lds = (size_t)L * (65 + 64) * sizeof(float);
+    if (lds > 64 * 1024) return VXB_ESIZE;
+    hipLaunchKernelGGL(attn_causal_small_kernel, dim3(H, n), dim3(128), lds, (hipStream_t)stream, qkv, out, L, H);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }

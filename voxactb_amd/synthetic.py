@@ -156,6 +156,41 @@ def hashed_state_dict(shapes: dict, seed: int = 0) -> dict:
     return {k: hashed_tensor(k, v, seed) for k, v in shapes.items()}
 
 
+def hashed_clip_text_state_dict(width=512, layers=12, vocab=49408, context=77, embed_dim=1024, seed: int = 0) -> dict:
+    """Name-hashed weights for the TEXT half of a CLIP checkpoint (state-dict keys of helpers/clip/core/clip.py; magnitudes
+    like its initialize_parameters, :366-393): the RN50 checkpoint itself is not available offline, so parity of the HIP text
+    encoder is pinned on the reference network run with these weights."""
+    shapes = {'token_embedding.weight': (vocab, width), 'positional_embedding': (context, width),
+              'ln_final.weight': (width,), 'ln_final.bias': (width,), 'text_projection': (width, embed_dim)}
+    for i in range(layers):
+        pre = 'transformer.resblocks.%d.' % i
+        shapes.update({pre + 'ln_1.weight': (width,), pre + 'ln_1.bias': (width,), pre + 'attn.in_proj_weight': (3 * width, width),
+                       pre + 'attn.in_proj_bias': (3 * width,), pre + 'attn.out_proj.weight': (width, width),
+                       pre + 'attn.out_proj.bias': (width,), pre + 'ln_2.weight': (width,), pre + 'ln_2.bias': (width,),
+                       pre + 'mlp.c_fc.weight': (4 * width, width), pre + 'mlp.c_fc.bias': (4 * width,),
+                       pre + 'mlp.c_proj.weight': (width, 4 * width), pre + 'mlp.c_proj.bias': (width,)})
+    out = {}
+    for name, shape in shapes.items():
+        g = _hrng('clip:' + name, seed)
+        n = int(np.prod(shape))
+        leaf = name.split('.')[-1]
+        if '.ln_' in name or name.startswith('ln_'):
+            u = g.uniform(-1.0, 1.0, n)
+            a = (1.0 + 0.1 * u) if leaf == 'weight' else 0.1 * u
+        elif name == 'token_embedding.weight':
+            a = 0.02 * g.standard_normal(n)
+        elif name == 'positional_embedding':
+            a = 0.01 * g.standard_normal(n)
+        elif name == 'text_projection':
+            a = width ** -0.5 * g.standard_normal(n)
+        elif leaf in ('weight', 'in_proj_weight'):
+            a = g.uniform(-1.0, 1.0, n) / np.sqrt(shape[1])
+        else:
+            a = 0.05 * g.uniform(-1.0, 1.0, n)
+        out[name] = torch.from_numpy(a.astype(np.float32).reshape(shape))
+    return out
+
+
 def hashed_uniform(name: str, shape, lo=0.0, hi=1.0, seed: int = 0) -> torch.Tensor:
     g = _hrng('u:' + name, seed)
     a = g.uniform(lo, hi, int(np.prod(shape)))
