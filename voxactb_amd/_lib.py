@@ -12,7 +12,8 @@ import re
 import torch  # noqa: F401  (must precede the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libvoxactb_hip.so')
+# (VOXACTB_HIP_LIB: A/B runs of two builds inside one process launch on the same GPU box -- boxes differ by several per cent)
+LIB_PATH = os.environ.get('VOXACTB_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libvoxactb_hip.so')
 HEADER = os.path.join(_HERE, '..', 'include', 'voxactb_hip.h')
 
 _ERR = {-1: 'bad argument', -2: 'unsupported size', -3: 'workspace too small', -4: 'HIP launch error'}
