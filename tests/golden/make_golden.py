@@ -236,7 +236,7 @@ def encoder_fixture(name, cfg, arm=False, with_grads=True, digest=False, crop=Fa
 
 
 # ----------------------------------------------------------------------------- F11: the 2Robots (one_policy_more_heads) encoder
-def encoder2_fixture(name, cfg):
+def encoder2_fixture(name, cfg, digest=False):
     """reference PerceiverVoxelLang2RobotsEncoder (perceiver_lang_io.py:488-860) forward + backward of the summed two-arm loss
     (agent :1283-1363) on hashed weights: six outputs, loss, every parameter gradient's norm (small ones in full)."""
     enc = ref_pl.PerceiverVoxelLang2RobotsEncoder(
@@ -262,6 +262,15 @@ def encoder2_fixture(name, cfg):
     proprio_left = ow.hashed_uniform('f11.proprio_left', (B, cfg['low_dim']), 0.0, 1.0)
     trans_left = ow.hashed_int('f11.trans_left', (B, 3), 0, V)
     rot_left = torch.cat((ow.hashed_int('f11.rot_left', (B, 3), 0, 72), ow.hashed_int('f11.grip_left', (B, 1), 0, 2)), 1)
+    dy_sums, hooks = {}, []
+    if digest:       # conv-bias gradients sum dY over 10^6 voxels: keep the float64 sums next to the reference's fp32 ones (see F5g)
+        def tap(nm):
+            def fwd_hook(mod, inp, out):
+                out.register_hook(lambda gr: dy_sums.__setitem__(nm, gr.double().sum(dim=(0, 2, 3, 4))))
+            return fwd_hook
+        for n, m_ in enc.named_modules():
+            if isinstance(m_, torch.nn.Conv3d):
+                hooks.append(m_.register_forward_hook(tap(n)))
     outs = enc(ins, rs['low_dim_state'], proprio_left, rs['lang_goal_emb'], rs['lang_token_embs'], None, bounds, None)
     tr, _ = oagent.losses(outs[0], outs[1], outs[2], rs['trans_action_indicies'], rs['rot_grip_action_indicies'], rs['ignore_collisions'])
     tl, _ = oagent.losses(outs[3], outs[4], outs[5], trans_left, rot_left, rs['ignore_collisions'])
@@ -269,14 +278,29 @@ def encoder2_fixture(name, cfg):
     total.backward()
     arrs = dict(cfg_V=V, cfg_k=cfg['k'], cfg_s=cfg['s'], cfg_depth=cfg['depth'], cfg_latents=cfg['latents'],
                 cfg_low_dim=cfg['low_dim'], cfg_B=B, cfg_H=cfg['H'], cfg_W=cfg['W'], cfg_ncam=len(cfg['cams']),
-                grid=grid, proprio_left=proprio_left, trans_left=trans_left, rot_grip_left=rot_left,
-                q_trans_right=outs[0].detach(), rot_grip_right=outs[1], collision_right=outs[2],
-                q_trans_left=outs[3].detach(), rot_grip_left_out=outs[4], collision_left=outs[5], loss=total.detach())
+                proprio_left=proprio_left, trans_left=trans_left, rot_grip_left=rot_left,
+                rot_grip_right=outs[1], collision_right=outs[2], rot_grip_left_out=outs[4], collision_left=outs[5],
+                loss=total.detach())
+    if digest:           # headline-size grid: keep digests of the two 10^6-logit maps instead of the tensors (as F5 does)
+        sidx = ow.hashed_int('digest', (4096,), 0, V ** 3)
+        for side, q in (('right', outs[0]), ('left', outs[3])):
+            flat = q.detach().reshape(B, -1)
+            top = flat.topk(16, dim=1)
+            arrs.update({'q_trans_%s_argmax' % side: flat.argmax(1), 'q_trans_%s_top_vals' % side: top.values,
+                         'q_trans_%s_top_idx' % side: top.indices, 'q_trans_%s_sample' % side: flat[:, sidx],
+                         'q_trans_%s_lse' % side: torch.logsumexp(flat.double(), 1)})
+        arrs['q_trans_sample_idx'] = sidx
+    else:
+        arrs.update(grid=grid, q_trans_right=outs[0].detach(), q_trans_left=outs[3].detach())
     arrs['grad_names'] = np.array([n for n, _ in enc.named_parameters()])
     arrs['grad_norms'] = torch.stack([p.grad.norm() for _, p in enc.named_parameters()])
     for n, p in enc.named_parameters():
         if p.numel() <= 20000 and not n.startswith(('pos_encoding', 'latents')):
             arrs['grad__' + n] = p.grad
+    for n, v in dy_sums.items():
+        arrs['dysum64__' + n + '.bias'] = v
+    for h in hooks:
+        h.remove()
     print('%s: loss %.6f' % (name, float(total)))
     save(name, **arrs)
 
@@ -603,6 +627,7 @@ SECTIONS = {
     'f5v200': lambda: encoder_fixture('f5v200_encoder_c5_digest', CFG_C5, with_grads=False, digest=True),
     'f11tiny': lambda: encoder2_fixture('f11_encoder_2robots_tiny', CFG_TINY),
     'f11c1': lambda: encoder2_fixture('f11_encoder_2robots_c1', CFG_C1),
+    'f11c2': lambda: encoder2_fixture('f11c2_encoder_2robots_c2_digest', CFG_C2, digest=True),
     'f12': f12_clip_text,
     'f6': f6_update_traces,
     'f9': f9_act,

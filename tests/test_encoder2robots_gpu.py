@@ -23,7 +23,7 @@ def maxerr(a, b):
     return float((a.detach().float().cpu() - b.detach().float().cpu()).abs().max())
 
 
-def run(g, cams, precision):
+def run(g, cams, precision, norm_tol=3e-3, elem_tol=3e-3, flips=0):
     V, B = int(g['cfg_V']), int(g['cfg_B'])
     enc = PerceiverVoxelLang2RobotsEncoder(
         depth=int(g['cfg_depth']), iterations=1, voxel_size=V, initial_dim=10, low_dim_size=int(g['cfg_low_dim']),
@@ -33,20 +33,40 @@ def run(g, cams, precision):
     enc = enc.to(DEV)
     rs = synthetic.make_replay_sample(B, cams, (int(g['cfg_H']), int(g['cfg_W'])), V, int(g['cfg_low_dim']), seed=1)
     rs = {k: (v[:, 0] if v.dim() > 2 else v) for k, v in rs.items()}
-    grid = T(g['grid']).to(DEV)
+    if 'grid' in g.files:
+        grid = T(g['grid']).to(DEV)
+    else:                                                    # headline-size fixture: voxelize the seeded clouds on the device
+        from voxactb_amd.voxel.voxel_grid import VoxelGrid
+        H, W = int(g['cfg_H']), int(g['cfg_W'])
+        vg = VoxelGrid(synthetic.SCENE_BOUNDS, V, DEV, B, 3, H * W * len(cams))
+        rgbs = [((rs['%s_rgb' % c].float() / 255.0) * 2.0 - 1.0).to(DEV) for c in cams]
+        grid = vg.voxelize_cameras([rs['%s_point_cloud' % c].float().to(DEV) for c in cams], rgbs,
+                                   torch.tensor([synthetic.SCENE_BOUNDS]).to(DEV))
     eng = enc.engine()
     eng.precision = precision
     outs, cache = eng.forward(grid, rs['low_dim_state'].float().to(DEV), rs['lang_token_embs'].float().to(DEV), training=False,
                               save=True, proprio_left=T(g['proprio_left']).to(DEV))
     assert len(outs) == 6
-    errs = [maxerr(o, T(g[k])) for o, k in zip(outs, ('q_trans_right', 'rot_grip_right', 'collision_right', 'q_trans_left',
-                                                      'rot_grip_left_out', 'collision_left'))]
+    if 'q_trans_right' in g.files:
+        errs = [maxerr(o, T(g[k])) for o, k in zip(outs, ('q_trans_right', 'rot_grip_right', 'collision_right', 'q_trans_left',
+                                                          'rot_grip_left_out', 'collision_left'))]
+    else:
+        errs = [maxerr(outs[1], T(g['rot_grip_right'])), maxerr(outs[2], T(g['collision_right'])),
+                maxerr(outs[4], T(g['rot_grip_left_out'])), maxerr(outs[5], T(g['collision_left']))]
+        sidx = T(g['q_trans_sample_idx']).long()
+        for side, q in (('right', outs[0]), ('left', outs[3])):
+            flat = q.reshape(B, -1).float().cpu()
+            assert torch.equal(flat.argmax(1), T(g['q_trans_%s_argmax' % side]))
+            errs.append(float((flat[:, sidx] - T(g['q_trans_%s_sample' % side])).abs().max()))
+            errs.append(float((torch.gather(flat, 1, T(g['q_trans_%s_top_idx' % side]).long()) - T(g['q_trans_%s_top_vals' % side])).abs().max()))
+            errs.append(float((torch.logsumexp(flat.double(), 1) - T(g['q_trans_%s_lse' % side])).abs().max()))
     print('%s forward max-abs (right trans/rot/coll, left trans/rot/coll): %s' % (precision, ' '.join('%.2e' % e for e in errs)))
     assert max(errs) < TOL_Q, errs
     # the module's forward() is the reference's call signature (agent :944-952)
-    o2 = enc(grid.permute(0, 4, 1, 2, 3), rs['low_dim_state'].float().to(DEV), T(g['proprio_left']).to(DEV), None,
-             rs['lang_token_embs'].float().to(DEV), None, None, None)
-    assert len(o2) == 6 and maxerr(o2[3], outs[3]) == 0.0
+    if V <= 32:
+        o2 = enc(grid.permute(0, 4, 1, 2, 3), rs['low_dim_state'].float().to(DEV), T(g['proprio_left']).to(DEV), None,
+                 rs['lang_token_embs'].float().to(DEV), None, None, None)
+        assert len(o2) == 6 and maxerr(o2[3], outs[3]) == 0.0
 
     # summed two-arm loss (agent :1283-1369) and its gradients
     def arm_loss(q, o, trans, rot_grip):
@@ -70,17 +90,29 @@ def run(g, cams, precision):
     bad, worst = [], 0.0
     for n, rn in zip([str(n) for n in g['grad_names']], T(g['grad_norms'])):
         gn, rn = float(P[n].grad.norm()), float(rn)
-        if abs(gn - rn) > 3e-3 * rn + 1e-5:
+        key64 = 'dysum64__' + n
+        if key64 in g.files:
+            # bias of a grid conv at V = 100: the yardstick is the reference's dY summed in float64 (its own fp32 sum is off by
+            # up to 1.5e-2 here; tests/test_c2_reference_gpu.py has the full story)
+            ref = T(g[key64])
+            e = float((P[n].grad.double().cpu() - ref).abs().max())
+            if e > max(2e-3, elem_tol) * float(ref.abs().max()) + 2e-5:
+                bad.append((n, 'vs float64 dY sum', e, float(ref.abs().max())))
+            continue
+        if abs(gn - rn) > norm_tol * rn + 1e-5:
             bad.append((n, gn, rn))
         elif rn > 1e-4:
             worst = max(worst, abs(gn - rn) / rn)
         key = 'grad__' + n
         if key in g.files:
             ref = T(g[key])
-            e = maxerr(P[n].grad, ref)
-            if e > 3e-3 * float(ref.abs().max()) + 1e-5:
-                bad.append((n, 'full', e, float(ref.abs().max())))
+            d = (P[n].grad.detach().float().cpu() - ref).abs()
+            lim = elem_tol * float(ref.abs().max()) + 1e-5
+            if int((d > lim).sum()) > flips:           # `flips`: elements allowed to sit on the other side of a LeakyReLU kink
+                bad.append((n, 'full', float(d.max()), float(ref.abs().max())))
     print('%s loss %.6f (reference %.6f), worst grad-norm rel. error %.2e' % (precision, loss, float(g['loss']), worst))
+    for b_ in bad:
+        print('   BAD', b_)
     assert not bad, bad
 
 
@@ -92,3 +124,19 @@ def test_2robots_tiny(golden, precision):
 @pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
 def test_2robots_c1(golden, precision):
     run(golden('f11_encoder_2robots_c1'), ['front'], precision)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_2robots_headline_size_digest(golden, precision):
+    """V=100, depth 6, 2048 latents (BASELINE.json configs[1] geometry) with the 192-wide context and both head sets:
+    forward digests, summed two-arm loss, every parameter gradient."""
+    if precision == 'fp32':
+        run(golden('f11c2_encoder_2robots_c2_digest'), synthetic.CAMERAS4, precision)      # worst gradient norm 1.4e-4
+    else:
+        # bf16x3 backward at this size (measured): gradient norms within 4.2e-3, elements within 1.6 % of the tensor's largest
+        # (worst: the 64 x 10 weight of the first 1x1x1 conv, which collects the SpatialSoftmax gradient of all 10^6 voxels).
+        # The forward differs from fp32 by ~1e-5 on `u`; SpatialSoftmax3D divides by its temperature 0.01 (network_utils.py
+        # :797-809), so its softmax weights -- and every gradient behind them -- carry ~1e-3 relative.  One element of the
+        # B = 1 head MLP (|h0| = 2.5e-7) lands on the other side of LeakyReLU's kink: its gradient differs by the slope ratio.
+        run(golden('f11c2_encoder_2robots_c2_digest'), synthetic.CAMERAS4, precision, norm_tol=5e-3, elem_tol=2e-2, flips=1)
+    torch.cuda.empty_cache()
