@@ -201,7 +201,14 @@ def main():
         for i in range(10):
             ev.act(i, dict(obs_t), deterministic=True)
         torch.cuda.synchronize()
-        act_lat['ms_per_act_with_text_encoder'] = (time.perf_counter() - t0) / 10 * 1e3
+        act_lat['ms_per_act_with_text_encoder'] = (time.perf_counter() - t0) / 10 * 1e3      # unchanged instruction: cached encoding
+        uncached = text.for_agent(cache=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(10):
+            uncached(tok[0, 0])
+        torch.cuda.synchronize()
+        act_lat['ms_text_encode'] = (time.perf_counter() - t0) / 10 * 1e3
         del ev, text
 
     if rank == 0:

@@ -69,3 +69,15 @@ def test_agent_act_uses_the_text_encoder(golden, encoder):
     obs2['lang_token_embs'] = T(g['emb'])[0:1].to(DEV)
     b = agent.act(0, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in obs2.items()})
     assert np.allclose(a.action, b.action) and a.action.shape == (9,)
+
+
+def test_cached_encoding_follows_the_tokens(golden, encoder):
+    g = golden('f12_clip_text')
+    f = encoder.for_agent()
+    a = f(T(g['tokens'])[0])
+    b = f(T(g['tokens'])[0].clone())
+    assert a[0] is b[0]                                        # same instruction: the stored encoding
+    c = f(T(g['tokens'])[1])
+    assert float((c[0].cpu() - T(g['feat'])[1:2]).abs().max()) < 5e-5 and c[0] is not a[0]
+    d = f(T(g['tokens'])[0])
+    assert float((d[0] - a[0]).abs().max()) == 0.0

@@ -195,6 +195,20 @@ class ClipTextEncoder:
             ops.PRECISION = prev
         return feat, emb.view(n, L, D)
 
-    def for_agent(self):
-        """callable for `QAttentionPerActBCAgent.set_text_encoder`: tokens [77] -> (lang_goal_emb [1, E], lang_token_embs [1, 77, W])."""
-        return lambda tokens: self.encode_text_with_embeddings(tokens)
+    def for_agent(self, cache=True):
+        """callable for `QAttentionPerActBCAgent.set_text_encoder`: tokens [77] -> (lang_goal_emb [1, E], lang_token_embs [1, 77, W]).
+        An episode repeats one instruction at every step (rollout_generator.py:233-244), so with `cache` the encoding of the
+        last token sequence is kept and reused while the tokens do not change (one 77-element comparison on the device
+        instead of the 12-layer transformer; the reference re-encodes every time, agent :661-664 -- same values)."""
+        if not cache:
+            return lambda tokens: self.encode_text_with_embeddings(tokens)
+        last = {}
+
+        def encode(tokens):
+            tok = torch.as_tensor(tokens).to(device=self.dev, dtype=torch.int64).reshape(-1)
+            if 'tok' in last and last['tok'].shape == tok.shape and bool(torch.equal(last['tok'], tok)):
+                return last['out']
+            out = self.encode_text_with_embeddings(tok)
+            last['tok'], last['out'] = tok.clone(), out
+            return out
+        return encode
