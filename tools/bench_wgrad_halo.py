@@ -16,6 +16,8 @@ def main():
     dy = torch.randn(B, S, S, S, 64, device=dev)
     fl = 2.0 * B * S ** 3 * 64 * 27 * 128
     from voxactb_amd import _lib
+    if os.environ.get('WH_NCH'):       # 16-channel chunks per workgroup: 1 or 2 (default: 2 where the channel count allows)
+        _lib.lib().vxb_debug_set_wgrad_halo_chunks(int(os.environ['WH_NCH']))
     if os.environ.get('WH_DBG'):       # timing experiments (wrong results): 1 = stage / prefetch the first tile only, 2 = no MFMA loop
         _lib.lib().vxb_debug_set_wgrad_halo_experiment(int(os.environ['WH_DBG']))
     for mode in ('bf16', 'bf16x3'):

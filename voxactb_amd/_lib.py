@@ -62,6 +62,8 @@ def lib():
             fn = getattr(L, name)       # AttributeError here == header/library mismatch: fail loudly
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get('VOXACTB_WGRAD_CHUNKS'):   # experiment switch: chunks per workgroup of the LDS-halo weight gradient
+            L.vxb_debug_set_wgrad_halo_chunks(int(os.environ['VOXACTB_WGRAD_CHUNKS']))
         if os.environ.get('VOXACTB_HALO_WN'):      # experiment switch: wave layout of the LDS-halo conv (conv_halo_bf16.hip)
             L.vxb_debug_set_halo_wn(int(os.environ['VOXACTB_HALO_WN']))
         _lib = L

@@ -30,7 +30,6 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 constexpr int WTW = 8, XW = WTW + 2;
 constexpr int DLD = 80;                               // u16 per dY row (64 + 16 pad): 40 dwords, 8 rows -> 8 bank octets
 constexpr int DPL = 128 * DLD;                        // u16 per dY plane
-constexpr int NDL = 128 * 16 / 256;                   // 8 float4 dY loads per thread per tile
 
 }  // namespace
 
@@ -66,18 +65,26 @@ __device__ __forceinline__ bf16x8 wh_frag(const u16* p0, const u16* p1) {
     return u.v;
 }
 
-template <int X3, int WTD, int WTH>
-__global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
+// NCH = 16-channel chunks per workgroup.  1: 4 waves, two workgroups per CU.  2: 8 waves = two 4-wave groups that own one
+// chunk each and SHARE the dY tile -- per MFMA 29 % less staging work (10 instead of 14 loads + conversions per thread and
+// tile), one workgroup per CU.  (Predicted from the timing experiments below: - 9 %.  Measured: - 2.7 % dense, + 5 % with tap
+// masks -- the second resident workgroup does hide part of the staging after all.)
+template <int X3, int WTD, int WTH, int NCH>
+__global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel(WhArgs g) {
+    constexpr int NTH = 256 * NCH;
     constexpr int XH = WTH + 2;                           // halo h extent; d extent WTD + 2, w extent 10
     constexpr int XSLOTS = (WTD + 2) * XH * XW;           // 400 / 360
     constexpr int XPL = XSLOTS * 16;                      // u16 per x plane
-    constexpr int NXL = (XSLOTS * 4 + 255) / 256;         // 7 / 6 float4 x loads per thread per tile
+    constexpr int XF4 = XSLOTS * 4;                       // float4 per chunk halo
+    constexpr int NXL = (NCH * XF4 + NTH - 1) / NTH;      // 7 / 6 float4 x loads per thread per tile
+    constexpr int NDL = 128 * 16 / NTH;                   // 8 / 4 float4 dY loads per thread per tile
     constexpr int HB = WTH / 4;                           // k-steps (4 h-rows x 8 w) per d-plane
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
-    u16* xs = smem;                                   // [1 + X3][XSLOTS][16]
-    u16* ds = smem + (1 + X3) * XPL;                  // [1 + X3][128][DLD]
+    u16* xs = smem;                                   // [NCH][1 + X3][XSLOTS][16]
+    u16* ds = smem + NCH * (1 + X3) * XPL;            // [1 + X3][128][DLD]
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform (scalar register)
+    const int wid8 = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform (scalar register)
+    const int wid = wid8 & 3, wch = wid8 >> 2;        // tap group of this wave / which of the workgroup's chunks it owns
     const int Ct = g.C0 + g.C1;
     // Workgroup -> (channel chunk bx, column block by, tile slice bz).  The chunk blocks of one (by, bz) read the SAME dY
     // tiles; hardware places linear workgroup id L on XCD L % 8, so when the number of (by, bz) pairs is a multiple of 8
@@ -95,12 +102,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
             bz = pair / gridDim.y;
         }
     }
-    const int cb = bx * 16;                           // this workgroup's 16 input channels
-    const int n0 = by * 64;                           // ... and 64 output channels
-    const bool second = cb >= g.C0;
-    const float* __restrict__ src = second ? g.src1 : g.src0;
-    const int Cs = second ? g.C1 : g.C0;
-    const int c0 = second ? cb - g.C0 : cb;
+    const int cb = (bx * NCH + wch) * 16;             // this wave's 16 input channels
+    const int n0 = by * 64;                           // ... and the workgroup's 64 output channels
     const int S = g.S_out;
     // dY of a depth-to-space output: column block nb is one phase (d2s_C == 64) of the fine grid
     int rd = 0, rh = 0, rw = 0;
@@ -139,11 +142,18 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
         unsigned m = 0;
 #pragma unroll
         for (int i = 0; i < NXL; ++i) {
-            const int e = tid_ + 256 * i;
-            int p = e >> 2;
-            const int c4 = (e & 3) * 4;
+            const int e = tid_ + NTH * i;
+            const int lch = NCH == 1 ? 0 : min(e / XF4, NCH - 1);      // which chunk of the workgroup this slot belongs to
+            const int e2 = e - lch * XF4;
+            int p = e2 >> 2;
+            const int c4 = (e2 & 3) * 4;
             bool ok = p < XSLOTS;
             p = min(p, XSLOTS - 1);
+            const int cbl = (bx * NCH + lch) * 16;                       // first channel of that chunk: source 0 or source 1
+            const bool second = cbl >= g.C0;
+            const float* __restrict__ src = second ? g.src1 : g.src0;
+            const int Cs = second ? g.C1 : g.C0;
+            const int c0 = second ? cbl - g.C0 : cbl;
             const int hw = p % XW; p /= XW;
             const int hh = p % XH; p /= XH;
             const int id = d0 + p + g.off, ih = h0 + hh + g.off, iw = w0 + hw + g.off;
@@ -155,7 +165,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
         }
 #pragma unroll
         for (int i = 0; i < NDL; ++i) {
-            const int e = tid_ + 256 * i;
+            const int e = tid_ + NTH * i;
             const int pos = e >> 4, n4 = (e & 15) * 4;
             const int od = d0 + pos / (WTH * 8), oh = h0 + ((pos >> 3) % WTH), ow = w0 + (pos & 7);
             const bool ok = od < S && oh < S && ow < S;
@@ -168,8 +178,10 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
     auto stage = [&]() {
 #pragma unroll
         for (int i = 0; i < NXL; ++i) {
-            const int e = tid + 256 * i;
-            if ((e >> 2) < XSLOTS) {
+            const int e0 = tid + NTH * i;
+            if (e0 < NCH * XF4) {
+                const int lch = NCH == 1 ? 0 : e0 / XF4;
+                const int e = e0 - lch * XF4 + lch * (1 + X3) * XPL / 4;     // slot index inside the chunk's plane pair
                 if (!((okm >> i) & 1u)) px[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 uint2 pk;
                 pk.x = wh_pack2(px[i].x, px[i].y); pk.y = wh_pack2(px[i].z, px[i].w);
@@ -184,7 +196,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
         }
 #pragma unroll
         for (int i = 0; i < NDL; ++i) {
-            const int e = tid + 256 * i;
+            const int e = tid + NTH * i;
             if (!((okm >> (8 + i)) & 1u)) pd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             uint2 pk;
             pk.x = wh_pack2(pd[i].x, pd[i].y); pk.y = wh_pack2(pd[i].z, pd[i].w);
@@ -235,7 +247,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
 #pragma unroll 1
         for (int ks = 0; ks < 4; ++ks) {
             const int dd = ks / HB, hb = (ks % HB) * 4;
-            const u16* xa0 = xs + ((dd * XH + hb + fh) * XW + fw) * 16 + fc;        // read r = 0 (tap offset added later)
+            const u16* xa0 = xs + wch * (1 + X3) * XPL + ((dd * XH + hb + fh) * XW + fw) * 16 + fc;   // read r = 0 (tap offset added later)
             const u16* xa1 = xa0 + XW * 16;                                          // r = 1: next h row
             const u16* db0 = ds + ((dd * WTH + hb + fh) * WTW + fw) * DLD + fc;
             const u16* db1 = db0 + WTW * DLD;
@@ -294,26 +306,28 @@ __global__ void __launch_bounds__(256, 2) wgrad_halo_kernel(WhArgs g) {
 
 }  // namespace
 
-template <int X3, int TD, int TH>
+template <int X3, int TD, int TH, int NCH>
 static int wgrad_halo_launch(WhArgs& g, int nsplit, hipStream_t st) {
     g.ntd = vxb_cdiv(g.S_out, TD); g.nth = vxb_cdiv(g.S_out, TH); g.ntw = vxb_cdiv(g.S_out, WTW);
     g.ntiles = (long long)g.B * g.ntd * g.nth * g.ntw;
     if (g.ntiles >= INT32_MAX) return VXB_ESIZE;
     g.tiles_per_split = (int)((g.ntiles + nsplit - 1) / nsplit);
-    const size_t lds = (size_t)(1 + X3) * ((TD + 2) * (TH + 2) * XW * 16 + DPL) * sizeof(u16);
-    dim3 grid((g.C0 + g.C1) / 16, g.N / 64, nsplit);
-    if (hipFuncSetAttribute((const void*)wgrad_halo_kernel<X3, TD, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
-    hipLaunchKernelGGL((wgrad_halo_kernel<X3, TD, TH>), grid, dim3(256), lds, st, g);
+    const size_t lds = (size_t)(1 + X3) * (NCH * (TD + 2) * (TH + 2) * XW * 16 + DPL) * sizeof(u16);
+    dim3 grid((g.C0 + g.C1) / (16 * NCH), g.N / 64, nsplit);
+    if (hipFuncSetAttribute((const void*)wgrad_halo_kernel<X3, TD, TH, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
+    hipLaunchKernelGGL((wgrad_halo_kernel<X3, TD, TH, NCH>), grid, dim3(256 * NCH), lds, st, g);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
 
 #ifdef WH_T44_UNIT
-int vxb_wgrad_halo_launch_t44(VxbWhArgs& g, int x3, int nsplit, hipStream_t st) {
-    return x3 ? wgrad_halo_launch<1, 4, 4>(g, nsplit, st) : wgrad_halo_launch<0, 4, 4>(g, nsplit, st);
+int vxb_wgrad_halo_launch_t44(VxbWhArgs& g, int x3, int nch, int nsplit, hipStream_t st) {
+    if (nch == 2) return x3 ? wgrad_halo_launch<1, 4, 4, 2>(g, nsplit, st) : wgrad_halo_launch<0, 4, 4, 2>(g, nsplit, st);
+    return x3 ? wgrad_halo_launch<1, 4, 4, 1>(g, nsplit, st) : wgrad_halo_launch<0, 4, 4, 1>(g, nsplit, st);
 }
 #else
-int vxb_wgrad_halo_launch_t44(VxbWhArgs& g, int x3, int nsplit, hipStream_t st);
+int vxb_wgrad_halo_launch_t44(VxbWhArgs& g, int x3, int nch, int nsplit, hipStream_t st);
+static int g_wh_nch = 0;          // experiment knob (vxb_debug_set_wgrad_halo_chunks): 0 = default, 1 / 2 = force
 
 static int g_wh_dbg = 0;
 static int g_wh_shape = -1;       // experiment knob (vxb_debug_set_wgrad_halo_shape): -1 = choose per grid, 0 / 1 = force
@@ -346,8 +360,13 @@ static int wgrad_halo_impl(int x3, const float* src0, const float* src1, int C0,
         if ((long long)B * S_in * S_in * S_in >= INT32_MAX || (long long)B * vf * vf * vf >= INT32_MAX) return VXB_ESIZE;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (wgrad_halo_shape(S_out, x3)) return vxb_wgrad_halo_launch_t44(g, x3, nsplit, st);
-    return x3 ? wgrad_halo_launch<1, 2, 8>(g, nsplit, st) : wgrad_halo_launch<0, 2, 8>(g, nsplit, st);
+    // two chunks per workgroup (8 waves sharing the dY tile): measured at B = 4 in 'bf16x3' (tools/bench_wgrad_halo.py, WH_NCH):
+    // + 2.7 % on the dense 128 -> 64 gradient at S = 100 (4.83 -> 4.70 ms), - 5 % on the tap-masked depth-to-space one (2.20 -> 2.31)
+    int nch = ((C0 + C1) % 32 == 0 && d2s_s <= 0) ? 2 : 1;
+    if (g_wh_nch) nch = (g_wh_nch == 2 && (C0 + C1) % 32 == 0) ? 2 : 1;
+    if (wgrad_halo_shape(S_out, x3)) return vxb_wgrad_halo_launch_t44(g, x3, nch, nsplit, st);
+    if (nch == 2) return x3 ? wgrad_halo_launch<1, 2, 8, 2>(g, nsplit, st) : wgrad_halo_launch<0, 2, 8, 2>(g, nsplit, st);
+    return x3 ? wgrad_halo_launch<1, 2, 8, 1>(g, nsplit, st) : wgrad_halo_launch<0, 2, 8, 1>(g, nsplit, st);
 }
 
 // 3x3x3 stride-1 specialisation of vxb_conv3d_wgrad_bf16_f32 / _bf16x3_f32 (same contract and part[z][K][N] layout;
@@ -374,5 +393,6 @@ extern "C" size_t vxb_conv3_wgrad_halo_tiles(int B, int S_out, int x3) {
 }
 
 extern "C" void vxb_debug_set_wgrad_halo_experiment(int bits) { g_wh_dbg = bits; }
+extern "C" void vxb_debug_set_wgrad_halo_chunks(int nch) { g_wh_nch = (nch == 1 || nch == 2) ? nch : 0; }
 extern "C" void vxb_debug_set_wgrad_halo_shape(int shape) { g_wh_shape = shape < 0 ? -1 : (shape ? 1 : 0); }
 #endif   // WH_T44_UNIT
