@@ -278,6 +278,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
     for (int k = 0; k < K; ++k) {
         const int j = lane + 64 * k;
         cell[k] = 0;
+        ra[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (j < n) {
             int lo = 0;                                     // largest chunk whose prefix is <= j (prefixes beyond NC equal n)
 #pragma unroll
