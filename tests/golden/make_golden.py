@@ -409,6 +409,68 @@ def f6_update_traces():
     save('f6_update_traces', **out)
 
 
+
+# ----------------------------------------------------------------------------- F13: update() of the reference 2Robots agent
+def two_arm_batch(cfg, seed):
+    """the single-arm synthetic sample re-keyed for two arms (tests/test_agent2robots_gpu.py builds the same batch):
+    right = its labels / proprio / pose, left = name-hashed labels and proprio."""
+    rs = batch_for(cfg, seed=seed)
+    B, V = cfg['B'], cfg['V']
+    out = {k: v for k, v in rs.items() if k.endswith(('_rgb', '_point_cloud')) or k in ('lang_goal_emb', 'lang_token_embs', 'ignore_collisions')}
+    out['low_dim_state_right_arm'] = rs['low_dim_state']
+    out['low_dim_state_left_arm'] = ow.hashed_uniform('f13.proprio_left', (B, cfg['low_dim']), 0.0, 1.0, seed)
+    out['trans_action_indicies_right'] = rs['trans_action_indicies']
+    out['rot_grip_action_indicies_right'] = rs['rot_grip_action_indicies']
+    out['gripper_pose_right'] = rs['gripper_pose']
+    out['trans_action_indicies_left'] = ow.hashed_int('f13.trans_left', (B, 3), 0, V, seed).float()
+    out['rot_grip_action_indicies_left'] = torch.cat((ow.hashed_int('f13.rot_left', (B, 3), 0, 72, seed),
+                                                      ow.hashed_int('f13.grip_left', (B, 1), 0, 2, seed)), 1).float()
+    out['gripper_pose_left'] = rs['gripper_pose'].clone()
+    return out
+
+
+def f13_update_traces_2robots():
+    """three update() steps (LAMB, no augmentation, no dropout) of the REFERENCE QAttentionPerActBCAgent2Robots
+    (qattention_peract_bc_agent.py:966-1455) on name-hashed weights: losses per step and the parameters afterwards."""
+    stub_modules()
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29534')
+    if not dist.is_initialized():
+        dist.init_process_group('gloo', rank=0, world_size=1)
+    ref_agent = sys.modules.get('ref_agent') or load('ref_agent', 'agents/peract_bc/qattention_peract_bc_agent.py')
+    # QFunction2Robots wraps with DDP(device_ids=[device]) unconditionally (agent :897-898; the single-arm QFunction has a CPU
+    # branch, :50-54): hand it a DDP that drops the argument on the CPU -- the reference source is untouched
+    real_ddp = ref_agent.DDP
+    ref_agent.DDP = lambda module, device_ids=None: real_ddp(module)
+    c = dict(CFG_UPD, low_dim=4)
+    enc = ref_pl.PerceiverVoxelLang2RobotsEncoder(
+        depth=c['depth'], iterations=1, voxel_size=c['V'], initial_dim=10, low_dim_size=c['low_dim'], num_latents=c['latents'],
+        voxel_patch_size=c['k'], voxel_patch_stride=c['s'], activation='lrelu', input_dropout=0.0, attn_dropout=0.0,
+        decoder_dropout=0.0)
+    enc.load_state_dict(ow.hashed_state_dict({n: tuple(p.shape) for n, p in enc.named_parameters()}, 0), strict=False)
+    enc.train()
+    agent = ref_agent.QAttentionPerActBCAgent2Robots(
+        layer=0, coordinate_bounds=synthetic.SCENE_BOUNDS, perceiver_encoder=enc, camera_names=c['cams'], batch_size=c['B'],
+        voxel_size=c['V'], bounds_offset=None, voxel_feature_size=3, image_crop_size=64, num_rotation_classes=72,
+        rotation_resolution=5, lr=5e-4, include_low_dim_state=True, image_resolution=[c['H'], c['W']], lambda_weight_l2=1e-6,
+        transform_augmentation=False, optimizer_type='lamb')
+    agent.build(training=True, device='cpu')
+    losses = []
+    for step in range(3):
+        r = agent.update(step, two_arm_batch(c, 10 + step))
+        sm = agent._summaries
+        losses.append([float(r['total_loss']), float(sm['losses/trans_loss']), float(sm['losses/rot_loss']),
+                       float(sm['losses/grip_loss']), float(sm['losses/collision_loss'])])
+    ref_agent.DDP = real_ddp
+    print('2Robots update trace: %s' % np.array(losses)[:, 0])
+    names = [n.replace('_qnet.module.', '') for n, _ in agent._q.named_parameters()]
+    save('f13_update_traces_2robots', losses=np.array(losses), param_names=np.array(names),
+         param_abs_sums=torch.stack([p.detach().double().abs().sum() for _, p in agent._q.named_parameters()]),
+         cfg_V=c['V'], cfg_k=c['k'], cfg_s=c['s'], cfg_depth=c['depth'], cfg_latents=c['latents'], cfg_B=c['B'], cfg_H=c['H'],
+         cfg_W=c['W'], cfg_low_dim=c['low_dim'])
+
+
 # ----------------------------------------------------------------------------- F7
 def f7_lamb():
     out = {}
@@ -629,6 +691,7 @@ SECTIONS = {
     'f11c1': lambda: encoder2_fixture('f11_encoder_2robots_c1', CFG_C1),
     'f11c2': lambda: encoder2_fixture('f11c2_encoder_2robots_c2_digest', CFG_C2, digest=True),
     'f12': f12_clip_text,
+    'f13': f13_update_traces_2robots,
     'f6': f6_update_traces,
     'f9': f9_act,
     'f10': f10_depth,

@@ -102,3 +102,38 @@ def agent_obs(obs):
         v = v.float()
         out[k] = (v / 255.0) * 2.0 - 1.0 if 'rgb' in k else v
     return out
+
+
+def test_update_traces_of_the_reference_agent(golden):
+    """three update() steps (LAMB, no augmentation, no dropout) against the losses and parameters the REFERENCE
+    QAttentionPerActBCAgent2Robots produced for the same batches (tests/golden/make_golden.py, section f13)."""
+    g = golden('f13_update_traces_2robots')
+    agent, _ = make_agent(g)
+    qa = agent._pose_agent._qattention_agents[0]
+    B, V, low = int(g['cfg_B']), int(g['cfg_V']), int(g['cfg_low_dim'])
+    got = []
+    for step in range(3):
+        seed = 10 + step
+        rs = synthetic.make_replay_sample(B, CAMS, (int(g['cfg_H']), int(g['cfg_W'])), V, low, seed=seed)
+        b = {k: v for k, v in rs.items() if k.endswith(('_rgb', '_point_cloud')) or k in ('lang_goal_emb', 'lang_token_embs', 'ignore_collisions')}
+        b['low_dim_state_right_arm'] = rs['low_dim_state']
+        b['low_dim_state_left_arm'] = ow.hashed_uniform('f13.proprio_left', (B, low), 0.0, 1.0, seed)[:, None]
+        b['trans_action_indicies_right'] = rs['trans_action_indicies']
+        b['rot_grip_action_indicies_right'] = rs['rot_grip_action_indicies']
+        b['gripper_pose_right'] = rs['gripper_pose']
+        b['trans_action_indicies_left'] = ow.hashed_int('f13.trans_left', (B, 3), 0, V, seed).int()[:, None]
+        b['rot_grip_action_indicies_left'] = torch.cat((ow.hashed_int('f13.rot_left', (B, 3), 0, 72, seed),
+                                                        ow.hashed_int('f13.grip_left', (B, 1), 0, 2, seed)), 1).int()[:, None]
+        b['gripper_pose_left'] = rs['gripper_pose'].clone()
+        r = agent.update(step, {k: v.to(DEV) for k, v in b.items()})
+        sm = qa._summaries
+        got.append([float(r['total_losses']), float(sm['losses/trans_loss']), float(sm['losses/rot_loss']),
+                    float(sm['losses/grip_loss']), float(sm['losses/collision_loss'])])
+    got, ref = np.array(got), g['losses']
+    print(got[:, 0], ref[:, 0])
+    assert np.abs(got[0] - ref[0]).max() < 1e-4                     # step 0: forward + loss parity
+    assert np.abs(got - ref).max() < 5e-3                           # later steps pass through LAMB (see test_agent_gpu.py)
+    names = [n.replace('_qnet.module.', '') for n, _ in qa._q.named_parameters()]
+    assert names == [str(n) for n in g['param_names']]
+    asum = np.array([float(p.detach().double().abs().sum()) for _, p in qa._q.named_parameters()])
+    assert np.abs(asum - g['param_abs_sums']).max() / np.abs(g['param_abs_sums']).max() < 1e-3
