@@ -640,6 +640,66 @@ def f9_act():
     save('f9_act', **out)
 
 
+
+# ----------------------------------------------------------------------------- F14: act() of the reference 2Robots stack
+def f14_act_2robots():
+    """QAttentionStackAgent2Robots.act (qattention_stack_agent.py:127-246) over QAttentionPerActBCAgent2Robots.act (agent
+    :1457-1582) with a stub text encoder, for which_arm = right and left.  (The reference PreprocessAgent passes the single-arm
+    extras positionally, preprocess_agent.py:46, which the 2Robots stack agent does not accept: the stack agent is called with
+    the observation PreprocessAgent would have produced.)"""
+    stub_modules()
+    import types
+    ref_agent = sys.modules.get('ref_agent') or load('ref_agent', 'agents/peract_bc/qattention_peract_bc_agent.py')
+    ref_agent.load_clip = lambda *a, **k: (MagicMock(), None)
+    ref_agent.build_model = lambda sd: _StubTextEncoder()
+    for pkg in ('agents', 'agents.peract_bc'):
+        if pkg not in sys.modules:
+            sys.modules[pkg] = types.ModuleType(pkg)
+            sys.modules[pkg].__path__ = []
+    sys.modules['agents.peract_bc.qattention_peract_bc_agent'] = ref_agent
+    ref_stack = sys.modules.get('ref_stack') or load('ref_stack', 'agents/peract_bc/qattention_stack_agent.py')
+    cfg = dict(CFG_UPD, low_dim=4, B=1)
+    enc = ref_pl.PerceiverVoxelLang2RobotsEncoder(
+        depth=cfg['depth'], iterations=1, voxel_size=cfg['V'], initial_dim=10, low_dim_size=cfg['low_dim'],
+        num_latents=cfg['latents'], voxel_patch_size=cfg['k'], voxel_patch_stride=cfg['s'], activation='lrelu',
+        input_dropout=0.0, attn_dropout=0.0, decoder_dropout=0.0)
+    enc.load_state_dict(ow.hashed_state_dict({n: tuple(p.shape) for n, p in enc.named_parameters()}, 0), strict=False)
+    qa = ref_agent.QAttentionPerActBCAgent2Robots(
+        layer=0, coordinate_bounds=synthetic.SCENE_BOUNDS, perceiver_encoder=enc, camera_names=cfg['cams'], batch_size=1,
+        voxel_size=cfg['V'], bounds_offset=None, voxel_feature_size=3, image_crop_size=64, num_rotation_classes=72,
+        rotation_resolution=5, lr=5e-4, include_low_dim_state=True, image_resolution=[cfg['H'], cfg['W']],
+        lambda_weight_l2=1e-6, transform_augmentation=False, optimizer_type='lamb')
+    agent = ref_stack.QAttentionStackAgent2Robots([qa], 5, cfg['cams'])
+    agent.build(training=False, device=torch.device('cpu'))
+    # (the agent keeps its bounds as a list until update() / a caller turns them into a tensor; act() indexes a tensor, :1467)
+    qa._coordinate_bounds = torch.tensor(synthetic.SCENE_BOUNDS).unsqueeze(0)
+    obs = _act_observation(cfg, seed=23)
+    obs['low_dim_state_right_arm'] = obs.pop('low_dim_state')
+    obs['low_dim_state_left_arm'] = ow.hashed_uniform('f14.proprio_left', (1, 1, cfg['low_dim']), 0.0, 1.0)
+    with torch.no_grad():
+        emb, tok = _StubTextEncoder().encode_text_with_embeddings(obs['lang_goal_tokens'][0])
+    out = {'cfg_' + k: cfg[k] for k in ('V', 'k', 's', 'depth', 'latents', 'low_dim', 'H', 'W', 'B')}
+    out.update(lang_goal_tokens=obs['lang_goal_tokens'], lang_goal_emb=emb, lang_token_embs=tok,
+               low_dim_state_left_arm=obs['low_dim_state_left_arm'])
+    for c in cfg['cams']:
+        out[c + '_ext'], out[c + '_int'] = obs['%s_camera_extrinsics' % c], obs['%s_camera_intrinsics' % c]
+    prep = {k: ((v.float() / 255.0) * 2.0 - 1.0 if 'rgb' in k else v.float()) for k, v in obs.items()}
+    for arm in ('right', 'left'):
+        with torch.no_grad():
+            res = agent.act(0, {k: v.clone() for k, v in prep.items()}, True, arm)
+        out[arm + '_continuous_action'] = np.asarray(res.action, dtype=np.float64)
+        out[arm + '_attention_coordinate'] = res.observation_elements['attention_coordinate_layer_0']
+        out[arm + '_trans_action_indicies'] = res.observation_elements['trans_action_indicies']
+        out[arm + '_rot_grip_action_indicies'] = res.observation_elements['rot_grip_action_indicies']
+        for c in cfg['cams']:
+            out[arm + '_' + c + '_pixel_coord'] = np.array(res.observation_elements['%s_pixel_coord' % c], dtype=np.float64)
+        qt = res.info['q_depth_%s0' % arm].reshape(1, -1)
+        top = qt.topk(8, dim=1)
+        out[arm + '_q_top_vals'], out[arm + '_q_top_idx'] = top.values, top.indices
+        print('f14 %s: action %s' % (arm, np.round(out[arm + '_continuous_action'], 4)))
+    save('f14_act_2robots', **out)
+
+
 # ----------------------------------------------------------------------------- F10: RGB-D -> point cloud (PyRep)
 def f10_depth():
     """PyRep's VisionSensor module cannot be imported (it loads the CoppeliaSim backend), but the point-cloud code is
@@ -692,6 +752,7 @@ SECTIONS = {
     'f11c2': lambda: encoder2_fixture('f11c2_encoder_2robots_c2_digest', CFG_C2, digest=True),
     'f12': f12_clip_text,
     'f13': f13_update_traces_2robots,
+    'f14': f14_act_2robots,
     'f6': f6_update_traces,
     'f9': f9_act,
     'f10': f10_depth,

@@ -137,3 +137,29 @@ def test_update_traces_of_the_reference_agent(golden):
     assert names == [str(n) for n in g['param_names']]
     asum = np.array([float(p.detach().double().abs().sum()) for _, p in qa._q.named_parameters()])
     assert np.abs(asum - g['param_abs_sums']).max() / np.abs(g['param_abs_sums']).max() < 1e-3
+
+
+def test_act_against_the_reference_stack_agent(golden):
+    """QAttentionStackAgent2Robots.act for both arms against what the REFERENCE stack agent returned (section f14): voxel
+    indices, rotation / gripper indices, attention coordinate, pixel coordinates, the continuous 9-vector, top-8 of softmax(q)."""
+    g = golden('f14_act_2robots')
+    agent, _ = make_agent(g, training=False)
+    rs = synthetic.make_replay_sample(1, CAMS, (int(g['cfg_H']), int(g['cfg_W'])), int(g['cfg_V']), int(g['cfg_low_dim']), seed=23)
+    obs = {}
+    for c in CAMS:
+        obs['%s_rgb' % c], obs['%s_point_cloud' % c] = rs['%s_rgb' % c], rs['%s_point_cloud' % c]
+        obs['%s_camera_extrinsics' % c], obs['%s_camera_intrinsics' % c] = T(g[c + '_ext']), T(g[c + '_int'])
+    obs['low_dim_state_right_arm'] = rs['low_dim_state']
+    obs['low_dim_state_left_arm'] = T(g['low_dim_state_left_arm'])
+    obs['lang_goal_emb'], obs['lang_token_embs'] = T(g['lang_goal_emb']), T(g['lang_token_embs'])
+    obs = {k: v.to(DEV) for k, v in obs.items()}
+    for arm in ('right', 'left'):
+        res = agent.act(0, {k: v.clone() for k, v in obs.items()}, deterministic=True, which_arm=arm)
+        assert np.array_equal(res.observation_elements['trans_action_indicies'], g[arm + '_trans_action_indicies'])
+        assert np.array_equal(res.observation_elements['rot_grip_action_indicies'], g[arm + '_rot_grip_action_indicies'])
+        assert np.abs(res.observation_elements['attention_coordinate_layer_0'] - g[arm + '_attention_coordinate']).max() < 1e-6
+        assert np.abs(res.action - g[arm + '_continuous_action']).max() < 1e-6
+        for c in CAMS:
+            assert np.array_equal(np.array(res.observation_elements['%s_pixel_coord' % c], dtype=np.float64), g[arm + '_' + c + '_pixel_coord'])
+        q = res.info['q_depth_%s0' % arm].reshape(1, -1).float().cpu()
+        assert float((torch.gather(q, 1, T(g[arm + '_q_top_idx']).long()) - T(g[arm + '_q_top_vals'])).abs().max()) < 1e-5
