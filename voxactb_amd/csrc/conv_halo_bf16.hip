@@ -520,7 +520,9 @@ inline bool hb_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 int g_halo_waves = 4;
 int g_halo_dbg = 0;
 int g_halo_wn = 0;         // experiment knob (vxb_debug_set_halo_wn): waves along N in the WD kernels, 1 or 2; 0 = default (2 in
-                          // 'bf16x3': B = 16, S = 100 forward 21.1 -> 19.9 ms, data gradient 21.8 -> 21.1 ms; 1 in 'bf16': no difference)        // experiment knob (vxb_debug_set_halo_waves): 4 waves x 2 M tiles or 8 waves x 1 M tile per workgroup
+                          // 'bf16x3'; 1 in 'bf16': no difference).  In the training step on one box (VOXACTB_HALO_WN=1 vs 2, two
+                          // repetitions each, B = 16, S = 100): forward 20.23 -> 19.43 ms, data gradient + padding adjoint
+                          // 21.89 -> 20.85 ms; the tap-list variant (up-conv data gradient) is unchanged, 11.0 ms either way        // experiment knob (vxb_debug_set_halo_waves): 4 waves x 2 M tiles or 8 waves x 1 M tile per workgroup
 
 template <int NT, int X3, int NW, int WD, int TL = 0, int WN = 1>
 int hb_launch(const HaloArgs& g, long long nblk, hipStream_t st) {
