@@ -79,8 +79,9 @@ class KernelTimer:
     """Optional per-entry-point timing with HIP events recorded on the launching stream (bench.py uses it to price
     the dominant kernel against its roofline).  `meta` = (label, flops, bytes) supplied by the ops wrappers."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = []          # (label, name, start_event, stop_event, flops, bytes)
+        self.only = only           # None = every launch; a set of labels = only those (two events per launch are not free)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -107,7 +108,7 @@ def call(name, *args):
     """Call a C-ABI entry point; tensors are passed as device pointers, None as NULL; the current stream is appended."""
     global _META
     meta, _META = _META, None
-    if TIMER is not None:
+    if TIMER is not None and (TIMER.only is None or (meta is not None and meta[0] in TIMER.only)):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -99,6 +99,8 @@ class VoxelGrid(nn.Module):
         cp = (ctypes.c_void_p * n_src)(*coord_ptrs)
         fp = (ctypes.c_void_p * n_src)(*feat_ptrs) if F > 0 else None
         timer = _lib.TIMER
+        if timer is not None and timer.only is not None and 'voxelize' not in timer.only:
+            timer = None
         if timer is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
