@@ -257,6 +257,19 @@ int vxb_conv3_c1_wgrad_mfma(const float* u, const float* dq, float* dw, float* d
                             vxb_stream_t stream);
 size_t vxb_conv3_c1_wgrad_mfma_blocks(int B, int S);
 
+/* The same two layers fused with the statistics / backward of the pooled features of THEIR OUTPUT (perceiver_lang_io.py:357
+ * + :360, network_utils.py:773-809): the forward stores y and folds it into the SpatialSoftmax3D / max partials while it is in
+ * registers (bit-identical to vxb_pointwise_fwd_f32 + vxb_ss3d_max_fwd_f32, one pass less over 256 B per voxel); the
+ * weight gradient adds the term vxb_ss3d_max_bwd_f32 would have written into dy on the fly.  x [B,S,S,S,Cin], y / dy
+ * [B,S,S,S,64]; part_ws as for vxb_ss3d_max_fwd_f32 (C = 64), resp. B * ceil(S^3 / 4096) * (64*Cin + 64) floats. */
+int vxb_pointwise_ss3d_fwd_f32(const float* x, const float* W, const float* bias, float* y, int B, int S, int Cin, int Cout,
+                               float slope, const float* lin, float* part_ws, float* out_ss, float* out_max, float* stats,
+                               int32_t* argmax, vxb_stream_t stream);
+int vxb_pointwise_wgrad_ss3d_f32(const float* x, const float* y, const float* dy, float* dW, float* db, float* part_ws, int B,
+                                 int S, int Cin, int Cout, float slope, const float* lin, const float* stats,
+                                 const float* out_ss, const int32_t* argmax, const float* g_ss, const float* g_max,
+                                 vxb_stream_t stream);
+
 /* SpatialSoftmax3D (T=0.01, meshgrid 'xy' quirk) + AdaptiveMaxPool3d(1) in one streaming pass
  * (network_utils.py:773-809; perceiver_lang_io.py:360,:451,:470), and the backward of both.
  * part_ws: B * nchunk * C * 7 floats with nchunk = ceil(S^2 / max(1, S^2 / want)), want = max(64, ceil(1024 / B))

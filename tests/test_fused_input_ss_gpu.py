@@ -1,0 +1,63 @@
+"""The input conv fused with the pooled features of its output (vxb_pointwise_ss3d_fwd_f32, vxb_pointwise_wgrad_ss3d_f32):
+forward bit-identical to the two-kernel path, gradients against torch autograd of the reference formulation
+(perceiver_lang_io.py:357 + :360; network_utils.py:773-809)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from voxactb_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def rnd(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+def ref_ss3d(x):
+    """oracle restatement of network_utils.py:773-809 (SpatialSoftmax3D) + AdaptiveMaxPool3d(1) on x [B,C,D,H,W]."""
+    from oracle import perceiver as operc
+    return operc.spatial_softmax3d(x), x.amax(dim=(2, 3, 4))
+
+
+@pytest.mark.parametrize('B,S', [(2, 12), (3, 13), (1, 20)])
+def test_fused_forward_is_bit_identical(B, S):
+    x = (rnd(B, S, S, S, 10, seed=S) * 0.5).to(DEV)
+    W = (rnd(64, 10, seed=1) * 0.1).to(DEV)
+    b = (rnd(64, seed=2) * 0.05).to(DEV)
+    y0 = ops.pointwise_fwd(x, W, b)
+    ss0 = ops.ss3d_max_fwd(y0, S ** 3 * 64, B, S, 64)
+    y1, ss1 = ops.pointwise_ss3d_fwd(x, W, b, B, S)
+    assert torch.equal(y0, y1)
+    for a, c, name in zip(ss0, ss1, ('out_ss', 'out_max', 'stats', 'argmax')):
+        assert torch.equal(a, c), name
+
+
+@pytest.mark.parametrize('B,S', [(2, 12), (2, 17)])
+def test_fused_weight_gradient(B, S):
+    x = (rnd(B, S, S, S, 10, seed=3) * 0.5)
+    W = (rnd(64, 10, seed=1) * 0.1).requires_grad_(True)
+    b = (rnd(64, seed=2) * 0.05).requires_grad_(True)
+    dy = rnd(B, S, S, S, 64, seed=4) * 0.01
+    g_ss, g_mx = rnd(B, 192, seed=5), rnd(B, 64, seed=6)
+    # reference formulation in float64 autograd
+    y = F.leaky_relu(x.double() @ W.double().t() + b.double(), 0.02)
+    ss, mx = ref_ss3d(y.permute(0, 4, 1, 2, 3))
+    ((y * dy.double()).sum() + (ss * g_ss.double()).sum() + (mx * g_mx.double()).sum()).backward()
+    xd, Wd, bd, dyd = x.to(DEV), W.detach().to(DEV), b.detach().to(DEV), dy.to(DEV)
+    yd, (o_ss, o_mx, stats, arg) = ops.pointwise_ss3d_fwd(xd, Wd, bd, B, S)
+    dW, db = torch.zeros(64, 10, device=DEV), torch.zeros(64, device=DEV)
+    ops.pointwise_wgrad_ss3d(xd, yd, dyd, dW, db, B, S, stats, o_ss, arg, g_ss.to(DEV), g_mx.to(DEV))
+    # and the unfused pair the engine used before
+    dtot = dyd.clone()
+    ops.ss3d_max_bwd(yd, S ** 3 * 64, B, S, 64, stats, o_ss, arg, g_ss.to(DEV), g_mx.to(DEV), dtot, S ** 3 * 64, accumulate=True)
+    dW2, db2 = torch.zeros(64, 10, device=DEV), torch.zeros(64, device=DEV)
+    ops.pointwise_wgrad(xd, yd, dtot, dW2, db2)
+    for mine, pair, ref, name in ((dW, dW2, W.grad, 'dW'), (db, db2, b.grad, 'db')):
+        scale = float(ref.abs().max())
+        e_ref = float((mine.cpu().double() - ref.double()).abs().max()) / scale
+        e_pair = float((mine - pair).abs().max()) / scale
+        print(name, 'vs float64 autograd %.2e, vs the unfused kernels %.2e' % (e_ref, e_pair))
+        assert e_ref < 2e-4 and e_pair < 2e-5, (name, e_ref, e_pair)

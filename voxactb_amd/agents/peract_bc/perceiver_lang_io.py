@@ -27,6 +27,11 @@ from torch import nn
 from ... import flash, ops
 from ..._lib import VoxactbHipError, require_cuda
 
+import os as _os
+# the pooled features of d0 (SpatialSoftmax3D + max, perceiver :360) ride on the input conv's forward / weight-gradient kernels
+# instead of making their own passes over the grid ('0': the separate kernels, for A/B runs and the equality test)
+FUSE_INPUT_SS = _os.environ.get('VOXACTB_FUSE_INPUT_SS', '1') != '0'
+
 LRELU_SLOPE = 0.02
 LANG_FEAT_DIM, LANG_EMB_DIM, LANG_MAX_SEQ_LEN = 1024, 512, 77
 
@@ -481,9 +486,13 @@ class PerceiverEngine:
         lang = lang_token_embs.float().contiguous().view(B * T0, LANG_EMB_DIM)
         c = {}
         # 1. input 1x1x1 conv + lrelu (perceiver :357)
-        d0 = ops.pointwise_fwd(vox, self.p('input_preprocess.conv3d.weight').view(C, -1), self.p('input_preprocess.conv3d.bias'))
-        # 2. SpatialSoftmax3D + max (perceiver :360)
-        ss0 = ops.ss3d_max_fwd(d0, V ** 3 * C, B, V, C)
+        # 2. SpatialSoftmax3D + max (perceiver :360) -- taken while d0 is written (one pass over the 256 B per voxel)
+        if C == 64 and FUSE_INPUT_SS:
+            d0, ss0 = ops.pointwise_ss3d_fwd(vox, self.p('input_preprocess.conv3d.weight').view(C, -1),
+                                             self.p('input_preprocess.conv3d.bias'), B, V)
+        else:
+            d0 = ops.pointwise_fwd(vox, self.p('input_preprocess.conv3d.weight').view(C, -1), self.p('input_preprocess.conv3d.bias'))
+            ss0 = ops.ss3d_max_fwd(d0, V ** 3 * C, B, V, C)
         # 3. patchify (perceiver :363)
         patch = ops.conv3d(d0, ops.conv_weight_fwd(self.p('patchify.conv3d.weight')), C, B, V, G, k, -(k // 2), stride=s,
                            bias=self.p('patchify.conv3d.bias'), act=ops.ACT_LRELU)
@@ -661,16 +670,20 @@ class PerceiverEngine:
         self.g('final.conv3d.weight').add_(dWt.view(27, 2 * C, C).permute(2, 1, 0).reshape(Wf.shape))
         ops.colsum(du.view(-1, C), self.g('final.conv3d.bias'), accumulate=True)
         dd0 = E(B, V, V, V, C)
-        ss, mx, st, am = c['ss0']
-        ops.ss3d_max_bwd(d0, V ** 3 * C, B, V, C, st, ss, am, gs[0], gs[1], dd0, V ** 3 * C)
+        # the pooled-feature gradient of d0 (ss0) is added inside the input conv's weight-gradient kernel, the last reader of
+        # dd0; otherwise it is dd0's first writer
+        fuse_ss0 = C == 64 and FUSE_INPUT_SS
+        if not fuse_ss0:
+            ss, mx, st, am = c['ss0']
+            ops.ss3d_max_bwd(d0, V ** 3 * C, B, V, C, st, ss, am, gs[0], gs[1], dd0, V ** 3 * C)
         du0 = E(B, V, V, V, C)
         if C == 64 and ops.dgrad_fold_ok(C, 2 * C, V):
-            # data gradient and the adjoint of the replicate padding in one kernel: the first 64 columns add into dd0,
+            # data gradient and the adjoint of the replicate padding in one kernel: the first 64 columns go (add) into dd0,
             # the other 64 become d(pre-activation of up0's last conv) through u0's LeakyReLU'
-            ops.conv3_dgrad_fold(du, ops.conv_weight_dgrad(Wf), B, V, 2 * C, [(dd0, True, None), (du0, False, u0)])
+            ops.conv3_dgrad_fold(du, ops.conv_weight_dgrad(Wf), B, V, 2 * C, [(dd0, not fuse_ss0, None), (du0, False, u0)])
         else:
             dcat = ops.conv3d(du, ops.conv_weight_dgrad(Wf), 2 * C, B, V, V + 2, 3, -2, replicate=False)
-            ops.fold_pad(dcat, V + 2, 2 * C, 0, dd0, B, V, C, 1, accumulate=True)
+            ops.fold_pad(dcat, V + 2, 2 * C, 0, dd0, B, V, C, 1, accumulate=not fuse_ss0)
             ops.fold_pad(dcat, V + 2, 2 * C, C, du0, B, V, C, 1, lrelu_of=u0)         # d(pre-activation of up0's last conv)
             del dcat
         del du
@@ -765,8 +778,13 @@ class PerceiverEngine:
             dxp = ops.conv3d(dpatch, ops.conv_weight_dgrad(Wp), C, B, G, V + 2 * pk, k, -(k - 1), replicate=False)
             ops.fold_pad(dxp, V + 2 * pk, C, 0, dd0, B, V, C, pk, accumulate=True)
         # ---- input conv (its LeakyReLU' is applied inside the weight-gradient kernel)
-        ops.pointwise_wgrad(c['vox'], d0, dd0, self.g('input_preprocess.conv3d.weight').view(C, -1),
-                            self.g('input_preprocess.conv3d.bias'))
+        if fuse_ss0:
+            ss, mx, st, am = c['ss0']
+            ops.pointwise_wgrad_ss3d(c['vox'], d0, dd0, self.g('input_preprocess.conv3d.weight').view(C, -1),
+                                     self.g('input_preprocess.conv3d.bias'), B, V, st, ss, am, gs[0], gs[1])
+        else:
+            ops.pointwise_wgrad(c['vox'], d0, dd0, self.g('input_preprocess.conv3d.weight').view(C, -1),
+                                self.g('input_preprocess.conv3d.bias'))
         self._bucket_ready('head')
 
     def _bucket_ready(self, name):

@@ -154,6 +154,36 @@ __global__ void __launch_bounds__(256) pw_wgrad4_kernel(const float* __restrict_
 // =====================================================================================================
 struct SsPart { float m, s, sx, sy, sz, xmax; int arg; };
 
+// x / T for the SpatialSoftmax3D temperature.  The reference divides (network_utils.py:801: feature / self.temperature); the
+// IEEE division the compiler emits costs ~12 VALU instructions, which made the statistics pass VALU-bound (2.6 TB/s).  With
+// rT = RN(1/T): q = RN(x rT), r = x - q T (exact, fma), RN(q + r rT) IS the correctly rounded quotient (Markstein) -- checked
+// exhaustively on the CPU for T = 0.01f and every float 2^-100 <= |x| < 2^119; outside that range (and for any other T) the
+// plain division is used, so the result is bit-identical to x / T everywhere.
+struct DivT {
+    float T, rT;
+    bool fast;
+    __device__ __forceinline__ explicit DivT(float T_) : T(T_), rT(__fdiv_rn(1.0f, T_)), fast(T_ == 0.01f) {}
+    __device__ __forceinline__ float operator()(float x) const {
+        const float ax = fabsf(x);
+        if (fast && ax >= 0x1p-100f && ax < 0x1p119f) {
+            const float q = x * rT;
+            const float r = fmaf(-q, T, x);
+            return fmaf(r, rT, q);
+        }
+        return __fdiv_rn(x, T);
+    }
+};
+
+// e^d on v_exp_f32 with the rounding error of d * log2(e) carried along (<= ~1.5 ulp for |d| < 10^4; results below the normal
+// range flush to zero -- those terms are < 2^-126 of the running sum)
+__device__ __forceinline__ float exp_v(float d) {
+    const float L2E = 1.44269502162933349609375f;           // float(log2 e)
+    const float t = d * L2E;
+    float r = fmaf(d, L2E, -t);
+    r = fmaf(d, 1.92596299e-8f, r);                          // log2 e - float(log2 e)
+    return __builtin_amdgcn_exp2f(t) * fmaf(r, 0.693147180559945f, 1.0f);
+}
+
 __device__ __forceinline__ void ss_merge(SsPart& a, const SsPart& b) {
     if (b.s > 0.f || b.m > -INFINITY) {
         const float m = fmaxf(a.m, b.m);
@@ -172,6 +202,7 @@ __global__ void __launch_bounds__(256) ss_part_kernel(const float* __restrict__ 
                                                       const float* __restrict__ lin, int rows_per_chunk,
                                                       SsPart* __restrict__ part, int nchunk, float T) {
     __shared__ SsPart red[256];
+    const DivT divT(T);
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int c = threadIdx.x % C, pl = threadIdx.x / C, npl = 256 / C;
     const float* xb = x + (long long)b * bs;
@@ -184,14 +215,14 @@ __global__ void __launch_bounds__(256) ss_part_kernel(const float* __restrict__ 
         for (int k = pl; k < S; k += npl) {
             const int p = row * S + k;
             const float xv = xb[(long long)p * ld + c];
-            const float l = __fdiv_rn(xv, T);
+            const float l = divT(xv);
             if (xv > a.xmax) { a.xmax = xv; a.arg = p; }
             if (l > a.m) {
-                const float f = a.m > -INFINITY ? expf(a.m - l) : 0.f;
+                const float f = a.m > -INFINITY ? exp_v(a.m - l) : 0.f;
                 a.s *= f; a.sx *= f; a.sy *= f; a.sz *= f;
                 a.m = l;
             }
-            const float e = expf(l - a.m);
+            const float e = exp_v(l - a.m);
             a.s += e; a.sx = fmaf(e, wx, a.sx); a.sy = fmaf(e, wy, a.sy); a.sz = fmaf(e, lin[k], a.sz);
         }
     }
@@ -207,15 +238,15 @@ __global__ void __launch_bounds__(256) ss_part_kernel(const float* __restrict__ 
 // float4 variant of stage 1 (16-byte aligned rows): a thread owns 4 channels, C/4 threads cover a voxel, and four voxels
 // per thread are loaded before any of them is consumed -- the scalar kernel keeps one 256-byte row per wave in flight,
 // far too little to cover HBM latency on 256 CUs.
-__device__ __forceinline__ void ss_update(SsPart& a, float xv, int p, float wx, float wy, float wz, float T) {
-    const float l = __fdiv_rn(xv, T);
+__device__ __forceinline__ void ss_update(SsPart& a, float xv, int p, float wx, float wy, float wz, const DivT& divT) {
+    const float l = divT(xv);
     if (xv > a.xmax) { a.xmax = xv; a.arg = p; }
     if (l > a.m) {
-        const float f = a.m > -INFINITY ? expf(a.m - l) : 0.f;
+        const float f = a.m > -INFINITY ? exp_v(a.m - l) : 0.f;
         a.s *= f; a.sx *= f; a.sy *= f; a.sz *= f;
         a.m = l;
     }
-    const float e = expf(l - a.m);
+    const float e = exp_v(l - a.m);
     a.s += e; a.sx = fmaf(e, wx, a.sx); a.sy = fmaf(e, wy, a.sy); a.sz = fmaf(e, wz, a.sz);
 }
 
@@ -223,6 +254,7 @@ __global__ void __launch_bounds__(256) ss_part4_kernel(const float* __restrict__
                                                        const float* __restrict__ lin, int rows_per_chunk,
                                                        SsPart* __restrict__ part, int nchunk, float T) {
     __shared__ SsPart red[256 * 4];
+    const DivT divT(T);
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int q = C >> 2;
     const int cq = threadIdx.x % q, pl = threadIdx.x / q, npl = 256 / q;
@@ -247,8 +279,91 @@ __global__ void __launch_bounds__(256) ss_part4_kernel(const float* __restrict__
                 if (k < S) {
                     const int p = row * S + k;
                     const float wz = lin[k];
-                    ss_update(a[0], v[uu].x, p, wx, wy, wz, T); ss_update(a[1], v[uu].y, p, wx, wy, wz, T);
-                    ss_update(a[2], v[uu].z, p, wx, wy, wz, T); ss_update(a[3], v[uu].w, p, wx, wy, wz, T);
+                    ss_update(a[0], v[uu].x, p, wx, wy, wz, divT); ss_update(a[1], v[uu].y, p, wx, wy, wz, divT);
+                    ss_update(a[2], v[uu].z, p, wx, wy, wz, divT); ss_update(a[3], v[uu].w, p, wx, wy, wz, divT);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[threadIdx.x * 4 + e] = a[e];
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        const int tq = threadIdx.x >> 2, e = threadIdx.x & 3;      // channel c = threadIdx.x = 4 tq + e
+        SsPart r = red[tq * 4 + e];
+        for (int g = 1; g < npl; ++g) ss_merge(r, red[(g * q + tq) * 4 + e]);
+        part[((long long)b * nchunk + chunk) * C + threadIdx.x] = r;
+    }
+}
+
+// The input conv and the statistics pass over its output in one kernel (perceiver :357 + :360): thread -> (voxel, 4 channels)
+// exactly as in ss_part4_kernel (same chunks, same visiting order, so the partials are bit-identical to the two-kernel
+// path), y = lrelu(W x + b) is stored and folded into the running softmax / max statistics while it is still in registers:
+// the 256 B per voxel are written once and never read back (4.1 GB per step at B = 16, V = 100).  Cout == 64, Cin <= 16.
+__global__ void __launch_bounds__(256) pw_fwd_ss_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int S, int Cin,
+                                                        float slope, const float* __restrict__ lin, int rows_per_chunk,
+                                                        SsPart* __restrict__ part, int nchunk, float T) {
+    __shared__ SsPart red[256 * 4];
+    __shared__ float sw[16 * 64];      // [ci][co]
+    __shared__ float sb[64];
+    const DivT divT(T);
+    constexpr int C = 64, q = 16, npl = 16;
+    for (int i = threadIdx.x; i < Cin * C; i += 256) {
+        const int co = i / Cin, ci = i % Cin;
+        sw[ci * C + co] = W[i];
+    }
+    if (threadIdx.x < C) sb[threadIdx.x] = bias[threadIdx.x];
+    __syncthreads();
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int cq = threadIdx.x % q, pl = threadIdx.x / q;
+    const long long vox0 = (long long)b * S * S * S;
+    const float* xb = x + vox0 * Cin;
+    float* yb = y + vox0 * C + 4 * cq;
+    float wreg[16][4];
+#pragma unroll
+    for (int ci = 0; ci < 16; ++ci) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wreg[ci][e] = ci < Cin ? sw[ci * C + 4 * cq + e] : 0.f;
+    }
+    const float b0 = sb[4 * cq], b1 = sb[4 * cq + 1], b2 = sb[4 * cq + 2], b3 = sb[4 * cq + 3];
+    SsPart a[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e].m = -INFINITY; a[e].s = 0.f; a[e].sx = 0.f; a[e].sy = 0.f; a[e].sz = 0.f; a[e].xmax = -INFINITY; a[e].arg = 0x7fffffff; }
+    const int row0 = chunk * rows_per_chunk, row1 = min(S * S, row0 + rows_per_chunk);
+    for (int row = row0; row < row1; ++row) {
+        const int i = row / S, j = row - i * S;
+        const float wy = lin[i], wx = lin[j];        // meshgrid 'xy' quirk: pos_x follows axis 1, pos_y axis 0
+        for (int k0 = pl; k0 < S; k0 += 4 * npl) {
+            float xr[4][16];
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) {
+                const int k = k0 + uu * npl;
+                const float* xp = xb + (long long)(row * S + k) * Cin;
+#pragma unroll
+                for (int ci = 0; ci < 16; ++ci) xr[uu][ci] = (k < S && ci < Cin) ? xp[ci] : 0.f;
+            }
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) {
+                const int k = k0 + uu * npl;
+                if (k < S) {
+                    const int p = row * S + k;
+                    float a0 = b0, a1 = b1, a2 = b2, a3 = b3;
+#pragma unroll
+                    for (int ci = 0; ci < 16; ++ci) {
+                        if (ci < Cin) {
+                            const float xv = xr[uu][ci];
+                            a0 = fmaf(xv, wreg[ci][0], a0); a1 = fmaf(xv, wreg[ci][1], a1);
+                            a2 = fmaf(xv, wreg[ci][2], a2); a3 = fmaf(xv, wreg[ci][3], a3);
+                        }
+                    }
+                    float4 o;
+                    o.x = a0 > 0.f ? a0 : a0 * slope; o.y = a1 > 0.f ? a1 : a1 * slope;
+                    o.z = a2 > 0.f ? a2 : a2 * slope; o.w = a3 > 0.f ? a3 : a3 * slope;
+                    *reinterpret_cast<float4*>(yb + (long long)p * C) = o;
+                    const float wz = lin[k];
+                    ss_update(a[0], o.x, p, wx, wy, wz, divT); ss_update(a[1], o.y, p, wx, wy, wz, divT);
+                    ss_update(a[2], o.z, p, wx, wy, wz, divT); ss_update(a[3], o.w, p, wx, wy, wz, divT);
                 }
             }
         }
@@ -319,6 +434,7 @@ __global__ void __launch_bounds__(256) ss_bwd4_kernel(const float* __restrict__ 
                                                       const float* __restrict__ g_ss, const float* __restrict__ g_max,
                                                       float* __restrict__ dx, long long dbs, int rows_per_chunk, float T,
                                                       int accumulate) {
+    const DivT divT(T);
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int q = C >> 2;
     const int cq = threadIdx.x % q, pl = threadIdx.x / q, npl = 256 / q;
@@ -359,9 +475,9 @@ __global__ void __launch_bounds__(256) ss_bwd4_kernel(const float* __restrict__ 
                     float r[4] = {old[uu].x, old[uu].y, old[uu].z, old[uu].w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float l = __fdiv_rn(xs[e], T);
-                        const float a = expf(l - m[e]) * inv_s[e];
-                        float g = __fdiv_rn(a * (base[e] + gz[e] * (lk - ez[e])), T);
+                        const float l = divT(xs[e]);
+                        const float a = exp_v(l - m[e]) * inv_s[e];
+                        float g = divT(a * (base[e] + gz[e] * (lk - ez[e])));
                         if (p == am[e]) g += gm[e];
                         r[e] = accumulate ? r[e] + g : g;
                     }
@@ -379,6 +495,7 @@ __global__ void __launch_bounds__(256) ss_bwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ g_ss, const float* __restrict__ g_max,
                                                      float* __restrict__ dx, long long dbs, int rows_per_chunk, float T,
                                                      int accumulate) {
+    const DivT divT(T);
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int c = threadIdx.x % C, pl = threadIdx.x / C, npl = 256 / C;
     const float* xb = x + (long long)b * bs;
@@ -396,12 +513,103 @@ __global__ void __launch_bounds__(256) ss_bwd_kernel(const float* __restrict__ x
         for (int k = pl; k < S; k += npl) {
             const int p = row * S + k;
             const long long o = (long long)p * ld + c;
-            const float l = __fdiv_rn(xb[o], T);
-            const float a = expf(l - m) * inv_s;
-            float g = __fdiv_rn(a * (base + gz * (lin[k] - ez)), T);
+            const float l = divT(xb[o]);
+            const float a = exp_v(l - m) * inv_s;
+            float g = divT(a * (base + gz * (lin[k] - ez)));
             if (p == am) g += gm;
             if (accumulate) db[o] += g; else db[o] = g;
         }
+    }
+}
+
+// Weight gradient of the input conv with the backward of SpatialSoftmax3D + max pool of its OUTPUT folded in: the gradient
+// that reaches y is dy (conv paths) + the pooled-feature term of ss_bwd4_kernel (same formula per element), so that term
+// never makes its own read-y / write-dy pass over the grid.  One workgroup per 4096 voxels of ONE sample (grid.y = b).
+__global__ void __launch_bounds__(256) pw_wgrad4_ss_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ dy, float* __restrict__ partW,
+                                                           float* __restrict__ partB, int S, int Cin, int vox_per_block, float slope,
+                                                           const float* __restrict__ lin, const float* __restrict__ stats,
+                                                           const float* __restrict__ out_ss, const int* __restrict__ argmax,
+                                                           const float* __restrict__ g_ss, const float* __restrict__ g_max, float T) {
+    __shared__ float red[4][64 * 17];
+    const DivT divT(T);
+    const int b = blockIdx.y;
+    const int c4 = (threadIdx.x & 15) * 4, gl = threadIdx.x >> 4, wid = threadIdx.x >> 6;
+    const long long S3 = (long long)S * S * S;
+    x += (long long)b * S3 * Cin; y += (long long)b * S3 * 64; dy += (long long)b * S3 * 64;
+    float m[4], inv_s[4], ex[4], ey[4], ez[4], gx[4], gy[4], gz[4], gm[4];
+    int am[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int bc = b * 64 + c4 + e;
+        m[e] = stats[2 * bc]; inv_s[e] = 1.0f / stats[2 * bc + 1];
+        ex[e] = out_ss[3LL * bc]; ey[e] = out_ss[3LL * bc + 1]; ez[e] = out_ss[3LL * bc + 2];
+        gx[e] = g_ss[3LL * bc]; gy[e] = g_ss[3LL * bc + 1]; gz[e] = g_ss[3LL * bc + 2];
+        gm[e] = g_max[bc]; am[e] = argmax[bc];
+    }
+    float acc[4][16], accb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        accb[e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[e][i] = 0.f;
+    }
+    const long long v0 = (long long)blockIdx.x * vox_per_block;
+    const long long v1 = min(S3, v0 + vox_per_block);
+    for (long long vb = v0 + gl; vb < v1; vb += 32) {
+        float4 yy[2], dd[2];
+        float xr[2][16];
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) {
+            const long long v = vb + 16 * uu;
+            const bool ok = v < v1;
+            yy[uu] = ok ? *reinterpret_cast<const float4*>(y + v * 64 + c4) : make_float4(1.f, 1.f, 1.f, 1.f);
+            dd[uu] = ok ? *reinterpret_cast<const float4*>(dy + v * 64 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int ci = 0; ci < 16; ++ci) xr[uu][ci] = (ok && ci < Cin) ? x[v * Cin + ci] : 0.f;
+        }
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) {
+            const long long v = vb + 16 * uu;
+            if (v < v1) {
+                const int p = (int)v;
+                const int row = p / S, k = p - row * S, i = row / S, j = row - i * S;
+                const float li = lin[i], lj = lin[j], lk = lin[k];
+                const float ys[4] = {yy[uu].x, yy[uu].y, yy[uu].z, yy[uu].w};
+                const float ds[4] = {dd[uu].x, dd[uu].y, dd[uu].z, dd[uu].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float l = divT(ys[e]);
+                    const float a = exp_v(l - m[e]) * inv_s[e];
+                    float g = divT(a * ((gx[e] * (lj - ex[e]) + gy[e] * (li - ey[e])) + gz[e] * (lk - ez[e])));
+                    if (p == am[e]) g += gm[e];
+                    float d = ds[e] + g;
+                    d = ys[e] > 0.f ? d : d * slope;
+                    accb[e] += d;
+#pragma unroll
+                    for (int ci = 0; ci < 16; ++ci) acc[e][ci] = fmaf(d, xr[uu][ci], acc[e][ci]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int ci = 0; ci < 17; ++ci) {
+            float v = ci < 16 ? acc[e][ci] : accb[e];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if ((threadIdx.x & 63) < 16) red[wid][(c4 + e) * 17 + ci] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int co = threadIdx.x;
+        const long long blk = (long long)b * gridDim.x + blockIdx.x;
+        for (int ci = 0; ci < Cin; ++ci)
+            partW[blk * 64 * Cin + co * Cin + ci] =
+                (red[0][co * 17 + ci] + red[1][co * 17 + ci]) + (red[2][co * 17 + ci] + red[3][co * 17 + ci]);
+        partB[blk * 64 + co] = (red[0][co * 17 + 16] + red[1][co * 17 + 16]) + (red[2][co * 17 + 16] + red[3][co * 17 + 16]);
     }
 }
 
@@ -953,6 +1161,51 @@ extern "C" int vxb_ss3d_max_bwd_f32(const float* x, int64_t bs, int B, int S, in
     }
     VXB_CHECK_LAUNCH();
     return VXB_OK;
+}
+
+// Fused forms for the first layer (C = 64 output channels): the input conv + LeakyReLU with the SpatialSoftmax3D / max-pool
+// statistics of its output taken while the output is written, and the conv's parameter gradients with the pooled features'
+// backward term added to dy on the fly.  Same results as the two-kernel paths (forward: bit-identical).
+extern "C" int vxb_pointwise_ss3d_fwd_f32(const float* x, const float* W, const float* bias, float* y, int B, int S, int Cin, int Cout,
+                                          float slope, const float* lin, float* part_ws, float* out_ss, float* out_max, float* stats,
+                                          int32_t* argmax, vxb_stream_t stream) {
+    if (!x || !W || !bias || !y || !lin || !part_ws || !out_ss || !out_max || !stats || !argmax || B < 1 || S < 1 || Cin < 1 ||
+        Cin > 16) return VXB_EARG;
+    if (Cout != 64 || (((uintptr_t)y) & 15)) return VXB_ESIZE;
+    hipStream_t st = (hipStream_t)stream;
+    const int want = vxb_ss3d_chunks(B);
+    const int rpc = (S * S / want) < 1 ? 1 : S * S / want;
+    const int nchunk = vxb_cdiv(S * S, rpc);
+    hipLaunchKernelGGL(pw_fwd_ss_kernel, dim3(nchunk, B), dim3(256), 0, st, x, W, bias, y, S, Cin, slope, lin, rpc, (SsPart*)part_ws,
+                       nchunk, 0.01f);
+    if (nchunk > 128)
+        hipLaunchKernelGGL(ss_final_wide_kernel, dim3(B * 64), dim3(256), 0, st, (const SsPart*)part_ws, nchunk, B, 64, 64, 0, out_ss,
+                           out_max, stats, argmax);
+    else
+        hipLaunchKernelGGL(ss_final_kernel, dim3(vxb_cdiv(B * 64, 256)), dim3(256), 0, st, (const SsPart*)part_ws, nchunk, B, 64, 64, 0,
+                           out_ss, out_max, stats, argmax);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+// part_ws: B * ceil(S^3 / 4096) * (64*Cin + 64) floats.  dW [64][Cin] and db [64] are ACCUMULATED.
+extern "C" int vxb_pointwise_wgrad_ss3d_f32(const float* x, const float* y, const float* dy, float* dW, float* db, float* part_ws, int B,
+                                            int S, int Cin, int Cout, float slope, const float* lin, const float* stats,
+                                            const float* out_ss, const int32_t* argmax, const float* g_ss, const float* g_max,
+                                            vxb_stream_t stream) {
+    if (!x || !y || !dy || !dW || !db || !part_ws || !lin || !stats || !out_ss || !argmax || !g_ss || !g_max || B < 1 || S < 1 ||
+        Cin < 1 || Cin > 16) return VXB_EARG;
+    if (Cout != 64 || ((((uintptr_t)y) | ((uintptr_t)dy)) & 15)) return VXB_ESIZE;
+    const int vpb = 4096;
+    const int nbs = vxb_cdiv((long long)S * S * S, vpb);
+    const int nb = nbs * B;
+    float* pW = part_ws;
+    float* pB = part_ws + (size_t)nb * 64 * Cin;
+    hipLaunchKernelGGL(pw_wgrad4_ss_kernel, dim3(nbs, B), dim3(256), 0, (hipStream_t)stream, x, y, dy, pW, pB, S, Cin, vpb, slope, lin,
+                       stats, out_ss, argmax, g_ss, g_max, 0.01f);
+    VXB_CHECK_LAUNCH();
+    int rc = vxb_sum_splits_f32(pW, nb, 64 * Cin, dW, 1, 1.0f, stream);
+    if (rc) return rc;
+    return vxb_sum_splits_f32(pB, nb, 64, db, 1, 1.0f, stream);
 }
 
 extern "C" int vxb_conv3_c1_fwd_f32(const float* u, const float* w, const float* bias, float* q, int B, int S, int C,

@@ -612,6 +612,33 @@ def ss3d_max_fwd(x, bs, B, S, C):
     return out_ss, out_max, stats, argmax
 
 
+def pointwise_ss3d_fwd(x, W, bias, B, S):
+    """pointwise_fwd + ss3d_max_fwd of its output in one pass (x [B,S,S,S,Cin] -> y [B,S,S,S,64], (out_ss, out_max, stats, argmax))."""
+    dev = x.device
+    Cout = W.shape[0]
+    y = torch.empty(x.shape[:-1] + (Cout,), dtype=torch.float32, device=dev)
+    want = max(64, (1024 + B - 1) // B)
+    rpc = max(1, S * S // want)
+    nchunk = (S * S + rpc - 1) // rpc
+    ws = torch.empty(B * nchunk * Cout * 7, dtype=torch.float32, device=dev)
+    out_ss = torch.empty((B, 3 * Cout), dtype=torch.float32, device=dev)
+    out_max = torch.empty((B, Cout), dtype=torch.float32, device=dev)
+    stats = torch.empty((B, Cout, 2), dtype=torch.float32, device=dev)
+    argmax = torch.empty((B, Cout), dtype=torch.int32, device=dev)
+    call('vxb_pointwise_ss3d_fwd_f32', x, W, bias, y, B, S, x.shape[-1], Cout, LRELU_SLOPE, lin_table(S, dev), ws, out_ss, out_max,
+         stats, argmax)
+    return y, (out_ss, out_max, stats, argmax)
+
+
+def pointwise_wgrad_ss3d(x, y, dy, dW, db, B, S, stats, out_ss, argmax, g_ss, g_max):
+    """pointwise_wgrad with the ss3d_max_bwd term of y's pooled features added to dy on the fly (dy itself is not modified)."""
+    Cin = x.shape[-1]
+    nb = B * ((S ** 3 + 4095) // 4096)
+    ws = torch.empty(nb * (64 * Cin + 64), dtype=torch.float32, device=x.device)
+    call('vxb_pointwise_wgrad_ss3d_f32', x, y, dy, dW, db, ws, B, S, Cin, y.shape[-1], LRELU_SLOPE, lin_table(S, x.device), stats,
+         out_ss, argmax, g_ss, g_max)
+
+
 def ss3d_max_bwd(x, bs, B, S, C, stats, out_ss, argmax, g_ss, g_max, dx, dbs, accumulate=False):
     call('vxb_ss3d_max_bwd_f32', x, bs, B, S, C, lin_table(S, x.device), stats, out_ss, argmax, g_ss, g_max, dx, dbs,
          int(accumulate))
