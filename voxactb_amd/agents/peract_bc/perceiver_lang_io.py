@@ -672,7 +672,7 @@ class PerceiverEngine:
         dd0 = E(B, V, V, V, C)
         # the pooled-feature gradient of d0 (ss0) is added inside the input conv's weight-gradient kernel, the last reader of
         # dd0; otherwise it is dd0's first writer
-        fuse_ss0 = C == 64 and FUSE_INPUT_SS
+        fuse_ss0 = C == 64 and FUSE_INPUT_SS and c['vox'].shape[-1] == 10
         if not fuse_ss0:
             ss, mx, st, am = c['ss0']
             ops.ss3d_max_bwd(d0, V ** 3 * C, B, V, C, st, ss, am, gs[0], gs[1], dd0, V ** 3 * C)

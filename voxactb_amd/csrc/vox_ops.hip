@@ -155,22 +155,18 @@ __global__ void __launch_bounds__(256) pw_wgrad4_kernel(const float* __restrict_
 struct SsPart { float m, s, sx, sy, sz, xmax; int arg; };
 
 // x / T for the SpatialSoftmax3D temperature.  The reference divides (network_utils.py:801: feature / self.temperature); the
-// IEEE division the compiler emits costs ~12 VALU instructions, which made the statistics pass VALU-bound (2.6 TB/s).  With
-// rT = RN(1/T): q = RN(x rT), r = x - q T (exact, fma), RN(q + r rT) IS the correctly rounded quotient (Markstein) -- checked
-// exhaustively on the CPU for T = 0.01f and every float 2^-100 <= |x| < 2^119; outside that range (and for any other T) the
-// plain division is used, so the result is bit-identical to x / T everywhere.
+// IEEE division the compiler emits costs ~12 VALU instructions plus a scaling branch, which made the statistics pass
+// VALU-bound (2.6 TB/s).  With rT = RN(1/T): q = RN(x rT), r = x - q T (exact, fma), RN(q + r rT) IS the correctly rounded
+// quotient (Markstein) -- checked exhaustively on the CPU for T = 0.01f and every float with 2^-100 <= |x| < 2^119; outside
+// that range the result is within 1 ulp of x / T (|x| < 2^-100: a difference of 2^-124 or less in the softmax exponent).
+// The temperature is the network's constant 0.01 (network_utils.py:776).
 struct DivT {
     float T, rT;
-    bool fast;
-    __device__ __forceinline__ explicit DivT(float T_) : T(T_), rT(__fdiv_rn(1.0f, T_)), fast(T_ == 0.01f) {}
+    __device__ __forceinline__ explicit DivT(float) : T(0.01f), rT(__fdiv_rn(1.0f, 0.01f)) {}      // (every caller passes 0.01f)
     __device__ __forceinline__ float operator()(float x) const {
-        const float ax = fabsf(x);
-        if (fast && ax >= 0x1p-100f && ax < 0x1p119f) {
-            const float q = x * rT;
-            const float r = fmaf(-q, T, x);
-            return fmaf(r, rT, q);
-        }
-        return __fdiv_rn(x, T);
+        const float q = x * rT;
+        const float r = fmaf(-q, T, x);
+        return fmaf(r, rT, q);
     }
 };
 
@@ -238,16 +234,33 @@ __global__ void __launch_bounds__(256) ss_part_kernel(const float* __restrict__ 
 // float4 variant of stage 1 (16-byte aligned rows): a thread owns 4 channels, C/4 threads cover a voxel, and four voxels
 // per thread are loaded before any of them is consumed -- the scalar kernel keeps one 256-byte row per wave in flight,
 // far too little to cover HBM latency on 256 CUs.
-__device__ __forceinline__ void ss_update(SsPart& a, float xv, int p, float wx, float wy, float wz, const DivT& divT) {
-    const float l = divT(xv);
-    if (xv > a.xmax) { a.xmax = xv; a.arg = p; }
-    if (l > a.m) {
-        const float f = a.m > -INFINITY ? exp_v(a.m - l) : 0.f;
-        a.s *= f; a.sx *= f; a.sy *= f; a.sz *= f;
-        a.m = l;
+// One channel, four voxels (p0, p0 + dp, ...; bit u of `vm` = voxel u exists; voxel 0 always does): ONE rescale of the running
+// sums to the new maximum, then four terms -- no data-dependent branch (the per-element "new maximum?" branch of the scalar
+// kernel cost more scalar instructions than the arithmetic).
+__device__ __forceinline__ void ss_update4(SsPart& a, float x0, float x1, float x2, float x3, int p0, int dp, unsigned vm, float wx,
+                                           float wy, float wz0, float wz1, float wz2, float wz3, const DivT& divT) {
+    const float xs[4] = {x0, x1, x2, x3};
+    const float wz[4] = {wz0, wz1, wz2, wz3};
+    float l[4];
+    float mn = a.m;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const bool ok = (vm >> u) & 1u;
+        l[u] = divT(xs[u]);
+        mn = ok ? fmaxf(mn, l[u]) : mn;
+        const bool gt = ok && xs[u] > a.xmax;
+        a.xmax = gt ? xs[u] : a.xmax;
+        a.arg = gt ? p0 + u * dp : a.arg;
     }
-    const float e = exp_v(l - a.m);
-    a.s += e; a.sx = fmaf(e, wx, a.sx); a.sy = fmaf(e, wy, a.sy); a.sz = fmaf(e, wz, a.sz);
+    const float f = a.m > -INFINITY ? exp_v(a.m - mn) : 0.f;
+    a.s *= f; a.sx *= f; a.sy *= f; a.sz *= f;
+    a.m = mn;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const bool ok = (vm >> u) & 1u;
+        const float e = ok ? exp_v(l[u] - mn) : 0.f;
+        a.s += e; a.sx = fmaf(e, wx, a.sx); a.sy = fmaf(e, wy, a.sy); a.sz = fmaf(e, wz[u], a.sz);
+    }
 }
 
 __global__ void __launch_bounds__(256) ss_part4_kernel(const float* __restrict__ x, long long bs, int S, int C, int ld,
@@ -273,16 +286,19 @@ __global__ void __launch_bounds__(256) ss_part4_kernel(const float* __restrict__
                 const int k = k0 + uu * npl;
                 v[uu] = k < S ? *reinterpret_cast<const float4*>(xb + (long long)(row * S + k) * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            unsigned vm = 0;
+            float wz[4];
 #pragma unroll
             for (int uu = 0; uu < 4; ++uu) {
                 const int k = k0 + uu * npl;
-                if (k < S) {
-                    const int p = row * S + k;
-                    const float wz = lin[k];
-                    ss_update(a[0], v[uu].x, p, wx, wy, wz, divT); ss_update(a[1], v[uu].y, p, wx, wy, wz, divT);
-                    ss_update(a[2], v[uu].z, p, wx, wy, wz, divT); ss_update(a[3], v[uu].w, p, wx, wy, wz, divT);
-                }
+                vm |= (k < S ? 1u : 0u) << uu;
+                wz[uu] = lin[k < S ? k : 0];
             }
+            const int p0 = row * S + k0;
+            ss_update4(a[0], v[0].x, v[1].x, v[2].x, v[3].x, p0, npl, vm, wx, wy, wz[0], wz[1], wz[2], wz[3], divT);
+            ss_update4(a[1], v[0].y, v[1].y, v[2].y, v[3].y, p0, npl, vm, wx, wy, wz[0], wz[1], wz[2], wz[3], divT);
+            ss_update4(a[2], v[0].z, v[1].z, v[2].z, v[3].z, p0, npl, vm, wx, wy, wz[0], wz[1], wz[2], wz[3], divT);
+            ss_update4(a[3], v[0].w, v[1].w, v[2].w, v[3].w, p0, npl, vm, wx, wy, wz[0], wz[1], wz[2], wz[3], divT);
         }
     }
 #pragma unroll
@@ -299,74 +315,97 @@ __global__ void __launch_bounds__(256) ss_part4_kernel(const float* __restrict__
 // The input conv and the statistics pass over its output in one kernel (perceiver :357 + :360): thread -> (voxel, 4 channels)
 // exactly as in ss_part4_kernel (same chunks, same visiting order, so the partials are bit-identical to the two-kernel
 // path), y = lrelu(W x + b) is stored and folded into the running softmax / max statistics while it is still in registers:
-// the 256 B per voxel are written once and never read back (4.1 GB per step at B = 16, V = 100).  Cout == 64, Cin <= 16.
+// the 256 B per voxel are written once and never read back (4.1 GB per step at B = 16, V = 100).  Cout == 64.
+// A (d, h) row of x (S voxels x CIN floats, contiguous) is staged in LDS by the whole workgroup, one row ahead: the 16 threads
+// that share a voxel read its CIN inputs as LDS broadcasts instead of 16 x CIN global loads.
+constexpr int PWSS_MAX_S = 256;
+template <int CIN>
 __global__ void __launch_bounds__(256) pw_fwd_ss_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                                        const float* __restrict__ bias, float* __restrict__ y, int S, int Cin,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int S,
                                                         float slope, const float* __restrict__ lin, int rows_per_chunk,
                                                         SsPart* __restrict__ part, int nchunk, float T) {
     __shared__ SsPart red[256 * 4];
-    __shared__ float sw[16 * 64];      // [ci][co]
-    __shared__ float sb[64];
+    __shared__ float sx[2][PWSS_MAX_S * CIN];
     const DivT divT(T);
     constexpr int C = 64, q = 16, npl = 16;
-    for (int i = threadIdx.x; i < Cin * C; i += 256) {
-        const int co = i / Cin, ci = i % Cin;
-        sw[ci * C + co] = W[i];
-    }
-    if (threadIdx.x < C) sb[threadIdx.x] = bias[threadIdx.x];
-    __syncthreads();
+    constexpr int NLD = (PWSS_MAX_S * CIN + 255) / 256;
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int cq = threadIdx.x % q, pl = threadIdx.x / q;
     const long long vox0 = (long long)b * S * S * S;
-    const float* xb = x + vox0 * Cin;
+    const float* xb = x + vox0 * CIN;
     float* yb = y + vox0 * C + 4 * cq;
-    float wreg[16][4];
+    float wreg[CIN][4];
 #pragma unroll
-    for (int ci = 0; ci < 16; ++ci) {
+    for (int ci = 0; ci < CIN; ++ci) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) wreg[ci][e] = ci < Cin ? sw[ci * C + 4 * cq + e] : 0.f;
+        for (int e = 0; e < 4; ++e) wreg[ci][e] = W[(4 * cq + e) * CIN + ci];
     }
-    const float b0 = sb[4 * cq], b1 = sb[4 * cq + 1], b2 = sb[4 * cq + 2], b3 = sb[4 * cq + 3];
+    const float b0 = bias[4 * cq], b1 = bias[4 * cq + 1], b2 = bias[4 * cq + 2], b3 = bias[4 * cq + 3];
     SsPart a[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) { a[e].m = -INFINITY; a[e].s = 0.f; a[e].sx = 0.f; a[e].sy = 0.f; a[e].sz = 0.f; a[e].xmax = -INFINITY; a[e].arg = 0x7fffffff; }
     const int row0 = chunk * rows_per_chunk, row1 = min(S * S, row0 + rows_per_chunk);
+    const int rowlen = S * CIN;
+    float nxt[NLD];
+    if (row0 < row1) {
+        const float* xr = xb + (long long)row0 * rowlen;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int i = threadIdx.x + 256 * u;
+            if (i < rowlen) sx[0][i] = xr[i];
+        }
+    }
+    __syncthreads();
+    int cur = 0;
     for (int row = row0; row < row1; ++row) {
-        const int i = row / S, j = row - i * S;
-        const float wy = lin[i], wx = lin[j];        // meshgrid 'xy' quirk: pos_x follows axis 1, pos_y axis 0
-        for (int k0 = pl; k0 < S; k0 += 4 * npl) {
-            float xr[4][16];
+        if (row + 1 < row1) {
+            const float* xr = xb + (long long)(row + 1) * rowlen;
 #pragma unroll
-            for (int uu = 0; uu < 4; ++uu) {
-                const int k = k0 + uu * npl;
-                const float* xp = xb + (long long)(row * S + k) * Cin;
-#pragma unroll
-                for (int ci = 0; ci < 16; ++ci) xr[uu][ci] = (k < S && ci < Cin) ? xp[ci] : 0.f;
-            }
-#pragma unroll
-            for (int uu = 0; uu < 4; ++uu) {
-                const int k = k0 + uu * npl;
-                if (k < S) {
-                    const int p = row * S + k;
-                    float a0 = b0, a1 = b1, a2 = b2, a3 = b3;
-#pragma unroll
-                    for (int ci = 0; ci < 16; ++ci) {
-                        if (ci < Cin) {
-                            const float xv = xr[uu][ci];
-                            a0 = fmaf(xv, wreg[ci][0], a0); a1 = fmaf(xv, wreg[ci][1], a1);
-                            a2 = fmaf(xv, wreg[ci][2], a2); a3 = fmaf(xv, wreg[ci][3], a3);
-                        }
-                    }
-                    float4 o;
-                    o.x = a0 > 0.f ? a0 : a0 * slope; o.y = a1 > 0.f ? a1 : a1 * slope;
-                    o.z = a2 > 0.f ? a2 : a2 * slope; o.w = a3 > 0.f ? a3 : a3 * slope;
-                    *reinterpret_cast<float4*>(yb + (long long)p * C) = o;
-                    const float wz = lin[k];
-                    ss_update(a[0], o.x, p, wx, wy, wz, divT); ss_update(a[1], o.y, p, wx, wy, wz, divT);
-                    ss_update(a[2], o.z, p, wx, wy, wz, divT); ss_update(a[3], o.w, p, wx, wy, wz, divT);
-                }
+            for (int u = 0; u < NLD; ++u) {
+                const int i = threadIdx.x + 256 * u;
+                nxt[u] = i < rowlen ? xr[i] : 0.f;
             }
         }
+        const int i = row / S, j = row - i * S;
+        const float wy = lin[i], wx = lin[j];        // meshgrid 'xy' quirk: pos_x follows axis 1, pos_y axis 0
+        const float* sxr = sx[cur];
+        for (int k0 = pl; k0 < S; k0 += 4 * npl) {
+            float4 o[4];
+            float wz[4];
+            unsigned vm = 0;
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) {
+                const int k = k0 + uu * npl;
+                const bool ok = k < S;
+                const int kc = ok ? k : 0;
+                vm |= (ok ? 1u : 0u) << uu;
+                wz[uu] = lin[kc];
+                float a0 = b0, a1 = b1, a2 = b2, a3 = b3;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) {
+                    const float xv = sxr[kc * CIN + ci];
+                    a0 = fmaf(xv, wreg[ci][0], a0); a1 = fmaf(xv, wreg[ci][1], a1);
+                    a2 = fmaf(xv, wreg[ci][2], a2); a3 = fmaf(xv, wreg[ci][3], a3);
+                }
+                o[uu].x = a0 > 0.f ? a0 : a0 * slope; o[uu].y = a1 > 0.f ? a1 : a1 * slope;
+                o[uu].z = a2 > 0.f ? a2 : a2 * slope; o[uu].w = a3 > 0.f ? a3 : a3 * slope;
+                if (ok) *reinterpret_cast<float4*>(yb + (long long)(row * S + k) * C) = o[uu];
+            }
+            const int p0 = row * S + k0;
+            ss_update4(a[0], o[0].x, o[1].x, o[2].x, o[3].x, p0, npl, vm, wx, wy, wz[0], wz[1], wz[2], wz[3], divT);
+            ss_update4(a[1], o[0].y, o[1].y, o[2].y, o[3].y, p0, npl, vm, wx, wy, wz[0], wz[1], wz[2], wz[3], divT);
+            ss_update4(a[2], o[0].z, o[1].z, o[2].z, o[3].z, p0, npl, vm, wx, wy, wz[0], wz[1], wz[2], wz[3], divT);
+            ss_update4(a[3], o[0].w, o[1].w, o[2].w, o[3].w, p0, npl, vm, wx, wy, wz[0], wz[1], wz[2], wz[3], divT);
+        }
+        if (row + 1 < row1) {
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int i2 = threadIdx.x + 256 * u;
+                if (i2 < rowlen) sx[cur ^ 1][i2] = nxt[u];
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) red[threadIdx.x * 4 + e] = a[e];
@@ -524,19 +563,22 @@ __global__ void __launch_bounds__(256) ss_bwd_kernel(const float* __restrict__ x
 
 // Weight gradient of the input conv with the backward of SpatialSoftmax3D + max pool of its OUTPUT folded in: the gradient
 // that reaches y is dy (conv paths) + the pooled-feature term of ss_bwd4_kernel (same formula per element), so that term
-// never makes its own read-y / write-dy pass over the grid.  One workgroup per 4096 voxels of ONE sample (grid.y = b).
+// never makes its own read-y / write-dy pass over the grid.  One workgroup per 4096 voxels of ONE sample (grid.y = b); x is
+// staged through LDS in tiles of 256 voxels (the 16 threads of a voxel share its CIN inputs).
+template <int CIN>
 __global__ void __launch_bounds__(256) pw_wgrad4_ss_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dy, float* __restrict__ partW,
-                                                           float* __restrict__ partB, int S, int Cin, int vox_per_block, float slope,
+                                                           float* __restrict__ partB, int S, int vox_per_block, float slope,
                                                            const float* __restrict__ lin, const float* __restrict__ stats,
                                                            const float* __restrict__ out_ss, const int* __restrict__ argmax,
                                                            const float* __restrict__ g_ss, const float* __restrict__ g_max, float T) {
-    __shared__ float red[4][64 * 17];
+    __shared__ float red[4][64 * (CIN + 1)];
+    __shared__ float sx[2][256 * CIN];
     const DivT divT(T);
     const int b = blockIdx.y;
     const int c4 = (threadIdx.x & 15) * 4, gl = threadIdx.x >> 4, wid = threadIdx.x >> 6;
     const long long S3 = (long long)S * S * S;
-    x += (long long)b * S3 * Cin; y += (long long)b * S3 * 64; dy += (long long)b * S3 * 64;
+    x += (long long)b * S3 * CIN; y += (long long)b * S3 * 64 + c4; dy += (long long)b * S3 * 64 + c4;
     float m[4], inv_s[4], ex[4], ey[4], ez[4], gx[4], gy[4], gz[4], gm[4];
     int am[4];
 #pragma unroll
@@ -547,69 +589,100 @@ __global__ void __launch_bounds__(256) pw_wgrad4_ss_kernel(const float* __restri
         gx[e] = g_ss[3LL * bc]; gy[e] = g_ss[3LL * bc + 1]; gz[e] = g_ss[3LL * bc + 2];
         gm[e] = g_max[bc]; am[e] = argmax[bc];
     }
-    float acc[4][16], accb[4];
+    float acc[4][CIN], accb[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         accb[e] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[e][i] = 0.f;
+        for (int i = 0; i < CIN; ++i) acc[e][i] = 0.f;
     }
     const long long v0 = (long long)blockIdx.x * vox_per_block;
     const long long v1 = min(S3, v0 + vox_per_block);
-    for (long long vb = v0 + gl; vb < v1; vb += 32) {
-        float4 yy[2], dd[2];
-        float xr[2][16];
+    float nxt[CIN];
+    {
+        const long long n = min((long long)256, v1 - v0) * CIN;
 #pragma unroll
-        for (int uu = 0; uu < 2; ++uu) {
-            const long long v = vb + 16 * uu;
-            const bool ok = v < v1;
-            yy[uu] = ok ? *reinterpret_cast<const float4*>(y + v * 64 + c4) : make_float4(1.f, 1.f, 1.f, 1.f);
-            dd[uu] = ok ? *reinterpret_cast<const float4*>(dy + v * 64 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int ci = 0; ci < 16; ++ci) xr[uu][ci] = (ok && ci < Cin) ? x[v * Cin + ci] : 0.f;
+        for (int u = 0; u < CIN; ++u) {
+            const int i = threadIdx.x + 256 * u;
+            if (i < n) sx[0][i] = x[v0 * CIN + i];
         }
+    }
+    __syncthreads();
+    int cur = 0;
+    for (long long t0 = v0; t0 < v1; t0 += 256) {
+        const long long tn = t0 + 256;
+        if (tn < v1) {
+            const long long n = min((long long)256, v1 - tn) * CIN;
 #pragma unroll
-        for (int uu = 0; uu < 2; ++uu) {
-            const long long v = vb + 16 * uu;
-            if (v < v1) {
-                const int p = (int)v;
-                const int row = p / S, k = p - row * S, i = row / S, j = row - i * S;
-                const float li = lin[i], lj = lin[j], lk = lin[k];
-                const float ys[4] = {yy[uu].x, yy[uu].y, yy[uu].z, yy[uu].w};
-                const float ds[4] = {dd[uu].x, dd[uu].y, dd[uu].z, dd[uu].w};
+            for (int u = 0; u < CIN; ++u) {
+                const int i = threadIdx.x + 256 * u;
+                nxt[u] = i < n ? x[tn * CIN + i] : 0.f;
+            }
+        }
+        const float* sxr = sx[cur];
+#pragma unroll 1
+        for (int lv = gl; lv < 256; lv += 32) {
+            float4 yy[2], dd[2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float l = divT(ys[e]);
-                    const float a = exp_v(l - m[e]) * inv_s[e];
-                    float g = divT(a * ((gx[e] * (lj - ex[e]) + gy[e] * (li - ey[e])) + gz[e] * (lk - ez[e])));
-                    if (p == am[e]) g += gm[e];
-                    float d = ds[e] + g;
-                    d = ys[e] > 0.f ? d : d * slope;
-                    accb[e] += d;
+            for (int uu = 0; uu < 2; ++uu) {
+                const long long v = t0 + lv + 16 * uu;
+                const bool ok = v < v1;
+                yy[uu] = ok ? *reinterpret_cast<const float4*>(y + v * 64) : make_float4(1.f, 1.f, 1.f, 1.f);
+                dd[uu] = ok ? *reinterpret_cast<const float4*>(dy + v * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
-                    for (int ci = 0; ci < 16; ++ci) acc[e][ci] = fmaf(d, xr[uu][ci], acc[e][ci]);
+            for (int uu = 0; uu < 2; ++uu) {
+                const long long v = t0 + lv + 16 * uu;
+                if (v < v1) {
+                    const int p = (int)v;
+                    const int row = p / S, k = p - row * S, i = row / S, j = row - i * S;
+                    const float li = lin[i], lj = lin[j], lk = lin[k];
+                    const float ys[4] = {yy[uu].x, yy[uu].y, yy[uu].z, yy[uu].w};
+                    const float ds[4] = {dd[uu].x, dd[uu].y, dd[uu].z, dd[uu].w};
+                    float xr[CIN];
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) xr[ci] = sxr[(lv + 16 * uu) * CIN + ci];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float l = divT(ys[e]);
+                        const float a = exp_v(l - m[e]) * inv_s[e];
+                        float g = divT(a * ((gx[e] * (lj - ex[e]) + gy[e] * (li - ey[e])) + gz[e] * (lk - ez[e])));
+                        if (p == am[e]) g += gm[e];
+                        float d = ds[e] + g;
+                        d = ys[e] > 0.f ? d : d * slope;
+                        accb[e] += d;
+#pragma unroll
+                        for (int ci = 0; ci < CIN; ++ci) acc[e][ci] = fmaf(d, xr[ci], acc[e][ci]);
+                    }
                 }
             }
         }
+        if (tn < v1) {
+#pragma unroll
+            for (int u = 0; u < CIN; ++u) sx[cur ^ 1][threadIdx.x + 256 * u] = nxt[u];
+        }
+        __syncthreads();
+        cur ^= 1;
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
 #pragma unroll
-        for (int ci = 0; ci < 17; ++ci) {
-            float v = ci < 16 ? acc[e][ci] : accb[e];
+        for (int ci = 0; ci < CIN + 1; ++ci) {
+            float v = ci < CIN ? acc[e][ci < CIN ? ci : 0] : accb[e];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            if ((threadIdx.x & 63) < 16) red[wid][(c4 + e) * 17 + ci] = v;
+            if ((threadIdx.x & 63) < 16) red[wid][(c4 + e) * (CIN + 1) + ci] = v;
         }
     }
     __syncthreads();
     if (threadIdx.x < 64) {
         const int co = threadIdx.x;
         const long long blk = (long long)b * gridDim.x + blockIdx.x;
-        for (int ci = 0; ci < Cin; ++ci)
-            partW[blk * 64 * Cin + co * Cin + ci] =
-                (red[0][co * 17 + ci] + red[1][co * 17 + ci]) + (red[2][co * 17 + ci] + red[3][co * 17 + ci]);
-        partB[blk * 64 + co] = (red[0][co * 17 + 16] + red[1][co * 17 + 16]) + (red[2][co * 17 + 16] + red[3][co * 17 + 16]);
+        constexpr int R = CIN + 1;
+        for (int ci = 0; ci < CIN; ++ci)
+            partW[blk * 64 * CIN + co * CIN + ci] =
+                (red[0][co * R + ci] + red[1][co * R + ci]) + (red[2][co * R + ci] + red[3][co * R + ci]);
+        partB[blk * 64 + co] = (red[0][co * R + CIN] + red[1][co * R + CIN]) + (red[2][co * R + CIN] + red[3][co * R + CIN]);
     }
 }
 
@@ -1172,11 +1245,16 @@ extern "C" int vxb_pointwise_ss3d_fwd_f32(const float* x, const float* W, const 
     if (!x || !W || !bias || !y || !lin || !part_ws || !out_ss || !out_max || !stats || !argmax || B < 1 || S < 1 || Cin < 1 ||
         Cin > 16) return VXB_EARG;
     if (Cout != 64 || (((uintptr_t)y) & 15)) return VXB_ESIZE;
+    if (Cin != 10 || S > PWSS_MAX_S) {          // other shapes: the two kernels one after the other (same results)
+        const int rc = vxb_pointwise_fwd_f32(x, W, bias, y, (int64_t)B * S * S * S, Cin, Cout, slope, stream);
+        if (rc) return rc;
+        return vxb_ss3d_max_fwd_f32(y, (int64_t)S * S * S * 64, B, S, 64, lin, part_ws, out_ss, out_max, stats, argmax, stream);
+    }
     hipStream_t st = (hipStream_t)stream;
     const int want = vxb_ss3d_chunks(B);
     const int rpc = (S * S / want) < 1 ? 1 : S * S / want;
     const int nchunk = vxb_cdiv(S * S, rpc);
-    hipLaunchKernelGGL(pw_fwd_ss_kernel, dim3(nchunk, B), dim3(256), 0, st, x, W, bias, y, S, Cin, slope, lin, rpc, (SsPart*)part_ws,
+    hipLaunchKernelGGL(pw_fwd_ss_kernel<10>, dim3(nchunk, B), dim3(256), 0, st, x, W, bias, y, S, slope, lin, rpc, (SsPart*)part_ws,
                        nchunk, 0.01f);
     if (nchunk > 128)
         hipLaunchKernelGGL(ss_final_wide_kernel, dim3(B * 64), dim3(256), 0, st, (const SsPart*)part_ws, nchunk, B, 64, 64, 0, out_ss,
@@ -1187,20 +1265,21 @@ extern "C" int vxb_pointwise_ss3d_fwd_f32(const float* x, const float* W, const 
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
-// part_ws: B * ceil(S^3 / 4096) * (64*Cin + 64) floats.  dW [64][Cin] and db [64] are ACCUMULATED.
+// part_ws: B * ceil(S^3 / 4096) * (64*Cin + 64) floats.  dW [64][Cin] and db [64] are ACCUMULATED.  Cin = 10 (the network's
+// voxel features: 3 + 3 + 3 + 1) -- other widths return VXB_ESIZE and the caller uses the two separate kernels.
 extern "C" int vxb_pointwise_wgrad_ss3d_f32(const float* x, const float* y, const float* dy, float* dW, float* db, float* part_ws, int B,
                                             int S, int Cin, int Cout, float slope, const float* lin, const float* stats,
                                             const float* out_ss, const int32_t* argmax, const float* g_ss, const float* g_max,
                                             vxb_stream_t stream) {
     if (!x || !y || !dy || !dW || !db || !part_ws || !lin || !stats || !out_ss || !argmax || !g_ss || !g_max || B < 1 || S < 1 ||
         Cin < 1 || Cin > 16) return VXB_EARG;
-    if (Cout != 64 || ((((uintptr_t)y) | ((uintptr_t)dy)) & 15)) return VXB_ESIZE;
+    if (Cout != 64 || Cin != 10 || ((((uintptr_t)y) | ((uintptr_t)dy)) & 15)) return VXB_ESIZE;
     const int vpb = 4096;
     const int nbs = vxb_cdiv((long long)S * S * S, vpb);
     const int nb = nbs * B;
     float* pW = part_ws;
     float* pB = part_ws + (size_t)nb * 64 * Cin;
-    hipLaunchKernelGGL(pw_wgrad4_ss_kernel, dim3(nbs, B), dim3(256), 0, (hipStream_t)stream, x, y, dy, pW, pB, S, Cin, vpb, slope, lin,
+    hipLaunchKernelGGL(pw_wgrad4_ss_kernel<10>, dim3(nbs, B), dim3(256), 0, (hipStream_t)stream, x, y, dy, pW, pB, S, vpb, slope, lin,
                        stats, out_ss, argmax, g_ss, g_max, 0.01f);
     VXB_CHECK_LAUNCH();
     int rc = vxb_sum_splits_f32(pW, nb, 64 * Cin, dW, 1, 1.0f, stream);
