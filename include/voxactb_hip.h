@@ -270,6 +270,16 @@ int vxb_pointwise_wgrad_ss3d_f32(const float* x, const float* y, const float* dy
                                  const float* out_ss, const int32_t* argmax, const float* g_ss, const float* g_max,
                                  vxb_stream_t stream);
 
+/* Backward of everything that reads u = final(...) (perceiver_lang_io.py:462-470) in one pass over u: du = lrelu'(u) *
+ * ([du if accumulate] + data gradient of trans_decoder (Cout = 1 conv, vxb_conv3_c1_dgrad_f32) + the pooled-feature term of
+ * vxb_ss3d_max_bwd_f32 on u), and dbias[64] += column sums of du (the bias gradient of `final`).  Bit-identical du to the
+ * separate kernels.  S % 4 == 0, C = 64; part_ws: vxb_conv3_c1_dgrad_ss3d_ws_floats(B, S) floats. */
+size_t vxb_conv3_c1_dgrad_ss3d_ws_floats(int B, int S);
+int vxb_conv3_c1_dgrad_ss3d_f32(const float* dq, const float* w, const float* u, float* du, int B, int S, int C,
+                                int accumulate, float slope, const float* lin, const float* stats, const float* out_ss,
+                                const int32_t* argmax, const float* g_ss, const float* g_max, float* dbias,
+                                float* part_ws, vxb_stream_t stream);
+
 /* SpatialSoftmax3D (T=0.01, meshgrid 'xy' quirk) + AdaptiveMaxPool3d(1) in one streaming pass
  * (network_utils.py:773-809; perceiver_lang_io.py:360,:451,:470), and the backward of both.
  * part_ws: B * nchunk * C * 7 floats with nchunk = ceil(S^2 / max(1, S^2 / want)), want = max(64, ceil(1024 / B))

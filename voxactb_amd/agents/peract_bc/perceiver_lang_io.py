@@ -31,6 +31,8 @@ import os as _os
 # the pooled features of d0 (SpatialSoftmax3D + max, perceiver :360) ride on the input conv's forward / weight-gradient kernels
 # instead of making their own passes over the grid ('0': the separate kernels, for A/B runs and the equality test)
 FUSE_INPUT_SS = _os.environ.get('VOXACTB_FUSE_INPUT_SS', '1') != '0'
+# backward of u = final(...): pooled-feature term + translation head's data gradient + LeakyReLU' + bias column sums in one pass
+FUSE_U_BWD = _os.environ.get('VOXACTB_FUSE_U_BWD', '1') != '0'
 
 LRELU_SLOPE = 0.02
 LANG_FEAT_DIM, LANG_EMB_DIM, LANG_MAX_SEQ_LEN = 1024, 512, 77
@@ -656,19 +658,28 @@ class PerceiverEngine:
         u, d0, u0 = c['u'], c['d0'], c['u0']
         du = E(B, V, V, V, C)
         ss, mx, st, am = c['ss2']
-        ops.ss3d_max_bwd(u, V ** 3 * C, B, V, C, st, ss, am, gs[4], gs[5], du, V ** 3 * C)
         wt = self.p('trans_decoder.conv3d.weight')
+        # one pass over u: the pooled features' term, the translation head's data gradient, final's LeakyReLU' and the column
+        # sums of the result (final's bias gradient) -- instead of ss3d_max_bwd, conv3_c1_dgrad and colsum one after the other
+        fuse_u = FUSE_U_BWD and ops.c1_dgrad_ss3d_ok(V, C)
+        if not fuse_u:
+            ops.ss3d_max_bwd(u, V ** 3 * C, B, V, C, st, ss, am, gs[4], gs[5], du, V ** 3 * C)
         ops.conv3_c1_wgrad(u, dq_trans, self.g('trans_decoder.conv3d.weight'), self.g('trans_decoder.conv3d.bias'), B, V)
         if self.two:
             dql = dq_trans_left.contiguous().view(B, V, V, V)
             ops.conv3_c1_wgrad(u, dql, self.g('trans_decoder_left_arm.conv3d.weight'), self.g('trans_decoder_left_arm.conv3d.bias'), B, V)
-            ops.conv3_c1_dgrad(dql, self.p('trans_decoder_left_arm.conv3d.weight'), u, du, B, V, accumulate=True, mask=False)
-        ops.conv3_c1_dgrad(dq_trans, wt, u, du, B, V, accumulate=True, mask=True)      # du is now d(pre-activation of `final`)
+            ops.conv3_c1_dgrad(dql, self.p('trans_decoder_left_arm.conv3d.weight'), u, du, B, V, accumulate=not fuse_u, mask=False)
+        if fuse_u:
+            ops.conv3_c1_dgrad_ss3d(dq_trans, wt, u, du, B, V, st, ss, am, gs[4], gs[5], self.g('final.conv3d.bias'),
+                                    accumulate=self.two)
+        else:
+            ops.conv3_c1_dgrad(dq_trans, wt, u, du, B, V, accumulate=True, mask=True)      # du is now d(pre-activation of `final`)
         # ---- final conv (two sources)
         Wf = self.p('final.conv3d.weight')
         dWt = ops.conv3d_wgrad(d0, du, C, B, V, V, 3, -1, src1=u0)
         self.g('final.conv3d.weight').add_(dWt.view(27, 2 * C, C).permute(2, 1, 0).reshape(Wf.shape))
-        ops.colsum(du.view(-1, C), self.g('final.conv3d.bias'), accumulate=True)
+        if not fuse_u:
+            ops.colsum(du.view(-1, C), self.g('final.conv3d.bias'), accumulate=True)
         dd0 = E(B, V, V, V, C)
         # the pooled-feature gradient of d0 (ss0) is added inside the input conv's weight-gradient kernel, the last reader of
         # dd0; otherwise it is dd0's first writer

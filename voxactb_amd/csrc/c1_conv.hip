@@ -97,6 +97,138 @@ __global__ void __launch_bounds__(256, 4) c1_dgrad4_kernel(const float* __restri
     }
 }
 
+// The data gradient above with the two other things that happen to the same tensor around it folded in (perceiver :465-470,
+// backward): the pooled-feature term of SpatialSoftmax3D + max pool of u (the formula of ss_bwd4_kernel in vox_ops.hip, same
+// arithmetic per element) is ADDED here instead of being written to du by its own read-u / write-du pass, and the column sums
+// of the finished du (= the bias gradient of the conv that produced u) are taken while du is in registers instead of by a
+// colsum pass.  du = lrelu'(u) * ([du_in] + sum_t dq w + ss term); partB[block][64] = sum over the block's voxels of du.
+// One sample per blockIdx.y, so the per-(sample, channel) softmax constants stay in registers.
+__global__ void __launch_bounds__(256, 2) c1_dgrad4_ss_kernel(const float* __restrict__ dq, const float* __restrict__ w,
+                                                           const float* __restrict__ u, float* __restrict__ du, int S,
+                                                           int accumulate, float slope, const float* __restrict__ lin,
+                                                           const float* __restrict__ stats, const float* __restrict__ out_ss,
+                                                           const int* __restrict__ argmax, const float* __restrict__ g_ss,
+                                                           const float* __restrict__ g_max, float* __restrict__ partB) {
+    __shared__ float sw[27 * 64];          // [t][c]
+    __shared__ float red[16][64];
+    for (int i = threadIdx.x; i < 27 * 64; i += 256) sw[(i % 27) * 64 + i / 27] = w[i];
+    const DivT divT(0.01f);
+    const int c4 = (threadIdx.x & 15) * 4, gl = threadIdx.x >> 4;
+    const int b = blockIdx.y;
+    float m[4], inv_s[4], ex[4], ey[4], ez[4], gx[4], gy[4], gz[4], gm[4], bsum[4];
+    int am[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int bc = b * 64 + c4 + e;
+        m[e] = stats[2 * bc]; inv_s[e] = 1.0f / stats[2 * bc + 1];
+        ex[e] = out_ss[3LL * bc]; ey[e] = out_ss[3LL * bc + 1]; ez[e] = out_ss[3LL * bc + 2];
+        gx[e] = g_ss[3LL * bc]; gy[e] = g_ss[3LL * bc + 1]; gz[e] = g_ss[3LL * bc + 2];
+        gm[e] = g_max[bc]; am[e] = argmax[bc];
+        bsum[e] = 0.f;
+    }
+    __syncthreads();
+    const int XG = S >> 2;
+    const int ngroups = S * S * XG;
+    const long long S3 = (long long)S * S * S;
+    const float* dqb = dq + b * S3;
+    const float* ub = u + b * S3 * 64 + c4;
+    float* dub = du + b * S3 * 64 + c4;
+    for (int gi = blockIdx.x * 16 + gl; gi < ngroups; gi += gridDim.x * 16) {
+        const int xg = gi % XG;
+        const int row = gi / XG;
+        const int h = row % S;
+        const int d = row / S;
+        const int x0 = xg * 4;
+        float4 uu[4], old[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                       // (issued before the tap loop: in flight under its 432 FMAs)
+            const long long o = ((long long)row * S + x0 + i) * 64;
+            uu[i] = *reinterpret_cast<const float4*>(ub + o);
+            old[i] = accumulate ? *reinterpret_cast<const float4*>(dub + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d >= 1 && d <= S - 2 && h >= 1 && h <= S - 2 && x0 >= 1 && x0 + 4 <= S - 1) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 3; ++bb) {
+                    const float* rp = dqb + ((long long)(d + 1 - a) * S + (h + 1 - bb)) * S + x0 - 1;
+                    float g[6];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) g[j] = rp[j];
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        const float4 wv = *reinterpret_cast<const float4*>(&sw[((a * 3 + bb) * 3 + cc) * 64 + c4]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) c1_fma4(acc[i], g[i + 2 - cc], wv);   // o_x = x0+i+1-cc
+                    }
+                }
+        } else {
+            int od[3], td[3], oh[3], th[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                int o = d + 1 - k; td[k] = o < 0 ? 0 : (o > S - 1 ? 2 : k); od[k] = c1_clampi(o, 0, S - 1);
+                o = h + 1 - k;     th[k] = o < 0 ? 0 : (o > S - 1 ? 2 : k); oh[k] = c1_clampi(o, 0, S - 1);
+            }
+            for (int i = 0; i < 4; ++i) {
+                const int x = x0 + i;
+                int ox[3], tx[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const int o = x + 1 - k; tx[k] = o < 0 ? 0 : (o > S - 1 ? 2 : k); ox[k] = c1_clampi(o, 0, S - 1); }
+                float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int bb = 0; bb < 3; ++bb)
+#pragma unroll
+                        for (int cc = 0; cc < 3; ++cc) {
+                            const float g = dqb[((long long)od[a] * S + oh[bb]) * S + ox[cc]];
+                            const int t = (td[a] * 3 + th[bb]) * 3 + tx[cc];
+                            c1_fma4(a4, g, *reinterpret_cast<const float4*>(&sw[t * 64 + c4]));
+                        }
+                acc[i] = a4;
+            }
+        }
+        const float li = lin[d], lj = lin[h];
+        float base[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) base[e] = gx[e] * (lj - ex[e]) + gy[e] * (li - ey[e]);     // meshgrid 'xy' quirk, as ss_bwd4
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = row * S + x0 + i;
+            const float lk = lin[x0 + i];
+            const float xs[4] = {uu[i].x, uu[i].y, uu[i].z, uu[i].w};
+            const float od4[4] = {old[i].x, old[i].y, old[i].z, old[i].w};
+            const float ac[4] = {acc[i].x, acc[i].y, acc[i].z, acc[i].w};
+            float r[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float l = divT(xs[e]);
+                const float a = exp_v(l - m[e]) * inv_s[e];
+                float g = divT(a * (base[e] + gz[e] * (lk - ez[e])));
+                if (p == am[e]) g += gm[e];
+                if (accumulate) g = od4[e] + g;
+                float v = ac[e] + g;                        // (same two addends as c1_dgrad4 after ss_bwd4: bit-identical)
+                v = xs[e] > 0.f ? v : v * slope;
+                bsum[e] += v;
+                r[e] = v;
+            }
+            *reinterpret_cast<float4*>(dub + (long long)p * 64) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[gl][c4 + e] = bsum[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) sacc += red[g][threadIdx.x];
+        partB[((long long)b * gridDim.x + blockIdx.x) * 64 + threadIdx.x] = sacc;
+    }
+}
+
 // part[blk][c*27 + t] = sum over the block's rows of dq[o] * u[clamp(o + t - 1)][c];  partB[blk] = sum dq
 // 16 threads (4 channels each) walk one (b, d, h) row with a sliding 3x3x3 window of float4; 16 rows per pass.
 __global__ void __launch_bounds__(256) c1_wgrad4_kernel(const float* __restrict__ u, const float* __restrict__ dq,
@@ -254,6 +386,21 @@ int vxb_c1_dgrad4_launch(const float* dq, const float* w, const float* u, float*
     const long long ngroups = (long long)B * S * S * (S >> 2);
     const int grid = (int)((ngroups + 15) / 16 > 16384 ? 16384 : (ngroups + 15) / 16);
     hipLaunchKernelGGL(c1_dgrad4_kernel, dim3(grid), dim3(256), 0, st, dq, w, u, du, B, S, accumulate, mask, slope);
+    return hipGetLastError() == hipSuccess ? VXB_OK : VXB_ELAUNCH;
+}
+
+// fused data gradient (see c1_dgrad4_ss_kernel); part_ws: vxb_c1_dgrad_ss_blocks(B, S) * 64 floats; dbias [64] ACCUMULATED
+int vxb_c1_dgrad_ss_blocks_per_sample(int S) {
+    const long long g = (long long)S * S * (S >> 2);
+    return (int)((g + 15) / 16 > 1024 ? 1024 : (g + 15) / 16);
+}
+int vxb_c1_dgrad4_ss_launch(const float* dq, const float* w, const float* u, float* du, int B, int S, int accumulate, float slope,
+                            const float* lin, const float* stats, const float* out_ss, const int* argmax, const float* g_ss,
+                            const float* g_max, float* dbias, float* part_ws, hipStream_t st) {
+    const int nbx = vxb_c1_dgrad_ss_blocks_per_sample(S);
+    hipLaunchKernelGGL(c1_dgrad4_ss_kernel, dim3(nbx, B), dim3(256), 0, st, dq, w, u, du, S, accumulate, slope, lin, stats, out_ss,
+                       argmax, g_ss, g_max, part_ws);
+    hipLaunchKernelGGL(c1_reduce_kernel, dim3(1), dim3(256), 0, st, part_ws, nbx * B, 64, dbias);
     return hipGetLastError() == hipSuccess ? VXB_OK : VXB_ELAUNCH;
 }
 

@@ -154,32 +154,6 @@ __global__ void __launch_bounds__(256) pw_wgrad4_kernel(const float* __restrict_
 // =====================================================================================================
 struct SsPart { float m, s, sx, sy, sz, xmax; int arg; };
 
-// x / T for the SpatialSoftmax3D temperature.  The reference divides (network_utils.py:801: feature / self.temperature); the
-// IEEE division the compiler emits costs ~12 VALU instructions plus a scaling branch, which made the statistics pass
-// VALU-bound (2.6 TB/s).  With rT = RN(1/T): q = RN(x rT), r = x - q T (exact, fma), RN(q + r rT) IS the correctly rounded
-// quotient (Markstein) -- checked exhaustively on the CPU for T = 0.01f and every float with 2^-100 <= |x| < 2^119; outside
-// that range the result is within 1 ulp of x / T (|x| < 2^-100: a difference of 2^-124 or less in the softmax exponent).
-// The temperature is the network's constant 0.01 (network_utils.py:776).
-struct DivT {
-    float T, rT;
-    __device__ __forceinline__ explicit DivT(float) : T(0.01f), rT(__fdiv_rn(1.0f, 0.01f)) {}      // (every caller passes 0.01f)
-    __device__ __forceinline__ float operator()(float x) const {
-        const float q = x * rT;
-        const float r = fmaf(-q, T, x);
-        return fmaf(r, rT, q);
-    }
-};
-
-// e^d on v_exp_f32 with the rounding error of d * log2(e) carried along (<= ~1.5 ulp for |d| < 10^4; results below the normal
-// range flush to zero -- those terms are < 2^-126 of the running sum)
-__device__ __forceinline__ float exp_v(float d) {
-    const float L2E = 1.44269502162933349609375f;           // float(log2 e)
-    const float t = d * L2E;
-    float r = fmaf(d, L2E, -t);
-    r = fmaf(d, 1.92596299e-8f, r);                          // log2 e - float(log2 e)
-    return __builtin_amdgcn_exp2f(t) * fmaf(r, 0.693147180559945f, 1.0f);
-}
-
 __device__ __forceinline__ void ss_merge(SsPart& a, const SsPart& b) {
     if (b.s > 0.f || b.m > -INFINITY) {
         const float m = fmaxf(a.m, b.m);
@@ -1310,6 +1284,21 @@ extern "C" int vxb_conv3_c1_dgrad_f32(const float* dq, const float* w, const flo
     return VXB_OK;
 }
 // part_ws: nblk*(64*27 + 1) floats, nblk = ceil(B*S*S / 64).  dw [1][64][27] and db [1] are ACCUMULATED.
+// du = lrelu'(u) * ([du] + conv3_c1 data gradient of dq + the pooled-feature term of vxb_ss3d_max_bwd_f32 on u), and
+// dbias[64] += column sums of the finished du -- one pass over u / du instead of three (c1_conv.hip).  S % 4 == 0, C = 64.
+extern "C" size_t vxb_conv3_c1_dgrad_ss3d_ws_floats(int B, int S) {
+    return (size_t)vxb_c1_dgrad_ss_blocks_per_sample(S) * (size_t)B * 64;
+}
+extern "C" int vxb_conv3_c1_dgrad_ss3d_f32(const float* dq, const float* w, const float* u, float* du, int B, int S, int C,
+                                           int accumulate, float slope, const float* lin, const float* stats, const float* out_ss,
+                                           const int32_t* argmax, const float* g_ss, const float* g_max, float* dbias,
+                                           float* part_ws, vxb_stream_t stream) {
+    if (!dq || !w || !u || !du || !lin || !stats || !out_ss || !argmax || !g_ss || !g_max || !dbias || !part_ws || B < 1 || S < 4)
+        return VXB_EARG;
+    if (C != 64 || (S & 3) || ((((uintptr_t)u) | ((uintptr_t)du)) & 15)) return VXB_ESIZE;
+    return vxb_c1_dgrad4_ss_launch(dq, w, u, du, B, S, accumulate, slope, lin, stats, out_ss, argmax, g_ss, g_max, dbias, part_ws,
+                                   (hipStream_t)stream);
+}
 extern "C" int vxb_conv3_c1_wgrad_f32(const float* u, const float* dq, float* dw, float* db, float* part_ws, int B, int S, int C,
                                       vxb_stream_t stream) {
     if (!u || !dq || !dw || !db || !part_ws || B < 1 || S < 1) return VXB_EARG;

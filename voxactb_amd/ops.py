@@ -664,6 +664,18 @@ def conv3_c1_dgrad(dq, w, u, du, B, S, accumulate=True, mask=True):
     return du
 
 
+def c1_dgrad_ss3d_ok(S, C):
+    return C == 64 and S % 4 == 0
+
+
+def conv3_c1_dgrad_ss3d(dq, w, u, du, B, S, stats, out_ss, argmax, g_ss, g_max, dbias, accumulate=False):
+    """du = lrelu'(u) * ([du] + c1 data gradient + the ss3d_max_bwd term of u); dbias += column sums of du."""
+    ws = torch.empty(int(_lib.lib().vxb_conv3_c1_dgrad_ss3d_ws_floats(B, S)), dtype=torch.float32, device=u.device)
+    call('vxb_conv3_c1_dgrad_ss3d_f32', dq, w, u, du, B, S, 64, int(accumulate), LRELU_SLOPE, lin_table(S, u.device), stats, out_ss,
+         argmax, g_ss, g_max, dbias, ws)
+    return du
+
+
 def conv3_c1_wgrad(u, dq, dw, db, B, S):
     if C1_MFMA and _mm() and u.shape[-1] == 64:
         nb = int(_lib.lib().vxb_conv3_c1_wgrad_mfma_blocks(B, S))
