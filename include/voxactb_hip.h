@@ -260,7 +260,8 @@ size_t vxb_conv3_c1_wgrad_mfma_blocks(int B, int S);
 /* The same two layers fused with the statistics / backward of the pooled features of THEIR OUTPUT (perceiver_lang_io.py:357
  * + :360, network_utils.py:773-809): the forward stores y and folds it into the SpatialSoftmax3D / max partials while it is in
  * registers (bit-identical to vxb_pointwise_fwd_f32 + vxb_ss3d_max_fwd_f32, one pass less over 256 B per voxel); the
- * weight gradient adds the term vxb_ss3d_max_bwd_f32 would have written into dy on the fly.  x [B,S,S,S,Cin], y / dy
+ * weight gradient adds the term vxb_ss3d_max_bwd_f32 would have written into dy on the fly, and (fold_src != NULL) the
+ * padding adjoint vxb_fold_pad_f32 would have added to dy from a [B, Sp^3, 64] data gradient.  x [B,S,S,S,Cin], y / dy
  * [B,S,S,S,64]; part_ws as for vxb_ss3d_max_fwd_f32 (C = 64), resp. B * ceil(S^3 / 4096) * (64*Cin + 64) floats. */
 int vxb_pointwise_ss3d_fwd_f32(const float* x, const float* W, const float* bias, float* y, int B, int S, int Cin, int Cout,
                                float slope, const float* lin, float* part_ws, float* out_ss, float* out_max, float* stats,
@@ -268,7 +269,7 @@ int vxb_pointwise_ss3d_fwd_f32(const float* x, const float* W, const float* bias
 int vxb_pointwise_wgrad_ss3d_f32(const float* x, const float* y, const float* dy, float* dW, float* db, float* part_ws, int B,
                                  int S, int Cin, int Cout, float slope, const float* lin, const float* stats,
                                  const float* out_ss, const int32_t* argmax, const float* g_ss, const float* g_max,
-                                 vxb_stream_t stream);
+                                 const float* fold_src, int Sp, int pad, vxb_stream_t stream);
 
 /* Backward of everything that reads u = final(...) (perceiver_lang_io.py:462-470) in one pass over u: du = lrelu'(u) *
  * ([du if accumulate] + data gradient of trans_decoder (Cout = 1 conv, vxb_conv3_c1_dgrad_f32) + the pooled-feature term of

@@ -61,3 +61,24 @@ def test_fused_weight_gradient(B, S):
         e_pair = float((mine - pair).abs().max()) / scale
         print(name, 'vs float64 autograd %.2e, vs the unfused kernels %.2e' % (e_ref, e_pair))
         assert e_ref < 2e-4 and e_pair < 2e-5, (name, e_ref, e_pair)
+
+
+def test_fused_weight_gradient_with_padding_adjoint():
+    """fold_src: the padding adjoint of a padded-domain data gradient gathered on the fly == fold_pad + the fused kernel."""
+    B, S, pad = 2, 12, 2
+    Sp = S + 2 * pad + 1                     # (the strided patchify gradient's buffer is wider than the valid extent)
+    x = (rnd(B, S, S, S, 10, seed=3) * 0.5).to(DEV)
+    W, b = (rnd(64, 10, seed=1) * 0.1).to(DEV), (rnd(64, seed=2) * 0.05).to(DEV)
+    dy = (rnd(B, S, S, S, 64, seed=4) * 0.01).to(DEV)
+    src = (rnd(B, Sp, Sp, Sp, 64, seed=8) * 0.01).to(DEV)
+    g_ss, g_mx = rnd(B, 192, seed=5).to(DEV), rnd(B, 64, seed=6).to(DEV)
+    y, (o_ss, o_mx, stats, arg) = ops.pointwise_ss3d_fwd(x, W, b, B, S)
+    dW, db = torch.zeros(64, 10, device=DEV), torch.zeros(64, device=DEV)
+    ops.pointwise_wgrad_ss3d(x, y, dy, dW, db, B, S, stats, o_ss, arg, g_ss, g_mx, fold_src=src, Sp=Sp, pad=pad)
+    dtot = dy.clone()
+    ops.fold_pad(src, Sp, 64, 0, dtot, B, S, 64, pad, accumulate=True)
+    dW2, db2 = torch.zeros(64, 10, device=DEV), torch.zeros(64, device=DEV)
+    ops.pointwise_wgrad_ss3d(x, y, dtot, dW2, db2, B, S, stats, o_ss, arg, g_ss, g_mx)
+    for mine, ref, name in ((dW, dW2, 'dW'), (db, db2, 'db')):
+        e = float((mine - ref).abs().max()) / float(ref.abs().max())
+        assert e < 2e-5, (name, e)

@@ -784,15 +784,17 @@ class PerceiverEngine:
             wtp, U = ops.strided_dgrad_weights(Wp, s)
             Gp = (V + 2 * pk + s - 1) // s
             dxp = ops.conv3d(dpatch, wtp, s ** 3 * C, B, G, Gp, U, -(U - 1), replicate=False, d2s=(s, C))
-            ops.fold_pad(dxp, Gp * s, C, 0, dd0, B, V, C, pk, accumulate=True)
+            Sp = Gp * s
         else:
             dxp = ops.conv3d(dpatch, ops.conv_weight_dgrad(Wp), C, B, G, V + 2 * pk, k, -(k - 1), replicate=False)
-            ops.fold_pad(dxp, V + 2 * pk, C, 0, dd0, B, V, C, pk, accumulate=True)
+            Sp = V + 2 * pk
+        if not fuse_ss0:          # (fused: the padding adjoint of dxp is gathered inside the input conv's weight-gradient kernel)
+            ops.fold_pad(dxp, Sp, C, 0, dd0, B, V, C, pk, accumulate=True)
         # ---- input conv (its LeakyReLU' is applied inside the weight-gradient kernel)
         if fuse_ss0:
             ss, mx, st, am = c['ss0']
             ops.pointwise_wgrad_ss3d(c['vox'], d0, dd0, self.g('input_preprocess.conv3d.weight').view(C, -1),
-                                     self.g('input_preprocess.conv3d.bias'), B, V, st, ss, am, gs[0], gs[1])
+                                     self.g('input_preprocess.conv3d.bias'), B, V, st, ss, am, gs[0], gs[1], fold_src=dxp, Sp=Sp, pad=pk)
         else:
             ops.pointwise_wgrad(c['vox'], d0, dd0, self.g('input_preprocess.conv3d.weight').view(C, -1),
                                 self.g('input_preprocess.conv3d.bias'))

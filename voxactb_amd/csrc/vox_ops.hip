@@ -545,7 +545,8 @@ __global__ void __launch_bounds__(256) pw_wgrad4_ss_kernel(const float* __restri
                                                            float* __restrict__ partB, int S, int vox_per_block, float slope,
                                                            const float* __restrict__ lin, const float* __restrict__ stats,
                                                            const float* __restrict__ out_ss, const int* __restrict__ argmax,
-                                                           const float* __restrict__ g_ss, const float* __restrict__ g_max, float T) {
+                                                           const float* __restrict__ g_ss, const float* __restrict__ g_max, float T,
+                                                           const float* __restrict__ fold_src, int Sp, int pad) {
     __shared__ float red[4][64 * (CIN + 1)];
     __shared__ float sx[2][256 * CIN];
     const DivT divT(T);
@@ -553,6 +554,7 @@ __global__ void __launch_bounds__(256) pw_wgrad4_ss_kernel(const float* __restri
     const int c4 = (threadIdx.x & 15) * 4, gl = threadIdx.x >> 4, wid = threadIdx.x >> 6;
     const long long S3 = (long long)S * S * S;
     x += (long long)b * S3 * CIN; y += (long long)b * S3 * 64 + c4; dy += (long long)b * S3 * 64 + c4;
+    if (fold_src) fold_src += (long long)b * Sp * Sp * Sp * 64 + c4;
     float m[4], inv_s[4], ex[4], ey[4], ez[4], gx[4], gy[4], gz[4], gm[4];
     int am[4];
 #pragma unroll
@@ -594,28 +596,60 @@ __global__ void __launch_bounds__(256) pw_wgrad4_ss_kernel(const float* __restri
             }
         }
         const float* sxr = sx[cur];
-#pragma unroll 1
-        for (int lv = gl; lv < 256; lv += 32) {
-            float4 yy[2], dd[2];
-#pragma unroll
-            for (int uu = 0; uu < 2; ++uu) {
-                const long long v = t0 + lv + 16 * uu;
-                const bool ok = v < v1;
-                yy[uu] = ok ? *reinterpret_cast<const float4*>(y + v * 64) : make_float4(1.f, 1.f, 1.f, 1.f);
-                dd[uu] = ok ? *reinterpret_cast<const float4*>(dy + v * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+        // 16 voxels per thread and tile (lv = gl, gl + 16, ...), one per iteration; the y / dy / fold_src loads of the voxel two
+        // iterations ahead are in flight while one is consumed; (i, j, k) advance by 16 voxels without divisions
+        int li_ = 0, lj_ = 0, lk_ = 0, ci_ = 0, cj_ = 0, ck_ = 0;
+        {
+            const int p = (int)min(t0 + gl, S3 - 1);
+            const int row = p / S;
+            lk_ = ck_ = p - row * S; li_ = ci_ = row / S; lj_ = cj_ = row - li_ * S;
+        }
+        float4 qy[2], qd[2], qf[2];
+        auto issue = [&](int slot, int lv) {
+            const long long v = t0 + lv;
+            const bool ok = v < v1;
+            qy[slot] = ok ? *reinterpret_cast<const float4*>(y + v * 64) : make_float4(1.f, 1.f, 1.f, 1.f);
+            qd[slot] = ok ? *reinterpret_cast<const float4*>(dy + v * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (fold_src && ok) {
+                // one more gradient path into y, gathered in place: the adjoint of the replicate padding of a data gradient
+                // that was computed on the padded domain (fold_kernel's sum; one source voxel except on the faces)
+                const int i = li_, j = lj_, k = lk_;
+                if (i > 0 && i < S - 1 && j > 0 && j < S - 1 && k > 0 && k < S - 1) {
+                    a = *reinterpret_cast<const float4*>(fold_src + (((long long)(i + pad) * Sp + (j + pad)) * Sp + (k + pad)) * 64);
+                } else {
+                    const int d0 = i == 0 ? 0 : i + pad, d1 = i == S - 1 ? S - 1 + 2 * pad : i + pad;
+                    const int h0 = j == 0 ? 0 : j + pad, h1 = j == S - 1 ? S - 1 + 2 * pad : j + pad;
+                    const int x0 = k == 0 ? 0 : k + pad, x1 = k == S - 1 ? S - 1 + 2 * pad : k + pad;
+                    for (int dz = d0; dz <= d1; ++dz)
+                        for (int hh = h0; hh <= h1; ++hh)
+                            for (int xx = x0; xx <= x1; ++xx) {
+                                const float4 sv = *reinterpret_cast<const float4*>(fold_src + (((long long)dz * Sp + hh) * Sp + xx) * 64);
+                                a.x += sv.x; a.y += sv.y; a.z += sv.z; a.w += sv.w;
+                            }
+                }
             }
+            qf[slot] = a;
+            lk_ += 16;
+            while (lk_ >= S) { lk_ -= S; if (++lj_ >= S) { lj_ = 0; ++li_; } }
+        };
+        issue(0, gl);
+        issue(1, gl + 16);
+#pragma unroll 1
+        for (int it = 0; it < 16; it += 2) {
 #pragma unroll
-            for (int uu = 0; uu < 2; ++uu) {
-                const long long v = t0 + lv + 16 * uu;
-                if (v < v1) {
-                    const int p = (int)v;
-                    const int row = p / S, k = p - row * S, i = row / S, j = row - i * S;
-                    const float li = lin[i], lj = lin[j], lk = lin[k];
-                    const float ys[4] = {yy[uu].x, yy[uu].y, yy[uu].z, yy[uu].w};
-                    const float ds[4] = {dd[uu].x, dd[uu].y, dd[uu].z, dd[uu].w};
+            for (int slot = 0; slot < 2; ++slot) {
+                const int lv = gl + 16 * (it + slot);
+                const float4 yy = qy[slot], d4 = qd[slot], f4 = qf[slot];
+                if (it + slot + 2 < 16) issue(slot, lv + 32);
+                if (t0 + lv < v1) {
+                    const int p = (int)(t0 + lv);
+                    const float li = lin[ci_], lj = lin[cj_], lk = lin[ck_];
+                    const float ys[4] = {yy.x, yy.y, yy.z, yy.w};
+                    const float ds[4] = {d4.x + f4.x, d4.y + f4.y, d4.z + f4.z, d4.w + f4.w};
                     float xr[CIN];
 #pragma unroll
-                    for (int ci = 0; ci < CIN; ++ci) xr[ci] = sxr[(lv + 16 * uu) * CIN + ci];
+                    for (int ci = 0; ci < CIN; ++ci) xr[ci] = sxr[lv * CIN + ci];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float l = divT(ys[e]);
@@ -629,6 +663,8 @@ __global__ void __launch_bounds__(256) pw_wgrad4_ss_kernel(const float* __restri
                         for (int ci = 0; ci < CIN; ++ci) acc[e][ci] = fmaf(d, xr[ci], acc[e][ci]);
                     }
                 }
+                ck_ += 16;
+                while (ck_ >= S) { ck_ -= S; if (++cj_ >= S) { cj_ = 0; ++ci_; } }
             }
         }
         if (tn < v1) {
@@ -1241,20 +1277,22 @@ extern "C" int vxb_pointwise_ss3d_fwd_f32(const float* x, const float* W, const 
 }
 // part_ws: B * ceil(S^3 / 4096) * (64*Cin + 64) floats.  dW [64][Cin] and db [64] are ACCUMULATED.  Cin = 10 (the network's
 // voxel features: 3 + 3 + 3 + 1) -- other widths return VXB_ESIZE and the caller uses the two separate kernels.
+// fold_src (or null): [B, Sp^3, 64], a data gradient on the replicate-padded domain (S + 2 pad valid per axis) whose padding
+// adjoint (vxb_fold_pad_f32) is gathered and added to dy on the fly as well.
 extern "C" int vxb_pointwise_wgrad_ss3d_f32(const float* x, const float* y, const float* dy, float* dW, float* db, float* part_ws, int B,
                                             int S, int Cin, int Cout, float slope, const float* lin, const float* stats,
                                             const float* out_ss, const int32_t* argmax, const float* g_ss, const float* g_max,
-                                            vxb_stream_t stream) {
+                                            const float* fold_src, int Sp, int pad, vxb_stream_t stream) {
     if (!x || !y || !dy || !dW || !db || !part_ws || !lin || !stats || !out_ss || !argmax || !g_ss || !g_max || B < 1 || S < 1 ||
-        Cin < 1 || Cin > 16) return VXB_EARG;
-    if (Cout != 64 || Cin != 10 || ((((uintptr_t)y) | ((uintptr_t)dy)) & 15)) return VXB_ESIZE;
+        Cin < 1 || Cin > 16 || (fold_src && (pad < 0 || Sp < S + 2 * pad))) return VXB_EARG;
+    if (Cout != 64 || Cin != 10 || ((((uintptr_t)y) | ((uintptr_t)dy) | ((uintptr_t)fold_src)) & 15)) return VXB_ESIZE;
     const int vpb = 4096;
     const int nbs = vxb_cdiv((long long)S * S * S, vpb);
     const int nb = nbs * B;
     float* pW = part_ws;
     float* pB = part_ws + (size_t)nb * 64 * Cin;
     hipLaunchKernelGGL(pw_wgrad4_ss_kernel<10>, dim3(nbs, B), dim3(256), 0, (hipStream_t)stream, x, y, dy, pW, pB, S, vpb, slope, lin,
-                       stats, out_ss, argmax, g_ss, g_max, 0.01f);
+                       stats, out_ss, argmax, g_ss, g_max, 0.01f, fold_src, Sp, pad);
     VXB_CHECK_LAUNCH();
     int rc = vxb_sum_splits_f32(pW, nb, 64 * Cin, dW, 1, 1.0f, stream);
     if (rc) return rc;

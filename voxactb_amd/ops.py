@@ -630,13 +630,14 @@ def pointwise_ss3d_fwd(x, W, bias, B, S):
     return y, (out_ss, out_max, stats, argmax)
 
 
-def pointwise_wgrad_ss3d(x, y, dy, dW, db, B, S, stats, out_ss, argmax, g_ss, g_max):
-    """pointwise_wgrad with the ss3d_max_bwd term of y's pooled features added to dy on the fly (dy itself is not modified)."""
+def pointwise_wgrad_ss3d(x, y, dy, dW, db, B, S, stats, out_ss, argmax, g_ss, g_max, fold_src=None, Sp=0, pad=0):
+    """pointwise_wgrad with the ss3d_max_bwd term of y's pooled features added to dy on the fly (dy itself is not modified);
+    fold_src [B, Sp^3, 64]: fold_pad(fold_src, Sp, ..., pad) is added to dy on the fly as well."""
     Cin = x.shape[-1]
     nb = B * ((S ** 3 + 4095) // 4096)
     ws = torch.empty(nb * (64 * Cin + 64), dtype=torch.float32, device=x.device)
     call('vxb_pointwise_wgrad_ss3d_f32', x, y, dy, dW, db, ws, B, S, Cin, y.shape[-1], LRELU_SLOPE, lin_table(S, x.device), stats,
-         out_ss, argmax, g_ss, g_max)
+         out_ss, argmax, g_ss, g_max, fold_src, Sp, pad)
 
 
 def ss3d_max_bwd(x, bs, B, S, C, stats, out_ss, argmax, g_ss, g_max, dx, dbs, accumulate=False):
