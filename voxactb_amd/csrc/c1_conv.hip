@@ -371,6 +371,18 @@ __global__ void __launch_bounds__(256) c1_reduce_kernel(const float* __restrict_
     if (rl == 0 && c < n) dst[c] += (red[cl] + red[64 + cl]) + (red[128 + cl] + red[192 + cl]);
 }
 
+// out[blockIdx.x][64] = sum of rows [blockIdx.x * per, +per) of part [nb][64] (zeros for an empty range)
+__global__ void __launch_bounds__(256) c1_rows_kernel(const float* __restrict__ part, int nb, int per, float* __restrict__ out) {
+    __shared__ float red[256];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * per, r1 = min(nb, r0 + per);
+    float s0 = 0.f;
+    for (int r = r0 + rl; r < r1; r += 4) s0 += part[(long long)r * 64 + cl];
+    red[threadIdx.x] = s0;
+    __syncthreads();
+    if (rl == 0) out[blockIdx.x * 64 + cl] = (red[cl] + red[64 + cl]) + (red[128 + cl] + red[192 + cl]);
+}
+
 }  // namespace
 
 int vxb_c1_fwd4_launch(const float* u, const float* w, const float* bias, float* q, int B, int S, hipStream_t st) {
@@ -389,7 +401,7 @@ int vxb_c1_dgrad4_launch(const float* dq, const float* w, const float* u, float*
     return hipGetLastError() == hipSuccess ? VXB_OK : VXB_ELAUNCH;
 }
 
-// fused data gradient (see c1_dgrad4_ss_kernel); part_ws: vxb_c1_dgrad_ss_blocks(B, S) * 64 floats; dbias [64] ACCUMULATED
+// fused data gradient (see c1_dgrad4_ss_kernel); part_ws: (vxb_c1_dgrad_ss_blocks_per_sample(S) * B + 64) * 64 floats; dbias [64] ACCUMULATED
 int vxb_c1_dgrad_ss_blocks_per_sample(int S) {
     const long long g = (long long)S * S * (S >> 2);
     return (int)((g + 15) / 16 > 1024 ? 1024 : (g + 15) / 16);
@@ -400,7 +412,11 @@ int vxb_c1_dgrad4_ss_launch(const float* dq, const float* w, const float* u, flo
     const int nbx = vxb_c1_dgrad_ss_blocks_per_sample(S);
     hipLaunchKernelGGL(c1_dgrad4_ss_kernel, dim3(nbx, B), dim3(256), 0, st, dq, w, u, du, S, accumulate, slope, lin, stats, out_ss,
                        argmax, g_ss, g_max, part_ws);
-    hipLaunchKernelGGL(c1_reduce_kernel, dim3(1), dim3(256), 0, st, part_ws, nbx * B, 64, dbias);
+    // two stages (fixed order): 64 workgroups fold nb / 64 partial rows each into the head of a second buffer, one more folds those
+    const int nb = nbx * B, per = (nb + 63) / 64;
+    float* part2 = part_ws + (size_t)nb * 64;
+    hipLaunchKernelGGL(c1_rows_kernel, dim3(64), dim3(256), 0, st, part_ws, nb, per, part2);
+    hipLaunchKernelGGL(c1_reduce_kernel, dim3(1), dim3(256), 0, st, part2, 64, 64, dbias);
     return hipGetLastError() == hipSuccess ? VXB_OK : VXB_ELAUNCH;
 }
 

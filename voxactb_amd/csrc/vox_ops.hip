@@ -1325,7 +1325,7 @@ extern "C" int vxb_conv3_c1_dgrad_f32(const float* dq, const float* w, const flo
 // du = lrelu'(u) * ([du] + conv3_c1 data gradient of dq + the pooled-feature term of vxb_ss3d_max_bwd_f32 on u), and
 // dbias[64] += column sums of the finished du -- one pass over u / du instead of three (c1_conv.hip).  S % 4 == 0, C = 64.
 extern "C" size_t vxb_conv3_c1_dgrad_ss3d_ws_floats(int B, int S) {
-    return (size_t)vxb_c1_dgrad_ss_blocks_per_sample(S) * (size_t)B * 64;
+    return ((size_t)vxb_c1_dgrad_ss_blocks_per_sample(S) * (size_t)B + 64) * 64;
 }
 extern "C" int vxb_conv3_c1_dgrad_ss3d_f32(const float* dq, const float* w, const float* u, float* du, int B, int S, int C,
                                            int accumulate, float slope, const float* lin, const float* stats, const float* out_ss,

@@ -193,15 +193,38 @@ __global__ void __launch_bounds__(256) vt_route_kernel(Src src, Geom g, const fl
     }
 }
 
-// one compact record per occupied cell: means of the 3 + F channels, address of the cell inside the sample
+// one compact record per occupied cell: means of the 3 + F channels, address of the cell inside the sample; with `out` the
+// cell's 3 + F + 4 floats of the dense grid are written here as well (voxel_grid.py:184-198 for an occupied cell) and no
+// patch pass follows -- the grid already holds the empty pattern everywhere else (fill / unpatch ran before)
 template <int F>
-__device__ __forceinline__ void emit_cell(float4* __restrict__ res, size_t slot, const float (&acc)[7], int cnt, int gc) {
+__device__ __forceinline__ void emit_cell(float4* __restrict__ res, size_t slot, const float (&acc)[7], int cnt, int gc,
+                                          float* __restrict__ out_b, int V) {
+    constexpr int C = 3 + F + 4;
     const float Lf = (float)cnt;                                    // clamp_(1) is a no-op for occupied cells (:121)
     float mean[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 3 + F; ++c) mean[c] = __fdiv_rn(acc[c], Lf);
     res[slot * 2] = make_float4(mean[0], mean[1], mean[2], mean[3]);
     res[slot * 2 + 1] = make_float4(mean[4], mean[5], mean[6], __int_as_float(gc));
+    if (out_b) {
+        const float Vf = (float)V;                                  // self._voxel_d (:197)
+        const int x = gc / (V * V), y = (gc / V) % V, z = gc % V;
+        float v[C];
+#pragma unroll
+        for (int c = 0; c < 3 + F; ++c) v[c] = mean[c];
+        v[3 + F + 0] = __fdiv_rn((float)x, Vf);
+        v[3 + F + 1] = __fdiv_rn((float)y, Vf);
+        v[3 + F + 2] = __fdiv_rn((float)z, Vf);
+        v[3 + F + 3] = 1.0f;                                        // (count/count > 0).float()  (:192)
+        float* o = out_b + (size_t)gc * C;
+        if ((C & 1) == 0 && ((reinterpret_cast<uintptr_t>(out_b) & 7) == 0)) {
+#pragma unroll
+            for (int c = 0; c < C; c += 2) *reinterpret_cast<float2*>(o + c) = make_float2(v[c], v[c + 1]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) o[c] = v[c];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------ light
@@ -240,7 +263,7 @@ __global__ void __launch_bounds__(256) vt_classify_kernel(Geom g, TileWs w) {
 }
 
 template <int F>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) vt_light_kernel(Geom g, TileWs w) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) vt_light_kernel(Geom g, TileWs w, float* __restrict__ out) {
     __shared__ unsigned short s_cnt[CELLS];                 // points per cell, then first slot of the cell
     __shared__ int s_segs[64], s_segp[65];                  // per chunk: start of the tile's segment, exclusive prefix of lengths
     __shared__ float4 s_rec[LIGHT * 2];                     // the tile's records in (cell, id) order
@@ -362,7 +385,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
             }
             const int cellid = 16 * lane + i;
             const int X = tx * TX + (cellid >> 7), Y = ty * TY + ((cellid >> 4) & 7), Z = tz * TZ + (cellid & 15);
-            emit_cell<F>(res, (size_t)slot, acc, cnt, (X * g.V + Y) * g.V + Z);
+            emit_cell<F>(res, (size_t)slot, acc, cnt, (X * g.V + Y) * g.V + Z,
+                         out ? out + (size_t)b * g.V * g.V * g.V * (3 + F + 4) : nullptr, g.V);
             ++slot;
         }
     }
@@ -386,7 +410,7 @@ constexpr int HB = 4;                                   // 64-record batches a w
 // instead of 53 for the kernel -- the reduction is not what it waits for)
 
 template <int F>
-__global__ void __launch_bounds__(256) vt_heavy_kernel(Geom g, TileWs w, int all_tiles) {
+__global__ void __launch_bounds__(256) vt_heavy_kernel(Geom g, TileWs w, int all_tiles, float* __restrict__ out) {
     __shared__ unsigned s_hist[4 * CELLS];              // per wave: count, then write cursor, of every cell
     __shared__ unsigned s_cell[CELLS + 1];              // occupied cells before this one << 20 | first slot of the cell
     __shared__ int s_segs[MAX_NC];                      // start of the tile's segment inside chunk c
@@ -542,7 +566,8 @@ __global__ void __launch_bounds__(256) vt_heavy_kernel(Geom g, TileWs w, int all
                     for (int c = 0; c < 3 + F; ++c) acc[c] = __fadd_rn(acc[c], r[c]);
                 }
                 const int X = tx * TX + (cellid >> 7), Y = ty * TY + ((cellid >> 4) & 7), Z = tz * TZ + (cellid & 15);
-                emit_cell<F>(res, (size_t)(rbase + (int)(info >> 20)), acc, cnt, (X * g.V + Y) * g.V + Z);
+                emit_cell<F>(res, (size_t)(rbase + (int)(info >> 20)), acc, cnt, (X * g.V + Y) * g.V + Z,
+                             out ? out + (size_t)b * g.V * g.V * g.V * (3 + F + 4) : nullptr, g.V);
             }
         }
         __syncthreads();
@@ -558,6 +583,8 @@ template <int F>
 __global__ void __launch_bounds__(256) vt_unpatch_kernel(Geom g, TileWs w, float* __restrict__ out) {
     constexpr int C = 3 + F + 4;
     const int b = blockIdx.y, V = g.V;
+    if (blockIdx.x == 0 && b == 0)                       // this call's counters (the other set than ctr_prev): no memset node
+        for (int i = threadIdx.x; i < 64 + 32 * g.B; i += 256) w.ctr[i] = 0;
     const int nocc = w.ctr_prev[64 + 32 * b];
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= nocc) return;
@@ -643,8 +670,8 @@ Layout vt_layout(long long B, long long N, int V) {
 template <int F>
 int vt_launch(const Src& src, const Geom& g, const float* bounds, float* out, const TileWs& w, hipStream_t st, hipStream_t side,
               hipEvent_t ev_fork, hipEvent_t ev_mid, hipEvent_t ev_join, int order, int C) {
-    // order 2: fresh buffer.   route, classify, heavy, light, fill, patch          -- all in order on `st`: no side stream, no
-    // order 4: incremental.    unpatch, route, classify, heavy, light, patch         events, capturable in a hipGraph
+    // order 2: fresh buffer.   fill, route, classify, heavy, light           -- all in order on `st`: no side stream, no
+    // order 4: incremental.    unpatch (+ counter reset), route, classify, heavy, light     events, capturable in a hipGraph
     // orders 0 / 3 (A/B measurements): the fill on the side stream, from the start / after the classify kernel.
     // Every attempt to run two of these kernels side by side (fill || chain, light || heavy, unpatch || route) ended LATER
     // than running them back to back on MI355X: they are all bound by memory latency, and sharing the memory system
@@ -652,9 +679,14 @@ int vt_launch(const Src& src, const Geom& g, const float* bounds, float* out, co
     const long long cap = (long long)g.N < (long long)g.V * g.V * g.V ? g.N : (long long)g.V * g.V * g.V;   // occupied cells per sample
     const bool forked = order == 0 || order == 3;       // only the A/B orders use the side stream
     if (forked && (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess)) return VXB_ELAUNCH;
+    // orders 2 and 4 (the shipped ones): the reduce kernels write the occupied cells straight into the grid, so the dense part
+    // (fill, or the reset of the previously occupied cells) runs FIRST and there is no patch kernel
+    const bool direct = order == 2 || order == 4;
+    float* dout = direct ? out : nullptr;
     if (order == 4) hipLaunchKernelGGL(vt_unpatch_kernel<F>, dim3((unsigned)((cap + 255) / 256), g.B), dim3(256), 0, st, g, w, out);
     if (order == 0) vox_launch_fill(out, g.B, g.V, C, side);
-    if (hipMemsetAsync(w.ctr, 0, CTR_INTS(g.B) * sizeof(int), st) != hipSuccess) return VXB_ELAUNCH;
+    if (order == 2) vox_launch_fill(out, g.B, g.V, C, st);
+    if (order != 4 && hipMemsetAsync(w.ctr, 0, CTR_INTS(g.B) * sizeof(int), st) != hipSuccess) return VXB_ELAUNCH;
     const size_t lds = (size_t)4 * w.NT * sizeof(unsigned short);
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute((const void*)vt_route_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -668,15 +700,14 @@ int vt_launch(const Src& src, const Geom& g, const float* bounds, float* out, co
         // (light and heavy tiles on two streams were measured: the heavy kernel stretches from 53 to 75 us next to the
         // light one and the pair ends later than back to back)
         if (order == 3) vox_launch_fill(out, g.B, g.V, C, side);
-        hipLaunchKernelGGL(vt_heavy_kernel<F>, dim3(512), dim3(256), heavy_lds, st, g, w, 0);
-        hipLaunchKernelGGL(vt_light_kernel<F>, dim3((unsigned)(tiles < 4096 ? tiles : 4096)), dim3(64), 0, st, g, w);
+        hipLaunchKernelGGL(vt_heavy_kernel<F>, dim3(512), dim3(256), heavy_lds, st, g, w, 0, dout);
+        hipLaunchKernelGGL(vt_light_kernel<F>, dim3((unsigned)(tiles < 4096 ? tiles : 4096)), dim3(64), 0, st, g, w, dout);
     } else {                                                    // more than 64 chunks per sample: every tile by the workgroup kernel
         if (order == 3) vox_launch_fill(out, g.B, g.V, C, side);
-        hipLaunchKernelGGL(vt_heavy_kernel<F>, dim3((unsigned)(tiles < 4096 ? tiles : 4096)), dim3(256), heavy_lds, st, g, w, 1);
+        hipLaunchKernelGGL(vt_heavy_kernel<F>, dim3((unsigned)(tiles < 4096 ? tiles : 4096)), dim3(256), heavy_lds, st, g, w, 1, dout);
     }
-    if (order == 2) vox_launch_fill(out, g.B, g.V, C, st);
     if (forked && (hipEventRecord(ev_join, side) != hipSuccess || hipStreamWaitEvent(st, ev_join, 0) != hipSuccess)) return VXB_ELAUNCH;
-    hipLaunchKernelGGL(vt_patch_kernel<F>, dim3((unsigned)((cap + 255) / 256), g.B), dim3(256), 0, st, g, w, out);
+    if (!direct) hipLaunchKernelGGL(vt_patch_kernel<F>, dim3((unsigned)((cap + 255) / 256), g.B), dim3(256), 0, st, g, w, out);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
