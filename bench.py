@@ -293,18 +293,18 @@ def main():
 # runs, KiB units; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950, WRITE_SIZE exact)
 PMC_TRAFFIC_C2 = {
     'conv3d_wgrad[k3 s1 128->64 S100]': (
-        2 * 9340496.6 * 1024.0, 'wgrad_halo_kernel<1,4,4> (mean over the final conv\'s and the up-conv\'s weight gradients, same kernel): '
-                                'FETCH_SIZE 9.56 GB raw per launch (x2 = 19.1 GB; 33.8 GB before the round-2 rework) for 12.3 GB compulsory on '
-                                'the final conv (x 4.1 GB + the second source 4.1 GB + dY 4.1 GB), output 0.2 GB; profiles/r02_v3_pmc_*'),
+        2 * 10765698.2 * 1024.0, 'wgrad_halo_kernel<1,4,4,2> (weight gradient of the final conv): FETCH_SIZE 11.0 GB raw per launch (x2 = 22.0 GB; '
+                                 '33.8 GB before the round-2 rework) for 12.3 GB compulsory (x 4.1 GB + the second source 4.1 GB + dY 4.1 GB), '
+                                 'output 0.2 GB; profiles/r02_v4_pmc_*'),
     'conv3d_bf16[k3 s1 128->64 S100': (
-        (2 * 9030619.0 + 6000000.0) * 1024.0,
-        'conv3_halo_kernel<2,1,4,1,0,2> (final conv forward / data gradient + padding adjoint), mean per launch: FETCH_SIZE 9.25 GB '
-        'raw (x2 = 18.5 GB) + WRITE_SIZE 6.14 GB; 24.6 GB / 19.8 ms = 1.2 TB/s: matrix-core-bound, not HBM-bound; profiles/r02_v3_pmc_*'),
+        (2 * 7903011.6 + 6000000.0) * 1024.0,
+        'conv3_halo_kernel<2,1,4,1,0,2> (final conv forward / data gradient + padding adjoint), mean per launch: FETCH_SIZE 8.09 GB '
+        'raw (x2 = 16.2 GB) + WRITE_SIZE 6.14 GB; 22.3 GB / 19.9 ms = 1.1 TB/s: matrix-core-bound, not HBM-bound; profiles/r02_v4_pmc_*'),
     'conv3d_bf16[k3 s1 64->128 S102': (
-        (2 * 9030619.0 + 6000000.0) * 1024.0,
+        (2 * 7903011.6 + 6000000.0) * 1024.0,
         'conv3_halo_kernel<2,1,4,1,0,2> (the same kernel: mean over the final conv\'s forward and its data gradient + padding adjoint): '
-        'FETCH_SIZE 9.25 GB raw (x2 = 18.5 GB) + WRITE_SIZE 6.14 GB per launch; 24.6 GB / 20.4 ms = 1.2 TB/s: matrix-core-bound, not '
-        'HBM-bound; profiles/r02_v3_pmc_*'),
+        'FETCH_SIZE 8.09 GB raw (x2 = 16.2 GB) + WRITE_SIZE 6.14 GB per launch; 22.3 GB / 19.9 ms = 1.1 TB/s: matrix-core-bound, not '
+        'HBM-bound; profiles/r02_v4_pmc_*'),
 }
 
 MODE_DTYPE = {

@@ -104,3 +104,43 @@ def test_two_rank_update_matches_one_process_on_the_concatenated_batch(tmp_path,
     assert abs(loss - 0.5 * (r0['losses'][0] + r1['losses'][0])) < 1e-5          # mean over the global batch
     dw = (qa._arena.flat_w.cpu() - r0['w_step0']).abs().max()
     assert float(dw) < 5e-6, float(dw)
+
+
+def _rccl_worker(port, out_dir, force):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['VOXACTB_FORCE_COLLECTIVES'] = '1' if force else '0'
+    torch.cuda.set_device(0)
+    if force:
+        dist.init_process_group('nccl', rank=0, world_size=1)          # backend "nccl" IS RCCL on ROCm
+    agent, qa = _make_agent(B, seed=7)
+    calls = []
+    orig = qa._arena.reduce_bucket
+    qa._arena.reduce_bucket = lambda name: (calls.append((name, len(qa._arena._pending))), orig(name))[1]
+    losses = []
+    for step in range(3):
+        rs = {k: v.to('cuda:0') for k, v in _shard(step % 2).items()}
+        losses.append(float(agent.update(step, rs)['total_losses']))
+    torch.cuda.synchronize()
+    torch.save(dict(w=qa._arena.flat_w.cpu(), losses=losses, calls=[c[0] for c in calls], buckets=list(qa._arena._buckets)),
+               os.path.join(out_dir, 'rccl%d.pt' % int(force)))
+    if force:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_bucketed_exchange_on_the_real_rccl_backend(tmp_path):
+    """The exchange the 8-GPU run makes -- rank-0 broadcast at build(), one asynchronous in-place all-reduce per gradient bucket
+    started from inside the backward pass, the wait before LAMB -- on the RCCL backend itself.  One GPU means world size 1 (the
+    collectives are identities), so three update() steps must leave exactly the weights of a run without any process group."""
+    ctx = mp.get_context('spawn')
+    for force in (True, False):
+        p = ctx.Process(target=_rccl_worker, args=(_free_port(), str(tmp_path), force))
+        p.start()
+        p.join(600)
+        assert p.exitcode == 0, 'worker (collectives %s) failed' % force
+    a, b = (torch.load(os.path.join(str(tmp_path), 'rccl%d.pt' % f)) for f in (1, 0))
+    assert a['calls'] == a['buckets'] * 3 and a['buckets'][0] == 'tail' and a['buckets'][-1] == 'head'
+    assert a['losses'] == b['losses']
+    assert torch.equal(a['w'], b['w'])

@@ -13,9 +13,16 @@ input side).  `bucket(prefixes)` names a contiguous slice by parameter-name pref
 asynchronous all-reduce (RCCL runs it on its own stream behind an event on the compute stream) while the backward
 pass continues; `finish_reduce()` makes the compute stream wait for all of them before the optimizer.
 """
+import os
+
 import torch
 
-ALIGN = 64   # floats: every tensor starts on a 256-byte boundary
+ALIGN = 64
+# debug / test switch: issue the collectives even with a single rank (RCCL refuses two ranks on one GPU, so a 1-GPU box can
+# only exercise the real backend -- communicator creation, the asynchronous bucket all-reduces on RCCL's stream behind the
+# compute stream's event, the wait before the optimizer -- with world size 1; tests/test_distributed_gpu.py)
+FORCE_COLLECTIVES = os.environ.get('VOXACTB_FORCE_COLLECTIVES', '0') == '1'
+   # floats: every tensor starts on a 256-byte boundary
 
 
 class FlatParams:
@@ -64,6 +71,11 @@ class FlatParams:
         return bool(spans) and spans[0][0] == 0 and spans[-1][1] == self.total and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
 
     @staticmethod
+    def _initialised():
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized()
+
+    @staticmethod
     def _world():
         import torch.distributed as dist
         return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -74,7 +86,7 @@ class FlatParams:
         if name in self._done:
             raise RuntimeError('bucket %r reduced twice in one step' % name)
         self._done.add(name)
-        if self._world() > 1:
+        if self._world() > 1 or (FORCE_COLLECTIVES and self._initialised()):
             import torch.distributed as dist
             lo, hi = self._buckets[name]
             self._pending.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
@@ -94,7 +106,7 @@ class FlatParams:
         """Rank `src`'s parameters to every rank -- what DistributedDataParallel does implicitly when it wraps the module
         (agent :50-54): run_seed_fn.py never seeds torch, so without it every replica would start from its own init."""
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES):
             dist.broadcast(self.flat_w, src=src)
 
     def all_reduce_grads(self):
