@@ -382,3 +382,14 @@ def test_conv3d_bf16w_two_sources_and_d2s():
     u_ref = ops.conv3d(cl(bf(z1)).to(DEV), bf(Weff), s ** 3 * 64, B, G, G, kl, -R, d2s=(s, 64))
     u = ops.conv3d_bf16w(cl(z1).to(DEV), ops.to_bf16_nk(Weff), s ** 3 * 64, B, G, G, kl, -R, d2s=(s, 64))
     close(u, u_ref, 3e-5, 'bf16 polyphase d2s')
+
+
+@pytest.mark.parametrize('rows,N,ld', [(300, 64, 64), (1000, 4096, 4096), (777, 1280, 1284), (513, 258, 258), (4100, 512, 512)])
+def test_colsum_variants(rows, N, ld):
+    """bias gradients: column sums of [rows, N] (flat, scalar and float4 partial kernels) against a float64 sum."""
+    buf = rnd(rows, ld, seed=rows)
+    x = buf.to(DEV)[:, :N]
+    out = torch.full((N,), 0.25, device=DEV)
+    ops.colsum(x, out, accumulate=True)
+    ref = buf[:, :N].double().sum(0) + 0.25
+    assert float((out.cpu().double() - ref).abs().max()) < 2e-5 * float(ref.abs().max()) + 1e-5

@@ -198,6 +198,41 @@ __global__ void __launch_bounds__(256) colsum_part_kernel(const float* __restric
     }
 }
 
+// float4 variant for wide matrices (N % 4 == 0, 16-byte aligned rows): 64 column lanes x 4 columns x 4 row lanes -- a wave reads
+// 1 KB of one row per instruction (the scalar kernel above moved 2.3 TB/s on the 32768 x 4096 GEGLU gradient)
+__global__ void __launch_bounds__(256) colsum_part4_kernel(const float* __restrict__ x, long long rows, int N, long long ld,
+                                                           int rows_per_block, float* __restrict__ part) {
+    __shared__ float4 red[256];
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(rows, r0 + rows_per_block);
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < N; c0 += 256) {
+        const int c = c0 + 4 * cl;
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+        if (c < N) {
+            long long r = r0 + rl;
+            for (; r + 4 < r1; r += 8) {
+                const float4 a = *reinterpret_cast<const float4*>(x + r * ld + c);
+                const float4 b = *reinterpret_cast<const float4*>(x + (r + 4) * ld + c);
+                s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+                s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+            }
+            for (; r < r1; r += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(x + r * ld + c);
+                s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            }
+        }
+        red[threadIdx.x] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+        __syncthreads();
+        if (rl == 0 && c < N) {
+            const float4 a = red[cl], b = red[64 + cl], d = red[128 + cl], e = red[192 + cl];
+            *reinterpret_cast<float4*>(part + (long long)blockIdx.x * N + c) =
+                make_float4(a.x + b.x + d.x + e.x, a.y + b.y + d.y + e.y, a.z + b.z + d.z + e.z, a.w + b.w + d.w + e.w);
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------ softmax rows
 // in place: S[row, :cols] -> P; optional second output Pd = P * keep / (1-p)
 __global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ S, float* __restrict__ Pd, int cols,
@@ -554,6 +589,8 @@ extern "C" int vxb_colsum_f32(const float* x, int64_t rows, int N, int64_t ld, f
     const int nb = vxb_cdiv(rows, rpb);
     if (ld == N && N >= 4 && N <= 1024 && 1024 % N == 0 && ((uintptr_t)x & 15) == 0)
         hipLaunchKernelGGL(colsum_flat_kernel, dim3(nb), dim3(256), 0, st, x, (long long)rows, N, (int)rpb, part_ws);
+    else if ((N & 3) == 0 && (ld & 3) == 0 && N >= 256 && ((((uintptr_t)x) | ((uintptr_t)part_ws)) & 15) == 0)
+        hipLaunchKernelGGL(colsum_part4_kernel, dim3(nb), dim3(256), 0, st, x, (long long)rows, N, (long long)ld, (int)rpb, part_ws);
     else
         hipLaunchKernelGGL(colsum_part_kernel, dim3(nb), dim3(256), 0, st, x, (long long)rows, N, (long long)ld, (int)rpb, part_ws);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(vxb_cdiv(N, 64)), dim3(256), 0, st, part_ws, nb, N, (long long)N, out, accumulate);
