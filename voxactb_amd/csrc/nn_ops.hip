@@ -109,6 +109,87 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
+// float4 variant for D = 256 * NV (D = 512: the latent width): a lane owns 4 adjacent columns per 256-column group, and TWO rows
+// of a wave are in flight (the scalar kernel keeps one row per wave between its load, its wave reduction and its store: 3 TB/s).
+// Every column still adds its rows in the same order, so dgamma / dbeta are bit-identical to ln_bwd_kernel.
+template <int NV>
+__global__ void __launch_bounds__(256) ln_bwd4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, float* __restrict__ dx,
+                                                      float* __restrict__ part, long long rows, int rows_per_block, int accumulate) {
+    constexpr int D = 256 * NV;
+    __shared__ float sg[4][D], sb[4][D];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float4 ag[NV], ab[NV], gm[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = ag[i];
+        gm[i] = *reinterpret_cast<const float4*>(gamma + 256 * i + 4 * lane);
+    }
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    for (int rr = wid; rr < rows_per_block; rr += 8) {
+        float4 xv[2][NV], dv[2][NV];
+        float mu[2], rs[2];
+        bool ok[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long row = r0 + rr + 4 * u;
+            ok[u] = rr + 4 * u < rows_per_block && row < rows;
+            mu[u] = ok[u] ? mean[row] : 0.f; rs[u] = ok[u] ? rstd[row] : 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                xv[u][i] = ok[u] ? *reinterpret_cast<const float4*>(x + row * D + 256 * i + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+                dv[u][i] = ok[u] ? *reinterpret_cast<const float4*>(dy + row * D + 256 * i + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!ok[u]) continue;                     // (wave-uniform)
+            const long long row = r0 + rr + 4 * u;
+            float xh[NV][4], dg[NV][4];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const float xs[4] = {xv[u][i].x, xv[u][i].y, xv[u][i].z, xv[u][i].w};
+                const float ds[4] = {dv[u][i].x, dv[u][i].y, dv[u][i].z, dv[u][i].w};
+                const float gs[4] = {gm[i].x, gm[i].y, gm[i].z, gm[i].w};
+                float* agp = reinterpret_cast<float*>(&ag[i]);
+                float* abp = reinterpret_cast<float*>(&ab[i]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[i][e] = (xs[e] - mu[u]) * rs[u];
+                    dg[i][e] = ds[e] * gs[e];
+                    s1 += dg[i][e];
+                    s2 += dg[i][e] * xh[i][e];
+                    agp[e] += ds[e] * xh[i][e];
+                    abp[e] += ds[e];
+                }
+            }
+            s1 = wave_sum(s1) / (float)D;
+            s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                float4 v;
+                v.x = rs[u] * (dg[i][0] - s1 - xh[i][0] * s2); v.y = rs[u] * (dg[i][1] - s1 - xh[i][1] * s2);
+                v.z = rs[u] * (dg[i][2] - s1 - xh[i][2] * s2); v.w = rs[u] * (dg[i][3] - s1 - xh[i][3] * s2);
+                float4* o = reinterpret_cast<float4*>(dx + row * D + 256 * i + 4 * lane);
+                if (accumulate) { const float4 p = *o; v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+                *o = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        *reinterpret_cast<float4*>(&sg[wid][256 * i + 4 * lane]) = ag[i];
+        *reinterpret_cast<float4*>(&sb[wid][256 * i + 4 * lane]) = ab[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        part[((long long)blockIdx.x * 2 + 0) * D + c] = sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c];
+        part[((long long)blockIdx.x * 2 + 1) * D + c] = sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c];
+    }
+}
+
 // dst[i] (+)= alpha * sum_s part[s][i]
 __global__ void __launch_bounds__(256) sum_splits_kernel(const float* __restrict__ part, int nsplit, long long n,
                                                          float* __restrict__ dst, int accumulate, float alpha) {
@@ -557,7 +638,10 @@ extern "C" int vxb_layernorm_bwd_f32(const float* dy, const float* x, const floa
     hipStream_t st = (hipStream_t)stream;
     const int rpb = 64;
     const int grid = vxb_cdiv(rows, rpb);
-    if (D <= 128) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(grid), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, part_ws, rows, D, rpb, accumulate_dx);
+    const bool al16 = ((((uintptr_t)dy) | ((uintptr_t)x) | ((uintptr_t)dx) | ((uintptr_t)gamma)) & 15) == 0;
+    if (D == 512 && al16) hipLaunchKernelGGL(ln_bwd4_kernel<2>, dim3(grid), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, part_ws, rows, rpb, accumulate_dx);
+    else if (D == 256 && al16) hipLaunchKernelGGL(ln_bwd4_kernel<1>, dim3(grid), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, part_ws, rows, rpb, accumulate_dx);
+    else if (D <= 128) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(grid), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, part_ws, rows, D, rpb, accumulate_dx);
     else if (D <= 512) hipLaunchKernelGGL(ln_bwd_kernel<8>, dim3(grid), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, part_ws, rows, D, rpb, accumulate_dx);
     else return VXB_ESIZE;
     // part layout [grid][2][D]: dgamma += column sums of the first half, dbeta += of the second (parallel over columns)
