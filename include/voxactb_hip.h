@@ -164,6 +164,11 @@ int vxb_conv3d_wgrad_bf16x3_f32(const float* src0, const float* src1, int C0, in
  * Cin % 32 == 0, one source).  zeros: >= 16 bytes of device zeros, fetched for zero-padded taps. */
 int vxb_split_bf16_f32(const float* src, int64_t ld, int64_t rows, int cols, void* dst_planes, int nplanes,
                        vxb_stream_t stream);
+/* The same split for MANY matrices in one launch (all linear-layer weights of a training step, each also in transposed form
+ * for the data-gradient GEMM): desc = device table of n x 6 int64 {src fp32 [rows][cols], dst planes, rows, cols,
+ * transposed, first tile}; dst receives [nplanes][rows][cols] or, transposed, [nplanes][cols][rows]; tiles of an entry =
+ * ceil(rows/64) * ceil(cols/64), first tiles ascending, total_tiles = their sum.  Bit-identical to vxb_split_bf16_f32. */
+int vxb_split_bf16_batch_f32(const int64_t* desc, int n, int64_t total_tiles, int nplanes, vxb_stream_t stream);
 int vxb_gemm_dl_f32(const void* A_planes, const void* Bw_planes, const void* Bw_frag, int nplanes, float* C, int64_t ldc, const float* bias,
                     const float* residual, int M, int N, int K, int act, float slope, int accumulate,
                     vxb_stream_t stream);

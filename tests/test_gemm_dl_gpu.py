@@ -127,3 +127,30 @@ def test_gemm256_matches_float64_and_the_128_tile_kernels(M, N, K):
     close(got, ref, 3e-5, 'gemm256 vs 128-tile kernel')
     close(got, F.leaky_relu(x.double() @ W.double().t() + b.double(), 0.02).float() + r, 2e-5, 'gemm256 vs fp64')
     close(acc, (base.cpu().double() + x.double() @ W.double().t()).float(), 2e-5, 'gemm256 accumulate')
+
+
+@pytest.mark.parametrize('precision', ['bf16x3', 'bf16'])
+def test_batched_weight_split_is_bit_identical(precision):
+    """vxb_split_bf16_batch_f32 (all linear weights of a step, plain + transposed, one launch) == the per-weight split."""
+    g = torch.Generator().manual_seed(5)
+    ws = [torch.randn(n, k, generator=g).to(DEV) * 0.05 for n, k in ((512, 512), (1024, 512), (64, 128), (72, 200), (4096, 512))]
+    old = ops.PRECISION
+    ops.PRECISION = precision
+    try:
+        ops.new_step()
+        ref = [(ops.split_bf16(w.contiguous()), ops.split_bf16(w.t().contiguous())) for w in ws]
+        ops.prepare_linear_weights(ws)
+        for w, (r0, r1) in zip(ws, ref):
+            a0, a1 = ops._bf16_weight(w, False), ops._bf16_weight(w, True)
+            assert a0.shape == r0.shape and a1.shape == r1.shape
+            assert torch.equal(a0.view(torch.int16), r0.view(torch.int16))
+            assert torch.equal(a1.view(torch.int16), r1.view(torch.int16))
+        # second step with changed weights: same buffers, new contents
+        for w in ws:
+            w.mul_(1.5)
+        ops.new_step()
+        ops.prepare_linear_weights(ws)
+        assert torch.equal(ops._bf16_weight(ws[3], True).view(torch.int16), ops.split_bf16(ws[3].t().contiguous()).view(torch.int16))
+    finally:
+        ops.PRECISION = old
+        ops.new_step()

@@ -307,6 +307,7 @@ class PerceiverEngine:
             self._Lt_host = Lt
         self._Lt = None
         self._on_bucket = None
+        self._lin_weights = None          # names of the linear-layer weights whose bf16 planes are made in one launch per step
         self.step_seed = 0
         # Precision of the matrix-core kernels (tensors, accumulators, softmax / norm statistics are fp32 in every mode):
         #   'bf16x3' (default): every fp32 operand is used as hi + lo bf16 halves, three bf16 MFMAs per product
@@ -465,6 +466,9 @@ class PerceiverEngine:
         ops.new_step()
         ops.PRECISION = self.precision
         try:
+            if self._lin_weights is None:
+                self._lin_weights = [n for n, prm in self.P.items() if prm.dim() == 2 and n.endswith('.weight') and prm.numel() >= 4096]
+            ops.prepare_linear_weights([self.p(n) for n in self._lin_weights])
             return self._forward(vox, proprio, lang_token_embs, training, save, seed, proprio_left)
         finally:
             ops.PRECISION = 'fp32'

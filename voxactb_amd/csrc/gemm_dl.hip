@@ -378,6 +378,46 @@ __global__ void __launch_bounds__(256) split_bf16_kernel(const float* __restrict
     }
 }
 
+// All linear-layer weights of a step in ONE launch: entry e of the device table desc[e] = {src, dst, rows, cols, transposed,
+// first tile} describes an fp32 [rows][cols] matrix whose planes go to dst as [nplanes][rows][cols] or, transposed, as
+// [nplanes][cols][rows] (the B operand of the data-gradient GEMM) -- the same hi / lo values vxb_split_bf16_f32 produces.
+// The per-weight launches (one split + one ATen transpose copy each, ~120 per step at ~11 us of latency apiece) cost more
+// than moving the 33 M parameters.  A workgroup converts one 64 x 64 tile through LDS.
+struct SplitDesc { const float* src; u16* dst; long long rows, cols, transposed, tile0; };
+
+__global__ void __launch_bounds__(256) split_batch_kernel(const SplitDesc* __restrict__ desc, int n, int nplanes) {
+    __shared__ float tile[64][65];
+    int lo_i = 0, hi_i = n - 1;                                   // last entry whose first tile is <= blockIdx.x
+    while (lo_i < hi_i) {
+        const int mid = (lo_i + hi_i + 1) >> 1;
+        if (desc[mid].tile0 <= (long long)blockIdx.x) lo_i = mid; else hi_i = mid - 1;
+    }
+    const SplitDesc d = desc[lo_i];
+    const int tcols = (int)((d.cols + 63) >> 6);
+    const int t = (int)(blockIdx.x - d.tile0);
+    const int r0 = (t / tcols) * 64, c0 = (t % tcols) * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        tile[r][c] = (r0 + r < d.rows && c0 + c < d.cols) ? d.src[(long long)(r0 + r) * d.cols + c0 + c] : 0.f;
+    }
+    __syncthreads();
+    // output pairs: (orow, ocol..ocol+1); transposed: out[c][r]
+    const long long orows = d.transposed ? d.cols : d.rows, ocols = d.transposed ? d.rows : d.cols;
+    const int or0 = d.transposed ? c0 : r0, oc0 = d.transposed ? r0 : c0;
+    u16* hi = d.dst;
+    u16* lo = nplanes == 2 ? d.dst + d.rows * d.cols : nullptr;
+    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+        const int orr = i >> 5, oc = (i & 31) * 2;
+        if (or0 + orr >= orows || oc0 + oc >= ocols) continue;
+        const float a = d.transposed ? tile[oc][orr] : tile[orr][oc];
+        const float b = d.transposed ? tile[oc + 1][orr] : tile[orr][oc + 1];
+        const unsigned ph = vxb_pack_bf16(a, b);
+        const long long o = (long long)(or0 + orr) * ocols + oc0 + oc;
+        *reinterpret_cast<unsigned*>(hi + o) = ph;
+        if (lo) *reinterpret_cast<unsigned*>(lo + o) = vxb_pack_bf16(a - __uint_as_float(ph << 16), b - __uint_as_float(ph & 0xffff0000u));
+    }
+}
+
 template <int AMODE, int X3, int BD>
 int dl_launch2(const DlArgs& g, hipStream_t st) {
     const dim3 grid(vxb_cdiv(g.N, 128), vxb_cdiv(g.M, 128));
@@ -409,6 +449,17 @@ extern "C" int vxb_split_bf16_f32(const float* src, int64_t ld, int64_t rows, in
     const long long total = rows * (cols >> 2);
     const int grid = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
     hipLaunchKernelGGL(split_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (long long)ld, (long long)rows, cols, hi, lo);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+// desc: device table of n entries x 6 int64 {src pointer, dst pointer, rows, cols, transposed (0/1), first tile}, entries in
+// ascending first-tile order with tiles = ceil(rows/64) * ceil(cols/64); total_tiles = their sum.  rows, cols even.
+extern "C" int vxb_split_bf16_batch_f32(const int64_t* desc, int n, int64_t total_tiles, int nplanes, vxb_stream_t stream) {
+    if (!desc || n < 1 || total_tiles < 1 || total_tiles >= INT32_MAX || (nplanes != 1 && nplanes != 2)) return VXB_EARG;
+    static_assert(sizeof(SplitDesc) == 6 * sizeof(int64_t), "descriptor layout");
+    hipLaunchKernelGGL(split_batch_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const SplitDesc*>(desc), n, nplanes);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }

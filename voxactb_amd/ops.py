@@ -52,6 +52,47 @@ def new_step():
     _FCACHE.clear()
 
 
+_WPREP = {}
+BATCH_WEIGHT_SPLIT = os.environ.get('VOXACTB_BATCH_WSPLIT', '1') != '0'      # '0': per-weight splits (A/B runs)
+
+
+def prepare_linear_weights(weights):
+    """bf16 planes of every linear-layer weight of the step, plain AND transposed (the B operands of the forward / data-gradient
+    GEMMs), made by ONE launch (vxb_split_bf16_batch_f32) instead of a split + a transposing copy per weight and use; fills the
+    cache _bf16_weight() reads.  `weights`: 2-D fp32 tensors (views into the flat parameter arena, so the descriptor table and
+    the output buffer are built once and reused every step)."""
+    if not (BATCH_WEIGHT_SPLIT and _mm()):
+        return
+    ws = [w for w in weights if w.dim() == 2 and w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
+          and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0 and w.data_ptr() % 16 == 0]
+    if not ws:
+        return
+    npl = 2 if PRECISION == 'bf16x3' else 1
+    key = (tuple(w.data_ptr() for w in ws), tuple(tuple(w.shape) for w in ws), npl)
+    ent = _WPREP.get(key)
+    if ent is None:
+        if len(_WPREP) > 8:
+            _WPREP.clear()
+        total = sum(2 * npl * w.numel() for w in ws)
+        buf = torch.empty(total, dtype=torch.bfloat16, device=ws[0].device)
+        rows, views, off, tile0 = [], [], 0, 0
+        for w in ws:
+            N, K = w.shape
+            for tr in (0, 1):
+                rows.append([w.data_ptr(), buf.data_ptr() + 2 * off, N, K, tr, tile0])
+                shape = ((K, N) if tr else (N, K))
+                v = buf[off:off + npl * N * K].view((2,) + shape if npl == 2 else shape)
+                views.append(((w.data_ptr(), (N, K), bool(tr)), v))
+                off += npl * N * K
+                tile0 += ((N + 63) // 64) * ((K + 63) // 64)
+        desc = torch.tensor(rows, dtype=torch.int64).to(ws[0].device)
+        ent = _WPREP[key] = (desc, len(rows), tile0, buf, views, ws)       # (ws keeps the sources alive: keyed by address)
+    desc, n, tiles, buf, views, _ = ent
+    call('vxb_split_bf16_batch_f32', desc, n, tiles, npl)
+    for (ptr, shape, tr), v in views:
+        _WCACHE[(ptr, shape, tr, PRECISION)] = v
+
+
 def split_bf16(w, x3=None):
     """fp32 [N][K] -> bf16 [N][K] ('bf16') or the hi/lo planes [2][N][K] of the 'bf16x3' split (lo = bf16(w - hi))."""
     if x3 is None:
