@@ -279,7 +279,8 @@ def main():
             'device_time_ms_per_step': tot_ms / prof_steps, 'ms_per_step_profile_pass': dt_prof / prof_steps * 1e3,
             'timing_note': 'value / ms_per_step / roofline / voxel_scatter: the K-step timed region, in which only the dominant kernel and '
                            'the voxelizer are bracketed by HIP events; device_time_ms_per_step, rooflines_other and the kernel table: a '
-                           'separate %d-step pass with every launch event-timed (ms_per_step_profile_pass)' % prof_steps,
+                           'separate %d-step pass with every launch event-timed (ms_per_step_profile_pass: ~2 200 event records per step make that pass '
+                           'host-bound, it is not a throughput figure)' % prof_steps,
             'roofline': roofline, 'rooflines_other': extra, 'cpu_baseline': cpu, 'precision_note': MODE_NOTE[headline_mode],
             'parity_vs_reference': probe, 'act_latency': act_lat, 'other_precisions': others,
         }
