@@ -66,6 +66,8 @@ def lib():
             L.vxb_debug_set_wgrad_halo_chunks(int(os.environ['VOXACTB_WGRAD_CHUNKS']))
         if os.environ.get('VOXACTB_HALO_WN'):      # experiment switch: wave layout of the LDS-halo conv (conv_halo_bf16.hip)
             L.vxb_debug_set_halo_wn(int(os.environ['VOXACTB_HALO_WN']))
+        if os.environ.get('VOXACTB_HALO_DBG'):     # experiment bits of conv_halo_bf16.hip (4 = no skipping of depth-edge waves; 1, 2: timing only, WRONG results)
+            L.vxb_debug_set_halo_experiment(int(os.environ['VOXACTB_HALO_DBG']))
         _lib = L
     return _lib
 

@@ -77,6 +77,8 @@ __device__ __forceinline__ unsigned hb_pack2(float lo, float hi) {
     return (a >> 16) | (b & 0xffff0000u);
 }
 
+__device__ __forceinline__ bool g_dbg_all_waves(const HaloArgs& g) { return (g.dbg & 4) != 0; }    // experiment bit 4: no wave skipping
+
 template <int NTG, int X3, int NW, int WD, int TL = 0, int WN = 1>
                                               // NTG = N / 32 column tiles per workgroup; the NW waves form a (NW / WN) x WN grid over
                                               // (8 M tiles) x (NTG column tiles): 4 x 1 -> 2 M tiles x 2 column tiles per wave,
@@ -114,6 +116,11 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
     const int b = t;
     const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
     const int Ct = g.C0 + g.C1;
+    // A wave whose M tiles all lie beyond the last depth slice (the last depth tile of S_out = 22 or 102: two of its four depths
+    // do not exist) has nothing to compute: in the WD kernels (no barrier inside the tap loop) it only helps staging the halo.
+    // 1/6 of the workgroups of the up-conv data gradient (22^3 grid in 24^3 of tiles) and 1/26 of the final conv's run at half
+    // their matrix work this way.
+    const bool wave_on = __builtin_amdgcn_readfirstlane((int)(!WD || g_dbg_all_waves(g) || d0 + (((wid / WN) * (8 / (NW / WN))) >> 1) < g.S_out)) != 0;
 
     f32x16 acc[MTW][NT];
 #pragma unroll
@@ -349,12 +356,14 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
             HB_LOAD_W(rw1, 1)
             // (the barrier that ended the previous chunk's last tap already freed the halo and both weight buffers)
         } else {
-            if (BD == 2) {
-                HD_LOADB(bq0, 0)
-                HD_LOADB(bq1, 1)
-            } else {
+            if (wave_on) {
+                if (BD == 2) {
+                    HD_LOADB(bq0, 0)
+                    HD_LOADB(bq1, 1)
+                } else {
 #pragma unroll
-                for (int t0 = 0; t0 < BD; ++t0) { HD_LOADB(bqr[t0], t0) }
+                    for (int t0 = 0; t0 < BD; ++t0) { HD_LOADB(bqr[t0], t0) }
+                }
             }
             __syncthreads();                        // no per-tap barriers here: every wave must be done with the old halo
         }
@@ -374,6 +383,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
         }
         if (!WD) { HB_STORE_W(rw0, 0) }
         __syncthreads();
+        if (!wave_on) continue;                     // (WD only: the two barriers above are the chunk's only ones)
         if (TL) {
             HB_READ_A_OFF(afa, __builtin_amdgcn_readlane(taplist, 0))
             int n = 0;
