@@ -79,6 +79,7 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
         b_rw = ph % g.d2s_s; b_rh = (ph / g.d2s_s) % g.d2s_s; b_rd = ph / (g.d2s_s * g.d2s_s);
     }
 
+    const bool plain = g.S_in == 1 && g.S_out == 1 && g.kext == 1 && g.off == 0 && g.C1 == 0 && g.d2s_s == 0;     // (kernel arguments: uniform)
     long long nkt = (g.P + BP - 1) / BP;
     long long kt_begin = (long long)blockIdx.z * g.tiles_per_split;
     if (nkt > kt_begin + g.tiles_per_split) nkt = kt_begin + g.tiles_per_split;
@@ -121,7 +122,10 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
         for (int i = 0; i < A_F4; ++i) {
             const long long pos = k0 + (tid >> 5) + 8 * i;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a_ok && pos < g.P) {
+            if (plain) {
+                // linear-layer weight gradient (a 1 x 1 x 1 "conv" over M positions): row pos of a row-major matrix, no gather
+                if (a_ok && pos < g.P) v = *reinterpret_cast<const float4*>(a_src + pos * a_Cs + a_ch);
+            } else if (a_ok && pos < g.P) {
                 int id = ad[i] * g.stride + a_td + g.off;
                 int ih = ah[i] * g.stride + a_th + g.off;
                 int iw = aw[i] * g.stride + a_tw + g.off;
@@ -203,10 +207,12 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
         store_tile();
         __syncthreads();
         if (kt + 1 < nkt) {
+            if (!plain) {
 #pragma unroll
-            for (int i = 0; i < A_F4; ++i) advance(aw[i], ah[i], ad[i], ab[i]);
+                for (int i = 0; i < A_F4; ++i) advance(aw[i], ah[i], ad[i], ab[i]);
 #pragma unroll
-            for (int i = 0; i < B_F4; ++i) advance(bw[i], bh[i], bd[i], bb[i]);
+                for (int i = 0; i < B_F4; ++i) advance(bw[i], bh[i], bd[i], bb[i]);
+            }
             load_tile(kt + 1);
         }
 #pragma unroll
