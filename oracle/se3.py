@@ -4,15 +4,20 @@ Restates /root/reference/peract/voxel/augmentation.py:7-185 and the helpers it
 uses from /root/reference/peract/helpers/utils.py (:63-64 normalize_quaternion,
 :92-97 quaternion_to_discrete_euler, :104-116 point_to_voxel_index).
 
-PARITY UNPINNED UPSTREAM: the reference calls pytorch3d==0.3.0
+PINNED BY A REFERENCE RUN (fixture F8): tests/golden/make_golden.py path-loads the reference's own
+voxel/augmentation.py and runs `apply_se3_augmentation` / `apply_se3_augmentation_2Robots` with scripted draws
+(shared and per-sample bounds, layer 0 / 1, a forced whole-batch retry, two arms); `augment` below reproduces its
+labels exactly and its transformed points bit for bit.
+
+ONE PIECE STAYS UNPINNED UPSTREAM: the reference calls pytorch3d==0.3.0
 (peract/requirements.txt:11; call sites augmentation.py:106,142,152), which is
-neither vendored under /root/reference nor installed here.  The three helpers
-below restate pytorch3d 0.3.0's published definitions:
+neither vendored under /root/reference nor installed here, so that reference run uses the three helpers
+below, restated from pytorch3d 0.3.0's published definitions:
   quaternion_to_matrix(wxyz)      : real-first, scaled by 2/|q|^2
   euler_angles_to_matrix(a,'XYZ') : Rx(a0) @ Ry(a1) @ Rz(a2)
   matrix_to_quaternion            : 0.5*sqrt(max(0, 1 +- m00 +- m11 +- m22)) with
                                     copysign from the off-diagonal differences
-They are checked by invariants only (orthonormality, round trip, scipy agreement).
+These three are checked by invariants only (orthonormality, round trip, scipy agreement).
 The random draws (`torch.rand` / `torch.randint` on CPU, augmentation.py:123-141)
 are passed in explicitly so that tests are deterministic.
 """

@@ -495,27 +495,125 @@ def f7_lamb():
     save('f7_lamb', **out)
 
 
-# ----------------------------------------------------------------------------- F8 (oracle-only; unpinned upstream)
+# ----------------------------------------------------------------------------- F8: SE(3) augmentation, run by the REFERENCE
+def _load_ref_augmentation():
+    """path-load the reference's voxel/augmentation.py.  Its `pytorch3d.transforms` (pytorch3d==0.3.0, not vendored, not
+    installed) is a module holding the three restated helpers of oracle/se3.py -- the only part that is not reference code --
+    and `helpers.utils.rand_dist / rand_discrete` (utils.py:501-508, torch.rand / torch.randint) are scripted so that the
+    draws of every attempt are explicit inputs of the fixture."""
+    import types
+    stub_modules()
+    t3d = types.ModuleType('pytorch3d.transforms')
+    t3d.quaternion_to_matrix = ose3.quaternion_to_matrix
+    t3d.euler_angles_to_matrix = ose3.euler_angles_to_matrix
+    t3d.matrix_to_quaternion = ose3.matrix_to_quaternion
+    sys.modules['pytorch3d'].transforms = t3d
+    sys.modules['pytorch3d.transforms'] = t3d
+    ref_aug = load('ref_augmentation', 'voxel/augmentation.py')
+    return ref_aug, sys.modules['helpers.utils']
+
+
+class _ScriptedDraws:
+    """stands in for utils.rand_dist / utils.rand_discrete: attempt a returns unit[a] and, for the a-th roll / pitch / yaw
+    call, steps[a][:, i]; counts the attempts the reference consumed."""
+
+    def __init__(self, unit, steps):
+        self.unit, self.steps, self.n_dist, self.n_disc = unit, steps, 0, 0
+
+    def rand_dist(self, size, min=-1.0, max=1.0):
+        u = self.unit[self.n_dist]
+        self.n_dist += 1
+        assert tuple(u.shape) == tuple(size)
+        return u.clone()
+
+    def rand_discrete(self, size, min=0, max=1):
+        a, i = divmod(self.n_disc, 3)
+        self.n_disc += 1
+        v = self.steps[a][:, i:i + 1].clone()
+        assert int(v.min()) >= min and int(v.max()) <= max, (min, max, v)
+        return v
+
+
 def f8_se3():
-    B = 8
-    rs = synthetic.make_replay_sample(B, ['front'], (16, 16), 100, 4, seed=5)
-    pose = rs['gripper_pose'][:, 0]
-    rg = rs['rot_grip_action_indicies'][:, 0]
-    pcd = [rs['front_point_cloud'][:, 0]]
-    bounds = torch.tensor([synthetic.SCENE_BOUNDS])
-    shift_unit = ow.hashed_uniform('se3_shift', (B, 3), -1, 1)
-    steps = torch.cat([torch.zeros(B, 2, dtype=torch.int64), ow.hashed_int('se3_yaw', (B, 1), -9, 10)], 1)
-    ti, ri, pp, ok = ose3.augment(pcd, pose, rg, bounds, shift_unit, steps, [0.125] * 3, 5, 100, 5)
-    # invariants that stand in for the missing pytorch3d pin
-    q = torch.cat([pose[:, 6:7], pose[:, 3:6]], 1)
+    ref_aug, ref_utils = _load_ref_augmentation()
+    V = 100
+    out = {}
+    real = ref_utils.rand_dist, ref_utils.rand_discrete
+    cases = [('a', 8, False, 0, False), ('b', 6, True, 1, False), ('c', 5, True, 0, False), ('r', 4, False, 0, True)]
+    try:
+        for tag, B, per_sample, layer, retry in cases:
+            rs = synthetic.make_replay_sample(B, ['front', 'wrist'], (16, 16), V, 4, seed=5 + len(out), crop_target_obj_voxel=per_sample,
+                                              crop_radius=0.45)
+            pose = rs['gripper_pose'][:, 0].clone()
+            rg = rs['rot_grip_action_indicies'][:, 0]
+            tr = rs['trans_action_indicies'][:, 0]
+            pcd = [rs['front_point_cloud'][:, 0], rs['wrist_point_cloud'][:, 0]]
+            bounds = rs['target_object_scene_bounds'][:, 0] if per_sample else torch.tensor([synthetic.SCENE_BOUNDS])
+            A = 3
+            unit = ow.hashed_uniform('se3_shift_' + tag, (A, B, 3), -1, 1)
+            steps = torch.cat([torch.zeros(A, B, 2, dtype=torch.int64), ow.hashed_int('se3_yaw_' + tag, (A, B, 1), -9, 10)], 2)
+            if retry:
+                # sample 2 sits in a corner of the scene: attempt 0 and 1 push it out of the lower bound (index < 0), so the
+                # reference re-draws the WHOLE batch (augmentation.py:116); attempt 2 keeps everyone inside
+                pose[2, :3] = torch.tensor(synthetic.SCENE_BOUNDS[:3]) + 0.01
+                unit[0, 2], unit[1, 2], unit[2] = -1.0, -0.9, 0.05
+            draws = _ScriptedDraws(unit, steps)
+            ref_utils.rand_dist, ref_utils.rand_discrete = draws.rand_dist, draws.rand_discrete
+            ti, ri, pp = ref_aug.apply_se3_augmentation(
+                [p.clone() for p in pcd], pose, tr, rg, bounds, layer, torch.from_numpy(np.array([0.125] * 3)), [0.0, 0.0, 45.0], 5, V, 5, 'cpu')
+            used = draws.n_dist
+            assert (used == 3) if retry else (used == 1), used
+            # the oracle's one-attempt restatement on the accepted draw
+            oti, ori, opp, ok = ose3.augment(pcd, pose, rg, bounds, unit[used - 1], steps[used - 1], [0.125] * 3, 5, V, 5, layer=layer)
+            assert ok and torch.equal(oti.long(), ti.long()) and torch.equal(ori.long(), ri.long())
+            assert max(float((a - b).abs().max()) for a, b in zip(opp, pp)) == 0.0
+            for a in range(used - 1):
+                assert not ose3.augment(pcd, pose, rg, bounds, unit[a], steps[a], [0.125] * 3, 5, V, 5, layer=layer)[3]
+            out.update({tag + '_pose': pose, tag + '_rot_grip': rg, tag + '_pcd0': pcd[0], tag + '_pcd1': pcd[1], tag + '_bounds': bounds,
+                        tag + '_shift_unit': unit, tag + '_rpy_steps': steps, tag + '_layer': layer, tag + '_attempts': used,
+                        tag + '_trans_idx': ti, tag + '_rot_grip_idx': ri, tag + '_pcd0_out': pp[0], tag + '_pcd1_out': pp[1]})
+        # two arms under one perturbation (augmentation.py:187-348): right = the synthetic sample, left = a second one;
+        # attempt 0 pushes only the LEFT arm of sample 1 out -> both arms are re-drawn
+        B, A = 6, 3
+        rs_r = synthetic.make_replay_sample(B, ['front'], (16, 16), V, 4, seed=70)
+        rs_l = synthetic.make_replay_sample(B, ['front'], (16, 16), V, 4, seed=170)
+        pose_r, rg_r, tr_r = rs_r['gripper_pose'][:, 0].clone(), rs_r['rot_grip_action_indicies'][:, 0], rs_r['trans_action_indicies'][:, 0]
+        pose_l, rg_l, tr_l = rs_l['gripper_pose'][:, 0].clone(), rs_l['rot_grip_action_indicies'][:, 0], rs_l['trans_action_indicies'][:, 0]
+        pcd = [rs_r['front_point_cloud'][:, 0]]
+        bounds = torch.tensor([synthetic.SCENE_BOUNDS])
+        unit = ow.hashed_uniform('se3_shift_2', (A, B, 3), -1, 1)
+        steps = torch.cat([torch.zeros(A, B, 2, dtype=torch.int64), ow.hashed_int('se3_yaw_2', (A, B, 1), -9, 10)], 2)
+        pose_l[1, :3] = torch.tensor(synthetic.SCENE_BOUNDS[:3]) + 0.01
+        unit[0, 1], unit[1] = -1.0, 0.1
+        draws = _ScriptedDraws(unit, steps)
+        ref_utils.rand_dist, ref_utils.rand_discrete = draws.rand_dist, draws.rand_discrete
+        tir, rir, til, ril, pp = ref_aug.apply_se3_augmentation_2Robots(
+            [p.clone() for p in pcd], pose_r, tr_r, rg_r, pose_l, tr_l, rg_l, bounds, 0, torch.from_numpy(np.array([0.125] * 3)),
+            [0.0, 0.0, 45.0], 5, V, 5, 'cpu')
+        used = draws.n_dist
+        assert used == 2, used
+        o_r = ose3.augment(pcd, pose_r, rg_r, bounds, unit[1], steps[1], [0.125] * 3, 5, V, 5)
+        o_l = ose3.augment(pcd, pose_l, rg_l, bounds, unit[1], steps[1], [0.125] * 3, 5, V, 5)
+        assert o_r[3] and o_l[3] and torch.equal(o_r[0].long(), tir.long()) and torch.equal(o_r[1].long(), rir.long())
+        assert torch.equal(o_l[0].long(), til.long()) and torch.equal(o_l[1].long(), ril.long())
+        assert float((o_r[2][0] - pp[0]).abs().max()) == 0.0          # the clouds turn about the RIGHT arm (:343-346)
+        assert ose3.augment(pcd, pose_r, rg_r, bounds, unit[0], steps[0], [0.125] * 3, 5, V, 5)[3]          # right alone would pass
+        assert not ose3.augment(pcd, pose_l, rg_l, bounds, unit[0], steps[0], [0.125] * 3, 5, V, 5)[3]
+        out.update(t_pose_right=pose_r, t_rot_grip_right=rg_r, t_pose_left=pose_l, t_rot_grip_left=rg_l, t_pcd0=pcd[0], t_bounds=bounds,
+                   t_shift_unit=unit, t_rpy_steps=steps, t_attempts=used, t_trans_idx_right=tir, t_rot_grip_idx_right=rir,
+                   t_trans_idx_left=til, t_rot_grip_idx_left=ril, t_pcd0_out=pp[0])
+    finally:
+        ref_utils.rand_dist, ref_utils.rand_discrete = real
+    # invariants of the three restated pytorch3d helpers (the one piece the reference tree does not hold)
+    q = torch.cat([pose_r[:, 6:7], pose_r[:, 3:6]], 1)
     R = ose3.quaternion_to_matrix(q)
     assert float((R @ R.transpose(1, 2) - torch.eye(3)).abs().max()) < 1e-5
     from scipy.spatial.transform import Rotation
-    assert np.abs(R.numpy() - Rotation.from_quat(pose[:, 3:].numpy()).as_matrix()).max() < 1e-5
+    assert np.abs(R.numpy() - Rotation.from_quat(pose_r[:, 3:].numpy()).as_matrix()).max() < 1e-5
     q2 = ose3.matrix_to_quaternion(R)
     assert float(torch.minimum((q2 - q).abs().amax(1), (q2 + q).abs().amax(1)).max()) < 1e-5
-    save('f8_se3', pose=pose, rot_grip=rg, pcd=pcd[0], bounds=bounds, shift_unit=shift_unit, rpy_steps=steps,
-         trans_idx=ti, rot_grip_idx=ri, pcd_out=pp[0], ok=int(ok))
+    out['cases'] = np.array([c[0] for c in cases])
+    save('f8_se3', **out)
 
 
 # ----------------------------------------------------------------------------- F9: act() through the whole agent stack

@@ -92,16 +92,34 @@ def test_lamb(golden):
 
 
 def test_se3_fixture(golden):
+    """F8: outputs of the REFERENCE's apply_se3_augmentation / _2Robots (augmentation.py:68-185, :187-348) for scripted draws
+    (make_golden.py f8: shared and per-sample bounds, layer 0 / 1, a forced whole-batch retry, two arms)."""
     g = golden('f8_se3')
-    ti, ri, pp, ok = ose3.augment([T(g['pcd'])], T(g['pose']), T(g['rot_grip']), T(g['bounds']), T(g['shift_unit']),
-                                  T(g['rpy_steps']), [0.125] * 3, 5, 100, 5)
-    assert torch.equal(ti, T(g['trans_idx'])) and torch.equal(ri, T(g['rot_grip_idx']))
-    assert torch.allclose(pp[0], T(g['pcd_out']), atol=1e-6)
-    # rigid: pairwise distances preserved
-    a, b = T(g['pcd']).reshape(8, 3, -1), pp[0].reshape(8, 3, -1)
-    da = (a[:, :, :50, None] - a[:, :, None, :50]).norm(dim=1)
-    db = (b[:, :, :50, None] - b[:, :, None, :50]).norm(dim=1)
-    assert torch.allclose(da, db, atol=1e-5)
+    for tag in [str(c) for c in g['cases']]:
+        used, layer = int(g[tag + '_attempts']), int(g[tag + '_layer'])
+        pcd = [T(g[tag + '_pcd0']), T(g[tag + '_pcd1'])]
+        args = (pcd, T(g[tag + '_pose']), T(g[tag + '_rot_grip']), T(g[tag + '_bounds']))
+        for a in range(used):
+            ti, ri, pp, ok = ose3.augment(*args, T(g[tag + '_shift_unit'])[a], T(g[tag + '_rpy_steps'])[a], [0.125] * 3, 5, 100, 5, layer=layer)
+            assert ok == (a == used - 1), (tag, a)
+        assert torch.equal(ti.long(), T(g[tag + '_trans_idx']).long()) and torch.equal(ri.long(), T(g[tag + '_rot_grip_idx']).long())
+        assert torch.equal(pp[0], T(g[tag + '_pcd0_out'])) and torch.equal(pp[1], T(g[tag + '_pcd1_out']))
+        # rigid: pairwise distances preserved
+        B = pcd[0].shape[0]
+        a, b = pcd[0].reshape(B, 3, -1), pp[0].reshape(B, 3, -1)
+        da = (a[:, :, :50, None] - a[:, :, None, :50]).norm(dim=1)
+        db = (b[:, :, :50, None] - b[:, :, None, :50]).norm(dim=1)
+        assert torch.allclose(da, db, atol=1e-5)
+    # two arms, one perturbation; kept only when BOTH arms stay inside
+    used = int(g['t_attempts'])
+    pcd, bounds = [T(g['t_pcd0'])], T(g['t_bounds'])
+    for a in range(used):
+        r = ose3.augment(pcd, T(g['t_pose_right']), T(g['t_rot_grip_right']), bounds, T(g['t_shift_unit'])[a], T(g['t_rpy_steps'])[a], [0.125] * 3, 5, 100, 5)
+        l = ose3.augment(pcd, T(g['t_pose_left']), T(g['t_rot_grip_left']), bounds, T(g['t_shift_unit'])[a], T(g['t_rpy_steps'])[a], [0.125] * 3, 5, 100, 5)
+        assert (r[3] and l[3]) == (a == used - 1)
+    assert torch.equal(r[0].long(), T(g['t_trans_idx_right']).long()) and torch.equal(r[1].long(), T(g['t_rot_grip_idx_right']).long())
+    assert torch.equal(l[0].long(), T(g['t_trans_idx_left']).long()) and torch.equal(l[1].long(), T(g['t_rot_grip_idx_left']).long())
+    assert torch.equal(r[2][0], T(g['t_pcd0_out']))
 
 
 def test_depth_to_point_cloud_fixture(golden):

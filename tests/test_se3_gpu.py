@@ -1,6 +1,8 @@
-"""GPU: the SE(3) augmentation on the device (csrc/se3_relabel.hip + the voxelizer's fused point transform) against the
-oracle's restatement of reference peract/voxel/augmentation.py:68-185 (oracle/se3.py) and its fixture F8
-(tests/golden/f8_se3.npz: explicit random draws -> labels + transformed points; pytorch3d helpers unpinned upstream)."""
+"""GPU: the SE(3) augmentation on the device (csrc/se3_relabel.hip + the voxelizer's fused point transform) against
+fixture F8 = outputs of the REFERENCE's own apply_se3_augmentation / apply_se3_augmentation_2Robots
+(peract/voxel/augmentation.py:68-185, :187-348) run with scripted draws by tests/golden/make_golden.py, and against the
+oracle's restatement (oracle/se3.py, equal to the reference on those fixtures) on randomised batches.  The three
+pytorch3d==0.3.0 helpers the reference calls are in neither tree: both sides use the oracle's restatement of them."""
 import numpy as np
 import pytest
 import torch
@@ -23,14 +25,32 @@ def _plan(pose, rot_grip, bounds, unit, steps, layer=0, V=100):
 
 
 def test_f8_fixture(golden):
+    """labels, the attempt the retry loop settles on and the transformed clouds of the reference itself: shared bounds,
+    per-sample bounds with layer 1 and layer 0 (the bounds[0] quirk, augmentation.py:161-162), a forced whole-batch retry."""
     g = golden('f8_se3')
-    pose, rg, bounds = T(g['pose']), T(g['rot_grip']), T(g['bounds'])
-    ti, ri, xf, status = _plan(pose, rg, bounds, T(g['shift_unit'])[None], T(g['rpy_steps'])[None].int())
-    assert int(status.item()) == 0
-    assert torch.equal(ti.cpu().long(), T(g['trans_idx']).long())
-    assert torch.equal(ri.cpu().long(), T(g['rot_grip_idx']).long())
-    moved = aug.transform_point_clouds([T(g['pcd']).to(DEV)], xf)[0]
-    assert float((moved.cpu() - T(g['pcd_out'])).abs().max()) < 2e-6
+    for tag in [str(c) for c in g['cases']]:
+        pose, rg, bounds = T(g[tag + '_pose']), T(g[tag + '_rot_grip']), T(g[tag + '_bounds'])
+        ti, ri, xf, status = _plan(pose, rg, bounds, T(g[tag + '_shift_unit']), T(g[tag + '_rpy_steps']).int(), layer=int(g[tag + '_layer']))
+        assert int(status.item()) == int(g[tag + '_attempts']) - 1, tag
+        assert torch.equal(ti.cpu().long(), T(g[tag + '_trans_idx']).long()), tag
+        assert torch.equal(ri.cpu().long(), T(g[tag + '_rot_grip_idx']).long()), tag
+        moved = aug.transform_point_clouds([T(g[tag + '_pcd0']).to(DEV), T(g[tag + '_pcd1']).to(DEV)], xf)
+        assert float((moved[0].cpu() - T(g[tag + '_pcd0_out'])).abs().max()) < 2e-6, tag
+        assert float((moved[1].cpu() - T(g[tag + '_pcd1_out'])).abs().max()) < 2e-6, tag
+
+
+def test_f8_fixture_two_arms(golden):
+    """reference apply_se3_augmentation_2Robots: attempt 0 pushes only the LEFT arm out -> both arms re-drawn."""
+    g = golden('f8_se3')
+    out = aug.se3_augmentation_plan_2robots(T(g['t_pose_right']).to(DEV), T(g['t_rot_grip_right']).to(DEV), T(g['t_pose_left']).to(DEV),
+                                            T(g['t_rot_grip_left']).to(DEV), T(g['t_bounds']).to(DEV), 0,
+                                            torch.tensor([0.125] * 3, dtype=torch.float64), [0.0, 0.0, 45.0], 5, 100, 5, DEV,
+                                            draws=(T(g['t_shift_unit']), T(g['t_rpy_steps']).int()))
+    assert int(out[5].item()) == int(g['t_attempts']) - 1
+    for got, key in zip(out[:4], ('t_trans_idx_right', 't_rot_grip_idx_right', 't_trans_idx_left', 't_rot_grip_idx_left')):
+        assert torch.equal(got.cpu().long(), T(g[key]).long()), key
+    moved = aug.transform_point_clouds([T(g['t_pcd0']).to(DEV)], out[4])[0]
+    assert float((moved.cpu() - T(g['t_pcd0_out'])).abs().max()) < 2e-6
 
 
 @pytest.mark.parametrize('per_sample,layer', [(False, 0), (True, 0), (True, 1)])

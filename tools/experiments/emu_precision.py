@@ -1,0 +1,175 @@
+"""Precision experiment (GPU): which matrix products tolerate ONE 16-bit operand pair instead of the bf16x3 triple?
+
+The exact-fp32 kernels (v_mfma_f32_32x32x2_f32) fed with operands that were first rounded to fp16 / bf16 compute what a
+single fp16 / bf16 MFMA with fp32 accumulation computes (the product of two 11-bit or 8-bit mantissas is exact in fp32), so
+the effect of a cheaper product type on the REFERENCE digests (F5g / F5c3: loss, Q-values, every parameter-gradient norm,
+the small gradients in full) can be measured before any kernel is written.
+
+    python tools/experiments/emu_precision.py [f5g|f5c3] ...
+
+Each row = one configuration {forward linears, forward convs, forward attention core, backward products, loss scale}.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from voxactb_amd import ops                                    # noqa: E402
+import tests.test_c2_reference_gpu as T                        # noqa: E402
+
+DEV = 'cuda:0'
+EMU = dict(lin_fwd=None, conv_fwd=None, attn_fwd=None, bwd=None)
+PHASE = ['fwd']
+
+
+def rnd(t, kind):
+    if t is None or kind is None:
+        return t
+    if kind == 'fp16':
+        return t.half().float()
+    if kind == 'bf16':
+        return t.bfloat16().float()
+    raise ValueError(kind)
+
+
+def rnd_(t, kind):
+    if t is not None and kind is not None:
+        t.copy_(rnd(t, kind))
+    return t
+
+
+_linear, _linear_bwd, _conv3d, _conv3d_wgrad, _gemm = ops.linear, ops.linear_bwd, ops.conv3d, ops.conv3d_wgrad, ops.gemm
+
+
+def linear(x, W, bias=None, act=ops.ACT_NONE, residual=None, out=None):
+    k = EMU['lin_fwd'] if PHASE[0] == 'fwd' else EMU['bwd']
+    return _linear(rnd(x, k), rnd(W, k), bias, act, residual, out)
+
+
+def linear_bwd(x, W, dy, dW, db=None, dx=None, dx_accumulate=False, ws=None):
+    k = EMU['bwd']
+    _linear_bwd(rnd(x, k), rnd(W, k), rnd(dy, k), dW, None, dx, dx_accumulate, ws)
+    if db is not None:
+        ops.colsum(dy, db, accumulate=True)             # bias gradients are fp32 column sums of the unrounded dy
+
+
+def conv3d(src0, wt, *a, **kw):
+    k = EMU['conv_fwd'] if PHASE[0] == 'fwd' else EMU['bwd']
+    if kw.get('src1') is not None:
+        kw['src1'] = rnd(kw['src1'], k)
+    return _conv3d(rnd(src0, k), rnd(wt, k), *a, **kw)
+
+
+def conv3d_wgrad(src0, dy, *a, **kw):
+    k = EMU['bwd']
+    if kw.get('src1') is not None:
+        kw['src1'] = rnd(kw['src1'], k)
+    return _conv3d_wgrad(rnd(src0, k), rnd(dy, k), *a, **kw)
+
+
+def gemm(A, B, C, *a, **kw):
+    if kw.get('label') == 'attn_core':
+        k = EMU['attn_fwd'] if PHASE[0] == 'fwd' else EMU['bwd']
+        rnd_(A, k)
+        rnd_(B, k)
+    return _gemm(A, B, C, *a, **kw)
+
+
+ops.linear, ops.linear_bwd, ops.conv3d, ops.conv3d_wgrad, ops.gemm = linear, linear_bwd, conv3d, conv3d_wgrad, gemm
+
+
+def run(g, fwd_precision, bwd_precision, emu, S, tag):
+    EMU.update(dict(lin_fwd=None, conv_fwd=None, attn_fwd=None, bwd=None))
+    EMU.update(emu)
+    enc, rs, grid, arm, V, B = T._setup(g)
+    eng = enc.engine()
+    eng.precision = fwd_precision
+    eng.bwd_precision = bwd_precision
+    PHASE[0] = 'fwd'
+    outs, cache = eng.forward(grid, rs['low_dim_state'].to(DEV), rs['lang_token_embs'].to(DEV), training=False, save=True)
+    flat = outs[0].reshape(B, -1).float().cpu()
+    sidx = T.T(g['q_trans_sample_idx']).long()
+    e_q = float((flat[:, sidx] - T.T(g['q_trans_sample'])).abs().max())
+    e_r = float((outs[1].float().cpu() - T.T(g['rot_grip'])).abs().max())
+    e_c = float((outs[2].float().cpu() - T.T(g['collision'])).abs().max())
+    at = rs['trans_action_indicies'].long()
+    lab = ((at[:, 0] * V + at[:, 1]) * V + at[:, 2]).int().to(DEV)
+    dq = torch.empty((B, V ** 3), device=DEV)
+    l_t, _, _ = ops.ce_big(outs[0].view(B, -1), lab, dq, S / B)
+    labs = torch.cat([rs['rot_grip_action_indicies'].int(), rs['ignore_collisions'].int()[:, :1]], 1).to(DEV).contiguous()
+    d_o = torch.empty_like(cache['o'])
+    l_h, _ = ops.ce_rows(cache['o'], [(0, 72), (72, 72), (144, 72), (216, 2), (218, 2)], labs, d_o, S / B)
+    total = l_t + l_h.sum(1)
+    d_arm = None
+    if arm:
+        d_arm = torch.empty_like(outs[3])
+        la, _ = ops.ce_rows(outs[3], [(0, 2)], rs['label'].int()[:, :1].to(DEV).contiguous(), d_arm, S / B)
+        total = total + la[:, 0]
+    loss = float(total.mean())
+    for p in enc.parameters():
+        p.grad = None
+    PHASE[0] = 'bwd'
+    eng.backward(cache, dq, d_o, d_arm)
+    PHASE[0] = 'fwd'
+    P = dict(enc.named_parameters())
+    worst_n, worst_e, worst_b, nbad, names, wname = 0.0, 0.0, 0.0, 0, [], '-'
+    nonfinite = 0
+    for n, rn in zip([str(n) for n in g['grad_names']], T.T(g['grad_norms'])):
+        gr = P[n].grad / S
+        if not bool(torch.isfinite(gr).all()):
+            nonfinite += 1
+            continue
+        gn, rn = float(gr.norm()), float(rn)
+        key64 = 'dysum64__' + n
+        if key64 in g.files:
+            ref = T.T(g[key64])
+            e = float((gr.double().cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-12)
+            worst_b = max(worst_b, e)
+            continue
+        if rn > 1e-4:
+            rel = abs(gn - rn) / rn
+            if rel > worst_n:
+                worst_n, wname = rel, n
+            if abs(gn - rn) > 3e-3 * rn + 1e-5:
+                nbad += 1
+                names.append(n)
+        key = 'grad__' + n
+        if key in g.files:
+            ref = T.T(g[key])
+            e = float((gr.float().cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-12)
+            worst_e = max(worst_e, e)
+    print('%-58s q %.2e rot %.2e col %.2e | loss err %.2e | grad norm %.2e (%s) elem %.2e bias64 %.2e | gate fails %d nonfinite %d %s'
+          % (tag, e_q, e_r, e_c, abs(loss - float(g['loss'])), worst_n, wname, worst_e, worst_b, nbad, nonfinite,
+             names[:4]), flush=True)
+    del cache, outs
+    torch.cuda.empty_cache()
+
+
+if __name__ == '__main__':
+    fixtures = [a for a in sys.argv[1:] if not a.startswith('-')] or ['f5g']
+    names = {'f5g': 'f5g_encoder_c2_grads', 'f5c3': 'f5c3_encoder_c3_digest'}
+    quick = '--quick' in sys.argv
+    for f in fixtures:
+        g = np.load(os.path.join(ROOT, 'tests', 'golden', names[f] + '.npz'), allow_pickle=False)
+        print('== %s' % f)
+        # baselines on the real kernels
+        run(g, 'fp32', '', {}, 1.0, 'fp32 fwd / fp32 bwd')
+        run(g, 'bf16x3', '', {}, 1.0, 'bf16x3 fwd / bf16x3 bwd (shipped)')
+        run(g, 'bf16x3', '', {}, 4096.0, 'bf16x3 fwd / bf16x3 bwd, loss scale 2^12')
+        run(g, 'fp32', 'bf16x3', {}, 1.0, 'fp32 fwd / bf16x3 bwd (convs, linears; attention fp32)')
+        run(g, 'bf16x3', 'bf16', {}, 1.0, 'bf16x3 fwd / bf16 bwd (real kernels)')
+        # emulated single-product types on the exact-fp32 kernels
+        run(g, 'fp32', '', dict(bwd='bf16'), 1.0, 'fp32 fwd / EMU bf16 bwd')
+        run(g, 'fp32', '', dict(bwd='fp16'), 1.0, 'fp32 fwd / EMU fp16 bwd, no loss scale')
+        for S in ([4096.0] if quick else [256.0, 4096.0, 65536.0, 2.0 ** 20]):
+            run(g, 'fp32', '', dict(bwd='fp16'), S, 'fp32 fwd / EMU fp16 bwd, loss scale %g' % S)
+        run(g, 'fp32', '', dict(attn_fwd='fp16'), 1.0, 'EMU fp16 attention core fwd, rest fp32')
+        run(g, 'fp32', '', dict(attn_fwd='bf16'), 1.0, 'EMU bf16 attention core fwd, rest fp32')
+        run(g, 'fp32', '', dict(lin_fwd='fp16'), 1.0, 'EMU fp16 linears fwd, rest fp32')
+        run(g, 'fp32', '', dict(lin_fwd='fp16', attn_fwd='fp16'), 1.0, 'EMU fp16 linears + attention fwd, rest fp32')
+        run(g, 'fp32', '', dict(conv_fwd='fp16'), 1.0, 'EMU fp16 convs fwd, rest fp32')
+        run(g, 'fp32', '', dict(lin_fwd='fp16', attn_fwd='fp16', bwd='fp16'), 4096.0, 'EMU fp16 lin+attn fwd, fp16 bwd, scale 2^12')
