@@ -837,6 +837,124 @@ def f10_depth():
     save('f10_depth_clouds', **out)
 
 
+# ----------------------------------------------------------------------------- F15: launch_utils labels + replay fill (reference-run)
+from tests.f15_common import *      # noqa: E402,F401,F403  (stub demo / stubs / case lists shared with tests/test_replay_cpu.py)
+from tests import f15_common as f15c      # noqa: E402
+
+
+def f15_launch_utils():
+    """`_get_action` for every which_arm branch and `_add_keypoints_to_replay` on a stub demo, run by the REFERENCE's own
+    launch_utils.py (:167-298, :301-486; path-loaded with the simulator / CLIP / hydra imports stubbed)."""
+    import copy
+    stub_modules()
+    for n in ('omegaconf', 'hydra'):
+        sys.modules.setdefault(n, MagicMock())
+    ref_lu = sys.modules.get('ref_launch_utils') or load('ref_launch_utils', 'agents/peract_bc/launch_utils.py')
+    ref_utils = sys.modules['helpers.utils']
+    d = f15_stub_demo()
+    out = {'demo_' + k: v for k, v in d.items()}
+    for ci, (arm, label, dom) in enumerate(F15_ACTION_CASES):
+        for di, (vs, off, crop_aug, seed) in enumerate(F15_DEPTH_CASES):
+            res = []
+            np.random.seed(seed)
+            demo = f15_observations(d)
+            for i in range(len(demo)):
+                a = (demo[i], demo[max(0, i - 1)], list(F15_BOUNDS), vs, off, 5, crop_aug, arm, label)
+                res.append(ref_lu._get_action(*a, dom))
+            tag = 'act%d_%d' % (ci, di)
+            names = (('trans', 'rot_grip', 'ignore', 'action', 'attention') if arm != 'both' else
+                     ('trans_right', 'rot_grip_right', 'ignore', 'action_right', 'attention_right', 'trans_left', 'rot_grip_left',
+                      'action_left', 'attention_left'))
+            for j, nm in enumerate(names):
+                out['%s_%s' % (tag, nm)] = np.array([np.asarray(r[j]) for r in res])
+    real = ref_utils.extract_obs, ref_lu.tokenize
+    ref_utils.extract_obs, ref_lu.tokenize = f15_extract_obs, f15_tokenize
+    try:
+        for tag, kw, labels, dom, bounds in F15_FILL_CASES:
+            demo = f15_observations(d)
+            rec = F15Recorder()
+            try:
+                ref_lu._add_keypoints_to_replay(f15_cfg(**kw), 'open_jar', 1, rec, demo[0], demo, F15_KEYPOINTS, F15_CAMS,
+                                                copy.deepcopy(bounds), [F15_V], [0.15], 5, False, description=F15_DESCRIPTION,
+                                                clip_model=F15Clip(), device='cpu', labels=labels, dominant_assistive_arm=dom)
+            except TypeError as e:
+                # upstream's which_arm == 'both' branch calls _get_action with 9 of its 10 positional arguments
+                # (launch_utils.py:356-359 vs :167-177): the reference cannot fill a two-arm replay as published.  The build
+                # gives `dominant_assistive_arm` a default; its two-arm fill is checked against the per-arm labels above.
+                assert kw['which_arm'] == 'both' and 'dominant_assistive_arm' in str(e), e
+                out['fill_both_reference_raises'] = np.array(str(e))
+                continue
+            f15_flatten_calls('fill_' + tag, rec.calls, out)
+    finally:
+        ref_utils.extract_obs, ref_lu.tokenize = real
+    save('f15_launch_utils', **out)
+
+
+# ----------------------------------------------------------------------------- F16: YARR's replay store (reference-run)
+def f16_replay():
+    """identical add / add_final sequences into the reference's TaskUniformReplayBuffer (YARR/yarr/replay_buffer/
+    task_uniform_replay_buffer.py + uniform_replay_buffer.py:259-301, :639-756; pickle-per-transition on disk, as
+    launch_utils.create_replay configures it): `sample_transition_batch(indices=...)` of every valid row, the rows it refuses,
+    the per-task index lists and, for a two-rank world, the set of rows each rank's sampler ever draws."""
+    import tempfile
+    stub_modules()
+    if not hasattr(np, 'bool'):
+        np.bool = bool                       # uniform_replay_buffer.py:706 was written for numpy < 1.24 (environment shim)
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29536')
+    if not dist.is_initialized():
+        dist.init_process_group('gloo', rank=0, world_size=1)
+    from yarr.replay_buffer.task_uniform_replay_buffer import TaskUniformReplayBuffer
+    from yarr.replay_buffer.replay_buffer import ReplayElement
+    from yarr.utils.observation_type import ObservationElement
+    from tests import f16_common as fc
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        obs = [ObservationElement(n, sh, t) if is_obs else ReplayElement(n, sh, t) for n, sh, t, is_obs in fc.F16_OBS]
+        extra = [ReplayElement(n, sh, t) for n, sh, t in fc.F16_EXTRA]
+        buf = TaskUniformReplayBuffer(save_dir=os.path.join(tmp, 'replay'), batch_size=4, timesteps=1, replay_capacity=1000,
+                                      action_shape=(8,), action_dtype=np.float32, reward_shape=(), reward_dtype=np.float32,
+                                      update_horizon=1, observation_elements=obs, extra_replay_elements=extra)
+        n = fc.f16_fill(buf)
+        assert int(buf.add_count) == n
+        valid, invalid = [], []
+        for i in range(n):
+            try:
+                b = buf.sample_transition_batch(1, indices=[i])
+                valid.append(i)
+                for k, v in b.items():
+                    a = np.asarray(v)[0]
+                    out.setdefault('row__' + k, []).append(a.astype(str) if a.dtype == object else a)      # (no pickles in fixtures)
+            except ValueError:
+                invalid.append(i)
+        for k in list(out):
+            out[k] = np.stack(out[k])
+        b = buf.sample_transition_batch(len(valid), indices=valid)
+        out['batch_keys'] = np.array(sorted(b))
+        out['batch_dtypes'] = np.array([str(np.asarray(b[k]).dtype) for k in sorted(b)])
+        out['batch_shapes'] = np.array([str(tuple(np.asarray(b[k]).shape[1:])) for k in sorted(b)])
+        out['valid'], out['invalid'] = np.array(valid), np.array(invalid)
+        for t, rows in buf._task_idxs.items():
+            out['task_rows__' + t] = np.array(rows)
+        np.random.seed(0)
+        counts = {}
+        for _ in range(60):
+            for i in buf.sample_transition_batch(32)['indices'][:, 0]:
+                counts[int(i)] = counts.get(int(i), 0) + 1
+        out['world1_drawn'] = np.array(sorted(counts))
+        for r in range(2):                  # DDP stride (task_uniform_replay_buffer.py:103-108): what rank r of 2 can ever draw
+            buf._num_replicas, buf._rank = 2, r
+            np.random.seed(r)
+            seen = set()
+            for _ in range(60):
+                seen |= set(int(i) for i in buf.sample_transition_batch(32)['indices'][:, 0])
+            out['world2_rank%d_drawn' % r] = np.array(sorted(seen))
+        buf._num_replicas, buf._rank = 1, 0
+        buf.shutdown()
+    save('f16_replay', **out)
+
+
 SECTIONS = {
     'f1': f1_voxel_kats,
     'f3tiny': lambda: encoder_fixture('f3_encoder_tiny', CFG_TINY, arm=True),
@@ -856,6 +974,8 @@ SECTIONS = {
     'f10': f10_depth,
     'f7': f7_lamb,
     'f8': f8_se3,
+    'f15': f15_launch_utils,
+    'f16': f16_replay,
 }
 
 if __name__ == '__main__':

@@ -194,8 +194,10 @@ def test_run_seed_call_sequence_with_stub_demos(tmp_path):
             continue
         assert tuple(batch[name].shape) == (3, 1) + tuple(shape), name
         assert tuple(batch[name + '_tp1'].shape) == (3, 1) + tuple(shape), name      # every observation element has its twin
-    # labels are the discretised keyframe poses (helpers/rotation.py), keyframe 3 / 7 / 11 of demo 0
-    from voxactb_amd.helpers import rotation
+    # labels are the discretised keyframe poses, keyframe 3 / 7 / 11 of demo 0 -- against the oracle's scipy-based restatement of
+    # helpers/utils.py:63-116 (itself equal to the reference on fixtures F8 / F15), not against the product's own helpers
+    from oracle import se3 as rotation
+    rotation.normalize_quaternion = lambda q: q / np.linalg.norm(q, axis=-1, keepdims=True)
     o = demos[0][3]
     want_t = rotation.point_to_voxel_index(o.gripper_right_pose[:3], V, np.array(cfg.rlbench.scene_bounds))
     q = rotation.normalize_quaternion(o.gripper_right_pose[3:])
@@ -250,7 +252,8 @@ def test_two_arm_fill_for_the_one_policy_more_heads_baseline(tmp_path):
     lu.fill_replay(cfg, None, 0, rb, 'open_jar', 0, 1, False, 5, cams, cfg.rlbench.scene_bounds, [V], cfg.method.bounds_offset,
                    cfg.method.rotation_resolution, False, clip_model=Clip(), keypoint_method='heuristic')
     assert int(rb.add_count) == 4                                        # 3 transitions + the terminal observation
-    from voxactb_amd.helpers import rotation
+    from oracle import se3 as rotation
+    rotation.normalize_quaternion = lambda q: q / np.linalg.norm(q, axis=-1, keepdims=True)
     row = rb.sample_transition_batch(1, indices=[0])
     o = demo[3]
     for side in ('right', 'left'):
@@ -271,3 +274,126 @@ def test_two_arm_fill_for_the_one_policy_more_heads_baseline(tmp_path):
     assert type(agent._pose_agent._qattention_agents[0]).__name__ == 'QAttentionPerActBCAgent2Robots'
     assert type(agent._pose_agent._qattention_agents[0]._perceiver_encoder).__name__ == 'PerceiverVoxelLang2RobotsEncoder'
     rb.shutdown()
+
+
+# ------------------------------------------------------------------------------------------------ F15: labels + fill vs the REFERENCE
+def test_get_action_equals_the_reference_for_every_which_arm_branch(golden):
+    """fixture F15: `_get_action` of the reference's launch_utils.py:167-298 on a stub two-arm demo -- right / left / multiarm
+    (both labels) / dominant / assistive (both sides) / both, one and two voxelization depths, with and without the seeded
+    crop jitter (which shifts the keyframe pose IN PLACE upstream, so the returned action carries it)."""
+    from tests import f15_common as fc
+    lu = peract_bc.launch_utils
+    g = golden('f15_launch_utils')
+    d = {k[5:]: g[k] for k in g.files if k.startswith('demo_')}
+    for ci, (arm, label, dom) in enumerate(fc.F15_ACTION_CASES):
+        for di, (vs, off, crop_aug, seed) in enumerate(fc.F15_DEPTH_CASES):
+            np.random.seed(seed)
+            demo = fc.f15_observations(d)
+            tag = 'act%d_%d' % (ci, di)
+            names = (('trans', 'rot_grip', 'ignore', 'action', 'attention') if arm != 'both' else
+                     ('trans_right', 'rot_grip_right', 'ignore', 'action_right', 'attention_right', 'trans_left', 'rot_grip_left',
+                      'action_left', 'attention_left'))
+            for i in range(len(demo)):
+                got = lu._get_action(demo[i], demo[max(0, i - 1)], list(fc.F15_BOUNDS), vs, off, 5, crop_aug, arm, label, dom)
+                assert len(got) == len(names)
+                for j, nm in enumerate(names):
+                    want = g['%s_%s' % (tag, nm)][i]
+                    if nm.startswith(('trans', 'rot_grip', 'ignore')):
+                        assert np.array_equal(np.asarray(got[j]), want), (tag, nm, i)
+                    else:
+                        assert np.array_equal(np.asarray(got[j], dtype=np.float64), want), (tag, nm, i)      # same float64 arithmetic
+
+
+def test_add_keypoints_to_replay_equals_the_reference_call_for_call(golden):
+    """fixture F15: every `replay.add(...)` / `replay.add_final(...)` the reference's `_add_keypoints_to_replay`
+    (launch_utils.py:301-486) issues for the stub demo -- keys, values, rewards, terminal flags, the per-keyframe crop bounds
+    (fixed radius and 'auto'), arm labels, the multiarm instruction split, multi-task scene-bounds lists."""
+    import copy
+    from tests import f15_common as fc
+    lu = peract_bc.launch_utils
+    g = golden('f15_launch_utils')
+    d = {k[5:]: g[k] for k in g.files if k.startswith('demo_')}
+    ref_utils_crop = lambda radius, pos: (lambda p: [p[0] - radius, p[1] - radius, p[2] - radius, p[0] + radius, p[1] + radius, p[2] + radius])(np.round(pos, 2))  # noqa: E731
+    ref_split = lambda text: (text.split(' and ')[0], text.split(' and ')[-1])      # noqa: E731  (helpers/utils.py:24-30, asserts dropped)
+    lu.set_upstream(extract_obs=fc.f15_extract_obs, tokenize=fc.f15_tokenize, get_new_scene_bounds_based_on_crop=ref_utils_crop,
+                    extract_left_and_right_arm_instruction=ref_split)
+    checked = 0
+    for tag, kw, labels, dom, bounds in fc.F15_FILL_CASES:
+        demo = fc.f15_observations(d)
+        rec = fc.F15Recorder()
+        lu._add_keypoints_to_replay(fc.f15_cfg(**kw), 'open_jar', 1, rec, demo[0], demo, fc.F15_KEYPOINTS, fc.F15_CAMS, copy.deepcopy(bounds),
+                                    [fc.F15_V], [0.15], 5, False, description=fc.F15_DESCRIPTION, clip_model=fc.F15Clip(), device='cpu',
+                                    labels=labels, dominant_assistive_arm=dom)
+        if kw['which_arm'] == 'both':
+            # upstream raises here (it calls _get_action with 9 of 10 positional arguments, fixture key below); the build's
+            # two-arm fill is checked in test_two_arm_fill_for_the_one_policy_more_heads_baseline
+            assert 'fill_both_reference_raises' in g.files and len(rec.calls) == len(fc.F15_KEYPOINTS) + 1
+            continue
+        mine = {}
+        fc.f15_flatten_calls('fill_' + tag, rec.calls, mine)
+        assert int(mine['fill_%s_ncalls' % tag]) == int(g['fill_%s_ncalls' % tag])
+        for k, v in mine.items():
+            assert k in g.files, k
+            v, want = np.asarray(v), g[k]
+            if v.dtype.kind in 'US':
+                assert [str(x) for x in np.atleast_1d(v)] == [str(x) for x in np.atleast_1d(want)], k
+            else:
+                assert v.shape == want.shape and np.array_equal(v, want), (k, v, want)
+            checked += 1
+        assert not [k for k in g.files if k.startswith('fill_%s_' % tag) and k not in mine]
+    assert checked > 150
+
+
+# ------------------------------------------------------------------------------------------------ F16: the store vs YARR's own
+@pytest.mark.parametrize('disk', [False, True])
+def test_shard_store_equals_yarr_task_uniform_replay_buffer(golden, tmp_path, disk):
+    """fixture F16: the same add / add_final sequence went into the REFERENCE's TaskUniformReplayBuffer (pickle-per-transition,
+    YARR/yarr/replay_buffer/uniform_replay_buffer.py:259-386, :639-756; task_uniform_replay_buffer.py:30-133).  Every row it
+    can sample comes back element for element (keys, dtypes, shapes, values, `_tp1` twins, reward / terminal / indices), the
+    rows it refuses are refused, the per-task row lists are equal and each rank of a two-rank world draws from the same rows."""
+    from tests import f16_common as fc
+    g = golden('f16_replay')
+    obs = [(R.ObservationElement if is_obs else R.ReplayElement)(n, sh, t) for n, sh, t, is_obs in fc.F16_OBS]
+    extra = [R.ReplayElement(n, sh, t) for n, sh, t in fc.F16_EXTRA]
+
+    def make(rank=0, world=1):
+        return R.ShardReplayBuffer(save_dir=str(tmp_path / ('replay%d%d' % (rank, world))) if disk else None, batch_size=4, timesteps=1,
+                                   replay_capacity=1000, action_shape=(8,), action_dtype=np.float32, reward_shape=(), reward_dtype=np.float32,
+                                   update_horizon=1, observation_elements=obs, extra_replay_elements=extra, rank=rank, num_replicas=world,
+                                   rows_per_shard=7)
+    buf = make()
+    n = fc.f16_fill(buf)
+    valid, invalid = g['valid'].tolist(), g['invalid'].tolist()
+    assert int(buf.add_count) == n == len(valid) + len(invalid)
+    b = buf.sample_transition_batch(len(valid), indices=valid)
+    keys = [str(k) for k in g['batch_keys']]
+    # yarr deletes `task` / `task_tp1` only (uniform_replay_buffer.py:750-754): the object-typed `lang_goal` stays in ITS batches
+    # and is dropped later, by the runner's tensor filter (offline_train_runner.py:140)
+    assert sorted(b) == keys
+    for k, dt, sh in zip(keys, g['batch_dtypes'], g['batch_shapes']):
+        mine = np.asarray(b[k])
+        assert str(tuple(mine.shape[1:])) == str(sh), (k, mine.shape, sh)
+        if str(dt) != 'object':
+            assert str(mine.dtype) == str(dt), (k, mine.dtype, dt)
+            assert np.array_equal(mine, g['row__' + k]), k
+        else:
+            assert [str(x) for x in mine.reshape(-1)] == [str(x) for x in g['row__' + k].reshape(-1)], k
+    for i in invalid:                                                # episode-final observations (terminal = -1) and the last row
+        assert not buf._is_valid(i)
+    for t in fc.F16_TASKS:
+        assert buf._task_idxs[t] == g['task_rows__' + t].tolist()
+    buf.seed(0)
+    drawn = set()
+    for _ in range(60):
+        drawn |= set(buf.sample_transition_batch(32)['indices'][:, 0].tolist())
+    assert sorted(drawn) == g['world1_drawn'].tolist()
+    for r in range(2):
+        br = make(r, 2)
+        fc.f16_fill(br)
+        br.seed(r)
+        seen = set()
+        for _ in range(60):
+            seen |= set(br.sample_transition_batch(32)['indices'][:, 0].tolist())
+        assert sorted(seen) == g['world2_rank%d_drawn' % r].tolist(), r
+        br.shutdown()
+    buf.shutdown()

@@ -22,7 +22,8 @@ from voxactb_amd import ops                                    # noqa: E402
 import tests.test_c2_reference_gpu as T                        # noqa: E402
 
 DEV = 'cuda:0'
-EMU = dict(lin_fwd=None, conv_fwd=None, attn_fwd=None, bwd=None)
+KINDS = ('lin_fwd', 'conv_fwd', 'attn_fwd', 'conv_dgrad', 'conv_wgrad', 'lin_dgrad', 'lin_wgrad', 'attn_bwd', 'final_dgrad', 'final_wgrad', 'up_wgrad')
+EMU = {k: None for k in KINDS}
 PHASE = ['fwd']
 
 
@@ -46,26 +47,37 @@ _linear, _linear_bwd, _conv3d, _conv3d_wgrad, _gemm = ops.linear, ops.linear_bwd
 
 
 def linear(x, W, bias=None, act=ops.ACT_NONE, residual=None, out=None):
-    k = EMU['lin_fwd'] if PHASE[0] == 'fwd' else EMU['bwd']
+    k = EMU['lin_fwd'] if PHASE[0] == 'fwd' else None
     return _linear(rnd(x, k), rnd(W, k), bias, act, residual, out)
 
 
 def linear_bwd(x, W, dy, dW, db=None, dx=None, dx_accumulate=False, ws=None):
-    k = EMU['bwd']
-    _linear_bwd(rnd(x, k), rnd(W, k), rnd(dy, k), dW, None, dx, dx_accumulate, ws)
+    kw, kd = EMU['lin_wgrad'], EMU['lin_dgrad']
+    if kw == kd:
+        _linear_bwd(rnd(x, kw), rnd(W, kw), rnd(dy, kw), dW, None, dx, dx_accumulate, ws)
+    else:
+        _linear_bwd(rnd(x, kw), W, rnd(dy, kw), dW, None, None, False, ws)                    # weight gradient only
+        if dx is not None:
+            _linear_bwd(x, rnd(W, kd), rnd(dy, kd), torch.zeros_like(dW), None, dx, dx_accumulate, ws)   # data gradient only
     if db is not None:
         ops.colsum(dy, db, accumulate=True)             # bias gradients are fp32 column sums of the unrounded dy
 
 
 def conv3d(src0, wt, *a, **kw):
-    k = EMU['conv_fwd'] if PHASE[0] == 'fwd' else EMU['bwd']
+    k = EMU['conv_fwd'] if PHASE[0] == 'fwd' else EMU['conv_dgrad']
+    if PHASE[0] == 'bwd' and len(a) >= 5 and a[0] == 128 and a[4] == 3:          # (N, B, S_in, S_out, kext): final's data gradient
+        k = EMU['final_dgrad'] or k
     if kw.get('src1') is not None:
         kw['src1'] = rnd(kw['src1'], k)
     return _conv3d(rnd(src0, k), rnd(wt, k), *a, **kw)
 
 
 def conv3d_wgrad(src0, dy, *a, **kw):
-    k = EMU['bwd']
+    k = EMU['conv_wgrad']
+    if kw.get('src1') is not None:
+        k = EMU['final_wgrad'] or k
+    elif kw.get('d2s', (0, 0))[0] > 0:
+        k = EMU['up_wgrad'] or k
     if kw.get('src1') is not None:
         kw['src1'] = rnd(kw['src1'], k)
     return _conv3d_wgrad(rnd(src0, k), rnd(dy, k), *a, **kw)
@@ -73,7 +85,7 @@ def conv3d_wgrad(src0, dy, *a, **kw):
 
 def gemm(A, B, C, *a, **kw):
     if kw.get('label') == 'attn_core':
-        k = EMU['attn_fwd'] if PHASE[0] == 'fwd' else EMU['bwd']
+        k = EMU['attn_fwd'] if PHASE[0] == 'fwd' else EMU['attn_bwd']
         rnd_(A, k)
         rnd_(B, k)
     return _gemm(A, B, C, *a, **kw)
@@ -82,13 +94,17 @@ def gemm(A, B, C, *a, **kw):
 ops.linear, ops.linear_bwd, ops.conv3d, ops.conv3d_wgrad, ops.gemm = linear, linear_bwd, conv3d, conv3d_wgrad, gemm
 
 
-def run(g, fwd_precision, bwd_precision, emu, S, tag):
-    EMU.update(dict(lin_fwd=None, conv_fwd=None, attn_fwd=None, bwd=None))
+def run(g, fwd_precision, bwd_precision, emu, S, tag, attn_bwd=''):
+    EMU.update({k: None for k in KINDS})
+    if 'bwd' in emu:
+        emu = dict(emu, **{k: emu['bwd'] for k in KINDS[3:]})
+        emu.pop('bwd')
     EMU.update(emu)
     enc, rs, grid, arm, V, B = T._setup(g)
     eng = enc.engine()
     eng.precision = fwd_precision
     eng.bwd_precision = bwd_precision
+    eng.attn_bwd_precision = attn_bwd
     PHASE[0] = 'fwd'
     outs, cache = eng.forward(grid, rs['low_dim_state'].to(DEV), rs['lang_token_embs'].to(DEV), training=False, save=True)
     flat = outs[0].reshape(B, -1).float().cpu()
@@ -156,20 +172,42 @@ if __name__ == '__main__':
     for f in fixtures:
         g = np.load(os.path.join(ROOT, 'tests', 'golden', names[f] + '.npz'), allow_pickle=False)
         print('== %s' % f)
-        # baselines on the real kernels
+        if '--round1' in sys.argv:
+            run(g, 'fp32', '', {}, 1.0, 'fp32 fwd / fp32 bwd')
+            run(g, 'bf16x3', '', {}, 1.0, 'bf16x3 fwd / bf16x3 bwd (shipped)')
+            run(g, 'fp32', 'bf16x3', {}, 1.0, 'fp32 fwd / bf16x3 bwd (convs, linears; attention fp32)')
+            run(g, 'bf16x3', 'bf16', {}, 1.0, 'bf16x3 fwd / bf16 bwd (real kernels)')
+            run(g, 'fp32', '', dict(bwd='bf16'), 1.0, 'fp32 fwd / EMU bf16 bwd')
+            for S in [256.0, 4096.0]:
+                run(g, 'fp32', '', dict(bwd='fp16'), S, 'fp32 fwd / EMU fp16 bwd, loss scale %g' % S)
+            run(g, 'fp32', '', dict(attn_fwd='fp16'), 1.0, 'EMU fp16 attention core fwd, rest fp32')
+            run(g, 'fp32', '', dict(lin_fwd='fp16'), 1.0, 'EMU fp16 linears fwd, rest fp32')
+            run(g, 'fp32', '', dict(conv_fwd='fp16'), 1.0, 'EMU fp16 convs fwd, rest fp32')
+            continue
+        S = 4096.0
+        if '--round2' not in sys.argv:
+            CW = dict(final_wgrad='fp16', up_wgrad='fp16')
+            run(g, 'bf16x3', 'fp32', {}, 1.0, 'x3 fwd | fp32 conv+linear bwd, x3 attention bwd', attn_bwd='bf16x3')
+            run(g, 'bf16x3', 'fp32', CW, S, 'x3 fwd | fp16 final + up-conv weight gradients', attn_bwd='bf16x3')
+            run(g, 'bf16x3', 'fp32', dict(conv_wgrad='fp16'), S, 'x3 fwd | fp16 all conv weight gradients', attn_bwd='bf16x3')
+            run(g, 'bf16x3', 'fp32', dict(CW, final_dgrad='fp16'), S, 'x3 fwd | fp16 final + up-conv wgrads + final dgrad', attn_bwd='bf16x3')
+            run(g, 'bf16x3', 'fp32', dict(final_dgrad='fp16'), S, 'x3 fwd | fp16 final dgrad only', attn_bwd='bf16x3')
+            run(g, 'bf16x3', 'fp32', dict(conv_dgrad='fp16'), S, 'x3 fwd | fp16 all conv dgrads only', attn_bwd='bf16x3')
+            run(g, 'bf16x3', 'fp32', dict(lin_wgrad='fp16'), S, 'x3 fwd | fp16 linear wgrads only', attn_bwd='bf16x3')
+            run(g, 'bf16x3', 'fp32', dict(CW, final_dgrad='fp16'), 256.0, 'x3 fwd | fp16 final + up wgrads + final dgrad, scale 2^8', attn_bwd='bf16x3')
+            run(g, 'fp32', '', dict(CW, final_dgrad='fp16'), S, 'fp32 fwd | fp16 final + up wgrads + final dgrad')
+            continue
+        W16 = dict(conv_wgrad='fp16', lin_wgrad='fp16')
         run(g, 'fp32', '', {}, 1.0, 'fp32 fwd / fp32 bwd')
-        run(g, 'bf16x3', '', {}, 1.0, 'bf16x3 fwd / bf16x3 bwd (shipped)')
-        run(g, 'bf16x3', '', {}, 4096.0, 'bf16x3 fwd / bf16x3 bwd, loss scale 2^12')
-        run(g, 'fp32', 'bf16x3', {}, 1.0, 'fp32 fwd / bf16x3 bwd (convs, linears; attention fp32)')
-        run(g, 'bf16x3', 'bf16', {}, 1.0, 'bf16x3 fwd / bf16 bwd (real kernels)')
-        # emulated single-product types on the exact-fp32 kernels
-        run(g, 'fp32', '', dict(bwd='bf16'), 1.0, 'fp32 fwd / EMU bf16 bwd')
-        run(g, 'fp32', '', dict(bwd='fp16'), 1.0, 'fp32 fwd / EMU fp16 bwd, no loss scale')
-        for S in ([4096.0] if quick else [256.0, 4096.0, 65536.0, 2.0 ** 20]):
-            run(g, 'fp32', '', dict(bwd='fp16'), S, 'fp32 fwd / EMU fp16 bwd, loss scale %g' % S)
-        run(g, 'fp32', '', dict(attn_fwd='fp16'), 1.0, 'EMU fp16 attention core fwd, rest fp32')
-        run(g, 'fp32', '', dict(attn_fwd='bf16'), 1.0, 'EMU bf16 attention core fwd, rest fp32')
-        run(g, 'fp32', '', dict(lin_fwd='fp16'), 1.0, 'EMU fp16 linears fwd, rest fp32')
-        run(g, 'fp32', '', dict(lin_fwd='fp16', attn_fwd='fp16'), 1.0, 'EMU fp16 linears + attention fwd, rest fp32')
-        run(g, 'fp32', '', dict(conv_fwd='fp16'), 1.0, 'EMU fp16 convs fwd, rest fp32')
-        run(g, 'fp32', '', dict(lin_fwd='fp16', attn_fwd='fp16', bwd='fp16'), 4096.0, 'EMU fp16 lin+attn fwd, fp16 bwd, scale 2^12')
+        run(g, 'fp32', '', W16, S, 'fp32 | fp16 weight gradients (convs + linears)')
+        run(g, 'fp32', '', dict(W16, conv_dgrad='fp16'), S, 'fp32 | fp16 weight gradients + conv data gradients')
+        run(g, 'fp32', '', dict(W16, conv_dgrad='fp16', attn_bwd='fp16'), S, 'fp32 | fp16 wgrads + conv dgrads + attention bwd')
+        run(g, 'fp32', '', dict(W16, conv_dgrad='fp16', lin_dgrad='fp16'), S, 'fp32 | fp16 wgrads + conv dgrads + linear dgrads')
+        run(g, 'fp32', '', dict(W16, lin_dgrad='fp16'), S, 'fp32 | fp16 wgrads + linear dgrads')
+        run(g, 'fp32', '', dict(conv_wgrad='bf16', lin_wgrad='bf16'), 1.0, 'fp32 | bf16 weight gradients')
+        run(g, 'fp32', '', dict(conv_wgrad='bf16', lin_wgrad='bf16', conv_dgrad='bf16'), 1.0, 'fp32 | bf16 wgrads + conv dgrads')
+        # the forward as shipped (bf16x3 kernels, fused attention); backward convs / linears on the emulation, attention bwd bf16x3
+        run(g, 'bf16x3', 'fp32', {}, 1.0, 'bf16x3 fwd | fp32 conv+linear bwd, x3 attention bwd', attn_bwd='bf16x3')
+        run(g, 'bf16x3', 'fp32', W16, S, 'bf16x3 fwd | fp16 wgrads, x3 attention bwd', attn_bwd='bf16x3')
+        run(g, 'bf16x3', 'fp32', dict(W16, conv_dgrad='fp16'), S, 'bf16x3 fwd | fp16 wgrads + conv dgrads, x3 attention bwd', attn_bwd='bf16x3')
+        run(g, 'bf16x3', 'fp32', dict(W16, conv_dgrad='fp16'), 16384.0, 'bf16x3 fwd | same, loss scale 2^14', attn_bwd='bf16x3')
