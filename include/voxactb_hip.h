@@ -224,6 +224,15 @@ int vxb_conv3_wgrad_halo_bf16_f32(const float* src0, const float* src1, int C0, 
 int vxb_conv3_wgrad_halo_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                                     int off, int replicate, const float* dy, int N, int64_t ldy, int d2s_s, int d2s_C,
                                     float* part, int nsplit, const uint32_t* phase_mask, vxb_stream_t stream);
+/* ... with ONE fp16 product per term (v_mfma_f32_16x16x32_f16, fp32 accumulate): the weight gradients of `final`
+ * (perceiver_lang_io.py:462) and of the up-conv (network_utils.py:245-250) in the default precision -- a weight gradient is a
+ * leaf of the backward pass, its operand rounding (2^-12) averages out over >= 10^5 voxels and never propagates.  x saturates at
+ * +-65504; dY is multiplied by *dy_scale (device float, a power of two from vxb_absmax_scale_f32; NULL = 1) before the
+ * conversion, `part` holds dy_scale * dW (undo it with vxb_sum_splits_dev_f32). */
+int vxb_conv3_wgrad_halo_f16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
+                                 int off, int replicate, const float* dy, int N, int64_t ldy, int d2s_s, int d2s_C,
+                                 float* part, int nsplit, const uint32_t* phase_mask, const float* dy_scale,
+                                 vxb_stream_t stream);
 size_t vxb_conv3_wgrad_halo_tiles(int B, int S_out, int x3);
 /* bf16 matrix-core weight gradient (same contract as vxb_conv3d_wgrad_f32): both operands are staged position-major and
  * transposed for the matrix cores by ds_read_b64_tr_b16. */
@@ -353,6 +362,13 @@ int vxb_sum_splits_f32(const float* part, int nsplit, int64_t n, float* dst, int
                        vxb_stream_t stream);
 int vxb_colsum_f32(const float* x, int64_t rows, int N, int64_t ld, float* part_ws, float* out, int accumulate,
                    vxb_stream_t stream);
+/* the same with the factor read from device memory (*alpha): no host round trip for a scale computed on the device. */
+int vxb_sum_splits_dev_f32(const float* part, int nsplit, int64_t n, float* dst, int accumulate, const float* alpha,
+                           vxb_stream_t stream);
+/* scale[0] = the power of two that maps max |x[i]| into [2^14, 2^15) (1 if the array is all zero or holds inf / NaN),
+ * scale[1] = 1 / scale[0]: the operand scale of the fp16 single-product kernels (fp16 keeps 11 bits from 6e-5 to 65504).
+ * x dense, n elements; ws: 1024 words.  Two launches, no host sync. */
+int vxb_absmax_scale_f32(const float* x, int64_t n, float* ws, float* scale, vxb_stream_t stream);
 
 /* CLIP text transformer pieces of the act() path (reference peract/helpers/clip/core/clip.py:426-440
  * encode_text_with_embeddings, :224-245 ResidualAttentionBlock, :219-221 QuickGELU): token + positional embedding (or a

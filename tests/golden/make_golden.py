@@ -348,17 +348,17 @@ def stub_modules():
     sys.modules['rlbench.backend.const'].DEPTH_SCALE = 2 ** 24 - 1
 
 
-def f6_update_traces():
+def f6_update_traces(name='f6_update_traces', cfg=None, tags=(('a', False, False), ('b', True, True)), steps=3):
     stub_modules()
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29533')
     if not dist.is_initialized():
         dist.init_process_group('gloo', rank=0, world_size=1)
-    ref_agent = load('ref_agent', 'agents/peract_bc/qattention_peract_bc_agent.py')
-    cfg = CFG_UPD
+    ref_agent = sys.modules.get('ref_agent') or load('ref_agent', 'agents/peract_bc/qattention_peract_bc_agent.py')
+    cfg = cfg or CFG_UPD
     out = {}
-    for tag, arm, crop in (('a', False, False), ('b', True, True)):
+    for tag, arm, crop in tags:
         c = dict(cfg, low_dim=4 if tag == 'a' else 7)
         enc, sd = make_ref_encoder(c, arm)
         enc.train()
@@ -371,7 +371,7 @@ def f6_update_traces():
         agent.build(training=True, device='cpu')
         losses = []
         batches = []
-        for step in range(3):
+        for step in range(steps):
             rs = batch_for(c, seed=10 + step, arm=arm, crop=crop)
             batches.append(rs)
             r = agent.update(step, dict(rs))
@@ -394,7 +394,7 @@ def f6_update_traces():
                            bounds=rs['target_object_scene_bounds'] if crop else torch.tensor([synthetic.SCENE_BOUNDS]),
                            trans=rs['trans_action_indicies'], rot_grip=rs['rot_grip_action_indicies'],
                            ignore_collisions=rs['ignore_collisions'], label=rs.get('label')))
-        tr = oagent.train_steps(P, ob, c['V'], 3, **enc_kw(c, arm))
+        tr = oagent.train_steps(P, ob, c['V'], steps, **enc_kw(c, arm))
         ol = np.array([t['total'] for t in tr])
         print('update trace %s: reference %s oracle %s' % (tag, np.array(losses)[:, 0], ol))
         # Step 0 is a pure forward comparison.  Later steps go through LAMB, whose first-step update is
@@ -405,8 +405,8 @@ def f6_update_traces():
         assert dl[0] < 5e-5 and dl.max() < 5e-3, dl
         out[tag + '_oracle_losses'] = ol
     out.update(cfg_V=cfg['V'], cfg_k=cfg['k'], cfg_s=cfg['s'], cfg_depth=cfg['depth'], cfg_latents=cfg['latents'],
-               cfg_B=cfg['B'], cfg_H=cfg['H'], cfg_W=cfg['W'])
-    save('f6_update_traces', **out)
+               cfg_B=cfg['B'], cfg_H=cfg['H'], cfg_W=cfg['W'], cfg_ncam=len(cfg['cams']))
+    save(name, **out)
 
 
 
@@ -970,6 +970,8 @@ SECTIONS = {
     'f13': f13_update_traces_2robots,
     'f14': f14_act_2robots,
     'f6': f6_update_traces,
+    # three LAMB update() steps of the REAL reference agent at BASELINE.json configs[1] geometry (V=100, depth 6, 2048 latents, B=1)
+    'f6c2': lambda: f6_update_traces('f6c2_update_traces_c2', CFG_C2, tags=(('a', False, False),)),
     'f9': f9_act,
     'f10': f10_depth,
     'f7': f7_lamb,

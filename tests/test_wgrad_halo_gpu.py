@@ -66,3 +66,68 @@ def test_wgrad_halo_depth_to_space_dy(mode):
     ref = _generic(lambda: ops.conv3d_wgrad(z, dyf, N, B, G, G, 3, -1, d2s=(s, 64), force_bf16=mode))
     got = ops.conv3d_wgrad(z, dyf, N, B, G, G, 3, -1, d2s=(s, 64), force_bf16=mode)
     close(got, ref, 3e-5, 'halo wgrad d2s ' + mode)
+
+
+# ------------------------------------------------------------------------------------------------ fp16 single-product mode
+def _f16(fn):
+    ops.WGRAD_PRECISION = 'fp16'
+    try:
+        return fn()
+    finally:
+        ops.WGRAD_PRECISION = ''
+
+
+@pytest.mark.parametrize('C0,C1,N,S,gain', [(64, 64, 64, 18, 1.0), (32, 0, 64, 21, 3e-9), (16, 0, 128, 17, 4e6)])
+def test_wgrad_halo_fp16_matches_fp64(C0, C1, N, S, gain):
+    """one fp16 product per term with the gradient operand scaled on the device: against float64 at the 2^-12 operand
+    rounding averaged over the B S^3 voxels of the reduction, for gradients of ordinary, tiny (3e-9: far below fp16's
+    smallest normal 6e-5) and huge (4e6: far above its largest 65504) magnitude -- the scale comes from the tensor itself."""
+    B = 2
+    a, c = rnd(B, C0, S, S, S), (rnd(B, C1, S, S, S, seed=5) if C1 else None)
+    dy = rnd(B, N, S, S, S, seed=3) * gain
+    dy[0, :, 0, 0, 0] *= 50.0                                     # a few spikes 50x above the bulk, like SpatialSoftmax3D's gradient
+    xin = torch.cat([a, c], 1) if C1 else a
+    W = torch.zeros(N, C0 + C1, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    ref_conv(xin.double(), W, None).backward(dy.double())
+    ref = ops.conv_weight_fwd(W.grad.float())
+    got = _f16(lambda: ops.conv3d_wgrad(cl(a).to(DEV), cl(dy).to(DEV), N, B, S, S, 3, -1, src1=cl(c).to(DEV) if C1 else None,
+                                        force_bf16='bf16x3'))
+    err = float((got.cpu() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 4e-4, err                                        # (bf16x3: 2e-5; plain bf16 would be ~3e-3)
+    x3 = ops.conv3d_wgrad(cl(a).to(DEV), cl(dy).to(DEV), N, B, S, S, 3, -1, src1=cl(c).to(DEV) if C1 else None, force_bf16='bf16x3')
+    assert float((x3.cpu() - ref).abs().max()) / float(ref.abs().max()) < 3e-5
+
+
+def test_wgrad_halo_fp16_depth_to_space_tap_masks_and_saturation():
+    """the polyphase up-conv's gradient (fine-grid dY, per-phase tap masks) in fp16; activations beyond fp16's range saturate
+    at 65504 instead of turning the gradient into inf / NaN."""
+    B, C, G, s, k = 1, 64, 20, 5, 5
+    z = cl(rnd(B, C, G, G, G)).to(DEV)
+    dyf = cl(rnd(B, 64, G * s, G * s, G * s, seed=3) * 1e-6).to(DEV)
+    N = s ** 3 * 64
+    st = ops.polyphase_structure(k, s, DEV)
+    kw = dict(d2s=(s, 64), force_bf16='bf16x3', phase_mask=st['phase_mask_t'], flops_frac=st['frac'])
+    ref = ops.conv3d_wgrad(z, dyf, N, B, G, G, 3, -1, **kw)
+    got = _f16(lambda: ops.conv3d_wgrad(z, dyf, N, B, G, G, 3, -1, **kw))
+    assert float((got - ref).abs().max()) / float(ref.abs().max()) < 1e-3
+    assert torch.equal(got == 0, ref == 0)                        # the structurally zero (tap, phase) blocks stay exactly zero
+    z[0, 3, 3, 3, :] = 1e9
+    big = _f16(lambda: ops.conv3d_wgrad(z, dyf, N, B, G, G, 3, -1, **kw))
+    assert bool(torch.isfinite(big).all())
+
+
+def test_absmax_scale():
+    for n, val in ((5, 3.0), (1 << 20, 1e-7), (12345, 7e5), (64, 0.0)):
+        x = torch.rand(n, device=DEV) * val
+        if n > 100:
+            x[n // 3] = -val * 1.5                                # the maximum is a negative element
+        sc = ops.absmax_scale(x).cpu()
+        m = float(x.abs().max())
+        if m == 0:
+            assert sc.tolist() == [1.0, 1.0]
+            continue
+        assert 2.0 ** 14 <= m * float(sc[0]) < 2.0 ** 15 and float(sc[0]) * float(sc[1]) == 1.0
+        assert float(torch.log2(sc[0])) == round(float(torch.log2(sc[0])))
+    x = torch.ones(100, device=DEV)
+    x[7] = float('nan')
+    assert ops.absmax_scale(x).cpu().tolist() == [1.0, 1.0]      # non-finite input: no scaling (the NaN then shows in the result)

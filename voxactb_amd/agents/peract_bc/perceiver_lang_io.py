@@ -327,6 +327,12 @@ class PerceiverEngine:
         # precision of the matrix products of the BACKWARD pass ('' = same as the forward); see DESIGN.md section 4a
         self.bwd_precision = os.environ.get('VOXACTB_BWD_PRECISION', '')
         self.attn_bwd_precision = os.environ.get('VOXACTB_ATTN_BWD_PRECISION', '')
+        # weight gradients of the two big 3x3x3 convs (`final`, the polyphase up-conv) when the backward runs in 'bf16x3':
+        # 'fp16' (default) = one fp16 product per term, the gradient operand scaled by a power of two taken from its largest
+        # magnitude on the device; 'bf16x3' = the triple.  Leaves of the backward pass: nothing downstream sees their rounding.
+        self.wgrad_precision = os.environ.get('VOXACTB_WGRAD_PRECISION', 'fp16')
+        if self.wgrad_precision not in ('fp16', 'bf16x3'):
+            raise ValueError('VOXACTB_WGRAD_PRECISION must be fp16 or bf16x3')
 
     # -------------------------------------------------------------------------------------------------- helpers
     def _draw_seed(self):
@@ -604,11 +610,13 @@ class PerceiverEngine:
         d_arm [B,2] or None.  Accumulates into every parameter's .grad.  `on_bucket_ready(name)` is called as soon as the
         last kernel that writes gradients of bucket `name` (see grad_buckets) has been enqueued."""
         ops.PRECISION = self.bwd_precision or self.precision
+        ops.WGRAD_PRECISION = 'fp16' if (ops.PRECISION == 'bf16x3' and self.wgrad_precision == 'fp16') else ''
         self._on_bucket = on_bucket_ready
         try:
             return self._backward(c, dq_trans, d_o, d_arm, dq_trans_left, d_o_left)
         finally:
             ops.PRECISION = 'fp32'
+            ops.WGRAD_PRECISION = ''
 
     def _backward(self, c, dq_trans, d_o, d_arm=None, dq_trans_left=None, d_o_left=None):
         m = self.m

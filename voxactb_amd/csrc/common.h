@@ -40,6 +40,15 @@ __device__ __forceinline__ unsigned vxb_pack_bf16(float lo, float hi) {
     return t.u;
 }
 
+// two fp32 -> packed fp16 pair, round-to-nearest-even: one v_cvt_pk_f16_f32 on gfx950 (overflow -> inf: clamp first)
+typedef _Float16 vxb_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned vxb_pack_f16(float lo, float hi) {
+    const vxb_f32x2 v = {lo, hi};
+    union { vxb_f16x2 h; unsigned u; } t;
+    t.h = __builtin_convertvector(v, vxb_f16x2);
+    return t.u;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

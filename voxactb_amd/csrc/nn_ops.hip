@@ -201,6 +201,55 @@ __global__ void __launch_bounds__(256) sum_splits_kernel(const float* __restrict
     }
 }
 
+__global__ void __launch_bounds__(256) sum_splits_dev_kernel(const float* __restrict__ part, int nsplit, long long n,
+                                                             float* __restrict__ dst, int accumulate, const float* __restrict__ alpha_p) {
+    const float alpha = *alpha_p;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += part[(long long)k * n + i];
+        s *= alpha;
+        if (accumulate) dst[i] += s; else dst[i] = s;
+    }
+}
+
+// max |x| as an integer maximum of the magnitude bits: NaN > inf > every finite value, so a non-finite element is not lost
+__global__ void __launch_bounds__(256) absmax_part_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ part) {
+    __shared__ unsigned red[4];
+    unsigned m = 0;
+    const long long n4 = n >> 2;
+    const uint4* __restrict__ p = reinterpret_cast<const uint4*>(x);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const uint4 v = p[i];
+        m = max(max(m, v.x & 0x7fffffffu), max(max(v.y & 0x7fffffffu, v.z & 0x7fffffffu), v.w & 0x7fffffffu));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = max(m, __float_as_uint(x[(n4 << 2) + threadIdx.x]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
+}
+
+__global__ void __launch_bounds__(256) absmax_final_kernel(const unsigned* __restrict__ part, int nb, float* __restrict__ scale) {
+    __shared__ unsigned red[4];
+    unsigned m = 0;
+    for (int i = threadIdx.x; i < nb; i += 256) m = max(m, part[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(red[0], red[1]), max(red[2], red[3]));
+        int k = 0;                                           // scale = 2^k
+        if (m != 0 && m < 0x7f800000u) {
+            const int e = (int)(m >> 23) - 127;              // m in [2^e, 2^(e+1)) (a denormal maximum: e = -127, clamped below)
+            k = min(max(14 - e, -100), 100);
+        }
+        scale[0] = __uint_as_float((unsigned)(k + 127) << 23);
+        scale[1] = __uint_as_float((unsigned)(127 - k) << 23);
+    }
+}
+
 // column sums of a DENSE [rows, N] matrix whose row length divides 1024 floats (N = 64 ... 1024, the bias gradients of
 // the voxel-sized convs): the slab is streamed as one flat array with float4 loads -- thread t always lands on the same
 // 4 columns, so it keeps 4 running sums and the block folds the 1024 / N threads of a column group at the end.
@@ -659,6 +708,24 @@ extern "C" int vxb_sum_splits_f32(const float* part, int nsplit, int64_t n, floa
                            (long long)n, dst, accumulate);
     else
         hipLaunchKernelGGL(sum_splits_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, part, nsplit, (long long)n, dst, accumulate, alpha);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+extern "C" int vxb_sum_splits_dev_f32(const float* part, int nsplit, int64_t n, float* dst, int accumulate, const float* alpha,
+                                      vxb_stream_t stream) {
+    if (!part || !dst || !alpha || nsplit < 1 || n < 1) return VXB_EARG;
+    hipLaunchKernelGGL(sum_splits_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, part, nsplit, (long long)n, dst, accumulate, alpha);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+extern "C" int vxb_absmax_scale_f32(const float* x, int64_t n, float* ws, float* scale, vxb_stream_t stream) {
+    if (!x || !ws || !scale || n < 1) return VXB_EARG;
+    if ((uintptr_t)x & 15) return VXB_ESIZE;
+    const int nb = (int)min((long long)1024, (long long)vxb_cdiv(n, 1024));
+    hipLaunchKernelGGL(absmax_part_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, (long long)n, reinterpret_cast<unsigned*>(ws));
+    hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const unsigned*>(ws), nb, scale);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }

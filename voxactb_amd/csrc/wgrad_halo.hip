@@ -1,4 +1,4 @@
-// LDS-halo weight gradient of a 3x3x3 stride-1 conv3d on the bf16 matrix cores ('bf16' and 'bf16x3' precisions):
+// LDS-halo weight gradient of a 3x3x3 stride-1 conv3d on the 16-bit matrix cores ('bf16', 'bf16x3' and 'fp16' products):
 //     part[z][(tap, ci)][n] = sum over the z-th slice of voxel tiles of  x[clamp(pos + tap + off)][ci] * dY[pos][n]
 // (the `final` conv of the Q-function, perceiver_lang_io.py:462, and the polyphase form of the decoder's up-conv,
 // network_utils.py:245-250, whose dY is gathered from the fine grid by space-to-depth).
@@ -22,6 +22,7 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
@@ -51,12 +52,26 @@ struct VxbWhArgs {
     int dbg;                      // timing experiments only (vxb_debug_set_wgrad_halo_experiment); results are WRONG when != 0
     const unsigned* phase_mask;   // d2s: bit t of phase_mask[column block] clear -> that (tap, phase) weight block is
                                   // structurally zero (polyphase up-conv) and is neither computed nor stored
+    const float* dy_scale;        // 'fp16' products: dY is multiplied by *dy_scale (a power of two on the device, chosen from
+                                  // the tensor's largest magnitude: vxb_absmax_scale_f32) before the conversion; part = scale * dW
 };
 typedef VxbWhArgs WhArgs;
 
 namespace {
 
-__device__ __forceinline__ unsigned wh_pack2(float lo, float hi) { return vxb_pack_bf16(lo, hi); }
+// PM = product mode: 0 plain bf16, 1 bf16x3 (hi/lo planes, three MFMAs), 2 plain fp16 (11-bit mantissa, 5-bit exponent: the
+// gradient operand is pre-scaled, the activation operand saturates at the largest half instead of becoming inf)
+template <int PM>
+__device__ __forceinline__ unsigned wh_pack2(float lo, float hi) {
+    if (PM == 2) return vxb_pack_f16(__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f));
+    return vxb_pack_bf16(lo, hi);
+}
+
+template <int PM>
+__device__ __forceinline__ f32x4 wh_mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+    if (PM == 2) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 
 __device__ __forceinline__ bf16x8 wh_frag(const u16* p0, const u16* p1) {
     union { s16x4 s[2]; bf16x8 v; } u;
@@ -69,8 +84,9 @@ __device__ __forceinline__ bf16x8 wh_frag(const u16* p0, const u16* p1) {
 // chunk each and SHARE the dY tile -- per MFMA 29 % less staging work (10 instead of 14 loads + conversions per thread and
 // tile), one workgroup per CU.  (Predicted from the timing experiments below: - 9 %.  Measured: - 2.7 % dense, + 5 % with tap
 // masks -- the second resident workgroup does hide part of the staging after all.)
-template <int X3, int WTD, int WTH, int NCH>
+template <int PM, int WTD, int WTH, int NCH>
 __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel(WhArgs g) {
+    constexpr int X3 = PM == 1;
     constexpr int NTH = 256 * NCH;
     constexpr int XH = WTH + 2;                           // halo h extent; d extent WTD + 2, w extent 10
     constexpr int XSLOTS = (WTD + 2) * XH * XW;           // 400 / 360
@@ -175,6 +191,7 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
         }
         okm = m;
     };
+    const float dysc = (PM == 2 && g.dy_scale) ? *g.dy_scale : 1.0f;
     auto stage = [&]() {
 #pragma unroll
         for (int i = 0; i < NXL; ++i) {
@@ -184,12 +201,12 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
                 const int e = e0 - lch * XF4 + lch * (1 + X3) * XPL / 4;     // slot index inside the chunk's plane pair
                 if (!((okm >> i) & 1u)) px[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 uint2 pk;
-                pk.x = wh_pack2(px[i].x, px[i].y); pk.y = wh_pack2(px[i].z, px[i].w);
+                pk.x = wh_pack2<PM>(px[i].x, px[i].y); pk.y = wh_pack2<PM>(px[i].z, px[i].w);
                 *reinterpret_cast<uint2*>(&xs[(e >> 2) * 16 + (e & 3) * 4]) = pk;
                 if (X3) {
                     uint2 q;
-                    q.x = wh_pack2(px[i].x - __uint_as_float(pk.x << 16), px[i].y - __uint_as_float(pk.x & 0xffff0000u));
-                    q.y = wh_pack2(px[i].z - __uint_as_float(pk.y << 16), px[i].w - __uint_as_float(pk.y & 0xffff0000u));
+                    q.x = wh_pack2<PM>(px[i].x - __uint_as_float(pk.x << 16), px[i].y - __uint_as_float(pk.x & 0xffff0000u));
+                    q.y = wh_pack2<PM>(px[i].z - __uint_as_float(pk.y << 16), px[i].w - __uint_as_float(pk.y & 0xffff0000u));
                     *reinterpret_cast<uint2*>(&xs[XPL + (e >> 2) * 16 + (e & 3) * 4]) = q;
                 }
             }
@@ -198,13 +215,14 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
         for (int i = 0; i < NDL; ++i) {
             const int e = tid + NTH * i;
             if (!((okm >> (8 + i)) & 1u)) pd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (PM == 2) { pd[i].x *= dysc; pd[i].y *= dysc; pd[i].z *= dysc; pd[i].w *= dysc; }
             uint2 pk;
-            pk.x = wh_pack2(pd[i].x, pd[i].y); pk.y = wh_pack2(pd[i].z, pd[i].w);
+            pk.x = wh_pack2<PM>(pd[i].x, pd[i].y); pk.y = wh_pack2<PM>(pd[i].z, pd[i].w);
             *reinterpret_cast<uint2*>(&ds[(e >> 4) * DLD + (e & 15) * 4]) = pk;
             if (X3) {
                 uint2 q;
-                q.x = wh_pack2(pd[i].x - __uint_as_float(pk.x << 16), pd[i].y - __uint_as_float(pk.x & 0xffff0000u));
-                q.y = wh_pack2(pd[i].z - __uint_as_float(pk.y << 16), pd[i].w - __uint_as_float(pk.y & 0xffff0000u));
+                q.x = wh_pack2<PM>(pd[i].x - __uint_as_float(pk.x << 16), pd[i].y - __uint_as_float(pk.x & 0xffff0000u));
+                q.y = wh_pack2<PM>(pd[i].z - __uint_as_float(pk.y << 16), pd[i].w - __uint_as_float(pk.y & 0xffff0000u));
                 *reinterpret_cast<uint2*>(&ds[DPL + (e >> 4) * DLD + (e & 15) * 4]) = q;
             }
         }
@@ -273,15 +291,15 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
                 __builtin_amdgcn_sched_barrier(0);
                 if (X3) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[ti][j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) acc[ti][j] = wh_mfma<PM>(al, bh[j], acc[ti][j]);
                     __builtin_amdgcn_sched_barrier(0);
                     if (ti + 1 < 7) al = wh_frag(xa0 + XPL + toffs[ti + 1], xa1 + XPL + toffs[ti + 1]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[ti][j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) acc[ti][j] = wh_mfma<PM>(ah, bl[j], acc[ti][j]);
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[ti][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[ti][j] = wh_mfma<PM>(ah, bh[j], acc[ti][j]);
                 ah = ahn;
             }
         }
@@ -306,27 +324,29 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
 
 }  // namespace
 
-template <int X3, int TD, int TH, int NCH>
+template <int PM, int TD, int TH, int NCH>
 static int wgrad_halo_launch(WhArgs& g, int nsplit, hipStream_t st) {
+    constexpr int X3 = PM == 1;
     g.ntd = vxb_cdiv(g.S_out, TD); g.nth = vxb_cdiv(g.S_out, TH); g.ntw = vxb_cdiv(g.S_out, WTW);
     g.ntiles = (long long)g.B * g.ntd * g.nth * g.ntw;
     if (g.ntiles >= INT32_MAX) return VXB_ESIZE;
     g.tiles_per_split = (int)((g.ntiles + nsplit - 1) / nsplit);
     const size_t lds = (size_t)(1 + X3) * (NCH * (TD + 2) * (TH + 2) * XW * 16 + DPL) * sizeof(u16);
     dim3 grid((g.C0 + g.C1) / (16 * NCH), g.N / 64, nsplit);
-    if (hipFuncSetAttribute((const void*)wgrad_halo_kernel<X3, TD, TH, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
-    hipLaunchKernelGGL((wgrad_halo_kernel<X3, TD, TH, NCH>), grid, dim3(256 * NCH), lds, st, g);
+    if (hipFuncSetAttribute((const void*)wgrad_halo_kernel<PM, TD, TH, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
+    hipLaunchKernelGGL((wgrad_halo_kernel<PM, TD, TH, NCH>), grid, dim3(256 * NCH), lds, st, g);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
 
 #ifdef WH_T44_UNIT
-int vxb_wgrad_halo_launch_t44(VxbWhArgs& g, int x3, int nch, int nsplit, hipStream_t st) {
-    if (nch == 2) return x3 ? wgrad_halo_launch<1, 4, 4, 2>(g, nsplit, st) : wgrad_halo_launch<0, 4, 4, 2>(g, nsplit, st);
-    return x3 ? wgrad_halo_launch<1, 4, 4, 1>(g, nsplit, st) : wgrad_halo_launch<0, 4, 4, 1>(g, nsplit, st);
+int vxb_wgrad_halo_launch_t44(VxbWhArgs& g, int pm, int nch, int nsplit, hipStream_t st) {
+    if (pm == 2) return nch == 2 ? wgrad_halo_launch<2, 4, 4, 2>(g, nsplit, st) : wgrad_halo_launch<2, 4, 4, 1>(g, nsplit, st);
+    if (nch == 2) return pm ? wgrad_halo_launch<1, 4, 4, 2>(g, nsplit, st) : wgrad_halo_launch<0, 4, 4, 2>(g, nsplit, st);
+    return pm ? wgrad_halo_launch<1, 4, 4, 1>(g, nsplit, st) : wgrad_halo_launch<0, 4, 4, 1>(g, nsplit, st);
 }
 #else
-int vxb_wgrad_halo_launch_t44(VxbWhArgs& g, int x3, int nch, int nsplit, hipStream_t st);
+int vxb_wgrad_halo_launch_t44(VxbWhArgs& g, int pm, int nch, int nsplit, hipStream_t st);
 static int g_wh_nch = 0;          // experiment knob (vxb_debug_set_wgrad_halo_chunks): 0 = default, 1 / 2 = force
 
 static int g_wh_dbg = 0;
@@ -342,7 +362,7 @@ static inline int wgrad_halo_shape(int S, int x3) {
     return b <= a;
 }
 
-static int wgrad_halo_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out, int off,
+static int wgrad_halo_impl(int pm, const float* dy_scale, const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out, int off,
                            int replicate, const float* dy, int N, int64_t ldy, int d2s_s, int d2s_C, float* part, int nsplit,
                            const uint32_t* phase_mask, vxb_stream_t stream) {
     if (!src0 || !dy || !part || B < 1 || S_in < 1 || S_out < 1 || N < 1 || nsplit < 1) return VXB_EARG;
@@ -353,6 +373,7 @@ static int wgrad_halo_impl(int x3, const float* src0, const float* src1, int C0,
     g.src0 = src0; g.src1 = src1; g.dy = dy; g.part = part; g.C0 = C0; g.C1 = C1; g.B = B; g.S_in = S_in; g.S_out = S_out;
     g.off = off; g.replicate = replicate; g.N = N; g.Krows = 27 * (C0 + C1); g.ldy = ldy; g.d2s_s = d2s_s; g.d2s_C = d2s_C;
     g.phase_mask = phase_mask;
+    g.dy_scale = dy_scale;
     g.dbg = g_wh_dbg;
     if (nsplit > 65535 || N / 64 > 65535) return VXB_ESIZE;
     {   // voxel indices are 32-bit inside the kernel
@@ -364,9 +385,10 @@ static int wgrad_halo_impl(int x3, const float* src0, const float* src1, int C0,
     // + 2.7 % on the dense 128 -> 64 gradient at S = 100 (4.83 -> 4.70 ms), - 5 % on the tap-masked depth-to-space one (2.20 -> 2.31)
     int nch = ((C0 + C1) % 32 == 0 && d2s_s <= 0) ? 2 : 1;
     if (g_wh_nch) nch = (g_wh_nch == 2 && (C0 + C1) % 32 == 0) ? 2 : 1;
-    if (wgrad_halo_shape(S_out, x3)) return vxb_wgrad_halo_launch_t44(g, x3, nch, nsplit, st);
-    if (nch == 2) return x3 ? wgrad_halo_launch<1, 2, 8, 2>(g, nsplit, st) : wgrad_halo_launch<0, 2, 8, 2>(g, nsplit, st);
-    return x3 ? wgrad_halo_launch<1, 2, 8, 1>(g, nsplit, st) : wgrad_halo_launch<0, 2, 8, 1>(g, nsplit, st);
+    if (wgrad_halo_shape(S_out, pm == 1)) return vxb_wgrad_halo_launch_t44(g, pm, nch, nsplit, st);
+    if (pm == 2) return nch == 2 ? wgrad_halo_launch<2, 2, 8, 2>(g, nsplit, st) : wgrad_halo_launch<2, 2, 8, 1>(g, nsplit, st);
+    if (nch == 2) return pm ? wgrad_halo_launch<1, 2, 8, 2>(g, nsplit, st) : wgrad_halo_launch<0, 2, 8, 2>(g, nsplit, st);
+    return pm ? wgrad_halo_launch<1, 2, 8, 1>(g, nsplit, st) : wgrad_halo_launch<0, 2, 8, 1>(g, nsplit, st);
 }
 
 // 3x3x3 stride-1 specialisation of vxb_conv3d_wgrad_bf16_f32 / _bf16x3_f32 (same contract and part[z][K][N] layout;
@@ -376,16 +398,28 @@ static int wgrad_halo_impl(int x3, const float* src0, const float* src1, int C0,
 extern "C" int vxb_conv3_wgrad_halo_bf16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                                              int off, int replicate, const float* dy, int N, int64_t ldy, int d2s_s,
                                              int d2s_C, float* part, int nsplit, const uint32_t* phase_mask, vxb_stream_t stream) {
-    return wgrad_halo_impl(0, src0, src1, C0, C1, B, S_in, S_out, off, replicate, dy, N, ldy, d2s_s, d2s_C, part, nsplit, phase_mask, stream);
+    return wgrad_halo_impl(0, nullptr, src0, src1, C0, C1, B, S_in, S_out, off, replicate, dy, N, ldy, d2s_s, d2s_C, part, nsplit, phase_mask, stream);
 }
 
 extern "C" int vxb_conv3_wgrad_halo_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                                                int off, int replicate, const float* dy, int N, int64_t ldy, int d2s_s,
                                                int d2s_C, float* part, int nsplit, const uint32_t* phase_mask, vxb_stream_t stream) {
-    return wgrad_halo_impl(1, src0, src1, C0, C1, B, S_in, S_out, off, replicate, dy, N, ldy, d2s_s, d2s_C, part, nsplit, phase_mask, stream);
+    return wgrad_halo_impl(1, nullptr, src0, src1, C0, C1, B, S_in, S_out, off, replicate, dy, N, ldy, d2s_s, d2s_C, part, nsplit, phase_mask, stream);
 }
 
-// number of voxel tiles the two entries above split into z slices (for choosing nsplit)
+// The same gradient with ONE fp16 product per term (v_mfma_f32_16x16x32_f16, fp32 accumulate) instead of the bf16x3 triple:
+// a weight gradient is a leaf of the backward pass -- its rounding errors (2^-12 per operand, averaged over >= 10^5 voxels) do not
+// propagate, and against the reference's gradients at configs[1] / [2] size it is indistinguishable from the bf16x3 kernel
+// (tools/experiments/emu_precision.py).  Range: x saturates at +-65504; dY is multiplied by *dy_scale (device
+// float, a power of two, see vxb_absmax_scale_f32; NULL = 1) before the conversion and `part` comes out as dy_scale * dW.
+extern "C" int vxb_conv3_wgrad_halo_f16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
+                                            int off, int replicate, const float* dy, int N, int64_t ldy, int d2s_s,
+                                            int d2s_C, float* part, int nsplit, const uint32_t* phase_mask, const float* dy_scale,
+                                            vxb_stream_t stream) {
+    return wgrad_halo_impl(2, dy_scale, src0, src1, C0, C1, B, S_in, S_out, off, replicate, dy, N, ldy, d2s_s, d2s_C, part, nsplit, phase_mask, stream);
+}
+
+// number of voxel tiles the entries above split into z slices (for choosing nsplit)
 extern "C" size_t vxb_conv3_wgrad_halo_tiles(int B, int S_out, int x3) {
     if (B < 1 || S_out < 1) return 0;
     const int sh = wgrad_halo_shape(S_out, x3);

@@ -20,6 +20,11 @@ PRECISION = 'fp32'
 HALO_CONV = True     # 3x3x3 stride-1 bf16 convs go through the LDS-halo kernel (conv_halo_bf16.hip)
 HALO_D2S = False     # ... also the depth-to-space forward of the polyphase up-conv: measured 21.0 ms vs 19.3 ms generic at
                      # 20^3 x 8000 columns (the 4x8x8 tile wastes 44 % on a 20^3 grid and the halo is re-staged per column block)
+# Weight gradients of the 3x3x3 LDS-halo convs (`final`, the polyphase up-conv) in the 'bf16x3' precision: 'fp16' = ONE fp16
+# product per term with the gradient operand pre-scaled by a power of two from its largest magnitude (absmax_scale); '' = the
+# bf16x3 triple.  Set by PerceiverEngine.backward from its `wgrad_precision`.  A weight gradient is a leaf of the backward pass:
+# measured against the reference's gradients at configs[1] / [2] size the two are indistinguishable.
+WGRAD_PRECISION = ''
 _WCACHE = {}
 
 
@@ -210,7 +215,19 @@ def colsum(x, out, accumulate=False):
 
 
 def sum_splits(part, nsplit, n, dst, accumulate=False, alpha=1.0):
+    if isinstance(alpha, torch.Tensor):         # a factor that lives on the device (e.g. 1 / the fp16 operand scale): no host sync
+        call('vxb_sum_splits_dev_f32', part, nsplit, n, dst, int(accumulate), alpha)
+        return
     call('vxb_sum_splits_f32', part, nsplit, n, dst, int(accumulate), float(alpha))
+
+
+def absmax_scale(x):
+    """-> device tensor [scale, 1 / scale]: the power of two that maps max |x| into [2^14, 2^15) (vxb_absmax_scale_f32)."""
+    assert x.is_contiguous() and x.dtype == torch.float32
+    ws = torch.empty(1024, dtype=torch.float32, device=x.device)
+    sc = torch.empty(2, dtype=torch.float32, device=x.device)
+    call('vxb_absmax_scale_f32', x, x.numel(), ws, sc)
+    return sc
 
 
 def layernorm_fwd(x, gamma, beta, eps=1e-5):
@@ -330,7 +347,18 @@ def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
             part = torch.zeros((ns, K, N), dtype=torch.float32, device=src0.device)      # skipped blocks stay zero
         else:
             part, phase_mask, flops_frac = torch.empty((ns, K, N), dtype=torch.float32, device=src0.device), None, 1.0
-        _lib.set_meta(label or 'conv3d_wgrad[k%d s%d %d->%d S%d]' % (kext, stride, C0 + C1, N, S_out), 2.0 * P * N * K * flops_frac)
+        lbl = label or 'conv3d_wgrad[k%d s%d %d->%d S%d]' % (kext, stride, C0 + C1, N, S_out)
+        f16 = mode == 'bf16x3' and WGRAD_PRECISION == 'fp16' and dy.is_contiguous()
+        if f16:
+            _lib.set_meta(lbl, 0.0)
+            sc = absmax_scale(dy)
+            _lib.set_meta(lbl, 2.0 * P * N * K * flops_frac)
+            call('vxb_conv3_wgrad_halo_f16_f32', src0, src1, C0, C1, B, S_in, S_out, off, int(replicate), dy, N,
+                 ldy if ldy is not None else N, d2s[0], d2s[1], part, ns, phase_mask, sc)
+            out = torch.empty((K, N), dtype=torch.float32, device=src0.device)
+            sum_splits(part, ns, K * N, out, alpha=sc[1:])
+            return out
+        _lib.set_meta(lbl, 2.0 * P * N * K * flops_frac)
         call('vxb_conv3_wgrad_halo_bf16x3_f32' if mode == 'bf16x3' else 'vxb_conv3_wgrad_halo_bf16_f32', src0, src1, C0, C1,
              B, S_in, S_out, off, int(replicate), dy, N, ldy if ldy is not None else N, d2s[0], d2s[1], part, ns, phase_mask)
         if ns == 1:
