@@ -395,10 +395,13 @@ int vxb_ce_rows_f32(const float* logits, int64_t ld, int rows, int nseg, const i
                     vxb_stream_t stream);
 
 /* Fused multi-tensor LAMB (peract/helpers/optim/lamb.py:94-122; no bias correction, ||w|| clamp 10).  The betas come as
- * doubles: 1 - beta is evaluated in double and then rounded to fp32, as Python evaluates `alpha=1 - beta1` upstream. */
+ * doubles: 1 - beta is evaluated in double and then rounded to fp32, as Python evaluates `alpha=1 - beta1` upstream.
+ * skip_if_negative (optional device word): when it holds a negative value the step is a no-op (weights, moments untouched):
+ * the status word of vxb_se3_relabel_f32 -- upstream raises before the forward pass (augmentation.py:119-120), here the
+ * poisoned step must not reach the optimizer state. */
 int vxb_lamb_step_f32(float* w, const float* g, float* m, float* v, float* upd, const int32_t* chunks, int nchunks,
                       const int32_t* first, int ntensors, float* part, float* trust, float lr, double beta1, double beta2,
-                      float eps, float weight_decay, vxb_stream_t stream);
+                      float eps, float weight_decay, const int32_t* skip_if_negative, vxb_stream_t stream);
 
 /* 256 x 256-tile GEMM for the big linear layers (nn.Linear forward / data gradient at M = B * 2048 latent rows,
  * perceiver_lang_io.py:80-132): C[M][N] (+)= act(A[M][K] @ W[N][K]^T + bias) (+ residual).  Both operands are bf16 planes
@@ -410,7 +413,7 @@ int vxb_gemm256_f32(const void* A_planes, int64_t lda, const void* W_planes, int
 /* torch.optim.Adam step over a flat parameter buffer (the reference's `optimizer: adam` alternative, agent :263-268):
  * L2 weight decay folded into the gradient, bias correction with `step` (1-based), eps 1e-8 by default upstream. */
 int vxb_adam_step_f32(float* w, const float* g, float* m, float* v, int64_t n, float lr, double beta1, double beta2, float eps,
-                      float weight_decay, int64_t step, vxb_stream_t stream);
+                      float weight_decay, int64_t step, const int32_t* skip_if_negative, vxb_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -963,6 +963,8 @@ SECTIONS = {
     'f5g': lambda: encoder_fixture('f5g_encoder_c2_grads', CFG_C2, with_grads=True, digest=True, f64_grads=True),
     'f5c3': lambda: encoder_fixture('f5c3_encoder_c3_digest', CFG_C3, arm=True, with_grads=True, digest=True, crop=True, f64_grads=True),
     'f5v200': lambda: encoder_fixture('f5v200_encoder_c5_digest', CFG_C5, with_grads=False, digest=True),
+    # the same grid with the reference's loss and backward (~45 GB of autograd state: run it alone, under a memory watchdog)
+    'f5v200g': lambda: encoder_fixture('f5v200g_encoder_c5_grads', CFG_C5, with_grads=True, digest=True, check_oracle=False, f64_grads=True),
     'f11tiny': lambda: encoder2_fixture('f11_encoder_2robots_tiny', CFG_TINY),
     'f11c1': lambda: encoder2_fixture('f11_encoder_2robots_c1', CFG_C1),
     'f11c2': lambda: encoder2_fixture('f11c2_encoder_2robots_c2_digest', CFG_C2, digest=True),
@@ -988,7 +990,7 @@ if __name__ == '__main__':
     todo = [s for s in a.only.split(',') if s] or list(SECTIONS)
     torch.manual_seed(0)
     for s in todo:
-        if s in ('f5', 'f5g', 'f5c3', 'f5v200') and a.skip_c2:
+        if s in ('f5', 'f5g', 'f5c3', 'f5v200', 'f5v200g') and a.skip_c2:
             continue
         print('==', s)
         SECTIONS[s]()

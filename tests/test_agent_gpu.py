@@ -20,7 +20,7 @@ def make_agent(g, tag, **over):
                          method__num_latents=int(g['cfg_latents']), replay__batch_size=int(g['cfg_B']),
                          method__input_dropout=0.0, method__attn_dropout=0.0,
                          method__which_arm='dominant' if arm else 'right', method__arm_pred_loss=arm,
-                         method__crop_target_obj_voxel=arm, rlbench__cameras=['front', 'wrist'],
+                         method__crop_target_obj_voxel=arm, rlbench__cameras=_cams(g),
                          rlbench__camera_resolution=[int(g['cfg_H']), int(g['cfg_W'])], **over)
     cfg.method.transform_augmentation.apply_se3 = False
     agent = lu.create_agent(cfg)
@@ -30,9 +30,13 @@ def make_agent(g, tag, **over):
     return agent, cfg
 
 
+def _cams(g):
+    return synthetic.CAMERAS4[:int(g['cfg_ncam'])] if 'cfg_ncam' in g.files and int(g['cfg_ncam']) > 2 else ['front', 'wrist']
+
+
 def raw_batch(g, tag, seed):
     arm = tag == 'b'
-    rs = synthetic.make_replay_sample(int(g['cfg_B']), ['front', 'wrist'], (int(g['cfg_H']), int(g['cfg_W'])), int(g['cfg_V']),
+    rs = synthetic.make_replay_sample(int(g['cfg_B']), _cams(g), (int(g['cfg_H']), int(g['cfg_W'])), int(g['cfg_V']),
                                       7 if arm else 4, seed=seed, arm_pred_loss=arm, crop_target_obj_voxel=arm)
     return {k: v.to(DEV) for k, v in rs.items()}
 
@@ -61,6 +65,40 @@ def test_update_traces(golden, tag):
     asum = np.array([float(p.detach().double().abs().sum()) for _, p in qa._q.named_parameters()])
     assert np.abs(asum - g[tag + '_param_abs_sums']).max() / np.abs(g[tag + '_param_abs_sums']).max() < 1e-3
     assert np.isfinite(sums).all()
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_update_traces_at_headline_size(golden, precision):
+    """fixture F6c2: three LAMB update() steps of the REAL reference agent (QAttentionPerActBCAgent, DDP-gloo world 1,
+    qattention_peract_bc_agent.py:418-641 + lamb.py:60-124 over 33 M parameters) at BASELINE.json configs[1] geometry -- V=100,
+    4 cameras 128x128, depth 6, 2048 latents, B=1 -- replayed in the exact-fp32 AND the default precision (bf16x3 products, fp16
+    conv weight gradients): step 0 is forward parity (1e-4); steps 1 and 2 have passed through LAMB, whose sign-like first
+    updates amplify fp32 noise of mathematically-zero gradients (make_golden.py:f6: the reference-vs-oracle spread, two fp32
+    implementations, is 2e-5 here and ~1e-3 at the small configs) -- every later loss within 5e-3, and the parameters after
+    three steps within 1e-3 of the reference's in sum |w|."""
+    g = golden('f6c2_update_traces_c2')
+    os.environ['VOXACTB_PRECISION'] = precision
+    try:
+        agent, _ = make_agent(g, 'a')
+    finally:
+        del os.environ['VOXACTB_PRECISION']
+    qa = agent._pose_agent._qattention_agents[0]
+    assert qa._q.encoder.engine().precision == precision
+    ref = g['a_losses']
+    got = []
+    for step in range(3):
+        r = agent.update(step, raw_batch(g, 'a', 10 + step))
+        s = qa._summaries
+        got.append([float(r['total_losses']), float(s['losses/trans_loss']), float(s['losses/rot_loss']),
+                    float(s['losses/grip_loss']), float(s['losses/collision_loss']), 0.0])
+    got = np.array(got)
+    print(precision, got[:, 0], ref[:, 0], np.abs(got - ref).max(0))
+    assert np.abs(got[0] - ref[0]).max() < 1e-4
+    assert np.abs(got - ref).max() < 5e-3
+    asum = np.array([float(p.detach().double().abs().sum()) for _, p in qa._q.named_parameters()])
+    assert np.abs(asum - g['a_param_abs_sums']).max() / np.abs(g['a_param_abs_sums']).max() < 1e-3
+    del agent
+    torch.cuda.empty_cache()
 
 
 def test_checkpoint_roundtrip_act_and_summaries(golden, tmp_path):
@@ -114,6 +152,17 @@ def test_se3_augmentation_path_runs(golden):
     # a keyframe pose far outside the scene: every attempt fails -> NaN loss on that step, the exception on the next one
     bad = raw_batch(g, 'a', 12)
     bad['gripper_pose'][:, :, :3] = -50.0
+    before = qa._arena.flat_w.clone()
+    m_before = qa._optimizer.exp_avg.clone()
     assert not np.isfinite(float(agent.update(2, bad)['total_losses']))
+    # the reference raises BEFORE the forward pass (augmentation.py:119-120): the failed step must leave weights and optimizer
+    # moments exactly as they were (the optimizer kernels read the status word on the device and do nothing)
+    assert torch.equal(qa._arena.flat_w, before) and torch.equal(qa._optimizer.exp_avg, m_before)
+    assert bool(torch.isfinite(qa._arena.flat_w).all())
     with pytest.raises(Exception, match='Failing to perturb'):
         agent.update(3, raw_batch(g, 'a', 13))
+    # ... and a checkpoint taken right after a failed step raises instead of persisting it unseen
+    agent.update(4, raw_batch(g, 'a', 14))
+    agent.update(5, bad)
+    with pytest.raises(Exception, match='Failing to perturb'):
+        agent.save_weights('/tmp')

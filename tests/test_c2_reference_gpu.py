@@ -129,11 +129,15 @@ def _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, tag):
     assert not bad, (tag, bad)
 
 
-def _run(g, precision, tag, backward):
+def _run(g, precision, tag, backward, bwd_precision='', wgrad_precision=None):
     enc, rs, grid, arm, V, B = _setup(g)
     _check_grid(g, grid)
     eng = enc.engine()
     eng.precision = precision
+    eng.bwd_precision = bwd_precision
+    if wgrad_precision is not None:
+        eng.wgrad_precision = wgrad_precision
+    tag = tag + ('|bwd ' + bwd_precision if bwd_precision else '') + ('|wgrad ' + wgrad_precision if wgrad_precision else '')
     outs, cache = eng.forward(grid, rs['low_dim_state'].to(DEV), rs['lang_token_embs'].to(DEV), training=False, save=backward)
     errs = _check_forward(g, outs, arm, '%s/%s' % (tag, precision))
     if backward:
@@ -165,3 +169,16 @@ def test_c3_twin_agent_shape_digest(golden, precision):
 def test_c5_v200_forward_digest(golden, precision):
     """BASELINE.json configs[4] grid: V=200 (40^3 patches, 64 077 context tokens), depth 6, 2048 latents, forward."""
     _run(golden('f5v200_encoder_c5_digest'), precision, 'f5v200', backward=False)
+
+
+@pytest.mark.parametrize('fixture', ['f5g_encoder_c2_grads', 'f5c3_encoder_c3_digest'])
+@pytest.mark.parametrize('fwd,bwd,wgrad', [('fp32', 'bf16x3', 'bf16x3'), ('fp32', 'bf16x3', 'fp16'), ('bf16x3', '', 'bf16x3')])
+def test_forward_and_backward_precisions_separately(golden, fixture, fwd, bwd, wgrad):
+    """which pass the gradient differences of the default precision come from: an exact-fp32 FORWARD followed by the bf16x3
+    BACKWARD (conv / linear products; the attention core of that cache is the unfused fp32 one), with the conv weight gradients
+    as the bf16x3 triple or as single fp16 products, and the all-bf16x3 pair without the fp16 weight gradients -- every
+    combination holds the same gates against the reference's gradients as the default (3e-3 on norms and on the small tensors
+    in full).  Measured (tools/experiments/emu_precision.py): worst gradient-norm error 9e-5 (fp32 / fp32),
+    9e-5 (fp32 / bf16x3), 1.2e-4 (bf16x3 / bf16x3) on F5g -- the backward products are not what moves the gradients; a
+    forward difference of 1e-5 is (SpatialSoftmax3D's 1 / 0.01 temperature, max-pool ties)."""
+    _run(golden(fixture), fwd, fixture[:4], backward=True, bwd_precision=bwd, wgrad_precision=wgrad)

@@ -44,3 +44,43 @@ def test_stream_feeds_update_with_store_contents():
         losses.append(float(agent.update(step, batch)['total_losses']))
     stream.close()
     assert all(np.isfinite(losses))
+
+
+def test_stream_does_not_refill_a_staging_buffer_under_a_pending_copy():
+    """the consumer runs several batches ahead of a stalled compute stream (no .item() per step: augmentation off, bench loops):
+    every batch that comes out must still be the batch that was sampled for it -- rows consistent across elements and in the
+    order the sampler drew them -- i.e. a pinned staging buffer is never refilled while the copy out of it is still queued."""
+    obs = [R.ObservationElement('low_dim_state', (4,), np.float32), R.ObservationElement('front_rgb', (3, 64, 64), np.float32),
+           R.ReplayElement('task', (), str)]
+    buf = R.ShardReplayBuffer(batch_size=8, timesteps=1, replay_capacity=4096, action_shape=(8,), action_dtype=np.float32,
+                              observation_elements=obs, extra_replay_elements=[R.ReplayElement('demo', (), bool)], rank=0, num_replicas=1)
+    for i in range(600):
+        if i % 6 == 5:
+            buf.add_final(low_dim_state=np.full(4, i, np.float32), front_rgb=np.full((3, 64, 64), i, np.float32), task='t%d' % (i % 3))
+        else:
+            buf.add(np.full(8, i, np.float32), 0.0, i % 6 == 4, False, low_dim_state=np.full(4, i, np.float32),
+                    front_rgb=np.full((3, 64, 64), i, np.float32), demo=True, task='t%d' % (i % 3))
+    buf.seed(1)
+    drawn = []
+    real = buf.sample_index_batch
+
+    def logged(n):
+        idx = real(n)
+        drawn.append(list(idx))
+        return idx
+    buf.sample_index_batch = logged
+    stream = R.DeviceBatchStream(buf, device=0, depth=2)
+    torch.cuda.synchronize()
+    torch.cuda._sleep(int(3e9))                      # ~1.5 s of nothing on the compute stream: the host runs ahead of the GPU
+    seen = []
+    for step, batch in zip(range(7), stream):
+        # "use" the batch on the stalled stream, without a host sync
+        seen.append((batch['indices'][:, 0].clone(), batch['low_dim_state'][:, 0, 0].clone(), batch['front_rgb'][:, 0, 0, 0, 0].clone(),
+                     batch['front_rgb'][:, 0, 2, 63, 63].clone(), batch['action'][:, 0, 7].clone()))
+    stream.close()
+    torch.cuda.synchronize()
+    for step, (idx, a, b, c, d) in enumerate(seen):
+        want = np.asarray(drawn[step], np.float32)
+        assert np.array_equal(idx.cpu().numpy(), want.astype(np.int32)), step
+        for t in (a, b, c, d):
+            assert np.array_equal(t.cpu().numpy(), want), step

@@ -263,13 +263,33 @@ class QAttentionPerActBCAgent(Agent):
         return buf[:, :2]
 
     def _check_se3_status(self):
-        """augmentation.py:119-120 raises after 100 failed attempts; the device kernel flags the same condition (and poisons
-        that step's labels, so its loss is NaN) -- surfaced here, at the start of the next update(), without a mid-step sync."""
+        """augmentation.py:119-120 raises after 100 failed attempts, BEFORE the forward pass.  The device kernel flags the same
+        condition (and poisons that step's labels, so its loss is NaN); the optimizer kernels read the flag on the device and
+        make that step a no-op (`_gate_step`), so weights and moments are exactly what they were -- the exception itself is
+        raised here, at the start of the next update() / in save_weights(), without a mid-step sync."""
         st = getattr(self, '_se3_status', None)
         if st is not None:
             self._se3_status = None
+            self._optimizer.skip_flag = None
             if int(st.item()) < 0:
                 raise Exception('Failing to perturb action and keep it within bounds.')
+
+    def _gate_step(self):
+        """hand the SE(3) status word of this step to the optimizer kernels (negative -> no-op); with several ranks every rank
+        must take the same decision, so the words are MIN-reduced first (4 bytes, started here, overlapped with the step)."""
+        st = getattr(self, '_se3_status', None)
+        self._status_work = None
+        if st is None:
+            return
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            self._status_work = torch.distributed.all_reduce(st, op=torch.distributed.ReduceOp.MIN, async_op=True)
+        self._optimizer.skip_flag = st
+
+    def _step_optimizer(self):
+        if getattr(self, '_status_work', None) is not None:
+            self._status_work.wait()
+            self._status_work = None
+        self._optimizer.step()
 
     # ------------------------------------------------------------------------------------------------------------ update
     def update(self, step: int, replay_sample: dict) -> dict:
@@ -306,6 +326,7 @@ class QAttentionPerActBCAgent(Agent):
                 action_gripper_pose.to(device), action_rot_grip.to(device), bounds, self._layer,
                 self._transform_augmentation_xyz, self._transform_augmentation_rpy,
                 self._transform_augmentation_rot_resolution, self._voxel_size, self._rotation_resolution, device)
+            self._gate_step()
 
         # forward (agent :486-508): voxelize (the augmentation's rigid transform rides on the point load) + encoder,
         # keeping the backward cache
@@ -353,7 +374,7 @@ class QAttentionPerActBCAgent(Agent):
         # next to the rest of the backward pass; the optimizer waits for all of them (DDP's bucketed overlap, agent :50-54)
         eng.backward(cache, dq, d_o, d_arm, on_bucket_ready=self._arena.reduce_bucket)
         self._arena.finish_reduce()
-        self._optimizer.step()
+        self._step_optimizer()
 
         coords = torch.stack([torch.div(torch.div(amax, V, rounding_mode='trunc'), V, rounding_mode='trunc'),
                               torch.div(amax, V, rounding_mode='trunc') % V, amax % V], 1).long()
@@ -486,6 +507,8 @@ class QAttentionPerActBCAgent(Agent):
         print("loaded weights from %s" % ckpt_file)
 
     def save_weights(self, savedir: str):
+        if getattr(self, '_optimizer', None) is not None:
+            self._check_se3_status()           # the last training step's augmentation status has not been looked at yet
         torch.save(self._q.state_dict(), os.path.join(savedir, '%s.pt' % self._name))
 
 
@@ -586,6 +609,7 @@ class QAttentionPerActBCAgent2Robots(QAttentionPerActBCAgent):
                     action_rot_grip_left.to(device), bounds, L, self._transform_augmentation_xyz,
                     self._transform_augmentation_rpy, self._transform_augmentation_rot_resolution, self._voxel_size,
                     self._rotation_resolution, device)
+            self._gate_step()
 
         grid = self._q.voxelize(obs, pcd, bounds, xform)
         voxel_grid = grid.permute(0, 4, 1, 2, 3).detach()
@@ -604,7 +628,7 @@ class QAttentionPerActBCAgent2Robots(QAttentionPerActBCAgent):
         eng.backward(cache, r['dq'], r['d_o'], None, on_bucket_ready=self._arena.reduce_bucket, dq_trans_left=l['dq'],
                      d_o_left=l['d_o'])
         self._arena.finish_reduce()
-        self._optimizer.step()
+        self._step_optimizer()
 
         V = self._voxel_size
 

@@ -1082,8 +1082,10 @@ __global__ void __launch_bounds__(256) weff_bwd_kernel(const float* __restrict__
 __global__ void __launch_bounds__(256) lamb_stage1_kernel(const float* __restrict__ w, const float* __restrict__ g,
                                                           float* __restrict__ m, float* __restrict__ v, float* __restrict__ upd,
                                                           const int* __restrict__ chunks, float* __restrict__ part, float beta1,
-                                                          float beta2, float omb1, float omb2, float eps, float wd) {
+                                                          float beta2, float omb1, float omb2, float eps, float wd,
+                                                          const int* __restrict__ skip) {
     __shared__ float r1[4], r2[4];
+    if (skip && *skip < 0) return;             // a step whose inputs were flagged invalid on the device is a no-op (see the C entry)
     const int* ch = chunks + 3 * blockIdx.x;
     const long long start = ch[1];
     const int len = ch[2];
@@ -1124,7 +1126,9 @@ __global__ void lamb_stage2_kernel(const float* __restrict__ part, const int* __
     trust[t] = (wn == 0.f || an == 0.f) ? 1.0f : wn / an;
 }
 __global__ void __launch_bounds__(256) lamb_stage3_kernel(float* __restrict__ w, const float* __restrict__ upd,
-                                                          const int* __restrict__ chunks, const float* __restrict__ trust, float lr) {
+                                                          const int* __restrict__ chunks, const float* __restrict__ trust, float lr,
+                                                          const int* __restrict__ skip) {
+    if (skip && *skip < 0) return;
     const int* ch = chunks + 3 * blockIdx.x;
     const long long start = ch[1];
     const int len = ch[2];
@@ -1138,7 +1142,8 @@ __global__ void __launch_bounds__(256) lamb_stage3_kernel(float* __restrict__ w,
 // w -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, float beta2, float omb1, float omb2, float eps,
-                                                   float wd, float step_size, float bc2_sqrt) {
+                                                   float wd, float step_size, float bc2_sqrt, const int* __restrict__ skip) {
+    if (skip && *skip < 0) return;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         float gv = g[i];
         const float wv = w[i];
@@ -1154,11 +1159,11 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ w, const 
 }  // namespace
 
 extern "C" int vxb_adam_step_f32(float* w, const float* g, float* m, float* v, int64_t n, float lr, double beta1, double beta2,
-                                 float eps, float weight_decay, int64_t step, vxb_stream_t stream) {
+                                 float eps, float weight_decay, int64_t step, const int32_t* skip_if_negative, vxb_stream_t stream) {
     if (!w || !g || !m || !v || n < 1 || step < 1) return VXB_EARG;
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, (long long)n, (float)beta2,
-                       (float)(1.0 - beta1), (float)(1.0 - beta2), eps, weight_decay, (float)((double)lr / bc1), (float)sqrt(bc2));
+                       (float)(1.0 - beta1), (float)(1.0 - beta2), eps, weight_decay, (float)((double)lr / bc1), (float)sqrt(bc2), skip_if_negative);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
@@ -1412,15 +1417,18 @@ extern "C" int vxb_polyphase_weights_bwd_f32(const float* dWeff, const float* L,
 
 // chunks: int32 [nchunks][3] = {tensor id, start, len} (device); first: int32 [ntensors+1] (device);
 // upd: scratch of the same length as w; part: 2*nchunks floats; trust: ntensors floats (kept for inspection).
+// skip_if_negative (optional, device): *skip < 0 makes the whole step a no-op -- weights and moments untouched.  The SE(3)
+// relabel kernel sets its status word negative when the retry budget is exhausted (augmentation.py:119-120 raises BEFORE the
+// forward pass upstream); that step's loss and gradients are NaN and must not reach the optimizer state.
 extern "C" int vxb_lamb_step_f32(float* w, const float* g, float* m, float* v, float* upd, const int32_t* chunks, int nchunks,
                                  const int32_t* first, int ntensors, float* part, float* trust, float lr, double beta1, double beta2,
-                                 float eps, float weight_decay, vxb_stream_t stream) {
+                                 float eps, float weight_decay, const int32_t* skip_if_negative, vxb_stream_t stream) {
     if (!w || !g || !m || !v || !upd || !chunks || !first || !part || !trust || nchunks < 1 || ntensors < 1) return VXB_EARG;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(lamb_stage1_kernel, dim3(nchunks), dim3(256), 0, st, w, g, m, v, upd, chunks, part, (float)beta1, (float)beta2,
-                       (float)(1.0 - beta1), (float)(1.0 - beta2), eps, weight_decay);
+                       (float)(1.0 - beta1), (float)(1.0 - beta2), eps, weight_decay, skip_if_negative);
     hipLaunchKernelGGL(lamb_stage2_kernel, dim3(vxb_cdiv(ntensors, 64)), dim3(64), 0, st, part, first, ntensors, trust);
-    hipLaunchKernelGGL(lamb_stage3_kernel, dim3(nchunks), dim3(256), 0, st, w, upd, chunks, trust, lr);
+    hipLaunchKernelGGL(lamb_stage3_kernel, dim3(nchunks), dim3(256), 0, st, w, upd, chunks, trust, lr, skip_if_negative);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }

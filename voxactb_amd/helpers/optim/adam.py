@@ -12,6 +12,7 @@ class Adam(Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._arena = None
         self.steps = 0
+        self.skip_flag = None          # optional device int32: a negative value turns step() into a no-op on the device
 
     def attach(self, arena):
         self._arena = arena
@@ -31,7 +32,7 @@ class Adam(Optimizer):
         g, a = self.param_groups[0], self._arena
         self.steps += 1
         call('vxb_adam_step_f32', a.flat_w, a.flat_g, self.exp_avg, self.exp_avg_sq, a.total, float(g['lr']), float(g['betas'][0]),
-             float(g['betas'][1]), float(g['eps']), float(g['weight_decay']), self.steps)
+             float(g['betas'][1]), float(g['eps']), float(g['weight_decay']), self.steps, self.skip_flag)
         for p in a.params:
             self.state[p]['step'] = self.steps
         return loss

@@ -34,6 +34,7 @@ class Lamb(Optimizer):
         super(Lamb, self).__init__(params, defaults)
         self._arena = None
         self._plan = None
+        self.skip_flag = None          # optional device int32: a negative value turns step() into a no-op on the device
 
     def attach(self, arena):
         """arena: FlatParams holding every parameter of this optimizer (contiguous flat weights / grads)."""
@@ -68,7 +69,7 @@ class Lamb(Optimizer):
         a = self._arena
         call('vxb_lamb_step_f32', a.flat_w, a.flat_g, self.exp_avg, self.exp_avg_sq, self._upd, self._chunks, self._nchunks,
              self._first, self._ntensors, self._part, self.trust_ratio, float(g['lr']), float(g['betas'][0]),
-             float(g['betas'][1]), float(g['eps']), float(g['weight_decay']))
+             float(g['betas'][1]), float(g['eps']), float(g['weight_decay']), self.skip_flag)
         self.steps += 1
         for p in a.params:                   # per-parameter step counter, as the reference keeps it (lamb.py:90)
             self.state[p]['step'] = self.steps

@@ -314,6 +314,12 @@ class DeviceBatchStream:
                 if self._stop:
                     break
                 host = self._host[slot]
+                if self._ready[slot] is not None:
+                    # the previous copy OUT of this pinned buffer may still be queued (it waits on the GPU for the step that
+                    # read the slot's device twin, and the consumer frees a slot when that step is ENQUEUED, not executed):
+                    # refilling the buffer before it ran would hand the GPU torn or later data.  Host-side wait, producer
+                    # thread only.
+                    self._ready[slot].synchronize()
                 views = {k: v.numpy() for k, v in host.items()}
                 self._replay.sample_transition_batch(self._b, out=views)
                 with torch.cuda.stream(self._copy_stream):
