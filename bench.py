@@ -53,6 +53,12 @@ def main():
                     help='skip the secondary measurements in the other precisions and the parity probe')
     ap.add_argument('--cpu-voxel-size', type=int, default=0, help='debug: smaller grid for the CPU baseline leg')
     ap.add_argument('--kernel-table', action='store_true', help='print the per-kernel timing table to stderr')
+    ap.add_argument('--replay-stream', action='store_true',
+                    help='feed the HEADLINE region from the replay store: a fresh task-uniform batch per step through '
+                         'ShardReplayBuffer + DeviceBatchStream (host gather into pinned memory, H2D on a side stream) instead of '
+                         'two batches resident in HBM.  Without the flag the same measurement is reported beside the headline '
+                         'as `replay_stream` (offline_train_runner.py:136-143: Sample time + Step time)')
+    ap.add_argument('--replay-rows', type=int, default=96, help='distinct synthetic transitions in the replay store of --replay-stream')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -106,23 +112,68 @@ def main():
     counter = [0]
     updates_per_step = len(agents) * a.aug_copies
 
+    streams = [None]                  # [list of one DeviceBatchStream per agent] while a replay-stream region is measured
+    sample_s = [0.0]
+
     def step():
         i = counter[0]
         counter[0] += 1
         loss = 0.0
         for ai, ag in enumerate(agents):           # the twin agents are stepped back to back on this GPU's shard
+            if streams[0] is not None:
+                t_s = time.perf_counter()
+                batch = next(streams[0][ai])       # offline_train_runner.py:137-140: next(data_iter) + .to(device) (already there)
+                sample_s[0] += time.perf_counter() - t_s
+            else:
+                batch = batches[ai][i % 2]
             for _ in range(a.aug_copies):          # every call draws a fresh SE(3) perturbation of the same replay samples
-                out = ag.update(i, dict(batches[ai][i % 2]))
+                out = ag.update(i, dict(batch))
                 loss = float(out['total_losses'])  # the runner's .item() (device sync every update)
         return loss
 
-    def measure(mode, steps, warmup, only=None):
+    def open_streams():
+        """one replay store per agent, filled with --replay-rows synthetic transitions of the configs' schema, task-uniform over
+        two tasks, rank-strided (task_uniform_replay_buffer.py:103-108); batches come out of DeviceBatchStream on the device"""
+        import numpy as np
+        from voxactb_amd import replay as R
+        out = []
+        for ai, (ag, cf) in enumerate(zip(agents, cfgs)):
+            buf = lu.create_replay(B, 1, False, True, None, cf.rlbench.cameras, [V], [HW, HW], which_arm=cf.method.which_arm,
+                                   crop_target_obj_voxel=cf.method.crop_target_obj_voxel, arm_pred_loss=cf.method.arm_pred_loss,
+                                   arm_id_to_proprio=cf.method.arm_id_to_proprio)
+            buf._rank, buf._num_replicas = rank, world
+            n = a.replay_rows
+            src = synthetic.make_replay_sample(n, cf.rlbench.cameras, (HW, HW), V, low_dim, seed=4242 + ai, scene_bounds=scene,
+                                               arm_pred_loss=twin, crop_target_obj_voxel=twin, crop_radius=0.3 if ai == 0 else 0.4,
+                                               keyframes_near_target=twin)
+            names = [e.name for e in buf._observation_elements]
+            for i in range(n):
+                row = {}
+                for nm in names:
+                    if nm == 'task':
+                        row[nm] = 'open_jar' if i % 2 else 'open_drawer'
+                    elif nm == 'lang_goal':
+                        row[nm] = np.array(['open it'], dtype=object)
+                    else:
+                        row[nm] = src[nm][i, 0].numpy()
+                if i % 6 == 5:
+                    buf.add_final(**row)
+                else:
+                    buf.add(np.zeros(8, np.float32), 0.0, i % 6 == 4, False, demo=True, **row)
+            buf.seed(977 + 13 * rank + ai)
+            out.append(R.DeviceBatchStream(buf, device=dev_index, depth=2))
+        return out
+
+    def measure(mode, steps, warmup, only=None, stream=False):
         """W untimed + exactly K timed steps in `mode`, bracketed by barrier + synchronize; max over ranks.  `only`: the timer
-        labels whose launches are bracketed by HIP events (None = every launch)."""
+        labels whose launches are bracketed by HIP events (None = every launch).  stream: batches from the replay store."""
         for e_ in engines:
             e_.precision, _, e_.bwd_precision = mode.partition('/')      # 'bf16x3/bf16' = forward bf16x3, backward products bf16
+        if stream:
+            streams[0] = open_streams()
         for _ in range(warmup):
             step()
+        sample_s[0] = 0.0
         timer = _lib.KernelTimer(only)
         if world > 1:
             dist.barrier()
@@ -142,6 +193,10 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         for e_ in engines:
             e_.precision, e_.bwd_precision = headline_mode, headline_bwd
+        if stream:
+            for st_ in streams[0]:
+                st_.close()
+            streams[0] = None
         return float(tt[0]), loss, timer.summary()
 
     torch.manual_seed(1000 + rank)    # augmentation draws differ per rank, as they would with per-rank replay shards
@@ -151,7 +206,19 @@ def main():
     dt_prof, _, agg = measure(headline_mode, prof_steps, a.warmup)
     dom_label = max((l for l in agg if agg[l]['flops'] > 0), key=lambda l: agg[l]['ms'])
     # (2) THE timed region: exactly K steps; only the dominant kernel and the voxelizer are event-timed inside it
-    dt, loss, agg_head = measure(headline_mode, a.steps, 0, only={dom_label, 'voxelize'})
+    dt, loss, agg_head = measure(headline_mode, a.steps, 1 if a.replay_stream else 0, only={dom_label, 'voxelize'}, stream=a.replay_stream)
+    sample_ms_head = sample_s[0] / a.steps * 1e3
+    # (3) the same K steps fed from the replay store (fresh batch per step, host gather + H2D inside the region) -- reported
+    #     beside the headline, never as `value` (inputs resident in HBM is the contract of `value`)
+    replay_stream = None
+    if not a.no_other_modes and not a.replay_stream:
+        dt_rs, _, _ = measure(headline_mode, a.steps, 1, only=set(), stream=True)
+        replay_stream = {'value': world * a.steps / dt_rs, 'unit': 'steps/s', 'ms_per_step': dt_rs / a.steps * 1e3,
+                         'sample_ms_per_step': sample_s[0] / a.steps * 1e3, 'rows_in_store': a.replay_rows,
+                         'what': 'the same K steps with a fresh task-uniform batch per step from ShardReplayBuffer through '
+                                 'DeviceBatchStream (host gather into pinned staging, H2D on a side stream, rank-strided rows): '
+                                 'sample_ms_per_step = host time blocked in next(data_iter), the reference\'s "Sample time" '
+                                 '(offline_train_runner.py:136-143)'}
 
     # secondary measurements of the same workload in the other precisions (never the headline `value`)
     others = {}
@@ -228,9 +295,7 @@ def main():
         d = agg_head[dom_label]
         tf = d['flops'] / (d['ms'] * 1e-3) / 1e12
         roofline = {'bound': 'mfma', 'achieved': tf, 'peak': MODE_PEAK[headline_mode], 'unit': 'TFLOP/s',
-                    'frac': tf / MODE_PEAK[headline_mode], 'frac_of_bf16_dense_peak': tf / PEAK_BF16_MFMA_TFLOPS,
-                    'peak_basis': {'fp32': 'fp32 MFMA 157.3', 'bf16x3': 'bf16 dense MFMA 2500 / 3 MFMAs per product',
-                                   'bf16': 'bf16 dense MFMA 2500'}[headline_mode],
+                    'frac': tf / MODE_PEAK[headline_mode], 'peak_basis': MODE_PEAK_BASIS[headline_mode],
                     'kernel': dom_label, 'entry': d['entry'], 'launches': d['calls'] // a.steps,
                     'avg_launch_ms': d['ms'] / max(d['calls'], 1), 'ms_per_step': d['ms'] / a.steps,
                     'algorithmic_flops_per_launch': d['flops'] / max(d['calls'], 1), 'traffic': None}
@@ -240,20 +305,15 @@ def main():
                 if dom_label.startswith(pref):
                     roofline['traffic'] = nbytes
                     roofline['traffic_note'] = note
+        if headline_mode == 'bf16x3':
+            roofline['frac_of_x3_roof'] = tf / (PEAK_BF16_MFMA_TFLOPS / 3.0)
         roofline['share_of_device_time'] = agg[dom_label]['ms'] / tot_ms
         extra = dict(roofs)
         if 'voxelize' in agg_head:
             v = agg_head['voxelize']
-            gbps = v['bytes'] / (v['ms'] * 1e-3) / 1e9
-            extra['voxel_scatter'] = {'bound': 'hbm', 'achieved': gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
-                                      'frac': gbps / PEAK_HBM_GBPS, 'avg_launch_ms': v['ms'] / v['calls'], 'traffic': None,
-                                      'algorithmic_bytes_per_launch': v['bytes'] / v['calls'],
-                                      'note': 'training path: the grid lives in two persistent buffers that are UPDATED (cells '
-                                              'occupied two steps ago reset, new ones written: ~80 B per occupied cell) instead '
-                                              'of re-written (40 B per cell); `achieved` prices the launch against the bytes of '
-                                              'the full read-points + write-grid formulation (SURVEY.md 8d), so it can exceed '
-                                              'what a full rewrite could reach.  Full-rewrite (stateless) call: '
-                                              'profiles/r02_voxel_fresh_kernel_stats.txt'}
+            extra['voxel_scatter'] = voxel_roofline(v['ms'] / v['calls'], v['bytes'] / v['calls'], V, B, True)
+            if not a.no_other_modes:
+                extra['voxel_scatter_stateless'] = voxel_stateless(agents[0], batches[0][0], cfg, V, B)
         if a.kernel_table:
             for label, d in sorted(agg.items(), key=lambda kv: -kv[1]['ms']):
                 sys.stderr.write('%-44s calls %5d  %9.2f ms/step  %7.2f TF/s\n' % (
@@ -281,6 +341,9 @@ def main():
                            'the voxelizer are bracketed by HIP events; device_time_ms_per_step, rooflines_other and the kernel table: a '
                            'separate %d-step pass with every launch event-timed (ms_per_step_profile_pass: ~2 200 event records per step make that pass '
                            'host-bound, it is not a throughput figure)' % prof_steps,
+            'input': ('replay-stream: fresh batch per step from ShardReplayBuffer via DeviceBatchStream (H2D inside the timed region), '
+                      'sample_ms_per_step %.3f' % sample_ms_head) if a.replay_stream else 'two synthetic batches resident in HBM, alternated',
+            'replay_stream': replay_stream,
             'roofline': roofline, 'rooflines_other': extra, 'cpu_baseline': cpu, 'precision_note': MODE_NOTE[headline_mode],
             'parity_vs_reference': probe, 'act_latency': act_lat, 'other_precisions': others,
         }
@@ -308,9 +371,69 @@ PMC_TRAFFIC_C2 = {
         'HBM-bound; profiles/r02_v4_pmc_*'),
 }
 
+# HBM bytes the voxelizer chain really moves per call at configs[1] (B=16, V=100, 4 x 128 x 128 points), from separate
+# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/bench_voxel.py (sum over the kernels of one call; FETCH_SIZE x 2 as
+# MI355X_MICROARCH.md prescribes for gfx950); profiles/r03_voxel_*_pmc_*.txt.  None = not measured for this geometry.
+PMC_VOXEL_BYTES = {('incremental', 100, 16): None, ('stateless', 100, 16): None}
+
+
+def voxel_roofline(ms, alg_bytes, V, B, incremental):
+    """HBM roofline of one voxelizer call.  `achieved` / `frac` are REAL bandwidth: the HBM bytes the call moves (PMC) over its
+    duration -- for the training path (two persistent grids updated in place: only the cells occupied now / two steps ago are
+    touched) that is far less than the algorithmic read-points + write-grid bytes of SURVEY.md 8d, so the figure priced on those
+    is reported separately as `algorithmic_equivalent_gbps` (what a full-rewrite voxelizer would need to sustain to be as fast)
+    and never as a fraction of the peak."""
+    traffic = PMC_VOXEL_BYTES.get(('incremental' if incremental else 'stateless', V, B))
+    r = {'bound': 'hbm', 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'avg_launch_ms': ms, 'traffic': traffic,
+         'algorithmic_bytes_per_launch': alg_bytes, 'algorithmic_equivalent_gbps': alg_bytes / (ms * 1e-3) / 1e9,
+         'target': 'north_star: >= 0.60 of HBM peak on the algorithmic bytes = <= %.0f us per call' % (alg_bytes / (0.6 * PEAK_HBM_GBPS * 1e9) * 1e6)}
+    if incremental:
+        # the call does not do the priced work (it rewrites ~3 % of the grid): no fraction of peak is claimed for it
+        if traffic is not None:
+            r['achieved'] = traffic / (ms * 1e-3) / 1e9
+            r['frac'] = r['achieved'] / PEAK_HBM_GBPS
+        else:
+            r['achieved'], r['frac'] = None, None
+        r['note'] = ('training path: the grid lives in two persistent buffers that are UPDATED in place (reset the cells occupied two '
+                     'steps ago, write the ones occupied now: ~2 x 40 B per occupied cell + ~100 B per point); achieved = PMC bytes / '
+                     'time: a latency-bound chain of six small kernels, not a bandwidth figure to compare with the 60 % target -- '
+                     'see voxel_scatter_stateless for the call that does write all V^3 cells')
+    else:
+        r['achieved'] = alg_bytes / (ms * 1e-3) / 1e9
+        r['frac'] = r['achieved'] / PEAK_HBM_GBPS
+        r['note'] = ('stateless call (fresh output tensor, every cell written: what VoxelGrid.coords_to_bounding_voxel_grid and act() do); '
+                     'achieved = algorithmic bytes (read N*6*4 + write V^3*10*4 per sample) / time')
+    return r
+
+
+def voxel_stateless(agent, batch, cfg, V, B):
+    """time the stateless voxelizer call (fresh grid, all V^3 cells written) on one of the bench's batches"""
+    from voxactb_amd.voxel.voxel_grid import VoxelGrid
+    from voxactb_amd import synthetic
+    cams = cfg.rlbench.cameras
+    dev = batch['%s_rgb' % cams[0]].device
+    pcd = [batch['%s_point_cloud' % c][:, 0].float().contiguous() for c in cams]
+    rgb = [((batch['%s_rgb' % c][:, 0].float() / 255.0) * 2.0 - 1.0).contiguous() for c in cams]
+    vg = VoxelGrid(synthetic.SCENE_BOUNDS, V, dev, B, 3, pcd[0].shape[-1] * pcd[0].shape[-2] * len(cams))
+    for _ in range(3):
+        vg.voxelize_cameras(pcd, rgb)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 10
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        g = vg.voxelize_cameras(pcd, rgb)
+    e1.record()
+    torch.cuda.synchronize()
+    del g
+    nbytes = B * (len(cams) * pcd[0].shape[-1] * pcd[0].shape[-2] * 6 * 4 + V ** 3 * 10 * 4)
+    return voxel_roofline(e0.elapsed_time(e1) / n, float(nbytes), V, B, False)
+
+
 MODE_DTYPE = {
     'fp32': 'f32 (v_mfma_f32_32x32x2_f32 everywhere)',
-    'bf16x3': 'f32 storage / accumulate; matrix products as bf16x3 split (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16)',
+    'bf16x3': 'f32 storage / accumulate; matrix products as bf16x3 split (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16); the weight '
+              'gradients of the two 3x3x3 grid convs as single fp16 products with a device-side power-of-two operand scale',
     'bf16': 'bf16 matrix cores (fp32 accumulate) for convs, large linears and fused attention; everything else f32',
     'bf16x3/bf16': 'forward as bf16x3 (Q-values inside 1e-4 of the reference), matrix products of the BACKWARD pass on plain bf16',
 }
@@ -322,8 +445,12 @@ MODE_NOTE = {
     'bf16x3/bf16': 'mixed mode (VOXACTB_BWD_PRECISION=bf16): the forward keeps the 1e-4 Q-value bound, parameter gradients are '
                    'within 0.5 % of the reference (norms within 4e-3) instead of 0.2 % -- not the default',
 }
-# matrix-core roof per algorithmic FLOP: fp32 MFMA; bf16 dense MFMA / 3 instructions per product; bf16 dense MFMA
-MODE_PEAK = {'fp32': PEAK_FP32_MFMA_TFLOPS, 'bf16x3': PEAK_BF16_MFMA_TFLOPS / 3.0, 'bf16': PEAK_BF16_MFMA_TFLOPS}
+# `peak` of every matrix-core roofline = the guide's dense MFMA peak of the operand type (MI355X_MICROARCH.md): 157.3 TF/s fp32,
+# 2500 TF/s bf16 / fp16.  The bf16x3 precision spends three MFMAs per product, so an ideal bf16x3 kernel tops out at 1/3 of that
+# peak: reported next to `frac` as `frac_of_x3_roof` (secondary, never the headline fraction).
+MODE_PEAK = {'fp32': PEAK_FP32_MFMA_TFLOPS, 'bf16x3': PEAK_BF16_MFMA_TFLOPS, 'bf16': PEAK_BF16_MFMA_TFLOPS}
+MODE_PEAK_BASIS = {'fp32': 'fp32 MFMA 157.3 TF/s', 'bf16x3': 'dense bf16 MFMA 2500 TF/s (MI355X_MICROARCH.md); bf16x3 issues 3 MFMAs per product',
+                   'bf16': 'dense bf16 MFMA 2500 TF/s (MI355X_MICROARCH.md)'}
 
 
 def group_rooflines(agg, mode, steps):
@@ -338,9 +465,10 @@ def group_rooflines(agg, mode, steps):
             peak = MODE_PEAK[mode]
             tf = fl / (ms * 1e-3) / 1e12
             out[key] = {'bound': 'mfma', 'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak,
-                        'peak_basis': {'fp32': 'fp32 MFMA 157.3', 'bf16x3': 'bf16 dense MFMA 2500 / 3 MFMAs per product',
-                                       'bf16': 'bf16 dense MFMA 2500'}[mode],
+                        'peak_basis': MODE_PEAK_BASIS[mode],
                         'launches': calls // steps, 'avg_launch_ms': ms / max(calls, 1), 'ms_per_step': ms / steps}
+            if mode == 'bf16x3':
+                out[key]['frac_of_x3_roof'] = tf / (peak / 3.0)
     return out
 
 

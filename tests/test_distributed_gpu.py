@@ -144,3 +144,78 @@ def test_bucketed_exchange_on_the_real_rccl_backend(tmp_path):
     assert a['calls'] == a['buckets'] * 3 and a['buckets'][0] == 'tail' and a['buckets'][-1] == 'head'
     assert a['losses'] == b['losses']
     assert torch.equal(a['w'], b['w'])
+
+
+# ------------------------------------------------------------------------------------------------ twin agents, SE(3) on, default precision
+TWIN = dict(method__voxel_sizes=[16], method__voxel_patch_size=3, method__voxel_patch_stride=4, method__transformer_depth=2,
+            method__num_latents=32, rlbench__cameras=['front', 'wrist'], rlbench__camera_resolution=[16, 16],
+            method__arm_pred_loss=True, method__crop_target_obj_voxel=True)
+
+
+def _twin_worker(rank, world, port, out_dir):
+    """BASELINE.json configs[2] / [3] control flow on two ranks: the acting (`dominant`) and the stabilizing (`assistive`) agent
+    both resident, stepped back to back on this rank's shard, SE(3) augmentation and dropout ON, default bf16x3 precision
+    (fp16 conv weight gradients) -- `bench.py --agents 2` at a small geometry."""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.pop('VOXACTB_PRECISION', None)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from voxactb_amd import synthetic
+    from voxactb_amd.agents.peract_bc import launch_utils as lu
+    agents, qas = [], []
+    for ai, arm in enumerate(('dominant', 'assistive')):
+        cfg = lu.default_cfg(replay__batch_size=B, method__which_arm=arm, **TWIN)
+        torch.manual_seed(3000 + 31 * rank + ai)                      # different initialisations: rank 0's are broadcast at build()
+        ag = lu.create_agent(cfg)
+        ag.build(training=True, device=0)
+        agents.append(ag)
+        qas.append(ag._pose_agent._qattention_agents[0])
+        assert qas[-1]._q.encoder.engine().precision == 'bf16x3' and qas[-1]._transform_augmentation
+    torch.manual_seed(500 + rank)                                     # per-rank augmentation / dropout draws
+    res = dict(losses=[], w=[], w_before_bad=[], w_after_bad=[], raised=[])
+    for step in range(2):
+        for ai, ag in enumerate(agents):
+            rs = synthetic.make_replay_sample(B, TWIN['rlbench__cameras'], (16, 16), 16, 7, seed=60 + 10 * rank + step + 100 * ai,
+                                              arm_pred_loss=True, crop_target_obj_voxel=True, crop_radius=0.3 + 0.1 * ai,
+                                              keyframes_near_target=True)
+            res['losses'].append(float(ag.update(step, {k: v.to('cuda:0') for k, v in rs.items()})['total_losses']))
+    res['w'] = [qa._arena.flat_w.cpu() for qa in qas]
+    # rank 1 alone draws a keyframe far outside the scene: its retry budget runs out.  Every rank must skip that optimizer step
+    # (the status words are MIN-reduced) and every rank raises at its next update(), as the reference job would die as a whole
+    res['w_before_bad'] = qas[0]._arena.flat_w.cpu()
+    rs = synthetic.make_replay_sample(B, TWIN['rlbench__cameras'], (16, 16), 16, 7, seed=77 + rank, arm_pred_loss=True,
+                                      crop_target_obj_voxel=True, keyframes_near_target=True)
+    if rank == 1:
+        rs['gripper_pose'][:, :, :3] = -50.0
+    agents[0].update(2, {k: v.to('cuda:0') for k, v in rs.items()})
+    res['w_after_bad'] = qas[0]._arena.flat_w.cpu()
+    try:
+        agents[0].update(3, {k: v.to('cuda:0') for k, v in rs.items()})
+        res['raised'] = False
+    except Exception as e:  # noqa: BLE001
+        res['raised'] = 'Failing to perturb' in str(e)
+    torch.save(res, os.path.join(out_dir, 'twin%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_twin_agents_with_se3_in_the_default_precision(tmp_path, monkeypatch):
+    monkeypatch.delenv('VOXACTB_PRECISION', raising=False)
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=_twin_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+        assert p.exitcode == 0
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), 'twin%d.pt' % r)) for r in range(world))
+    assert all(np.isfinite(r0['losses'])) and all(np.isfinite(r1['losses']))
+    assert r0['losses'] != r1['losses']                                    # different shards, different perturbations
+    for a, b in zip(r0['w'], r1['w']):                                     # ... one model per agent on both ranks, bit for bit
+        assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    assert not torch.equal(r0['w'][0], r0['w'][1])                         # the two agents are independent networks
+    for r in (r0, r1):                                                     # the failed step touched nothing, on either rank
+        assert torch.equal(r['w_before_bad'], r['w_after_bad'])
+        assert r['raised'] is True

@@ -51,8 +51,13 @@ def linear(x, W, bias=None, act=ops.ACT_NONE, residual=None, out=None):
     return _linear(rnd(x, k), rnd(W, k), bias, act, residual, out)
 
 
+BIG_ONLY = [False]      # round only the linears with >= 1024 rows (the ones that reach the matrix-core weight-gradient kernel)
+
+
 def linear_bwd(x, W, dy, dW, db=None, dx=None, dx_accumulate=False, ws=None):
     kw, kd = EMU['lin_wgrad'], EMU['lin_dgrad']
+    if BIG_ONLY[0] and x.shape[0] < 1024:
+        kw = kd = None
     if kw == kd:
         _linear_bwd(rnd(x, kw), rnd(W, kw), rnd(dy, kw), dW, None, dx, dx_accumulate, ws)
     else:
@@ -185,6 +190,20 @@ if __name__ == '__main__':
             run(g, 'fp32', '', dict(conv_fwd='fp16'), 1.0, 'EMU fp16 convs fwd, rest fp32')
             continue
         S = 4096.0
+        if '--round3' in sys.argv:
+            run(g, 'fp32', '', {}, 1.0, 'fp32 fwd / fp32 bwd')
+            run(g, 'fp32', '', dict(attn_bwd='fp16'), S, 'fp32 | fp16 attention bwd only')
+            run(g, 'fp32', '', dict(attn_fwd='fp16', attn_bwd='fp16'), S, 'fp16 attention fwd + bwd, rest fp32')
+            run(g, 'fp32', '', dict(lin_dgrad='fp16'), S, 'fp32 | fp16 linear dgrads only')
+            run(g, 'fp32', '', dict(lin_wgrad='fp16'), S, 'fp32 | fp16 linear wgrads only')
+            run(g, 'fp32', '', dict(attn_bwd='fp16', lin_wgrad='fp16', conv_wgrad='fp16'), S, 'fp32 | fp16 attention bwd + all wgrads')
+            BIG_ONLY[0] = True
+            run(g, 'fp32', '', dict(lin_wgrad='fp16'), S, 'fp32 | fp16 linear wgrads, M >= 1024 only')
+            run(g, 'fp32', '', dict(lin_wgrad='fp16', conv_wgrad='fp16'), S, 'fp32 | fp16 linear (M >= 1024) + conv wgrads')
+            run(g, 'fp32', '', dict(lin_wgrad='fp16', conv_wgrad='fp16', attn_bwd='fp16', attn_fwd='fp16'), S, 'fp16 attention fwd+bwd, fp16 big-linear + conv wgrads')
+            run(g, 'fp32', '', dict(lin_dgrad='fp16'), S, 'fp32 | fp16 linear dgrads, M >= 1024 only')
+            BIG_ONLY[0] = False
+            continue
         if '--round2' not in sys.argv:
             CW = dict(final_wgrad='fp16', up_wgrad='fp16')
             run(g, 'bf16x3', 'fp32', {}, 1.0, 'x3 fwd | fp32 conv+linear bwd, x3 attention bwd', attn_bwd='bf16x3')

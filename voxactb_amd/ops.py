@@ -556,9 +556,11 @@ def conv3_dgrad_fold(dy, wt_dgrad, B, S, N, dsts, label=None):
     x3 = wb.dim() == 3
     d0, a0, y0 = dsts[0]
     d1, a1, y1 = dsts[1] if len(dsts) > 1 else (None, False, None)
-    _lib.set_meta(label or 'conv3d_bf16[k3 s1 %d->%d S%d dgrad+fold]' % (C0, N, S + 2), 2.0 * B * (S + 2) ** 3 * N * 27 * C0)
+    # algorithmic work = the data gradient on the S^3 grid (the kernel evaluates it on the zero-padded (S+2)^3 domain and folds the
+    # border back in its epilogue: those 6 % extra MFMAs are not counted)
+    _lib.set_meta(label or 'conv3d_bf16[k3 s1 %d->%d S%d dgrad+fold]' % (C0, N, S + 2), 2.0 * B * S ** 3 * N * 27 * C0)
     wf = halo_wfrag(wb, C0)
-    _lib.set_meta(label or 'conv3d_bf16[k3 s1 %d->%d S%d dgrad+fold]' % (C0, N, S + 2), 2.0 * B * (S + 2) ** 3 * N * 27 * C0)
+    _lib.set_meta(label or 'conv3d_bf16[k3 s1 %d->%d S%d dgrad+fold]' % (C0, N, S + 2), 2.0 * B * S ** 3 * N * 27 * C0)
     call('vxb_conv3_dgrad_fold_f32', dy, C0, B, S, wb, int(x3), N, d0, d1, y0, y1, int(a0), int(a1), LRELU_SLOPE, wf)
 
 
