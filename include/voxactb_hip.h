@@ -212,6 +212,11 @@ int vxb_conv3_halo_bf16x3_f32(const float* src0, const float* src1, int C0, int 
 int vxb_conv3_dgrad_fold_f32(const float* dy, int C0, int B, int S, const void* wt_bf16, int x3, int N, float* dst0,
                              float* dst1, const float* y0, const float* y1, int acc0, int acc1, float slope,
                              const void* wfrag, vxb_stream_t stream);
+/* ... one 64-column block of it with a single fp16 product per term (dy * scale[0] -> half, result * scale[1]; scale on the
+ * device, vxb_absmax_scale_f32; weights in fragment order of the fp16 [64][27 C0] matrix): the d(d0) half of `final`'s data
+ * gradient, which only feeds the weight gradient of the 1x1x1 input conv (a leaf of the backward pass). */
+int vxb_conv3_dgrad_fold_f16_f32(const float* dy, int C0, int B, int S, const void* wfrag_f16, float* dst, const float* y,
+                                 int acc, float slope, const float* scale, vxb_stream_t stream);
 /* LDS-halo weight gradient of the same 3x3x3 stride-1 convs (contract of vxb_conv3d_wgrad_f32 with kext = 3, stride = 1;
  * the z slices of part[z][K][N] are runs of 128-voxel tiles, 2x8x8 or 4x4x8 -- chosen by the voxels wasted on the
  * edge of an S_out^3 grid; vxb_conv3_wgrad_halo_tiles returns their number).  C0, C1 % 16 == 0, N % 64 == 0; d2s needs

@@ -50,3 +50,33 @@ def test_dgrad_fold_x3_vs_autograd():
     finally:
         ops.PRECISION = 'fp32'
     close(out, cl(x.grad.float()), 2e-5, 'fused dgrad + fold vs autograd')
+
+
+@pytest.mark.parametrize('S,B,gain', [(16, 2, 1.0), (20, 1, 2e-8), (34, 1, 3e5)])
+def test_dgrad_fold_leaf_block_on_single_fp16_products(S, B, gain):
+    """`leaf_blocks=(0,)` with WGRAD_PRECISION = 'fp16': column block 0 (a gradient that only feeds a weight gradient) runs on single
+    fp16 products with dy scaled on the device, block 1 stays bit-identical to the all-bf16x3 call; dy of ordinary, tiny and huge
+    magnitude (the scale comes from the tensor)."""
+    C, N = 64, 128
+    dy = (cl(rnd(B, C, S, S, S, seed=3)) * gain).to(DEV)
+    dy[0, 0, 0, 0, :8] *= 40.0
+    W = rnd(C, N, 3, 3, 3, seed=1, scale=0.1).to(DEV)
+    y1 = cl(rnd(B, 64, S, S, S, seed=5)).to(DEV)
+    base0 = (cl(rnd(B, 64, S, S, S, seed=6)) * gain).to(DEV)
+    ops.PRECISION = 'bf16x3'
+    try:
+        wd = ops.conv_weight_dgrad(W)
+        r0, r1 = base0.clone(), torch.empty(B, S, S, S, 64, device=DEV)
+        ops.conv3_dgrad_fold(dy, wd, B, S, N, [(r0, True, None), (r1, False, y1)])
+        ops.WGRAD_PRECISION = 'fp16'
+        g0, g1 = base0.clone(), torch.empty(B, S, S, S, 64, device=DEV)
+        ops.conv3_dgrad_fold(dy, wd, B, S, N, [(g0, True, None), (g1, False, y1)], leaf_blocks=(0,))
+        h0, h1 = base0.clone(), torch.empty(B, S, S, S, 64, device=DEV)
+        ops.conv3_dgrad_fold(dy, wd, B, S, N, [(h0, True, None), (h1, False, y1)], leaf_blocks=(0,), dy_scale=ops.absmax_scale(dy))
+    finally:
+        ops.PRECISION = 'fp32'
+        ops.WGRAD_PRECISION = ''
+    assert torch.equal(g1, r1) and torch.equal(h1, r1)                       # the propagating block: untouched arithmetic
+    assert torch.equal(g0, h0)
+    err = float((g0 - r0).abs().max()) / float((r0 - base0).abs().max())
+    assert 0 < err < 1.5e-3, err                                             # 2^-12 per operand over a 27 x 64 term sum

@@ -51,6 +51,7 @@ def linear(x, W, bias=None, act=ops.ACT_NONE, residual=None, out=None):
     return _linear(rnd(x, k), rnd(W, k), bias, act, residual, out)
 
 
+HALF = [None]
 BIG_ONLY = [False]      # round only the linears with >= 1024 rows (the ones that reach the matrix-core weight-gradient kernel)
 
 
@@ -72,6 +73,13 @@ def conv3d(src0, wt, *a, **kw):
     k = EMU['conv_fwd'] if PHASE[0] == 'fwd' else EMU['conv_dgrad']
     if PHASE[0] == 'bwd' and len(a) >= 5 and a[0] == 128 and a[4] == 3:          # (N, B, S_in, S_out, kext): final's data gradient
         k = EMU['final_dgrad'] or k
+        if HALF[0] is not None and k is not None:
+            # only one 64-column half of the data gradient (0: d(d0), 1: d(u0)) on the cheap product, the other exact
+            full = _conv3d(src0, wt, *a, **kw)
+            cheap = _conv3d(rnd(src0, k), rnd(wt, k), *a, **kw)
+            lo, hi = (0, 64) if HALF[0] == 0 else (64, 128)
+            full[..., lo:hi] = cheap[..., lo:hi]
+            return full
     if kw.get('src1') is not None:
         kw['src1'] = rnd(kw['src1'], k)
     return _conv3d(rnd(src0, k), rnd(wt, k), *a, **kw)
@@ -190,6 +198,14 @@ if __name__ == '__main__':
             run(g, 'fp32', '', dict(conv_fwd='fp16'), 1.0, 'EMU fp16 convs fwd, rest fp32')
             continue
         S = 4096.0
+        if '--round4' in sys.argv:
+            for half in (0, 1):
+                HALF[0] = half
+                run(g, 'bf16x3', 'fp32', dict(final_dgrad='fp16'), S, 'x3 fwd | fp16 final dgrad, %s half only' % ('d(d0)' if half == 0 else 'd(u0)'), attn_bwd='bf16x3')
+                run(g, 'fp32', '', dict(final_dgrad='fp16'), S, 'fp32 | fp16 final dgrad, %s half only' % ('d(d0)' if half == 0 else 'd(u0)'))
+            HALF[0] = None
+            run(g, 'fp32', '', dict(final_dgrad='fp16'), S, 'fp32 | fp16 final dgrad (both halves)')
+            continue
         if '--round3' in sys.argv:
             run(g, 'fp32', '', {}, 1.0, 'fp32 fwd / fp32 bwd')
             run(g, 'fp32', '', dict(attn_bwd='fp16'), S, 'fp32 | fp16 attention bwd only')

@@ -688,7 +688,10 @@ class PerceiverEngine:
             ops.conv3_c1_dgrad(dq_trans, wt, u, du, B, V, accumulate=True, mask=True)      # du is now d(pre-activation of `final`)
         # ---- final conv (two sources)
         Wf = self.p('final.conv3d.weight')
-        dWt = ops.conv3d_wgrad(d0, du, C, B, V, V, 3, -1, src1=u0)
+        # one |du| maximum serves both single-fp16-product kernels that read du (the weight gradient and the d(d0) half of the data
+        # gradient); None in the other precisions
+        sc_du = ops.absmax_scale(du) if (ops.WGRAD_PRECISION == 'fp16' and C == 64 and ops.dgrad_fold_ok(C, 2 * C, V)) else None
+        dWt = ops.conv3d_wgrad(d0, du, C, B, V, V, 3, -1, src1=u0, dy_scale=sc_du)
         self.g('final.conv3d.weight').add_(dWt.view(27, 2 * C, C).permute(2, 1, 0).reshape(Wf.shape))
         if not fuse_u:
             ops.colsum(du.view(-1, C), self.g('final.conv3d.bias'), accumulate=True)
@@ -703,7 +706,10 @@ class PerceiverEngine:
         if C == 64 and ops.dgrad_fold_ok(C, 2 * C, V):
             # data gradient and the adjoint of the replicate padding in one kernel: the first 64 columns go (add) into dd0,
             # the other 64 become d(pre-activation of up0's last conv) through u0's LeakyReLU'
-            ops.conv3_dgrad_fold(du, ops.conv_weight_dgrad(Wf), B, V, 2 * C, [(dd0, not fuse_ss0, None), (du0, False, u0)])
+            # d(d0) feeds nothing but the weight gradient of the 1x1x1 input conv (the voxel grid is a detached input, agent :100):
+            # a leaf -- its column block may run on single fp16 products; d(u0) propagates through the decoder and stays bf16x3
+            ops.conv3_dgrad_fold(du, ops.conv_weight_dgrad(Wf), B, V, 2 * C, [(dd0, not fuse_ss0, None), (du0, False, u0)],
+                                 dy_scale=sc_du, leaf_blocks=(0,))
         else:
             dcat = ops.conv3d(du, ops.conv_weight_dgrad(Wf), 2 * C, B, V, V + 2, 3, -2, replicate=False)
             ops.fold_pad(dcat, V + 2, 2 * C, 0, dd0, B, V, C, 1, accumulate=not fuse_ss0)

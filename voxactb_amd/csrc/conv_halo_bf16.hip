@@ -24,6 +24,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
 constexpr int TD = 4, TH = 8, TW = 8;                 // output tile
@@ -63,14 +64,26 @@ struct HaloArgs {
     const float* fold_y[2];  // != nullptr: multiply by LeakyReLU'(y) (the producer's activation)
     int fold_acc[2];         // 1: dst += ..., 0: dst = ...
     int dbg;                 // timing experiments only (vxb_debug_set_halo_experiment): results are WRONG when != 0
+    // 'fp16' products (PM = 2): the input is multiplied by scale[0] before the conversion to half (a power of two taken from
+    // its largest magnitude, vxb_absmax_scale_f32) and the result by scale[1] = 1 / scale[0] in the epilogue; nullptr = 1
+    const float* scale;
 };
 
 // bf16 pair from two fp32 (RNE).  Both forms give identical bits; which one is FASTER was measured per precision on the
 // 128->64 forward (4 waves x 2 M tiles): the integer form 765 TF/s vs v_cvt_pk_bf16_f32 590 TF/s in 'bf16', but 351 vs 365
 // TF/s in 'bf16x3' -- the cheaper conversion bunches the two resident workgroups' ds_write bursts together.
-template <int X3>
+// PM = product mode: 0 plain bf16, 1 bf16x3 (hi | lo halves, three MFMAs per product), 2 plain fp16 (pre-scaled input,
+// saturating conversion)
+template <int PM>
+__device__ __forceinline__ f32x16 hb_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+    if (PM == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int PM>
 __device__ __forceinline__ unsigned hb_pack2(float lo, float hi) {
-    if (X3) return vxb_pack_bf16(lo, hi);
+    if (PM == 2) return vxb_pack_f16(__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f));
+    if (PM == 1) return vxb_pack_bf16(lo, hi);
     unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
     a += 0x7fffu + ((a >> 16) & 1u);
     b += 0x7fffu + ((b >> 16) & 1u);
@@ -79,13 +92,14 @@ __device__ __forceinline__ unsigned hb_pack2(float lo, float hi) {
 
 __device__ __forceinline__ bool g_dbg_all_waves(const HaloArgs& g) { return (g.dbg & 4) != 0; }    // experiment bit 4: no wave skipping
 
-template <int NTG, int X3, int NW, int WD, int TL = 0, int WN = 1>
+template <int NTG, int PM, int NW, int WD, int TL = 0, int WN = 1>
                                               // NTG = N / 32 column tiles per workgroup; the NW waves form a (NW / WN) x WN grid over
                                               // (8 M tiles) x (NTG column tiles): 4 x 1 -> 2 M tiles x 2 column tiles per wave,
                                               // 2 x 2 -> 4 x 1 (half the B-fragment traffic per MFMA, twice the A reads from LDS),
                                               // 8 x 1 -> 1 x 2; WD: B fragments straight from global (pre-shuffled weights); TL:
                                               // per-chunk tap lists (block-sparse weights, WD only)
 __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
+    constexpr int X3 = PM == 1;
     constexpr int NTH = NW * 64, MTW = 8 / (NW / WN), NT = NTG / WN;
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* halo = smem;                               // [HALO_SLOTS][SP]
@@ -221,15 +235,15 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
         /* term-major order: consecutive MFMAs hit different accumulators (no back-to-back dependent issue) */       \
         _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                                 \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][1], bfr[j][X3 ? 0 : 1], acc[i][j], 0, 0, 0);   \
+            acc[i][j] = hb_mfma<PM>(AC[i][1], bfr[j][X3 ? 0 : 1], acc[i][j]);   \
         if (X3) {                                                                                                    \
             _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                             \
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][0], bfr[j][1], acc[i][j], 0, 0, 0);        \
+                acc[i][j] = hb_mfma<PM>(AC[i][0], bfr[j][1], acc[i][j]);        \
         }                                                                                                            \
         _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                                 \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][0], bfr[j][0], acc[i][j], 0, 0, 0);            \
+            acc[i][j] = hb_mfma<PM>(AC[i][0], bfr[j][0], acc[i][j]);            \
         __syncthreads();                                                                                             \
     }
     // ---- WD variant: the B fragments of a tap come straight from global memory (weights pre-shuffled on the host into
@@ -264,15 +278,15 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                               \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][1], BC[j][X3 ? 0 : 1], acc[i][j], 0, 0, 0);    \
+            acc[i][j] = hb_mfma<PM>(AC[i][1], BC[j][X3 ? 0 : 1], acc[i][j]);    \
         if (X3) {                                                                                                    \
             _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                           \
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][0], BC[j][1], acc[i][j], 0, 0, 0);         \
+                acc[i][j] = hb_mfma<PM>(AC[i][0], BC[j][1], acc[i][j]);         \
         }                                                                                                            \
         _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                               \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][0], BC[j][0], acc[i][j], 0, 0, 0);             \
+            acc[i][j] = hb_mfma<PM>(AC[i][0], BC[j][0], acc[i][j]);             \
     }
     int* ttab = reinterpret_cast<int*>(wsm);        // TL: the tap table lives in the (otherwise unused) weight buffers
     if (TL) {
@@ -283,15 +297,15 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
     {                                                                                                                \
         _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                               \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][1], BC[j][X3 ? 0 : 1], acc[i][j], 0, 0, 0);    \
+            acc[i][j] = hb_mfma<PM>(AC[i][1], BC[j][X3 ? 0 : 1], acc[i][j]);    \
         if (X3) {                                                                                                    \
             _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                           \
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][0], BC[j][1], acc[i][j], 0, 0, 0);         \
+                acc[i][j] = hb_mfma<PM>(AC[i][0], BC[j][1], acc[i][j]);         \
         }                                                                                                            \
         _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                               \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][0], BC[j][0], acc[i][j], 0, 0, 0);             \
+            acc[i][j] = hb_mfma<PM>(AC[i][0], BC[j][0], acc[i][j]);             \
     }
 #define HD_TAP(tap_, BC, BL, AC, AN)                                                                                 \
     {                                                                                                                \
@@ -301,20 +315,22 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                               \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][1], BC[j][X3 ? 0 : 1], acc[i][j], 0, 0, 0);    \
+            acc[i][j] = hb_mfma<PM>(AC[i][1], BC[j][X3 ? 0 : 1], acc[i][j]);    \
         if (X3) {                                                                                                    \
             _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                           \
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][0], BC[j][1], acc[i][j], 0, 0, 0);         \
+                acc[i][j] = hb_mfma<PM>(AC[i][0], BC[j][1], acc[i][j]);         \
         }                                                                                                            \
         _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                               \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[i][0], BC[j][0], acc[i][j], 0, 0, 0);             \
+            acc[i][j] = hb_mfma<PM>(AC[i][0], BC[j][0], acc[i][j]);             \
     }
     // (Measured and rejected, round 2: fetching the halo of chunk ch + 1 into registers during the taps of chunk ch -- 40 more
     // VGPRs in 'bf16x3', no spills -- is 3.6 % SLOWER.  The vector L1 returns data in request order for the whole CU, so HBM-latency
     // halo loads in the middle of a tap loop hold up the L2-hit B-fragment loads of both resident workgroups.)
     constexpr bool PF = false;
+    const float in_sc = (PM == 2 && g.scale) ? g.scale[0] : 1.0f;
+    const float out_sc = (PM == 2 && g.scale) ? g.scale[1] : 1.0f;
     float4 hv[NLD];
     auto halo_issue = [&](int ch_) {
         const int cb_ = ch_ * CPC;
@@ -370,13 +386,14 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             if (st_goff[i] != -1 && !dbg_skip_stage) {
+                if (PM == 2) { hv[i].x *= in_sc; hv[i].y *= in_sc; hv[i].z *= in_sc; hv[i].w *= in_sc; }
                 uint2 pk;
-                pk.x = hb_pack2<X3>(hv[i].x, hv[i].y); pk.y = hb_pack2<X3>(hv[i].z, hv[i].w);
+                pk.x = hb_pack2<PM>(hv[i].x, hv[i].y); pk.y = hb_pack2<PM>(hv[i].z, hv[i].w);
                 *reinterpret_cast<uint2*>(&halo[st_soff[i]]) = pk;
                 if (X3) {
                     uint2 q;
-                    q.x = hb_pack2<X3>(hv[i].x - __uint_as_float(pk.x << 16), hv[i].y - __uint_as_float(pk.x & 0xffff0000u));
-                    q.y = hb_pack2<X3>(hv[i].z - __uint_as_float(pk.y << 16), hv[i].w - __uint_as_float(pk.y & 0xffff0000u));
+                    q.x = hb_pack2<PM>(hv[i].x - __uint_as_float(pk.x << 16), hv[i].y - __uint_as_float(pk.x & 0xffff0000u));
+                    q.y = hb_pack2<PM>(hv[i].z - __uint_as_float(pk.y << 16), hv[i].w - __uint_as_float(pk.y & 0xffff0000u));
                     *reinterpret_cast<uint2*>(&halo[st_soff[i] + 16]) = q;
                 }
             }
@@ -479,6 +496,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
                         const float4 v = *reinterpret_cast<const float4*>(&ft[(((dl + dd) * TH + hl + hh) * TW + wl + ww) * 64 + c4]);
                         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
                     }
+            if (PM == 2) { a.x *= out_sc; a.y *= out_sc; a.z *= out_sc; a.w *= out_sc; }
             const int jd = min(max(id - P, 0), S - 1), jh = min(max(ih - P, 0), S - 1), jw = min(max(iw - P, 0), S - 1);
             const long long o = ((((long long)b * S + jd) * S + jh) * S + jw) * 64 + c4;
             if (facc) {
@@ -516,7 +534,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const int n = n0 + (wn * NT + j) * 32 + lq;
-                    float v = acc[i][j][r] + (g.bias ? g.bias[n] : 0.f);
+                    float v = (PM == 2 ? acc[i][j][r] * out_sc : acc[i][j][r]) + (g.bias ? g.bias[n] : 0.f);
                     if (g.act == 1) v = v > 0.f ? v : v * g.slope;
                     op[n] = v;
                 }
@@ -534,22 +552,23 @@ int g_halo_wn = 0;         // experiment knob (vxb_debug_set_halo_wn): waves alo
                           // repetitions each, B = 16, S = 100): forward 20.23 -> 19.43 ms, data gradient + padding adjoint
                           // 21.89 -> 20.85 ms; the tap-list variant (up-conv data gradient) is unchanged, 11.0 ms either way        // experiment knob (vxb_debug_set_halo_waves): 4 waves x 2 M tiles or 8 waves x 1 M tile per workgroup
 
-template <int NT, int X3, int NW, int WD, int TL = 0, int WN = 1>
+template <int NT, int PM, int NW, int WD, int TL = 0, int WN = 1>
 int hb_launch(const HaloArgs& g, long long nblk, hipStream_t st) {
     // (the fold epilogue re-uses the buffer as an fp32 [256][64] tile: keep the full size in every variant)
     const size_t lds = (size_t)(HALO_SLOTS * SP + 2 * NT * 32 * LDW) * sizeof(u16);
     if (TL && (size_t)(g.ncls * 32 + g.nphase * 2) * sizeof(int) > (size_t)2 * NT * 32 * LDW * sizeof(u16)) return VXB_ESIZE;
-    if (hipFuncSetAttribute((const void*)conv3_halo_kernel<NT, X3, NW, WD, TL, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv3_halo_kernel<NT, PM, NW, WD, TL, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VXB_ELAUNCH;
-    hipLaunchKernelGGL((conv3_halo_kernel<NT, X3, NW, WD, TL, WN>), dim3((unsigned)(nblk * (g.N / (NT * 32)))), dim3(NW * 64), lds, st, g);
+    hipLaunchKernelGGL((conv3_halo_kernel<NT, PM, NW, WD, TL, WN>), dim3((unsigned)(nblk * (g.N / (NT * 32)))), dim3(NW * 64), lds, st, g);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
 
-int hb_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out, int off, int replicate,
+int hb_impl(int x3 /* product mode: 0 bf16, 1 bf16x3, 2 fp16 (WD kernels only, `scale` = {in, 1 / in} on the device) */, const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out, int off, int replicate,
             const void* wt_bf16, int N, const float* bias, float* out, int act, float slope, int s2d_s, int s2d_C,
             int d2s_s, vxb_stream_t stream, const HaloArgs* fold = nullptr, const void* wfrag = nullptr,
-            const int32_t* taptab = nullptr, int ncls = 0, int nphase = 0, int tap_total = 0) {
+            const int32_t* taptab = nullptr, int ncls = 0, int nphase = 0, int tap_total = 0, const float* scale = nullptr) {
+    if (x3 == 2 && (!wfrag || taptab)) return VXB_EARG;
     if (!src0 || !wt_bf16 || (!out && !fold) || B < 1 || S_in < 1 || S_out < 1) return VXB_EARG;
     if ((C0 & 31) || (C1 & 31) || C0 < 32 || (C1 > 0 && !src1) || N < 64 || (N & 63)) return VXB_ESIZE;
     if (!hb_aligned16(src0) || !hb_aligned16(wt_bf16) || (src1 && !hb_aligned16(src1))) return VXB_ESIZE;
@@ -561,6 +580,7 @@ int hb_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B,
     g.taptab = taptab; g.ncls = ncls; g.nphase = nphase; g.tap_total = tap_total;
     g.s2d_s = s2d_s; g.s2d_C = s2d_C; g.d2s_s = d2s_s; g.wfrag = (const u16*)wfrag;
     g.dbg = g_halo_dbg;
+    g.scale = scale;
     g.fold_pad = 0; g.fold_S = 0; g.fold_dst[0] = g.fold_dst[1] = nullptr; g.fold_y[0] = g.fold_y[1] = nullptr;
     g.fold_acc[0] = g.fold_acc[1] = 0;
     if (fold) {
@@ -576,6 +596,7 @@ int hb_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B,
     hipStream_t st = (hipStream_t)stream;
     // 64 output channels per workgroup (162-225 VGPRs -> two workgroups per CU); N = 128 runs two column blocks that each
     // stage the halo -- cheaper than the register spills of a 128-wide accumulator tile.
+    if (x3 == 2) return hb_launch<2, 2, 4, 1>(g, nblk, st);
     const int wn = g_halo_wn ? g_halo_wn : (x3 ? 2 : 1);
     if (g.taptab && wn == 2) return x3 ? hb_launch<2, 1, 4, 1, 1, 2>(g, nblk, st) : hb_launch<2, 0, 4, 1, 1, 2>(g, nblk, st);
     if (g.taptab) return x3 ? hb_launch<2, 1, 4, 1, 1>(g, nblk, st) : hb_launch<2, 0, 4, 1, 1>(g, nblk, st);
@@ -629,5 +650,24 @@ extern "C" int vxb_conv3_dgrad_fold_f32(const float* dy, int C0, int B, int S, c
     HaloArgs f;
     f.fold_pad = pad; f.fold_S = S; f.fold_dst[0] = dst0; f.fold_dst[1] = dst1; f.fold_y[0] = y0; f.fold_y[1] = y1;
     f.fold_acc[0] = acc0; f.fold_acc[1] = acc1;
-    return hb_impl(x3, dy, nullptr, C0, 0, B, S, S_out, -2 * pad, 0, wt_bf16, N, nullptr, nullptr, 0, slope, 0, 0, 0, stream, &f, wfrag);
+    return hb_impl(x3 ? 1 : 0, dy, nullptr, C0, 0, B, S, S_out, -2 * pad, 0, wt_bf16, N, nullptr, nullptr, 0, slope, 0, 0, 0, stream, &f, wfrag);
+}
+
+// The same data gradient + padding adjoint for ONE 64-column block with a single fp16 product per term: dy is multiplied by
+// scale[0] (device, a power of two: vxb_absmax_scale_f32) before the conversion to half, the result by scale[1]; weights only in
+// fragment order (ops.halo_wfrag of the fp16 [64][27 C0] matrix).  Used for the d(d0) half of `final`'s data gradient
+// (perceiver_lang_io.py:462): that tensor only feeds the weight gradient of the 1x1x1 input conv -- a leaf: against the reference's
+// gradients it is indistinguishable from the bf16x3 evaluation (tools/experiments/emu_precision.py --round4), while the d(u0)
+// half, which propagates through the whole decoder and trunk, stays bf16x3.
+extern "C" int vxb_conv3_dgrad_fold_f16_f32(const float* dy, int C0, int B, int S, const void* wfrag_f16, float* dst, const float* y,
+                                            int acc, float slope, const float* scale, vxb_stream_t stream) {
+    if (!dy || !wfrag_f16 || !dst || S < 2) return VXB_EARG;
+    const int pad = 1, S_out = S + 2 * pad;
+    if ((S_out - 1 - pad) / TD != (S_out - 1) / TD || (S_out - 1 - pad) / TH != (S_out - 1) / TH || (S_out - 1 - pad) / TW != (S_out - 1) / TW)
+        return VXB_ESIZE;
+    HaloArgs f;
+    f.fold_pad = pad; f.fold_S = S; f.fold_dst[0] = dst; f.fold_dst[1] = nullptr; f.fold_y[0] = y; f.fold_y[1] = nullptr;
+    f.fold_acc[0] = acc; f.fold_acc[1] = 0;
+    return hb_impl(2, dy, nullptr, C0, 0, B, S, S_out, -2 * pad, 0, wfrag_f16, 64, nullptr, nullptr, 0, slope, 0, 0, 0, stream, &f,
+                   wfrag_f16, nullptr, 0, 0, 0, scale);
 }

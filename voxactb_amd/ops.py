@@ -324,7 +324,7 @@ def conv3d(src0, wt, N, B, S_in, S_out, kext, off, stride=1, replicate=True, bia
 
 
 def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=True, src1=None, ldy=None, d2s=(0, 0),
-                 nsplit=None, label=None, force_bf16=False, phase_mask=None, flops_frac=1.0):
+                 nsplit=None, label=None, force_bf16=False, phase_mask=None, flops_frac=1.0, dy_scale=None):
     """returns dWt [(tap, ci)][N] (fp32, deterministic split reduction).  phase_mask (LDS-halo kernel, d2s only): int32
     [N / 64] tap masks of the polyphase structure -- the structurally zero (tap, phase) blocks come back as zeros."""
     C0 = src0.shape[-1]
@@ -350,8 +350,10 @@ def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
         lbl = label or 'conv3d_wgrad[k%d s%d %d->%d S%d]' % (kext, stride, C0 + C1, N, S_out)
         f16 = mode == 'bf16x3' and WGRAD_PRECISION == 'fp16' and dy.is_contiguous()
         if f16:
-            _lib.set_meta(lbl, 0.0)
-            sc = absmax_scale(dy)
+            sc = dy_scale
+            if sc is None:                           # (the caller may already hold the scale of this dY: absmax_scale)
+                _lib.set_meta(lbl, 0.0)
+                sc = absmax_scale(dy)
             _lib.set_meta(lbl, 2.0 * P * N * K * flops_frac)
             call('vxb_conv3_wgrad_halo_f16_f32', src0, src1, C0, C1, B, S_in, S_out, off, int(replicate), dy, N,
                  ldy if ldy is not None else N, d2s[0], d2s[1], part, ns, phase_mask, sc)
@@ -548,19 +550,39 @@ def dgrad_fold_ok(C_dy, N, S):
             and (So - 2) // 4 == (So - 1) // 4 and (So - 2) // 8 == (So - 1) // 8)
 
 
-def conv3_dgrad_fold(dy, wt_dgrad, B, S, N, dsts, label=None):
+def conv3_dgrad_fold(dy, wt_dgrad, B, S, N, dsts, label=None, dy_scale=None, leaf_blocks=()):
     """fold_pad(conv3d(dy, wt_dgrad, zero pad, S+2), pad=1) without the padded tensor: dsts = [(dst [B,S,S,S,64],
-    accumulate, lrelu_of or None)] per 64-column block (1 or 2 entries)."""
+    accumulate, lrelu_of or None)] per 64-column block (1 or 2 entries).
+    leaf_blocks: the column blocks whose result only feeds a weight gradient (nothing propagates from them); with
+    WGRAD_PRECISION == 'fp16' those are evaluated with a single fp16 product per term, dy scaled by dy_scale (absmax_scale of dy,
+    computed here when None) -- the others keep the bf16x3 triple."""
     C0 = dy.shape[-1]
     wb = to_bf16_nk(wt_dgrad)
     x3 = wb.dim() == 3
     d0, a0, y0 = dsts[0]
     d1, a1, y1 = dsts[1] if len(dsts) > 1 else (None, False, None)
+    lbl = label or 'conv3d_bf16[k3 s1 %d->%d S%d dgrad+fold]' % (C0, N, S + 2)
     # algorithmic work = the data gradient on the S^3 grid (the kernel evaluates it on the zero-padded (S+2)^3 domain and folds the
     # border back in its epilogue: those 6 % extra MFMAs are not counted)
-    _lib.set_meta(label or 'conv3d_bf16[k3 s1 %d->%d S%d dgrad+fold]' % (C0, N, S + 2), 2.0 * B * S ** 3 * N * 27 * C0)
+    flops = 2.0 * B * S ** 3 * N * 27 * C0
+    _lib.set_meta(lbl, flops)
     wf = halo_wfrag(wb, C0)
-    _lib.set_meta(label or 'conv3d_bf16[k3 s1 %d->%d S%d dgrad+fold]' % (C0, N, S + 2), 2.0 * B * S ** 3 * N * 27 * C0)
+    if x3 and wf is not None and WGRAD_PRECISION == 'fp16' and leaf_blocks and N == 64 * len(dsts) and dy.is_contiguous():
+        sc = dy_scale
+        for nb, (dst, acc, yv) in enumerate(dsts):
+            if nb in leaf_blocks:
+                if sc is None:
+                    _lib.set_meta(lbl, 0.0)
+                    sc = absmax_scale(dy)
+                w16 = wt_dgrad[:, 64 * nb:64 * nb + 64].t().contiguous().half()           # [64][27 C0]
+                wf16 = halo_wfrag(w16, C0)
+                _lib.set_meta(lbl, flops / len(dsts))
+                call('vxb_conv3_dgrad_fold_f16_f32', dy, C0, B, S, wf16, dst, yv, int(acc), LRELU_SLOPE, sc)
+            else:
+                _lib.set_meta(lbl, flops / len(dsts))
+                call('vxb_conv3_dgrad_fold_f32', dy, C0, B, S, wb, 1, 64, dst, None, yv, None, int(acc), 0, LRELU_SLOPE, wf[nb:nb + 1])
+        return
+    _lib.set_meta(lbl, flops)
     call('vxb_conv3_dgrad_fold_f32', dy, C0, B, S, wb, int(x3), N, d0, d1, y0, y1, int(a0), int(a1), LRELU_SLOPE, wf)
 
 
