@@ -374,7 +374,12 @@ PMC_TRAFFIC_C2 = {
 # HBM bytes the voxelizer chain really moves per call at configs[1] (B=16, V=100, 4 x 128 x 128 points), from separate
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/bench_voxel.py (sum over the kernels of one call; FETCH_SIZE x 2 as
 # MI355X_MICROARCH.md prescribes for gfx950); profiles/r03_voxel_*_pmc_*.txt.  None = not measured for this geometry.
-PMC_VOXEL_BYTES = {('incremental', 100, 16): None, ('stateless', 100, 16): None}
+PMC_VOXEL_BYTES = {
+    # route 12.5 + light 17.6 + heavy 12.5 + unpatch 7.3 + classify 0.6 = 50.6 MiB fetched (x2) + 127.3 MiB written
+    ('incremental', 100, 16): (2 * 50564.0 + 127279.0) * 1024.0,
+    # the same chain + the 640 MB fill of a fresh grid: 43.3 MiB fetched (x2) + 727.2 MiB written
+    ('stateless', 100, 16): (2 * 43264.0 + 727173.0) * 1024.0,
+}
 
 
 def voxel_roofline(ms, alg_bytes, V, B, incremental):

@@ -211,7 +211,9 @@ int vxb_conv3_halo_bf16x3_f32(const float* src0, const float* src1, int C0, int 
  * Replaces the pair at perceiver_lang_io.py:462 (backward of `final` into d0 and u0). */
 int vxb_conv3_dgrad_fold_f32(const float* dy, int C0, int B, int S, const void* wt_bf16, int x3, int N, float* dst0,
                              float* dst1, const float* y0, const float* y1, int acc0, int acc1, float slope,
-                             const void* wfrag, vxb_stream_t stream);
+                             const void* wfrag, float* dst_scale, float* scale_ws, vxb_stream_t stream);
+/* workgroups of that launch = words of scale_ws needed when dst_scale is asked for */
+size_t vxb_conv3_dgrad_fold_blocks(int B, int S, int N);
 /* ... one 64-column block of it with a single fp16 product per term (dy * scale[0] -> half, result * scale[1]; scale on the
  * device, vxb_absmax_scale_f32; weights in fragment order of the fp16 [64][27 C0] matrix): the d(d0) half of `final`'s data
  * gradient, which only feeds the weight gradient of the 1x1x1 input conv (a leaf of the backward pass). */
@@ -298,7 +300,7 @@ size_t vxb_conv3_c1_dgrad_ss3d_ws_floats(int B, int S);
 int vxb_conv3_c1_dgrad_ss3d_f32(const float* dq, const float* w, const float* u, float* du, int B, int S, int C,
                                 int accumulate, float slope, const float* lin, const float* stats, const float* out_ss,
                                 const int32_t* argmax, const float* g_ss, const float* g_max, float* dbias,
-                                float* part_ws, vxb_stream_t stream);
+                                float* part_ws, float* du_scale, vxb_stream_t stream);
 
 /* SpatialSoftmax3D (T=0.01, meshgrid 'xy' quirk) + AdaptiveMaxPool3d(1) in one streaming pass
  * (network_utils.py:773-809; perceiver_lang_io.py:360,:451,:470), and the backward of both.

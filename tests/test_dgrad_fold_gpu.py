@@ -80,3 +80,30 @@ def test_dgrad_fold_leaf_block_on_single_fp16_products(S, B, gain):
     assert torch.equal(g0, h0)
     err = float((g0 - r0).abs().max()) / float((r0 - base0).abs().max())
     assert 0 < err < 1.5e-3, err                                             # 2^-12 per operand over a 27 x 64 term sum
+
+
+def test_fused_operand_scales_equal_the_absmax_pass():
+    """the fp16 operand scales taken inside the producers (the fused du kernel, the data gradient's fold epilogue) are the ones
+    vxb_absmax_scale_f32 computes from the finished tensors"""
+    B, S, C = 2, 20, 64
+    dy = cl(rnd(B, C, S, S, S, seed=3) * 3e-4).to(DEV)
+    W = rnd(C, 128, 3, 3, 3, seed=1, scale=0.1).to(DEV)
+    y1 = cl(rnd(B, 64, S, S, S, seed=5)).to(DEV)
+    ops.PRECISION, ops.WGRAD_PRECISION = 'bf16x3', 'fp16'
+    try:
+        g0, g1 = torch.zeros(B, S, S, S, 64, device=DEV), torch.empty(B, S, S, S, 64, device=DEV)
+        sc = ops.conv3_dgrad_fold(dy, ops.conv_weight_dgrad(W), B, S, 128, [(g0, False, None), (g1, False, y1)], leaf_blocks=(0,),
+                                  scale_blocks=(1,))
+    finally:
+        ops.PRECISION, ops.WGRAD_PRECISION = 'fp32', ''
+    assert torch.equal(sc[1], ops.absmax_scale(g1))
+    # the fused backward of u (c1 data gradient + SpatialSoftmax3D term + LeakyReLU' + bias sums)
+    u = cl(rnd(B, 64, S, S, S, seed=8)).to(DEV)
+    dq = rnd(B, S, S, S, seed=9).to(DEV) * 1e-5
+    w = rnd(1, 64, 3, 3, 3, seed=10, scale=0.1).to(DEV)
+    ss, mx, st, am = ops.ss3d_max_fwd(u, S ** 3 * 64, B, S, 64)
+    gss, gmx = rnd(B, 192, seed=11).to(DEV) * 1e-3, rnd(B, 64, seed=12).to(DEV) * 1e-3
+    du = torch.empty_like(u)
+    db = torch.zeros(64, device=DEV)
+    _, sc_du = ops.conv3_c1_dgrad_ss3d(dq, w, u, du, B, S, st, ss, am, gss, gmx, db, want_scale=True)
+    assert torch.equal(sc_du, ops.absmax_scale(du))

@@ -19,6 +19,18 @@ for grp in "GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAI
 done
 python tools/pmc_clock.py $O/sq 24 > $O/sq_summary.txt 2>&1
 rm -rf $O/sq $O/sq_*.log
+# the voxelizer alone: kernel times and the HBM bytes one call really moves, incremental (persistent = 2: the training path) and
+# stateless (persistent = 0: fresh grid, every cell written); 5 warm-up + 20 timed calls each -> divide the totals by 25
+for pv in 0 2; do
+  rocprofv3 --kernel-trace --stats -d $O/vprof$pv -o p -- python tools/bench_voxel.py --persistent $pv --iters 20 > $O/voxel_p$pv.json 2>/dev/null
+  python tools/prof_summary.py $O/vprof$pv/p_results.db 12 > $O/voxel_p${pv}_kernel_stats.txt
+  rm -rf $O/vprof$pv
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/vpmc -- python tools/bench_voxel.py --persistent $pv --iters 20 > /dev/null 2>&1
+    python tools/pmc_summary.py $O/vpmc 12 > $O/voxel_p${pv}_pmc_${c}.txt
+    rm -rf $O/vpmc
+  done
+done
 head -14 $O/step_kernel_stats.txt | cut -c1-150
 head -8 $O/pmc_FETCH_SIZE_summary.txt | cut -c1-150
 python -c "

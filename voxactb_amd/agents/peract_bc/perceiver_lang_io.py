@@ -681,20 +681,26 @@ class PerceiverEngine:
             dql = dq_trans_left.contiguous().view(B, V, V, V)
             ops.conv3_c1_wgrad(u, dql, self.g('trans_decoder_left_arm.conv3d.weight'), self.g('trans_decoder_left_arm.conv3d.bias'), B, V)
             ops.conv3_c1_dgrad(dql, self.p('trans_decoder_left_arm.conv3d.weight'), u, du, B, V, accumulate=not fuse_u, mask=False)
+        f16_leaf = ops.WGRAD_PRECISION == 'fp16' and C == 64 and ops.dgrad_fold_ok(C, 2 * C, V)
+        sc_du = None
         if fuse_u:
-            ops.conv3_c1_dgrad_ss3d(dq_trans, wt, u, du, B, V, st, ss, am, gs[4], gs[5], self.g('final.conv3d.bias'),
-                                    accumulate=self.two)
+            r = ops.conv3_c1_dgrad_ss3d(dq_trans, wt, u, du, B, V, st, ss, am, gs[4], gs[5], self.g('final.conv3d.bias'),
+                                        accumulate=self.two, want_scale=f16_leaf)
+            if f16_leaf:
+                sc_du = r[1]
         else:
             ops.conv3_c1_dgrad(dq_trans, wt, u, du, B, V, accumulate=True, mask=True)      # du is now d(pre-activation of `final`)
         # ---- final conv (two sources)
         Wf = self.p('final.conv3d.weight')
         # one |du| maximum serves both single-fp16-product kernels that read du (the weight gradient and the d(d0) half of the data
         # gradient); None in the other precisions
-        sc_du = ops.absmax_scale(du) if (ops.WGRAD_PRECISION == 'fp16' and C == 64 and ops.dgrad_fold_ok(C, 2 * C, V)) else None
+        if f16_leaf and sc_du is None:
+            sc_du = ops.absmax_scale(du)
         dWt = ops.conv3d_wgrad(d0, du, C, B, V, V, 3, -1, src1=u0, dy_scale=sc_du)
         self.g('final.conv3d.weight').add_(dWt.view(27, 2 * C, C).permute(2, 1, 0).reshape(Wf.shape))
         if not fuse_u:
             ops.colsum(du.view(-1, C), self.g('final.conv3d.bias'), accumulate=True)
+        sc_du0 = None
         dd0 = E(B, V, V, V, C)
         # the pooled-feature gradient of d0 (ss0) is added inside the input conv's weight-gradient kernel, the last reader of
         # dd0; otherwise it is dd0's first writer
@@ -708,8 +714,8 @@ class PerceiverEngine:
             # the other 64 become d(pre-activation of up0's last conv) through u0's LeakyReLU'
             # d(d0) feeds nothing but the weight gradient of the 1x1x1 input conv (the voxel grid is a detached input, agent :100):
             # a leaf -- its column block may run on single fp16 products; d(u0) propagates through the decoder and stays bf16x3
-            ops.conv3_dgrad_fold(du, ops.conv_weight_dgrad(Wf), B, V, 2 * C, [(dd0, not fuse_ss0, None), (du0, False, u0)],
-                                 dy_scale=sc_du, leaf_blocks=(0,))
+            sc_du0 = ops.conv3_dgrad_fold(du, ops.conv_weight_dgrad(Wf), B, V, 2 * C, [(dd0, not fuse_ss0, None), (du0, False, u0)],
+                                          dy_scale=sc_du, leaf_blocks=(0,), scale_blocks=(1,)).get(1)
         else:
             dcat = ops.conv3d(du, ops.conv_weight_dgrad(Wf), 2 * C, B, V, V + 2, 3, -2, replicate=False)
             ops.fold_pad(dcat, V + 2, 2 * C, 0, dd0, B, V, C, 1, accumulate=not fuse_ss0)
@@ -726,7 +732,8 @@ class PerceiverEngine:
             kl, R = self.kl, self.R
             pst = ops.polyphase_structure(k, s, dev) if ops.POLY_SPARSE else None
             dWeff = ops.conv3d_wgrad(z1, du0, s ** 3 * C, B, G, G, kl, -R, d2s=(s, C),
-                                     phase_mask=pst['phase_mask_t'] if pst else None, flops_frac=pst['frac'] if pst else 1.0)
+                                     phase_mask=pst['phase_mask_t'] if pst else None, flops_frac=pst['frac'] if pst else 1.0,
+                                     dy_scale=sc_du0)
             ops.polyphase_weights_bwd(dWeff, self.Lt(dev), self.g(up2 + '.weight'), s, kl)
             Sp = G + 2 * R
             if ops.s2d_halo_ok(kl, C, C):

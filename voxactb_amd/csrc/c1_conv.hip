@@ -108,9 +108,12 @@ __global__ void __launch_bounds__(256, 2) c1_dgrad4_ss_kernel(const float* __res
                                                            int accumulate, float slope, const float* __restrict__ lin,
                                                            const float* __restrict__ stats, const float* __restrict__ out_ss,
                                                            const int* __restrict__ argmax, const float* __restrict__ g_ss,
-                                                           const float* __restrict__ g_max, float* __restrict__ partB) {
+                                                           const float* __restrict__ g_max, float* __restrict__ partB,
+                                                           unsigned* __restrict__ part_amax) {
     __shared__ float sw[27 * 64];          // [t][c]
     __shared__ float red[16][64];
+    __shared__ unsigned ramx[4];
+    unsigned amx = 0;                       // largest |du| this thread wrote (magnitude bits: NaN > inf > finite)
     for (int i = threadIdx.x; i < 27 * 64; i += 256) sw[(i % 27) * 64 + i / 27] = w[i];
     const DivT divT(0.01f);
     const int c4 = (threadIdx.x & 15) * 4, gl = threadIdx.x >> 4;
@@ -214,6 +217,7 @@ __global__ void __launch_bounds__(256, 2) c1_dgrad4_ss_kernel(const float* __res
                 v = xs[e] > 0.f ? v : v * slope;
                 bsum[e] += v;
                 r[e] = v;
+                amx = max(amx, __float_as_uint(v) & 0x7fffffffu);
             }
             *reinterpret_cast<float4*>(dub + (long long)p * 64) = make_float4(r[0], r[1], r[2], r[3]);
         }
@@ -226,6 +230,13 @@ __global__ void __launch_bounds__(256, 2) c1_dgrad4_ss_kernel(const float* __res
 #pragma unroll
         for (int g = 0; g < 16; ++g) sacc += red[g][threadIdx.x];
         partB[((long long)b * gridDim.x + blockIdx.x) * 64 + threadIdx.x] = sacc;
+    }
+    if (part_amax) {                        // (uniform) per-block maximum of |du| for the fp16 kernels that read du next
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o, 64));
+        if ((threadIdx.x & 63) == 0) ramx[threadIdx.x >> 6] = amx;
+        __syncthreads();
+        if (threadIdx.x == 0) part_amax[b * gridDim.x + blockIdx.x] = max(max(ramx[0], ramx[1]), max(ramx[2], ramx[3]));
     }
 }
 
@@ -408,10 +419,10 @@ int vxb_c1_dgrad_ss_blocks_per_sample(int S) {
 }
 int vxb_c1_dgrad4_ss_launch(const float* dq, const float* w, const float* u, float* du, int B, int S, int accumulate, float slope,
                             const float* lin, const float* stats, const float* out_ss, const int* argmax, const float* g_ss,
-                            const float* g_max, float* dbias, float* part_ws, hipStream_t st) {
+                            const float* g_max, float* dbias, float* part_ws, unsigned* part_amax, hipStream_t st) {
     const int nbx = vxb_c1_dgrad_ss_blocks_per_sample(S);
     hipLaunchKernelGGL(c1_dgrad4_ss_kernel, dim3(nbx, B), dim3(256), 0, st, dq, w, u, du, S, accumulate, slope, lin, stats, out_ss,
-                       argmax, g_ss, g_max, part_ws);
+                       argmax, g_ss, g_max, part_ws, part_amax);
     // two stages (fixed order): 64 workgroups fold nb / 64 partial rows each into the head of a second buffer, one more folds those
     const int nb = nbx * B, per = (nb + 63) / 64;
     float* part2 = part_ws + (size_t)nb * 64;

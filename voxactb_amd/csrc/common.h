@@ -23,7 +23,9 @@ int vxb_c1_fwd4_launch(const float* u, const float* w, const float* bias, float*
 int vxb_c1_dgrad_ss_blocks_per_sample(int S);
 int vxb_c1_dgrad4_ss_launch(const float* dq, const float* w, const float* u, float* du, int B, int S, int accumulate, float slope,
                             const float* lin, const float* stats, const float* out_ss, const int* argmax, const float* g_ss,
-                            const float* g_max, float* dbias, float* part_ws, hipStream_t st);
+                            const float* g_max, float* dbias, float* part_ws, unsigned* part_amax, hipStream_t st);
+// scale[0] = 2^k mapping the largest of n per-block |x| maxima (magnitude bits) into [2^14, 2^15), scale[1] = 1 / scale[0] (nn_ops.hip)
+int vxb_absmax_finish_launch(const unsigned* part, int n, float* scale, hipStream_t st);
 int vxb_c1_dgrad4_launch(const float* dq, const float* w, const float* u, float* du, int B, int S, int accumulate, int mask,
                          float slope, hipStream_t st);
 int vxb_c1_wgrad4_launch(const float* u, const float* dq, float* dw, float* db, float* part_ws, int B, int S, hipStream_t st);

@@ -67,6 +67,7 @@ struct HaloArgs {
     // 'fp16' products (PM = 2): the input is multiplied by scale[0] before the conversion to half (a power of two taken from
     // its largest magnitude, vxb_absmax_scale_f32) and the result by scale[1] = 1 / scale[0] in the epilogue; nullptr = 1
     const float* scale;
+    unsigned* amax_part;     // fold mode, optional: word [workgroup] = largest magnitude (bits) this workgroup wrote to its destination
 };
 
 // bf16 pair from two fp32 (RNE).  Both forms give identical bits; which one is FASTER was measured per precision on the
@@ -479,6 +480,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
         float* __restrict__ dst = g.fold_dst[nb];
         const float* __restrict__ yv = g.fold_y[nb];
         const int facc = g.fold_acc[nb];
+        unsigned amx = 0;
         for (int item = tid; item < TD * TH * TW * 16; item += NTH) {
             const int c4 = (item & 15) * 4, pos = item >> 4;
             const int wl = pos % TW, hl = (pos / TW) % TH, dl = pos / (TW * TH);
@@ -509,6 +511,20 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
                 a.z = yy.z > 0.f ? a.z : a.z * g.slope; a.w = yy.w > 0.f ? a.w : a.w * g.slope;
             }
             *reinterpret_cast<float4*>(dst + o) = a;
+            amx = max(max(amx, __float_as_uint(a.x) & 0x7fffffffu), max(max(__float_as_uint(a.y) & 0x7fffffffu, __float_as_uint(a.z) & 0x7fffffffu),
+                                                                         __float_as_uint(a.w) & 0x7fffffffu));
+        }
+        if (g.amax_part) {                  // (uniform) the fp16 operand scale of the tensor just written is taken on the way
+            __shared__ unsigned famx[8];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o, 64));
+            if (lane == 0) famx[wid] = amx;
+            __syncthreads();
+            if (tid == 0) {
+                unsigned m = 0;
+                for (int w = 0; w < NW; ++w) m = max(m, famx[w]);
+                g.amax_part[blockIdx.x] = m;
+            }
         }
         return;
     }
@@ -581,6 +597,7 @@ int hb_impl(int x3 /* product mode: 0 bf16, 1 bf16x3, 2 fp16 (WD kernels only, `
     g.s2d_s = s2d_s; g.s2d_C = s2d_C; g.d2s_s = d2s_s; g.wfrag = (const u16*)wfrag;
     g.dbg = g_halo_dbg;
     g.scale = scale;
+    g.amax_part = fold ? fold->amax_part : nullptr;
     g.fold_pad = 0; g.fold_S = 0; g.fold_dst[0] = g.fold_dst[1] = nullptr; g.fold_y[0] = g.fold_y[1] = nullptr;
     g.fold_acc[0] = g.fold_acc[1] = 0;
     if (fold) {
@@ -641,8 +658,11 @@ extern "C" int vxb_conv3_halo_bf16x3_f32(const float* src0, const float* src1, i
 // given).  x3 != 0: weights are the [2][N][K] planes ('bf16x3').  pad = 1.
 extern "C" int vxb_conv3_dgrad_fold_f32(const float* dy, int C0, int B, int S, const void* wt_bf16, int x3, int N, float* dst0,
                                         float* dst1, const float* y0, const float* y1, int acc0, int acc1, float slope,
-                                        const void* wfrag, vxb_stream_t stream) {
+                                        const void* wfrag, float* dst_scale, float* scale_ws, vxb_stream_t stream) {
+    // dst_scale (optional, [2], needs scale_ws of vxb_conv3_dgrad_fold_blocks words; N = 64 only): the fp16 operand scale of dst0 as
+    // vxb_absmax_scale_f32 would compute it, taken while dst0 is written
     if (!dy || !wt_bf16 || !dst0 || (N > 64 && !dst1) || N > 128 || S < 2) return VXB_EARG;
+    if (dst_scale && (!scale_ws || N != 64)) return VXB_EARG;
     const int pad = 1, S_out = S + 2 * pad;
     // every border group {0..pad} / {S-1+pad..S-1+2 pad} must lie inside one tile
     if ((S_out - 1 - pad) / TD != (S_out - 1) / TD || (S_out - 1 - pad) / TH != (S_out - 1) / TH || (S_out - 1 - pad) / TW != (S_out - 1) / TW)
@@ -650,7 +670,16 @@ extern "C" int vxb_conv3_dgrad_fold_f32(const float* dy, int C0, int B, int S, c
     HaloArgs f;
     f.fold_pad = pad; f.fold_S = S; f.fold_dst[0] = dst0; f.fold_dst[1] = dst1; f.fold_y[0] = y0; f.fold_y[1] = y1;
     f.fold_acc[0] = acc0; f.fold_acc[1] = acc1;
-    return hb_impl(x3 ? 1 : 0, dy, nullptr, C0, 0, B, S, S_out, -2 * pad, 0, wt_bf16, N, nullptr, nullptr, 0, slope, 0, 0, 0, stream, &f, wfrag);
+    f.amax_part = dst_scale ? reinterpret_cast<unsigned*>(scale_ws) : nullptr;
+    int rc = hb_impl(x3 ? 1 : 0, dy, nullptr, C0, 0, B, S, S_out, -2 * pad, 0, wt_bf16, N, nullptr, nullptr, 0, slope, 0, 0, 0, stream, &f, wfrag);
+    if (rc || !dst_scale) return rc;
+    return vxb_absmax_finish_launch(f.amax_part, (int)vxb_conv3_dgrad_fold_blocks(B, S, N), dst_scale, (hipStream_t)stream);
+}
+
+extern "C" size_t vxb_conv3_dgrad_fold_blocks(int B, int S, int N) {
+    if (B < 1 || S < 2 || N < 64) return 0;
+    const int So = S + 2;
+    return (size_t)B * vxb_cdiv(So, TD) * vxb_cdiv(So, TH) * vxb_cdiv(So, TW) * (N / 64);
 }
 
 // The same data gradient + padding adjoint for ONE 64-column block with a single fp16 product per term: dy is multiplied by
@@ -668,6 +697,7 @@ extern "C" int vxb_conv3_dgrad_fold_f16_f32(const float* dy, int C0, int B, int 
     HaloArgs f;
     f.fold_pad = pad; f.fold_S = S; f.fold_dst[0] = dst; f.fold_dst[1] = nullptr; f.fold_y[0] = y; f.fold_y[1] = nullptr;
     f.fold_acc[0] = acc; f.fold_acc[1] = 0;
+    f.amax_part = nullptr;
     return hb_impl(2, dy, nullptr, C0, 0, B, S, S_out, -2 * pad, 0, wfrag_f16, 64, nullptr, nullptr, 0, slope, 0, 0, 0, stream, &f,
                    wfrag_f16, nullptr, 0, 0, 0, scale);
 }

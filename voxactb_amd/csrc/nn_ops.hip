@@ -720,6 +720,13 @@ extern "C" int vxb_sum_splits_dev_f32(const float* part, int nsplit, int64_t n, 
     return VXB_OK;
 }
 
+int vxb_absmax_finish_launch(const unsigned* part, int n, float* scale, hipStream_t st) {
+    if (!part || !scale || n < 1) return VXB_EARG;
+    hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, st, part, n, scale);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
 extern "C" int vxb_absmax_scale_f32(const float* x, int64_t n, float* ws, float* scale, vxb_stream_t stream) {
     if (!x || !ws || !scale || n < 1) return VXB_EARG;
     if ((uintptr_t)x & 15) return VXB_ESIZE;

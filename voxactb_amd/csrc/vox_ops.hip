@@ -1330,17 +1330,22 @@ extern "C" int vxb_conv3_c1_dgrad_f32(const float* dq, const float* w, const flo
 // du = lrelu'(u) * ([du] + conv3_c1 data gradient of dq + the pooled-feature term of vxb_ss3d_max_bwd_f32 on u), and
 // dbias[64] += column sums of the finished du -- one pass over u / du instead of three (c1_conv.hip).  S % 4 == 0, C = 64.
 extern "C" size_t vxb_conv3_c1_dgrad_ss3d_ws_floats(int B, int S) {
-    return ((size_t)vxb_c1_dgrad_ss_blocks_per_sample(S) * (size_t)B + 64) * 64;
+    return ((size_t)vxb_c1_dgrad_ss_blocks_per_sample(S) * (size_t)B + 64) * 65;      // (+ one |du| maximum per block)
 }
 extern "C" int vxb_conv3_c1_dgrad_ss3d_f32(const float* dq, const float* w, const float* u, float* du, int B, int S, int C,
                                            int accumulate, float slope, const float* lin, const float* stats, const float* out_ss,
                                            const int32_t* argmax, const float* g_ss, const float* g_max, float* dbias,
-                                           float* part_ws, vxb_stream_t stream) {
+                                           float* part_ws, float* du_scale, vxb_stream_t stream) {
     if (!dq || !w || !u || !du || !lin || !stats || !out_ss || !argmax || !g_ss || !g_max || !dbias || !part_ws || B < 1 || S < 4)
         return VXB_EARG;
     if (C != 64 || (S & 3) || ((((uintptr_t)u) | ((uintptr_t)du)) & 15)) return VXB_ESIZE;
-    return vxb_c1_dgrad4_ss_launch(dq, w, u, du, B, S, accumulate, slope, lin, stats, out_ss, argmax, g_ss, g_max, dbias, part_ws,
-                                   (hipStream_t)stream);
+    // du_scale (optional, [2]): the fp16 operand scale of du (as vxb_absmax_scale_f32 would compute it), taken while du is written
+    const int nb = vxb_c1_dgrad_ss_blocks_per_sample(S) * B;
+    unsigned* part_amax = du_scale ? reinterpret_cast<unsigned*>(part_ws + ((size_t)nb + 64) * 64) : nullptr;
+    int rc = vxb_c1_dgrad4_ss_launch(dq, w, u, du, B, S, accumulate, slope, lin, stats, out_ss, argmax, g_ss, g_max, dbias, part_ws,
+                                     part_amax, (hipStream_t)stream);
+    if (rc || !du_scale) return rc;
+    return vxb_absmax_finish_launch(part_amax, nb, du_scale, (hipStream_t)stream);
 }
 extern "C" int vxb_conv3_c1_wgrad_f32(const float* u, const float* dq, float* dw, float* db, float* part_ws, int B, int S, int C,
                                       vxb_stream_t stream) {

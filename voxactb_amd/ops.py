@@ -550,12 +550,13 @@ def dgrad_fold_ok(C_dy, N, S):
             and (So - 2) // 4 == (So - 1) // 4 and (So - 2) // 8 == (So - 1) // 8)
 
 
-def conv3_dgrad_fold(dy, wt_dgrad, B, S, N, dsts, label=None, dy_scale=None, leaf_blocks=()):
+def conv3_dgrad_fold(dy, wt_dgrad, B, S, N, dsts, label=None, dy_scale=None, leaf_blocks=(), scale_blocks=()):
     """fold_pad(conv3d(dy, wt_dgrad, zero pad, S+2), pad=1) without the padded tensor: dsts = [(dst [B,S,S,S,64],
     accumulate, lrelu_of or None)] per 64-column block (1 or 2 entries).
     leaf_blocks: the column blocks whose result only feeds a weight gradient (nothing propagates from them); with
     WGRAD_PRECISION == 'fp16' those are evaluated with a single fp16 product per term, dy scaled by dy_scale (absmax_scale of dy,
-    computed here when None) -- the others keep the bf16x3 triple."""
+    computed here when None) -- the others keep the bf16x3 triple.  scale_blocks: the (non-leaf) blocks whose destination's own fp16
+    operand scale is wanted (taken in the epilogue while the tensor is written); returns {block: [scale, 1 / scale]}."""
     C0 = dy.shape[-1]
     wb = to_bf16_nk(wt_dgrad)
     x3 = wb.dim() == 3
@@ -567,6 +568,7 @@ def conv3_dgrad_fold(dy, wt_dgrad, B, S, N, dsts, label=None, dy_scale=None, lea
     flops = 2.0 * B * S ** 3 * N * 27 * C0
     _lib.set_meta(lbl, flops)
     wf = halo_wfrag(wb, C0)
+    scales = {}
     if x3 and wf is not None and WGRAD_PRECISION == 'fp16' and leaf_blocks and N == 64 * len(dsts) and dy.is_contiguous():
         sc = dy_scale
         for nb, (dst, acc, yv) in enumerate(dsts):
@@ -579,11 +581,17 @@ def conv3_dgrad_fold(dy, wt_dgrad, B, S, N, dsts, label=None, dy_scale=None, lea
                 _lib.set_meta(lbl, flops / len(dsts))
                 call('vxb_conv3_dgrad_fold_f16_f32', dy, C0, B, S, wf16, dst, yv, int(acc), LRELU_SLOPE, sc)
             else:
+                dsc = sws = None
+                if nb in scale_blocks:
+                    dsc = scales[nb] = torch.empty(2, dtype=torch.float32, device=dy.device)
+                    sws = torch.empty(int(_lib.lib().vxb_conv3_dgrad_fold_blocks(B, S, 64)), dtype=torch.float32, device=dy.device)
                 _lib.set_meta(lbl, flops / len(dsts))
-                call('vxb_conv3_dgrad_fold_f32', dy, C0, B, S, wb, 1, 64, dst, None, yv, None, int(acc), 0, LRELU_SLOPE, wf[nb:nb + 1])
-        return
+                call('vxb_conv3_dgrad_fold_f32', dy, C0, B, S, wb, 1, 64, dst, None, yv, None, int(acc), 0, LRELU_SLOPE, wf[nb:nb + 1],
+                     dsc, sws)
+        return scales
     _lib.set_meta(lbl, flops)
-    call('vxb_conv3_dgrad_fold_f32', dy, C0, B, S, wb, int(x3), N, d0, d1, y0, y1, int(a0), int(a1), LRELU_SLOPE, wf)
+    call('vxb_conv3_dgrad_fold_f32', dy, C0, B, S, wb, int(x3), N, d0, d1, y0, y1, int(a0), int(a1), LRELU_SLOPE, wf, None, None)
+    return scales
 
 
 def s2d_halo_ok(kl, C, N):
@@ -762,12 +770,15 @@ def c1_dgrad_ss3d_ok(S, C):
     return C == 64 and S % 4 == 0
 
 
-def conv3_c1_dgrad_ss3d(dq, w, u, du, B, S, stats, out_ss, argmax, g_ss, g_max, dbias, accumulate=False):
-    """du = lrelu'(u) * ([du] + c1 data gradient + the ss3d_max_bwd term of u); dbias += column sums of du."""
+def conv3_c1_dgrad_ss3d(dq, w, u, du, B, S, stats, out_ss, argmax, g_ss, g_max, dbias, accumulate=False, want_scale=False):
+    """du = lrelu'(u) * ([du] + c1 data gradient + the ss3d_max_bwd term of u); dbias += column sums of du.
+    want_scale: also return the fp16 operand scale of du ([scale, 1 / scale] on the device, as absmax_scale(du)), taken while du
+    is written -- no extra pass over the 4 GB tensor."""
     ws = torch.empty(int(_lib.lib().vxb_conv3_c1_dgrad_ss3d_ws_floats(B, S)), dtype=torch.float32, device=u.device)
+    sc = torch.empty(2, dtype=torch.float32, device=u.device) if want_scale else None
     call('vxb_conv3_c1_dgrad_ss3d_f32', dq, w, u, du, B, S, 64, int(accumulate), LRELU_SLOPE, lin_table(S, u.device), stats, out_ss,
-         argmax, g_ss, g_max, dbias, ws)
-    return du
+         argmax, g_ss, g_max, dbias, ws, sc)
+    return (du, sc) if want_scale else du
 
 
 def conv3_c1_wgrad(u, dq, dw, db, B, S):
