@@ -95,6 +95,7 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
     constexpr int NXL = (NCH * XF4 + NTH - 1) / NTH;      // 7 / 6 float4 x loads per thread per tile
     constexpr int NDL = 128 * 16 / NTH;                   // 8 / 4 float4 dY loads per thread per tile
     constexpr int HB = WTH / 4;                           // k-steps (4 h-rows x 8 w) per d-plane
+    constexpr bool FASTADDR = PM == 2;                    // table-driven load addresses (below): the issue-bound fp16 variants only
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* xs = smem;                                   // [NCH][1 + X3][XSLOTS][16]
     u16* ds = smem + NCH * (1 + X3) * XPL;            // [1 + X3][128][DLD]
@@ -146,7 +147,74 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
     // opaque copy of the thread id on every call.  As loop invariants the ~40 values were hoisted out of the tile loop, kept
     // live across it and spilled -- and every scratch reload in here is an s_waitcnt vmcnt(0) that drains the prefetch
     // loads issued before it: the 15 loads of a tile arrived one at a time (half of the kernel's time was that wait).
-    auto issue = [&](int tile) {
+    // ---- fast path of issue() for tiles whose halo and dY block lie inside the grid (no clamping, no padding, no ragged edge):
+    // the address of load slot i is  (per-tile scalar base) + (per-slot constant offset).  The per-slot constants are computed
+    // ONCE and parked in LDS (as registers they would be hoisted values that spill, see above); a tile then costs one LDS read
+    // and one load per slot instead of ~35 VALU instructions of index arithmetic -- the fp16 variants of this kernel are
+    // issue-bound on exactly that arithmetic (profiles/r03_v1_sq_summary.txt: 42-48 % of wave time issuing, matrix pipe 23-33 %).
+    int* tabx = reinterpret_cast<int*>(smem + (1 + X3) * (NCH * XPL + DPL));      // [NXL][NTH] element offset, -1 = slot past the halo
+    int* tabd = tabx + NXL * NTH;                                                  // [NDL][NTH]
+    // all chunks of this workgroup in one source (always, unless a chunk pair straddles the concatenation point)
+    const bool one_src = ((bx * NCH) * 16 >= g.C0) == ((bx * NCH + NCH - 1) * 16 >= g.C0);
+    const bool src_second = (bx * NCH) * 16 >= g.C0;
+    const int Cs_f = src_second ? g.C1 : g.C0;
+    const float* __restrict__ src_f = src_second ? g.src1 : g.src0;
+    if (FASTADDR) {
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) {
+            const int e = tid + NTH * i;
+            const int lch = NCH == 1 ? 0 : min(e / XF4, NCH - 1);
+            const int e2 = e - lch * XF4;
+            int p = e2 >> 2;
+            const int c4 = (e2 & 3) * 4;
+            const bool ok = p < XSLOTS && e < NCH * XF4;
+            p = min(p, XSLOTS - 1);
+            const int cbl = (bx * NCH + lch) * 16;
+            const int c0 = src_second ? cbl - g.C0 : cbl;
+            const int hw = p % XW; p /= XW;
+            const int hh = p % XH; p /= XH;
+            tabx[i * NTH + tid] = ok ? ((p * g.S_in + hh) * g.S_in + hw) * Cs_f + c0 + c4 : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < NDL; ++i) {
+            const int e = tid + NTH * i;
+            const int pos = e >> 4, n4 = (e & 15) * 4;
+            const int od = pos / (WTH * 8), oh = (pos >> 3) % WTH, ow = pos & 7;
+            tabd[i * NTH + tid] = (int)((((long long)od * ds_ * Vf + oh * ds_) * Vf + ow * ds_) * dy_row) + n4;
+        }
+        // (every thread reads back only its own entries: no barrier needed)
+    }
+    auto issue_fast = [&](int tile) __attribute__((always_inline)) -> bool {
+        int t = tile;
+        const int tw = t % g.ntw; t /= g.ntw;
+        const int th = t % g.nth; t /= g.nth;
+        const int td = t % g.ntd; t /= g.ntd;
+        const int b = t;
+        const int d0 = td * WTD, h0 = th * WTH, w0 = tw * WTW;
+        // uniform: everything in range?
+        const bool in = one_src && d0 + g.off >= 0 && d0 + WTD + 1 + g.off <= Sm && h0 + g.off >= 0 && h0 + WTH + 1 + g.off <= Sm &&
+                        w0 + g.off >= 0 && w0 + WTW + 1 + g.off <= Sm && d0 + WTD <= S && h0 + WTH <= S && w0 + WTW <= S;
+        if (!in) return false;
+        const long long xb = ((((long long)b * g.S_in + d0 + g.off) * g.S_in + h0 + g.off) * g.S_in + w0 + g.off) * Cs_f;
+        const float* __restrict__ xp = src_f + xb;
+        unsigned m = 0;
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) {
+            const int o = tabx[i * NTH + tid];
+            m |= (o >= 0 ? 1u : 0u) << i;
+            px[i] = *reinterpret_cast<const float4*>(xp + max(o, 0));
+        }
+        const long long db = ((((long long)b * Vf + (long long)d0 * ds_ + rd) * Vf + h0 * ds_ + rh) * Vf + w0 * ds_ + rw) * dy_row;
+        const float* __restrict__ dp = dyb + db;
+#pragma unroll
+        for (int i = 0; i < NDL; ++i) {
+            pd[i] = *reinterpret_cast<const float4*>(dp + tabd[i * NTH + tid]);
+            m |= 1u << (8 + i);
+        }
+        okm = m;
+        return true;
+    };
+    auto issue_slow = [&](int tile) __attribute__((always_inline)) {
         int t = tile;
         const int tw = t % g.ntw; t /= g.ntw;
         const int th = t % g.nth; t /= g.nth;
@@ -190,6 +258,9 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
             pd[i] = *reinterpret_cast<const float4*>(dyb + (long long)vox * dy_row + n4);
         }
         okm = m;
+    };
+    auto issue = [&](int tile) __attribute__((always_inline)) {
+        if (!(FASTADDR && issue_fast(tile))) issue_slow(tile);
     };
     const float dysc = (PM == 2 && g.dy_scale) ? *g.dy_scale : 1.0f;
     auto stage = [&]() {
@@ -331,7 +402,10 @@ static int wgrad_halo_launch(WhArgs& g, int nsplit, hipStream_t st) {
     g.ntiles = (long long)g.B * g.ntd * g.nth * g.ntw;
     if (g.ntiles >= INT32_MAX) return VXB_ESIZE;
     g.tiles_per_split = (int)((g.ntiles + nsplit - 1) / nsplit);
-    const size_t lds = (size_t)(1 + X3) * (NCH * (TD + 2) * (TH + 2) * XW * 16 + DPL) * sizeof(u16);
+    constexpr int NTHR = 256 * NCH;
+    constexpr int XF4_ = (TD + 2) * (TH + 2) * XW * 4;
+    const size_t lds = (size_t)(1 + X3) * (NCH * (TD + 2) * (TH + 2) * XW * 16 + DPL) * sizeof(u16) +
+                       (PM == 2 ? (size_t)((NCH * XF4_ + NTHR - 1) / NTHR + 128 * 16 / NTHR) * NTHR * sizeof(int) : 0);
     dim3 grid((g.C0 + g.C1) / (16 * NCH), g.N / 64, nsplit);
     if (hipFuncSetAttribute((const void*)wgrad_halo_kernel<PM, TD, TH, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
     hipLaunchKernelGGL((wgrad_halo_kernel<PM, TD, TH, NCH>), grid, dim3(256 * NCH), lds, st, g);
