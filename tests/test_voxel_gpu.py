@@ -210,6 +210,24 @@ def test_persistent_buffers_are_updated_in_place_to_the_same_grids():
         assert torch.equal(got, fresh.voxelize_cameras(far, rgb, bounds)) and float(got[..., -1].sum()) == 0
 
 
+def test_persistent_grid_check_catches_a_caller_that_wrote_into_a_returned_grid(monkeypatch):
+    """VOXACTB_VOXEL_CHECK: the reused buffers are handed out as views; the debug check compares an incremental update with a full
+    rewrite and raises when a holder has modified a grid in an EMPTY cell (which the incremental reset does not touch)."""
+    from voxactb_amd.voxel import voxel_grid as vgm
+    B, H, W, V = 2, 16, 16, 24
+    cams = ['front']
+    monkeypatch.setattr(vgm, 'CHECK_EVERY', 1)
+    pers = VoxelGrid(synthetic.SCENE_BOUNDS, V, DEV, B, 3, H * W, persistent=1)
+    pcd, rgb = cams_batch(B, cams, H, W, V, seed=31)
+    pcd, rgb = [p.to(DEV) for p in pcd], [r.to(DEV) for r in rgb]
+    g0 = pers.voxelize_cameras(pcd, rgb)
+    pers.voxelize_cameras(pcd, rgb)                         # incremental, checked, fine
+    empty = torch.nonzero(g0[..., -1] == 0)[0]
+    g0[empty[0], empty[1], empty[2], empty[3], 0] = 123.0      # a caller scribbles into the view it was given
+    with pytest.raises(Exception, match='differs from a full rewrite'):
+        pers.voxelize_cameras(pcd, rgb)
+
+
 def test_overlapped_launch_orders_give_the_same_grid():
     from voxactb_amd import _lib
     pcd, rgb = cams_batch(2, ['front', 'wrist'], 64, 64, 50, seed=8)

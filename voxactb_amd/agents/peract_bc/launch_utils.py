@@ -4,8 +4,13 @@
 
 `create_agent` accepts any object with the attribute paths hydra's DictConfig exposes upstream (cfg.method.*,
 cfg.rlbench.*, cfg.replay.batch_size, cfg.ddp.num_devices, cfg.framework.*), see `default_cfg()`.
-`create_replay` builds YARR's TaskUniformReplayBuffer when `yarr` is importable, else the built-in shard store
-(voxactb_amd/replay.py); `replay_schema` returns the element list either way.
+`create_replay` ALWAYS builds the built-in shard store (voxactb_amd/replay.py: `ShardReplayBuffer`, checked element for element
+against YARR's TaskUniformReplayBuffer by fixture F16) -- same constructor arguments, `add` / `add_final` /
+`sample_transition_batch` semantics and rank-strided task-uniform sampling, but: no wrap-around (it raises when `replay_size`
+rows are full; the offline demo replay never wraps), `timesteps == 1` and `update_horizon == 1` only, and binary column shards
+on disk instead of one pickle per transition, so an existing YARR replay directory is NOT reusable (refill it).
+`BatchStreamReplayBuffer(replay, num_workers=...)` accepts and ignores `num_workers` (one producer thread).
+`replay_schema` returns the element list.
 `fill_replay` / `_add_keypoints_to_replay` / `_get_action` do the label arithmetic here (helpers/rotation.py) and reach the
 simulator-side pieces -- stored-demo loading, keypoint discovery, observation extraction, CLIP tokenizer / text encoder --
 through `UPSTREAM`, a table of callables that resolves to the reference's own modules when they are importable (the

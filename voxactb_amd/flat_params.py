@@ -17,12 +17,11 @@ import os
 
 import torch
 
-ALIGN = 64
+ALIGN = 64        # floats: every tensor starts on a 256-byte boundary
 # debug / test switch: issue the collectives even with a single rank (RCCL refuses two ranks on one GPU, so a 1-GPU box can
 # only exercise the real backend -- communicator creation, the asynchronous bucket all-reduces on RCCL's stream behind the
 # compute stream's event, the wait before the optimizer -- with world size 1; tests/test_distributed_gpu.py)
 FORCE_COLLECTIVES = os.environ.get('VOXACTB_FORCE_COLLECTIVES', '0') == '1'
-   # floats: every tensor starts on a 256-byte boundary
 
 
 class FlatParams:

@@ -26,15 +26,53 @@ MAX_ATTEMPTS = 100        # augmentation.py:119
 MAX_ATTEMPTS_2ROBOTS = 400        # augmentation.py:239
 
 
-def _draws(bs, rot_aug_range, rot_aug_resolution, attempts):
-    """Random numbers of `attempts` attempts from torch's CPU generator: shifts uniform in (-1, 1), integer angle steps in
-    [-n, n] per axis with n = range // resolution (all zero for an axis whose range is smaller than one step)."""
-    unit = 2.0 * torch.rand((attempts, bs, 3)) - 1.0
-    steps = torch.zeros((attempts, bs, 3), dtype=torch.int32)
+_GEN = None          # dedicated CPU generator of the augmentation draws (seeded from torch's global seed at first use)
+_PINNED = {}         # (attempts, bs) -> ring of pinned staging buffers for the draws
+
+
+def _generator():
+    """Augmentation draws come from their OWN generator, seeded once from the global seed (so `torch.manual_seed(s)` before the
+    first update() still governs them), instead of from the global CPU generator: unrelated `torch.rand` calls of the host
+    program no longer shift the augmentation stream, and the dropout seed (drawn from the global generator) is independent."""
+    global _GEN
+    if _GEN is None:
+        _GEN = torch.Generator()
+        _GEN.manual_seed((torch.initial_seed() ^ 0x5E3A06) & 0x7FFFFFFFFFFFFFFF)
+    return _GEN
+
+
+def _draws(bs, rot_aug_range, rot_aug_resolution, attempts, device=None):
+    """Random numbers of `attempts` attempts: shifts uniform in (-1, 1), integer angle steps in [-n, n] per axis with
+    n = range // resolution (all zero for an axis whose range is smaller than one step).  The reference draws one attempt at a
+    time (utils.rand_dist / rand_discrete, augmentation.py:123-141); all attempts are drawn up front here because the retry
+    loop runs on the device.  With `device` the numbers are written into a ring of PINNED buffers and uploaded with
+    non-blocking copies (a pageable .to(device) on the compute stream would serialise the host with the GPU every step)."""
+    gen = _generator()
+    if device is None or torch.device(device).type != 'cuda':
+        unit = 2.0 * torch.rand((attempts, bs, 3), generator=gen) - 1.0
+        steps = torch.zeros((attempts, bs, 3), dtype=torch.int32)
+        for axis in range(3):
+            n = int(rot_aug_range[axis] // rot_aug_resolution)
+            if n > 0:
+                steps[:, :, axis] = torch.randint(-n, n + 1, (attempts, bs), dtype=torch.int32, generator=gen)
+        return unit, steps
+    ring = _PINNED.get((attempts, bs))
+    if ring is None:
+        ring = _PINNED[(attempts, bs)] = dict(slot=0, bufs=[
+            [torch.empty((attempts, bs, 3), dtype=torch.float32).pin_memory(), torch.zeros((attempts, bs, 3), dtype=torch.int32).pin_memory(),
+             None] for _ in range(4)])
+    buf = ring['bufs'][ring['slot']]
+    ring['slot'] = (ring['slot'] + 1) % len(ring['bufs'])
+    if buf[2] is not None:
+        buf[2].synchronize()                     # the upload out of this staging pair four calls ago has completed
+    buf[0].uniform_(-1.0, 1.0, generator=gen)
     for axis in range(3):
         n = int(rot_aug_range[axis] // rot_aug_resolution)
         if n > 0:
-            steps[:, :, axis] = torch.randint(-n, n + 1, (attempts, bs), dtype=torch.int32)
+            buf[1][:, :, axis].random_(-n, n + 1, generator=gen)
+    unit, steps = buf[0].to(device, non_blocking=True), buf[1].to(device, non_blocking=True)
+    buf[2] = torch.cuda.Event()
+    buf[2].record(torch.cuda.current_stream(device))
     return unit, steps
 
 
@@ -47,7 +85,7 @@ def se3_augmentation_plan(action_gripper_pose, action_rot_grip, bounds, layer, t
     bs = action_gripper_pose.shape[0]
     dev = action_gripper_pose.device
     if draws is None:
-        draws = _draws(bs, rot_aug_range, rot_aug_resolution, attempts)
+        draws = _draws(bs, rot_aug_range, rot_aug_resolution, attempts, dev)
     unit = draws[0].to(device=dev, dtype=torch.float32).contiguous()
     steps = draws[1].to(device=dev, dtype=torch.int32).contiguous()
     K = unit.shape[0]
@@ -101,7 +139,7 @@ def se3_augmentation_plan_2robots(pose_right, rot_grip_right, pose_left, rot_gri
     bs = pose_right.shape[0]
     dev = pose_right.device
     if draws is None:
-        draws = _draws(bs, rot_aug_range, rot_aug_resolution, attempts)
+        draws = _draws(bs, rot_aug_range, rot_aug_resolution, attempts, dev)
     unit = draws[0].to(device=dev, dtype=torch.float32).contiguous()
     steps = draws[1].to(device=dev, dtype=torch.int32).contiguous()
     bnd = bounds.float().reshape(-1, 6).contiguous()

@@ -27,6 +27,8 @@ from torch import nn
 from .. import _lib
 
 MIN_DENOMINATOR = 1e-12
+# debug: compare every N-th incremental update of a persistent grid with a full rewrite (0 = off)
+CHECK_EVERY = int(__import__('os').environ.get('VOXACTB_VOXEL_CHECK', '0') or 0)
 
 
 class VoxelGrid(nn.Module):
@@ -123,6 +125,26 @@ class VoxelGrid(nn.Module):
         if slot is not None:
             slot[2] = 2 if state == 1 else 1     # complete result in place: the next use may be incremental (the value names
                                                  # which of the workspace's two cell lists this call wrote, see the C header)
+            if CHECK_EVERY > 0 and state != 0 and self._calls % CHECK_EVERY == 0:
+                # debug (VOXACTB_VOXEL_CHECK=N): every N-th incremental update is compared with a full rewrite of the same
+                # input.  A mismatch means somebody wrote into a grid this object handed out (the buffers are reused, see the
+                # module docstring) -- the incremental update only resets the cells IT recorded.
+                fresh = torch.empty_like(out)
+                ws2 = torch.empty_like(ws)
+                with _lib.on_device(device):
+                    if depth is None:
+                        rc = _lib.lib().vxb_voxelize_f32(cp, fp, n_src, B, pps, F, cs[0], cs[1], cs[2], fs[0], fs[1], fs[2],
+                                                         _lib.ptr(bounds), bounds.shape[0], V, _lib.ptr(xform), _lib.ptr(fresh), 0,
+                                                         _lib.ptr(ws2), ws2.numel() * 4, _lib.stream_ptr(device))
+                    else:
+                        rc = _lib.lib().vxb_voxelize_depth_f32(cp, fp, n_src, B, H, W, F, fs[0], fs[1], fs[2], _lib.ptr(proj),
+                                                               int(normalised), _lib.ptr(bounds), bounds.shape[0], V, _lib.ptr(xform),
+                                                               _lib.ptr(fresh), 0, _lib.ptr(ws2), ws2.numel() * 4, _lib.stream_ptr(device))
+                _lib.check(rc, 'vxb_voxelize_f32 (check)')
+                if not torch.equal(fresh, out):
+                    raise _lib.VoxactbHipError(
+                        'persistent voxel grid differs from a full rewrite: a grid returned earlier by this VoxelGrid was modified '
+                        'by its holder (update() hands out views of %d reused buffers: clone them to keep or edit them)' % self._persistent)
         return out
 
     # ------------------------------------------------------------------ reference API
