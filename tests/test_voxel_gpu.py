@@ -210,10 +210,12 @@ def test_persistent_buffers_are_updated_in_place_to_the_same_grids():
         assert torch.equal(got, fresh.voxelize_cameras(far, rgb, bounds)) and float(got[..., -1].sum()) == 0
 
 
-def test_persistent_grid_check_catches_a_caller_that_wrote_into_a_returned_grid(monkeypatch):
+def test_persistent_grid_check_catches_a_caller_that_wrote_into_a_returned_grid(monkeypatch, chain):
     """VOXACTB_VOXEL_CHECK: the reused buffers are handed out as views; the debug check compares an incremental update with a full
     rewrite and raises when a holder has modified a grid in an EMPTY cell (which the incremental reset does not touch)."""
     from voxactb_amd.voxel import voxel_grid as vgm
+    if chain == 'table':
+        pytest.skip('the table-based fallback chain rewrites the whole grid on every call: nothing incremental to check')
     B, H, W, V = 2, 16, 16, 24
     cams = ['front']
     monkeypatch.setattr(vgm, 'CHECK_EVERY', 1)
