@@ -357,18 +357,18 @@ def main():
 # runs, KiB units; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950, WRITE_SIZE exact)
 PMC_TRAFFIC_C2 = {
     'conv3d_wgrad[k3 s1 128->64 S100]': (
-        2 * 10765698.2 * 1024.0, 'wgrad_halo_kernel<1,4,4,2> (weight gradient of the final conv): FETCH_SIZE 11.0 GB raw per launch (x2 = 22.0 GB; '
-                                 '33.8 GB before the round-2 rework) for 12.3 GB compulsory (x 4.1 GB + the second source 4.1 GB + dY 4.1 GB), '
-                                 'output 0.2 GB; profiles/r02_v4_pmc_*'),
+        2 * 10769866.9 * 1024.0, 'wgrad_halo_kernel<2,4,4,2> (weight gradient of the final conv, single fp16 products): FETCH_SIZE 11.0 GB raw per '
+                                 'launch (x2 = 22.1 GB) for 12.3 GB compulsory (x 4.1 GB + the second source 4.1 GB + dY 4.1 GB), output 0.2 GB; '
+                                 'profiles/r03_v1_pmc_*'),
     'conv3d_bf16[k3 s1 128->64 S100': (
-        (2 * 7903011.6 + 6000000.0) * 1024.0,
-        'conv3_halo_kernel<2,1,4,1,0,2> (final conv forward / data gradient + padding adjoint), mean per launch: FETCH_SIZE 8.09 GB '
-        'raw (x2 = 16.2 GB) + WRITE_SIZE 6.14 GB; 22.3 GB / 19.9 ms = 1.1 TB/s: matrix-core-bound, not HBM-bound; profiles/r02_v4_pmc_*'),
+        (2 * 7685863.5 + 4000000.0) * 1024.0,
+        'conv3_halo_kernel<2,1,4,1,0,2> (final conv forward; the d(u0) block of its data gradient is the same kernel): FETCH_SIZE 7.87 GB '
+        'raw (x2 = 15.7 GB) + WRITE_SIZE 4.10 GB per launch = 19.8 GB for 12.3 GB compulsory (1.6x: the 6x10x10 halo of a 4x8x8 tile); '
+        '19.8 GB / 19.0 ms = 1.0 TB/s: matrix-core / LDS-bound, not HBM-bound; profiles/r03_v1_pmc_*'),
     'conv3d_bf16[k3 s1 64->128 S102': (
-        (2 * 7903011.6 + 6000000.0) * 1024.0,
-        'conv3_halo_kernel<2,1,4,1,0,2> (the same kernel: mean over the final conv\'s forward and its data gradient + padding adjoint): '
-        'FETCH_SIZE 8.09 GB raw (x2 = 16.2 GB) + WRITE_SIZE 6.14 GB per launch; 22.3 GB / 19.9 ms = 1.1 TB/s: matrix-core-bound, not '
-        'HBM-bound; profiles/r02_v4_pmc_*'),
+        (2 * 7685863.5 + 4000000.0) * 1024.0 + (2 * 3131520.0 + 4000000.0) * 1024.0,
+        'the two launches of the data gradient + padding adjoint: conv3_halo_kernel<2,1,4,1,0,2> (d(u0), bf16x3: 15.7 GB fetched + 4.1 GB '
+        'written) + conv3_halo_kernel<2,2,4,1,0,1> (d(d0), fp16: 6.4 GB + 4.1 GB); profiles/r03_v1_pmc_*'),
 }
 
 # HBM bytes the voxelizer chain really moves per call at configs[1] (B=16, V=100, 4 x 128 x 128 points), from separate
