@@ -157,7 +157,7 @@ int vxb_conv3d_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, 
                           int d2s_s, int d2s_C, vxb_stream_t stream);
 int vxb_conv3d_wgrad_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                                 int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
-                                int d2s_s, int d2s_C, float* part, int nsplit, vxb_stream_t stream);
+                                int d2s_s, int d2s_C, float* part, int nsplit, float* possum, vxb_stream_t stream);
 /* Direct-to-LDS variants (global_load_lds_dwordx4, no register round trip): BOTH operands are bf16 planes in HBM.
  * vxb_split_bf16_f32 makes the activation planes [nplanes][rows][cols] (plane 0 = bf16(x), plane 1 = bf16(x - plane 0));
  * weights are the same [nplanes][N][K] planes as above.  nplanes = 1 ('bf16') or 2 ('bf16x3').  K % 32 == 0 (conv:
@@ -242,10 +242,12 @@ int vxb_conv3_wgrad_halo_f16_f32(const float* src0, const float* src1, int C0, i
                                  vxb_stream_t stream);
 size_t vxb_conv3_wgrad_halo_tiles(int B, int S_out, int x3);
 /* bf16 matrix-core weight gradient (same contract as vxb_conv3d_wgrad_f32): both operands are staged position-major and
- * transposed for the matrix cores by ds_read_b64_tr_b16. */
+ * transposed for the matrix cores by ds_read_b64_tr_b16.  possum (optional; plain GEMM form only: kext = S_in = S_out = 1, one
+ * source): possum[z][C0] = fp32 sums over the z-th slice of positions of src0's rows, i.e. with src0 = dY of a linear layer its
+ * bias gradient (nn.Linear backward, perceiver_lang_io.py:80-132) from the same launch instead of a second pass over dY. */
 int vxb_conv3d_wgrad_bf16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                               int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
-                              int d2s_s, int d2s_C, float* part, int nsplit, vxb_stream_t stream);
+                              int d2s_s, int d2s_C, float* part, int nsplit, float* possum, vxb_stream_t stream);
 /* Polyphase form of Upsample(x s, trilinear, align_corners=False) followed by Conv3d(k) (network_utils.py:245-250):
  * Weff[(j3*Cin+ci)][(r3*Cout+co)] = sum_t W[co][ci][t] * L[r][t][j] per axis; and its adjoint (dW ACCUMULATED). */
 int vxb_polyphase_weights_f32(const float* W, const float* L, float* Weff, int Cin, int Cout, int k, int s, int kl,

@@ -36,3 +36,24 @@ def test_wgrad_bf16_two_sources_and_d2s():
     ref = ops.conv3d_wgrad(bf(z1), bf(dyf), s ** 3 * 64, B, G, G, kl, -R, d2s=(s, 64), nsplit=1)
     got = ops.conv3d_wgrad(z1, dyf, s ** 3 * 64, B, G, G, kl, -R, d2s=(s, 64), nsplit=2, force_bf16=True)
     close(got, ref, 3e-5, 'polyphase d2s wgrad')
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'bf16x3'])
+@pytest.mark.parametrize('M,N,K', [(4096, 512, 512), (2048 + 96, 256, 128), (8192, 1024, 64)])
+def test_linear_bias_gradient_comes_out_of_the_weight_gradient_launch(mode, M, N, K):
+    """linear_bwd in the matrix-core modes: db = column sums of dy are taken inside the weight-gradient kernel (`possum`) -- exact
+    fp32 sums in a fixed order, equal to vxb_colsum_f32 up to the summation order; dW and dx unchanged."""
+    from .test_ops_gpu import rnd, DEV
+    x, W, dy = rnd(M, K).to(DEV), rnd(N, K, seed=1).to(DEV), rnd(M, N, seed=2).to(DEV)
+    ops.PRECISION = mode
+    try:
+        dW, db, dx = torch.zeros(N, K, device=DEV), torch.full((N,), 0.5, device=DEV), torch.empty(M, K, device=DEV)
+        ops.linear_bwd(x, W, dy, dW, db, dx)
+        ref = torch.full((N,), 0.5, device=DEV)
+        ops.colsum(dy, ref, accumulate=True)
+    finally:
+        ops.PRECISION = 'fp32'
+    want = dy.double().sum(0).cpu() + 0.5
+    assert float((db.double().cpu() - want).abs().max()) < 1e-4 * float(want.abs().max())
+    assert float((db - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    assert float((dW.double().cpu() - (dy.double().t() @ x.double()).cpu()).abs().max()) < (3e-2 if mode == 'bf16' else 2e-4) * float(dW.abs().max())

@@ -27,6 +27,8 @@ struct WgArgs {
     long long ldy;       // dY row stride (row-major mode)
     int d2s_s, d2s_C;    // > 0: dY is a fine grid [B, (S_out*s)^3, d2s_C], column n = (phase, co)
     int tiles_per_split;
+    float* possum;       // optional, plain mode only: possum[z][Krows] = sum over the z-th slice of positions of src0's rows (fp32, fixed
+                         // order) -- the bias gradient of a linear layer falls out of its weight-gradient launch
 };
 
 __device__ __forceinline__ unsigned pack_bf16_2(float lo, float hi) { return vxb_pack_bf16(lo, hi); }
@@ -116,6 +118,8 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
     for (int i = 0; i < B_F4; ++i) decode(kt_begin * BP + tid / (BN / 4) + (256 / (BN / 4)) * i, bw[i], bh[i], bd[i], bb[i]);
 
     float4 ra[A_F4], rb[B_F4];
+    float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool want_psum = g.possum != nullptr && blockIdx.x == 0;      // (uniform) the first column block adds up src0's rows
     auto load_tile = [&](long long kt) {
         const long long k0 = kt * BP;
 #pragma unroll
@@ -160,6 +164,10 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
         }
     };
     auto store_tile = [&]() {
+        if (want_psum) {
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) { psum.x += ra[i].x; psum.y += ra[i].y; psum.z += ra[i].z; psum.w += ra[i].w; }
+        }
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             uint2 p;
@@ -269,6 +277,19 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
         }
     }
 
+    if (want_psum) {
+        // fold the 8 position lanes (tid >> 5) of every row quad in a fixed order
+        __syncthreads();
+        float4* red = reinterpret_cast<float4*>(&As[0]);          // 256 float4 = 4 KB <= the A tile
+        red[tid] = psum;
+        __syncthreads();
+        if (tid < 32 && a_ok) {
+            float4 a = red[tid];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) { const float4 b = red[tid + 32 * j]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+            *reinterpret_cast<float4*>(g.possum + (long long)blockIdx.z * g.Krows + kr) = a;
+        }
+    }
     float* __restrict__ C = g.part + (long long)blockIdx.z * g.Krows * g.N;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -288,13 +309,14 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
 
 static int wgrad_bf16_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                           int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
-                          int d2s_s, int d2s_C, float* part, int nsplit, vxb_stream_t stream) {
+                          int d2s_s, int d2s_C, float* part, int nsplit, float* possum, vxb_stream_t stream) {
     if (!src0 || !dy || !part || B < 1 || S_in < 1 || S_out < 1 || kext < 1 || stride < 1 || N < 1 || nsplit < 1) return VXB_EARG;
+    if (possum && !(S_in == 1 && S_out == 1 && kext == 1 && off == 0 && C1 == 0 && d2s_s <= 0)) return VXB_EARG;     // plain GEMM form only
     if ((C0 & 3) || (C1 & 3) || C0 < 4 || (C1 > 0 && !src1) || (N & 3)) return VXB_ESIZE;
     if (d2s_s > 0 && (d2s_C < 4 || (d2s_C & 3) || N % d2s_C)) return VXB_EARG;
     if (d2s_s <= 0 && (ldy & 3)) return VXB_ESIZE;
     WgArgs g;
-    g.src0 = src0; g.src1 = src1; g.dy = dy; g.part = part;
+    g.src0 = src0; g.src1 = src1; g.dy = dy; g.part = part; g.possum = possum;
     g.C0 = C0; g.C1 = C1; g.S_in = S_in; g.S_out = S_out; g.stride = stride; g.kext = kext; g.off = off; g.replicate = replicate;
     const long long K = (long long)kext * kext * kext * (C0 + C1);
     if (K >= INT32_MAX) return VXB_ESIZE;
@@ -318,15 +340,15 @@ static int wgrad_bf16_impl(int x3, const float* src0, const float* src1, int C0,
 // Same contract as vxb_conv3d_wgrad_f32 (include/voxactb_hip.h); operands are rounded to bf16 while staged, fp32 accumulate.
 extern "C" int vxb_conv3d_wgrad_bf16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                                          int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
-                                         int d2s_s, int d2s_C, float* part, int nsplit, vxb_stream_t stream) {
+                                         int d2s_s, int d2s_C, float* part, int nsplit, float* possum, vxb_stream_t stream) {
     return wgrad_bf16_impl(0, src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, replicate, dy, N, ldy, d2s_s, d2s_C, part,
-                           nsplit, stream);
+                           nsplit, possum, stream);
 }
 
 // "bf16x3" twin: both operands split into hi/lo bf16 planes while staged; hi*hi + hi*lo + lo*hi, fp32 accumulate.
 extern "C" int vxb_conv3d_wgrad_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                                            int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
-                                           int d2s_s, int d2s_C, float* part, int nsplit, vxb_stream_t stream) {
+                                           int d2s_s, int d2s_C, float* part, int nsplit, float* possum, vxb_stream_t stream) {
     return wgrad_bf16_impl(1, src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, replicate, dy, N, ldy, d2s_s, d2s_C, part,
-                           nsplit, stream);
+                           nsplit, possum, stream);
 }

@@ -188,8 +188,10 @@ def linear_bwd(x, W, dy, dW, db=None, dx=None, dx_accumulate=False, ws=None):
         if _mm() and dW.is_contiguous() and dy.stride(0) == N:
             # both operands are row(position)-major -> the transposed-read bf16 kernel (a 1x1x1 "conv" over M positions)
             nsb = max(1, min(64, (512 + tiles - 1) // tiles, M // 256))
-            res = conv3d_wgrad(dy, x, K, M, 1, 1, 1, 0, ldy=x.stride(0), nsplit=nsb, label='gemm_wgrad %dx%dx%d' % (N, K, M))
+            res = conv3d_wgrad(dy, x, K, M, 1, 1, 1, 0, ldy=x.stride(0), nsplit=nsb, label='gemm_wgrad %dx%dx%d' % (N, K, M),
+                               possum_into=db)
             axpy_(dW, res)
+            db = None                    # (the bias gradient came out of the same launch)
         elif ns > 1:
             rc = M // ns
             part = torch.empty((ns, N, K), dtype=torch.float32, device=x.device)
@@ -324,7 +326,7 @@ def conv3d(src0, wt, N, B, S_in, S_out, kext, off, stride=1, replicate=True, bia
 
 
 def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=True, src1=None, ldy=None, d2s=(0, 0),
-                 nsplit=None, label=None, force_bf16=False, phase_mask=None, flops_frac=1.0, dy_scale=None):
+                 nsplit=None, label=None, force_bf16=False, phase_mask=None, flops_frac=1.0, dy_scale=None, possum_into=None):
     """returns dWt [(tap, ci)][N] (fp32, deterministic split reduction).  phase_mask (LDS-halo kernel, d2s only): int32
     [N / 64] tap masks of the polyphase structure -- the structurally zero (tap, phase) blocks come back as zeros."""
     C0 = src0.shape[-1]
@@ -375,8 +377,18 @@ def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
     _lib.set_meta(label or 'conv3d_wgrad[k%d s%d %d->%d S%d]' % (kext, stride, C0 + C1, N, S_out), 2.0 * P * N * K)
     entry = {'bf16': 'vxb_conv3d_wgrad_bf16_f32', 'bf16x3': 'vxb_conv3d_wgrad_bf16x3_f32'}.get(
         force_bf16 if isinstance(force_bf16, str) else ('bf16' if force_bf16 else PRECISION), 'vxb_conv3d_wgrad_f32')
-    call(entry, src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, int(replicate), dy, N,
-         ldy if ldy is not None else N, d2s[0], d2s[1], part, nsplit)
+    if entry != 'vxb_conv3d_wgrad_f32':
+        # possum_into [C0] (plain GEMM form: the weight gradient of a linear layer, src0 = its dY): += the sums of src0 over the
+        # positions, i.e. the bias gradient, from this launch (no second pass over dY)
+        psum = torch.empty((nsplit, K), dtype=torch.float32, device=src0.device) if possum_into is not None else None
+        call(entry, src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, int(replicate), dy, N,
+             ldy if ldy is not None else N, d2s[0], d2s[1], part, nsplit, psum)
+        if psum is not None:
+            sum_splits(psum, nsplit, K, possum_into, accumulate=True)
+    else:
+        assert possum_into is None
+        call(entry, src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, int(replicate), dy, N,
+             ldy if ldy is not None else N, d2s[0], d2s[1], part, nsplit)
     if nsplit == 1:
         return part[0]
     out = torch.empty((K, N), dtype=torch.float32, device=src0.device)
