@@ -211,8 +211,10 @@ int vxb_conv3_halo_bf16x3_f32(const float* src0, const float* src1, int C0, int 
  * Replaces the pair at perceiver_lang_io.py:462 (backward of `final` into d0 and u0). */
 int vxb_conv3_dgrad_fold_f32(const float* dy, int C0, int B, int S, const void* wt_bf16, int x3, int N, float* dst0,
                              float* dst1, const float* y0, const float* y1, int acc0, int acc1, float slope,
-                             const void* wfrag, float* dst_scale, float* scale_ws, vxb_stream_t stream);
-/* workgroups of that launch = words of scale_ws needed when dst_scale is asked for */
+                             const void* wfrag, float* dst_scale, float* scale_ws, float* dst_colsum, float* colsum_ws,
+                             vxb_stream_t stream);
+/* workgroups of that launch = words of scale_ws needed when dst_scale is asked for; dst_colsum ([64], accumulated: column sums of
+ * dst0 as written = the bias gradient of the conv whose activation y0 is; N = 64) needs colsum_ws of 64 * (that + 64) floats */
 size_t vxb_conv3_dgrad_fold_blocks(int B, int S, int N);
 /* ... one 64-column block of it with a single fp16 product per term (dy * scale[0] -> half, result * scale[1]; scale on the
  * device, vxb_absmax_scale_f32; weights in fragment order of the fp16 [64][27 C0] matrix): the d(d0) half of `final`'s data

@@ -92,11 +92,14 @@ def test_fused_operand_scales_equal_the_absmax_pass():
     ops.PRECISION, ops.WGRAD_PRECISION = 'bf16x3', 'fp16'
     try:
         g0, g1 = torch.zeros(B, S, S, S, 64, device=DEV), torch.empty(B, S, S, S, 64, device=DEV)
+        bias = torch.full((64,), 0.25, device=DEV)
         sc = ops.conv3_dgrad_fold(dy, ops.conv_weight_dgrad(W), B, S, 128, [(g0, False, None), (g1, False, y1)], leaf_blocks=(0,),
-                                  scale_blocks=(1,))
+                                  scale_blocks=(1,), colsum_into={1: bias})
     finally:
         ops.PRECISION, ops.WGRAD_PRECISION = 'fp32', ''
     assert torch.equal(sc[1], ops.absmax_scale(g1))
+    want = g1.double().sum(dim=(0, 1, 2, 3)).cpu() + 0.25          # column sums of the block as written, accumulated into `bias`
+    assert float((bias.double().cpu() - want).abs().max()) < 1e-5 * float(want.abs().max())
     # the fused backward of u (c1 data gradient + SpatialSoftmax3D term + LeakyReLU' + bias sums)
     u = cl(rnd(B, 64, S, S, S, seed=8)).to(DEV)
     dq = rnd(B, S, S, S, seed=9).to(DEV) * 1e-5

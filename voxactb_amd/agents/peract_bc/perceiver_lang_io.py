@@ -701,6 +701,7 @@ class PerceiverEngine:
         if not fuse_u:
             ops.colsum(du.view(-1, C), self.g('final.conv3d.bias'), accumulate=True)
         sc_du0 = None
+        du0_bias_done = False
         dd0 = E(B, V, V, V, C)
         # the pooled-feature gradient of d0 (ss0) is added inside the input conv's weight-gradient kernel, the last reader of
         # dd0; otherwise it is dd0's first writer
@@ -714,8 +715,10 @@ class PerceiverEngine:
             # the other 64 become d(pre-activation of up0's last conv) through u0's LeakyReLU'
             # d(d0) feeds nothing but the weight gradient of the 1x1x1 input conv (the voxel grid is a detached input, agent :100):
             # a leaf -- its column block may run on single fp16 products; d(u0) propagates through the decoder and stays bf16x3
+            up2b = 'up0.conv_up.%d.conv3d.bias' % (2 if s > 1 else 1)
             sc_du0 = ops.conv3_dgrad_fold(du, ops.conv_weight_dgrad(Wf), B, V, 2 * C, [(dd0, not fuse_ss0, None), (du0, False, u0)],
-                                          dy_scale=sc_du, leaf_blocks=(0,), scale_blocks=(1,)).get(1)
+                                          dy_scale=sc_du, leaf_blocks=(0,), scale_blocks=(1,), colsum_into={1: self.g(up2b)}).get(1)
+            du0_bias_done = True
         else:
             dcat = ops.conv3d(du, ops.conv_weight_dgrad(Wf), 2 * C, B, V, V + 2, 3, -2, replicate=False)
             ops.fold_pad(dcat, V + 2, 2 * C, 0, dd0, B, V, C, 1, accumulate=not fuse_ss0)
@@ -726,7 +729,8 @@ class PerceiverEngine:
         z1, zc = c['z1'], c['zc']
         up2 = 'up0.conv_up.%d.conv3d' % (2 if s > 1 else 1)
         W2 = self.p(up2 + '.weight')
-        ops.colsum(du0.view(-1, C), self.g(up2 + '.bias'), accumulate=True)
+        if not du0_bias_done:
+            ops.colsum(du0.view(-1, C), self.g(up2 + '.bias'), accumulate=True)
         dz1 = E(B, G, G, G, C)
         if s > 1:
             kl, R = self.kl, self.R

@@ -431,6 +431,17 @@ int vxb_c1_dgrad4_ss_launch(const float* dq, const float* w, const float* u, flo
     return hipGetLastError() == hipSuccess ? VXB_OK : VXB_ELAUNCH;
 }
 
+// out[64] += column sums of part[nrows][64], two fixed-order stages (64 workgroups fold nrows / 64 rows each into the 64 rows behind
+// the partials, one more folds those)
+int vxb_rows64_sum_launch(float* part, int nrows, float* out, hipStream_t st) {
+    if (!part || !out || nrows < 1) return VXB_EARG;
+    const int per = (nrows + 63) / 64;
+    float* part2 = part + (size_t)nrows * 64;
+    hipLaunchKernelGGL(c1_rows_kernel, dim3(64), dim3(256), 0, st, part, nrows, per, part2);
+    hipLaunchKernelGGL(c1_reduce_kernel, dim3(1), dim3(256), 0, st, part2, 64, 64, out);
+    return hipGetLastError() == hipSuccess ? VXB_OK : VXB_ELAUNCH;
+}
+
 // part_ws: (ceil(B*S*S / 128) * (64*27 + 1)) floats (smaller than the scalar kernel's requirement)
 int vxb_c1_wgrad4_launch(const float* u, const float* dq, float* dw, float* db, float* part_ws, int B, int S, hipStream_t st) {
     const long long nrows = (long long)B * S * S;

@@ -68,6 +68,8 @@ struct HaloArgs {
     // its largest magnitude, vxb_absmax_scale_f32) and the result by scale[1] = 1 / scale[0] in the epilogue; nullptr = 1
     const float* scale;
     unsigned* amax_part;     // fold mode, optional: word [workgroup] = largest magnitude (bits) this workgroup wrote to its destination
+    float* colsum_part;      // fold mode, optional: [workgroup][64] = column sums of what this workgroup wrote (the bias gradient of the
+                             // conv that produced the destination's activation, taken on the way instead of by a pass over 4 GB)
 };
 
 // bf16 pair from two fp32 (RNE).  Both forms give identical bits; which one is FASTER was measured per precision on the
@@ -481,6 +483,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
         const float* __restrict__ yv = g.fold_y[nb];
         const int facc = g.fold_acc[nb];
         unsigned amx = 0;
+        float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int item = tid; item < TD * TH * TW * 16; item += NTH) {
             const int c4 = (item & 15) * 4, pos = item >> 4;
             const int wl = pos % TW, hl = (pos / TW) % TH, dl = pos / (TW * TH);
@@ -513,6 +516,18 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
             *reinterpret_cast<float4*>(dst + o) = a;
             amx = max(max(amx, __float_as_uint(a.x) & 0x7fffffffu), max(max(__float_as_uint(a.y) & 0x7fffffffu, __float_as_uint(a.z) & 0x7fffffffu),
                                                                          __float_as_uint(a.w) & 0x7fffffffu));
+            csum.x += a.x; csum.y += a.y; csum.z += a.z; csum.w += a.w;      // (item & 15 is the same for all of a thread's items)
+        }
+        if (g.colsum_part) {                // (uniform) fixed-order fold of the 16 threads that share a channel quad
+            __syncthreads();                // everyone is done reading the fp32 tile in ft
+            float4* cred = reinterpret_cast<float4*>(ft);
+            cred[tid] = csum;
+            __syncthreads();
+            if (tid < 16) {
+                float4 a = cred[tid];
+                for (int j = 1; j < NTH / 16; ++j) { const float4 b = cred[tid + 16 * j]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+                *reinterpret_cast<float4*>(g.colsum_part + (long long)blockIdx.x * 64 + 4 * tid) = a;
+            }
         }
         if (g.amax_part) {                  // (uniform) the fp16 operand scale of the tensor just written is taken on the way
             __shared__ unsigned famx[8];
@@ -598,6 +613,7 @@ int hb_impl(int x3 /* product mode: 0 bf16, 1 bf16x3, 2 fp16 (WD kernels only, `
     g.dbg = g_halo_dbg;
     g.scale = scale;
     g.amax_part = fold ? fold->amax_part : nullptr;
+    g.colsum_part = fold ? fold->colsum_part : nullptr;
     g.fold_pad = 0; g.fold_S = 0; g.fold_dst[0] = g.fold_dst[1] = nullptr; g.fold_y[0] = g.fold_y[1] = nullptr;
     g.fold_acc[0] = g.fold_acc[1] = 0;
     if (fold) {
@@ -658,11 +674,15 @@ extern "C" int vxb_conv3_halo_bf16x3_f32(const float* src0, const float* src1, i
 // given).  x3 != 0: weights are the [2][N][K] planes ('bf16x3').  pad = 1.
 extern "C" int vxb_conv3_dgrad_fold_f32(const float* dy, int C0, int B, int S, const void* wt_bf16, int x3, int N, float* dst0,
                                         float* dst1, const float* y0, const float* y1, int acc0, int acc1, float slope,
-                                        const void* wfrag, float* dst_scale, float* scale_ws, vxb_stream_t stream) {
+                                        const void* wfrag, float* dst_scale, float* scale_ws, float* dst_colsum, float* colsum_ws,
+                                        vxb_stream_t stream) {
+    // dst_colsum (optional, [64], ACCUMULATED; needs colsum_ws of 64 * vxb_conv3_dgrad_fold_blocks + 64 * 64 floats; N = 64 only): column
+    // sums of dst0 as written (after the LeakyReLU' factor) = the bias gradient of the conv whose activation y0 is
     // dst_scale (optional, [2], needs scale_ws of vxb_conv3_dgrad_fold_blocks words; N = 64 only): the fp16 operand scale of dst0 as
     // vxb_absmax_scale_f32 would compute it, taken while dst0 is written
     if (!dy || !wt_bf16 || !dst0 || (N > 64 && !dst1) || N > 128 || S < 2) return VXB_EARG;
     if (dst_scale && (!scale_ws || N != 64)) return VXB_EARG;
+    if (dst_colsum && (!colsum_ws || N != 64)) return VXB_EARG;
     const int pad = 1, S_out = S + 2 * pad;
     // every border group {0..pad} / {S-1+pad..S-1+2 pad} must lie inside one tile
     if ((S_out - 1 - pad) / TD != (S_out - 1) / TD || (S_out - 1 - pad) / TH != (S_out - 1) / TH || (S_out - 1 - pad) / TW != (S_out - 1) / TW)
@@ -671,9 +691,16 @@ extern "C" int vxb_conv3_dgrad_fold_f32(const float* dy, int C0, int B, int S, c
     f.fold_pad = pad; f.fold_S = S; f.fold_dst[0] = dst0; f.fold_dst[1] = dst1; f.fold_y[0] = y0; f.fold_y[1] = y1;
     f.fold_acc[0] = acc0; f.fold_acc[1] = acc1;
     f.amax_part = dst_scale ? reinterpret_cast<unsigned*>(scale_ws) : nullptr;
+    f.colsum_part = dst_colsum ? colsum_ws : nullptr;
     int rc = hb_impl(x3 ? 1 : 0, dy, nullptr, C0, 0, B, S, S_out, -2 * pad, 0, wt_bf16, N, nullptr, nullptr, 0, slope, 0, 0, 0, stream, &f, wfrag);
-    if (rc || !dst_scale) return rc;
-    return vxb_absmax_finish_launch(f.amax_part, (int)vxb_conv3_dgrad_fold_blocks(B, S, N), dst_scale, (hipStream_t)stream);
+    if (rc) return rc;
+    const int nblk = (int)vxb_conv3_dgrad_fold_blocks(B, S, N);
+    if (dst_colsum) {
+        rc = vxb_rows64_sum_launch(colsum_ws, nblk, dst_colsum, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    if (!dst_scale) return VXB_OK;
+    return vxb_absmax_finish_launch(f.amax_part, nblk, dst_scale, (hipStream_t)stream);
 }
 
 extern "C" size_t vxb_conv3_dgrad_fold_blocks(int B, int S, int N) {
@@ -697,7 +724,7 @@ extern "C" int vxb_conv3_dgrad_fold_f16_f32(const float* dy, int C0, int B, int 
     HaloArgs f;
     f.fold_pad = pad; f.fold_S = S; f.fold_dst[0] = dst; f.fold_dst[1] = nullptr; f.fold_y[0] = y; f.fold_y[1] = nullptr;
     f.fold_acc[0] = acc; f.fold_acc[1] = 0;
-    f.amax_part = nullptr;
+    f.amax_part = nullptr; f.colsum_part = nullptr;
     return hb_impl(2, dy, nullptr, C0, 0, B, S, S_out, -2 * pad, 0, wfrag_f16, 64, nullptr, nullptr, 0, slope, 0, 0, 0, stream, &f,
                    wfrag_f16, nullptr, 0, 0, 0, scale);
 }

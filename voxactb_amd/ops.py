@@ -562,13 +562,15 @@ def dgrad_fold_ok(C_dy, N, S):
             and (So - 2) // 4 == (So - 1) // 4 and (So - 2) // 8 == (So - 1) // 8)
 
 
-def conv3_dgrad_fold(dy, wt_dgrad, B, S, N, dsts, label=None, dy_scale=None, leaf_blocks=(), scale_blocks=()):
+def conv3_dgrad_fold(dy, wt_dgrad, B, S, N, dsts, label=None, dy_scale=None, leaf_blocks=(), scale_blocks=(), colsum_into=None):
     """fold_pad(conv3d(dy, wt_dgrad, zero pad, S+2), pad=1) without the padded tensor: dsts = [(dst [B,S,S,S,64],
     accumulate, lrelu_of or None)] per 64-column block (1 or 2 entries).
     leaf_blocks: the column blocks whose result only feeds a weight gradient (nothing propagates from them); with
     WGRAD_PRECISION == 'fp16' those are evaluated with a single fp16 product per term, dy scaled by dy_scale (absmax_scale of dy,
     computed here when None) -- the others keep the bf16x3 triple.  scale_blocks: the (non-leaf) blocks whose destination's own fp16
-    operand scale is wanted (taken in the epilogue while the tensor is written); returns {block: [scale, 1 / scale]}."""
+    operand scale is wanted (taken in the epilogue while the tensor is written); returns {block: [scale, 1 / scale]}.
+    colsum_into {block: tensor [64]}: += the column sums of that block's destination (the bias gradient of the conv it is the
+    pre-activation gradient of) -- from the epilogue on the split path, by a colsum pass otherwise."""
     C0 = dy.shape[-1]
     wb = to_bf16_nk(wt_dgrad)
     x3 = wb.dim() == 3
@@ -581,6 +583,7 @@ def conv3_dgrad_fold(dy, wt_dgrad, B, S, N, dsts, label=None, dy_scale=None, lea
     _lib.set_meta(lbl, flops)
     wf = halo_wfrag(wb, C0)
     scales = {}
+    colsum_into = colsum_into or {}
     if x3 and wf is not None and WGRAD_PRECISION == 'fp16' and leaf_blocks and N == 64 * len(dsts) and dy.is_contiguous():
         sc = dy_scale
         for nb, (dst, acc, yv) in enumerate(dsts):
@@ -593,16 +596,22 @@ def conv3_dgrad_fold(dy, wt_dgrad, B, S, N, dsts, label=None, dy_scale=None, lea
                 _lib.set_meta(lbl, flops / len(dsts))
                 call('vxb_conv3_dgrad_fold_f16_f32', dy, C0, B, S, wf16, dst, yv, int(acc), LRELU_SLOPE, sc)
             else:
-                dsc = sws = None
+                dsc = sws = cs = cws = None
+                nblk = int(_lib.lib().vxb_conv3_dgrad_fold_blocks(B, S, 64))
                 if nb in scale_blocks:
                     dsc = scales[nb] = torch.empty(2, dtype=torch.float32, device=dy.device)
-                    sws = torch.empty(int(_lib.lib().vxb_conv3_dgrad_fold_blocks(B, S, 64)), dtype=torch.float32, device=dy.device)
+                    sws = torch.empty(nblk, dtype=torch.float32, device=dy.device)
+                if nb in colsum_into:
+                    cs = colsum_into[nb]
+                    cws = torch.empty(64 * (nblk + 64), dtype=torch.float32, device=dy.device)
                 _lib.set_meta(lbl, flops / len(dsts))
                 call('vxb_conv3_dgrad_fold_f32', dy, C0, B, S, wb, 1, 64, dst, None, yv, None, int(acc), 0, LRELU_SLOPE, wf[nb:nb + 1],
-                     dsc, sws)
+                     dsc, sws, cs, cws)
         return scales
     _lib.set_meta(lbl, flops)
-    call('vxb_conv3_dgrad_fold_f32', dy, C0, B, S, wb, int(x3), N, d0, d1, y0, y1, int(a0), int(a1), LRELU_SLOPE, wf, None, None)
+    call('vxb_conv3_dgrad_fold_f32', dy, C0, B, S, wb, int(x3), N, d0, d1, y0, y1, int(a0), int(a1), LRELU_SLOPE, wf, None, None, None, None)
+    for nb, into in colsum_into.items():
+        colsum(dsts[nb][0].view(-1, 64), into, accumulate=True)
     return scales
 
 
