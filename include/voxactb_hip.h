@@ -158,6 +158,15 @@ int vxb_conv3d_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, 
 int vxb_conv3d_wgrad_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                                 int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
                                 int d2s_s, int d2s_C, float* part, int nsplit, float* possum, vxb_stream_t stream);
+/* ... with ONE fp16 product per term: the gradient operand (src0 when grad_is_src0 != 0: the plain-GEMM form of a linear layer's
+ * weight gradient, src0 = its dY; else dy) times scale[0] (device, power of two) before the conversion to half, `part` = scale[0] * dW,
+ * the other operand saturating at +-65504.  next_scale (optional, [2]; amax_ws of vxb_conv3d_wgrad_f16_amax_words words): the scale
+ * vxb_absmax_scale_f32 would give for the gradient operand this launch read -- for the next step (delayed scaling). */
+int vxb_conv3d_wgrad_f16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
+                             int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
+                             int d2s_s, int d2s_C, float* part, int nsplit, float* possum, const float* scale,
+                             int grad_is_src0, float* next_scale, float* amax_ws, vxb_stream_t stream);
+size_t vxb_conv3d_wgrad_f16_amax_words(int C0, int C1, int kext, int N, int nsplit, int grad_is_src0);
 /* Direct-to-LDS variants (global_load_lds_dwordx4, no register round trip): BOTH operands are bf16 planes in HBM.
  * vxb_split_bf16_f32 makes the activation planes [nplanes][rows][cols] (plane 0 = bf16(x), plane 1 = bf16(x - plane 0));
  * weights are the same [nplanes][N][K] planes as above.  nplanes = 1 ('bf16') or 2 ('bf16x3').  K % 32 == 0 (conv:

@@ -57,3 +57,37 @@ def test_linear_bias_gradient_comes_out_of_the_weight_gradient_launch(mode, M, N
     assert float((db.double().cpu() - want).abs().max()) < 1e-4 * float(want.abs().max())
     assert float((db - ref).abs().max()) < 2e-5 * float(ref.abs().max())
     assert float((dW.double().cpu() - (dy.double().t() @ x.double()).cpu()).abs().max()) < (3e-2 if mode == 'bf16' else 2e-4) * float(dW.abs().max())
+
+
+def test_generic_weight_gradients_on_single_fp16_products_with_delayed_scaling():
+    """VOXACTB_GENERIC_WGRAD_F16: a linear layer's weight gradient (plain-GEMM form, gradient operand = src0) and a 5^3 conv's
+    (gradient operand = dy) with ONE fp16 product per term.  First call at a site: explicit absmax scale; later calls use the
+    maximum the previous launch reported (with 5 bits of headroom) -- checked by growing / shrinking the gradient 30x between calls
+    (inside the margin: same accuracy) and 3000x (the stale scale saturates THAT call, the next one is right again)."""
+    from .test_ops_gpu import rnd, DEV, cl
+    M, N, K = 4096, 256, 512
+    x, W = rnd(M, K).to(DEV), rnd(N, K, seed=1).to(DEV)
+    ops.PRECISION, ops.WGRAD_PRECISION, ops.GENERIC_WGRAD_F16, ops._GRAD_SCALE = 'bf16x3', 'fp16', True, {}
+    try:
+        errs = []
+        for gain in (1e-5, 3e-4, 1e-5, 3e-2, 3e-2):
+            dy = rnd(M, N, seed=2).to(DEV) * gain
+            dW, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+            ops.linear_bwd(x, W, dy, dW, db, None)
+            ref = (dy.double().t() @ x.double())
+            errs.append(float((dW.double() - ref).abs().max() / ref.abs().max()))
+            assert float((db.double() - dy.double().sum(0)).abs().max()) < 1e-4 * float(dy.double().sum(0).abs().max())     # bias: exact fp32 sums
+        assert max(errs[:3]) < 1e-3 and errs[4] < 1e-3 and errs[3] > 0.1, errs        # (errs[3]: the 3000x jump meets a stale scale)
+        assert ('lin', W.data_ptr()) in ops._GRAD_SCALE
+        # 5^3 conv (the decoder's first up-conv): gradient operand = dy
+        B, S, Ci, Co = 2, 12, 128, 64
+        a = cl(rnd(B, Ci, S, S, S)).to(DEV)
+        g = cl(rnd(B, Co, S, S, S, seed=3) * 1e-6).to(DEV)
+        ops.GENERIC_WGRAD_F16 = False
+        want = ops.conv3d_wgrad(a, g, Co, B, S, S, 5, -2, grad_key=('conv', 7))
+        ops.GENERIC_WGRAD_F16 = True
+        got = ops.conv3d_wgrad(a, g, Co, B, S, S, 5, -2, grad_key=('conv', 7))
+        got2 = ops.conv3d_wgrad(a, g, Co, B, S, S, 5, -2, grad_key=('conv', 7))       # second call: delayed scale == the exact one
+        assert float((got - want).abs().max()) < 1e-3 * float(want.abs().max()) and torch.equal(got, got2)
+    finally:
+        ops.PRECISION, ops.WGRAD_PRECISION, ops.GENERIC_WGRAD_F16, ops._GRAD_SCALE = 'fp32', '', False, {}

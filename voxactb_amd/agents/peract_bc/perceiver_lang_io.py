@@ -333,6 +333,9 @@ class PerceiverEngine:
         self.wgrad_precision = os.environ.get('VOXACTB_WGRAD_PRECISION', 'fp16')
         if self.wgrad_precision not in ('fp16', 'bf16x3'):
             raise ValueError('VOXACTB_WGRAD_PRECISION must be fp16 or bf16x3')
+        # ... also the weight gradients of the linear layers (>= 1024 rows) and of the two 5^3 convs (generic kernel, delayed scaling)
+        self.generic_wgrad_f16 = os.environ.get('VOXACTB_GENERIC_WGRAD_F16', '1') != '0'
+        self._grad_scales = {}            # per call site: the delayed fp16 operand scales of THIS engine's gradients (ops._GRAD_SCALE)
 
     # -------------------------------------------------------------------------------------------------- helpers
     def _draw_seed(self):
@@ -611,12 +614,15 @@ class PerceiverEngine:
         last kernel that writes gradients of bucket `name` (see grad_buckets) has been enqueued."""
         ops.PRECISION = self.bwd_precision or self.precision
         ops.WGRAD_PRECISION = 'fp16' if (ops.PRECISION == 'bf16x3' and self.wgrad_precision == 'fp16') else ''
+        ops.GENERIC_WGRAD_F16 = bool(ops.WGRAD_PRECISION) and self.generic_wgrad_f16
+        ops._GRAD_SCALE = self._grad_scales
         self._on_bucket = on_bucket_ready
         try:
             return self._backward(c, dq_trans, d_o, d_arm, dq_trans_left, d_o_left)
         finally:
             ops.PRECISION = 'fp32'
             ops.WGRAD_PRECISION = ''
+            ops.GENERIC_WGRAD_F16 = False
 
     def _backward(self, c, dq_trans, d_o, d_arm=None, dq_trans_left=None, d_o_left=None):
         m = self.m
@@ -755,7 +761,7 @@ class PerceiverEngine:
             ops.fold_pad(dzp, G + 2 * (k // 2), C, 0, dz1, B, G, C, k // 2, lrelu_of=z1)
         del du0, dzp
         W1 = self.p('up0.conv_up.0.conv3d.weight')
-        dWt = ops.conv3d_wgrad(zc, dz1, C, B, G, G, k, -(k // 2))
+        dWt = ops.conv3d_wgrad(zc, dz1, C, B, G, G, k, -(k // 2), grad_key=('conv', W1.data_ptr()))
         self.g('up0.conv_up.0.conv3d.weight').add_(dWt.view(k ** 3, Cx, C).permute(2, 1, 0).reshape(W1.shape))
         ops.colsum(dz1.view(-1, C), self.g('up0.conv_up.0.conv3d.bias'), accumulate=True)
         pk = k // 2
@@ -806,7 +812,7 @@ class PerceiverEngine:
         # ---- patchify
         ops.lrelu_bwd_(dpatch, c['patch'])
         Wp = self.p('patchify.conv3d.weight')
-        dWt = ops.conv3d_wgrad(d0, dpatch, C, B, V, G, k, -pk, stride=s)
+        dWt = ops.conv3d_wgrad(d0, dpatch, C, B, V, G, k, -pk, stride=s, grad_key=('conv', Wp.data_ptr()))
         self.g('patchify.conv3d.weight').add_(dWt.view(k ** 3, C, C).permute(2, 1, 0).reshape(Wp.shape))
         ops.colsum(dpatch, self.g('patchify.conv3d.bias'), accumulate=True)
         if s > 1:

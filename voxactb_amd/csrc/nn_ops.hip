@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256) absmax_part_kernel(const float* __restric
     if (threadIdx.x == 0) part[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
 }
 
-__global__ void __launch_bounds__(256) absmax_final_kernel(const unsigned* __restrict__ part, int nb, float* __restrict__ scale) {
+__global__ void __launch_bounds__(256) absmax_final_kernel(const unsigned* __restrict__ part, int nb, float* __restrict__ scale, int headroom) {
     __shared__ unsigned red[4];
     unsigned m = 0;
     for (int i = threadIdx.x; i < nb; i += 256) m = max(m, part[i]);
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(256) absmax_final_kernel(const unsigned* __res
         int k = 0;                                           // scale = 2^k
         if (m != 0 && m < 0x7f800000u) {
             const int e = (int)(m >> 23) - 127;              // m in [2^e, 2^(e+1)) (a denormal maximum: e = -127, clamped below)
-            k = min(max(14 - e, -100), 100);
+            k = min(max(14 - headroom - e, -100), 100);   // headroom bits below [2^14, 2^15): for scales that are used one step late
         }
         scale[0] = __uint_as_float((unsigned)(k + 127) << 23);
         scale[1] = __uint_as_float((unsigned)(127 - k) << 23);
@@ -720,9 +720,9 @@ extern "C" int vxb_sum_splits_dev_f32(const float* part, int nsplit, int64_t n, 
     return VXB_OK;
 }
 
-int vxb_absmax_finish_launch(const unsigned* part, int n, float* scale, hipStream_t st) {
+int vxb_absmax_finish_launch(const unsigned* part, int n, float* scale, hipStream_t st, int headroom_bits) {
     if (!part || !scale || n < 1) return VXB_EARG;
-    hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, st, part, n, scale);
+    hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, st, part, n, scale, headroom_bits);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
@@ -732,7 +732,7 @@ extern "C" int vxb_absmax_scale_f32(const float* x, int64_t n, float* ws, float*
     if ((uintptr_t)x & 15) return VXB_ESIZE;
     const int nb = (int)min((long long)1024, (long long)vxb_cdiv(n, 1024));
     hipLaunchKernelGGL(absmax_part_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, (long long)n, reinterpret_cast<unsigned*>(ws));
-    hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const unsigned*>(ws), nb, scale);
+    hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const unsigned*>(ws), nb, scale, 0);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }

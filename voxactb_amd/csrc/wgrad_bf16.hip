@@ -13,6 +13,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
 struct WgArgs {
@@ -27,11 +28,26 @@ struct WgArgs {
     long long ldy;       // dY row stride (row-major mode)
     int d2s_s, d2s_C;    // > 0: dY is a fine grid [B, (S_out*s)^3, d2s_C], column n = (phase, co)
     int tiles_per_split;
+    // 'fp16' products (PM = 2): the GRADIENT operand (src0 when grad_is_src0, else dy) is multiplied by scale[0] before the conversion
+    // to half; `part` comes out as scale[0] * dW.  amax_part (optional): word [z * nblk + blk] = largest |gradient operand| (bits,
+    // unscaled) seen by a workgroup that walks all of that operand's columns once -- the next step's scale (delayed scaling)
+    const float* scale;
+    int grad_is_src0;
+    unsigned* amax_part;
     float* possum;       // optional, plain mode only: possum[z][Krows] = sum over the z-th slice of positions of src0's rows (fp32, fixed
                          // order) -- the bias gradient of a linear layer falls out of its weight-gradient launch
 };
 
-__device__ __forceinline__ unsigned pack_bf16_2(float lo, float hi) { return vxb_pack_bf16(lo, hi); }
+template <int PM>
+__device__ __forceinline__ unsigned pack_bf16_2(float lo, float hi) {
+    if (PM == 2) return vxb_pack_f16(__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f));
+    return vxb_pack_bf16(lo, hi);
+}
+template <int PM>
+__device__ __forceinline__ f32x16 wg_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+    if (PM == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 
 __device__ __forceinline__ unsigned long long ds_read_tr16(unsigned addr) {
     unsigned long long v;
@@ -42,8 +58,9 @@ __device__ __forceinline__ unsigned long long ds_read_tr16(unsigned addr) {
 constexpr int BP = 32;      // positions per K-tile
 
 // X3 = 1: "bf16x3" split products (see gemm_conv.hip): both operands are staged as hi/lo bf16 planes, 3 MFMAs per product.
-template <int BN, int X3>
+template <int BN, int PM>
 __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
+    constexpr int X3 = PM == 1;
     constexpr int BM = 128;                       // (tap, ci) rows per block
     constexpr int LDA = BM + 32;                  // 160 bf16 = 80 dwords  (= 16 mod 64)
     constexpr int LDB = BN == 128 ? 160 : 96;     // 80 / 48 dwords        (= 16 / 48 mod 64)
@@ -163,32 +180,56 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
             rb[i] = v;
         }
     };
+    const float sc_a = (PM == 2 && g.scale && g.grad_is_src0) ? g.scale[0] : 1.0f;
+    const float sc_b = (PM == 2 && g.scale && !g.grad_is_src0) ? g.scale[0] : 1.0f;
+    // (uniform) this workgroup sees every value of the gradient operand's slice exactly once per row / column block
+    const bool want_amax = PM == 2 && g.amax_part != nullptr && (g.grad_is_src0 ? blockIdx.x == 0 : blockIdx.y == 0);
+    unsigned amx = 0;
     auto store_tile = [&]() {
         if (want_psum) {
 #pragma unroll
             for (int i = 0; i < A_F4; ++i) { psum.x += ra[i].x; psum.y += ra[i].y; psum.z += ra[i].z; psum.w += ra[i].w; }
         }
+        if (PM == 2) {
+            if (want_amax) {
+                if (g.grad_is_src0) {
+#pragma unroll
+                    for (int i = 0; i < A_F4; ++i)
+                        amx = max(max(amx, __float_as_uint(ra[i].x) & 0x7fffffffu), max(max(__float_as_uint(ra[i].y) & 0x7fffffffu,
+                                  __float_as_uint(ra[i].z) & 0x7fffffffu), __float_as_uint(ra[i].w) & 0x7fffffffu));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < B_F4; ++i)
+                        amx = max(max(amx, __float_as_uint(rb[i].x) & 0x7fffffffu), max(max(__float_as_uint(rb[i].y) & 0x7fffffffu,
+                                  __float_as_uint(rb[i].z) & 0x7fffffffu), __float_as_uint(rb[i].w) & 0x7fffffffu));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) { ra[i].x *= sc_a; ra[i].y *= sc_a; ra[i].z *= sc_a; ra[i].w *= sc_a; }
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) { rb[i].x *= sc_b; rb[i].y *= sc_b; rb[i].z *= sc_b; rb[i].w *= sc_b; }
+        }
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             uint2 p;
-            p.x = pack_bf16_2(ra[i].x, ra[i].y); p.y = pack_bf16_2(ra[i].z, ra[i].w);
+            p.x = pack_bf16_2<PM>(ra[i].x, ra[i].y); p.y = pack_bf16_2<PM>(ra[i].z, ra[i].w);
             *reinterpret_cast<uint2*>(&As[((tid >> 5) + 8 * i) * LDA + (tid & 31) * 4]) = p;
             if (X3) {
                 uint2 q;
-                q.x = pack_bf16_2(ra[i].x - __uint_as_float(p.x << 16), ra[i].y - __uint_as_float(p.x & 0xffff0000u));
-                q.y = pack_bf16_2(ra[i].z - __uint_as_float(p.y << 16), ra[i].w - __uint_as_float(p.y & 0xffff0000u));
+                q.x = pack_bf16_2<PM>(ra[i].x - __uint_as_float(p.x << 16), ra[i].y - __uint_as_float(p.x & 0xffff0000u));
+                q.y = pack_bf16_2<PM>(ra[i].z - __uint_as_float(p.y << 16), ra[i].w - __uint_as_float(p.y & 0xffff0000u));
                 *reinterpret_cast<uint2*>(&As[BP * LDA + ((tid >> 5) + 8 * i) * LDA + (tid & 31) * 4]) = q;
             }
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             uint2 p;
-            p.x = pack_bf16_2(rb[i].x, rb[i].y); p.y = pack_bf16_2(rb[i].z, rb[i].w);
+            p.x = pack_bf16_2<PM>(rb[i].x, rb[i].y); p.y = pack_bf16_2<PM>(rb[i].z, rb[i].w);
             *reinterpret_cast<uint2*>(&Bs[(tid / (BN / 4) + (256 / (BN / 4)) * i) * LDB + (tid % (BN / 4)) * 4]) = p;
             if (X3) {
                 uint2 q;
-                q.x = pack_bf16_2(rb[i].x - __uint_as_float(p.x << 16), rb[i].y - __uint_as_float(p.x & 0xffff0000u));
-                q.y = pack_bf16_2(rb[i].z - __uint_as_float(p.y << 16), rb[i].w - __uint_as_float(p.y & 0xffff0000u));
+                q.x = pack_bf16_2<PM>(rb[i].x - __uint_as_float(p.x << 16), rb[i].y - __uint_as_float(p.x & 0xffff0000u));
+                q.y = pack_bf16_2<PM>(rb[i].z - __uint_as_float(p.y << 16), rb[i].w - __uint_as_float(p.y & 0xffff0000u));
                 *reinterpret_cast<uint2*>(&Bs[BP * LDB + (tid / (BN / 4) + (256 / (BN / 4)) * i) * LDB + (tid % (BN / 4)) * 4]) = q;
             }
         }
@@ -258,8 +299,8 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
                         union { unsigned long long u[2]; bf16x8 v; } fb, fm;
                         fb.u[0] = b0[j]; fb.u[1] = b1[j];
                         fm.u[0] = bl0[j]; fm.u[1] = bl1[j];
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl.v, fb.v, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fm.v, acc[i][j], 0, 0, 0);
+                        acc[i][j] = wg_mfma<PM>(fl.v, fb.v, acc[i][j]);
+                        acc[i][j] = wg_mfma<PM>(fa.v, fm.v, acc[i][j]);
                     }
                 }
             }
@@ -271,12 +312,23 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
                 for (int j = 0; j < TN; ++j) {
                     union { unsigned long long u[2]; bf16x8 v; } fb;
                     fb.u[0] = b0[j]; fb.u[1] = b1[j];
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, acc[i][j], 0, 0, 0);
+                    acc[i][j] = wg_mfma<PM>(fa.v, fb.v, acc[i][j]);
                 }
             }
         }
     }
 
+    if (want_amax) {
+        __shared__ unsigned wamx[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o, 64));
+        if (lane == 0) wamx[wid] = amx;
+        __syncthreads();
+        if (tid == 0) {
+            const int nblk = g.grad_is_src0 ? gridDim.y : gridDim.x, blk = g.grad_is_src0 ? blockIdx.y : blockIdx.x;
+            g.amax_part[(long long)blockIdx.z * nblk + blk] = max(max(wamx[0], wamx[1]), max(wamx[2], wamx[3]));
+        }
+    }
     if (want_psum) {
         // fold the 8 position lanes (tid >> 5) of every row quad in a fixed order
         __syncthreads();
@@ -309,7 +361,8 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
 
 static int wgrad_bf16_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                           int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
-                          int d2s_s, int d2s_C, float* part, int nsplit, float* possum, vxb_stream_t stream) {
+                          int d2s_s, int d2s_C, float* part, int nsplit, float* possum, vxb_stream_t stream,
+                          const float* scale = nullptr, int grad_is_src0 = 0, float* next_scale = nullptr, float* amax_ws = nullptr) {
     if (!src0 || !dy || !part || B < 1 || S_in < 1 || S_out < 1 || kext < 1 || stride < 1 || N < 1 || nsplit < 1) return VXB_EARG;
     if (possum && !(S_in == 1 && S_out == 1 && kext == 1 && off == 0 && C1 == 0 && d2s_s <= 0)) return VXB_EARG;     // plain GEMM form only
     if ((C0 & 3) || (C1 & 3) || C0 < 4 || (C1 > 0 && !src1) || (N & 3)) return VXB_ESIZE;
@@ -317,6 +370,7 @@ static int wgrad_bf16_impl(int x3, const float* src0, const float* src1, int C0,
     if (d2s_s <= 0 && (ldy & 3)) return VXB_ESIZE;
     WgArgs g;
     g.src0 = src0; g.src1 = src1; g.dy = dy; g.part = part; g.possum = possum;
+    g.scale = scale; g.grad_is_src0 = grad_is_src0; g.amax_part = (next_scale && amax_ws) ? reinterpret_cast<unsigned*>(amax_ws) : nullptr;
     g.C0 = C0; g.C1 = C1; g.S_in = S_in; g.S_out = S_out; g.stride = stride; g.kext = kext; g.off = off; g.replicate = replicate;
     const long long K = (long long)kext * kext * kext * (C0 + C1);
     if (K >= INT32_MAX) return VXB_ESIZE;
@@ -324,17 +378,48 @@ static int wgrad_bf16_impl(int x3, const float* src0, const float* src1, int C0,
     const long long nkt = (g.P + BP - 1) / BP;
     g.tiles_per_split = (int)((nkt + nsplit - 1) / nsplit);
     hipStream_t st = (hipStream_t)stream;
+    int nblk;
     if (N > 64) {
         dim3 grid(vxb_cdiv(N, 128), vxb_cdiv(K, 128), nsplit);
-        if (x3) hipLaunchKernelGGL((wgrad_bf16_kernel<128, 1>), grid, dim3(256), 0, st, g);
+        nblk = grad_is_src0 ? grid.y : grid.x;
+        if (x3 == 2) hipLaunchKernelGGL((wgrad_bf16_kernel<128, 2>), grid, dim3(256), 0, st, g);
+        else if (x3) hipLaunchKernelGGL((wgrad_bf16_kernel<128, 1>), grid, dim3(256), 0, st, g);
         else hipLaunchKernelGGL((wgrad_bf16_kernel<128, 0>), grid, dim3(256), 0, st, g);
     } else {
         dim3 grid(vxb_cdiv(N, 64), vxb_cdiv(K, 128), nsplit);
-        if (x3) hipLaunchKernelGGL((wgrad_bf16_kernel<64, 1>), grid, dim3(256), 0, st, g);
+        nblk = grad_is_src0 ? grid.y : grid.x;
+        if (x3 == 2) hipLaunchKernelGGL((wgrad_bf16_kernel<64, 2>), grid, dim3(256), 0, st, g);
+        else if (x3) hipLaunchKernelGGL((wgrad_bf16_kernel<64, 1>), grid, dim3(256), 0, st, g);
         else hipLaunchKernelGGL((wgrad_bf16_kernel<64, 0>), grid, dim3(256), 0, st, g);
     }
     VXB_CHECK_LAUNCH();
+    // five bits of headroom: the scale is used by the NEXT step's launch, whose gradient may be up to 32x larger before anything
+    // saturates (half still keeps 11 bits down to 2^-19 of the maximum: nothing is lost at the small end)
+    if (g.amax_part) return vxb_absmax_finish_launch(g.amax_part, nblk * nsplit, next_scale, st, 5);
     return VXB_OK;
+}
+
+// workspace words of `amax_ws` for the entry below
+extern "C" size_t vxb_conv3d_wgrad_f16_amax_words(int C0, int C1, int kext, int N, int nsplit, int grad_is_src0) {
+    const long long K = (long long)kext * kext * kext * (C0 + C1);
+    const int bn = N > 64 ? 128 : 64;
+    return (size_t)nsplit * (size_t)(grad_is_src0 ? vxb_cdiv(K, 128) : vxb_cdiv(N, bn));
+}
+
+// ONE fp16 product per term (fp32 accumulate), same contract and `part` layout as the entries below.  The GRADIENT operand (src0 when
+// grad_is_src0 != 0 -- the plain-GEMM form of a linear layer's weight gradient, src0 = its dY -- else dy) is multiplied by scale[0]
+// (device, a power of two) before the conversion to half and `part` holds scale[0] * dW (undo it with vxb_sum_splits_dev_f32 and
+// scale[1]); the other operand saturates at +-65504.  next_scale (optional, [2], needs amax_ws of vxb_conv3d_wgrad_f16_amax_words
+// words): the scale vxb_absmax_scale_f32 would compute from the gradient operand as seen by THIS launch -- for the next step's call
+// (delayed scaling: the operand's magnitude moves slowly from step to step; the reported scale leaves 5 bits of headroom, a 32-fold
+// jump is still inside half's range).
+extern "C" int vxb_conv3d_wgrad_f16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
+                                        int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
+                                        int d2s_s, int d2s_C, float* part, int nsplit, float* possum, const float* scale,
+                                        int grad_is_src0, float* next_scale, float* amax_ws, vxb_stream_t stream) {
+    if (!scale) return VXB_EARG;
+    return wgrad_bf16_impl(2, src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, replicate, dy, N, ldy, d2s_s, d2s_C, part,
+                           nsplit, possum, stream, scale, grad_is_src0, next_scale, amax_ws);
 }
 
 // Same contract as vxb_conv3d_wgrad_f32 (include/voxactb_hip.h); operands are rounded to bf16 while staged, fp32 accumulate.

@@ -25,6 +25,12 @@ HALO_D2S = False     # ... also the depth-to-space forward of the polyphase up-c
 # bf16x3 triple.  Set by PerceiverEngine.backward from its `wgrad_precision`.  A weight gradient is a leaf of the backward pass:
 # measured against the reference's gradients at configs[1] / [2] size the two are indistinguishable.
 WGRAD_PRECISION = ''
+# ... and the weight gradients that go through the generic transposed-read kernel (wgrad_bf16.hip): the linear layers with >= 1024
+# rows and the 5^3 convs.  Their gradient operand is scaled by the power of two computed from the PREVIOUS call at the same site
+# (delayed scaling: the kernel reports the maximum it saw, for free; the first call takes an explicit absmax pass), with 5 bits
+# of headroom (a 32-fold jump from one step to the next still fits) and saturation on top -- see DESIGN.md 4a.
+GENERIC_WGRAD_F16 = False
+_GRAD_SCALE = {}          # call site (weight address / name) -> [current scale, next scale] device tensors, used in turn
 _WCACHE = {}
 
 
@@ -189,7 +195,7 @@ def linear_bwd(x, W, dy, dW, db=None, dx=None, dx_accumulate=False, ws=None):
             # both operands are row(position)-major -> the transposed-read bf16 kernel (a 1x1x1 "conv" over M positions)
             nsb = max(1, min(64, (512 + tiles - 1) // tiles, M // 256))
             res = conv3d_wgrad(dy, x, K, M, 1, 1, 1, 0, ldy=x.stride(0), nsplit=nsb, label='gemm_wgrad %dx%dx%d' % (N, K, M),
-                               possum_into=db)
+                               possum_into=db, grad_key=('lin', W.data_ptr()) if M >= 1024 else None, grad_is_src0=True)
             axpy_(dW, res)
             db = None                    # (the bias gradient came out of the same launch)
         elif ns > 1:
@@ -326,7 +332,8 @@ def conv3d(src0, wt, N, B, S_in, S_out, kext, off, stride=1, replicate=True, bia
 
 
 def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=True, src1=None, ldy=None, d2s=(0, 0),
-                 nsplit=None, label=None, force_bf16=False, phase_mask=None, flops_frac=1.0, dy_scale=None, possum_into=None):
+                 nsplit=None, label=None, force_bf16=False, phase_mask=None, flops_frac=1.0, dy_scale=None, possum_into=None,
+                 grad_key=None, grad_is_src0=False):
     """returns dWt [(tap, ci)][N] (fp32, deterministic split reduction).  phase_mask (LDS-halo kernel, d2s only): int32
     [N / 64] tap masks of the polyphase structure -- the structurally zero (tap, phase) blocks come back as zeros."""
     C0 = src0.shape[-1]
@@ -377,6 +384,25 @@ def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
     _lib.set_meta(label or 'conv3d_wgrad[k%d s%d %d->%d S%d]' % (kext, stride, C0 + C1, N, S_out), 2.0 * P * N * K)
     entry = {'bf16': 'vxb_conv3d_wgrad_bf16_f32', 'bf16x3': 'vxb_conv3d_wgrad_bf16x3_f32'}.get(
         force_bf16 if isinstance(force_bf16, str) else ('bf16' if force_bf16 else PRECISION), 'vxb_conv3d_wgrad_f32')
+    if (entry == 'vxb_conv3d_wgrad_bf16x3_f32' and WGRAD_PRECISION == 'fp16' and GENERIC_WGRAD_F16 and grad_key is not None
+            and (dy if not grad_is_src0 else src0).is_contiguous()):
+        grad = src0 if grad_is_src0 else dy
+        st = _GRAD_SCALE.get(grad_key)
+        if st is None or st[0].device != grad.device:
+            st = _GRAD_SCALE[grad_key] = [absmax_scale(grad), torch.empty(2, dtype=torch.float32, device=grad.device)]
+        cur, nxt = st
+        aws = torch.empty(int(_lib.lib().vxb_conv3d_wgrad_f16_amax_words(C0, C1, kext, N, nsplit, int(grad_is_src0))),
+                          dtype=torch.float32, device=grad.device)
+        psum = torch.empty((nsplit, K), dtype=torch.float32, device=src0.device) if possum_into is not None else None
+        _lib.set_meta(label or 'conv3d_wgrad[k%d s%d %d->%d S%d]' % (kext, stride, C0 + C1, N, S_out), 2.0 * P * N * K)
+        call('vxb_conv3d_wgrad_f16_f32', src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, int(replicate), dy, N,
+             ldy if ldy is not None else N, d2s[0], d2s[1], part, nsplit, psum, cur, int(grad_is_src0), nxt, aws)
+        st[0], st[1] = nxt, cur                       # the next call at this site uses the maximum this launch saw
+        if psum is not None:
+            sum_splits(psum, nsplit, K, possum_into, accumulate=True)
+        out = torch.empty((K, N), dtype=torch.float32, device=src0.device)
+        sum_splits(part, nsplit, K * N, out, alpha=cur[1:])
+        return out
     if entry != 'vxb_conv3d_wgrad_f32':
         # possum_into [C0] (plain GEMM form: the weight gradient of a linear layer, src0 = its dY): += the sums of src0 over the
         # positions, i.e. the bias gradient, from this launch (no second pass over dY)
