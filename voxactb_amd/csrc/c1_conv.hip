@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(256, 2) c1_dgrad4_ss_kernel(const float* __res
     __shared__ float sw[27 * 64];          // [t][c]
     __shared__ float red[16][64];
     __shared__ unsigned ramx[4];
-    unsigned amx = 0;                       // largest |du| this thread wrote (magnitude bits: NaN > inf > finite)
+    float amxf = 0.f;                       // largest |du| this thread wrote (one v_max_f32 with an |x| modifier per element)
     for (int i = threadIdx.x; i < 27 * 64; i += 256) sw[(i % 27) * 64 + i / 27] = w[i];
     const DivT divT(0.01f);
     const int c4 = (threadIdx.x & 15) * 4, gl = threadIdx.x >> 4;
@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(256, 2) c1_dgrad4_ss_kernel(const float* __res
                 v = xs[e] > 0.f ? v : v * slope;
                 bsum[e] += v;
                 r[e] = v;
-                amx = max(amx, __float_as_uint(v) & 0x7fffffffu);
+                amxf = fmaxf(amxf, fabsf(v));
             }
             *reinterpret_cast<float4*>(dub + (long long)p * 64) = make_float4(r[0], r[1], r[2], r[3]);
         }
@@ -232,6 +232,7 @@ __global__ void __launch_bounds__(256, 2) c1_dgrad4_ss_kernel(const float* __res
         partB[((long long)b * gridDim.x + blockIdx.x) * 64 + threadIdx.x] = sacc;
     }
     if (part_amax) {                        // (uniform) per-block maximum of |du| for the fp16 kernels that read du next
+        unsigned amx = __float_as_uint(amxf);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o, 64));
         if ((threadIdx.x & 63) == 0) ramx[threadIdx.x >> 6] = amx;

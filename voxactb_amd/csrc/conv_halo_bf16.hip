@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
         float* __restrict__ dst = g.fold_dst[nb];
         const float* __restrict__ yv = g.fold_y[nb];
         const int facc = g.fold_acc[nb];
-        unsigned amx = 0;
+        float amxf = 0.f;
         float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int item = tid; item < TD * TH * TW * 16; item += NTH) {
             const int c4 = (item & 15) * 4, pos = item >> 4;
@@ -514,8 +514,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
                 a.z = yy.z > 0.f ? a.z : a.z * g.slope; a.w = yy.w > 0.f ? a.w : a.w * g.slope;
             }
             *reinterpret_cast<float4*>(dst + o) = a;
-            amx = max(max(amx, __float_as_uint(a.x) & 0x7fffffffu), max(max(__float_as_uint(a.y) & 0x7fffffffu, __float_as_uint(a.z) & 0x7fffffffu),
-                                                                         __float_as_uint(a.w) & 0x7fffffffu));
+            amxf = fmaxf(fmaxf(amxf, fabsf(a.x)), fmaxf(fmaxf(fabsf(a.y), fabsf(a.z)), fabsf(a.w)));
             csum.x += a.x; csum.y += a.y; csum.z += a.z; csum.w += a.w;      // (item & 15 is the same for all of a thread's items)
         }
         if (g.colsum_part) {                // (uniform) fixed-order fold of the 16 threads that share a channel quad
@@ -531,6 +530,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
         }
         if (g.amax_part) {                  // (uniform) the fp16 operand scale of the tensor just written is taken on the way
             __shared__ unsigned famx[8];
+            unsigned amx = __float_as_uint(amxf);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o, 64));
             if (lane == 0) famx[wid] = amx;

@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
     const float sc_b = (PM == 2 && g.scale && !g.grad_is_src0) ? g.scale[0] : 1.0f;
     // (uniform) this workgroup sees every value of the gradient operand's slice exactly once per row / column block
     const bool want_amax = PM == 2 && g.amax_part != nullptr && (g.grad_is_src0 ? blockIdx.x == 0 : blockIdx.y == 0);
-    unsigned amx = 0;
+    float amxf = 0.f;
     auto store_tile = [&]() {
         if (want_psum) {
 #pragma unroll
@@ -194,14 +194,10 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
             if (want_amax) {
                 if (g.grad_is_src0) {
 #pragma unroll
-                    for (int i = 0; i < A_F4; ++i)
-                        amx = max(max(amx, __float_as_uint(ra[i].x) & 0x7fffffffu), max(max(__float_as_uint(ra[i].y) & 0x7fffffffu,
-                                  __float_as_uint(ra[i].z) & 0x7fffffffu), __float_as_uint(ra[i].w) & 0x7fffffffu));
+                    for (int i = 0; i < A_F4; ++i) amxf = fmaxf(fmaxf(amxf, fabsf(ra[i].x)), fmaxf(fmaxf(fabsf(ra[i].y), fabsf(ra[i].z)), fabsf(ra[i].w)));
                 } else {
 #pragma unroll
-                    for (int i = 0; i < B_F4; ++i)
-                        amx = max(max(amx, __float_as_uint(rb[i].x) & 0x7fffffffu), max(max(__float_as_uint(rb[i].y) & 0x7fffffffu,
-                                  __float_as_uint(rb[i].z) & 0x7fffffffu), __float_as_uint(rb[i].w) & 0x7fffffffu));
+                    for (int i = 0; i < B_F4; ++i) amxf = fmaxf(fmaxf(amxf, fabsf(rb[i].x)), fmaxf(fmaxf(fabsf(rb[i].y), fabsf(rb[i].z)), fabsf(rb[i].w)));
                 }
             }
 #pragma unroll
@@ -320,6 +316,7 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
 
     if (want_amax) {
         __shared__ unsigned wamx[4];
+        unsigned amx = __float_as_uint(amxf);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o, 64));
         if (lane == 0) wamx[wid] = amx;
