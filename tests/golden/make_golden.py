@@ -963,7 +963,9 @@ SECTIONS = {
     'f5g': lambda: encoder_fixture('f5g_encoder_c2_grads', CFG_C2, with_grads=True, digest=True, f64_grads=True),
     'f5c3': lambda: encoder_fixture('f5c3_encoder_c3_digest', CFG_C3, arm=True, with_grads=True, digest=True, crop=True, f64_grads=True),
     'f5v200': lambda: encoder_fixture('f5v200_encoder_c5_digest', CFG_C5, with_grads=False, digest=True),
-    # the same grid with the reference's loss and backward (~45 GB of autograd state: run it alone, under a memory watchdog)
+    # the same grid with the reference's loss and backward.  NOT part of the committed fixtures: on the 8-core build container the
+    # reference's CPU backward at 200^3 did not finish in 75 minutes (33 GB resident, all cores busy inside one ATen op), so the
+    # configs[4] backward is covered by tests/test_fullsize_gpu.py::test_v200_* (two kernel families against each other) instead
     'f5v200g': lambda: encoder_fixture('f5v200g_encoder_c5_grads', CFG_C5, with_grads=True, digest=True, check_oracle=False, f64_grads=True),
     'f11tiny': lambda: encoder2_fixture('f11_encoder_2robots_tiny', CFG_TINY),
     'f11c1': lambda: encoder2_fixture('f11_encoder_2robots_c1', CFG_C1),
