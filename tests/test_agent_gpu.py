@@ -166,3 +166,30 @@ def test_se3_augmentation_path_runs(golden):
     agent.update(5, bad)
     with pytest.raises(Exception, match='Failing to perturb'):
         agent.save_weights('/tmp')
+
+
+def test_training_curve_default_precision_tracks_exact_fp32(golden):
+    """30 LAMB steps of the same agent on the same batches in the exact-fp32 mode and in the default precision (bf16x3 products,
+    single-fp16 weight gradients with exact and DELAYED operand scales, fp16 d(d0)): the loss curves stay together (the new
+    arithmetic does not change what is being optimised) and both go down.  Cheap geometry (the F6 one), dropout and augmentation off
+    so that the two runs see identical inputs."""
+    g = golden('f6_update_traces')
+    curves = {}
+    for precision in ('fp32', 'bf16x3'):
+        os.environ['VOXACTB_PRECISION'] = precision
+        try:
+            agent, _ = make_agent(g, 'b')
+        finally:
+            del os.environ['VOXACTB_PRECISION']
+        qa = agent._pose_agent._qattention_agents[0]
+        eng = qa._q.encoder.engine()
+        assert eng.precision == precision and (precision == 'fp32' or (eng.wgrad_precision == 'fp16' and eng.generic_wgrad_f16))
+        curves[precision] = [float(agent.update(step, raw_batch(g, 'b', 10 + step % 4))['total_losses']) for step in range(30)]
+        del agent
+        torch.cuda.empty_cache()
+    a, b = np.array(curves['fp32']), np.array(curves['bf16x3'])
+    print('fp32   ', np.round(a[::3], 3))
+    print('default', np.round(b[::3], 3))
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    assert a[-4:].mean() < a[:4].mean() - 1.0 and b[-4:].mean() < b[:4].mean() - 1.0          # both train
+    assert np.abs(a - b).max() < 0.05 * np.abs(a).max(), np.abs(a - b).max()                 # and stay together (LAMB amplifies 1e-5 noise)
