@@ -58,10 +58,12 @@ __device__ __forceinline__ unsigned long long ds_read_tr16(unsigned addr) {
 constexpr int BP = 32;      // positions per K-tile
 
 // X3 = 1: "bf16x3" split products (see gemm_conv.hip): both operands are staged as hi/lo bf16 planes, 3 MFMAs per product.
-template <int BN, int PM>
+template <int BN, int PM, int BM = 128>          // BM = (tap, ci) rows per block: 128, or 256 (fp16 products: a quarter fewer LDS fragment
+                                                 // reads per MFMA -- 12 per 8 instead of 8 per 4 -- for the same staging per row)
 __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
     constexpr int X3 = PM == 1;
-    constexpr int BM = 128;                       // (tap, ci) rows per block
+    constexpr int TPR = BM / 4;                   // threads per position row of the A tile (32 / 64), RPP = position rows per pass
+    constexpr int RPP = 256 / TPR;
     constexpr int LDA = BM + 32;                  // 160 bf16 = 80 dwords  (= 16 mod 64)
     constexpr int LDB = BN == 128 ? 160 : 96;     // 80 / 48 dwords        (= 16 / 48 mod 64)
     constexpr int WN = BN == 128 ? 2 : 1, WM = 4 / WN;
@@ -78,7 +80,7 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
     const int Ct = g.C0 + g.C1;
 
     // ---- A: thread-constant (tap, channel) part; e = tid + 256 i -> pos = e / 32, row4 = (e % 32) * 4 = (tid % 32) * 4
-    const int kr = m0 + (tid & 31) * 4;
+    const int kr = m0 + (tid % TPR) * 4;
     const bool a_ok = kr < g.Krows;
     int a_td = 0, a_th = 0, a_tw = 0, a_ch = 0, a_Cs = g.C0;
     const float* a_src = g.src0;
@@ -130,7 +132,7 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
         }
     };
 #pragma unroll
-    for (int i = 0; i < A_F4; ++i) decode(kt_begin * BP + (tid >> 5) + 8 * i, aw[i], ah[i], ad[i], ab[i]);
+    for (int i = 0; i < A_F4; ++i) decode(kt_begin * BP + tid / TPR + RPP * i, aw[i], ah[i], ad[i], ab[i]);
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) decode(kt_begin * BP + tid / (BN / 4) + (256 / (BN / 4)) * i, bw[i], bh[i], bd[i], bb[i]);
 
@@ -141,7 +143,7 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
         const long long k0 = kt * BP;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
-            const long long pos = k0 + (tid >> 5) + 8 * i;
+            const long long pos = k0 + tid / TPR + RPP * i;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (plain) {
                 // linear-layer weight gradient (a 1 x 1 x 1 "conv" over M positions): row pos of a row-major matrix, no gather
@@ -209,12 +211,12 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
         for (int i = 0; i < A_F4; ++i) {
             uint2 p;
             p.x = pack_bf16_2<PM>(ra[i].x, ra[i].y); p.y = pack_bf16_2<PM>(ra[i].z, ra[i].w);
-            *reinterpret_cast<uint2*>(&As[((tid >> 5) + 8 * i) * LDA + (tid & 31) * 4]) = p;
+            *reinterpret_cast<uint2*>(&As[(tid / TPR + RPP * i) * LDA + (tid % TPR) * 4]) = p;
             if (X3) {
                 uint2 q;
                 q.x = pack_bf16_2<PM>(ra[i].x - __uint_as_float(p.x << 16), ra[i].y - __uint_as_float(p.x & 0xffff0000u));
                 q.y = pack_bf16_2<PM>(ra[i].z - __uint_as_float(p.y << 16), ra[i].w - __uint_as_float(p.y & 0xffff0000u));
-                *reinterpret_cast<uint2*>(&As[BP * LDA + ((tid >> 5) + 8 * i) * LDA + (tid & 31) * 4]) = q;
+                *reinterpret_cast<uint2*>(&As[BP * LDA + (tid / TPR + RPP * i) * LDA + (tid % TPR) * 4]) = q;
             }
         }
 #pragma unroll
@@ -327,15 +329,15 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
         }
     }
     if (want_psum) {
-        // fold the 8 position lanes (tid >> 5) of every row quad in a fixed order
+        // fold the RPP position lanes (tid / TPR) of every row quad in a fixed order
         __syncthreads();
         float4* red = reinterpret_cast<float4*>(&As[0]);          // 256 float4 = 4 KB <= the A tile
         red[tid] = psum;
         __syncthreads();
-        if (tid < 32 && a_ok) {
+        if (tid < TPR && a_ok) {
             float4 a = red[tid];
 #pragma unroll
-            for (int j = 1; j < 8; ++j) { const float4 b = red[tid + 32 * j]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+            for (int j = 1; j < RPP; ++j) { const float4 b = red[tid + TPR * j]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
             *reinterpret_cast<float4*>(g.possum + (long long)blockIdx.z * g.Krows + kr) = a;
         }
     }
@@ -355,6 +357,10 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
 }
 
 }  // namespace
+
+static int g_wg_bm256 = 0;        // experiment knob (vxb_debug_set_wgrad_bm256): 256-row tiles for the fp16 products.  Measured (round 3, linear_bwd
+                                  // at M = 32768, N x K = 4096x512 / 512x2048 / 1024x512): 0.548 / 0.271 / 0.149 ms against 0.491 / 0.239 / 0.128 ms
+                                  // with 128-row tiles -- a quarter fewer LDS fragment reads per MFMA, but half the workgroups and 176 VGPRs: OFF
 
 static int wgrad_bf16_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                           int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
@@ -379,7 +385,11 @@ static int wgrad_bf16_impl(int x3, const float* src0, const float* src1, int C0,
     if (N > 64) {
         dim3 grid(vxb_cdiv(N, 128), vxb_cdiv(K, 128), nsplit);
         nblk = grad_is_src0 ? grid.y : grid.x;
-        if (x3 == 2) hipLaunchKernelGGL((wgrad_bf16_kernel<128, 2>), grid, dim3(256), 0, st, g);
+        if (x3 == 2 && K >= 512 && g_wg_bm256) {
+            grid.y = vxb_cdiv(K, 256);
+            nblk = grad_is_src0 ? grid.y : grid.x;
+            hipLaunchKernelGGL((wgrad_bf16_kernel<128, 2, 256>), grid, dim3(256), 0, st, g);
+        } else if (x3 == 2) hipLaunchKernelGGL((wgrad_bf16_kernel<128, 2>), grid, dim3(256), 0, st, g);
         else if (x3) hipLaunchKernelGGL((wgrad_bf16_kernel<128, 1>), grid, dim3(256), 0, st, g);
         else hipLaunchKernelGGL((wgrad_bf16_kernel<128, 0>), grid, dim3(256), 0, st, g);
     } else {
@@ -396,12 +406,13 @@ static int wgrad_bf16_impl(int x3, const float* src0, const float* src1, int C0,
     return VXB_OK;
 }
 
-// workspace words of `amax_ws` for the entry below
+// workspace words of `amax_ws` for the entry below (an upper bound over the tile shapes the launch may pick)
 extern "C" size_t vxb_conv3d_wgrad_f16_amax_words(int C0, int C1, int kext, int N, int nsplit, int grad_is_src0) {
     const long long K = (long long)kext * kext * kext * (C0 + C1);
     const int bn = N > 64 ? 128 : 64;
     return (size_t)nsplit * (size_t)(grad_is_src0 ? vxb_cdiv(K, 128) : vxb_cdiv(N, bn));
 }
+extern "C" void vxb_debug_set_wgrad_bm256(int on) { g_wg_bm256 = on ? 1 : 0; }
 
 // ONE fp16 product per term (fp32 accumulate), same contract and `part` layout as the entries below.  The GRADIENT operand (src0 when
 // grad_is_src0 != 0 -- the plain-GEMM form of a linear layer's weight gradient, src0 = its dY -- else dy) is multiplied by scale[0]
