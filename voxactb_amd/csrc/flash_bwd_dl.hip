@@ -58,10 +58,12 @@ __device__ __forceinline__ bf16x8 bd_join(unsigned long long a, unsigned long lo
     t.u[0] = a; t.u[1] = b;
     return t.v;
 }
-__device__ __forceinline__ unsigned long long bd_tr16(unsigned addr) {
-    unsigned long long v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-    return v;
+typedef short bd_v4s __attribute__((ext_vector_type(4)));
+// transposed 8-byte LDS read through the compiler builtin (lane base + immediate offset, compiler-placed waits)
+__device__ __forceinline__ unsigned long long bd_tr16(const u16* p) {
+    union { bd_v4s v; unsigned long long u; } t;
+    t.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bd_v4s*)p);
+    return t.u;
 }
 template <int X3>
 __device__ __forceinline__ f32x16 bd_mma(const bf16x8 ah, const bf16x8 al, const bf16x8 bh, const bf16x8 bl, f32x16 c) {
@@ -100,7 +102,7 @@ __device__ __forceinline__ void bd_frag8(const float* p, float s, bf16x8& fh, bf
 // ------------------------------------------------------------------------------------------------ dQ
 // lane = query (swapped form).  Per K/V tile: S^T = K Q^T, P = exp2(S^T - lse); dP^T = V dO^T;
 // dS^T = scale * P * (dP * keep/(1-p) - D); dQ^T += K^T dS^T (K^T by transposed reads of the same K tile).
-template <int X3>
+template <int X3, int DROP>
 __global__ void __launch_bounds__(256, 2) flash_bwd_dq_dl_kernel(BdArgs g) {
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     constexpr int NPL = 1 + X3;
@@ -157,6 +159,14 @@ __global__ void __launch_bounds__(256, 2) flash_bwd_dq_dl_kernel(BdArgs g) {
     const int t16 = lane & 15, gq = lane >> 4;
     const int trow0 = 4 * (gq >> 1) + (t16 >> 2);
     const int tchunk0 = 2 * (gq & 1) + ((t16 & 3) >> 1), thalf = (t16 & 1) * 4;
+    // a read's tile offset (multiples of 8 rows) only reaches the swizzle key through its 8-row bit: one lane offset per
+    // (d-block, second-read) pair, the rest of the address is an immediate
+    int tlane[2][2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+            tlane[db][rr] = trow0 * 64 + ((tchunk0 + 4 * db) ^ bd_swz(8 * rr + trow0)) * 8 + thalf;
 
     const int nkt = (g.Nk + BT - 1) / BT;
     issue(0, 0);
@@ -192,7 +202,7 @@ __global__ void __launch_bounds__(256, 2) flash_bwd_dq_dl_kernel(BdArgs g) {
                 float p0 = key < g.Nk ? __builtin_amdgcn_exp2f(sacc[kb][r] - lse2) : 0.f;
                 float p1 = key + 1 < g.Nk ? __builtin_amdgcn_exp2f(sacc[kb][r + 1] - lse2) : 0.f;
                 float d0 = pacc[kb][r], d1 = pacc[kb][r + 1];
-                if (thr > 0u) {
+                if (DROP) {
                     const unsigned hsh = bd_keep_pair(g.seed, row_id, (unsigned)key >> 1);
                     d0 = (hsh & 0xffffu) >= thr ? d0 * keep_scale : 0.f;
                     d1 = (hsh >> 16) >= thr ? d1 * keep_scale : 0.f;
@@ -201,7 +211,6 @@ __global__ void __launch_bounds__(256, 2) flash_bwd_dq_dl_kernel(BdArgs g) {
                 if (X3) bd_split2(s0, s1, sbh[kb][r >> 1], sbl[kb][r >> 1]);
                 else sbh[kb][r >> 1] = vxb_pack_bf16(s0, s1);
             }
-        const unsigned kb_addr = (unsigned)(size_t)sb;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -213,13 +222,10 @@ __global__ void __launch_bounds__(256, 2) flash_bwd_dq_dl_kernel(BdArgs g) {
                 for (int db = 0; db < 2; ++db)
 #pragma unroll
                     for (int rr = 0; rr < 2; ++rr) {
-                        const int row = kb * 32 + 16 * ks + 8 * rr + trow0;
-                        const unsigned ad = kb_addr + 2u * (unsigned)(row * 64 + ((tchunk0 + 4 * db) ^ bd_swz(row)) * 8 + thalf);
+                        const u16* ad = sb + tlane[db][rr] + (kb * 32 + 16 * ks + 8 * rr) * 64;
                         ka[db][rr] = bd_tr16(ad);
-                        if (X3) kl[db][rr] = bd_tr16(ad + 2u * (unsigned)TILE);
+                        if (X3) kl[db][rr] = bd_tr16(ad + TILE);
                     }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
                     const bf16x8 kfh = bd_join(ka[db][0], ka[db][1]);
@@ -244,7 +250,7 @@ __global__ void __launch_bounds__(256, 2) flash_bwd_dq_dl_kernel(BdArgs g) {
 //   S = Q K^T, dP = dO V^T   : A = Q / dO rows from LDS (ds_read_b128), B = K^T * (scale log2e) / V^T fragments in registers
 //   P = exp2(S - lse[q]), dS = scale * P * (dP * keep/(1-p) - D[q])
 //   dV += Pd^T dO, dK += dS^T Q : A = the P / dS registers packed to bf16, B = dO / Q by transposed reads of the same tiles
-template <int X3>
+template <int X3, int DROP>
 __global__ void __launch_bounds__(256, 2) flash_bwd_dkv_dl_kernel(BdArgs g) {
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     constexpr int NPL = 1 + X3;
@@ -298,9 +304,18 @@ __global__ void __launch_bounds__(256, 2) flash_bwd_dkv_dl_kernel(BdArgs g) {
     };
     const unsigned thr = (unsigned)(g.p_drop * 65536.0f);
     const float keep_scale = 1.0f / (1.0f - g.p_drop);
+    const unsigned kodd = (unsigned)key & 1u, hshift = kodd ? 0u : 16u, thr16 = thr << 16;      // key parity == lane parity
     const int t16 = lane & 15, gq = lane >> 4;
     const int trow0 = 4 * (gq >> 1) + (t16 >> 2);
     const int tchunk0 = 2 * (gq & 1) + ((t16 & 3) >> 1), thalf = (t16 & 1) * 4;
+    // a read's tile offset (multiples of 8 rows) only reaches the swizzle key through its 8-row bit: one lane offset per
+    // (d-block, second-read) pair, the rest of the address is an immediate
+    int tlane[2][2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+            tlane[db][rr] = trow0 * 64 + ((tchunk0 + 4 * db) ^ bd_swz(8 * rr + trow0)) * 8 + thalf;
 
     const int nqt = (g.Nq + BT - 1) / BT;
     issue(0, 0);
@@ -310,7 +325,8 @@ __global__ void __launch_bounds__(256, 2) flash_bwd_dkv_dl_kernel(BdArgs g) {
         if (qt + 1 < nqt) issue((qt + 1) & 1, qt + 1);
         const int st = qt & 1;
         const u16* sb = smem + st * STAGE;
-        const unsigned q_addr = (unsigned)(size_t)sb, o_addr = (unsigned)(size_t)(sb + NPL * TILE);
+        const u16* q_t = sb;
+        const u16* o_t = sb + NPL * TILE;
         // the two 32-query blocks of the tile one after the other (a real loop): only one block's S / dP / P / dS
         // registers are live at a time, which is what lets two waves share a SIMD
 #pragma unroll 1
@@ -340,12 +356,14 @@ __global__ void __launch_bounds__(256, 2) flash_bwd_dkv_dl_kernel(BdArgs g) {
                 float p1 = k_ok ? __builtin_amdgcn_exp2f(sacc[r + 1] - s_lse[st][ql + 1]) : 0.f;
                 float d0 = pacc[r], d1 = pacc[r + 1];
                 float pd0 = p0, pd1 = p1;
-                if (thr > 0u) {
+                if (DROP) {
                     const unsigned row0 = (unsigned)bh * (unsigned)g.Nq + (unsigned)(qt * BT + ql);
-                    const unsigned h0 = bd_keep_pair(g.seed, row0, (unsigned)key >> 1);
-                    const unsigned h1 = bd_keep_pair(g.seed, row0 + 1u, (unsigned)key >> 1);
-                    const bool k0 = ((key & 1) ? (h0 >> 16) : (h0 & 0xffffu)) >= thr;
-                    const bool k1 = ((key & 1) ? (h1 >> 16) : (h1 & 0xffffu)) >= thr;
+                    // the mask word of (row, key pair) covers this lane's key and its neighbour's (lane ^ 1): the even lane
+                    // hashes row0, the odd lane row0 + 1 and the two swap words (one DPP move) instead of hashing both
+                    const unsigned hm = bd_keep_pair(g.seed, row0 + kodd, (unsigned)key >> 1);
+                    const unsigned ho = (unsigned)__builtin_amdgcn_mov_dpp((int)hm, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+                    const unsigned h0 = kodd ? ho : hm, h1 = kodd ? hm : ho;
+                    const bool k0 = (h0 << hshift) >= thr16, k1 = (h1 << hshift) >= thr16;      // this key's 16-bit half >= thr
                     d0 = k0 ? d0 * keep_scale : 0.f; d1 = k1 ? d1 * keep_scale : 0.f;
                     pd0 = k0 ? p0 * keep_scale : 0.f; pd1 = k1 ? p1 * keep_scale : 0.f;
                 }
@@ -368,17 +386,14 @@ __global__ void __launch_bounds__(256, 2) flash_bwd_dkv_dl_kernel(BdArgs g) {
                 for (int db = 0; db < 2; ++db)
 #pragma unroll
                     for (int rr = 0; rr < 2; ++rr) {
-                        const int row = qb * 32 + 16 * ks + 8 * rr + trow0;
-                        const unsigned off = 2u * (unsigned)(row * 64 + ((tchunk0 + 4 * db) ^ bd_swz(row)) * 8 + thalf);
-                        oa[db][rr] = bd_tr16(o_addr + off);
-                        qa[db][rr] = bd_tr16(q_addr + off);
+                        const int off = qb * 32 * 64 + tlane[db][rr] + (16 * ks + 8 * rr) * 64;
+                        oa[db][rr] = bd_tr16(o_t + off);
+                        qa[db][rr] = bd_tr16(q_t + off);
                         if (X3) {
-                            ol[db][rr] = bd_tr16(o_addr + off + 2u * (unsigned)TILE);
-                            ql2[db][rr] = bd_tr16(q_addr + off + 2u * (unsigned)TILE);
+                            ol[db][rr] = bd_tr16(o_t + off + TILE);
+                            ql2[db][rr] = bd_tr16(q_t + off + TILE);
                         }
                     }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
                     const bf16x8 ofh = bd_join(oa[db][0], oa[db][1]), q2h = bd_join(qa[db][0], qa[db][1]);
@@ -449,15 +464,27 @@ extern "C" int vxb_flash_attn_bwd_dl(const float* q, const float* kv, const floa
     g.lse = lse; g.dsum = dsum_ws; g.dq = dq; g.dkv = dkv;
     g.B = B; g.H = H; g.Nq = Nq; g.Nk = Nk; g.scale = scale; g.p_drop = dropout_p; g.seed = seed;
     const size_t lds = (size_t)2 * 2 * nplanes * TILE * sizeof(u16);
+    const bool drop = (unsigned)(dropout_p * 65536.0f) > 0u;
+    const dim3 gq(vxb_cdiv(Nq, BQ), B * H), gk(vxb_cdiv(Nk, BQ), B * H);
     if (nplanes == 2) {
-        if (hipFuncSetAttribute((const void*)flash_bwd_dq_dl_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)flash_bwd_dkv_dl_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)flash_bwd_dq_dl_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)flash_bwd_dq_dl_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)flash_bwd_dkv_dl_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)flash_bwd_dkv_dl_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return VXB_ELAUNCH;
-        hipLaunchKernelGGL(flash_bwd_dq_dl_kernel<1>, dim3(vxb_cdiv(Nq, BQ), B * H), dim3(256), lds, st, g);
-        hipLaunchKernelGGL(flash_bwd_dkv_dl_kernel<1>, dim3(vxb_cdiv(Nk, BQ), B * H), dim3(256), lds, st, g);
+        if (drop) {
+            hipLaunchKernelGGL((flash_bwd_dq_dl_kernel<1, 1>), gq, dim3(256), lds, st, g);
+            hipLaunchKernelGGL((flash_bwd_dkv_dl_kernel<1, 1>), gk, dim3(256), lds, st, g);
+        } else {
+            hipLaunchKernelGGL((flash_bwd_dq_dl_kernel<1, 0>), gq, dim3(256), lds, st, g);
+            hipLaunchKernelGGL((flash_bwd_dkv_dl_kernel<1, 0>), gk, dim3(256), lds, st, g);
+        }
+    } else if (drop) {
+        hipLaunchKernelGGL((flash_bwd_dq_dl_kernel<0, 1>), gq, dim3(256), lds, st, g);
+        hipLaunchKernelGGL((flash_bwd_dkv_dl_kernel<0, 1>), gk, dim3(256), lds, st, g);
     } else {
-        hipLaunchKernelGGL(flash_bwd_dq_dl_kernel<0>, dim3(vxb_cdiv(Nq, BQ), B * H), dim3(256), lds, st, g);
-        hipLaunchKernelGGL(flash_bwd_dkv_dl_kernel<0>, dim3(vxb_cdiv(Nk, BQ), B * H), dim3(256), lds, st, g);
+        hipLaunchKernelGGL((flash_bwd_dq_dl_kernel<0, 0>), gq, dim3(256), lds, st, g);
+        hipLaunchKernelGGL((flash_bwd_dkv_dl_kernel<0, 0>), gk, dim3(256), lds, st, g);
     }
     VXB_CHECK_LAUNCH();
     return VXB_OK;

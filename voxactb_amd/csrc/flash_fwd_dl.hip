@@ -55,10 +55,13 @@ __device__ __forceinline__ bf16x8 fd_join(unsigned long long a, unsigned long lo
     t.u[0] = a; t.u[1] = b;
     return t.v;
 }
-__device__ __forceinline__ unsigned long long fd_tr16(unsigned addr) {
-    unsigned long long v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-    return v;
+typedef short fd_v4s __attribute__((ext_vector_type(4)));
+// transposed 8-byte LDS read through the compiler builtin: a lane base + compile-time offset folds into the instruction's
+// immediate (no address arithmetic per read) and the compiler places the waits
+__device__ __forceinline__ unsigned long long fd_tr16(const u16* p) {
+    union { fd_v4s v; unsigned long long u; } t;
+    t.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) fd_v4s*)p);
+    return t.u;
 }
 template <int X3>
 __device__ __forceinline__ f32x16 fd_mma(const bf16x8 ah, const bf16x8 al, const bf16x8 bh, const bf16x8 bl, f32x16 c) {
@@ -73,7 +76,7 @@ __device__ __forceinline__ void fd_load16(const u16* src, u16* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int X3>
+template <int X3, int DROP>
 __global__ void __launch_bounds__(256, 2) flash_fwd_dl_kernel(FdArgs g) {
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     constexpr int NPL = 1 + X3;
@@ -148,6 +151,11 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_dl_kernel(FdArgs g) {
     const int t16 = lane & 15, gq = lane >> 4;
     const int vrow0 = 4 * (gq >> 1) + (t16 >> 2);
     const int vchunk0 = 2 * (gq & 1) + ((t16 & 3) >> 1), vhalf = (t16 & 1) * 4;     // u16 offset inside the chunk
+    // the tile offsets of a read (32 kb + 16 ks + 8 rr keys) are multiples of 8 rows, so the swizzle bit (row >> 1) & 1 is the
+    // lane's own: one lane offset per d-block, everything else is an immediate
+    int vlane[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) vlane[db] = vrow0 * 64 + ((vchunk0 + 4 * db) ^ (4 * ((vrow0 >> 1) & 1))) * 8 + vhalf;
 
     const int nkt = (g.Nk + BKV - 1) / BKV;
     issue(0, 0);
@@ -200,7 +208,7 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_dl_kernel(FdArgs g) {
             for (int r = 0; r < 16; r += 2) {
                 float p0 = __builtin_amdgcn_exp2f(sacc[kb][r] - m_new), p1 = __builtin_amdgcn_exp2f(sacc[kb][r + 1] - m_new);
                 psum += p0 + p1;
-                if (thr > 0u) {
+                if (DROP) {
                     const unsigned key = (unsigned)(kbase_t + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
                     const unsigned hsh = fd_keep_pair(g.seed, row_id, key >> 1);
                     p0 = (hsh & 0xffffu) >= thr ? p0 * keep_scale : 0.f;
@@ -215,7 +223,7 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_dl_kernel(FdArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
         // ---- O^T += V^T P^T : 2 d-blocks x (2 key blocks x 2 k-steps of 16 keys)
-        const unsigned vb = (unsigned)(size_t)(sb + NPL * TILE);
+        const u16* vt = sb + NPL * TILE;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -227,15 +235,11 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_dl_kernel(FdArgs g) {
                 for (int db = 0; db < 2; ++db) {
 #pragma unroll
                     for (int rr = 0; rr < 2; ++rr) {            // second read: keys + 8
-                        const int row = kb * 32 + 16 * ks + 8 * rr + vrow0;
-                        const int chunk = (vchunk0 + 4 * db) ^ (4 * ((row >> 1) & 1));
-                        const unsigned ad = vb + 2u * (unsigned)(row * 64 + chunk * 8 + vhalf);
+                        const u16* ad = vt + vlane[db] + (kb * 32 + 16 * ks + 8 * rr) * 64;
                         va[db][rr] = fd_tr16(ad);
-                        if (X3) vl[db][rr] = fd_tr16(ad + 2u * (unsigned)TILE);
+                        if (X3) vl[db][rr] = fd_tr16(ad + TILE);
                     }
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
                     const bf16x8 vfh = fd_join(va[db][0], va[db][1]);
@@ -275,12 +279,16 @@ extern "C" int vxb_flash_attn_fwd_dl(const float* q, const void* kv_planes, int 
     g.B = B; g.H = H; g.Nq = Nq; g.Nk = Nk; g.scale = scale; g.p_drop = dropout_p; g.seed = seed;
     const dim3 grid(vxb_cdiv(Nq, BQ), B * H);
     const size_t lds = (size_t)2 * 2 * nplanes * TILE * sizeof(u16);
+    const bool drop = (unsigned)(dropout_p * 65536.0f) > 0u;
     if (nplanes == 2) {
-        if (hipFuncSetAttribute((const void*)flash_fwd_dl_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)flash_fwd_dl_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)flash_fwd_dl_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return VXB_ELAUNCH;
-        hipLaunchKernelGGL(flash_fwd_dl_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, g);
+        if (drop) hipLaunchKernelGGL((flash_fwd_dl_kernel<1, 1>), grid, dim3(256), lds, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL((flash_fwd_dl_kernel<1, 0>), grid, dim3(256), lds, (hipStream_t)stream, g);
     } else {
-        hipLaunchKernelGGL(flash_fwd_dl_kernel<0>, grid, dim3(256), lds, (hipStream_t)stream, g);
+        if (drop) hipLaunchKernelGGL((flash_fwd_dl_kernel<0, 1>), grid, dim3(256), lds, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL((flash_fwd_dl_kernel<0, 0>), grid, dim3(256), lds, (hipStream_t)stream, g);
     }
     VXB_CHECK_LAUNCH();
     return VXB_OK;
