@@ -68,6 +68,8 @@ def lib():
             L.vxb_debug_set_halo_wn(int(os.environ['VOXACTB_HALO_WN']))
         if os.environ.get('VOXACTB_HALO_DBG'):     # experiment bits of conv_halo_bf16.hip (4 = no skipping of depth-edge waves; 1, 2: timing only, WRONG results)
             L.vxb_debug_set_halo_experiment(int(os.environ['VOXACTB_HALO_DBG']))
+        if os.environ.get('VOXACTB_WGRAD_LIN'):    # A/B switch of the linear layers' fp16 weight-gradient kernels (wgrad_bf16.hip): 0 generic, 1 pipelined, 2 wide
+            L.vxb_debug_set_wgrad_lin(int(os.environ['VOXACTB_WGRAD_LIN']))
         _lib = L
     return _lib
 

@@ -356,11 +356,402 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The plain-GEMM form (weight gradient of a linear layer: part[z][r][n] = sum_p src0[p][r] * dy[p][n]) on single fp16 products,
+// pipelined: the generic kernel above spends two barriers and an LDS drain on every 32-position tile of 8 MFMAs per wave (12 % of the
+// matrix pipe busy, half of the wave time in s_waitcnt: profiles/r03_v3_sq_summary.txt).  Here the LDS tiles are double-buffered:
+// tile t+1 is converted and stored into the other stage while tile t is multiplied, the global loads of tile t+2 are issued before
+// that, and there is ONE barrier per tile; the transposed fragment reads go through the compiler builtin (immediate offsets, waits
+// placed by the compiler).  Same tile shape, same operand rounding, same accumulation order as the generic kernel: bit-identical.
+typedef short wl_v4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned long long wl_tr16(const u16* p) {
+    union { wl_v4s v; unsigned long long u; } t;
+    t.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wl_v4s*)p);
+    return t.u;
+}
+
+template <int BN>
+__global__ void __launch_bounds__(256) wgrad_lin_f16_kernel(WgArgs g) {
+    constexpr int BM = 128, PM = 2;
+    constexpr int LDA = BM + 32;
+    constexpr int LDB = BN == 128 ? 160 : 96;
+    constexpr int WN = BN == 128 ? 2 : 1, WM = 4 / WN;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_F4 = BP * BM / 4 / 256;       // 4
+    constexpr int B_F4 = BP * BN / 4 / 256;       // 4 or 2
+    constexpr int BTR = BN / 4;                   // threads per position row of the B tile
+    __shared__ __attribute__((aligned(16))) u16 As[2][BP * LDA];
+    __shared__ __attribute__((aligned(16))) u16 Bs[2][BP * LDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kr = m0 + (tid & 31) * 4;
+    const bool a_ok = kr < g.Krows;
+    const int bn = n0 + (tid % BTR) * 4;
+    const bool b_ok = bn < g.N;
+    const float* __restrict__ ap = g.src0 + kr;
+    const float* __restrict__ bp = g.dy + bn;
+    const long long lda = g.C0;
+
+    long long nkt = (g.P + BP - 1) / BP;
+    const long long kt_begin = (long long)blockIdx.z * g.tiles_per_split;
+    if (nkt > kt_begin + g.tiles_per_split) nkt = kt_begin + g.tiles_per_split;
+
+    float4 ra[A_F4], rb[B_F4];
+    auto load_tile = [&](long long kt) {
+        const long long k0 = kt * BP;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const long long pos = k0 + (tid >> 5) + 8 * i;
+            ra[i] = (a_ok && pos < g.P) ? *reinterpret_cast<const float4*>(ap + pos * lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const long long pos = k0 + tid / BTR + (256 / BTR) * i;
+            rb[i] = (b_ok && pos < g.P) ? *reinterpret_cast<const float4*>(bp + pos * g.ldy) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    const float sc_a = (g.scale && g.grad_is_src0) ? g.scale[0] : 1.0f;
+    const float sc_b = (g.scale && !g.grad_is_src0) ? g.scale[0] : 1.0f;
+    const bool want_psum = g.possum != nullptr && blockIdx.x == 0;
+    const bool want_amax = g.amax_part != nullptr && (g.grad_is_src0 ? blockIdx.x == 0 : blockIdx.y == 0);
+    float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
+    float amxf = 0.f;
+    auto store_tile = [&](int stage) {
+        if (want_psum) {
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) { psum.x += ra[i].x; psum.y += ra[i].y; psum.z += ra[i].z; psum.w += ra[i].w; }
+        }
+        if (want_amax) {
+            if (g.grad_is_src0) {
+#pragma unroll
+                for (int i = 0; i < A_F4; ++i) amxf = fmaxf(fmaxf(amxf, fabsf(ra[i].x)), fmaxf(fmaxf(fabsf(ra[i].y), fabsf(ra[i].z)), fabsf(ra[i].w)));
+            } else {
+#pragma unroll
+                for (int i = 0; i < B_F4; ++i) amxf = fmaxf(fmaxf(amxf, fabsf(rb[i].x)), fmaxf(fmaxf(fabsf(rb[i].y), fabsf(rb[i].z)), fabsf(rb[i].w)));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            uint2 p;
+            p.x = pack_bf16_2<PM>(ra[i].x * sc_a, ra[i].y * sc_a); p.y = pack_bf16_2<PM>(ra[i].z * sc_a, ra[i].w * sc_a);
+            *reinterpret_cast<uint2*>(&As[stage][((tid >> 5) + 8 * i) * LDA + (tid & 31) * 4]) = p;
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            uint2 p;
+            p.x = pack_bf16_2<PM>(rb[i].x * sc_b, rb[i].y * sc_b); p.y = pack_bf16_2<PM>(rb[i].z * sc_b, rb[i].w * sc_b);
+            *reinterpret_cast<uint2*>(&Bs[stage][(tid / BTR + (256 / BTR) * i) * LDB + (tid % BTR) * 4]) = p;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addressing as in the generic kernel: group gq = lane >> 4, t = lane & 15
+    const int gq = lane >> 4, t = lane & 15;
+    const int f_pos = 8 * (gq >> 1) + (t >> 2);
+    const int f_ch = 16 * (gq & 1) + 4 * (t & 3);
+    const int a_lane = f_pos * LDA + wm * (BM / WM) + f_ch;
+    const int b_lane = f_pos * LDB + wn * (BN / WN) + f_ch;
+
+    if (kt_begin < nkt) {
+        load_tile(kt_begin);
+        store_tile(0);
+        if (kt_begin + 1 < nkt) load_tile(kt_begin + 1);
+    }
+    __syncthreads();
+    for (long long kt = kt_begin; kt < nkt; ++kt) {
+        const int cur = (int)(kt - kt_begin) & 1;
+        if (kt + 1 < nkt) store_tile(cur ^ 1);                 // tile kt + 1 (in registers since the previous iteration)
+        if (kt + 2 < nkt) load_tile(kt + 2);
+        const u16* at = &As[cur][a_lane];
+        const u16* bt = &Bs[cur][b_lane];
+#pragma unroll
+        for (int kk = 0; kk < BP; kk += 16) {
+            union { unsigned long long u[2]; bf16x8 v; } fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                fa[i].u[0] = wl_tr16(at + (kk + 0) * LDA + i * 32);
+                fa[i].u[1] = wl_tr16(at + (kk + 4) * LDA + i * 32);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                fb[j].u[0] = wl_tr16(bt + (kk + 0) * LDB + j * 32);
+                fb[j].u[1] = wl_tr16(bt + (kk + 4) * LDB + j * 32);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = wg_mfma<PM>(fa[i].v, fb[j].v, acc[i][j]);
+        }
+        __syncthreads();
+    }
+
+    if (want_amax) {
+        __shared__ unsigned wamx[4];
+        unsigned amx = __float_as_uint(amxf);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o, 64));
+        if (lane == 0) wamx[wid] = amx;
+        __syncthreads();
+        if (tid == 0) {
+            const int nblk = g.grad_is_src0 ? gridDim.y : gridDim.x, blk = g.grad_is_src0 ? blockIdx.y : blockIdx.x;
+            g.amax_part[(long long)blockIdx.z * nblk + blk] = max(max(wamx[0], wamx[1]), max(wamx[2], wamx[3]));
+        }
+    }
+    if (want_psum) {
+        // fold the 8 position lanes (tid >> 5) of every row quad in a fixed order (the last barrier of the loop freed the tiles)
+        float4* red = reinterpret_cast<float4*>(&As[0][0]);       // 256 float4 = 4 KB <= one A stage
+        red[tid] = psum;
+        __syncthreads();
+        if (tid < 32 && a_ok) {
+            float4 a = red[tid];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) { const float4 b = red[tid + 32 * j]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+            *reinterpret_cast<float4*>(g.possum + (long long)blockIdx.z * g.Krows + kr) = a;
+        }
+    }
+    float* __restrict__ C = g.part + (long long)blockIdx.z * g.Krows * g.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+            if (n >= g.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < g.Krows) C[(long long)m * g.N + n] = acc[i][j][r];
+            }
+        }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Wide form of the same plain GEMM for the linear layers whose narrower operand has exactly 512 channels (every big linear layer of
+// the Perceiver trunk: 4096x512, 512x2048, 512x512, 1024x512).  The 128 x 128 kernels move 128 B of fp32 operands per CU and clock
+// at full matrix rate and re-read the wide operand once per 128-column block from beyond the L2 (537 MB x 4 for the GEGLU up-projection):
+// that traffic, not the matrix pipe (12-15 % busy), is what they wait for.  Here a workgroup of 8 waves owns 128 channels of the WIDE
+// operand U and ALL 512 channels of the narrow operand V: U is read from HBM exactly once, V (67 MB) is re-read out of the L2 /
+// Infinity Cache, and a staged byte feeds 2.6x the MFMAs.  T[i][j] = sum_p U[p][i] * V[p][j]; the host says which of (src0, dy) is U
+// and the tile is written through (so_i, so_j) strides, i.e. transposed when U is the `dy` argument.
+//   waves 2 (i) x 4 (j): wave tile 64 x 128 = 2 x 4 MFMA tiles (128 accumulator VGPRs); 16-position tiles (one k-step), two LDS
+//   stages (2 x 22 KB); tile t+1 is converted + stored while tile t is multiplied, and the loads of tiles t+2 .. t+4 are in flight in
+//   three rotating register sets (120 KB per CU) -- a loaded tile takes ~2.5 us to arrive and nothing else hides that with one
+//   workgroup per CU; one barrier per tile.
+struct WideArgs {
+    const float* U; const float* V;       // [P][ldu], [P][ldv] fp32
+    long long ldu, ldv;
+    int Ru;                                // channels of U (a multiple of 128); V has 512
+    long long P;
+    int tiles_per_split;
+    float* part;                           // [nsplit][...]: element (i, j) at i * so_i + j * so_j, slices part_stride apart
+    long long so_i, so_j, part_stride;
+    const float* scale;                    // scale[0] multiplies the gradient operand (U when grad_is_u, else V)
+    int grad_is_u;
+    unsigned* amax_part;                   // optional: [z][i-tiles] (grad_is_u) or [z] (else: written by the i-tile 0 workgroups)
+    float* possum;                         // optional: position sums of src0's channels: [z][channels of src0]
+    int possum_is_u;                       // src0 is U (its 128 channels of this tile) or V (all 512, i-tile 0 only)
+    int possum_stride;                     // channels of src0
+};
+
+__global__ void __launch_bounds__(512) wgrad_wide_f16_kernel(WideArgs g) {
+    constexpr int PM = 2, BI = 128, BJ = 512, WP = 16;   // WP positions per tile = one MFMA k-step
+    constexpr int LDA = BI + 32, LDB = BJ + 32;          // 80 / 272 dwords per position row: both = 16 (mod 64)
+    extern __shared__ __attribute__((aligned(16))) u16 wsm[];
+    u16* As0 = wsm;                                      // [2][WP * LDA]
+    u16* Bs0 = wsm + 2 * WP * LDA;                       // [2][WP * LDB]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 2, wn = wid & 3;
+    const int i0 = blockIdx.x * BI;
+    // tile rows: A (U): pos = tid / 32 (16 rows x 32 quads); B (V): pos = tid / 128 + 4 i (4 rows per pass x 128 quads)
+    long long nkt = g.P / WP;                            // (host: P % 16 == 0)
+    const long long kt_begin = (long long)blockIdx.y * g.tiles_per_split;
+    if (nkt > kt_begin + g.tiles_per_split) nkt = kt_begin + g.tiles_per_split;
+    const int nt = nkt > kt_begin ? (int)(nkt - kt_begin) : 0;
+    // running load pointers: tiles are loaded strictly in order (0, 1, 2, ...), each load advances them by one tile
+    const float* __restrict__ up = g.U + i0 + (tid & 31) * 4 + (kt_begin * WP + (tid >> 5)) * g.ldu;
+    const float* __restrict__ vp = g.V + (tid & 127) * 4 + (kt_begin * WP + (tid >> 7)) * g.ldv;
+    const long long ustep = WP * g.ldu, v4 = 4 * g.ldv;
+
+    // three register sets: the loads of tiles t+2, t+3, t+4 are in flight while tile t is multiplied (a workgroup per CU: nothing
+    // else hides the ~2.5 us a loaded tile takes to arrive)
+    float4 ra[3], rb[3][4];
+#define WW_LOAD(S, t_)                                                                                               \
+    {                                                                                                                \
+        ra[S] = *reinterpret_cast<const float4*>(up);                                                                \
+        up += ustep;                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) { rb[S][i] = *reinterpret_cast<const float4*>(vp); vp += v4; } \
+    }
+    const float sc_a = (g.scale && g.grad_is_u) ? g.scale[0] : 1.0f;
+    const float sc_b = (g.scale && !g.grad_is_u) ? g.scale[0] : 1.0f;
+    const bool psum_u = g.possum != nullptr && g.possum_is_u;
+    const bool psum_v = g.possum != nullptr && !g.possum_is_u && blockIdx.x == 0;
+    const bool amax_u = g.amax_part != nullptr && g.grad_is_u;
+    const bool amax_v = g.amax_part != nullptr && !g.grad_is_u && blockIdx.x == 0;
+    float4 ps = make_float4(0.f, 0.f, 0.f, 0.f);        // position sums: of this thread's U quad (psum_u) or V quad (psum_v), never both
+    float amxf = 0.f;
+    const int a_st = (tid >> 5) * LDA + (tid & 31) * 4;
+    const int b_st = (tid >> 7) * LDB + (tid & 127) * 4;
+#define WW_STORE(S, stage_)                                                                                          \
+    {                                                                                                                \
+        if (psum_u) { ps.x += ra[S].x; ps.y += ra[S].y; ps.z += ra[S].z; ps.w += ra[S].w; }                          \
+        if (psum_v) {                                                                                                \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) { ps.x += rb[S][i].x; ps.y += rb[S][i].y; ps.z += rb[S][i].z; ps.w += rb[S][i].w; } \
+        }                                                                                                            \
+        if (amax_u) amxf = fmaxf(fmaxf(amxf, fabsf(ra[S].x)), fmaxf(fmaxf(fabsf(ra[S].y), fabsf(ra[S].z)), fabsf(ra[S].w))); \
+        if (amax_v) {                                                                                                \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
+                amxf = fmaxf(fmaxf(amxf, fabsf(rb[S][i].x)), fmaxf(fmaxf(fabsf(rb[S][i].y), fabsf(rb[S][i].z)), fabsf(rb[S][i].w))); \
+        }                                                                                                            \
+        u16* as_ = As0 + (stage_) * WP * LDA;                                                                        \
+        u16* bs_ = Bs0 + (stage_) * WP * LDB;                                                                        \
+        uint2 p_;                                                                                                    \
+        p_.x = pack_bf16_2<PM>(ra[S].x * sc_a, ra[S].y * sc_a); p_.y = pack_bf16_2<PM>(ra[S].z * sc_a, ra[S].w * sc_a); \
+        *reinterpret_cast<uint2*>(&as_[a_st]) = p_;                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                               \
+            uint2 q_;                                                                                                \
+            q_.x = pack_bf16_2<PM>(rb[S][i].x * sc_b, rb[S][i].y * sc_b); q_.y = pack_bf16_2<PM>(rb[S][i].z * sc_b, rb[S][i].w * sc_b); \
+            *reinterpret_cast<uint2*>(&bs_[b_st + 4 * i * LDB]) = q_;                                                \
+        }                                                                                                            \
+    }
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int gq = lane >> 4, t16 = lane & 15;
+    const int f_pos = 8 * (gq >> 1) + (t16 >> 2);
+    const int f_ch = 16 * (gq & 1) + 4 * (t16 & 3);
+    const int a_lane = f_pos * LDA + wm * 64 + f_ch;
+    const int b_lane = f_pos * LDB + wn * 128 + f_ch;
+
+    // one step: tile t is multiplied out of LDS stage t & 1; tile t+1 (register set S1 = (t+1) % 3) is converted into the other
+    // stage and that set is refilled with tile t+4
+#define WW_STEP(t_, S1)                                                                                              \
+    {                                                                                                                \
+        const int tt_ = (t_);                                                                                        \
+        if (tt_ < nt) {                                                                                              \
+            const int cur_ = tt_ & 1;                                                                                \
+            if (tt_ + 1 < nt) WW_STORE(S1, cur_ ^ 1)                                                                 \
+            if (tt_ + 4 < nt) WW_LOAD(S1, tt_ + 4)                                                                   \
+            const u16* at_ = As0 + cur_ * WP * LDA + a_lane;                                                         \
+            const u16* bt_ = Bs0 + cur_ * WP * LDB + b_lane;                                                         \
+            union { unsigned long long u[2]; bf16x8 v; } fa_[2], fb_[4];                                             \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                           \
+                fa_[i].u[0] = wl_tr16(at_ + i * 32);                                                                 \
+                fa_[i].u[1] = wl_tr16(at_ + 4 * LDA + i * 32);                                                       \
+            }                                                                                                        \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
+                fb_[j].u[0] = wl_tr16(bt_ + j * 32);                                                                 \
+                fb_[j].u[1] = wl_tr16(bt_ + 4 * LDB + j * 32);                                                       \
+            }                                                                                                        \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                             \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = wg_mfma<PM>(fa_[i].v, fb_[j].v, acc[i][j]);     \
+            __syncthreads();                                                                                         \
+        }                                                                                                            \
+    }
+    if (nt > 0) {
+        WW_LOAD(0, 0)
+        WW_STORE(0, 0)
+        if (nt > 1) WW_LOAD(1, 1)
+        if (nt > 2) WW_LOAD(2, 2)
+        if (nt > 3) WW_LOAD(0, 3)
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < nt; t += 3) {
+        WW_STEP(t, 1)
+        WW_STEP(t + 1, 2)
+        WW_STEP(t + 2, 0)
+    }
+#undef WW_LOAD
+#undef WW_STORE
+#undef WW_STEP
+
+    if (amax_u || amax_v) {                   // (uniform per workgroup)
+        __shared__ unsigned wamx[8];
+        unsigned amx = __float_as_uint(amxf);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o, 64));
+        if (lane == 0) wamx[wid] = amx;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned m = 0;
+            for (int w = 0; w < 8; ++w) m = max(m, wamx[w]);
+            if (amax_u) g.amax_part[(long long)blockIdx.y * gridDim.x + blockIdx.x] = m;
+            else g.amax_part[blockIdx.y] = m;
+        }
+    }
+    if (psum_u || psum_v) {
+        // fixed-order fold over the position lanes of a channel quad (the loop's last barrier freed the stages)
+        float4* red = reinterpret_cast<float4*>(wsm);       // 512 float4 = 8 KB
+        __syncthreads();
+        red[tid] = ps;
+        __syncthreads();
+        if (psum_u && tid < 32) {
+            float4 a = red[tid];
+#pragma unroll
+            for (int j = 1; j < 16; ++j) { const float4 b = red[tid + 32 * j]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+            *reinterpret_cast<float4*>(g.possum + (long long)blockIdx.y * g.possum_stride + i0 + tid * 4) = a;
+        }
+        if (psum_v && tid < 128) {
+            float4 a = red[tid];
+#pragma unroll
+            for (int j = 1; j < 4; ++j) { const float4 b = red[tid + 128 * j]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+            *reinterpret_cast<float4*>(g.possum + (long long)blockIdx.y * g.possum_stride + tid * 4) = a;
+        }
+    }
+    float* __restrict__ C = g.part + (long long)blockIdx.y * g.part_stride;
+    if (g.so_i == 1) {
+        // transposed tile (U is the `dy` argument): the 4 consecutive i of an accumulator register quad are contiguous in memory
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long long jn = wn * 128 + j * 32 + (lane & 31);
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const long long im = i0 + wm * 64 + i * 32 + 8 * r4 + 4 * (lane >> 5);
+                    *reinterpret_cast<float4*>(C + jn * g.so_j + im) =
+                        make_float4(acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2], acc[i][j][4 * r4 + 3]);
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long jn = wn * 128 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long im = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                C[im * g.so_i + jn] = acc[i][j][r];
+            }
+        }
+}
+
 }  // namespace
 
 static int g_wg_bm256 = 0;        // experiment knob (vxb_debug_set_wgrad_bm256): 256-row tiles for the fp16 products.  Measured (round 3, linear_bwd
                                   // at M = 32768, N x K = 4096x512 / 512x2048 / 1024x512): 0.548 / 0.271 / 0.149 ms against 0.491 / 0.239 / 0.128 ms
                                   // with 128-row tiles -- a quarter fewer LDS fragment reads per MFMA, but half the workgroups and 176 VGPRs: OFF
+
+static int g_wg_lin = 2;          // plain-GEMM form of the fp16 products: 2 = wide kernel where it applies, else the pipelined 128^2 one;
+                                  // 1 = pipelined 128^2 only; 0 = the generic kernel (vxb_debug_set_wgrad_lin: A/B switch)
 
 static int wgrad_bf16_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                           int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
@@ -382,10 +773,37 @@ static int wgrad_bf16_impl(int x3, const float* src0, const float* src1, int C0,
     g.tiles_per_split = (int)((nkt + nsplit - 1) / nsplit);
     hipStream_t st = (hipStream_t)stream;
     int nblk;
+    const bool plain = S_in == 1 && S_out == 1 && kext == 1 && off == 0 && C1 == 0 && d2s_s <= 0 && stride == 1;
+    if (x3 == 2 && plain && g_wg_lin >= 2 && !(((uintptr_t)src0 | (uintptr_t)dy) & 15)) {
+        // wide form: the operand with exactly 512 channels is V (see wgrad_wide_f16_kernel); ops.wide_wgrad_tiles mirrors this test
+        const bool c1 = N == 512 && K >= 128 && (K & 127) == 0;
+        const bool c2 = !c1 && K == 512 && N >= 128 && (N & 127) == 0;
+        if ((c1 || c2) && (g.P & 15) == 0) {
+            WideArgs w;
+            w.U = c1 ? src0 : dy; w.V = c1 ? dy : src0;
+            w.ldu = c1 ? C0 : ldy; w.ldv = c1 ? ldy : C0;
+            w.Ru = c1 ? (int)K : N;
+            w.P = g.P; w.tiles_per_split = (int)((g.P / 16 + nsplit - 1) / nsplit);
+            w.part = part; w.part_stride = K * N;
+            w.so_i = c1 ? N : 1; w.so_j = c1 ? 1 : N;
+            w.scale = scale; w.grad_is_u = c1 ? grad_is_src0 : !grad_is_src0;
+            w.amax_part = g.amax_part; w.possum = possum; w.possum_is_u = c1 ? 1 : 0; w.possum_stride = (int)K;
+            const size_t lds = (size_t)2 * 16 * (160 + 544) * sizeof(u16);
+            if (hipFuncSetAttribute((const void*)wgrad_wide_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return VXB_ELAUNCH;
+            const int tiles_i = w.Ru / 128;
+            hipLaunchKernelGGL(wgrad_wide_f16_kernel, dim3(tiles_i, nsplit), dim3(512), lds, st, w);
+            VXB_CHECK_LAUNCH();
+            if (g.amax_part) return vxb_absmax_finish_launch(g.amax_part, (w.grad_is_u ? tiles_i : 1) * nsplit, next_scale, st, 5);
+            return VXB_OK;
+        }
+    }
     if (N > 64) {
         dim3 grid(vxb_cdiv(N, 128), vxb_cdiv(K, 128), nsplit);
         nblk = grad_is_src0 ? grid.y : grid.x;
-        if (x3 == 2 && K >= 512 && g_wg_bm256) {
+        if (x3 == 2 && plain && g_wg_lin) {
+            hipLaunchKernelGGL((wgrad_lin_f16_kernel<128>), grid, dim3(256), 0, st, g);
+        } else if (x3 == 2 && K >= 512 && g_wg_bm256) {
             grid.y = vxb_cdiv(K, 256);
             nblk = grad_is_src0 ? grid.y : grid.x;
             hipLaunchKernelGGL((wgrad_bf16_kernel<128, 2, 256>), grid, dim3(256), 0, st, g);
@@ -395,7 +813,8 @@ static int wgrad_bf16_impl(int x3, const float* src0, const float* src1, int C0,
     } else {
         dim3 grid(vxb_cdiv(N, 64), vxb_cdiv(K, 128), nsplit);
         nblk = grad_is_src0 ? grid.y : grid.x;
-        if (x3 == 2) hipLaunchKernelGGL((wgrad_bf16_kernel<64, 2>), grid, dim3(256), 0, st, g);
+        if (x3 == 2 && plain && g_wg_lin) hipLaunchKernelGGL((wgrad_lin_f16_kernel<64>), grid, dim3(256), 0, st, g);
+        else if (x3 == 2) hipLaunchKernelGGL((wgrad_bf16_kernel<64, 2>), grid, dim3(256), 0, st, g);
         else if (x3) hipLaunchKernelGGL((wgrad_bf16_kernel<64, 1>), grid, dim3(256), 0, st, g);
         else hipLaunchKernelGGL((wgrad_bf16_kernel<64, 0>), grid, dim3(256), 0, st, g);
     }
@@ -413,6 +832,7 @@ extern "C" size_t vxb_conv3d_wgrad_f16_amax_words(int C0, int C1, int kext, int 
     return (size_t)nsplit * (size_t)(grad_is_src0 ? vxb_cdiv(K, 128) : vxb_cdiv(N, bn));
 }
 extern "C" void vxb_debug_set_wgrad_bm256(int on) { g_wg_bm256 = on ? 1 : 0; }
+extern "C" void vxb_debug_set_wgrad_lin(int mode) { g_wg_lin = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
 
 // ONE fp16 product per term (fp32 accumulate), same contract and `part` layout as the entries below.  The GRADIENT operand (src0 when
 // grad_is_src0 != 0 -- the plain-GEMM form of a linear layer's weight gradient, src0 = its dY -- else dy) is multiplied by scale[0]

@@ -194,6 +194,10 @@ def linear_bwd(x, W, dy, dW, db=None, dx=None, dx_accumulate=False, ws=None):
         if _mm() and dW.is_contiguous() and dy.stride(0) == N:
             # both operands are row(position)-major -> the transposed-read bf16 kernel (a 1x1x1 "conv" over M positions)
             nsb = max(1, min(64, (512 + tiles - 1) // tiles, M // 256))
+            wt = wide_wgrad_tiles(N, K)
+            if wt and WGRAD_PRECISION == 'fp16' and GENERIC_WGRAD_F16 and M >= 1024:
+                # the wide kernel's workgroups own 128 x 512 tiles, one per CU: slices so that tiles x slices fills the 256 CUs once
+                nsb = max(1, min(64, int(os.environ.get('VOXACTB_WIDE_WGS', 256)) // wt, M // 1024))
             res = conv3d_wgrad(dy, x, K, M, 1, 1, 1, 0, ldy=x.stride(0), nsplit=nsb, label='gemm_wgrad %dx%dx%d' % (N, K, M),
                                possum_into=db, grad_key=('lin', W.data_ptr()) if M >= 1024 else None, grad_is_src0=True)
             axpy_(dW, res)
@@ -213,6 +217,16 @@ def linear_bwd(x, W, dy, dW, db=None, dx=None, dx_accumulate=False, ws=None):
                  label='gemm_dgrad %dx%dx%d' % (M, K, N))
     if db is not None:
         colsum(dy, db, accumulate=True)
+
+
+def wide_wgrad_tiles(R, N):
+    """row tiles of the wide fp16 weight-gradient kernel (wgrad_bf16.hip: one operand with exactly 512 channels, the other a
+    multiple of 128) for part [R][N], 0 where it does not apply -- mirrors the test in wgrad_bf16_impl."""
+    if N == 512 and R >= 128 and R % 128 == 0:
+        return R // 128
+    if R == 512 and N >= 128 and N % 128 == 0:
+        return N // 128
+    return 0
 
 
 def colsum(x, out, accumulate=False):
