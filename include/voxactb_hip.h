@@ -253,6 +253,13 @@ int vxb_conv3_wgrad_halo_f16_f32(const float* src0, const float* src1, int C0, i
                                  int off, int replicate, const float* dy, int N, int64_t ldy, int d2s_s, int d2s_C,
                                  float* part, int nsplit, const uint32_t* phase_mask, const float* dy_scale,
                                  vxb_stream_t stream);
+/* ... of a 5x5x5 stride-1 conv (first conv of the decoder's up-block: network_utils.py:236-244, perceiver_lang_io.py:381-389) on the
+ * same kernel: the 125 taps as eight shifted 3x3x3 blocks in one launch.  shift_rows: device int32 [8][27] = the row block
+ * (kd * 5 + kh) * 5 + kw of every (shift, tap), -1 where the tap belongs to another shift (shift bit 4 / 2 / 1 set: the block of
+ * axis d / h / w covers the offsets {0, +1, +2} and owns the last two; clear: {-2, -1, 0}).  part [nsplit][125 * (C0 + C1)][N]. */
+int vxb_conv3_wgrad_halo5_f16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S, int off, int replicate,
+                                  const float* dy, int N, int64_t ldy, float* part, int nsplit, const int32_t* shift_rows,
+                                  const float* dy_scale, vxb_stream_t stream);
 size_t vxb_conv3_wgrad_halo_tiles(int B, int S_out, int x3);
 /* bf16 matrix-core weight gradient (same contract as vxb_conv3d_wgrad_f32): both operands are staged position-major and
  * transposed for the matrix cores by ds_read_b64_tr_b16.  possum (optional; plain GEMM form only: kext = S_in = S_out = 1, one

@@ -116,6 +116,30 @@ def test_wgrad_halo_fp16_depth_to_space_tap_masks_and_saturation():
     assert bool(torch.isfinite(big).all())
 
 
+@pytest.mark.parametrize('C0,C1,N,S,gain', [(128, 0, 64, 20, 1.0), (32, 32, 64, 17, 3e-9), (16, 0, 128, 16, 4e6)])
+def test_wgrad_k5_as_shifted_blocks_fp16_matches_fp64(C0, C1, N, S, gain):
+    """5x5x5 stride-1 weight gradient as eight shifted 3x3x3 blocks of the LDS-halo kernel (vxb_conv3_wgrad_halo5_f16_f32):
+    every one of the 125 taps against F.conv3d's float64 autograd on the replicate-padded input (pad 2), ragged grids, two
+    sources, tiny / huge gradients; and against the generic gather kernel (bf16x3) it replaces."""
+    B = 2
+    a, c = rnd(B, C0, S, S, S), (rnd(B, C1, S, S, S, seed=5) if C1 else None)
+    dy = rnd(B, N, S, S, S, seed=3) * gain
+    dy[0, :, 0, 0, 0] *= 50.0
+    xin = torch.cat([a, c], 1) if C1 else a
+    W = torch.zeros(N, C0 + C1, 5, 5, 5, dtype=torch.float64, requires_grad=True)
+    F.conv3d(F.pad(xin.double(), (2,) * 6, mode='replicate'), W).backward(dy.double())
+    ref = ops.conv_weight_fwd(W.grad.float())
+    args = (cl(a).to(DEV), cl(dy).to(DEV), N, B, S, S, 5, -2)
+    kw = dict(src1=cl(c).to(DEV) if C1 else None, force_bf16='bf16x3')
+    got = _f16(lambda: ops.conv3d_wgrad(*args, **kw))
+    assert got.shape == ref.shape
+    err = float((got.cpu() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 4e-4, err
+    gen = ops.conv3d_wgrad(*args, **kw)                      # (WGRAD_PRECISION is not 'fp16' here: the generic bf16x3 kernel)
+    assert float((gen.cpu() - ref).abs().max()) / float(ref.abs().max()) < 3e-5
+    assert float((got - gen).abs().max()) / float(ref.abs().max()) < 4e-4
+
+
 def test_absmax_scale():
     for n, val in ((5, 3.0), (1 << 20, 1e-7), (12345, 7e5), (64, 0.0)):
         x = torch.rand(n, device=DEV) * val

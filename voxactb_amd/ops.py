@@ -391,6 +391,25 @@ def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
         out = torch.empty((K, N), dtype=torch.float32, device=src0.device)
         sum_splits(part, ns, K * N, out)
         return out
+    if (HALO_CONV and K5_HALO_WGRAD and mode == 'bf16x3' and WGRAD_PRECISION == 'fp16' and kext == 5 and stride == 1 and S_in == S_out
+            and S_out >= 16 and C0 % 16 == 0 and C1 % 16 == 0 and N % 64 == 0 and d2s[0] == 0 and dy.is_contiguous()
+            and (ldy is None or ldy == N)):
+        # 5^3 taps as eight shifted 3^3 blocks on the LDS-halo kernel, one launch (wgrad_halo.hip: vxb_conv3_wgrad_halo5_f16_f32)
+        blocks = 8 * max(1, (C0 + C1) // 32) * (N // 64)
+        ntiles = int(_lib.lib().vxb_conv3_wgrad_halo_tiles(B, S_out, 1))
+        ns = nsplit if nsplit is not None else max(1, min(64, (512 + blocks - 1) // blocks, ntiles // 8))
+        part = torch.empty((ns, K, N), dtype=torch.float32, device=src0.device)
+        lbl = label or 'conv3d_wgrad[k%d s%d %d->%d S%d]' % (kext, stride, C0 + C1, N, S_out)
+        sc = dy_scale
+        if sc is None:
+            _lib.set_meta(lbl, 0.0)
+            sc = absmax_scale(dy)
+        _lib.set_meta(lbl, 2.0 * P * N * K)
+        call('vxb_conv3_wgrad_halo5_f16_f32', src0, src1, C0, C1, B, S_out, off, int(replicate), dy, N, N, part, ns,
+             k5_shift_rows(src0.device), sc)
+        out = torch.empty((K, N), dtype=torch.float32, device=src0.device)
+        sum_splits(part, ns, K * N, out, alpha=sc[1:])
+        return out
     if nsplit is None:
         tiles = ((K + 127) // 128) * ((N + 127) // 128 if N > 64 else 1)
         nsplit = max(1, min(64, 1024 // max(tiles, 1), (P + 4095) // 4096))
@@ -434,6 +453,33 @@ def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
     out = torch.empty((K, N), dtype=torch.float32, device=src0.device)
     sum_splits(part, nsplit, K * N, out)
     return out
+
+
+K5_HALO_WGRAD = True      # 5^3 stride-1 weight gradients on the LDS-halo kernel (eight shifted 3^3 blocks); False: generic gather kernel
+_K5_ROWS = {}
+
+
+def k5_shift_rows(dev):
+    """int32 [8][27]: row block (kd * 5 + kh) * 5 + kw of (shift, 3^3 tap), -1 where the tap belongs to another shift
+    (include/voxactb_hip.h: vxb_conv3_wgrad_halo5_f16_f32)."""
+    t = _K5_ROWS.get(dev)
+    if t is None:
+        rows = np.full((8, 27), -1, dtype=np.int32)
+        for sh in range(8):
+            bits = ((sh >> 2) & 1, (sh >> 1) & 1, sh & 1)
+            for tap in range(27):
+                loc = (tap // 9, (tap // 3) % 3, tap % 3)
+                g = []
+                for b, l in zip(bits, loc):
+                    if b and l == 0:          # offset 0 belongs to the block without the shift
+                        g = None
+                        break
+                    g.append(l + 2 * b)       # offsets {-2, -1, 0} -> 0..2; {+1, +2} -> 3..4
+                if g is not None:
+                    rows[sh, tap] = (g[0] * 5 + g[1]) * 5 + g[2]
+        assert sorted(rows[rows >= 0].tolist()) == list(range(125))
+        t = _K5_ROWS[dev] = torch.from_numpy(rows).to(dev)
+    return t
 
 
 def fold_pad(src, Sp, Cs, c0, dst, B, S, C, pad, accumulate=False, lrelu_of=None):
