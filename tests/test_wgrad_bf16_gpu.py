@@ -91,3 +91,30 @@ def test_generic_weight_gradients_on_single_fp16_products_with_delayed_scaling()
         assert float((got - want).abs().max()) < 1e-3 * float(want.abs().max()) and torch.equal(got, got2)
     finally:
         ops.PRECISION, ops.WGRAD_PRECISION, ops.GENERIC_WGRAD_F16, ops._GRAD_SCALE = 'fp32', '', False, {}
+
+
+@pytest.mark.parametrize('M,N,K', [(4096, 512, 1024), (2048, 512, 512), (4096, 1024, 512), (2048 + 8, 512, 1024), (4096, 384, 128)])
+def test_linear_weight_gradient_fp16_wide_and_pipelined_kernels(M, N, K):
+    """The plain-GEMM forms of the fp16 weight gradient (wgrad_bf16.hip): wide 128 x 512 tiles when one side has 512 channels --
+    with the wide operand as `dy` argument (transposed store, bias sums and gradient maximum taken from the narrow operand: N = 512,
+    K = 1024) or as src0 (N = 1024, K = 512) --, the pipelined 128 x 128 kernel otherwise (M % 16 != 0, no 512 side); each against
+    float64 and against the generic kernel (vxb_debug_set_wgrad_lin(0)), bias gradients exact, second call on the delayed scale."""
+    from .test_ops_gpu import rnd, DEV
+    from voxactb_amd import _lib
+    x, W = rnd(M, K).to(DEV), rnd(N, K, seed=1).to(DEV)
+    dy = rnd(M, N, seed=2).to(DEV) * 3e-4
+    ref = dy.double().t() @ x.double()
+    ops.PRECISION, ops.WGRAD_PRECISION, ops.GENERIC_WGRAD_F16, ops._GRAD_SCALE = 'bf16x3', 'fp16', True, {}
+    try:
+        outs = []
+        for mode in (2, 2, 0):                  # first call: explicit scale; second: the scale the first launch reported; then the generic kernel
+            _lib.lib().vxb_debug_set_wgrad_lin(mode)
+            dW, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+            ops.linear_bwd(x, W, dy, dW, db, None)
+            assert float((dW.double() - ref).abs().max() / ref.abs().max()) < 1e-3
+            assert float((db.double() - dy.double().sum(0)).abs().max()) < 1e-4 * float(dy.double().sum(0).abs().max())
+            outs.append(dW)
+        assert float((outs[0] - outs[2]).abs().max()) < 1e-3 * float(ref.abs().max())
+    finally:
+        _lib.lib().vxb_debug_set_wgrad_lin(2)
+        ops.PRECISION, ops.WGRAD_PRECISION, ops.GENERIC_WGRAD_F16, ops._GRAD_SCALE = 'fp32', '', False, {}
