@@ -55,7 +55,9 @@ __device__ __forceinline__ void dl_load16(const u16* src, u16* lds_wave_base) {
 // register sets -- no weight traffic through LDS.  With both operands in LDS the 2x2-tile waves of the x3 kernel need
 // 16 ds_read_b128 + 8 KB of direct loads per 24 MFMAs, which saturates the CU's 128 B/clk; the B half of that moves to
 // the L1/L2 path (weights are shared by every workgroup) and the A stages shrink to 16 KB.
-template <int AMODE, int X3, int BD>
+// TN = 32-column MFMA tiles per wave: 2 (128-column workgroup tiles) or, BD only, 1 (64-column tiles for N <= 64: the 5^3 conv of the
+// decoder's up-block has 64 output channels, and half of a 128-column tile's MFMAs would multiply zero padding)
+template <int AMODE, int X3, int BD, int TN = 2>
 __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     constexpr int NPL = 1 + X3;
@@ -74,7 +76,8 @@ __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
         tile_x = lid2 % gx;
         tile_y = lid2 / gx;
     }
-    const int m0 = tile_y * 128, n0 = tile_x * 128;
+    constexpr int BN = 64 * TN;
+    const int m0 = tile_y * 128, n0 = tile_x * BN;
 
     // ---- load slots of this lane: instruction (wid, i) fills rows (2 wid + i) * 16 .. +15; lane -> row + (lane >> 2),
     //      destination chunk position lane & 3, i.e. source chunk (lane & 3) ^ ((row >> 2) & 3)
@@ -162,11 +165,11 @@ __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -175,7 +178,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
     int fa[2], fb[2], fx[2];                    // row * 32 u16 base and the row's swizzle key, per 32-row tile
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int ra = wm * 64 + t * 32 + lm, rb = wn * 64 + t * 32 + lm;
+        const int ra = wm * 64 + t * 32 + lm, rb = wn * (32 * TN) + t * 32 + lm;
         fa[t] = ra * 32; fb[t] = rb * 32;
         fx[t] = (lm >> 2) & 3;                  // (row >> 2) & 3: the tile bases are multiples of 32, so only lm matters
     }
@@ -183,15 +186,15 @@ __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
     const int nkt = masked ? __builtin_popcount(it_rem) * (g.Cin >> 5) : g.K / 32;
     if (BD) {
         // B fragments of tile t (32 columns), k-step ks, plane p: 1 KB at ((ntile * K/16 + k0/16 + ks) * NPL + p) * 512 + lane * 8
-        bf16x8 b0[2][2][NPL], b1[2][2][NPL];
+        bf16x8 b0[TN][2][NPL], b1[TN][2][NPL];
         const long long nks = g.K >> 4;
-        const u16* bfb = g.Bfrag + ((long long)((n0 + wn * 64) >> 5) * nks * NPL) * 512 + lane * 8;
+        const u16* bfb = g.Bfrag + ((long long)((n0 + wn * (32 * TN)) >> 5) * nks * NPL) * 512 + lane * 8;
         // The fragment loads are inline asm on purpose: the compiler's waitcnt pass cannot count register loads and
         // direct-to-LDS loads on one in-order counter and drains vmcnt to 0 before the first use of a loaded register --
         // i.e. it would wait for the A tiles deliberately left in flight.  Hidden from it, the loads are covered by the
         // hand-placed s_waitcnt at the top of the next k-tile (they are issued BEFORE that tile's direct loads).
 #define DL_LOADB(SET, k0_)                                                                                            \
-        _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                \
+        _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                                               \
             const u16* bp_ = bfb + (((long long)t * nks + ((k0_) >> 4)) * NPL) * 512;                                  \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                           \
             _Pragma("unroll") for (int p = 0; p < NPL; ++p)                                                            \
@@ -206,7 +209,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
             if (kt + 1 < nkt) { if (X3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); } \
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
             /* tie the fragments to the wait: the compiler must not move an MFMA that reads them above it */          \
-            _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                              \
+            _Pragma("unroll") for (int t = 0; t < TN; ++t)                                                             \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                           \
             _Pragma("unroll") for (int p = 0; p < NPL; ++p) asm volatile("" : "+v"(CUR[t][ks][p]));                    \
             vxb_raw_barrier();                                                                                        \
@@ -222,14 +225,14 @@ __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
                 }                                                                                                     \
                 if (X3) {                                                                                             \
                     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                      \
-                    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
+                    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                      \
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], CUR[j][ks][0], acc[i][j], 0, 0, 0); \
                     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                      \
-                    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
+                    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                      \
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], CUR[j][ks][NPL - 1], acc[i][j], 0, 0, 0); \
                 }                                                                                                     \
                 _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                          \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], CUR[j][ks][0], acc[i][j], 0, 0, 0);     \
             }                                                                                                         \
             k0_next = k0_issued;                                                                                      \
@@ -270,16 +273,16 @@ __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
 
@@ -292,12 +295,12 @@ __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
         // both are decoded once per row / per column tile, the row with multiply-high divisions (host-checked range)
         const int s = g.d2s_s, G = g.d2s_G, Cc = g.d2s_C;
         const long long Vv = (long long)G * s;
-        long long coloff[2];
-        float bsv[2];
-        bool cok[2];
+        long long coloff[TN];
+        float bsv[TN];
+        bool cok[TN];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (32 * TN) + j * 32 + (lane & 31);
             cok[j] = n < g.N;
             const int nn = cok[j] ? n : 0;
             int ph = nn / Cc;
@@ -322,7 +325,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
                 const int qw = m - q1 * G, qh = q1 - q2 * G, qd = q2 - q3 * G;
                 const long long rowoff = ((((long long)q3 * Vv + qd * s) * Vv + qh * s) * Vv + qw * s) * Cc;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < TN; ++j) {
                     if (!cok[j]) continue;
                     float v = acc[i][j][r] + bsv[j];
                     if (g.act == 1) v = v > 0.f ? v : v * g.slope;
@@ -338,8 +341,8 @@ __global__ void __launch_bounds__(256, 2) gemm_dl_kernel(DlArgs g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (32 * TN) + j * 32 + (lane & 31);
             if (n >= g.N) continue;
             const float bsv = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
@@ -418,18 +421,20 @@ __global__ void __launch_bounds__(256) split_batch_kernel(const SplitDesc* __res
     }
 }
 
-template <int AMODE, int X3, int BD>
+template <int AMODE, int X3, int BD, int TN = 2>
 int dl_launch2(const DlArgs& g, hipStream_t st) {
-    const dim3 grid(vxb_cdiv(g.N, 128), vxb_cdiv(g.M, 128));
+    const dim3 grid(vxb_cdiv(g.N, 64 * TN), vxb_cdiv(g.M, 128));
     const size_t lds = (size_t)(BD ? 3 : 2 * 2) * (1 + X3) * DTILE * sizeof(u16);     // BD: three A stages; else 2 x (A + B)
     if (lds > 48 * 1024 &&
-        hipFuncSetAttribute((const void*)gemm_dl_kernel<AMODE, X3, BD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
-    hipLaunchKernelGGL((gemm_dl_kernel<AMODE, X3, BD>), grid, dim3(256), lds, st, g);
+        hipFuncSetAttribute((const void*)gemm_dl_kernel<AMODE, X3, BD, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
+    hipLaunchKernelGGL((gemm_dl_kernel<AMODE, X3, BD, TN>), grid, dim3(256), lds, st, g);
     return hipGetLastError() == hipSuccess ? VXB_OK : VXB_ELAUNCH;
 }
 
 template <int AMODE>
 int dl_launch(const DlArgs& g, int x3, hipStream_t st) {
+    // N <= 64 with weight fragments, no depth-to-space store, no tap mask: 64-column tiles (no MFMAs on zero-padded columns)
+    if (g.Bfrag && x3 && g.N <= 64 && g.d2s_s <= 0 && !g.tapmask) return dl_launch2<AMODE, 1, 1, 1>(g, st);
     if (g.Bfrag) return x3 ? dl_launch2<AMODE, 1, 1>(g, st) : dl_launch2<AMODE, 0, 1>(g, st);
     return x3 ? dl_launch2<AMODE, 1, 0>(g, st) : dl_launch2<AMODE, 0, 0>(g, st);
 }
