@@ -334,7 +334,7 @@ int vxb_ss3d_max_bwd_f32(const float* x, int64_t bs, int B, int S, int C, const 
                          const float* out_ss, const int32_t* argmax, const float* g_ss, const float* g_max,
                          float* dx, int64_t dbs, int accumulate, vxb_stream_t stream);
 
-/* PreNorm LayerNorm (perceiver_lang_io.py:56-71), eps 1e-5.  bwd: dgamma/dbeta ACCUMULATED. */
+/* PreNorm LayerNorm (perceiver_lang_io.py:56-71), eps 1e-5.  bwd: dgamma/dbeta ACCUMULATED; part_ws: ceil(rows / 32) * 2 * D floats. */
 int vxb_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                           float* rstd, int64_t rows, int D, float eps, vxb_stream_t stream);
 int vxb_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean,

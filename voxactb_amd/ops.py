@@ -265,7 +265,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_d
     rows, D = x.shape
     if dx is None:
         dx = torch.empty_like(x)
-    nblk = (rows + 63) // 64
+    nblk = (rows + 31) // 32
     ws = torch.empty(nblk * 2 * D + 2 * D, dtype=torch.float32, device=x.device)
     call('vxb_layernorm_bwd_f32', dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, rows, D, int(accumulate_dx))
     return dx
