@@ -59,6 +59,7 @@ struct VxbWhArgs {
     // [out_taps][Ct][N] gradient (-1: the tap belongs to another shift and is neither computed nor stored)
     int nshift;
     const int* shift_rows;
+    int tabn;                     // fp16 variants: entries per axis of the clamp tables (max(S_in, S_out) + 16), 0 = tables not usable
 };
 typedef VxbWhArgs WhArgs;
 
@@ -162,6 +163,14 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
     // issue-bound on exactly that arithmetic (profiles/r03_v1_sq_summary.txt: 42-48 % of wave time issuing, matrix pipe 23-33 %).
     int* tabx = reinterpret_cast<int*>(smem + (1 + X3) * (NCH * XPL + DPL));      // [NXL][NTH] element offset, -1 = slot past the halo
     int* tabd = tabx + NXL * NTH;                                                  // [NDL][NTH]
+    // ... and for the tiles that DO touch the border of the grid (at S = 20 that is 66 of 75 tiles, at S = 100 a quarter): clamping and
+    // padding are separable per axis, so three small tables per operand hold  clamp(j) * stride | invalid << 31  for every coordinate
+    // j a halo / tile voxel can have, and a slot's address is the sum of three entries -- ~14 VALU instructions and 4 LDS reads per
+    // slot instead of the ~35 of issue_slow().  tabp / tabq: the (d, h, w) position of a slot inside the halo / tile, packed.
+    int* tabp = tabd + NDL * NTH;                                                  // [NXL][NTH]  pd << 27 | ph << 23 | pw << 19 | channel offset; -1 = no slot
+    int* tabq = tabp + NXL * NTH;                                                  // [NDL][NTH]  od << 27 | oh << 23 | ow << 19 | n4
+    int* axx = tabq + NDL * NTH;                                                   // [3][tabn] x: index j + 4
+    int* ayy = axx + 3 * g.tabn;                                                   // [3][tabn] dY: index j
     // all chunks of this workgroup in one source (always, unless a chunk pair straddles the concatenation point)
     const bool one_src = ((bx * NCH) * 16 >= g.C0) == ((bx * NCH + NCH - 1) * 16 >= g.C0);
     const bool src_second = (bx * NCH) * 16 >= g.C0;
@@ -189,8 +198,37 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
             const int pos = e >> 4, n4 = (e & 15) * 4;
             const int od = pos / (WTH * 8), oh = (pos >> 3) % WTH, ow = pos & 7;
             tabd[i * NTH + tid] = (int)((((long long)od * ds_ * Vf + oh * ds_) * Vf + ow * ds_) * dy_row) + n4;
+            tabq[i * NTH + tid] = (od << 27) | (oh << 23) | (ow << 19) | n4;
         }
-        // (every thread reads back only its own entries: no barrier needed)
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) {
+            const int e = tid + NTH * i;
+            const int lch = NCH == 1 ? 0 : min(e / XF4, NCH - 1);
+            const int e2 = e - lch * XF4;
+            int p = e2 >> 2;
+            const int c4 = (e2 & 3) * 4;
+            const bool ok = p < XSLOTS && e < NCH * XF4;
+            p = min(p, XSLOTS - 1);
+            const int cbl = (bx * NCH + lch) * 16;
+            const int c0 = src_second ? cbl - g.C0 : cbl;
+            const int hw = p % XW; p /= XW;
+            const int hh = p % XH; p /= XH;
+            tabp[i * NTH + tid] = ok ? ((p << 27) | (hh << 23) | (hw << 19) | (c0 + c4)) : -1;
+        }
+        if (g.tabn > 0) {
+            for (int j = tid; j < 3 * g.tabn; j += NTH) {
+                const int ax = j / g.tabn, jj = j - ax * g.tabn;
+                // x: coordinate jj - 4 (halo voxels reach from off to S + tile overhang + 1 + off)
+                const int cx = jj - 4, cc = min(max(cx, 0), Sm);
+                const int sx = ax == 0 ? g.S_in * g.S_in * Cs_f : (ax == 1 ? g.S_in * Cs_f : Cs_f);
+                axx[j] = cc * sx | ((g.replicate || cc == cx) ? 0 : (int)0x80000000);
+                // dY: coordinate jj (tile voxels reach from 0 to S + tile overhang)
+                const int cy = min(jj, S - 1);
+                const long long sy = ax == 0 ? (long long)ds_ * Vf * Vf * dy_row : (ax == 1 ? (long long)ds_ * Vf * dy_row : (long long)ds_ * dy_row);
+                ayy[j] = (int)(cy * sy) | (jj < S ? 0 : (int)0x80000000);
+            }
+        }
+        __syncthreads();           // (the axis tables are shared; tabx / tabd / tabp / tabq entries are read back only by their writer)
     }
     auto issue_fast = [&](int tile) __attribute__((always_inline)) -> bool {
         int t = tile;
@@ -221,6 +259,39 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
         }
         okm = m;
         return true;
+    };
+    auto issue_mid = [&](int tile) __attribute__((always_inline)) {
+        int t = tile;
+        const int tw = t % g.ntw; t /= g.ntw;
+        const int th = t % g.nth; t /= g.nth;
+        const int td = t % g.ntd; t /= g.ntd;
+        const int b = t;
+        const int d0 = td * WTD, h0 = th * WTH, w0 = tw * WTW;
+        const float* __restrict__ xp = src_f + (long long)b * g.S_in * g.S_in * g.S_in * Cs_f;
+        const int* ad = axx + d0 + offd + 4;
+        const int* ah = axx + g.tabn + h0 + offh + 4;
+        const int* aw = axx + 2 * g.tabn + w0 + offw + 4;
+        unsigned m = 0;
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) {
+            const int pk = tabp[i * NTH + tid];
+            const int pu = max(pk, 0);
+            const int a = ad[(pu >> 27) & 15], bb = ah[(pu >> 23) & 15], c = aw[(pu >> 19) & 15];
+            m |= (((unsigned)~(a | bb | c | pk)) >> 31) << i;
+            px[i] = *reinterpret_cast<const float4*>(xp + (((a + bb + c) & 0x7fffffff) + (pu & 0x7ffff)));
+        }
+        const float* __restrict__ dp = dyb + ((((long long)b * Vf + rd) * Vf + rh) * Vf + rw) * dy_row;
+        const int* yd = ayy + d0;
+        const int* yh = ayy + g.tabn + h0;
+        const int* yw = ayy + 2 * g.tabn + w0;
+#pragma unroll
+        for (int i = 0; i < NDL; ++i) {
+            const int pk = tabq[i * NTH + tid];
+            const int a = yd[(pk >> 27) & 15], bb = yh[(pk >> 23) & 15], c = yw[(pk >> 19) & 15];
+            m |= (((unsigned)~(a | bb | c)) >> 31) << (8 + i);
+            pd[i] = *reinterpret_cast<const float4*>(dp + (((a + bb + c) & 0x7fffffff) + (pk & 0x7ffff)));
+        }
+        okm = m;
     };
     auto issue_slow = [&](int tile) __attribute__((always_inline)) {
         int t = tile;
@@ -267,8 +338,11 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
         }
         okm = m;
     };
+    const bool mid_ok = FASTADDR && one_src && g.tabn > 0;           // (uniform)
     auto issue = [&](int tile) __attribute__((always_inline)) {
-        if (!(FASTADDR && issue_fast(tile))) issue_slow(tile);
+        if (FASTADDR && issue_fast(tile)) return;
+        if (mid_ok) issue_mid(tile);
+        else issue_slow(tile);
     };
     const float dysc = (PM == 2 && g.dy_scale) ? *g.dy_scale : 1.0f;
     auto stage = [&]() {
@@ -416,8 +490,19 @@ static int wgrad_halo_launch(WhArgs& g, int nsplit, hipStream_t st) {
     g.tiles_per_split = (int)((g.ntiles + nsplit - 1) / nsplit);
     constexpr int NTHR = 256 * NCH;
     constexpr int XF4_ = (TD + 2) * (TH + 2) * XW * 4;
+    // fp16 variants: per-slot tables (offsets + packed positions) and the per-axis clamp tables (wgrad_halo_kernel: issue_fast / issue_mid)
+    g.tabn = 0;
+    if (PM == 2) {
+        const long long vf = (long long)g.S_out * (g.d2s_s > 0 ? g.d2s_s : 1);
+        const long long xspan = (long long)g.S_in * g.S_in * g.S_in * (g.C0 > g.C1 ? g.C0 : g.C1);
+        const long long yspan = vf * vf * vf * (g.d2s_s > 0 ? g.d2s_C : g.ldy);
+        const int off_lo = g.off, off_hi = g.off + (g.nshift > 1 ? 2 : 0);
+        // coordinates off_lo .. S_out + 7 + 1 + off_hi must fit the table (index + 4) and the packed fields (< 16 per axis), sums < 2^30
+        if (xspan < (1ll << 30) && yspan < (1ll << 30) && off_lo >= -4 && off_hi <= 4 && (g.C0 + g.C1) < (1 << 19) && g.N < (1 << 19))
+            g.tabn = (g.S_in > g.S_out ? g.S_in : g.S_out) + 20;
+    }
     const size_t lds = (size_t)(1 + X3) * (NCH * (TD + 2) * (TH + 2) * XW * 16 + DPL) * sizeof(u16) +
-                       (PM == 2 ? (size_t)((NCH * XF4_ + NTHR - 1) / NTHR + 128 * 16 / NTHR) * NTHR * sizeof(int) : 0);
+                       (PM == 2 ? (size_t)2 * ((NCH * XF4_ + NTHR - 1) / NTHR + 128 * 16 / NTHR) * NTHR * sizeof(int) + (size_t)6 * g.tabn * sizeof(int) : 0);
     dim3 grid((g.C0 + g.C1) / (16 * NCH), (g.N / 64) * (g.nshift > 1 ? g.nshift : 1), nsplit);
     if (hipFuncSetAttribute((const void*)wgrad_halo_kernel<PM, TD, TH, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
     hipLaunchKernelGGL((wgrad_halo_kernel<PM, TD, TH, NCH>), grid, dim3(256 * NCH), lds, st, g);
