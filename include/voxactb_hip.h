@@ -175,10 +175,19 @@ void vxb_debug_set_wgrad_lin(int mode);       /* A/B switch of the linear layers
  * Cin % 32 == 0, one source).  zeros: >= 16 bytes of device zeros, fetched for zero-padded taps. */
 int vxb_split_bf16_f32(const float* src, int64_t ld, int64_t rows, int cols, void* dst_planes, int nplanes,
                        vxb_stream_t stream);
+/* Wide form of vxb_gemm_bf16x3_f32 for N % 512 == 0 (the linear layers of the Perceiver trunk, perceiver_lang_io.py:74-132, forward
+ * and data gradient): one workgroup owns 128 rows x 512 columns (grid.y = N / 512 column groups), A is read three k-tiles ahead, the
+ * weights come ONLY in MFMA fragment order (Bw_frag = [N / 32][K / 16][2][64][8] bf16, see vxb_gemm_dl_f32) and never touch LDS.
+ * K % 32 == 0, K >= 64.  Bit-identical to vxb_gemm_bf16x3_f32. */
+int vxb_gemm_wide_bf16x3_f32(const float* A, int64_t lda, const void* Bw_frag, float* C, int64_t ldc, const float* bias,
+                             const float* residual, int M, int N, int K, int act, float slope, int accumulate,
+                             vxb_stream_t stream);
 /* The same split for MANY matrices in one launch (all linear-layer weights of a training step, each also in transposed form
  * for the data-gradient GEMM): desc = device table of n x 6 int64 {src fp32 [rows][cols], dst planes, rows, cols,
- * transposed, first tile}; dst receives [nplanes][rows][cols] or, transposed, [nplanes][cols][rows]; tiles of an entry =
- * ceil(rows/64) * ceil(cols/64), first tiles ascending, total_tiles = their sum.  Bit-identical to vxb_split_bf16_f32. */
+ * flags, first tile}; dst receives [nplanes][rows][cols] or, transposed (flags bit 0), [nplanes][cols][rows]; with flags bit 1 the
+ * (possibly transposed) [n][k] matrix goes out in MFMA fragment order [n / 32][k / 16][nplanes][64][8] instead (n % 32 == 0, k % 16
+ * == 0: the Bw_frag operand of vxb_gemm_wide_bf16x3_f32 / vxb_gemm_dl_f32); tiles of an entry = ceil(rows/64) * ceil(cols/64), first
+ * tiles ascending, total_tiles = their sum.  Bit-identical to vxb_split_bf16_f32. */
 int vxb_split_bf16_batch_f32(const int64_t* desc, int n, int64_t total_tiles, int nplanes, vxb_stream_t stream);
 int vxb_gemm_dl_f32(const void* A_planes, const void* Bw_planes, const void* Bw_frag, int nplanes, float* C, int64_t ldc, const float* bias,
                     const float* residual, int M, int N, int K, int act, float slope, int accumulate,

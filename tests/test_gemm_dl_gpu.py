@@ -154,3 +154,53 @@ def test_batched_weight_split_is_bit_identical(precision):
     finally:
         ops.PRECISION = old
         ops.new_step()
+
+
+def test_batched_weight_split_emits_fragment_order_for_the_wide_gemm():
+    """the same launch writes the MFMA fragment order of every (weight, orientation) the wide GEMM takes (output width % 512 == 0,
+    K % 32 == 0, K >= 256): bit-identical to the shuffling copy ops.gemm_wfrag would make, found by gemm_wfrag through the cache."""
+    g = torch.Generator().manual_seed(6)
+    ws = [torch.randn(n, k, generator=g).to(DEV) * 0.05 for n, k in ((512, 512), (1024, 512), (64, 128), (4096, 512), (512, 2048))]
+    old = ops.PRECISION
+    ops.PRECISION = 'bf16x3'
+    try:
+        ops.new_step()
+        ops.prepare_linear_weights(ws)
+        hits = 0
+        for w in ws:
+            for tr in (False, True):
+                wb = ops._bf16_weight(w, tr)
+                n_o, k_o = wb.shape[-2:]
+                cached = (wb.data_ptr(), tuple(wb.shape)) in ops._FCACHE
+                assert cached == (n_o % 512 == 0 and k_o % 32 == 0 and k_o >= 256), (n_o, k_o)
+                f = ops.gemm_wfrag(wb)
+                want = wb.view(2, n_o // 32, 32, k_o // 16, 2, 8).permute(1, 3, 0, 4, 2, 5).contiguous() if n_o % 128 == 0 else None
+                if want is not None:
+                    assert f.shape == want.shape and torch.equal(f.view(torch.int16), want.view(torch.int16))
+                hits += int(cached)
+        assert hits == 8            # both orientations of 512x512, 1024x512, 4096x512 and 512x2048; none of 64x128
+    finally:
+        ops.PRECISION = old
+        ops.new_step()
+
+
+@pytest.mark.parametrize('M,N,K', [(2048, 512, 256), (4096, 1024, 512), (2300, 512, 2048), (1024, 4096, 512)])
+def test_gemm_wide_is_bit_identical_to_the_register_staged_kernel(M, N, K):
+    """gemm_wide.hip (128 x 512 workgroup tiles, A three k-tiles ahead, weight fragments from global memory) in bf16x3: ragged M, every
+    epilogue option; same products in the same order as the kernels it replaces -> equal bits; and against float64."""
+    x, W, b, r = rnd(M, K), rnd(N, K, seed=1), rnd(N, seed=2), rnd(M, N, seed=3)
+    wb = ops.split_bf16(W.to(DEV), True)
+    keep = ops.WIDE_GEMM, ops.GEMM256, ops.DL_GEMM
+    try:
+        ops.WIDE_GEMM, ops.GEMM256, ops.DL_GEMM = False, False, False
+        ref = ops.gemm_bf16w(x.to(DEV), wb, bias=b.to(DEV), act=ops.ACT_LRELU, residual=r.to(DEV))
+        ops.WIDE_GEMM = True
+        got = ops.gemm_bf16w(x.to(DEV), wb, bias=b.to(DEV), act=ops.ACT_LRELU, residual=r.to(DEV))
+        base = rnd(M, N, seed=6).to(DEV)
+        acc = base.clone()
+        ops.gemm_bf16w(x.to(DEV), wb, out=acc, accumulate=True)
+    finally:
+        ops.WIDE_GEMM, ops.GEMM256, ops.DL_GEMM = keep
+    assert torch.equal(got, ref)
+    close(got, F.leaky_relu(x.double() @ W.double().t() + b.double(), 0.02).float() + r, 2e-5, 'gemm_wide vs fp64')
+    close(acc, (base.cpu().double() + x.double() @ W.double().t()).float(), 2e-5, 'gemm_wide accumulate')

@@ -1,5 +1,6 @@
 """Micro-benchmark: the linear-layer GEMMs of the Perceiver stack (M = B * latents = 32768) in bf16x3 / bf16 --
-register-staged kernel vs direct-to-LDS kernel (with and without weight fragments from global memory)."""
+register-staged kernel vs direct-to-LDS kernel (with and without weight fragments from global memory), the 256^2 kernel and, for
+N = 512, the wide 128 x 512 kernel (|d| = largest difference from the register-staged result: 0 = bit-identical)."""
 import sys
 import os
 import torch
@@ -22,15 +23,18 @@ def main():
             res = []
             ref = None
             for name, g256, dl, bd in (('staged', False, False, False), ('dl', False, 'force', False), ('dl+bfrag', False, 'force', True),
-                                       ('gemm256', 'force', True, True)):
-                ops.GEMM256, ops.DL_GEMM, ops.GEMM_BD = g256, dl, bd
+                                       ('gemm256', 'force', True, True), ('wide', False, False, True)):
+                if name == "wide" and not (x3 and N % 512 == 0 and K >= 256):
+                    continue
+                ops.GEMM256, ops.DL_GEMM, ops.GEMM_BD, ops.WIDE_GEMM = g256, dl, bd, name == 'wide'
+
                 ops.new_step()
                 t = timeit(lambda: ops.gemm_bf16w(x, wb, out=out), n=10)
                 if ref is None:
                     ref = out.clone()
                 err = float((out - ref).abs().max())
                 res.append('%s %.3f ms %5.0f TF/s (|d| %.1e)' % (name, t, fl / t * 1e-9, err))
-            ops.GEMM256, ops.DL_GEMM, ops.GEMM_BD = True, True, True
+            ops.GEMM256, ops.DL_GEMM, ops.GEMM_BD, ops.WIDE_GEMM = True, True, True, True
             print('%s  %5d x %5d x %5d   %s' % ('bf16x3' if x3 else 'bf16  ', M, N, K, '   '.join(res)))
 
 

@@ -381,9 +381,11 @@ __global__ void __launch_bounds__(256) split_bf16_kernel(const float* __restrict
     }
 }
 
-// All linear-layer weights of a step in ONE launch: entry e of the device table desc[e] = {src, dst, rows, cols, transposed,
-// first tile} describes an fp32 [rows][cols] matrix whose planes go to dst as [nplanes][rows][cols] or, transposed, as
-// [nplanes][cols][rows] (the B operand of the data-gradient GEMM) -- the same hi / lo values vxb_split_bf16_f32 produces.
+// All linear-layer weights of a step in ONE launch: entry e of the device table desc[e] = {src, dst, rows, cols, flags,
+// first tile} describes an fp32 [rows][cols] matrix whose planes go to dst as [nplanes][rows][cols] or, transposed (flags bit 0),
+// as [nplanes][cols][rows] (the B operand of the data-gradient GEMM) -- the same hi / lo values vxb_split_bf16_f32 produces; with
+// flags bit 1 the (possibly transposed) [n][k] matrix is written in MFMA fragment order [n / 32][k / 16][nplanes][64 lanes][8]
+// instead (n % 32 == 0, k % 16 == 0): the weight operand of vxb_gemm_wide_bf16x3_f32 / vxb_gemm_dl_f32 without a shuffling copy.
 // The per-weight launches (one split + one ATen transpose copy each, ~120 per step at ~11 us of latency apiece) cost more
 // than moving the 33 M parameters.  A workgroup converts one 64 x 64 tile through LDS.
 struct SplitDesc { const float* src; u16* dst; long long rows, cols, transposed, tile0; };
@@ -396,6 +398,7 @@ __global__ void __launch_bounds__(256) split_batch_kernel(const SplitDesc* __res
         if (desc[mid].tile0 <= (long long)blockIdx.x) lo_i = mid; else hi_i = mid - 1;
     }
     const SplitDesc d = desc[lo_i];
+    const bool tr = (d.transposed & 1) != 0, frag = (d.transposed & 2) != 0;
     const int tcols = (int)((d.cols + 63) >> 6);
     const int t = (int)(blockIdx.x - d.tile0);
     const int r0 = (t / tcols) * 64, c0 = (t % tcols) * 64;
@@ -405,17 +408,22 @@ __global__ void __launch_bounds__(256) split_batch_kernel(const SplitDesc* __res
     }
     __syncthreads();
     // output pairs: (orow, ocol..ocol+1); transposed: out[c][r]
-    const long long orows = d.transposed ? d.cols : d.rows, ocols = d.transposed ? d.rows : d.cols;
-    const int or0 = d.transposed ? c0 : r0, oc0 = d.transposed ? r0 : c0;
+    const long long orows = tr ? d.cols : d.rows, ocols = tr ? d.rows : d.cols;
+    const int or0 = tr ? c0 : r0, oc0 = tr ? r0 : c0;
     u16* hi = d.dst;
-    u16* lo = nplanes == 2 ? d.dst + d.rows * d.cols : nullptr;
+    // plain: the lo plane follows the hi plane; fragment order: the planes of a (column tile, k-step) block are adjacent (512 each)
+    u16* lo = nplanes == 2 ? d.dst + (frag ? 512 : d.rows * d.cols) : nullptr;
+    const long long nks = ocols >> 4;
     for (int i = threadIdx.x; i < 64 * 32; i += 256) {
         const int orr = i >> 5, oc = (i & 31) * 2;
         if (or0 + orr >= orows || oc0 + oc >= ocols) continue;
-        const float a = d.transposed ? tile[oc][orr] : tile[orr][oc];
-        const float b = d.transposed ? tile[oc + 1][orr] : tile[orr][oc + 1];
+        const float a = tr ? tile[oc][orr] : tile[orr][oc];
+        const float b = tr ? tile[oc + 1][orr] : tile[orr][oc + 1];
         const unsigned ph = vxb_pack_bf16(a, b);
-        const long long o = (long long)(or0 + orr) * ocols + oc0 + oc;
+        const long long n_ = or0 + orr, k_ = oc0 + oc;
+        // MFMA fragment order [n / 32][k / 16][plane][half = (k % 16) / 8][n % 32][k % 8] (ops.gemm_wfrag) or row-major [n][k]
+        const long long o = frag ? (((n_ >> 5) * nks + (k_ >> 4)) * nplanes) * 512 + ((k_ >> 3) & 1) * 256 + (n_ & 31) * 8 + (k_ & 7)
+                                 : n_ * ocols + k_;
         *reinterpret_cast<unsigned*>(hi + o) = ph;
         if (lo) *reinterpret_cast<unsigned*>(lo + o) = vxb_pack_bf16(a - __uint_as_float(ph << 16), b - __uint_as_float(ph & 0xffff0000u));
     }
@@ -458,8 +466,9 @@ extern "C" int vxb_split_bf16_f32(const float* src, int64_t ld, int64_t rows, in
     return VXB_OK;
 }
 
-// desc: device table of n entries x 6 int64 {src pointer, dst pointer, rows, cols, transposed (0/1), first tile}, entries in
-// ascending first-tile order with tiles = ceil(rows/64) * ceil(cols/64); total_tiles = their sum.  rows, cols even.
+// desc: device table of n entries x 6 int64 {src pointer, dst pointer, rows, cols, flags (bit 0: transposed, bit 1: fragment order),
+// first tile}, entries in ascending first-tile order with tiles = ceil(rows/64) * ceil(cols/64); total_tiles = their sum.
+// rows, cols even; fragment order: output rows % 32 == 0, output columns % 16 == 0.
 extern "C" int vxb_split_bf16_batch_f32(const int64_t* desc, int n, int64_t total_tiles, int nplanes, vxb_stream_t stream) {
     if (!desc || n < 1 || total_tiles < 1 || total_tiles >= INT32_MAX || (nplanes != 1 && nplanes != 2)) return VXB_EARG;
     static_assert(sizeof(SplitDesc) == 6 * sizeof(int64_t), "descriptor layout");

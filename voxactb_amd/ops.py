@@ -35,6 +35,7 @@ _WCACHE = {}
 
 
 _FCACHE = {}
+WIDE_GEMM = os.environ.get('VOXACTB_WIDE_GEMM', '1') != '0'     # N = 512 linear layers on the wide kernel (gemm_wide.hip); '0': register-staged 128^2 kernel
 GEMM_BD = True       # direct-to-LDS GEMMs read their weight fragments straight from global memory (no B tile in LDS)
 
 
@@ -84,9 +85,11 @@ def prepare_linear_weights(weights):
     if ent is None:
         if len(_WPREP) > 8:
             _WPREP.clear()
-        total = sum(2 * npl * w.numel() for w in ws)
+        def wants_frag(n_out, k_in):        # the shapes gemm_bf16w() sends to the wide kernel: also emit the MFMA fragment order
+            return WIDE_GEMM and GEMM_BD and npl == 2 and n_out % 512 == 0 and k_in % 32 == 0 and k_in >= 256
+        total = sum(npl * w.numel() * (2 + int(wants_frag(*w.shape)) + int(wants_frag(w.shape[1], w.shape[0]))) for w in ws)
         buf = torch.empty(total, dtype=torch.bfloat16, device=ws[0].device)
-        rows, views, off, tile0 = [], [], 0, 0
+        rows, views, frags, off, tile0 = [], [], [], 0, 0
         for w in ws:
             N, K = w.shape
             for tr in (0, 1):
@@ -96,12 +99,21 @@ def prepare_linear_weights(weights):
                 views.append(((w.data_ptr(), (N, K), bool(tr)), v))
                 off += npl * N * K
                 tile0 += ((N + 63) // 64) * ((K + 63) // 64)
+                if wants_frag(*shape):
+                    rows.append([w.data_ptr(), buf.data_ptr() + 2 * off, N, K, tr | 2, tile0])
+                    n_o, k_o = shape
+                    f = buf[off:off + npl * N * K].view(n_o // 32, k_o // 16, npl, 2, 32, 8)
+                    frags.append((v, f))
+                    off += npl * N * K
+                    tile0 += ((N + 63) // 64) * ((K + 63) // 64)
         desc = torch.tensor(rows, dtype=torch.int64).to(ws[0].device)
-        ent = _WPREP[key] = (desc, len(rows), tile0, buf, views, ws)       # (ws keeps the sources alive: keyed by address)
-    desc, n, tiles, buf, views, _ = ent
+        ent = _WPREP[key] = (desc, len(rows), tile0, buf, views, ws, frags)       # (ws keeps the sources alive: keyed by address)
+    desc, n, tiles, buf, views, _, frags = ent
     call('vxb_split_bf16_batch_f32', desc, n, tiles, npl)
     for (ptr, shape, tr), v in views:
         _WCACHE[(ptr, shape, tr, PRECISION)] = v
+    for v, f in frags:                      # gemm_wfrag(v) finds the fragment-order copy made by the same launch
+        _FCACHE[(v.data_ptr(), tuple(v.shape))] = (f, v)
 
 
 def split_bf16(w, x3=None):
@@ -979,6 +991,15 @@ def gemm_bf16w(x, Wb, out=None, bias=None, act=ACT_NONE, residual=None, accumula
     assert Wb.dtype == torch.bfloat16 and Wb.is_contiguous() and Wb.shape[-1] == K
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    if (WIDE_GEMM and x3 and N % 512 == 0 and K % 32 == 0 and K >= 256 and M >= 1024 and x.stride(1) == 1 and x.stride(0) % 4 == 0
+            and x.data_ptr() % 16 == 0):
+        wf = gemm_wfrag(Wb)
+        if wf is not None:
+            # 128 x 512 workgroup tiles, A read once and three k-tiles ahead, weights as fragments from global memory (gemm_wide.hip)
+            _lib.set_meta(label or 'gemm_bf16 %dx%dx%d' % (M, N, K), 2.0 * M * N * K)
+            call('vxb_gemm_wide_bf16x3_f32', x, x.stride(0), wf, out, out.stride(0), bias, residual, M, N, K, act, LRELU_SLOPE,
+                 int(accumulate))
+            return out
     # measured at M = 32768 in bf16x3 (tools/bench_gemm.py): N x K = 4096 x 512: 239 TF/s vs 217 (direct-to-LDS 128^2 + weight
     # fragments) / 174 (register-staged); at N <= 2048 the 128^2 kernels win (270 vs 244 at 2048 x 512, 283 vs 257 at 512 x 4096)
     if (GEMM256 and x3 and K % 32 == 0 and N % 256 == 0 and (N >= 4096 or GEMM256 == 'force') and M >= 2048 and x.stride(1) == 1
