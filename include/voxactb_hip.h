@@ -182,6 +182,14 @@ int vxb_split_bf16_f32(const float* src, int64_t ld, int64_t rows, int cols, voi
 int vxb_gemm_wide_bf16x3_f32(const float* A, int64_t lda, const void* Bw_frag, float* C, int64_t ldc, const float* bias,
                              const float* residual, int M, int N, int K, int act, float slope, int accumulate,
                              vxb_stream_t stream);
+/* Forward of the polyphase up-conv (network_utils.py:245-250 as ops.conv3_polyphase_fwd evaluates it: the low-res kext^3 conv with
+ * s^3 * 64 phase columns and a depth-to-space store) on the same 128 x 512 workgroup tiles: z [B, S^3, Cin] fp32 is gathered and split
+ * in the kernel (no activation planes), wt_frag = the [N][kext^3 * Cin] weights (column blocks in `perm` order) as hi / lo planes in
+ * MFMA fragment order, blockmask [N / 64] = tap mask of every 64-column block (a wave skips the taps its phase does not reach:
+ * exact zeros), perm [N / 64] = fine-grid phase of every block.  Bit-identical to vxb_conv3d_dl_f32 with the same masks. */
+int vxb_conv3_poly_wide_bf16x3_f32(const float* z, int Cin, int B, int S, int kext, int off, int replicate, const void* wt_frag,
+                                   int N, const float* bias, float* out, int act, float slope, int d2s_s,
+                                   const int32_t* blockmask, const int32_t* perm, vxb_stream_t stream);
 /* The same split for MANY matrices in one launch (all linear-layer weights of a training step, each also in transposed form
  * for the data-gradient GEMM): desc = device table of n x 6 int64 {src fp32 [rows][cols], dst planes, rows, cols,
  * flags, first tile}; dst receives [nplanes][rows][cols] or, transposed (flags bit 0), [nplanes][cols][rows]; with flags bit 1 the

@@ -169,6 +169,210 @@ __global__ void __launch_bounds__(512) gemm_wide_x3_kernel(GwArgs g) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same workgroup shape for the polyphase up-conv forward (network_utils.py:245-250 as the low-res 3^3 conv with s^3 * 64 phase
+// columns and a depth-to-space store, ops.conv3_polyphase_fwd): implicit GEMM  out[m = low-res voxel][n = (phase, co)] =
+// sum over (tap, ci) z[clamp(m + tap + off)][ci] * W[n][(tap, ci)],  N = 8000, K = 27 * 64 with 17.6 of the 27 (tap, phase) weight
+// blocks non-zero.  The 128 x 128 direct-to-LDS kernel (gemm_dl.hip) asks the vector L1 for 12 KB of operands per 24 MFMAs and wave
+// (64 B/clk per CU at full matrix rate: the L1's peak) and sits at 38 % pipe-busy; with 128 x 64 wave tiles it is 8 KB per 48.
+//   * A: the gathered low-res rows, fp32 -> registers -> hi / lo -> LDS as in gemm_wide_x3_kernel; a k-tile is 32 channels of one tap,
+//     the source voxel of a thread's row is recomputed when the tap changes; the workgroup walks the UNION of its eight phases' taps;
+//   * every wave is one phase (64 columns): it skips the MFMAs of the taps its phase does not reach (their weights are exact zeros)
+//     but keeps loading B fragments so that the rotating register sets stay in step;
+//   * epilogue: bias, LeakyReLU, depth-to-space store through the phase permutation (ops.polyphase_structure).
+// Same products in the same order as the kernel it replaces (and as the dense evaluation): bit-identical.
+struct PwArgs {
+    const float* z;          // [B, S^3, Cin] fp32
+    const u16* Bfrag;        // [ceil(N / 128) * 4][K / 16][2][64][8]
+    const float* bias;       // [N] or nullptr
+    float* out;              // fine grid [B, (S s)^3, 64]
+    const int* perm;         // column block p holds phase perm[p]
+    const int* blockmask;    // tap mask of column block p (bit t set <=> its phase has weights at tap t)
+    int B, S, Cin, kext, off, replicate;
+    int N, s;
+    int act;
+    float slope;
+};
+
+__global__ void __launch_bounds__(512) conv_poly_wide_x3_kernel(PwArgs g) {
+    __shared__ __attribute__((aligned(16))) u16 As[2][2][WBM * WLD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * WBM;
+    const int cg = blockIdx.y;
+    const int M = g.B * g.S * g.S * g.S;
+    const int K = g.kext * g.kext * g.kext * g.Cin;
+    const int nks = K >> 4, cpt = g.Cin >> 5;                                   // k-steps of the whole K; 32-channel tiles per tap
+    const int nblk = g.N >> 6;                                                  // 64-column blocks (phases)
+    const int blk = cg * 8 + wn;                                                // this wave's block
+    const bool wave_on = blk < nblk;
+    const unsigned wmask = (unsigned)__builtin_amdgcn_readfirstlane(wave_on ? g.blockmask[blk] : 0);
+    unsigned umask = 0;                                                         // union over the workgroup's blocks
+    for (int w = 0; w < 8; ++w) if (cg * 8 + w < nblk) umask |= (unsigned)g.blockmask[cg * 8 + w];
+    umask = (unsigned)__builtin_amdgcn_readfirstlane((int)umask);
+    const int nkt = __builtin_popcount(umask) * cpt;
+
+    // ---- A: thread -> row tid / 4 (its low-res voxel), 8 consecutive channels of the current 32-channel tile
+    const int ar = tid >> 2, akq = (tid & 3) * 8;
+    int aw, ah_, ad, ab;
+    {
+        int r = min(m0 + ar, M - 1);
+        aw = r % g.S; r /= g.S;
+        ah_ = r % g.S; r /= g.S;
+        ad = r % g.S; r /= g.S;
+        ab = r;
+    }
+    // two walkers over the union's taps in ascending order: the A loads run 4 tiles ahead of the MFMAs, the B loads one tile
+    unsigned a_rem = umask, b_rem = umask;
+    int a_cc = 0, a_tap = 0, b_cc = 0, b_tap = 0;
+    long long a_src = -1;                                                       // element offset of the row's source voxel (-1: zero padding)
+    float4 ra[3][2];
+#define PW_LOADA(S_)                                                                                                  \
+    {                                                                                                                \
+        if (a_cc == 0) {                                                                                             \
+            a_tap = a_rem ? __builtin_ctz(a_rem) : a_tap;                                                            \
+            a_rem &= a_rem - 1;                                                                                      \
+            const int tw_ = a_tap % g.kext, th_ = (a_tap / g.kext) % g.kext, td_ = a_tap / (g.kext * g.kext);        \
+            int id_ = ad + td_ + g.off, ih_ = ah_ + th_ + g.off, iw_ = aw + tw_ + g.off;                             \
+            bool ok_ = true;                                                                                         \
+            if (g.replicate) { id_ = min(max(id_, 0), g.S - 1); ih_ = min(max(ih_, 0), g.S - 1); iw_ = min(max(iw_, 0), g.S - 1); } \
+            else ok_ = id_ >= 0 && id_ < g.S && ih_ >= 0 && ih_ < g.S && iw_ >= 0 && iw_ < g.S;                      \
+            a_src = ok_ ? ((((long long)ab * g.S + id_) * g.S + ih_) * g.S + iw_) * g.Cin + akq : -1;                \
+        }                                                                                                            \
+        const float* p_ = g.z + max(a_src, 0LL) + a_cc * 32;                                                         \
+        ra[S_][0] = *reinterpret_cast<const float4*>(p_);                                                            \
+        ra[S_][1] = *reinterpret_cast<const float4*>(p_ + 4);                                                        \
+        if (a_src < 0) { ra[S_][0] = make_float4(0.f, 0.f, 0.f, 0.f); ra[S_][1] = ra[S_][0]; }                       \
+        if (++a_cc == cpt) a_cc = 0;                                                                                 \
+    }
+#define PW_STOREA(S_, stage_)                                                                                         \
+    {                                                                                                                \
+        const float v_[8] = {ra[S_][0].x, ra[S_][0].y, ra[S_][0].z, ra[S_][0].w, ra[S_][1].x, ra[S_][1].y, ra[S_][1].z, ra[S_][1].w}; \
+        uint4 h_, l_;                                                                                                \
+        unsigned* hp_ = reinterpret_cast<unsigned*>(&h_);                                                            \
+        unsigned* lp_ = reinterpret_cast<unsigned*>(&l_);                                                            \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                               \
+            hp_[e] = vxb_pack_bf16(v_[2 * e], v_[2 * e + 1]);                                                        \
+            lp_[e] = vxb_pack_bf16(v_[2 * e] - __uint_as_float(hp_[e] << 16), v_[2 * e + 1] - __uint_as_float(hp_[e] & 0xffff0000u)); \
+        }                                                                                                            \
+        *reinterpret_cast<uint4*>(&As[(stage_)][0][ar * WLD + akq]) = h_;                                            \
+        *reinterpret_cast<uint4*>(&As[(stage_)][1][ar * WLD + akq]) = l_;                                            \
+    }
+    // ---- B fragments of this wave's two 32-column tiles (block blk = column tiles 2 blk, 2 blk + 1); idle waves read block 0
+    const u16* __restrict__ bfb = g.Bfrag + ((long long)((wave_on ? blk : 0) * 2) * nks * 2) * 512 + lane * 8;
+    bf16x8 bq[4][2][2];          // the two k-steps of a tile: sets {0, 1} and {2, 3} alternate per tile
+    int b_ks0 = 0;               // first k-step (in W's k order) of the tile whose fragments were loaded last
+    // loads the fragments of the NEXT tile of the walk into sets (2 P, 2 P + 1)
+#define PW_LOADB(P_)                                                                                                  \
+    {                                                                                                                \
+        if (b_cc == 0) { b_tap = b_rem ? __builtin_ctz(b_rem) : b_tap; b_rem &= b_rem - 1; }                         \
+        b_ks0 = b_tap * (g.Cin >> 4) + b_cc * 2;                                                                     \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                                 \
+            bq[2 * (P_) + h][j][p] = *reinterpret_cast<const bf16x8*>(bfb + (((long long)j * nks + b_ks0 + h) * 2 + p) * 512); \
+        if (++b_cc == cpt) b_cc = 0;                                                                                 \
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int lm = lane & 31, lk = (lane >> 5) * 8;
+#define PW_STEP(st_, kk_, SB)                                                                                         \
+    {                                                                                                                \
+        _Pragma("unroll") for (int ip = 0; ip < 2; ++ip) {                                                            \
+            bf16x8 ah2_[2], al2_[2];                                                                                 \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                           \
+                ah2_[i] = *reinterpret_cast<const bf16x8*>(&As[(st_)][0][((2 * ip + i) * 32 + lm) * WLD + (kk_) + lk]); \
+                al2_[i] = *reinterpret_cast<const bf16x8*>(&As[(st_)][1][((2 * ip + i) * 32 + lm) * WLD + (kk_) + lk]); \
+            }                                                                                                        \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                             \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
+                acc[2 * ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al2_[i], bq[SB][j][0], acc[2 * ip + i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                             \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
+                acc[2 * ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah2_[i], bq[SB][j][1], acc[2 * ip + i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                             \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
+                acc[2 * ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah2_[i], bq[SB][j][0], acc[2 * ip + i][j], 0, 0, 0); \
+        }                                                                                                            \
+    }
+    // the tap of the tile being multiplied: a third walker, advanced once per tile (wave-uniform)
+    unsigned c_rem = umask;
+    int c_cc = 0, c_tap = 0;
+    // one k-tile (kt_ % 3 == R_, kt_ % 2 == P_): as GW_TILE, with the B fragments of tile kt_ + 1 loaded in one go (both k-steps)
+#define PW_TILE(kt_, R_, P_)                                                                                          \
+    {                                                                                                                \
+        const int st = (P_);                                                                                         \
+        if (c_cc == 0) { c_tap = c_rem ? __builtin_ctz(c_rem) : c_tap; c_rem &= c_rem - 1; }                         \
+        if (++c_cc == cpt) c_cc = 0;                                                                                 \
+        const bool mine_ = (wmask >> c_tap) & 1u;                                                                    \
+        PW_STOREA((R_ + 1) % 3, st ^ 1)                                                                              \
+        PW_LOADB(1 - (P_))                                                                                           \
+        PW_LOADA((R_ + 1) % 3)                                                                                       \
+        if (mine_) {                                                                                                 \
+            PW_STEP(st, 0, 2 * (P_))                                                                                 \
+            PW_STEP(st, 16, 2 * (P_) + 1)                                                                            \
+        }                                                                                                            \
+        __syncthreads();                                                                                             \
+    }
+
+    // prologue: tile 0 -> LDS stage 0, tiles 1..3 in flight, B fragments of tile 0
+    PW_LOADA(0)
+    PW_STOREA(0, 0)
+    PW_LOADB(0)
+    PW_LOADA(1)
+    PW_LOADA(2)
+    PW_LOADA(0)
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < nkt; kt += 6) {
+        PW_TILE(kt, 0, 0)
+        if (kt + 1 < nkt) PW_TILE(kt + 1, 1, 1)
+        if (kt + 2 < nkt) PW_TILE(kt + 2, 2, 0)
+        if (kt + 3 < nkt) PW_TILE(kt + 3, 0, 1)
+        if (kt + 4 < nkt) PW_TILE(kt + 4, 1, 0)
+        if (kt + 5 < nkt) PW_TILE(kt + 5, 2, 1)
+    }
+#undef PW_LOADA
+#undef PW_STOREA
+#undef PW_LOADB
+#undef PW_STEP
+#undef PW_TILE
+
+    if (!wave_on) return;
+    // ---- epilogue: column block blk is phase perm[blk] of the fine grid; row m is a low-res voxel
+    const int sfac = g.s, ph = g.perm ? g.perm[blk] : blk;
+    const int rw = ph % sfac, rh = (ph / sfac) % sfac, rd = ph / (sfac * sfac);
+    const long long Vf = (long long)g.S * sfac;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m >= M) continue;
+            int q = m;
+            const int qw = q % g.S; q /= g.S;
+            const int qh = q % g.S; q /= g.S;
+            const int qd = q % g.S; q /= g.S;
+            float* op = g.out + ((((long long)q * Vf + qd * sfac + rd) * Vf + qh * sfac + rh) * Vf + qw * sfac + rw) * 64;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int co = j * 32 + (lane & 31);
+                float v = acc[i][j][r] + (g.bias ? g.bias[blk * 64 + co] : 0.f);
+                if (g.act == 1) v = v > 0.f ? v : v * g.slope;
+                op[co] = v;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // C[M, N] (+)= act(A[M, K] (fp32, row stride lda) @ W^T + bias) (+ residual) in 'bf16x3', N % 512 == 0, W given ONLY in MFMA fragment
@@ -183,6 +387,25 @@ extern "C" int vxb_gemm_wide_bf16x3_f32(const float* A, int64_t lda, const void*
     g.A = A; g.lda = lda; g.Bfrag = (const u16*)Bw_frag; g.C = C; g.ldc = ldc; g.bias = bias; g.residual = residual;
     g.M = M; g.K = K; g.act = act; g.slope = slope; g.accumulate = accumulate;
     hipLaunchKernelGGL(gemm_wide_x3_kernel, dim3(vxb_cdiv(M, WBM), N / 512), dim3(512), 0, (hipStream_t)stream, g);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+// Forward of the polyphase up-conv (see conv_poly_wide_x3_kernel): z [B, S^3, Cin] fp32 -> out fine grid [B, (S s)^3, 64] fp32 with
+// out[.., phase perm[p], co] = act(sum_(tap, ci) z[clamp / zero-pad(m + tap + off)][ci] * W[p * 64 + co][(tap, ci)] + bias[p * 64 + co]).
+// wt_frag: the [N][kext^3 * Cin] weights (column blocks already in `perm` order) as hi / lo bf16 planes in MFMA fragment order
+// (ops.gemm_wfrag).  blockmask [N / 64]: bit t set <=> block p has non-zero weights at tap t (kext^3 <= 32).  N % 64 == 0, Cin % 32 == 0.
+extern "C" int vxb_conv3_poly_wide_bf16x3_f32(const float* z, int Cin, int B, int S, int kext, int off, int replicate,
+                                              const void* wt_frag, int N, const float* bias, float* out, int act, float slope,
+                                              int d2s_s, const int32_t* blockmask, const int32_t* perm, vxb_stream_t stream) {
+    if (!z || !wt_frag || !out || !blockmask || B < 1 || S < 1 || kext < 1 || N < 64 || d2s_s < 1) return VXB_EARG;
+    if ((Cin & 31) || Cin < 32 || (N & 63) || kext * kext * kext > 32 || (((uintptr_t)z | (uintptr_t)wt_frag) & 15)) return VXB_ESIZE;
+    const long long M = (long long)B * S * S * S;
+    if (M >= INT32_MAX || M * Cin >= (1ll << 40)) return VXB_ESIZE;
+    PwArgs g;
+    g.z = z; g.Bfrag = (const u16*)wt_frag; g.bias = bias; g.out = out; g.perm = perm; g.blockmask = blockmask;
+    g.B = B; g.S = S; g.Cin = Cin; g.kext = kext; g.off = off; g.replicate = replicate; g.N = N; g.s = d2s_s; g.act = act; g.slope = slope;
+    hipLaunchKernelGGL(conv_poly_wide_x3_kernel, dim3((unsigned)vxb_cdiv(M, WBM), vxb_cdiv(N, 512)), dim3(512), 0, (hipStream_t)stream, g);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }

@@ -597,14 +597,31 @@ def polyphase_structure(k, s, dev):
         order += [a, b]
     order += left
     tm = [pm[order[i]] | (pm[order[i + 1]] if i + 1 < nph else 0) for i in range(0, nph, 2)]
+    # the wide kernel (gemm_wide.hip) walks the UNION of eight phases' taps per workgroup: groups of eight grown greedily from the
+    # largest remaining footprint by whatever adds the fewest taps (k = s = 5: 83 % of the wave slots do real work, 74 % in pair order)
+    rem, order8 = set(range(nph)), []
+    while rem:
+        seed = max(rem, key=lambda p: (pc(pm[p]), -p))
+        grp, u = [seed], pm[seed]
+        rem.remove(seed)
+        while len(grp) < 8 and rem:
+            nxt = min(rem, key=lambda p: (pc(u | pm[p]) - pc(u), -pc(pm[p]), p))
+            grp.append(nxt)
+            rem.remove(nxt)
+            u |= pm[nxt]
+        order8 += grp
     st = dict(kl=kl, R=R, phase_mask=pm, order=order,
               perm=torch.tensor(order, dtype=torch.int32, device=dev), perm_long=torch.tensor(order, dtype=torch.int64, device=dev),
               tile_mask=torch.tensor(tm, dtype=torch.int32, device=dev), phase_mask_t=torch.tensor(pm, dtype=torch.int32, device=dev),
+              order8=order8, perm8=torch.tensor(order8, dtype=torch.int32, device=dev),
+              perm8_long=torch.tensor(order8, dtype=torch.int64, device=dev),
+              block_mask8=torch.tensor([pm[p] for p in order8], dtype=torch.int32, device=dev),
               frac=sum(pc(m) for m in pm) / float(nph * kl ** 3), tile_frac=sum(pc(m) for m in tm) * 2 / float(2 * len(tm) * kl ** 3))
     _POLY[key] = st
     return st
 
 
+WIDE_POLY = os.environ.get('VOXACTB_WIDE_POLY', '1') != '0'     # polyphase up-conv forward on the wide kernel (gemm_wide.hip); '0': direct-to-LDS 128^2 kernel
 POLY_SPARSE = True       # skip the structurally zero (tap, phase) blocks of the polyphase up-conv
 
 
@@ -624,11 +641,19 @@ def conv3_polyphase_fwd(z, Weff, Cout, B, G, k, s, bias, act=ACT_NONE, label=Non
     npl = 2 if PRECISION == 'bf16x3' else 1
     lbl = label or 'conv3_polyphase[k%d s%d %d->%d G%d]' % (k, s, C, Cout, G)
     _lib.set_meta(lbl, 0.0)
+    out = torch.empty((B, G * s, G * s, G * s, Cout), dtype=torch.float32, device=z.device)
+    if WIDE_POLY and GEMM_BD and npl == 2 and Cout == 64 and z.is_contiguous() and K % 16 == 0:
+        # 128 x 512 workgroup tiles, one phase per wave, A gathered + split in the kernel (gemm_wide.hip: conv_poly_wide_x3_kernel);
+        # column blocks in the order that keeps the eight footprints of a workgroup alike
+        wt = Weff.t().view(s ** 3, Cout, K).index_select(0, st['perm8_long']).view(N, K)
+        wf = gemm_wfrag(split_planes(wt, npl))
+        _lib.set_meta(lbl, 2.0 * B * G ** 3 * N * kl ** 3 * C * st['frac'])
+        call('vxb_conv3_poly_wide_bf16x3_f32', z, C, B, G, kl, -R, 1, wf, N, bias, out, act, LRELU_SLOPE, s, st['block_mask8'], st['perm8'])
+        return out
     wt = Weff.t().view(s ** 3, Cout, K).index_select(0, st['perm_long']).view(N, K)      # [(phase in tile order, co)][K]
     wb = split_planes(wt, npl)
     _lib.set_meta(lbl, 0.0)
     planes = split_planes(z.reshape(-1, C), npl)
-    out = torch.empty((B, G * s, G * s, G * s, Cout), dtype=torch.float32, device=z.device)
     _lib.set_meta(lbl, 2.0 * B * G ** 3 * N * kl ** 3 * C * st['frac'])
     call('vxb_conv3d_dl_f32', planes, C, B, G, G, 1, kl, -R, 1, wb, gemm_wfrag(wb), npl, N, bias, out, N, act, LRELU_SLOPE, 0, s, Cout,
          _zeros16(z.device), st['tile_mask'], st['perm'])
