@@ -144,8 +144,13 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
     const int t_begin = bz * g.tiles_per_split;
     const int t_end = (int)min((long long)t_begin + g.tiles_per_split, g.ntiles);
 
-    float4 px[NXL], pd[NDL];
-    unsigned okm = 0;                  // bit i: x load i is real data (not zero padding / a slot past the halo); bit 8 + i: dY load i
+    // the loads of a tile in flight: px / pd and okm (bit i: x load i is real data, not zero padding / a slot past the halo; bit 8 + i:
+    // dY load i).  PF2 (fp16, two chunks per workgroup: 10 float4 per thread and tile): TWO sets, the loads of tiles t+1 and t+2 are in
+    // flight while tile t is multiplied -- a tile's MFMAs take ~0.9 us, a load ~2.5 us to arrive, and one workgroup per CU has nobody
+    // else to hide that (33.9 % pipe-busy, 36 % of the wave time waiting: profiles/r03_v4_sq_summary.txt)
+    struct LoadSet { float4 px[NXL]; float4 pd[NDL]; unsigned okm; };
+    constexpr bool PF2 = PM == 2 && NCH == 2;
+    LoadSet ls0, ls1;
     // dY addressing without a branch on the layout: fine-grid extent, voxel step and phase offsets (1 / 0 without d2s)
     const int ds_ = g.d2s_s > 0 ? g.d2s_s : 1;
     const int Vf = S * ds_;
@@ -230,7 +235,7 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
         }
         __syncthreads();           // (the axis tables are shared; tabx / tabd / tabp / tabq entries are read back only by their writer)
     }
-    auto issue_fast = [&](int tile) __attribute__((always_inline)) -> bool {
+    auto issue_fast = [&](LoadSet& L, int tile) __attribute__((always_inline)) -> bool {
         int t = tile;
         const int tw = t % g.ntw; t /= g.ntw;
         const int th = t % g.nth; t /= g.nth;
@@ -248,19 +253,19 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
         for (int i = 0; i < NXL; ++i) {
             const int o = tabx[i * NTH + tid];
             m |= (o >= 0 ? 1u : 0u) << i;
-            px[i] = *reinterpret_cast<const float4*>(xp + max(o, 0));
+            L.px[i] = *reinterpret_cast<const float4*>(xp + max(o, 0));
         }
         const long long db = ((((long long)b * Vf + (long long)d0 * ds_ + rd) * Vf + h0 * ds_ + rh) * Vf + w0 * ds_ + rw) * dy_row;
         const float* __restrict__ dp = dyb + db;
 #pragma unroll
         for (int i = 0; i < NDL; ++i) {
-            pd[i] = *reinterpret_cast<const float4*>(dp + tabd[i * NTH + tid]);
+            L.pd[i] = *reinterpret_cast<const float4*>(dp + tabd[i * NTH + tid]);
             m |= 1u << (8 + i);
         }
-        okm = m;
+        L.okm = m;
         return true;
     };
-    auto issue_mid = [&](int tile) __attribute__((always_inline)) {
+    auto issue_mid = [&](LoadSet& L, int tile) __attribute__((always_inline)) {
         int t = tile;
         const int tw = t % g.ntw; t /= g.ntw;
         const int th = t % g.nth; t /= g.nth;
@@ -278,7 +283,7 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
             const int pu = max(pk, 0);
             const int a = ad[(pu >> 27) & 15], bb = ah[(pu >> 23) & 15], c = aw[(pu >> 19) & 15];
             m |= (((unsigned)~(a | bb | c | pk)) >> 31) << i;
-            px[i] = *reinterpret_cast<const float4*>(xp + (((a + bb + c) & 0x7fffffff) + (pu & 0x7ffff)));
+            L.px[i] = *reinterpret_cast<const float4*>(xp + (((a + bb + c) & 0x7fffffff) + (pu & 0x7ffff)));
         }
         const float* __restrict__ dp = dyb + ((((long long)b * Vf + rd) * Vf + rh) * Vf + rw) * dy_row;
         const int* yd = ayy + d0;
@@ -289,11 +294,11 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
             const int pk = tabq[i * NTH + tid];
             const int a = yd[(pk >> 27) & 15], bb = yh[(pk >> 23) & 15], c = yw[(pk >> 19) & 15];
             m |= (((unsigned)~(a | bb | c)) >> 31) << (8 + i);
-            pd[i] = *reinterpret_cast<const float4*>(dp + (((a + bb + c) & 0x7fffffff) + (pk & 0x7ffff)));
+            L.pd[i] = *reinterpret_cast<const float4*>(dp + (((a + bb + c) & 0x7fffffff) + (pk & 0x7ffff)));
         }
-        okm = m;
+        L.okm = m;
     };
-    auto issue_slow = [&](int tile) __attribute__((always_inline)) {
+    auto issue_slow = [&](LoadSet& L, int tile) __attribute__((always_inline)) {
         int t = tile;
         const int tw = t % g.ntw; t /= g.ntw;
         const int th = t % g.nth; t /= g.nth;
@@ -324,7 +329,7 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
             ok = ok && (g.replicate || (cd == id && ch == ih && cw == iw));
             m |= (ok ? 1u : 0u) << i;
             const int vox = ((b * g.S_in + cd) * g.S_in + ch) * g.S_in + cw;
-            px[i] = *reinterpret_cast<const float4*>(src + (long long)vox * Cs + c0 + c4);
+            L.px[i] = *reinterpret_cast<const float4*>(src + (long long)vox * Cs + c0 + c4);
         }
 #pragma unroll
         for (int i = 0; i < NDL; ++i) {
@@ -334,32 +339,32 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
             const bool ok = od < S && oh < S && ow < S;
             m |= (ok ? 1u : 0u) << (8 + i);
             const int vox = ((b * Vf + min(od, S - 1) * ds_ + rd) * Vf + min(oh, S - 1) * ds_ + rh) * Vf + min(ow, S - 1) * ds_ + rw;
-            pd[i] = *reinterpret_cast<const float4*>(dyb + (long long)vox * dy_row + n4);
+            L.pd[i] = *reinterpret_cast<const float4*>(dyb + (long long)vox * dy_row + n4);
         }
-        okm = m;
+        L.okm = m;
     };
     const bool mid_ok = FASTADDR && one_src && g.tabn > 0;           // (uniform)
-    auto issue = [&](int tile) __attribute__((always_inline)) {
-        if (FASTADDR && issue_fast(tile)) return;
-        if (mid_ok) issue_mid(tile);
-        else issue_slow(tile);
+    auto issue = [&](LoadSet& L, int tile) __attribute__((always_inline)) {
+        if (FASTADDR && issue_fast(L, tile)) return;
+        if (mid_ok) issue_mid(L, tile);
+        else issue_slow(L, tile);
     };
     const float dysc = (PM == 2 && g.dy_scale) ? *g.dy_scale : 1.0f;
-    auto stage = [&]() {
+    auto stage = [&](LoadSet& L) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NXL; ++i) {
             const int e0 = tid + NTH * i;
             if (e0 < NCH * XF4) {
                 const int lch = NCH == 1 ? 0 : e0 / XF4;
                 const int e = e0 - lch * XF4 + lch * (1 + X3) * XPL / 4;     // slot index inside the chunk's plane pair
-                if (!((okm >> i) & 1u)) px[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!((L.okm >> i) & 1u)) L.px[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 uint2 pk;
-                pk.x = wh_pack2<PM>(px[i].x, px[i].y); pk.y = wh_pack2<PM>(px[i].z, px[i].w);
+                pk.x = wh_pack2<PM>(L.px[i].x, L.px[i].y); pk.y = wh_pack2<PM>(L.px[i].z, L.px[i].w);
                 *reinterpret_cast<uint2*>(&xs[(e >> 2) * 16 + (e & 3) * 4]) = pk;
                 if (X3) {
                     uint2 q;
-                    q.x = wh_pack2<PM>(px[i].x - __uint_as_float(pk.x << 16), px[i].y - __uint_as_float(pk.x & 0xffff0000u));
-                    q.y = wh_pack2<PM>(px[i].z - __uint_as_float(pk.y << 16), px[i].w - __uint_as_float(pk.y & 0xffff0000u));
+                    q.x = wh_pack2<PM>(L.px[i].x - __uint_as_float(pk.x << 16), L.px[i].y - __uint_as_float(pk.x & 0xffff0000u));
+                    q.y = wh_pack2<PM>(L.px[i].z - __uint_as_float(pk.y << 16), L.px[i].w - __uint_as_float(pk.y & 0xffff0000u));
                     *reinterpret_cast<uint2*>(&xs[XPL + (e >> 2) * 16 + (e & 3) * 4]) = q;
                 }
             }
@@ -367,15 +372,15 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
 #pragma unroll
         for (int i = 0; i < NDL; ++i) {
             const int e = tid + NTH * i;
-            if (!((okm >> (8 + i)) & 1u)) pd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (PM == 2) { pd[i].x *= dysc; pd[i].y *= dysc; pd[i].z *= dysc; pd[i].w *= dysc; }
+            if (!((L.okm >> (8 + i)) & 1u)) L.pd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (PM == 2) { L.pd[i].x *= dysc; L.pd[i].y *= dysc; L.pd[i].z *= dysc; L.pd[i].w *= dysc; }
             uint2 pk;
-            pk.x = wh_pack2<PM>(pd[i].x, pd[i].y); pk.y = wh_pack2<PM>(pd[i].z, pd[i].w);
+            pk.x = wh_pack2<PM>(L.pd[i].x, L.pd[i].y); pk.y = wh_pack2<PM>(L.pd[i].z, L.pd[i].w);
             *reinterpret_cast<uint2*>(&ds[(e >> 4) * DLD + (e & 15) * 4]) = pk;
             if (X3) {
                 uint2 q;
-                q.x = wh_pack2<PM>(pd[i].x - __uint_as_float(pk.x << 16), pd[i].y - __uint_as_float(pk.x & 0xffff0000u));
-                q.y = wh_pack2<PM>(pd[i].z - __uint_as_float(pk.y << 16), pd[i].w - __uint_as_float(pk.y & 0xffff0000u));
+                q.x = wh_pack2<PM>(L.pd[i].x - __uint_as_float(pk.x << 16), L.pd[i].y - __uint_as_float(pk.x & 0xffff0000u));
+                q.y = wh_pack2<PM>(L.pd[i].z - __uint_as_float(pk.y << 16), L.pd[i].w - __uint_as_float(pk.y & 0xffff0000u));
                 *reinterpret_cast<uint2*>(&ds[DPL + (e >> 4) * DLD + (e & 15) * 4]) = q;
             }
         }
@@ -412,13 +417,13 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
     // The VALU work of issue() + stage() (~650 instructions per thread and tile) is not hidden behind the other resident
     // workgroup's MFMAs -- the times add.  Delaying every second workgroup by 1-8 thousand cycles to break a possible
     // lockstep of the two changed nothing.)
-    if (t_begin < t_end) issue(t_begin);
-    for (int tile = t_begin; tile < t_end; ++tile) {
+    // one tile: stage the loads of set L into LDS, issue the loads of tile + AHEAD into the freed set, multiply
+    auto tile_body = [&](LoadSet& L, int tile, int ahead) __attribute__((always_inline)) {
         __syncthreads();                 // every wave is done reading the previous tile
-        if (!(g.dbg & 1) || tile == t_begin) stage();
+        if (!(g.dbg & 1) || tile == t_begin) stage(L);
         __syncthreads();
-        if (tile + 1 < t_end && !(g.dbg & 1)) issue(tile + 1);
-        if (g.dbg & 2) continue;
+        if (tile + ahead < t_end && !(g.dbg & 1)) issue(L, tile + ahead);
+        if (g.dbg & 2) return;
 #pragma unroll 1
         for (int ks = 0; ks < 4; ++ks) {
             const int dd = ks / HB, hb = (ks % HB) * 4;
@@ -460,6 +465,17 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
                 ah = ahn;
             }
         }
+    };
+    if (PF2) {
+        if (t_begin < t_end) issue(ls0, t_begin);
+        if (t_begin + 1 < t_end) issue(ls1, t_begin + 1);
+        for (int tile = t_begin; tile < t_end; tile += 2) {
+            tile_body(ls0, tile, 2);
+            if (tile + 1 < t_end) tile_body(ls1, tile + 1, 2);
+        }
+    } else {
+        if (t_begin < t_end) issue(ls0, t_begin);
+        for (int tile = t_begin; tile < t_end; ++tile) tile_body(ls0, tile, 1);
     }
 
     // D tile (16 ci x 16 n): lane l holds column n = l & 15, rows 4 (l >> 4) + r
