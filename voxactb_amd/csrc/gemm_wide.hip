@@ -263,15 +263,19 @@ __global__ void __launch_bounds__(512) conv_poly_wide_x3_kernel(PwArgs g) {
     const u16* __restrict__ bfb = g.Bfrag + ((long long)((wave_on ? blk : 0) * 2) * nks * 2) * 512 + lane * 8;
     bf16x8 bq[4][2][2];          // the two k-steps of a tile: sets {0, 1} and {2, 3} alternate per tile
     int b_ks0 = 0;               // first k-step (in W's k order) of the tile whose fragments were loaded last
+    const long long jstride = (long long)nks * 1024;         // u16 between the fragments of the wave's two 32-column tiles
     // loads the fragments of the NEXT tile of the walk into sets (2 P, 2 P + 1)
 #define PW_LOADB(P_)                                                                                                  \
     {                                                                                                                \
         if (b_cc == 0) { b_tap = b_rem ? __builtin_ctz(b_rem) : b_tap; b_rem &= b_rem - 1; }                         \
         b_ks0 = b_tap * (g.Cin >> 4) + b_cc * 2;                                                                     \
+        const u16* q0_ = bfb + (long long)b_ks0 * 1024;            /* one 64-bit add per tile; (h, p) are immediates */ \
+        const u16* q1_ = q0_ + jstride;                                                                              \
         _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                                 \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
-        _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                                 \
-            bq[2 * (P_) + h][j][p] = *reinterpret_cast<const bf16x8*>(bfb + (((long long)j * nks + b_ks0 + h) * 2 + p) * 512); \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                               \
+            bq[2 * (P_) + h][0][p] = *reinterpret_cast<const bf16x8*>(q0_ + (h * 2 + p) * 512);                      \
+            bq[2 * (P_) + h][1][p] = *reinterpret_cast<const bf16x8*>(q1_ + (h * 2 + p) * 512);                      \
+        }                                                                                                            \
         if (++b_cc == cpt) b_cc = 0;                                                                                 \
     }
 
