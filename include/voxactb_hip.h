@@ -182,6 +182,15 @@ int vxb_split_bf16_f32(const float* src, int64_t ld, int64_t rows, int cols, voi
 int vxb_gemm_wide_bf16x3_f32(const float* A, int64_t lda, const void* Bw_frag, float* C, int64_t ldc, const float* bias,
                              const float* residual, int M, int N, int K, int act, float slope, int accumulate,
                              vxb_stream_t stream);
+/* FeedForward with GEGLU (perceiver_lang_io.py:74-78, :100-106) on the wide kernel.  _fwd: the up-projection h [M][2 F] = A @ W^T + bias
+ * and gg [M][F] = h[:, :F] * gelu(h[:, F:]) from one launch (Bw_frag: fragment order with the value / gate rows interleaved, see
+ * vxb_split_bf16_batch_f32 flag bit 2); 2 F % 512 == 0.  _bwd: the data gradient of the down-projection d(gg) = dY [M][K] @ W2 (Bw_frag:
+ * fragment order of the transposed weight's planes [2][F][K]) with GEGLU's backward applied in the epilogue: dh [M][2 F] = [d * gelu(h_gate)
+ * | d * h_value * gelu'(h_gate)]; F % 512 == 0.  Same bits as vxb_gemm_bf16x3_f32 followed by vxb_geglu_fwd_f32 / vxb_geglu_bwd_f32. */
+int vxb_gemm_wide_geglu_fwd_f32(const float* A, int64_t lda, const void* Bw_frag, const float* bias, float* h, float* gg, int M, int F,
+                                int K, vxb_stream_t stream);
+int vxb_gemm_wide_geglu_bwd_f32(const float* dY, int64_t lda, const void* Bw_frag, const float* h, float* dh, int M, int F, int K,
+                                vxb_stream_t stream);
 /* Forward of the polyphase up-conv (network_utils.py:245-250 as ops.conv3_polyphase_fwd evaluates it: the low-res kext^3 conv with
  * s^3 * 64 phase columns and a depth-to-space store) on the same 128 x 512 workgroup tiles: z [B, S^3, Cin] fp32 is gathered and split
  * in the kernel (no activation planes), wt_frag = the [N][kext^3 * Cin] weights (column blocks in `perm` order) as hi / lo planes in
@@ -194,8 +203,9 @@ int vxb_conv3_poly_wide_bf16x3_f32(const float* z, int Cin, int B, int S, int ke
  * for the data-gradient GEMM): desc = device table of n x 6 int64 {src fp32 [rows][cols], dst planes, rows, cols,
  * flags, first tile}; dst receives [nplanes][rows][cols] or, transposed (flags bit 0), [nplanes][cols][rows]; with flags bit 1 the
  * (possibly transposed) [n][k] matrix goes out in MFMA fragment order [n / 32][k / 16][nplanes][64][8] instead (n % 32 == 0, k % 16
- * == 0: the Bw_frag operand of vxb_gemm_wide_bf16x3_f32 / vxb_gemm_dl_f32); tiles of an entry = ceil(rows/64) * ceil(cols/64), first
- * tiles ascending, total_tiles = their sum.  Bit-identical to vxb_split_bf16_f32. */
+ * == 0: the Bw_frag operand of vxb_gemm_wide_bf16x3_f32 / vxb_gemm_dl_f32), with bit 2 as well its rows interleaved per 64-row block as
+ * [32 value rows | their 32 gate rows] (the operand of vxb_gemm_wide_geglu_fwd_f32); tiles of an entry = ceil(rows/64) * ceil(cols/64),
+ * first tiles ascending, total_tiles = their sum.  Bit-identical to vxb_split_bf16_f32. */
 int vxb_split_bf16_batch_f32(const int64_t* desc, int n, int64_t total_tiles, int nplanes, vxb_stream_t stream);
 int vxb_gemm_dl_f32(const void* A_planes, const void* Bw_planes, const void* Bw_frag, int nplanes, float* C, int64_t ldc, const float* bias,
                     const float* residual, int M, int N, int K, int act, float slope, int accumulate,

@@ -204,3 +204,43 @@ def test_gemm_wide_is_bit_identical_to_the_register_staged_kernel(M, N, K):
     assert torch.equal(got, ref)
     close(got, F.leaky_relu(x.double() @ W.double().t() + b.double(), 0.02).float() + r, 2e-5, 'gemm_wide vs fp64')
     close(acc, (base.cpu().double() + x.double() @ W.double().t()).float(), 2e-5, 'gemm_wide accumulate')
+
+
+@pytest.mark.parametrize('M,F,K', [(2048, 256, 256), (2300, 2048, 512)])
+def test_geglu_fused_into_the_wide_gemm_is_bit_identical(M, F, K):
+    """FeedForward's up-projection + GEGLU from one launch (value / gate rows interleaved in the fragment order), and the data
+    gradient of the down-projection + GEGLU's backward: the same bits as the separate passes; the interleaved fragments written by
+    the batched weight split equal the gather + shuffle of ops.gemm_wfrag_geglu."""
+    x, W1, b1 = rnd(M, K).to(DEV), (rnd(2 * F, K, seed=1) * 0.05).to(DEV), rnd(2 * F, seed=2).to(DEV)
+    old = ops.PRECISION
+    ops.PRECISION = 'bf16x3'
+    keep = ops.FUSE_GEGLU
+    try:
+        ops.new_step()
+        ops.FUSE_GEGLU = False
+        h0, g0 = ops.linear_geglu(x, W1, b1)
+        ops.FUSE_GEGLU = True
+        h1, g1 = ops.linear_geglu(x, W1, b1)                 # fragments by gather + shuffle
+        assert torch.equal(h0, h1) and torch.equal(g0, g1)
+        ref = ops.gemm_wfrag_geglu(ops._bf16_weight(W1, False)).clone()
+        ops.new_step()
+        ops.prepare_linear_weights([W1], geglu=[W1])         # fragments by the batched split (flag bit 2)
+        got = ops.gemm_wfrag_geglu(ops._bf16_weight(W1, False))
+        if (2 * F) % 512 == 0 and K % 32 == 0 and K >= 256:
+            assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+        h2, g2 = ops.linear_geglu(x, W1, b1)
+        assert torch.equal(h0, h2) and torch.equal(g0, g2)
+        if F % 512 == 0:
+            # backward: dy [M][Kout] @ W2 [Kout][F] -> d(gg) -> dh
+            Ko = 512
+            W2, dy = (rnd(Ko, F, seed=3) * 0.05).to(DEV), rnd(M, Ko, seed=4).to(DEV)
+            dh = ops.linear_dgrad_geglu_bwd(dy, W2, h0)
+            assert dh is not None
+            dgg = torch.empty(M, F, device=DEV)
+            ops.linear_bwd(g0, W2, dy, torch.zeros(Ko, F, device=DEV), None, dgg)
+            want = ops.geglu_bwd(h0, dgg)
+            assert torch.equal(dh, want)
+    finally:
+        ops.PRECISION = old
+        ops.FUSE_GEGLU = keep
+        ops.new_step()

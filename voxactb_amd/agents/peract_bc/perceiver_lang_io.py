@@ -446,17 +446,20 @@ class PerceiverEngine:
 
     def _ff_fwd(self, pre, x2d, save):
         xn, mean, rstd = ops.layernorm_fwd(x2d, self.p(pre + '.norm.weight'), self.p(pre + '.norm.bias'))
-        h = ops.linear(xn, self.p(pre + '.fn.net.0.weight'), self.p(pre + '.fn.net.0.bias'))
-        gg = ops.geglu_fwd(h)
+        h, gg = ops.linear_geglu(xn, self.p(pre + '.fn.net.0.weight'), self.p(pre + '.fn.net.0.bias'))
         out = ops.linear(gg, self.p(pre + '.fn.net.2.weight'), self.p(pre + '.fn.net.2.bias'), residual=x2d)
         return out, (dict(x=x2d, mean=mean, rstd=rstd, xn=xn, h=h, gg=gg) if save else None)
 
     def _ff_bwd(self, pre, c, dx):
         """dx: gradient wrt the block output (also the residual path); updated in place to the input gradient."""
-        dgg = torch.empty_like(c['gg'])
-        ops.linear_bwd(c['gg'], self.p(pre + '.fn.net.2.weight'), dx, self.g(pre + '.fn.net.2.weight'),
-                       self.g(pre + '.fn.net.2.bias'), dgg)
-        dh = ops.geglu_bwd(c['h'], dgg)
+        W2 = self.p(pre + '.fn.net.2.weight')
+        dh = ops.linear_dgrad_geglu_bwd(dx, W2, c['h'])      # d(gg) = dx @ W2 and GEGLU's backward in one launch where it applies
+        if dh is not None:
+            ops.linear_bwd(c['gg'], W2, dx, self.g(pre + '.fn.net.2.weight'), self.g(pre + '.fn.net.2.bias'), None)
+        else:
+            dgg = torch.empty_like(c['gg'])
+            ops.linear_bwd(c['gg'], W2, dx, self.g(pre + '.fn.net.2.weight'), self.g(pre + '.fn.net.2.bias'), dgg)
+            dh = ops.geglu_bwd(c['h'], dgg)
         dxn = torch.empty_like(c['xn'])
         ops.linear_bwd(c['xn'], self.p(pre + '.fn.net.0.weight'), dh, self.g(pre + '.fn.net.0.weight'),
                        self.g(pre + '.fn.net.0.bias'), dxn)
@@ -477,7 +480,8 @@ class PerceiverEngine:
         try:
             if self._lin_weights is None:
                 self._lin_weights = [n for n, prm in self.P.items() if prm.dim() == 2 and n.endswith('.weight') and prm.numel() >= 4096]
-            ops.prepare_linear_weights([self.p(n) for n in self._lin_weights])
+            ops.prepare_linear_weights([self.p(n) for n in self._lin_weights],
+                                       geglu=[self.p(n) for n in self._lin_weights if n.endswith('.fn.net.0.weight')])
             return self._forward(vox, proprio, lang_token_embs, training, save, seed, proprio_left)
         finally:
             ops.PRECISION = 'fp32'

@@ -81,6 +81,15 @@ __device__ __forceinline__ void vxb_lds_barrier() {
 // Bare s_barrier for kernels whose LDS is written ONLY by direct-to-LDS loads that the code tracks itself with
 // s_waitcnt vmcnt(n): even the LDS-only fence above waits for every outstanding direct load (they are LDS writes), i.e.
 // for the tiles deliberately left in flight.  The asm clobbers keep the compiler from moving LDS reads across it.
+// exact (erf) GELU and its derivative: GEGLU (perceiver_lang_io.py:74-78), as a stand-alone pass (nn_ops.hip) and in the GEMM
+// epilogues that fuse it (gemm_wide.hip) -- one definition, so both give the same bits
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
 __device__ __forceinline__ void vxb_raw_barrier() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();

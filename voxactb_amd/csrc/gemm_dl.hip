@@ -385,7 +385,9 @@ __global__ void __launch_bounds__(256) split_bf16_kernel(const float* __restrict
 // first tile} describes an fp32 [rows][cols] matrix whose planes go to dst as [nplanes][rows][cols] or, transposed (flags bit 0),
 // as [nplanes][cols][rows] (the B operand of the data-gradient GEMM) -- the same hi / lo values vxb_split_bf16_f32 produces; with
 // flags bit 1 the (possibly transposed) [n][k] matrix is written in MFMA fragment order [n / 32][k / 16][nplanes][64 lanes][8]
-// instead (n % 32 == 0, k % 16 == 0): the weight operand of vxb_gemm_wide_bf16x3_f32 / vxb_gemm_dl_f32 without a shuffling copy.
+// instead (n % 32 == 0, k % 16 == 0): the weight operand of vxb_gemm_wide_bf16x3_f32 / vxb_gemm_dl_f32 without a shuffling copy;
+// with bit 2 as well (n % 64 == 0) the rows are interleaved for vxb_gemm_wide_geglu_fwd_f32: row q < n / 2 goes to position
+// (q / 32) * 64 + q % 32, row n / 2 + q to (q / 32) * 64 + 32 + q % 32.
 // The per-weight launches (one split + one ATen transpose copy each, ~120 per step at ~11 us of latency apiece) cost more
 // than moving the 33 M parameters.  A workgroup converts one 64 x 64 tile through LDS.
 struct SplitDesc { const float* src; u16* dst; long long rows, cols, transposed, tile0; };
@@ -398,7 +400,7 @@ __global__ void __launch_bounds__(256) split_batch_kernel(const SplitDesc* __res
         if (desc[mid].tile0 <= (long long)blockIdx.x) lo_i = mid; else hi_i = mid - 1;
     }
     const SplitDesc d = desc[lo_i];
-    const bool tr = (d.transposed & 1) != 0, frag = (d.transposed & 2) != 0;
+    const bool tr = (d.transposed & 1) != 0, frag = (d.transposed & 2) != 0, glu = (d.transposed & 4) != 0;
     const int tcols = (int)((d.cols + 63) >> 6);
     const int t = (int)(blockIdx.x - d.tile0);
     const int r0 = (t / tcols) * 64, c0 = (t % tcols) * 64;
@@ -420,7 +422,12 @@ __global__ void __launch_bounds__(256) split_batch_kernel(const SplitDesc* __res
         const float a = tr ? tile[oc][orr] : tile[orr][oc];
         const float b = tr ? tile[oc + 1][orr] : tile[orr][oc + 1];
         const unsigned ph = vxb_pack_bf16(a, b);
-        const long long n_ = or0 + orr, k_ = oc0 + oc;
+        long long n_ = or0 + orr;
+        const long long k_ = oc0 + oc;
+        if (glu) {           // GEGLU up-projection: every 64-row block of the fragment order = [32 value rows | their 32 gate rows]
+            const long long F = orows >> 1, q = n_ < F ? n_ : n_ - F;
+            n_ = (q >> 5) * 64 + (n_ < F ? 0 : 32) + (q & 31);
+        }
         // MFMA fragment order [n / 32][k / 16][plane][half = (k % 16) / 8][n % 32][k % 8] (ops.gemm_wfrag) or row-major [n][k]
         const long long o = frag ? (((n_ >> 5) * nks + (k_ >> 4)) * nplanes) * 512 + ((k_ >> 3) & 1) * 256 + (n_ & 31) * 8 + (k_ & 7)
                                  : n_ * ocols + k_;

@@ -38,6 +38,16 @@ struct GwArgs {
     int act;
     float slope;
     int accumulate;
+    // GEGLU fused into the epilogue (perceiver_lang_io.py:74-78; F = half the width of the up-projection):
+    //   geglu 1 (forward of the up-projection, N = 2 F): the weight fragments come with the rows of every 64-column block interleaved
+    //     as [32 value columns 32 b .. | 32 gate columns F + 32 b ..] (vxb_split_bf16_batch_f32 flag bit 2), so a lane holds h[m][c] and
+    //     h[m][F + c] side by side: C = h [M][2 F] in its natural column order (the backward pass reads it) and C2 = h[:, c] *
+    //     gelu(h[:, F + c]) [M][F] -- the same bits as vxb_geglu_fwd_f32 on the stored h
+    //   geglu 2 (data gradient of the down-projection, N = F): the tile is d(gg); C = dh [M][2 F] = [d * gelu(h_gate) | d * h_value *
+    //     gelu'(h_gate)] with h = H [M][2 F] -- vxb_geglu_bwd_f32 without the round trip of d(gg) through HBM
+    int geglu, F;
+    float* C2;
+    const float* H;
 };
 
 __global__ void __launch_bounds__(512) gemm_wide_x3_kernel(GwArgs g) {
@@ -148,6 +158,41 @@ __global__ void __launch_bounds__(512) gemm_wide_x3_kernel(GwArgs g) {
 
     float* __restrict__ C = g.C;
     const float* __restrict__ R = g.residual;
+    if (g.geglu == 1) {
+        const int F = g.F, c = (cg * 8 + wn) * 32 + (lane & 31);          // value column; its gate is column F + c
+        const float bv = g.bias ? g.bias[c] : 0.f, bg = g.bias ? g.bias[F + c] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= g.M) continue;
+                const float hv = acc[i][0][r] + bv, hg = acc[i][1][r] + bg;
+                C[(long long)m * g.ldc + c] = hv;
+                C[(long long)m * g.ldc + F + c] = hg;
+                g.C2[(long long)m * F + c] = hv * gelu_erf(hg);
+            }
+        return;
+    }
+    if (g.geglu == 2) {
+        const int F = g.F;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = cg * 512 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (m >= g.M) continue;
+                    const long long o = (long long)m * 2 * F + c;
+                    const float a = g.H[o], gt = g.H[o + F], d = acc[i][j][r];
+                    C[o] = d * gelu_erf(gt);
+                    C[o + F] = d * a * gelu_erf_grad(gt);
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -390,7 +435,40 @@ extern "C" int vxb_gemm_wide_bf16x3_f32(const float* A, int64_t lda, const void*
     GwArgs g;
     g.A = A; g.lda = lda; g.Bfrag = (const u16*)Bw_frag; g.C = C; g.ldc = ldc; g.bias = bias; g.residual = residual;
     g.M = M; g.K = K; g.act = act; g.slope = slope; g.accumulate = accumulate;
+    g.geglu = 0; g.F = 0; g.C2 = nullptr; g.H = nullptr;
     hipLaunchKernelGGL(gemm_wide_x3_kernel, dim3(vxb_cdiv(M, WBM), N / 512), dim3(512), 0, (hipStream_t)stream, g);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+// GEGLU up-projection (perceiver_lang_io.py:74-78 with :100-106): h [M][2 F] = A @ W^T + bias and gg [M][F] = h[:, :F] * gelu(h[:, F:])
+// from one launch.  Bw_frag: the fragment order of W's planes with the rows of every 64-column block interleaved [32 value | 32 gate]
+// (vxb_split_bf16_batch_f32 flag bit 2 / ops.gemm_wfrag_geglu).  2 F % 512 == 0.  Same bits as vxb_gemm_bf16x3_f32 + vxb_geglu_fwd_f32.
+extern "C" int vxb_gemm_wide_geglu_fwd_f32(const float* A, int64_t lda, const void* Bw_frag, const float* bias, float* h, float* gg,
+                                           int M, int F, int K, vxb_stream_t stream) {
+    if (!A || !Bw_frag || !h || !gg || M < 1 || K < 64 || F < 256) return VXB_EARG;
+    if ((F & 255) || (K & 31) || (lda & 3) || (((uintptr_t)A | (uintptr_t)Bw_frag) & 15)) return VXB_ESIZE;
+    GwArgs g;
+    g.A = A; g.lda = lda; g.Bfrag = (const u16*)Bw_frag; g.C = h; g.ldc = 2 * (long long)F; g.bias = bias; g.residual = nullptr;
+    g.M = M; g.K = K; g.act = 0; g.slope = 0.f; g.accumulate = 0;
+    g.geglu = 1; g.F = F; g.C2 = gg; g.H = nullptr;
+    hipLaunchKernelGGL(gemm_wide_x3_kernel, dim3(vxb_cdiv(M, WBM), 2 * F / 512), dim3(512), 0, (hipStream_t)stream, g);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+// Data gradient of the down-projection fused with GEGLU's backward: dh [M][2 F] = geglu'(h) applied to d(gg) = dY [M][K] @ W2 [K][F]
+// (Bw_frag: fragment order of the TRANSPOSED weight's planes [2][F][K], i.e. of the B operand of vxb_gemm_bf16x3_f32 for that data
+// gradient); d(gg) never goes to HBM.  F % 512 == 0.  Same bits as vxb_gemm_bf16x3_f32 + vxb_geglu_bwd_f32.
+extern "C" int vxb_gemm_wide_geglu_bwd_f32(const float* dY, int64_t lda, const void* Bw_frag, const float* h, float* dh, int M, int F,
+                                           int K, vxb_stream_t stream) {
+    if (!dY || !Bw_frag || !h || !dh || M < 1 || K < 64 || F < 512) return VXB_EARG;
+    if ((F & 511) || (K & 31) || (lda & 3) || (((uintptr_t)dY | (uintptr_t)Bw_frag) & 15)) return VXB_ESIZE;
+    GwArgs g;
+    g.A = dY; g.lda = lda; g.Bfrag = (const u16*)Bw_frag; g.C = dh; g.ldc = 2 * (long long)F; g.bias = nullptr; g.residual = nullptr;
+    g.M = M; g.K = K; g.act = 0; g.slope = 0.f; g.accumulate = 0;
+    g.geglu = 2; g.F = F; g.C2 = nullptr; g.H = h;
+    hipLaunchKernelGGL(gemm_wide_x3_kernel, dim3(vxb_cdiv(M, WBM), F / 512), dim3(512), 0, (hipStream_t)stream, g);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }

@@ -477,12 +477,7 @@ __global__ void __launch_bounds__(256) softmax_bwd_rows_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------ GEGLU / lrelu
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
-    return cdf + x * pdf;
-}
+// (gelu_erf / gelu_erf_grad: common.h -- shared with the GEMM epilogues that fuse GEGLU, gemm_wide.hip)
 __global__ void __launch_bounds__(256) geglu_fwd_kernel(const float* __restrict__ h, float* __restrict__ out, long long rows, int F) {
     const long long n = rows * F;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {

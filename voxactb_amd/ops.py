@@ -58,6 +58,24 @@ def gemm_wfrag(wb):
     return f[0]
 
 
+def gemm_wfrag_geglu(wb):
+    """fragment order of the GEGLU up-projection's planes [2][2 F][K] with the rows of every 64-row block interleaved as [32 value rows
+    | their 32 gate rows] (include/voxactb_hip.h: vxb_gemm_wide_geglu_fwd_f32); made by prepare_linear_weights(..., geglu=...) in the
+    step, by a gather + shuffle here otherwise."""
+    key = (wb.data_ptr(), tuple(wb.shape), 'glu')
+    f = _FCACHE.get(key)
+    if f is not None:
+        return f[0]
+    P, N, K = wb.shape
+    F = N // 2
+    q = torch.arange(F, device=wb.device).view(F // 32, 32)
+    idx = torch.cat((q, q + F), dim=1).reshape(-1)                      # position -> source row
+    w3 = wb.index_select(1, idx)
+    f = w3.view(P, N // 32, 32, K // 16, 2, 8).permute(1, 3, 0, 4, 2, 5).contiguous()
+    _FCACHE[key] = (f, wb)
+    return f
+
+
 def new_step():
     """weights change every optimizer step: drop the per-step bf16 weight copies."""
     _WCACHE.clear()
@@ -68,7 +86,7 @@ _WPREP = {}
 BATCH_WEIGHT_SPLIT = os.environ.get('VOXACTB_BATCH_WSPLIT', '1') != '0'      # '0': per-weight splits (A/B runs)
 
 
-def prepare_linear_weights(weights):
+def prepare_linear_weights(weights, geglu=()):
     """bf16 planes of every linear-layer weight of the step, plain AND transposed (the B operands of the forward / data-gradient
     GEMMs), made by ONE launch (vxb_split_bf16_batch_f32) instead of a split + a transposing copy per weight and use; fills the
     cache _bf16_weight() reads.  `weights`: 2-D fp32 tensors (views into the flat parameter arena, so the descriptor table and
@@ -80,7 +98,8 @@ def prepare_linear_weights(weights):
     if not ws:
         return
     npl = 2 if PRECISION == 'bf16x3' else 1
-    key = (tuple(w.data_ptr() for w in ws), tuple(tuple(w.shape) for w in ws), npl)
+    glu = set(w.data_ptr() for w in geglu)      # GEGLU up-projections: their forward fragments get the value / gate interleave
+    key = (tuple(w.data_ptr() for w in ws), tuple(tuple(w.shape) for w in ws), npl, tuple(sorted(glu)))
     ent = _WPREP.get(key)
     if ent is None:
         if len(_WPREP) > 8:
@@ -100,10 +119,11 @@ def prepare_linear_weights(weights):
                 off += npl * N * K
                 tile0 += ((N + 63) // 64) * ((K + 63) // 64)
                 if wants_frag(*shape):
-                    rows.append([w.data_ptr(), buf.data_ptr() + 2 * off, N, K, tr | 2, tile0])
+                    il = 4 if (not tr and w.data_ptr() in glu and N % 512 == 0) else 0
+                    rows.append([w.data_ptr(), buf.data_ptr() + 2 * off, N, K, tr | 2 | il, tile0])
                     n_o, k_o = shape
                     f = buf[off:off + npl * N * K].view(n_o // 32, k_o // 16, npl, 2, 32, 8)
-                    frags.append((v, f))
+                    frags.append((v, f, bool(il)))
                     off += npl * N * K
                     tile0 += ((N + 63) // 64) * ((K + 63) // 64)
         desc = torch.tensor(rows, dtype=torch.int64).to(ws[0].device)
@@ -112,8 +132,8 @@ def prepare_linear_weights(weights):
     call('vxb_split_bf16_batch_f32', desc, n, tiles, npl)
     for (ptr, shape, tr), v in views:
         _WCACHE[(ptr, shape, tr, PRECISION)] = v
-    for v, f in frags:                      # gemm_wfrag(v) finds the fragment-order copy made by the same launch
-        _FCACHE[(v.data_ptr(), tuple(v.shape))] = (f, v)
+    for v, f, il in frags:                  # gemm_wfrag(v) / gemm_wfrag_geglu(v) find the fragment-order copy made by the same launch
+        _FCACHE[(v.data_ptr(), tuple(v.shape)) + (('glu',) if il else ())] = (f, v)
 
 
 def split_bf16(w, x3=None):
@@ -298,6 +318,46 @@ def softmax_rows(S, rows, cols, ld, p=0.0, seed=0):
 def softmax_bwd_rows(P, dP, rows, cols, ld, scale, p=0.0, seed=0):
     call('vxb_softmax_bwd_rows_f32', P, dP, rows, cols, ld, float(scale), float(p), int(seed) & 0xFFFFFFFF)
     return dP
+
+
+FUSE_GEGLU = os.environ.get('VOXACTB_FUSE_GEGLU', '1') != '0'     # GEGLU inside the wide GEMM's epilogues (gemm_wide.hip); '0': separate passes
+
+
+def _geglu_wide_ok(x, rows_out, K):
+    return (FUSE_GEGLU and WIDE_GEMM and GEMM_BD and PRECISION == 'bf16x3' and rows_out % 512 == 0 and K % 32 == 0 and K >= 256
+            and x.shape[0] >= 1024 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
+
+
+def linear_geglu(x, W, bias):
+    """h = x @ W^T + bias [M][2 F] and gg = h[:, :F] * gelu(h[:, F:]) [M][F] (FeedForward's up-projection + GEGLU, perceiver_lang_io.py:
+    74-78, :100-106): one launch on the wide kernel where it applies (same bits as linear() + geglu_fwd())."""
+    M, K = x.shape
+    N = W.shape[0]
+    if _geglu_wide_ok(x, N, K) and W.is_contiguous() and bias is not None:
+        wf = gemm_wfrag_geglu(_bf16_weight(W, False))
+        h = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        gg = torch.empty((M, N // 2), dtype=torch.float32, device=x.device)
+        _lib.set_meta('gemm_fwd %dx%dx%d' % (M, N, K), 2.0 * M * N * K)
+        call('vxb_gemm_wide_geglu_fwd_f32', x, x.stride(0), wf, bias, h, gg, M, N // 2, K)
+        return h, gg
+    h = linear(x, W, bias)
+    return h, geglu_fwd(h)
+
+
+def linear_dgrad_geglu_bwd(dy, W2, h):
+    """dh [M][2 F] = GEGLU'(h) applied to d(gg) = dy [M][K] @ W2 [K][F] (data gradient of FeedForward's down-projection + GEGLU's
+    backward): one launch on the wide kernel where it applies, else None (the caller takes the two-pass route)."""
+    M, K = dy.shape
+    F = W2.shape[1]
+    if not (_geglu_wide_ok(dy, F, K) and W2.is_contiguous() and h.is_contiguous()):
+        return None
+    wf = gemm_wfrag(_bf16_weight(W2, True))
+    if wf is None:
+        return None
+    dh = torch.empty_like(h)
+    _lib.set_meta('gemm_dgrad %dx%dx%d' % (M, F, K), 2.0 * M * F * K)
+    call('vxb_gemm_wide_geglu_bwd_f32', dy, dy.stride(0), wf, h, dh, M, F, K)
+    return dh
 
 
 def geglu_fwd(h):
