@@ -234,7 +234,11 @@ def test_geglu_fused_into_the_wide_gemm_is_bit_identical(M, F, K):
             # backward: dy [M][Kout] @ W2 [Kout][F] -> d(gg) -> dh
             Ko = 512
             W2, dy = (rnd(Ko, F, seed=3) * 0.05).to(DEV), rnd(M, Ko, seed=4).to(DEV)
-            dh = ops.linear_dgrad_geglu_bwd(dy, W2, h0)
+            ops.FUSE_GEGLU_BWD = True                        # (off by default: slower in the step, see ops.py)
+            try:
+                dh = ops.linear_dgrad_geglu_bwd(dy, W2, h0)
+            finally:
+                ops.FUSE_GEGLU_BWD = False
             assert dh is not None
             dgg = torch.empty(M, F, device=DEV)
             ops.linear_bwd(g0, W2, dy, torch.zeros(Ko, F, device=DEV), None, dgg)

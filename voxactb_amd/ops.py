@@ -323,6 +323,12 @@ def softmax_bwd_rows(P, dP, rows, cols, ld, scale, p=0.0, seed=0):
 FUSE_GEGLU = os.environ.get('VOXACTB_FUSE_GEGLU', '1') != '0'     # GEGLU inside the wide GEMM's epilogues (gemm_wide.hip); '0': separate passes
 
 
+# ... and its backward inside the down-projection's data gradient: OFF.  Measured in the step (same box): the fused launch takes 0.63 ms where
+# the wide GEMM (0.235 ms) + vxb_geglu_bwd_f32 (0.264 ms, a streaming pass at 5 TB/s) take 0.50 -- with one workgroup per CU the 1 MB of
+# epilogue traffic and the erf / exp arithmetic of a 128 x 512 tile are serial with its main loop instead of running at full HBM bandwidth.
+FUSE_GEGLU_BWD = os.environ.get('VOXACTB_FUSE_GEGLU_BWD', '0') != '0'
+
+
 def _geglu_wide_ok(x, rows_out, K):
     return (FUSE_GEGLU and WIDE_GEMM and GEMM_BD and PRECISION == 'bf16x3' and rows_out % 512 == 0 and K % 32 == 0 and K >= 256
             and x.shape[0] >= 1024 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
@@ -349,7 +355,7 @@ def linear_dgrad_geglu_bwd(dy, W2, h):
     backward): one launch on the wide kernel where it applies, else None (the caller takes the two-pass route)."""
     M, K = dy.shape
     F = W2.shape[1]
-    if not (_geglu_wide_ok(dy, F, K) and W2.is_contiguous() and h.is_contiguous()):
+    if not (FUSE_GEGLU_BWD and _geglu_wide_ok(dy, F, K) and W2.is_contiguous() and h.is_contiguous()):
         return None
     wf = gemm_wfrag(_bf16_weight(W2, True))
     if wf is None:
