@@ -361,6 +361,18 @@ int vxb_ss3d_max_bwd_f32(const float* x, int64_t bs, int B, int S, int C, const 
                          const float* out_ss, const int32_t* argmax, const float* g_ss, const float* g_max,
                          float* dx, int64_t dbs, int accumulate, vxb_stream_t stream);
 
+/* The patchify data gradient folded into the input conv's weight gradient (perceiver_lang_io.py:357-371: patchify = Conv3DBlock(64 -> 64,
+ * k = stride, replicate padding) on d0 = input_preprocess(voxel grid); the grid is a detached input, agent :100, so d(d0) only feeds
+ * dW_in / db_in): for every (patch p, tap t), v = clamp(k p + t - pad) per axis,
+ *   dW[c][j] += lrelu'(d0[v][c]) * (sum_kout dpatch[p][kout] * Wp[kout][c][t]) * vox[v][j],   db[c] += the same without vox,
+ * i.e. the padding adjoint and the data gradient tensor (4.7 GB at configs[1]) never exist.  Single fp16 products (a leaf): dpatch is
+ * multiplied by scale[0] (device, power of two: vxb_absmax_scale_f32), the sums by scale[1].  wt_f16: fp16 [k^3][64][64] =
+ * Wp[kout][c][t] transposed per tap (t = (kd k + kh) k + kw).  dW [64][10], db [64] ACCUMULATED; ws: ..._ws_floats(k, nsplit) floats. */
+size_t vxb_patch_dgrad_input_wgrad_ws_floats(int k, int nsplit);
+int vxb_patch_dgrad_input_wgrad_f32(const float* dpatch, const void* wt_f16, const float* d0, const float* vox, int B, int V, int G,
+                                    int k, int pad, float slope, const float* scale, float* ws, int nsplit, float* dW, float* db,
+                                    vxb_stream_t stream);
+
 /* PreNorm LayerNorm (perceiver_lang_io.py:56-71), eps 1e-5.  bwd: dgamma/dbeta ACCUMULATED; part_ws: ceil(rows / 32) * 2 * D floats. */
 int vxb_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                           float* rstd, int64_t rows, int D, float eps, vxb_stream_t stream);

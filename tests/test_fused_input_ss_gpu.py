@@ -82,3 +82,38 @@ def test_fused_weight_gradient_with_padding_adjoint():
     for mine, ref, name in ((dW, dW2, 'dW'), (db, db2, 'db')):
         e = float((mine - ref).abs().max()) / float(ref.abs().max())
         assert e < 2e-5, (name, e)
+
+
+@pytest.mark.parametrize('B,V,gain', [(2, 10, 1.0), (1, 23, 3e-7), (3, 12, 2e5)])
+def test_patchify_data_gradient_folded_into_the_input_weight_gradient(B, V, gain):
+    """vxb_patch_dgrad_input_wgrad_f32: the patchify block's data gradient (k = stride = 5, replicate padding 2) never becomes a
+    tensor -- its share of dW_in [64][10] / db_in [64] straight from dpatch, against torch autograd in float64: the gradient of the
+    replicate-padded stride-5 conv w.r.t. d0, times LeakyReLU'(d0), times the voxel inputs.  Ragged grids (V = 23, 12: voxels the
+    patches never reach get nothing), tiny / huge gradients (device-side power-of-two scale), accumulation into non-zero dW / db."""
+    k, pad, C, Cin = 5, 2, 64, 10
+    G = (V + 2 * pad - k) // k + 1
+    d0 = rnd(B, C, V, V, V, seed=1)
+    vox = rnd(B, Cin, V, V, V, seed=2)
+    Wp = rnd(C, C, k, k, k, seed=3) * 0.05
+    dpatch = rnd(B, C, G, G, G, seed=4) * gain
+    x = d0.double().requires_grad_(True)
+    out = F.conv3d(F.pad(x, (pad,) * 6, mode='replicate'), Wp.double(), stride=k)
+    assert out.shape[-1] == G
+    dd0, = torch.autograd.grad(out, x, dpatch.double())
+    m = torch.where(d0 > 0, 1.0, ops.LRELU_SLOPE).double()
+    g = (dd0 * m).permute(0, 2, 3, 4, 1).reshape(-1, C)                       # [voxels][64]
+    xv = vox.double().permute(0, 2, 3, 4, 1).reshape(-1, Cin)
+    dW_ref, db_ref = g.t() @ xv, g.sum(0)
+    cl = lambda t: t.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+    dW = torch.full((C, Cin), 0.25 * gain, device=DEV)
+    db = torch.full((C,), -0.5 * gain, device=DEV)
+    keep = ops.PRECISION, ops.WGRAD_PRECISION
+    ops.PRECISION, ops.WGRAD_PRECISION = 'bf16x3', 'fp16'
+    try:
+        assert ops.patch_dgrad_input_wgrad_ok(k, k, C, Cin)
+        ops.patch_dgrad_input_wgrad(cl(dpatch), Wp.to(DEV), cl(d0), cl(vox), dW, db, B, V, G, k, pad)
+    finally:
+        ops.PRECISION, ops.WGRAD_PRECISION = keep
+    eW = float((dW.double().cpu() - 0.25 * gain - dW_ref).abs().max() / dW_ref.abs().max())
+    eb = float((db.double().cpu() + 0.5 * gain - db_ref).abs().max() / db_ref.abs().max())
+    assert eW < 2e-3 and eb < 2e-3, (eW, eb)

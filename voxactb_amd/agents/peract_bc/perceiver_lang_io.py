@@ -819,7 +819,13 @@ class PerceiverEngine:
         dWt = ops.conv3d_wgrad(d0, dpatch, C, B, V, G, k, -pk, stride=s, grad_key=('conv', Wp.data_ptr()))
         self.g('patchify.conv3d.weight').add_(dWt.view(k ** 3, C, C).permute(2, 1, 0).reshape(Wp.shape))
         ops.colsum(dpatch, self.g('patchify.conv3d.bias'), accumulate=True)
-        if s > 1:
+        gW_in, gb_in = self.g('input_preprocess.conv3d.weight').view(C, -1), self.g('input_preprocess.conv3d.bias')
+        dxp, Sp = None, 0
+        if fuse_ss0 and ops.patch_dgrad_input_wgrad_ok(k, s, C, c['vox'].shape[-1]) and dpatch.is_contiguous():
+            # the patchify data gradient only feeds the input conv's weight gradient (the voxel grid is a detached input): its share
+            # of dW_in / db_in straight from dpatch, no 105^3 x 64 gradient tensor (patch_wgrad.hip)
+            ops.patch_dgrad_input_wgrad(dpatch, Wp, d0, c['vox'], gW_in, gb_in, B, V, G, k, pk)
+        elif s > 1:
             wtp, U = ops.strided_dgrad_weights(Wp, s)
             Gp = (V + 2 * pk + s - 1) // s
             dxp = ops.conv3d(dpatch, wtp, s ** 3 * C, B, G, Gp, U, -(U - 1), replicate=False, d2s=(s, C))
@@ -832,11 +838,9 @@ class PerceiverEngine:
         # ---- input conv (its LeakyReLU' is applied inside the weight-gradient kernel)
         if fuse_ss0:
             ss, mx, st, am = c['ss0']
-            ops.pointwise_wgrad_ss3d(c['vox'], d0, dd0, self.g('input_preprocess.conv3d.weight').view(C, -1),
-                                     self.g('input_preprocess.conv3d.bias'), B, V, st, ss, am, gs[0], gs[1], fold_src=dxp, Sp=Sp, pad=pk)
+            ops.pointwise_wgrad_ss3d(c['vox'], d0, dd0, gW_in, gb_in, B, V, st, ss, am, gs[0], gs[1], fold_src=dxp, Sp=Sp, pad=pk)
         else:
-            ops.pointwise_wgrad(c['vox'], d0, dd0, self.g('input_preprocess.conv3d.weight').view(C, -1),
-                                self.g('input_preprocess.conv3d.bias'))
+            ops.pointwise_wgrad(c['vox'], d0, dd0, gW_in, gb_in)
         self._bucket_ready('head')
 
     def _bucket_ready(self, name):

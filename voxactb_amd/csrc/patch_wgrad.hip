@@ -1,0 +1,180 @@
+// The patchify data gradient folded straight into the input conv's weight gradient (perceiver_lang_io.py:357-371 forward;
+// backward of patchify = Conv3DBlock(k = stride = 5, replicate padding 2) into input_preprocess = Conv3DBlock(10 -> 64, k = 1)).
+//
+// d(d0) receives three terms: `final`'s data gradient, the pooled-feature term of d0's SpatialSoftmax3D, and the patchify data
+// gradient.  The voxel grid is a detached input (agent :100), so d(d0) feeds NOTHING but dW_in [64][10] and db_in [64] -- and those
+// are linear in d(d0):   dW_in[c][j] = sum_v lrelu'(d0[v][c]) * d(d0)[v][c] * vox[v][j].
+// The patchify term used to travel as a tensor: a 1^3 GEMM with 8000 output columns wrote it on the padded 105^3 grid (4.7 GB, 1.7 ms)
+// and vxb_pointwise_wgrad_ss3d_f32 gathered it back through the padding adjoint (4.7 of its 13.6 GB).  With non-overlapping patches
+// every (patch p, tap t) pair is ONE voxel v = clamp(5 p + t - 2) (the replicate padding's adjoint is that clamp), so the term is
+//     sum over (p, t) of  lrelu'(d0[v][c]) * G[p][t][c] * vox[v][j],      G[p][t][c] = sum_k dpatch[p][k] * Wp[k][c][t],
+// and G never needs to exist outside registers: a workgroup owns one tap (its 64 x 64 weight slice stays in registers as MFMA B
+// fragments) and streams over patches, 32 per wave and step: G tile by v_mfma_f32_32x32x16_f16 (a leaf of the backward pass: single
+// fp16 products, dpatch scaled by a power of two taken on the device), then per accumulator row the voxel's LeakyReLU' mask
+// and its 10 inputs, 22 running sums per lane.  Deterministic: per-workgroup partials in a fixed order, a second kernel adds them up.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+constexpr int PCIN = 10;             // channels of the voxel grid
+
+struct PgArgs {
+    const float* dpatch;     // [B, G^3, 64] fp32 (after the patchify block's LeakyReLU')
+    const u16* wt;           // fp16 [k^3][64 c][64 kout]: Wp[kout][c][tap] transposed per tap (ops.patch_dgrad_weights)
+    const float* d0;         // [B, V^3, 64] output of the input conv (its sign = LeakyReLU')
+    const float* vox;        // [B, V^3, 10]
+    const float* scale;      // {s, 1 / s}: dpatch is multiplied by s before the conversion to half
+    float* part;             // [k^3 * Z][64][11] partial sums (scaled by s)
+    int B, V, G, k, pad, Z;
+    float slope;
+    unsigned magic;          // floor(2^32 / G) + 1: p / G == __umulhi(p, magic) for p * G < 2^32 (host-checked)
+};
+
+__global__ void __launch_bounds__(256) patch_wgrad_kernel(PgArgs g) {
+    __shared__ float red[4][64][PCIN + 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lm = lane & 31, half = lane >> 5;
+    const int tap = blockIdx.x, z = blockIdx.y;
+    const int tw = tap % g.k, th = (tap / g.k) % g.k, td = tap / (g.k * g.k);
+    const int G = g.G, V = g.V;
+    const long long P = (long long)g.B * G * G * G;
+    // B fragments of this tap: lane (col n = lm, k half) holds Wt[tap][32 j + n][16 ks + 8 half .. + 7]
+    f16x8 bf[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            bf[j][ks] = *reinterpret_cast<const f16x8*>(g.wt + ((long long)(tap * 64 + 32 * j + lm)) * 64 + 16 * ks + 8 * half);
+    const float sc = g.scale[0];
+    float aw[2][PCIN], ab[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        ab[j] = 0.f;
+#pragma unroll
+        for (int e = 0; e < PCIN; ++e) aw[j][e] = 0.f;
+    }
+    // this workgroup's slice of the patches, 128 per step (32 per wave)
+    const long long per = (P + g.Z - 1) / g.Z;
+    const long long p_begin = (long long)z * per, p_end = min(P, p_begin + per);
+    for (long long p0 = p_begin + wid * 32; p0 < p_end; p0 += 128) {
+        // A fragments: lane (row = patch p0 + lm, k half)
+        const long long pr = min(p0 + lm, P - 1);
+        f16x8 af[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float4 u = *reinterpret_cast<const float4*>(g.dpatch + pr * 64 + 16 * ks + 8 * half);
+            const float4 w = *reinterpret_cast<const float4*>(g.dpatch + pr * 64 + 16 * ks + 8 * half + 4);
+            union { unsigned x[4]; f16x8 v; } t;
+            t.x[0] = vxb_pack_f16(u.x * sc, u.y * sc); t.x[1] = vxb_pack_f16(u.z * sc, u.w * sc);
+            t.x[2] = vxb_pack_f16(w.x * sc, w.y * sc); t.x[3] = vxb_pack_f16(w.z * sc, w.w * sc);
+            af[ks] = t.v;
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], bf[j][ks], acc[j], 0, 0, 0);
+        }
+        // acc[j][r] = G[patch p0 + (r & 3) + 8 (r >> 2) + 4 half][c = 32 j + lm]
+        const unsigned pbase = (unsigned)p0 + 4u * (unsigned)half, pend = (unsigned)p_end;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // (no branch per row: rows past the slice re-read its last patch and contribute zero, so that the loads of all 16 rows
+            // can be in flight together)
+            const unsigned pu = pbase + (unsigned)((r & 3) + 8 * (r >> 2));
+            const bool live = pu < pend;
+            const unsigned p = live ? pu : pend - 1u;
+            // (b, pd, ph, pw) of patch p by multiply-high divisions (64-bit % and / cost ~100 instructions each: the first version of
+            // this kernel spent 3.7 ms on them)
+            const unsigned q1 = __umulhi(p, g.magic), q2 = __umulhi(q1, g.magic), q3 = __umulhi(q2, g.magic);
+            const int pw = (int)(p - q1 * (unsigned)G), ph = (int)(q1 - q2 * (unsigned)G), pd = (int)(q2 - q3 * (unsigned)G), b = (int)q3;
+            const int vw = min(max(pw * g.k + tw - g.pad, 0), V - 1);
+            const int vh = min(max(ph * g.k + th - g.pad, 0), V - 1);
+            const int vd = min(max(pd * g.k + td - g.pad, 0), V - 1);
+            const long long v = (long long)(((b * V + vd) * V + vh) * V + vw);          // < 2^31 (host-checked)
+            const float* xv = g.vox + v * PCIN;
+            float x[PCIN];
+#pragma unroll
+            for (int e = 0; e < PCIN; e += 2) {                       // (40-byte rows: 8-byte aligned)
+                const float2 t = *reinterpret_cast<const float2*>(xv + e);
+                x[e] = t.x; x[e + 1] = t.y;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float y = g.d0[v * 64 + 32 * j + lm];
+                float d = live ? acc[j][r] : 0.f;
+                d = y > 0.f ? d : d * g.slope;
+                ab[j] += d;
+#pragma unroll
+                for (int e = 0; e < PCIN; ++e) aw[j][e] = fmaf(d, x[e], aw[j][e]);
+            }
+        }
+    }
+    // fold the two row halves of a wave, then the four waves, in a fixed order
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int e = 0; e <= PCIN; ++e) {
+            float s = e < PCIN ? aw[j][e < PCIN ? e : 0] : ab[j];
+            s += __shfl_xor(s, 32, 64);
+            if (half == 0) red[wid][32 * j + lm][e] = s;
+        }
+    }
+    __syncthreads();
+    float* out = g.part + ((long long)tap * g.Z + z) * 64 * (PCIN + 1);
+    for (int i = tid; i < 64 * (PCIN + 1); i += 256) {
+        const int c = i / (PCIN + 1), e = i - c * (PCIN + 1);
+        out[i] = (red[0][c][e] + red[1][c][e]) + (red[2][c][e] + red[3][c][e]);
+    }
+}
+
+// dW[c][j] += inv * sum_n part[n][c][j], db[c] += inv * sum_n part[n][c][10]: one thread per output, partials in index order
+__global__ void __launch_bounds__(256) patch_wgrad_finish_kernel(const float* __restrict__ part, int n, const float* __restrict__ scale,
+                                                                 float* __restrict__ dW, float* __restrict__ db) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 64 * (PCIN + 1)) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < n; k += 4) {
+        s0 += part[(long long)k * 704 + i]; s1 += part[(long long)(k + 1) * 704 + i];
+        s2 += part[(long long)(k + 2) * 704 + i]; s3 += part[(long long)(k + 3) * 704 + i];
+    }
+    for (; k < n; ++k) s0 += part[(long long)k * 704 + i];
+    const float s = ((s0 + s1) + (s2 + s3)) * scale[1];
+    const int c = i / (PCIN + 1), e = i - c * (PCIN + 1);
+    if (e < PCIN) dW[c * PCIN + e] += s; else db[c] += s;
+}
+
+}  // namespace
+
+extern "C" size_t vxb_patch_dgrad_input_wgrad_ws_floats(int k, int nsplit) { return (size_t)k * k * k * (nsplit > 0 ? nsplit : 1) * 704; }
+
+// The patchify data gradient's contribution to the input conv's weight / bias gradient, without the data gradient tensor (see the head
+// of this file): dpatch [B, G^3, 64] (gradient of the patchify block's pre-activation), wt_f16 = fp16 [k^3][64][64] with
+// wt[t][c][kout] = Wp[kout][c][t] (t = (kd k + kh) k + kw), d0 [B, V^3, 64] = output of the input conv, vox [B, V^3, 10] its input,
+// patches of size k at stride k with replicate padding `pad` (G = ceil((V + 2 pad - k) / k) + 1 patches per axis);
+// scale = {s, 1 / s} on the device (vxb_absmax_scale_f32 of dpatch).  dW [64][10] and db [64] are ACCUMULATED.
+// ws: vxb_patch_dgrad_input_wgrad_ws_floats(k, nsplit) floats.
+extern "C" int vxb_patch_dgrad_input_wgrad_f32(const float* dpatch, const void* wt_f16, const float* d0, const float* vox, int B, int V,
+                                               int G, int k, int pad, float slope, const float* scale, float* ws, int nsplit,
+                                               float* dW, float* db, vxb_stream_t stream) {
+    if (!dpatch || !wt_f16 || !d0 || !vox || !scale || !ws || !dW || !db || B < 1 || V < 1 || G < 1 || k < 1 || nsplit < 1) return VXB_EARG;
+    if ((((uintptr_t)dpatch | (uintptr_t)wt_f16) & 15) || (((uintptr_t)vox) & 7) || nsplit > 65535) return VXB_ESIZE;
+    if ((long long)B * V * V * V >= INT32_MAX || (long long)B * G * G * G * G >= (1ll << 32) || G < 2) return VXB_ESIZE;
+    PgArgs g;
+    g.magic = (unsigned)((1ull << 32) / (unsigned)G) + 1u;
+    g.dpatch = dpatch; g.wt = (const u16*)wt_f16; g.d0 = d0; g.vox = vox; g.scale = scale; g.part = ws;
+    g.B = B; g.V = V; g.G = G; g.k = k; g.pad = pad; g.Z = nsplit; g.slope = slope;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(patch_wgrad_kernel, dim3(k * k * k, nsplit), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(patch_wgrad_finish_kernel, dim3(vxb_cdiv(704, 256)), dim3(256), 0, st, ws, k * k * k * nsplit, scale, dW, db);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
