@@ -259,6 +259,12 @@ size_t vxb_conv3_dgrad_fold_blocks(int B, int S, int N);
  * gradient, which only feeds the weight gradient of the 1x1x1 input conv (a leaf of the backward pass). */
 int vxb_conv3_dgrad_fold_f16_f32(const float* dy, int C0, int B, int S, const void* wfrag_f16, float* dst, const float* y,
                                  int acc, float slope, const float* scale, vxb_stream_t stream);
+/* ... when that block is the data gradient of a 1x1x1 conv's output y = lrelu(W_in x + b_in) whose input x [B, S^3, 10] is a detached
+ * tensor (the input conv of the Q-function, perceiver_lang_io.py:357; agent :100): it only feeds dW_in [64][10] / db_in [64], so it is
+ * not stored -- the epilogue multiplies it with LeakyReLU'(y) and x, and the sums are ACCUMULATED into dW / db.
+ * ws: 704 * (vxb_conv3_dgrad_fold_blocks(B, S, 64) + 512) floats. */
+int vxb_conv3_dgrad_fold_f16_wgin_f32(const float* dy, int C0, int B, int S, const void* wfrag_f16, const float* y, const float* x,
+                                      float slope, const float* scale, float* ws, float* dW, float* db, vxb_stream_t stream);
 /* LDS-halo weight gradient of the same 3x3x3 stride-1 convs (contract of vxb_conv3d_wgrad_f32 with kext = 3, stride = 1;
  * the z slices of part[z][K][N] are runs of 128-voxel tiles, 2x8x8 or 4x4x8 -- chosen by the voxels wasted on the
  * edge of an S_out^3 grid; vxb_conv3_wgrad_halo_tiles returns their number).  C0, C1 % 16 == 0, N % 64 == 0; d2s needs
@@ -332,7 +338,8 @@ size_t vxb_conv3_c1_wgrad_mfma_blocks(int B, int S);
  * registers (bit-identical to vxb_pointwise_fwd_f32 + vxb_ss3d_max_fwd_f32, one pass less over 256 B per voxel); the
  * weight gradient adds the term vxb_ss3d_max_bwd_f32 would have written into dy on the fly, and (fold_src != NULL) the
  * padding adjoint vxb_fold_pad_f32 would have added to dy from a [B, Sp^3, 64] data gradient.  x [B,S,S,S,Cin], y / dy
- * [B,S,S,S,64]; part_ws as for vxb_ss3d_max_fwd_f32 (C = 64), resp. B * ceil(S^3 / 4096) * (64*Cin + 64) floats. */
+ * [B,S,S,S,64] (dy may be NULL: only the pooled-feature and fold_src terms, when every conv path into y has added its share of
+ * dW / db itself: vxb_conv3_dgrad_fold_f16_wgin_f32, vxb_patch_dgrad_input_wgrad_f32); part_ws as for vxb_ss3d_max_fwd_f32 (C = 64), resp. B * ceil(S^3 / 4096) * (64*Cin + 64) floats. */
 int vxb_pointwise_ss3d_fwd_f32(const float* x, const float* W, const float* bias, float* y, int B, int S, int Cin, int Cout,
                                float slope, const float* lin, float* part_ws, float* out_ss, float* out_max, float* stats,
                                int32_t* argmax, vxb_stream_t stream);

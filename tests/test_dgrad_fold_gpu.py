@@ -110,3 +110,40 @@ def test_fused_operand_scales_equal_the_absmax_pass():
     db = torch.zeros(64, device=DEV)
     _, sc_du = ops.conv3_c1_dgrad_ss3d(dq, w, u, du, B, S, st, ss, am, gss, gmx, db, want_scale=True)
     assert torch.equal(sc_du, ops.absmax_scale(du))
+
+
+@pytest.mark.parametrize('B,S,gain', [(2, 18, 1.0), (1, 22, 1e-6), (1, 100, 1.0), (2, 38, 1.0)])
+def test_leaf_block_folded_into_the_input_weight_gradient(B, S, gain):
+    """vxb_conv3_dgrad_fold_f16_wgin_f32: the d(d0) block of `final`'s data gradient is not stored -- its epilogue multiplies it with
+    LeakyReLU'(d0) and the voxel inputs and accumulates dW_in [64][10] / db_in [64]: against the stored-tensor route (same fp16
+    kernel, then the products in float64)."""
+    from .test_ops_gpu import rnd, cl, DEV
+    C = 64
+    du = cl(rnd(B, C, S, S, S, seed=1) * gain).to(DEV)
+    Wf = (rnd(C, 2 * C, 3, 3, 3, seed=2) * 0.05).to(DEV)
+    d0 = cl(rnd(B, C, S, S, S, seed=3)).to(DEV)
+    u0 = cl(rnd(B, C, S, S, S, seed=4)).to(DEV)
+    vox = cl(rnd(B, 10, S, S, S, seed=5)).to(DEV)
+    keep = ops.PRECISION, ops.WGRAD_PRECISION, ops.WGIN_FOLD
+    ops.PRECISION, ops.WGRAD_PRECISION, ops.WGIN_FOLD = 'bf16x3', 'fp16', True      # (the fold is opt-in: VOXACTB_WGIN_FOLD=1)
+    try:
+        assert ops.wgin_fold_ok(C, 2 * C, S, 10)
+        wt = ops.conv_weight_dgrad(Wf)
+        dd0, du0 = torch.empty_like(d0), torch.empty_like(d0)
+        ops.conv3_dgrad_fold(du, wt, B, S, 2 * C, [(dd0, False, None), (du0, False, u0)], leaf_blocks=(0,))
+        g = (dd0.double() * torch.where(d0 > 0, 1.0, ops.LRELU_SLOPE).double()).view(-1, C)
+        dW_ref, db_ref = g.t() @ vox.double().view(-1, 10), g.sum(0)
+        dW, db = torch.full((C, 10), 0.5 * gain, device=DEV), torch.full((C,), -0.25 * gain, device=DEV)
+        du0b = torch.empty_like(d0)
+        ops.conv3_dgrad_fold(du, wt, B, S, 2 * C, [(None, False, None), (du0b, False, u0)], leaf_blocks=(0,),
+                             wgin={0: (d0, vox, dW, db)})
+        dW2, db2 = torch.full((C, 10), 0.5 * gain, device=DEV), torch.full((C,), -0.25 * gain, device=DEV)
+        ops.conv3_dgrad_fold(du, wt, B, S, 2 * C, [(None, False, None), (du0b, False, u0)], leaf_blocks=(0,),
+                             wgin={0: (d0, vox, dW2, db2)})
+    finally:
+        ops.PRECISION, ops.WGRAD_PRECISION, ops.WGIN_FOLD = keep
+    assert torch.equal(du0, du0b)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)        # fixed-order sums: the same bits every run
+    eW = float((dW.double() - 0.5 * gain - dW_ref).abs().max() / dW_ref.abs().max())
+    eb = float((db.double() + 0.25 * gain - db_ref).abs().max() / db_ref.abs().max())
+    assert eW < 2e-5 and eb < 2e-5, (eW, eb)

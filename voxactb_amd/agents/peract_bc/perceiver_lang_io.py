@@ -712,10 +712,17 @@ class PerceiverEngine:
             ops.colsum(du.view(-1, C), self.g('final.conv3d.bias'), accumulate=True)
         sc_du0 = None
         du0_bias_done = False
-        dd0 = E(B, V, V, V, C)
         # the pooled-feature gradient of d0 (ss0) is added inside the input conv's weight-gradient kernel, the last reader of
         # dd0; otherwise it is dd0's first writer
         fuse_ss0 = C == 64 and FUSE_INPUT_SS and c['vox'].shape[-1] == 10
+        Wp = self.p('patchify.conv3d.weight')
+        gW_in, gb_in = self.g('input_preprocess.conv3d.weight').view(C, -1), self.g('input_preprocess.conv3d.bias')
+        # d(d0) only feeds the input conv's weight gradient (the voxel grid is a detached input): when every conv path into d0 can add
+        # its share of dW_in / db_in itself -- `final`'s data gradient in its fold epilogue, the patchify data gradient in
+        # patch_wgrad.hip -- the 4.1 GB tensor dd0 never exists and the input conv's kernel only adds the pooled-feature term
+        no_dd0 = (fuse_ss0 and ops.wgin_fold_ok(C, 2 * C, V, c['vox'].shape[-1])
+                  and ops.patch_dgrad_input_wgrad_ok(k, s, C, c['vox'].shape[-1]))
+        dd0 = None if no_dd0 else E(B, V, V, V, C)
         if not fuse_ss0:
             ss, mx, st, am = c['ss0']
             ops.ss3d_max_bwd(d0, V ** 3 * C, B, V, C, st, ss, am, gs[0], gs[1], dd0, V ** 3 * C)
@@ -727,7 +734,8 @@ class PerceiverEngine:
             # a leaf -- its column block may run on single fp16 products; d(u0) propagates through the decoder and stays bf16x3
             up2b = 'up0.conv_up.%d.conv3d.bias' % (2 if s > 1 else 1)
             sc_du0 = ops.conv3_dgrad_fold(du, ops.conv_weight_dgrad(Wf), B, V, 2 * C, [(dd0, not fuse_ss0, None), (du0, False, u0)],
-                                          dy_scale=sc_du, leaf_blocks=(0,), scale_blocks=(1,), colsum_into={1: self.g(up2b)}).get(1)
+                                          dy_scale=sc_du, leaf_blocks=(0,), scale_blocks=(1,), colsum_into={1: self.g(up2b)},
+                                          wgin={0: (d0, c['vox'], gW_in, gb_in)} if no_dd0 else None).get(1)
             du0_bias_done = True
         else:
             dcat = ops.conv3d(du, ops.conv_weight_dgrad(Wf), 2 * C, B, V, V + 2, 3, -2, replicate=False)
@@ -815,13 +823,12 @@ class PerceiverEngine:
                        self.g('proprio_preprocess.linear.bias'))
         # ---- patchify
         ops.lrelu_bwd_(dpatch, c['patch'])
-        Wp = self.p('patchify.conv3d.weight')
         dWt = ops.conv3d_wgrad(d0, dpatch, C, B, V, G, k, -pk, stride=s, grad_key=('conv', Wp.data_ptr()))
         self.g('patchify.conv3d.weight').add_(dWt.view(k ** 3, C, C).permute(2, 1, 0).reshape(Wp.shape))
         ops.colsum(dpatch, self.g('patchify.conv3d.bias'), accumulate=True)
-        gW_in, gb_in = self.g('input_preprocess.conv3d.weight').view(C, -1), self.g('input_preprocess.conv3d.bias')
         dxp, Sp = None, 0
-        if fuse_ss0 and ops.patch_dgrad_input_wgrad_ok(k, s, C, c['vox'].shape[-1]) and dpatch.is_contiguous():
+        if fuse_ss0 and ops.patch_dgrad_input_wgrad_ok(k, s, C, c['vox'].shape[-1]) and (dpatch.is_contiguous() or no_dd0):
+            dpatch = dpatch.contiguous()
             # the patchify data gradient only feeds the input conv's weight gradient (the voxel grid is a detached input): its share
             # of dW_in / db_in straight from dpatch, no 105^3 x 64 gradient tensor (patch_wgrad.hip)
             ops.patch_dgrad_input_wgrad(dpatch, Wp, d0, c['vox'], gW_in, gb_in, B, V, G, k, pk)

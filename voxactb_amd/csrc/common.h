@@ -27,6 +27,9 @@ int vxb_c1_dgrad4_ss_launch(const float* dq, const float* w, const float* u, flo
 // scale[0] = 2^k mapping the largest of n per-block |x| maxima (magnitude bits) into [2^14, 2^15), scale[1] = 1 / scale[0] (nn_ops.hip)
 int vxb_absmax_finish_launch(const unsigned* part, int n, float* scale, hipStream_t st, int headroom_bits = 0);
 // out[64] += column sums of part[nrows][64] in a fixed order; part must have room for 64 more rows behind the nrows (c1_conv.hip)
+// dW [64][10] += scale[1] * sum_n part[n][c][0..9], db [64] += scale[1] * sum_n part[n][c][10] (part: n x [64][11]); patch_wgrad.hip
+constexpr int VXB_WGIN_FINISH_ROWS = 512;
+int vxb_wgin_finish_launch(float* part, int n, const float* scale, float* dW, float* db, hipStream_t st);
 int vxb_rows64_sum_launch(float* part, int nrows, float* out, hipStream_t st);
 int vxb_c1_dgrad4_launch(const float* dq, const float* w, const float* u, float* du, int B, int S, int accumulate, int mask,
                          float slope, hipStream_t st);

@@ -70,6 +70,12 @@ struct HaloArgs {
     unsigned* amax_part;     // fold mode, optional: word [workgroup] = largest magnitude (bits) this workgroup wrote to its destination
     float* colsum_part;      // fold mode, optional: [workgroup][64] = column sums of what this workgroup wrote (the bias gradient of the
                              // conv that produced the destination's activation, taken on the way instead of by a pass over 4 GB)
+    // fold mode, 64-column fp16 launches, fold_acc[1] == 2 ("wgin"; the second block's fields are free there and carry the operands,
+    // so that the argument block -- and with it the register allocation of every other variant -- stays as it was): the destination
+    // is the output of a 1x1x1 conv of x = fold_y[1] [B, S^3, 10] whose data gradient nothing else reads (the input conv of the
+    // Q-function: the voxel grid is a detached input, agent :100) -- instead of storing the folded gradient, its share of that conv's
+    // weight / bias gradient is accumulated on the spot: fold_dst[1] [workgroup][64][11] = sum over the workgroup's voxels of
+    // g[c] * {x[0..9], 1}, g after fold_y[0]'s LeakyReLU' (still multiplied by the fp16 operand scale: the finishing kernel undoes it)
 };
 
 // bf16 pair from two fp32 (RNE).  Both forms give identical bits; which one is FASTER was measured per precision on the
@@ -478,6 +484,83 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
             }
         }
         __syncthreads();
+        if constexpr (PM == 2) {
+            if (g.fold_acc[1] == 2) {           // "wgin" (uniform): see HaloArgs
+                const int P = g.fold_pad, S = g.fold_S;
+                const float* __restrict__ yv = g.fold_y[0];
+                const float* __restrict__ wgin_x = g.fold_y[1];
+                float* __restrict__ wgin_part = g.fold_dst[1];
+                float wgx[4][10], wgb[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    wgb[e] = 0.f;
+#pragma unroll
+                    for (int jx = 0; jx < 10; ++jx) wgx[e][jx] = 0.f;
+                }
+                for (int item = tid; item < TD * TH * TW * 16; item += NTH) {
+                    const int c4 = (item & 15) * 4, pos = item >> 4;
+                    const int wl = pos % TW, hl = (pos / TW) % TH, dl = pos / (TW * TH);
+                    const int id = d0 + dl, ih = h0 + hl, iw = w0 + wl;
+                    if (id >= g.S_out || ih >= g.S_out || iw >= g.S_out) continue;
+                    if ((id >= 1 && id <= P) || id > S - 1 + P || (ih >= 1 && ih <= P) || ih > S - 1 + P || (iw >= 1 && iw <= P) || iw > S - 1 + P) continue;
+                    const int nd = (id == 0 || id == S - 1 + P) ? P + 1 : 1;
+                    const int nh = (ih == 0 || ih == S - 1 + P) ? P + 1 : 1;
+                    const int nw = (iw == 0 || iw == S - 1 + P) ? P + 1 : 1;
+                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int dd = 0; dd < nd; ++dd)
+                        for (int hh = 0; hh < nh; ++hh)
+                            for (int ww = 0; ww < nw; ++ww) {
+                                const float4 v = *reinterpret_cast<const float4*>(&ft[(((dl + dd) * TH + hl + hh) * TW + wl + ww) * 64 + c4]);
+                                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+                            }
+                    const int jd = min(max(id - P, 0), S - 1), jh = min(max(ih - P, 0), S - 1), jw = min(max(iw - P, 0), S - 1);
+                    const long long vox = (((long long)b * S + jd) * S + jh) * S + jw;
+                    const float4 yy = *reinterpret_cast<const float4*>(yv + vox * 64 + c4);
+                    a.x = yy.x > 0.f ? a.x : a.x * g.slope; a.y = yy.y > 0.f ? a.y : a.y * g.slope;
+                    a.z = yy.z > 0.f ? a.z : a.z * g.slope; a.w = yy.w > 0.f ? a.w : a.w * g.slope;
+                    const float* xv = wgin_x + vox * 10;
+                    float xr[10];
+#pragma unroll
+                    for (int jx = 0; jx < 10; jx += 2) {
+                        const float2 t2 = *reinterpret_cast<const float2*>(xv + jx);
+                        xr[jx] = t2.x; xr[jx + 1] = t2.y;
+                    }
+                    // every input value in a register of its own, so that the packed fp32 FMAs below take it as the low half of their
+                    // operand.  With the odd values picked out of a loaded register pair instead (v_pk_fma_f32 ... op_sel:[0,1,0], what
+                    // the compiler emits without this) the LOW lane of the result missed a term in about one workgroup in 15, differently
+                    // from run to run; build with -DWGIN_NO_OPAQUE to see it (tools/experiments/README.md, wgin_pk_fma_repro.py)
+#ifndef WGIN_NO_OPAQUE
+#pragma unroll
+                    for (int jx = 0; jx < 10; ++jx) asm volatile("" : "+v"(xr[jx]));
+#endif
+                    const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        wgb[e] += av[e];
+#pragma unroll
+                        for (int jx = 0; jx < 10; ++jx) wgx[e][jx] = fmaf(av[e], xr[jx], wgx[e][jx]);
+                    }
+                }
+                // fixed-order fold of the NTH / 16 threads that share a channel quad: 11 values (10 inputs + bias) per channel
+                __syncthreads();                // everyone is done reading the fp32 tile in ft
+                float4* wred = reinterpret_cast<float4*>(ft);          // [11][NTH] float4 (45 KB at 256 threads)
+#pragma unroll
+                for (int jx = 0; jx < 10; ++jx) wred[jx * NTH + tid] = make_float4(wgx[0][jx], wgx[1][jx], wgx[2][jx], wgx[3][jx]);
+                wred[10 * NTH + tid] = make_float4(wgb[0], wgb[1], wgb[2], wgb[3]);
+                __syncthreads();
+                for (int t2 = tid; t2 < 16 * 11; t2 += NTH) {
+                    const int quad = t2 & 15, jx = t2 >> 4;
+                    float4 acc4 = wred[jx * NTH + quad];
+                    for (int j2 = 1; j2 < NTH / 16; ++j2) {
+                        const float4 b4 = wred[jx * NTH + quad + 16 * j2];
+                        acc4.x += b4.x; acc4.y += b4.y; acc4.z += b4.z; acc4.w += b4.w;
+                    }
+                    float* po = wgin_part + (long long)blockIdx.x * 704 + (quad * 4) * 11 + jx;
+                    po[0] = acc4.x; po[11] = acc4.y; po[22] = acc4.z; po[33] = acc4.w;
+                }
+                return;
+            }
+        }
         const int nb = n0 / N, P = g.fold_pad, S = g.fold_S;
         float* __restrict__ dst = g.fold_dst[nb];
         const float* __restrict__ yv = g.fold_y[nb];
@@ -727,4 +810,27 @@ extern "C" int vxb_conv3_dgrad_fold_f16_f32(const float* dy, int C0, int B, int 
     f.amax_part = nullptr; f.colsum_part = nullptr;
     return hb_impl(2, dy, nullptr, C0, 0, B, S, S_out, -2 * pad, 0, wfrag_f16, 64, nullptr, nullptr, 0, slope, 0, 0, 0, stream, &f,
                    wfrag_f16, nullptr, 0, 0, 0, scale);
+}
+
+// The same launch when the 64-column block is the data gradient of a 1x1x1 conv's OUTPUT y [B, S^3, 64] = lrelu(W_in x + b_in) whose
+// input x [B, S^3, 10] is a detached tensor (the input conv of the Q-function, perceiver_lang_io.py:357; agent :100): that gradient only
+// feeds dW_in [64][10] / db_in [64], so it is not stored -- the epilogue multiplies it with LeakyReLU'(y) and the voxel's inputs and the
+// sums are ACCUMULATED into dW / db (4.1 GB less written here, 4.1 GB less read by vxb_pointwise_wgrad_ss3d_f32).
+// ws: 704 * (vxb_conv3_dgrad_fold_blocks(B, S, 64) + 512) floats.
+extern "C" int vxb_conv3_dgrad_fold_f16_wgin_f32(const float* dy, int C0, int B, int S, const void* wfrag_f16, const float* y,
+                                                 const float* x, float slope, const float* scale, float* ws, float* dW, float* db,
+                                                 vxb_stream_t stream) {
+    if (!dy || !wfrag_f16 || !y || !x || !scale || !ws || !dW || !db || S < 2) return VXB_EARG;
+    if ((((uintptr_t)x) & 7) || (((uintptr_t)y) & 15)) return VXB_ESIZE;
+    const int pad = 1, S_out = S + 2 * pad;
+    if ((S_out - 1 - pad) / TD != (S_out - 1) / TD || (S_out - 1 - pad) / TH != (S_out - 1) / TH || (S_out - 1 - pad) / TW != (S_out - 1) / TW)
+        return VXB_ESIZE;
+    HaloArgs f;
+    f.fold_pad = pad; f.fold_S = S; f.fold_dst[0] = ws /* (never written in this mode) */; f.fold_dst[1] = ws;
+    f.fold_y[0] = y; f.fold_y[1] = x; f.fold_acc[0] = 0; f.fold_acc[1] = 2;          // "wgin": see HaloArgs
+    f.amax_part = nullptr; f.colsum_part = nullptr;
+    int rc = hb_impl(2, dy, nullptr, C0, 0, B, S, S_out, -2 * pad, 0, wfrag_f16, 64, nullptr, nullptr, 0, slope, 0, 0, 0, stream, &f,
+                     wfrag_f16, nullptr, 0, 0, 0, scale);
+    if (rc) return rc;
+    return vxb_wgin_finish_launch(ws, (int)vxb_conv3_dgrad_fold_blocks(B, S, 64), scale, dW, db, (hipStream_t)stream);
 }

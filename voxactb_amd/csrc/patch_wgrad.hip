@@ -152,9 +152,44 @@ __global__ void __launch_bounds__(256) patch_wgrad_finish_kernel(const float* __
     if (e < PCIN) dW[c * PCIN + e] += s; else db[c] += s;
 }
 
+// first level of a long partial list: workgroup (r, y) sums rows [r chunk, (r + 1) chunk) in a fixed order into out[r]
+__global__ void __launch_bounds__(256) wgin_reduce_kernel(const float* __restrict__ part, int n, int chunk, float* __restrict__ out) {
+    const int i = blockIdx.y * 256 + threadIdx.x;
+    if (i >= 704) return;
+    const int k1 = min(n, ((int)blockIdx.x + 1) * chunk);
+    int k = blockIdx.x * chunk;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (; k + 3 < k1; k += 4) {
+        s0 += part[(long long)k * 704 + i]; s1 += part[(long long)(k + 1) * 704 + i];
+        s2 += part[(long long)(k + 2) * 704 + i]; s3 += part[(long long)(k + 3) * 704 + i];
+    }
+    for (; k < k1; ++k) s0 += part[(long long)k * 704 + i];
+    out[(long long)blockIdx.x * 704 + i] = (s0 + s1) + (s2 + s3);
+}
+
 }  // namespace
 
-extern "C" size_t vxb_patch_dgrad_input_wgrad_ws_floats(int k, int nsplit) { return (size_t)k * k * k * (nsplit > 0 ? nsplit : 1) * 704; }
+// part: n rows of 704 partial sums, followed by room for VXB_WGIN_FINISH_ROWS more (the first-level sums of a long list)
+int vxb_wgin_finish_launch(float* part, int n, const float* scale, float* dW, float* db, hipStream_t st) {
+    if (!part || !scale || !dW || !db || n < 1) return VXB_EARG;
+    if (n > 64) {                           // two levels of about sqrt(n) rows each (a single thread per entry walks a level serially)
+        int chunk = 8;
+        while ((long long)chunk * chunk < n) ++chunk;
+        chunk = max(chunk, vxb_cdiv(n, VXB_WGIN_FINISH_ROWS));
+        const int rows = vxb_cdiv(n, chunk);
+        float* lvl1 = part + (long long)n * 704;
+        hipLaunchKernelGGL(wgin_reduce_kernel, dim3(rows, vxb_cdiv(704, 256)), dim3(256), 0, st, part, n, chunk, lvl1);
+        part = lvl1;
+        n = rows;
+    }
+    hipLaunchKernelGGL(patch_wgrad_finish_kernel, dim3(vxb_cdiv(704, 256)), dim3(256), 0, st, part, n, scale, dW, db);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+extern "C" size_t vxb_patch_dgrad_input_wgrad_ws_floats(int k, int nsplit) {
+    return ((size_t)k * k * k * (nsplit > 0 ? nsplit : 1) + VXB_WGIN_FINISH_ROWS) * 704;
+}
 
 // The patchify data gradient's contribution to the input conv's weight / bias gradient, without the data gradient tensor (see the head
 // of this file): dpatch [B, G^3, 64] (gradient of the patchify block's pre-activation), wt_f16 = fp16 [k^3][64][64] with
@@ -174,7 +209,5 @@ extern "C" int vxb_patch_dgrad_input_wgrad_f32(const float* dpatch, const void* 
     g.B = B; g.V = V; g.G = G; g.k = k; g.pad = pad; g.Z = nsplit; g.slope = slope;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(patch_wgrad_kernel, dim3(k * k * k, nsplit), dim3(256), 0, st, g);
-    hipLaunchKernelGGL(patch_wgrad_finish_kernel, dim3(vxb_cdiv(704, 256)), dim3(256), 0, st, ws, k * k * k * nsplit, scale, dW, db);
-    VXB_CHECK_LAUNCH();
-    return VXB_OK;
+    return vxb_wgin_finish_launch(ws, k * k * k * nsplit, scale, dW, db, st);
 }

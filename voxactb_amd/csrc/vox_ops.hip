@@ -553,6 +553,7 @@ __global__ void __launch_bounds__(256) pw_wgrad4_ss_kernel(const float* __restri
     const int b = blockIdx.y;
     const int c4 = (threadIdx.x & 15) * 4, gl = threadIdx.x >> 4, wid = threadIdx.x >> 6;
     const long long S3 = (long long)S * S * S;
+    const bool has_dy = dy != nullptr;           // (uniform) nullptr: only the pooled-feature (and fold_src) terms reach y
     x += (long long)b * S3 * CIN; y += (long long)b * S3 * 64 + c4; dy += (long long)b * S3 * 64 + c4;
     if (fold_src) fold_src += (long long)b * Sp * Sp * Sp * 64 + c4;
     float m[4], inv_s[4], ex[4], ey[4], ez[4], gx[4], gy[4], gz[4], gm[4];
@@ -609,7 +610,7 @@ __global__ void __launch_bounds__(256) pw_wgrad4_ss_kernel(const float* __restri
             const long long v = t0 + lv;
             const bool ok = v < v1;
             qy[slot] = ok ? *reinterpret_cast<const float4*>(y + v * 64) : make_float4(1.f, 1.f, 1.f, 1.f);
-            qd[slot] = ok ? *reinterpret_cast<const float4*>(dy + v * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+            qd[slot] = (ok && has_dy) ? *reinterpret_cast<const float4*>(dy + v * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
             if (fold_src && ok) {
                 // one more gradient path into y, gathered in place: the adjoint of the replicate padding of a data gradient
@@ -1288,7 +1289,7 @@ extern "C" int vxb_pointwise_wgrad_ss3d_f32(const float* x, const float* y, cons
                                             int S, int Cin, int Cout, float slope, const float* lin, const float* stats,
                                             const float* out_ss, const int32_t* argmax, const float* g_ss, const float* g_max,
                                             const float* fold_src, int Sp, int pad, vxb_stream_t stream) {
-    if (!x || !y || !dy || !dW || !db || !part_ws || !lin || !stats || !out_ss || !argmax || !g_ss || !g_max || B < 1 || S < 1 ||
+    if (!x || !y || !dW || !db || !part_ws || !lin || !stats || !out_ss || !argmax || !g_ss || !g_max || B < 1 || S < 1 ||
         Cin < 1 || Cin > 16 || (fold_src && (pad < 0 || Sp < S + 2 * pad))) return VXB_EARG;
     if (Cout != 64 || Cin != 10 || ((((uintptr_t)y) | ((uintptr_t)dy) | ((uintptr_t)fold_src)) & 15)) return VXB_ESIZE;
     const int vpb = 4096;

@@ -751,7 +751,8 @@ def dgrad_fold_ok(C_dy, N, S):
             and (So - 2) // 4 == (So - 1) // 4 and (So - 2) // 8 == (So - 1) // 8)
 
 
-def conv3_dgrad_fold(dy, wt_dgrad, B, S, N, dsts, label=None, dy_scale=None, leaf_blocks=(), scale_blocks=(), colsum_into=None):
+def conv3_dgrad_fold(dy, wt_dgrad, B, S, N, dsts, label=None, dy_scale=None, leaf_blocks=(), scale_blocks=(), colsum_into=None,
+                     wgin=None):
     """fold_pad(conv3d(dy, wt_dgrad, zero pad, S+2), pad=1) without the padded tensor: dsts = [(dst [B,S,S,S,64],
     accumulate, lrelu_of or None)] per 64-column block (1 or 2 entries).
     leaf_blocks: the column blocks whose result only feeds a weight gradient (nothing propagates from them); with
@@ -759,7 +760,10 @@ def conv3_dgrad_fold(dy, wt_dgrad, B, S, N, dsts, label=None, dy_scale=None, lea
     computed here when None) -- the others keep the bf16x3 triple.  scale_blocks: the (non-leaf) blocks whose destination's own fp16
     operand scale is wanted (taken in the epilogue while the tensor is written); returns {block: [scale, 1 / scale]}.
     colsum_into {block: tensor [64]}: += the column sums of that block's destination (the bias gradient of the conv it is the
-    pre-activation gradient of) -- from the epilogue on the split path, by a colsum pass otherwise."""
+    pre-activation gradient of) -- from the epilogue on the split path, by a colsum pass otherwise.
+    wgin {block: (y, x, dW, db)} (leaf blocks on the fp16 path only; see wgin_fold_ok): the block is the data gradient of y = lrelu(1x1x1
+    conv of the detached x [B,S,S,S,10]); instead of being stored to its dst (which may then be None) it is multiplied with
+    LeakyReLU'(y) and x in the epilogue and dW [64][10] / db [64] are accumulated."""
     C0 = dy.shape[-1]
     wb = to_bf16_nk(wt_dgrad)
     x3 = wb.dim() == 3
@@ -783,6 +787,11 @@ def conv3_dgrad_fold(dy, wt_dgrad, B, S, N, dsts, label=None, dy_scale=None, lea
                 w16 = wt_dgrad[:, 64 * nb:64 * nb + 64].t().contiguous().half()           # [64][27 C0]
                 wf16 = halo_wfrag(w16, C0)
                 _lib.set_meta(lbl, flops / len(dsts))
+                if wgin and nb in wgin:
+                    yw, xw, dWw, dbw = wgin[nb]
+                    ws = torch.empty(704 * (int(_lib.lib().vxb_conv3_dgrad_fold_blocks(B, S, 64)) + 512), dtype=torch.float32, device=dy.device)
+                    call('vxb_conv3_dgrad_fold_f16_wgin_f32', dy, C0, B, S, wf16, yw, xw, LRELU_SLOPE, sc, ws, dWw, dbw)
+                    continue
                 call('vxb_conv3_dgrad_fold_f16_f32', dy, C0, B, S, wf16, dst, yv, int(acc), LRELU_SLOPE, sc)
             else:
                 dsc = sws = cs = cws = None
@@ -802,6 +811,15 @@ def conv3_dgrad_fold(dy, wt_dgrad, B, S, N, dsts, label=None, dy_scale=None, lea
     for nb, into in colsum_into.items():
         colsum(dsts[nb][0].view(-1, 64), into, accumulate=True)
     return scales
+
+
+WGIN_FOLD = os.environ.get('VOXACTB_WGIN_FOLD', '0') != '0'     # d(d0) of `final` straight into the input conv's weight gradient (no dd0 tensor)
+
+
+def wgin_fold_ok(C, N, S, Cin):
+    """conv3_dgrad_fold(..., leaf_blocks=(0,), wgin={0: ...}) will take the fused route (mirrors its fp16-path test)"""
+    return (WGIN_FOLD and WGRAD_PRECISION == 'fp16' and PRECISION == 'bf16x3' and HALO_CONV and HALO_WD and C == 64 and N == 128
+            and Cin == 10 and dgrad_fold_ok(C, N, S))
 
 
 def s2d_halo_ok(kl, C, N):
