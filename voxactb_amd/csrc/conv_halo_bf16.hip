@@ -101,14 +101,16 @@ __device__ __forceinline__ unsigned hb_pack2(float lo, float hi) {
 
 __device__ __forceinline__ bool g_dbg_all_waves(const HaloArgs& g) { return (g.dbg & 4) != 0; }    // experiment bit 4: no wave skipping
 
-template <int NTG, int PM, int NW, int WD, int TL = 0, int WN = 1>
+template <int NTG, int PM, int NW, int WD, int TL, int WN, int HALF>
                                               // NTG = N / 32 column tiles per workgroup; the NW waves form a (NW / WN) x WN grid over
                                               // (8 M tiles) x (NTG column tiles): 4 x 1 -> 2 M tiles x 2 column tiles per wave,
                                               // 2 x 2 -> 4 x 1 (half the B-fragment traffic per MFMA, twice the A reads from LDS),
                                               // 8 x 1 -> 1 x 2; WD: B fragments straight from global (pre-shuffled weights); TL:
                                               // per-chunk tap lists (block-sparse weights, WD only)
-__global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
+                                              // HALF = 1: an edge tile whose odd M tiles hold no output voxel (see the kernel below)
+__device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     constexpr int X3 = PM == 1;
+    constexpr int ST = HALF ? 2 : 1;                // M-tile stride of the tap loop
     constexpr int NTH = NW * 64, MTW = 8 / (NW / WN), NT = NTG / WN;
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* halo = smem;                               // [HALO_SLOTS][SP]
@@ -145,6 +147,17 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
     // their matrix work this way.
     const bool wave_on = __builtin_amdgcn_readfirstlane((int)(!WD || g_dbg_all_waves(g) || d0 + (((wid / WN) * (8 / (NW / WN))) >> 1) < g.S_out)) != 0;
 
+    // HALF: edge tiles of a plain (non-fold) launch whose upper half holds no output voxel (S_out = 100: the 13th tile along h / w
+    // covers 96..103) run half their matrix work.  Along w the odd M tiles (w half 1) are simply left out; along h the M tile of such
+    // a workgroup is a 4(h) x 8(w) patch instead of 8(h) x 4(w), so that again the odd M tiles (h half 1) are the empty ones.  The
+    // lane order inside the 4 x 8 patch keeps ds_read_b128 conflict-free: its 16-lane service groups {0-3, 12-15, 20-27} / {4-11,
+    // 16-19, 28-31} take the rows {0, 2} / {1, 3} of the patch, whose 16 voxels fall on 16 different 16-byte slots with 80-byte
+    // voxels and 12-voxel rows (brute-forced).  The same products in the same order for every output voxel: bit-identical results.
+    const bool half_h = HALF && __builtin_amdgcn_readfirstlane((int)(w0 + 4 < g.S_out)) != 0;     // (else: the w edge)
+    // 4 x 8 patch: lane row l -> h' = parity(l >> 2) + 2 (l >> 4), w = 4 ((l >> 3) & 1) + (l & 3)
+    auto alt_h = [](int l) { return (((l >> 2) ^ (l >> 3) ^ (l >> 4)) & 1) + 2 * (l >> 4); };
+    auto alt_w = [](int l) { return ((l >> 3) & 1) * 4 + (l & 3); };
+
     f32x16 acc[MTW][NT];
 #pragma unroll
     for (int i = 0; i < MTW; ++i)
@@ -160,6 +173,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
     for (int i = 0; i < MTW; ++i) {
         const int mt = wm * MTW + i;
         abase[i] = (((mt >> 1) * HHp + (lq >> 2)) * HWp + (mt & 1) * 4 + (lq & 3)) * SP + 8 * hi;
+        if (HALF && half_h) abase[i] = (((mt >> 1) * HHp + (mt & 1) * 4 + alt_h(lq)) * HWp + alt_w(lq)) * SP + 8 * hi;
     }
     const int wrow = lq * LDW + 8 * hi;            // B-operand row of this lane inside a weight tile (+ nt*32*LDW)
 
@@ -191,6 +205,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
             st_soff[i] = ((pd * HHp + ph) * HWp + pw) * SP + c4;
             if (ok) st_goff[i] = ((id * sm) * Vin + ih * sm) * Vin + iw * sm;
             else st_goff[i] = -2;                   // staged as zeros
+            if (HALF && (half_h ? ph : pw) >= 6) st_goff[i] = -1;      // the even M tiles of a half tile read 6 of the 10 rows / columns
         }
     }
     const long long bvox = (long long)b * Vin * Vin * Vin;
@@ -219,7 +234,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
     {                                                                                                                \
         const int tp_ = (tap_);                                                                                      \
         const int toff_ = (((tp_ / 9) * HHp + (tp_ / 3) % 3) * HWp + tp_ % 3) * SP;                                  \
-        _Pragma("unroll") for (int i = 0; i < MTW; ++i) {                                                               \
+        _Pragma("unroll") for (int i = 0; i < MTW; i += ST) {                                                        \
             AF[i][0] = *reinterpret_cast<const bf16x8*>(&halo[abase[i] + toff_]);                                    \
             AF[i][1] = *reinterpret_cast<const bf16x8*>(&halo[abase[i] + toff_ + 16]);                               \
         }                                                                                                            \
@@ -304,15 +319,15 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
     }
 #define HD_MFMA(AC, BC)                                                                                              \
     {                                                                                                                \
-        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                               \
+        _Pragma("unroll") for (int i = 0; i < MTW; i += ST)                                                          \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
             acc[i][j] = hb_mfma<PM>(AC[i][1], BC[j][X3 ? 0 : 1], acc[i][j]);    \
         if (X3) {                                                                                                    \
-            _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                           \
+            _Pragma("unroll") for (int i = 0; i < MTW; i += ST)                                                      \
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
                 acc[i][j] = hb_mfma<PM>(AC[i][0], BC[j][1], acc[i][j]);         \
         }                                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                               \
+        _Pragma("unroll") for (int i = 0; i < MTW; i += ST)                                                          \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
             acc[i][j] = hb_mfma<PM>(AC[i][0], BC[j][0], acc[i][j]);             \
     }
@@ -628,13 +643,14 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
     }
     // ---- epilogue: acc[i][j][r] = C[voxel row (r&3) + 8*(r>>2) + 4*hi of M tile i][channel j*32 + lq]
 #pragma unroll
-    for (int i = 0; i < MTW; ++i) {
+    for (int i = 0; i < MTW; i += ST) {
         const int mt = wm * MTW + i;
         const int od = d0 + (mt >> 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const int oh = h0 + (m >> 2), ow = w0 + (mt & 1) * 4 + (m & 3);
+            int oh = h0 + (m >> 2), ow = w0 + (mt & 1) * 4 + (m & 3);
+            if (HALF && half_h) { oh = h0 + (mt & 1) * 4 + alt_h(m); ow = w0 + alt_w(m); }
             if (od < g.S_out && oh < g.S_out && ow < g.S_out) {
                 float* op;
                 if (g.d2s_s > 0) {
@@ -655,6 +671,24 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
             }
         }
     }
+}
+
+template <int NTG, int PM, int NW, int WD, int TL = 0, int WN = 1>
+__global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
+    constexpr bool EDGE = WD && !TL && WN == 2 && NW == 4;
+    if constexpr (EDGE) {
+        // this workgroup's tile (the body decodes it again): is its upper half along w, or else along h, beyond the output grid?
+        const int nwg = gridDim.x, lid = blockIdx.x;
+        const int xcd = lid & 7, slot = lid >> 3, q = nwg >> 3, r = nwg & 7;
+        int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        t /= g.N / (NTG * 32);
+        const int tw = t % g.ntw, th = (t / g.ntw) % g.nth;
+        if (g.fold_pad == 0 && !g_dbg_all_waves(g) && (tw * TW + 4 >= g.S_out || th * TH + 4 >= g.S_out)) {
+            conv3_halo_body<NTG, PM, NW, WD, TL, WN, 1>(g);
+            return;
+        }
+    }
+    conv3_halo_body<NTG, PM, NW, WD, TL, WN, 0>(g);
 }
 
 inline bool hb_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
