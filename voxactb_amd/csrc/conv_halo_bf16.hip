@@ -110,7 +110,8 @@ template <int NTG, int PM, int NW, int WD, int TL, int WN, int HALF>
                                               // HALF = 1: an edge tile whose odd M tiles hold no output voxel (see the kernel below)
 __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     constexpr int X3 = PM == 1;
-    constexpr int ST = HALF ? 2 : 1;                // M-tile stride of the tap loop
+    constexpr int ST = HALF == 1 ? 2 : 1;           // M-tile stride of the tap loops
+    constexpr int MLIM = HALF == 2 ? 3 : 8 / (NW / WN);     // ... and their end: HALF = 2 runs three of a wave's four M tiles
     constexpr int NTH = NW * 64, MTW = 8 / (NW / WN), NT = NTG / WN;
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* halo = smem;                               // [HALO_SLOTS][SP]
@@ -147,16 +148,34 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     // their matrix work this way.
     const bool wave_on = __builtin_amdgcn_readfirstlane((int)(!WD || g_dbg_all_waves(g) || d0 + (((wid / WN) * (8 / (NW / WN))) >> 1) < g.S_out)) != 0;
 
-    // HALF: edge tiles of a plain (non-fold) launch whose upper half holds no output voxel (S_out = 100: the 13th tile along h / w
-    // covers 96..103) run half their matrix work.  Along w the odd M tiles (w half 1) are simply left out; along h the M tile of such
-    // a workgroup is a 4(h) x 8(w) patch instead of 8(h) x 4(w), so that again the odd M tiles (h half 1) are the empty ones.  The
-    // lane order inside the 4 x 8 patch keeps ds_read_b128 conflict-free: its 16-lane service groups {0-3, 12-15, 20-27} / {4-11,
-    // 16-19, 28-31} take the rows {0, 2} / {1, 3} of the patch, whose 16 voxels fall on 16 different 16-byte slots with 80-byte
-    // voxels and 12-voxel rows (brute-forced).  The same products in the same order for every output voxel: bit-identical results.
-    const bool half_h = HALF && __builtin_amdgcn_readfirstlane((int)(w0 + 4 < g.S_out)) != 0;     // (else: the w edge)
-    // 4 x 8 patch: lane row l -> h' = parity(l >> 2) + 2 (l >> 4), w = 4 ((l >> 3) & 1) + (l & 3)
-    auto alt_h = [](int l) { return (((l >> 2) ^ (l >> 3) ^ (l >> 4)) & 1) + 2 * (l >> 4); };
-    auto alt_w = [](int l) { return ((l >> 3) & 1) * 4 + (l & 3); };
+    // HALF: edge tiles whose last rows / columns lie beyond the output grid run a part of their matrix work, with the same products
+    // in the same order for every output voxel (bit-identical results).
+    //   HALF = 1 (at most 4 of the 8 rows or columns exist; S_out = 100: the 13th tile covers 96..103): along w the odd M tiles
+    //     (w half 1) are simply left out; along h the M tile of such a workgroup is a 4(h) x 8(w) patch instead of 8(h) x 4(w), so
+    //     that again the odd M tiles (h half 1) are the empty ones.
+    //   HALF = 2 (6 of 8 exist: S_out = 22 -- the up-conv's data gradient -- and 102): a wave (two depths) runs three M tiles: the
+    //     two patches of the existing half, one per depth, and the 2-wide strip of rows / columns 4..5 of both depths.
+    // The lane order inside the 4 x 8 patch and the h strip keeps ds_read_b128 conflict-free: its 16-lane service groups {0-3, 12-15,
+    // 20-27} / {4-11, 16-19, 28-31} take the rows {0, 2} / {1, 3} of the patch (h = 4 / h = 5 of the strip), whose 16 voxels fall on
+    // 16 different 16-byte slots with 80-byte voxels and 12-voxel rows; the w strip (8 distinct slots for 32 voxels) is read with
+    // 2-way conflicts (tools/experiments/halo_rowmap_check.py).
+    const bool edge_h = HALF && __builtin_amdgcn_readfirstlane((int)(w0 + (HALF == 1 ? 4 : 6) < g.S_out)) != 0;     // (else: the w edge)
+    // tile-local voxel (dd, hh, ww) of row l (0..31) of this wave's i-th M tile
+    auto rowmap = [&](int i, int l, int& dd, int& hh, int& ww) {
+        const int mt = wm * MTW + i;
+        const int par = ((l >> 2) ^ (l >> 3) ^ (l >> 4)) & 1;          // service group of lane l
+        const int aw = ((l >> 3) & 1) * 4 + (l & 3), k = (l >> 3) * 4 + (l & 3);
+        dd = mt >> 1; hh = l >> 2; ww = (mt & 1) * 4 + (l & 3);
+        if (HALF == 1 && edge_h) { hh = (mt & 1) * 4 + par + 2 * (l >> 4); ww = aw; }
+        if (HALF == 2) {
+            dd = 2 * wm + i; ww = l & 3;
+            if (edge_h) { hh = par + 2 * (l >> 4); ww = aw; }
+            if (i == 2) {
+                if (edge_h) { dd = 2 * wm + (l >> 4); hh = 4 + par; ww = aw; }
+                else { dd = 2 * wm + par; hh = k >> 1; ww = 4 + (k & 1); }
+            }
+        }
+    };
 
     f32x16 acc[MTW][NT];
 #pragma unroll
@@ -171,9 +190,9 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     int abase[MTW];
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
-        const int mt = wm * MTW + i;
-        abase[i] = (((mt >> 1) * HHp + (lq >> 2)) * HWp + (mt & 1) * 4 + (lq & 3)) * SP + 8 * hi;
-        if (HALF && half_h) abase[i] = (((mt >> 1) * HHp + (mt & 1) * 4 + alt_h(lq)) * HWp + alt_w(lq)) * SP + 8 * hi;
+        int dd, hh, ww;
+        rowmap(i, lq, dd, hh, ww);
+        abase[i] = ((dd * HHp + hh) * HWp + ww) * SP + 8 * hi;
     }
     const int wrow = lq * LDW + 8 * hi;            // B-operand row of this lane inside a weight tile (+ nt*32*LDW)
 
@@ -205,7 +224,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
             st_soff[i] = ((pd * HHp + ph) * HWp + pw) * SP + c4;
             if (ok) st_goff[i] = ((id * sm) * Vin + ih * sm) * Vin + iw * sm;
             else st_goff[i] = -2;                   // staged as zeros
-            if (HALF && (half_h ? ph : pw) >= 6) st_goff[i] = -1;      // the even M tiles of a half tile read 6 of the 10 rows / columns
+            if (HALF && (edge_h ? ph : pw) >= (HALF == 1 ? 6 : 8)) st_goff[i] = -1;      // a part tile reads 6 / 8 of the 10 rows or columns
         }
     }
     const long long bvox = (long long)b * Vin * Vin * Vin;
@@ -234,7 +253,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     {                                                                                                                \
         const int tp_ = (tap_);                                                                                      \
         const int toff_ = (((tp_ / 9) * HHp + (tp_ / 3) % 3) * HWp + tp_ % 3) * SP;                                  \
-        _Pragma("unroll") for (int i = 0; i < MTW; i += ST) {                                                        \
+        _Pragma("unroll") for (int i = 0; i < MLIM; i += ST) {                                                       \
             AF[i][0] = *reinterpret_cast<const bf16x8*>(&halo[abase[i] + toff_]);                                    \
             AF[i][1] = *reinterpret_cast<const bf16x8*>(&halo[abase[i] + toff_ + 16]);                               \
         }                                                                                                            \
@@ -288,7 +307,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
 #define HB_READ_A_OFF(AF, off_)                                                                                      \
     {                                                                                                                \
         const int toff_ = (off_);                                                                                    \
-        _Pragma("unroll") for (int i = 0; i < MTW; ++i) {                                                             \
+        _Pragma("unroll") for (int i = 0; i < MLIM; i += ST) {                                                       \
             AF[i][0] = *reinterpret_cast<const bf16x8*>(&halo[abase[i] + toff_]);                                    \
             AF[i][1] = *reinterpret_cast<const bf16x8*>(&halo[abase[i] + toff_ + 16]);                               \
         }                                                                                                            \
@@ -300,15 +319,15 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
         if (ln_ + 2 < ntap) { HD_LOADB(BL, ln_ + 2) }                                                                \
         if (ln_ + 1 < ntap) { HB_READ_A_OFF(AN, __builtin_amdgcn_readlane(taplist, ln_ + 1)) }                       \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                               \
+        _Pragma("unroll") for (int i = 0; i < MLIM; i += ST)                                                         \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
             acc[i][j] = hb_mfma<PM>(AC[i][1], BC[j][X3 ? 0 : 1], acc[i][j]);    \
         if (X3) {                                                                                                    \
-            _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                           \
+            _Pragma("unroll") for (int i = 0; i < MLIM; i += ST)                                                     \
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
                 acc[i][j] = hb_mfma<PM>(AC[i][0], BC[j][1], acc[i][j]);         \
         }                                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                               \
+        _Pragma("unroll") for (int i = 0; i < MLIM; i += ST)                                                         \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
             acc[i][j] = hb_mfma<PM>(AC[i][0], BC[j][0], acc[i][j]);             \
     }
@@ -319,15 +338,15 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     }
 #define HD_MFMA(AC, BC)                                                                                              \
     {                                                                                                                \
-        _Pragma("unroll") for (int i = 0; i < MTW; i += ST)                                                          \
+        _Pragma("unroll") for (int i = 0; i < MLIM; i += ST)                                                         \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
             acc[i][j] = hb_mfma<PM>(AC[i][1], BC[j][X3 ? 0 : 1], acc[i][j]);    \
         if (X3) {                                                                                                    \
-            _Pragma("unroll") for (int i = 0; i < MTW; i += ST)                                                      \
+            _Pragma("unroll") for (int i = 0; i < MLIM; i += ST)                                                     \
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
                 acc[i][j] = hb_mfma<PM>(AC[i][0], BC[j][1], acc[i][j]);         \
         }                                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < MTW; i += ST)                                                          \
+        _Pragma("unroll") for (int i = 0; i < MLIM; i += ST)                                                         \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
             acc[i][j] = hb_mfma<PM>(AC[i][0], BC[j][0], acc[i][j]);             \
     }
@@ -488,12 +507,13 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
         float* ft = reinterpret_cast<float*>(smem);
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < MTW; ++i) {
-            const int mt = wm * MTW + i;
+        for (int i = 0; i < MLIM; i += ST) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int pos = ((mt >> 1) * TH + (m >> 2)) * TW + (mt & 1) * 4 + (m & 3);
+                int dd, hh, ww;
+                rowmap(i, m, dd, hh, ww);
+                const int pos = (dd * TH + hh) * TW + ww;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) ft[pos * 64 + (wn * NT + j) * 32 + lq] = acc[i][j][r];
             }
@@ -643,14 +663,13 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     }
     // ---- epilogue: acc[i][j][r] = C[voxel row (r&3) + 8*(r>>2) + 4*hi of M tile i][channel j*32 + lq]
 #pragma unroll
-    for (int i = 0; i < MTW; i += ST) {
-        const int mt = wm * MTW + i;
-        const int od = d0 + (mt >> 1);
+    for (int i = 0; i < MLIM; i += ST) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            int oh = h0 + (m >> 2), ow = w0 + (mt & 1) * 4 + (m & 3);
-            if (HALF && half_h) { oh = h0 + (mt & 1) * 4 + alt_h(m); ow = w0 + alt_w(m); }
+            int dd, hh, ww;
+            rowmap(i, m, dd, hh, ww);
+            const int od = d0 + dd, oh = h0 + hh, ow = w0 + ww;
             if (od < g.S_out && oh < g.S_out && ow < g.S_out) {
                 float* op;
                 if (g.d2s_s > 0) {
@@ -675,16 +694,18 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
 
 template <int NTG, int PM, int NW, int WD, int TL = 0, int WN = 1>
 __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
-    constexpr bool EDGE = WD && !TL && WN == 2 && NW == 4;
+    constexpr bool EDGE = WD && WN == 2 && NW == 4;
     if constexpr (EDGE) {
-        // this workgroup's tile (the body decodes it again): is its upper half along w, or else along h, beyond the output grid?
+        // this workgroup's tile (the body decodes it again): how many of its 8 columns (else: rows) lie inside the output grid?
         const int nwg = gridDim.x, lid = blockIdx.x;
         const int xcd = lid & 7, slot = lid >> 3, q = nwg >> 3, r = nwg & 7;
         int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
         t /= g.N / (NTG * 32);
         const int tw = t % g.ntw, th = (t / g.ntw) % g.nth;
-        if (g.fold_pad == 0 && !g_dbg_all_waves(g) && (tw * TW + 4 >= g.S_out || th * TH + 4 >= g.S_out)) {
-            conv3_halo_body<NTG, PM, NW, WD, TL, WN, 1>(g);
+        const int rem = min(g.S_out - tw * TW, g.S_out - th * TH);
+        if (rem <= 6 && !g_dbg_all_waves(g)) {
+            if (rem <= 4) conv3_halo_body<NTG, PM, NW, WD, TL, WN, 1>(g);
+            else conv3_halo_body<NTG, PM, NW, WD, TL, WN, 2>(g);
             return;
         }
     }
