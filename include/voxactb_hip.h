@@ -240,6 +240,13 @@ int vxb_conv3_halo_bf16x3_f32(const float* src0, const float* src1, int C0, int 
                               int off, int replicate, const void* wt_bf16, int N, const float* bias, float* out,
                               int act, float slope, int s2d_s, int s2d_C, int d2s_s, const void* wfrag, const int32_t* taptab,
                               int ncls, int tap_total, vxb_stream_t stream);
+/* The tap-list launch above (space-to-depth input + taptab: the data gradient of the polyphase up-conv, network_utils.py:245-250 via
+ * perceiver_lang_io.py:449-455) with the reduction split over ksplit workgroups per tile: part p accumulates the chunks
+ * kparts[p] .. kparts[p + 1] - 1 (DEVICE int32 [ksplit + 1]; a chunk = 16 input channels in bf16x3, 32 in bf16) into
+ * out_parts[p] [B, S_out^3, N]; the caller sums the parts in order (vxb_sum_splits_f32).  x3 != 0: wt_bf16 = hi/lo planes. */
+int vxb_conv3_s2d_splitk_f32(const float* src_fine, int C0, int B, int S_in, int S_out, int off, const void* wt_bf16, int x3,
+                             int N, float* out_parts, int s2d_s, int s2d_C, const void* wfrag, const int32_t* taptab,
+                             int ncls, int tap_total, int ksplit, const int32_t* kparts, vxb_stream_t stream);
 /* wfrag (optional, NULL = weights staged through LDS per tap): the same weights pre-shuffled into MFMA fragment order,
  * [N/64][chunk][tap][column tile 2][k half or plane 2][lane 64][8 bf16] with chunk = 32 channels ('bf16') or 16 ('bf16x3');
  * the kernel then loads its B fragments straight from global memory and the 27-tap loop has no barrier.

@@ -98,10 +98,23 @@ def test_sparse_data_gradient_is_bit_identical_to_dense(mode):
         wd = ops.polyphase_dgrad_weights_lowres(Weff, C, C, s, kl)
         assert ops.s2d_halo_ok(kl, C, C)
         dense = ops.conv3_s2d(du, wd, C, B, G, Sp, -(kl - 1), s, C)
+        ks_default, ops.S2D_KSPLIT = ops.S2D_KSPLIT, 1
         got = ops.conv3_s2d(du, wd, C, B, G, Sp, -(kl - 1), s, C, poly_k=k)
+        # the reduction split over several workgroups per tile (the default in the step): same products, the partial sums of the
+        # parts added in order -- equal up to the fp32 rounding of K = 8000 x 17.6 terms summed in a different association
+        splits = []
+        for ks in (2, 3, ks_default, 16):
+            ops.S2D_KSPLIT = ks
+            splits.append((ks, ops.conv3_s2d(du, wd, C, B, G, Sp, -(kl - 1), s, C, poly_k=k)))
     finally:
         ops.PRECISION = 'fp32'
+        ops.S2D_KSPLIT = ks_default
     assert torch.equal(got, dense)
+    for ks, sp in splits:
+        kp = ops.s2d_kparts(k, s, DEV, 16 if mode == 'bf16x3' else 32, C // (16 if mode == 'bf16x3' else 32), ks).tolist()
+        assert kp[0] == 0 and kp[-1] == s ** 3 * C // (16 if mode == 'bf16x3' else 32) and all(a <= b for a, b in zip(kp, kp[1:]))
+        err = float((sp - dense).abs().max() / dense.abs().max())
+        assert err < 3e-5, (ks, err)
     tt, ncls, total, rows = ops.s2d_taptab(k, s, DEV, 16, 4)
     assert ncls == 27 and total == rows.numel() and total % 3 == 0
     assert total == 4 * (8 * 9 + 36 * 12 + 54 * 18 + 27 * 27)          # 8-tap lists padded to 9

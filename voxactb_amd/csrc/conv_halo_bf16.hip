@@ -76,6 +76,12 @@ struct HaloArgs {
     // Q-function: the voxel grid is a detached input, agent :100) -- instead of storing the folded gradient, its share of that conv's
     // weight / bias gradient is accumulated on the spot: fold_dst[1] [workgroup][64][11] = sum over the workgroup's voxels of
     // g[c] * {x[0..9], 1}, g after fold_y[0]'s LeakyReLU' (still multiplied by the fp16 operand scale: the finishing kernel undoes it)
+    // TL kernels, split K (ksplit > 1): the launch has ksplit workgroups per tile; part p walks the chunks kparts[p] .. kparts[p + 1] - 1
+    // (device array, balanced by listed taps on the host) and writes its partial sums to out + p * part_stride -- the up-conv's data
+    // gradient has only B * 54 tiles of ~5 ms each for the chip's 512 workgroup slots
+    int ksplit;
+    const int* kparts;
+    long long part_stride;
 };
 
 // bf16 pair from two fp32 (RNE).  Both forms give identical bits; which one is FASTER was measured per precision on the
@@ -136,6 +142,8 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     const int nnb = g.N / N;                       // column blocks of one voxel tile are neighbours in launch order
     const int n0 = (t % nnb) * N;                   // this workgroup's 64 output channels
     t /= nnb;
+    int kpart = 0;
+    if (TL) { kpart = t % g.ksplit; t /= g.ksplit; }
     const int tw = t % g.ntw; t /= g.ntw;
     const int th = t % g.nth; t /= g.nth;
     const int td = t % g.ntd; t /= g.ntd;
@@ -397,7 +405,12 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
         }
     };
     if (PF) halo_issue(0);
-    for (int ch = 0; ch < nchunk; ++ch) {
+    int ch_begin = 0, ch_end = nchunk;
+    if (TL && g.ksplit > 1) {
+        ch_begin = __builtin_amdgcn_readfirstlane(g.kparts[kpart]);
+        ch_end = __builtin_amdgcn_readfirstlane(g.kparts[kpart + 1]);
+    }
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
         const int cb = ch * CPC;
         const bool dbg_skip_stage = (g.dbg & 1) && ch > 0;
         if (TL) {
@@ -679,6 +692,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
                     op = g.out + ((((long long)b * Vf + od * s + ph / (s * s)) * Vf + oh * s + (ph / s) % s) * Vf + ow * s + ph % s) * N - n0;
                 } else {
                     op = g.out + ((((long long)b * g.S_out + od) * g.S_out + oh) * g.S_out + ow) * g.N;
+                    if (TL) op += kpart * g.part_stride;
                 }
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
@@ -701,6 +715,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
         const int xcd = lid & 7, slot = lid >> 3, q = nwg >> 3, r = nwg & 7;
         int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
         t /= g.N / (NTG * 32);
+        if (TL) t /= g.ksplit;
         const int tw = t % g.ntw, th = (t / g.ntw) % g.nth;
         const int rem = min(g.S_out - tw * TW, g.S_out - th * TH);
         if (rem <= 6 && !g_dbg_all_waves(g)) {
@@ -728,7 +743,7 @@ int hb_launch(const HaloArgs& g, long long nblk, hipStream_t st) {
     if (TL && (size_t)(g.ncls * 32 + g.nphase * 2) * sizeof(int) > (size_t)2 * NT * 32 * LDW * sizeof(u16)) return VXB_ESIZE;
     if (hipFuncSetAttribute((const void*)conv3_halo_kernel<NT, PM, NW, WD, TL, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VXB_ELAUNCH;
-    hipLaunchKernelGGL((conv3_halo_kernel<NT, PM, NW, WD, TL, WN>), dim3((unsigned)(nblk * (g.N / (NT * 32)))), dim3(NW * 64), lds, st, g);
+    hipLaunchKernelGGL((conv3_halo_kernel<NT, PM, NW, WD, TL, WN>), dim3((unsigned)(nblk * (g.N / (NT * 32)) * (TL ? g.ksplit : 1))), dim3(NW * 64), lds, st, g);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
@@ -736,7 +751,8 @@ int hb_launch(const HaloArgs& g, long long nblk, hipStream_t st) {
 int hb_impl(int x3 /* product mode: 0 bf16, 1 bf16x3, 2 fp16 (WD kernels only, `scale` = {in, 1 / in} on the device) */, const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out, int off, int replicate,
             const void* wt_bf16, int N, const float* bias, float* out, int act, float slope, int s2d_s, int s2d_C,
             int d2s_s, vxb_stream_t stream, const HaloArgs* fold = nullptr, const void* wfrag = nullptr,
-            const int32_t* taptab = nullptr, int ncls = 0, int nphase = 0, int tap_total = 0, const float* scale = nullptr) {
+            const int32_t* taptab = nullptr, int ncls = 0, int nphase = 0, int tap_total = 0, const float* scale = nullptr,
+            int ksplit = 1, const int32_t* kparts = nullptr) {
     if (x3 == 2 && (!wfrag || taptab)) return VXB_EARG;
     if (!src0 || !wt_bf16 || (!out && !fold) || B < 1 || S_in < 1 || S_out < 1) return VXB_EARG;
     if ((C0 & 31) || (C1 & 31) || C0 < 32 || (C1 > 0 && !src1) || N < 64 || (N & 63)) return VXB_ESIZE;
@@ -745,7 +761,9 @@ int hb_impl(int x3 /* product mode: 0 bf16, 1 bf16x3, 2 fp16 (WD kernels only, `
     const long long Vin = (long long)S_in * (s2d_s > 0 ? s2d_s : 1);
     if (Vin * Vin * Vin >= INT32_MAX) return VXB_ESIZE;
     if (taptab && (!wfrag || s2d_s <= 0 || fold || ncls < 1 || tap_total < 3 || nphase != s2d_s * s2d_s * s2d_s)) return VXB_EARG;
+    if (ksplit < 1 || ksplit > 16 || (ksplit > 1 && (!taptab || !kparts || fold))) return VXB_EARG;
     HaloArgs g;
+    g.ksplit = ksplit; g.kparts = kparts; g.part_stride = (long long)B * S_out * S_out * S_out * N;
     g.taptab = taptab; g.ncls = ncls; g.nphase = nphase; g.tap_total = tap_total;
     g.s2d_s = s2d_s; g.s2d_C = s2d_C; g.d2s_s = d2s_s; g.wfrag = (const u16*)wfrag;
     g.dbg = g_halo_dbg;
@@ -804,6 +822,19 @@ extern "C" int vxb_conv3_halo_bf16x3_f32(const float* src0, const float* src1, i
                                          int ncls, int tap_total, vxb_stream_t stream) {
     return hb_impl(1, src0, src1, C0, C1, B, S_in, S_out, off, replicate, wt_bf16, N, bias, out, act, slope, s2d_s, s2d_C, d2s_s,
                    stream, nullptr, wfrag, taptab, ncls, s2d_s * s2d_s * s2d_s, tap_total);
+}
+
+// The tap-list launch of vxb_conv3_halo_bf16x3_f32 / _bf16w_f32 (space-to-depth input, block-sparse weights: the polyphase up-conv's
+// data gradient) with the reduction split over ksplit workgroups per tile: part p accumulates the chunks kparts[p] .. kparts[p + 1] - 1
+// (kparts: DEVICE int32 [ksplit + 1], kparts[0] = 0, kparts[ksplit] = C0 / (16 or 32 channels per chunk)) into out_parts[p] [B, S_out^3, N];
+// the caller sums the parts (vxb_sum_splits_f32).  B * ceil(S_out/4) * ceil(S_out/8)^2 tiles of 8000 input channels are 864 workgroups
+// of ~5 ms at the step's size -- 1.7 rounds of the chip's 512 slots; with ksplit parts the tail is a ksplit-th as long.
+extern "C" int vxb_conv3_s2d_splitk_f32(const float* src_fine, int C0, int B, int S_in, int S_out, int off, const void* wt_bf16, int x3,
+                                        int N, float* out_parts, int s2d_s, int s2d_C, const void* wfrag, const int32_t* taptab,
+                                        int ncls, int tap_total, int ksplit, const int32_t* kparts, vxb_stream_t stream) {
+    if (!taptab || !wfrag || !kparts || ksplit < 1) return VXB_EARG;
+    return hb_impl(x3 ? 1 : 0, src_fine, nullptr, C0, 0, B, S_in, S_out, off, 0, wt_bf16, N, nullptr, out_parts, 0, 0.f, s2d_s, s2d_C, 0,
+                   stream, nullptr, wfrag, taptab, ncls, s2d_s * s2d_s * s2d_s, tap_total, nullptr, ksplit, kparts);
 }
 
 // Data gradient of a 3x3x3 replicate-padded conv fused with the adjoint of its padding (vxb_conv3_halo_* followed by

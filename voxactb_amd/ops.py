@@ -861,6 +861,30 @@ def s2d_taptab(k, s, dev, cpc, chunks_per_phase):
         total += chunks_per_phase * len(taps)
     r = (torch.tensor(table, dtype=torch.int32, device=dev), ncls, total, torch.tensor(rows, dtype=torch.int64, device=dev))
     _POLY[key] = r
+    # listed taps per chunk, in chunk order (for the split-K boundaries)
+    _POLY[('ttc',) + key[1:]] = [len(by_cls[cls_of[ph]]) for ph in range(s ** 3) for _ in range(chunks_per_phase)]
+    return r
+
+
+S2D_KSPLIT = int(os.environ.get('VOXACTB_S2D_KSPLIT', '6'))    # workgroups per tile of the tap-list data gradient (1 = no split)
+
+
+def s2d_kparts(k, s, dev, cpc, chunks_per_phase, ksplit):
+    """chunk boundaries [ksplit + 1] (device int32) that give every part about the same number of listed taps."""
+    key = ('kp', k, s, str(dev), cpc, chunks_per_phase, ksplit)
+    r = _POLY.get(key)
+    if r is None:
+        s2d_taptab(k, s, dev, cpc, chunks_per_phase)
+        taps = _POLY[('ttc', k, s, str(dev), cpc, chunks_per_phase)]
+        total, acc, bounds = sum(taps), 0, [0]
+        for i, n in enumerate(taps):
+            if len(bounds) < ksplit and acc + n / 2.0 >= total * len(bounds) / float(ksplit):
+                bounds.append(i)
+            acc += n
+        while len(bounds) < ksplit:
+            bounds.append(len(taps))
+        bounds.append(len(taps))
+        r = _POLY[key] = torch.tensor(bounds, dtype=torch.int32, device=dev)
     return r
 
 
@@ -882,6 +906,14 @@ def conv3_s2d(src_fine, wt, N, B, G, S_out, off, s, Cf, label=None, poly_k=None)
         tt, ncls, total, rows = s2d_taptab(poly_k, s, src_fine.device, cpc, Cf // cpc)
         wf = wf.view(wf.shape[0], wf.shape[1] * 27, -1).index_select(1, rows).contiguous()
         frac = polyphase_structure(poly_k, s, src_fine.device)['frac']
+    if tt is not None and S2D_KSPLIT > 1:
+        ks = S2D_KSPLIT
+        kp = s2d_kparts(poly_k, s, src_fine.device, cpc, Cf // cpc, ks)
+        parts = torch.empty((ks, B, S_out, S_out, S_out, N), dtype=torch.float32, device=src_fine.device)
+        _lib.set_meta(lbl, 2.0 * B * S_out ** 3 * N * 27 * C0 * frac)
+        call('vxb_conv3_s2d_splitk_f32', src_fine, C0, B, G, S_out, off, wb, int(x3), N, parts, s, Cf, wf, tt, ncls, total, ks, kp)
+        sum_splits(parts, ks, out.numel(), out)
+        return out
     _lib.set_meta(lbl, 2.0 * B * S_out ** 3 * N * 27 * C0 * frac)
     call('vxb_conv3_halo_bf16x3_f32' if x3 else 'vxb_conv3_halo_bf16w_f32', src_fine, None, C0, 0, B, G, S_out, off,
          0, wb, N, None, out, ACT_NONE, LRELU_SLOPE, s, Cf, 0, wf, tt, ncls, total)
