@@ -247,6 +247,16 @@ int vxb_conv3_halo_bf16x3_f32(const float* src0, const float* src1, int C0, int 
 int vxb_conv3_s2d_splitk_f32(const float* src_fine, int C0, int B, int S_in, int S_out, int off, const void* wt_bf16, int x3,
                              int N, float* out_parts, int s2d_s, int s2d_C, const void* wfrag, const int32_t* taptab,
                              int ncls, int tap_total, int ksplit, const int32_t* kparts, vxb_stream_t stream);
+/* `final` conv + SpatialSoftmax3D / global max pool of its output in one pass over the output (perceiver_lang_io.py:462 then :470;
+ * network_utils.py:768-800): vxb_conv3_halo_bf16x3_f32 (N = 64, two sources, replicate padding, S_in = S_out = S, wfrag required)
+ * whose epilogue also takes the online-softmax partial of every (tile, channel); one small launch merges them into the outputs of
+ * vxb_ss3d_max_fwd_f32 (out_ss [B,192], out_max [B,64], stats [B,64,2], argmax [B,64]).  lin: the S coordinate values.
+ * part_ws: vxb_conv3_halo_ss3d_ws(B, S) floats.  `out` is bit-identical to the plain entry's. */
+size_t vxb_conv3_halo_ss3d_ws(int B, int S);
+int vxb_conv3_halo_ss3d_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S, const void* wt_bf16,
+                                   const float* bias, float* out, int act, float slope, const void* wfrag, const float* lin,
+                                   float* part_ws, float* out_ss, float* out_max, float* stats, int32_t* argmax,
+                                   vxb_stream_t stream);
 /* wfrag (optional, NULL = weights staged through LDS per tap): the same weights pre-shuffled into MFMA fragment order,
  * [N/64][chunk][tap][column tile 2][k half or plane 2][lane 64][8 bf16] with chunk = 32 channels ('bf16') or 16 ('bf16x3');
  * the kernel then loads its B fragments straight from global memory and the 27-tap loop has no barrier.

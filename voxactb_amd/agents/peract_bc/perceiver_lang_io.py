@@ -569,11 +569,15 @@ class PerceiverEngine:
             u0 = ops.conv3d(z1, ops.conv_weight_fwd(self.p(up2 + '.weight')), C, B, G, G, k, -(k // 2),
                             bias=self.p(up2 + '.bias'), act=ops.ACT_LRELU)
         # final conv over cat([d0, u0]) without the cat (perceiver :462)
-        u = ops.conv3d(d0, ops.conv_weight_fwd(self.p('final.conv3d.weight')), C, B, V, V, 3, -1,
-                       bias=self.p('final.conv3d.bias'), act=ops.ACT_LRELU, src1=u0)
-        # translation head (perceiver :465) and pooled features (:470)
+        if ops.conv3_ss3d_ok(C, C, C, V):
+            # ... with the pooled features of its output (:470) taken in the conv's epilogue: no statistics pass over u
+            u, ss2 = ops.conv3_ss3d_fwd(d0, u0, ops.conv_weight_fwd(self.p('final.conv3d.weight')), self.p('final.conv3d.bias'), B, V)
+        else:
+            u = ops.conv3d(d0, ops.conv_weight_fwd(self.p('final.conv3d.weight')), C, B, V, V, 3, -1,
+                           bias=self.p('final.conv3d.bias'), act=ops.ACT_LRELU, src1=u0)
+            ss2 = ops.ss3d_max_fwd(u, V ** 3 * C, B, V, C)
+        # translation head (perceiver :465)
         q_trans = ops.conv3_c1_fwd(u, self.p('trans_decoder.conv3d.weight'), self.p('trans_decoder.conv3d.bias'), B, V)
-        ss2 = ops.ss3d_max_fwd(u, V ** 3 * C, B, V, C)
         feats = torch.cat([ss0[0], ss0[1], ss1[0], ss1[1], ss2[0], ss2[1]], dim=1)
         h0 = ops.linear(feats, self.p('dense0.linear.weight'), self.p('dense0.linear.bias'), ops.ACT_LRELU)
         h1 = ops.linear(h0, self.p('dense1.linear.weight'), self.p('dense1.linear.bias'), ops.ACT_LRELU)

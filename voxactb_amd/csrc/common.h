@@ -31,6 +31,9 @@ int vxb_absmax_finish_launch(const unsigned* part, int n, float* scale, hipStrea
 constexpr int VXB_WGIN_FINISH_ROWS = 512;
 int vxb_wgin_finish_launch(float* part, int n, const float* scale, float* dW, float* db, hipStream_t st);
 int vxb_rows64_sum_launch(float* part, int nrows, float* out, hipStream_t st);
+// SpatialSoftmax3D + max: final merge of the per-tile partials [B][C][ntiles] written by the `final` conv's epilogue (vox_ops.hip)
+int vxb_ss3d_final_tiles_launch(const float* part, int ntiles, int B, int C, float* out_ss, float* out_max, float* stats, int32_t* argmax,
+                                hipStream_t st);
 int vxb_c1_dgrad4_launch(const float* dq, const float* w, const float* u, float* du, int B, int S, int accumulate, int mask,
                          float slope, hipStream_t st);
 int vxb_c1_wgrad4_launch(const float* u, const float* dq, float* dw, float* db, float* part_ws, int B, int S, hipStream_t st);

@@ -19,6 +19,7 @@
 // patch of voxels that forms one 32-row MFMA tile is conflict-free for ds_read_b128 (brute-forced over the four
 // 16-lane service groups of that instruction).  Output: C[row = voxel][col = channel] -> 128-byte stores per voxel.
 #include "common.h"
+#include "ss3d.h"
 
 namespace {
 
@@ -82,6 +83,12 @@ struct HaloArgs {
     int ksplit;
     const int* kparts;
     long long part_stride;
+    // plain launches with 64 columns per tile (N = 64), optional: SpatialSoftmax3D + max statistics of the OUTPUT (after bias and
+    // activation) taken in the epilogue -- the online-softmax partial of every (tile, channel) goes to ss_part [B][N][ntiles] (SsPart),
+    // ss_lin = the S_out coordinate values (ops.lin_table); vxb_ss3d_final_tiles_launch merges them (perceiver_lang_io.py:470 on the
+    // output of :462, without the 4.1 GB pass over u)
+    float* ss_part;
+    const float* ss_lin;
 };
 
 // bf16 pair from two fp32 (RNE).  Both forms give identical bits; which one is FASTER was measured per precision on the
@@ -339,6 +346,10 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
             acc[i][j] = hb_mfma<PM>(AC[i][0], BC[j][0], acc[i][j]);             \
     }
+    // the S_out coordinate values of the SpatialSoftmax3D statistics (ss_part launches; S_out <= 128): staged here, read in the
+    // epilogue -- published by the chunk loop's barriers
+    __shared__ float slin[128];
+    if (WD && !TL && WN == 2 && NW == 4 && g.ss_part != nullptr && tid < g.S_out) slin[tid] = g.ss_lin[tid];
     int* ttab = reinterpret_cast<int*>(wsm);        // TL: the tap table lives in the (otherwise unused) weight buffers
     if (TL) {
         for (int i = tid; i < g.ncls * 32 + g.nphase * 2; i += NTH) ttab[i] = g.taptab[i];
@@ -675,15 +686,27 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
         return;
     }
     // ---- epilogue: acc[i][j][r] = C[voxel row (r&3) + 8*(r>>2) + 4*hi of M tile i][channel j*32 + lq]
+    constexpr bool SSOK = WD && !TL && WN == 2 && NW == 4 && NT == 1;
+    const bool ss_on = SSOK && g.ss_part != nullptr;              // (uniform)
+    SsPart sa;
+    sa.m = -INFINITY; sa.s = 0.f; sa.sx = 0.f; sa.sy = 0.f; sa.sz = 0.f; sa.xmax = -INFINITY; sa.arg = 0x7fffffff;
+    const DivT divT(0.01f);
+    // one group = the four rows r4 .. r4 + 3 of M tile i: bias + activation + store, and (ss_on) the group's term of this lane's
+    // channel statistics exactly as ss_update4 forms it (vox_ops.hip): one rescale of the running sums, then four terms.  ASC: the
+    // caller visits this lane's voxels in ascending index order, so a strict > keeps the lowest index among equal maxima.
+    auto do_group = [&](int i, int r4, bool asc) {
+        float xv[4], lv[4], wxv[4], wyv[4], wzv[4];
+        bool okv[4];
+        float mn = sa.m;
 #pragma unroll
-    for (int i = 0; i < MLIM; i += ST) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        for (int u = 0; u < 4; ++u) {
+            const int m = u + 8 * (r4 >> 2) + 4 * hi;
             int dd, hh, ww;
             rowmap(i, m, dd, hh, ww);
             const int od = d0 + dd, oh = h0 + hh, ow = w0 + ww;
-            if (od < g.S_out && oh < g.S_out && ow < g.S_out) {
+            okv[u] = od < g.S_out && oh < g.S_out && ow < g.S_out;
+            float vj[NT];
+            if (okv[u]) {
                 float* op;
                 if (g.d2s_s > 0) {
                     // depth-to-space output: this workgroup's 64 columns are one phase of the fine grid
@@ -697,11 +720,64 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const int n = n0 + (wn * NT + j) * 32 + lq;
-                    float v = (PM == 2 ? acc[i][j][r] * out_sc : acc[i][j][r]) + (g.bias ? g.bias[n] : 0.f);
+                    float v = (PM == 2 ? acc[i][j][r4 + u] * out_sc : acc[i][j][r4 + u]) + (g.bias ? g.bias[n] : 0.f);
                     if (g.act == 1) v = v > 0.f ? v : v * g.slope;
                     op[n] = v;
+                    vj[j] = v;
                 }
             }
+            if (SSOK && ss_on) {
+                const float v = okv[u] ? vj[0] : 0.f;
+                const int pidx = (od * g.S_out + oh) * g.S_out + ow;
+                xv[u] = v;
+                lv[u] = divT(v);
+                mn = okv[u] ? fmaxf(mn, lv[u]) : mn;
+                const bool gt = okv[u] && (v > sa.xmax || (!asc && v == sa.xmax && pidx < sa.arg));
+                sa.xmax = gt ? v : sa.xmax;
+                sa.arg = gt ? pidx : sa.arg;
+                wyv[u] = slin[okv[u] ? od : 0]; wxv[u] = slin[okv[u] ? oh : 0]; wzv[u] = slin[okv[u] ? ow : 0];   // meshgrid 'xy' quirk
+            }
+        }
+        if (SSOK && ss_on) {
+            const float f = sa.m > -INFINITY ? exp_v(sa.m - mn) : 0.f;
+            sa.s *= f; sa.sx *= f; sa.sy *= f; sa.sz *= f;
+            sa.m = mn;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float e = okv[u] ? exp_v(lv[u] - mn) : 0.f;
+                sa.s += e; sa.sx = fmaf(e, wxv[u], sa.sx); sa.sy = fmaf(e, wyv[u], sa.sy); sa.sz = fmaf(e, wzv[u], sa.sz);
+            }
+        }
+    };
+    if (HALF == 0 && MTW == 4) {
+        // a wave's voxels in ascending index order: depth (i >> 1), then the row pair of the group (h = 2 (r4 >> 2) + hi), then the w half
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+            for (int r4 = 0; r4 < 16; r4 += 4)
+#pragma unroll
+                for (int iw = 0; iw < 2; ++iw) do_group(2 * ip + iw, r4, true);
+    } else {
+#pragma unroll
+        for (int i = 0; i < MLIM; i += ST)
+#pragma unroll
+            for (int r4 = 0; r4 < 16; r4 += 4) do_group(i, r4, false);
+    }
+    if (SSOK && ss_on) {
+        // fixed-order merge: the two row halves of a wave (lanes l, l + 32), then the two waves that share the column tile
+        SsPart ob;
+        ob.m = __shfl_xor(sa.m, 32, 64); ob.s = __shfl_xor(sa.s, 32, 64); ob.sx = __shfl_xor(sa.sx, 32, 64); ob.sy = __shfl_xor(sa.sy, 32, 64);
+        ob.sz = __shfl_xor(sa.sz, 32, 64); ob.xmax = __shfl_xor(sa.xmax, 32, 64); ob.arg = __shfl_xor(sa.arg, 32, 64);
+        if (hi == 0) ss_merge(sa, ob);
+        SsPart* sred = reinterpret_cast<SsPart*>(smem);          // (the halo is free once every wave has left the tap loop)
+        __syncthreads();
+        if (wm == 1 && hi == 0) sred[wn * 32 + lq] = sa;
+        __syncthreads();
+        if (wm == 0 && hi == 0) {
+            ss_merge(sa, sred[wn * 32 + lq]);
+            const int ntile = g.ntd * g.nth * g.ntw;
+            const int tile = (td * g.nth + th) * g.ntw + tw;
+            reinterpret_cast<SsPart*>(g.ss_part)[((long long)b * g.N + n0 + wn * 32 + lq) * ntile + tile] = sa;
         }
     }
 }
@@ -752,7 +828,7 @@ int hb_impl(int x3 /* product mode: 0 bf16, 1 bf16x3, 2 fp16 (WD kernels only, `
             const void* wt_bf16, int N, const float* bias, float* out, int act, float slope, int s2d_s, int s2d_C,
             int d2s_s, vxb_stream_t stream, const HaloArgs* fold = nullptr, const void* wfrag = nullptr,
             const int32_t* taptab = nullptr, int ncls = 0, int nphase = 0, int tap_total = 0, const float* scale = nullptr,
-            int ksplit = 1, const int32_t* kparts = nullptr) {
+            int ksplit = 1, const int32_t* kparts = nullptr, float* ss_part = nullptr, const float* ss_lin = nullptr) {
     if (x3 == 2 && (!wfrag || taptab)) return VXB_EARG;
     if (!src0 || !wt_bf16 || (!out && !fold) || B < 1 || S_in < 1 || S_out < 1) return VXB_EARG;
     if ((C0 & 31) || (C1 & 31) || C0 < 32 || (C1 > 0 && !src1) || N < 64 || (N & 63)) return VXB_ESIZE;
@@ -764,6 +840,8 @@ int hb_impl(int x3 /* product mode: 0 bf16, 1 bf16x3, 2 fp16 (WD kernels only, `
     if (ksplit < 1 || ksplit > 16 || (ksplit > 1 && (!taptab || !kparts || fold))) return VXB_EARG;
     HaloArgs g;
     g.ksplit = ksplit; g.kparts = kparts; g.part_stride = (long long)B * S_out * S_out * S_out * N;
+    g.ss_part = ss_part; g.ss_lin = ss_lin;
+    if (ss_part && (x3 != 1 || !wfrag || taptab || fold || N != 64 || !ss_lin || d2s_s > 0 || S_out > 128 || (g_halo_wn && g_halo_wn != 2))) return VXB_EARG;
     g.taptab = taptab; g.ncls = ncls; g.nphase = nphase; g.tap_total = tap_total;
     g.s2d_s = s2d_s; g.s2d_C = s2d_C; g.d2s_s = d2s_s; g.wfrag = (const u16*)wfrag;
     g.dbg = g_halo_dbg;
@@ -822,6 +900,28 @@ extern "C" int vxb_conv3_halo_bf16x3_f32(const float* src0, const float* src1, i
                                          int ncls, int tap_total, vxb_stream_t stream) {
     return hb_impl(1, src0, src1, C0, C1, B, S_in, S_out, off, replicate, wt_bf16, N, bias, out, act, slope, s2d_s, s2d_C, d2s_s,
                    stream, nullptr, wfrag, taptab, ncls, s2d_s * s2d_s * s2d_s, tap_total);
+}
+
+// vxb_conv3_halo_bf16x3_f32 for a 64-column conv (two concatenated sources, replicate padding, S_in = S_out = S, fragment-order
+// weights) followed by SpatialSoftmax3D + global max pool of its OUTPUT (vxb_ss3d_max_fwd_f32 on `out`: same outputs, same argmax
+// rule) -- the statistics of every (tile, channel) are taken in the conv's epilogue while the tile is in registers and merged by one
+// small launch: `final` + ss_final of the Q-function (perceiver_lang_io.py:462, :470) without the 4.1 GB statistics pass over u.
+// part_ws: vxb_conv3_halo_ss3d_ws(B, S) floats.  The conv output is bit-identical to the plain entry; the pooled features differ
+// from the statistics kernel's by the association of the partial sums (~1e-7 relative).
+extern "C" size_t vxb_conv3_halo_ss3d_ws(int B, int S) {
+    if (B < 1 || S < 1) return 0;
+    return (size_t)B * 64 * vxb_cdiv(S, TD) * vxb_cdiv(S, TH) * vxb_cdiv(S, TW) * 7;
+}
+extern "C" int vxb_conv3_halo_ss3d_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S, const void* wt_bf16,
+                                              const float* bias, float* out, int act, float slope, const void* wfrag, const float* lin,
+                                              float* part_ws, float* out_ss, float* out_max, float* stats, int32_t* argmax,
+                                              vxb_stream_t stream) {
+    if (!wfrag || !lin || !part_ws || !out_ss || !out_max || !stats || !argmax) return VXB_EARG;
+    const int rc = hb_impl(1, src0, src1, C0, C1, B, S, S, -1, 1, wt_bf16, 64, bias, out, act, slope, 0, 0, 0, stream, nullptr, wfrag,
+                           nullptr, 0, 0, 0, nullptr, 1, nullptr, part_ws, lin);
+    if (rc) return rc;
+    return vxb_ss3d_final_tiles_launch(part_ws, vxb_cdiv(S, TD) * vxb_cdiv(S, TH) * vxb_cdiv(S, TW), B, 64, out_ss, out_max, stats, argmax,
+                                       (hipStream_t)stream);
 }
 
 // The tap-list launch of vxb_conv3_halo_bf16x3_f32 / _bf16w_f32 (space-to-depth input, block-sparse weights: the polyphase up-conv's

@@ -294,6 +294,15 @@ __global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restri
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < N) {
         int r = rl;
+        // sixteen rows of a thread in flight (with four, the 256 rows per thread of a 1024-row partial table -- LayerNorm's dgamma /
+        // dbeta, 33 launches per step of 16 workgroups each -- were 64 dependent round trips: 24 us per launch)
+        for (; r + 60 < nb; r += 64) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = part[(long long)(r + 4 * u) * ld + c];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
+        }
         for (; r + 12 < nb; r += 16) {
             s0 += part[(long long)r * ld + c]; s1 += part[(long long)(r + 4) * ld + c];
             s2 += part[(long long)(r + 8) * ld + c]; s3 += part[(long long)(r + 12) * ld + c];

@@ -8,6 +8,7 @@
 //   * fused multi-tensor LAMB                                            (helpers/optim/lamb.py:60-124)
 // All are HBM/L2-bound; none is reshaped into a GEMM.
 #include "common.h"
+#include "ss3d.h"
 
 namespace {
 
@@ -152,21 +153,7 @@ __global__ void __launch_bounds__(256) pw_wgrad4_kernel(const float* __restrict_
 // SpatialSoftmax3D (T = 0.01) + global max.   x: [B, S^3, C] (batch stride bs), C in {64, 128}
 // stage 1: per (b, row-chunk) online-softmax partials part[b][chunk][c][7] = {m, s, sx, sy, sz, xmax, argmax}
 // =====================================================================================================
-struct SsPart { float m, s, sx, sy, sz, xmax; int arg; };
-
-__device__ __forceinline__ void ss_merge(SsPart& a, const SsPart& b) {
-    if (b.s > 0.f || b.m > -INFINITY) {
-        const float m = fmaxf(a.m, b.m);
-        const float fa = a.m > -INFINITY ? expf(a.m - m) : 0.f;
-        const float fb = b.m > -INFINITY ? expf(b.m - m) : 0.f;
-        a.s = a.s * fa + b.s * fb;
-        a.sx = a.sx * fa + b.sx * fb;
-        a.sy = a.sy * fa + b.sy * fb;
-        a.sz = a.sz * fa + b.sz * fb;
-        a.m = m;
-    }
-    if (b.xmax > a.xmax || (b.xmax == a.xmax && b.arg < a.arg)) { a.xmax = b.xmax; a.arg = b.arg; }
-}
+// (SsPart, ss_merge: ss3d.h -- shared with the `final` conv's epilogue, conv_halo_bf16.hip)
 
 __global__ void __launch_bounds__(256) ss_part_kernel(const float* __restrict__ x, long long bs, int S, int C, int ld,
                                                       const float* __restrict__ lin, int rows_per_chunk,
@@ -415,12 +402,14 @@ __global__ void __launch_bounds__(256) ss_final_kernel(const SsPart* __restrict_
 // strided subset of the chunks, then a fixed-order tree over the 256 partial results
 __global__ void __launch_bounds__(256) ss_final_wide_kernel(const SsPart* __restrict__ part, int nchunk, int B, int C, int Ct, int c0,
                                                             float* __restrict__ out_ss, float* __restrict__ out_max,
-                                                            float* __restrict__ stats, int* __restrict__ argmax) {
+                                                            float* __restrict__ stats, int* __restrict__ argmax,
+                                                            long long sb, long long sk, long long sc) {
+    // partial (b, k, c) at part[b * sb + k * sk + c * sc]: [b][chunk][c] from the statistics kernels, [b][c][tile] from the conv epilogue
     __shared__ SsPart red[256];
     const int i = blockIdx.x, b = i / C, c = i % C;
     SsPart r;
     r.m = -INFINITY; r.s = 0.f; r.sx = 0.f; r.sy = 0.f; r.sz = 0.f; r.xmax = -INFINITY; r.arg = 0x7fffffff;
-    for (int k = threadIdx.x; k < nchunk; k += 256) ss_merge(r, part[((long long)b * nchunk + k) * C + c]);
+    for (int k = threadIdx.x; k < nchunk; k += 256) ss_merge(r, part[b * sb + k * sk + c * sc]);
     red[threadIdx.x] = r;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -1222,7 +1211,7 @@ extern "C" int vxb_ss3d_max_fwd_f32(const float* x, int64_t bs, int B, int S, in
             hipLaunchKernelGGL(ss_part_kernel, dim3(nchunk, B), dim3(256), 0, st, xs, (long long)bs, S, Cs, C, lin, rpc, (SsPart*)part_ws, nchunk, 0.01f);
         if (nchunk > 128)
             hipLaunchKernelGGL(ss_final_wide_kernel, dim3(B * Cs), dim3(256), 0, st, (const SsPart*)part_ws, nchunk, B, Cs, C, c0, out_ss,
-                               out_max, stats, argmax);
+                               out_max, stats, argmax, (long long)nchunk * Cs, (long long)Cs, 1LL);
         else
             hipLaunchKernelGGL(ss_final_kernel, dim3(vxb_cdiv(B * Cs, 256)), dim3(256), 0, st, (const SsPart*)part_ws, nchunk, B, Cs, C, c0,
                                out_ss, out_max, stats, argmax);
@@ -1230,6 +1219,15 @@ extern "C" int vxb_ss3d_max_fwd_f32(const float* x, int64_t bs, int B, int S, in
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
+// final merge of the partials the `final` conv's epilogue wrote (conv_halo_bf16.hip): part [B][C][ntiles]
+int vxb_ss3d_final_tiles_launch(const float* part, int ntiles, int B, int C, float* out_ss, float* out_max, float* stats, int32_t* argmax,
+                                hipStream_t st) {
+    hipLaunchKernelGGL(ss_final_wide_kernel, dim3(B * C), dim3(256), 0, st, (const SsPart*)part, ntiles, B, C, C, 0, out_ss, out_max, stats,
+                       argmax, (long long)C * ntiles, 1LL, (long long)ntiles);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
 extern "C" int vxb_ss3d_max_bwd_f32(const float* x, int64_t bs, int B, int S, int C, const float* lin, const float* stats,
                                     const float* out_ss, const int32_t* argmax, const float* g_ss, const float* g_max,
                                     float* dx, int64_t dbs, int accumulate, vxb_stream_t stream) {
@@ -1274,7 +1272,7 @@ extern "C" int vxb_pointwise_ss3d_fwd_f32(const float* x, const float* W, const 
                        nchunk, 0.01f);
     if (nchunk > 128)
         hipLaunchKernelGGL(ss_final_wide_kernel, dim3(B * 64), dim3(256), 0, st, (const SsPart*)part_ws, nchunk, B, 64, 64, 0, out_ss,
-                           out_max, stats, argmax);
+                           out_max, stats, argmax, (long long)nchunk * 64, (long long)64, 1LL);
     else
         hipLaunchKernelGGL(ss_final_kernel, dim3(vxb_cdiv(B * 64, 256)), dim3(256), 0, st, (const SsPart*)part_ws, nchunk, B, 64, 64, 0,
                            out_ss, out_max, stats, argmax);

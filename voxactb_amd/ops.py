@@ -993,6 +993,36 @@ def ss3d_max_fwd(x, bs, B, S, C):
     return out_ss, out_max, stats, argmax
 
 
+FINAL_SS3D = os.environ.get('VOXACTB_FINAL_SS3D', '1') != '0'     # SS3D / max statistics of `final`'s output from the conv's epilogue
+
+
+def conv3_ss3d_ok(C0, C1, N, S):
+    return (FINAL_SS3D and HALO_CONV and HALO_WD and PRECISION == 'bf16x3' and N == 64 and C0 % 32 == 0 and C1 % 32 == 0 and S >= 16
+            and os.environ.get('VOXACTB_HALO_WN', '2') == '2')
+
+
+def conv3_ss3d_fwd(src0, src1, wt, bias, B, S, act=ACT_LRELU, label=None):
+    """conv3d(src0 | src1, 3x3x3, replicate padding, 64 columns) + ss3d_max_fwd of its output, the statistics taken in the conv's
+    epilogue (vxb_conv3_halo_ss3d_bf16x3_f32): -> (out [B,S,S,S,64], (out_ss, out_max, stats, argmax)).  `out` is bit-identical to
+    conv3d's; the pooled features equal ss3d_max_fwd's up to the association of the partial sums."""
+    dev = src0.device
+    C0 = src0.shape[-1]
+    C1 = src1.shape[-1] if src1 is not None else 0
+    wb = to_bf16_nk(wt)
+    assert wb.dim() == 3
+    wf = halo_wfrag(wb, C0 + C1)
+    out = torch.empty((B, S, S, S, 64), dtype=torch.float32, device=dev)
+    ws = torch.empty(int(_lib.lib().vxb_conv3_halo_ss3d_ws(B, S)), dtype=torch.float32, device=dev)
+    out_ss = torch.empty((B, 3 * 64), dtype=torch.float32, device=dev)
+    out_max = torch.empty((B, 64), dtype=torch.float32, device=dev)
+    stats = torch.empty((B, 64, 2), dtype=torch.float32, device=dev)
+    argmax = torch.empty((B, 64), dtype=torch.int32, device=dev)
+    _lib.set_meta(label or 'conv3d_bf16[k3 s1 %d->64 S%d]' % (C0 + C1, S), 2.0 * B * S ** 3 * 64 * 27 * (C0 + C1))
+    call('vxb_conv3_halo_ss3d_bf16x3_f32', src0, src1, C0, C1, B, S, wb, bias, out, act, LRELU_SLOPE, wf, lin_table(S, dev), ws,
+         out_ss, out_max, stats, argmax)
+    return out, (out_ss, out_max, stats, argmax)
+
+
 def pointwise_ss3d_fwd(x, W, bias, B, S):
     """pointwise_fwd + ss3d_max_fwd of its output in one pass (x [B,S,S,S,Cin] -> y [B,S,S,S,64], (out_ss, out_max, stats, argmax))."""
     dev = x.device
