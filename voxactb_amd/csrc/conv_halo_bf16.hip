@@ -346,9 +346,9 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
             acc[i][j] = hb_mfma<PM>(AC[i][0], BC[j][0], acc[i][j]);             \
     }
-    // the S_out coordinate values of the SpatialSoftmax3D statistics (ss_part launches; S_out <= 128): staged here, read in the
+    // the S_out coordinate values of the SpatialSoftmax3D statistics (ss_part launches; S_out <= 256): staged here, read in the
     // epilogue -- published by the chunk loop's barriers
-    __shared__ float slin[128];
+    __shared__ float slin[256];
     if (WD && !TL && WN == 2 && NW == 4 && g.ss_part != nullptr && tid < g.S_out) slin[tid] = g.ss_lin[tid];
     int* ttab = reinterpret_cast<int*>(wsm);        // TL: the tap table lives in the (otherwise unused) weight buffers
     if (TL) {
@@ -841,7 +841,7 @@ int hb_impl(int x3 /* product mode: 0 bf16, 1 bf16x3, 2 fp16 (WD kernels only, `
     HaloArgs g;
     g.ksplit = ksplit; g.kparts = kparts; g.part_stride = (long long)B * S_out * S_out * S_out * N;
     g.ss_part = ss_part; g.ss_lin = ss_lin;
-    if (ss_part && (x3 != 1 || !wfrag || taptab || fold || N != 64 || !ss_lin || d2s_s > 0 || S_out > 128 || (g_halo_wn && g_halo_wn != 2))) return VXB_EARG;
+    if (ss_part && (x3 != 1 || !wfrag || taptab || fold || N != 64 || !ss_lin || d2s_s > 0 || S_out > 256 || (g_halo_wn && g_halo_wn != 2))) return VXB_EARG;
     g.taptab = taptab; g.ncls = ncls; g.nphase = nphase; g.tap_total = tap_total;
     g.s2d_s = s2d_s; g.s2d_C = s2d_C; g.d2s_s = d2s_s; g.wfrag = (const u16*)wfrag;
     g.dbg = g_halo_dbg;

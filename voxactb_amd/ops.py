@@ -997,7 +997,7 @@ FINAL_SS3D = os.environ.get('VOXACTB_FINAL_SS3D', '1') != '0'     # SS3D / max s
 
 
 def conv3_ss3d_ok(C0, C1, N, S):
-    return (FINAL_SS3D and HALO_CONV and HALO_WD and PRECISION == 'bf16x3' and N == 64 and C0 % 32 == 0 and C1 % 32 == 0 and S >= 16
+    return (FINAL_SS3D and HALO_CONV and HALO_WD and PRECISION == 'bf16x3' and N == 64 and C0 % 32 == 0 and C1 % 32 == 0 and 16 <= S <= 256
             and os.environ.get('VOXACTB_HALO_WN', '2') == '2')
 
 
