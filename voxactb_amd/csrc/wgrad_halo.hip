@@ -572,7 +572,8 @@ static int wgrad_halo_impl(int pm, const float* dy_scale, const float* src0, con
     hipStream_t st = (hipStream_t)stream;
     // two chunks per workgroup (8 waves sharing the dY tile): measured at B = 4 in 'bf16x3' (tools/bench_wgrad_halo.py, WH_NCH):
     // + 2.7 % on the dense 128 -> 64 gradient at S = 100 (4.83 -> 4.70 ms), - 5 % on the tap-masked depth-to-space one (2.20 -> 2.31)
-    int nch = ((C0 + C1) % 32 == 0 && d2s_s <= 0) ? 2 : 1;
+    // (depth-to-space dY -- the up-conv, one phase per 64-column block -- in fp16: 5.52 -> 4.72 ms in the training step, B = 16)
+    int nch = ((C0 + C1) % 32 == 0 && (d2s_s <= 0 || pm == 2)) ? 2 : 1;
     if (g_wh_nch) nch = (g_wh_nch == 2 && (C0 + C1) % 32 == 0) ? 2 : 1;
     if (wgrad_halo_shape(S_out, pm == 1)) return vxb_wgrad_halo_launch_t44(g, pm, nch, nsplit, st);
     if (pm == 2) return nch == 2 ? wgrad_halo_launch<2, 2, 8, 2>(g, nsplit, st) : wgrad_halo_launch<2, 2, 8, 1>(g, nsplit, st);
