@@ -150,7 +150,13 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     const int n0 = (t % nnb) * N;                   // this workgroup's 64 output channels
     t /= nnb;
     int kpart = 0;
-    if (TL) { kpart = t % g.ksplit; t /= g.ksplit; }
+    if (TL) {
+        // the part is the SLOWEST index of the launch order: workgroups that run together are neighbouring tiles of one part, which read
+        // the same lines of the fine grid through their halos.  (Part fastest -- the ksplit parts of a tile side by side -- fetched
+        // 2.75 x the bytes: profiles/r03_v8_pmc_FETCH_SIZE_summary.txt, 21.5 against 7.8 M KiB per launch.)
+        const int ntile_ = g.B * g.ntd * g.nth * g.ntw;
+        kpart = t / ntile_; t -= kpart * ntile_;
+    }
     const int tw = t % g.ntw; t /= g.ntw;
     const int th = t % g.nth; t /= g.nth;
     const int td = t % g.ntd; t /= g.ntd;
@@ -791,7 +797,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
         const int xcd = lid & 7, slot = lid >> 3, q = nwg >> 3, r = nwg & 7;
         int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
         t /= g.N / (NTG * 32);
-        if (TL) t /= g.ksplit;
+        if (TL) t %= g.B * g.ntd * g.nth * g.ntw;
         const int tw = t % g.ntw, th = (t / g.ntw) % g.nth;
         const int rem = min(g.S_out - tw * TW, g.S_out - th * TH);
         if (rem <= 6 && !g_dbg_all_waves(g)) {

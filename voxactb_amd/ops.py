@@ -866,7 +866,7 @@ def s2d_taptab(k, s, dev, cpc, chunks_per_phase):
     return r
 
 
-S2D_KSPLIT = int(os.environ.get('VOXACTB_S2D_KSPLIT', '6'))    # workgroups per tile of the tap-list data gradient (1 = no split)
+S2D_KSPLIT = int(os.environ.get('VOXACTB_S2D_KSPLIT', '8'))    # workgroups per tile of the tap-list data gradient (1 = no split)
 
 
 def s2d_kparts(k, s, dev, cpc, chunks_per_phase, ksplit):
