@@ -172,15 +172,37 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_dl_kernel(FdArgs g) {
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+            // all K fragments of the key block in flight before its chain of MFMAs (the registers are there: two waves per SIMD by
+            // the LDS budget): read - wait - multiply per k-step exposed an LDS round trip eight times per tile
+            bf16x8 ahf[4], alf[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int co = kbase[kb] + ((2 * ks + hi) ^ kkey[kb]) * 8;
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(sb + co);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(sb + X3 * TILE + co);
-                sacc[kb] = fd_mma<X3>(ah, al, qfh[ks], qfl[ks], sacc[kb]);
+                ahf[ks] = *reinterpret_cast<const bf16x8*>(sb + co);
+                alf[ks] = *reinterpret_cast<const bf16x8*>(sb + X3 * TILE + co);
             }
+            __builtin_amdgcn_sched_barrier(0);          // (without it the scheduler sinks every read next to its MFMA again)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) sacc[kb] = fd_mma<X3>(ahf[ks], alf[ks], qfh[ks], qfl[ks], sacc[kb]);
         }
         __builtin_amdgcn_s_setprio(0);
+        // the V^T fragments of the whole tile are requested here, before the softmax arithmetic that does not depend on them: their
+        // LDS round trips run under it instead of in front of every group of PV MFMAs (64 VGPRs; two waves per SIMD either way)
+        const u16* vt = sb + NPL * TILE;
+        unsigned long long vaf[2][2][2][2], vlf[2][2][2][2];        // [kb][ks][db][rr]
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {            // second read: keys + 8
+                        const u16* ad = vt + vlane[db] + (kb * 32 + 16 * ks + 8 * rr) * 64;
+                        vaf[kb][ks][db][rr] = fd_tr16(ad);
+                        if (X3) vlf[kb][ks][db][rr] = fd_tr16(ad + TILE);
+                    }
+        __builtin_amdgcn_sched_barrier(0);
         const int kbase_t = kt * BKV;
         float mt = -INFINITY;
         if (kbase_t + BKV > g.Nk) {                      // only the last tile can hold keys >= Nk
@@ -223,27 +245,16 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_dl_kernel(FdArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
         // ---- O^T += V^T P^T : 2 d-blocks x (2 key blocks x 2 k-steps of 16 keys)
-        const u16* vt = sb + NPL * TILE;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const bf16x8 pfh = fd_from4(&pbh[kb][4 * ks]);
                 const bf16x8 pfl = X3 ? fd_from4(&pbl[kb][4 * ks]) : pfh;
-                unsigned long long va[2][2], vl[2][2];
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-#pragma unroll
-                    for (int rr = 0; rr < 2; ++rr) {            // second read: keys + 8
-                        const u16* ad = vt + vlane[db] + (kb * 32 + 16 * ks + 8 * rr) * 64;
-                        va[db][rr] = fd_tr16(ad);
-                        if (X3) vl[db][rr] = fd_tr16(ad + TILE);
-                    }
-                }
-#pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    const bf16x8 vfh = fd_join(va[db][0], va[db][1]);
-                    const bf16x8 vfl = X3 ? fd_join(vl[db][0], vl[db][1]) : vfh;
+                    const bf16x8 vfh = fd_join(vaf[kb][ks][db][0], vaf[kb][ks][db][1]);
+                    const bf16x8 vfl = X3 ? fd_join(vlf[kb][ks][db][0], vlf[kb][ks][db][1]) : vfh;
                     oacc[db] = fd_mma<X3>(vfh, vfl, pfh, pfl, oacc[db]);
                 }
             }
