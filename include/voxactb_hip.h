@@ -243,10 +243,12 @@ int vxb_conv3_halo_bf16x3_f32(const float* src0, const float* src1, int C0, int 
 /* The tap-list launch above (space-to-depth input + taptab: the data gradient of the polyphase up-conv, network_utils.py:245-250 via
  * perceiver_lang_io.py:449-455) with the reduction split over ksplit workgroups per tile: part p accumulates the chunks
  * kparts[p] .. kparts[p + 1] - 1 (DEVICE int32 [ksplit + 1]; a chunk = 16 input channels in bf16x3, 32 in bf16) into
- * out_parts[p] [B, S_out^3, N]; the caller sums the parts in order (vxb_sum_splits_f32).  x3 != 0: wt_bf16 = hi/lo planes. */
+ * out_parts[p] [B, S_out^3, N]; the caller sums the parts in order (vxb_sum_splits_f32).  x3 = 1: wt_bf16 = hi/lo planes;
+ * x3 = 3 ("fp16x2", two MFMAs per product): src_fine * scale[0] (device, power of two) as an fp16 hi + lo pair, the weights ONE fp16
+ * value each (wfrag from the fp16 matrix, single plane), parts multiplied by scale[1]; scale = NULL otherwise. */
 int vxb_conv3_s2d_splitk_f32(const float* src_fine, int C0, int B, int S_in, int S_out, int off, const void* wt_bf16, int x3,
                              int N, float* out_parts, int s2d_s, int s2d_C, const void* wfrag, const int32_t* taptab,
-                             int ncls, int tap_total, int ksplit, const int32_t* kparts, vxb_stream_t stream);
+                             int ncls, int tap_total, int ksplit, const int32_t* kparts, const float* scale, vxb_stream_t stream);
 /* `final` conv + SpatialSoftmax3D / global max pool of its output in one pass over the output (perceiver_lang_io.py:462 then :470;
  * network_utils.py:768-800): vxb_conv3_halo_bf16x3_f32 (N = 64, two sources, replicate padding, S_in = S_out = S, wfrag required)
  * whose epilogue also takes the online-softmax partial of every (tile, channel); one small launch merges them into the outputs of
@@ -276,6 +278,12 @@ size_t vxb_conv3_dgrad_fold_blocks(int B, int S, int N);
  * gradient, which only feeds the weight gradient of the 1x1x1 input conv (a leaf of the backward pass). */
 int vxb_conv3_dgrad_fold_f16_f32(const float* dy, int C0, int B, int S, const void* wfrag_f16, float* dst, const float* y,
                                  int acc, float slope, const float* scale, vxb_stream_t stream);
+/* ... on TWO fp16 products per term for a block that propagates (the d(u0) half): dy * scale[0] as an fp16 hi + lo pair, the weights
+ * as one fp16 value (wfrag_f16x2: single-plane fragment order of the fp16 [64][27 C0] matrix); optional by-products as in
+ * vxb_conv3_dgrad_fold_f32 (dst_scale [2] + scale_ws, dst_colsum [64] ACCUMULATED + colsum_ws). */
+int vxb_conv3_dgrad_fold_f16x2_f32(const float* dy, int C0, int B, int S, const void* wfrag_f16x2, float* dst, const float* y,
+                                   int acc, float slope, const float* scale, float* dst_scale, float* scale_ws,
+                                   float* dst_colsum, float* colsum_ws, vxb_stream_t stream);
 /* ... when that block is the data gradient of a 1x1x1 conv's output y = lrelu(W_in x + b_in) whose input x [B, S^3, 10] is a detached
  * tensor (the input conv of the Q-function, perceiver_lang_io.py:357; agent :100): it only feeds dW_in [64][10] / db_in [64], so it is
  * not stored -- the epilogue multiplies it with LeakyReLU'(y) and x, and the sums are ACCUMULATED into dW / db.

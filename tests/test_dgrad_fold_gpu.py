@@ -55,8 +55,10 @@ def test_dgrad_fold_x3_vs_autograd():
 @pytest.mark.parametrize('S,B,gain', [(16, 2, 1.0), (20, 1, 2e-8), (34, 1, 3e5)])
 def test_dgrad_fold_leaf_block_on_single_fp16_products(S, B, gain):
     """`leaf_blocks=(0,)` with WGRAD_PRECISION = 'fp16': column block 0 (a gradient that only feeds a weight gradient) runs on single
-    fp16 products with dy scaled on the device, block 1 stays bit-identical to the all-bf16x3 call; dy of ordinary, tiny and huge
-    magnitude (the scale comes from the tensor)."""
+    fp16 products with dy scaled on the device; block 1 (it propagates) runs on TWO fp16 products -- dy as an fp16 hi + lo pair, the
+    weights as one fp16 value: only the weight rounding (2^-12 per weight) separates it from the bf16x3 result -- or, with
+    DGRAD_PRECISION = 'bf16x3', stays bit-identical to the all-bf16x3 call; dy of ordinary, tiny and huge magnitude (the scale comes
+    from the tensor)."""
     C, N = 64, 128
     dy = (cl(rnd(B, C, S, S, S, seed=3)) * gain).to(DEV)
     dy[0, 0, 0, 0, :8] *= 40.0
@@ -73,10 +75,20 @@ def test_dgrad_fold_leaf_block_on_single_fp16_products(S, B, gain):
         ops.conv3_dgrad_fold(dy, wd, B, S, N, [(g0, True, None), (g1, False, y1)], leaf_blocks=(0,))
         h0, h1 = base0.clone(), torch.empty(B, S, S, S, 64, device=DEV)
         ops.conv3_dgrad_fold(dy, wd, B, S, N, [(h0, True, None), (h1, False, y1)], leaf_blocks=(0,), dy_scale=ops.absmax_scale(dy))
+        dp, ops.DGRAD_PRECISION = ops.DGRAD_PRECISION, 'bf16x3'
+        k0, k1 = base0.clone(), torch.empty(B, S, S, S, 64, device=DEV)
+        ops.conv3_dgrad_fold(dy, wd, B, S, N, [(k0, True, None), (k1, False, y1)], leaf_blocks=(0,))
+        ops.DGRAD_PRECISION = dp
     finally:
         ops.PRECISION = 'fp32'
         ops.WGRAD_PRECISION = ''
-    assert torch.equal(g1, r1) and torch.equal(h1, r1)                       # the propagating block: untouched arithmetic
+    assert torch.equal(k1, r1) and torch.equal(k0, g0)                       # 'bf16x3' data gradients: the propagating block untouched
+    assert torch.equal(g1, h1)
+    if ops.DGRAD_PRECISION == 'fp16x2':
+        e1 = float((g1 - r1).abs().max()) / float(r1.abs().max())
+        assert 0 < e1 < 4e-4, e1                                             # weights rounded to 11 bits, dy carried in 22
+    else:
+        assert torch.equal(g1, r1)
     assert torch.equal(g0, h0)
     err = float((g0 - r0).abs().max()) / float((r0 - base0).abs().max())
     assert 0 < err < 1.5e-3, err                                             # 2^-12 per operand over a 27 x 64 term sum
@@ -147,3 +159,37 @@ def test_leaf_block_folded_into_the_input_weight_gradient(B, S, gain):
     eW = float((dW.double() - 0.5 * gain - dW_ref).abs().max() / dW_ref.abs().max())
     eb = float((db.double() + 0.25 * gain - db_ref).abs().max() / db_ref.abs().max())
     assert eW < 2e-5 and eb < 2e-5, (eW, eb)
+
+
+@pytest.mark.parametrize('gain', [1.0, 3e-9, 4e6])
+def test_two_product_data_gradients_match_bf16x3_up_to_the_weight_rounding(gain):
+    """DGRAD_PRECISION = 'fp16x2' on both LDS-halo data gradients that propagate (final's d(u0) block and the polyphase up-conv's tap-list
+    launch): with weights that ARE fp16 values the two-product result equals the bf16x3 one to its own rounding (the gradient operand
+    is carried as an fp16 hi + lo pair: 22 bits); with arbitrary weights the difference is the 2^-12 weight rounding.  Gradients of
+    ordinary, tiny and huge magnitude with a 50x spike (the operand scale comes from the tensor)."""
+    B, C, k, s, G = 1, 64, 5, 5, 6
+    Lh, R = ops.polyphase_tables(k, s)
+    kl = 2 * R + 1
+    du = (cl(rnd(B, C, G * s, G * s, G * s, seed=3)) * gain).to(DEV)
+    du[0, 1, 2, 3, :4] *= 50.0
+    Sp = G + 2 * R
+    res = {}
+    for exact_w in (True, False):
+        Weff = rnd(kl ** 3 * C, s ** 3 * C, seed=1, scale=0.05).to(DEV)
+        if exact_w:
+            Weff = Weff.half().float()
+        ops.PRECISION, ops.WGRAD_PRECISION = 'bf16x3', 'fp16'
+        dp = ops.DGRAD_PRECISION
+        try:
+            wd = ops.polyphase_dgrad_weights_lowres(Weff, C, C, s, kl)
+            ops.DGRAD_PRECISION = 'bf16x3'
+            ref = ops.conv3_s2d(du, wd, C, B, G, Sp, -(kl - 1), s, C, poly_k=k)
+            ops.DGRAD_PRECISION = 'fp16x2'
+            got = ops.conv3_s2d(du, wd, C, B, G, Sp, -(kl - 1), s, C, poly_k=k)
+            got2 = ops.conv3_s2d(du, wd, C, B, G, Sp, -(kl - 1), s, C, poly_k=k, dy_scale=ops.absmax_scale(du))
+        finally:
+            ops.PRECISION, ops.WGRAD_PRECISION, ops.DGRAD_PRECISION = 'fp32', '', dp
+        assert torch.equal(got, got2)
+        res[exact_w] = float((got - ref).abs().max()) / float(ref.abs().max())
+    assert res[True] < 3e-5, res                  # fp32 accumulation noise of K = 8000 x 17.6 terms, as between two bf16x3 associations
+    assert 0 < res[False] < 4e-4, res

@@ -27,9 +27,13 @@ EMU = {k: None for k in KINDS}
 PHASE = ['fwd']
 
 
-def rnd(t, kind):
+def rnd(t, kind, role='a'):
+    """kind 'fp16w' / 'fp16a' (round 5): only the weight operand (role 'w') / only the data operand (role 'a') is rounded to fp16 --
+    what a TWO-product scheme computes that carries the other operand as an fp16 hi + lo pair (22 bits: exact for this purpose)."""
     if t is None or kind is None:
         return t
+    if kind in ('fp16w', 'fp16a'):
+        return t.half().float() if kind[-1] == role else t
     if kind == 'fp16':
         return t.half().float()
     if kind == 'bf16':
@@ -64,7 +68,7 @@ def linear_bwd(x, W, dy, dW, db=None, dx=None, dx_accumulate=False, ws=None):
     else:
         _linear_bwd(rnd(x, kw), W, rnd(dy, kw), dW, None, None, False, ws)                    # weight gradient only
         if dx is not None:
-            _linear_bwd(x, rnd(W, kd), rnd(dy, kd), torch.zeros_like(dW), None, dx, dx_accumulate, ws)   # data gradient only
+            _linear_bwd(x, rnd(W, kd, 'w'), rnd(dy, kd), torch.zeros_like(dW), None, dx, dx_accumulate, ws)   # data gradient only
     if db is not None:
         ops.colsum(dy, db, accumulate=True)             # bias gradients are fp32 column sums of the unrounded dy
 
@@ -73,6 +77,12 @@ def conv3d(src0, wt, *a, **kw):
     k = EMU['conv_fwd'] if PHASE[0] == 'fwd' else EMU['conv_dgrad']
     if PHASE[0] == 'bwd' and len(a) >= 5 and a[0] == 128 and a[4] == 3:          # (N, B, S_in, S_out, kext): final's data gradient
         k = EMU['final_dgrad'] or k
+        if HALF[0] == 'both':
+            # round 5: d(d0) half as shipped (single fp16 product: both operands rounded), d(u0) half on the kind under test
+            full = _conv3d(rnd(src0, 'fp16'), rnd(wt, 'fp16'), *a, **kw)
+            other = _conv3d(rnd(src0, k), rnd(wt, k, 'w'), *a, **kw)
+            full[..., 64:128] = other[..., 64:128]
+            return full
         if HALF[0] is not None and k is not None:
             # only one 64-column half of the data gradient (0: d(d0), 1: d(u0)) on the cheap product, the other exact
             full = _conv3d(src0, wt, *a, **kw)
@@ -82,7 +92,7 @@ def conv3d(src0, wt, *a, **kw):
             return full
     if kw.get('src1') is not None:
         kw['src1'] = rnd(kw['src1'], k)
-    return _conv3d(rnd(src0, k), rnd(wt, k), *a, **kw)
+    return _conv3d(rnd(src0, k), rnd(wt, k, 'w'), *a, **kw)
 
 
 def conv3d_wgrad(src0, dy, *a, **kw):
@@ -198,6 +208,23 @@ if __name__ == '__main__':
             run(g, 'fp32', '', dict(conv_fwd='fp16'), 1.0, 'EMU fp16 convs fwd, rest fp32')
             continue
         S = 4096.0
+        if '--round5' in sys.argv:
+            # two-product candidates for the data gradients that PROPAGATE (second session): the gradient operand as an fp16 hi + lo
+            # pair, the weights as one fp16 value ('fp16w'); the leaves as shipped (conv / big-linear weight gradients and the d(d0)
+            # half of final's data gradient on single fp16 products)
+            LEAF = dict(conv_wgrad='fp16', lin_wgrad='fp16')
+            BIG_ONLY[0] = True
+            HALF[0] = 'both'
+            run(g, 'bf16x3', 'fp32', dict(LEAF, final_dgrad=None), S, 'shipped leaves, propagating dgrads exact', attn_bwd='bf16x3')
+            run(g, 'bf16x3', 'fp32', dict(LEAF, final_dgrad='fp16w'), S, '+ d(u0): weights fp16, dY exact', attn_bwd='bf16x3')
+            run(g, 'bf16x3', 'fp32', dict(LEAF, final_dgrad='fp16a'), S, '+ d(u0): dY fp16, weights exact', attn_bwd='bf16x3')
+            run(g, 'bf16x3', 'fp32', dict(LEAF, final_dgrad='fp16'), S, '+ d(u0): single fp16 product', attn_bwd='bf16x3')
+            run(g, 'bf16x3', 'fp32', dict(LEAF, final_dgrad='fp16w', conv_dgrad='fp16w'), S, '+ all conv dgrads: weights fp16, dY exact', attn_bwd='bf16x3')
+            run(g, 'bf16x3', 'fp32', dict(LEAF, final_dgrad='fp16w', conv_dgrad='fp16w', lin_dgrad='fp16w'), S, '+ conv and linear dgrads: weights fp16', attn_bwd='bf16x3')
+            run(g, 'bf16x3', 'fp32', dict(LEAF, lin_dgrad='fp16w'), S, '+ linear dgrads only: weights fp16', attn_bwd='bf16x3')
+            HALF[0] = None
+            BIG_ONLY[0] = False
+            continue
         if '--round4' in sys.argv:
             for half in (0, 1):
                 HALF[0] = half

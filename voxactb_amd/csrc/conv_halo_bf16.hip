@@ -95,21 +95,35 @@ struct HaloArgs {
 // 128->64 forward (4 waves x 2 M tiles): the integer form 765 TF/s vs v_cvt_pk_bf16_f32 590 TF/s in 'bf16', but 351 vs 365
 // TF/s in 'bf16x3' -- the cheaper conversion bunches the two resident workgroups' ds_write bursts together.
 // PM = product mode: 0 plain bf16, 1 bf16x3 (hi | lo halves, three MFMAs per product), 2 plain fp16 (pre-scaled input,
-// saturating conversion)
+// saturating conversion), 3 "fp16x2": the input as an fp16 hi | lo pair (pre-scaled: 22 bits), the weights as ONE fp16 value, two
+// MFMAs per product -- the data gradients that propagate (DESIGN 4a, round 5 of tools/experiments/emu_precision.py: rounding the
+// WEIGHTS of a data gradient to 11 bits moves no reference gate, rounding its dY does)
 template <int PM>
 __device__ __forceinline__ f32x16 hb_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
-    if (PM == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    if (PM >= 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 template <int PM>
 __device__ __forceinline__ unsigned hb_pack2(float lo, float hi) {
-    if (PM == 2) return vxb_pack_f16(__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f));
+    if (PM >= 2) return vxb_pack_f16(__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f));
     if (PM == 1) return vxb_pack_bf16(lo, hi);
     unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
     a += 0x7fffu + ((a >> 16) & 1u);
     b += 0x7fffu + ((b >> 16) & 1u);
     return (a >> 16) | (b & 0xffff0000u);
+}
+
+// the fp32 values of a packed pair as the matrix cores will see them (bf16: the upper halves; fp16: converted back)
+template <int PM>
+__device__ __forceinline__ float hb_unpack_lo(unsigned pk) {
+    if (PM >= 2) return (float)__builtin_bit_cast(_Float16, (unsigned short)(pk & 0xffffu));
+    return __uint_as_float(pk << 16);
+}
+template <int PM>
+__device__ __forceinline__ float hb_unpack_hi(unsigned pk) {
+    if (PM >= 2) return (float)__builtin_bit_cast(_Float16, (unsigned short)(pk >> 16));
+    return __uint_as_float(pk & 0xffff0000u);
 }
 
 __device__ __forceinline__ bool g_dbg_all_waves(const HaloArgs& g) { return (g.dbg & 4) != 0; }    // experiment bit 4: no wave skipping
@@ -122,7 +136,10 @@ template <int NTG, int PM, int NW, int WD, int TL, int WN, int HALF>
                                               // per-chunk tap lists (block-sparse weights, WD only)
                                               // HALF = 1: an edge tile whose odd M tiles hold no output voxel (see the kernel below)
 __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
-    constexpr int X3 = PM == 1;
+    constexpr int X3 = PM == 1;                     // three products: input hi | lo, weight planes hi / lo
+    constexpr int X2 = PM == 3;                     // two products: input hi | lo, one weight plane
+    constexpr int HL = X3 || X2;                    // a chunk is 16 channels as hi | lo halves
+    constexpr int NF = X2 ? 1 : 2;                  // weight fragments per (tap, column tile): k halves (PM 0, 2) / planes (1) / one (3)
     constexpr int ST = HALF == 1 ? 2 : 1;           // M-tile stride of the tap loops
     constexpr int MLIM = HALF == 2 ? 3 : 8 / (NW / WN);     // ... and their end: HALF = 2 runs three of a wave's four M tiles
     constexpr int NTH = NW * 64, MTW = 8 / (NW / WN), NT = NTG / WN;
@@ -130,7 +147,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     u16* halo = smem;                               // [HALO_SLOTS][SP]
     u16* wsm = smem + HALO_SLOTS * SP;              // [2][N][LDW]
     constexpr int N = NTG * 32;
-    constexpr int CPC = X3 ? 16 : 32;               // channels per chunk
+    constexpr int CPC = HL ? 16 : 32;               // channels per chunk
     constexpr int F4P = CPC / 4;                    // float4 per voxel per chunk
     constexpr int NLD = (NPOS * F4P + NTH - 1) / NTH;   // halo float4 loads per thread per chunk (10 / 19)
     constexpr int W_V8 = (N * 4 + NTH - 1) / NTH;              // 16-byte weight loads per thread per tap (1 / 2)
@@ -299,7 +316,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
         /* term-major order: consecutive MFMAs hit different accumulators (no back-to-back dependent issue) */       \
         _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                                 \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
-            acc[i][j] = hb_mfma<PM>(AC[i][1], bfr[j][X3 ? 0 : 1], acc[i][j]);   \
+            acc[i][j] = hb_mfma<PM>(AC[i][1], bfr[j][HL ? 0 : 1], acc[i][j]);   \
         if (X3) {                                                                                                    \
             _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                             \
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
@@ -323,8 +340,8 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
 #define HD_LOADB(BQ, tap_)                                                                                           \
     if (!(g.dbg & 2) || (tap_) < 3)                                                                                   \
     _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                    \
-    _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                     \
-        BQ[j][f] = *reinterpret_cast<const bf16x8*>(g.wfrag + (((long long)(n0 / N) * wf_rows + (TL ? tapbase : ch * 27) + (tap_)) * (NTG * 2) + (wn * NT + j) * 2 + f) * 512 + lane * 8);
+    _Pragma("unroll") for (int f = 0; f < NF; ++f)                                                                    \
+        BQ[j][f] = *reinterpret_cast<const bf16x8*>(g.wfrag + (((long long)(n0 / N) * wf_rows + (TL ? tapbase : ch * 27) + (tap_)) * (NTG * NF) + (wn * NT + j) * NF + f) * 512 + lane * 8);
 #define HB_READ_A_OFF(AF, off_)                                                                                      \
     {                                                                                                                \
         const int toff_ = (off_);                                                                                    \
@@ -342,7 +359,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         _Pragma("unroll") for (int i = 0; i < MLIM; i += ST)                                                         \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
-            acc[i][j] = hb_mfma<PM>(AC[i][1], BC[j][X3 ? 0 : 1], acc[i][j]);    \
+            acc[i][j] = hb_mfma<PM>(AC[i][1], BC[j][HL ? 0 : 1], acc[i][j]);    \
         if (X3) {                                                                                                    \
             _Pragma("unroll") for (int i = 0; i < MLIM; i += ST)                                                     \
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
@@ -365,7 +382,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     {                                                                                                                \
         _Pragma("unroll") for (int i = 0; i < MLIM; i += ST)                                                         \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
-            acc[i][j] = hb_mfma<PM>(AC[i][1], BC[j][X3 ? 0 : 1], acc[i][j]);    \
+            acc[i][j] = hb_mfma<PM>(AC[i][1], BC[j][HL ? 0 : 1], acc[i][j]);    \
         if (X3) {                                                                                                    \
             _Pragma("unroll") for (int i = 0; i < MLIM; i += ST)                                                     \
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
@@ -383,7 +400,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                               \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
-            acc[i][j] = hb_mfma<PM>(AC[i][1], BC[j][X3 ? 0 : 1], acc[i][j]);    \
+            acc[i][j] = hb_mfma<PM>(AC[i][1], BC[j][HL ? 0 : 1], acc[i][j]);    \
         if (X3) {                                                                                                    \
             _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                           \
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
@@ -397,8 +414,8 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     // VGPRs in 'bf16x3', no spills -- is 3.6 % SLOWER.  The vector L1 returns data in request order for the whole CU, so HBM-latency
     // halo loads in the middle of a tap loop hold up the L2-hit B-fragment loads of both resident workgroups.)
     constexpr bool PF = false;
-    const float in_sc = (PM == 2 && g.scale) ? g.scale[0] : 1.0f;
-    const float out_sc = (PM == 2 && g.scale) ? g.scale[1] : 1.0f;
+    const float in_sc = (PM >= 2 && g.scale) ? g.scale[0] : 1.0f;
+    const float out_sc = (PM >= 2 && g.scale) ? g.scale[1] : 1.0f;
     float4 hv[NLD];
     auto halo_issue = [&](int ch_) {
         const int cb_ = ch_ * CPC;
@@ -459,14 +476,14 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             if (st_goff[i] != -1 && !dbg_skip_stage) {
-                if (PM == 2) { hv[i].x *= in_sc; hv[i].y *= in_sc; hv[i].z *= in_sc; hv[i].w *= in_sc; }
+                if (PM >= 2) { hv[i].x *= in_sc; hv[i].y *= in_sc; hv[i].z *= in_sc; hv[i].w *= in_sc; }
                 uint2 pk;
                 pk.x = hb_pack2<PM>(hv[i].x, hv[i].y); pk.y = hb_pack2<PM>(hv[i].z, hv[i].w);
                 *reinterpret_cast<uint2*>(&halo[st_soff[i]]) = pk;
-                if (X3) {
+                if (HL) {
                     uint2 q;
-                    q.x = hb_pack2<PM>(hv[i].x - __uint_as_float(pk.x << 16), hv[i].y - __uint_as_float(pk.x & 0xffff0000u));
-                    q.y = hb_pack2<PM>(hv[i].z - __uint_as_float(pk.y << 16), hv[i].w - __uint_as_float(pk.y & 0xffff0000u));
+                    q.x = hb_pack2<PM>(hv[i].x - hb_unpack_lo<PM>(pk.x), hv[i].y - hb_unpack_hi<PM>(pk.x));
+                    q.y = hb_pack2<PM>(hv[i].z - hb_unpack_lo<PM>(pk.y), hv[i].w - hb_unpack_hi<PM>(pk.y));
                     *reinterpret_cast<uint2*>(&halo[st_soff[i] + 16]) = q;
                 }
             }
@@ -649,7 +666,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
                         const float4 v = *reinterpret_cast<const float4*>(&ft[(((dl + dd) * TH + hl + hh) * TW + wl + ww) * 64 + c4]);
                         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
                     }
-            if (PM == 2) { a.x *= out_sc; a.y *= out_sc; a.z *= out_sc; a.w *= out_sc; }
+            if (PM >= 2) { a.x *= out_sc; a.y *= out_sc; a.z *= out_sc; a.w *= out_sc; }
             const int jd = min(max(id - P, 0), S - 1), jh = min(max(ih - P, 0), S - 1), jw = min(max(iw - P, 0), S - 1);
             const long long o = ((((long long)b * S + jd) * S + jh) * S + jw) * 64 + c4;
             if (facc) {
@@ -726,7 +743,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const int n = n0 + (wn * NT + j) * 32 + lq;
-                    float v = (PM == 2 ? acc[i][j][r4 + u] * out_sc : acc[i][j][r4 + u]) + (g.bias ? g.bias[n] : 0.f);
+                    float v = (PM >= 2 ? acc[i][j][r4 + u] * out_sc : acc[i][j][r4 + u]) + (g.bias ? g.bias[n] : 0.f);
                     if (g.act == 1) v = v > 0.f ? v : v * g.slope;
                     op[n] = v;
                     vj[j] = v;
@@ -836,6 +853,7 @@ int hb_impl(int x3 /* product mode: 0 bf16, 1 bf16x3, 2 fp16 (WD kernels only, `
             const int32_t* taptab = nullptr, int ncls = 0, int nphase = 0, int tap_total = 0, const float* scale = nullptr,
             int ksplit = 1, const int32_t* kparts = nullptr, float* ss_part = nullptr, const float* ss_lin = nullptr) {
     if (x3 == 2 && (!wfrag || taptab)) return VXB_EARG;
+    if (x3 == 3 && (!wfrag || !scale || src1 || replicate || d2s_s > 0)) return VXB_EARG;     // data gradients only
     if (!src0 || !wt_bf16 || (!out && !fold) || B < 1 || S_in < 1 || S_out < 1) return VXB_EARG;
     if ((C0 & 31) || (C1 & 31) || C0 < 32 || (C1 > 0 && !src1) || N < 64 || (N & 63)) return VXB_ESIZE;
     if (!hb_aligned16(src0) || !hb_aligned16(wt_bf16) || (src1 && !hb_aligned16(src1))) return VXB_ESIZE;
@@ -870,6 +888,7 @@ int hb_impl(int x3 /* product mode: 0 bf16, 1 bf16x3, 2 fp16 (WD kernels only, `
     // 64 output channels per workgroup (162-225 VGPRs -> two workgroups per CU); N = 128 runs two column blocks that each
     // stage the halo -- cheaper than the register spills of a 128-wide accumulator tile.
     if (x3 == 2) return hb_launch<2, 2, 4, 1>(g, nblk, st);
+    if (x3 == 3) return g.taptab ? hb_launch<2, 3, 4, 1, 1, 2>(g, nblk, st) : hb_launch<2, 3, 4, 1, 0, 2>(g, nblk, st);
     const int wn = g_halo_wn ? g_halo_wn : (x3 ? 2 : 1);
     if (g.taptab && wn == 2) return x3 ? hb_launch<2, 1, 4, 1, 1, 2>(g, nblk, st) : hb_launch<2, 0, 4, 1, 1, 2>(g, nblk, st);
     if (g.taptab) return x3 ? hb_launch<2, 1, 4, 1, 1>(g, nblk, st) : hb_launch<2, 0, 4, 1, 1>(g, nblk, st);
@@ -935,12 +954,17 @@ extern "C" int vxb_conv3_halo_ss3d_bf16x3_f32(const float* src0, const float* sr
 // (kparts: DEVICE int32 [ksplit + 1], kparts[0] = 0, kparts[ksplit] = C0 / (16 or 32 channels per chunk)) into out_parts[p] [B, S_out^3, N];
 // the caller sums the parts (vxb_sum_splits_f32).  B * ceil(S_out/4) * ceil(S_out/8)^2 tiles of 8000 input channels are 864 workgroups
 // of ~5 ms at the step's size -- 1.7 rounds of the chip's 512 slots; with ksplit parts the tail is a ksplit-th as long.
+// x3 = 3 ("fp16x2", see the product modes in the kernel): src_fine is multiplied by scale[0] (device, a power of two:
+// vxb_absmax_scale_f32) and carried as an fp16 hi + lo pair, the weights are ONE fp16 value each -- wfrag = ops.halo_wfrag_x2 of the
+// fp16 [N][27 C0] matrix, listed taps only; wt_bf16 is then only checked for alignment (pass wfrag) -- and every part is multiplied
+// by scale[1]: two MFMAs per product instead of three.
 extern "C" int vxb_conv3_s2d_splitk_f32(const float* src_fine, int C0, int B, int S_in, int S_out, int off, const void* wt_bf16, int x3,
                                         int N, float* out_parts, int s2d_s, int s2d_C, const void* wfrag, const int32_t* taptab,
-                                        int ncls, int tap_total, int ksplit, const int32_t* kparts, vxb_stream_t stream) {
-    if (!taptab || !wfrag || !kparts || ksplit < 1) return VXB_EARG;
-    return hb_impl(x3 ? 1 : 0, src_fine, nullptr, C0, 0, B, S_in, S_out, off, 0, wt_bf16, N, nullptr, out_parts, 0, 0.f, s2d_s, s2d_C, 0,
-                   stream, nullptr, wfrag, taptab, ncls, s2d_s * s2d_s * s2d_s, tap_total, nullptr, ksplit, kparts);
+                                        int ncls, int tap_total, int ksplit, const int32_t* kparts, const float* scale,
+                                        vxb_stream_t stream) {
+    if (!taptab || !wfrag || !kparts || ksplit < 1 || x3 < 0 || x3 == 2 || x3 > 3 || (x3 == 3) != (scale != nullptr)) return VXB_EARG;
+    return hb_impl(x3, src_fine, nullptr, C0, 0, B, S_in, S_out, off, 0, wt_bf16, N, nullptr, out_parts, 0, 0.f, s2d_s, s2d_C, 0,
+                   stream, nullptr, wfrag, taptab, ncls, s2d_s * s2d_s * s2d_s, tap_total, scale, ksplit, kparts);
 }
 
 // Data gradient of a 3x3x3 replicate-padded conv fused with the adjoint of its padding (vxb_conv3_halo_* followed by
@@ -1002,6 +1026,36 @@ extern "C" int vxb_conv3_dgrad_fold_f16_f32(const float* dy, int C0, int B, int 
     f.amax_part = nullptr; f.colsum_part = nullptr;
     return hb_impl(2, dy, nullptr, C0, 0, B, S, S_out, -2 * pad, 0, wfrag_f16, 64, nullptr, nullptr, 0, slope, 0, 0, 0, stream, &f,
                    wfrag_f16, nullptr, 0, 0, 0, scale);
+}
+
+// One 64-column block of the data gradient + padding adjoint on TWO fp16 products per term ("fp16x2": dy * scale[0] as an fp16
+// hi + lo pair, the weights as one fp16 value; wfrag_f16x2 = ops.halo_wfrag_x2 of the fp16 [64][27 C0] matrix): for the blocks that
+// PROPAGATE -- the d(u0) half of `final`'s data gradient (perceiver_lang_io.py:462) -- with the optional by-products of
+// vxb_conv3_dgrad_fold_f32 (operand scale of dst, column sums of dst).  Against the reference's gradients the weight rounding of a
+// data gradient moves no gate (tools/experiments/emu_precision.py --round5), and a third of the MFMAs is gone.
+extern "C" int vxb_conv3_dgrad_fold_f16x2_f32(const float* dy, int C0, int B, int S, const void* wfrag_f16x2, float* dst, const float* y,
+                                              int acc, float slope, const float* scale, float* dst_scale, float* scale_ws,
+                                              float* dst_colsum, float* colsum_ws, vxb_stream_t stream) {
+    if (!dy || !wfrag_f16x2 || !dst || !scale || S < 2) return VXB_EARG;
+    if ((dst_scale && !scale_ws) || (dst_colsum && !colsum_ws)) return VXB_EARG;
+    const int pad = 1, S_out = S + 2 * pad;
+    if ((S_out - 1 - pad) / TD != (S_out - 1) / TD || (S_out - 1 - pad) / TH != (S_out - 1) / TH || (S_out - 1 - pad) / TW != (S_out - 1) / TW)
+        return VXB_ESIZE;
+    HaloArgs f;
+    f.fold_pad = pad; f.fold_S = S; f.fold_dst[0] = dst; f.fold_dst[1] = nullptr; f.fold_y[0] = y; f.fold_y[1] = nullptr;
+    f.fold_acc[0] = acc; f.fold_acc[1] = 0;
+    f.amax_part = dst_scale ? reinterpret_cast<unsigned*>(scale_ws) : nullptr;
+    f.colsum_part = dst_colsum ? colsum_ws : nullptr;
+    int rc = hb_impl(3, dy, nullptr, C0, 0, B, S, S_out, -2 * pad, 0, wfrag_f16x2, 64, nullptr, nullptr, 0, slope, 0, 0, 0, stream, &f,
+                     wfrag_f16x2, nullptr, 0, 0, 0, scale);
+    if (rc) return rc;
+    const int nblk = (int)vxb_conv3_dgrad_fold_blocks(B, S, 64);
+    if (dst_colsum) {
+        rc = vxb_rows64_sum_launch(colsum_ws, nblk, dst_colsum, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    if (!dst_scale) return VXB_OK;
+    return vxb_absmax_finish_launch(f.amax_part, nblk, dst_scale, (hipStream_t)stream);
 }
 
 // The same launch when the 64-column block is the data gradient of a 1x1x1 conv's OUTPUT y [B, S^3, 64] = lrelu(W_in x + b_in) whose

@@ -744,6 +744,22 @@ def halo_wfrag(wb, Ct):
     return v.permute(0, 4, 3, 1, 5, 6, 2, 7).contiguous()                 # (nb, ch, tap, j, f, hi, lq, e)
 
 
+def halo_wfrag_x2(w16, Ct):
+    """fp16 weights [N][27*Ct] -> MFMA fragment order for the 'fp16x2' product mode of the LDS-halo conv (the input as an fp16
+    hi | lo pair, 16 channels per chunk, ONE weight fragment per (tap, column tile)): [N/64][chunk][tap][column tile 2][lane = hi*32 +
+    lq][8]."""
+    N = w16.shape[0]
+    v = w16.view(N // 64, 2, 32, 27, Ct // 16, 2, 8)                    # (nb, j, lq, tap, ch, hi, e)
+    return v.permute(0, 4, 3, 1, 5, 2, 6).contiguous()                  # (nb, ch, tap, j, hi, lq, e)
+
+
+# product type of the data gradients that PROPAGATE (final's d(u0), the up-conv's): 'fp16x2' = the gradient operand as an fp16 hi + lo
+# pair (pre-scaled by a device-side power of two), the weights as one fp16 value: two MFMAs per product instead of bf16x3's three;
+# against the reference digests F5g / F5c3 rounding the WEIGHTS of a data gradient to 11 bits moves no gate, rounding dY does
+# (tools/experiments/emu_precision.py --round5, profiles/r03_emu_6_two_product_dgrads.log).  'bf16x3': round 2's arithmetic.
+DGRAD_PRECISION = os.environ.get('VOXACTB_DGRAD_PRECISION', 'fp16x2')
+
+
 def dgrad_fold_ok(C_dy, N, S):
     """the fused data-gradient + fold kernel: bf16 modes, 3x3x3 / pad 1, border groups inside one 4x8x8 tile."""
     So = S + 2
@@ -802,6 +818,14 @@ def conv3_dgrad_fold(dy, wt_dgrad, B, S, N, dsts, label=None, dy_scale=None, lea
                 if nb in colsum_into:
                     cs = colsum_into[nb]
                     cws = torch.empty(64 * (nblk + 64), dtype=torch.float32, device=dy.device)
+                if DGRAD_PRECISION == 'fp16x2':
+                    if sc is None:
+                        _lib.set_meta(lbl, 0.0)
+                        sc = absmax_scale(dy)
+                    wf2 = halo_wfrag_x2(wt_dgrad[:, 64 * nb:64 * nb + 64].t().contiguous().half(), C0)
+                    _lib.set_meta(lbl, flops / len(dsts))
+                    call('vxb_conv3_dgrad_fold_f16x2_f32', dy, C0, B, S, wf2, dst, yv, int(acc), LRELU_SLOPE, sc, dsc, sws, cs, cws)
+                    continue
                 _lib.set_meta(lbl, flops / len(dsts))
                 call('vxb_conv3_dgrad_fold_f32', dy, C0, B, S, wb, 1, 64, dst, None, yv, None, int(acc), 0, LRELU_SLOPE, wf[nb:nb + 1],
                      dsc, sws, cs, cws)
@@ -888,7 +912,7 @@ def s2d_kparts(k, s, dev, cpc, chunks_per_phase, ksplit):
     return r
 
 
-def conv3_s2d(src_fine, wt, N, B, G, S_out, off, s, Cf, label=None, poly_k=None):
+def conv3_s2d(src_fine, wt, N, B, G, S_out, off, s, Cf, label=None, poly_k=None, dy_scale=None):
     """out[B, S_out^3, N] = 3x3x3 zero-pad conv over the low-res grid G^3 whose input channel (phase, co) is read from
     src_fine [B, (G*s)^3, Cf] at fine voxel (q*s + r); wt fp32 [(tap, phase, co)][N].  LDS-halo kernel only (bf16 modes).
     poly_k: wt is the data gradient of the polyphase up-conv of a k^3 kernel -- only its non-zero (tap, phase) blocks are
@@ -910,8 +934,19 @@ def conv3_s2d(src_fine, wt, N, B, G, S_out, off, s, Cf, label=None, poly_k=None)
         ks = S2D_KSPLIT
         kp = s2d_kparts(poly_k, s, src_fine.device, cpc, Cf // cpc, ks)
         parts = torch.empty((ks, B, S_out, S_out, S_out, N), dtype=torch.float32, device=src_fine.device)
-        _lib.set_meta(lbl, 2.0 * B * S_out ** 3 * N * 27 * C0 * frac)
-        call('vxb_conv3_s2d_splitk_f32', src_fine, C0, B, G, S_out, off, wb, int(x3), N, parts, s, Cf, wf, tt, ncls, total, ks, kp)
+        if x3 and DGRAD_PRECISION == 'fp16x2' and WGRAD_PRECISION == 'fp16' and src_fine.is_contiguous():
+            # two fp16 products per term: src_fine * 2^k as an fp16 hi + lo pair, the weights as one fp16 value (single-plane fragments)
+            sc = dy_scale
+            if sc is None:
+                _lib.set_meta(lbl, 0.0)
+                sc = absmax_scale(src_fine)
+            wf2 = halo_wfrag_x2(wt.t().contiguous().half(), C0)
+            wf2 = wf2.view(wf2.shape[0], wf2.shape[1] * 27, -1).index_select(1, rows).contiguous()
+            _lib.set_meta(lbl, 2.0 * B * S_out ** 3 * N * 27 * C0 * frac)
+            call('vxb_conv3_s2d_splitk_f32', src_fine, C0, B, G, S_out, off, wf2, 3, N, parts, s, Cf, wf2, tt, ncls, total, ks, kp, sc)
+        else:
+            _lib.set_meta(lbl, 2.0 * B * S_out ** 3 * N * 27 * C0 * frac)
+            call('vxb_conv3_s2d_splitk_f32', src_fine, C0, B, G, S_out, off, wb, int(x3), N, parts, s, Cf, wf, tt, ncls, total, ks, kp, None)
         sum_splits(parts, ks, out.numel(), out)
         return out
     _lib.set_meta(lbl, 2.0 * B * S_out ** 3 * N * 27 * C0 * frac)
