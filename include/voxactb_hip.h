@@ -182,6 +182,11 @@ int vxb_split_bf16_f32(const float* src, int64_t ld, int64_t rows, int cols, voi
 int vxb_gemm_wide_bf16x3_f32(const float* A, int64_t lda, const void* Bw_frag, float* C, int64_t ldc, const float* bias,
                              const float* residual, int M, int N, int K, int act, float slope, int accumulate,
                              vxb_stream_t stream);
+/* ... on TWO fp16 products per term for the data gradients of the linear layers (dX = dY @ W, perceiver_lang_io.py:74-132 backward):
+ * A = dY times scale[0] / 16 as an fp16 hi + lo pair, the weights as one fp16 value (Bw_frag16: single-plane fragment order of the fp16
+ * [N][K] matrix, vxb_split_bf16_batch_f32 flag bit 3), the sums times 16 scale[1]; scale = device {2^k, 2^-k}. */
+int vxb_gemm_wide_f16x2_f32(const float* A, int64_t lda, const void* Bw_frag16, float* C, int64_t ldc, const float* residual,
+                            int M, int N, int K, int accumulate, const float* scale, vxb_stream_t stream);
 /* FeedForward with GEGLU (perceiver_lang_io.py:74-78, :100-106) on the wide kernel.  _fwd: the up-projection h [M][2 F] = A @ W^T + bias
  * and gg [M][F] = h[:, :F] * gelu(h[:, F:]) from one launch (Bw_frag: fragment order with the value / gate rows interleaved, see
  * vxb_split_bf16_batch_f32 flag bit 2); 2 F % 512 == 0.  _bwd: the data gradient of the down-projection d(gg) = dY [M][K] @ W2 (Bw_frag:

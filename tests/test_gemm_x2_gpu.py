@@ -1,0 +1,72 @@
+"""GPU: data gradient of a linear layer on two fp16 products (vxb_gemm_wide_f16x2_f32 through ops.linear_bwd: dY * 2^k as an fp16
+hi + lo pair, the weight as one fp16 value, its single-plane fragments made by the batched weight split) against the bf16x3 GEMM:
+equal to fp32 rounding when the weights ARE fp16 values, 2^-12 per weight otherwise; gradients of ordinary, tiny and huge magnitude
+(first call: exact operand scale from an absmax pass; later calls: the delayed scale of the weight-gradient launch)."""
+import pytest
+import torch
+
+from voxactb_amd import ops
+from .test_ops_gpu import rnd, DEV
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('N,K', [(512, 512), (256, 1024), (2048, 512)])
+@pytest.mark.parametrize('gain', [1.0, 2e-9, 5e5])
+def test_linear_dgrad_on_two_fp16_products(N, K, gain):
+    M = 2048
+    x = rnd(M, K, seed=1).to(DEV)
+    dy = (rnd(M, N, seed=2) * gain).to(DEV)
+    dy[3, :5] *= 30.0
+    res = {}
+    state = (ops.PRECISION, ops.WGRAD_PRECISION, ops.GENERIC_WGRAD_F16, ops.DGRAD_PRECISION)
+    try:
+        ops.PRECISION, ops.WGRAD_PRECISION, ops.GENERIC_WGRAD_F16 = 'bf16x3', 'fp16', True
+        for exact_w in (True, False):
+            W = (rnd(N, K, seed=3, scale=0.05)).to(DEV)
+            if exact_w:
+                W = W.half().float()
+            out = {}
+            for mode in ('bf16x3', 'fp16x2'):
+                ops.DGRAD_PRECISION = mode
+                ops.new_step()
+                ops._GRAD_SCALE.clear()
+                ops.prepare_linear_weights([W], f16_dgrad=True)
+                dxs = []
+                for it in range(2):                      # second call: the delayed scale reported by the first weight-gradient launch
+                    dW, db, dx = torch.zeros_like(W), torch.zeros(N, device=DEV), torch.full((M, K), float('nan'), device=DEV)
+                    ops.linear_bwd(x, W, dy, dW, db, dx)
+                    dxs.append(dx)
+                assert torch.isfinite(dxs[0]).all() and torch.isfinite(dxs[1]).all()
+                out[mode] = dxs
+            ref = out['bf16x3'][0]
+            assert torch.equal(out['bf16x3'][0], out['bf16x3'][1])
+            scale = float(ref.abs().max())
+            res[exact_w] = [float((d - ref).abs().max()) / scale for d in out['fp16x2']]
+    finally:
+        ops.PRECISION, ops.WGRAD_PRECISION, ops.GENERIC_WGRAD_F16, ops.DGRAD_PRECISION = state
+        ops.new_step()
+        ops._GRAD_SCALE.clear()
+    assert max(res[True]) < 2e-5, res                 # exact weights, dY in 22 bits: what is left is bf16x3's own dropped lo * lo terms
+    assert 0 < max(res[False]) < 4e-4, res            # ... the 2^-12 weight rounding over K terms
+
+
+def test_linear_dgrad_accumulates_into_dx():
+    M, N, K = 1024, 512, 512
+    x, dy, W = rnd(M, K, seed=1).to(DEV), rnd(M, N, seed=2).to(DEV), rnd(N, K, seed=3, scale=0.05).to(DEV).half().float()
+    base = rnd(M, K, seed=4).to(DEV)
+    state = (ops.PRECISION, ops.WGRAD_PRECISION, ops.GENERIC_WGRAD_F16, ops.DGRAD_PRECISION)
+    try:
+        ops.PRECISION, ops.WGRAD_PRECISION, ops.GENERIC_WGRAD_F16, ops.DGRAD_PRECISION = 'bf16x3', 'fp16', True, 'fp16x2'
+        ops.new_step()
+        ops._GRAD_SCALE.clear()
+        ops.prepare_linear_weights([W], f16_dgrad=True)
+        dx0 = torch.empty(M, K, device=DEV)
+        ops.linear_bwd(x, W, dy, torch.zeros_like(W), None, dx0)
+        dx1 = base.clone()
+        ops.linear_bwd(x, W, dy, torch.zeros_like(W), None, dx1, dx_accumulate=True)
+    finally:
+        ops.PRECISION, ops.WGRAD_PRECISION, ops.GENERIC_WGRAD_F16, ops.DGRAD_PRECISION = state
+        ops.new_step()
+        ops._GRAD_SCALE.clear()
+    assert float((dx1 - (base + dx0)).abs().max()) < 2e-5 * float(dx0.abs().max())

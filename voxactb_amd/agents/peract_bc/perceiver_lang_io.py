@@ -481,7 +481,8 @@ class PerceiverEngine:
             if self._lin_weights is None:
                 self._lin_weights = [n for n, prm in self.P.items() if prm.dim() == 2 and n.endswith('.weight') and prm.numel() >= 4096]
             ops.prepare_linear_weights([self.p(n) for n in self._lin_weights],
-                                       geglu=[self.p(n) for n in self._lin_weights if n.endswith('.fn.net.0.weight')])
+                                       geglu=[self.p(n) for n in self._lin_weights if n.endswith('.fn.net.0.weight')],
+                                       f16_dgrad=save and self.precision == 'bf16x3' and self.wgrad_precision == 'fp16')
             return self._forward(vox, proprio, lang_token_embs, training, save, seed, proprio_left)
         finally:
             ops.PRECISION = 'fp32'

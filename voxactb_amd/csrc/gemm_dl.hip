@@ -387,7 +387,8 @@ __global__ void __launch_bounds__(256) split_bf16_kernel(const float* __restrict
 // flags bit 1 the (possibly transposed) [n][k] matrix is written in MFMA fragment order [n / 32][k / 16][nplanes][64 lanes][8]
 // instead (n % 32 == 0, k % 16 == 0): the weight operand of vxb_gemm_wide_bf16x3_f32 / vxb_gemm_dl_f32 without a shuffling copy;
 // with bit 2 as well (n % 64 == 0) the rows are interleaved for vxb_gemm_wide_geglu_fwd_f32: row q < n / 2 goes to position
-// (q / 32) * 64 + q % 32, row n / 2 + q to (q / 32) * 64 + 32 + q % 32.
+// (q / 32) * 64 + q % 32, row n / 2 + q to (q / 32) * 64 + 32 + q % 32; with bit 3 (and bit 1) the entry is ONE plane of fp16 values
+// (RNE; [n / 32][k / 16][64 lanes][8]): the weight operand of vxb_gemm_wide_f16x2_f32.
 // The per-weight launches (one split + one ATen transpose copy each, ~120 per step at ~11 us of latency apiece) cost more
 // than moving the 33 M parameters.  A workgroup converts one 64 x 64 tile through LDS.
 struct SplitDesc { const float* src; u16* dst; long long rows, cols, transposed, tile0; };
@@ -401,6 +402,8 @@ __global__ void __launch_bounds__(256) split_batch_kernel(const SplitDesc* __res
     }
     const SplitDesc d = desc[lo_i];
     const bool tr = (d.transposed & 1) != 0, frag = (d.transposed & 2) != 0, glu = (d.transposed & 4) != 0;
+    const bool h16 = (d.transposed & 8) != 0;     // ONE fp16 plane (fragment order): the weight operand of vxb_gemm_wide_f16x2_f32
+    if (h16) nplanes = 1;
     const int tcols = (int)((d.cols + 63) >> 6);
     const int t = (int)(blockIdx.x - d.tile0);
     const int r0 = (t / tcols) * 64, c0 = (t % tcols) * 64;
@@ -421,7 +424,7 @@ __global__ void __launch_bounds__(256) split_batch_kernel(const SplitDesc* __res
         if (or0 + orr >= orows || oc0 + oc >= ocols) continue;
         const float a = tr ? tile[oc][orr] : tile[orr][oc];
         const float b = tr ? tile[oc + 1][orr] : tile[orr][oc + 1];
-        const unsigned ph = vxb_pack_bf16(a, b);
+        const unsigned ph = h16 ? vxb_pack_f16(a, b) : vxb_pack_bf16(a, b);
         long long n_ = or0 + orr;
         const long long k_ = oc0 + oc;
         if (glu) {           // GEGLU up-projection: every 64-row block of the fragment order = [32 value rows | their 32 gate rows]

@@ -48,14 +48,30 @@ struct GwArgs {
     int geglu, F;
     float* C2;
     const float* H;
+    // X2 kernel ("fp16x2", the data gradients of the linear layers: two MFMAs per product instead of three): A * scale[0] * 2^-4 is
+    // carried as an fp16 hi | lo pair, Bfrag holds ONE fp16 plane ([N / 32][K / 16][64 lanes][8]), the sums are multiplied by
+    // scale[1] * 2^4.  scale = {2^k, 2^-k} on the device: the operand scale of this dY from the weight-gradient launch of the same
+    // linear_bwd (delayed by one step, 5 bits of headroom; 4 more here: a propagating gradient may jump 512-fold between steps)
+    const float* scale;
 };
 
-__global__ void __launch_bounds__(512) gemm_wide_x3_kernel(GwArgs g) {
+typedef _Float16 gw_f16x8 __attribute__((ext_vector_type(8)));
+template <int X2>
+__device__ __forceinline__ f32x16 gw_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+    if (X2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gw_f16x8, a), __builtin_bit_cast(gw_f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// X2 = 0: bf16x3 (hi*hi + hi*lo + lo*hi), X2 = 1: fp16x2 (A hi | lo, one weight plane)
+template <int X2>
+__global__ void __launch_bounds__(512) gemm_wide_kernel(GwArgs g) {
     __shared__ __attribute__((aligned(16))) u16 As[2][2][WBM * WLD];          // [stage][plane]: 40 KB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);                  // this wave's 64 columns
     const int m0 = blockIdx.x * WBM;
     const int nkt = g.K / WBK, nks = g.K >> 4;
+    constexpr int NPB = X2 ? 1 : 2;                                           // weight planes
+    const float in_sc = X2 ? g.scale[0] * 0.0625f : 1.f, out_sc = X2 ? g.scale[1] * 16.f : 1.f;
 
     // ---- A: thread -> row tid / 4, 8 consecutive k
     const int ar = tid >> 2, akq = (tid & 3) * 8;
@@ -74,22 +90,30 @@ __global__ void __launch_bounds__(512) gemm_wide_x3_kernel(GwArgs g) {
         unsigned* hp_ = reinterpret_cast<unsigned*>(&h_);                                                            \
         unsigned* lp_ = reinterpret_cast<unsigned*>(&l_);                                                            \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                               \
-            hp_[e] = vxb_pack_bf16(v_[2 * e], v_[2 * e + 1]);                                                        \
-            lp_[e] = vxb_pack_bf16(v_[2 * e] - __uint_as_float(hp_[e] << 16), v_[2 * e + 1] - __uint_as_float(hp_[e] & 0xffff0000u)); \
+            if (X2) {                                                                                                \
+                const float a_ = __builtin_amdgcn_fmed3f(v_[2 * e] * in_sc, -65504.f, 65504.f);                      \
+                const float b_ = __builtin_amdgcn_fmed3f(v_[2 * e + 1] * in_sc, -65504.f, 65504.f);                  \
+                hp_[e] = vxb_pack_f16(a_, b_);                                                                       \
+                lp_[e] = vxb_pack_f16(a_ - (float)__builtin_bit_cast(_Float16, (unsigned short)(hp_[e] & 0xffffu)),  \
+                                      b_ - (float)__builtin_bit_cast(_Float16, (unsigned short)(hp_[e] >> 16)));     \
+            } else {                                                                                                 \
+                hp_[e] = vxb_pack_bf16(v_[2 * e], v_[2 * e + 1]);                                                    \
+                lp_[e] = vxb_pack_bf16(v_[2 * e] - __uint_as_float(hp_[e] << 16), v_[2 * e + 1] - __uint_as_float(hp_[e] & 0xffff0000u)); \
+            }                                                                                                        \
         }                                                                                                            \
         *reinterpret_cast<uint4*>(&As[(stage_)][0][ar * WLD + akq]) = h_;                                            \
         *reinterpret_cast<uint4*>(&As[(stage_)][1][ar * WLD + akq]) = l_;                                            \
     }
     // ---- B fragments of this wave's two 32-column tiles: frag(j, ks, plane) at ((j * nks + ks) * 2 + plane) * 512 + lane * 8
     const int cg = blockIdx.y;                                                // 512-column group (N = 512: one)
-    const u16* __restrict__ bfb = g.Bfrag + ((long long)(cg * 16 + wn * 2) * nks * 2) * 512 + lane * 8;
+    const u16* __restrict__ bfb = g.Bfrag + ((long long)(cg * 16 + wn * 2) * nks * NPB) * 512 + lane * 8;
     bf16x8 bq[3][2][2];
 #define GW_LOADB(S, ks_)                                                                                              \
     {                                                                                                                \
         const long long k_ = min((ks_), nks - 1);                                                                    \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
-        _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                                 \
-            bq[S][j][p] = *reinterpret_cast<const bf16x8*>(bfb + (((long long)j * nks + k_) * 2 + p) * 512);         \
+        _Pragma("unroll") for (int p = 0; p < NPB; ++p)                                                               \
+            bq[S][j][p] = *reinterpret_cast<const bf16x8*>(bfb + (((long long)j * nks + k_) * NPB + p) * 512);       \
     }
 
     f32x16 acc[4][2];
@@ -112,13 +136,15 @@ __global__ void __launch_bounds__(512) gemm_wide_x3_kernel(GwArgs g) {
             }                                                                                                        \
             _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                             \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
-                acc[2 * ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al_[i], bq[SB][j][0], acc[2 * ip + i][j], 0, 0, 0); \
+                acc[2 * ip + i][j] = gw_mfma<X2>(al_[i], bq[SB][j][0], acc[2 * ip + i][j]);                          \
+            if (!X2) {                                                                                               \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
+                    acc[2 * ip + i][j] = gw_mfma<X2>(ah_[i], bq[SB][j][1], acc[2 * ip + i][j]);                      \
+            }                                                                                                        \
             _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                             \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
-                acc[2 * ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_[i], bq[SB][j][1], acc[2 * ip + i][j], 0, 0, 0); \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                             \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
-                acc[2 * ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_[i], bq[SB][j][0], acc[2 * ip + i][j], 0, 0, 0); \
+                acc[2 * ip + i][j] = gw_mfma<X2>(ah_[i], bq[SB][j][0], acc[2 * ip + i][j]);                          \
         }                                                                                                            \
     }
     // one k-tile kt_ (kt_ % 3 == R_): LDS stage kt_ & 1 holds it; register set (R_+1) % 3 holds tile kt_+1 (stored into the other
@@ -203,7 +229,7 @@ __global__ void __launch_bounds__(512) gemm_wide_x3_kernel(GwArgs g) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m >= g.M) continue;
-                float v = acc[i][j][r] + bsv;
+                float v = (X2 ? acc[i][j][r] * out_sc : acc[i][j][r]) + bsv;
                 if (g.act == 1) v = v > 0.f ? v : v * g.slope;
                 const long long off = (long long)m * g.ldc + n;
                 if (R) v += R[off];
@@ -435,8 +461,27 @@ extern "C" int vxb_gemm_wide_bf16x3_f32(const float* A, int64_t lda, const void*
     GwArgs g;
     g.A = A; g.lda = lda; g.Bfrag = (const u16*)Bw_frag; g.C = C; g.ldc = ldc; g.bias = bias; g.residual = residual;
     g.M = M; g.K = K; g.act = act; g.slope = slope; g.accumulate = accumulate;
-    g.geglu = 0; g.F = 0; g.C2 = nullptr; g.H = nullptr;
-    hipLaunchKernelGGL(gemm_wide_x3_kernel, dim3(vxb_cdiv(M, WBM), N / 512), dim3(512), 0, (hipStream_t)stream, g);
+    g.geglu = 0; g.F = 0; g.C2 = nullptr; g.H = nullptr; g.scale = nullptr;
+    hipLaunchKernelGGL(gemm_wide_kernel<0>, dim3(vxb_cdiv(M, WBM), N / 512), dim3(512), 0, (hipStream_t)stream, g);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+// The same GEMM on TWO fp16 products per term ("fp16x2") for the DATA GRADIENTS of the linear layers (dX = dY @ W: A = dY, the weight
+// operand = W^T): A * scale[0] / 16 is carried as an fp16 hi + lo pair, the weights as ONE fp16 value -- Bw_frag16: fragment order of the
+// fp16 matrix [N][K], single plane ([N / 32][K / 16][64][8]; vxb_split_bf16_batch_f32 flag bit 3) -- and the sums are multiplied by
+// 16 scale[1].  scale: device {2^k, 2^-k}, the operand scale of dY (vxb_absmax_scale_f32, or the delayed scale of the weight-gradient
+// launch that read the same dY).  Rounding the weights of a data gradient to 11 bits moves none of the reference's gradient gates
+// (tools/experiments/emu_precision.py --round5); two thirds of the MFMAs of vxb_gemm_wide_bf16x3_f32.
+extern "C" int vxb_gemm_wide_f16x2_f32(const float* A, int64_t lda, const void* Bw_frag16, float* C, int64_t ldc, const float* residual,
+                                       int M, int N, int K, int accumulate, const float* scale, vxb_stream_t stream) {
+    if (!A || !Bw_frag16 || !C || !scale || M < 1 || K < 64) return VXB_EARG;
+    if (N < 512 || (N & 511) || (K & 31) || (lda & 3) || (((uintptr_t)A | (uintptr_t)Bw_frag16) & 15)) return VXB_ESIZE;
+    GwArgs g;
+    g.A = A; g.lda = lda; g.Bfrag = (const u16*)Bw_frag16; g.C = C; g.ldc = ldc; g.bias = nullptr; g.residual = residual;
+    g.M = M; g.K = K; g.act = 0; g.slope = 0.f; g.accumulate = accumulate;
+    g.geglu = 0; g.F = 0; g.C2 = nullptr; g.H = nullptr; g.scale = scale;
+    hipLaunchKernelGGL(gemm_wide_kernel<1>, dim3(vxb_cdiv(M, WBM), N / 512), dim3(512), 0, (hipStream_t)stream, g);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
@@ -451,8 +496,8 @@ extern "C" int vxb_gemm_wide_geglu_fwd_f32(const float* A, int64_t lda, const vo
     GwArgs g;
     g.A = A; g.lda = lda; g.Bfrag = (const u16*)Bw_frag; g.C = h; g.ldc = 2 * (long long)F; g.bias = bias; g.residual = nullptr;
     g.M = M; g.K = K; g.act = 0; g.slope = 0.f; g.accumulate = 0;
-    g.geglu = 1; g.F = F; g.C2 = gg; g.H = nullptr;
-    hipLaunchKernelGGL(gemm_wide_x3_kernel, dim3(vxb_cdiv(M, WBM), 2 * F / 512), dim3(512), 0, (hipStream_t)stream, g);
+    g.geglu = 1; g.F = F; g.C2 = gg; g.H = nullptr; g.scale = nullptr;
+    hipLaunchKernelGGL(gemm_wide_kernel<0>, dim3(vxb_cdiv(M, WBM), 2 * F / 512), dim3(512), 0, (hipStream_t)stream, g);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
@@ -467,8 +512,8 @@ extern "C" int vxb_gemm_wide_geglu_bwd_f32(const float* dY, int64_t lda, const v
     GwArgs g;
     g.A = dY; g.lda = lda; g.Bfrag = (const u16*)Bw_frag; g.C = dh; g.ldc = 2 * (long long)F; g.bias = nullptr; g.residual = nullptr;
     g.M = M; g.K = K; g.act = 0; g.slope = 0.f; g.accumulate = 0;
-    g.geglu = 2; g.F = F; g.C2 = nullptr; g.H = h;
-    hipLaunchKernelGGL(gemm_wide_x3_kernel, dim3(vxb_cdiv(M, WBM), F / 512), dim3(512), 0, (hipStream_t)stream, g);
+    g.geglu = 2; g.F = F; g.C2 = nullptr; g.H = h; g.scale = nullptr;
+    hipLaunchKernelGGL(gemm_wide_kernel<0>, dim3(vxb_cdiv(M, WBM), F / 512), dim3(512), 0, (hipStream_t)stream, g);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }

@@ -35,7 +35,11 @@ _WCACHE = {}
 
 
 _FCACHE = {}
+_F16CACHE = {}       # transposed weight planes (address, shape) -> the same matrix as ONE fp16 plane in fragment order (fp16x2 data gradients)
+_LAST_GRAD_SCALE = [None]     # operand scale (device {2^k, 2^-k}) the last delayed-scaling weight-gradient launch applied to its gradient
 WIDE_GEMM = os.environ.get('VOXACTB_WIDE_GEMM', '1') != '0'     # N = 512 linear layers on the wide kernel (gemm_wide.hip); '0': register-staged 128^2 kernel
+# the data gradients of the big linear layers on two fp16 products (vxb_gemm_wide_f16x2_f32; DGRAD_PRECISION below selects the arithmetic)
+LIN_DGRAD_X2 = os.environ.get('VOXACTB_DGRAD_PRECISION', 'fp16x2') == 'fp16x2' and os.environ.get('VOXACTB_LIN_DGRAD_X2', '1') != '0'
 GEMM_BD = True       # direct-to-LDS GEMMs read their weight fragments straight from global memory (no B tile in LDS)
 
 
@@ -80,17 +84,19 @@ def new_step():
     """weights change every optimizer step: drop the per-step bf16 weight copies."""
     _WCACHE.clear()
     _FCACHE.clear()
+    _F16CACHE.clear()
 
 
 _WPREP = {}
 BATCH_WEIGHT_SPLIT = os.environ.get('VOXACTB_BATCH_WSPLIT', '1') != '0'      # '0': per-weight splits (A/B runs)
 
 
-def prepare_linear_weights(weights, geglu=()):
+def prepare_linear_weights(weights, geglu=(), f16_dgrad=False):
     """bf16 planes of every linear-layer weight of the step, plain AND transposed (the B operands of the forward / data-gradient
     GEMMs), made by ONE launch (vxb_split_bf16_batch_f32) instead of a split + a transposing copy per weight and use; fills the
     cache _bf16_weight() reads.  `weights`: 2-D fp32 tensors (views into the flat parameter arena, so the descriptor table and
-    the output buffer are built once and reused every step)."""
+    the output buffer are built once and reused every step).  f16_dgrad: the backward pass of this step will run the data gradients
+    of the wide linear layers on two fp16 products (fp16x2): also emit every such transposed matrix as one fp16 plane in fragment order."""
     if not (BATCH_WEIGHT_SPLIT and _mm()):
         return
     ws = [w for w in weights if w.dim() == 2 and w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
@@ -99,16 +105,20 @@ def prepare_linear_weights(weights, geglu=()):
         return
     npl = 2 if PRECISION == 'bf16x3' else 1
     glu = set(w.data_ptr() for w in geglu)      # GEGLU up-projections: their forward fragments get the value / gate interleave
-    key = (tuple(w.data_ptr() for w in ws), tuple(tuple(w.shape) for w in ws), npl, tuple(sorted(glu)))
+    f16_dgrad = bool(f16_dgrad and LIN_DGRAD_X2 and DGRAD_PRECISION == 'fp16x2')
+    key = (tuple(w.data_ptr() for w in ws), tuple(tuple(w.shape) for w in ws), npl, tuple(sorted(glu)), f16_dgrad)
     ent = _WPREP.get(key)
     if ent is None:
         if len(_WPREP) > 8:
             _WPREP.clear()
         def wants_frag(n_out, k_in):        # the shapes gemm_bf16w() sends to the wide kernel: also emit the MFMA fragment order
             return WIDE_GEMM and GEMM_BD and npl == 2 and n_out % 512 == 0 and k_in % 32 == 0 and k_in >= 256
-        total = sum(npl * w.numel() * (2 + int(wants_frag(*w.shape)) + int(wants_frag(w.shape[1], w.shape[0]))) for w in ws)
+        def wants_f16(n_out, k_in):         # ... and, for the transposed matrix (the data gradient's weight operand), one fp16 plane
+            return wants_frag(n_out, k_in) and f16_dgrad
+        total = sum(npl * w.numel() * (2 + int(wants_frag(*w.shape)) + int(wants_frag(w.shape[1], w.shape[0])))
+                    + w.numel() * int(wants_f16(w.shape[1], w.shape[0])) for w in ws)
         buf = torch.empty(total, dtype=torch.bfloat16, device=ws[0].device)
-        rows, views, frags, off, tile0 = [], [], [], 0, 0
+        rows, views, frags, f16s, off, tile0 = [], [], [], [], 0, 0
         for w in ws:
             N, K = w.shape
             for tr in (0, 1):
@@ -126,14 +136,22 @@ def prepare_linear_weights(weights, geglu=()):
                     frags.append((v, f, bool(il)))
                     off += npl * N * K
                     tile0 += ((N + 63) // 64) * ((K + 63) // 64)
+                if tr and wants_f16(*shape):
+                    rows.append([w.data_ptr(), buf.data_ptr() + 2 * off, N, K, tr | 2 | 8, tile0])
+                    n_o, k_o = shape
+                    f16s.append((v, buf[off:off + N * K].view(n_o // 32, k_o // 16, 2, 32, 8)))
+                    off += N * K
+                    tile0 += ((N + 63) // 64) * ((K + 63) // 64)
         desc = torch.tensor(rows, dtype=torch.int64).to(ws[0].device)
-        ent = _WPREP[key] = (desc, len(rows), tile0, buf, views, ws, frags)       # (ws keeps the sources alive: keyed by address)
-    desc, n, tiles, buf, views, _, frags = ent
+        ent = _WPREP[key] = (desc, len(rows), tile0, buf, views, ws, frags, f16s)       # (ws keeps the sources alive: keyed by address)
+    desc, n, tiles, buf, views, _, frags, f16s = ent
     call('vxb_split_bf16_batch_f32', desc, n, tiles, npl)
     for (ptr, shape, tr), v in views:
         _WCACHE[(ptr, shape, tr, PRECISION)] = v
     for v, f, il in frags:                  # gemm_wfrag(v) / gemm_wfrag_geglu(v) find the fragment-order copy made by the same launch
         _FCACHE[(v.data_ptr(), tuple(v.shape)) + (('glu',) if il else ())] = (f, v)
+    for v, f in f16s:
+        _F16CACHE[(v.data_ptr(), tuple(v.shape))] = (f, v)
 
 
 def split_bf16(w, x3=None):
@@ -219,6 +237,7 @@ def linear_bwd(x, W, dy, dW, db=None, dx=None, dx_accumulate=False, ws=None):
         # dW = dy^T x reduces over M rows: few output tiles, so split the reduction across workgroups (batch = split)
         tiles = ((N + 127) // 128) * ((K + 127) // 128 if K > 64 else 1)
         ns = 1
+        sc_dy = None                 # the operand scale of dy, when the weight-gradient launch below takes (and reports) one
         if tiles < 512 and dW.is_contiguous():
             cands = [d for d in range(1, 65) if M % d == 0 and (M // d) >= 256]
             ok = [d for d in cands if tiles * d >= 512]
@@ -230,10 +249,12 @@ def linear_bwd(x, W, dy, dW, db=None, dx=None, dx_accumulate=False, ws=None):
             if wt and WGRAD_PRECISION == 'fp16' and GENERIC_WGRAD_F16 and M >= 1024:
                 # the wide kernel's workgroups own 128 x 512 tiles, one per CU: slices so that tiles x slices fills the 256 CUs once
                 nsb = max(1, min(64, int(os.environ.get('VOXACTB_WIDE_WGS', 256)) // wt, M // 1024))
+            _LAST_GRAD_SCALE[0] = None
             res = conv3d_wgrad(dy, x, K, M, 1, 1, 1, 0, ldy=x.stride(0), nsplit=nsb, label='gemm_wgrad %dx%dx%d' % (N, K, M),
                                possum_into=db, grad_key=('lin', W.data_ptr()) if M >= 1024 else None, grad_is_src0=True)
             axpy_(dW, res)
             db = None                    # (the bias gradient came out of the same launch)
+            sc_dy, _LAST_GRAD_SCALE[0] = _LAST_GRAD_SCALE[0], None
         elif ns > 1:
             rc = M // ns
             part = torch.empty((ns, N, K), dtype=torch.float32, device=x.device)
@@ -243,7 +264,15 @@ def linear_bwd(x, W, dy, dW, db=None, dx=None, dx_accumulate=False, ws=None):
         else:
             gemm(dy, x, dW, N, K, M, 1, dy.stride(0), x.stride(0), 1, dW.stride(0), accumulate=True, label='gemm_wgrad %dx%dx%d' % (N, K, M))
         if dx is not None and _mm() and N % 8 == 0 and W.is_contiguous():
-            gemm_bf16w(dy, _bf16_weight(W, True), dx, accumulate=dx_accumulate, label='gemm_dgrad %dx%dx%d' % (M, K, N))
+            Wt = _bf16_weight(W, True)
+            f16 = _F16CACHE.get((Wt.data_ptr(), tuple(Wt.shape))) if (LIN_DGRAD_X2 and DGRAD_PRECISION == 'fp16x2' and sc_dy is not None) else None
+            if (f16 is not None and K % 512 == 0 and N % 32 == 0 and N >= 256 and M >= 1024 and dy.stride(1) == 1 and dy.stride(0) % 4 == 0
+                    and dy.data_ptr() % 16 == 0):
+                # dX = dY @ W on two fp16 products: dY * 2^k as an fp16 hi + lo pair, W as one fp16 value (gemm_wide.hip, X2)
+                _lib.set_meta('gemm_dgrad %dx%dx%d' % (M, K, N), 2.0 * M * N * K)
+                call('vxb_gemm_wide_f16x2_f32', dy, dy.stride(0), f16[0], dx, dx.stride(0), None, M, K, N, int(dx_accumulate), sc_dy)
+            else:
+                gemm_bf16w(dy, Wt, dx, accumulate=dx_accumulate, label='gemm_dgrad %dx%dx%d' % (M, K, N))
         elif dx is not None:
             gemm(dy, W, dx, M, K, N, dy.stride(0), 1, W.stride(0), 1, dx.stride(0), accumulate=dx_accumulate,
                  label='gemm_dgrad %dx%dx%d' % (M, K, N))
@@ -509,6 +538,7 @@ def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
         call('vxb_conv3d_wgrad_f16_f32', src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, int(replicate), dy, N,
              ldy if ldy is not None else N, d2s[0], d2s[1], part, nsplit, psum, cur, int(grad_is_src0), nxt, aws)
         st[0], st[1] = nxt, cur                       # the next call at this site uses the maximum this launch saw
+        _LAST_GRAD_SCALE[0] = cur if grad_is_src0 else None
         if psum is not None:
             sum_splits(psum, nsplit, K, possum_into, accumulate=True)
         out = torch.empty((K, N), dtype=torch.float32, device=src0.device)
