@@ -141,7 +141,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     constexpr int HL = X3 || X2;                    // a chunk is 16 channels as hi | lo halves
     constexpr int NF = X2 ? 1 : 2;                  // weight fragments per (tap, column tile): k halves (PM 0, 2) / planes (1) / one (3)
     constexpr int ST = HALF == 1 ? 2 : 1;           // M-tile stride of the tap loops
-    constexpr int MLIM = HALF == 2 ? 3 : 8 / (NW / WN);     // ... and their end: HALF = 2 runs three of a wave's four M tiles
+    constexpr int MLIM = HALF == 2 ? 3 : (HALF == 3 ? 2 : 8 / (NW / WN));     // ... and their end: HALF = 2 runs three of a wave's four M tiles, 3 two
     constexpr int NTH = NW * 64, MTW = 8 / (NW / WN), NT = NTG / WN;
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* halo = smem;                               // [HALO_SLOTS][SP]
@@ -184,7 +184,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     // do not exist) has nothing to compute: in the WD kernels (no barrier inside the tap loop) it only helps staging the halo.
     // 1/6 of the workgroups of the up-conv data gradient (22^3 grid in 24^3 of tiles) and 1/26 of the final conv's run at half
     // their matrix work this way.
-    const bool wave_on = __builtin_amdgcn_readfirstlane((int)(!WD || g_dbg_all_waves(g) || d0 + (((wid / WN) * (8 / (NW / WN))) >> 1) < g.S_out)) != 0;
+    const bool wave_on = HALF == 3 || __builtin_amdgcn_readfirstlane((int)(!WD || g_dbg_all_waves(g) || d0 + (((wid / WN) * (8 / (NW / WN))) >> 1) < g.S_out)) != 0;
 
     // HALF: edge tiles whose last rows / columns lie beyond the output grid run a part of their matrix work, with the same products
     // in the same order for every output voxel (bit-identical results).
@@ -197,7 +197,9 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     // 20-27} / {4-11, 16-19, 28-31} take the rows {0, 2} / {1, 3} of the patch (h = 4 / h = 5 of the strip), whose 16 voxels fall on
     // 16 different 16-byte slots with 80-byte voxels and 12-voxel rows; the w strip (8 distinct slots for 32 voxels) is read with
     // 2-way conflicts (tools/experiments/halo_rowmap_check.py).
-    const bool edge_h = HALF && __builtin_amdgcn_readfirstlane((int)(w0 + (HALF == 1 ? 4 : 6) < g.S_out)) != 0;     // (else: the w edge)
+    //   HALF = 3 (the last depth tile holds two depths: S_out = 22, 102): instead of two waves doing both depths and two idling (the
+    //     wave_on rule of the other modes), every wave row takes ONE depth, its two M tiles -- the workgroup is done in half the time.
+    const bool edge_h = HALF && HALF != 3 && __builtin_amdgcn_readfirstlane((int)(w0 + (HALF == 1 ? 4 : 6) < g.S_out)) != 0;     // (else: the w edge)
     // tile-local voxel (dd, hh, ww) of row l (0..31) of this wave's i-th M tile
     auto rowmap = [&](int i, int l, int& dd, int& hh, int& ww) {
         const int mt = wm * MTW + i;
@@ -205,6 +207,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
         const int aw = ((l >> 3) & 1) * 4 + (l & 3), k = (l >> 3) * 4 + (l & 3);
         dd = mt >> 1; hh = l >> 2; ww = (mt & 1) * 4 + (l & 3);
         if (HALF == 1 && edge_h) { hh = (mt & 1) * 4 + par + 2 * (l >> 4); ww = aw; }
+        if (HALF == 3) { dd = wm; ww = (i & 1) * 4 + (l & 3); }
         if (HALF == 2) {
             dd = 2 * wm + i; ww = l & 3;
             if (edge_h) { hh = par + 2 * (l >> 4); ww = aw; }
@@ -262,7 +265,8 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
             st_soff[i] = ((pd * HHp + ph) * HWp + pw) * SP + c4;
             if (ok) st_goff[i] = ((id * sm) * Vin + ih * sm) * Vin + iw * sm;
             else st_goff[i] = -2;                   // staged as zeros
-            if (HALF && (edge_h ? ph : pw) >= (HALF == 1 ? 6 : 8)) st_goff[i] = -1;      // a part tile reads 6 / 8 of the 10 rows or columns
+            if (HALF && HALF != 3 && (edge_h ? ph : pw) >= (HALF == 1 ? 6 : 8)) st_goff[i] = -1;      // a part tile reads 6 / 8 of the 10 rows or columns
+            if (HALF == 3 && pd >= 4) st_goff[i] = -1;                                           // ... two depths: 4 of the 6 halo slices
         }
     }
     const long long bvox = (long long)b * Vin * Vin * Vin;
@@ -816,6 +820,11 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
         t /= g.N / (NTG * 32);
         if (TL) t %= g.B * g.ntd * g.nth * g.ntw;
         const int tw = t % g.ntw, th = (t / g.ntw) % g.nth;
+        const int td = (t / (g.ntw * g.nth)) % g.ntd;
+        if (g.S_out - td * TD <= 2 && !g_dbg_all_waves(g)) {
+            conv3_halo_body<NTG, PM, NW, WD, TL, WN, 3>(g);
+            return;
+        }
         const int rem = min(g.S_out - tw * TW, g.S_out - th * TH);
         if (rem <= 6 && !g_dbg_all_waves(g)) {
             if (rem <= 4) conv3_halo_body<NTG, PM, NW, WD, TL, WN, 1>(g);
