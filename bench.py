@@ -365,11 +365,11 @@ PMC_TRAFFIC_C2 = {
         'conv3_halo_kernel<2,1,4,1,0,2> (final conv forward; since the two-product data gradients the only launch of this kernel per step): '
         'FETCH_SIZE 9.94 GB raw (x2 = 19.9 GB) + WRITE_SIZE 4.32 GB (output 4.1 GB + the statistics partials) per launch = 24.2 GB for 12.3 GB '
         'compulsory (2 x 4.1 GB read, 4.1 GB written; 2.3x on the reads: the 6x10x10 halo of a 4x8x8 tile); 24.2 GB / 19.0 ms = 1.3 TB/s: '
-        'matrix-core / LDS-bound, not HBM-bound; profiles/r03_v9_pmc_*'),
+        'matrix-core / LDS-bound, not HBM-bound; profiles/r03_v10_pmc_*'),
     'conv3d_bf16[k3 s1 64->128 S102': (
         (2 * 5344162.6 + 4000000.0) * 1024.0 + (2 * 3131520.0 + 4000000.0) * 1024.0,
         'the two launches of the data gradient + padding adjoint: conv3_halo_kernel<2,3,4,1,0,2> (d(u0), fp16x2: 10.9 GB fetched + 4.1 GB '
-        'written) + conv3_halo_kernel<2,2,4,1,0,1> (d(d0), fp16: 6.4 GB + 4.1 GB); profiles/r03_v9_pmc_*'),
+        'written) + conv3_halo_kernel<2,2,4,1,0,1> (d(d0), fp16: 6.4 GB + 4.1 GB); profiles/r03_v10_pmc_*'),
 }
 
 # HBM bytes the voxelizer chain really moves per call at configs[1] (B=16, V=100, 4 x 128 x 128 points), from separate
