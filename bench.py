@@ -439,7 +439,9 @@ def voxel_stateless(agent, batch, cfg, V, B):
 MODE_DTYPE = {
     'fp32': 'f32 (v_mfma_f32_32x32x2_f32 everywhere)',
     'bf16x3': 'f32 storage / accumulate; matrix products as bf16x3 split (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16); the weight '
-              'gradients of the two 3x3x3 grid convs as single fp16 products with a device-side power-of-two operand scale',
+              'gradients (convs, big linear layers) and the d(d0) data gradient -- leaves of the backward pass -- as single fp16 products, the conv and '
+              'wide-linear data gradients that propagate as two fp16 products (gradient hi + lo, weight in 11 bits), all with device-side '
+              'power-of-two operand scales',
     'bf16': 'bf16 matrix cores (fp32 accumulate) for convs, large linears and fused attention; everything else f32',
     'bf16x3/bf16': 'forward as bf16x3 (Q-values inside 1e-4 of the reference), matrix products of the BACKWARD pass on plain bf16',
 }
