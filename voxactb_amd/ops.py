@@ -251,8 +251,10 @@ def linear_bwd(x, W, dy, dW, db=None, dx=None, dx_accumulate=False, ws=None):
                 nsb = max(1, min(64, int(os.environ.get('VOXACTB_WIDE_WGS', 256)) // wt, M // 1024))
             _LAST_GRAD_SCALE[0] = None
             res = conv3d_wgrad(dy, x, K, M, 1, 1, 1, 0, ldy=x.stride(0), nsplit=nsb, label='gemm_wgrad %dx%dx%d' % (N, K, M),
-                               possum_into=db, grad_key=('lin', W.data_ptr()) if M >= 1024 else None, grad_is_src0=True)
-            axpy_(dW, res)
+                               possum_into=db, grad_key=('lin', W.data_ptr()) if M >= 1024 else None, grad_is_src0=True,
+                               add_into=dW)
+            if res is not None:
+                axpy_(dW, res)
             db = None                    # (the bias gradient came out of the same launch)
             sc_dy, _LAST_GRAD_SCALE[0] = _LAST_GRAD_SCALE[0], None
         elif ns > 1:
@@ -454,7 +456,7 @@ def conv3d(src0, wt, N, B, S_in, S_out, kext, off, stride=1, replicate=True, bia
 
 def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=True, src1=None, ldy=None, d2s=(0, 0),
                  nsplit=None, label=None, force_bf16=False, phase_mask=None, flops_frac=1.0, dy_scale=None, possum_into=None,
-                 grad_key=None, grad_is_src0=False):
+                 grad_key=None, grad_is_src0=False, add_into=None):
     """returns dWt [(tap, ci)][N] (fp32, deterministic split reduction).  phase_mask (LDS-halo kernel, d2s only): int32
     [N / 64] tap masks of the polyphase structure -- the structurally zero (tap, phase) blocks come back as zeros."""
     C0 = src0.shape[-1]
@@ -541,6 +543,9 @@ def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
         _LAST_GRAD_SCALE[0] = cur if grad_is_src0 else None
         if psum is not None:
             sum_splits(psum, nsplit, K, possum_into, accumulate=True)
+        if add_into is not None:                      # [K][N] contiguous: the partial sums are added straight into it (no temporary, no axpy)
+            sum_splits(part, nsplit, K * N, add_into, accumulate=True, alpha=cur[1:])
+            return None
         out = torch.empty((K, N), dtype=torch.float32, device=src0.device)
         sum_splits(part, nsplit, K * N, out, alpha=cur[1:])
         return out
