@@ -736,7 +736,7 @@ class PerceiverEngine:
             # data gradient and the adjoint of the replicate padding in one kernel: the first 64 columns go (add) into dd0,
             # the other 64 become d(pre-activation of up0's last conv) through u0's LeakyReLU'
             # d(d0) feeds nothing but the weight gradient of the 1x1x1 input conv (the voxel grid is a detached input, agent :100):
-            # a leaf -- its column block may run on single fp16 products; d(u0) propagates through the decoder and stays bf16x3
+            # a leaf -- its column block may run on single fp16 products; d(u0) propagates through the decoder: two fp16 products (dY hi + lo, ops.DGRAD_PRECISION)
             up2b = 'up0.conv_up.%d.conv3d.bias' % (2 if s > 1 else 1)
             sc_du0 = ops.conv3_dgrad_fold(du, ops.conv_weight_dgrad(Wf), B, V, 2 * C, [(dd0, not fuse_ss0, None), (du0, False, u0)],
                                           dy_scale=sc_du, leaf_blocks=(0,), scale_blocks=(1,), colsum_into={1: self.g(up2b)},
