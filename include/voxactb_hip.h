@@ -165,7 +165,8 @@ int vxb_conv3d_wgrad_bf16x3_f32(const float* src0, const float* src1, int C0, in
 int vxb_conv3d_wgrad_f16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                              int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
                              int d2s_s, int d2s_C, float* part, int nsplit, float* possum, const float* scale,
-                             int grad_is_src0, float* next_scale, float* amax_ws, vxb_stream_t stream);
+                             int grad_is_src0, float* next_scale, float* amax_ws, float* sum_dst, int sum_accumulate,
+                             vxb_stream_t stream);
 size_t vxb_conv3d_wgrad_f16_amax_words(int C0, int C1, int kext, int N, int nsplit, int grad_is_src0);
 void vxb_debug_set_wgrad_bm256(int on);       /* experiment knob: 256-row tiles of the fp16 weight-gradient kernel (measured slower: default off) */
 void vxb_debug_set_wgrad_lin(int mode);       /* A/B switch of the linear layers' fp16 weight gradients: 2 (default) wide kernel where one operand has 512 channels, 1 pipelined 128x128 kernel only, 0 generic kernel */

@@ -26,6 +26,9 @@ int vxb_c1_dgrad4_ss_launch(const float* dq, const float* w, const float* u, flo
                             const float* g_max, float* dbias, float* part_ws, unsigned* part_amax, hipStream_t st);
 // scale[0] = 2^k mapping the largest of n per-block |x| maxima (magnitude bits) into [2^14, 2^15), scale[1] = 1 / scale[0] (nn_ops.hip)
 int vxb_absmax_finish_launch(const unsigned* part, int n, float* scale, hipStream_t st, int headroom_bits = 0);
+// ... fused with the split-sum of the same launch's partial results: dst (+)= alpha[0] * sum_s part[s][0..n) (nn_ops.hip)
+int vxb_wgrad_finish_launch(const float* part, int nsplit, long long n, float* dst, int accumulate, const float* alpha,
+                            const unsigned* amax, int nb, float* scale, int headroom_bits, hipStream_t st);
 // out[64] += column sums of part[nrows][64] in a fixed order; part must have room for 64 more rows behind the nrows (c1_conv.hip)
 // dW [64][10] += scale[1] * sum_n part[n][c][0..9], db [64] += scale[1] * sum_n part[n][c][10] (part: n x [64][11]); patch_wgrad.hip
 constexpr int VXB_WGIN_FINISH_ROWS = 512;

@@ -727,6 +727,50 @@ extern "C" int vxb_sum_splits_dev_f32(const float* part, int nsplit, int64_t n, 
     return VXB_OK;
 }
 
+// dst (+)= alpha[0] * sum_s part[s] (blocks 0 .. gridDim.x - 2) AND the next operand scale from the launch's per-workgroup maxima (the
+// last block): the two finishing launches of a delayed-scaling fp16 weight gradient in one
+__global__ void __launch_bounds__(256) wgrad_finish_kernel(const float* __restrict__ part, int nsplit, long long n, float* __restrict__ dst,
+                                                           int accumulate, const float* __restrict__ alpha_p,
+                                                           const unsigned* __restrict__ amax, int nb, float* __restrict__ scale, int headroom) {
+    if (blockIdx.x == gridDim.x - 1) {
+        __shared__ unsigned red[4];
+        unsigned m = 0;
+        for (int i = threadIdx.x; i < nb; i += 256) m = max(m, amax[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = max(max(red[0], red[1]), max(red[2], red[3]));
+            int k = 0;
+            if (m != 0 && m < 0x7f800000u) {
+                const int e = (int)(m >> 23) - 127;
+                k = min(max(14 - headroom - e, -100), 100);
+            }
+            scale[0] = __uint_as_float((unsigned)(k + 127) << 23);
+            scale[1] = __uint_as_float((unsigned)(127 - k) << 23);
+        }
+        return;
+    }
+    const float alpha = *alpha_p;
+    const long long nblk = gridDim.x - 1;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += nblk * 256) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += part[(long long)k * n + i];
+        s *= alpha;
+        if (accumulate) dst[i] += s; else dst[i] = s;
+    }
+}
+
+int vxb_wgrad_finish_launch(const float* part, int nsplit, long long n, float* dst, int accumulate, const float* alpha,
+                            const unsigned* amax, int nb, float* scale, int headroom_bits, hipStream_t st) {
+    if (!part || !dst || !alpha || !amax || !scale || nsplit < 1 || n < 1 || nb < 1) return VXB_EARG;
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(grid_for(n) + 1), dim3(256), 0, st, part, nsplit, n, dst, accumulate, alpha, amax, nb, scale,
+                       headroom_bits);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
 int vxb_absmax_finish_launch(const unsigned* part, int n, float* scale, hipStream_t st, int headroom_bits) {
     if (!part || !scale || n < 1) return VXB_EARG;
     hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, st, part, n, scale, headroom_bits);

@@ -756,7 +756,8 @@ static int g_wg_lin = 2;          // plain-GEMM form of the fp16 products: 2 = w
 static int wgrad_bf16_impl(int x3, const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                           int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
                           int d2s_s, int d2s_C, float* part, int nsplit, float* possum, vxb_stream_t stream,
-                          const float* scale = nullptr, int grad_is_src0 = 0, float* next_scale = nullptr, float* amax_ws = nullptr) {
+                          const float* scale = nullptr, int grad_is_src0 = 0, float* next_scale = nullptr, float* amax_ws = nullptr,
+                          float* sum_dst = nullptr, int sum_accumulate = 0) {
     if (!src0 || !dy || !part || B < 1 || S_in < 1 || S_out < 1 || kext < 1 || stride < 1 || N < 1 || nsplit < 1) return VXB_EARG;
     if (possum && !(S_in == 1 && S_out == 1 && kext == 1 && off == 0 && C1 == 0 && d2s_s <= 0)) return VXB_EARG;     // plain GEMM form only
     if ((C0 & 3) || (C1 & 3) || C0 < 4 || (C1 > 0 && !src1) || (N & 3)) return VXB_ESIZE;
@@ -794,6 +795,9 @@ static int wgrad_bf16_impl(int x3, const float* src0, const float* src1, int C0,
             const int tiles_i = w.Ru / 128;
             hipLaunchKernelGGL(wgrad_wide_f16_kernel, dim3(tiles_i, nsplit), dim3(512), lds, st, w);
             VXB_CHECK_LAUNCH();
+            if (g.amax_part && sum_dst)
+                return vxb_wgrad_finish_launch(part, nsplit, K * N, sum_dst, sum_accumulate, scale + 1, g.amax_part,
+                                               (w.grad_is_u ? tiles_i : 1) * nsplit, next_scale, 5, st);
             if (g.amax_part) return vxb_absmax_finish_launch(g.amax_part, (w.grad_is_u ? tiles_i : 1) * nsplit, next_scale, st, 5);
             return VXB_OK;
         }
@@ -821,6 +825,8 @@ static int wgrad_bf16_impl(int x3, const float* src0, const float* src1, int C0,
     VXB_CHECK_LAUNCH();
     // five bits of headroom: the scale is used by the NEXT step's launch, whose gradient may be up to 32x larger before anything
     // saturates (half still keeps 11 bits down to 2^-19 of the maximum: nothing is lost at the small end)
+    if (g.amax_part && sum_dst)
+        return vxb_wgrad_finish_launch(part, nsplit, K * N, sum_dst, sum_accumulate, scale + 1, g.amax_part, nblk * nsplit, next_scale, 5, st);
     if (g.amax_part) return vxb_absmax_finish_launch(g.amax_part, nblk * nsplit, next_scale, st, 5);
     return VXB_OK;
 }
@@ -844,10 +850,13 @@ extern "C" void vxb_debug_set_wgrad_lin(int mode) { g_wg_lin = mode < 0 ? 0 : (m
 extern "C" int vxb_conv3d_wgrad_f16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                                         int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
                                         int d2s_s, int d2s_C, float* part, int nsplit, float* possum, const float* scale,
-                                        int grad_is_src0, float* next_scale, float* amax_ws, vxb_stream_t stream) {
-    if (!scale) return VXB_EARG;
+                                        int grad_is_src0, float* next_scale, float* amax_ws, float* sum_dst, int sum_accumulate,
+                                        vxb_stream_t stream) {
+    // sum_dst (optional, with next_scale): [(tap, ci)][N] (+)= scale[1] * the sum of the nsplit partial results, from the same
+    // finishing launch that computes next_scale -- the caller then skips vxb_sum_splits_dev_f32
+    if (!scale || (sum_dst && !(next_scale && amax_ws))) return VXB_EARG;
     return wgrad_bf16_impl(2, src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, replicate, dy, N, ldy, d2s_s, d2s_C, part,
-                           nsplit, possum, stream, scale, grad_is_src0, next_scale, amax_ws);
+                           nsplit, possum, stream, scale, grad_is_src0, next_scale, amax_ws, sum_dst, sum_accumulate);
 }
 
 // Same contract as vxb_conv3d_wgrad_f32 (include/voxactb_hip.h); operands are rounded to bf16 while staged, fp32 accumulate.

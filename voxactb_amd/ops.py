@@ -537,18 +537,15 @@ def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
                           dtype=torch.float32, device=grad.device)
         psum = torch.empty((nsplit, K), dtype=torch.float32, device=src0.device) if possum_into is not None else None
         _lib.set_meta(label or 'conv3d_wgrad[k%d s%d %d->%d S%d]' % (kext, stride, C0 + C1, N, S_out), 2.0 * P * N * K)
+        # the partial sums are folded (times 1 / scale) by the same finishing launch that turns this launch's maxima into the next scale
+        out = add_into if add_into is not None else torch.empty((K, N), dtype=torch.float32, device=src0.device)
         call('vxb_conv3d_wgrad_f16_f32', src0, src1, C0, C1, B, S_in, S_out, stride, kext, off, int(replicate), dy, N,
-             ldy if ldy is not None else N, d2s[0], d2s[1], part, nsplit, psum, cur, int(grad_is_src0), nxt, aws)
+             ldy if ldy is not None else N, d2s[0], d2s[1], part, nsplit, psum, cur, int(grad_is_src0), nxt, aws, out, int(add_into is not None))
         st[0], st[1] = nxt, cur                       # the next call at this site uses the maximum this launch saw
         _LAST_GRAD_SCALE[0] = cur if grad_is_src0 else None
         if psum is not None:
             sum_splits(psum, nsplit, K, possum_into, accumulate=True)
-        if add_into is not None:                      # [K][N] contiguous: the partial sums are added straight into it (no temporary, no axpy)
-            sum_splits(part, nsplit, K * N, add_into, accumulate=True, alpha=cur[1:])
-            return None
-        out = torch.empty((K, N), dtype=torch.float32, device=src0.device)
-        sum_splits(part, nsplit, K * N, out, alpha=cur[1:])
-        return out
+        return None if add_into is not None else out
     if entry != 'vxb_conv3d_wgrad_f32':
         # possum_into [C0] (plain GEMM form: the weight gradient of a linear layer, src0 = its dY): += the sums of src0 over the
         # positions, i.e. the bias gradient, from this launch (no second pass over dY)
