@@ -161,7 +161,9 @@ int vxb_conv3d_wgrad_bf16x3_f32(const float* src0, const float* src1, int C0, in
 /* ... with ONE fp16 product per term: the gradient operand (src0 when grad_is_src0 != 0: the plain-GEMM form of a linear layer's
  * weight gradient, src0 = its dY; else dy) times scale[0] (device, power of two) before the conversion to half, `part` = scale[0] * dW,
  * the other operand saturating at +-65504.  next_scale (optional, [2]; amax_ws of vxb_conv3d_wgrad_f16_amax_words words): the scale
- * vxb_absmax_scale_f32 would give for the gradient operand this launch read -- for the next step (delayed scaling). */
+ * vxb_absmax_scale_f32 would give for the gradient operand this launch read -- for the next step (delayed scaling).  sum_dst (optional,
+ * with next_scale): [(tap, ci)][N] = (sum_accumulate ? sum_dst : 0) + scale[1] * the sum of the nsplit partial results, written by the
+ * same finishing launch that computes next_scale (the caller then skips vxb_sum_splits_dev_f32). */
 int vxb_conv3d_wgrad_f16_f32(const float* src0, const float* src1, int C0, int C1, int B, int S_in, int S_out,
                              int stride, int kext, int off, int replicate, const float* dy, int N, int64_t ldy,
                              int d2s_s, int d2s_C, float* part, int nsplit, float* possum, const float* scale,
