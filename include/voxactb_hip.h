@@ -447,6 +447,18 @@ int vxb_flash_attn_bwd_bf16x3(const float* q, const float* kv, const float* o, c
                               float* dq, float* dkv, float* dsum_ws, int B, int H, int Nq, int Nk, int head_dim,
                               float scale, float dropout_p, uint32_t seed, vxb_stream_t stream);
 
+/* fp16 twin of vxb_split_bf16_f32: plane 0 = RNE(x) saturated at +-65504, plane 1 (nplanes = 2) = RNE(x - plane 0). */
+int vxb_split_f16_f32(const float* src, int64_t ld, int64_t rows, int cols, void* dst_planes, int nplanes, vxb_stream_t stream);
+
+/* Attention.forward (perceiver_lang_io.py:107-132: sim = q k^T * scale, softmax, dropout, attn v), pipelined structure of round 4
+ * (csrc/flash2_fwd.hip): per wave the scores of tile j+1, the exponentials of tile j and the P V product of tile j-1 are independent
+ * instruction streams of one region; the row offset is subtracted inside the matrix product (no per-tile maximum / rescale).
+ * mode 0: kv_planes = one bf16 plane [B*Nk][2*H*64] ('bf16'); 1: one fp16 plane ('f16'); one MFMA per product.
+ * waves = 4 or 8 per workgroup, 0 = by grid size.
+ * Outputs and dropout mask as vxb_flash_attn_fwd_dl (o [B,Nq,H*64], lse [B*H,Nq], natural log). */
+int vxb_flash2_attn_fwd(const float* q, const void* kv_planes, int mode, float* o, float* lse, int B, int H, int Nq, int Nk,
+                        int head_dim, float scale, float dropout_p, uint32_t seed, int waves, vxb_stream_t stream);
+
 /* Forward with k | v as bf16 planes [nplanes][B*Nk][2*H*64] (vxb_split_bf16_f32 of the to_kv output): K/V tiles go
  * global -> LDS directly (double-buffered, one barrier per 64-key tile).  Same outputs / dropout mask as the entries above. */
 int vxb_flash_attn_fwd_dl(const float* q, const void* kv_planes, int nplanes, float* o, float* lse, int B, int H, int Nq,

@@ -18,4 +18,4 @@ The generator itself lives with the other synthetic-data code in `voxactb_amd/sy
 check needs it too and must not import `oracle/`); this module re-exports it under the names the tests use.
 """
 from voxactb_amd.synthetic import (LRELU_SLOPE, hashed_int, hashed_normal, hashed_state_dict, hashed_tensor,  # noqa: F401
-                                   hashed_uniform)
+                                   hashed_uniform, project, projection_error, projection_signs)

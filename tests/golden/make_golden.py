@@ -235,6 +235,71 @@ def encoder_fixture(name, cfg, arm=False, with_grads=True, digest=False, crop=Fa
 
 
 
+# ----------------------------------------------------------------------------- F5n: the reference's own fp32-vs-fp64 noise floor
+def grad_noise_fixture(name, cfg, seed, arm=False, crop=False, nproj=16):
+    """The reference encoder run TWICE on one batch: in fp32 (what F5g / F5c3 hold) and in float64 (the truth both the reference's fp32
+    arithmetic and the product approximate).  Stored per parameter tensor: ||g64||, ||g32 - g64|| (the reference's own rounding noise,
+    exact), `nproj` random +-1 projections of g64 (oracle/weights.py: projection_signs -- the GPU test estimates ||g - g64|| of ITS
+    gradient from the same projections without the 133 MB tensor) and, for small tensors, g64 in full; the Q-value digest of the fp64
+    forward with |q32 - q64|.  A gradient gate of "k x the reference's own spread" replaces per-fixture hand-set tolerances where the
+    reference itself is ill-conditioned (a global max-pool tie hands a whole gradient to another voxel under a 1e-6 perturbation)."""
+    enc, sd = make_ref_encoder(cfg, arm)
+    rs = batch_for(cfg, seed=seed, arm=arm, crop=crop)
+    pcd = [rs['%s_point_cloud' % c] for c in cfg['cams']]
+    rgb = [rs['%s_rgb' % c] for c in cfg['cams']]
+    bounds = rs['target_object_scene_bounds'] if crop else torch.tensor([synthetic.SCENE_BOUNDS])
+    coords, feats = ovox.flatten_cameras(pcd, rgb)
+    grid = ref_voxelize(coords, feats, bounds, cfg['V'], cfg['B'])
+    ins = grid.permute(0, 4, 1, 2, 3).detach()
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        t0 = time.time()
+        enc = enc.to(dt)
+        for p in enc.parameters():
+            p.requires_grad_(True)
+            p.grad = None
+        outs = enc(ins.to(dt), rs['low_dim_state'].to(dt), rs['lang_goal_emb'].to(dt), rs['lang_token_embs'].to(dt), None, bounds, None)
+        total, _ = oagent.losses(outs[0], outs[1], outs[2], rs['trans_action_indicies'], rs['rot_grip_action_indicies'],
+                                 rs['ignore_collisions'], outs[3] if arm else None, rs.get('label'))
+        total.backward()
+        res[dt] = dict(outs=[o.detach().double() for o in outs[:4 if arm else 3]], loss=total.detach().double(),
+                       grads={n: p.grad.detach().double().clone() for n, p in enc.named_parameters()})
+        print('%s: reference %s forward + backward %.0fs' % (name, dt, time.time() - t0))
+        del outs, total
+    r32, r64 = res[torch.float32], res[torch.float64]
+    arrs = dict(cfg_V=cfg['V'], cfg_k=cfg['k'], cfg_s=cfg['s'], cfg_depth=cfg['depth'], cfg_latents=cfg['latents'],
+                cfg_low_dim=cfg['low_dim'], cfg_B=cfg['B'], cfg_H=cfg['H'], cfg_W=cfg['W'], cfg_ncam=len(cfg['cams']),
+                cfg_arm=int(arm), cfg_crop=int(crop), cfg_seed=seed, nproj=nproj)
+    flat64, flat32 = r64['outs'][0].reshape(cfg['B'], -1), r32['outs'][0].reshape(cfg['B'], -1)
+    sidx = ow.hashed_int('digest', (4096,), 0, flat64.shape[1])
+    top = flat64.topk(16, dim=1)
+    arrs.update(q_trans_argmax=flat64.argmax(1), q_trans_top_vals=top.values, q_trans_top_idx=top.indices, q_trans_sample_idx=sidx,
+                q_trans_sample=flat64[:, sidx], q_trans_lse=torch.logsumexp(flat64, 1), rot_grip=r64['outs'][1], collision=r64['outs'][2],
+                q_spread32=torch.stack([(a - b).abs().max() for a, b in zip(r32['outs'], r64['outs'])]),
+                loss=r64['loss'], loss32=r32['loss'])
+    if arm:
+        arrs['arm_out'] = r64['outs'][3]
+    names = list(r64['grads'])
+    arrs['grad_names'] = np.array(names)
+    arrs['grad_norm64'] = torch.stack([r64['grads'][n].norm() for n in names])
+    arrs['grad_err32'] = torch.stack([(r32['grads'][n] - r64['grads'][n]).norm() for n in names])
+    arrs['grad_max64'] = torch.stack([r64['grads'][n].abs().max() for n in names])
+    arrs['grad_proj64'] = torch.stack([ow.project(r64['grads'][n], n, nproj) for n in names])
+    # self-check of the estimator on the reference's own fp32 gradient: estimated vs exact ||g32 - g64||
+    est = torch.stack([ow.projection_error(ow.project(r32['grads'][n], n, nproj), arrs['grad_proj64'][i])
+                       for i, n in enumerate(names)])
+    rel = (est / (arrs['grad_err32'] + 1e-300))
+    print('%s: projection estimate / exact ||g32 - g64||: median %.2f, range %.2f .. %.2f' % (name, float(rel.median()), float(rel.min()), float(rel.max())))
+    worst = sorted(((float(arrs['grad_err32'][i] / (arrs['grad_norm64'][i] + 1e-300)), n) for i, n in enumerate(names)), reverse=True)[:8]
+    print('%s: largest reference fp32 noise ||g32 - g64|| / ||g64||: %s' % (name, ', '.join('%s %.1e' % (n, e) for e, n in worst)))
+    print('%s: |q32 - q64| per output %s, loss32 - loss64 %.2e' % (name, [float(x) for x in arrs['q_spread32']], float(r32['loss'] - r64['loss'])))
+    for n in names:
+        if r64['grads'][n].numel() <= 20000 and not n.startswith(('pos_encoding', 'latents')):
+            arrs['grad64__' + n] = r64['grads'][n]
+            arrs['grad32__' + n] = r32['grads'][n].float()
+    save(name, **arrs)
+
+
 # ----------------------------------------------------------------------------- F11: the 2Robots (one_policy_more_heads) encoder
 def encoder2_fixture(name, cfg, digest=False):
     """reference PerceiverVoxelLang2RobotsEncoder (perceiver_lang_io.py:488-860) forward + backward of the summed two-arm loss
@@ -967,6 +1032,10 @@ SECTIONS = {
     # reference's CPU backward at 200^3 did not finish in 75 minutes (33 GB resident, all cores busy inside one ATen op), so the
     # configs[4] backward is covered by tests/test_fullsize_gpu.py::test_v200_* (two kernel families against each other) instead
     'f5v200g': lambda: encoder_fixture('f5v200g_encoder_c5_grads', CFG_C5, with_grads=True, digest=True, check_oracle=False, f64_grads=True),
+    # the reference in fp32 AND float64 on three batches per headline shape (the fp32-vs-fp64 spread is the yardstick of the gradient gates)
+    **{'f5n_c2_s%d' % sd: (lambda sd=sd: grad_noise_fixture('f5n_noise_c2_s%d' % sd, CFG_C2, sd)) for sd in (1, 2, 3)},
+    **{'f5n_c3_s%d' % sd: (lambda sd=sd: grad_noise_fixture('f5n_noise_c3_s%d' % sd, CFG_C3, sd, arm=True, crop=True)) for sd in (1, 2, 3)},
+    'f5n_tiny': lambda: grad_noise_fixture('f5n_noise_tiny_s1', CFG_TINY, 1, arm=True),
     'f11tiny': lambda: encoder2_fixture('f11_encoder_2robots_tiny', CFG_TINY),
     'f11c1': lambda: encoder2_fixture('f11_encoder_2robots_c1', CFG_C1),
     'f11c2': lambda: encoder2_fixture('f11c2_encoder_2robots_c2_digest', CFG_C2, digest=True),
@@ -992,7 +1061,7 @@ if __name__ == '__main__':
     todo = [s for s in a.only.split(',') if s] or list(SECTIONS)
     torch.manual_seed(0)
     for s in todo:
-        if s in ('f5', 'f5g', 'f5c3', 'f5v200', 'f5v200g') and a.skip_c2:
+        if (s in ('f5', 'f5g', 'f5c3', 'f5v200', 'f5v200g') or s.startswith('f5n_c')) and a.skip_c2:
             continue
         print('==', s)
         SECTIONS[s]()

@@ -1,0 +1,509 @@
+// Fused attention forward, second structure (round 4): every wave runs a three-stage software pipeline over the key tiles,
+//
+//      region j:   S'(j+1) = K(j+1) Q^T - m      (matrix cores)
+//                  P(j)    = exp2(S'(j))          (vector ALU: exp2, dropout, pack -- nothing else)
+//                  O      += V(j-1)^T P(j-1)      (matrix cores)
+//
+// so the matrix-core stream and the vector stream of ONE wave are independent inside a region and the compiler interleaves
+// them (round 3's kernel ran S-MFMAs -> softmax -> PV-MFMAs serially per tile and relied on the second wave of the SIMD to
+// fill the gaps: 42 % matrix-pipe duty).  What makes the vector stream short enough:
+//
+//  * the running maximum is NOT recomputed per tile.  The row offset m (an integer, exactly representable as a 16-bit hi | lo
+//    pair) is subtracted INSIDE the matrix product: a fifth k-step whose K-side fragment is the constant (1, 1, tail, 0 ..) and
+//    whose Q-side fragment is (-m_hi, -m_lo, -BIG, 0 ..) -- one extra MFMA per 32 x 32 block of scores instead of 32 v_max +
+//    32 v_sub + the rescale of the output accumulators per tile and lane, and exp2 can start on the first finished register
+//    instead of waiting for a row maximum.  m is the (rounded-up) row maximum of the FIRST tile; a later tile whose scores
+//    exceed it by more than 2^12 (detected on the tile's row sum, which is needed anyway) takes a rare fix-up path that raises m
+//    by an integer -- the rescale factors are exact powers of two.  Keys beyond Nk in the last tile are masked by the same
+//    extra k-step (tail = 1 -> score - 60000 / -3e38 -> P = 0).
+//  * dropout's keep_scale and the softmax normaliser are applied once, to the output.
+//
+// K | V tiles travel global -> LDS by global_load_lds_dwordx4 (as in flash_fwd_dl.hip) into rings of four stages each,
+// tracked with a COUNTED s_waitcnt vmcnt(n): one bare s_barrier per tile, the loads never drain inside the loop.  A region's
+// top waits for the tiles of the NEXT region, so the first fragments of the next region are read before its barrier and the
+// fragment pipeline (two groups ahead) never restarts.  Workgroups of 8 waves (256 queries) share the tiles; the block index is remapped so that the
+// workgroups of one (batch, head) run on one XCD (their K | V stay in that L2).
+//
+// Products (MODE): 0 = bf16 operands, 1 = fp16 operands; one MFMA per product.  (An 'f16x2' variant -- q and v as hi + lo, k and
+// the probabilities single -- was built and measured first: 1.9x the MFMAs for a 1.4x smaller error, since each product still has
+// one singly-rounded side; dropped.)
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+#ifndef F2_ABLATE
+#define F2_ABLATE 0          // timing experiments only (tools/ab_flash2.sh): 1 no tile loads, 2 no barrier, 4 no exponentials, 8 no LDS fragment reads
+#endif
+constexpr int HD = 64, BKV = 64;
+constexpr int TILE = BKV * HD;              // u16 per K or V plane tile (8 KB)
+constexpr int NST = 4;                      // ring stages of K and of V
+constexpr int VOFF = NST * TILE;            // V ring behind the K ring
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float P_LIMIT = 4096.0f;          // a tile's row sum above this -> raise m (every P <= 4096 fits fp16)
+
+enum { M_BF16 = 0, M_F16 = 1 };
+
+struct F2Args {
+    const float* q;       // [B, Nq, H*64] fp32
+    const u16* kv;        // [B*Nk][2*H*64] bf16 or fp16
+    float* o;
+    float* lse;
+    int B, H, Nq, Nk, nqb;
+    float scale, p_drop;
+    unsigned seed;
+};
+
+__device__ __forceinline__ unsigned f2_hash(unsigned x) {      // == fd_hash (flash_fwd_dl.hip): the backward kernels rebuild the same mask
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15;
+    return x;
+}
+template <int MODE>
+__device__ __forceinline__ unsigned f2_pack(float a, float b) {
+    return MODE == M_BF16 ? vxb_pack_bf16(a, b) : vxb_pack_f16(a, b);
+}
+// the 16-bit value a pack kept, back as fp32
+template <int MODE>
+__device__ __forceinline__ void f2_unpack(unsigned p, float& a, float& b) {
+    if (MODE == M_BF16) { a = __uint_as_float(p << 16); b = __uint_as_float(p & 0xffff0000u); }
+    else {
+        union { unsigned u; vxb_f16x2 h; } t; t.u = p;
+        a = (float)t.h[0]; b = (float)t.h[1];
+    }
+}
+template <int MODE>
+__device__ __forceinline__ f32x16 f2_mma(const bf16x8 a, const bf16x8 b, f32x16 c) {
+    if (MODE == M_BF16) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x8 f2_from4(unsigned a, unsigned b, unsigned c, unsigned d) {
+    union { unsigned u[4]; bf16x8 v; } t;
+    t.u[0] = a; t.u[1] = b; t.u[2] = c; t.u[3] = d;
+    return t.v;
+}
+__device__ __forceinline__ bf16x8 f2_join(unsigned long long a, unsigned long long b) {
+    union { unsigned long long u[2]; bf16x8 v; } t;
+    t.u[0] = a; t.u[1] = b;
+    return t.v;
+}
+typedef short f2_v4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned long long f2_tr16(const u16* p) {
+    union { f2_v4s v; unsigned long long u; } t;
+    t.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) f2_v4s*)p);
+    return t.u;
+}
+// 16 bytes per lane, global (base + 32-bit lane offset) -> LDS[wave base + 16 lane], as INLINE ASM: the compiler's waitcnt pass orders
+// every later LDS read behind a direct-to-LDS load it knows about (s_waitcnt vmcnt(0) in front of the first ds_read_b64_tr_b16 of a
+// region -- the loads this kernel keeps in flight on purpose); issued this way it sees nothing and the hand-placed counted waits are
+// the only ones.  m0 = wave base.
+__device__ __forceinline__ void f2_load16(const u16* base, unsigned byte_off, unsigned lds_wave_base) {
+    if (F2_ABLATE & 1) return;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(byte_off), "s"(base), "s"(lds_wave_base) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void f2_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// acc += x as one instruction the optimiser cannot re-associate: written as C the 32 additions of a region's row sum are collected
+// into ONE dependent chain of v_pk_add_f32 behind the last MFMA (16 x (add + s_nop) with nothing to overlap)
+__device__ __forceinline__ void f2_acc(float& acc, float x) { asm volatile("v_add_f32 %0, %1, %0" : "+v"(acc) : "v"(x)); }
+
+template <int MODE, int DROP, int NW>
+__global__ void __launch_bounds__(NW * 64, 2) flash2_fwd_kernel(F2Args g) {
+    extern __shared__ __attribute__((aligned(16))) u16 smem[];
+    constexpr int LPW = 8 / NW;                     // load instructions per wave and plane tile
+    constexpr int NLOAD = 2 * LPW;                  // per wave and load group {K(t + 4), V(t + 2)}
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, lq = lane & 31;
+    // block -> (bh, query block): consecutive block ids go round-robin over the 8 XCDs, so ids congruent mod 8 get one
+    // contiguous range of (bh, qb) pairs -- the query blocks of a (batch, head) share an L2
+    int vb = blockIdx.x;
+    {
+        const int total = gridDim.x;
+        if ((total & 7) == 0) vb = (vb & 7) * (total >> 3) + (vb >> 3);
+    }
+    const int bh = vb / g.nqb, qblk = vb - bh * g.nqb;
+    const int b = bh / g.H, h = bh - b * g.H;
+    const int inner = g.H * HD;
+    const int qrow = qblk * (NW * 32) + wid * 32 + lq;         // this lane's query
+    const bool q_ok = qrow < g.Nq;
+    const float* qp = g.q + ((long long)b * g.Nq + (q_ok ? qrow : 0)) * inner + h * HD;
+    const float qs = g.scale * LOG2E;                          // scores live in the log2 domain
+
+    // Q^T fragments: lane (q, hi) holds q[16 ks + 8 hi .. +8] for ks = 0..3
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const float4 a = *reinterpret_cast<const float4*>(qp + 16 * ks + 8 * hi);
+        const float4 c = *reinterpret_cast<const float4*>(qp + 16 * ks + 8 * hi + 4);
+        float v[8] = {a.x * qs, a.y * qs, a.z * qs, a.w * qs, c.x * qs, c.y * qs, c.z * qs, c.w * qs};
+        unsigned ph[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float x0 = v[2 * i], x1 = v[2 * i + 1];
+            if (MODE != M_BF16) { x0 = __builtin_amdgcn_fmed3f(x0, -65504.f, 65504.f); x1 = __builtin_amdgcn_fmed3f(x1, -65504.f, 65504.f); }
+            ph[i] = f2_pack<MODE>(x0, x1);
+        }
+        qf[ks] = f2_from4(ph[0], ph[1], ph[2], ph[3]);
+    }
+    // the fifth k-step: K side (1, 1, tail, 0 ..) in the hi = 0 lanes, query side (-m_hi, -m_lo, -BIG, 0 ..)
+    const unsigned one2 = hi ? 0u : f2_pack<MODE>(1.f, 1.f);
+    const unsigned big2 = hi ? 0u : f2_pack<MODE>(MODE == M_BF16 ? -3.0e38f : -60000.f, 0.f);
+    unsigned mslot = 0u;                                       // pack(-m_hi, -m_lo)
+    float m_run = 0.f, l_run = 0.f;
+    auto set_m = [&](float m) {
+        const unsigned ph = f2_pack<MODE>(-m, 0.f);
+        float h0, h1;
+        f2_unpack<MODE>(ph, h0, h1);
+        const unsigned p2 = f2_pack<MODE>(-m, -m - h0);
+        mslot = hi ? 0u : p2;
+    };
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+
+    // ---- tile loads: a plane tile = 64 keys x 8 chunks = 8 wave instructions of 1 KB; wave w issues instructions w + NW t.
+    //      Address = (b, h) base (SGPR pair) + 32-bit lane offset; keys beyond Nk re-read the last row (masked by the tail slot)
+    const u16* kbase_g = g.kv + (long long)b * g.Nk * (2 * inner) + h * HD;
+    const u16* vbase_g = kbase_g + inner;
+    const unsigned rowb = 2u * 2u * (unsigned)inner;           // bytes per k | v row
+    const unsigned smem0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+    int lkey[LPW];
+    unsigned kchb[LPW], vchb[LPW];
+#pragma unroll
+    for (int t = 0; t < LPW; ++t) {
+        lkey[t] = (wid + NW * t) * 8 + (lane >> 3);
+        kchb[t] = (unsigned)(((lane & 7) ^ ((lkey[t] >> 1) & 7)) * 16);
+        vchb[t] = (unsigned)(((lane & 7) ^ (4 * ((lkey[t] >> 1) & 1))) * 16);
+    }
+    auto issue_kv = [&](int ktk, int ktv) {                   // K(ktk) and V(ktv) into their ring slots (ktv < 0: K only)
+#pragma unroll
+        for (int t = 0; t < LPW; ++t) {
+            const unsigned key = (unsigned)min(ktk * BKV + lkey[t], g.Nk - 1);
+            f2_load16(kbase_g, key * rowb + kchb[t], smem0 + (unsigned)(((ktk & 3) * TILE + (wid + NW * t) * 512) * 2));
+        }
+        if (ktv < 0) return;
+#pragma unroll
+        for (int t = 0; t < LPW; ++t) {
+            const unsigned key = (unsigned)min(ktv * BKV + lkey[t], g.Nk - 1);
+            f2_load16(vbase_g, key * rowb + vchb[t], smem0 + (unsigned)((VOFF + (ktv & 3) * TILE + (wid + NW * t) * 512) * 2));
+        }
+    };
+
+    const unsigned thr = (unsigned)(g.p_drop * 65536.0f);
+    const unsigned row_id = (unsigned)bh * (unsigned)g.Nq + (unsigned)qrow;
+    const unsigned rowh = row_id * 0x9E3779B1U + g.seed;
+    // K fragment (A operand of S^T): key row kb*32 + lq, chunk 2 ks + hi, swizzle key (row >> 1) & 7
+    int kbase[2], kkey[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) { const int row = kb * 32 + lq; kbase[kb] = row * 64; kkey[kb] = (row >> 1) & 7; }
+    // V^T transposed-read addressing (as flash_fwd_dl.hip)
+    const int t16 = lane & 15, gq = lane >> 4;
+    const int vrow0 = 4 * (gq >> 1) + (t16 >> 2);
+    const int vchunk0 = 2 * (gq & 1) + ((t16 & 3) >> 1), vhalf = (t16 & 1) * 4;
+    int vlane[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) vlane[db] = vrow0 * 64 + ((vchunk0 + 4 * db) ^ (4 * ((vrow0 >> 1) & 1))) * 8 + vhalf;
+
+    const int nkt = (g.Nk + BKV - 1) / BKV;
+
+    // fragment group gi = 2 i + kb (i = 0..3: k-step of the scores / (key step, d block) of the P V product; kb: 32-key block)
+    auto k_frag = [&](int kt, int gi) -> bf16x8 {
+        const int kb = gi & 1, i = gi >> 1;
+        if (F2_ABLATE & 8) return qf[i];
+        return *reinterpret_cast<const bf16x8*>(smem + (kt & 3) * TILE + kbase[kb] + (((2 * i + hi) ^ kkey[kb]) * 8));
+    };
+    auto v_frag = [&](int kt, int gi) -> bf16x8 {             // V^T (d block (i & 1) ^ kb, keys kb*32 + 16 (i >> 1) .. +16)
+        const int kb = gi & 1, i = gi >> 1;
+        if (F2_ABLATE & 8) return qf[i ^ 1];
+        const u16* ad = smem + VOFF + (kt & 3) * TILE + vlane[(i & 1) ^ kb] + (kb * 32 + 16 * (i >> 1)) * 64;
+        return f2_join(f2_tr16(ad), f2_tr16(ad + 8 * 64));
+    };
+    auto ones_frag = [&](int kt, int kb) -> bf16x8 {
+        const unsigned tail = (kt * BKV + kb * 32 + lq >= g.Nk) ? one2 & 0xffffu : 0u;        // (1, 0): hi = 0 lanes of keys >= Nk
+        return f2_from4(one2, tail, 0u, 0u);
+    };
+    // element pair t = 0..15 of tile kts: P = exp2(S') (dropout applied) packed into pc, row-sum contribution into ps[t & 3]
+    auto pair = [&](int kts_colb, int t, const f32x16 (&sa)[2], unsigned (&pc)[2][8], float (&ps)[4]) {
+        const int kb = t >> 3, r = 2 * (t & 7);
+        if (F2_ABLATE & 4) { pc[kb][r >> 1] = __float_as_uint(sa[kb][r]); return; }
+        float p0 = __builtin_amdgcn_exp2f(sa[kb][r]), p1 = __builtin_amdgcn_exp2f(sa[kb][r + 1]);
+        f2_acc(ps[t & 3], p0);
+        f2_acc(ps[(t + 2) & 3], p1);
+        if (DROP) {
+            const unsigned cp = (unsigned)((kb * 32 + (r & 3) + 8 * (r >> 2)) >> 1) * 0x85EBCA77U;
+            const unsigned hsh = f2_hash(rowh ^ ((unsigned)kts_colb + cp));
+            p0 = (hsh & 0xffffu) >= thr ? p0 : 0.f;
+            p1 = (hsh >> 16) >= thr ? p1 : 0.f;
+        }
+        pc[kb][r >> 1] = f2_pack<MODE>(p0, p1);
+    };
+    // fragments of the NEXT region's first two groups, read at the end of a region (their tiles were waited for at its top)
+    bf16x8 kfc[2], vfc[2];
+
+    // One region, pinned issue order (sched_barrier between the steps; inside a step the compiler orders freely).  For the eight
+    // groups gi = 2 i + kb:   [i == 0: S'(kb) = ones x m-slot]
+    //                         O(d block (i & 1) ^ kb) += V^T(ktv; kb, i) P_prev(kb, i >> 1)     | element pair 2 gi of P_cur = exp2(S_a)
+    //                         S'(kb) += K(ktq; kb, i) Q^T(i)                                    | element pair 2 gi + 1
+    // so every accumulator is touched once in four MFMAs.  The fragments of group gi + 2 are requested in group gi -- the last two
+    // requests are for the next region (tiles ktq + 1, ktv + 1, landed and synchronised at this region's top).
+    auto region = [&](auto has_pv, int ktq, int kts, int ktv, const f32x16 (&sa)[2], f32x16 (&sb)[2], const unsigned (&pp)[2][8],
+                      unsigned (&pc)[2][8]) -> float {
+        constexpr bool HAS_PV = decltype(has_pv)::value;
+        const int colb = (int)((unsigned)((kts * BKV + 4 * hi) >> 1) * 0x85EBCA77U + 0xC2B2AE3DU);
+        const bf16x8 msl = f2_from4(mslot, big2, 0u, 0u);
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+        bf16x8 kf[10], vf[10];
+        kf[0] = kfc[0]; kf[1] = kfc[1]; vf[0] = vfc[0]; vf[1] = vfc[1];
+#pragma unroll
+        for (int gi = 0; gi < 8; ++gi) {
+            const int kb = gi & 1, i = gi >> 1;
+            {
+                const int gn = gi + 2;
+                kf[gn] = k_frag(gn < 8 ? ktq : ktq + 1, gn & 7);
+                if (HAS_PV || gn >= 8) vf[gn] = v_frag(gn < 8 ? ktv : ktv + 1, gn & 7);
+            }
+            if (i == 0) {
+                f32x16 c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = 0.f;
+                sb[kb] = f2_mma<MODE>(ones_frag(ktq, kb), msl, c);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (HAS_PV) {
+                const int ks = i >> 1, db = (i & 1) ^ kb;
+                oacc[db] = f2_mma<MODE>(vf[gi], f2_from4(pp[kb][4 * ks], pp[kb][4 * ks + 1], pp[kb][4 * ks + 2], pp[kb][4 * ks + 3]), oacc[db]);
+            }
+            pair(colb, 2 * gi, sa, pc, ps);
+            __builtin_amdgcn_sched_barrier(0);
+            sb[kb] = f2_mma<MODE>(kf[gi], qf[i], sb[kb]);
+            pair(colb, 2 * gi + 1, sa, pc, ps);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        kfc[0] = kf[8]; kfc[1] = kf[9]; vfc[0] = vf[8]; vfc[1] = vf[9];
+        return (ps[0] + ps[1]) + (ps[2] + ps[3]);
+    };
+    // P of a tile without the pipeline (the rare fix-up path)
+    auto softmax = [&](int kt, const f32x16 (&s)[2], unsigned (&pk)[2][8]) -> float {
+        const int colb = (int)((unsigned)((kt * BKV + 4 * hi) >> 1) * 0x85EBCA77U + 0xC2B2AE3DU);
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 16; ++t) pair(colb, t, s, pk, ps);
+        return (ps[0] + ps[1]) + (ps[2] + ps[3]);
+    };
+    // rare: some P of tile kt (scores sa, already offset by the current m) may exceed P_LIMIT -> raise m by an integer, rescale
+    // what has been accumulated (exact: powers of two), redo the tile's P and shift the next tile's scores
+    auto raise_m = [&](int kt, f32x16 (&sa)[2], f32x16 (&sb2)[2], unsigned (&pk)[2][8], float& ps) {
+        float mt = sa[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sa[kb][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float delta = fmaxf(ceilf(mt), 0.f);
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { oacc[i][r] *= alpha; sa[i][r] -= delta; sb2[i][r] -= delta; }
+        l_run *= alpha;
+        m_run += delta;
+        set_m(m_run);
+        ps = softmax(kt, sa, pk);
+    };
+
+    // ---- prologue: K0 K1 {K2 V0} {K3 V1} in flight; first tile's scores with m = 0, then m = ceil(row maximum).
+    //      Region j consumes K(j+1), V(j-1) and reads the first fragments of K(j+2), V(j): its top waits for {K(j+2), V(j)} and
+    //      issues {K(j+4), V(j+2)} -- K slot (j+4) & 3 held K(j) (read in region j-1), V slot (j+2) & 3 held V(j-2) (likewise).
+    issue_kv(0, -1); issue_kv(1, -1); issue_kv(2, 0); issue_kv(3, 1);
+    f2_wait_vm<2 * NLOAD>();                               // K0 K1 landed (this wave's part)
+    vxb_raw_barrier();
+    f32x16 sa[2], sb2[2];
+    unsigned pa[2][8], pb[2][8];
+    {
+        const bf16x8 msl0 = f2_from4(0u, big2, 0u, 0u);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[r] = 0.f;
+            c = f2_mma<MODE>(ones_frag(0, kb), msl0, c);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) c = f2_mma<MODE>(k_frag(0, 2 * ks + kb), qf[ks], c);
+            sa[kb] = c;
+        }
+        float mt = sa[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sa[kb][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        m_run = ceilf(mt);
+        set_m(m_run);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sa[kb][r] -= m_run;
+        kfc[0] = k_frag(1, 0); kfc[1] = k_frag(1, 1);
+        vfc[0] = kfc[0]; vfc[1] = kfc[1];                  // (region 0 has no P V product)
+    }
+    // ---- region 0: S'(1) | P(0)
+    f2_wait_vm<NLOAD>();                                   // {K2 V0} landed
+    vxb_raw_barrier();
+    issue_kv(4, 2);
+    {
+        float ps = region(std::false_type(), 1, 0, -1, sa, sb2, pa, pa);
+        if (__builtin_amdgcn_ballot_w64(!(ps <= P_LIMIT))) raise_m(0, sa, sb2, pa, ps);
+        l_run += ps;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) sa[kb] = sb2[kb];
+    }
+    // ---- regions 1 .. nkt-1: S'(j+1) | P(j) | O += V(j-1) P(j-1); P alternates between pa and pb
+    int j = 1;
+    for (; j + 1 < nkt; j += 2) {
+        f2_wait_vm<NLOAD>();                               // {K(j+2), V(j)} landed (needed by the NEXT region); {K(j+3), V(j+1)} may be in flight
+        vxb_raw_barrier();
+        issue_kv(j + 4, j + 2);
+        {
+            float ps = region(std::true_type(), j + 1, j, j - 1, sa, sb2, pa, pb);
+            if (__builtin_amdgcn_ballot_w64(!(ps <= P_LIMIT))) raise_m(j, sa, sb2, pb, ps);
+            l_run += ps;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) sa[kb] = sb2[kb];
+        }
+        f2_wait_vm<NLOAD>();
+        vxb_raw_barrier();
+        issue_kv(j + 5, j + 3);
+        {
+            float ps = region(std::true_type(), j + 2, j + 1, j, sa, sb2, pb, pa);
+            if (__builtin_amdgcn_ballot_w64(!(ps <= P_LIMIT))) raise_m(j + 1, sa, sb2, pa, ps);
+            l_run += ps;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) sa[kb] = sb2[kb];
+        }
+    }
+    // O += V(nkt-1) P(nkt-1): the tile was synchronised at the last region's top, its first two fragments are in vfc.  (Two calls, not
+    // a runtime choice between pa and pb: a select between the two ARRAYS sends both to scratch memory.)
+    auto last_pv = [&](const unsigned (&pl)[2][8]) {
+        bf16x8 vf[8];
+        vf[0] = vfc[0]; vf[1] = vfc[1];
+#pragma unroll
+        for (int gi = 2; gi < 8; ++gi) vf[gi] = v_frag(nkt - 1, gi);
+#pragma unroll
+        for (int gi = 0; gi < 8; ++gi) {
+            const int kb = gi & 1, i = gi >> 1, ks = i >> 1, db = (i & 1) ^ kb;
+            oacc[db] = f2_mma<MODE>(vf[gi], f2_from4(pl[kb][4 * ks], pl[kb][4 * ks + 1], pl[kb][4 * ks + 2], pl[kb][4 * ks + 3]), oacc[db]);
+        }
+    };
+    if (j < nkt) {                                          // one region left: P(j) into pb
+        f2_wait_vm<NLOAD>();
+        vxb_raw_barrier();
+        issue_kv(j + 4, j + 2);
+        float ps = region(std::true_type(), j + 1, j, j - 1, sa, sb2, pa, pb);
+        if (__builtin_amdgcn_ballot_w64(!(ps <= P_LIMIT))) raise_m(j, sa, sb2, pb, ps);
+        l_run += ps;
+        last_pv(pb);
+    } else {
+        last_pv(pa);
+    }
+    f2_wait_vm<0>();                                        // the clamped loads of tiles >= nkt must not outlive the workgroup's LDS
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (q_ok) {
+        const float inv = (1.0f / (1.0f - g.p_drop)) / l_tot;
+        float* op = g.o + ((long long)b * g.Nq + qrow) * inner + h * HD;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                float4 v;
+                v.x = oacc[db][4 * r4 + 0] * inv; v.y = oacc[db][4 * r4 + 1] * inv;
+                v.z = oacc[db][4 * r4 + 2] * inv; v.w = oacc[db][4 * r4 + 3] * inv;
+                *reinterpret_cast<float4*>(op + db * 32 + 8 * r4 + 4 * hi) = v;
+            }
+        if (hi == 0) g.lse[(long long)bh * g.Nq + qrow] = (m_run + log2f(l_tot)) * (1.0f / LOG2E);
+    }
+}
+
+template <int MODE, int NW>
+int f2_launch(const F2Args& g, bool drop, hipStream_t st) {
+    const size_t lds = (size_t)2 * NST * TILE * sizeof(u16);
+    const dim3 grid(g.nqb * g.B * g.H);
+    if (drop) {
+        if (hipFuncSetAttribute((const void*)flash2_fwd_kernel<MODE, 1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
+        hipLaunchKernelGGL((flash2_fwd_kernel<MODE, 1, NW>), grid, dim3(NW * 64), lds, st, g);
+    } else {
+        if (hipFuncSetAttribute((const void*)flash2_fwd_kernel<MODE, 0, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
+        hipLaunchKernelGGL((flash2_fwd_kernel<MODE, 0, NW>), grid, dim3(NW * 64), lds, st, g);
+    }
+    return VXB_OK;
+}
+
+// fp32 [rows][cols] -> fp16 planes [nplanes][rows][cols]: plane 0 = RNE(x) (saturated at +-65504), plane 1 = RNE(x - plane 0)
+__global__ void __launch_bounds__(256) split_f16_kernel(const float* __restrict__ src, long long ld, long long rows, int cols,
+                                                        u16* __restrict__ hi, u16* __restrict__ lo) {
+    const int q = cols >> 2;
+    const long long total = rows * q;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / q;
+        const int c4 = (int)(i - r * q) * 4;
+        float4 v = *reinterpret_cast<const float4*>(src + r * ld + c4);
+        v.x = __builtin_amdgcn_fmed3f(v.x, -65504.f, 65504.f); v.y = __builtin_amdgcn_fmed3f(v.y, -65504.f, 65504.f);
+        v.z = __builtin_amdgcn_fmed3f(v.z, -65504.f, 65504.f); v.w = __builtin_amdgcn_fmed3f(v.w, -65504.f, 65504.f);
+        uint2 ph;
+        ph.x = vxb_pack_f16(v.x, v.y); ph.y = vxb_pack_f16(v.z, v.w);
+        *reinterpret_cast<uint2*>(hi + r * cols + c4) = ph;
+        if (lo) {
+            float a0, a1, a2, a3;
+            f2_unpack<M_F16>(ph.x, a0, a1); f2_unpack<M_F16>(ph.y, a2, a3);
+            uint2 pl;
+            pl.x = vxb_pack_f16(v.x - a0, v.y - a1); pl.y = vxb_pack_f16(v.z - a2, v.w - a3);
+            *reinterpret_cast<uint2*>(lo + r * cols + c4) = pl;
+        }
+    }
+}
+
+}  // namespace
+
+// fp16 twin of vxb_split_bf16_f32
+extern "C" int vxb_split_f16_f32(const float* src, int64_t ld, int64_t rows, int cols, void* dst_planes, int nplanes,
+                                 vxb_stream_t stream) {
+    if (!src || !dst_planes || rows < 1 || cols < 4 || (nplanes != 1 && nplanes != 2)) return VXB_EARG;
+    if ((cols & 3) || (ld & 3) || (((uintptr_t)src) & 15) || (((uintptr_t)dst_planes) & 15)) return VXB_ESIZE;
+    u16* hi = (u16*)dst_planes;
+    u16* lo = nplanes == 2 ? hi + rows * cols : nullptr;
+    const long long total = rows * (cols >> 2);
+    const int grid = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+    hipLaunchKernelGGL(split_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (long long)ld, (long long)rows, cols, hi, lo);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+// Forward of the fused attention, pipelined structure.  mode 0: kv_planes = ONE bf16 plane [B*Nk][2*H*64]; mode 1: one fp16 plane.
+// waves: 4 or 8 per workgroup (0 = choose).  Same outputs (o, lse) and the same dropout mask as vxb_flash_attn_fwd_dl.
+extern "C" int vxb_flash2_attn_fwd(const float* q, const void* kv_planes, int mode, float* o, float* lse, int B, int H, int Nq, int Nk,
+                                   int head_dim, float scale, float dropout_p, uint32_t seed, int waves, vxb_stream_t stream) {
+    if (!q || !kv_planes || !o || !lse || B < 1 || H < 1 || Nq < 1 || Nk < 1 || mode < 0 || mode > 1) return VXB_EARG;
+    if (head_dim != HD || dropout_p < 0.f || dropout_p >= 1.f || (((uintptr_t)kv_planes) & 15)) return VXB_ESIZE;
+    if (waves == 0) waves = ((long long)vxb_cdiv(Nq, 256) * B * H >= 512) ? 8 : 4;
+    if (waves != 4 && waves != 8) return VXB_EARG;
+    F2Args g;
+    g.q = q; g.kv = (const u16*)kv_planes; g.o = o; g.lse = lse;
+    g.B = B; g.H = H; g.Nq = Nq; g.Nk = Nk; g.nqb = vxb_cdiv(Nq, waves * 32); g.scale = scale; g.p_drop = dropout_p; g.seed = seed;
+    const bool drop = (unsigned)(dropout_p * 65536.0f) > 0u;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((long long)Nk * 2 * H * HD * 2 * 2 > 0xffffffffLL) return VXB_ESIZE;          // 32-bit lane offsets inside one sample's k | v rows
+    if (waves == 8) rc = mode == M_BF16 ? f2_launch<M_BF16, 8>(g, drop, st) : f2_launch<M_F16, 8>(g, drop, st);
+    else rc = mode == M_BF16 ? f2_launch<M_BF16, 4>(g, drop, st) : f2_launch<M_F16, 4>(g, drop, st);
+    if (rc != VXB_OK) return rc;
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}

@@ -62,3 +62,29 @@ def flash_attn_bwd(q, kv, o, d_o, lse, B, H, Nq, Nk, scale, p=0.0, seed=0, x3=Fa
     call('vxb_flash_attn_bwd_bf16x3' if x3 else 'vxb_flash_attn_bwd_bf16', q, kv, o, d_o, lse, dq, dkv, ws, B, H, Nq, Nk, 64,
          float(scale), float(p), int(seed) & 0xFFFFFFFF)
     return dq, dkv
+
+
+MODES = {'bf16': 0, 'f16': 1}
+
+
+def kv_planes(kv, mode):
+    """k | v operand plane of the round-4 kernels: bf16 ('bf16') or fp16 ('f16'), [1][B*Nk][2*H*64]."""
+    npl = 1
+    out = torch.empty((npl,) + tuple(kv.shape), dtype=torch.bfloat16 if mode == 'bf16' else torch.float16, device=kv.device)
+    set_meta('attn_core', 0.0)
+    call('vxb_split_bf16_f32' if mode == 'bf16' else 'vxb_split_f16_f32', kv, kv.stride(0), kv.shape[0], kv.shape[1], out, npl)
+    return out
+
+
+def flash2_attn_fwd(q, kv, B, H, Nq, Nk, scale, p=0.0, seed=0, mode='f16', waves=0, planes=None, return_planes=False):
+    """Pipelined forward (csrc/flash2_fwd.hip).  Same contract as flash_attn_fwd_dl."""
+    if planes is None:
+        planes = kv_planes(kv, mode)
+    o = torch.empty_like(q)
+    lse = torch.empty((B * H, Nq), dtype=torch.float32, device=q.device)
+    set_meta('attn_core', 4.0 * B * H * Nq * Nk * 64)
+    call('vxb_flash2_attn_fwd', q, planes, MODES[mode], o, lse, B, H, Nq, Nk, 64, float(scale), float(p), int(seed) & 0xFFFFFFFF,
+         int(waves))
+    if return_planes:
+        return o, lse, planes
+    return o, lse

@@ -208,3 +208,28 @@ def hashed_int(name: str, shape, lo: int, hi: int, seed: int = 0) -> torch.Tenso
     g = _hrng('i:' + name, seed)
     a = g.integers(lo, hi, int(np.prod(shape)))
     return torch.from_numpy(a.astype(np.int64).reshape(tuple(shape)))
+
+
+def projection_signs(name: str, numel: int, k: int, device='cpu') -> torch.Tensor:
+    """+-1 vector number k for the tensor called `name`: a multiplicative hash of the element index (pure integer torch ops, so the
+    fixture generator on the CPU and the GPU test produce the same signs)."""
+    h = 0
+    for ch in name:
+        h = (h * 131 + ord(ch)) & 0x7FFFFFFF
+    i = torch.arange(numel, dtype=torch.int64, device=device)
+    x = (i * 0x9E3779B1 + (h + 1) * 0x85EBCA77 + (k + 1) * 0xC2B2AE3D) & 0xFFFFFFFF
+    x = ((x ^ (x >> 16)) * 0x7FEB352D) & 0xFFFFFFFF
+    x = ((x ^ (x >> 15)) * 0x846CA68B) & 0xFFFFFFFF
+    x = x ^ (x >> 16)
+    return ((x >> 7) & 1).to(torch.float64) * 2.0 - 1.0
+
+
+def project(t: torch.Tensor, name: str, nproj: int) -> torch.Tensor:
+    """nproj random +-1 projections of a tensor, in float64 (on the tensor's device)."""
+    f = t.detach().reshape(-1).double()
+    return torch.stack([(f * projection_signs(name, f.numel(), k, f.device)).sum() for k in range(nproj)]).cpu()
+
+
+def projection_error(pa: torch.Tensor, pb: torch.Tensor) -> torch.Tensor:
+    """estimate of ||a - b|| from the projections of a and b: E[(s . (a - b))^2] = ||a - b||^2 for independent +-1 signs."""
+    return ((pa.double() - pb.double()) ** 2).mean().sqrt()
