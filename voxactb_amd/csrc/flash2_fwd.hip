@@ -45,7 +45,10 @@ constexpr int TILE = BKV * HD;              // u16 per K or V plane tile (8 KB)
 constexpr int NST = 4;                      // ring stages of K and of V
 constexpr int VOFF = NST * TILE;            // V ring behind the K ring
 constexpr float LOG2E = 1.4426950408889634f;
-constexpr float P_LIMIT = 4096.0f;          // a tile's row sum above this -> raise m (every P <= 4096 fits fp16)
+#ifndef F2_PLIMIT
+#define F2_PLIMIT 4096.0f
+#endif
+constexpr float P_LIMIT = F2_PLIMIT;          // a tile's row sum above this -> raise m (every P <= 4096 fits fp16)
 
 enum { M_BF16 = 0, M_F16 = 1 };
 
@@ -107,9 +110,15 @@ __device__ __forceinline__ void f2_load16(const u16* base, unsigned byte_off, un
 }
 template <int N>
 __device__ __forceinline__ void f2_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// acc += x as one instruction the optimiser cannot re-associate: written as C the 32 additions of a region's row sum are collected
-// into ONE dependent chain of v_pk_add_f32 behind the last MFMA (16 x (add + s_nop) with nothing to overlap)
-__device__ __forceinline__ void f2_acc(float& acc, float x) { asm volatile("v_add_f32 %0, %1, %0" : "+v"(acc) : "v"(x)); }
+// acc += x that the optimiser cannot re-associate: written as plain C the 32 additions of a region's row sum are collected into ONE
+// dependent chain of v_pk_add_f32 behind the last MFMA (16 x (add + s_nop) with nothing to overlap).  The add itself stays a compiler
+// instruction -- as inline asm it would read v_exp_f32's result without the wait state the hazard recogniser inserts (lanes of the
+// later transcendental passes then see the register's old contents: measured, rows with (q & 4) == 0 wrong); the EMPTY asm only pins
+// the value at this point of the program.
+__device__ __forceinline__ void f2_acc(float& acc, float x) {
+    acc += x;
+    asm volatile("" : "+v"(acc));
+}
 
 template <int MODE, int DROP, int NW>
 __global__ void __launch_bounds__(NW * 64, 2) flash2_fwd_kernel(F2Args g) {
@@ -492,7 +501,7 @@ extern "C" int vxb_flash2_attn_fwd(const float* q, const void* kv_planes, int mo
                                    int head_dim, float scale, float dropout_p, uint32_t seed, int waves, vxb_stream_t stream) {
     if (!q || !kv_planes || !o || !lse || B < 1 || H < 1 || Nq < 1 || Nk < 1 || mode < 0 || mode > 1) return VXB_EARG;
     if (head_dim != HD || dropout_p < 0.f || dropout_p >= 1.f || (((uintptr_t)kv_planes) & 15)) return VXB_ESIZE;
-    if (waves == 0) waves = ((long long)vxb_cdiv(Nq, 256) * B * H >= 512) ? 8 : 4;
+    if (waves == 0) waves = 4;          // two 4-wave workgroups per CU overlap each other's prologue / epilogue; 8 waves measured 3-30 % slower
     if (waves != 4 && waves != 8) return VXB_EARG;
     F2Args g;
     g.q = q; g.kv = (const u16*)kv_planes; g.o = o; g.lse = lse;
