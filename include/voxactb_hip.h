@@ -459,6 +459,17 @@ int vxb_split_f16_f32(const float* src, int64_t ld, int64_t rows, int cols, void
 int vxb_flash2_attn_fwd(const float* q, const void* kv_planes, int mode, float* o, float* lse, int B, int H, int Nq, int Nk,
                         int head_dim, float scale, float dropout_p, uint32_t seed, int waves, vxb_stream_t stream);
 
+/* Backward of Attention.forward (autograd of perceiver_lang_io.py:107-132), pipelined structure (csrc/flash2_bwd.hip): per wave the
+ * scores / dP of unit s+1, the score gradients of unit s and the dQ (or dK | dV) products of unit s-1 overlap; -lse and -D are folded
+ * into the matrix products.  kv_plane: the 16-bit plane of k | v the forward used (mode 0 bf16 / 1 fp16: vxb_split_bf16_f32 /
+ * vxb_split_f16_f32, one plane); gx = 1: dO and dS as hi + lo pairs (two MFMAs per product).  dO is scaled by a power of two taken from
+ * its largest magnitude on the device (fp16 range) and the results are scaled back.  which: 1 = dq, 2 = dkv, 3 = both (written, not
+ * accumulated).  ws: vxb_flash2_attn_bwd_ws_bytes(B, H, Nq, gx) bytes, 256-byte aligned.  Same dropout mask as the forward. */
+size_t vxb_flash2_attn_bwd_ws_bytes(int B, int H, int Nq, int gx);
+int vxb_flash2_attn_bwd(const float* q, const float* kv, const float* o, const float* d_o, const float* lse, const void* kv_plane,
+                        int mode, int gx, float* dq, float* dkv, void* ws, int B, int H, int Nq, int Nk, int head_dim, float scale,
+                        float dropout_p, uint32_t seed, int which, vxb_stream_t stream);
+
 /* Forward with k | v as bf16 planes [nplanes][B*Nk][2*H*64] (vxb_split_bf16_f32 of the to_kv output): K/V tiles go
  * global -> LDS directly (double-buffered, one barrier per 64-key tile).  Same outputs / dropout mask as the entries above. */
 int vxb_flash_attn_fwd_dl(const float* q, const void* kv_planes, int nplanes, float* o, float* lse, int B, int H, int Nq,

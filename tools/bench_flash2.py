@@ -19,6 +19,87 @@ def ref_attn(q, kv, B, H, Nq, Nk, scale):
     return o.permute(0, 2, 1, 3).reshape(B * Nq, H * 64), lse.reshape(B * H, Nq)
 
 
+def ref_bwd(q, kv, d_o, B, H, Nq, Nk, scale):
+    """fp64 autograd of the softmax attention (no dropout) -> dq, dkv"""
+    q64 = q.double().requires_grad_(True)
+    kv64 = kv.double().requires_grad_(True)
+    q4 = q64.view(B, Nq, H, 64).permute(0, 2, 1, 3)
+    k4 = kv64[:, :H * 64].reshape(B, Nk, H, 64).permute(0, 2, 1, 3)
+    v4 = kv64[:, H * 64:].reshape(B, Nk, H, 64).permute(0, 2, 1, 3)
+    s = torch.einsum('bhid,bhjd->bhij', q4, k4) * scale
+    o = torch.einsum('bhij,bhjd->bhid', torch.softmax(s, -1), v4).permute(0, 2, 1, 3).reshape(B * Nq, H * 64)
+    (o * d_o.double()).sum().backward()
+    return q64.grad, kv64.grad
+
+
+def check_bwd(which=3):
+    dev = 'cuda:0'
+    torch.manual_seed(1)
+    ok = True
+    for (B, H, Nq, Nk) in ((2, 2, 200, 333), (1, 1, 64, 64), (2, 8, 512, 640), (1, 1, 300, 8077), (1, 2, 8077, 130)):
+        q = torch.randn(B * Nq, H * 64, device=dev)
+        kv = torch.randn(B * Nk, 2 * H * 64, device=dev)
+        d_o = torch.randn(B * Nq, H * 64, device=dev) * 3e-4
+        d_o[3] *= 40.0
+        dq_ref, dkv_ref = ref_bwd(q, kv, d_o, B, H, Nq, Nk, 0.125)
+        for mode in ('bf16', 'f16'):
+            pl = flash.kv_planes(kv, mode)
+            o, lse = flash.flash2_attn_fwd(q, kv, B, H, Nq, Nk, 0.125, 0.0, 5, mode=mode, planes=pl)
+            for gx in (False, True):
+                dq, dkv = flash.flash2_attn_bwd(q, kv, o, d_o, lse, pl, B, H, Nq, Nk, 0.125, 0.0, 5, mode=mode, gx=gx, which=which)
+                tol = {'bf16': 3e-2, 'f16': 4e-3}[mode]
+                msg = ''
+                for nm, a, r in (('dq', dq, dq_ref), ('dkv', dkv, dkv_ref)):
+                    if a is None:
+                        continue
+                    e = (a.double() - r).abs().max().item() / r.abs().max().item()
+                    en = ((a.double() - r).norm() / r.norm()).item()
+                    good = e < tol and bool(torch.isfinite(a).all())
+                    ok &= good
+                    msg += ' %s max %.2e rms %.2e %s' % (nm, e, en, 'ok' if good else 'FAIL')
+                print('%-18s bwd %-5s gx=%d %s' % ((B, H, Nq, Nk), mode, gx, msg))
+        # dropout: against the round-3 kernels (same mask)
+        o3, lse3, kvp3 = flash.flash_attn_fwd_dl(q, kv, B, H, Nq, Nk, 0.125, 0.1, 7, x3=True, return_planes=True)
+        dq3, dkv3 = flash.flash_attn_bwd_dl(q, kv, o3, d_o, lse3, B, H, Nq, Nk, 0.125, 0.1, 7, x3=True, kv_planes=kvp3)
+        pl = flash.kv_planes(kv, 'f16')
+        o, lse = flash.flash2_attn_fwd(q, kv, B, H, Nq, Nk, 0.125, 0.1, 7, mode='f16', planes=pl)
+        for gx in (False, True):
+            dq, dkv = flash.flash2_attn_bwd(q, kv, o, d_o, lse, pl, B, H, Nq, Nk, 0.125, 0.1, 7, mode='f16', gx=gx, which=which)
+            msg = ''
+            for nm, a, r in (('dq', dq, dq3), ('dkv', dkv, dkv3)):
+                if a is None:
+                    continue
+                e = (a - r).abs().max().item() / r.abs().max().item()
+                good = e < 8e-3
+                ok &= good
+                msg += ' %s %.2e %s' % (nm, e, 'ok' if good else 'FAIL')
+            print('%-18s bwd dropout f16 gx=%d vs round-3 bf16x3:%s' % ((B, H, Nq, Nk), gx, msg))
+    print('CHECK BWD', 'PASSED' if ok else 'FAILED')
+    return ok
+
+
+def bench_bwd(which=3):
+    dev = 'cuda:0'
+    B = 16
+    for name, H, Nq, Nk in (('self', 8, 2048, 2048), ('cross', 1, 2048, 8077), ('decoder', 1, 8077, 2048)):
+        q = torch.randn(B * Nq, H * 64, device=dev)
+        kv = torch.randn(B * Nk, 2 * H * 64, device=dev)
+        d_o = torch.randn(B * Nq, H * 64, device=dev) * 1e-3
+        fl = 10.0 * B * H * Nq * Nk * 64
+        for p in (0.0, 0.1):
+            o3, lse3, kvp3 = flash.flash_attn_fwd_dl(q, kv, B, H, Nq, Nk, 0.125, p, 7, x3=True, return_planes=True)
+            t = timeit(lambda: flash.flash_attn_bwd_dl(q, kv, o3, d_o, lse3, B, H, Nq, Nk, 0.125, p, 7, x3=True, kv_planes=kvp3), n=5)
+            print('%-8s p=%.1f  round-3 bf16x3 bwd (with its split passes) %.3f ms %7.1f TF/s' % (name, p, t, fl / t * 1e-9))
+            for mode in ('bf16', 'f16'):
+                pl = flash.kv_planes(kv, mode)
+                o, lse = flash.flash2_attn_fwd(q, kv, B, H, Nq, Nk, 0.125, p, 7, mode=mode, planes=pl)
+                for gx in (False, True):
+                    for w in sorted({1, 2, 3} & ({which, 1, 2} if which == 3 else {which})):
+                        t = timeit(lambda: flash.flash2_attn_bwd(q, kv, o, d_o, lse, pl, B, H, Nq, Nk, 0.125, p, 7, mode=mode, gx=gx, which=w), n=5)
+                        f = fl * (0.4 if w == 1 else 0.6 if w == 2 else 1.0)
+                        print('%-8s p=%.1f  flash2 bwd %-5s gx=%d which=%d (with prep) %.3f ms %7.1f TF/s' % (name, p, mode, gx, w, t, f / t * 1e-9))
+
+
 def timeit(fn, n=10, warm=3):
     for _ in range(warm):
         fn()
@@ -111,6 +192,12 @@ def one(spec):
 
 
 if __name__ == '__main__':
+    if '--bwd' in sys.argv:
+        w = int(sys.argv[sys.argv.index('--bwd') + 1])
+        good = check_bwd(w)
+        if '--quick' not in sys.argv:
+            bench_bwd(w)
+        sys.exit(0 if good else 1)
     if '--one' in sys.argv:
         one(sys.argv[sys.argv.index('--one') + 1])
         sys.exit(0)

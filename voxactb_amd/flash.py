@@ -88,3 +88,16 @@ def flash2_attn_fwd(q, kv, B, H, Nq, Nk, scale, p=0.0, seed=0, mode='f16', waves
     if return_planes:
         return o, lse, planes
     return o, lse
+
+
+def flash2_attn_bwd(q, kv, o, d_o, lse, planes, B, H, Nq, Nk, scale, p=0.0, seed=0, mode='f16', gx=True, which=3):
+    """Pipelined backward (csrc/flash2_bwd.hip) -> (dq, dkv); planes: the forward's k | v plane (kv_planes(kv, mode))."""
+    from ._lib import lib
+    dq = torch.empty_like(q) if which & 1 else None
+    dkv = torch.empty_like(kv) if which & 2 else None
+    nws = lib().vxb_flash2_attn_bwd_ws_bytes(B, H, Nq, int(gx))
+    ws = torch.empty(nws, dtype=torch.uint8, device=q.device)
+    set_meta('attn_core', 10.0 * B * H * Nq * Nk * 64 * (0.4 if which == 1 else 0.6 if which == 2 else 1.0))
+    call('vxb_flash2_attn_bwd', q, kv, o, d_o, lse, planes, MODES[mode], int(gx), dq, dkv, ws, B, H, Nq, Nk, 64, float(scale), float(p),
+         int(seed) & 0xFFFFFFFF, int(which))
+    return dq, dkv
