@@ -105,6 +105,7 @@ def main():
         B, cfg.rlbench.cameras, (HW, HW), V, low_dim, seed=100 * rank + 10 * ai + j, scene_bounds=scene, arm_pred_loss=twin,
         crop_target_obj_voxel=twin, crop_radius=0.3 if ai == 0 else 0.4, keyframes_near_target=twin).items()} for j in range(2)] for ai in range(len(agents))]
 
+    arenas = [ag._pose_agent._qattention_agents[0]._arena for ag in agents]
     engines = [ag._pose_agent._qattention_agents[0]._q.encoder.engine() for ag in agents]
     eng = engines[0]
     headline_mode = eng.precision          # 'bf16x3' unless VOXACTB_PRECISION overrides it
@@ -206,7 +207,15 @@ def main():
     dt_prof, _, agg = measure(headline_mode, prof_steps, a.warmup)
     dom_label = max((l for l in agg if agg[l]['flops'] > 0), key=lambda l: agg[l]['ms'])
     # (2) THE timed region: exactly K steps; only the dominant kernel and the voxelizer are event-timed inside it
+    for ar in arenas:
+        ar.timing = world > 1         # N > 1: events around the bucketed gradient exchange of the timed region (flat_params.py)
     dt, loss, agg_head = measure(headline_mode, a.steps, 1 if a.replay_stream else 0, only={dom_label, 'voxelize'}, stream=a.replay_stream)
+    exchange = None
+    if world > 1:
+        exchange = {'backend': dist.get_backend(), 'world_size_observed': dist.get_world_size(), 'rank': rank,
+                    'agents': [ar.exchange_summary() for ar in arenas]}
+        for ar in arenas:
+            ar.timing = False
     sample_ms_head = sample_s[0] / a.steps * 1e3
     # (3) the same K steps fed from the replay store (fresh batch per step, host gather + H2D inside the region) -- reported
     #     beside the headline, never as `value` (inputs resident in HBM is the contract of `value`)
@@ -343,7 +352,9 @@ def main():
                            'host-bound, it is not a throughput figure)' % prof_steps,
             'input': ('replay-stream: fresh batch per step from ShardReplayBuffer via DeviceBatchStream (H2D inside the timed region), '
                       'sample_ms_per_step %.3f' % sample_ms_head) if a.replay_stream else 'two synthetic batches resident in HBM, alternated',
-            'replay_stream': replay_stream,
+            'replay_stream': replay_stream, 'gradient_exchange': exchange,
+            'shard_note': None if world == 1 else 'rank r steps replay batches seeded 100 r + ..: %d distinct shards, no data-path collective except '
+                                                  'the per-bucket gradient all-reduce' % world,
             'roofline': roofline, 'rooflines_other': extra, 'cpu_baseline': cpu, 'precision_note': MODE_NOTE[headline_mode],
             'parity_vs_reference': probe, 'act_latency': act_lat, 'other_precisions': others,
         }

@@ -219,3 +219,32 @@ def test_two_rank_twin_agents_with_se3_in_the_default_precision(tmp_path, monkey
     for r in (r0, r1):                                                     # the failed step touched nothing, on either rank
         assert torch.equal(r['w_before_bad'], r['w_after_bad'])
         assert r['raised'] is True
+
+
+def test_bench_scaling_command_with_two_ranks_on_one_gpu():
+    """The driver's SCALE command at N = 2 -- `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 ...` -- with the
+    gloo backend (RCCL refuses two ranks per GPU) at the headline size: the launch plumbing, the barrier + max-over-ranks timing, the
+    rank-0 JSON line (n_gpus, weak scaling, whole-job value, the gradient-exchange record) cannot fail for the first time on the 8-GPU
+    node.  Both ranks' shards are distinct (seeds 100 r + ..)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VOXACTB_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--no-cpu-baseline', '--no-other-modes']
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]                    # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['steps'] == 2 and d['warmup'] == 1
+    assert np.isfinite(d['value']) and d['value'] > 0 and abs(d['value'] - 2 * 1e3 / d['ms_per_step']) < 1e-6 * d['value'] + 1e-9
+    assert d['config']['global_batch'] == 2 * 16 and d['config']['parallelism'] == 'dp2'
+    ex = d['gradient_exchange']
+    assert ex['world_size_observed'] == 2 and ex['backend'] == 'gloo'
+    ag = ex['agents'][0]
+    assert ag['steps_timed'] == 2 and len(ag['buckets_bytes']) >= 2 and sum(ag['buckets_bytes'].values()) >= 4 * d['config']['params']
+    assert ag['exposed_wait_ms_per_step'] >= 0.0 and set(ag['start_to_done_ms']) == set(ag['buckets_bytes'])
+    assert np.isfinite(d['final_loss'])

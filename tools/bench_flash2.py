@@ -198,6 +198,18 @@ if __name__ == '__main__':
         if '--quick' not in sys.argv:
             bench_bwd(w)
         sys.exit(0 if good else 1)
+    if '--one-bwd' in sys.argv:
+        f = sys.argv[sys.argv.index('--one-bwd') + 1].split(',')
+        mode, gx, p = f[0], int(f[1]), float(f[2])
+        name, H, Nq, Nk = {'self': ('self', 8, 2048, 2048), 'cross': ('cross', 1, 2048, 8077), 'decoder': ('decoder', 1, 8077, 2048)}[f[3] if len(f) > 3 else 'self']
+        B = 16
+        q = torch.randn(B * Nq, H * 64, device='cuda:0'); kv = torch.randn(B * Nk, 2 * H * 64, device='cuda:0')
+        d_o = torch.randn(B * Nq, H * 64, device='cuda:0') * 1e-3
+        pl = flash.kv_planes(kv, mode)
+        o, lse = flash.flash2_attn_fwd(q, kv, B, H, Nq, Nk, 0.125, p, 7, mode=mode, planes=pl)
+        t = timeit(lambda: flash.flash2_attn_bwd(q, kv, o, d_o, lse, pl, B, H, Nq, Nk, 0.125, p, 7, mode=mode, gx=bool(gx)))
+        print('bwd %s: %.3f ms' % (f, t))
+        sys.exit(0)
     if '--one' in sys.argv:
         one(sys.argv[sys.argv.index('--one') + 1])
         sys.exit(0)

@@ -327,6 +327,12 @@ class PerceiverEngine:
         # precision of the matrix products of the BACKWARD pass ('' = same as the forward); see DESIGN.md section 4a
         self.bwd_precision = os.environ.get('VOXACTB_BWD_PRECISION', '')
         self.attn_bwd_precision = os.environ.get('VOXACTB_ATTN_BWD_PRECISION', '')
+        # attention core: 'r3' = round 3's kernels (bf16x3 triples, or plain bf16 in the 'bf16' precision); 'f16' / 'bf16' = the pipelined
+        # kernels of round 4 (csrc/flash2_*.hip) on single fp16 / bf16 products; attn_bwd_gx: dO and dS as hi + lo pairs in their backward
+        self.attn_kernel = os.environ.get('VOXACTB_ATTN_KERNEL', 'r3')
+        if self.attn_kernel not in ('r3', 'f16', 'bf16'):
+            raise ValueError('VOXACTB_ATTN_KERNEL must be r3, f16 or bf16')
+        self.attn_bwd_gx = os.environ.get('VOXACTB_ATTN_BWD_GX', '1') != '0'
         # weight gradients of the two big 3x3x3 convs (`final`, the polyphase up-conv) when the backward runs in 'bf16x3':
         # 'fp16' (default) = one fp16 product per term, the gradient operand scaled by a power of two taken from its largest
         # magnitude on the device; 'bf16x3' = the triple.  Leaves of the backward pass: nothing downstream sees their rounding.
@@ -383,6 +389,12 @@ class PerceiverEngine:
         inner = H * d
         q = ops.linear(xq.view(B * Nq, Dq), Wq)
         kv = ops.linear(ctxn.reshape(B * Nk, ctxn.shape[2]), Wkv)
+        if self.precision in ('bf16', 'bf16x3') and d == 64 and self.fused_attention and self.attn_kernel != 'r3':
+            mode = 'bf16' if self.precision == 'bf16' else self.attn_kernel
+            O, lse, kvp = flash.flash2_attn_fwd(q, kv, B, H, Nq, Nk, d ** -0.5, p, seed, mode=mode, return_planes=True)
+            out = ops.linear(O, Wo, bo, residual=residual)
+            cache = dict(q=q, kv=kv, kvp=kvp, O=O, lse=lse, flash=2, mode=mode, dims=(B, Nq, Nk, H, d, 0), p=p, seed=seed) if save else None
+            return out, cache
         if self.precision in ('bf16', 'bf16x3') and d == 64 and self.fused_attention:
             # fused attention on the bf16 matrix cores, no [B*h, i, j] tensor (csrc/flash_attn.hip); 'bf16x3' carries
             # q, k, v, dO, P and dS as hi + lo halves
@@ -411,6 +423,10 @@ class PerceiverEngine:
         dev = dout.device
         dO = torch.empty((B * Nq, inner), dtype=torch.float32, device=dev)
         ops.linear_bwd(c['O'], Wo, dout, self.g(pre + '.fn.to_out.weight'), self.g(pre + '.fn.to_out.bias'), dO)
+        if c.get('flash') == 2:
+            dq, dkv = flash.flash2_attn_bwd(c['q'], c['kv'], c['O'], dO, c['lse'], c['kvp'], B, H, Nq, Nk, d ** -0.5, c['p'], c['seed'],
+                                            mode=c['mode'], gx=self.attn_bwd_gx)
+            return self._attn_bwd_proj(pre, dq, dkv, xq2d, ctx2d, same_src)
         if c.get('flash'):
             bp = self.attn_bwd_precision or self.bwd_precision or self.precision
             dq, dkv = flash.flash_attn_bwd_dl(c['q'], c['kv'], c['O'], dO, c['lse'], B, H, Nq, Nk, d ** -0.5, c['p'], c['seed'],

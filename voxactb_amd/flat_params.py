@@ -46,6 +46,12 @@ class FlatParams:
         self._buckets = {}
         self._pending = []
         self._done = set()
+        # exchange timing (bench.py at N > 1): per step, events on the compute stream at each bucket's start, in front of and behind
+        # the waits of finish_reduce -> how long after its start a bucket was complete at the latest, and how long the compute
+        # stream stood still for the exchange (the exposed part)
+        self.timing = False
+        self.timing_records = []
+        self._t_start = {}
 
     def zero_grad(self):
         self.flat_g.zero_()
@@ -88,6 +94,10 @@ class FlatParams:
         if self._world() > 1 or (FORCE_COLLECTIVES and self._initialised()):
             import torch.distributed as dist
             lo, hi = self._buckets[name]
+            if self.timing:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                self._t_start[name] = ev
             self._pending.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def finish_reduce(self):
@@ -97,9 +107,30 @@ class FlatParams:
                 self.reduce_bucket(name)
         if not self._buckets:
             self.all_reduce_grads()
-        for w in self._pending:
-            w.wait()
+        if self.timing and self._pending:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for w in self._pending:
+                w.wait()
+            e1.record()
+            self.timing_records.append((dict(self._t_start), e0, e1))
+            self._t_start = {}
+        else:
+            for w in self._pending:
+                w.wait()
         self._pending = []
+
+    def exchange_summary(self):
+        """(call after torch.cuda.synchronize()) -> dict for the bench JSON: bucket sizes, mean exposed wait per step and, per bucket, the
+        mean time from its start to the end of the step's waits (an upper bound of its all-reduce time)."""
+        n = len(self.timing_records)
+        out = {'buckets_bytes': {k: 4 * (hi - lo) for k, (lo, hi) in self._buckets.items()}, 'steps_timed': n}
+        if n:
+            out['exposed_wait_ms_per_step'] = sum(e0.elapsed_time(e1) for _, e0, e1 in self.timing_records) / n
+            names = list(self.timing_records[0][0])
+            out['start_to_done_ms'] = {k: sum(r[0][k].elapsed_time(r[2]) for r in self.timing_records if k in r[0]) / n for k in names}
+        self.timing_records = []
+        return out
 
     def broadcast_weights(self, src=0):
         """Rank `src`'s parameters to every rank -- what DistributedDataParallel does implicitly when it wraps the module
