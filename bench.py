@@ -447,19 +447,18 @@ def voxel_stateless(agent, batch, cfg, V, B):
     return voxel_roofline(e0.elapsed_time(e1) / n, float(nbytes), V, B, False)
 
 
-MODE_DTYPE = {
-    'fp32': 'f32 (v_mfma_f32_32x32x2_f32 everywhere)',
-    'bf16x3': 'f32 storage / accumulate; matrix products as bf16x3 split (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16); the weight '
-              'gradients (convs, big linear layers) and the d(d0) data gradient -- leaves of the backward pass -- as single fp16 products, the conv and '
-              'wide-linear data gradients that propagate as two fp16 products (gradient hi + lo, weight in 11 bits), all with device-side '
-              'power-of-two operand scales',
-    'bf16': 'bf16 matrix cores (fp32 accumulate) for convs, large linears and fused attention; everything else f32',
-    'bf16x3/bf16': 'forward as bf16x3 (Q-values inside 1e-4 of the reference), matrix products of the BACKWARD pass on plain bf16',
+MODE_DTYPE = {         # (short: the driver's record truncates long strings; the long form is `precision_note`)
+    'fp32': 'f32 (exact fp32 MFMA everywhere)',
+    'bf16x3': 'f32 storage/accumulate; fwd products bf16x3 (3 bf16 MFMA); bwd: weight grads 1x fp16, data grads 2x fp16 (scaled)',
+    'bf16': 'bf16 MFMA, f32 accumulate/storage',
+    'bf16x3/bf16': 'fwd bf16x3, bwd products plain bf16',
 }
 MODE_NOTE = {
     'fp32': 'exact fp32 matrix cores: the reference-parity mode of the first measurements (tests/test_encoder_gpu.py, 1e-4)',
-    'bf16x3': 'held to the same 1e-4 Q-value / 2e-5 per-op bounds as the exact-fp32 mode (tests/test_encoder_gpu.py::'
-              'test_encoder_fixtures_bf16x3_split_mode, test_bf16x3_gpu.py, test_flash_x3_gpu.py); 3 MFMAs per product',
+    'bf16x3': 'f32 storage / accumulate; forward products as the bf16x3 split (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16), held to the '
+              '1e-4 Q-value bound of the exact-fp32 mode (tests/test_c2_reference_gpu.py, test_encoder_gpu.py); backward: weight gradients '
+              '(leaves) as single fp16 products, propagating conv / wide-linear data gradients as two fp16 products (gradient hi + lo), all with '
+              'device-side power-of-two operand scales',
     'bf16': 'throughput mode, NOT held to the 1e-4 Q-value bound (tests/test_bf16_mode_gpu.py: ~4e-3 on q_trans)',
     'bf16x3/bf16': 'mixed mode (VOXACTB_BWD_PRECISION=bf16): the forward keeps the 1e-4 Q-value bound, parameter gradients are '
                    'within 0.5 % of the reference (norms within 4e-3) instead of 0.2 % -- not the default',

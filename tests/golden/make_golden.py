@@ -119,6 +119,10 @@ CFG_C2 = dict(V=100, k=5, s=5, depth=6, latents=2048, low_dim=4, B=1, cams=synth
 CFG_C3 = dict(V=100, k=5, s=5, depth=6, latents=2048, low_dim=7, B=2, cams=synthetic.CAMERAS4, H=128, W=128)
 # BASELINE.json configs[4] shape: 200^3 voxels, depth 6 (forward digest only: the autograd graph of the reference at this
 # size does not fit the build container's memory budget comfortably)
+# the recipe VoxAct-B releases (scripts/train_open_jar_ours_vlm_10_demos_v2_11_acting.sh:8-36): V = 50, cameras front | wrist | wrist2,
+# replay.batch_size = 1, twin-agent proprioception of 7 (8 with arm_id_to_proprio, launch_utils.py:738-743), arm loss, crop bounds
+CFG_V50 = dict(V=50, k=5, s=5, depth=6, latents=2048, low_dim=7, B=1, cams=['front', 'wrist', 'wrist2'], H=128, W=128)
+CFG_V50B = dict(CFG_V50, low_dim=8)
 CFG_C5 = dict(V=200, k=5, s=5, depth=6, latents=2048, low_dim=4, B=1, cams=synthetic.CAMERAS4, H=128, W=128)
 
 
@@ -191,7 +195,7 @@ def encoder_fixture(name, cfg, arm=False, with_grads=True, digest=False, crop=Fa
             inter = None
     arrs = dict(cfg_V=cfg['V'], cfg_k=cfg['k'], cfg_s=cfg['s'], cfg_depth=cfg['depth'], cfg_latents=cfg['latents'],
                 cfg_low_dim=cfg['low_dim'], cfg_B=cfg['B'], cfg_H=cfg['H'], cfg_W=cfg['W'], cfg_ncam=len(cfg['cams']),
-                cfg_arm=int(arm), cfg_crop=int(crop), rot_grip=outs[1], collision=outs[2])
+                cfg_cams=np.array(cfg['cams']), cfg_arm=int(arm), cfg_crop=int(crop), rot_grip=outs[1], collision=outs[2])
     if arm:
         arrs['arm_out'] = outs[3]
     qt = outs[0].detach()
@@ -236,6 +240,25 @@ def encoder_fixture(name, cfg, arm=False, with_grads=True, digest=False, crop=Fa
 
 
 # ----------------------------------------------------------------------------- F5n: the reference's own fp32-vs-fp64 noise floor
+_ORIG_CONV3D = torch.nn.functional.conv3d
+
+
+def _chunked_conv3d_f64(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+    """torch's float64 Conv3d on the CPU is the vol2col path: k^3 Cin columns per output voxel, 27.6 GB for the `final` conv at V = 100 (the
+    float32 path is oneDNN and has no such buffer) -- the build container's 64 GB did not survive it.  Same arithmetic in slabs of eight
+    output depths (the reference's module code is untouched: only the functional it calls is wrapped, for float64 inputs only)."""
+    st = (stride,) * 3 if isinstance(stride, int) else tuple(stride)
+    if input.dtype != torch.float64 or st != (1, 1, 1) or input.shape[2] < 40 or isinstance(padding, str):
+        return _ORIG_CONV3D(input, weight, bias, stride, padding, dilation, groups)
+    pd = (padding,) * 3 if isinstance(padding, int) else tuple(padding)
+    k = weight.shape[2]
+    if pd[0]:
+        input = torch.nn.functional.pad(input, (0, 0, 0, 0, pd[0], pd[0]))
+    d_out = input.shape[2] - k + 1
+    return torch.cat([_ORIG_CONV3D(input[:, :, z0:min(d_out, z0 + 8) + k - 1], weight, bias, 1, (0, pd[1], pd[2]), dilation, groups)
+                      for z0 in range(0, d_out, 8)], 2)
+
+
 def grad_noise_fixture(name, cfg, seed, arm=False, crop=False, nproj=16):
     """The reference encoder run TWICE on one batch: in fp32 (what F5g / F5c3 hold) and in float64 (the truth both the reference's fp32
     arithmetic and the product approximate).  Stored per parameter tensor: ||g64||, ||g32 - g64|| (the reference's own rounding noise,
@@ -254,6 +277,7 @@ def grad_noise_fixture(name, cfg, seed, arm=False, crop=False, nproj=16):
     res = {}
     for dt in (torch.float32, torch.float64):
         t0 = time.time()
+        torch.nn.functional.conv3d = _chunked_conv3d_f64 if dt == torch.float64 else _ORIG_CONV3D
         enc = enc.to(dt)
         for p in enc.parameters():
             p.requires_grad_(True)
@@ -264,12 +288,13 @@ def grad_noise_fixture(name, cfg, seed, arm=False, crop=False, nproj=16):
         total.backward()
         res[dt] = dict(outs=[o.detach().double() for o in outs[:4 if arm else 3]], loss=total.detach().double(),
                        grads={n: p.grad.detach().double().clone() for n, p in enc.named_parameters()})
-        print('%s: reference %s forward + backward %.0fs' % (name, dt, time.time() - t0))
+        print('%s: reference %s forward + backward %.0fs' % (name, dt, time.time() - t0), flush=True)
         del outs, total
+    torch.nn.functional.conv3d = _ORIG_CONV3D
     r32, r64 = res[torch.float32], res[torch.float64]
     arrs = dict(cfg_V=cfg['V'], cfg_k=cfg['k'], cfg_s=cfg['s'], cfg_depth=cfg['depth'], cfg_latents=cfg['latents'],
                 cfg_low_dim=cfg['low_dim'], cfg_B=cfg['B'], cfg_H=cfg['H'], cfg_W=cfg['W'], cfg_ncam=len(cfg['cams']),
-                cfg_arm=int(arm), cfg_crop=int(crop), cfg_seed=seed, nproj=nproj)
+                cfg_cams=np.array(cfg['cams']), cfg_arm=int(arm), cfg_crop=int(crop), cfg_seed=seed, nproj=nproj)
     flat64, flat32 = r64['outs'][0].reshape(cfg['B'], -1), r32['outs'][0].reshape(cfg['B'], -1)
     sidx = ow.hashed_int('digest', (4096,), 0, flat64.shape[1])
     top = flat64.topk(16, dim=1)
@@ -1028,6 +1053,8 @@ SECTIONS = {
     'f5g': lambda: encoder_fixture('f5g_encoder_c2_grads', CFG_C2, with_grads=True, digest=True, f64_grads=True),
     'f5c3': lambda: encoder_fixture('f5c3_encoder_c3_digest', CFG_C3, arm=True, with_grads=True, digest=True, crop=True, f64_grads=True),
     'f5v200': lambda: encoder_fixture('f5v200_encoder_c5_digest', CFG_C5, with_grads=False, digest=True),
+    'f5v50a': lambda: encoder_fixture('f5v50a_encoder_release_digest', CFG_V50, arm=True, with_grads=True, digest=True, crop=True, f64_grads=True),
+    'f5v50b': lambda: encoder_fixture('f5v50b_encoder_release_digest', CFG_V50B, arm=True, with_grads=True, digest=True, crop=True, f64_grads=True),
     # the same grid with the reference's loss and backward.  NOT part of the committed fixtures: on the 8-core build container the
     # reference's CPU backward at 200^3 did not finish in 75 minutes (33 GB resident, all cores busy inside one ATen op), so the
     # configs[4] backward is covered by tests/test_fullsize_gpu.py::test_v200_* (two kernel families against each other) instead

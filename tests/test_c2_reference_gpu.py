@@ -28,14 +28,15 @@ def T(a):
 def _setup(g):
     arm, crop = bool(g['cfg_arm']), bool(g['cfg_crop']) if 'cfg_crop' in g.files else False
     V, B, H, W = int(g['cfg_V']), int(g['cfg_B']), int(g['cfg_H']), int(g['cfg_W'])
-    cams = synthetic.CAMERAS4[:int(g['cfg_ncam'])]
+    cams = [str(c) for c in g['cfg_cams']] if 'cfg_cams' in g.files else synthetic.CAMERAS4[:int(g['cfg_ncam'])]
+    seed = int(g['cfg_seed']) if 'cfg_seed' in g.files else 1
     enc = PerceiverVoxelLangEncoder(
         depth=int(g['cfg_depth']), iterations=1, voxel_size=V, initial_dim=10, low_dim_size=int(g['cfg_low_dim']),
         num_latents=int(g['cfg_latents']), voxel_patch_size=int(g['cfg_k']), voxel_patch_stride=int(g['cfg_s']),
         activation='lrelu', input_dropout=0.0, attn_dropout=0.0, decoder_dropout=0.0, arm_pred_loss=arm)
     enc.load_state_dict(ow.hashed_state_dict({n: tuple(p.shape) for n, p in enc.named_parameters()}, 0), strict=False)
     enc = enc.to(DEV)
-    rs = synthetic.make_replay_sample(B, cams, (H, W), V, int(g['cfg_low_dim']), seed=1, arm_pred_loss=arm,
+    rs = synthetic.make_replay_sample(B, cams, (H, W), V, int(g['cfg_low_dim']), seed=seed, arm_pred_loss=arm,
                                       crop_target_obj_voxel=crop)
     rs = {k: (v[:, 0] if v.dim() > 2 else v) for k, v in rs.items()}
     rs = {k: ((v.float() / 255.0) * 2.0 - 1.0 if 'rgb' in k else v.float()) for k, v in rs.items()}

@@ -272,6 +272,14 @@ class QAttentionPerActBCAgent(Agent):
             self._se3_status = None
             self._optimizer.skip_flag = None
             if int(st.item()) < 0:
+                # that step was a no-op on the device: take the host-side step counters back too (bias correction and the reference's
+                # `state[p]['step']` must match the moments), and drop the delayed fp16 operand scales its all-NaN gradients reported
+                opt = self._optimizer
+                opt.steps = max(0, opt.steps - 1)
+                for p_ in opt.state:
+                    if 'step' in opt.state[p_]:
+                        opt.state[p_]['step'] = opt.steps
+                self._q.encoder.engine()._grad_scales.clear()
                 raise Exception('Failing to perturb action and keep it within bounds.')
 
     def _gate_step(self):
@@ -494,6 +502,7 @@ class QAttentionPerActBCAgent(Agent):
             elif '_voxelizer' not in k:
                 logging.warning("key %s not found in checkpoint" % k)
         self._q.load_state_dict(merged)
+        self._q.encoder.engine()._grad_scales.clear()   # delayed fp16 operand scales belong to the weights that were just replaced
         if self._training:
             self._arena.broadcast_weights(0)            # every rank resumes from rank 0's file contents
 

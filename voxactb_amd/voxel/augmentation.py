@@ -27,6 +27,7 @@ MAX_ATTEMPTS_2ROBOTS = 400        # augmentation.py:239
 
 
 _GEN = None          # dedicated CPU generator of the augmentation draws (seeded from torch's global seed at first use)
+_GEN_SEED = None
 _PINNED = {}         # (attempts, bs) -> ring of pinned staging buffers for the draws
 
 
@@ -34,11 +35,22 @@ def _generator():
     """Augmentation draws come from their OWN generator, seeded once from the global seed (so `torch.manual_seed(s)` before the
     first update() still governs them), instead of from the global CPU generator: unrelated `torch.rand` calls of the host
     program no longer shift the augmentation stream, and the dropout seed (drawn from the global generator) is independent."""
-    global _GEN
-    if _GEN is None:
+    global _GEN, _GEN_SEED
+    if _GEN is None or _GEN_SEED != torch.initial_seed():
+        # (re-derived whenever the global seed changes: a `torch.manual_seed(s)` on resume or per epoch governs the augmentation stream
+        # again, as it does the reference's draws from the global generator, utils.rand_dist / rand_discrete)
+        _GEN_SEED = torch.initial_seed()
         _GEN = torch.Generator()
-        _GEN.manual_seed((torch.initial_seed() ^ 0x5E3A06) & 0x7FFFFFFFFFFFFFFF)
+        _GEN.manual_seed((_GEN_SEED ^ 0x5E3A06) & 0x7FFFFFFFFFFFFFFF)
     return _GEN
+
+
+def seed_augmentation(seed: int):
+    """Explicit seed of the augmentation stream (independent of torch's global generator until the next torch.manual_seed)."""
+    global _GEN, _GEN_SEED
+    _GEN_SEED = torch.initial_seed()
+    _GEN = torch.Generator()
+    _GEN.manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
 
 
 def _draws(bs, rot_aug_range, rot_aug_resolution, attempts, device=None):
@@ -70,6 +82,8 @@ def _draws(bs, rot_aug_range, rot_aug_resolution, attempts, device=None):
         n = int(rot_aug_range[axis] // rot_aug_resolution)
         if n > 0:
             buf[1][:, :, axis].random_(-n, n + 1, generator=gen)
+        else:
+            buf[1][:, :, axis].zero_()       # (the ring is keyed by (attempts, bs) only: another agent's rpy range may have filled this axis)
     unit, steps = buf[0].to(device, non_blocking=True), buf[1].to(device, non_blocking=True)
     buf[2] = torch.cuda.Event()
     buf[2].record(torch.cuda.current_stream(device))
