@@ -1,0 +1,101 @@
+"""Gradient gates against the FLOAT64 reference (fixtures f5n_noise_*: tests/golden/make_golden.py, section F5n).
+
+The reference encoder was run in fp32 AND in float64 on three seeded batches per headline shape (configs[1] geometry, B = 1; the
+configs[2] twin-agent shape, B = 2).  The fixture holds, per parameter tensor, ||g64||, ||g32 - g64|| (the reference's own rounding
+noise) and 16 random +-1 projections of g64, from which this test estimates ||g - g64|| of the product's gradient (E[(s.(a - b))^2] =
+||a - b||^2; 16 projections: +-18 %) without the 133 MB tensor.
+
+Gate, stated once:   ||g - g64|| <= max(REL * ||g64||, K * ||g32 - g64||) + ABS      with REL = 3e-3, K = 3, ABS = 1e-7 * max ||g64||
+i.e. every parameter gradient within 0.3 % (relative L2) of the float64 truth, or within three times the reference's own fp32 error
+where that is larger (conv bias gradients: fp32 sums over 10^6 voxels, 0.6 - 1.3 %).  Q-values: within 1e-4 of the float64 forward
+(BASELINE.json north_star).  Every precision the engine ships is held to the same gate on every seed."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import weights as ow
+from tests.test_c2_reference_gpu import DEV, T, _setup
+from voxactb_amd import ops
+
+pytestmark = pytest.mark.gpu
+REL, K_NOISE = 3e-3, 3.0
+FIXTURES = ['f5n_noise_c2_s1', 'f5n_noise_c2_s2', 'f5n_noise_c2_s3', 'f5n_noise_c3_s1', 'f5n_noise_c3_s2', 'f5n_noise_c3_s3']
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _grads(g, precision, attn_kernel, attn_gx):
+    enc, rs, grid, arm, V, B = _setup(g)
+    eng = enc.engine()
+    eng.precision = precision
+    eng.attn_kernel, _, eng.attn_bwd_kernel = attn_kernel.partition('/')
+    eng.attn_bwd_gx = attn_gx
+    outs, cache = eng.forward(grid, rs['low_dim_state'].to(DEV), rs['lang_token_embs'].to(DEV), training=False, save=True)
+    at = rs['trans_action_indicies'].long()
+    lab = ((at[:, 0] * V + at[:, 1]) * V + at[:, 2]).int().to(DEV)
+    dq = torch.empty((B, V ** 3), device=DEV)
+    l_t, _, _ = ops.ce_big(outs[0].view(B, -1), lab, dq, 1.0 / B)
+    labs = torch.cat([rs['rot_grip_action_indicies'].int(), rs['ignore_collisions'].int()[:, :1]], 1).to(DEV).contiguous()
+    d_o = torch.empty_like(cache['o'])
+    l_h, _ = ops.ce_rows(cache['o'], [(0, 72), (72, 72), (144, 72), (216, 2), (218, 2)], labs, d_o, 1.0 / B)
+    total = l_t + l_h.sum(1)
+    d_arm = None
+    if arm:
+        d_arm = torch.empty_like(outs[3])
+        la, _ = ops.ce_rows(outs[3], [(0, 2)], rs['label'].int()[:, :1].to(DEV).contiguous(), d_arm, 1.0 / B)
+        total = total + la[:, 0]
+    loss = float(total.mean())
+    for p in enc.parameters():
+        p.grad = None
+    eng.backward(cache, dq, d_o, d_arm)
+    return enc, outs, loss, arm
+
+
+def _measure(g, precision, attn_kernel, attn_gx, tag):
+    enc, outs, loss, arm = _grads(g, precision, attn_kernel, attn_gx)
+    B = outs[0].shape[0]
+    flat = outs[0].reshape(B, -1).double().cpu()
+    sidx = T(g['q_trans_sample_idx']).long()
+    eq = max(float((flat[:, sidx] - T(g['q_trans_sample'])).abs().max()),
+             float((torch.gather(flat, 1, T(g['q_trans_top_idx']).long()) - T(g['q_trans_top_vals'])).abs().max()),
+             float((outs[1].double().cpu() - T(g['rot_grip'])).abs().max()), float((outs[2].double().cpu() - T(g['collision'])).abs().max()))
+    if arm:
+        eq = max(eq, float((outs[3].double().cpu() - T(g['arm_out'])).abs().max()))
+    names = [str(n) for n in g['grad_names']]
+    n64, e32, p64 = T(g['grad_norm64']), T(g['grad_err32']), T(g['grad_proj64'])
+    nproj = int(g['nproj'])
+    P = dict(enc.named_parameters())
+    rows = []
+    absfloor = 1e-7 * float(n64.max())
+    for i, n in enumerate(names):
+        est = float(ow.projection_error(ow.project(P[n].grad, n, nproj), p64[i]))
+        lim = max(REL * float(n64[i]), K_NOISE * float(e32[i])) + absfloor
+        rows.append((est / lim, n, est, float(n64[i]), float(e32[i])))
+    rows.sort(reverse=True)
+    print('%s: loss %.6f (f64 %.6f, reference fp32 %.6f) | max |Q - Q64| %.2e (reference fp32: %.2e)' % (
+        tag, loss, float(g['loss']), float(g['loss32']), eq, float(T(g['q_spread32']).max())))
+    for r in rows[:6]:
+        print('   %-46s ||g-g64||/||g64|| %.2e   reference fp32 %.2e   (x gate %.2f)' % (r[1], r[2] / (r[3] + 1e-300), r[4] / (r[3] + 1e-300), r[0]))
+    med = float(np.median([r[2] / (r[3] + 1e-300) for r in rows if r[3] > 1e-6]))
+    print('   median relative L2 error over the tensors %.2e' % med)
+    return eq, rows, loss
+
+
+def _available():
+    return [f for f in FIXTURES if os.path.exists(os.path.join(GOLDEN, f + '.npz'))]
+
+
+@pytest.mark.parametrize('fixture', FIXTURES)
+@pytest.mark.parametrize('mode', ['fp32', 'bf16x3+r3', 'bf16x3+r3/f16', 'bf16x3+r3/f16-gx0', 'bf16x3+f16'])
+def test_gradients_against_the_float64_reference(golden, fixture, mode):
+    if fixture not in _available():
+        pytest.skip('fixture not generated')
+    g = golden(fixture)
+    precision, _, attn = mode.partition('+')
+    gx = not attn.endswith('-gx0')
+    eq, rows, loss = _measure(g, precision, attn.replace('-gx0', '') or 'r3', gx, '%s/%s' % (fixture[10:], mode))
+    assert eq < 1e-4
+    assert abs(loss - float(g['loss'])) < 1e-4
+    bad = [(r[1], 'x gate %.2f' % r[0], '%.2e' % (r[2] / (r[3] + 1e-300))) for r in rows if r[0] > 1.0]
+    assert not bad, bad

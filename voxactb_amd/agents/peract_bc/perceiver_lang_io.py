@@ -333,6 +333,9 @@ class PerceiverEngine:
         if self.attn_kernel not in ('r3', 'f16', 'bf16'):
             raise ValueError('VOXACTB_ATTN_KERNEL must be r3, f16 or bf16')
         self.attn_bwd_gx = os.environ.get('VOXACTB_ATTN_BWD_GX', '1') != '0'
+        # backward of the attention core when the forward ran round 3's kernels: '' = round 3's backward too, 'f16' / 'bf16' = the
+        # pipelined backward (it only needs q, k | v, O, lse and the dropout seed of the forward)
+        self.attn_bwd_kernel = os.environ.get('VOXACTB_ATTN_BWD_KERNEL', 'f16')
         # weight gradients of the two big 3x3x3 convs (`final`, the polyphase up-conv) when the backward runs in 'bf16x3':
         # 'fp16' (default) = one fp16 product per term, the gradient operand scaled by a power of two taken from its largest
         # magnitude on the device; 'bf16x3' = the triple.  Leaves of the backward pass: nothing downstream sees their rounding.
@@ -426,6 +429,12 @@ class PerceiverEngine:
         if c.get('flash') == 2:
             dq, dkv = flash.flash2_attn_bwd(c['q'], c['kv'], c['O'], dO, c['lse'], c['kvp'], B, H, Nq, Nk, d ** -0.5, c['p'], c['seed'],
                                             mode=c['mode'], gx=self.attn_bwd_gx)
+            return self._attn_bwd_proj(pre, dq, dkv, xq2d, ctx2d, same_src)
+        if c.get('flash') and self.attn_bwd_kernel in ('f16', 'bf16') and (self.bwd_precision or self.precision) != 'fp32':
+            mode = 'bf16' if self.precision == 'bf16' else self.attn_bwd_kernel
+            planes = flash.kv_planes(c['kv'], mode)
+            dq, dkv = flash.flash2_attn_bwd(c['q'], c['kv'], c['O'], dO, c['lse'], planes, B, H, Nq, Nk, d ** -0.5, c['p'], c['seed'],
+                                            mode=mode, gx=self.attn_bwd_gx)
             return self._attn_bwd_proj(pre, dq, dkv, xq2d, ctx2d, same_src)
         if c.get('flash'):
             bp = self.attn_bwd_precision or self.bwd_precision or self.precision
