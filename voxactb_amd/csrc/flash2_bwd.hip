@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(NW * 64, 2) f2b_dq_kernel(F2bArgs g) {
 // dV += P^T dO', dK += dS^T Q of unit u - 1 (B = dO' / Q by transposed reads of the same tiles).  Region j = steps 2j + 1, 2j + 2
 // (tiles j, j + 1); rings of three stages, tile j + 2 is requested at the top of region j.
 template <int MODE, int GX, int DROP, int NW>
-__global__ void __launch_bounds__(NW * 64, 1) f2b_dkv_kernel(F2bArgs g) {
+__global__ void __launch_bounds__(NW * 64, GX ? 1 : 2) f2b_dkv_kernel(F2bArgs g) {
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     constexpr int NG = 1 + GX;
     constexpr int NS = 3;
@@ -514,7 +514,7 @@ __global__ void __launch_bounds__(NW * 64, 1) f2b_dkv_kernel(F2bArgs g) {
         return fb_join(fb_tr16(ad + tlane[i & 1][0]), fb_tr16(ad + tlane[i & 1][1] + 8 * 64));
     };
     // element pair t of unit (qt, qb): rows ql, ql + 1 of this lane's key
-    auto pair = [&](int qt, int qb, int t, const f32x16& s, const f32x16& tt, const float (&nd)[16], unsigned (&pp)[8], unsigned (&ds)[NG][8]) {
+    auto pair = [&](int qt, int qb, int t, const f32x16& s, const f32x16& tt, const float* nd_tile, unsigned (&pp)[8], unsigned (&ds)[NG][8]) {
         const int r = 2 * t;
         const float p0 = __builtin_amdgcn_exp2f(s[r]), p1 = __builtin_amdgcn_exp2f(s[r + 1]);
         float t0 = tt[r], t1 = tt[r + 1], pd0 = p0, pd1 = p1;
@@ -526,7 +526,8 @@ __global__ void __launch_bounds__(NW * 64, 1) f2b_dkv_kernel(F2bArgs g) {
             const unsigned ho = (unsigned)__builtin_amdgcn_mov_dpp((int)hm, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
             const unsigned h0 = kodd ? ho : hm, h1 = kodd ? hm : ho;
             const bool k0 = (h0 << hshift) >= thr16, k1 = (h1 << hshift) >= thr16;
-            t0 = k0 ? t0 : nd[r]; t1 = k1 ? t1 : nd[r + 1];
+            const float2 nd = *reinterpret_cast<const float2*>(nd_tile + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);      // -D' of rows ql, ql + 1
+            t0 = k0 ? t0 : nd.x; t1 = k1 ? t1 : nd.y;
             pd0 = k0 ? p0 : 0.f; pd1 = k1 ? p1 : 0.f;
         }
         pp[t] = fb_pack<MODE>(pd0, pd1);
@@ -558,14 +559,7 @@ __global__ void __launch_bounds__(NW * 64, 1) f2b_dkv_kernel(F2bArgs g) {
         };
 #pragma unroll
         for (int i = 0; i < PF; ++i) load_group(i);
-        float nd[16];
-        if (HC && DROP) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(smem + NOFF + stc * 128) + qbc * 32 + 8 * m + 4 * hi);
-                nd[4 * m] = v.x; nd[4 * m + 1] = v.y; nd[4 * m + 2] = v.z; nd[4 * m + 3] = v.w;
-            }
-        }
+        const float* nd = reinterpret_cast<const float*>(smem + NOFF + stc * 128);
         if (HN) {
             const uint4 w = *reinterpret_cast<const uint4*>(hi ? smem + ZOFF : smem + ROFF + stn * 512 + (qbn * 32 + lk) * 8);
             f32x16 z;
@@ -600,9 +594,87 @@ __global__ void __launch_bounds__(NW * 64, 1) f2b_dkv_kernel(F2bArgs g) {
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    // LEAN step (GX = 0, two waves per SIMD): S'T'(next unit) | P, dS of the current unit | dV, dK of the CURRENT unit as soon as its
+    // words exist (key-step 0 after the first four pairs, key-step 1 behind the loop): no second P / dS buffer, fragments one group ahead
+    auto step_lean = [&](auto has_n, auto has_c, int qtn, int qbn, int qtc, int qbc, f32x16& sn, f32x16& tn, const f32x16& sc_,
+                         const f32x16& tc_, unsigned (&pp)[8], unsigned (&ds)[NG][8]) {
+        constexpr bool HN = decltype(has_n)::value, HC = decltype(has_c)::value;
+        const int stn = qtn % NS, stc = qtc % NS;
+        const float* nd = reinterpret_cast<const float*>(smem + NOFF + stc * 128);
+        bf16x8 qa[4], da[NG][4], tq[4], td[NG][4];
+        auto load_n = [&](int i) {
+            if (HN) {
+                qa[i] = row_frag(QOFF + stn * TILE, qbn, i);
+#pragma unroll
+                for (int p = 0; p < NG; ++p) da[p][i] = row_frag(DOFF + (stn * NG + p) * TILE, qbn, i);
+            }
+        };
+        auto load_d = [&](int i) {
+            if (HC) {
+                tq[i] = tr_frag(QOFF + stc * TILE, qbc, i);
+#pragma unroll
+                for (int p = 0; p < NG; ++p) td[p][i] = tr_frag(DOFF + (stc * NG + p) * TILE, qbc, i);
+            }
+        };
+        auto dvdk = [&](int i) {
+            if (!HC) return;
+            const int ks = i >> 1, db = i & 1;
+            const bf16x8 pf = fb_from4(pp[4 * ks], pp[4 * ks + 1], pp[4 * ks + 2], pp[4 * ks + 3]);
+#pragma unroll
+            for (int p = 0; p < NG; ++p) {
+                dvacc[db] = fb_mma<MODE>(pf, td[p][i], dvacc[db]);
+                dkacc[db] = fb_mma<MODE>(fb_from4(ds[p][4 * ks], ds[p][4 * ks + 1], ds[p][4 * ks + 2], ds[p][4 * ks + 3]), tq[i], dkacc[db]);
+            }
+        };
+        load_n(0);
+        if (HN) {
+            const uint4 w = *reinterpret_cast<const uint4*>(hi ? smem + ZOFF : smem + ROFF + stn * 512 + (qbn * 32 + lk) * 8);
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            sn = fb_mma<MODE>(fb_from4(w.x, w.y, 0u, 0u), ones, z);
+            tn = fb_mma<MODE>(fb_from4(w.z, w.w, 0u, 0u), ones, z);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i + 1 < 4) load_n(i + 1);
+            if (i == 1) { load_d(0); load_d(1); }
+            if (i == 3) { load_d(2); load_d(3); }
+            if (HC) pair(qtc, qbc, 2 * i, sc_, tc_, nd, pp, ds);
+            __builtin_amdgcn_sched_barrier(0);
+            if (HN) {
+                sn = fb_mma<MODE>(qa[i], kf[i], sn);
+#pragma unroll
+                for (int p = 0; p < NG; ++p) tn = fb_mma<MODE>(da[p][i], vf[i], tn);
+            }
+            if (i == 2) { dvdk(0); }
+            if (i == 3) { dvdk(1); }
+            if (HC) pair(qtc, qbc, 2 * i + 1, sc_, tc_, nd, pp, ds);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        dvdk(2); dvdk(3);
+        __builtin_amdgcn_sched_barrier(0);
+    };
     const std::true_type T_;
     const std::false_type F_;
 
+    if constexpr (!GX) {
+        issue(0); issue(1);
+        fb_wait_vm<0>();
+        __syncthreads();
+        f32x16 s_[2], t_[2];
+        unsigned pp1[8], ds1[NG][8];
+        step_lean(T_, F_, 0, 0, 0, 0, s_[0], t_[0], s_[0], t_[0], pp1, ds1);
+        for (int j = 0; j < nqt; ++j) {
+            // region j = units (j, 0), (j, 1): tiles j (current) and j + 1 (the next unit's scores)
+            step_lean(T_, T_, j, 1, j, 0, s_[1], t_[1], s_[0], t_[0], pp1, ds1);
+            fb_wait_vm<0>();                                // tile j + 1 (requested one region ago) landed
+            vxb_raw_barrier();
+            if (j + 2 < nqt + 1) issue(j + 2);              // stage (j + 2) % 3 held tile j - 1
+            step_lean(T_, T_, j + 1, 0, j, 1, s_[0], t_[0], s_[1], t_[1], pp1, ds1);
+        }
+        fb_wait_vm<0>();
+    } else {
     issue(0); issue(1);
     fb_wait_vm<0>();
     __syncthreads();
@@ -618,6 +690,7 @@ __global__ void __launch_bounds__(NW * 64, 1) f2b_dkv_kernel(F2bArgs g) {
         step(T_, T_, T_, j + 1, 1, j + 1, 0, j, 1, s_[1], t_[1], s_[0], t_[0], ppb[0], dsb[0], ppb[1], dsb[1]);
     }
     fb_wait_vm<0>();
+    }
     // accumulators: C[i = key (rows, regs)][j = d (lane)]
     const int kw0 = kblk * (NW * 32) + wid * 32;
     const float fk = g.scale * g.scale_ws[1], fv = g.scale_ws[1];
