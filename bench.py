@@ -44,6 +44,10 @@ def main():
     ap.add_argument('--image', type=int, default=128)
     ap.add_argument('--depth', type=int, default=6)
     ap.add_argument('--latents', type=int, default=2048)
+    ap.add_argument('--cams', type=int, default=4, choices=(3, 4), help='3 = front | wrist | wrist2: the cameras of the released VoxAct-B recipe '
+                    '(scripts/train_open_jar_ours_vlm_10_demos_v2_11_acting.sh:12; with --voxel-size 50 --batch 1 --release-recipe)')
+    ap.add_argument('--release-recipe', action='store_true', help='the single released agent: which_arm dominant, 7-dim proprioception, arm loss, '
+                    'crop bounds, aug_rpy [0, 0, 45] (same script, lines 18-27)')
     ap.add_argument('--agents', type=int, default=1, choices=(1, 2),
                     help='2 = the acting + stabilizing twin agents of BASELINE.json configs[2] / [3]')
     ap.add_argument('--aug-copies', type=int, default=1,
@@ -84,14 +88,19 @@ def main():
     over = dict(method__voxel_sizes=[V], method__voxel_patch_size=5, method__voxel_patch_stride=patch,
                 method__transformer_depth=a.depth, method__num_latents=a.latents, replay__batch_size=B,
                 rlbench__camera_resolution=[HW, HW], ddp__num_devices=world)
+    if a.cams == 3:
+        over['rlbench__cameras'] = ['front', 'wrist', 'wrist2']
+    twin = twin or a.release_recipe          # (the released agent is one of the twins)
     # twin agents: `which_arm` dominant (acting) / assistive (stabilizing), 7-dim proprioception, arm-prediction head,
     # grid cropped around the target object (scripts/train_open_jar_ours_vlm_10_demos_v2_11_{acting,stabilizing}.sh:22-24)
-    arms = ['dominant', 'assistive'] if twin else ['right']
+    arms = ['dominant'] if a.release_recipe else ['dominant', 'assistive'] if twin else ['right']
     agents, cfgs = [], []
     torch.manual_seed(1234)           # (the agent broadcasts rank 0's weights at build(), as DDP does upstream)
     for arm in arms:
         cfg = lu.default_cfg(**over) if not twin else lu.default_cfg(
             method__which_arm=arm, method__arm_pred_loss=True, method__crop_target_obj_voxel=True, **over)
+        if a.release_recipe:
+            cfg.method.transform_augmentation.aug_rpy = [0.0, 0.0, 45.0]
         ag = lu.create_agent(cfg)
         ag.build(training=True, device=dev_index)
         agents.append(ag)
@@ -334,7 +343,9 @@ def main():
             'metric': 'voxel-policy train steps/sec (100^3 grid, 4 cams, B=16)', 'value': value, 'unit': 'steps/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': MODE_DTYPE[headline_mode], 'data': 'synthetic',
-            'config': {'workload': ('BASELINE.json configs[2] / [3] (twin acting + stabilizing agents, low_dim 7, arm loss, crop bounds; '
+            'config': {'workload': ('released VoxAct-B recipe (train_open_jar_ours_vlm_10_demos_v2_11_acting.sh: one dominant-arm agent, V=50, '
+                                    'front | wrist | wrist2, replay batch 1, low_dim 7, arm loss, crop bounds, aug_rpy [0, 0, 45]); ' if a.release_recipe else
+                                    'BASELINE.json configs[2] / [3] (twin acting + stabilizing agents, low_dim 7, arm loss, crop bounds; '
                                     'one step = %d agents x %d SE(3)-perturbed copies = %d update() calls of B=%d; ' % (
                                         len(agents), a.aug_copies, updates_per_step, B) if twin else '') +
                                    ('BASELINE.json configs[1]' if (V, B, HW) == (100, 16, 128) else

@@ -172,6 +172,15 @@ def test_c5_v200_forward_digest(golden, precision):
     _run(golden('f5v200_encoder_c5_digest'), precision, 'f5v200', backward=False)
 
 
+@pytest.mark.parametrize('fixture', ['f5v50a_encoder_release_digest', 'f5v50b_encoder_release_digest'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_released_recipe_geometry_digest(golden, fixture, precision):
+    """The recipe VoxAct-B releases (peract/scripts/train_open_jar_ours_vlm_10_demos_v2_11_acting.sh:8-36, launch_utils.py:738-743): V = 50
+    (6 x 8 + 2: the part-tile paths of every halo kernel), cameras front | wrist | wrist2, replay batch 1 (M = 2048 rows: the 128^2
+    linear kernels), proprioception 7 and 8, arm loss, crop bounds -- forward + backward against the reference's digest."""
+    _run(golden(fixture), precision, fixture[:6], backward=True)
+
+
 @pytest.mark.parametrize('fixture', ['f5g_encoder_c2_grads', 'f5c3_encoder_c3_digest'])
 @pytest.mark.parametrize('fwd,bwd,wgrad', [('fp32', 'bf16x3', 'bf16x3'), ('fp32', 'bf16x3', 'fp16'), ('bf16x3', '', 'bf16x3')])
 def test_forward_and_backward_precisions_separately(golden, fixture, fwd, bwd, wgrad):

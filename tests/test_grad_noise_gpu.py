@@ -8,7 +8,12 @@ noise) and 16 random +-1 projections of g64, from which this test estimates ||g 
 Gate, stated once:   ||g - g64|| <= max(REL * ||g64||, K * ||g32 - g64||) + ABS      with REL = 3e-3, K = 3, ABS = 1e-7 * max ||g64||
 i.e. every parameter gradient within 0.3 % (relative L2) of the float64 truth, or within three times the reference's own fp32 error
 where that is larger (conv bias gradients: fp32 sums over 10^6 voxels, 0.6 - 1.3 %).  Q-values: within 1e-4 of the float64 forward
-(BASELINE.json north_star).  Every precision the engine ships is held to the same gate on every seed."""
+(BASELINE.json north_star).  Every precision the engine ships is held to the same gate on every seed.
+
+The loss is only piecewise smooth (three global max pools over up to 10^6 voxels per channel: a pair of voxels closer than the arithmetic's
+rounding hands the pooled feature's whole gradient to the other voxel -- observed in 2 of 6 fixtures for perturbations of 1e-5, in either
+direction).  The fixtures therefore carry the float64 run's arg-max voxels and the backward is evaluated AT THOSE choices; the number of
+the product's own choices that differ is printed beside the reference-fp32-vs-float64 count."""
 import os
 
 import numpy as np
@@ -21,11 +26,12 @@ from voxactb_amd import ops
 
 pytestmark = pytest.mark.gpu
 REL, K_NOISE = 3e-3, 3.0
-FIXTURES = ['f5n_noise_c2_s1', 'f5n_noise_c2_s2', 'f5n_noise_c2_s3', 'f5n_noise_c3_s1', 'f5n_noise_c3_s2', 'f5n_noise_c3_s3']
+FIXTURES = ['f5n_noise_c2_s1', 'f5n_noise_c2_s2', 'f5n_noise_c2_s3', 'f5n_noise_c3_s1', 'f5n_noise_c3_s2', 'f5n_noise_c3_s3',
+            'f5n_noise_v50a_s1', 'f5n_noise_v50b_s1']
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
-def _grads(g, precision, attn_kernel, attn_gx):
+def _grads(g, precision, attn_kernel, attn_gx, force_pools=True):
     enc, rs, grid, arm, V, B = _setup(g)
     eng = enc.engine()
     eng.precision = precision
@@ -48,12 +54,21 @@ def _grads(g, precision, attn_kernel, attn_gx):
     loss = float(total.mean())
     for p in enc.parameters():
         p.grad = None
+    flips = None
+    if force_pools and 'pool_argmax64_0' in g.files:
+        # the backward at the float64 run's max-pool choices (the loss is piecewise smooth: see make_golden.py, grad_noise_fixture)
+        flips = []
+        for i, key in enumerate(('ss0', 'ss1', 'ss2')):
+            ss, mx, st, am = cache[key]
+            ref = T(g['pool_argmax64_%d' % i]).to(DEV).int().reshape(am.shape).contiguous()
+            flips.append(int((am != ref).sum()))
+            cache[key] = (ss, mx, st, ref)
     eng.backward(cache, dq, d_o, d_arm)
-    return enc, outs, loss, arm
+    return enc, outs, loss, arm, flips
 
 
 def _measure(g, precision, attn_kernel, attn_gx, tag):
-    enc, outs, loss, arm = _grads(g, precision, attn_kernel, attn_gx)
+    enc, outs, loss, arm, flips = _grads(g, precision, attn_kernel, attn_gx)
     B = outs[0].shape[0]
     flat = outs[0].reshape(B, -1).double().cpu()
     sidx = T(g['q_trans_sample_idx']).long()
@@ -73,8 +88,9 @@ def _measure(g, precision, attn_kernel, attn_gx, tag):
         lim = max(REL * float(n64[i]), K_NOISE * float(e32[i])) + absfloor
         rows.append((est / lim, n, est, float(n64[i]), float(e32[i])))
     rows.sort(reverse=True)
-    print('%s: loss %.6f (f64 %.6f, reference fp32 %.6f) | max |Q - Q64| %.2e (reference fp32: %.2e)' % (
-        tag, loss, float(g['loss']), float(g['loss32']), eq, float(T(g['q_spread32']).max())))
+    print('%s: loss %.6f (f64 %.6f, reference fp32 %.6f) | max |Q - Q64| %.2e (reference fp32: %.2e) | max-pool choices differing from float64: %s '
+          '(reference fp32: %s)' % (tag, loss, float(g['loss']), float(g['loss32']), eq, float(T(g['q_spread32']).max()), flips,
+                                    g['pool_flips32'].tolist() if 'pool_flips32' in g.files else None))
     for r in rows[:6]:
         print('   %-46s ||g-g64||/||g64|| %.2e   reference fp32 %.2e   (x gate %.2f)' % (r[1], r[2] / (r[3] + 1e-300), r[4] / (r[3] + 1e-300), r[0]))
     med = float(np.median([r[2] / (r[3] + 1e-300) for r in rows if r[3] > 1e-6]))

@@ -775,7 +775,9 @@ static int wgrad_bf16_impl(int x3, const float* src0, const float* src1, int C0,
     hipStream_t st = (hipStream_t)stream;
     int nblk;
     const bool plain = S_in == 1 && S_out == 1 && kext == 1 && off == 0 && C1 == 0 && d2s_s <= 0 && stride == 1;
-    if (x3 == 2 && plain && g_wg_lin >= 2 && !(((uintptr_t)src0 | (uintptr_t)dy) & 15)) {
+    // (the wide kernel's 128 x 512 tiles need >= 16384 positions to fill the chip with tiles x slices; below that -- replay batches of
+    //  1 .. 4 samples -- the 128^2 kernel with its finer split runs: ops.WIDE_MIN_M mirrors this)
+    if (x3 == 2 && plain && g_wg_lin >= 2 && g.P >= 16384 && !(((uintptr_t)src0 | (uintptr_t)dy) & 15)) {
         // wide form: the operand with exactly 512 channels is V (see wgrad_wide_f16_kernel); ops.wide_wgrad_tiles mirrors this test
         const bool c1 = N == 512 && K >= 128 && (K & 127) == 0;
         const bool c2 = !c1 && K == 512 && N >= 128 && (N & 127) == 0;

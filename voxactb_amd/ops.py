@@ -37,6 +37,10 @@ _WCACHE = {}
 _FCACHE = {}
 _F16CACHE = {}       # transposed weight planes (address, shape) -> the same matrix as ONE fp16 plane in fragment order (fp16x2 data gradients)
 _LAST_GRAD_SCALE = [None]     # operand scale (device {2^k, 2^-k}) the last delayed-scaling weight-gradient launch applied to its gradient
+# rows from which the 128 x 512 workgroup tiles of the wide kernels fill the chip (M / 128 workgroups per 512 columns: 128 at M = 16384).
+# Below it -- the released VoxAct-B recipe trains with replay.batch_size = 1, M = 2048 -- the 128 x 64 / 128 x 128 tile kernels run
+# (16 workgroups of 92 us each per linear layer otherwise: profiles/r04_v50_*).
+WIDE_MIN_M = int(os.environ.get('VOXACTB_WIDE_MIN_M', 16384))
 WIDE_GEMM = os.environ.get('VOXACTB_WIDE_GEMM', '1') != '0'     # N = 512 linear layers on the wide kernel (gemm_wide.hip); '0': register-staged 128^2 kernel
 # the data gradients of the big linear layers on two fp16 products (vxb_gemm_wide_f16x2_f32; DGRAD_PRECISION below selects the arithmetic)
 LIN_DGRAD_X2 = os.environ.get('VOXACTB_DGRAD_PRECISION', 'fp16x2') == 'fp16x2' and os.environ.get('VOXACTB_LIN_DGRAD_X2', '1') != '0'
@@ -246,7 +250,7 @@ def linear_bwd(x, W, dy, dW, db=None, dx=None, dx_accumulate=False, ws=None):
             # both operands are row(position)-major -> the transposed-read bf16 kernel (a 1x1x1 "conv" over M positions)
             nsb = max(1, min(64, (512 + tiles - 1) // tiles, M // 256))
             wt = wide_wgrad_tiles(N, K)
-            if wt and WGRAD_PRECISION == 'fp16' and GENERIC_WGRAD_F16 and M >= 1024:
+            if wt and WGRAD_PRECISION == 'fp16' and GENERIC_WGRAD_F16 and M >= WIDE_MIN_M:
                 # the wide kernel's workgroups own 128 x 512 tiles, one per CU: slices so that tiles x slices fills the 256 CUs once
                 nsb = max(1, min(64, int(os.environ.get('VOXACTB_WIDE_WGS', 256)) // wt, M // 1024))
             _LAST_GRAD_SCALE[0] = None
@@ -268,7 +272,7 @@ def linear_bwd(x, W, dy, dW, db=None, dx=None, dx_accumulate=False, ws=None):
         if dx is not None and _mm() and N % 8 == 0 and W.is_contiguous():
             Wt = _bf16_weight(W, True)
             f16 = _F16CACHE.get((Wt.data_ptr(), tuple(Wt.shape))) if (LIN_DGRAD_X2 and DGRAD_PRECISION == 'fp16x2' and sc_dy is not None) else None
-            if (f16 is not None and K % 512 == 0 and N % 32 == 0 and N >= 256 and M >= 1024 and dy.stride(1) == 1 and dy.stride(0) % 4 == 0
+            if (f16 is not None and K % 512 == 0 and N % 32 == 0 and N >= 256 and M >= WIDE_MIN_M and dy.stride(1) == 1 and dy.stride(0) % 4 == 0
                     and dy.data_ptr() % 16 == 0):
                 # dX = dY @ W on two fp16 products: dY * 2^k as an fp16 hi + lo pair, W as one fp16 value (gemm_wide.hip, X2)
                 _lib.set_meta('gemm_dgrad %dx%dx%d' % (M, K, N), 2.0 * M * N * K)
@@ -362,7 +366,7 @@ FUSE_GEGLU_BWD = os.environ.get('VOXACTB_FUSE_GEGLU_BWD', '0') != '0'
 
 def _geglu_wide_ok(x, rows_out, K):
     return (FUSE_GEGLU and WIDE_GEMM and GEMM_BD and PRECISION == 'bf16x3' and rows_out % 512 == 0 and K % 32 == 0 and K >= 256
-            and x.shape[0] >= 1024 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
+            and x.shape[0] >= WIDE_MIN_M and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
 
 
 def linear_geglu(x, W, bias):
@@ -1249,7 +1253,7 @@ def gemm_bf16w(x, Wb, out=None, bias=None, act=ACT_NONE, residual=None, accumula
     assert Wb.dtype == torch.bfloat16 and Wb.is_contiguous() and Wb.shape[-1] == K
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
-    if (WIDE_GEMM and x3 and N % 512 == 0 and K % 32 == 0 and K >= 256 and M >= 1024 and x.stride(1) == 1 and x.stride(0) % 4 == 0
+    if (WIDE_GEMM and x3 and N % 512 == 0 and K % 32 == 0 and K >= 256 and M >= WIDE_MIN_M and x.stride(1) == 1 and x.stride(0) % 4 == 0
             and x.data_ptr() % 16 == 0):
         wf = gemm_wfrag(Wb)
         if wf is not None:
