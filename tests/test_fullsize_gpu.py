@@ -4,8 +4,12 @@ needs ~6 s per sample at this size, so the checks are (a) two independent kernel
 'bf16x3' precision against the exact-fp32 matrix-core kernels -- inside the 1e-4 north-star bound on every Q head and
 inside 1e-2 (max and L2, relative) on every parameter gradient -- activation-mask flips, see below, (b) run-to-run determinism, (c) occupancy bookkeeping
 of the voxel grid that feeds it."""
+import numpy as np
 import pytest
 import torch
+
+from oracle import weights as ow
+from voxactb_amd import synthetic
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -203,3 +207,62 @@ def test_v200_batch8_update_steps():
     assert all(m > 0 for _, m in moved), [n for n, m in moved if m == 0][:5]
     del agent, qa
     torch.cuda.empty_cache()
+
+
+def _train_curve(precision, steps, spike_at=None, B=2):
+    """`steps` LAMB update() calls at BASELINE.json configs[1] geometry (V = 100, 4 cameras 128 x 128, depth 6, 2048 latents), B = 2,
+    dropout and augmentation off, four batches in turn; spike_at: that step's loss (hence every gradient) is multiplied by 100."""
+    import os
+    from voxactb_amd.agents.peract_bc import launch_utils as lu
+    os.environ['VOXACTB_PRECISION'] = precision
+    try:
+        cfg = lu.default_cfg(method__voxel_sizes=[100], method__voxel_patch_size=5, method__voxel_patch_stride=5, method__transformer_depth=6,
+                             method__num_latents=2048, replay__batch_size=B, method__input_dropout=0.0, method__attn_dropout=0.0,
+                             rlbench__cameras=synthetic.CAMERAS4, rlbench__camera_resolution=[128, 128])
+        cfg.method.transform_augmentation.apply_se3 = False
+        agent = lu.create_agent(cfg)
+        enc = agent._pose_agent._qattention_agents[0]._perceiver_encoder
+        enc.load_state_dict(ow.hashed_state_dict({n: tuple(p.shape) for n, p in enc.named_parameters()}, 0), strict=False)
+        agent.build(training=True, device=0)
+    finally:
+        del os.environ['VOXACTB_PRECISION']
+    qa = agent._pose_agent._qattention_agents[0]
+    assert qa._q.encoder.engine().precision == precision
+    batches = [{k: v.to(DEV) for k, v in synthetic.make_replay_sample(B, synthetic.CAMERAS4, (128, 128), 100, 4, seed=300 + j).items()}
+               for j in range(4)]
+    curve = []
+    for step in range(steps):
+        qa._loss_weights = (100.0,) * 5 if step == spike_at else None
+        r = agent.update(step, dict(batches[step % 4]))
+        curve.append(float(r['total_losses']) / (100.0 if step == spike_at else 1.0))
+    qa._loss_weights = None
+    del agent
+    torch.cuda.empty_cache()
+    return np.array(curve)
+
+
+def test_sixty_steps_at_headline_geometry_default_precision_tracks_exact_fp32():
+    """Training equivalence AT SIZE (round 3 had it at V = 16 only): 60 LAMB steps at configs[1] geometry in the exact-fp32 mode and in the
+    default precision (bf16x3 forward; single / double fp16 products with exact and DELAYED operand scales in the backward, pipelined
+    fp16 attention backward) on identical batches.  Both curves fall, and they stay together."""
+    a = _train_curve('fp32', 60)
+    b = _train_curve('bf16x3', 60)
+    print('fp32   ', np.round(a[::6], 3))
+    print('default', np.round(b[::6], 3))
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    assert a[-8:].mean() < a[:8].mean() - 1.0 and b[-8:].mean() < b[:8].mean() - 1.0
+    assert np.abs(a - b).max() < 0.05 * np.abs(a).max(), np.abs(a - b).max()
+
+
+def test_gradient_spike_at_size_is_absorbed_by_the_delayed_scales():
+    """The same run with every gradient multiplied by 100 at step 30 (loss weights): beyond the 32-fold headroom of the delayed fp16
+    operand scales, so that step's weight gradients of the generic kernel saturate once and the scales re-centre on the next step.  The
+    default-precision curve must follow the exact-fp32 curve of the SAME spiked run afterwards (LAMB normalises the step, so the spike
+    itself is one ordinary-sized update in both arithmetics)."""
+    a = _train_curve('fp32', 45, spike_at=30)
+    b = _train_curve('bf16x3', 45, spike_at=30)
+    print('fp32   ', np.round(a[24:45:2], 3))
+    print('default', np.round(b[24:45:2], 3))
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    assert np.abs(a[:31] - b[:31]).max() < 0.05 * np.abs(a).max()
+    assert np.abs(a[31:] - b[31:]).max() < 0.08 * np.abs(a).max(), np.abs(a[31:] - b[31:]).max()
