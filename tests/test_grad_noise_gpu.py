@@ -114,7 +114,7 @@ FORWARD_SENSITIVE = {'f5n_noise_c2_s3': 0.10, 'f5n_noise_v50b_s1': 0.10}
 
 
 @pytest.mark.parametrize('fixture', FIXTURES)
-@pytest.mark.parametrize('mode', ['fp32', 'bf16x3+r3/f16'])
+@pytest.mark.parametrize('mode', ['fp32', 'bf16x3+r3/f16', 'bf16x3+r3/f16-gx0'])
 def test_gradients_against_the_float64_reference(golden, fixture, mode):
     """'fp32': the exact-fp32 kernels; 'bf16x3+r3/f16': the shipped default (bf16x3 forward incl. round 3's attention forward, fp16 single /
     double products in the backward, pipelined fp16 attention backward with hi + lo gradient operands)."""
@@ -122,7 +122,7 @@ def test_gradients_against_the_float64_reference(golden, fixture, mode):
         pytest.skip('fixture not generated')
     g = golden(fixture)
     precision, _, attn = mode.partition('+')
-    eq, rows, loss = _measure(g, precision, attn or 'r3', True, '%s/%s' % (fixture[10:], mode))
+    eq, rows, loss = _measure(g, precision, attn.replace('-gx0', '') or 'r3', not attn.endswith('-gx0'), '%s/%s' % (fixture[10:], mode))
     assert eq < 1e-4
     assert abs(loss - float(g['loss'])) < 1e-4
     if precision != 'fp32' and fixture in FORWARD_SENSITIVE:

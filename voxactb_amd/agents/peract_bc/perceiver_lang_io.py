@@ -332,7 +332,7 @@ class PerceiverEngine:
         self.attn_kernel = os.environ.get('VOXACTB_ATTN_KERNEL', 'r3')
         if self.attn_kernel not in ('r3', 'f16', 'bf16'):
             raise ValueError('VOXACTB_ATTN_KERNEL must be r3, f16 or bf16')
-        self.attn_bwd_gx = os.environ.get('VOXACTB_ATTN_BWD_GX', '1') != '0'
+        self.attn_bwd_gx = os.environ.get('VOXACTB_ATTN_BWD_GX', '0') != '0'
         # backward of the attention core when the forward ran round 3's kernels: '' = round 3's backward too, 'f16' / 'bf16' = the
         # pipelined backward (it only needs q, k | v, O, lse and the dropout seed of the forward)
         self.attn_bwd_kernel = os.environ.get('VOXACTB_ATTN_BWD_KERNEL', 'f16')
