@@ -453,8 +453,9 @@ int vxb_split_f16_f32(const float* src, int64_t ld, int64_t rows, int cols, void
 /* Attention.forward (perceiver_lang_io.py:107-132: sim = q k^T * scale, softmax, dropout, attn v), pipelined structure of round 4
  * (csrc/flash2_fwd.hip): per wave the scores of tile j+1, the exponentials of tile j and the P V product of tile j-1 are independent
  * instruction streams of one region; the row offset is subtracted inside the matrix product (no per-tile maximum / rescale).
- * mode 0: kv_planes = one bf16 plane [B*Nk][2*H*64] ('bf16'); 1: one fp16 plane ('f16'); one MFMA per product.
- * waves = 4 or 8 per workgroup, 0 = by grid size.
+ * mode 0: kv_planes = one bf16 plane [B*Nk][2*H*64] ('bf16'); 1: one fp16 plane ('f16'); one MFMA per product.  mode 2 ('bf16x3', the
+ * default precision's forward): kv_planes = the hi | lo bf16 planes [2][B*Nk][2*H*64], three MFMAs per product, unit-pipelined kernel.
+ * waves = 4 or 8 per workgroup, 0 = by grid size (mode 2: always 8).
  * Outputs and dropout mask as vxb_flash_attn_fwd_dl (o [B,Nq,H*64], lse [B*H,Nq], natural log). */
 int vxb_flash2_attn_fwd(const float* q, const void* kv_planes, int mode, float* o, float* lse, int B, int H, int Nq, int Nk,
                         int head_dim, float scale, float dropout_p, uint32_t seed, int waves, vxb_stream_t stream);

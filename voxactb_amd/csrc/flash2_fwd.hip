@@ -441,6 +441,288 @@ __global__ void __launch_bounds__(NW * 64, 2) flash2_fwd_kernel(F2Args g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ bf16x3 forward
+// The arithmetic the default precision needs (every product as hi*hi + hi*lo + lo*hi on bf16 operands: a single 16-bit product in the
+// attention FORWARD moves the parameter gradients by 5e-3, tests/test_grad_noise_gpu.py) in the pipelined structure, at the granularity
+// of the backward kernels: units u = 2 kt + kb of 32 keys,
+//      step u:   S'(u+1) = K(u+1) Q^T - m  (13 MFMAs)  |  P(u) = exp2(S'(u)), hi + lo split  |  O += V(u-1)^T P(u-1)  (12 MFMAs)
+// so only ONE unit's scores and probabilities are double-buffered (the tile-granular form above would need 270 registers).  Region j =
+// steps (j, 1), (j + 1, 0): K tile j + 1 and V tile j (hi | lo planes each), rings of three stages, 8 waves share them.
+struct F3Args {
+    const float* q;
+    const u16* kv;        // planes [2][B*Nk][2*H*64] bf16 (vxb_split_bf16_f32)
+    long long kv_plane;   // u16 per plane
+    float* o;
+    float* lse;
+    int B, H, Nq, Nk, nqb;
+    float scale, p_drop;
+    unsigned seed;
+};
+
+template <int DROP, int NW>
+__global__ void __launch_bounds__(NW * 64, 2) flash2_fwd_x3_kernel(F3Args g) {
+    extern __shared__ __attribute__((aligned(16))) u16 smem[];
+    constexpr int MODE = M_BF16;
+    constexpr int NS = 3;
+    constexpr int VOF = NS * 2 * TILE;              // V ring behind the K ring; a stage = [hi plane][lo plane]
+    constexpr int LPW = 8 / NW;
+    constexpr int NLOAD = 4 * LPW;                  // K hi | lo and V hi | lo pieces per wave and tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, lq = lane & 31;
+    int vb = blockIdx.x;
+    {
+        const int total = gridDim.x;
+        if ((total & 7) == 0) vb = (vb & 7) * (total >> 3) + (vb >> 3);
+    }
+    const int bh = vb / g.nqb, qblk = vb - bh * g.nqb;
+    const int b = bh / g.H, h = bh - b * g.H;
+    const int inner = g.H * HD;
+    const int qrow = qblk * (NW * 32) + wid * 32 + lq;
+    const bool q_ok = qrow < g.Nq;
+    const float* qp = g.q + ((long long)b * g.Nq + (q_ok ? qrow : 0)) * inner + h * HD;
+    const float qs = g.scale * LOG2E;
+    bf16x8 qfh[4], qfl[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const float4 a = *reinterpret_cast<const float4*>(qp + 16 * ks + 8 * hi);
+        const float4 c = *reinterpret_cast<const float4*>(qp + 16 * ks + 8 * hi + 4);
+        const float v[8] = {a.x * qs, a.y * qs, a.z * qs, a.w * qs, c.x * qs, c.y * qs, c.z * qs, c.w * qs};
+        unsigned ph[4], pl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ph[i] = vxb_pack_bf16(v[2 * i], v[2 * i + 1]);
+            pl[i] = vxb_pack_bf16(v[2 * i] - __uint_as_float(ph[i] << 16), v[2 * i + 1] - __uint_as_float(ph[i] & 0xffff0000u));
+        }
+        qfh[ks] = f2_from4(ph[0], ph[1], ph[2], ph[3]);
+        qfl[ks] = f2_from4(pl[0], pl[1], pl[2], pl[3]);
+    }
+    const unsigned one2 = hi ? 0u : vxb_pack_bf16(1.f, 1.f);
+    const unsigned big2 = hi ? 0u : vxb_pack_bf16(-3.0e38f, 0.f);
+    unsigned mslot = 0u;
+    float m_run = 0.f, l_run = 0.f;
+    auto set_m = [&](float m) {
+        const unsigned ph = vxb_pack_bf16(-m, 0.f);
+        const unsigned p2 = vxb_pack_bf16(-m, -m - __uint_as_float(ph << 16));
+        mslot = hi ? 0u : p2;
+    };
+    f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+
+    const u16* kbase_g = g.kv + (long long)b * g.Nk * (2 * inner) + h * HD;
+    const u16* vbase_g = kbase_g + inner;
+    const unsigned rowb = 2u * 2u * (unsigned)inner;
+    const unsigned planeb = (unsigned)(g.kv_plane * 2);
+    const unsigned smem0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+    int lkey[LPW];
+    unsigned kchb[LPW], vchb[LPW];
+#pragma unroll
+    for (int t = 0; t < LPW; ++t) {
+        lkey[t] = (wid + NW * t) * 8 + (lane >> 3);
+        kchb[t] = (unsigned)(((lane & 7) ^ ((lkey[t] >> 1) & 7)) * 16);
+        vchb[t] = (unsigned)(((lane & 7) ^ (4 * ((lkey[t] >> 1) & 1))) * 16);
+    }
+    auto issue_kv = [&](int ktk, int ktv) {                   // K(ktk) and V(ktv), both planes (ktv < 0: K only; ktk < 0: V only)
+#pragma unroll
+        for (int t = 0; t < LPW; ++t) {
+            if (ktk >= 0) {
+                const unsigned key = (unsigned)min(ktk * BKV + lkey[t], g.Nk - 1);
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    f2_load16(kbase_g, key * rowb + kchb[t] + p * planeb, smem0 + (unsigned)((((ktk % NS) * 2 + p) * TILE + (wid + NW * t) * 512) * 2));
+            }
+            if (ktv >= 0) {
+                const unsigned key = (unsigned)min(ktv * BKV + lkey[t], g.Nk - 1);
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    f2_load16(vbase_g, key * rowb + vchb[t] + p * planeb, smem0 + (unsigned)((VOF + ((ktv % NS) * 2 + p) * TILE + (wid + NW * t) * 512) * 2));
+            }
+        }
+    };
+    const unsigned thr = (unsigned)(g.p_drop * 65536.0f);
+    const unsigned row_id = (unsigned)bh * (unsigned)g.Nq + (unsigned)qrow;
+    const unsigned rowh = row_id * 0x9E3779B1U + g.seed;
+    int kbase[2], kkey[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) { const int row = kb * 32 + lq; kbase[kb] = row * 64; kkey[kb] = (row >> 1) & 7; }
+    const int t16 = lane & 15, gq = lane >> 4;
+    const int vrow0 = 4 * (gq >> 1) + (t16 >> 2);
+    const int vchunk0 = 2 * (gq & 1) + ((t16 & 3) >> 1), vhalf = (t16 & 1) * 4;
+    int vlane[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) vlane[db] = vrow0 * 64 + ((vchunk0 + 4 * db) ^ (4 * ((vrow0 >> 1) & 1))) * 8 + vhalf;
+    const int nkt = (g.Nk + BKV - 1) / BKV;
+
+    auto k_frag = [&](int kt, int kb, int i, int p) -> bf16x8 {
+        return *reinterpret_cast<const bf16x8*>(smem + ((kt % NS) * 2 + p) * TILE + kbase[kb] + (((2 * i + hi) ^ kkey[kb]) * 8));
+    };
+    auto v_frag = [&](int kt, int kb, int i, int p) -> bf16x8 {             // V^T: d block i & 1, keys kb*32 + 16 (i >> 1) .. +16
+        const u16* ad = smem + VOF + ((kt % NS) * 2 + p) * TILE + vlane[i & 1] + (kb * 32 + 16 * (i >> 1)) * 64;
+        return f2_join(f2_tr16(ad), f2_tr16(ad + 8 * 64));
+    };
+    auto ones_frag = [&](int kt, int kb) -> bf16x8 {
+        const unsigned tail = (kt * BKV + kb * 32 + lq >= g.Nk) ? one2 & 0xffffu : 0u;
+        return f2_from4(one2, tail, 0u, 0u);
+    };
+    // element pair t = 0..7 of unit (kt, kb): P = exp2(S') (dropout applied) as hi | lo pairs, row-sum contributions
+    auto pair = [&](int colb, int kb, int t, const f32x16& s, unsigned (&pc)[2][8], float (&ps)[4]) {
+        const int r = 2 * t;
+        float p0 = __builtin_amdgcn_exp2f(s[r]), p1 = __builtin_amdgcn_exp2f(s[r + 1]);
+        f2_acc(ps[t & 3], p0);
+        f2_acc(ps[(t + 2) & 3], p1);
+        if (DROP) {
+            const unsigned cp = (unsigned)((kb * 32 + (r & 3) + 8 * (r >> 2)) >> 1) * 0x85EBCA77U;
+            const unsigned hsh = f2_hash(rowh ^ ((unsigned)colb + cp));
+            p0 = (hsh & 0xffffu) >= thr ? p0 : 0.f;
+            p1 = (hsh >> 16) >= thr ? p1 : 0.f;
+        }
+        pc[0][t] = vxb_pack_bf16(p0, p1);
+        pc[1][t] = vxb_pack_bf16(p0 - __uint_as_float(pc[0][t] << 16), p1 - __uint_as_float(pc[0][t] & 0xffff0000u));
+    };
+    // One step.  Unit n = (ktn, kbn): its scores are formed (sn); unit c = (ktc, kbc): P from sc_ into pc, returns its row-sum part;
+    // unit d = (ktd, kbd): O += V^T pp.  Fragments are requested one group ahead (two: 256 registers + spills).
+    auto step = [&](auto has_n, auto has_c, auto has_d, int ktn, int kbn, int ktc, int kbc, int ktd, int kbd, f32x16& sn, const f32x16& sc_,
+                    unsigned (&pc)[2][8], const unsigned (&pp)[2][8]) -> float {
+        constexpr bool HN = decltype(has_n)::value, HC = decltype(has_c)::value, HD_ = decltype(has_d)::value;
+        const int colb = (int)((unsigned)((ktc * BKV + 4 * hi) >> 1) * 0x85EBCA77U + 0xC2B2AE3DU);
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+        bf16x8 kh[4], kl[4], vh[4], vl[4];
+        auto load_group = [&](int i) {
+            if (HN) { kh[i] = k_frag(ktn, kbn, i, 0); kl[i] = k_frag(ktn, kbn, i, 1); }
+            if (HD_) { vh[i] = v_frag(ktd, kbd, i, 0); vl[i] = v_frag(ktd, kbd, i, 1); }
+        };
+        load_group(0);
+        if (HN) {
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            sn = f2_mma<MODE>(ones_frag(ktn, kbn), f2_from4(mslot, big2, 0u, 0u), z);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i + 1 < 4) load_group(i + 1);
+            if (HD_) {
+                const int ks = i >> 1, db = i & 1;
+                const bf16x8 ph = f2_from4(pp[0][4 * ks], pp[0][4 * ks + 1], pp[0][4 * ks + 2], pp[0][4 * ks + 3]);
+                const bf16x8 pl = f2_from4(pp[1][4 * ks], pp[1][4 * ks + 1], pp[1][4 * ks + 2], pp[1][4 * ks + 3]);
+                oacc[db] = f2_mma<MODE>(vl[i], ph, oacc[db]);
+                oacc[db] = f2_mma<MODE>(vh[i], pl, oacc[db]);
+                oacc[db] = f2_mma<MODE>(vh[i], ph, oacc[db]);
+            }
+            if (HC) pair(colb, kbc, 2 * i, sc_, pc, ps);
+            __builtin_amdgcn_sched_barrier(0);
+            if (HN) {
+                sn = f2_mma<MODE>(kl[i], qfh[i], sn);
+                sn = f2_mma<MODE>(kh[i], qfl[i], sn);
+                sn = f2_mma<MODE>(kh[i], qfh[i], sn);
+            }
+            if (HC) pair(colb, kbc, 2 * i + 1, sc_, pc, ps);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return (ps[0] + ps[1]) + (ps[2] + ps[3]);
+    };
+    // rare: raise m by an integer (see the single-product kernel above); sa: the unit just exponentiated, sb: the next unit's scores
+    auto raise_m = [&](int kt, int kb, f32x16& sa, f32x16& sb, unsigned (&pk)[2][8], float& psum) {
+        float mt = sa[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sa[r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float delta = fmaxf(ceilf(mt), 0.f);
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; sa[r] -= delta; sb[r] -= delta; }
+        l_run *= alpha;
+        m_run += delta;
+        set_m(m_run);
+        const int colb = (int)((unsigned)((kt * BKV + 4 * hi) >> 1) * 0x85EBCA77U + 0xC2B2AE3DU);
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) pair(colb, kb, t, sa, pk, ps);
+        psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+    };
+    const std::true_type T_;
+    const std::false_type F_;
+
+    // ---- prologue: unit 0's scores with m = 0 -> m = ceil(row maximum over the whole first TILE is not needed: unit 0 suffices)
+    issue_kv(0, -1); issue_kv(1, 0); issue_kv(2, 1);
+    f2_wait_vm<2 * NLOAD>();                                // K0 landed ({K1 V0} {K2 V1} may be in flight)
+    vxb_raw_barrier();
+    f32x16 s_[2];
+    unsigned pb[2][2][8];
+    float dummy;
+    dummy = step(T_, F_, F_, 0, 0, 0, 0, 0, 0, s_[0], s_[0], pb[0], pb[0]);
+    {
+        float mt = s_[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s_[0][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        m_run = ceilf(mt);
+        set_m(m_run);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_[0][r] -= m_run;
+    }
+    // step 0: S'(0, 1), P(0, 0)
+    {
+        float ps = step(T_, T_, F_, 0, 1, 0, 0, 0, 0, s_[1], s_[0], pb[0], pb[0]);
+        if (__builtin_amdgcn_ballot_w64(!(ps <= P_LIMIT))) raise_m(0, 0, s_[0], s_[1], pb[0], ps);
+        l_run += ps;
+    }
+    (void)dummy;
+    // ---- region j = steps 2j + 1, 2j + 2: needs K(j + 1), V(j).  Top: {K(j+1), V(j)} landed; issue {K(j+3), V(j+2)}:
+    //      K stage (j+3) % 3 held K(j) (read in region j-1), V stage (j+2) % 3 held V(j-1) (read in region j-1)
+    for (int j = 0; j < nkt; ++j) {
+        f2_wait_vm<NLOAD>();
+        vxb_raw_barrier();
+        issue_kv(j + 3, j + 2);
+        {
+            float ps = step(T_, T_, T_, j + 1, 0, j, 1, j, 0, s_[0], s_[1], pb[1], pb[0]);
+            if (__builtin_amdgcn_ballot_w64(!(ps <= P_LIMIT))) raise_m(j, 1, s_[1], s_[0], pb[1], ps);
+            l_run += ps;
+        }
+        if (j + 1 < nkt) {
+            float ps = step(T_, T_, T_, j + 1, 1, j + 1, 0, j, 1, s_[1], s_[0], pb[0], pb[1]);
+            if (__builtin_amdgcn_ballot_w64(!(ps <= P_LIMIT))) raise_m(j + 1, 0, s_[0], s_[1], pb[0], ps);
+            l_run += ps;
+        } else {
+            step(F_, F_, T_, 0, 0, 0, 0, j, 1, s_[1], s_[0], pb[0], pb[1]);        // the last unit's P V product
+        }
+    }
+    f2_wait_vm<0>();
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (q_ok) {
+        const float inv = (1.0f / (1.0f - g.p_drop)) / l_tot;
+        float* op = g.o + ((long long)b * g.Nq + qrow) * inner + h * HD;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                float4 v;
+                v.x = oacc[db][4 * r4 + 0] * inv; v.y = oacc[db][4 * r4 + 1] * inv;
+                v.z = oacc[db][4 * r4 + 2] * inv; v.w = oacc[db][4 * r4 + 3] * inv;
+                *reinterpret_cast<float4*>(op + db * 32 + 8 * r4 + 4 * hi) = v;
+            }
+        if (hi == 0) g.lse[(long long)bh * g.Nq + qrow] = (m_run + log2f(l_tot)) * (1.0f / LOG2E);
+    }
+}
+
+template <int NW>
+int f3_launch(const F3Args& g, bool drop, hipStream_t st) {
+    const size_t lds = (size_t)2 * 3 * 2 * TILE * sizeof(u16);
+    const dim3 grid(g.nqb * g.B * g.H);
+    if (drop) {
+        if (hipFuncSetAttribute((const void*)flash2_fwd_x3_kernel<1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
+        hipLaunchKernelGGL((flash2_fwd_x3_kernel<1, NW>), grid, dim3(NW * 64), lds, st, g);
+    } else {
+        if (hipFuncSetAttribute((const void*)flash2_fwd_x3_kernel<0, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
+        hipLaunchKernelGGL((flash2_fwd_x3_kernel<0, NW>), grid, dim3(NW * 64), lds, st, g);
+    }
+    return VXB_OK;
+}
+
 template <int MODE, int NW>
 int f2_launch(const F2Args& g, bool drop, hipStream_t st) {
     const size_t lds = (size_t)2 * NST * TILE * sizeof(u16);
@@ -499,8 +781,18 @@ extern "C" int vxb_split_f16_f32(const float* src, int64_t ld, int64_t rows, int
 // waves: 4 or 8 per workgroup (0 = choose).  Same outputs (o, lse) and the same dropout mask as vxb_flash_attn_fwd_dl.
 extern "C" int vxb_flash2_attn_fwd(const float* q, const void* kv_planes, int mode, float* o, float* lse, int B, int H, int Nq, int Nk,
                                    int head_dim, float scale, float dropout_p, uint32_t seed, int waves, vxb_stream_t stream) {
-    if (!q || !kv_planes || !o || !lse || B < 1 || H < 1 || Nq < 1 || Nk < 1 || mode < 0 || mode > 1) return VXB_EARG;
+    if (!q || !kv_planes || !o || !lse || B < 1 || H < 1 || Nq < 1 || Nk < 1 || mode < 0 || mode > 2) return VXB_EARG;
     if (head_dim != HD || dropout_p < 0.f || dropout_p >= 1.f || (((uintptr_t)kv_planes) & 15)) return VXB_ESIZE;
+    if (mode == 2) {                    // 'bf16x3': kv_planes = the hi | lo bf16 planes of vxb_split_bf16_f32, 8 waves share the rings
+        if ((long long)Nk * 2 * H * HD * 2 * 2 > 0xffffffffLL) return VXB_ESIZE;
+        F3Args g3;
+        g3.q = q; g3.kv = (const u16*)kv_planes; g3.kv_plane = (long long)B * Nk * 2 * H * HD; g3.o = o; g3.lse = lse;
+        g3.B = B; g3.H = H; g3.Nq = Nq; g3.Nk = Nk; g3.nqb = vxb_cdiv(Nq, 256); g3.scale = scale; g3.p_drop = dropout_p; g3.seed = seed;
+        const int rc3 = f3_launch<8>(g3, (unsigned)(dropout_p * 65536.0f) > 0u, (hipStream_t)stream);
+        if (rc3 != VXB_OK) return rc3;
+        VXB_CHECK_LAUNCH();
+        return VXB_OK;
+    }
     if (waves == 0) waves = 4;          // two 4-wave workgroups per CU overlap each other's prologue / epilogue; 8 waves measured 3-30 % slower
     if (waves != 4 && waves != 8) return VXB_EARG;
     F2Args g;

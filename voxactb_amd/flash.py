@@ -64,15 +64,15 @@ def flash_attn_bwd(q, kv, o, d_o, lse, B, H, Nq, Nk, scale, p=0.0, seed=0, x3=Fa
     return dq, dkv
 
 
-MODES = {'bf16': 0, 'f16': 1}
+MODES = {'bf16': 0, 'f16': 1, 'bf16x3': 2}
 
 
 def kv_planes(kv, mode):
     """k | v operand plane of the round-4 kernels: bf16 ('bf16') or fp16 ('f16'), [1][B*Nk][2*H*64]."""
-    npl = 1
-    out = torch.empty((npl,) + tuple(kv.shape), dtype=torch.bfloat16 if mode == 'bf16' else torch.float16, device=kv.device)
+    npl = 2 if mode == 'bf16x3' else 1          # 'bf16x3' (forward only): the hi | lo bf16 planes of vxb_split_bf16_f32
+    out = torch.empty((npl,) + tuple(kv.shape), dtype=torch.float16 if mode == 'f16' else torch.bfloat16, device=kv.device)
     set_meta('attn_core', 0.0)
-    call('vxb_split_bf16_f32' if mode == 'bf16' else 'vxb_split_f16_f32', kv, kv.stride(0), kv.shape[0], kv.shape[1], out, npl)
+    call('vxb_split_f16_f32' if mode == 'f16' else 'vxb_split_bf16_f32', kv, kv.stride(0), kv.shape[0], kv.shape[1], out, npl)
     return out
 
 
