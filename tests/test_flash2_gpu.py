@@ -1,0 +1,96 @@
+"""GPU parity of the round-4 attention kernels (csrc/flash2_fwd.hip, flash2_bwd.hip) through the C ABI: forward (bf16 / fp16 single
+products, and the bf16x3 variant) and backward (dQ, dK | dV; single and hi + lo gradient operands) against a float64 softmax attention
+and its autograd, at ragged sizes (tails of 13 keys / 8 queries, one tile, 8077-long contexts), with a score far above the first tile's
+maximum in a late tile (the raise-m path), and under dropout against round 3's bf16x3 kernels (same mask)."""
+import pytest
+import torch
+
+from tools.bench_flash2 import ref_attn, ref_bwd
+from voxactb_amd import flash
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+SHAPES = [(2, 2, 200, 333), (1, 1, 64, 64), (2, 8, 512, 640), (1, 1, 300, 8077), (1, 2, 8077, 130)]
+TOL = {'bf16': 2e-2, 'f16': 3e-3, 'bf16x3': 6e-5}
+
+
+def _data(B, H, Nq, Nk, spike):
+    torch.manual_seed(B * 1000 + Nq + Nk)
+    q = torch.randn(B * Nq, H * 64, device=DEV)
+    kv = torch.randn(B * Nk, 2 * H * 64, device=DEV)
+    if spike:            # log2 score ~ +35 for query 5 in the last tile: far above m = ceil(max of the first tile)
+        for hh in range(H):
+            kv[Nk - 7, hh * 64:(hh + 1) * 64] = 3.0 * q[5, hh * 64:(hh + 1) * 64]
+    return q, kv
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+@pytest.mark.parametrize('mode', ['bf16', 'f16', 'bf16x3'])
+@pytest.mark.parametrize('spike', [0, 1])
+def test_forward_against_float64(shape, mode, spike):
+    B, H, Nq, Nk = shape
+    q, kv = _data(B, H, Nq, Nk, spike)
+    o_ref, lse_ref = ref_attn(q, kv, B, H, Nq, Nk, 0.125)
+    for waves in (4, 8):
+        o, lse = flash.flash2_attn_fwd(q, kv, B, H, Nq, Nk, 0.125, 0.0, 0, mode=mode, waves=waves)
+        assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+        tol = TOL[mode] * (8 if spike else 1)
+        assert (o.double() - o_ref).abs().max().item() < tol * o_ref.abs().max().item()
+        assert (lse.double() - lse_ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+@pytest.mark.parametrize('mode', ['f16', 'bf16x3'])
+def test_forward_dropout_mask_equals_round3(shape, mode):
+    B, H, Nq, Nk = shape
+    q, kv = _data(B, H, Nq, Nk, 0)
+    o3, lse3 = flash.flash_attn_fwd_dl(q, kv, B, H, Nq, Nk, 0.125, 0.1, 7, x3=True)
+    o, lse = flash.flash2_attn_fwd(q, kv, B, H, Nq, Nk, 0.125, 0.1, 7, mode=mode)
+    assert (o - o3).abs().max().item() < 4 * TOL[mode] * o3.abs().max().item()          # a different mask would differ by O(1)
+    assert (lse - lse3).abs().max().item() < 4 * max(TOL[mode], 1e-5)
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+@pytest.mark.parametrize('mode,gx', [('bf16', False), ('f16', False), ('f16', True)])
+def test_backward_against_float64_autograd(shape, mode, gx):
+    B, H, Nq, Nk = shape
+    q, kv = _data(B, H, Nq, Nk, 0)
+    d_o = torch.randn(B * Nq, H * 64, device=DEV) * 3e-4
+    d_o[3] *= 40.0
+    dq_ref, dkv_ref = ref_bwd(q, kv, d_o, B, H, Nq, Nk, 0.125)
+    pl = flash.kv_planes(kv, mode)
+    o, lse = flash.flash2_attn_fwd(q, kv, B, H, Nq, Nk, 0.125, 0.0, 5, mode=mode, planes=pl)
+    dq, dkv = flash.flash2_attn_bwd(q, kv, o, d_o, lse, pl, B, H, Nq, Nk, 0.125, 0.0, 5, mode=mode, gx=gx)
+    tol = {'bf16': 3e-2, 'f16': 4e-3}[mode]
+    for a, r in ((dq, dq_ref), (dkv, dkv_ref)):
+        assert torch.isfinite(a).all()
+        assert (a.double() - r).abs().max().item() < tol * r.abs().max().item()
+
+
+@pytest.mark.parametrize('shape', SHAPES[:3])
+@pytest.mark.parametrize('gx', [False, True])
+def test_backward_behind_the_bf16x3_forward_with_dropout(shape, gx):
+    """the shipped pairing: round 3's bf16x3 forward (its O, lse, dropout seed), pipelined fp16 backward -- against round 3's backward"""
+    B, H, Nq, Nk = shape
+    q, kv = _data(B, H, Nq, Nk, 0)
+    d_o = torch.randn(B * Nq, H * 64, device=DEV) * 1e-3
+    o3, lse3, kvp3 = flash.flash_attn_fwd_dl(q, kv, B, H, Nq, Nk, 0.125, 0.1, 7, x3=True, return_planes=True)
+    dq3, dkv3 = flash.flash_attn_bwd_dl(q, kv, o3, d_o, lse3, B, H, Nq, Nk, 0.125, 0.1, 7, x3=True, kv_planes=kvp3)
+    dq, dkv = flash.flash2_attn_bwd(q, kv, o3, d_o, lse3, flash.kv_planes(kv, 'f16'), B, H, Nq, Nk, 0.125, 0.1, 7, mode='f16', gx=gx)
+    for a, r in ((dq, dq3), (dkv, dkv3)):
+        assert (a - r).abs().max().item() < 8e-3 * r.abs().max().item()
+
+
+def test_zero_gradient_and_which():
+    B, H, Nq, Nk = 1, 2, 96, 160
+    q, kv = _data(B, H, Nq, Nk, 0)
+    pl = flash.kv_planes(kv, 'f16')
+    o, lse = flash.flash2_attn_fwd(q, kv, B, H, Nq, Nk, 0.125, 0.0, 1, mode='f16', planes=pl)
+    d_o = torch.zeros_like(q)
+    dq, dkv = flash.flash2_attn_bwd(q, kv, o, d_o, lse, pl, B, H, Nq, Nk, 0.125, 0.0, 1, mode='f16', gx=True)
+    assert float(dq.abs().max()) == 0.0 and float(dkv.abs().max()) == 0.0          # all-zero dO: scale 1, no NaN
+    d_o = torch.randn_like(q)
+    a, _ = flash.flash2_attn_bwd(q, kv, o, d_o, lse, pl, B, H, Nq, Nk, 0.125, 0.0, 1, mode='f16', gx=False, which=1)
+    _, b = flash.flash2_attn_bwd(q, kv, o, d_o, lse, pl, B, H, Nq, Nk, 0.125, 0.0, 1, mode='f16', gx=False, which=2)
+    c, d = flash.flash2_attn_bwd(q, kv, o, d_o, lse, pl, B, H, Nq, Nk, 0.125, 0.0, 1, mode='f16', gx=False, which=3)
+    assert torch.equal(a, c) and torch.equal(b, d)
