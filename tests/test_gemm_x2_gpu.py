@@ -11,6 +11,15 @@ from .test_ops_gpu import rnd, DEV
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _wide_kernels_at_test_sizes():
+    """the wide 128 x 512-tile kernels are dispatched from 16384 rows on (ops.WIDE_MIN_M: below that they leave most CUs idle); these
+    tests exercise them at a few thousand rows"""
+    ops.set_wide_min_rows(1024)
+    yield
+    ops.set_wide_min_rows(16384)
+
+
 @pytest.mark.parametrize('N,K', [(512, 512), (256, 1024), (2048, 512)])
 @pytest.mark.parametrize('gain', [1.0, 2e-9, 5e5])
 def test_linear_dgrad_on_two_fp16_products(N, K, gain):

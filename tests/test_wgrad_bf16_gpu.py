@@ -93,8 +93,15 @@ def test_generic_weight_gradients_on_single_fp16_products_with_delayed_scaling()
         ops.PRECISION, ops.WGRAD_PRECISION, ops.GENERIC_WGRAD_F16, ops._GRAD_SCALE = 'fp32', '', False, {}
 
 
+@pytest.fixture
+def _wide_at_test_sizes():
+    ops.set_wide_min_rows(1024)          # (dispatched from 16384 rows on by default: ops.WIDE_MIN_M)
+    yield
+    ops.set_wide_min_rows(16384)
+
+
 @pytest.mark.parametrize('M,N,K', [(4096, 512, 1024), (2048, 512, 512), (4096, 1024, 512), (2048 + 8, 512, 1024), (4096, 384, 128)])
-def test_linear_weight_gradient_fp16_wide_and_pipelined_kernels(M, N, K):
+def test_linear_weight_gradient_fp16_wide_and_pipelined_kernels(_wide_at_test_sizes, M, N, K):
     """The plain-GEMM forms of the fp16 weight gradient (wgrad_bf16.hip): wide 128 x 512 tiles when one side has 512 channels --
     with the wide operand as `dy` argument (transposed store, bias sums and gradient maximum taken from the narrow operand: N = 512,
     K = 1024) or as src0 (N = 1024, K = 512) --, the pipelined 128 x 128 kernel otherwise (M % 16 != 0, no 512 side); each against

@@ -433,8 +433,11 @@ class PerceiverEngine:
         if c.get('flash') and self.attn_bwd_kernel in ('f16', 'bf16') and (self.bwd_precision or self.precision) != 'fp32':
             mode = 'bf16' if self.precision == 'bf16' else self.attn_bwd_kernel
             planes = flash.kv_planes(c['kv'], mode)
+            # gradient operands as hi + lo pairs where asked for, and always on small problems (below ~4 M scores the second product is
+            # free and the rounding of single operands is averaged over too few terms: the V = 8 .. 32 fixtures' element gates)
+            gx = self.attn_bwd_gx or B * H * Nq * Nk < (1 << 22)
             dq, dkv = flash.flash2_attn_bwd(c['q'], c['kv'], c['O'], dO, c['lse'], planes, B, H, Nq, Nk, d ** -0.5, c['p'], c['seed'],
-                                            mode=mode, gx=self.attn_bwd_gx)
+                                            mode=mode, gx=gx)
             return self._attn_bwd_proj(pre, dq, dkv, xq2d, ctx2d, same_src)
         if c.get('flash'):
             bp = self.attn_bwd_precision or self.bwd_precision or self.precision

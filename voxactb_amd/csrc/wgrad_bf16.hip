@@ -750,6 +750,7 @@ static int g_wg_bm256 = 0;        // experiment knob (vxb_debug_set_wgrad_bm256)
                                   // at M = 32768, N x K = 4096x512 / 512x2048 / 1024x512): 0.548 / 0.271 / 0.149 ms against 0.491 / 0.239 / 0.128 ms
                                   // with 128-row tiles -- a quarter fewer LDS fragment reads per MFMA, but half the workgroups and 176 VGPRs: OFF
 
+static long long g_wide_min_rows = 16384;      // positions from which the wide kernel's tiles x slices fill the chip (ops.WIDE_MIN_M)
 static int g_wg_lin = 2;          // plain-GEMM form of the fp16 products: 2 = wide kernel where it applies, else the pipelined 128^2 one;
                                   // 1 = pipelined 128^2 only; 0 = the generic kernel (vxb_debug_set_wgrad_lin: A/B switch)
 
@@ -777,7 +778,7 @@ static int wgrad_bf16_impl(int x3, const float* src0, const float* src1, int C0,
     const bool plain = S_in == 1 && S_out == 1 && kext == 1 && off == 0 && C1 == 0 && d2s_s <= 0 && stride == 1;
     // (the wide kernel's 128 x 512 tiles need >= 16384 positions to fill the chip with tiles x slices; below that -- replay batches of
     //  1 .. 4 samples -- the 128^2 kernel with its finer split runs: ops.WIDE_MIN_M mirrors this)
-    if (x3 == 2 && plain && g_wg_lin >= 2 && g.P >= 16384 && !(((uintptr_t)src0 | (uintptr_t)dy) & 15)) {
+    if (x3 == 2 && plain && g_wg_lin >= 2 && g.P >= g_wide_min_rows && !(((uintptr_t)src0 | (uintptr_t)dy) & 15)) {
         // wide form: the operand with exactly 512 channels is V (see wgrad_wide_f16_kernel); ops.wide_wgrad_tiles mirrors this test
         const bool c1 = N == 512 && K >= 128 && (K & 127) == 0;
         const bool c2 = !c1 && K == 512 && N >= 128 && (N & 127) == 0;
@@ -840,6 +841,7 @@ extern "C" size_t vxb_conv3d_wgrad_f16_amax_words(int C0, int C1, int kext, int 
     return (size_t)nsplit * (size_t)(grad_is_src0 ? vxb_cdiv(K, 128) : vxb_cdiv(N, bn));
 }
 extern "C" void vxb_debug_set_wgrad_bm256(int on) { g_wg_bm256 = on ? 1 : 0; }
+extern "C" void vxb_debug_set_wide_min_rows(int rows) { g_wide_min_rows = rows < 16 ? 16 : rows; }
 extern "C" void vxb_debug_set_wgrad_lin(int mode) { g_wg_lin = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
 
 // ONE fp16 product per term (fp32 accumulate), same contract and `part` layout as the entries below.  The GRADIENT operand (src0 when

@@ -41,6 +41,15 @@ _LAST_GRAD_SCALE = [None]     # operand scale (device {2^k, 2^-k}) the last dela
 # Below it -- the released VoxAct-B recipe trains with replay.batch_size = 1, M = 2048 -- the 128 x 64 / 128 x 128 tile kernels run
 # (16 workgroups of 92 us each per linear layer otherwise: profiles/r04_v50_*).
 WIDE_MIN_M = int(os.environ.get('VOXACTB_WIDE_MIN_M', 16384))
+
+
+def set_wide_min_rows(n):
+    """tests / experiments: dispatch the wide kernels from `n` rows on (Python side and the weight-gradient entry's own test)"""
+    global WIDE_MIN_M
+    WIDE_MIN_M = int(n)
+    _lib.lib().vxb_debug_set_wide_min_rows(int(n))
+
+
 WIDE_GEMM = os.environ.get('VOXACTB_WIDE_GEMM', '1') != '0'     # N = 512 linear layers on the wide kernel (gemm_wide.hip); '0': register-staged 128^2 kernel
 # the data gradients of the big linear layers on two fp16 products (vxb_gemm_wide_f16x2_f32; DGRAD_PRECISION below selects the arithmetic)
 LIN_DGRAD_X2 = os.environ.get('VOXACTB_DGRAD_PRECISION', 'fp16x2') == 'fp16x2' and os.environ.get('VOXACTB_LIN_DGRAD_X2', '1') != '0'
