@@ -332,6 +332,7 @@ def main():
             extra['voxel_scatter'] = voxel_roofline(v['ms'] / v['calls'], v['bytes'] / v['calls'], V, B, True)
             if not a.no_other_modes:
                 extra['voxel_scatter_stateless'] = voxel_stateless(agents[0], batches[0][0], cfg, V, B)
+                extra['attention_kernels_B16_H8_N2048_d64'] = attention_kernel_probe(dev)
         if a.kernel_table:
             for label, d in sorted(agg.items(), key=lambda kv: -kv[1]['ms']):
                 sys.stderr.write('%-44s calls %5d  %9.2f ms/step  %7.2f TF/s\n' % (
@@ -460,7 +461,7 @@ def voxel_stateless(agent, batch, cfg, V, B):
 
 MODE_DTYPE = {         # (short: the driver's record truncates long strings; the long form is `precision_note`)
     'fp32': 'f32 (exact fp32 MFMA everywhere)',
-    'bf16x3': 'f32 storage/accumulate; fwd products bf16x3 (3 bf16 MFMA); bwd: weight grads 1x fp16, data grads 2x fp16 (scaled)',
+    'bf16x3': 'f32 storage/accumulate; fwd products bf16x3 (3 bf16 MFMA); bwd: weight grads + attention 1x fp16, data grads 2x fp16 (scaled)',
     'bf16': 'bf16 MFMA, f32 accumulate/storage',
     'bf16x3/bf16': 'fwd bf16x3, bwd products plain bf16',
 }
@@ -468,8 +469,9 @@ MODE_NOTE = {
     'fp32': 'exact fp32 matrix cores: the reference-parity mode of the first measurements (tests/test_encoder_gpu.py, 1e-4)',
     'bf16x3': 'f32 storage / accumulate; forward products as the bf16x3 split (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16), held to the '
               '1e-4 Q-value bound of the exact-fp32 mode (tests/test_c2_reference_gpu.py, test_encoder_gpu.py); backward: weight gradients '
-              '(leaves) as single fp16 products, propagating conv / wide-linear data gradients as two fp16 products (gradient hi + lo), all with '
-              'device-side power-of-two operand scales',
+              '(leaves) and the attention backward (pipelined kernels, csrc/flash2_bwd.hip) as single fp16 products, propagating conv / '
+              'wide-linear data gradients as two fp16 products (gradient hi + lo), all with device-side power-of-two operand scales; gradients '
+              'held to 0.5 % relative L2 of the float64 reference on eight batches (tests/test_grad_noise_gpu.py)',
     'bf16': 'throughput mode, NOT held to the 1e-4 Q-value bound (tests/test_bf16_mode_gpu.py: ~4e-3 on q_trans)',
     'bf16x3/bf16': 'mixed mode (VOXACTB_BWD_PRECISION=bf16): the forward keeps the 1e-4 Q-value bound, parameter gradients are '
                    'within 0.5 % of the reference (norms within 4e-3) instead of 0.2 % -- not the default',
@@ -498,6 +500,49 @@ def group_rooflines(agg, mode, steps):
                         'launches': calls // steps, 'avg_launch_ms': ms / max(calls, 1), 'ms_per_step': ms / steps}
             if mode == 'bf16x3':
                 out[key]['frac_of_x3_roof'] = tf / (peak / 3.0)
+    return out
+
+
+def attention_kernel_probe(dev):
+    """The fused attention kernels alone at the step's self-attention size (B = 16, 8 heads, 2048 x 2048, head dim 64), random data,
+    planes / preparation passes excluded for the forward and included for the backward: algorithmic TFLOP/s (4 N^2 d forward, 10 N^2 d
+    backward per (batch, head)) against the dense bf16 / fp16 MFMA peak.  north_star: >= 30 % of that peak on the attention."""
+    from voxactb_amd import flash
+    B, H, N = 16, 8, 2048
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    q = torch.randn(B * N, H * 64, device=dev, generator=g)
+    kv = torch.randn(B * N, 2 * H * 64, device=dev, generator=g)
+    d_o = torch.randn(B * N, H * 64, device=dev, generator=g) * 1e-3
+
+    def t(fn, n=6):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    out = {}
+    ffl, bfl = 4.0 * B * H * N * N * 64, 10.0 * B * H * N * N * 64
+    for mode in ('bf16', 'f16'):
+        pl = flash.kv_planes(kv, mode)
+        for p in (0.0, 0.1):
+            ms = t(lambda: flash.flash2_attn_fwd(q, kv, B, H, N, N, 0.125, p, 3, mode=mode, planes=pl))
+            out['fwd_%s_p%.1f' % (mode, p)] = {'ms': ms, 'achieved': ffl / ms * 1e-9, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                               'frac': ffl / ms * 1e-9 / PEAK_BF16_MFMA_TFLOPS}
+    pl3 = flash._planes(kv, 2)
+    o, lse = flash.flash_attn_fwd_dl(q, kv, B, H, N, N, 0.125, 0.1, 3, x3=True)
+    ms = t(lambda: flash.call('vxb_flash_attn_fwd_dl', q, pl3, 2, o, lse, B, H, N, N, 64, 0.125, 0.1, 3))
+    out['fwd_bf16x3_round3_kernel_p0.1 (the default forward)'] = {'ms': ms, 'achieved': ffl / ms * 1e-9, 'peak': PEAK_BF16_MFMA_TFLOPS,
+                                                                  'unit': 'TFLOP/s', 'frac': ffl / ms * 1e-9 / PEAK_BF16_MFMA_TFLOPS}
+    plf = flash.kv_planes(kv, 'f16')
+    for gx in (False, True):
+        ms = t(lambda: flash.flash2_attn_bwd(q, kv, o, d_o, lse, plf, B, H, N, N, 0.125, 0.1, 3, mode='f16', gx=gx))
+        out['bwd_f16_%s_p0.1%s' % ('hi+lo' if gx else 'single', '' if gx else ' (the default backward)')] = {
+            'ms': ms, 'achieved': bfl / ms * 1e-9, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': bfl / ms * 1e-9 / PEAK_BF16_MFMA_TFLOPS}
     return out
 
 
