@@ -13,7 +13,8 @@ from tools.bench_halo import timeit  # noqa: E402
 def main():
     dev = 'cuda:0'
     M = 32768
-    for x3 in (True, False):
+    ops.set_wide_min_rows(1024)
+    for x3 in (True,) if 'x3only' in sys.argv else (True, False):
         for N, K in [(4096, 512), (512, 4096), (2048, 512), (512, 2048), (512, 512), (1024, 512), (512, 1024)]:
             x = torch.randn(M, K, device=dev)
             W = torch.randn(N, K, device=dev) * 0.05
@@ -23,10 +24,12 @@ def main():
             res = []
             ref = None
             for name, g256, dl, bd in (('staged', False, False, False), ('dl', False, 'force', False), ('dl+bfrag', False, 'force', True),
-                                       ('gemm256', 'force', True, True), ('wide', False, False, True)):
-                if name == "wide" and not (x3 and N % 512 == 0 and K >= 256):
+                                       ('gemm256', 'force', True, True), ('wide', False, False, True), ('wide4', False, False, True)):
+                if name.startswith("wide") and not (x3 and N % 512 == 0 and K >= 256):
                     continue
-                ops.GEMM256, ops.DL_GEMM, ops.GEMM_BD, ops.WIDE_GEMM = g256, dl, bd, name == 'wide'
+                ops.GEMM256, ops.DL_GEMM, ops.GEMM_BD, ops.WIDE_GEMM = g256, dl, bd, name.startswith('wide')
+                from voxactb_amd import _lib
+                _lib.lib().vxb_debug_set_gemm_wide_waves(4 if name == 'wide4' else 8)
 
                 ops.new_step()
                 t = timeit(lambda: ops.gemm_bf16w(x, wb, out=out), n=10)

@@ -70,6 +70,8 @@ def lib():
             L.vxb_debug_set_halo_experiment(int(os.environ['VOXACTB_HALO_DBG']))
         if os.environ.get('VOXACTB_WGRAD_LIN'):    # A/B switch of the linear layers' fp16 weight-gradient kernels (wgrad_bf16.hip): 0 generic, 1 pipelined, 2 wide
             L.vxb_debug_set_wgrad_lin(int(os.environ['VOXACTB_WGRAD_LIN']))
+        if os.environ.get('VOXACTB_WIDE_WAVES'):   # A/B switch of the wide linear-layer GEMMs (gemm_wide.hip): 8 or 4 waves per workgroup
+            L.vxb_debug_set_gemm_wide_waves(int(os.environ['VOXACTB_WIDE_WAVES']))
         _lib = L
     return _lib
 

@@ -53,6 +53,8 @@ struct GwArgs {
     // scale[1] * 2^4.  scale = {2^k, 2^-k} on the device: the operand scale of this dY from the weight-gradient launch of the same
     // linear_bwd (delayed by one step, 5 bits of headroom; 4 more here: a propagating gradient may jump 512-fold between steps)
     const float* scale;
+    int dbg;                 // timing experiments (WRONG results): 1 no B loads in the loop, 2 no A loads, 4 no A store / barrier, 8 no epilogue
+    int ncg;                 // NW = 4 launches: column groups per row block (1-D grid)
 };
 
 typedef _Float16 gw_f16x8 __attribute__((ext_vector_type(8)));
@@ -63,29 +65,43 @@ __device__ __forceinline__ f32x16 gw_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
 }
 
 // X2 = 0: bf16x3 (hi*hi + hi*lo + lo*hi), X2 = 1: fp16x2 (A hi | lo, one weight plane)
-template <int X2>
-__global__ void __launch_bounds__(512) gemm_wide_kernel(GwArgs g) {
+// NW = 8: one workgroup of 8 waves per CU owns 128 x 512; NW = 4: 128 x 256 per workgroup of 4 waves, TWO workgroups per CU (one wave of
+// each per SIMD), so that one workgroup's barrier, prologue and epilogue stores run under the other's MFMAs.  The column groups of a row
+// block get consecutive virtual block ids on the same XCD (A comes out of that XCD's L2 for all but the first).
+template <int X2, int NW>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) gemm_wide_kernel(GwArgs g) {
     __shared__ __attribute__((aligned(16))) u16 As[2][2][WBM * WLD];          // [stage][plane]: 40 KB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);                  // this wave's 64 columns
-    const int m0 = blockIdx.x * WBM;
+    int bx = blockIdx.x, cg = blockIdx.y;                                     // row block, column group of 64 NW columns
+    if (NW == 4) {
+        const int total = gridDim.x, ncg = g.ncg;
+        int vb = bx;
+        if ((total & 7) == 0) vb = (bx & 7) * (total >> 3) + (bx >> 3);
+        cg = vb % ncg;
+        bx = vb / ncg;
+    }
+    const int m0 = bx * WBM;
     const int nkt = g.K / WBK, nks = g.K >> 4;
     constexpr int NPB = X2 ? 1 : 2;                                           // weight planes
     const float in_sc = X2 ? g.scale[0] * 0.0625f : 1.f, out_sc = X2 ? g.scale[1] * 16.f : 1.f;
 
     // ---- A: thread -> row tid / 4, 8 consecutive k
+    constexpr int HR = 8 / NW;                                                // rows per thread (NW = 4: rows ar and ar + 64)
     const int ar = tid >> 2, akq = (tid & 3) * 8;
-    const float* __restrict__ ap = g.A + (long long)min(m0 + ar, g.M - 1) * g.lda + akq;
-    float4 ra[3][2];
+    const float* __restrict__ ap[HR];
+#pragma unroll
+    for (int h = 0; h < HR; ++h) ap[h] = g.A + (long long)min(m0 + ar + 64 * h, g.M - 1) * g.lda + akq;
+    float4 ra[3][HR][2];
 #define GW_LOADA(S, kt_)                                                                                              \
-    {                                                                                                                \
-        const float* p_ = ap + (long long)min((kt_), nkt - 1) * WBK;                                                 \
-        ra[S][0] = *reinterpret_cast<const float4*>(p_);                                                             \
-        ra[S][1] = *reinterpret_cast<const float4*>(p_ + 4);                                                         \
+    _Pragma("unroll") for (int h = 0; h < HR; ++h) {                                                                  \
+        const float* p_ = ap[h] + (long long)min((kt_), nkt - 1) * WBK;                                              \
+        ra[S][h][0] = *reinterpret_cast<const float4*>(p_);                                                          \
+        ra[S][h][1] = *reinterpret_cast<const float4*>(p_ + 4);                                                      \
     }
 #define GW_STOREA(S, stage_)                                                                                          \
-    {                                                                                                                \
-        const float v_[8] = {ra[S][0].x, ra[S][0].y, ra[S][0].z, ra[S][0].w, ra[S][1].x, ra[S][1].y, ra[S][1].z, ra[S][1].w}; \
+    _Pragma("unroll") for (int h = 0; h < HR; ++h) {                                                                  \
+        const float v_[8] = {ra[S][h][0].x, ra[S][h][0].y, ra[S][h][0].z, ra[S][h][0].w, ra[S][h][1].x, ra[S][h][1].y, ra[S][h][1].z, ra[S][h][1].w}; \
         uint4 h_, l_;                                                                                                \
         unsigned* hp_ = reinterpret_cast<unsigned*>(&h_);                                                            \
         unsigned* lp_ = reinterpret_cast<unsigned*>(&l_);                                                            \
@@ -101,12 +117,11 @@ __global__ void __launch_bounds__(512) gemm_wide_kernel(GwArgs g) {
                 lp_[e] = vxb_pack_bf16(v_[2 * e] - __uint_as_float(hp_[e] << 16), v_[2 * e + 1] - __uint_as_float(hp_[e] & 0xffff0000u)); \
             }                                                                                                        \
         }                                                                                                            \
-        *reinterpret_cast<uint4*>(&As[(stage_)][0][ar * WLD + akq]) = h_;                                            \
-        *reinterpret_cast<uint4*>(&As[(stage_)][1][ar * WLD + akq]) = l_;                                            \
+        *reinterpret_cast<uint4*>(&As[(stage_)][0][(ar + 64 * h) * WLD + akq]) = h_;                                 \
+        *reinterpret_cast<uint4*>(&As[(stage_)][1][(ar + 64 * h) * WLD + akq]) = l_;                                 \
     }
     // ---- B fragments of this wave's two 32-column tiles: frag(j, ks, plane) at ((j * nks + ks) * 2 + plane) * 512 + lane * 8
-    const int cg = blockIdx.y;                                                // 512-column group (N = 512: one)
-    const u16* __restrict__ bfb = g.Bfrag + ((long long)(cg * 16 + wn * 2) * nks * NPB) * 512 + lane * 8;
+    const u16* __restrict__ bfb = g.Bfrag + ((long long)(cg * 2 * NW + wn * 2) * nks * NPB) * 512 + lane * 8;
     bf16x8 bq[3][2][2];
 #define GW_LOADB(S, ks_)                                                                                              \
     {                                                                                                                \
@@ -153,15 +168,16 @@ __global__ void __launch_bounds__(512) gemm_wide_kernel(GwArgs g) {
     {                                                                                                                \
         const int tk_ = (kt_);                                                                                       \
         const int st = tk_ & 1;                                                                                      \
-        GW_STOREA((R_ + 1) % 3, st ^ 1)                                                                              \
-        GW_LOADB((2 * R_ + 2) % 3, 2 * tk_ + 2)                                                                      \
+        if (!(dbg & 4)) GW_STOREA((R_ + 1) % 3, st ^ 1)                                                              \
+        if (!(dbg & 1)) GW_LOADB((2 * R_ + 2) % 3, 2 * tk_ + 2)                                                      \
         GW_STEP(st, 0, (2 * R_) % 3)                                                                                 \
-        GW_LOADB((2 * R_ + 3) % 3, 2 * tk_ + 3)                                                                      \
-        GW_LOADA((R_ + 1) % 3, tk_ + 4)                                                                              \
+        if (!(dbg & 1)) GW_LOADB((2 * R_ + 3) % 3, 2 * tk_ + 3)                                                      \
+        if (!(dbg & 2)) GW_LOADA((R_ + 1) % 3, tk_ + 4)                                                              \
         GW_STEP(st, 16, (2 * R_ + 1) % 3)                                                                            \
-        __syncthreads();                                                                                             \
+        if (!(dbg & 4)) __syncthreads();                                                                             \
     }
 
+    const int dbg = g.dbg;
     GW_LOADA(0, 0)
     GW_STOREA(0, 0)
     GW_LOADB(0, 0)
@@ -184,8 +200,9 @@ __global__ void __launch_bounds__(512) gemm_wide_kernel(GwArgs g) {
 
     float* __restrict__ C = g.C;
     const float* __restrict__ R = g.residual;
+    if ((dbg & 8) && acc[0][0][0] != 12345.f) return;
     if (g.geglu == 1) {
-        const int F = g.F, c = (cg * 8 + wn) * 32 + (lane & 31);          // value column; its gate is column F + c
+        const int F = g.F, c = (cg * NW + wn) * 32 + (lane & 31);          // value column; its gate is column F + c
         const float bv = g.bias ? g.bias[c] : 0.f, bg = g.bias ? g.bias[F + c] : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -206,7 +223,7 @@ __global__ void __launch_bounds__(512) gemm_wide_kernel(GwArgs g) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int c = cg * 512 + wn * 64 + j * 32 + (lane & 31);
+                const int c = cg * 64 * NW + wn * 64 + j * 32 + (lane & 31);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -223,7 +240,7 @@ __global__ void __launch_bounds__(512) gemm_wide_kernel(GwArgs g) {
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int n = cg * 512 + wn * 64 + j * 32 + (lane & 31);
+            const int n = cg * 64 * NW + wn * 64 + j * 32 + (lane & 31);
             const float bsv = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -448,7 +465,23 @@ __global__ void __launch_bounds__(512) conv_poly_wide_x3_kernel(PwArgs g) {
     }
 }
 
+int g_wide_waves = 8, g_wide_dbg = 0;
+template <int X2>
+void gw_launch(GwArgs& g, int M, int N, hipStream_t stream) {
+    g.dbg = g_wide_dbg;
+    if (g_wide_waves == 4) {
+        g.ncg = N / 256;
+        hipLaunchKernelGGL((gemm_wide_kernel<X2, 4>), dim3(vxb_cdiv(M, WBM) * g.ncg), dim3(256), 0, stream, g);
+    } else {
+        g.ncg = N / 512;
+        hipLaunchKernelGGL((gemm_wide_kernel<X2, 8>), dim3(vxb_cdiv(M, WBM), N / 512), dim3(512), 0, stream, g);
+    }
+}
+
 }  // namespace
+
+extern "C" void vxb_debug_set_gemm_wide_waves(int waves) { g_wide_waves = waves == 4 ? 4 : 8; }
+extern "C" void vxb_debug_set_gemm_wide_experiment(int bits) { g_wide_dbg = bits; }
 
 // C[M, N] (+)= act(A[M, K] (fp32, row stride lda) @ W^T + bias) (+ residual) in 'bf16x3', N % 512 == 0, W given ONLY in MFMA fragment
 // order (Bw_frag: [N / 32][K / 16][2][64][8] bf16 = ops.gemm_wfrag of the hi / lo planes [2][N][K]); K % 32 == 0, K >= 64.  Same contract and
@@ -462,7 +495,7 @@ extern "C" int vxb_gemm_wide_bf16x3_f32(const float* A, int64_t lda, const void*
     g.A = A; g.lda = lda; g.Bfrag = (const u16*)Bw_frag; g.C = C; g.ldc = ldc; g.bias = bias; g.residual = residual;
     g.M = M; g.K = K; g.act = act; g.slope = slope; g.accumulate = accumulate;
     g.geglu = 0; g.F = 0; g.C2 = nullptr; g.H = nullptr; g.scale = nullptr;
-    hipLaunchKernelGGL(gemm_wide_kernel<0>, dim3(vxb_cdiv(M, WBM), N / 512), dim3(512), 0, (hipStream_t)stream, g);
+    gw_launch<0>(g, M, N, (hipStream_t)stream);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
@@ -481,7 +514,7 @@ extern "C" int vxb_gemm_wide_f16x2_f32(const float* A, int64_t lda, const void* 
     g.A = A; g.lda = lda; g.Bfrag = (const u16*)Bw_frag16; g.C = C; g.ldc = ldc; g.bias = nullptr; g.residual = residual;
     g.M = M; g.K = K; g.act = 0; g.slope = 0.f; g.accumulate = accumulate;
     g.geglu = 0; g.F = 0; g.C2 = nullptr; g.H = nullptr; g.scale = scale;
-    hipLaunchKernelGGL(gemm_wide_kernel<1>, dim3(vxb_cdiv(M, WBM), N / 512), dim3(512), 0, (hipStream_t)stream, g);
+    gw_launch<1>(g, M, N, (hipStream_t)stream);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
@@ -497,7 +530,7 @@ extern "C" int vxb_gemm_wide_geglu_fwd_f32(const float* A, int64_t lda, const vo
     g.A = A; g.lda = lda; g.Bfrag = (const u16*)Bw_frag; g.C = h; g.ldc = 2 * (long long)F; g.bias = bias; g.residual = nullptr;
     g.M = M; g.K = K; g.act = 0; g.slope = 0.f; g.accumulate = 0;
     g.geglu = 1; g.F = F; g.C2 = gg; g.H = nullptr; g.scale = nullptr;
-    hipLaunchKernelGGL(gemm_wide_kernel<0>, dim3(vxb_cdiv(M, WBM), 2 * F / 512), dim3(512), 0, (hipStream_t)stream, g);
+    gw_launch<0>(g, M, 2 * F, (hipStream_t)stream);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
@@ -513,7 +546,7 @@ extern "C" int vxb_gemm_wide_geglu_bwd_f32(const float* dY, int64_t lda, const v
     g.A = dY; g.lda = lda; g.Bfrag = (const u16*)Bw_frag; g.C = dh; g.ldc = 2 * (long long)F; g.bias = nullptr; g.residual = nullptr;
     g.M = M; g.K = K; g.act = 0; g.slope = 0.f; g.accumulate = 0;
     g.geglu = 2; g.F = F; g.C2 = nullptr; g.H = h; g.scale = nullptr;
-    hipLaunchKernelGGL(gemm_wide_kernel<0>, dim3(vxb_cdiv(M, WBM), F / 512), dim3(512), 0, (hipStream_t)stream, g);
+    gw_launch<0>(g, M, F, (hipStream_t)stream);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
