@@ -172,7 +172,7 @@ int vxb_conv3d_wgrad_f16_f32(const float* src0, const float* src1, int C0, int C
 size_t vxb_conv3d_wgrad_f16_amax_words(int C0, int C1, int kext, int N, int nsplit, int grad_is_src0);
 void vxb_debug_set_wgrad_bm256(int on);       /* experiment knob: 256-row tiles of the fp16 weight-gradient kernel (measured slower: default off) */
 void vxb_debug_set_gemm_wide_waves(int waves);  /* wide linear-layer GEMMs: 8 = one 128 x 512 workgroup of 8 waves per CU, 4 = two 128 x 256 workgroups of 4 waves per CU */
-void vxb_debug_set_gemm_wide_experiment(int bits);  /* timing experiments of gemm_wide.hip (WRONG results): 1 no weight-fragment loads in the loop, 2 no A loads, 4 no A staging / barrier, 8 no epilogue */
+void vxb_debug_set_gemm_wide_experiment(int bits);  /* timing experiments of gemm_wide.hip (WRONG results): 1 no weight-fragment loads in the loop, 2 no A loads, 4 no A staging / barrier, 8 no epilogue; 32 = row blocks fastest in the grid (right results) */
 void vxb_debug_set_wide_min_rows(int rows);  /* rows from which the wide weight-gradient kernel is dispatched (default 16384; tests lower it) */
 void vxb_debug_set_wgrad_lin(int mode);       /* A/B switch of the linear layers' fp16 weight gradients: 2 (default) wide kernel where one operand has 512 channels, 1 pipelined 128x128 kernel only, 0 generic kernel */
 /* Direct-to-LDS variants (global_load_lds_dwordx4, no register round trip): BOTH operands are bf16 planes in HBM.

@@ -1,5 +1,7 @@
 """Timing experiments of the wide linear-layer GEMM (gemm_wide.hip): which of its streams the main loop waits for.
-Results of the ablated runs are WRONG by construction (vxb_debug_set_gemm_wide_experiment)."""
+Results of the ablated runs are WRONG by construction (vxb_debug_set_gemm_wide_experiment).  Needs a library built with
+VXB_EXTRA_FLAGS=-DVXB_GW_ABLATE (the bits are compiled out of the shipped kernel: a branch around a load splits the loop's basic block
+and costs ~10 % by itself); bit 32 (grid order) works in every build."""
 import sys
 import os
 import torch
@@ -23,7 +25,7 @@ def main():
             out = torch.empty(M, N, device=dev)
             fl = 2.0 * M * N * K
             res = []
-            for bits in (0, 1, 2, 4, 8, 3, 7, 15):
+            for bits in (0, 1, 2, 4, 8, 3, 7, 15, 32):
                 L.vxb_debug_set_gemm_wide_experiment(bits)
                 ops.new_step()
                 t = timeit(lambda: ops.gemm_bf16w(x, wb, out=out), n=10)

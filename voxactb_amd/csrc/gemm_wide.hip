@@ -53,7 +53,7 @@ struct GwArgs {
     // scale[1] * 2^4.  scale = {2^k, 2^-k} on the device: the operand scale of this dY from the weight-gradient launch of the same
     // linear_bwd (delayed by one step, 5 bits of headroom; 4 more here: a propagating gradient may jump 512-fold between steps)
     const float* scale;
-    int dbg;                 // timing experiments (WRONG results): 1 no B loads in the loop, 2 no A loads, 4 no A store / barrier, 8 no epilogue
+    int dbg;                 // timing experiments (WRONG results): 1 no B loads in the loop, 2 no A loads, 4 no A store / barrier, 8 no epilogue; 32: 2-D grid (row blocks fastest) for N > 512
     int ncg;                 // NW = 4 launches: column groups per row block (1-D grid)
 };
 
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) gemm_wide_kernel(GwA
     const int tid = threadIdx.x, lane = tid & 63;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);                  // this wave's 64 columns
     int bx = blockIdx.x, cg = blockIdx.y;                                     // row block, column group of 64 NW columns
-    if (NW == 4) {
+    if (g.ncg > 0) {                                                          // 1-D grid: the column groups of a row block side by side on one XCD
         const int total = gridDim.x, ncg = g.ncg;
         int vb = bx;
         if ((total & 7) == 0) vb = (bx & 7) * (total >> 3) + (bx >> 3);
@@ -177,7 +177,11 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) gemm_wide_kernel(GwA
         if (!(dbg & 4)) __syncthreads();                                                                             \
     }
 
+#ifdef VXB_GW_ABLATE       // timing-experiment build (tools/bench_gemm_ablate.py): branches around the loads split the loop's basic block
     const int dbg = g.dbg;
+#else
+    constexpr int dbg = 0;
+#endif
     GW_LOADA(0, 0)
     GW_STOREA(0, 0)
     GW_LOADB(0, 0)
@@ -472,8 +476,13 @@ void gw_launch(GwArgs& g, int M, int N, hipStream_t stream) {
     if (g_wide_waves == 4) {
         g.ncg = N / 256;
         hipLaunchKernelGGL((gemm_wide_kernel<X2, 4>), dim3(vxb_cdiv(M, WBM) * g.ncg), dim3(256), 0, stream, g);
-    } else {
+    } else if (N > 512 && !(g_wide_dbg & 32)) {
+        // the column groups of a row block on adjacent workgroups of one XCD: A out of that XCD's L2, C rows written side by side
+        // (4096 x 512: 0.55-0.60 -> 0.52-0.54 ms)
         g.ncg = N / 512;
+        hipLaunchKernelGGL((gemm_wide_kernel<X2, 8>), dim3(vxb_cdiv(M, WBM) * g.ncg), dim3(512), 0, stream, g);
+    } else {
+        g.ncg = 0;
         hipLaunchKernelGGL((gemm_wide_kernel<X2, 8>), dim3(vxb_cdiv(M, WBM), N / 512), dim3(512), 0, stream, g);
     }
 }
