@@ -193,13 +193,19 @@ def test_batched_weight_split_emits_fragment_order_for_the_wide_gemm():
         ops.new_step()
 
 
+@pytest.mark.parametrize('waves,grid_bits', [(8, 0), (8, 32), (4, 0)])
 @pytest.mark.parametrize('M,N,K', [(2048, 512, 256), (4096, 1024, 512), (2300, 512, 2048), (1024, 4096, 512)])
-def test_gemm_wide_is_bit_identical_to_the_register_staged_kernel(M, N, K):
+def test_gemm_wide_is_bit_identical_to_the_register_staged_kernel(M, N, K, waves, grid_bits):
     """gemm_wide.hip (128 x 512 workgroup tiles, A three k-tiles ahead, weight fragments from global memory) in bf16x3: ragged M, every
-    epilogue option; same products in the same order as the kernels it replaces -> equal bits; and against float64."""
+    epilogue option; same products in the same order as the kernels it replaces -> equal bits; and against float64.  waves = 4: the
+    128 x 256 workgroups of four waves (two per CU); grid_bits = 32: round 3's grid order (row blocks fastest) instead of the column
+    groups of a row block side by side on one XCD."""
+    from voxactb_amd import _lib
     x, W, b, r = rnd(M, K), rnd(N, K, seed=1), rnd(N, seed=2), rnd(M, N, seed=3)
     wb = ops.split_bf16(W.to(DEV), True)
     keep = ops.WIDE_GEMM, ops.GEMM256, ops.DL_GEMM
+    _lib.lib().vxb_debug_set_gemm_wide_waves(waves)
+    _lib.lib().vxb_debug_set_gemm_wide_experiment(grid_bits)
     try:
         ops.WIDE_GEMM, ops.GEMM256, ops.DL_GEMM = False, False, False
         ref = ops.gemm_bf16w(x.to(DEV), wb, bias=b.to(DEV), act=ops.ACT_LRELU, residual=r.to(DEV))
@@ -210,13 +216,23 @@ def test_gemm_wide_is_bit_identical_to_the_register_staged_kernel(M, N, K):
         ops.gemm_bf16w(x.to(DEV), wb, out=acc, accumulate=True)
     finally:
         ops.WIDE_GEMM, ops.GEMM256, ops.DL_GEMM = keep
+        _lib.lib().vxb_debug_set_gemm_wide_waves(8)
+        _lib.lib().vxb_debug_set_gemm_wide_experiment(0)
     assert torch.equal(got, ref)
     close(got, F.leaky_relu(x.double() @ W.double().t() + b.double(), 0.02).float() + r, 2e-5, 'gemm_wide vs fp64')
     close(acc, (base.cpu().double() + x.double() @ W.double().t()).float(), 2e-5, 'gemm_wide accumulate')
 
 
+@pytest.fixture(params=[8, 4])
+def _wide_waves(request):
+    from voxactb_amd import _lib
+    _lib.lib().vxb_debug_set_gemm_wide_waves(request.param)
+    yield request.param
+    _lib.lib().vxb_debug_set_gemm_wide_waves(8)
+
+
 @pytest.mark.parametrize('M,F,K', [(2048, 256, 256), (2300, 2048, 512)])
-def test_geglu_fused_into_the_wide_gemm_is_bit_identical(M, F, K):
+def test_geglu_fused_into_the_wide_gemm_is_bit_identical(M, F, K, _wide_waves):
     """FeedForward's up-projection + GEGLU from one launch (value / gate rows interleaved in the fragment order), and the data
     gradient of the down-projection + GEGLU's backward: the same bits as the separate passes; the interleaved fragments written by
     the batched weight split equal the gather + shuffle of ops.gemm_wfrag_geglu."""

@@ -330,8 +330,8 @@ class PerceiverEngine:
         # attention core: 'r3' = round 3's kernels (bf16x3 triples, or plain bf16 in the 'bf16' precision); 'f16' / 'bf16' = the pipelined
         # kernels of round 4 (csrc/flash2_*.hip) on single fp16 / bf16 products; attn_bwd_gx: dO and dS as hi + lo pairs in their backward
         self.attn_kernel = os.environ.get('VOXACTB_ATTN_KERNEL', 'r3')
-        if self.attn_kernel not in ('r3', 'f16', 'bf16'):
-            raise ValueError('VOXACTB_ATTN_KERNEL must be r3, f16 or bf16')
+        if self.attn_kernel not in ('r3', 'r3bf16', 'f16', 'bf16', 'bf16x3'):
+            raise ValueError('VOXACTB_ATTN_KERNEL must be r3, r3bf16, f16, bf16 or bf16x3')
         self.attn_bwd_gx = os.environ.get('VOXACTB_ATTN_BWD_GX', '0') != '0'
         # backward of the attention core when the forward ran round 3's kernels: '' = round 3's backward too, 'f16' / 'bf16' = the
         # pipelined backward (it only needs q, k | v, O, lse and the dropout seed of the forward)
@@ -392,7 +392,9 @@ class PerceiverEngine:
         inner = H * d
         q = ops.linear(xq.view(B * Nq, Dq), Wq)
         kv = ops.linear(ctxn.reshape(B * Nk, ctxn.shape[2]), Wkv)
-        if self.precision in ('bf16', 'bf16x3') and d == 64 and self.fused_attention and self.attn_kernel != 'r3':
+        # (the plain-bf16 throughput mode takes the pipelined forward by default: single bf16 products either way, VOXACTB_ATTN_KERNEL=r3bf16 keeps round 3's)
+        if (self.precision in ('bf16', 'bf16x3') and d == 64 and self.fused_attention
+                and (self.attn_kernel not in ('r3', 'r3bf16') or (self.precision == 'bf16' and self.attn_kernel == 'r3'))):
             mode = 'bf16' if self.precision == 'bf16' else self.attn_kernel
             O, lse, kvp = flash.flash2_attn_fwd(q, kv, B, H, Nq, Nk, d ** -0.5, p, seed, mode=mode, return_planes=True)
             out = ops.linear(O, Wo, bo, residual=residual)
@@ -427,8 +429,12 @@ class PerceiverEngine:
         dO = torch.empty((B * Nq, inner), dtype=torch.float32, device=dev)
         ops.linear_bwd(c['O'], Wo, dout, self.g(pre + '.fn.to_out.weight'), self.g(pre + '.fn.to_out.bias'), dO)
         if c.get('flash') == 2:
-            dq, dkv = flash.flash2_attn_bwd(c['q'], c['kv'], c['O'], dO, c['lse'], c['kvp'], B, H, Nq, Nk, d ** -0.5, c['p'], c['seed'],
-                                            mode=c['mode'], gx=self.attn_bwd_gx)
+            mode, planes = c['mode'], c['kvp']
+            if mode == 'bf16x3':                    # (the three-product pipelined forward has no backward twin: the fp16 one runs behind it)
+                mode = self.attn_bwd_kernel if self.attn_bwd_kernel in ('f16', 'bf16') else 'f16'
+                planes = flash.kv_planes(c['kv'], mode)
+            dq, dkv = flash.flash2_attn_bwd(c['q'], c['kv'], c['O'], dO, c['lse'], planes, B, H, Nq, Nk, d ** -0.5, c['p'], c['seed'],
+                                            mode=mode, gx=self.attn_bwd_gx or B * H * Nq * Nk < (1 << 22))
             return self._attn_bwd_proj(pre, dq, dkv, xq2d, ctx2d, same_src)
         if c.get('flash') and self.attn_bwd_kernel in ('f16', 'bf16') and (self.bwd_precision or self.precision) != 'fp32':
             mode = 'bf16' if self.precision == 'bf16' else self.attn_bwd_kernel
