@@ -239,6 +239,20 @@ def encoder_fixture(name, cfg, arm=False, with_grads=True, digest=False, crop=Fa
 
 
 
+def _f5v200g():
+    """configs[4] geometry, forward + backward of the reference in fp32: stride-1 convs evaluated in slabs of eight output depths
+    (_chunked_conv3d_f64 below: the module code is untouched), a stack dump every ten minutes so that a stuck ATen op is named."""
+    import faulthandler
+    faulthandler.dump_traceback_later(600, repeat=True)
+    torch.set_num_threads(8)
+    torch.nn.functional.conv3d = _chunked_conv3d_f64
+    try:
+        encoder_fixture('f5v200g_encoder_c5_grads', CFG_C5, with_grads=True, digest=True, check_oracle=False, f64_grads=True)
+    finally:
+        torch.nn.functional.conv3d = _ORIG_CONV3D
+        faulthandler.cancel_dump_traceback_later()
+
+
 # ----------------------------------------------------------------------------- F5n: the reference's own fp32-vs-fp64 noise floor
 _ORIG_CONV3D = torch.nn.functional.conv3d
 
@@ -248,7 +262,9 @@ def _chunked_conv3d_f64(input, weight, bias=None, stride=1, padding=0, dilation=
     float32 path is oneDNN and has no such buffer) -- the build container's 64 GB did not survive it.  Same arithmetic in slabs of eight
     output depths (the reference's module code is untouched: only the functional it calls is wrapped, for float64 inputs only)."""
     st = (stride,) * 3 if isinstance(stride, int) else tuple(stride)
-    if input.dtype != torch.float64 or st != (1, 1, 1) or input.shape[2] < 40 or isinstance(padding, str):
+    # (float32 too from 150 voxels per side on: the reference's backward at 200^3 sat inside one ATen op for 75 minutes in round 3)
+    big = input.dim() == 5 and (input.shape[2] >= 40 if input.dtype == torch.float64 else input.shape[2] >= 150)
+    if st != (1, 1, 1) or not big or isinstance(padding, str):
         return _ORIG_CONV3D(input, weight, bias, stride, padding, dilation, groups)
     pd = (padding,) * 3 if isinstance(padding, int) else tuple(padding)
     k = weight.shape[2]
@@ -1069,7 +1085,7 @@ SECTIONS = {
     # the same grid with the reference's loss and backward.  NOT part of the committed fixtures: on the 8-core build container the
     # reference's CPU backward at 200^3 did not finish in 75 minutes (33 GB resident, all cores busy inside one ATen op), so the
     # configs[4] backward is covered by tests/test_fullsize_gpu.py::test_v200_* (two kernel families against each other) instead
-    'f5v200g': lambda: encoder_fixture('f5v200g_encoder_c5_grads', CFG_C5, with_grads=True, digest=True, check_oracle=False, f64_grads=True),
+    'f5v200g': lambda: _f5v200g(),
     # the reference in fp32 AND float64 on three batches per headline shape (the fp32-vs-fp64 spread is the yardstick of the gradient gates)
     **{'f5n_c2_s%d' % sd: (lambda sd=sd: grad_noise_fixture('f5n_noise_c2_s%d' % sd, CFG_C2, sd)) for sd in (1, 2, 3)},
     **{'f5n_c3_s%d' % sd: (lambda sd=sd: grad_noise_fixture('f5n_noise_c3_s%d' % sd, CFG_C3, sd, arm=True, crop=True)) for sd in (1, 2, 3)},
