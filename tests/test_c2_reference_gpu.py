@@ -112,7 +112,13 @@ def _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, tag):
             e = float((P[n].grad.double().cpu() - ref).abs().max())
             ref32 = float((T(g['grad__' + n]).double() - ref).abs().max()) if ('grad__' + n) in g.files else float('nan')
             print('   %-34s |ours - f64 sum| %.2e   |reference fp32 - f64 sum| %.2e   (max |grad| %.2e)' % (n, e, ref32, float(ref.abs().max())))
-            if e > 2e-3 * float(ref.abs().max()) + 2e-5:
+            # (gate set at 10^6 voxels.  A conv bias gradient is a sum over V^3 voxels of terms that largely cancel; the noise of such a sum
+            # grows with the count -- taken as its square root: x 2.83 at V = 200.  Measured there: the reference's OWN fp32 sums are off
+            # by up to 4.0e-3 (final; 5.8e-3 and 1.4e-2 on the V = 100 fixtures), ours by at most 2.0e-3 (input_preprocess -- the same
+            # 2.0e-3 from the exact-fp32 kernels and from the fused default-precision ones, two unrelated kernel families; on the V = 100
+            # fixtures that tensor is at 3.8e-4 / 1.3e-3 with the reference's fp32 at 1.2e-3 / 1.7e-3))
+            size = max(1.0, (V / 100.0) ** 1.5)
+            if e > size * (2e-3 * float(ref.abs().max()) + 2e-5):
                 bad.append((n, 'vs float64 dY sum', e, float(ref.abs().max())))
             continue
         rel = abs(gn - rn) / (rn + 1e-12)
@@ -170,6 +176,15 @@ def test_c3_twin_agent_shape_digest(golden, precision):
 def test_c5_v200_forward_digest(golden, precision):
     """BASELINE.json configs[4] grid: V=200 (40^3 patches, 64 077 context tokens), depth 6, 2048 latents, forward."""
     _run(golden('f5v200_encoder_c5_digest'), precision, 'f5v200', backward=False)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_c5_v200_forward_backward_digest(golden, precision):
+    """The same grid with the reference's loss and backward (fixture f5v200g, round 4: the reference's stride-1 convs evaluated in slabs
+    of eight output depths -- its backward at 200^3 did not finish in 75 minutes as one ATen op per layer and takes ~15 minutes this
+    way): loss within 1e-4, every parameter-gradient norm within 3e-3, the small tensors element-wise, the conv bias gradients against
+    the float64 sums of the reference's dY."""
+    _run(golden('f5v200g_encoder_c5_grads'), precision, 'f5v200g', backward=True)
 
 
 @pytest.mark.parametrize('fixture', ['f5v50a_encoder_release_digest', 'f5v50b_encoder_release_digest'])
