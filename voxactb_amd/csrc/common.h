@@ -108,6 +108,14 @@ __device__ __forceinline__ void vxb_raw_barrier() {
     asm volatile("" ::: "memory");
 }
 
+// s_barrier once this wave's LDS reads and writes have completed; its vector-memory loads stay in flight (no vmcnt wait).  May sit
+// in wave-uniform control flow as long as every wave of the workgroup executes the same NUMBER of barriers.
+__device__ __forceinline__ void vxb_raw_barrier_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // ---- SpatialSoftmax3D arithmetic shared by vox_ops.hip and c1_conv.hip
 // x / T for the SpatialSoftmax3D temperature.  The reference divides (network_utils.py:801: feature / self.temperature); the
 // IEEE division the compiler emits costs ~12 VALU instructions plus a scaling branch, which made the statistics pass

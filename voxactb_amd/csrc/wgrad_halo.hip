@@ -102,6 +102,13 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
     constexpr int NDL = 128 * 16 / NTH;                   // 8 / 4 float4 dY loads per thread per tile
     constexpr int HB = WTH / 4;                           // k-steps (4 h-rows x 8 w) per d-plane
     constexpr bool FASTADDR = PM == 2;                    // table-driven load addresses (below): the issue-bound fp16 variants only
+    // DB (fp16, two chunks per workgroup -- the shape every big launch of the step takes): TWO LDS stages.  With one stage all eight
+    // waves convert and store a tile together (VALU, matrix pipe idle), then multiply it together (matrix pipe, VALU idle): measured at
+    // B = 8 on the `final` shape the staging alone takes 3.41 ms, the MFMA loop alone 3.12 ms and the kernel 5.47 ms -- the two hardly
+    // overlap.  With two stages the tile t + 1 is staged while tile t is multiplied, ONE barrier per tile, and the two waves of a SIMD
+    // (wave w of chunk 0, wave w + 4 of chunk 1) run the two halves of a period in opposite order: one converts while the other multiplies.
+    constexpr bool DB = PM == 2 && NCH == 2;
+    constexpr int BUFU = (1 + X3) * (NCH * XPL + DPL);     // u16 per LDS stage
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* xs = smem;                                   // [NCH][1 + X3][XSLOTS][16]
     u16* ds = smem + NCH * (1 + X3) * XPL;            // [1 + X3][128][DLD]
@@ -166,7 +173,7 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
     // ONCE and parked in LDS (as registers they would be hoisted values that spill, see above); a tile then costs one LDS read
     // and one load per slot instead of ~35 VALU instructions of index arithmetic -- the fp16 variants of this kernel are
     // issue-bound on exactly that arithmetic (profiles/r03_v1_sq_summary.txt: 42-48 % of wave time issuing, matrix pipe 23-33 %).
-    int* tabx = reinterpret_cast<int*>(smem + (1 + X3) * (NCH * XPL + DPL));      // [NXL][NTH] element offset, -1 = slot past the halo
+    int* tabx = reinterpret_cast<int*>(smem + (DB ? 2 : 1) * BUFU);              // [NXL][NTH] element offset, -1 = slot past the halo
     int* tabd = tabx + NXL * NTH;                                                  // [NDL][NTH]
     // ... and for the tiles that DO touch the border of the grid (at S = 20 that is 66 of 75 tiles, at S = 100 a quarter): clamping and
     // padding are separable per axis, so three small tables per operand hold  clamp(j) * stride | invalid << 31  for every coordinate
@@ -350,38 +357,40 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
         else issue_slow(L, tile);
     };
     const float dysc = (PM == 2 && g.dy_scale) ? *g.dy_scale : 1.0f;
-    auto stage = [&](LoadSet& L) __attribute__((always_inline)) {
+    auto stage = [&](LoadSet& L, const int bo) __attribute__((always_inline)) {      // bo: u16 offset of the LDS stage
+        int tid_s = tid;                  // (opaque copy: the slot arithmetic below is NOT to be hoisted out of the tile loop and kept live
+        asm volatile("" : "+v"(tid_s));   //  across the MFMAs -- with two LDS stages that cost 43-75 spilled VGPRs)
 #pragma unroll
         for (int i = 0; i < NXL; ++i) {
-            const int e0 = tid + NTH * i;
+            const int e0 = tid_s + NTH * i;
             if (e0 < NCH * XF4) {
                 const int lch = NCH == 1 ? 0 : e0 / XF4;
                 const int e = e0 - lch * XF4 + lch * (1 + X3) * XPL / 4;     // slot index inside the chunk's plane pair
                 if (!((L.okm >> i) & 1u)) L.px[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 uint2 pk;
                 pk.x = wh_pack2<PM>(L.px[i].x, L.px[i].y); pk.y = wh_pack2<PM>(L.px[i].z, L.px[i].w);
-                *reinterpret_cast<uint2*>(&xs[(e >> 2) * 16 + (e & 3) * 4]) = pk;
+                *reinterpret_cast<uint2*>(&xs[bo + (e >> 2) * 16 + (e & 3) * 4]) = pk;
                 if (X3) {
                     uint2 q;
                     q.x = wh_pack2<PM>(L.px[i].x - __uint_as_float(pk.x << 16), L.px[i].y - __uint_as_float(pk.x & 0xffff0000u));
                     q.y = wh_pack2<PM>(L.px[i].z - __uint_as_float(pk.y << 16), L.px[i].w - __uint_as_float(pk.y & 0xffff0000u));
-                    *reinterpret_cast<uint2*>(&xs[XPL + (e >> 2) * 16 + (e & 3) * 4]) = q;
+                    *reinterpret_cast<uint2*>(&xs[bo + XPL + (e >> 2) * 16 + (e & 3) * 4]) = q;
                 }
             }
         }
 #pragma unroll
         for (int i = 0; i < NDL; ++i) {
-            const int e = tid + NTH * i;
+            const int e = tid_s + NTH * i;
             if (!((L.okm >> (8 + i)) & 1u)) L.pd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (PM == 2) { L.pd[i].x *= dysc; L.pd[i].y *= dysc; L.pd[i].z *= dysc; L.pd[i].w *= dysc; }
             uint2 pk;
             pk.x = wh_pack2<PM>(L.pd[i].x, L.pd[i].y); pk.y = wh_pack2<PM>(L.pd[i].z, L.pd[i].w);
-            *reinterpret_cast<uint2*>(&ds[(e >> 4) * DLD + (e & 15) * 4]) = pk;
+            *reinterpret_cast<uint2*>(&ds[bo + (e >> 4) * DLD + (e & 15) * 4]) = pk;
             if (X3) {
                 uint2 q;
                 q.x = wh_pack2<PM>(L.pd[i].x - __uint_as_float(pk.x << 16), L.pd[i].y - __uint_as_float(pk.x & 0xffff0000u));
                 q.y = wh_pack2<PM>(L.pd[i].z - __uint_as_float(pk.y << 16), L.pd[i].w - __uint_as_float(pk.y & 0xffff0000u));
-                *reinterpret_cast<uint2*>(&ds[DPL + (e >> 4) * DLD + (e & 15) * 4]) = q;
+                *reinterpret_cast<uint2*>(&ds[bo + DPL + (e >> 4) * DLD + (e & 15) * 4]) = q;
             }
         }
     };
@@ -418,18 +427,14 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
     // workgroup's MFMAs -- the times add.  Delaying every second workgroup by 1-8 thousand cycles to break a possible
     // lockstep of the two changed nothing.)
     // one tile: stage the loads of set L into LDS, issue the loads of tile + AHEAD into the freed set, multiply
-    auto tile_body = [&](LoadSet& L, int tile, int ahead) __attribute__((always_inline)) {
-        __syncthreads();                 // every wave is done reading the previous tile
-        if (!(g.dbg & 1) || tile == t_begin) stage(L);
-        __syncthreads();
-        if (tile + ahead < t_end && !(g.dbg & 1)) issue(L, tile + ahead);
-        if (g.dbg & 2) return;
+    // the MFMAs of one tile, operands in the LDS stage at u16 offset bo
+    auto mma = [&](const int bo) __attribute__((always_inline)) {
 #pragma unroll 1
         for (int ks = 0; ks < 4; ++ks) {
             const int dd = ks / HB, hb = (ks % HB) * 4;
-            const u16* xa0 = xs + wch * (1 + X3) * XPL + ((dd * XH + hb + fh) * XW + fw) * 16 + fc;   // read r = 0 (tap offset added later)
+            const u16* xa0 = xs + bo + wch * (1 + X3) * XPL + ((dd * XH + hb + fh) * XW + fw) * 16 + fc;   // read r = 0 (tap offset added later)
             const u16* xa1 = xa0 + XW * 16;                                          // r = 1: next h row
-            const u16* db0 = ds + ((dd * WTH + hb + fh) * WTW + fw) * DLD + fc;
+            const u16* db0 = ds + bo + ((dd * WTH + hb + fh) * WTW + fw) * DLD + fc;
             const u16* db1 = db0 + WTW * DLD;
             bf16x8 bh[4], bl[4];
 #pragma unroll
@@ -466,7 +471,50 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
             }
         }
     };
-    if (PF2) {
+    auto tile_body = [&](LoadSet& L, int tile, int ahead) __attribute__((always_inline)) {
+        __syncthreads();                 // every wave is done reading the previous tile
+        if (!(g.dbg & 1) || tile == t_begin) stage(L, 0);
+        __syncthreads();
+        if (tile + ahead < t_end && !(g.dbg & 1)) issue(L, tile + ahead);
+        if (g.dbg & 2) return;
+        mma(0);
+    };
+    if (DB) {
+        // One loop body for all waves -- multiply tile t, then convert + store a later tile, one s_barrier per tile -- but the chunk-0
+        // waves ("lead") run one tile further ahead in the staging and take their barrier BETWEEN the two halves, the chunk-1 waves
+        // after both: between two barriers a lead wave converts tile t + 2 and then multiplies tile t + 1 while its SIMD partner
+        // multiplies tile t + 1 and then converts tile t + 2.  Stage t & 1 of the LDS holds tile t; a lead wave overwrites it with tile
+        // t + 2 right after the barrier that every wave reaches only after its MFMAs of tile t.  Set X (ls1 in even iterations) holds
+        // the loads of the tile staged next: t + 1 (chunk 1) / t + 2 (lead), refilled with the tile two further on.
+        const int lead = wch == 0 ? 1 : 0;      // wave-uniform
+        if (t_begin < t_end) issue(ls0, t_begin);
+        if (t_begin + 1 < t_end) issue(ls1, t_begin + 1);
+        if (t_begin < t_end) stage(ls0, 0);
+        if (lead) {
+            if (t_begin + 1 < t_end) stage(ls1, BUFU);
+            if (!(g.dbg & 1)) {
+                if (t_begin + 2 < t_end) issue(ls1, t_begin + 2);
+                if (t_begin + 3 < t_end) issue(ls0, t_begin + 3);
+            }
+        } else if (t_begin + 2 < t_end && !(g.dbg & 1)) {
+            issue(ls0, t_begin + 2);
+        }
+        __syncthreads();
+        auto period = [&](LoadSet& X, int tile, const int par) __attribute__((always_inline)) {      // par = (tile - t_begin) & 1
+            if (!(g.dbg & 2)) mma(par * BUFU);
+            if (lead) vxb_raw_barrier_lds();
+            const int nt = tile + 1 + lead;
+            if (nt < t_end && !(g.dbg & 1)) {
+                stage(X, ((par + 1 + lead) & 1) * BUFU);
+                if (nt + 2 < t_end) issue(X, nt + 2);
+            }
+            if (!lead) vxb_raw_barrier_lds();
+        };
+        for (int tile = t_begin; tile < t_end; tile += 2) {
+            period(ls1, tile, 0);
+            if (tile + 1 < t_end) period(ls0, tile + 1, 1);
+        }
+    } else if (PF2) {
         if (t_begin < t_end) issue(ls0, t_begin);
         if (t_begin + 1 < t_end) issue(ls1, t_begin + 1);
         for (int tile = t_begin; tile < t_end; tile += 2) {
@@ -517,7 +565,7 @@ static int wgrad_halo_launch(WhArgs& g, int nsplit, hipStream_t st) {
         if (xspan < (1ll << 30) && yspan < (1ll << 30) && off_lo >= -4 && off_hi <= 4 && (g.C0 + g.C1) < (1 << 19) && g.N < (1 << 19))
             g.tabn = (g.S_in > g.S_out ? g.S_in : g.S_out) + 20;
     }
-    const size_t lds = (size_t)(1 + X3) * (NCH * (TD + 2) * (TH + 2) * XW * 16 + DPL) * sizeof(u16) +
+    const size_t lds = (size_t)((PM == 2 && NCH == 2) ? 2 : 1) * (1 + X3) * (NCH * (TD + 2) * (TH + 2) * XW * 16 + DPL) * sizeof(u16) +
                        (PM == 2 ? (size_t)2 * ((NCH * XF4_ + NTHR - 1) / NTHR + 128 * 16 / NTHR) * NTHR * sizeof(int) + (size_t)6 * g.tabn * sizeof(int) : 0);
     dim3 grid((g.C0 + g.C1) / (16 * NCH), (g.N / 64) * (g.nshift > 1 ? g.nshift : 1), nsplit);
     if (hipFuncSetAttribute((const void*)wgrad_halo_kernel<PM, TD, TH, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
