@@ -175,6 +175,13 @@ void vxb_debug_set_gemm_wide_waves(int waves);  /* wide linear-layer GEMMs: 8 = 
 void vxb_debug_set_gemm_wide_experiment(int bits);  /* timing experiments of gemm_wide.hip (WRONG results): 1 no weight-fragment loads in the loop, 2 no A loads, 4 no A staging / barrier, 8 no epilogue; 32 = row blocks fastest in the grid (right results) */
 void vxb_debug_set_wide_min_rows(int rows);  /* rows from which the wide weight-gradient kernel is dispatched (default 16384; tests lower it) */
 void vxb_debug_set_wgrad_lin(int mode);       /* A/B switch of the linear layers' fp16 weight gradients: 2 (default) wide kernel where one operand has 512 channels, 1 pipelined 128x128 kernel only, 0 generic kernel */
+/* dst[i] = convert(src[idx[i]]), i < n: a weight tensor re-laid out through a cached index table in one pass (ops.gather_cvt: the
+   polyphase up-conv's effective weight, network_utils.py:245-250, into the fragment orders its forward and data-gradient kernels
+   read).  mode 0: dst fp16 (round to nearest even).  mode 1: dst bf16 planes: entry j < plane_off is the hi half of src[j],
+   j >= plane_off the lo half bf16(v - hi) of src[j - plane_off] (the values of vxb_split_bf16_f32).  idx < 0 gives 0.
+   n % 8 == 0; idx, dst 16-byte aligned. */
+int vxb_gather_cvt_f32(const float* src, const int32_t* idx, int64_t n, void* dst, int mode, int32_t plane_off, vxb_stream_t stream);
+
 /* Direct-to-LDS variants (global_load_lds_dwordx4, no register round trip): BOTH operands are bf16 planes in HBM.
  * vxb_split_bf16_f32 makes the activation planes [nplanes][rows][cols] (plane 0 = bf16(x), plane 1 = bf16(x - plane 0));
  * weights are the same [nplanes][N][K] planes as above.  nplanes = 1 ('bf16') or 2 ('bf16x3').  K % 32 == 0 (conv:

@@ -118,3 +118,33 @@ def test_sparse_data_gradient_is_bit_identical_to_dense(mode):
     tt, ncls, total, rows = ops.s2d_taptab(k, s, DEV, 16, 4)
     assert ncls == 27 and total == rows.numel() and total % 3 == 0
     assert total == 4 * (8 * 9 + 36 * 12 + 54 * 18 + 27 * 27)          # 8-tap lists padded to 9
+
+
+def test_weight_gather_equals_the_aten_layout_chains():
+    """ops.gather_cvt with a traced index table (one pass, vxb_gather_cvt_f32) writes the same bits as the ATen chains it replaces: the
+    forward's perm8 gather + hi / lo split + fragment shuffle of W_eff, and the data gradient's flip / permute / transpose / fp16 /
+    fragment shuffle / tap-list gather (network_utils.py:245-250 backward)."""
+    C, k, s = 64, 5, 5
+    Weff, _, R = _weff(C, k, s, seed=5)
+    kl = 2 * R + 1
+    st = ops.polyphase_structure(k, s, DEV)
+    N, K = s ** 3 * C, kl ** 3 * C
+    # forward: planes in fragment order
+    wt = Weff.t().view(s ** 3, C, K).index_select(0, st['perm8_long']).view(N, K)
+    ref = ops.gemm_wfrag(ops.split_planes(wt, 2))
+    idx = ops.traced_index(('test_polyf', k, s, C), tuple(Weff.shape),
+                           lambda I: ops._wfrag_index(I.t().view(s ** 3, C, K).index_select(0, st['perm8_long']).view(N, K), Weff.numel()), DEV)
+    got = ops.gather_cvt(Weff, idx, 1, Weff.numel())
+    assert got.numel() == ref.numel() and torch.equal(got.view(torch.int16), ref.reshape(-1).view(torch.int16))
+    # data gradient: fp16 fragments of the listed taps
+    C0 = s ** 3 * C
+    tt, ncls, total, rows = ops.s2d_taptab(k, s, DEV, 16, C // 16)
+    wd = ops.polyphase_dgrad_weights_lowres(Weff, C, C, s, kl)
+    f = ops.halo_wfrag_x2(wd.t().contiguous().half(), C0)
+    ref2 = f.view(f.shape[0], f.shape[1] * 27, -1).index_select(1, rows).contiguous()
+
+    def layout(I):
+        g = ops.halo_wfrag_x2(ops.polyphase_dgrad_weights_lowres(I, C, C, s, kl).t().contiguous(), C0)
+        return g.view(g.shape[0], g.shape[1] * 27, -1).index_select(1, rows).contiguous()
+    got2 = ops.gather_cvt(Weff, ops.traced_index(('test_s2dw', k, s, C), tuple(Weff.shape), layout, DEV), 0)
+    assert got2.numel() == ref2.numel() and torch.equal(got2.view(torch.int16), ref2.reshape(-1).view(torch.int16))

@@ -799,8 +799,7 @@ class PerceiverEngine:
             Sp = G + 2 * R
             if ops.s2d_halo_ok(kl, C, C):
                 # same gradient as a 3^3 conv over the low-res grid reading the fine dY by space-to-depth (LDS-halo kernel)
-                wd = ops.polyphase_dgrad_weights_lowres(c['Weff'], C, C, s, kl)
-                dzp = ops.conv3_s2d(du0, wd, C, B, G, Sp, -(kl - 1), s, C, poly_k=k, dy_scale=sc_du0)
+                dzp = ops.conv3_s2d(du0, None, C, B, G, Sp, -(kl - 1), s, C, poly_k=k, dy_scale=sc_du0, weff_src=(c['Weff'], C, C, s, kl))
             else:
                 wd = ops.polyphase_dgrad_weights(c['Weff'], C, C, s, kl)
                 dzp = ops.conv3d(du0, wd, C, B, V, Sp, s * kl, -s * (kl - 1), stride=s, replicate=False)

@@ -381,6 +381,38 @@ __global__ void __launch_bounds__(256) split_bf16_kernel(const float* __restrict
     }
 }
 
+// dst[i] = cvt(src[idx[i]]): a weight tensor re-laid out by a cached index table in ONE pass (the polyphase up-conv's 13.8 M-element
+// effective weight went through five ATen permute / gather / transpose copies per step, 0.9 ms).  MODE 0: fp16 (RNE); MODE 1: bf16
+// planes -- entry j < plane_off is the hi half of src[j], j >= plane_off the lo half bf16(v - hi) of src[j - plane_off] (the values
+// vxb_split_bf16_f32 produces).  idx < 0: zero (padding rows of a fragment layout).  Eight outputs per thread, one 16-byte store.
+template <int MODE>
+__global__ void __launch_bounds__(256) gather_cvt_kernel(const float* __restrict__ src, const int* __restrict__ idx, long long n8,
+                                                         u16* __restrict__ dst, int plane_off) {
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n8; t += (long long)gridDim.x * 256) {
+        const int4 i0 = *reinterpret_cast<const int4*>(idx + t * 8), i1 = *reinterpret_cast<const int4*>(idx + t * 8 + 4);
+        const int j[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int jj = j[e];
+            float x = 0.f;
+            if (jj >= 0) {
+                if (MODE == 1 && jj >= plane_off) {
+                    const float f = src[jj - plane_off];
+                    x = f - __uint_as_float((vxb_pack_bf16(f, 0.f) & 0xffffu) << 16);
+                } else {
+                    x = src[jj];
+                }
+            }
+            v[e] = x;
+        }
+        uint4 o;
+        if (MODE == 0) { o.x = vxb_pack_f16(v[0], v[1]); o.y = vxb_pack_f16(v[2], v[3]); o.z = vxb_pack_f16(v[4], v[5]); o.w = vxb_pack_f16(v[6], v[7]); }
+        else { o.x = vxb_pack_bf16(v[0], v[1]); o.y = vxb_pack_bf16(v[2], v[3]); o.z = vxb_pack_bf16(v[4], v[5]); o.w = vxb_pack_bf16(v[6], v[7]); }
+        *reinterpret_cast<uint4*>(dst + t * 8) = o;
+    }
+}
+
 // All linear-layer weights of a step in ONE launch: entry e of the device table desc[e] = {src, dst, rows, cols, flags,
 // first tile} describes an fp32 [rows][cols] matrix whose planes go to dst as [nplanes][rows][cols] or, transposed (flags bit 0),
 // as [nplanes][cols][rows] (the B operand of the data-gradient GEMM) -- the same hi / lo values vxb_split_bf16_f32 produces; with
@@ -463,6 +495,19 @@ inline bool dl_al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // dst planes [nplanes (1 or 2)][rows][cols] bf16 <- src fp32 [rows][cols] (row stride ld): plane 0 = bf16(src) (RNE),
 // plane 1 = bf16(src - plane 0): the operand format of the direct-to-LDS kernels.  cols % 4 == 0.
+// dst [n] (fp16: mode 0, bf16: mode 1) = converted src[idx[i]] (see gather_cvt_kernel); n % 8 == 0, idx and dst 16-byte aligned.
+extern "C" int vxb_gather_cvt_f32(const float* src, const int32_t* idx, int64_t n, void* dst, int mode, int32_t plane_off,
+                                  vxb_stream_t stream) {
+    if (!src || !idx || !dst || n < 8 || (mode != 0 && mode != 1)) return VXB_EARG;
+    if ((n & 7) || (((uintptr_t)idx | (uintptr_t)dst) & 15)) return VXB_ESIZE;
+    const long long n8 = n >> 3;
+    const int grid = (int)(n8 + 255) / 256 > 8192 ? 8192 : (int)((n8 + 255) / 256);
+    if (mode == 0) hipLaunchKernelGGL(gather_cvt_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, idx, n8, (u16*)dst, plane_off);
+    else hipLaunchKernelGGL(gather_cvt_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, idx, n8, (u16*)dst, plane_off);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
 extern "C" int vxb_split_bf16_f32(const float* src, int64_t ld, int64_t rows, int cols, void* dst_planes, int nplanes,
                                   vxb_stream_t stream) {
     if (!src || !dst_planes || rows < 1 || cols < 4 || (nplanes != 1 && nplanes != 2)) return VXB_EARG;

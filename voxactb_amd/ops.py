@@ -75,6 +75,46 @@ def gemm_wfrag(wb):
     return f[0]
 
 
+_IDX = {}          # cached index tables of gather_cvt (layout only: they do not depend on the weights' values)
+
+
+def traced_index(key, shape, layout_fn, dev):
+    """int32 table T with  layout_fn(x).reshape(-1) == x.reshape(-1)[T]  for any tensor x of `shape` and any chain of pure layout ops
+    (view / permute / flip / index_select / contiguous / cat with -1 padding): the chain is run ONCE on arange(numel) and cached."""
+    t = _IDX.get(key)
+    if t is None:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        assert n < (1 << 30)
+        t = layout_fn(torch.arange(n, dtype=torch.int32, device=dev).view(shape)).reshape(-1).contiguous()
+        _IDX[key] = t
+    return t
+
+
+def gather_cvt(src, idx, mode, plane_off=0):
+    """src fp32 (contiguous, any shape) -> flat fp16 (mode 0) / bf16 hi | lo by plane offset (mode 1) tensor dst[i] = cvt(src[idx[i]])
+    in one pass (gemm_dl.hip: vxb_gather_cvt_f32); idx from traced_index."""
+    assert src.is_contiguous() and src.dtype == torch.float32
+    dst = torch.empty(idx.numel(), dtype=torch.float16 if mode == 0 else torch.bfloat16, device=src.device)
+    call('vxb_gather_cvt_f32', src, idx, idx.numel(), dst, int(mode), int(plane_off))
+    return dst
+
+
+def _wfrag_index(I2, plane_off):
+    """gemm_wfrag's layout on an index matrix [N][K]: planes hi (index j) and lo (index plane_off + j), -1 in the zero rows that pad N
+    to a multiple of 128."""
+    N, K = I2.shape
+    w3 = torch.stack((I2, I2 + plane_off))
+    if N % 128:
+        w3 = torch.cat((w3, w3.new_full((2, 128 - N % 128, K), -1)), dim=1)
+        N = w3.shape[1]
+    return w3.view(2, N // 32, 32, K // 16, 2, 8).permute(1, 3, 0, 4, 2, 5).contiguous()
+
+
+WEIGHT_GATHER = os.environ.get('VOXACTB_WEIGHT_GATHER', '1') != '0'     # polyphase weights into their fragment orders by one gather pass each ('0': the ATen chains)
+
+
 def gemm_wfrag_geglu(wb):
     """fragment order of the GEGLU up-projection's planes [2][2 F][K] with the rows of every 64-row block interleaved as [32 value rows
     | their 32 gate rows] (include/voxactb_hip.h: vxb_gemm_wide_geglu_fwd_f32); made by prepare_linear_weights(..., geglu=...) in the
@@ -756,8 +796,16 @@ def conv3_polyphase_fwd(z, Weff, Cout, B, G, k, s, bias, act=ACT_NONE, label=Non
     if WIDE_POLY and GEMM_BD and npl == 2 and Cout == 64 and z.is_contiguous() and K % 16 == 0:
         # 128 x 512 workgroup tiles, one phase per wave, A gathered + split in the kernel (gemm_wide.hip: conv_poly_wide_x3_kernel);
         # column blocks in the order that keeps the eight footprints of a workgroup alike
-        wt = Weff.t().view(s ** 3, Cout, K).index_select(0, st['perm8_long']).view(N, K)
-        wf = gemm_wfrag(split_planes(wt, npl))
+        if WEIGHT_GATHER and Weff.is_contiguous() and K % 16 == 0:
+            # Weff [K][N] -> column blocks in perm8 order, hi | lo planes, MFMA fragment order: one gather pass through a cached table
+            # (was: transposing gather 166 us + split + fragment shuffle 54 us per step)
+            numel = Weff.numel()
+            idx = traced_index(('polyf', k, s, C, Cout, str(z.device)), tuple(Weff.shape),
+                               lambda I: _wfrag_index(I.t().view(s ** 3, Cout, K).index_select(0, st['perm8_long']).view(N, K), numel), z.device)
+            wf = gather_cvt(Weff, idx, 1, numel)
+        else:
+            wt = Weff.t().view(s ** 3, Cout, K).index_select(0, st['perm8_long']).view(N, K)
+            wf = gemm_wfrag(split_planes(wt, npl))
         _lib.set_meta(lbl, 2.0 * B * G ** 3 * N * kl ** 3 * C * st['frac'])
         call('vxb_conv3_poly_wide_bf16x3_f32', z, C, B, G, kl, -R, 1, wf, N, bias, out, act, LRELU_SLOPE, s, st['block_mask8'], st['perm8'])
         return out
@@ -957,14 +1005,42 @@ def s2d_kparts(k, s, dev, cpc, chunks_per_phase, ksplit):
     return r
 
 
-def conv3_s2d(src_fine, wt, N, B, G, S_out, off, s, Cf, label=None, poly_k=None, dy_scale=None):
+def conv3_s2d(src_fine, wt, N, B, G, S_out, off, s, Cf, label=None, poly_k=None, dy_scale=None, weff_src=None):
     """out[B, S_out^3, N] = 3x3x3 zero-pad conv over the low-res grid G^3 whose input channel (phase, co) is read from
     src_fine [B, (G*s)^3, Cf] at fine voxel (q*s + r); wt fp32 [(tap, phase, co)][N].  LDS-halo kernel only (bf16 modes).
     poly_k: wt is the data gradient of the polyphase up-conv of a k^3 kernel -- only its non-zero (tap, phase) blocks are
-    visited (POLY_SPARSE)."""
+    visited (POLY_SPARSE).  weff_src = (Weff, Ci, Co, s, kl) instead of wt (wt = None): wt = polyphase_dgrad_weights_lowres(*weff_src),
+    never formed on the two-product path -- its fp16 fragments are gathered from Weff in one pass."""
+    C0 = s ** 3 * Cf
+    if (weff_src is not None and WEIGHT_GATHER and poly_k is not None and POLY_SPARSE and HALO_WD and S2D_KSPLIT > 1 and PRECISION == 'bf16x3'
+            and DGRAD_PRECISION == 'fp16x2' and WGRAD_PRECISION == 'fp16' and src_fine.is_contiguous() and weff_src[0].is_contiguous()):
+        Weff, Ci, Co, s_, kl = weff_src
+        dev = src_fine.device
+        lbl = label or 'conv3_s2d[k3 %d->%d S%d dgrad]' % (C0, N, S_out)
+        tt, ncls, total, rows = s2d_taptab(poly_k, s, dev, 16, Cf // 16)
+        frac = polyphase_structure(poly_k, s, dev)['frac']
+        ks = S2D_KSPLIT
+        kp = s2d_kparts(poly_k, s, dev, 16, Cf // 16, ks)
+
+        def layout(I):
+            f = halo_wfrag_x2(polyphase_dgrad_weights_lowres(I, Ci, Co, s_, kl).t().contiguous(), C0)
+            return f.view(f.shape[0], f.shape[1] * 27, -1).index_select(1, rows).contiguous()
+        idx = traced_index(('s2dw', poly_k, s, Ci, Co, kl, Cf, str(dev)), tuple(Weff.shape), layout, dev)
+        wf2 = gather_cvt(Weff, idx, 0)
+        out = torch.empty((B, S_out, S_out, S_out, N), dtype=torch.float32, device=dev)
+        parts = torch.empty((ks, B, S_out, S_out, S_out, N), dtype=torch.float32, device=dev)
+        sc = dy_scale
+        if sc is None:
+            _lib.set_meta(lbl, 0.0)
+            sc = absmax_scale(src_fine)
+        _lib.set_meta(lbl, 2.0 * B * S_out ** 3 * N * 27 * C0 * frac)
+        call('vxb_conv3_s2d_splitk_f32', src_fine, C0, B, G, S_out, off, wf2, 3, N, parts, s, Cf, wf2, tt, ncls, total, ks, kp, sc)
+        sum_splits(parts, ks, out.numel(), out)
+        return out
+    if wt is None:
+        wt = polyphase_dgrad_weights_lowres(*weff_src)
     wb = to_bf16_nk(wt)
     out = torch.empty((B, S_out, S_out, S_out, N), dtype=torch.float32, device=src_fine.device)
-    C0 = s ** 3 * Cf
     x3 = wb.dim() == 3
     lbl = label or 'conv3_s2d[k3 %d->%d S%d dgrad]' % (C0, N, S_out)
     _lib.set_meta(lbl, 0.0)
