@@ -532,6 +532,37 @@ __global__ void __launch_bounds__(256) naive_gemm_kernel(const float* __restrict
     }
 }
 
+// the same for FEW outputs and a long reduction (the dense heads at a replay batch of 1-16: M N <= 16 K, K up to 4 K): one thread per
+// output walks K alone and waits a memory round trip per step (28-33 us per launch); here a WAVE owns an output, its lanes stride
+// over K and a fixed-order butterfly adds the 64 partial sums
+__global__ void __launch_bounds__(256) naive_gemm_wave_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                              float* __restrict__ C, const float* __restrict__ bias, int M, int N,
+                                                              int K, long long sAm, long long sAk, long long sBk, long long sBn,
+                                                              long long ldc, int act, float slope, int accumulate) {
+    const long long total = (long long)M * N;
+    const int lane = threadIdx.x & 63;
+    for (long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); i < total; i += (long long)gridDim.x * 4) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        const float* __restrict__ a = A + m * sAm;
+        const float* __restrict__ b = B + n * sBn;
+        float s0 = 0.f, s1 = 0.f;
+        int k = lane;
+        for (; k + 64 < K; k += 128) {
+            s0 = fmaf(a[k * sAk], b[k * sBk], s0);
+            s1 = fmaf(a[(k + 64) * sAk], b[(k + 64) * sBk], s1);
+        }
+        if (k < K) s0 = fmaf(a[k * sAk], b[k * sBk], s0);
+        float s = s0 + s1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) {
+            if (bias) s += bias[n];
+            if (act == 1) s = s > 0.f ? s : s * slope;
+            if (accumulate) C[m * ldc + n] += s; else C[m * ldc + n] = s;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ context assembly
 // ctx[b, t, :] = (t < T0 ? lang[b,t,:] : cat(patch[b,t-T0,:C], pp[b,:Cp])) + pos[t,:]     (perceiver_lang_io.py:370-422;
 // Cp = C for one proprio vector, 2 C for the right | left pair of the 2Robots encoder, :721-727)
@@ -868,8 +899,12 @@ extern "C" int vxb_naive_gemm_f32(const float* A, const float* B, float* C, cons
                                   int64_t sAm, int64_t sAk, int64_t sBk, int64_t sBn, int64_t ldc, int act, float slope,
                                   int accumulate, vxb_stream_t stream) {
     if (!A || !B || !C || M < 1 || N < 1 || K < 1) return VXB_EARG;
-    hipLaunchKernelGGL(naive_gemm_kernel, dim3(grid_for((long long)M * N)), dim3(256), 0, (hipStream_t)stream, A, B, C, bias, M, N, K,
-                       (long long)sAm, (long long)sAk, (long long)sBk, (long long)sBn, (long long)ldc, act, slope, accumulate);
+    if ((long long)M * N <= 16384 && K >= 128)
+        hipLaunchKernelGGL(naive_gemm_wave_kernel, dim3((unsigned)(((long long)M * N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, A, B, C, bias,
+                           M, N, K, (long long)sAm, (long long)sAk, (long long)sBk, (long long)sBn, (long long)ldc, act, slope, accumulate);
+    else
+        hipLaunchKernelGGL(naive_gemm_kernel, dim3(grid_for((long long)M * N)), dim3(256), 0, (hipStream_t)stream, A, B, C, bias, M, N, K,
+                           (long long)sAm, (long long)sAk, (long long)sBk, (long long)sBn, (long long)ldc, act, slope, accumulate);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
