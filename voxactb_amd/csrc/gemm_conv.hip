@@ -15,6 +15,7 @@
 // ds_read_b32 per lane (lane l: A[m = l&31][k = l>>5]).  Global loads of tile t+1 are issued into
 // registers before the MFMAs of tile t (register double buffering), one barrier pair per tile.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -580,10 +581,16 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs g, const u16* _
             a_b[i] = r;
         }
     }
-    float4 ra[A_F4];
-    uint4 rb[B_V8], rb_lo[X3 ? B_V8 : 1];
+    // NPF register sets of loads in flight.  The 64 x 64 tiles serve the few-row linear layers (act(), the released recipe's replay batch of
+    // 1: M = 2048): 256 workgroups of 16-128 k-tiles that each waited a memory round trip (~2 us) for 6 MFMAs per wave -- 35 us per launch,
+    // 48 launches per step.  With four tiles in flight (64 VGPRs; the accumulator is 16) the loop runs at the LDS / barrier rate.  Same k
+    // order, same sums.
+    constexpr int NPF = (BM == 64 && BN == 64 && AMODE == A_KCONTIG) ? 4 : 1;
+    float4 ra[NPF][A_F4];
+    uint4 rb[NPF][B_V8], rb_lo[NPF][X3 ? B_V8 : 1];
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt, auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
         const int k0 = kt * BK16;
         if (AMODE == A_KCONTIG) {
 #pragma unroll
@@ -592,7 +599,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs g, const u16* _
                 const int k = k0 + (tid & 7) * 4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (m < g.M && k < g.K) v = *reinterpret_cast<const float4*>(A + (long long)m * g.sAm + k);
-                ra[i] = v;
+                ra[SET][i] = v;
             }
         } else {
             const ConvGeom& c = g.cg;
@@ -622,7 +629,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs g, const u16* _
                     const long long vox = (((long long)a_b[i] * c.S_in + id) * c.S_in + ih) * c.S_in + iw;
                     v = *reinterpret_cast<const float4*>(src + vox * Cs + ch);
                 }
-                ra[i] = v;
+                ra[SET][i] = v;
             }
         }
 #pragma unroll
@@ -631,35 +638,36 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs g, const u16* _
             const int k = k0 + (tid & 3) * 8;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (n < g.N && k < g.K) v = *reinterpret_cast<const uint4*>(Bw + (long long)n * g.K + k);
-            rb[i] = v;
+            rb[SET][i] = v;
             if (X3) {
                 uint4 w = make_uint4(0u, 0u, 0u, 0u);
                 if (n < g.N && k < g.K) w = *reinterpret_cast<const uint4*>(Bw_lo + (long long)n * g.K + k);
-                rb_lo[i] = w;
+                rb_lo[SET][i] = w;
             }
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int r = (tid >> 3) + 32 * i, kq = (tid & 7) * 4;
             uint2 p;
-            p.x = pack_bf16(ra[i].x, ra[i].y);
-            p.y = pack_bf16(ra[i].z, ra[i].w);
+            p.x = pack_bf16(ra[SET][i].x, ra[SET][i].y);
+            p.y = pack_bf16(ra[SET][i].z, ra[SET][i].w);
             *reinterpret_cast<uint2*>(&As[r * LDS16 + kq]) = p;
             if (X3) {
                 // residuals a - float(hi): exact in fp32, then rounded to bf16
                 uint2 q;
-                q.x = pack_bf16(ra[i].x - __uint_as_float(p.x << 16), ra[i].y - __uint_as_float(p.x & 0xffff0000u));
-                q.y = pack_bf16(ra[i].z - __uint_as_float(p.y << 16), ra[i].w - __uint_as_float(p.y & 0xffff0000u));
+                q.x = pack_bf16(ra[SET][i].x - __uint_as_float(p.x << 16), ra[SET][i].y - __uint_as_float(p.x & 0xffff0000u));
+                q.y = pack_bf16(ra[SET][i].z - __uint_as_float(p.y << 16), ra[SET][i].w - __uint_as_float(p.y & 0xffff0000u));
                 *reinterpret_cast<uint2*>(&As[BM * LDS16 + r * LDS16 + kq]) = q;
             }
         }
 #pragma unroll
         for (int i = 0; i < B_V8; ++i) {
             const int r = (tid >> 2) + 64 * i, kq = (tid & 3) * 8;
-            *reinterpret_cast<uint4*>(&Bs[r * LDS16 + kq]) = rb[i];
-            if (X3) *reinterpret_cast<uint4*>(&Bs[BN * LDS16 + r * LDS16 + kq]) = rb_lo[i];
+            *reinterpret_cast<uint4*>(&Bs[r * LDS16 + kq]) = rb[SET][i];
+            if (X3) *reinterpret_cast<uint4*>(&Bs[BN * LDS16 + r * LDS16 + kq]) = rb_lo[SET][i];
         }
     };
 
@@ -672,12 +680,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs g, const u16* _
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nkt = (g.K + BK16 - 1) / BK16;
-    load_tile(0);
-    for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();
-        store_tile();
-        __syncthreads();
-        if (kt + 1 < nkt) load_tile(kt + 1);
+    auto mma_tile = [&]() {
         const int lk = (lane >> 5) * 8, lm = lane & 31;
 #pragma unroll
         for (int kk = 0; kk < BK16; kk += 16) {
@@ -709,6 +712,29 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs g, const u16* _
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    auto one_tile = [&](int kt, auto set_c) {
+        __syncthreads();
+        store_tile(set_c);
+        __syncthreads();
+        if (kt + NPF < nkt) load_tile(kt + NPF, set_c);
+        mma_tile();
+    };
+    if (NPF == 1) {
+        load_tile(0, std::integral_constant<int, 0>{});
+        for (int kt = 0; kt < nkt; ++kt) one_tile(kt, std::integral_constant<int, 0>{});
+    } else {
+        load_tile(0, std::integral_constant<int, 0>{});
+        if (1 < nkt) load_tile(1, std::integral_constant<int, 1 % NPF>{});
+        if (2 < nkt) load_tile(2, std::integral_constant<int, 2 % NPF>{});
+        if (3 < nkt) load_tile(3, std::integral_constant<int, 3 % NPF>{});
+#pragma unroll 1
+        for (int kt = 0; kt < nkt; kt += 4) {
+            one_tile(kt, std::integral_constant<int, 0>{});
+            if (kt + 1 < nkt) one_tile(kt + 1, std::integral_constant<int, 1 % NPF>{});
+            if (kt + 2 < nkt) one_tile(kt + 2, std::integral_constant<int, 2 % NPF>{});
+            if (kt + 3 < nkt) one_tile(kt + 3, std::integral_constant<int, 3 % NPF>{});
         }
     }
 
