@@ -14,9 +14,10 @@ ev = lu.create_agent(cfg)
 ev.build(training=False, device=0)
 dev = 'cuda:0'
 rs = synthetic.make_replay_sample(1, cfg.rlbench.cameras, (HW, HW), V, 4, seed=3)
-obs = {k: v.to(dev) for k, v in rs.items() if k.endswith(('_rgb', '_point_cloud')) or k == 'low_dim_state'}
-obs = {k: v.unsqueeze(0) if v.dim() < 5 and k != 'low_dim_state' else v for k, v in obs.items()}
-obs['low_dim_state'] = rs['low_dim_state'].to(dev)
+obs = {k: v.to(dev) for k, v in rs.items()
+       if k.endswith(('_rgb', '_point_cloud', '_camera_extrinsics', '_camera_intrinsics')) or k == 'low_dim_state'}
+for cam in cfg.rlbench.cameras:
+    obs['%s_camera_extrinsics' % cam][0, 0, 2, 3] = -1.0             # (a camera 1 m off the scene origin, as in bench.py)
 obs['lang_goal_emb'] = rs['lang_goal_emb'][0].to(dev)
 obs['lang_token_embs'] = rs['lang_token_embs'][0].to(dev)
 for i in range(3):
@@ -37,5 +38,5 @@ agg = timer.summary()
 tot = sum(d['ms'] for d in agg.values()) / 5
 calls = sum(d['calls'] for d in agg.values()) / 5
 print('act(): %.2f ms wall per call; %.2f ms in %d own kernels (event-timed, includes launch gaps inside a label)' % (wall, tot, calls))
-for label, d in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])[:14]:
+for label, d in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])[:24]:
     print('  %-46s calls %4d  %7.3f ms' % (label, d['calls'] // 5, d['ms'] / 5))

@@ -345,6 +345,12 @@ class PerceiverEngine:
         # ... also the weight gradients of the linear layers (>= 1024 rows) and of the two 5^3 convs (generic kernel, delayed scaling)
         self.generic_wgrad_f16 = os.environ.get('VOXACTB_GENERIC_WGRAD_F16', '1') != '0'
         self._grad_scales = {}            # per call site: the delayed fp16 operand scales of THIS engine's gradients (ops._GRAD_SCALE)
+        # inference with frozen weights (the evaluation agent's act()): the prepared forms of the weights -- bf16 planes / fragments of every
+        # linear layer, conv weight layouts, the polyphase W_eff and its fragments: 0.5 ms of a 6.5 ms act() -- are kept from call to call while
+        # the parameters' version counters, their storage and the precision are unchanged (load_state_dict bumps the counters)
+        self.freeze_weight_prep = False
+        self._prep_sig = None
+        self._weff_keep = None
 
     # -------------------------------------------------------------------------------------------------- helpers
     def _draw_seed(self):
@@ -509,14 +515,25 @@ class PerceiverEngine:
         require_cuda(vox, proprio, lang_token_embs)
         if self.two != (proprio_left is not None):
             raise VoxactbHipError('proprio_left is given exactly for the 2Robots encoder')
-        ops.new_step()
+        sig = None
+        if self.freeze_weight_prep and not training and not save:
+            first = next(iter(self.P.values()))
+            sig = (self.precision, sum(prm._version for prm in self.P.values()), first.data_ptr(), len(self.P))
+        reuse = sig is not None and sig == self._prep_sig and ops.CACHE_OWNER is self
+        if not reuse:
+            ops.new_step()
+            self._weff_keep = None
         ops.PRECISION = self.precision
         try:
-            if self._lin_weights is None:
-                self._lin_weights = [n for n, prm in self.P.items() if prm.dim() == 2 and n.endswith('.weight') and prm.numel() >= 4096]
-            ops.prepare_linear_weights([self.p(n) for n in self._lin_weights],
-                                       geglu=[self.p(n) for n in self._lin_weights if n.endswith('.fn.net.0.weight')],
-                                       f16_dgrad=save and self.precision == 'bf16x3' and self.wgrad_precision == 'fp16')
+            if not reuse:
+                if self._lin_weights is None:
+                    self._lin_weights = [n for n, prm in self.P.items() if prm.dim() == 2 and n.endswith('.weight') and prm.numel() >= 4096]
+                ops.prepare_linear_weights([self.p(n) for n in self._lin_weights],
+                                           geglu=[self.p(n) for n in self._lin_weights if n.endswith('.fn.net.0.weight')],
+                                           f16_dgrad=save and self.precision == 'bf16x3' and self.wgrad_precision == 'fp16')
+                self._prep_sig = sig
+                ops.CACHE_OWNER = self if sig is not None else None
+            self._frozen_now = sig is not None
             return self._forward(vox, proprio, lang_token_embs, training, save, seed, proprio_left)
         finally:
             ops.PRECISION = 'fp32'
@@ -593,7 +610,11 @@ class PerceiverEngine:
                         bias=self.p('up0.conv_up.0.conv3d.bias'), act=ops.ACT_LRELU)
         up2 = 'up0.conv_up.%d.conv3d' % (2 if s > 1 else 1)
         if s > 1:
-            Weff = ops.polyphase_weights(self.p(up2 + '.weight'), self.Lt(dev), s, self.kl)
+            if self._frozen_now and self._weff_keep is not None:
+                Weff = self._weff_keep
+            else:
+                Weff = ops.polyphase_weights(self.p(up2 + '.weight'), self.Lt(dev), s, self.kl)
+                self._weff_keep = Weff if self._frozen_now else None
             if ops.polyphase_fwd_ok(C, C, self.kl, B, G):
                 u0 = ops.conv3_polyphase_fwd(z1, Weff, C, B, G, k, s, self.p(up2 + '.bias').repeat(s ** 3), act=ops.ACT_LRELU)
             else:

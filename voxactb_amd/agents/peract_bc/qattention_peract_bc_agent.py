@@ -215,6 +215,8 @@ class QAttentionPerActBCAgent(Agent):
         else:
             for param in self._q.parameters():
                 param.requires_grad = False
+            # evaluation: the weights only change through load_weights() -- act() keeps their prepared forms (perceiver_lang_io.py: freeze_weight_prep)
+            self._q.encoder.engine().freeze_weight_prep = True
 
     def _make_q(self, dev, training):
         return QFunction(self._perceiver_encoder, self._voxelizer, self._bounds_offset, self._rotation_resolution, dev,
@@ -503,6 +505,7 @@ class QAttentionPerActBCAgent(Agent):
                 logging.warning("key %s not found in checkpoint" % k)
         self._q.load_state_dict(merged)
         self._q.encoder.engine()._grad_scales.clear()   # delayed fp16 operand scales belong to the weights that were just replaced
+        self._q.encoder.engine()._prep_sig = None       # ... and so do the prepared forms an evaluation agent keeps between act() calls
         if self._training:
             self._arena.broadcast_weights(0)            # every rank resumes from rank 0's file contents
 

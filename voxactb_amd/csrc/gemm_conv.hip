@@ -585,7 +585,8 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs g, const u16* _
     // 1: M = 2048): 256 workgroups of 16-128 k-tiles that each waited a memory round trip (~2 us) for 6 MFMAs per wave -- 35 us per launch,
     // 48 launches per step.  With four tiles in flight (64 VGPRs; the accumulator is 16) the loop runs at the LDS / barrier rate.  Same k
     // order, same sums.
-    constexpr int NPF = (BM == 64 && BN == 64 && AMODE == A_KCONTIG) ? 4 : 1;
+    // (also the 128 x 64 conv tiles: the patchify conv of a single sample is 63 workgroups of 250 k-tiles -- 0.37 ms of a 5.9 ms act())
+    constexpr int NPF = ((BM == 64 && BN == 64 && AMODE == A_KCONTIG) || (BM == 128 && BN == 64 && AMODE == A_CONV)) ? 4 : 1;
     float4 ra[NPF][A_F4];
     uint4 rb[NPF][B_V8], rb_lo[NPF][X3 ? B_V8 : 1];
 

@@ -133,8 +133,13 @@ def gemm_wfrag_geglu(wb):
     return f
 
 
+CACHE_OWNER = None       # the engine whose prepared weights fill the caches below (PerceiverEngine.forward: inference with frozen weights reuses them)
+
+
 def new_step():
     """weights change every optimizer step: drop the per-step bf16 weight copies."""
+    global CACHE_OWNER
+    CACHE_OWNER = None
     _WCACHE.clear()
     _FCACHE.clear()
     _F16CACHE.clear()
@@ -800,9 +805,15 @@ def conv3_polyphase_fwd(z, Weff, Cout, B, G, k, s, bias, act=ACT_NONE, label=Non
             # Weff [K][N] -> column blocks in perm8 order, hi | lo planes, MFMA fragment order: one gather pass through a cached table
             # (was: transposing gather 166 us + split + fragment shuffle 54 us per step)
             numel = Weff.numel()
-            idx = traced_index(('polyf', k, s, C, Cout, str(z.device)), tuple(Weff.shape),
-                               lambda I: _wfrag_index(I.t().view(s ** 3, Cout, K).index_select(0, st['perm8_long']).view(N, K), numel), z.device)
-            wf = gather_cvt(Weff, idx, 1, numel)
+            ck = ('polywf', Weff.data_ptr(), tuple(Weff.shape))
+            hit = _FCACHE.get(ck)          # (inference with frozen weights keeps W_eff and this; a training step clears it: new_step())
+            if hit is not None:
+                wf = hit[0]
+            else:
+                idx = traced_index(('polyf', k, s, C, Cout, str(z.device)), tuple(Weff.shape),
+                                   lambda I: _wfrag_index(I.t().view(s ** 3, Cout, K).index_select(0, st['perm8_long']).view(N, K), numel), z.device)
+                wf = gather_cvt(Weff, idx, 1, numel)
+                _FCACHE[ck] = (wf, Weff)
         else:
             wt = Weff.t().view(s ** 3, Cout, K).index_select(0, st['perm8_long']).view(N, K)
             wf = gemm_wfrag(split_planes(wt, npl))
