@@ -374,6 +374,11 @@ int vxb_conv3_c1_fwd_mfma(const float* u, const float* w, const float* bias, flo
                           vxb_stream_t stream);
 int vxb_conv3_c1_wgrad_mfma(const float* u, const float* dq, float* dw, float* db, float* part_ws, int B, int S,
                             vxb_stream_t stream);
+/* vxb_conv3_c1_wgrad_mfma on ONE fp16 product per term (this gradient is a leaf of the backward pass, perceiver_lang_io.py:466 backward):
+   dq * dq_scale[0] is the fp16 operand, the sums are multiplied by dq_scale[1]; dq_scale: device {2^k, 2^-k} with max |dq| * 2^k in
+   [2^14, 2^15) (vxb_absmax_scale_f32).  Same workspace as vxb_conv3_c1_wgrad_mfma. */
+int vxb_conv3_c1_wgrad_f16(const float* u, const float* dq, const float* dq_scale, float* dw, float* db, float* part_ws, int B, int S,
+                           vxb_stream_t stream);
 size_t vxb_conv3_c1_wgrad_mfma_blocks(int B, int S);
 
 /* The same two layers fused with the statistics / backward of the pooled features of THEIR OUTPUT (perceiver_lang_io.py:357

@@ -54,13 +54,25 @@ def test_c1_matrix_core_forward_and_wgrad(B, S, mode):
         assert ops.C1_MFMA
         q = ops.conv3_c1_fwd(ud, w1.detach().to(DEV), b1.detach().to(DEV), B, S)
         dw, dbb = torch.zeros(1, 64, 3, 3, 3, device=DEV), torch.zeros(1, device=DEV)
+        ops.C1_WGRAD_F16 = False
         ops.conv3_c1_wgrad(ud, dq.to(DEV), dw, dbb, B, S)
         dw2, db2 = torch.zeros_like(dw), torch.zeros_like(dbb)
         ops.conv3_c1_wgrad(ud, dq.to(DEV), dw2, db2, B, S)
+        # the shipped arithmetic of the default precision: one fp16 product per term, dq scaled by a device-side power of two
+        ops.C1_WGRAD_F16, ops.WGRAD_PRECISION = True, 'fp16'
+        dw16, db16 = torch.zeros_like(dw), torch.zeros_like(dbb)
+        ops.conv3_c1_wgrad(ud, dq.to(DEV), dw16, db16, B, S)
+        dw16b = torch.zeros_like(dw)
+        ops.conv3_c1_wgrad(ud, (dq * 1e-7).to(DEV), dw16b, torch.zeros_like(dbb), B, S)       # softmax - onehot far from a peak: ~1e-7
         ops.C1_MFMA = False
         q_exact = ops.conv3_c1_fwd(ud, w1.detach().to(DEV), b1.detach().to(DEV), B, S)
     finally:
-        ops.PRECISION, ops.C1_MFMA = 'fp32', True
+        ops.PRECISION, ops.C1_MFMA, ops.C1_WGRAD_F16, ops.WGRAD_PRECISION = 'fp32', True, True, ''
+    if mode == 'bf16x3':
+        close(dw16, w1.grad.float(), 1e-3, 'c1 fp16 wgrad')
+        close(dw16b * 1e7, w1.grad.float(), 1e-3, 'c1 fp16 wgrad, tiny dq')
+        close(db16, b1.grad.float(), 3e-5, 'c1 fp16 db')
+        assert not torch.equal(dw16, dw)
     close(q, q_ref[:, 0].float(), 2e-5, 'c1 mfma fwd')
     close(q, q_exact, 2e-5, 'c1 mfma fwd vs exact kernel')
     close(dw, w1.grad.float(), 3e-5, 'c1 mfma wgrad')

@@ -14,6 +14,7 @@
 //             ds_read_b64_tr_b16 into v_mfma_f32_16x16x32_bf16 (k = 32 voxels), exactly like wgrad_halo.hip.
 // Products are bf16x3 (hi*hi + hi*lo + lo*hi, fp32 accumulate) in both precisions: the pass is HBM-bound either way.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -144,9 +145,17 @@ __device__ __forceinline__ bf16x8 cm_frag(const u16* p0, const u16* p1) {
 }
 
 // part[blk][c * 27 + t], partB[blk]: partial sums of workgroup blk over its run of voxel tiles (summed by c1_reduce_kernel)
+// F16 = 1 (round 4): ONE fp16 product per term -- this weight gradient is a leaf of the backward pass like the other conv weight
+// gradients -- with dq * scale[0] (a device-side power of two that brings max |dq| into [2^14, 2^15): dq = softmax - onehot
+// spans 1 .. 1e-9) and the sums multiplied by scale[1].  The bf16x3 form spends 24 VALU instructions per MFMA on the hi / lo splits of u
+// and of the 128 x 32 Bq tile (2.6 TB/s for a pass that reads u once); fp16 needs a third of the MFMAs and a quarter of the conversions.
+typedef _Float16 cm_f16x8 __attribute__((ext_vector_type(8)));
+template <int F16>
 __global__ void __launch_bounds__(256, 2) c1_wgrad_mfma_kernel(const float* __restrict__ u, const float* __restrict__ dq,
                                                               float* __restrict__ part, float* __restrict__ partB, int B, int S,
-                                                              int ntd, int nth, int ntw, long long ntiles, int tiles_per_block) {
+                                                              int ntd, int nth, int ntw, long long ntiles, int tiles_per_block,
+                                                              const float* __restrict__ scale) {
+    const float qsc = F16 ? scale[0] : 1.f, qinv = F16 ? scale[1] : 1.f;
     extern __shared__ __attribute__((aligned(16))) u16 gsm[];
     u16* us = gsm;                                                 // [plane][128 voxels][ULD]
     u16* bs = gsm + 2 * UPL;                                       // [plane][128 voxels][BLD]
@@ -161,9 +170,14 @@ __global__ void __launch_bounds__(256, 2) c1_wgrad_mfma_kernel(const float* __re
     acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     float accb = 0.f;
 
-    float4 pu[8];
-    float pq[2];
-    auto issue = [&](long long tile) {
+    // two register sets of loads: the tiles t + 1 and t + 2 are in flight while tile t is converted and multiplied (one set left the
+    // loads in flight only between a tile's staging and the next one's: 2.6 TB/s for a pass that reads u once)
+    float4 pu2[2][8];
+    float pq2[2][2];
+    auto issue = [&](long long tile, auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
+        float4 (&pu)[8] = pu2[SET];
+        float (&pq)[2] = pq2[SET];
         long long t = tile;
         const int tw = (int)(t % ntw); t /= ntw;
         const int th = (int)(t % nth); t /= nth;
@@ -195,8 +209,10 @@ __global__ void __launch_bounds__(256, 2) c1_wgrad_mfma_kernel(const float* __re
     const int g4 = lane >> 4, tl = lane & 15;
     const int fh = 2 * (g4 >> 1), fw = 4 * (g4 & 1) + (tl >> 2), fc = 4 * (tl & 3);
 
-    if (t_begin < t_end) issue(t_begin);
-    for (long long tile = t_begin; tile < t_end; ++tile) {
+    auto one_tile = [&](long long tile, auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
+        float4 (&pu)[8] = pu2[SET];
+        float (&pq)[2] = pq2[SET];
         long long t = tile;
         const int tw = (int)(t % ntw); t /= ntw;
         const int th = (int)(t % nth); t /= nth;
@@ -207,9 +223,15 @@ __global__ void __launch_bounds__(256, 2) c1_wgrad_mfma_kernel(const float* __re
         for (int i = 0; i < 8; ++i) {
             const int e = tid + 256 * i;
             uint2 hi2, lo2;
-            cm_split2(pu[i].x, pu[i].y, hi2.x, lo2.x); cm_split2(pu[i].z, pu[i].w, hi2.y, lo2.y);
-            *reinterpret_cast<uint2*>(&us[(e >> 4) * ULD + (e & 15) * 4]) = hi2;
-            *reinterpret_cast<uint2*>(&us[UPL + (e >> 4) * ULD + (e & 15) * 4]) = lo2;
+            if (F16) {
+                hi2.x = vxb_pack_f16(__builtin_amdgcn_fmed3f(pu[i].x, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(pu[i].y, -65504.f, 65504.f));
+                hi2.y = vxb_pack_f16(__builtin_amdgcn_fmed3f(pu[i].z, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(pu[i].w, -65504.f, 65504.f));
+                *reinterpret_cast<uint2*>(&us[(e >> 4) * ULD + (e & 15) * 4]) = hi2;
+            } else {
+                cm_split2(pu[i].x, pu[i].y, hi2.x, lo2.x); cm_split2(pu[i].z, pu[i].w, hi2.y, lo2.y);
+                *reinterpret_cast<uint2*>(&us[(e >> 4) * ULD + (e & 15) * 4]) = hi2;
+                *reinterpret_cast<uint2*>(&us[UPL + (e >> 4) * ULD + (e & 15) * 4]) = lo2;
+            }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -222,7 +244,7 @@ __global__ void __launch_bounds__(256, 2) c1_wgrad_mfma_kernel(const float* __re
             }
         }
         __syncthreads();
-        if (tile + 1 < t_end) issue(tile + 1);
+        if (tile + 2 < t_end) issue(tile + 2, set_c);
         // ---- Bq[v'][t]: 128 x 27 entries (columns 27..31 are written as zeros).  A thread keeps its tap (tid & 31) and its
         // w position ((tid >> 5) & 7) for all 16 entries; tiles that touch no face of the cube read one dq per entry at a
         // compile-time offset from a per-thread base
@@ -235,6 +257,7 @@ __global__ void __launch_bounds__(256, 2) c1_wgrad_mfma_kernel(const float* __re
             for (int i = 0; i < 16; ++i) {
                 const int pos = lw + 8 * i;                         // lh = i & 7, ld = i >> 3
                 const float v = tp < 27 ? dbase[((i >> 3) * QH_H + (i & 7)) * QH_W] : 0.f;
+                if (F16) { bs[pos * BLD + tp] = (u16)(vxb_pack_f16(v * qsc, 0.f) & 0xffffu); continue; }
                 const unsigned hb = __float_as_uint(v);
                 const unsigned h16 = (hb + 0x7fffu + ((hb >> 16) & 1u)) >> 16;
                 const unsigned rb = __float_as_uint(v - __uint_as_float(h16 << 16));
@@ -262,6 +285,7 @@ __global__ void __launch_bounds__(256, 2) c1_wgrad_mfma_kernel(const float* __re
                         }
                 if (gd >= S || gh >= S || gw >= S) v = 0.f;
             }
+            if (F16) { bs[pos * BLD + tp] = (u16)(vxb_pack_f16(v * qsc, 0.f) & 0xffffu); continue; }
             const unsigned hb = __float_as_uint(v);
             // scalar bf16 split (one value): hi = RNE(v), lo = RNE(v - hi)
             unsigned h16 = (hb + 0x7fffu + ((hb >> 16) & 1u)) >> 16;
@@ -280,7 +304,16 @@ __global__ void __launch_bounds__(256, 2) c1_wgrad_mfma_kernel(const float* __re
             const u16* ua1 = ua0 + GT_W * ULD;
             const u16* bb0 = bs + vox * BLD + fc;
             const u16* bb1 = bb0 + GT_W * BLD;
-            const bf16x8 ah = cm_frag(ua0, ua1), al = cm_frag(ua0 + UPL, ua1 + UPL);
+            const bf16x8 ah = cm_frag(ua0, ua1);
+            if (F16) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bf16x8 bh = cm_frag(bb0 + 16 * j, bb1 + 16 * j);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cm_f16x8, ah), __builtin_bit_cast(cm_f16x8, bh), acc[j], 0, 0, 0);
+                }
+                continue;
+            }
+            const bf16x8 al = cm_frag(ua0 + UPL, ua1 + UPL);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const bf16x8 bh = cm_frag(bb0 + 16 * j, bb1 + 16 * j), bl = cm_frag(bb0 + BPL + 16 * j, bb1 + BPL + 16 * j);
@@ -289,6 +322,13 @@ __global__ void __launch_bounds__(256, 2) c1_wgrad_mfma_kernel(const float* __re
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[j], 0, 0, 0);
             }
         }
+    };
+    if (t_begin < t_end) issue(t_begin, std::integral_constant<int, 0>{});
+    if (t_begin + 1 < t_end) issue(t_begin + 1, std::integral_constant<int, 1>{});
+#pragma unroll 1
+    for (long long tile = t_begin; tile < t_end; tile += 2) {
+        one_tile(tile, std::integral_constant<int, 0>{});
+        if (tile + 1 < t_end) one_tile(tile + 1, std::integral_constant<int, 1>{});
     }
     // D tile (16 c x 16 taps): lane l holds column (tap) l & 15, rows (channels) 4 (l >> 4) + r
     float* __restrict__ pw_ = part + (long long)blockIdx.x * 64 * 27;
@@ -297,7 +337,7 @@ __global__ void __launch_bounds__(256, 2) c1_wgrad_mfma_kernel(const float* __re
         const int tp = 16 * j + tl;
         if (tp < 27) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pw_[(16 * wid + 4 * g4 + r) * 27 + tp] = acc[j][r];
+            for (int r = 0; r < 4; ++r) pw_[(16 * wid + 4 * g4 + r) * 27 + tp] = F16 ? acc[j][r] * qinv : acc[j][r];
         }
     }
     accb = wave_sum(accb);
@@ -344,8 +384,8 @@ extern "C" int vxb_conv3_c1_fwd_mfma(const float* u, const float* w, const float
 
 // dw [64][27] += sum_v dq[v] * u[clamp(v + t - 1)][c], db[0] += sum dq -- matrix-core version of vxb_conv3_c1_wgrad_f32.
 // part_ws: nblocks * (64 * 27 + 1) floats with nblocks = vxb_conv3_c1_wgrad_mfma_blocks(B, S).
-extern "C" int vxb_conv3_c1_wgrad_mfma(const float* u, const float* dq, float* dw, float* db, float* part_ws, int B, int S,
-                                       vxb_stream_t stream) {
+static int c1_wgrad_mfma_launch(const float* u, const float* dq, const float* dq_scale, float* dw, float* db, float* part_ws, int B, int S,
+                                vxb_stream_t stream) {
     if (!u || !dq || !dw || !db || !part_ws || B < 1 || S < 2) return VXB_EARG;
     if (((uintptr_t)u) & 15) return VXB_ESIZE;
     const int ntd = vxb_cdiv(S, GT_D), nth = vxb_cdiv(S, GT_H), ntw = vxb_cdiv(S, GT_W);
@@ -357,12 +397,30 @@ extern "C" int vxb_conv3_c1_wgrad_mfma(const float* u, const float* dq, float* d
     float* pB = part_ws + (size_t)nblk * 64 * 27;
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)(2 * UPL + 2 * BPL) * sizeof(u16) + (size_t)(QNPOS + 4) * sizeof(float);
-    if (hipFuncSetAttribute((const void*)c1_wgrad_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
-    hipLaunchKernelGGL(c1_wgrad_mfma_kernel, dim3(nblk), dim3(256), lds, st, u, dq, pW, pB, B, S, ntd, nth, ntw, ntiles, tpb);
+    if (dq_scale) {
+        if (hipFuncSetAttribute((const void*)c1_wgrad_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
+        hipLaunchKernelGGL(c1_wgrad_mfma_kernel<1>, dim3(nblk), dim3(256), lds, st, u, dq, pW, pB, B, S, ntd, nth, ntw, ntiles, tpb, dq_scale);
+    } else {
+        if (hipFuncSetAttribute((const void*)c1_wgrad_mfma_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
+        hipLaunchKernelGGL(c1_wgrad_mfma_kernel<0>, dim3(nblk), dim3(256), lds, st, u, dq, pW, pB, B, S, ntd, nth, ntw, ntiles, tpb, dq_scale);
+    }
     hipLaunchKernelGGL(c1m_reduce_kernel, dim3(27), dim3(256), 0, st, pW, nblk, 64 * 27, dw);
     hipLaunchKernelGGL(c1m_reduce_kernel, dim3(1), dim3(256), 0, st, pB, nblk, 1, db);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
+}
+
+extern "C" int vxb_conv3_c1_wgrad_mfma(const float* u, const float* dq, float* dw, float* db, float* part_ws, int B, int S,
+                                       vxb_stream_t stream) {
+    return c1_wgrad_mfma_launch(u, dq, nullptr, dw, db, part_ws, B, S, stream);
+}
+
+// The same weight gradient on ONE fp16 product per term (a leaf of the backward pass): dq * dq_scale[0] as the fp16 operand, the sums
+// times dq_scale[1]; dq_scale: device {2^k, 2^-k} with max |dq| * 2^k in [2^14, 2^15) (vxb_absmax_scale_f32).  db is summed in fp32 as before.
+extern "C" int vxb_conv3_c1_wgrad_f16(const float* u, const float* dq, const float* dq_scale, float* dw, float* db, float* part_ws, int B,
+                                      int S, vxb_stream_t stream) {
+    if (!dq_scale) return VXB_EARG;
+    return c1_wgrad_mfma_launch(u, dq, dq_scale, dw, db, part_ws, B, S, stream);
 }
 
 extern "C" size_t vxb_conv3_c1_wgrad_mfma_blocks(int B, int S) {

@@ -1258,10 +1258,20 @@ def conv3_c1_dgrad_ss3d(dq, w, u, du, B, S, stats, out_ss, argmax, g_ss, g_max, 
     return (du, sc) if want_scale else du
 
 
+C1_WGRAD_F16 = os.environ.get('VOXACTB_C1_WGRAD_F16', '1') != '0'    # trans_decoder weight gradient on single fp16 products ('0': bf16x3)
+
+
 def conv3_c1_wgrad(u, dq, dw, db, B, S):
     if C1_MFMA and _mm() and u.shape[-1] == 64:
         nb = int(_lib.lib().vxb_conv3_c1_wgrad_mfma_blocks(B, S))
         ws = torch.empty(nb * (64 * 27 + 1), dtype=torch.float32, device=u.device)
+        if C1_WGRAD_F16 and PRECISION == 'bf16x3' and WGRAD_PRECISION == 'fp16' and dq.is_contiguous():
+            # a leaf of the backward pass: one fp16 product per term, dq scaled by a device-side power of two (max |dq| -> [2^14, 2^15))
+            _lib.set_meta('vxb_conv3_c1_wgrad_mfma', 0.0)
+            sc = absmax_scale(dq)
+            _lib.set_meta('vxb_conv3_c1_wgrad_mfma', 0.0)
+            call('vxb_conv3_c1_wgrad_f16', u, dq, sc, dw, db, ws, B, S)
+            return
         _lib.set_meta('vxb_conv3_c1_wgrad_mfma', 0.0)
         call('vxb_conv3_c1_wgrad_mfma', u, dq, dw, db, ws, B, S)
         return
