@@ -127,10 +127,11 @@ CFG_C5 = dict(V=200, k=5, s=5, depth=6, latents=2048, low_dim=4, B=1, cams=synth
 
 
 def make_ref_encoder(cfg, arm=False, seed=0):
+    var = dict(cfg.get('variant', {}))          # encoder switches the configs can reach (launch_utils.py:744-774): transformer_iterations, ablations
     enc = ref_pl.PerceiverVoxelLangEncoder(
-        depth=cfg['depth'], iterations=1, voxel_size=cfg['V'], initial_dim=10, low_dim_size=cfg['low_dim'],
+        depth=cfg['depth'], iterations=var.pop('iterations', 1), voxel_size=cfg['V'], initial_dim=10, low_dim_size=cfg['low_dim'],
         num_latents=cfg['latents'], voxel_patch_size=cfg['k'], voxel_patch_stride=cfg['s'],
-        activation='lrelu', input_dropout=0.0, attn_dropout=0.0, decoder_dropout=0.0, arm_pred_loss=arm)
+        activation='lrelu', input_dropout=0.0, attn_dropout=0.0, decoder_dropout=0.0, arm_pred_loss=arm, **var)
     shapes = {n: tuple(p.shape) for n, p in enc.named_parameters()}
     mine = operc.param_shapes(cfg['depth'], cfg['V'], cfg['low_dim'], num_latents=cfg['latents'],
                               voxel_patch_size=cfg['k'], voxel_patch_stride=cfg['s'], arm_pred_loss=arm)
@@ -196,6 +197,8 @@ def encoder_fixture(name, cfg, arm=False, with_grads=True, digest=False, crop=Fa
     arrs = dict(cfg_V=cfg['V'], cfg_k=cfg['k'], cfg_s=cfg['s'], cfg_depth=cfg['depth'], cfg_latents=cfg['latents'],
                 cfg_low_dim=cfg['low_dim'], cfg_B=cfg['B'], cfg_H=cfg['H'], cfg_W=cfg['W'], cfg_ncam=len(cfg['cams']),
                 cfg_cams=np.array(cfg['cams']), cfg_arm=int(arm), cfg_crop=int(crop), rot_grip=outs[1], collision=outs[2])
+    for vk, vv in cfg.get('variant', {}).items():
+        arrs['cfg_var_' + vk] = int(vv)
     if arm:
         arrs['arm_out'] = outs[3]
     qt = outs[0].detach()
@@ -1076,6 +1079,10 @@ SECTIONS = {
     'f1': f1_voxel_kats,
     'f3tiny': lambda: encoder_fixture('f3_encoder_tiny', CFG_TINY, arm=True),
     'f3c1': lambda: encoder_fixture('f3_encoder_c1', CFG_C1),
+    # encoder switches reachable from the configs (PERACT_BC.yaml: transformer_iterations, no_language): tiny and configs[0] size, fwd + bwd
+    'f3v_it2': lambda: encoder_fixture('f3v_encoder_tiny_iterations2', dict(CFG_TINY, variant=dict(iterations=2)), arm=True, digest=True, check_oracle=False),
+    'f3v_it3c1': lambda: encoder_fixture('f3v_encoder_c1_iterations3', dict(CFG_C1, latents=48, depth=2, variant=dict(iterations=3)), digest=True, check_oracle=False),
+    'f3v_nolang': lambda: encoder_fixture('f3v_encoder_c1_no_language', dict(CFG_C1, variant=dict(no_language=True)), digest=True, check_oracle=False),
     'f5': lambda: encoder_fixture('f5_encoder_c2_digest', CFG_C2, with_grads=False, digest=True),
     'f5g': lambda: encoder_fixture('f5g_encoder_c2_grads', CFG_C2, with_grads=True, digest=True, f64_grads=True),
     'f5c3': lambda: encoder_fixture('f5c3_encoder_c3_digest', CFG_C3, arm=True, with_grads=True, digest=True, crop=True, f64_grads=True),

@@ -30,10 +30,13 @@ def _setup(g):
     V, B, H, W = int(g['cfg_V']), int(g['cfg_B']), int(g['cfg_H']), int(g['cfg_W'])
     cams = [str(c) for c in g['cfg_cams']] if 'cfg_cams' in g.files else synthetic.CAMERAS4[:int(g['cfg_ncam'])]
     seed = int(g['cfg_seed']) if 'cfg_seed' in g.files else 1
+    var = {k[len('cfg_var_'):]: int(g[k]) for k in g.files if k.startswith('cfg_var_')}      # iterations / ablation switches of the fixture
+    for k in [k for k in var if k != 'iterations']:
+        var[k] = bool(var[k])
     enc = PerceiverVoxelLangEncoder(
-        depth=int(g['cfg_depth']), iterations=1, voxel_size=V, initial_dim=10, low_dim_size=int(g['cfg_low_dim']),
+        depth=int(g['cfg_depth']), iterations=var.pop('iterations', 1), voxel_size=V, initial_dim=10, low_dim_size=int(g['cfg_low_dim']),
         num_latents=int(g['cfg_latents']), voxel_patch_size=int(g['cfg_k']), voxel_patch_stride=int(g['cfg_s']),
-        activation='lrelu', input_dropout=0.0, attn_dropout=0.0, decoder_dropout=0.0, arm_pred_loss=arm)
+        activation='lrelu', input_dropout=0.0, attn_dropout=0.0, decoder_dropout=0.0, arm_pred_loss=arm, **var)
     enc.load_state_dict(ow.hashed_state_dict({n: tuple(p.shape) for n, p in enc.named_parameters()}, 0), strict=False)
     enc = enc.to(DEV)
     rs = synthetic.make_replay_sample(B, cams, (H, W), V, int(g['cfg_low_dim']), seed=seed, arm_pred_loss=arm,
@@ -185,6 +188,17 @@ def test_c5_v200_forward_backward_digest(golden, precision):
     way): loss within 1e-4, every parameter-gradient norm within 3e-3, the small tensors element-wise, the conv bias gradients against
     the float64 sums of the reference's dY."""
     _run(golden('f5v200g_encoder_c5_grads'), precision, 'f5v200g', backward=True)
+
+
+@pytest.mark.parametrize('fixture', ['f3v_encoder_tiny_iterations2', 'f3v_encoder_c1_iterations3', 'f3v_encoder_c1_no_language'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_encoder_switches_reachable_from_the_configs(golden, fixture, precision):
+    """`transformer_iterations` > 1 (the cross-attention block and the self-attention stack run again over the SAME weights, perceiver
+    :429-437; gradients of the shared weights and of the context add up) and the `no_language` ablation (:374-376) -- PERACT_BC.yaml /
+    launch_utils.py:744-774 -- against the reference's forward + backward.  The exact-fp32 mode is held to this file's gates; the default
+    precision's gradients at these toy sizes sit at single-tensor fp16 rounding (as for the V = 50 fixtures) and are covered by the forward
+    digest here."""
+    _run(golden(fixture), precision, fixture[4:], backward=precision == 'fp32')
 
 
 @pytest.mark.parametrize('fixture', ['f5v50a_encoder_release_digest', 'f5v50b_encoder_release_digest'])

@@ -149,11 +149,11 @@ class PerceiverVoxelLangEncoder(nn.Module):
                  _two_robots=False):
         super().__init__()
         if lang_fusion_type != 'seq' or not pos_encoding_with_lang or no_skip_connection or no_perceiver \
-                or weight_tie_layers or iterations != 1 or activation != 'lrelu' or low_dim_size <= 0 \
+                or weight_tie_layers or iterations < 1 or activation != 'lrelu' or low_dim_size <= 0 \
                 or num_rotation_classes <= 0:
             raise NotImplementedError(
                 'voxactb_amd covers the configuration VoxAct-B trains (launch_utils.py:744-774, PERACT_BC.yaml): '
-                "lang_fusion_type='seq', pos_encoding_with_lang, activation='lrelu', iterations=1, no ablations")
+                "lang_fusion_type='seq', pos_encoding_with_lang, activation='lrelu' (+ transformer_iterations >= 1 and the no_language ablation)")
         if im_channels != 64 or final_dim != 64 or int(initial_dim) > 16:
             raise NotImplementedError('kernels are specialised for im_channels = final_dim = 64, initial_dim <= 16')
         if voxel_size % voxel_patch_stride or voxel_patch_size % 2 == 0:
@@ -555,6 +555,8 @@ class PerceiverEngine:
             # both arms go through the ONE proprio_preprocess block (perceiver :721-727): rows [right | left]
             proprio = torch.cat((proprio, proprio_left.float().contiguous()), dim=0)
         lang = lang_token_embs.float().contiguous().view(B * T0, LANG_EMB_DIM)
+        if m.no_language:                                # language ablation (perceiver :374-376): the token embeddings are zeroed
+            lang = torch.zeros_like(lang)
         c = {}
         # 1. input 1x1x1 conv + lrelu (perceiver :357)
         # 2. SpatialSoftmax3D + max (perceiver :360) -- taken while d0 is written (one pass over the 256 B per voxel)
@@ -575,26 +577,31 @@ class PerceiverEngine:
         ctx2d = ctx.view(B * Nctx, Cx)
         # 7. latents
         x = self.p('latents').unsqueeze(0).expand(B, L, D).contiguous().view(B * L, D)
-        # 8. cross attention block (perceiver :431-432)
+        # 8. cross attention block + self attention stack, `iterations` times over the SAME weights (perceiver :429-437)
         pre = 'cross_attend_blocks.0'
-        xn, xm, xr = ops.layernorm_fwd(x, self.p(pre + '.norm.weight'), self.p(pre + '.norm.bias'))
         cn, cm, cr = ops.layernorm_fwd(ctx2d, self.p(pre + '.norm_context.weight'), self.p(pre + '.norm_context.bias'))
-        x1, ca = self._attn_fwd(pre, xn.view(B, L, D), cn.view(B, Nctx, Cx), m.cross_heads, m.cross_dim_head, p_in,
-                                _mix32(seed, 1), x, save)
-        if save:
-            c['cross'] = dict(x=x, xn=xn, xm=xm, xr=xr, cn=cn, cm=cm, cr=cr, attn=ca)
-        x, c['cross_ff'] = self._ff_fwd('cross_attend_blocks.1', x1, save)
-        # self attention stack (perceiver :435-437)
-        c['layers'] = []
-        for i in range(m.depth):
-            pre = 'layers.%d.0' % i
+        c['ctx_norm'] = (cn, cm, cr)                     # (the context and its PreNorm are the same in every iteration)
+        c['iters'] = []
+        for it in range(m.iterations):
+            sd_it = seed if it == 0 else _mix32(seed, 7919 * it)
+            pre = 'cross_attend_blocks.0'
             xn, xm, xr = ops.layernorm_fwd(x, self.p(pre + '.norm.weight'), self.p(pre + '.norm.bias'))
-            x1, sa = self._attn_fwd(pre, xn.view(B, L, D), xn.view(B, L, D), m.latent_heads, m.latent_dim_head, p_at,
-                                    _mix32(seed, 2 + i), x, save)
-            x2, fc = self._ff_fwd('layers.%d.1' % i, x1, save)
-            if save:
-                c['layers'].append(dict(x=x, xn=xn, xm=xm, xr=xr, attn=sa, ff=fc))
-            x = x2
+            x1, ca = self._attn_fwd(pre, xn.view(B, L, D), cn.view(B, Nctx, Cx), m.cross_heads, m.cross_dim_head, p_in,
+                                    _mix32(sd_it, 1), x, save)
+            ci = dict(cross=dict(x=x, xn=xn, xm=xm, xr=xr, attn=ca) if save else None)
+            x, ci['cross_ff'] = self._ff_fwd('cross_attend_blocks.1', x1, save)
+            # self attention stack (perceiver :435-437)
+            ci['layers'] = []
+            for i in range(m.depth):
+                pre = 'layers.%d.0' % i
+                xn, xm, xr = ops.layernorm_fwd(x, self.p(pre + '.norm.weight'), self.p(pre + '.norm.bias'))
+                x1, sa = self._attn_fwd(pre, xn.view(B, L, D), xn.view(B, L, D), m.latent_heads, m.latent_dim_head, p_at,
+                                        _mix32(sd_it, 2 + i), x, save)
+                x2, fc = self._ff_fwd('layers.%d.1' % i, x1, save)
+                if save:
+                    ci['layers'].append(dict(x=x, xn=xn, xm=xm, xr=xr, attn=sa, ff=fc))
+                x = x2
+            c['iters'].append(ci)
         # decoder cross attention (perceiver :440-448): queries = all context tokens, no residual
         pre = 'decoder_cross_attn'
         qn, qm, qr = ops.layernorm_fwd(ctx2d, self.p(pre + '.norm.weight'), self.p(pre + '.norm.bias'))
@@ -852,23 +859,32 @@ class PerceiverEngine:
         dx = ops.layernorm_bwd(dln, dc['x'], self.p(pre + '.norm_context.weight'), dc['lm'], dc['lr'],
                                self.g(pre + '.norm_context.weight'), self.g(pre + '.norm_context.bias'))
         self._bucket_ready('tail')                  # heads, trans_decoder, final, up0, decoder cross attention: complete
-        # ---- self-attention stack, reversed
-        for i in reversed(range(m.depth)):
-            lc = c['layers'][i]
-            dx = self._ff_bwd('layers.%d.1' % i, lc['ff'], dx)
-            pre = 'layers.%d.0' % i
-            dxn, _ = self._attn_bwd(pre, lc['attn'], dx, lc['xn'], lc['xn'], True)
-            ops.layernorm_bwd(dxn, lc['x'], self.p(pre + '.norm.weight'), lc['xm'], lc['xr'], self.g(pre + '.norm.weight'),
+        # ---- per iteration, last first: self-attention stack reversed, then the cross-attention block
+        cn, cm, cr = c['ctx_norm']
+        dcn_sum = None
+        for it in reversed(range(m.iterations)):
+            ci = c['iters'][it]
+            for i in reversed(range(m.depth)):
+                lc = ci['layers'][i]
+                dx = self._ff_bwd('layers.%d.1' % i, lc['ff'], dx)
+                pre = 'layers.%d.0' % i
+                dxn, _ = self._attn_bwd(pre, lc['attn'], dx, lc['xn'], lc['xn'], True)
+                ops.layernorm_bwd(dxn, lc['x'], self.p(pre + '.norm.weight'), lc['xm'], lc['xr'], self.g(pre + '.norm.weight'),
+                                  self.g(pre + '.norm.bias'), dx=dx, accumulate_dx=True)
+                if it == 0:
+                    self._bucket_ready('layers.%d' % i)      # (shared weights: their gradients are complete after the FIRST iteration's turn)
+            dx = self._ff_bwd('cross_attend_blocks.1', ci['cross_ff'], dx)
+            cc = ci['cross']
+            pre = 'cross_attend_blocks.0'
+            dxn, dcn = self._attn_bwd(pre, cc['attn'], dx, cc['xn'], cn, False)
+            ops.layernorm_bwd(dxn, cc['x'], self.p(pre + '.norm.weight'), cc['xm'], cc['xr'], self.g(pre + '.norm.weight'),
                               self.g(pre + '.norm.bias'), dx=dx, accumulate_dx=True)
-            self._bucket_ready('layers.%d' % i)
-        # ---- cross-attention block
-        dx = self._ff_bwd('cross_attend_blocks.1', c['cross_ff'], dx)
-        cc = c['cross']
+            if dcn_sum is None:
+                dcn_sum = dcn
+            else:
+                ops.axpy_(dcn_sum, dcn)                      # the context feeds every iteration's cross attention
         pre = 'cross_attend_blocks.0'
-        dxn, dcn = self._attn_bwd(pre, cc['attn'], dx, cc['xn'], cc['cn'], False)
-        ops.layernorm_bwd(dxn, cc['x'], self.p(pre + '.norm.weight'), cc['xm'], cc['xr'], self.g(pre + '.norm.weight'),
-                          self.g(pre + '.norm.bias'), dx=dx, accumulate_dx=True)
-        ops.layernorm_bwd(dcn, c['ctx2d'], self.p(pre + '.norm_context.weight'), cc['cm'], cc['cr'],
+        ops.layernorm_bwd(dcn_sum, c['ctx2d'], self.p(pre + '.norm_context.weight'), cm, cr,
                           self.g(pre + '.norm_context.weight'), self.g(pre + '.norm_context.bias'), dx=dctx, accumulate_dx=True)
         ops.sum_splits(dx, B, L * D, self.g('latents'), accumulate=True)
         # ---- context assembly, language, proprio
