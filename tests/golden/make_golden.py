@@ -1087,6 +1087,7 @@ SECTIONS = {
     'f3v_it3c1': lambda: encoder_fixture('f3v_encoder_c1_iterations3', dict(CFG_C1, latents=48, depth=2, variant=dict(iterations=3)), digest=True, check_oracle=False),
     'f3v_noskip': lambda: encoder_fixture('f3v_encoder_c1_no_skip_connection', dict(CFG_C1, variant=dict(no_skip_connection=True)), digest=True, check_oracle=False),
     'f3v_noperc': lambda: encoder_fixture('f3v_encoder_c1_no_perceiver', dict(CFG_C1, variant=dict(no_perceiver=True)), digest=True, check_oracle=False),
+    'f3v_posgrid': lambda: encoder_fixture('f3v_encoder_c1_pos_encoding_grid_only', dict(CFG_C1, variant=dict(pos_encoding_with_lang=False)), digest=True, check_oracle=False),
     'f3v_nolang': lambda: encoder_fixture('f3v_encoder_c1_no_language', dict(CFG_C1, variant=dict(no_language=True)), digest=True, check_oracle=False),
     'f5': lambda: encoder_fixture('f5_encoder_c2_digest', CFG_C2, with_grads=False, digest=True),
     'f5g': lambda: encoder_fixture('f5g_encoder_c2_grads', CFG_C2, with_grads=True, digest=True, f64_grads=True),

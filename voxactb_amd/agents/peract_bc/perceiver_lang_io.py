@@ -148,12 +148,12 @@ class PerceiverVoxelLangEncoder(nn.Module):
                  no_skip_connection=False, no_perceiver=False, no_language=False, final_dim=64, arm_pred_loss=False,
                  _two_robots=False):
         super().__init__()
-        if lang_fusion_type != 'seq' or not pos_encoding_with_lang \
+        if lang_fusion_type != 'seq' \
                 or weight_tie_layers or iterations < 1 or activation != 'lrelu' or low_dim_size <= 0 \
                 or num_rotation_classes <= 0:
             raise NotImplementedError(
                 'voxactb_amd covers the configuration VoxAct-B trains (launch_utils.py:744-774, PERACT_BC.yaml): '
-                "lang_fusion_type='seq', pos_encoding_with_lang, activation='lrelu' (+ transformer_iterations >= 1 and the no_language / no_skip_connection / no_perceiver ablations)")
+                "lang_fusion_type='seq', activation='lrelu' (+ transformer_iterations >= 1 and the no_language / no_skip_connection / no_perceiver ablations)")
         if im_channels != 64 or final_dim != 64 or int(initial_dim) > 16:
             raise NotImplementedError('kernels are specialised for im_channels = final_dim = 64, initial_dim <= 16')
         if voxel_size % voxel_patch_stride or voxel_patch_size % 2 == 0:
@@ -176,7 +176,10 @@ class PerceiverVoxelLangEncoder(nn.Module):
         spatial_size = voxel_size // voxel_patch_stride
         # context width: patch features + one proprio embedding, or + the right and the left arm's (perceiver :547, :721-727)
         self.input_dim_before_seq = im_channels * (3 if self.two_robots else 2)
-        self.pos_encoding = nn.Parameter(torch.randn(1, LANG_MAX_SEQ_LEN + spatial_size ** 3, self.input_dim_before_seq))
+        if pos_encoding_with_lang:
+            self.pos_encoding = nn.Parameter(torch.randn(1, LANG_MAX_SEQ_LEN + spatial_size ** 3, self.input_dim_before_seq))
+        else:                                     # (perceiver :212-216: the grid tokens only; the language tokens get none)
+            self.pos_encoding = nn.Parameter(torch.randn(1, spatial_size, spatial_size, spatial_size, self.input_dim_before_seq))
         self.input_preprocess = Conv3DBlock(self.init_dim, im_channels, kernel_sizes=1, strides=1, activation=activation)
         self.patchify = Conv3DBlock(im_channels, im_channels, kernel_sizes=voxel_patch_size, strides=voxel_patch_stride,
                                     activation=activation)
@@ -574,7 +577,10 @@ class PerceiverEngine:
         pp = ops.linear(proprio, self.p('proprio_preprocess.linear.weight'), self.p('proprio_preprocess.linear.bias'), ops.ACT_LRELU)
         lg = ops.linear(lang, self.p('lang_preprocess.weight'), self.p('lang_preprocess.bias'))
         ppc = torch.cat((pp[:B], pp[B:]), dim=1) if self.two else pp          # [B, C] or [B, right C | left C]
-        ctx = ops.ctx_build(lg, patch, ppc, self.p('pos_encoding'), B, T0, T1, C)
+        pos = self.p('pos_encoding')
+        if not m.pos_encoding_with_lang:          # grid-only encoding (perceiver :391-392) = the full-length one with zero rows for the language tokens
+            pos = torch.cat((torch.zeros((T0, Cx), dtype=torch.float32, device=dev), pos.reshape(T1, Cx)), dim=0)
+        ctx = ops.ctx_build(lg, patch, ppc, pos, B, T0, T1, C)
         ctx2d = ctx.view(B * Nctx, Cx)
         # 7. latents
         x = self.p('latents').unsqueeze(0).expand(B, L, D).contiguous().view(B * L, D)
@@ -914,7 +920,12 @@ class PerceiverEngine:
                           self.g(pre + '.norm_context.weight'), self.g(pre + '.norm_context.bias'), dx=dctx, accumulate_dx=True)
         ops.sum_splits(dx, B, L * D, self.g('latents'), accumulate=True)
         # ---- context assembly, language, proprio
-        dlang, dpatch, dpp = ops.ctx_bwd(dctx, self.g('pos_encoding'), B, T0, T1, C, Cx - C)
+        if m.pos_encoding_with_lang:
+            dlang, dpatch, dpp = ops.ctx_bwd(dctx, self.g('pos_encoding'), B, T0, T1, C, Cx - C)
+        else:
+            dpos = torch.zeros((Nctx, Cx), dtype=torch.float32, device=dev)
+            dlang, dpatch, dpp = ops.ctx_bwd(dctx, dpos, B, T0, T1, C, Cx - C)
+            self.g('pos_encoding').view(T1, Cx).add_(dpos[T0:])
         if self.two:
             dpp = torch.cat((dpp[:, :C], dpp[:, C:]), dim=0).contiguous()      # rows [right | left], as c['proprio'] / c['pp']
         ops.linear_bwd(c['lang'], self.p('lang_preprocess.weight'), dlang, self.g('lang_preprocess.weight'),
