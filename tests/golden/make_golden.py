@@ -198,7 +198,7 @@ def encoder_fixture(name, cfg, arm=False, with_grads=True, digest=False, crop=Fa
                 cfg_low_dim=cfg['low_dim'], cfg_B=cfg['B'], cfg_H=cfg['H'], cfg_W=cfg['W'], cfg_ncam=len(cfg['cams']),
                 cfg_cams=np.array(cfg['cams']), cfg_arm=int(arm), cfg_crop=int(crop), rot_grip=outs[1], collision=outs[2])
     for vk, vv in cfg.get('variant', {}).items():
-        arrs['cfg_var_' + vk] = int(vv)
+        arrs['cfg_var_' + vk] = np.array(vv) if isinstance(vv, str) else int(vv)
     if arm:
         arrs['arm_out'] = outs[3]
     qt = outs[0].detach()
@@ -1088,6 +1088,7 @@ SECTIONS = {
     'f3v_noskip': lambda: encoder_fixture('f3v_encoder_c1_no_skip_connection', dict(CFG_C1, variant=dict(no_skip_connection=True)), digest=True, check_oracle=False),
     'f3v_noperc': lambda: encoder_fixture('f3v_encoder_c1_no_perceiver', dict(CFG_C1, variant=dict(no_perceiver=True)), digest=True, check_oracle=False),
     'f3v_posgrid': lambda: encoder_fixture('f3v_encoder_c1_pos_encoding_grid_only', dict(CFG_C1, variant=dict(pos_encoding_with_lang=False)), digest=True, check_oracle=False),
+    'f3v_concat': lambda: encoder_fixture('f3v_encoder_c1_lang_concat', dict(CFG_C1, variant=dict(lang_fusion_type='concat', pos_encoding_with_lang=False)), digest=True, check_oracle=False),
     'f3v_nolang': lambda: encoder_fixture('f3v_encoder_c1_no_language', dict(CFG_C1, variant=dict(no_language=True)), digest=True, check_oracle=False),
     'f5': lambda: encoder_fixture('f5_encoder_c2_digest', CFG_C2, with_grads=False, digest=True),
     'f5g': lambda: encoder_fixture('f5g_encoder_c2_grads', CFG_C2, with_grads=True, digest=True, f64_grads=True),

@@ -196,7 +196,8 @@ def test_training_curve_default_precision_tracks_exact_fp32(golden):
 
 
 @pytest.mark.parametrize('over', [dict(method__transformer_iterations=2), dict(method__no_language=True),
-                                  dict(method__no_skip_connection=True), dict(method__no_perceiver=True)])
+                                  dict(method__no_skip_connection=True), dict(method__no_perceiver=True),
+                                  dict(method__pos_encoding_with_lang=False), dict(method__lang_fusion_type='concat', method__pos_encoding_with_lang=False)])
 def test_update_runs_with_the_encoder_switches_of_the_configs(golden, over):
     """update() through the agent stack with the encoder switches PERACT_BC.yaml exposes (transformer_iterations, the three ablations;
     the encoder itself is pinned on the reference fixtures f3v_*): finite losses that fall over ten LAMB steps on a repeated batch, every

@@ -30,8 +30,8 @@ def _setup(g):
     V, B, H, W = int(g['cfg_V']), int(g['cfg_B']), int(g['cfg_H']), int(g['cfg_W'])
     cams = [str(c) for c in g['cfg_cams']] if 'cfg_cams' in g.files else synthetic.CAMERAS4[:int(g['cfg_ncam'])]
     seed = int(g['cfg_seed']) if 'cfg_seed' in g.files else 1
-    var = {k[len('cfg_var_'):]: int(g[k]) for k in g.files if k.startswith('cfg_var_')}      # iterations / ablation switches of the fixture
-    for k in [k for k in var if k != 'iterations']:
+    var = {k[len('cfg_var_'):]: (str(g[k]) if g[k].dtype.kind == 'U' else int(g[k])) for k in g.files if k.startswith('cfg_var_')}
+    for k in [k for k in var if k != 'iterations' and not isinstance(var[k], str)]:      # iterations / ablation switches / fusion type of the fixture
         var[k] = bool(var[k])
     enc = PerceiverVoxelLangEncoder(
         depth=int(g['cfg_depth']), iterations=var.pop('iterations', 1), voxel_size=V, initial_dim=10, low_dim_size=int(g['cfg_low_dim']),
@@ -151,7 +151,8 @@ def _run(g, precision, tag, backward, bwd_precision='', wgrad_precision=None):
     if wgrad_precision is not None:
         eng.wgrad_precision = wgrad_precision
     tag = tag + ('|bwd ' + bwd_precision if bwd_precision else '') + ('|wgrad ' + wgrad_precision if wgrad_precision else '')
-    outs, cache = eng.forward(grid, rs['low_dim_state'].to(DEV), rs['lang_token_embs'].to(DEV), training=False, save=backward)
+    outs, cache = eng.forward(grid, rs['low_dim_state'].to(DEV), rs['lang_token_embs'].to(DEV), training=False, save=backward,
+                              lang_goal_emb=rs['lang_goal_emb'].to(DEV))
     errs = _check_forward(g, outs, arm, '%s/%s' % (tag, precision))
     if backward:
         _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, '%s/%s' % (tag, precision))
@@ -194,7 +195,8 @@ def test_c5_v200_forward_backward_digest(golden, precision):
 
 
 @pytest.mark.parametrize('fixture', ['f3v_encoder_tiny_iterations2', 'f3v_encoder_c1_iterations3', 'f3v_encoder_c1_no_language',
-                                     'f3v_encoder_c1_no_skip_connection', 'f3v_encoder_c1_no_perceiver', 'f3v_encoder_c1_pos_encoding_grid_only'])
+                                     'f3v_encoder_c1_no_skip_connection', 'f3v_encoder_c1_no_perceiver', 'f3v_encoder_c1_pos_encoding_grid_only',
+                                     'f3v_encoder_c1_lang_concat'])
 @pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
 def test_encoder_switches_reachable_from_the_configs(golden, fixture, precision):
     """`transformer_iterations` > 1 (the cross-attention block and the self-attention stack run again over the SAME weights, perceiver

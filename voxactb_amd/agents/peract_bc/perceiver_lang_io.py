@@ -148,12 +148,12 @@ class PerceiverVoxelLangEncoder(nn.Module):
                  no_skip_connection=False, no_perceiver=False, no_language=False, final_dim=64, arm_pred_loss=False,
                  _two_robots=False):
         super().__init__()
-        if lang_fusion_type != 'seq' \
+        if lang_fusion_type not in ('seq', 'concat') or (lang_fusion_type == 'concat' and (pos_encoding_with_lang or _two_robots)) \
                 or weight_tie_layers or iterations < 1 or activation != 'lrelu' or low_dim_size <= 0 \
                 or num_rotation_classes <= 0:
             raise NotImplementedError(
                 'voxactb_amd covers the configuration VoxAct-B trains (launch_utils.py:744-774, PERACT_BC.yaml): '
-                "lang_fusion_type='seq', activation='lrelu' (+ transformer_iterations >= 1 and the no_language / no_skip_connection / no_perceiver ablations)")
+                "lang_fusion_type='seq' (or 'concat' with pos_encoding_with_lang=False, the only combination the reference's forward accepts: perceiver :391 vs :422), activation='lrelu' (+ transformer_iterations >= 1 and the no_language / no_skip_connection / no_perceiver ablations)")
         if im_channels != 64 or final_dim != 64 or int(initial_dim) > 16:
             raise NotImplementedError('kernels are specialised for im_channels = final_dim = 64, initial_dim <= 16')
         if voxel_size % voxel_patch_stride or voxel_patch_size % 2 == 0:
@@ -175,7 +175,7 @@ class PerceiverVoxelLangEncoder(nn.Module):
 
         spatial_size = voxel_size // voxel_patch_stride
         # context width: patch features + one proprio embedding, or + the right and the left arm's (perceiver :547, :721-727)
-        self.input_dim_before_seq = im_channels * (3 if self.two_robots else 2)
+        self.input_dim_before_seq = im_channels * (3 if (self.two_robots or lang_fusion_type == 'concat') else 2)     # (:201)
         if pos_encoding_with_lang:
             self.pos_encoding = nn.Parameter(torch.randn(1, LANG_MAX_SEQ_LEN + spatial_size ** 3, self.input_dim_before_seq))
         else:                                     # (perceiver :212-216: the grid tokens only; the language tokens get none)
@@ -183,7 +183,10 @@ class PerceiverVoxelLangEncoder(nn.Module):
         self.input_preprocess = Conv3DBlock(self.init_dim, im_channels, kernel_sizes=1, strides=1, activation=activation)
         self.patchify = Conv3DBlock(im_channels, im_channels, kernel_sizes=voxel_patch_size, strides=voxel_patch_stride,
                                     activation=activation)
-        self.lang_preprocess = nn.Linear(LANG_EMB_DIM, self.input_dim_before_seq)
+        if lang_fusion_type == 'concat':          # the sentence embedding, tiled over the grid as 64 more channels (perceiver :228-229, :379-384)
+            self.lang_preprocess = nn.Linear(LANG_FEAT_DIM, im_channels)
+        else:
+            self.lang_preprocess = nn.Linear(LANG_EMB_DIM, self.input_dim_before_seq)
         self.proprio_preprocess = DenseBlock(low_dim_size, im_channels, None, activation)
         self.ss0 = SpatialSoftmax3D(voxel_size, voxel_size, voxel_size, im_channels)
         flat_size = im_channels * 4
@@ -240,7 +243,7 @@ class PerceiverVoxelLangEncoder(nn.Module):
         if mask is not None:
             raise NotImplementedError('attention mask is never passed by the agent')
         eng = self.engine()
-        outs, _ = eng.forward(eng.to_channels_last(ins), proprio, lang_token_embs, training=False, save=False)
+        outs, _ = eng.forward(eng.to_channels_last(ins), proprio, lang_token_embs, training=False, save=False, lang_goal_emb=lang_goal_emb)
         return outs
 
 
@@ -304,7 +307,8 @@ class PerceiverEngine:
         self.two = bool(getattr(module, 'two_robots', False))
         self.D = module.latent_dim
         self.L = module.num_latents
-        self.T0 = LANG_MAX_SEQ_LEN
+        self.concat = getattr(module, 'lang_fusion_type', 'seq') == 'concat'
+        self.T0 = 0 if self.concat else LANG_MAX_SEQ_LEN          # 'concat': no language tokens in the sequence
         if s > 1:
             Lt, self.R = ops.polyphase_tables(k, s)
             self.kl = 2 * self.R + 1
@@ -512,7 +516,7 @@ class PerceiverEngine:
         return dx
 
     # -------------------------------------------------------------------------------------------------- forward
-    def forward(self, vox, proprio, lang_token_embs, training=False, save=True, seed=None, proprio_left=None):
+    def forward(self, vox, proprio, lang_token_embs, training=False, save=True, seed=None, proprio_left=None, lang_goal_emb=None):
         """vox [B,V,V,V,10] channels-last.  Returns ((trans [B,1,V,V,V], rot_and_grip, collision[, arm]), cache); for the
         2Robots encoder `proprio` is the right arm's, `proprio_left` the left arm's, and the outputs are (trans_right,
         rot_and_grip_right, collision_right, trans_left, rot_and_grip_left, collision_left)."""
@@ -538,6 +542,10 @@ class PerceiverEngine:
                 self._prep_sig = sig
                 ops.CACHE_OWNER = self if sig is not None else None
             self._frozen_now = sig is not None
+            if self.concat:
+                if lang_goal_emb is None:
+                    raise VoxactbHipError("lang_fusion_type='concat' reads lang_goal_emb")
+                lang_token_embs = lang_goal_emb       # (the language input of this fusion type: [B, 1024])
             return self._forward(vox, proprio, lang_token_embs, training, save, seed, proprio_left)
         finally:
             ops.PRECISION = 'fp32'
@@ -558,7 +566,8 @@ class PerceiverEngine:
         if self.two:
             # both arms go through the ONE proprio_preprocess block (perceiver :721-727): rows [right | left]
             proprio = torch.cat((proprio, proprio_left.float().contiguous()), dim=0)
-        lang = lang_token_embs.float().contiguous().view(B * T0, LANG_EMB_DIM)
+        lang = (lang_token_embs.float().contiguous().view(B, LANG_FEAT_DIM) if self.concat
+                else lang_token_embs.float().contiguous().view(B * T0, LANG_EMB_DIM))
         if m.no_language:                                # language ablation (perceiver :374-376): the token embeddings are zeroed
             lang = torch.zeros_like(lang)
         c = {}
@@ -577,6 +586,8 @@ class PerceiverEngine:
         pp = ops.linear(proprio, self.p('proprio_preprocess.linear.weight'), self.p('proprio_preprocess.linear.bias'), ops.ACT_LRELU)
         lg = ops.linear(lang, self.p('lang_preprocess.weight'), self.p('lang_preprocess.bias'))
         ppc = torch.cat((pp[:B], pp[B:]), dim=1) if self.two else pp          # [B, C] or [B, right C | left C]
+        if self.concat:                                                       # [B, proprio C | language C]: channels of every grid token
+            ppc, lg = torch.cat((pp, lg), dim=1), torch.zeros(1, dtype=torch.float32, device=dev)
         pos = self.p('pos_encoding')
         if not m.pos_encoding_with_lang:          # grid-only encoding (perceiver :391-392) = the full-length one with zero rows for the language tokens
             pos = torch.cat((torch.zeros((T0, Cx), dtype=torch.float32, device=dev), pos.reshape(T1, Cx)), dim=0)
@@ -928,6 +939,8 @@ class PerceiverEngine:
             self.g('pos_encoding').view(T1, Cx).add_(dpos[T0:])
         if self.two:
             dpp = torch.cat((dpp[:, :C], dpp[:, C:]), dim=0).contiguous()      # rows [right | left], as c['proprio'] / c['pp']
+        if self.concat:
+            dlang, dpp = dpp[:, C:].contiguous(), dpp[:, :C].contiguous()
         ops.linear_bwd(c['lang'], self.p('lang_preprocess.weight'), dlang, self.g('lang_preprocess.weight'),
                        self.g('lang_preprocess.bias'))
         ops.lrelu_bwd_(dpp, c['pp'])

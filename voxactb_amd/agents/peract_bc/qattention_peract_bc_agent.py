@@ -102,7 +102,7 @@ class QFunction(nn.Module):
         grid = self.voxelize(rgb_pcd, pcd, bounds)
         voxel_grid = grid.permute(0, 4, 1, 2, 3).detach()          # channels-first VIEW, as upstream exposes it
         eng = self.encoder.engine()
-        outs, _ = eng.forward(grid, proprio, lang_token_embs, training=False, save=False)
+        outs, _ = eng.forward(grid, proprio, lang_token_embs, training=False, save=False, lang_goal_emb=lang_goal_emb)
         if self._arm_pred_loss and self._is_training:
             return outs[0], outs[1], outs[2], voxel_grid, outs[3]
         return outs[0], outs[1], outs[2], voxel_grid
@@ -343,7 +343,7 @@ class QAttentionPerActBCAgent(Agent):
         grid = self._q.voxelize(obs, pcd, bounds, xform)
         voxel_grid = grid.permute(0, 4, 1, 2, 3).detach()
         eng = self._q.encoder.engine()
-        outs, cache = eng.forward(grid, proprio, lang_token_embs, training=True, save=True)
+        outs, cache = eng.forward(grid, proprio, lang_token_embs, training=True, save=True, lang_goal_emb=lang_goal_emb)
         q_trans, q_rot_grip, q_collision = outs[0], outs[1], outs[2]
         arm_out = outs[3] if self._arm_pred_loss else None
 

@@ -1291,7 +1291,7 @@ def ctx_build(lang, patch, pp, pos, B, T0, T1, C):
 def ctx_bwd(dctx, dpos, B, T0, T1, C, Cp=None):
     dev = dctx.device
     Cp = C if Cp is None else Cp
-    dlang = torch.empty((B * T0, C + Cp), dtype=torch.float32, device=dev)
+    dlang = torch.empty((max(B * T0, 1), C + Cp), dtype=torch.float32, device=dev)      # (T0 = 0 -- lang_fusion_type 'concat' -- one unused row)
     dpatch = torch.empty((B * T1, C), dtype=torch.float32, device=dev)
     dpp = torch.empty((B, Cp), dtype=torch.float32, device=dev)
     ws = torch.empty(B * 32 * Cp, dtype=torch.float32, device=dev)
