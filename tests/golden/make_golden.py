@@ -1089,6 +1089,7 @@ SECTIONS = {
     'f3v_noperc': lambda: encoder_fixture('f3v_encoder_c1_no_perceiver', dict(CFG_C1, variant=dict(no_perceiver=True)), digest=True, check_oracle=False),
     'f3v_posgrid': lambda: encoder_fixture('f3v_encoder_c1_pos_encoding_grid_only', dict(CFG_C1, variant=dict(pos_encoding_with_lang=False)), digest=True, check_oracle=False),
     'f3v_concat': lambda: encoder_fixture('f3v_encoder_c1_lang_concat', dict(CFG_C1, variant=dict(lang_fusion_type='concat', pos_encoding_with_lang=False)), digest=True, check_oracle=False),
+    'f3v_tie': lambda: encoder_fixture('f3v_encoder_c1_weight_tie_layers', dict(CFG_C1, depth=3, variant=dict(weight_tie_layers=True)), digest=True, check_oracle=False),
     'f3v_nolang': lambda: encoder_fixture('f3v_encoder_c1_no_language', dict(CFG_C1, variant=dict(no_language=True)), digest=True, check_oracle=False),
     'f5': lambda: encoder_fixture('f5_encoder_c2_digest', CFG_C2, with_grads=False, digest=True),
     'f5g': lambda: encoder_fixture('f5g_encoder_c2_grads', CFG_C2, with_grads=True, digest=True, f64_grads=True),

@@ -196,7 +196,7 @@ def test_c5_v200_forward_backward_digest(golden, precision):
 
 @pytest.mark.parametrize('fixture', ['f3v_encoder_tiny_iterations2', 'f3v_encoder_c1_iterations3', 'f3v_encoder_c1_no_language',
                                      'f3v_encoder_c1_no_skip_connection', 'f3v_encoder_c1_no_perceiver', 'f3v_encoder_c1_pos_encoding_grid_only',
-                                     'f3v_encoder_c1_lang_concat'])
+                                     'f3v_encoder_c1_lang_concat', 'f3v_encoder_c1_weight_tie_layers'])
 @pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
 def test_encoder_switches_reachable_from_the_configs(golden, fixture, precision):
     """`transformer_iterations` > 1 (the cross-attention block and the self-attention stack run again over the SAME weights, perceiver

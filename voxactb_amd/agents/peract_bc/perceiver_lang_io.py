@@ -149,7 +149,7 @@ class PerceiverVoxelLangEncoder(nn.Module):
                  _two_robots=False):
         super().__init__()
         if lang_fusion_type not in ('seq', 'concat') or (lang_fusion_type == 'concat' and (pos_encoding_with_lang or _two_robots)) \
-                or weight_tie_layers or iterations < 1 or activation != 'lrelu' or low_dim_size <= 0 \
+                or iterations < 1 or activation != 'lrelu' or low_dim_size <= 0 \
                 or num_rotation_classes <= 0:
             raise NotImplementedError(
                 'voxactb_amd covers the configuration VoxAct-B trains (launch_utils.py:744-774, PERACT_BC.yaml): '
@@ -196,10 +196,13 @@ class PerceiverVoxelLangEncoder(nn.Module):
                                           dropout=input_dropout), context_dim=self.input_dim_before_seq),
             PreNorm(latent_dim, FeedForward(latent_dim))])
         self.layers = nn.ModuleList([])
+        self.weight_tie_layers = bool(weight_tie_layers)
+        tied = None
         for _ in range(depth):
-            self.layers.append(nn.ModuleList([
-                PreNorm(latent_dim, Attention(latent_dim, heads=latent_heads, dim_head=latent_dim_head, dropout=attn_dropout)),
-                PreNorm(latent_dim, FeedForward(latent_dim))]))
+            if tied is None or not weight_tie_layers:      # weight_tie_layers (perceiver :262-276, cache_fn): ONE attention / feed-forward pair,
+                tied = (PreNorm(latent_dim, Attention(latent_dim, heads=latent_heads, dim_head=latent_dim_head, dropout=attn_dropout)),
+                        PreNorm(latent_dim, FeedForward(latent_dim)))             # listed `depth` times (state_dict keys for every layer, parameters once)
+            self.layers.append(nn.ModuleList([tied[0], tied[1]]))
         self.decoder_cross_attn = PreNorm(self.input_dim_before_seq,
                                           Attention(self.input_dim_before_seq, latent_dim, heads=cross_heads,
                                                     dim_head=cross_dim_head, dropout=decoder_dropout),
@@ -308,6 +311,7 @@ class PerceiverEngine:
         self.D = module.latent_dim
         self.L = module.num_latents
         self.concat = getattr(module, 'lang_fusion_type', 'seq') == 'concat'
+        self._tied = bool(getattr(module, 'weight_tie_layers', False))
         self.T0 = 0 if self.concat else LANG_MAX_SEQ_LEN          # 'concat': no language tokens in the sequence
         if s > 1:
             Lt, self.R = ops.polyphase_tables(k, s)
@@ -372,11 +376,19 @@ class PerceiverEngine:
         self.step_seed = _mix32(s, 0x51ED27 + rank)
         return self.step_seed
 
+    def _resolve(self, name):
+        prm = self.P.get(name)
+        if prm is None and self._tied and name.startswith('layers.'):          # weight_tie_layers: every layer is layer 0's parameters
+            prm = self.P['layers.0.' + name.split('.', 2)[2]]
+        if prm is None:
+            raise KeyError(name)
+        return prm
+
     def p(self, name):
-        return self.P[name].data
+        return self._resolve(name).data
 
     def g(self, name):
-        prm = self.P[name]
+        prm = self._resolve(name)
         if prm.grad is None:
             prm.grad = torch.zeros_like(prm.data)
         return prm.grad
@@ -914,7 +926,7 @@ class PerceiverEngine:
                 dxn, _ = self._attn_bwd(pre, lc['attn'], dx, lc['xn'], lc['xn'], True)
                 ops.layernorm_bwd(dxn, lc['x'], self.p(pre + '.norm.weight'), lc['xm'], lc['xr'], self.g(pre + '.norm.weight'),
                                   self.g(pre + '.norm.bias'), dx=dx, accumulate_dx=True)
-                if it == 0:
+                if it == 0 and (i == 0 or not self._tied):
                     self._bucket_ready('layers.%d' % i)      # (shared weights: their gradients are complete after the FIRST iteration's turn)
             dx = self._ff_bwd('cross_attend_blocks.1', ci['cross_ff'], dx)
             cc = ci['cross']
