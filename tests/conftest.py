@@ -31,3 +31,21 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
     return load
+
+
+@pytest.fixture
+def wide_dispatch(request):
+    """`wide_dispatch` parametrised True: the 128 x 512-tile ("wide") GEMM / fp16 weight-gradient / fp16x2 data-gradient kernels and the
+    fused GEGLU epilogue -- what bench.py's B = 16 headline dispatches (ops.WIDE_MIN_M = 16384 rows) -- are taken from 1024 rows on, so
+    that the B = 1 / 2 reference fixtures run through the headline's kernels; restored afterwards."""
+    on = bool(getattr(request, 'param', False))
+    if not on:
+        yield False
+        return
+    from voxactb_amd import ops
+    old = ops.WIDE_MIN_M
+    ops.set_wide_min_rows(1024)
+    try:
+        yield True
+    finally:
+        ops.set_wide_min_rows(old)

@@ -1097,10 +1097,13 @@ SECTIONS = {
     'f5v200': lambda: encoder_fixture('f5v200_encoder_c5_digest', CFG_C5, with_grads=False, digest=True),
     'f5v50a': lambda: encoder_fixture('f5v50a_encoder_release_digest', CFG_V50, arm=True, with_grads=True, digest=True, crop=True, f64_grads=True),
     'f5v50b': lambda: encoder_fixture('f5v50b_encoder_release_digest', CFG_V50B, arm=True, with_grads=True, digest=True, crop=True, f64_grads=True),
-    # the same grid with the reference's loss and backward.  NOT part of the committed fixtures: on the 8-core build container the
-    # reference's CPU backward at 200^3 did not finish in 75 minutes (33 GB resident, all cores busy inside one ATen op), so the
-    # configs[4] backward is covered by tests/test_fullsize_gpu.py::test_v200_* (two kernel families against each other) instead
+    # the same grid with the reference's loss and backward (committed since round 4: ~15 minutes on the 8-core build container with the
+    # stride-1 convs evaluated in slabs, _f5v200g above; as one ATen op per layer the backward had not finished in 75 minutes)
     'f5v200g': lambda: _f5v200g(),
+    # configs[1] geometry at B = 8: 16 384 rows per linear layer = the row count from which the product dispatches the 128 x 512-tile
+    # ("wide") GEMM / fp16 weight-gradient / fp16x2 data-gradient kernels and the fused GEGLU epilogue -- the headline's own dispatch
+    # (B = 16 takes the same kernels) pinned on the reference's forward + backward (round 5; ~25 GB resident, a few minutes)
+    'f5gb8': lambda: encoder_fixture('f5gb8_encoder_c2_b8_grads', dict(CFG_C2, B=8), with_grads=True, digest=True, check_oracle=False, f64_grads=True),
     # the reference in fp32 AND float64 on three batches per headline shape (the fp32-vs-fp64 spread is the yardstick of the gradient gates)
     **{'f5n_c2_s%d' % sd: (lambda sd=sd: grad_noise_fixture('f5n_noise_c2_s%d' % sd, CFG_C2, sd)) for sd in (1, 2, 3)},
     **{'f5n_c3_s%d' % sd: (lambda sd=sd: grad_noise_fixture('f5n_noise_c3_s%d' % sd, CFG_C3, sd, arm=True, crop=True)) for sd in (1, 2, 3)},
@@ -1132,7 +1135,7 @@ if __name__ == '__main__':
     todo = [s for s in a.only.split(',') if s] or list(SECTIONS)
     torch.manual_seed(0)
     for s in todo:
-        if (s in ('f5', 'f5g', 'f5c3', 'f5v200', 'f5v200g') or s.startswith('f5n_c')) and a.skip_c2:
+        if (s in ('f5', 'f5g', 'f5gb8', 'f5c3', 'f5v200', 'f5v200g') or s.startswith('f5n_c')) and a.skip_c2:
             continue
         print('==', s)
         SECTIONS[s]()

@@ -130,3 +130,15 @@ def test_act_keeps_prepared_weights_until_they_change():
     assert torch.equal(q3, act(make(1)))
     # another engine's forward takes the shared caches over: the first agent prepares again and still answers the same
     assert torch.equal(act(a), q3)
+    # a long evaluation run: the address-keyed caches of prepared weights and the device memory stay where they are after the second call
+    # (round-4 advisor finding: every act() re-laid the small conv weights into fresh temporaries, and gemm_wfrag cached a fragment copy
+    # per temporary -- ~8 MB per call, never released while the preparation was reused)
+    act(a)
+    torch.cuda.synchronize()
+    n_f, n_w, mem = len(ops._FCACHE), len(ops._WCACHE), torch.cuda.memory_allocated()
+    for _ in range(20):
+        q = act(a)
+    torch.cuda.synchronize()
+    assert torch.equal(q, q3)
+    assert (len(ops._FCACHE), len(ops._WCACHE)) == (n_f, n_w), (len(ops._FCACHE), n_f, len(ops._WCACHE), n_w)
+    assert torch.cuda.memory_allocated() <= mem + (1 << 20), (torch.cuda.memory_allocated(), mem)

@@ -67,15 +67,16 @@ def test_update_traces(golden, tag):
     assert np.isfinite(sums).all()
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
-def test_update_traces_at_headline_size(golden, precision):
+@pytest.mark.parametrize('precision,wide_dispatch', [('fp32', False), ('bf16x3', False), ('bf16x3', True)], indirect=['wide_dispatch'],
+                         ids=['fp32', 'bf16x3', 'bf16x3-wide'])
+def test_update_traces_at_headline_size(golden, precision, wide_dispatch):
     """fixture F6c2: three LAMB update() steps of the REAL reference agent (QAttentionPerActBCAgent, DDP-gloo world 1,
     qattention_peract_bc_agent.py:418-641 + lamb.py:60-124 over 33 M parameters) at BASELINE.json configs[1] geometry -- V=100,
     4 cameras 128x128, depth 6, 2048 latents, B=1 -- replayed in the exact-fp32 AND the default precision (bf16x3 products, fp16
     conv weight gradients): step 0 is forward parity (1e-4); steps 1 and 2 have passed through LAMB, whose sign-like first
     updates amplify fp32 noise of mathematically-zero gradients (make_golden.py:f6: the reference-vs-oracle spread, two fp32
     implementations, is 2e-5 here and ~1e-3 at the small configs) -- every later loss within 5e-3, and the parameters after
-    three steps within 1e-3 of the reference's in sum |w|."""
+    three steps within 1e-3 of the reference's in sum |w|.  'bf16x3-wide': through the kernels the B = 16 headline dispatches."""
     g = golden('f6c2_update_traces_c2')
     os.environ['VOXACTB_PRECISION'] = precision
     try:

@@ -167,16 +167,32 @@ def test_c2_forward_digest_f5(golden, precision):
     _run(golden('f5_encoder_c2_digest'), precision, 'f5', backward=False)
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
-def test_c2_forward_backward_digest(golden, precision):
-    """the same configuration with the reference's loss and per-parameter gradient norms (fwd + bwd of the reference)."""
-    _run(golden('f5g_encoder_c2_grads'), precision, 'f5g', backward=True)
+WIDE = pytest.mark.parametrize('precision,wide_dispatch', [('fp32', False), ('bf16x3', False), ('bf16x3', True)],
+                               indirect=['wide_dispatch'], ids=['fp32', 'bf16x3', 'bf16x3-wide'])
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
-def test_c3_twin_agent_shape_digest(golden, precision):
+@WIDE
+def test_c2_forward_backward_digest(golden, precision, wide_dispatch):
+    """the same configuration with the reference's loss and per-parameter gradient norms (fwd + bwd of the reference).  'bf16x3-wide':
+    the same fixture through the kernels the B = 16 headline dispatches (conftest.wide_dispatch)."""
+    _run(golden('f5g_encoder_c2_grads'), precision, 'f5g' + ('|wide' if wide_dispatch else ''), backward=True)
+
+
+@WIDE
+def test_c3_twin_agent_shape_digest(golden, precision, wide_dispatch):
     """BASELINE.json configs[2] shape of one twin agent: low_dim 7, arm head, per-sample crop bounds, B=2, fwd + bwd."""
-    _run(golden('f5c3_encoder_c3_digest'), precision, 'f5c3', backward=True)
+    _run(golden('f5c3_encoder_c3_digest'), precision, 'f5c3' + ('|wide' if wide_dispatch else ''), backward=True)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_c2_b8_forward_backward_digest_at_the_headline_dispatch(golden, precision):
+    """configs[1] geometry at B = 8 (fixture f5gb8, round 5: forward + backward of the reference, 16 384 rows per linear layer): the row
+    count from which ops.WIDE_MIN_M sends the linear layers to gemm_wide<0> / gemm_wide<1> (fp16x2 data gradient) / wgrad_wide_f16 and the
+    fused GEGLU epilogue WITHOUT any test switch -- the dispatch of bench.py's B = 16 headline, pinned to the reference
+    (qattention_peract_bc_agent.py:418-641, perceiver_lang_io.py:74-132)."""
+    g = golden('f5gb8_encoder_c2_b8_grads')
+    assert int(g['cfg_B']) * int(g['cfg_latents']) >= ops.WIDE_MIN_M
+    _run(g, precision, 'f5gb8', backward=True)
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])

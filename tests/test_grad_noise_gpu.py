@@ -116,8 +116,9 @@ FORWARD_SENSITIVE = {'f5n_noise_c2_s3': 0.10, 'f5n_noise_v50b_s1': 0.10}
 
 
 @pytest.mark.parametrize('fixture', FIXTURES)
-@pytest.mark.parametrize('mode', ['fp32', 'bf16x3+r3/f16', 'bf16x3+r3/f16-gx0'])
-def test_gradients_against_the_float64_reference(golden, fixture, mode):
+@pytest.mark.parametrize('mode,wide_dispatch', [('fp32', False), ('bf16x3+r3/f16', False), ('bf16x3+r3/f16-gx0', False), ('bf16x3+r3/f16', True)],
+                         indirect=['wide_dispatch'], ids=['fp32', 'bf16x3+r3/f16', 'bf16x3+r3/f16-gx0', 'bf16x3+r3/f16-wide'])
+def test_gradients_against_the_float64_reference(golden, fixture, mode, wide_dispatch):
     """'fp32': the exact-fp32 kernels; 'bf16x3+r3/f16': the shipped default (bf16x3 forward incl. round 3's attention forward, fp16 single /
     double products in the backward, pipelined fp16 attention backward with hi + lo gradient operands)."""
     if fixture not in _available():

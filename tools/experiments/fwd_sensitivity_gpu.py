@@ -1,0 +1,133 @@
+#!/usr/bin/env python
+"""Where does the default precision's forward move the gradients of the 'forward-sensitive' batches (tests/test_grad_noise_gpu.py)?
+
+Runs the engine's forward twice on one float64-reference fixture (f5n_noise_*), in the exact-fp32 and in the default bf16x3 arithmetic,
+reports how far every saved activation of the two runs is apart, and then evaluates ONE backward arithmetic (bf16x3 triples everywhere,
+round 3's attention backward: within 1e-4 of fp32 on every fixture) on HYBRID caches -- the fp32 run's saved tensors with one group at a
+time replaced by the bf16x3 run's -- against the float64 gradients of the fixture (16 projections per tensor, as the test does).  The
+group whose swap brings the 3-8 % error in is the site.
+
+    python tools/experiments/fwd_sensitivity_gpu.py f5n_noise_c2_s3 [f5n_noise_c2_s1 ...]
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from oracle import weights as ow
+from tests.test_c2_reference_gpu import DEV, T, _setup
+from voxactb_amd import ops
+
+GROUPS = {
+    'input (d0, ss0, patch)': ['d0', 'ss0', 'patch'],
+    'context + transformer (ctx2d, ctx_norm, iters, dec)': ['ctx2d', 'ctx_norm', 'iters', 'dec', 'pp', 'proprio', 'lang'],
+    'z (z, ss1, zc)': ['z', 'ss1', 'zc'],
+    'z1': ['z1'],
+    'u0 (u0, Weff)': ['u0', 'Weff'],
+    'u (u, ss2)': ['u', 'ss2'],
+    'heads (feats, h0, h1, h2, o)': ['feats', 'h0', 'h1', 'h2', 'o'],
+}
+UPSTREAM = ('up0.', 'decoder_cross_attn.', 'layers.', 'cross_attend_blocks.', 'latents', 'pos_encoding', 'patchify.', 'lang_preprocess.',
+            'proprio_preprocess.')
+
+
+def loss_grads(rs, outs, cache, arm, V, B):
+    at = rs['trans_action_indicies'].long()
+    lab = ((at[:, 0] * V + at[:, 1]) * V + at[:, 2]).int().to(DEV)
+    dq = torch.empty((B, V ** 3), device=DEV)
+    ops.ce_big(outs[0].view(B, -1), lab, dq, 1.0 / B)
+    labs = torch.cat([rs['rot_grip_action_indicies'].int(), rs['ignore_collisions'].int()[:, :1]], 1).to(DEV).contiguous()
+    d_o = torch.empty_like(cache['o'])
+    ops.ce_rows(cache['o'], [(0, 72), (72, 72), (144, 72), (216, 2), (218, 2)], labs, d_o, 1.0 / B)
+    d_arm = None
+    if arm:
+        d_arm = torch.empty_like(outs[3])
+        ops.ce_rows(outs[3], [(0, 2)], rs['label'].int()[:, :1].to(DEV).contiguous(), d_arm, 1.0 / B)
+    return dq, d_o, d_arm
+
+
+def errors(g, enc):
+    names = [str(n) for n in g['grad_names']]
+    n64, p64 = T(g['grad_norm64']), T(g['grad_proj64'])
+    nproj = int(g['nproj'])
+    P = dict(enc.named_parameters())
+    up, down = [], []
+    for i, n in enumerate(names):
+        if float(n64[i]) < 1e-6 * float(n64.max()):
+            continue
+        e = float(ow.projection_error(ow.project(P[n].grad, n, nproj), p64[i])) / float(n64[i])
+        (up if n.startswith(UPSTREAM) else down).append((e, n))
+    return up, down
+
+
+def main():
+    from tests.conftest import GOLDEN
+    for fx in sys.argv[1:]:
+        g = np.load(os.path.join(GOLDEN, fx + '.npz'), allow_pickle=False)
+        enc, rs, grid, arm, V, B = _setup(g)
+        eng = enc.engine()
+        eng.attn_kernel = 'r3'
+
+        def fwd(prec):
+            eng.precision = prec
+            return eng.forward(grid, rs['low_dim_state'].to(DEV), rs['lang_token_embs'].to(DEV), training=False, save=True)
+        o32, c32 = fwd('fp32')
+        oX, cX = fwd('bf16x3')                     # (last: the prepared weights left behind are the backward's)
+        print('== %s: forward differences  bf16x3 vs fp32   (rel. L2 | max abs | max |fp32|)' % fx)
+
+        def rep(name, a, b):
+            a, b = a.float(), b.float()
+            print('   %-26s %.2e | %.2e | %.2e' % (name, float((a - b).norm() / (b.norm() + 1e-30)), float((a - b).abs().max()), float(b.abs().max())))
+        for k in ('d0', 'patch', 'ctx2d'):
+            rep(k, cX[k], c32[k])
+        for i, (lx, l32) in enumerate(zip(cX['iters'][0]['layers'], c32['iters'][0]['layers'])):
+            rep('latents into layer %d' % i, lx['x'], l32['x'])
+        rep('latents out (dec x)', cX['dec']['x'], c32['dec']['x'])
+        for k in ('z', 'z1', 'u0', 'u'):
+            rep(k, cX[k], c32[k])
+        rep('q_trans', oX[0], o32[0])
+        rep('heads o', cX['o'], c32['o'])
+        for i, k in enumerate(('ss0', 'ss1', 'ss2')):
+            rep(k + ' expected coords', cX[k][0], c32[k][0])
+            rep(k + ' max', cX[k][1], c32[k][1])
+            print('   %-26s arg-max choices that differ: %d' % (k, int((cX[k][3] != c32[k][3]).sum())))
+        # one backward arithmetic for every hybrid
+        eng.precision, eng.bwd_precision, eng.wgrad_precision, eng.attn_bwd_kernel = 'bf16x3', '', 'bf16x3', ''
+
+        def run(tag, cache, outs):
+            c = dict(cache)
+            dq, d_o, d_arm = loss_grads(rs, outs, c, arm, V, B)
+            for p in enc.parameters():
+                p.grad = None
+            eng.backward(c, dq, d_o, d_arm)
+            up, down = errors(g, enc)
+            up.sort(reverse=True)
+            print('   %-58s upstream of u0: median %.2e worst %.2e (%s) | final / heads / input: worst %.2e'
+                  % (tag, float(np.median([e for e, _ in up])), up[0][0], up[0][1], max(e for e, _ in down)), flush=True)
+        print('== %s: gradients vs float64 (relative L2 per tensor), ONE backward arithmetic, hybrid caches' % fx)
+        run('all fp32', c32, o32)
+        run('all bf16x3', cX, oX)
+        for gname, keys in GROUPS.items():
+            c = dict(c32)
+            for k in keys:
+                c[k] = cX[k]
+            outs = oX if gname.startswith('u (') else o32
+            if gname.startswith('heads'):
+                outs = (o32[0],) + tuple(oX[1:])
+            run('fp32 + bf16x3 {%s}' % gname, c, outs)
+        for gname, keys in GROUPS.items():
+            c = dict(cX)
+            for k in keys:
+                c[k] = c32[k]
+            outs = o32 if gname.startswith('u (') else oX
+            run('bf16x3 + fp32 {%s}' % gname, c, outs)
+        del c32, cX, o32, oX, enc, eng
+        torch.cuda.empty_cache()
+
+
+if __name__ == '__main__':
+    main()

@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(256, 2) c1_dgrad4_ss_kernel(const float* __res
         partB[((long long)b * gridDim.x + blockIdx.x) * 64 + threadIdx.x] = sacc;
     }
     if (part_amax) {                        // (uniform) per-block maximum of |du| for the fp16 kernels that read du next
-        unsigned amx = __float_as_uint(amxf);
+        unsigned amx = vxb_amax_word(amxf, (bsum[0] + bsum[1]) + (bsum[2] + bsum[3]));      // (fmaxf drops NaN: the column sums keep it)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o, 64));
         if ((threadIdx.x & 63) == 0) ramx[threadIdx.x >> 6] = amx;

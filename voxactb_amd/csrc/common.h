@@ -62,6 +62,14 @@ __device__ __forceinline__ unsigned vxb_pack_f16(float lo, float hi) {
     return t.u;
 }
 
+// fp32 -> the fp16 range for a GRADIENT operand: finite values saturate at +-65504 (v_med3_f32), NaN and +-inf come out as NaN
+// (x * 0 is NaN exactly for those; +-0 otherwise) -- v_med3_f32 alone maps NaN to -65504, i.e. a NaN born in the backward pass would
+// become finite garbage the optimizer applies, where the reference's autograd propagates it (qattention_peract_bc_agent.py:578-590)
+__device__ __forceinline__ float vxb_sat_f16(float x) { return fmaf(x, 0.0f, __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f)); }
+// magnitude word of a per-workgroup |x| maximum for the operand-scale finish kernels (nn_ops.hip): NaN bits (larger than any finite
+// magnitude as an unsigned integer) when `witness` -- any sum or product the kernel formed from the same values -- is NaN
+__device__ __forceinline__ unsigned vxb_amax_word(float amxf, float witness) { return witness != witness ? 0x7fc00000u : __float_as_uint(amxf); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -699,7 +699,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
         }
         if (g.amax_part) {                  // (uniform) the fp16 operand scale of the tensor just written is taken on the way
             __shared__ unsigned famx[8];
-            unsigned amx = __float_as_uint(amxf);
+            unsigned amx = vxb_amax_word(amxf, (csum.x + csum.y) + (csum.z + csum.w));      // (fmaxf drops NaN: the column sums keep it)
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o, 64));
             if (lane == 0) famx[wid] = amx;

@@ -124,12 +124,13 @@ __global__ void __launch_bounds__(256) f2b_prep1_kernel(const float* __restrict_
     __shared__ float s_mx[4];
     const int sub = threadIdx.x & 15;
     const long long total = (long long)B * Nq * H;
-    float mx = 0.f;
+    float mx = 0.f, nanw = 0.f;             // nanw: NaN once a NaN / inf of dO was seen (fmaxf drops NaN)
     for (long long idx = ((long long)blockIdx.x * 256 + threadIdx.x) >> 4; idx < total; idx += (long long)gridDim.x * 16) {
         const float4 a = *reinterpret_cast<const float4*>(d_o + idx * HD + sub * 4);
         const float4 c = *reinterpret_cast<const float4*>(o + idx * HD + sub * 4);
         float s = a.x * c.x + a.y * c.y + a.z * c.z + a.w * c.w;
         mx = fmaxf(mx, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+        nanw = fmaf((a.x + a.y) + (a.z + a.w), 0.0f, nanw);
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
         if (sub == 0) {
@@ -139,11 +140,14 @@ __global__ void __launch_bounds__(256) f2b_prep1_kernel(const float* __restrict_
         }
     }
     mx = wave_max(mx);                      // (one atomic per block: per-wave atomics on one word cost 0.7 ms at 65 k waves)
-    if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = mx;
+    nanw = wave_sum(nanw);
+    if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = nanw != nanw ? INFINITY : mx;
     __syncthreads();
     if (threadIdx.x == 0) {
         mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
-        if (mx > 0.f && mx < INFINITY) atomicMax(amax, __float_as_uint(mx));
+        // a non-finite dO: the word becomes NaN bits and f2b_prep2 turns the operand scale into NaN -- dQ, dK and dV come out NaN as
+        // the reference's autograd would hand them on (fb_clamp alone would saturate the NaN to a finite value)
+        if (mx > 0.f) atomicMax(amax, mx < INFINITY ? __float_as_uint(mx) : 0x7fc00000u);
     }
 }
 // scale words, the row fragments and the 16-bit planes of q and dO'
@@ -159,6 +163,7 @@ __global__ void __launch_bounds__(256) f2b_prep2_kernel(const float* __restrict_
         if (a) {
             const int e = (int)((a >> 23) & 0xff) - 127;            // floor(log2 max)
             sc = __uint_as_float((unsigned)(127 + 4 - e) << 23);     // max * sc in [16, 32)
+            if (a >= 0x7f800000u) sc = __uint_as_float(0x7fc00000u);  // non-finite dO (f2b_prep1): NaN through every product and the 1 / sc epilogue
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { scale_ws[0] = sc; scale_ws[1] = 1.0f / sc; }

@@ -107,8 +107,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) gemm_wide_kernel(GwA
         unsigned* lp_ = reinterpret_cast<unsigned*>(&l_);                                                            \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                               \
             if (X2) {                                                                                                \
-                const float a_ = __builtin_amdgcn_fmed3f(v_[2 * e] * in_sc, -65504.f, 65504.f);                      \
-                const float b_ = __builtin_amdgcn_fmed3f(v_[2 * e + 1] * in_sc, -65504.f, 65504.f);                  \
+                const float a_ = vxb_sat_f16(v_[2 * e] * in_sc);          /* (NaN / inf stay non-finite: common.h) */  \
+                const float b_ = vxb_sat_f16(v_[2 * e + 1] * in_sc);                                                 \
                 hp_[e] = vxb_pack_f16(a_, b_);                                                                       \
                 lp_[e] = vxb_pack_f16(a_ - (float)__builtin_bit_cast(_Float16, (unsigned short)(hp_[e] & 0xffffu)),  \
                                       b_ - (float)__builtin_bit_cast(_Float16, (unsigned short)(hp_[e] >> 16)));     \

@@ -247,6 +247,9 @@ __global__ void __launch_bounds__(256) absmax_final_kernel(const unsigned* __res
         }
         scale[0] = __uint_as_float((unsigned)(k + 127) << 23);
         scale[1] = __uint_as_float((unsigned)(127 - k) << 23);
+        // an inf / NaN in the tensor: both factors NaN, so every kernel that multiplies by them hands on NaN instead of the
+        // saturated (finite) values its fp16 conversion would produce -- the reference's autograd propagates non-finite gradients
+        if (m >= 0x7f800000u) { scale[0] = __uint_as_float(0x7fc00000u); scale[1] = __uint_as_float(0x7fc00000u); }
     }
 }
 
@@ -780,6 +783,7 @@ __global__ void __launch_bounds__(256) wgrad_finish_kernel(const float* __restri
             }
             scale[0] = __uint_as_float((unsigned)(k + 127) << 23);
             scale[1] = __uint_as_float((unsigned)(127 - k) << 23);
+            if (m >= 0x7f800000u) { scale[0] = __uint_as_float(0x7fc00000u); scale[1] = __uint_as_float(0x7fc00000u); }     // (see absmax_final_kernel)
         }
         return;
     }

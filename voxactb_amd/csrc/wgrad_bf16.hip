@@ -40,7 +40,7 @@ struct WgArgs {
 
 template <int PM>
 __device__ __forceinline__ unsigned pack_bf16_2(float lo, float hi) {
-    if (PM == 2) return vxb_pack_f16(__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f));
+    if (PM == 2) return vxb_pack_f16(vxb_sat_f16(lo), vxb_sat_f16(hi));      // (NaN / inf stay non-finite: common.h)
     return vxb_pack_bf16(lo, hi);
 }
 template <int PM>
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
     const float sc_b = (PM == 2 && g.scale && !g.grad_is_src0) ? g.scale[0] : 1.0f;
     // (uniform) this workgroup sees every value of the gradient operand's slice exactly once per row / column block
     const bool want_amax = PM == 2 && g.amax_part != nullptr && (g.grad_is_src0 ? blockIdx.x == 0 : blockIdx.y == 0);
-    float amxf = 0.f;
+    float amxf = 0.f, nanw = 0.f;          // largest |gradient operand| seen; nanw: NaN once a NaN / inf was seen (fmaxf drops NaN)
     auto store_tile = [&]() {
         if (want_psum) {
 #pragma unroll
@@ -196,10 +196,16 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
             if (want_amax) {
                 if (g.grad_is_src0) {
 #pragma unroll
-                    for (int i = 0; i < A_F4; ++i) amxf = fmaxf(fmaxf(amxf, fabsf(ra[i].x)), fmaxf(fmaxf(fabsf(ra[i].y), fabsf(ra[i].z)), fabsf(ra[i].w)));
+                    for (int i = 0; i < A_F4; ++i) {
+                        amxf = fmaxf(fmaxf(amxf, fabsf(ra[i].x)), fmaxf(fmaxf(fabsf(ra[i].y), fabsf(ra[i].z)), fabsf(ra[i].w)));
+                        nanw = fmaf((ra[i].x + ra[i].y) + (ra[i].z + ra[i].w), 0.0f, nanw);
+                    }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < B_F4; ++i) amxf = fmaxf(fmaxf(amxf, fabsf(rb[i].x)), fmaxf(fmaxf(fabsf(rb[i].y), fabsf(rb[i].z)), fabsf(rb[i].w)));
+                    for (int i = 0; i < B_F4; ++i) {
+                        amxf = fmaxf(fmaxf(amxf, fabsf(rb[i].x)), fmaxf(fmaxf(fabsf(rb[i].y), fabsf(rb[i].z)), fabsf(rb[i].w)));
+                        nanw = fmaf((rb[i].x + rb[i].y) + (rb[i].z + rb[i].w), 0.0f, nanw);
+                    }
                 }
             }
 #pragma unroll
@@ -318,7 +324,7 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgs g) {
 
     if (want_amax) {
         __shared__ unsigned wamx[4];
-        unsigned amx = __float_as_uint(amxf);
+        unsigned amx = vxb_amax_word(amxf, nanw);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o, 64));
         if (lane == 0) wamx[wid] = amx;
@@ -418,7 +424,7 @@ __global__ void __launch_bounds__(256) wgrad_lin_f16_kernel(WgArgs g) {
     const bool want_psum = g.possum != nullptr && blockIdx.x == 0;
     const bool want_amax = g.amax_part != nullptr && (g.grad_is_src0 ? blockIdx.x == 0 : blockIdx.y == 0);
     float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
-    float amxf = 0.f;
+    float amxf = 0.f, nanw = 0.f;          // largest |gradient operand| seen; nanw: NaN once a NaN / inf was seen (fmaxf drops NaN)
     auto store_tile = [&](int stage) {
         if (want_psum) {
 #pragma unroll
@@ -427,10 +433,16 @@ __global__ void __launch_bounds__(256) wgrad_lin_f16_kernel(WgArgs g) {
         if (want_amax) {
             if (g.grad_is_src0) {
 #pragma unroll
-                for (int i = 0; i < A_F4; ++i) amxf = fmaxf(fmaxf(amxf, fabsf(ra[i].x)), fmaxf(fmaxf(fabsf(ra[i].y), fabsf(ra[i].z)), fabsf(ra[i].w)));
+                for (int i = 0; i < A_F4; ++i) {
+                    amxf = fmaxf(fmaxf(amxf, fabsf(ra[i].x)), fmaxf(fmaxf(fabsf(ra[i].y), fabsf(ra[i].z)), fabsf(ra[i].w)));
+                    nanw = fmaf((ra[i].x + ra[i].y) + (ra[i].z + ra[i].w), 0.0f, nanw);
+                }
             } else {
 #pragma unroll
-                for (int i = 0; i < B_F4; ++i) amxf = fmaxf(fmaxf(amxf, fabsf(rb[i].x)), fmaxf(fmaxf(fabsf(rb[i].y), fabsf(rb[i].z)), fabsf(rb[i].w)));
+                for (int i = 0; i < B_F4; ++i) {
+                    amxf = fmaxf(fmaxf(amxf, fabsf(rb[i].x)), fmaxf(fmaxf(fabsf(rb[i].y), fabsf(rb[i].z)), fabsf(rb[i].w)));
+                    nanw = fmaf((rb[i].x + rb[i].y) + (rb[i].z + rb[i].w), 0.0f, nanw);
+                }
             }
         }
 #pragma unroll
@@ -497,7 +509,7 @@ __global__ void __launch_bounds__(256) wgrad_lin_f16_kernel(WgArgs g) {
 
     if (want_amax) {
         __shared__ unsigned wamx[4];
-        unsigned amx = __float_as_uint(amxf);
+        unsigned amx = vxb_amax_word(amxf, nanw);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o, 64));
         if (lane == 0) wamx[wid] = amx;
@@ -598,7 +610,7 @@ __global__ void __launch_bounds__(512) wgrad_wide_f16_kernel(WideArgs g) {
     const bool amax_u = g.amax_part != nullptr && g.grad_is_u;
     const bool amax_v = g.amax_part != nullptr && !g.grad_is_u && blockIdx.x == 0;
     float4 ps = make_float4(0.f, 0.f, 0.f, 0.f);        // position sums: of this thread's U quad (psum_u) or V quad (psum_v), never both
-    float amxf = 0.f;
+    float amxf = 0.f, nanw = 0.f;          // largest |gradient operand| seen; nanw: NaN once a NaN / inf was seen (fmaxf drops NaN)
     const int a_st = (tid >> 5) * LDA + (tid & 31) * 4;
     const int b_st = (tid >> 7) * LDB + (tid & 127) * 4;
 #define WW_STORE(S, stage_)                                                                                          \
@@ -607,10 +619,15 @@ __global__ void __launch_bounds__(512) wgrad_wide_f16_kernel(WideArgs g) {
         if (psum_v) {                                                                                                \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) { ps.x += rb[S][i].x; ps.y += rb[S][i].y; ps.z += rb[S][i].z; ps.w += rb[S][i].w; } \
         }                                                                                                            \
-        if (amax_u) amxf = fmaxf(fmaxf(amxf, fabsf(ra[S].x)), fmaxf(fmaxf(fabsf(ra[S].y), fabsf(ra[S].z)), fabsf(ra[S].w))); \
+        if (amax_u) {                                                                                                \
+            amxf = fmaxf(fmaxf(amxf, fabsf(ra[S].x)), fmaxf(fmaxf(fabsf(ra[S].y), fabsf(ra[S].z)), fabsf(ra[S].w))); \
+            nanw = fmaf((ra[S].x + ra[S].y) + (ra[S].z + ra[S].w), 0.0f, nanw);                                      \
+        }                                                                                                            \
         if (amax_v) {                                                                                                \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                           \
                 amxf = fmaxf(fmaxf(amxf, fabsf(rb[S][i].x)), fmaxf(fmaxf(fabsf(rb[S][i].y), fabsf(rb[S][i].z)), fabsf(rb[S][i].w))); \
+                nanw = fmaf((rb[S][i].x + rb[S][i].y) + (rb[S][i].z + rb[S][i].w), 0.0f, nanw);                      \
+            }                                                                                                        \
         }                                                                                                            \
         u16* as_ = As0 + (stage_) * WP * LDA;                                                                        \
         u16* bs_ = Bs0 + (stage_) * WP * LDB;                                                                        \
@@ -683,7 +700,7 @@ __global__ void __launch_bounds__(512) wgrad_wide_f16_kernel(WideArgs g) {
 
     if (amax_u || amax_v) {                   // (uniform per workgroup)
         __shared__ unsigned wamx[8];
-        unsigned amx = __float_as_uint(amxf);
+        unsigned amx = vxb_amax_word(amxf, nanw);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o, 64));
         if (lane == 0) wamx[wid] = amx;

@@ -480,9 +480,18 @@ def axpy_(dst, src, alpha=1.0):
 
 # --------------------------------------------------------------------------------------------- conv family
 def conv_weight_fwd(W):
-    """[Co,Ci,k,k,k] -> [(tap, ci)][co]  (tiny re-layout, done with torch views + one copy)."""
+    """[Co,Ci,k,k,k] -> [(tap, ci)][co]  (tiny re-layout, done with torch views + one copy).  Memoised per weight tensor until new_step():
+    a second call on the same weights -- the evaluation agent's act() with frozen weight preparation -- gets the SAME tensor back, so that
+    the address-keyed caches downstream (to_bf16_nk, gemm_wfrag) hit instead of growing by one entry per call."""
+    key = (W.data_ptr(), tuple(W.shape), 'conv_fwd')
+    hit = _WCACHE.get(key)
+    if hit is not None:
+        return hit[0]
     Co, Ci = W.shape[:2]
-    return W.reshape(Co, Ci, -1).permute(2, 1, 0).reshape(-1, Co).contiguous()
+    out = W.reshape(Co, Ci, -1).permute(2, 1, 0).reshape(-1, Co).contiguous()
+    out._vxb_keep = True                     # (to_bf16_nk memoises only the layouts that are themselves kept)
+    _WCACHE[key] = (out, W)                  # (keeps W alive: the key is its address)
+    return out
 
 
 def conv_weight_dgrad(W):
@@ -1440,4 +1449,10 @@ def conv3d_bf16w(src0, wb, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
 def to_bf16_nk(wt_kn):
     """[K][N] fp32 weight layout of the fp32 kernels -> bf16 [N][K] (one small transposing copy per step); in 'bf16x3'
     mode the hi/lo planes [2][N][K]."""
+    if getattr(wt_kn, '_vxb_keep', False):
+        key = (wt_kn.data_ptr(), tuple(wt_kn.shape), 'nk', PRECISION)
+        hit = _WCACHE.get(key)
+        if hit is None:
+            hit = _WCACHE[key] = (split_bf16(wt_kn.t().contiguous()), wt_kn)
+        return hit[0]
     return split_bf16(wt_kn.t().contiguous())
