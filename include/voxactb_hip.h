@@ -52,9 +52,10 @@ int vxb_abi_version(void);
  */
 size_t vxb_voxelize_workspace_bytes(int B, int n_points, int V);
 /* Point chain used by vxb_voxelize_f32: 0 = automatic (tile-routed chain when F <= 4, V <= 200, N < 2^20, all kernels in
- * order on the caller's stream; otherwise the table-based chain), 1 = always the table-based chain, 3 / 5 = tile-routed
- * chain with the empty-grid fill overlapped on a side stream (3: after the route kernel, 5: from the start) -- kept for A/B
- * measurements.  All produce identical grids. */
+ * order on the caller's stream, heavy and light tiles in one launch and -- for a fresh output with 10 channels and even V -- no
+ * fill kernel: every tile writes its own block of the grid; otherwise the table-based chain), 1 = always the table-based
+ * chain, 3 = the tile-routed chain of rounds 2-4 (fill, route, classify, heavy, light as separate launches), 5 = that chain with
+ * the empty-grid fill on a side stream -- kept for A/B measurements.  All produce identical grids. */
 int vxb_voxelize_select_chain(int which);
 int vxb_voxelize_f32(const float* const* coord_src, const float* const* feat_src, int n_src,
                      int B, int pts_per_src, int F,

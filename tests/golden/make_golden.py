@@ -154,7 +154,34 @@ def enc_kw(cfg, arm=False):
     return dict(depth=cfg['depth'], voxel_patch_stride=cfg['s'], arm_pred_loss=arm)
 
 
-def encoder_fixture(name, cfg, arm=False, with_grads=True, digest=False, crop=False, check_oracle=True, f64_grads=False):
+KINK_SITES = ('input_preprocess', 'patchify', 'up0.conv_up.0', 'up0.conv_up.2', 'final')      # the grid-sized LeakyReLU blocks
+KINK_TAU = 3e-5
+
+
+def capture_kinks(enc, store, tau=KINK_TAU):
+    """forward hooks on the conv of every grid-sized LeakyReLU block: flat channels-LAST indices ([B, D, H, W, C], the product's layout) of
+    the pre-activations with |x| < tau and whether they are positive.  The loss is only piecewise smooth: LeakyReLU' jumps from 0.02 to 1
+    at x = 0, so ANY forward arithmetic that moves such an x across zero (the default precision's forward is within ~1e-5 of fp32) evaluates
+    another subgradient there -- and parameter gradients are heavily cancelling sums over 10^6 voxels in which one such element can weigh
+    percents (tools/experiments/fwd_sensitivity_gpu.py: 95 of 64 M elements of u0 carry the whole 3-8 % of the 'forward-sensitive' batches).
+    A test evaluates the product's backward at the SAME choices as the run the fixture's gradients come from."""
+    hooks = []
+
+    def make(site):
+        def hook(mod, inp, out):
+            x = out.detach()
+            xl = x.permute(0, 2, 3, 4, 1).reshape(-1)
+            idx = torch.nonzero(xl.abs() < tau)[:, 0]
+            store['kink__%s__idx' % site] = idx.int()
+            store['kink__%s__pos' % site] = (xl[idx] > 0).to(torch.uint8)
+        return hook
+    mods = dict(enc.named_modules())
+    for site in KINK_SITES:
+        hooks.append(mods[site + '.conv3d'].register_forward_hook(make(site)))
+    return hooks
+
+
+def encoder_fixture(name, cfg, arm=False, with_grads=True, digest=False, crop=False, check_oracle=True, f64_grads=False, kinks=False):
     enc, sd = make_ref_encoder(cfg, arm)
     rs = batch_for(cfg, seed=1, arm=arm, crop=crop)
     pcd = [rs['%s_point_cloud' % c] for c in cfg['cams']]
@@ -181,9 +208,14 @@ def encoder_fixture(name, cfg, arm=False, with_grads=True, digest=False, crop=Fa
         for n, m in enc.named_modules():
             if isinstance(m, torch.nn.Conv3d):
                 hooks.append(m.register_forward_hook(tap(n)))
+    kink_store = {}
+    if kinks:
+        hooks += capture_kinks(enc, kink_store)
     with torch.set_grad_enabled(with_grads):
         outs = enc(ins, rs['low_dim_state'], rs['lang_goal_emb'], rs['lang_token_embs'], None, bounds, None)
     print('%s: reference forward %.1fs' % (name, time.time() - t0))
+    if kinks:
+        print('%s: pre-activations within %.0e of zero: %s' % (name, KINK_TAU, {k.split('__')[1]: int(v.numel()) for k, v in kink_store.items() if k.endswith('idx')}))
     inter = None
     if check_oracle:
         with torch.no_grad():
@@ -241,6 +273,9 @@ def encoder_fixture(name, cfg, arm=False, with_grads=True, digest=False, crop=Fa
                 name, n, float((dict(enc.named_parameters())[n + '.bias'].grad.double() - v).abs().max()), float(v.abs().max())))
     for h in hooks:
         h.remove()
+    arrs.update(kink_store)
+    if kinks:
+        arrs['kink_tau'] = KINK_TAU
     save(name, **arrs)
 
 
@@ -356,6 +391,36 @@ def grad_noise_fixture(name, cfg, seed, arm=False, crop=False, nproj=16):
             arrs['grad64__' + n] = r64['grads'][n]
             arrs['grad32__' + n] = r32['grads'][n].float()
     save(name, **arrs)
+
+
+def grad_noise_kinks(name, cfg, seed, arm=False, crop=False):
+    """Supplement of grad_noise_fixture (same encoder, same batch): the FLOAT64 forward's pre-activations within KINK_TAU of zero at every
+    grid-sized LeakyReLU (capture_kinks) -- the subgradient choices of the run whose gradients f5n_noise_* holds.  Forward only."""
+    enc, sd = make_ref_encoder(cfg, arm)
+    rs = batch_for(cfg, seed=seed, arm=arm, crop=crop)
+    pcd = [rs['%s_point_cloud' % c] for c in cfg['cams']]
+    rgb = [rs['%s_rgb' % c] for c in cfg['cams']]
+    bounds = rs['target_object_scene_bounds'] if crop else torch.tensor([synthetic.SCENE_BOUNDS])
+    coords, feats = ovox.flatten_cameras(pcd, rgb)
+    grid = ref_voxelize(coords, feats, bounds, cfg['V'], cfg['B'])
+    ins = grid.permute(0, 4, 1, 2, 3).detach()
+    dt = torch.float64
+    torch.nn.functional.conv3d = _chunked_conv3d_f64
+    store = {}
+    t0 = time.time()
+    try:
+        enc = enc.to(dt)
+        hooks = capture_kinks(enc, store)
+        with torch.no_grad():
+            outs = enc(ins.to(dt), rs['low_dim_state'].to(dt), rs['lang_goal_emb'].to(dt), rs['lang_token_embs'].to(dt), None, bounds, None)
+        for h in hooks:
+            h.remove()
+    finally:
+        torch.nn.functional.conv3d = _ORIG_CONV3D
+    print('%s: float64 forward %.0fs; pre-activations within %.0e of zero: %s' % (
+        name, time.time() - t0, KINK_TAU, {k.split('__')[1]: int(v.numel()) for k, v in store.items() if k.endswith('idx')}), flush=True)
+    flat = outs[0].reshape(cfg['B'], -1)
+    save(name, kink_tau=KINK_TAU, cfg_seed=seed, q_trans_lse=torch.logsumexp(flat, 1), **store)      # (lse: ties the file to its f5n fixture)
 
 
 # ----------------------------------------------------------------------------- F11: the 2Robots (one_policy_more_heads) encoder
@@ -1103,11 +1168,16 @@ SECTIONS = {
     # configs[1] geometry at B = 8: 16 384 rows per linear layer = the row count from which the product dispatches the 128 x 512-tile
     # ("wide") GEMM / fp16 weight-gradient / fp16x2 data-gradient kernels and the fused GEGLU epilogue -- the headline's own dispatch
     # (B = 16 takes the same kernels) pinned on the reference's forward + backward (round 5; ~25 GB resident, a few minutes)
-    'f5gb8': lambda: encoder_fixture('f5gb8_encoder_c2_b8_grads', dict(CFG_C2, B=8), with_grads=True, digest=True, check_oracle=False, f64_grads=True),
+    'f5gb8': lambda: encoder_fixture('f5gb8_encoder_c2_b8_grads', dict(CFG_C2, B=8), with_grads=True, digest=True, check_oracle=False, f64_grads=True, kinks=True),
     # the reference in fp32 AND float64 on three batches per headline shape (the fp32-vs-fp64 spread is the yardstick of the gradient gates)
     **{'f5n_c2_s%d' % sd: (lambda sd=sd: grad_noise_fixture('f5n_noise_c2_s%d' % sd, CFG_C2, sd)) for sd in (1, 2, 3)},
     **{'f5n_c3_s%d' % sd: (lambda sd=sd: grad_noise_fixture('f5n_noise_c3_s%d' % sd, CFG_C3, sd, arm=True, crop=True)) for sd in (1, 2, 3)},
     'f5n_tiny': lambda: grad_noise_fixture('f5n_noise_tiny_s1', CFG_TINY, 1, arm=True),
+    # the float64 run's LeakyReLU choices near zero for the same batches (round 5: the root cause of the 'forward-sensitive' batches)
+    **{'f5k_c2_s%d' % sd: (lambda sd=sd: grad_noise_kinks('f5n_kinks_c2_s%d' % sd, CFG_C2, sd)) for sd in (1, 2, 3)},
+    **{'f5k_c3_s%d' % sd: (lambda sd=sd: grad_noise_kinks('f5n_kinks_c3_s%d' % sd, CFG_C3, sd, arm=True, crop=True)) for sd in (1, 2, 3)},
+    'f5k_v50a': lambda: grad_noise_kinks('f5n_kinks_v50a_s1', CFG_V50, 1, arm=True, crop=True),
+    'f5k_v50b': lambda: grad_noise_kinks('f5n_kinks_v50b_s1', CFG_V50B, 1, arm=True, crop=True),
     'f5n_v50a': lambda: grad_noise_fixture('f5n_noise_v50a_s1', CFG_V50, 1, arm=True, crop=True),
     'f5n_v50b': lambda: grad_noise_fixture('f5n_noise_v50b_s1', CFG_V50B, 1, arm=True, crop=True),
     'f11tiny': lambda: encoder2_fixture('f11_encoder_2robots_tiny', CFG_TINY),
@@ -1135,7 +1205,7 @@ if __name__ == '__main__':
     todo = [s for s in a.only.split(',') if s] or list(SECTIONS)
     torch.manual_seed(0)
     for s in todo:
-        if (s in ('f5', 'f5g', 'f5gb8', 'f5c3', 'f5v200', 'f5v200g') or s.startswith('f5n_c')) and a.skip_c2:
+        if (s in ('f5', 'f5g', 'f5gb8', 'f5c3', 'f5v200', 'f5v200g') or s.startswith(('f5n_c', 'f5k_c'))) and a.skip_c2:
             continue
         print('==', s)
         SECTIONS[s]()

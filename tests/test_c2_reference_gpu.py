@@ -81,6 +81,33 @@ def _check_forward(g, outs, arm, tag):
     return dict(q_samples=e_s, q_top=e_t, lse=e_l, rot_grip=e_r, collision=e_c)
 
 
+KINK_KEYS = {'input_preprocess': 'd0', 'patchify': 'patch', 'up0.conv_up.0': 'z1', 'up0.conv_up.2': 'u0', 'final': 'u'}
+
+
+def force_kinks(cache, g):
+    """The loss is piecewise smooth: LeakyReLU' jumps from 0.02 to 1 where a pre-activation crosses zero, and a forward arithmetic that is
+    1e-5 away from the reference's moves ~100 of the 64 M elements of u0 across (tools/experiments/fwd_sensitivity_gpu.py; DESIGN.md 5r5:
+    those elements alone carry the 3-8 % gradient differences of the 'forward-sensitive' batches -- parameter gradients are cancelling sums
+    over 10^6 voxels).  Fixtures that carry the reference run's pre-activations within 3e-5 of zero (make_golden.py: capture_kinks) let the
+    backward be evaluated at the SAME subgradient choices, exactly as the max-pool arg-maxima are: the saved activation is given the
+    reference's sign there (magnitude 1e-30: these values are < 3e-5 anyway).  Returns the number of choices that differed."""
+    flips = 0
+    for site, key in KINK_KEYS.items():
+        k = 'kink__%s__idx' % site
+        if k not in g.files:
+            continue
+        idx = T(g[k]).long().to(DEV)
+        pos = T(g['kink__%s__pos' % site]).to(DEV) > 0
+        t = cache[key]
+        assert t.is_contiguous()
+        flat = t.view(-1)
+        cur = flat[idx]
+        assert idx.numel() == 0 or float(cur.abs().max()) < 1e-3, (site, float(cur.abs().max()))      # (same layout, same elements)
+        flips += int(((cur > 0) != pos).sum())
+        flat[idx] = torch.where(pos, torch.full_like(cur, 1e-30), torch.full_like(cur, -1e-30))
+    return flips
+
+
 def _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, tag):
     at = rs['trans_action_indicies'].long()
     lab = ((at[:, 0] * V + at[:, 1]) * V + at[:, 2]).int().to(DEV)
@@ -99,6 +126,8 @@ def _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, tag):
     assert abs(loss - float(g['loss'])) < 1e-4, (tag, loss, float(g['loss']))
     for p in enc.parameters():
         p.grad = None
+    if 'kink_tau' in g.files:
+        print('%s: LeakyReLU choices near zero that differ from the reference run\'s (backward evaluated at the reference\'s): %d' % (tag, force_kinks(cache, g)))
     eng.backward(cache, dq, d_o, d_arm)
     P = dict(enc.named_parameters())
     for prm in P.values():            # (a block an ablation leaves unused has no gradient: the reference's .grad is None there, the fixture holds zeros)

@@ -13,16 +13,16 @@ precision over the regular fixtures: median 3e-4 .. 9e-4 per fixture, worst tens
 products over 8000 positions per sample; 5e-4 with VOXACTB_WGRAD_PRECISION=bf16x3); exact-fp32 mode: median 1e-4 .. 3e-4, worst 5e-4.  Q-values: within 1e-4 of the float64 forward
 (BASELINE.json north_star).  Every precision the engine ships is held to the same gate on every seed.
 
-Two of the eight batches (c2_s3, v50b_s1) are FORWARD-SENSITIVE: with the default precision's forward (activations within 1.4e-5 of the
-exact-fp32 forward) the gradients of up0 and of everything upstream of it differ from float64 by 3 - 8 %, while the exact-fp32 mode
-stays at 2e-4 on the same batches.  Measured, so that nobody has to repeat it: it is not the backward arithmetic (every backward
-precision and fusion switch -- VOXACTB_WGRAD_PRECISION / DGRAD_PRECISION / ATTN_BWD_KERNEL / FINAL_SS3D / FUSE_U_BWD / FUSE_INPUT_SS /
-HALO_CONV -- leaves the numbers unchanged to three digits, and the isolated-backward test below agrees to 4e-4 on these batches too); not
-the three global max pools (the product's arg-max voxels equal the float64 run's on every fixture: the fixtures carry them, the backward
-is evaluated at them and the count of differing choices is printed); not LeakyReLU masks (1e-6 of the voxel-channels of u0 / u flip, the
-same on the well-behaved batches).  What is left is the curvature of the loss in the grid activations -- SpatialSoftmax3D divides by a
-temperature of 0.01 (network_utils.py:776, :801); where such a soft-arg-max is nearly one-hot its gradient is a difference of nearly equal
-terms -- stated as the likely cause, not proven.  These two batches are gated at 10 % in the default precision and reported."""
+Root cause of the 'forward-sensitive' batches of round 4 (c2_s3, v50b_s1: gradients of up0 and everything upstream 3 - 8 % off float64
+in the default precision, 2e-4 in exact fp32), found in round 5 by swapping saved activations between an fp32 and a bf16x3 forward one
+group at a time (tools/experiments/fwd_sensitivity_gpu.py, profiles/r05_fwd_sensitivity.log): the WHOLE difference enters through u0, and
+through 95 of its 64 000 000 elements (21 of 8 M at V = 50) -- those whose pre-activation is within 1e-6 of zero and comes out with the
+other sign.  LeakyReLU' jumps from 0.02 to 1 there (network_utils.py:12, :128-170); parameter gradients are cancelling sums over 10^6
+voxels with heavy-tailed terms (SpatialSoftmax3D's 1 / 0.01), so one such element can weigh percents.  The loss is piecewise smooth and
+the product evaluates a DIFFERENT, equally valid subgradient -- the same situation as a max-pool tie.  The float64 run's choices at every
+pre-activation within 3e-5 of zero are therefore part of the fixtures (f5n_kinks_*.npz: 65 KB per batch) and the backward is evaluated at
+them, as it already was at the float64 run's pool arg-maxima; with that, every batch holds the regular 0.5 % gate in every precision and
+the 10 % carve-out of round 4 is gone.  test_unforced_kink_choices_* keeps the un-forced numbers on record."""
 import os
 
 import numpy as np
@@ -30,7 +30,7 @@ import pytest
 import torch
 
 from oracle import weights as ow
-from tests.test_c2_reference_gpu import DEV, T, _setup
+from tests.test_c2_reference_gpu import DEV, T, _setup, force_kinks
 from voxactb_amd import ops
 
 pytestmark = pytest.mark.gpu
@@ -40,7 +40,13 @@ FIXTURES = ['f5n_noise_c2_s1', 'f5n_noise_c2_s2', 'f5n_noise_c2_s3', 'f5n_noise_
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
-def _grads(g, precision, attn_kernel, attn_gx, force_pools=True):
+def _kinks(fixture_name):
+    """the float64 run's LeakyReLU choices near zero for this fixture's batch (f5n_kinks_*.npz, make_golden.py: grad_noise_kinks), or None"""
+    path = os.path.join(GOLDEN, fixture_name.replace('f5n_noise_', 'f5n_kinks_') + '.npz')
+    return np.load(path, allow_pickle=False) if os.path.exists(path) else None
+
+
+def _grads(g, precision, attn_kernel, attn_gx, force_pools=True, kinks=None):
     enc, rs, grid, arm, V, B = _setup(g)
     eng = enc.engine()
     eng.precision = precision
@@ -72,12 +78,14 @@ def _grads(g, precision, attn_kernel, attn_gx, force_pools=True):
             ref = T(g['pool_argmax64_%d' % i]).to(DEV).int().reshape(am.shape).contiguous()
             flips.append(int((am != ref).sum()))
             cache[key] = (ss, mx, st, ref)
+    if kinks is not None:
+        flips = (flips or []) + ['LeakyReLU: %d' % force_kinks(cache, kinks)]
     eng.backward(cache, dq, d_o, d_arm)
     return enc, outs, loss, arm, flips
 
 
-def _measure(g, precision, attn_kernel, attn_gx, tag):
-    enc, outs, loss, arm, flips = _grads(g, precision, attn_kernel, attn_gx)
+def _measure(g, precision, attn_kernel, attn_gx, tag, kinks=None):
+    enc, outs, loss, arm, flips = _grads(g, precision, attn_kernel, attn_gx, kinks=kinks)
     B = outs[0].shape[0]
     flat = outs[0].reshape(B, -1).double().cpu()
     sidx = T(g['q_trans_sample_idx']).long()
@@ -111,29 +119,47 @@ def _available():
     return [f for f in FIXTURES if os.path.exists(os.path.join(GOLDEN, f + '.npz'))]
 
 
-# forward-sensitive batches (module docstring): gated at 10 % in the default precision, at the regular gate in exact fp32
-FORWARD_SENSITIVE = {'f5n_noise_c2_s3': 0.10, 'f5n_noise_v50b_s1': 0.10}
-
-
 @pytest.mark.parametrize('fixture', FIXTURES)
 @pytest.mark.parametrize('mode,wide_dispatch', [('fp32', False), ('bf16x3+r3/f16', False), ('bf16x3+r3/f16-gx0', False), ('bf16x3+r3/f16', True)],
                          indirect=['wide_dispatch'], ids=['fp32', 'bf16x3+r3/f16', 'bf16x3+r3/f16-gx0', 'bf16x3+r3/f16-wide'])
 def test_gradients_against_the_float64_reference(golden, fixture, mode, wide_dispatch):
     """'fp32': the exact-fp32 kernels; 'bf16x3+r3/f16': the shipped default (bf16x3 forward incl. round 3's attention forward, fp16 single /
-    double products in the backward, pipelined fp16 attention backward with hi + lo gradient operands)."""
+    double products in the backward, pipelined fp16 attention backward with hi + lo gradient operands); '-wide': through the kernels the
+    B = 16 headline dispatches.  Backward evaluated at the float64 run's max-pool and LeakyReLU choices (module docstring)."""
     if fixture not in _available():
         pytest.skip('fixture not generated')
     g = golden(fixture)
+    kinks = _kinks(fixture)
+    assert kinks is not None, 'tests/golden/%s.npz is missing (make_golden.py --only f5k_*)' % fixture.replace('f5n_noise_', 'f5n_kinks_')
+    assert abs(float(kinks['q_trans_lse'][0]) - float(g['q_trans_lse'][0])) < 1e-9              # (the same float64 forward)
     precision, _, attn = mode.partition('+')
-    eq, rows, loss = _measure(g, precision, attn.replace('-gx0', '') or 'r3', not attn.endswith('-gx0'), '%s/%s' % (fixture[10:], mode))
+    eq, rows, loss = _measure(g, precision, attn.replace('-gx0', '') or 'r3', not attn.endswith('-gx0'), '%s/%s' % (fixture[10:], mode), kinks=kinks)
     assert eq < 1e-4
     assert abs(loss - float(g['loss'])) < 1e-4
-    if precision != 'fp32' and fixture in FORWARD_SENSITIVE:
-        worst = max(r[2] / (r[3] + 1e-300) for r in rows if r[3] > 1e-6 * max(q[3] for q in rows))
-        assert worst < FORWARD_SENSITIVE[fixture], worst
-        return
     bad = [(r[1], 'x gate %.2f' % r[0], '%.2e' % (r[2] / (r[3] + 1e-300))) for r in rows if r[0] > 1.0]
     assert not bad, bad
+
+
+@pytest.mark.parametrize('fixture', ['f5n_noise_c2_s3', 'f5n_noise_v50b_s1', 'f5n_noise_c2_s1'])
+def test_unforced_kink_choices_are_what_moved_the_forward_sensitive_batches(golden, fixture):
+    """On record: the default precision WITHOUT the float64 run's LeakyReLU choices.  c2_s3 / v50b_s1 then sit 3 - 8 % / ~1 % off float64
+    upstream of u0 (round 4's carve-out); c2_s1 is unaffected.  Asserted: forcing the choices -- a few dozen elements of 64 M -- is the
+    whole difference (the forced run holds the regular gate, tested above; here: the un-forced worst tensor is at least 5 x the forced one
+    on the two sensitive batches), and nothing is worse than round 4's 10 %."""
+    if fixture not in _available() or _kinks(fixture) is None:
+        pytest.skip('fixture not generated')
+    g = golden(fixture)
+
+    def worst(rows):
+        top = max(q[3] for q in rows)
+        return max(r[2] / (r[3] + 1e-300) for r in rows if r[3] > 1e-6 * top)
+    _, rows_u, _ = _measure(g, 'bf16x3', 'r3/f16', True, '%s/unforced' % fixture[10:])
+    _, rows_f, _ = _measure(g, 'bf16x3', 'r3/f16', True, '%s/forced' % fixture[10:], kinks=_kinks(fixture))
+    wu, wf = worst(rows_u), worst(rows_f)
+    print('%s: worst tensor, relative L2 vs float64: un-forced %.2e, at the float64 choices %.2e' % (fixture[10:], wu, wf))
+    assert wu < 0.10
+    if fixture != 'f5n_noise_c2_s1':
+        assert wu > 5 * wf, (wu, wf)
 
 
 @pytest.mark.parametrize('fixture', ['f5n_noise_c2_s1', 'f5n_noise_c2_s3', 'f5n_noise_c3_s2', 'f5n_noise_v50b_s1'])

@@ -27,6 +27,9 @@ from voxactb_amd import synthetic
 SITES = {
     'd0': 'input_preprocess', 'patch': 'patchify', 'x_cross': 'cross_attend_blocks.1', 'x_l2': 'layers.2.1', 'x_l5': 'layers.5.1',
     'z': 'decoder_cross_attn', 'z1': 'up0.conv_up.0', 'u0': 'up0', 'u': 'final',
+    # the PRE-activation of a LeakyReLU block (the conv's output, before the block's activation sees it): a perturbation here can move
+    # an element across zero, i.e. change LeakyReLU' from 0.02 to 1 -- the mechanism tools/experiments/fwd_sensitivity_gpu.py found
+    'u0pre': 'up0.conv_up.2.conv3d', 'upre': 'final.conv3d', 'z1pre': 'up0.conv_up.0.conv3d', 'd0pre': 'input_preprocess.conv3d',
 }
 # perturb what ONE consumer of z / u reads (perceiver :451, :454, :470): SpatialSoftmax3D, the global max pool (2nd / 3rd call), up0
 PRE_SITES = {'ss1_in': ('ss1', 1), 'maxp1_in': ('global_maxp', 2), 'up0_in': ('up0', 1), 'ss2_in': ('ss_final', 1), 'maxp2_in': ('global_maxp', 3),
@@ -101,6 +104,7 @@ if __name__ == '__main__':
     ap.add_argument('--eps', type=float, default=1.4e-5)
     ap.add_argument('--mode', default='uniform')
     ap.add_argument('--f64', action='store_true')
+    ap.add_argument('--draws', type=int, default=1, help='independent noise draws per site')
     a = ap.parse_args()
     torch.set_num_threads(8)
     cfg, arm, crop = {'c2': (mg.CFG_C2, False, False), 'c3': (mg.CFG_C3, True, True), 'v50a': (mg.CFG_V50, True, True),
@@ -121,7 +125,8 @@ if __name__ == '__main__':
     l0, g0, o0 = run(enc, ins, rs, bounds, arm, dtype=dt)
     print('%s seed %d: baseline loss %.6f (%.0f s)' % (a.cfg, a.seed, l0, time.time() - t0), flush=True)
     for site in [s for s in a.sites.split(',') if s]:
-        l1, g1, o1 = run(enc, ins, rs, bounds, arm, site=site, eps=a.eps, seed=a.seed, dtype=dt, mode=a.mode)
-        dq = max(float((x - y).abs().max()) for x, y in zip(o0, o1))
-        print('site %-8s loss %.6f  max |dQ| %.2e' % (site, l1, dq), flush=True)
-        summarise(site, g0, g1)
+        for d in range(a.draws):
+            l1, g1, o1 = run(enc, ins, rs, bounds, arm, site=site, eps=a.eps, seed=a.seed + 1000 * d, dtype=dt, mode=a.mode)
+            dq = max(float((x - y).abs().max()) for x, y in zip(o0, o1))
+            print('site %-8s draw %d loss %.6f  max |dQ| %.2e' % (site, d, l1, dq), flush=True)
+            summarise(site, g0, g1)

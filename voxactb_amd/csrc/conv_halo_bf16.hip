@@ -443,6 +443,13 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
         }
     };
     if (PF) halo_issue(0);
+    if (g.dbg & 0xf00) {
+        // start-up stagger (experiment bits 8-11, results stay correct): the two workgroups that share a CU start together, stage together
+        // and compete for the matrix pipe together; the one in the odd hardware wave slot waits ((dbg >> 8) & 15) x 1024 cycles once
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);       // HW_REG_HW_ID, WAVE_ID field
+        if (blockIdx.x < 512 && (slot & 1))
+            for (int i = 0; i < ((g.dbg >> 8) & 15); ++i) __builtin_amdgcn_s_sleep(16);
+    }
     int ch_begin = 0, ch_end = nchunk;
     if (TL && g.ksplit > 1) {
         ch_begin = __builtin_amdgcn_readfirstlane(g.kparts[kpart]);

@@ -614,7 +614,9 @@ static int vox_run(const float* const* coord_src, const float* const* feat_src, 
         // -> incremental update (no fill).  Orders 0 / 3 overlap the fill with the point chain; measured on MI355X that
         // overlap buys nothing (the store stream stretches the latency-bound chain by what it hides), so a stateless call
         // runs the fill after the chain.
-        const int order = out_state != 0 ? 4 : (g_vox_chain == 5 ? 0 : (g_vox_chain == 3 ? 3 : 2));
+        // g_vox_chain 0 (default): round 5's merged tile launch (orders 6 / 7; they fall back to 2 / 4 where they do not apply);
+        // 3: round 4's chain (fill, route, classify, heavy, light as separate launches: orders 2 / 4), 5: the fill on a side stream
+        const int order = out_state != 0 ? (g_vox_chain == 0 ? 7 : 4) : (g_vox_chain == 5 ? 0 : (g_vox_chain == 3 ? 2 : 6));
         // out_state 0 / 2 -> this call writes cell list 0, out_state 1 -> list 1 (and resets the cells of the other one)
         return vox_tiles_launch(src, g, bounds, out, workspace, st, fs, vs->ev_fork, vs->ev_placed, vs->ev_join, order,
                                 out_state == 1 ? 0 : (out_state == 2 ? 1 : -1), out_state == 1 ? 1 : 0);
