@@ -119,6 +119,7 @@ def main():
     eng = engines[0]
     headline_mode = eng.precision          # 'bf16x3' unless VOXACTB_PRECISION overrides it
     headline_bwd = eng.bwd_precision       # '' (= same as the forward) unless VOXACTB_BWD_PRECISION overrides it
+    headline_attn = eng.attn_kernel        # 'r3' (round 3's bf16x3 attention forward) unless VOXACTB_ATTN_KERNEL overrides it
     counter = [0]
     updates_per_step = len(agents) * a.aug_copies
 
@@ -177,8 +178,10 @@ def main():
     def measure(mode, steps, warmup, only=None, stream=False):
         """W untimed + exactly K timed steps in `mode`, bracketed by barrier + synchronize; max over ranks.  `only`: the timer
         labels whose launches are bracketed by HIP events (None = every launch).  stream: batches from the replay store."""
+        base_mode, _, attn = mode.partition('+')                         # 'bf16x3+attn_f16' = the pipelined single-fp16 attention forward
         for e_ in engines:
-            e_.precision, _, e_.bwd_precision = mode.partition('/')      # 'bf16x3/bf16' = forward bf16x3, backward products bf16
+            e_.precision, _, e_.bwd_precision = base_mode.partition('/')  # 'bf16x3/bf16' = forward bf16x3, backward products bf16
+            e_.attn_kernel = 'f16' if attn == 'attn_f16' else headline_attn
         if stream:
             streams[0] = open_streams()
         for _ in range(warmup):
@@ -202,7 +205,7 @@ def main():
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         for e_ in engines:
-            e_.precision, e_.bwd_precision = headline_mode, headline_bwd
+            e_.precision, e_.bwd_precision, e_.attn_kernel = headline_mode, headline_bwd, headline_attn
         if stream:
             for st_ in streams[0]:
                 st_.close()
@@ -241,12 +244,14 @@ def main():
     # secondary measurements of the same workload in the other precisions (never the headline `value`)
     others = {}
     if not a.no_other_modes:
-        for mode in ('fp32', 'bf16x3', 'bf16x3/bf16', 'bf16'):
+        for mode in ('fp32', 'bf16x3', 'bf16x3+attn_f16', 'bf16x3/bf16', 'bf16'):
             if mode == headline_mode and not headline_bwd:
+                continue
+            if mode == 'bf16x3+attn_f16' and (headline_mode != 'bf16x3' or headline_attn != 'r3'):
                 continue
             dt2, _, agg2 = measure(mode, a.steps, 1)
             others[mode] = {'value': world * a.steps / dt2, 'unit': 'steps/s', 'ms_per_step': dt2 / a.steps * 1e3,
-                            'dtype': MODE_DTYPE[mode], 'rooflines': group_rooflines(agg2, mode.partition('/')[0], a.steps),
+                            'dtype': MODE_DTYPE[mode], 'rooflines': group_rooflines(agg2, mode.partition('/')[0].partition('+')[0], a.steps),
                             'note': MODE_NOTE[mode]}
 
     # parity of the headline precision against the REFERENCE at this geometry: the digest the reference produced for a
@@ -254,7 +259,13 @@ def main():
     # reference's own modules; the same check runs as tests/test_c2_reference_gpu.py in both precisions)
     probe = None
     if rank == 0 and not a.no_other_modes:
-        probe = reference_digest_check(dev, headline_mode, V, a.depth, a.latents, HW)
+        # the timed region's linear layers run B * latents rows: from ops.WIDE_MIN_M rows on that is the 128 x 512-tile dispatch -- the B = 1
+        # digest is therefore forced through the same kernels, and the B = 8 reference fixture (16 384 rows) takes them by itself
+        from voxactb_amd import ops
+        wide = B * a.latents >= ops.WIDE_MIN_M
+        probe = reference_digest_check(dev, headline_mode, V, a.depth, a.latents, HW, 'f5_encoder_c2_digest', force_wide=wide)
+        if probe is not None:
+            probe['b8'] = reference_digest_check(dev, headline_mode, V, a.depth, a.latents, HW, 'f5gb8_encoder_c2_b8_grads')
 
     # act() latency: eval agent, B=1 observation, 1 voxelize + 1 forward + argmax + the D2H copy of the 9-vector
     # action -- with precomputed language embeddings, and with the CLIP text transformer in front (helpers/clip_text.py; the RN50
@@ -319,10 +330,9 @@ def main():
                     'algorithmic_flops_per_launch': d['flops'] / max(d['calls'], 1), 'traffic': None}
         dom_key = dom_label
         if headline_mode == 'bf16x3' and (V, B) == (100, 16):
-            for pref, (nbytes, note) in PMC_TRAFFIC_C2.items():
-                if dom_label.startswith(pref):
-                    roofline['traffic'] = nbytes
-                    roofline['traffic_note'] = note
+            tr = profile_traffic(dom_label)
+            if tr is not None:
+                roofline['traffic'], roofline['traffic_note'] = tr
         if headline_mode == 'bf16x3':
             roofline['frac_of_x3_roof'] = tf / (PEAK_BF16_MFMA_TFLOPS / 3.0)
         roofline['share_of_device_time'] = agg[dom_label]['ms'] / tot_ms
@@ -376,34 +386,99 @@ def main():
         dist.destroy_process_group()
 
 
-# HBM bytes per launch from the committed PMC passes of this command at configs[1] (separate --pmc FETCH_SIZE / WRITE_SIZE
-# runs, KiB units; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950, WRITE_SIZE exact)
-PMC_TRAFFIC_C2 = {
-    'conv3d_wgrad[k3 s1 128->64 S100]': (
-        2 * 10769866.9 * 1024.0, 'wgrad_halo_kernel<2,4,4,2> (weight gradient of the final conv, single fp16 products): FETCH_SIZE 11.0 GB raw per '
-                                 'launch (x2 = 22.1 GB) for 12.3 GB compulsory (x 4.1 GB + the second source 4.1 GB + dY 4.1 GB), output 0.2 GB; '
-                                 'profiles/r03_v1_pmc_*'),
-    'conv3d_bf16[k3 s1 128->64 S100': (
-        (2 * 9709523.1 + 4214281.2) * 1024.0,
-        'conv3_halo_kernel<2,1,4,1,0,2> (final conv forward; since the two-product data gradients the only launch of this kernel per step): '
-        'FETCH_SIZE 9.94 GB raw (x2 = 19.9 GB) + WRITE_SIZE 4.32 GB (output 4.1 GB + the statistics partials) per launch = 24.2 GB for 12.3 GB '
-        'compulsory (2 x 4.1 GB read, 4.1 GB written; 2.3x on the reads: the 6x10x10 halo of a 4x8x8 tile); 24.2 GB / 19.0 ms = 1.3 TB/s: '
-        'matrix-core / LDS-bound, not HBM-bound; profiles/r03_v10_pmc_*'),
-    'conv3d_bf16[k3 s1 64->128 S102': (
-        (2 * 5344162.6 + 4000000.0) * 1024.0 + (2 * 3131520.0 + 4000000.0) * 1024.0,
-        'the two launches of the data gradient + padding adjoint: conv3_halo_kernel<2,3,4,1,0,2> (d(u0), fp16x2: 10.9 GB fetched + 4.1 GB '
-        'written) + conv3_halo_kernel<2,2,4,1,0,1> (d(d0), fp16: 6.4 GB + 4.1 GB); profiles/r03_v10_pmc_*'),
+# HBM bytes per launch of the dominant kernel: read from the NEWEST committed PMC passes of this command at configs[1]
+# (profiles/rNN_vK_pmc_{FETCH,WRITE}_SIZE_summary.txt: separate rocprofv3 --pmc runs, tools/profile_round.sh; KiB per dispatch; FETCH_SIZE
+# doubled as MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950, WRITE_SIZE as reported) -- timer label -> the kernels one call
+# of that C-ABI entry launches.  tests/test_bench_traffic_cpu.py checks that every mapped kernel is present in the newest profile.
+TRAFFIC_KERNELS = {
+    'conv3d_bf16[k3 s1 128->64 S100': (['conv3_halo_kernel<2, 1, 4, 1, 0, 2>'],
+                                       'final conv forward (+ the SpatialSoftmax3D partials of its epilogue): 12.3 GB compulsory (2 x 4.1 GB read, 4.1 GB written)'),
+    'conv3d_wgrad[k3 s1 128->64 S100]': (['wgrad_halo_kernel<2, 4, 4, 2>'],
+                                         'weight gradient of the final conv (single fp16 products): 12.3 GB compulsory (x 4.1 GB + the second source 4.1 GB + dY 4.1 GB)'),
+    'conv3d_bf16[k3 s1 64->128 S102': (['conv3_halo_kernel<2, 3, 4, 1, 0, 2>', 'conv3_halo_kernel<2, 2, 4, 1, 0, 1>'],
+                                       'the two launches of the data gradient + padding adjoint of the final conv: d(u0) fp16x2, d(d0) fp16'),
 }
 
-# HBM bytes the voxelizer chain really moves per call at configs[1] (B=16, V=100, 4 x 128 x 128 points), from separate
-# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/bench_voxel.py (sum over the kernels of one call; FETCH_SIZE x 2 as
-# MI355X_MICROARCH.md prescribes for gfx950); profiles/r03_voxel_*_pmc_*.txt.  None = not measured for this geometry.
-PMC_VOXEL_BYTES = {
-    # route 12.5 + light 17.6 + heavy 12.5 + unpatch 7.3 + classify 0.6 = 50.6 MiB fetched (x2) + 127.3 MiB written
-    ('incremental', 100, 16): (2 * 50564.0 + 127279.0) * 1024.0,
-    # the same chain + the 640 MB fill of a fresh grid: 43.3 MiB fetched (x2) + 727.2 MiB written
-    ('stateless', 100, 16): (2 * 43264.0 + 727173.0) * 1024.0,
-}
+
+def newest_pmc_profiles(root=None):
+    """(fetch summary path, write summary path) of the newest rNN_vK pass under profiles/ that has both, or None"""
+    import glob
+    import re
+    root = root or os.path.join(ROOT, 'profiles')
+    best = None
+    for f in glob.glob(os.path.join(root, 'r*_v*_pmc_FETCH_SIZE_summary.txt')):
+        m = re.match(r'r(\d+)_v(\d+)_pmc_FETCH_SIZE_summary\.txt$', os.path.basename(f))
+        wf = f.replace('FETCH_SIZE', 'WRITE_SIZE')
+        if m and os.path.exists(wf):
+            key = (int(m.group(1)), int(m.group(2)))
+            if best is None or key > best[0]:
+                best = (key, f, wf)
+    return None if best is None else (best[1], best[2])
+
+
+def pmc_mean_per_dispatch(path):
+    """kernel name (as tools/pmc_summary.py prints it, truncated to 90 characters) -> mean counter value per dispatch"""
+    out = {}
+    with open(path) as fh:
+        for line in fh:
+            parts = line.rstrip('\n').rsplit(None, 3)
+            if len(parts) == 4 and parts[1].isdigit():
+                try:
+                    out[parts[0].strip()] = float(parts[2])
+                except ValueError:
+                    pass
+    return out
+
+
+def profile_traffic(label):
+    """(HBM bytes per call of the timer label, note) from the newest committed PMC passes, or None"""
+    ent = next((v for k, v in TRAFFIC_KERNELS.items() if label.startswith(k)), None)
+    prof = newest_pmc_profiles()
+    if ent is None or prof is None:
+        return None
+    fetch, write = pmc_mean_per_dispatch(prof[0]), pmc_mean_per_dispatch(prof[1])
+    total, parts = 0.0, []
+    for kern in ent[0]:
+        f = next((v for k, v in fetch.items() if kern in k), None)
+        w = next((v for k, v in write.items() if kern in k), None)
+        if f is None:
+            return None
+        total += (2.0 * f + (w or 0.0)) * 1024.0
+        parts.append('%s: FETCH_SIZE %.2f GB raw (x2), WRITE_SIZE %.2f GB' % (kern, f * 1024.0 / 1e9, (w or 0.0) * 1024.0 / 1e9))
+    return total, '%s; %s; %s' % (ent[1], '; '.join(parts), os.path.basename(prof[0]).replace('_pmc_FETCH_SIZE_summary.txt', '_pmc_*'))
+
+
+# HBM bytes the voxelizer chain really moves per call at configs[1] (B=16, V=100, 4 x 128 x 128 points): from the newest committed
+# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/bench_voxel.py (profiles/rNN_vK_voxel_p{0,2}_pmc_*.txt: 5 warm-up + 20 timed
+# calls = 25 per file; sum over the chain's kernels; FETCH_SIZE x 2 as MI355X_MICROARCH.md prescribes for gfx950).  None = no profile.
+VOXEL_PROFILE_CALLS = 25
+
+
+def voxel_profile_traffic(incremental, root=None):
+    import glob
+    import re
+    root = root or os.path.join(ROOT, 'profiles')
+    tag = 'p2' if incremental else 'p0'
+    best = None
+    for f in glob.glob(os.path.join(root, 'r*_v*_voxel_%s_pmc_FETCH_SIZE.txt' % tag)):
+        m = re.match(r'r(\d+)_v(\d+)_voxel_', os.path.basename(f))
+        wf = f.replace('FETCH_SIZE', 'WRITE_SIZE')
+        if m and os.path.exists(wf):
+            key = (int(m.group(1)), int(m.group(2)))
+            if best is None or key > best[0]:
+                best = (key, f, wf)
+    if best is None:
+        return None, None
+
+    def total(path):
+        t = 0.0
+        with open(path) as fh:
+            for line in fh:
+                parts = line.rstrip('\n').rsplit(None, 3)
+                if len(parts) == 4 and parts[1].isdigit() and ('vt_' in parts[0] or 'vox_' in parts[0]):
+                    t += float(parts[3])
+        return t
+    return (2.0 * total(best[1]) + total(best[2])) * 1024.0 / VOXEL_PROFILE_CALLS, os.path.basename(best[1]).replace('_pmc_FETCH_SIZE.txt', '_pmc_*')
 
 
 def voxel_roofline(ms, alg_bytes, V, B, incremental):
@@ -412,8 +487,8 @@ def voxel_roofline(ms, alg_bytes, V, B, incremental):
     touched) that is far less than the algorithmic read-points + write-grid bytes of SURVEY.md 8d, so the figure priced on those
     is reported separately as `algorithmic_equivalent_gbps` (what a full-rewrite voxelizer would need to sustain to be as fast)
     and never as a fraction of the peak."""
-    traffic = PMC_VOXEL_BYTES.get(('incremental' if incremental else 'stateless', V, B))
-    r = {'bound': 'hbm', 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'avg_launch_ms': ms, 'traffic': traffic,
+    traffic, traffic_src = voxel_profile_traffic(incremental) if (V, B) == (100, 16) else (None, None)
+    r = {'bound': 'hbm', 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'avg_launch_ms': ms, 'traffic': traffic, 'traffic_source': traffic_src,
          'algorithmic_bytes_per_launch': alg_bytes, 'algorithmic_equivalent_gbps': alg_bytes / (ms * 1e-3) / 1e9,
          'target': 'north_star: >= 0.60 of HBM peak on the algorithmic bytes = <= %.0f us per call' % (alg_bytes / (0.6 * PEAK_HBM_GBPS * 1e9) * 1e6)}
     if incremental:
@@ -464,6 +539,7 @@ MODE_DTYPE = {         # (short: the driver's record truncates long strings; the
     'bf16x3': 'f32 storage/accumulate; fwd products bf16x3 (3 bf16 MFMA); bwd: weight grads + attention 1x fp16, data grads 2x fp16 (scaled)',
     'bf16': 'bf16 MFMA, f32 accumulate/storage',
     'bf16x3/bf16': 'fwd bf16x3, bwd products plain bf16',
+    'bf16x3+attn_f16': 'as bf16x3, attention fwd on 1x fp16 products (VOXACTB_ATTN_KERNEL=f16)',
 }
 MODE_NOTE = {
     'fp32': 'exact fp32 matrix cores: the reference-parity mode of the first measurements (tests/test_encoder_gpu.py, 1e-4)',
@@ -475,6 +551,14 @@ MODE_NOTE = {
     'bf16': 'throughput mode, NOT held to the 1e-4 Q-value bound (tests/test_bf16_mode_gpu.py: ~4e-3 on q_trans)',
     'bf16x3/bf16': 'mixed mode (VOXACTB_BWD_PRECISION=bf16): the forward keeps the 1e-4 Q-value bound, parameter gradients are '
                    'within 0.5 % of the reference (norms within 4e-3) instead of 0.2 % -- not the default',
+    'bf16x3+attn_f16': 'named mode, NOT the default: the default precision with the attention FORWARD (QK^T, PV) on the pipelined kernel with ONE '
+                       'fp16 product per term (csrc/flash2_fwd.hip) instead of round 3\'s bf16x3 triple.  Measured against the float64 reference on '
+                       'eight batches at configs[1] / [2] / released-recipe geometry (tools/experiments/f16_attention_forward_gate.py, '
+                       'profiles/r05_attn_f16_forward_gate.log): max |Q - Q64| 2.4e-5 .. 6.6e-5 (the default: 2.0e-5 .. 3.9e-5; bound 1e-4), every '
+                       'parameter gradient inside the 0.5 % gate once the backward is evaluated at the float64 run\'s LeakyReLU choices (worst tensor '
+                       '0.74 x gate, the default 0.78 x) -- its round-4 rejection was the kink effect of DESIGN.md 5r5, not attention arithmetic.  Not '
+                       'the default because on the SMALL fixtures (V = 8 .. 32, tens of tokens) it leaves the 1e-4 bound (act() fixture: 1.15e-4 on a '
+                       'collision softmax) and its margin at configs[1] is 1.5 x',
 }
 # `peak` of every matrix-core roofline = the guide's dense MFMA peak of the operand type (MI355X_MICROARCH.md): 157.3 TF/s fp32,
 # 2500 TF/s bf16 / fp16.  The bf16x3 precision spends three MFMAs per product, so an ideal bf16x3 kernel tops out at 1/3 of that
@@ -546,19 +630,36 @@ def attention_kernel_probe(dev):
     return out
 
 
-def reference_digest_check(dev, mode, V, depth, latents, HW):
-    """Forward of the engine in precision `mode` on the seeded batch of fixture F5 (BASELINE.json configs[1] geometry, B=1) with
-    name-hashed weights, against the numbers the REFERENCE produced for it.  None when the bench runs at another size."""
+def reference_digest_check(dev, mode, V, depth, latents, HW, fixture, force_wide=False):
+    """Forward of the engine in precision `mode` on the seeded batch of a reference fixture at BASELINE.json configs[1] geometry (F5: B = 1;
+    f5gb8: B = 8) with name-hashed weights, against the numbers the REFERENCE produced for it.  None when the bench runs at another size.
+    force_wide: dispatch the 128 x 512-tile kernels of the B = 16 timed region for this smaller batch too (ops.set_wide_min_rows)."""
     import numpy as np
-    from voxactb_amd import synthetic
+    from voxactb_amd import ops, synthetic
     from voxactb_amd.agents.peract_bc.perceiver_lang_io import PerceiverVoxelLangEncoder
     from voxactb_amd.voxel.voxel_grid import VoxelGrid
-    path = os.path.join(ROOT, 'tests', 'golden', 'f5_encoder_c2_digest.npz')
+    path = os.path.join(ROOT, 'tests', 'golden', fixture + '.npz')
     if not os.path.exists(path):
         return None
     g = np.load(path, allow_pickle=False)
     if (V, depth, latents, HW) != (int(g['cfg_V']), int(g['cfg_depth']), int(g['cfg_latents']), int(g['cfg_H'])):
         return None
+    Bf = int(g['cfg_B'])
+    old_min = ops.WIDE_MIN_M
+    if force_wide:
+        ops.set_wide_min_rows(1024)
+    try:
+        return _digest_check(dev, mode, V, depth, latents, HW, fixture, g, Bf, force_wide or Bf * latents >= old_min)
+    finally:
+        if force_wide:
+            ops.set_wide_min_rows(old_min)
+
+
+def _digest_check(dev, mode, V, depth, latents, HW, fixture, g, Bf, wide):
+    import numpy as np
+    from voxactb_amd import synthetic
+    from voxactb_amd.agents.peract_bc.perceiver_lang_io import PerceiverVoxelLangEncoder
+    from voxactb_amd.voxel.voxel_grid import VoxelGrid
     T = lambda x: torch.from_numpy(np.asarray(x))       # noqa: E731
     cams = synthetic.CAMERAS4[:int(g['cfg_ncam'])]
     enc = PerceiverVoxelLangEncoder(depth=depth, iterations=1, voxel_size=V, initial_dim=10, low_dim_size=int(g['cfg_low_dim']),
@@ -566,19 +667,21 @@ def reference_digest_check(dev, mode, V, depth, latents, HW):
                                     activation='lrelu', input_dropout=0.0, attn_dropout=0.0, decoder_dropout=0.0)
     enc.load_state_dict(synthetic.hashed_state_dict({n: tuple(p.shape) for n, p in enc.named_parameters()}, 0), strict=False)
     enc = enc.to(dev)
-    rs = synthetic.make_replay_sample(1, cams, (HW, HW), V, int(g['cfg_low_dim']), seed=1)
+    rs = synthetic.make_replay_sample(Bf, cams, (HW, HW), V, int(g['cfg_low_dim']), seed=1)
     rs = {k: (v[:, 0] if v.dim() > 2 else v) for k, v in rs.items()}
     rs = {k: ((v.float() / 255.0) * 2.0 - 1.0 if 'rgb' in k else v.float()) for k, v in rs.items()}
-    vg = VoxelGrid(synthetic.SCENE_BOUNDS, V, dev, 1, 3, HW * HW * len(cams))
+    vg = VoxelGrid(synthetic.SCENE_BOUNDS, V, dev, Bf, 3, HW * HW * len(cams))
     grid = vg.voxelize_cameras([rs['%s_point_cloud' % c].to(dev) for c in cams], [rs['%s_rgb' % c].to(dev) for c in cams])
     occ = torch.nonzero((grid[..., -1] > 0).reshape(-1))[:, 0].int().cpu()
     eng = enc.engine()
     eng.precision = mode
     outs, _ = eng.forward(grid, rs['low_dim_state'].to(dev), rs['lang_token_embs'].to(dev), training=False, save=False)
-    flat = outs[0].reshape(1, -1).float().cpu()
+    flat = outs[0].reshape(Bf, -1).float().cpu()
     sidx = T(g['q_trans_sample_idx']).long()
-    res = {'what': 'engine forward in %s vs the reference digest tests/golden/f5_encoder_c2_digest.npz (V=%d, depth %d, %d latents, '
-                   'B=1, name-hashed weights): max abs error' % (mode, V, depth, latents),
+    res = {'what': 'engine forward in %s vs the reference digest tests/golden/%s.npz (V=%d, depth %d, %d latents, '
+                   'B=%d, name-hashed weights): max abs error' % (mode, fixture, V, depth, latents, Bf),
+           'linear_layer_dispatch': ('the timed region\'s: 128 x 512-tile GEMM + fused GEGLU epilogue (gemm_wide.hip)' if wide else
+                                     '128 x 128 / 128 x 64 tiles (fewer than ops.WIDE_MIN_M rows)'),
            'voxel_occupancy_bit_exact': bool(torch.equal(occ, T(g['grid_occ_flat']))),
            'q_trans_argmax_equal': bool(torch.equal(flat.argmax(1), T(g['q_trans_argmax']))),
            'q_trans_4096_samples': float((flat[:, sidx] - T(g['q_trans_sample'])).abs().max()),

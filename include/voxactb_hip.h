@@ -52,8 +52,7 @@ int vxb_abi_version(void);
  */
 size_t vxb_voxelize_workspace_bytes(int B, int n_points, int V);
 /* Point chain used by vxb_voxelize_f32: 0 = automatic (tile-routed chain when F <= 4, V <= 200, N < 2^20, all kernels in
- * order on the caller's stream, heavy and light tiles in one launch and -- for a fresh output with 10 channels and even V -- no
- * fill kernel: every tile writes its own block of the grid; otherwise the table-based chain), 1 = always the table-based
+ * order on the caller's stream, heavy and light tiles in one launch; otherwise the table-based chain), 1 = always the table-based
  * chain, 3 = the tile-routed chain of rounds 2-4 (fill, route, classify, heavy, light as separate launches), 5 = that chain with
  * the empty-grid fill on a side stream -- kept for A/B measurements.  All produce identical grids. */
 int vxb_voxelize_select_chain(int which);
@@ -176,6 +175,14 @@ void vxb_debug_set_gemm_wide_waves(int waves);  /* wide linear-layer GEMMs: 8 = 
 void vxb_debug_set_gemm_wide_experiment(int bits);  /* timing experiments of gemm_wide.hip (WRONG results): 1 no weight-fragment loads in the loop, 2 no A loads, 4 no A staging / barrier, 8 no epilogue; 32 = row blocks fastest in the grid (right results) */
 void vxb_debug_set_wide_min_rows(int rows);  /* rows from which the wide weight-gradient kernel is dispatched (default 16384; tests lower it) */
 void vxb_debug_set_wgrad_lin(int mode);       /* A/B switch of the linear layers' fp16 weight gradients: 2 (default) wide kernel where one operand has 512 channels, 1 pipelined 128x128 kernel only, 0 generic kernel */
+/* experiment knobs of the LDS-halo conv kernels (conv_halo_bf16.hip, wgrad_halo.hip; tools/bench_halo.py, tools/bench_wgrad_halo*.py).
+   Everything the library exports is declared in this header: libvoxactb_hip.so is linked with csrc/exports.map (vxb_* only). */
+void vxb_debug_set_halo_waves(int nw);              /* 4 (default) or 8 waves per workgroup */
+void vxb_debug_set_halo_wn(int wn);                 /* waves along the output channels in the fragment-from-global kernels: 1 or 2; 0 = default */
+void vxb_debug_set_halo_experiment(int bits);       /* timing experiments (1, 2, 16, 32, 64: WRONG results -- no halo staging / weight-fragment loads / conversion / halo loads / output stores after the first chunk; 4: no skipping of empty waves; 0x100..0xf00: start-up stagger, right results): profiles/r05_final_conv_ablation.log */
+void vxb_debug_set_wgrad_halo_experiment(int bits); /* timing experiments of wgrad_halo.hip (WRONG results): staging only / matrix loop only */
+void vxb_debug_set_wgrad_halo_chunks(int nch);      /* input-channel chunks per workgroup: 1 or 2; 0 = default */
+void vxb_debug_set_wgrad_halo_shape(int shape);     /* voxel tile: 0 = 2x8x8, 1 = 4x4x8, -1 = choose by the grid edge (default) */
 /* dst[i] = convert(src[idx[i]]), i < n: a weight tensor re-laid out through a cached index table in one pass (ops.gather_cvt: the
    polyphase up-conv's effective weight, network_utils.py:245-250, into the fragment orders its forward and data-gradient kernels
    read).  mode 0: dst fp16 (round to nearest even).  mode 1: dst bf16 planes: entry j < plane_off is the hi half of src[j],

@@ -23,6 +23,17 @@ def test_library_exports_all_declared_symbols():
     assert L.vxb_abi_version() >= 1
 
 
+def test_library_exports_nothing_but_the_declared_symbols():
+    """the other direction (round-4 review: debug setters and mangled C++ launchers were exported but not declared): the dynamic symbol table
+    of the .so holds exactly the header's names (csrc/exports.map)."""
+    import subprocess
+    from voxactb_amd.csrc import build
+    lib = build.build(verbose=False)
+    out = subprocess.run(['nm', '-D', '--defined-only', lib], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(line.split()[-1] for line in out.splitlines() if line.strip()))
+    assert exported == declared_symbols(), sorted(set(exported) ^ set(declared_symbols()))
+
+
 def test_workspace_size_query():
     from voxactb_amd import _lib
     n = _lib.lib().vxb_voxelize_workspace_bytes(16, 65536, 100)

@@ -160,3 +160,24 @@ def test_two_arms_share_one_perturbation():
             assert torch.equal(got.cpu().long(), ref.long()), seed
         moved = aug.transform_point_clouds([pcd.to(DEV)], out[4])[0]
         assert float((moved.cpu() - want[5][0]).abs().max()) < 2e-6
+
+
+def test_perturb_se3_reference_name_and_signature():
+    """voxel/augmentation.py:7-65 under its own name: point clouds moved by (p - t) R + clamp(t + shift), against the oracle's
+    restatement of that function on random poses (5e-6: two fp32 evaluation orders)."""
+    from oracle import se3 as ose3
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 3, 8, 8
+    pcd = [torch.rand(B, 3, H, W, generator=g) * 2 - 1 for _ in range(2)]
+    bounds = torch.tensor([[-0.3, -0.5, 0.6, 0.7, 0.5, 1.6]])
+    grip = torch.eye(4).repeat(B, 1, 1)
+    grip[:, :3, 3] = torch.rand(B, 3, generator=g) * 0.5
+    shift = torch.eye(4).repeat(B, 1, 1)
+    shift[:, :3, 3] = (torch.rand(B, 3, generator=g) - 0.5) * 2.0        # (large: some samples hit the clamp)
+    rot3 = ose3.euler_angles_to_matrix((torch.rand(B, 3, generator=g) - 0.5) * 1.5, 'XYZ')
+    rot = torch.eye(4).repeat(B, 1, 1)
+    rot[:, :3, :3] = rot3
+    want = ose3.perturb_points(pcd, shift[:, :3, 3], rot3, grip[:, :3, 3], bounds)
+    got = aug.perturb_se3([p.to(DEV) for p in pcd], shift.to(DEV), rot.to(DEV), grip.to(DEV), bounds.to(DEV))
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and float((a.cpu() - b).abs().max()) < 5e-6

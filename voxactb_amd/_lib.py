@@ -72,6 +72,8 @@ def lib():
             L.vxb_debug_set_wgrad_lin(int(os.environ['VOXACTB_WGRAD_LIN']))
         if os.environ.get('VOXACTB_WIDE_WAVES'):   # A/B switch of the wide linear-layer GEMMs (gemm_wide.hip): 8 or 4 waves per workgroup
             L.vxb_debug_set_gemm_wide_waves(int(os.environ['VOXACTB_WIDE_WAVES']))
+        if os.environ.get('VOXACTB_WIDE_MIN_M'):   # rows from which the wide linear-layer kernels are dispatched: ops.WIDE_MIN_M reads the same variable
+            L.vxb_debug_set_wide_min_rows(int(os.environ['VOXACTB_WIDE_MIN_M']))
         if os.environ.get('VOXACTB_WIDE_DBG'):     # gemm_wide.hip experiment bits (32: row blocks fastest in the grid, round 3's order)
             L.vxb_debug_set_gemm_wide_experiment(int(os.environ['VOXACTB_WIDE_DBG']))
         _lib = L

@@ -348,6 +348,10 @@ class PerceiverEngine:
         # backward of the attention core when the forward ran round 3's kernels: '' = round 3's backward too, 'f16' / 'bf16' = the
         # pipelined backward (it only needs q, k | v, O, lse and the dropout seed of the forward)
         self.attn_bwd_kernel = os.environ.get('VOXACTB_ATTN_BWD_KERNEL', 'f16')
+        if self.attn_bwd_kernel not in ('', 'f16', 'bf16'):
+            raise ValueError("VOXACTB_ATTN_BWD_KERNEL must be '' (round 3's backward: VOXACTB_ATTN_BWD_PRECISION then selects bf16x3 / bf16), f16 or bf16")
+        if self.attn_bwd_precision and self.attn_bwd_kernel and 'VOXACTB_ATTN_BWD_KERNEL' not in os.environ:
+            self.attn_bwd_kernel = ''         # an explicitly chosen precision of round 3's backward is not silently overridden by the new default
         # weight gradients of the two big 3x3x3 convs (`final`, the polyphase up-conv) when the backward runs in 'bf16x3':
         # 'fp16' (default) = one fp16 product per term, the gradient operand scaled by a power of two taken from its largest
         # magnitude on the device; 'bf16x3' = the triple.  Leaves of the backward pass: nothing downstream sees their rounding.

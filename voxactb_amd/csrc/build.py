@@ -38,6 +38,7 @@ def sources():
 def _headers_mtime():
     hs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith('.h')]
     hs.append(os.path.join(HERE, '..', '..', 'include', 'voxactb_hip.h'))
+    hs.append(os.path.join(HERE, 'exports.map'))
     return max(os.path.getmtime(h) for h in hs)
 
 
@@ -63,7 +64,7 @@ def build(force=False, verbose=True):
         res = list(ex.map(lambda s: _compile(s, force), srcs))
     objs = [o for o, _ in res]
     if force or any(c for _, c in res) or not os.path.exists(LIB):
-        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,--version-script=' + os.path.join(HERE, 'exports.map'), '-o', LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))

@@ -438,7 +438,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             hv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (st_goff[i] >= 0 && !dbg_skip_stage)
+            if (st_goff[i] >= 0 && !dbg_skip_stage && !((g.dbg & 0x20) && ch_ > 0))      // (0x20: no halo loads after the first chunk)
                 hv[i] = *reinterpret_cast<const float4*>(src + (vbase + st_goff[i]) * Cs + c0 + (((tid + NTH * i) % F4P) * 4));
         }
     };
@@ -486,7 +486,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
         }
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            if (st_goff[i] != -1 && !dbg_skip_stage) {
+            if (st_goff[i] != -1 && !dbg_skip_stage && !((g.dbg & 0x10) && ch > 0)) {       // (0x10: loads, but no conversion / LDS stores after the first chunk)
                 if (PM >= 2) { hv[i].x *= in_sc; hv[i].y *= in_sc; hv[i].z *= in_sc; hv[i].w *= in_sc; }
                 uint2 pk;
                 pk.x = hb_pack2<PM>(hv[i].x, hv[i].y); pk.y = hb_pack2<PM>(hv[i].z, hv[i].w);
@@ -756,7 +756,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
                     const int n = n0 + (wn * NT + j) * 32 + lq;
                     float v = (PM >= 2 ? acc[i][j][r4 + u] * out_sc : acc[i][j][r4 + u]) + (g.bias ? g.bias[n] : 0.f);
                     if (g.act == 1) v = v > 0.f ? v : v * g.slope;
-                    op[n] = v;
+                    if (!(g.dbg & 0x40)) op[n] = v;                  // (0x40: no output stores)
                     vj[j] = v;
                 }
             }

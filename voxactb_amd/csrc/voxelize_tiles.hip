@@ -262,137 +262,6 @@ __global__ void __launch_bounds__(256) vt_classify_kernel(Geom g, TileWs w) {
     if (is_heavy) w.heavy[s_base[1] + (ex >> 16)] = bt;
 }
 
-template <int F>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) vt_light_kernel(Geom g, TileWs w, float* __restrict__ out) {
-    __shared__ unsigned short s_cnt[CELLS];                 // points per cell, then first slot of the cell
-    __shared__ int s_segs[64], s_segp[65];                  // per chunk: start of the tile's segment, exclusive prefix of lengths
-    __shared__ float4 s_rec[LIGHT * 2];                     // the tile's records in (cell, id) order
-    const int lane = threadIdx.x;
-    const int NT = w.NT, NC = w.NC;
-    const int nlight = w.ctr[0];
-  for (int e = blockIdx.x; e < nlight; e += gridDim.x) {
-    const int bt = w.light[e];
-    const int b = bt / NT, tile = bt - b * NT;
-    const unsigned short* row = w.off + ((size_t)b * (NT + 1) + tile) * NC;
-    int s = 0, len = 0;
-    if (lane < NC) {
-        s = row[lane];
-        len = (int)row[NC + lane] - s;                      // next tile's row: where this tile's segment ends
-    }
-    int incl = len;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-    }
-    const int n = __shfl(incl, 63, 64);
-    wave_sync();                                            // (LDS of the previous tile of this wave is no longer read)
-    s_segs[lane] = s;
-    s_segp[lane] = incl - len;
-    if (lane == 63) s_segp[64] = n;
-    for (int i = lane; i < CELLS / 2; i += 64) reinterpret_cast<unsigned*>(s_cnt)[i] = 0u;
-    wave_sync();
-    // the tile's records, stream position j = lane + 64 k (chunk order = ascending point id)
-    constexpr int K = LIGHT / 64;
-    float4 ra[K], rb[K];
-    unsigned cell[K], pos[K];
-    const size_t rec0 = (size_t)b * w.NP;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int j = lane + 64 * k;
-        cell[k] = 0;
-        ra[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        rb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j < n) {
-            int lo = 0;                                     // largest chunk whose prefix is <= j (prefixes beyond NC equal n)
-#pragma unroll
-            for (int st = 32; st > 0; st >>= 1)
-                if (s_segp[lo + st] <= j) lo += st;
-            const size_t idx = rec0 + (size_t)lo * CHUNK + s_segs[lo] + (j - s_segp[lo]);
-            ra[k] = w.recs[idx * 2];
-            rb[k] = w.recs[idx * 2 + 1];
-            cell[k] = __float_as_uint(rb[k].w) >> ID_BITS;
-        }
-    }
-    // stable rank inside the cell: earlier batches first, lower lanes first
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const bool valid = lane + 64 * k < n;
-        const unsigned long long m = match_bits(cell[k], 10, valid);
-        const int rank = lanes_below(m), cnt = __popcll(m);
-        const unsigned before = valid ? s_cnt[cell[k]] : 0u;
-        if (valid && rank == 0) s_cnt[cell[k]] = (unsigned short)(before + cnt);
-        pos[k] = before + rank;
-        wave_sync();
-    }
-    // cell starts: lane L owns the z-column of cells 16 L .. 16 L + 15 (counts are re-read from LDS instead of being kept in
-    // register arrays: indexed arrays end up in scratch memory)
-    int tot = 0, occ = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int c = s_cnt[16 * lane + i];
-        tot += c;
-        occ += c > 0 ? 1 : 0;
-    }
-    int packed = (occ << 16) | tot, pincl = packed;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(pincl, o, 64);
-        if (lane >= o) pincl += t;
-    }
-    const int nocc = __shfl(pincl, 63, 64) >> 16;
-    const int lane_start = (pincl - packed) & 0xFFFF;
-    const int occ_before = (pincl - packed) >> 16;
-    wave_sync();
-    {
-        int run = lane_start;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int c = s_cnt[16 * lane + i];
-            s_cnt[16 * lane + i] = (unsigned short)run;
-            run += c;
-        }
-    }
-    // dense slots of this sample's compact list (order across tiles is arbitrary: every record carries its cell address)
-    int rbase = 0;
-    if (lane == 0) rbase = atomicAdd(&w.ctr[64 + 32 * b], nocc);
-    wave_sync();
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        if (lane + 64 * k < n) {
-            const int p = s_cnt[cell[k]] + pos[k];
-            s_rec[2 * p] = ra[k];
-            s_rec[2 * p + 1] = rb[k];
-        }
-    }
-    wave_sync();
-    rbase = __shfl(rbase, 0, 64);
-    const int tz = tile % w.Tz, ty = (tile / w.Tz) % w.Ty, tx = tile / (w.Tz * w.Ty);
-    float4* res = w.res + (size_t)b * w.NP * 2;
-    int slot = rbase + occ_before;
-    const int lane_end = lane_start + tot;
-#pragma unroll 1
-    for (int i = 0; i < 16; ++i) {
-        const int st = s_cnt[16 * lane + i];
-        const int cnt = (i < 15 ? (int)s_cnt[16 * lane + i + 1] : lane_end) - st;
-        if (cnt > 0) {
-            float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                // zeros_like(self._flat_output) (:145)
-            for (int k = 0; k < cnt; ++k) {
-                const float4 a = s_rec[2 * (st + k)], c4 = s_rec[2 * (st + k) + 1];
-                const float r[7] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z};
-#pragma unroll
-                for (int c = 0; c < 3 + F; ++c) acc[c] = __fadd_rn(acc[c], r[c]);
-            }
-            const int cellid = 16 * lane + i;
-            const int X = tx * TX + (cellid >> 7), Y = ty * TY + ((cellid >> 4) & 7), Z = tz * TZ + (cellid & 15);
-            emit_cell<F>(res, (size_t)slot, acc, cnt, (X * g.V + Y) * g.V + Z,
-                         out ? out + (size_t)b * g.V * g.V * g.V * (3 + F + 4) : nullptr, g.V);
-            ++slot;
-        }
-    }
-  }
-}
-
 // slot (inside the sample's record array) of stream position s of a tile: chunk by binary search over the prefix of the
 // segment lengths, then the offset inside that chunk's segment
 __device__ __forceinline__ size_t locate(const int* s_segp, const int* s_segs, int NC, int s) {
@@ -409,178 +278,17 @@ constexpr int HB = 4;                                   // 64-record batches a w
 // (keeping the sorted records of tiles up to 3584 points in 112 KB of LDS, with 8 batches in flight, was measured: 64 us
 // instead of 53 for the kernel -- the reduction is not what it waits for)
 
-template <int F>
-__global__ void __launch_bounds__(256) vt_heavy_kernel(Geom g, TileWs w, int all_tiles, float* __restrict__ out) {
-    __shared__ unsigned s_hist[4 * CELLS];              // per wave: count, then write cursor, of every cell
-    __shared__ unsigned s_cell[CELLS + 1];              // occupied cells before this one << 20 | first slot of the cell
-    __shared__ int s_segs[MAX_NC];                      // start of the tile's segment inside chunk c
-    __shared__ int s_segp[MAX_NC + 1];                  // exclusive prefix of the segment lengths
-    __shared__ int s_red[4];
-    __shared__ int s_rbase;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int NT = w.NT, NC = w.NC;
-    const int nwork = all_tiles ? g.B * NT : w.ctr[32];
-    for (int e = blockIdx.x; e < nwork; e += gridDim.x) {
-        const int bt = all_tiles ? e : w.heavy[e];
-        const int b = bt / NT, tile = bt - b * NT;
-        // 1. the tile's segments, chunk by chunk (= ascending point id)
-        const unsigned short* row = w.off + ((size_t)b * (NT + 1) + tile) * NC;
-        int n = 0, base_part = 0;
-        for (int c0 = 0; c0 < NC; c0 += 256) {
-            const int c = c0 + tid;
-            int s = 0, len = 0;
-            if (c < NC) {
-                s = row[c];
-                len = (int)row[NC + c] - s;
-                s_segs[c] = s;
-            }
-            int tot;
-            const int ex = block_excl_scan(len, s_red, &tot);
-            if (c < NC) s_segp[c] = n + ex;
-            n += tot;
-            base_part += s;
-        }
-        if (n == 0) { __syncthreads(); continue; }      // (only reachable with all_tiles)
-        if (tid == 0) s_segp[NC] = n;
-        int base;                                       // points of this sample in lower-numbered tiles
-        block_excl_scan(base_part, s_red, &base);
-        for (int i = tid; i < 4 * CELLS; i += 256) s_hist[i] = 0u;
-        __syncthreads();
-        // 2. count per (wave, cell); wave w owns the w-th quarter of the stream
-        const int q = (((n + 3) >> 2) + 63) & ~63;
-        const int r0 = min(n, wv * q), r1 = min(n, r0 + q);
-        unsigned* myh = s_hist + wv * CELLS;
-        const size_t rec0 = (size_t)b * w.NP;
-        for (int s0 = r0; s0 < r1; s0 += 64 * HB) {         // HB batches of 64 in flight, ranked in stream order
-            unsigned cell[HB];
-            bool valid[HB];
-#pragma unroll
-            for (int u = 0; u < HB; ++u) {
-                const int s = s0 + 64 * u + lane;
-                valid[u] = s < r1;
-                cell[u] = 0;
-                if (valid[u]) cell[u] = __float_as_uint(w.recs[(rec0 + locate(s_segp, s_segs, NC, s)) * 2 + 1].w) >> ID_BITS;
-            }
-#pragma unroll
-            for (int u = 0; u < HB; ++u) {
-                if (s0 + 64 * u >= r1) break;                   // (wave-uniform)
-                const unsigned long long m = match_bits(cell[u], 10, valid[u]);
-                const int rank = lanes_below(m), cnt = __popcll(m);
-                if (valid[u] && rank == 0) myh[cell[u]] += (unsigned)cnt;
-            }
-        }
-        __syncthreads();
-        // 3. cell starts: cells in order, waves in order inside a cell
-        {
-            unsigned h[4][4];
-            int cs[4], tot = 0, occ = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int cellid = 4 * tid + i;
-                cs[i] = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { h[i][k] = s_hist[k * CELLS + cellid]; cs[i] += (int)h[i][k]; }
-                tot += cs[i];
-                occ += cs[i] > 0 ? 1 : 0;
-            }
-            int dummy;
-            unsigned run = (unsigned)block_excl_scan((occ << 20) | tot, s_red, &dummy);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int cellid = 4 * tid + i;
-                s_cell[cellid] = run;
-                const unsigned start = run & 0xFFFFFu;
-                s_hist[cellid] = start;
-                s_hist[CELLS + cellid] = start + h[i][0];
-                s_hist[2 * CELLS + cellid] = start + h[i][0] + h[i][1];
-                s_hist[3 * CELLS + cellid] = start + h[i][0] + h[i][1] + h[i][2];
-                run += (cs[i] > 0 ? (1u << 20) : 0u) + (unsigned)cs[i];
-            }
-            if (tid == 255) {
-                s_cell[CELLS] = run;
-                s_rbase = atomicAdd(&w.ctr[64 + 32 * b], (int)(run >> 20));
-            }
-        }
-        __syncthreads();
-        // 4. move every record to its cell segment (stable: stream order = id order)
-        float4* sorted = w.sorted + ((size_t)b * w.NP + base) * 2;
-        for (int s0 = r0; s0 < r1; s0 += 64 * HB) {
-            float4 ra[HB], rb[HB];
-            bool valid[HB];
-#pragma unroll
-            for (int u = 0; u < HB; ++u) {
-                const int s = s0 + 64 * u + lane;
-                valid[u] = s < r1;
-                ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                rb[u] = ra[u];
-                if (valid[u]) {
-                    const size_t idx = rec0 + locate(s_segp, s_segs, NC, s);
-                    ra[u] = w.recs[idx * 2];
-                    rb[u] = w.recs[idx * 2 + 1];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < HB; ++u) {
-                if (s0 + 64 * u >= r1) break;                   // (wave-uniform)
-                const unsigned cell = __float_as_uint(rb[u].w) >> ID_BITS;
-                const unsigned long long m = match_bits(cell, 10, valid[u]);
-                const int rank = lanes_below(m), cnt = __popcll(m);
-                const unsigned before = valid[u] ? myh[cell] : 0u;
-                if (valid[u] && rank == 0) myh[cell] = before + (unsigned)cnt;
-                if (valid[u]) {
-                    const size_t pos = before + rank;
-                    sorted[pos * 2] = ra[u];
-                    sorted[pos * 2 + 1] = rb[u];
-                }
-            }
-        }
-        __syncthreads();
-        // 5. one thread per cell: add the records front to back (ascending id), emit a compact record per occupied cell
-        const int tz = tile % w.Tz, ty = (tile / w.Tz) % w.Ty, tx = tile / (w.Tz * w.Ty);
-        float4* res = w.res + (size_t)b * w.NP * 2;
-        const int rbase = s_rbase;
-#pragma unroll 1
-        for (int i = 0; i < 4; ++i) {
-            const int cellid = i * 256 + tid;
-            const unsigned info = s_cell[cellid], next = s_cell[cellid + 1];
-            const int start = (int)(info & 0xFFFFFu), cnt = (int)(next & 0xFFFFFu) - start;
-            if (cnt > 0) {
-                float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // zeros_like(self._flat_output) (:145)
-                const float4* sp = sorted + (size_t)start * 2;
-                int k = 0;
-                for (; k + 8 <= cnt; k += 8) {                              // eight records in flight, added in order
-                    float4 a[8], c4[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) { a[u] = sp[(k + u) * 2]; c4[u] = sp[(k + u) * 2 + 1]; }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const float r[7] = {a[u].x, a[u].y, a[u].z, a[u].w, c4[u].x, c4[u].y, c4[u].z};
-#pragma unroll
-                        for (int c = 0; c < 3 + F; ++c) acc[c] = __fadd_rn(acc[c], r[c]);
-                    }
-                }
-                for (; k < cnt; ++k) {
-                    const float4 a = sp[k * 2], c4 = sp[k * 2 + 1];
-                    const float r[7] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z};
-#pragma unroll
-                    for (int c = 0; c < 3 + F; ++c) acc[c] = __fadd_rn(acc[c], r[c]);
-                }
-                const int X = tx * TX + (cellid >> 7), Y = ty * TY + ((cellid >> 4) & 7), Z = tz * TZ + (cellid & 15);
-                emit_cell<F>(res, (size_t)(rbase + (int)(info >> 20)), acc, cnt, (X * g.V + Y) * g.V + Z,
-                             out ? out + (size_t)b * g.V * g.V * g.V * (3 + F + 4) : nullptr, g.V);
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------ merged tile kernel
-// Round 5.  One launch instead of heavy -> light (-> and, for a fresh grid, the 640 MB fill in front): workgroups [0, heavy_blocks) take the
-// heavy tiles of the classify list (they are dispatched first and their ~60 us run under everything else), the other workgroups are
-// four independent waves, one tile each.  FULL = 1 (a fresh output tensor): EVERY tile is visited and its whole 8 x 8 x 16-cell block of the
-// grid is written by its owner -- the empty pattern (zeros | x/V, y/V, z/V | 0) as aligned float4 stores along the z-runs, then the
-// occupied cells over it (same wave / same workgroup after a vmcnt(0) barrier: program order) -- so the 640 MB store stream is issued by
-// ~19 K independent waves whose latency-bound point chains hide under their neighbours' stores, and there is no fill kernel.
+// Round 5.  One launch instead of heavy -> light: workgroups [0, heavy_blocks) take the heavy tiles of the classify list (they are
+// dispatched first, and their ~60 us run under everything else), the other workgroups are four independent waves that walk the light
+// list, one tile each.  Both kinds are latency-bound chains of dependent round trips, so -- unlike every pairing with the store-bound
+// fill (below) -- they overlap: 110 -> 55 us for the pair, the incremental call 162 -> 120 us.
+//
+// Measured and NOT kept (profiles/r05_v1_voxel_bench.log, r05_v2_*): a fresh grid without the fill kernel, every tile (or every column of
+// tiles, as aligned 32 KB streams) writing its own block of the grid before patching its occupied cells -- 262 / 287 us against
+// 225 us for fill -> route -> classify -> this kernel.  The store phase of a workgroup is bandwidth-bound and its chain phase
+// latency-bound; workgroups that start together stay in step (all storing, then all waiting), so the launch takes the SUM of the two
+// phases, and a loaded memory system stretches every dependent round trip of the chains by what the overlap would have hidden.
 struct LightLds {
     unsigned short cnt[CELLS];
     int segs[64], segp[66];
@@ -597,64 +305,8 @@ struct HeavyLds {
 static_assert(sizeof(LightLds) % 16 == 0 && sizeof(HeavyLds) % 16 == 0, "16-byte LDS carve");
 constexpr size_t TILES_LDS = 4 * sizeof(LightLds) > sizeof(HeavyLds) ? 4 * sizeof(LightLds) : sizeof(HeavyLds);
 
-// empty-cell pattern of tile (tx, ty, tz) of one sample (C = 10 channels, V even: every z-run starts 16-byte aligned), written by `nt`
-// threads of which this is thread `t` (a wave: nt = 64; a workgroup: 256)
-__device__ __forceinline__ void write_empty_tile(float* __restrict__ out_b, int V, int tx, int ty, int tz, int t, int nt) {
-    const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
-    const int nx = min(TX, V - x0), ny = min(TY, V - y0), nz = min(TZ, V - z0);
-    const float Vf = (float)V;                                  // self._voxel_d (:197)
-    if (nx == TX && ny == TY && nz == TZ && nt == 64) {
-        // interior tile, one wave: 64 z-runs of 40 float4; lane L's k-th store is float4 i = L + 64 k of the tile = (run i / 40, j = i % 40),
-        // and i + 320 is the same (y, j) one x further -- five (y, j) patterns per lane, eight x each
-        float xv[TX];
-#pragma unroll
-        for (int m = 0; m < TX; ++m) xv[m] = __fdiv_rn((float)(x0 + m), Vf);
-#pragma unroll
-        for (int kk = 0; kk < 5; ++kk) {
-            const int i0 = t + 64 * kk;
-            const int run0 = i0 / 40, j = i0 - 40 * run0;       // run0 < 8: x offset 0, y offset run0
-            const int y = y0 + run0;
-            const float yv = __fdiv_rn((float)y, Vf);
-            float v[4];
-            int ex = -1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int f = 4 * j + e, c = f / 10, ch = f - 10 * c;
-                v[e] = ch == 7 ? yv : (ch == 8 ? __fdiv_rn((float)(z0 + c), Vf) : 0.0f);
-                if (ch == 6) ex = e;
-            }
-            float* p = out_b + (((size_t)x0 * V + y) * V + z0) * 10 + 4 * j;
-#pragma unroll
-            for (int m = 0; m < TX; ++m) {
-                float4 o = make_float4(v[0], v[1], v[2], v[3]);
-                if (ex == 0) o.x = xv[m];
-                if (ex == 1) o.y = xv[m];
-                if (ex == 2) o.z = xv[m];
-                if (ex == 3) o.w = xv[m];
-                *reinterpret_cast<float4*>(p + (size_t)m * V * V * 10) = o;
-            }
-        }
-        return;
-    }
-    const int Q = (nz * 10) >> 2;                               // float4 per z-run (nz even: V even)
-    const int total = nx * ny * Q;
-    for (int i = t; i < total; i += nt) {
-        const int run = i / Q, j = i - run * Q;
-        const int xr = run / ny, yr = run - xr * ny;
-        const int x = x0 + xr, y = y0 + yr;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int f = 4 * j + e, c = f / 10, ch = f - 10 * c;
-            v[e] = ch == 6 ? __fdiv_rn((float)x, Vf) : (ch == 7 ? __fdiv_rn((float)y, Vf) : (ch == 8 ? __fdiv_rn((float)(z0 + c), Vf) : 0.0f));
-        }
-        *reinterpret_cast<float4*>(out_b + (((size_t)x * V + y) * V + z0) * 10 + 4 * j) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-}
-
-// one wave, one tile (the algorithm of vt_light_kernel).  FULL: the tile's whole block of the grid is written here (nothing at all for a
-// heavy tile: its workgroup does that), otherwise only the occupied cells of a listed light tile.
-template <int F, int FULL>
+// one wave, one listed light tile (the algorithm of vt_light_kernel): its occupied cells into the compact list and, with `out`, the grid
+template <int F>
 __device__ __forceinline__ void wave_tile(const Geom& g, const TileWs& w, float* __restrict__ out, LightLds& L, int bt, int lane) {
     const int NT = w.NT, NC = w.NC;
     const int b = bt / NT, tile = bt - b * NT;
@@ -673,11 +325,6 @@ __device__ __forceinline__ void wave_tile(const Geom& g, const TileWs& w, float*
         if (lane >= o) incl += t;
     }
     const int n = __shfl(incl, 63, 64);
-    if (FULL) {
-        if (n > LIGHT) return;                              // (classify's rule with NC <= 64: a heavy tile, written by its workgroup)
-        write_empty_tile(out_b, g.V, tx, ty, tz, lane, 64);
-        if (n == 0) return;
-    }
     wave_sync();                                            // (LDS of the previous tile of this wave is no longer read)
     L.segs[lane] = s;
     L.segp[lane] = incl - len;
@@ -780,15 +427,14 @@ __device__ __forceinline__ void wave_tile(const Geom& g, const TileWs& w, float*
     }
 }
 
-// one workgroup, one heavy tile (the algorithm of vt_heavy_kernel); FULL: the tile's empty pattern first
-template <int F, int FULL>
+// one workgroup, one heavy tile (the algorithm of vt_heavy_kernel)
+template <int F>
 __device__ __forceinline__ void group_tile(const Geom& g, const TileWs& w, float* __restrict__ out, HeavyLds& H, int bt, int tid) {
     const int lane = tid & 63, wv = tid >> 6;
     const int NT = w.NT, NC = w.NC;
     const int b = bt / NT, tile = bt - b * NT;
     const int tz = tile % w.Tz, ty = (tile / w.Tz) % w.Ty, tx = tile / (w.Tz * w.Ty);
     float* out_b = out ? out + (size_t)b * g.V * g.V * g.V * (3 + F + 4) : nullptr;
-    if (FULL) write_empty_tile(out_b, g.V, tx, ty, tz, tid, 256);
     const unsigned short* row = w.off + ((size_t)b * (NT + 1) + tile) * NC;
     int n = 0, base_part = 0;
     for (int c0 = 0; c0 < NC; c0 += 256) {
@@ -805,6 +451,7 @@ __device__ __forceinline__ void group_tile(const Geom& g, const TileWs& w, float
         n += tot;
         base_part += s;
     }
+    if (n == 0) { __syncthreads(); return; }            // (uniform; only reachable when every tile is visited: more than 64 chunks per sample)
     if (tid == 0) H.segp[NC] = n;
     int base;                                           // points of this sample in lower-numbered tiles
     block_excl_scan(base_part, H.red, &base);
@@ -895,9 +542,6 @@ __device__ __forceinline__ void group_tile(const Geom& g, const TileWs& w, float
             }
         }
     }
-    // every store of this workgroup (the empty pattern, the sorted records) has reached the L2 before anyone reads `sorted` or overwrites
-    // a pattern cell with its result
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     float4* res = w.res + (size_t)b * w.NP * 2;
     const int rbase = H.rbase;
@@ -934,25 +578,36 @@ __device__ __forceinline__ void group_tile(const Geom& g, const TileWs& w, float
     __syncthreads();
 }
 
-template <int F, int FULL>
+template <int F>
 __global__ void __launch_bounds__(256) vt_tiles_kernel(Geom g, TileWs w, float* __restrict__ out, int heavy_blocks) {
     __shared__ __attribute__((aligned(16))) char smem[TILES_LDS];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < heavy_blocks) {
         HeavyLds& H = *reinterpret_cast<HeavyLds*>(smem);
         const int nheavy = w.ctr[32];
-        for (int e = blockIdx.x; e < nheavy; e += heavy_blocks) group_tile<F, FULL>(g, w, out, H, w.heavy[e], tid);
+        for (int e = blockIdx.x; e < nheavy; e += heavy_blocks) group_tile<F>(g, w, out, H, w.heavy[e], tid);
         return;
     }
     LightLds& L = reinterpret_cast<LightLds*>(smem)[tid >> 6];
     const int wave = ((int)blockIdx.x - heavy_blocks) * 4 + (tid >> 6), nwaves = ((int)gridDim.x - heavy_blocks) * 4;
-    if (FULL) {
-        const int ntile = g.B * w.NT;
-        for (int bt = wave; bt < ntile; bt += nwaves) wave_tile<F, 1>(g, w, out, L, bt, tid & 63);
-    } else {
-        const int nlight = w.ctr[0];
-        for (int e = wave; e < nlight; e += nwaves) wave_tile<F, 0>(g, w, out, L, w.light[e], tid & 63);
-    }
+    const int nlight = w.ctr[0];
+    for (int e = wave; e < nlight; e += nwaves) wave_tile<F>(g, w, out, L, w.light[e], tid & 63);
+}
+
+// the same two routines as separate launches: the chain of rounds 2-4 (vxb_voxelize_select_chain(3), A/B measurements) and, heavy
+// routine only over EVERY tile, samples of more than 64 chunks
+template <int F>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) vt_light_kernel(Geom g, TileWs w, float* __restrict__ out) {
+    __shared__ LightLds L;
+    const int nlight = w.ctr[0];
+    for (int e = blockIdx.x; e < nlight; e += gridDim.x) wave_tile<F>(g, w, out, L, w.light[e], threadIdx.x);
+}
+
+template <int F>
+__global__ void __launch_bounds__(256) vt_heavy_kernel(Geom g, TileWs w, int all_tiles, float* __restrict__ out) {
+    __shared__ HeavyLds H;
+    const int nwork = all_tiles ? g.B * w.NT : w.ctr[32];
+    for (int e = blockIdx.x; e < nwork; e += gridDim.x) group_tile<F>(g, w, out, H, all_tiles ? e : w.heavy[e], threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------ unpatch
@@ -1063,17 +718,15 @@ int vt_launch(const Src& src, const Geom& g, const float* bounds, float* out, co
     if (forked && (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess)) return VXB_ELAUNCH;
     // orders 2 and 4 (the shipped ones): the reduce kernels write the occupied cells straight into the grid, so the dense part
     // (fill, or the reset of the previously occupied cells) runs FIRST and there is no patch kernel
-    // orders 6 / 7 (round 5, the shipped ones when they apply: at most 64 chunks per sample; 6 also needs C = 10, V even, 16-byte aligned
-    // output): stateless / incremental with heavy and light tiles in ONE launch (vt_tiles_kernel); 6 has no fill -- every tile writes
-    // its own block of the grid
-    const bool merged = (order == 6 || order == 7) && w.NC <= 64;
-    if (order == 6) order = (merged && C == 10 && (g.V & 1) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) ? 6 : 2;
-    if (order == 7) order = merged ? 7 : 4;
+    // orders 6 / 7 (round 5, the shipped ones when a sample has at most 64 chunks): fresh buffer / incremental with heavy and light
+    // tiles in ONE launch (vt_tiles_kernel): fill | unpatch, route, classify, tiles
+    if (order == 6 && w.NC > 64) order = 2;
+    if (order == 7 && w.NC > 64) order = 4;
     const bool direct = order == 2 || order == 4 || order == 6 || order == 7;
     float* dout = direct ? out : nullptr;
     if (order == 4 || order == 7) hipLaunchKernelGGL(vt_unpatch_kernel<F>, dim3((unsigned)((cap + 255) / 256), g.B), dim3(256), 0, st, g, w, out);
     if (order == 0) vox_launch_fill(out, g.B, g.V, C, side);
-    if (order == 2) vox_launch_fill(out, g.B, g.V, C, st);
+    if (order == 2 || order == 6) vox_launch_fill(out, g.B, g.V, C, st);
     if (order != 4 && order != 7 && hipMemsetAsync(w.ctr, 0, CTR_INTS(g.B) * sizeof(int), st) != hipSuccess) return VXB_ELAUNCH;
     const size_t lds = (size_t)4 * w.NT * sizeof(unsigned short);
     if (lds > 48 * 1024) {
@@ -1086,10 +739,7 @@ int vt_launch(const Src& src, const Geom& g, const float* bounds, float* out, co
     if (order == 6 || order == 7) {
         hipLaunchKernelGGL(vt_classify_kernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, st, g, w);
         const int hb = (int)(tiles < 512 ? tiles : 512);
-        if (order == 6)
-            hipLaunchKernelGGL((vt_tiles_kernel<F, 1>), dim3((unsigned)(hb + (tiles + 3) / 4)), dim3(256), 0, st, g, w, out, hb);
-        else
-            hipLaunchKernelGGL((vt_tiles_kernel<F, 0>), dim3((unsigned)(hb + (tiles < 4096 ? (tiles + 3) / 4 : 1024))), dim3(256), 0, st, g, w, out, hb);
+        hipLaunchKernelGGL((vt_tiles_kernel<F>), dim3((unsigned)(hb + (tiles < 4096 ? (tiles + 3) / 4 : 1024))), dim3(256), 0, st, g, w, out, hb);
     } else if (w.NC <= 64) {
         hipLaunchKernelGGL(vt_classify_kernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, st, g, w);
         // (light and heavy tiles on two streams were measured: the heavy kernel stretches from 53 to 75 us next to the

@@ -130,6 +130,23 @@ def transform_point_clouds(pcd, xform):
     return out
 
 
+def perturb_se3(pcd, trans_shift_4x4, rot_shift_4x4, action_gripper_4x4, bounds):
+    """Reference name, signature and result (peract/voxel/augmentation.py:7-65): the point clouds of every camera moved by
+    p' = (p - t) R + clamp(t + shift, scene extent), t = the keyframe gripper position.  The [B, 15] transform record of the fused kernel
+    is put together from the three 4 x 4 matrices (B x 15 values of plumbing); the clouds go through vxb_se3_points_f32."""
+    require_cuda(*pcd)
+    dev = pcd[0].device
+    bs = pcd[0].shape[0]
+    bounds = bounds.to(dev).float().reshape(-1, 6)
+    t = action_gripper_4x4[:, 0:3, 3].to(dev).float()
+    shift = trans_shift_4x4[:, 0:3, 3].to(dev).float()
+    rot = rot_shift_4x4.to(dev).float()
+    lo, hi = bounds[:, 0:3].amin(0), bounds[:, 3:6].amax(0)                  # (:45-47: the extent over ALL rows of the bounds)
+    c = torch.minimum(torch.maximum(t + shift, lo), hi) + rot[:, 3, 0:3]     # (row vectors: the matrix's last ROW adds on, zero for a rotation)
+    xform = torch.cat([rot[:, 0:3, 0:3].reshape(bs, 9), t, c], dim=1).contiguous()
+    return transform_point_clouds(pcd, xform)
+
+
 def apply_se3_augmentation(pcd, action_gripper_pose, action_trans, action_rot_grip, bounds, layer, trans_aug_range,
                            rot_aug_range, rot_aug_resolution, voxel_size, rot_resolution, device):
     """Reference signature and return values (perturbed action_trans, action_rot_grip, pcd).  Unlike the fused path of the
