@@ -154,4 +154,8 @@ def test_absmax_scale():
         assert float(torch.log2(sc[0])) == round(float(torch.log2(sc[0])))
     x = torch.ones(100, device=DEV)
     x[7] = float('nan')
-    assert ops.absmax_scale(x).cpu().tolist() == [1.0, 1.0]      # non-finite input: no scaling (the NaN then shows in the result)
+    # non-finite input: BOTH factors NaN -- every kernel that multiplies by them then hands on NaN instead of the saturated (finite)
+    # values its fp16 conversion would make of the tensor (round 5; tests/test_nan_backward_gpu.py)
+    for bad in (float('nan'), float('inf'), -float('inf')):
+        x[7] = bad
+        assert bool(torch.isnan(ops.absmax_scale(x)).all())
