@@ -178,10 +178,10 @@ def main():
     def measure(mode, steps, warmup, only=None, stream=False):
         """W untimed + exactly K timed steps in `mode`, bracketed by barrier + synchronize; max over ranks.  `only`: the timer
         labels whose launches are bracketed by HIP events (None = every launch).  stream: batches from the replay store."""
-        base_mode, _, attn = mode.partition('+')                         # 'bf16x3+attn_f16' = the pipelined single-fp16 attention forward
+        base_mode, _, attn = mode.partition('+')                         # 'bf16x3+attn_f16' = the pipelined single-fp16 attention forward (VOXACTB_ATTN_KERNEL=auto)
         for e_ in engines:
             e_.precision, _, e_.bwd_precision = base_mode.partition('/')  # 'bf16x3/bf16' = forward bf16x3, backward products bf16
-            e_.attn_kernel = 'f16' if attn == 'attn_f16' else headline_attn
+            e_.attn_kernel = 'auto' if attn == 'attn_f16' else headline_attn
         if stream:
             streams[0] = open_streams()
         for _ in range(warmup):
@@ -539,7 +539,7 @@ MODE_DTYPE = {         # (short: the driver's record truncates long strings; the
     'bf16x3': 'f32 storage/accumulate; fwd products bf16x3 (3 bf16 MFMA); bwd: weight grads + attention 1x fp16, data grads 2x fp16 (scaled)',
     'bf16': 'bf16 MFMA, f32 accumulate/storage',
     'bf16x3/bf16': 'fwd bf16x3, bwd products plain bf16',
-    'bf16x3+attn_f16': 'as bf16x3, attention fwd on 1x fp16 products (VOXACTB_ATTN_KERNEL=f16)',
+    'bf16x3+attn_f16': 'as bf16x3, attention fwd on 1x fp16 products (VOXACTB_ATTN_KERNEL=auto)',
 }
 MODE_NOTE = {
     'fp32': 'exact fp32 matrix cores: the reference-parity mode of the first measurements (tests/test_encoder_gpu.py, 1e-4)',
@@ -551,14 +551,13 @@ MODE_NOTE = {
     'bf16': 'throughput mode, NOT held to the 1e-4 Q-value bound (tests/test_bf16_mode_gpu.py: ~4e-3 on q_trans)',
     'bf16x3/bf16': 'mixed mode (VOXACTB_BWD_PRECISION=bf16): the forward keeps the 1e-4 Q-value bound, parameter gradients are '
                    'within 0.5 % of the reference (norms within 4e-3) instead of 0.2 % -- not the default',
-    'bf16x3+attn_f16': 'named mode, NOT the default: the default precision with the attention FORWARD (QK^T, PV) on the pipelined kernel with ONE '
-                       'fp16 product per term (csrc/flash2_fwd.hip) instead of round 3\'s bf16x3 triple.  Measured against the float64 reference on '
-                       'eight batches at configs[1] / [2] / released-recipe geometry (tools/experiments/f16_attention_forward_gate.py, '
-                       'profiles/r05_attn_f16_forward_gate.log): max |Q - Q64| 2.4e-5 .. 6.6e-5 (the default: 2.0e-5 .. 3.9e-5; bound 1e-4), every '
-                       'parameter gradient inside the 0.5 % gate once the backward is evaluated at the float64 run\'s LeakyReLU choices (worst tensor '
-                       '0.74 x gate, the default 0.78 x) -- its round-4 rejection was the kink effect of DESIGN.md 5r5, not attention arithmetic.  Not '
-                       'the default because on the SMALL fixtures (V = 8 .. 32, tens of tokens) it leaves the 1e-4 bound (act() fixture: 1.15e-4 on a '
-                       'collision softmax) and its margin at configs[1] is 1.5 x',
+    'bf16x3+attn_f16': 'named mode, NOT the default (VOXACTB_ATTN_KERNEL=auto): the default precision with the attention FORWARD (QK^T, PV) on the '
+                       'pipelined kernel with ONE fp16 product per term (csrc/flash2_fwd.hip) from 2^22 score elements on, instead of round 3\'s bf16x3 '
+                       'triple.  Measured (DESIGN.md 5r5; profiles/r05_attn_f16_forward_gate.log): Q-values within 1e-4 of the reference on every fixture '
+                       'at these sizes (max 8.1e-5, the default 7.0e-5), every parameter gradient inside the 0.5 % float64 gate on eight batches once the '
+                       'backward is evaluated at the reference run\'s LeakyReLU choices (worst tensor 0.74 x gate, the default 0.78 x: its round-4 '
+                       'rejection was the kink effect, not attention arithmetic) -- but the element gates of the F5c3 gradient digest (0.3 % of a small '
+                       'tensor\'s maximum) are missed by 2 x, so it is not the default',
 }
 # `peak` of every matrix-core roofline = the guide's dense MFMA peak of the operand type (MI355X_MICROARCH.md): 157.3 TF/s fp32,
 # 2500 TF/s bf16 / fp16.  The bf16x3 precision spends three MFMAs per product, so an ideal bf16x3 kernel tops out at 1/3 of that
@@ -615,7 +614,7 @@ def attention_kernel_probe(dev):
         pl = flash.kv_planes(kv, mode)
         for p in (0.0, 0.1):
             ms = t(lambda: flash.flash2_attn_fwd(q, kv, B, H, N, N, 0.125, p, 3, mode=mode, planes=pl))
-            out['fwd_%s_p%.1f' % (mode, p)] = {'ms': ms, 'achieved': ffl / ms * 1e-9, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            out['fwd_%s_p%.1f%s' % (mode, p, ' (the forward of the named mode bf16x3+attn_f16)' if (mode, p) == ('f16', 0.1) else '')] = {'ms': ms, 'achieved': ffl / ms * 1e-9, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                                'frac': ffl / ms * 1e-9 / PEAK_BF16_MFMA_TFLOPS}
     pl3 = flash._planes(kv, 2)
     o, lse = flash.flash_attn_fwd_dl(q, kv, B, H, N, N, 0.125, 0.1, 3, x3=True)

@@ -120,12 +120,16 @@ def _available():
 
 
 @pytest.mark.parametrize('fixture', FIXTURES)
-@pytest.mark.parametrize('mode,wide_dispatch', [('fp32', False), ('bf16x3+r3/f16', False), ('bf16x3+r3/f16-gx0', False), ('bf16x3+r3/f16', True)],
-                         indirect=['wide_dispatch'], ids=['fp32', 'bf16x3+r3/f16', 'bf16x3+r3/f16-gx0', 'bf16x3+r3/f16-wide'])
+@pytest.mark.parametrize('mode,wide_dispatch', [('fp32', False), ('bf16x3+r3/f16', False), ('bf16x3+r3/f16-gx0', False), ('bf16x3+r3/f16', True),
+                                                ('bf16x3+auto/f16', False)],
+                         indirect=['wide_dispatch'], ids=['fp32', 'bf16x3+r3/f16', 'bf16x3+r3/f16-gx0', 'bf16x3+r3/f16-wide', 'bf16x3+auto/f16'])
 def test_gradients_against_the_float64_reference(golden, fixture, mode, wide_dispatch):
     """'fp32': the exact-fp32 kernels; 'bf16x3+r3/f16': the shipped default (bf16x3 forward incl. round 3's attention forward, fp16 single /
     double products in the backward, pipelined fp16 attention backward with hi + lo gradient operands); '-wide': through the kernels the
-    B = 16 headline dispatches.  Backward evaluated at the float64 run's max-pool and LeakyReLU choices (module docstring)."""
+    B = 16 headline dispatches; 'bf16x3+auto/f16': the named mode VOXACTB_ATTN_KERNEL=auto (the attention FORWARD on single fp16 products at
+    these sizes; bench.py's `bf16x3+attn_f16`) -- it holds this gate too since the kink effect is separated out (round 4 had rejected it on
+    this very test), and stays a named mode for the F5c3 element gates it misses (perceiver_lang_io.py: attn_kernel).  Backward evaluated at
+    the float64 run's max-pool and LeakyReLU choices (module docstring)."""
     if fixture not in _available():
         pytest.skip('fixture not generated')
     g = golden(fixture)
@@ -187,14 +191,3 @@ def test_pipelined_attention_backward_equals_the_bf16x3_backward_on_the_same_for
             worst, wn = e, n
     print('%s %s: worst relative L2 difference %.2e (%s)' % (fixture[10:], variant, worst, wn))
     assert worst < (1e-3 if variant.endswith('gx1') else 3e-3), (wn, worst)
-
-
-@pytest.mark.parametrize('fixture', ['f5n_noise_c2_s1', 'f5n_noise_v50a_s1'])
-def test_single_fp16_attention_forward_is_recorded_not_shipped(golden, fixture):
-    """VOXACTB_ATTN_KERNEL=f16 (one fp16 product in the attention FORWARD): Q-values stay inside 1e-4, but the median gradient error
-    against float64 rises from 8e-4 to 5e-3 at configs[1] (above the 3e-3 gate); the measurement that keeps the forward on bf16x3."""
-    if fixture not in _available():
-        pytest.skip('fixture not generated')
-    g = golden(fixture)
-    eq, rows, loss = _measure(g, 'bf16x3', 'f16', True, '%s/bf16x3+f16' % fixture[10:])
-    assert eq < 1e-4
