@@ -430,11 +430,15 @@ int vxb_ss3d_max_bwd_f32(const float* x, int64_t bs, int B, int S, int C, const 
  *   dW[c][j] += lrelu'(d0[v][c]) * (sum_kout dpatch[p][kout] * Wp[kout][c][t]) * vox[v][j],   db[c] += the same without vox,
  * i.e. the padding adjoint and the data gradient tensor (4.7 GB at configs[1]) never exist.  Single fp16 products (a leaf): dpatch is
  * multiplied by scale[0] (device, power of two: vxb_absmax_scale_f32), the sums by scale[1].  wt_f16: fp16 [k^3][64][64] =
- * Wp[kout][c][t] transposed per tap (t = (kd k + kh) k + kw).  dW [64][10], db [64] ACCUMULATED; ws: ..._ws_floats(k, nsplit) floats. */
+ * Wp[kout][c][t] transposed per tap (t = (kd k + kh) k + kw).  dW [64][10], db [64] ACCUMULATED; ws: ..._ws_floats(k, nsplit) floats.
+ * dWp (optional; with ws_wp of vxb_patch_wgrad_weight_ws_floats(k, nsplit) floats, both or neither): the patchify conv's own WEIGHT
+ * gradient (network_utils.py:128-170 backward), dWp[kout][c][t] += sum_p d0[v(p, t)][c] * dpatch[p][kout] in the parameter's layout --
+ * from the d0 values the same launch fetches for lrelu', instead of a second pass over d0. */
 size_t vxb_patch_dgrad_input_wgrad_ws_floats(int k, int nsplit);
+size_t vxb_patch_wgrad_weight_ws_floats(int k, int nsplit);
 int vxb_patch_dgrad_input_wgrad_f32(const float* dpatch, const void* wt_f16, const float* d0, const float* vox, int B, int V, int G,
                                     int k, int pad, float slope, const float* scale, float* ws, int nsplit, float* dW, float* db,
-                                    vxb_stream_t stream);
+                                    float* dWp, float* ws_wp, vxb_stream_t stream);
 
 /* PreNorm LayerNorm (perceiver_lang_io.py:56-71), eps 1e-5.  bwd: dgamma/dbeta ACCUMULATED; part_ws: ceil(rows / 32) * 2 * D floats. */
 int vxb_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,

@@ -99,6 +99,9 @@ def test_patchify_data_gradient_folded_into_the_input_weight_gradient(B, V, gain
     x = d0.double().requires_grad_(True)
     out = F.conv3d(F.pad(x, (pad,) * 6, mode='replicate'), Wp.double(), stride=k)
     assert out.shape[-1] == G
+    wp64 = Wp.double().requires_grad_(True)
+    out_w = F.conv3d(F.pad(d0.double(), (pad,) * 6, mode='replicate'), wp64, stride=k)
+    dWp_ref, = torch.autograd.grad(out_w, wp64, dpatch.double())            # the patchify conv's own weight gradient (round 5: same launch)
     dd0, = torch.autograd.grad(out, x, dpatch.double())
     m = torch.where(d0 > 0, 1.0, ops.LRELU_SLOPE).double()
     g = (dd0 * m).permute(0, 2, 3, 4, 1).reshape(-1, C)                       # [voxels][64]
@@ -111,9 +114,15 @@ def test_patchify_data_gradient_folded_into_the_input_weight_gradient(B, V, gain
     ops.PRECISION, ops.WGRAD_PRECISION = 'bf16x3', 'fp16'
     try:
         assert ops.patch_dgrad_input_wgrad_ok(k, k, C, Cin)
-        ops.patch_dgrad_input_wgrad(cl(dpatch), Wp.to(DEV), cl(d0), cl(vox), dW, db, B, V, G, k, pad)
+        dWp = torch.full((C, C, k, k, k), 0.125 * gain, device=DEV)
+        ops.patch_dgrad_input_wgrad(cl(dpatch), Wp.to(DEV), cl(d0), cl(vox), dW, db, B, V, G, k, pad, dWp=dWp)
+        dW2, db2 = torch.zeros_like(dW), torch.zeros_like(db)
+        ops.patch_dgrad_input_wgrad(cl(dpatch), Wp.to(DEV), cl(d0), cl(vox), dW2, db2, B, V, G, k, pad)      # (without it: the same dW / db bits)
     finally:
         ops.PRECISION, ops.WGRAD_PRECISION = keep
     eW = float((dW.double().cpu() - 0.25 * gain - dW_ref).abs().max() / dW_ref.abs().max())
     eb = float((db.double().cpu() + 0.5 * gain - db_ref).abs().max() / db_ref.abs().max())
     assert eW < 2e-3 and eb < 2e-3, (eW, eb)
+    assert float((dW2 - (dW - 0.25 * gain)).abs().max()) <= 2e-6 * float(dW2.abs().max())
+    ep = float((dWp.double().cpu() - 0.125 * gain - dWp_ref).abs().max() / dWp_ref.abs().max())
+    assert ep < 2e-3, ep

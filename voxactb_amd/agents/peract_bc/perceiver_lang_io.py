@@ -975,15 +975,20 @@ class PerceiverEngine:
                        self.g('proprio_preprocess.linear.bias'))
         # ---- patchify
         ops.lrelu_bwd_(dpatch, c['patch'])
-        dWt = ops.conv3d_wgrad(d0, dpatch, C, B, V, G, k, -pk, stride=s, grad_key=('conv', Wp.data_ptr()))
-        self.g('patchify.conv3d.weight').add_(dWt.view(k ** 3, C, C).permute(2, 1, 0).reshape(Wp.shape))
+        fuse_patch = fuse_ss0 and ops.patch_dgrad_input_wgrad_ok(k, s, C, c['vox'].shape[-1]) and (dpatch.is_contiguous() or no_dd0)
+        # (fused path: the patchify weight gradient comes out of the launch that already reads d0 for the input conv's gradient)
+        wp_in_fused = fuse_patch and ops.PATCH_WGRAD_WEIGHT and self.g('patchify.conv3d.weight').is_contiguous()
+        if not wp_in_fused:
+            dWt = ops.conv3d_wgrad(d0, dpatch, C, B, V, G, k, -pk, stride=s, grad_key=('conv', Wp.data_ptr()))
+            self.g('patchify.conv3d.weight').add_(dWt.view(k ** 3, C, C).permute(2, 1, 0).reshape(Wp.shape))
         ops.colsum(dpatch, self.g('patchify.conv3d.bias'), accumulate=True)
         dxp, Sp = None, 0
-        if fuse_ss0 and ops.patch_dgrad_input_wgrad_ok(k, s, C, c['vox'].shape[-1]) and (dpatch.is_contiguous() or no_dd0):
+        if fuse_patch:
             dpatch = dpatch.contiguous()
             # the patchify data gradient only feeds the input conv's weight gradient (the voxel grid is a detached input): its share
             # of dW_in / db_in straight from dpatch, no 105^3 x 64 gradient tensor (patch_wgrad.hip)
-            ops.patch_dgrad_input_wgrad(dpatch, Wp, d0, c['vox'], gW_in, gb_in, B, V, G, k, pk)
+            ops.patch_dgrad_input_wgrad(dpatch, Wp, d0, c['vox'], gW_in, gb_in, B, V, G, k, pk,
+                                        dWp=self.g('patchify.conv3d.weight') if wp_in_fused else None)
         elif s > 1:
             wtp, U = ops.strided_dgrad_weights(Wp, s)
             Gp = (V + 2 * pk + s - 1) // s

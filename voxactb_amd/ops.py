@@ -1114,17 +1114,25 @@ def patch_dgrad_input_wgrad_ok(k, s, C, Cin):
     return PATCH_WGRAD_FUSE and WGRAD_PRECISION == 'fp16' and PRECISION == 'bf16x3' and k == s and C == 64 and Cin == 10
 
 
-def patch_dgrad_input_wgrad(dpatch, Wp, d0, vox, dW, db, B, V, G, k, pad):
+PATCH_WGRAD_WEIGHT = os.environ.get('VOXACTB_PATCH_WGRAD_WEIGHT', '1') != '0'      # '0': the patchify weight gradient as its own launch (A/B)
+
+
+def patch_dgrad_input_wgrad(dpatch, Wp, d0, vox, dW, db, B, V, G, k, pad, dWp=None):
     """dW [64][10] += / db [64] += the patchify data gradient's share of the input conv's weight / bias gradient, straight from
     dpatch [B, G^3, 64] (patch_wgrad.hip: vxb_patch_dgrad_input_wgrad_f32) -- the 4.7 GB data gradient tensor and its padding
-    adjoint are never formed."""
+    adjoint are never formed.  dWp (the patchify weight's gradient tensor [64][64][k][k][k], contiguous): += the patchify conv's own
+    weight gradient from the same pass over d0."""
     wt = Wp.reshape(Wp.shape[0], Wp.shape[1], k ** 3).permute(2, 1, 0).contiguous().to(torch.float16)      # [tap][c][kout]
     ns = max(1, min(64, 1024 // (k ** 3)))
     ws = torch.empty(int(_lib.lib().vxb_patch_dgrad_input_wgrad_ws_floats(k, ns)), dtype=torch.float32, device=dpatch.device)
+    ws_wp = None
+    if dWp is not None:
+        assert dWp.is_contiguous() and tuple(dWp.shape) == (64, 64, k, k, k)
+        ws_wp = torch.empty(int(_lib.lib().vxb_patch_wgrad_weight_ws_floats(k, ns)), dtype=torch.float32, device=dpatch.device)
     _lib.set_meta('patch_dgrad_input_wgrad[k%d V%d]' % (k, V), 0.0)
     sc = absmax_scale(dpatch)
-    _lib.set_meta('patch_dgrad_input_wgrad[k%d V%d]' % (k, V), 2.0 * B * G ** 3 * k ** 3 * 64 * 64)
-    call('vxb_patch_dgrad_input_wgrad_f32', dpatch, wt, d0, vox, B, V, G, k, pad, LRELU_SLOPE, sc, ws, ns, dW, db)
+    _lib.set_meta('patch_dgrad_input_wgrad[k%d V%d]' % (k, V), 2.0 * B * G ** 3 * k ** 3 * 64 * 64 * (2 if dWp is not None else 1))
+    call('vxb_patch_dgrad_input_wgrad_f32', dpatch, wt, d0, vox, B, V, G, k, pad, LRELU_SLOPE, sc, ws, ns, dW, db, dWp, ws_wp)
 
 
 # --------------------------------------------------------------------------------------------- voxel-sized ops
