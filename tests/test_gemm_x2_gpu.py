@@ -44,6 +44,7 @@ def test_linear_dgrad_on_two_fp16_products(N, K, gain):
                 dxs = []
                 for it in range(2):                      # second call: the delayed scale reported by the first weight-gradient launch
                     dW, db, dx = torch.zeros_like(W), torch.zeros(N, device=DEV), torch.full((M, K), float('nan'), device=DEV)
+                    ops.begin_backward()
                     ops.linear_bwd(x, W, dy, dW, db, dx)
                     dxs.append(dx)
                 assert torch.isfinite(dxs[0]).all() and torch.isfinite(dxs[1]).all()
@@ -71,8 +72,10 @@ def test_linear_dgrad_accumulates_into_dx():
         ops._GRAD_SCALE.clear()
         ops.prepare_linear_weights([W], f16_dgrad=True)
         dx0 = torch.empty(M, K, device=DEV)
+        ops.begin_backward()
         ops.linear_bwd(x, W, dy, torch.zeros_like(W), None, dx0)
         dx1 = base.clone()
+        ops.begin_backward()
         ops.linear_bwd(x, W, dy, torch.zeros_like(W), None, dx1, dx_accumulate=True)
     finally:
         ops.PRECISION, ops.WGRAD_PRECISION, ops.GENERIC_WGRAD_F16, ops.DGRAD_PRECISION = state

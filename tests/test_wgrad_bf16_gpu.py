@@ -73,12 +73,22 @@ def test_generic_weight_gradients_on_single_fp16_products_with_delayed_scaling()
         for gain in (1e-5, 3e-4, 1e-5, 3e-2, 3e-2):
             dy = rnd(M, N, seed=2).to(DEV) * gain
             dW, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+            ops.begin_backward()                  # (every call of this loop stands for one training step)
             ops.linear_bwd(x, W, dy, dW, db, None)
             ref = (dy.double().t() @ x.double())
             errs.append(float((dW.double() - ref).abs().max() / ref.abs().max()))
             assert float((db.double() - dy.double().sum(0)).abs().max()) < 1e-4 * float(dy.double().sum(0).abs().max())     # bias: exact fp32 sums
         assert max(errs[:3]) < 1e-3 and errs[4] < 1e-3 and errs[3] > 0.1, errs        # (errs[3]: the 3000x jump meets a stale scale)
-        assert ('lin', W.data_ptr()) in ops._GRAD_SCALE
+        assert (('lin', W.data_ptr()), 0) in ops._GRAD_SCALE
+        # a second use of the same weight INSIDE one backward pass (transformer_iterations > 1, tied layers) keeps its own delayed scale
+        ops.begin_backward()
+        for use, gain in enumerate((3e-2, 1e-6)):
+            dy = rnd(M, N, seed=2).to(DEV) * gain
+            dW = torch.zeros(N, K, device=DEV)
+            ops.linear_bwd(x, W, dy, dW, None, None)
+            ref = (dy.double().t() @ x.double())
+            assert float((dW.double() - ref).abs().max() / ref.abs().max()) < 1e-3, (use, gain)
+        assert (('lin', W.data_ptr()), 1) in ops._GRAD_SCALE
         # 5^3 conv (the decoder's first up-conv): gradient operand = dy
         B, S, Ci, Co = 2, 12, 128, 64
         a = cl(rnd(B, Ci, S, S, S)).to(DEV)
@@ -86,7 +96,9 @@ def test_generic_weight_gradients_on_single_fp16_products_with_delayed_scaling()
         ops.GENERIC_WGRAD_F16 = False
         want = ops.conv3d_wgrad(a, g, Co, B, S, S, 5, -2, grad_key=('conv', 7))
         ops.GENERIC_WGRAD_F16 = True
+        ops.begin_backward()
         got = ops.conv3d_wgrad(a, g, Co, B, S, S, 5, -2, grad_key=('conv', 7))
+        ops.begin_backward()
         got2 = ops.conv3d_wgrad(a, g, Co, B, S, S, 5, -2, grad_key=('conv', 7))       # second call: delayed scale == the exact one
         assert float((got - want).abs().max()) < 1e-3 * float(want.abs().max()) and torch.equal(got, got2)
     finally:
@@ -117,6 +129,7 @@ def test_linear_weight_gradient_fp16_wide_and_pipelined_kernels(_wide_at_test_si
         for mode in (2, 2, 0):                  # first call: explicit scale; second: the scale the first launch reported; then the generic kernel
             _lib.lib().vxb_debug_set_wgrad_lin(mode)
             dW, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+            ops.begin_backward()
             ops.linear_bwd(x, W, dy, dW, db, None)
             assert float((dW.double() - ref).abs().max() / ref.abs().max()) < 1e-3
             assert float((db.double() - dy.double().sum(0)).abs().max()) < 1e-4 * float(dy.double().sum(0).abs().max())

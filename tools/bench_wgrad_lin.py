@@ -40,9 +40,10 @@ def main():
         dW = torch.zeros(N, K, device=dev)
         db = torch.zeros(N, device=dev)
         ops._GRAD_SCALE = {}
-        t = timeit(lambda: ops.linear_bwd(x, W, dy, dW, db))
+        t = timeit(lambda: (ops.begin_backward(), ops.linear_bwd(x, W, dy, dW, db)))
         # reference on the first call's operands
         dW.zero_(); db.zero_()
+        ops.begin_backward()
         ops.linear_bwd(x, W, dy, dW, db)
         ref = dy.double().t() @ x.double()
         err = float((dW.double() - ref).abs().max() / ref.abs().max())
@@ -55,7 +56,7 @@ def main():
         x = torch.randn(B, S_in, S_in, S_in, Cin, device=dev)
         dy = torch.randn(B, S_out, S_out, S_out, Cout, device=dev) * 1e-3
         ops._GRAD_SCALE = {}
-        t = timeit(lambda: ops.conv3d_wgrad(x, dy, Cout, B, S_in, S_out, k, off, stride=stride, grad_key=('conv', k * 1000 + stride)), n=5)
+        t = timeit(lambda: (ops.begin_backward(), ops.conv3d_wgrad(x, dy, Cout, B, S_in, S_out, k, off, stride=stride, grad_key=('conv', k * 1000 + stride))), n=5)
         print('conv3d_wgrad k%d s%d %d->%d S%d  %.3f ms  %.1f TF/s' % (k, stride, Cin, Cout, S_out, t,
                                                                       2.0 * B * S_out ** 3 * Cout * k ** 3 * Cin / t * 1e-9))
 

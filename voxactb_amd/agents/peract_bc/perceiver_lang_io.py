@@ -739,6 +739,7 @@ class PerceiverEngine:
         ops.WGRAD_PRECISION = 'fp16' if (ops.PRECISION == 'bf16x3' and self.wgrad_precision == 'fp16') else ''
         ops.GENERIC_WGRAD_F16 = bool(ops.WGRAD_PRECISION) and self.generic_wgrad_f16
         ops._GRAD_SCALE = self._grad_scales
+        ops.begin_backward()
         self._on_bucket = on_bucket_ready
         try:
             return self._backward(c, dq_trans, d_o, d_arm, dq_trans_left, d_o_left)

@@ -30,7 +30,10 @@ WGRAD_PRECISION = ''
 # (delayed scaling: the kernel reports the maximum it saw, for free; the first call takes an explicit absmax pass), with 5 bits
 # of headroom (a 32-fold jump from one step to the next still fits) and saturation on top -- see DESIGN.md 4a.
 GENERIC_WGRAD_F16 = False
-_GRAD_SCALE = {}          # call site (weight address / name) -> [current scale, next scale] device tensors, used in turn
+_GRAD_SCALE = {}          # call site (weight address / name, use within the step) -> [current scale, next scale] device tensors, used in turn
+_GRAD_USE = {}            # call site -> how often this backward pass has used it so far (PerceiverEngine.backward resets it): with
+                          # transformer_iterations > 1 or weight_tie_layers one weight is hit several times per step, by gradients of
+                          # different magnitude -- every use keeps its own delayed scale (round-4 advisor)
 _WCACHE = {}
 
 
@@ -41,6 +44,11 @@ _LAST_GRAD_SCALE = [None]     # operand scale (device {2^k, 2^-k}) the last dela
 # Below it -- the released VoxAct-B recipe trains with replay.batch_size = 1, M = 2048 -- the 128 x 64 / 128 x 128 tile kernels run
 # (16 workgroups of 92 us each per linear layer otherwise: profiles/r04_v50_*).
 WIDE_MIN_M = int(os.environ.get('VOXACTB_WIDE_MIN_M', 16384))
+
+
+def begin_backward():
+    """a new backward pass starts: every delayed-scaling call site counts its uses from zero again (_GRAD_USE)"""
+    _GRAD_USE.clear()
 
 
 def set_wide_min_rows(n):
@@ -596,9 +604,12 @@ def conv3d_wgrad(src0, dy, N, B, S_in, S_out, kext, off, stride=1, replicate=Tru
     if (entry == 'vxb_conv3d_wgrad_bf16x3_f32' and WGRAD_PRECISION == 'fp16' and GENERIC_WGRAD_F16 and grad_key is not None
             and (dy if not grad_is_src0 else src0).is_contiguous()):
         grad = src0 if grad_is_src0 else dy
-        st = _GRAD_SCALE.get(grad_key)
+        use = _GRAD_USE.get(grad_key, 0)
+        _GRAD_USE[grad_key] = use + 1
+        skey = (grad_key, use)
+        st = _GRAD_SCALE.get(skey)
         if st is None or st[0].device != grad.device:
-            st = _GRAD_SCALE[grad_key] = [absmax_scale(grad), torch.empty(2, dtype=torch.float32, device=grad.device)]
+            st = _GRAD_SCALE[skey] = [absmax_scale(grad), torch.empty(2, dtype=torch.float32, device=grad.device)]
         cur, nxt = st
         aws = torch.empty(int(_lib.lib().vxb_conv3d_wgrad_f16_amax_words(C0, C1, kext, N, nsplit, int(grad_is_src0))),
                           dtype=torch.float32, device=grad.device)
