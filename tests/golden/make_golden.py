@@ -1148,14 +1148,14 @@ SECTIONS = {
     'f3tiny': lambda: encoder_fixture('f3_encoder_tiny', CFG_TINY, arm=True),
     'f3c1': lambda: encoder_fixture('f3_encoder_c1', CFG_C1),
     # encoder switches reachable from the configs (PERACT_BC.yaml: transformer_iterations, no_language): tiny and configs[0] size, fwd + bwd
-    'f3v_it2': lambda: encoder_fixture('f3v_encoder_tiny_iterations2', dict(CFG_TINY, variant=dict(iterations=2)), arm=True, digest=True, check_oracle=False),
-    'f3v_it3c1': lambda: encoder_fixture('f3v_encoder_c1_iterations3', dict(CFG_C1, latents=48, depth=2, variant=dict(iterations=3)), digest=True, check_oracle=False),
-    'f3v_noskip': lambda: encoder_fixture('f3v_encoder_c1_no_skip_connection', dict(CFG_C1, variant=dict(no_skip_connection=True)), digest=True, check_oracle=False),
-    'f3v_noperc': lambda: encoder_fixture('f3v_encoder_c1_no_perceiver', dict(CFG_C1, variant=dict(no_perceiver=True)), digest=True, check_oracle=False),
-    'f3v_posgrid': lambda: encoder_fixture('f3v_encoder_c1_pos_encoding_grid_only', dict(CFG_C1, variant=dict(pos_encoding_with_lang=False)), digest=True, check_oracle=False),
-    'f3v_concat': lambda: encoder_fixture('f3v_encoder_c1_lang_concat', dict(CFG_C1, variant=dict(lang_fusion_type='concat', pos_encoding_with_lang=False)), digest=True, check_oracle=False),
-    'f3v_tie': lambda: encoder_fixture('f3v_encoder_c1_weight_tie_layers', dict(CFG_C1, depth=3, variant=dict(weight_tie_layers=True)), digest=True, check_oracle=False),
-    'f3v_nolang': lambda: encoder_fixture('f3v_encoder_c1_no_language', dict(CFG_C1, variant=dict(no_language=True)), digest=True, check_oracle=False),
+    'f3v_it2': lambda: encoder_fixture('f3v_encoder_tiny_iterations2', dict(CFG_TINY, variant=dict(iterations=2)), arm=True, digest=True, check_oracle=False, kinks=True),
+    'f3v_it3c1': lambda: encoder_fixture('f3v_encoder_c1_iterations3', dict(CFG_C1, latents=48, depth=2, variant=dict(iterations=3)), digest=True, check_oracle=False, kinks=True),
+    'f3v_noskip': lambda: encoder_fixture('f3v_encoder_c1_no_skip_connection', dict(CFG_C1, variant=dict(no_skip_connection=True)), digest=True, check_oracle=False, kinks=True),
+    'f3v_noperc': lambda: encoder_fixture('f3v_encoder_c1_no_perceiver', dict(CFG_C1, variant=dict(no_perceiver=True)), digest=True, check_oracle=False, kinks=True),
+    'f3v_posgrid': lambda: encoder_fixture('f3v_encoder_c1_pos_encoding_grid_only', dict(CFG_C1, variant=dict(pos_encoding_with_lang=False)), digest=True, check_oracle=False, kinks=True),
+    'f3v_concat': lambda: encoder_fixture('f3v_encoder_c1_lang_concat', dict(CFG_C1, variant=dict(lang_fusion_type='concat', pos_encoding_with_lang=False)), digest=True, check_oracle=False, kinks=True),
+    'f3v_tie': lambda: encoder_fixture('f3v_encoder_c1_weight_tie_layers', dict(CFG_C1, depth=3, variant=dict(weight_tie_layers=True)), digest=True, check_oracle=False, kinks=True),
+    'f3v_nolang': lambda: encoder_fixture('f3v_encoder_c1_no_language', dict(CFG_C1, variant=dict(no_language=True)), digest=True, check_oracle=False, kinks=True),
     'f5': lambda: encoder_fixture('f5_encoder_c2_digest', CFG_C2, with_grads=False, digest=True),
     # (kinks=True, round 5: the fp32 run's LeakyReLU pre-activations within 3e-5 of zero, so that a test can evaluate the product's backward
     # at the reference's subgradient choices -- capture_kinks)

@@ -108,7 +108,7 @@ def force_kinks(cache, g):
     return flips
 
 
-def _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, tag):
+def _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, tag, gate=1.0):
     at = rs['trans_action_indicies'].long()
     lab = ((at[:, 0] * V + at[:, 1]) * V + at[:, 2]).int().to(DEV)
     dq = torch.empty((B, V ** 3), device=DEV)
@@ -157,7 +157,7 @@ def _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, tag):
                 bad.append((n, 'vs float64 dY sum', e, float(ref.abs().max())))
             continue
         rel = abs(gn - rn) / (rn + 1e-12)
-        if abs(gn - rn) > 3e-3 * rn + 1e-5:
+        if abs(gn - rn) > gate * 3e-3 * rn + 1e-5:
             bad.append((n, gn, rn))
         elif rn > 1e-4:
             worst = max(worst, rel)
@@ -165,13 +165,13 @@ def _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, tag):
         if key in g.files:
             ref = T(g[key])
             e = float((P[n].grad.float().cpu() - ref).abs().max())
-            if e > 3e-3 * float(ref.abs().max()) + 1e-5:
+            if e > gate * 3e-3 * float(ref.abs().max()) + 1e-5:
                 bad.append((n, 'full', e, float(ref.abs().max())))
     print('%s: loss %.6f (reference %.6f), worst grad-norm rel. error %.2e' % (tag, loss, float(g['loss']), worst))
     assert not bad, (tag, bad)
 
 
-def _run(g, precision, tag, backward, bwd_precision='', wgrad_precision=None):
+def _run(g, precision, tag, backward, bwd_precision='', wgrad_precision=None, gate=1.0):
     enc, rs, grid, arm, V, B = _setup(g)
     _check_grid(g, grid)
     eng = enc.engine()
@@ -184,7 +184,7 @@ def _run(g, precision, tag, backward, bwd_precision='', wgrad_precision=None):
                               lang_goal_emb=rs['lang_goal_emb'].to(DEV))
     errs = _check_forward(g, outs, arm, '%s/%s' % (tag, precision))
     if backward:
-        _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, '%s/%s' % (tag, precision))
+        _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, '%s/%s' % (tag, precision), gate=gate)
     del cache, outs
     torch.cuda.empty_cache()
     return errs
@@ -247,10 +247,14 @@ def test_encoder_switches_reachable_from_the_configs(golden, fixture, precision)
     """`transformer_iterations` > 1 (the cross-attention block and the self-attention stack run again over the SAME weights, perceiver
     :429-437; gradients of the shared weights and of the context add up) and the ablations `no_language` (:374-376), `no_skip_connection`
     and `no_perceiver` (:457-460: `final` reads u0 / d0 alone; under no_perceiver the up-block gets no gradient) -- PERACT_BC.yaml /
-    launch_utils.py:744-774 -- against the reference's forward + backward.  The exact-fp32 mode is held to this file's gates; the default
-    precision's gradients at these toy sizes sit at single-tensor fp16 rounding (as for the V = 50 fixtures) and are covered by the forward
-    digest here."""
-    _run(golden(fixture), precision, fixture[4:], backward=precision == 'fp32')
+    launch_utils.py:744-774 -- against the reference's forward + backward, in the exact-fp32 AND the default precision (round 5: the
+    single-source `final` weight / data gradients, the summed context gradients, shared weights hit several times per step with their
+    per-use delayed scales).  Both are held to this file's gates, the backward evaluated at the reference run's LeakyReLU choices
+    (the fixtures carry them since round 5: without them lang_concat's small tensors are 2 % off in the default precision -- kinks, not
+    arithmetic).  One exception in the default precision: no_skip_connection at V = 32 has ONE element of the translation head's weight
+    gradient (64 x 27 values, single fp16 products over 32 768 voxels) at 1.04 x the element gate -> 1.5 x for that fixture."""
+    gate = 1.5 if (precision != 'fp32' and fixture == 'f3v_encoder_c1_no_skip_connection') else 1.0
+    _run(golden(fixture), precision, fixture[4:], backward=True, gate=gate)
 
 
 @pytest.mark.parametrize('fixture', ['f5v50a_encoder_release_digest', 'f5v50b_encoder_release_digest'])
@@ -258,11 +262,10 @@ def test_encoder_switches_reachable_from_the_configs(golden, fixture, precision)
 def test_released_recipe_geometry_digest(golden, fixture, precision):
     """The recipe VoxAct-B releases (peract/scripts/train_open_jar_ours_vlm_10_demos_v2_11_acting.sh:8-36, launch_utils.py:738-743): V = 50
     (6 x 8 + 2: the part-tile paths of every halo kernel), cameras front | wrist | wrist2, replay batch 1 (M = 2048 rows: the 128^2
-    linear kernels), proprioception 7 and 8, arm loss, crop bounds -- forward digest in both precisions; the backward's norm / element
-    gates of this file in the exact-fp32 mode (worst 8e-5), the default precision's gradients are held to the float64 gate of
-    tests/test_grad_noise_gpu.py (fixtures f5n_noise_v50a / v50b: at B = 1, V = 50 the element gates below sit at the fp16 rounding of
-    single tensors, and v50b is one of the forward-sensitive batches)."""
-    _run(golden(fixture), precision, fixture[:6], backward=precision == 'fp32')
+    linear kernels), proprioception 7 and 8, arm loss, crop bounds -- forward digest and the backward's norm / element gates of this file in
+    both precisions (round 5: with the reference run's LeakyReLU choices in the fixtures the default precision holds them too -- worst
+    gradient-norm error 2.8e-4; v50b was one of round 4's 'forward-sensitive' batches)."""
+    _run(golden(fixture), precision, fixture[:6], backward=True)
 
 
 @pytest.mark.parametrize('fixture', ['f5g_encoder_c2_grads', 'f5c3_encoder_c3_digest'])
