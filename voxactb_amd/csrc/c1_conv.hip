@@ -112,6 +112,10 @@ __global__ void __launch_bounds__(256, 2) c1_dgrad4_ss_kernel(const float* __res
                                                            unsigned* __restrict__ part_amax) {
     __shared__ float sw[27 * 64];          // [t][c]
     __shared__ float red[16][64];
+    // the 3 x 3 x 6 dq window of each of the 16 voxel groups in flight, through LDS: read straight from global memory its 54 loads sit
+    // BEHIND the group's u loads on the in-order vector-memory counter, so the tap loop waited for the HBM round trip it was meant to
+    // hide (round 5).  The 16 lanes of a group are in one wave: wave-level ordering is enough.
+    __shared__ float sdq[16][56];
     __shared__ unsigned ramx[4];
     float amxf = 0.f;                       // largest |du| this thread wrote (one v_max_f32 with an |x| modifier per element)
     for (int i = threadIdx.x; i < 27 * 64; i += 256) sw[(i % 27) * 64 + i / 27] = w[i];
@@ -142,6 +146,17 @@ __global__ void __launch_bounds__(256, 2) c1_dgrad4_ss_kernel(const float* __res
         const int h = row % S;
         const int d = row / S;
         const int x0 = xg * 4;
+        const bool interior = d >= 1 && d <= S - 2 && h >= 1 && h <= S - 2 && x0 >= 1 && x0 + 4 <= S - 1;
+        float wv4[4];
+        if (interior) {
+            const int l16 = threadIdx.x & 15;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = l16 + 16 * q;                   // (a, bb, j) = (idx / 18, (idx / 6) % 3, idx % 6)
+                wv4[q] = idx < 54 ? dqb[((long long)(d + 1 - idx / 18) * S + (h + 1 - (idx / 6) % 3)) * S + x0 - 1 + idx % 6] : 0.f;
+            }
+        }
+        asm volatile("" ::: "memory");                      // the window loads are issued BEFORE the u loads (in-order return)
         float4 uu[4], old[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                       // (issued before the tap loop: in flight under its 432 FMAs)
@@ -152,15 +167,25 @@ __global__ void __launch_bounds__(256, 2) c1_dgrad4_ss_kernel(const float* __res
         float4 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (d >= 1 && d <= S - 2 && h >= 1 && h <= S - 2 && x0 >= 1 && x0 + 4 <= S - 1) {
+        if (interior) {
+            {
+                const int l16 = threadIdx.x & 15;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (l16 + 16 * q < 54) sdq[gl][l16 + 16 * q] = wv4[q];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
                 for (int bb = 0; bb < 3; ++bb) {
-                    const float* rp = dqb + ((long long)(d + 1 - a) * S + (h + 1 - bb)) * S + x0 - 1;
                     float g[6];
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) g[j] = rp[j];
+                    for (int j = 0; j < 6; ++j) g[j] = sdq[gl][(a * 3 + bb) * 6 + j];
 #pragma unroll
                     for (int cc = 0; cc < 3; ++cc) {
                         const float4 wv = *reinterpret_cast<const float4*>(&sw[((a * 3 + bb) * 3 + cc) * 64 + c4]);

@@ -528,7 +528,10 @@ __global__ void __launch_bounds__(256) ss_bwd_kernel(const float* __restrict__ x
 // that reaches y is dy (conv paths) + the pooled-feature term of ss_bwd4_kernel (same formula per element), so that term
 // never makes its own read-y / write-dy pass over the grid.  One workgroup per 4096 voxels of ONE sample (grid.y = b); x is
 // staged through LDS in tiles of 256 voxels (the 16 threads of a voxel share its CIN inputs).
-template <int CIN>
+// LEAN (dy == nullptr and fold_src == nullptr: every conv path into y adds its share of dW / db itself, the shape the training step
+// takes): only y is streamed, EIGHT voxels ahead instead of two -- the kernel moved 4.3 GB in 2.18 ms (2 TB/s) with 32 KB per CU in
+// flight; it is bound by memory latency, not by its arithmetic (profiles/r05_*: 56 % of the wave time in s_waitcnt).
+template <int CIN, bool LEAN>
 __global__ void __launch_bounds__(256) pw_wgrad4_ss_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dy, float* __restrict__ partW,
                                                            float* __restrict__ partB, int S, int vox_per_block, float slope,
@@ -538,13 +541,18 @@ __global__ void __launch_bounds__(256) pw_wgrad4_ss_kernel(const float* __restri
                                                            const float* __restrict__ fold_src, int Sp, int pad) {
     __shared__ float red[4][64 * (CIN + 1)];
     __shared__ float sx[2][256 * CIN];
+    // the coordinate table in LDS: read from global memory its three loads per voxel sit BEHIND the y prefetches on the in-order
+    // vector-memory counter and every voxel waits for the newest prefetch (round 5)
+    __shared__ float slin[1024];                  // (S <= 1024: checked by the entry point)
+    for (int i = threadIdx.x; i < S; i += 256) slin[i] = lin[i];
     const DivT divT(T);
     const int b = blockIdx.y;
     const int c4 = (threadIdx.x & 15) * 4, gl = threadIdx.x >> 4, wid = threadIdx.x >> 6;
     const long long S3 = (long long)S * S * S;
-    const bool has_dy = dy != nullptr;           // (uniform) nullptr: only the pooled-feature (and fold_src) terms reach y
+    constexpr int NS = LEAN ? 8 : 2;              // voxels in flight per thread
+    const bool has_dy = !LEAN && dy != nullptr;   // (uniform) nullptr: only the pooled-feature (and fold_src) terms reach y
     x += (long long)b * S3 * CIN; y += (long long)b * S3 * 64 + c4; dy += (long long)b * S3 * 64 + c4;
-    if (fold_src) fold_src += (long long)b * Sp * Sp * Sp * 64 + c4;
+    if (!LEAN && fold_src) fold_src += (long long)b * Sp * Sp * Sp * 64 + c4;
     float m[4], inv_s[4], ex[4], ey[4], ez[4], gx[4], gy[4], gz[4], gm[4];
     int am[4];
 #pragma unroll
@@ -594,11 +602,12 @@ __global__ void __launch_bounds__(256) pw_wgrad4_ss_kernel(const float* __restri
             const int row = p / S;
             lk_ = ck_ = p - row * S; li_ = ci_ = row / S; lj_ = cj_ = row - li_ * S;
         }
-        float4 qy[2], qd[2], qf[2];
+        float4 qy[NS], qd[LEAN ? 1 : NS], qf[LEAN ? 1 : NS];
         auto issue = [&](int slot, int lv) {
             const long long v = t0 + lv;
             const bool ok = v < v1;
             qy[slot] = ok ? *reinterpret_cast<const float4*>(y + v * 64) : make_float4(1.f, 1.f, 1.f, 1.f);
+            if (LEAN) return;
             qd[slot] = (ok && has_dy) ? *reinterpret_cast<const float4*>(dy + v * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
             if (fold_src && ok) {
@@ -623,18 +632,19 @@ __global__ void __launch_bounds__(256) pw_wgrad4_ss_kernel(const float* __restri
             lk_ += 16;
             while (lk_ >= S) { lk_ -= S; if (++lj_ >= S) { lj_ = 0; ++li_; } }
         };
-        issue(0, gl);
-        issue(1, gl + 16);
-#pragma unroll 1
-        for (int it = 0; it < 16; it += 2) {
 #pragma unroll
-            for (int slot = 0; slot < 2; ++slot) {
+        for (int slot = 0; slot < NS; ++slot) issue(slot, gl + 16 * slot);
+#pragma unroll 1
+        for (int it = 0; it < 16; it += NS) {
+#pragma unroll
+            for (int slot = 0; slot < NS; ++slot) {
                 const int lv = gl + 16 * (it + slot);
-                const float4 yy = qy[slot], d4 = qd[slot], f4 = qf[slot];
-                if (it + slot + 2 < 16) issue(slot, lv + 32);
+                const float4 yy = qy[slot];
+                const float4 d4 = LEAN ? make_float4(0.f, 0.f, 0.f, 0.f) : qd[LEAN ? 0 : slot], f4 = LEAN ? make_float4(0.f, 0.f, 0.f, 0.f) : qf[LEAN ? 0 : slot];
+                if (it + slot + NS < 16) issue(slot, lv + 16 * NS);
                 if (t0 + lv < v1) {
                     const int p = (int)(t0 + lv);
-                    const float li = lin[ci_], lj = lin[cj_], lk = lin[ck_];
+                    const float li = slin[ci_], lj = slin[cj_], lk = slin[ck_];
                     const float ys[4] = {yy.x, yy.y, yy.z, yy.w};
                     const float ds[4] = {d4.x + f4.x, d4.y + f4.y, d4.z + f4.z, d4.w + f4.w};
                     float xr[CIN];
@@ -1289,14 +1299,18 @@ extern "C" int vxb_pointwise_wgrad_ss3d_f32(const float* x, const float* y, cons
                                             const float* fold_src, int Sp, int pad, vxb_stream_t stream) {
     if (!x || !y || !dW || !db || !part_ws || !lin || !stats || !out_ss || !argmax || !g_ss || !g_max || B < 1 || S < 1 ||
         Cin < 1 || Cin > 16 || (fold_src && (pad < 0 || Sp < S + 2 * pad))) return VXB_EARG;
-    if (Cout != 64 || Cin != 10 || ((((uintptr_t)y) | ((uintptr_t)dy) | ((uintptr_t)fold_src)) & 15)) return VXB_ESIZE;
+    if (Cout != 64 || Cin != 10 || S > 1024 || ((((uintptr_t)y) | ((uintptr_t)dy) | ((uintptr_t)fold_src)) & 15)) return VXB_ESIZE;
     const int vpb = 4096;
     const int nbs = vxb_cdiv((long long)S * S * S, vpb);
     const int nb = nbs * B;
     float* pW = part_ws;
     float* pB = part_ws + (size_t)nb * 64 * Cin;
-    hipLaunchKernelGGL(pw_wgrad4_ss_kernel<10>, dim3(nbs, B), dim3(256), 0, (hipStream_t)stream, x, y, dy, pW, pB, S, vpb, slope, lin,
-                       stats, out_ss, argmax, g_ss, g_max, 0.01f, fold_src, Sp, pad);
+    if (!dy && !fold_src)
+        hipLaunchKernelGGL((pw_wgrad4_ss_kernel<10, true>), dim3(nbs, B), dim3(256), 0, (hipStream_t)stream, x, y, dy, pW, pB, S, vpb, slope, lin,
+                           stats, out_ss, argmax, g_ss, g_max, 0.01f, fold_src, Sp, pad);
+    else
+        hipLaunchKernelGGL((pw_wgrad4_ss_kernel<10, false>), dim3(nbs, B), dim3(256), 0, (hipStream_t)stream, x, y, dy, pW, pB, S, vpb, slope, lin,
+                           stats, out_ss, argmax, g_ss, g_max, 0.01f, fold_src, Sp, pad);
     VXB_CHECK_LAUNCH();
     int rc = vxb_sum_splits_f32(pW, nb, 64 * Cin, dW, 1, 1.0f, stream);
     if (rc) return rc;
