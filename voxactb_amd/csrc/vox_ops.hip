@@ -287,6 +287,10 @@ __global__ void __launch_bounds__(256) pw_fwd_ss_kernel(const float* __restrict_
                                                         SsPart* __restrict__ part, int nchunk, float T) {
     __shared__ SsPart red[256 * 4];
     __shared__ float sx[2][PWSS_MAX_S * CIN];
+    // the coordinate table in LDS: as global loads its reads queue BEHIND the next row's prefetch on the in-order vector-memory counter,
+    // and every row waited for the prefetch it had just issued (round 5)
+    __shared__ float slin[PWSS_MAX_S];
+    for (int i = threadIdx.x; i < S; i += 256) slin[i] = lin[i];
     const DivT divT(T);
     constexpr int C = 64, q = 16, npl = 16;
     constexpr int NLD = (PWSS_MAX_S * CIN + 255) / 256;
@@ -328,7 +332,7 @@ __global__ void __launch_bounds__(256) pw_fwd_ss_kernel(const float* __restrict_
             }
         }
         const int i = row / S, j = row - i * S;
-        const float wy = lin[i], wx = lin[j];        // meshgrid 'xy' quirk: pos_x follows axis 1, pos_y axis 0
+        const float wy = slin[i], wx = slin[j];      // meshgrid 'xy' quirk: pos_x follows axis 1, pos_y axis 0
         const float* sxr = sx[cur];
         for (int k0 = pl; k0 < S; k0 += 4 * npl) {
             float4 o[4];
@@ -340,7 +344,7 @@ __global__ void __launch_bounds__(256) pw_fwd_ss_kernel(const float* __restrict_
                 const bool ok = k < S;
                 const int kc = ok ? k : 0;
                 vm |= (ok ? 1u : 0u) << uu;
-                wz[uu] = lin[kc];
+                wz[uu] = slin[kc];
                 float a0 = b0, a1 = b1, a2 = b2, a3 = b3;
 #pragma unroll
                 for (int ci = 0; ci < CIN; ++ci) {
@@ -531,7 +535,7 @@ __global__ void __launch_bounds__(256) ss_bwd_kernel(const float* __restrict__ x
 // LEAN (dy == nullptr and fold_src == nullptr: every conv path into y adds its share of dW / db itself, the shape the training step
 // takes): only y is streamed, EIGHT voxels ahead instead of two -- the kernel moved 4.3 GB in 2.18 ms (2 TB/s) with 32 KB per CU in
 // flight; it is bound by memory latency, not by its arithmetic (profiles/r05_*: 56 % of the wave time in s_waitcnt).
-template <int CIN, bool LEAN>
+template <int CIN, int MODE>           // MODE 1: LEAN; 2: y and dy, no fold_src (the default training step): four voxels in flight; 0: generic
 __global__ void __launch_bounds__(256) pw_wgrad4_ss_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dy, float* __restrict__ partW,
                                                            float* __restrict__ partB, int S, int vox_per_block, float slope,
@@ -549,10 +553,11 @@ __global__ void __launch_bounds__(256) pw_wgrad4_ss_kernel(const float* __restri
     const int b = blockIdx.y;
     const int c4 = (threadIdx.x & 15) * 4, gl = threadIdx.x >> 4, wid = threadIdx.x >> 6;
     const long long S3 = (long long)S * S * S;
-    constexpr int NS = LEAN ? 8 : 2;              // voxels in flight per thread
+    constexpr bool LEAN = MODE == 1, NOFOLD = MODE != 0;
+    constexpr int NS = LEAN ? 8 : (MODE == 2 ? 4 : 2);   // voxels in flight per thread
     const bool has_dy = !LEAN && dy != nullptr;   // (uniform) nullptr: only the pooled-feature (and fold_src) terms reach y
     x += (long long)b * S3 * CIN; y += (long long)b * S3 * 64 + c4; dy += (long long)b * S3 * 64 + c4;
-    if (!LEAN && fold_src) fold_src += (long long)b * Sp * Sp * Sp * 64 + c4;
+    if (!NOFOLD && fold_src) fold_src += (long long)b * Sp * Sp * Sp * 64 + c4;
     float m[4], inv_s[4], ex[4], ey[4], ez[4], gx[4], gy[4], gz[4], gm[4];
     int am[4];
 #pragma unroll
@@ -602,13 +607,14 @@ __global__ void __launch_bounds__(256) pw_wgrad4_ss_kernel(const float* __restri
             const int row = p / S;
             lk_ = ck_ = p - row * S; li_ = ci_ = row / S; lj_ = cj_ = row - li_ * S;
         }
-        float4 qy[NS], qd[LEAN ? 1 : NS], qf[LEAN ? 1 : NS];
+        float4 qy[NS], qd[LEAN ? 1 : NS], qf[NOFOLD ? 1 : NS];
         auto issue = [&](int slot, int lv) {
             const long long v = t0 + lv;
             const bool ok = v < v1;
             qy[slot] = ok ? *reinterpret_cast<const float4*>(y + v * 64) : make_float4(1.f, 1.f, 1.f, 1.f);
             if (LEAN) return;
             qd[slot] = (ok && has_dy) ? *reinterpret_cast<const float4*>(dy + v * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (NOFOLD) return;
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
             if (fold_src && ok) {
                 // one more gradient path into y, gathered in place: the adjoint of the replicate padding of a data gradient
@@ -640,7 +646,7 @@ __global__ void __launch_bounds__(256) pw_wgrad4_ss_kernel(const float* __restri
             for (int slot = 0; slot < NS; ++slot) {
                 const int lv = gl + 16 * (it + slot);
                 const float4 yy = qy[slot];
-                const float4 d4 = LEAN ? make_float4(0.f, 0.f, 0.f, 0.f) : qd[LEAN ? 0 : slot], f4 = LEAN ? make_float4(0.f, 0.f, 0.f, 0.f) : qf[LEAN ? 0 : slot];
+                const float4 d4 = LEAN ? make_float4(0.f, 0.f, 0.f, 0.f) : qd[LEAN ? 0 : slot], f4 = NOFOLD ? make_float4(0.f, 0.f, 0.f, 0.f) : qf[NOFOLD ? 0 : slot];
                 if (it + slot + NS < 16) issue(slot, lv + 16 * NS);
                 if (t0 + lv < v1) {
                     const int p = (int)(t0 + lv);
@@ -1305,12 +1311,12 @@ extern "C" int vxb_pointwise_wgrad_ss3d_f32(const float* x, const float* y, cons
     const int nb = nbs * B;
     float* pW = part_ws;
     float* pB = part_ws + (size_t)nb * 64 * Cin;
-    if (!dy && !fold_src)
-        hipLaunchKernelGGL((pw_wgrad4_ss_kernel<10, true>), dim3(nbs, B), dim3(256), 0, (hipStream_t)stream, x, y, dy, pW, pB, S, vpb, slope, lin,
-                           stats, out_ss, argmax, g_ss, g_max, 0.01f, fold_src, Sp, pad);
-    else
-        hipLaunchKernelGGL((pw_wgrad4_ss_kernel<10, false>), dim3(nbs, B), dim3(256), 0, (hipStream_t)stream, x, y, dy, pW, pB, S, vpb, slope, lin,
-                           stats, out_ss, argmax, g_ss, g_max, 0.01f, fold_src, Sp, pad);
+#define PW_WG(MODE_) hipLaunchKernelGGL((pw_wgrad4_ss_kernel<10, MODE_>), dim3(nbs, B), dim3(256), 0, (hipStream_t)stream, x, y, dy, pW, pB, S, vpb, slope, \
+                                        lin, stats, out_ss, argmax, g_ss, g_max, 0.01f, fold_src, Sp, pad)
+    if (!dy && !fold_src) PW_WG(1);
+    else if (!fold_src) PW_WG(2);
+    else PW_WG(0);
+#undef PW_WG
     VXB_CHECK_LAUNCH();
     int rc = vxb_sum_splits_f32(pW, nb, 64 * Cin, dW, 1, 1.0f, stream);
     if (rc) return rc;
