@@ -28,11 +28,15 @@
 
 using namespace vox;
 
+#ifndef VT_ABL
+#define VT_ABL 0          // timing-experiment builds of the route kernel (-DVT_ABL=bits through VXB_EXTRA_FLAGS; results WRONG when != 0)
+#endif
+
 namespace {
 
 constexpr int TX = 8, TY = 8, TZ = 16;          // cells per tile and axis
 constexpr int CELLS = TX * TY * TZ;             // 1024: cell-in-tile = (x & 7) << 7 | (y & 7) << 4 | (z & 15)
-constexpr int CHUNK = 2048;                     // points per route workgroup (256 threads x 8)
+constexpr int CHUNK = 1024;                     // points per route workgroup (256 threads x 4)
 constexpr int ID_BITS = 20;                     // key = cell-in-tile << 20 | point id
 constexpr int MAX_TILES = 8191;                 // 13-bit tile field in the route kernel's per-point word
 constexpr int MAX_NC = 512;                     // chunks per sample
@@ -94,12 +98,13 @@ __device__ __forceinline__ int block_excl_scan(int v, int* s_red, int* total) {
 }
 
 // ------------------------------------------------------------------------------------------------------------ route
+// (s_hist: [4][NT] unsigned short of dynamic LDS: per wave, points of this chunk per tile)
 template <int F>
-__global__ void __launch_bounds__(256) vt_route_kernel(Src src, Geom g, const float* __restrict__ bounds, TileWs w) {
-    extern __shared__ unsigned short s_hist[];          // [4][NT]: per wave, points of this chunk per tile
+__device__ __forceinline__ void route_chunk(const Src& src, const Geom& g, const float* __restrict__ bounds, const TileWs& w,
+                                            const int chunk, const int b, unsigned short* s_hist) {
     __shared__ int s_red[4];
     const int NT = w.NT;
-    const int chunk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int i = tid; i < 2 * NT; i += 256) reinterpret_cast<unsigned*>(s_hist)[i] = 0u;
     __syncthreads();
     const float* bd = bounds + (g.bounds_rows > 1 ? b * 6 : 0);
@@ -112,13 +117,27 @@ __global__ void __launch_bounds__(256) vt_route_kernel(Src src, Geom g, const fl
     float pv[PT][3 + F];
     unsigned validmask = 0;
     const int n0 = chunk * CHUNK + wv * (CHUNK / 4) + lane;
+    // A chunk that lies inside ONE source (camera) -- always, when the points per source are a multiple of the chunk -- takes that
+    // source's base pointers once, as scalars.  Indexing the by-value pointer arrays of `src` with a per-lane source index costs a
+    // dependent (vector) load of the pointer in front of every coordinate load: 11 of the kernel's 29 us (profiles/r05_voxel_route_ablation.log).
+    const int cbeg = chunk * CHUNK;
+    const int s_u = __builtin_amdgcn_readfirstlane(cbeg / g.pps);
+    const bool one_src = !g.proj && (cbeg - s_u * g.pps) + CHUNK <= g.pps;          // (uniform)
+    const float* __restrict__ cbase = one_src ? src.c[s_u] + (long long)b * g.cb - (long long)s_u * g.pps * g.cp : nullptr;
+    const float* __restrict__ fbase = (one_src && F > 0) ? src.f[s_u] + (long long)b * g.fb - (long long)s_u * g.pps * g.fp : nullptr;
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
         const int n = n0 + j * 64;
         tilecell[j] = 0;
         if (n < g.N) {
             float p[3];
-            load_coords(src, g, b, n, p);
+            if (VT_ABL & 16) { p[0] = bmn[0] + 1e-3f * (n & 255); p[1] = bmn[1] + 1e-3f * ((n >> 8) & 255); p[2] = bmn[2] + 1e-3f * (n >> 16); }
+            else if (one_src) {
+                const float* cp = cbase + (long long)n * g.cp;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) p[a] = cp[a * g.cc];
+                if (g.xf) xform_point(g.xf + b * 15, p);
+            } else load_coords(src, g, b, n, p);
             int ix[3];
             bool inside = true;
 #pragma unroll
@@ -134,8 +153,8 @@ __global__ void __launch_bounds__(256) vt_route_kernel(Src src, Geom g, const fl
                 tilecell[j] = tile | (cell << 13);
 #pragma unroll
                 for (int a = 0; a < 3; ++a) pv[j][a] = p[a];
-                if (F > 0) {
-                    const float* fp = point_ptr(src.f, n, g.pps, b, g.fb, g.fp);
+                if (F > 0 && !(VT_ABL & 8)) {
+                    const float* fp = one_src ? fbase + (long long)n * g.fp : point_ptr(src.f, n, g.pps, b, g.fb, g.fp);
 #pragma unroll
                     for (int c = 0; c < F; ++c) pv[j][3 + c] = fp[c * g.fc];
                 }
@@ -150,7 +169,7 @@ __global__ void __launch_bounds__(256) vt_route_kernel(Src src, Geom g, const fl
     for (int j = 0; j < PT; ++j) {
         const bool valid = (validmask >> j) & 1u;
         const unsigned tile = tilecell[j] & 0x1FFFu;
-        const unsigned long long m = match_bits(tile, w.tile_bits, valid);
+        const unsigned long long m = (VT_ABL & 4) ? (1ull << lane) : match_bits(tile, w.tile_bits, valid);
         const int rank = lanes_below(m), cnt = __popcll(m);
         const unsigned before = valid ? myh[tile] : 0u;
         if (valid && rank == 0) myh[tile] = (unsigned short)(before + cnt);
@@ -167,7 +186,7 @@ __global__ void __launch_bounds__(256) vt_route_kernel(Src src, Geom g, const fl
     unsigned short* offp = w.off + (size_t)b * (NT + 1) * w.NC + chunk;       // [tile][chunk]: a tile's row is contiguous
     for (int t = t0; t < t1; ++t) {
         const int h0 = s_hist[t], h1 = s_hist[NT + t], h2 = s_hist[2 * NT + t], h3 = s_hist[3 * NT + t];
-        offp[(size_t)t * w.NC] = (unsigned short)run;
+        if (!(VT_ABL & 2)) offp[(size_t)t * w.NC] = (unsigned short)run;
         s_hist[t] = (unsigned short)run;
         s_hist[NT + t] = (unsigned short)(run + h0);
         s_hist[2 * NT + t] = (unsigned short)(run + h0 + h1);
@@ -187,10 +206,20 @@ __global__ void __launch_bounds__(256) vt_route_kernel(Src src, Geom g, const fl
 #pragma unroll
             for (int c = 0; c < 3 + F; ++c) v[c] = pv[j][c];
             v[7] = __uint_as_float(key);
-            w.recs[dst * 2] = make_float4(v[0], v[1], v[2], v[3]);
-            w.recs[dst * 2 + 1] = make_float4(v[4], v[5], v[6], v[7]);
+            if (!(VT_ABL & 1)) {
+                w.recs[dst * 2] = make_float4(v[0], v[1], v[2], v[3]);
+                w.recs[dst * 2 + 1] = make_float4(v[4], v[5], v[6], v[7]);
+            }
         }
     }
+}
+
+template <int F>
+__global__ void __launch_bounds__(256) vt_route_kernel(Src src, Geom g, const float* __restrict__ bounds, TileWs w, int clear_ctr) {
+    extern __shared__ unsigned short s_dyn[];
+    if (clear_ctr && blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = threadIdx.x; i < 64 + 32 * g.B; i += 256) w.ctr[i] = 0;
+    route_chunk<F>(src, g, bounds, w, blockIdx.x, blockIdx.y, s_dyn);
 }
 
 // one compact record per occupied cell: means of the 3 + F channels, address of the cell inside the sample; with `out` the
@@ -727,13 +756,13 @@ int vt_launch(const Src& src, const Geom& g, const float* bounds, float* out, co
     if (order == 4 || order == 7) hipLaunchKernelGGL(vt_unpatch_kernel<F>, dim3((unsigned)((cap + 255) / 256), g.B), dim3(256), 0, st, g, w, out);
     if (order == 0) vox_launch_fill(out, g.B, g.V, C, side);
     if (order == 2 || order == 6) vox_launch_fill(out, g.B, g.V, C, st);
-    if (order != 4 && order != 7 && hipMemsetAsync(w.ctr, 0, CTR_INTS(g.B) * sizeof(int), st) != hipSuccess) return VXB_ELAUNCH;
     const size_t lds = (size_t)4 * w.NT * sizeof(unsigned short);
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute((const void*)vt_route_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return VXB_ELAUNCH;
     }
-    hipLaunchKernelGGL(vt_route_kernel<F>, dim3(w.NC, g.B), dim3(256), lds, st, src, g, bounds, w);
+    // (this call's counters are cleared by the route kernel's first workgroup unless the unpatch kernel already did: no memset node)
+    hipLaunchKernelGGL(vt_route_kernel<F>, dim3(w.NC, g.B), dim3(256), lds, st, src, g, bounds, w, (order != 4 && order != 7) ? 1 : 0);
     const long long tiles = (long long)g.B * w.NT;
     const size_t heavy_lds = 0;
     if (order == 6 || order == 7) {
