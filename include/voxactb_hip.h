@@ -285,6 +285,15 @@ int vxb_conv3_halo_ss3d_bf16x3_f32(const float* src0, const float* src1, int C0,
                                    const float* bias, float* out, int act, float slope, const void* wfrag, const float* lin,
                                    float* part_ws, float* out_ss, float* out_max, float* stats, int32_t* argmax,
                                    vxb_stream_t stream);
+/* The same launch with the filter's depth axis evaluated by Winograd's F(2, 3): per (kh, kw) four products for two output depths
+ * instead of six -- two thirds of the matrix work (helpers/network_utils.py:128-170 `final`, the step's largest kernel).  wfrag_wg: the
+ * 36 transformed taps (xi, kh, kw), xi = {g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2} over the depth taps, as bf16 hi/lo planes in
+ * fragment order [1][chunk][36][column tile 2][plane 2][lane 64][8] (ops.halo_wfrag_wg).  S % 4 == 0.  Agrees with the direct entry to
+ * fp32 rounding of the transforms (~1e-6 relative), not bit for bit. */
+int vxb_conv3_halo_ss3d_wg_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S, const float* bias,
+                                      float* out, int act, float slope, const void* wfrag_wg, const float* lin,
+                                      float* part_ws, float* out_ss, float* out_max, float* stats, int32_t* argmax,
+                                      vxb_stream_t stream);
 /* wfrag (optional, NULL = weights staged through LDS per tap): the same weights pre-shuffled into MFMA fragment order,
  * [N/64][chunk][tap][column tile 2][k half or plane 2][lane 64][8 bf16] with chunk = 32 channels ('bf16') or 16 ('bf16x3');
  * the kernel then loads its B fragments straight from global memory and the 27-tap loop has no barrier.
@@ -308,6 +317,12 @@ int vxb_conv3_dgrad_fold_f16_f32(const float* dy, int C0, int B, int S, const vo
  * as one fp16 value (wfrag_f16x2: single-plane fragment order of the fp16 [64][27 C0] matrix); optional by-products as in
  * vxb_conv3_dgrad_fold_f32 (dst_scale [2] + scale_ws, dst_colsum [64] ACCUMULATED + colsum_ws). */
 int vxb_conv3_dgrad_fold_f16x2_f32(const float* dy, int C0, int B, int S, const void* wfrag_f16x2, float* dst, const float* y,
+                                   int acc, float slope, const float* scale, float* dst_scale, float* scale_ws,
+                                   float* dst_colsum, float* colsum_ws, vxb_stream_t stream);
+/* ... with the filter's depth axis by Winograd's F(2, 3) (see vxb_conv3_halo_ss3d_wg_bf16x3_f32): wfrag_f16x2_wg = ops.halo_wfrag_x2_wg,
+ * the 36 transformed taps rounded to fp16 after the transform; S even.  dy * scale[0] / 2 is carried (the transformed operand is a sum
+ * of two values).  Against the direct entry: ~1e-6 of the largest output (tests/test_halo_winograd_gpu.py). */
+int vxb_conv3_dgrad_fold_f16x2_wg_f32(const float* dy, int C0, int B, int S, const void* wfrag_f16x2_wg, float* dst, const float* y,
                                    int acc, float slope, const float* scale, float* dst_scale, float* scale_ws,
                                    float* dst_colsum, float* colsum_ws, vxb_stream_t stream);
 /* ... when that block is the data gradient of a 1x1x1 conv's output y = lrelu(W_in x + b_in) whose input x [B, S^3, 10] is a detached

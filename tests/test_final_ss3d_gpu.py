@@ -19,6 +19,7 @@ def test_conv_epilogue_statistics_match_the_statistics_pass(S, B):
     W = rnd(C, 2 * C, 3, 3, 3, seed=3, scale=0.03).to(DEV)
     bias = rnd(C, seed=4).to(DEV)
     ops.PRECISION = 'bf16x3'
+    wino, ops.FINAL_WINOGRAD = ops.FINAL_WINOGRAD, False        # the DIRECT kernel's claim (tests/test_halo_winograd_gpu.py: the other one)
     try:
         assert ops.conv3_ss3d_ok(C, C, C, S)
         wt = ops.conv_weight_fwd(W)
@@ -27,6 +28,7 @@ def test_conv_epilogue_statistics_match_the_statistics_pass(S, B):
         got, (g_ss, g_max, g_stats, g_arg) = ops.conv3_ss3d_fwd(d0, u0, wt, bias, B, S)
     finally:
         ops.PRECISION = 'fp32'
+        ops.FINAL_WINOGRAD = wino
     assert torch.equal(got, ref)
     assert torch.equal(g_arg, r_arg)
     assert torch.equal(g_max, r_max)

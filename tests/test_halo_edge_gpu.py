@@ -33,10 +33,17 @@ def test_forward_part_tiles(S, B):
         full, part = _both(lambda: ops.conv3d(d0, wt, C, B, S, S, 3, -1, bias=bias, act=ops.ACT_LRELU, src1=u0))
         assert torch.equal(full, part)
         if ops.conv3_ss3d_ok(C, C, C, S):
-            f2, p2 = _both(lambda: ops.conv3_ss3d_fwd(d0, u0, wt, bias, B, S))
-            assert torch.equal(f2[0], p2[0]) and torch.equal(f2[0], full)
-            for a, b in zip(f2[1], p2[1]):
-                assert torch.equal(a, b)
+            for wino in (False, True):              # the direct kernel, then the Winograd-along-depth one (S % 4 == 0: half tiles only)
+                old = ops.FINAL_WINOGRAD
+                ops.FINAL_WINOGRAD = wino
+                try:
+                    f2, p2 = _both(lambda: ops.conv3_ss3d_fwd(d0, u0, wt, bias, B, S))
+                finally:
+                    ops.FINAL_WINOGRAD = old
+                assert torch.equal(f2[0], p2[0])
+                assert wino or torch.equal(f2[0], full)
+                for a, b in zip(f2[1], p2[1]):
+                    assert torch.equal(a, b)
     finally:
         ops.PRECISION = 'fp32'
 

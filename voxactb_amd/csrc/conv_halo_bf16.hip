@@ -128,14 +128,26 @@ __device__ __forceinline__ float hb_unpack_hi(unsigned pk) {
 
 __device__ __forceinline__ bool g_dbg_all_waves(const HaloArgs& g) { return (g.dbg & 4) != 0; }    // experiment bit 4: no wave skipping
 
-template <int NTG, int PM, int NW, int WD, int TL, int WN, int HALF>
+template <int NTG, int PM, int NW, int WD, int TL, int WN, int HALF, int WG = 0>
                                               // NTG = N / 32 column tiles per workgroup; the NW waves form a (NW / WN) x WN grid over
                                               // (8 M tiles) x (NTG column tiles): 4 x 1 -> 2 M tiles x 2 column tiles per wave,
                                               // 2 x 2 -> 4 x 1 (half the B-fragment traffic per MFMA, twice the A reads from LDS),
                                               // 8 x 1 -> 1 x 2; WD: B fragments straight from global (pre-shuffled weights); TL:
                                               // per-chunk tap lists (block-sparse weights, WD only)
                                               // HALF = 1: an edge tile whose odd M tiles hold no output voxel (see the kernel below)
+                                              // WG = 1: Winograd F(2, 3) along the depth axis (see WG_* below)
 __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
+    // ---- WG: the two output depths 2p, 2p + 1 of a tile (p = 0, 1: the wave row wm) come from FOUR products per (kh, kw) instead of six:
+    //   m0 = (x0 - x2) g0,  m1 = (x1 + x2) (g0 + g1 + g2) / 2,  m2 = (x2 - x1) (g0 - g1 + g2) / 2,  m3 = (x1 - x3) g2
+    //   y0 = m0 + m1 + m2,  y1 = m1 - m2 - m3                                   (x: input depths 2p .. 2p + 3, g: the three depth taps)
+    // The input transform is applied on the way into LDS (fp32, before the hi | lo split; the image holds the 2 x 4 transformed planes
+    // instead of the 6 raw ones), the weight transform on the host (ops.halo_wfrag_wg: 36 "taps" (xi, kh, kw)), the output transform on
+    // the accumulators (a wave's M tiles are (depth, w half), so y0 / y1 are its own registers).  36 x 2 instead of 27 x 4 MFMA groups
+    // per wave and chunk: two thirds of the matrix work, which is what bounds the direct kernel (73 % of its time).
+    static_assert(!WG || (WD && !TL && WN == 2 && NW == 4 && NTG == 2 && (HALF == 0 || HALF == 1) && (PM == 1 || PM == 3)),
+                  "WG: the final conv's forward (bf16x3) and its propagating data gradient (fp16x2)");
+    constexpr int NTAP = WG ? 36 : 27;
+    constexpr int PLANE = HHp * HWp * SP;           // u16 per depth plane of the LDS image
     constexpr int X3 = PM == 1;                     // three products: input hi | lo, weight planes hi / lo
     constexpr int X2 = PM == 3;                     // two products: input hi | lo, one weight plane
     constexpr int HL = X3 || X2;                    // a chunk is 16 channels as hi | lo halves
@@ -145,7 +157,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     constexpr int NTH = NW * 64, MTW = 8 / (NW / WN), NT = NTG / WN;
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* halo = smem;                               // [HALO_SLOTS][SP]
-    u16* wsm = smem + HALO_SLOTS * SP;              // [2][N][LDW]
+    u16* wsm = smem + (WG ? 8 : HDp) * PLANE;       // [2][N][LDW]   (WG: 8 planes, and no weight tiles -- WD)
     constexpr int N = NTG * 32;
     constexpr int CPC = HL ? 16 : 32;               // channels per chunk
     constexpr int F4P = CPC / 4;                    // float4 per voxel per chunk
@@ -236,6 +248,22 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
         abase[i] = ((dd * HHp + hh) * HWp + ww) * SP + 8 * hi;
     }
     const int wrow = lq * LDW + 8 * hi;            // B-operand row of this lane inside a weight tile (+ nt*32*LDW)
+    // WG: m0..m3 of this wave's two (w half) tiles; the A operand of product xi is transformed plane 4 wm + xi
+    constexpr int WLIM = HALF == 1 ? 1 : 2;
+    f32x16 wacc[WG ? 2 : 1][WG ? 4 : 1];
+    int wabase[2] = {0, 0};
+    if constexpr (WG) {
+#pragma unroll
+        for (int wh = 0; wh < 2; ++wh) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) wacc[wh][x][r] = 0.f;
+            int dd, hh, ww;
+            rowmap(wh, lq, dd, hh, ww);
+            wabase[wh] = ((4 * wm * HHp + hh) * HWp + ww) * SP + 8 * hi;
+        }
+    }
 
     // halo staging slots of this thread: element e = tid + 256 i -> voxel e / F4P, channel quad e % F4P
     // space-to-depth source (s2d_s > 0): the input "channels" are (phase, co) of a fine grid [B, (S_in*s)^3, s2d_C];
@@ -270,6 +298,36 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
         }
     }
     const long long bvox = (long long)b * Vin * Vin * Vin;
+    // WG staging: a thread owns whole depth COLUMNS (h, w, channel quad) of the halo -- 10 x 10 x 4 = 400 over 256 threads -- because the
+    // transform mixes the six depths of a column
+    constexpr int NCOL = WG ? 2 : 1;
+    int wg_hw[NCOL];        // (h, w) part of the source voxel offset, -1 = unused, -2 = zero fill
+    int wg_soff[NCOL];      // LDS offset inside plane 0
+    int wg_d[HDp];          // depth part of the source voxel offset (uniform), -2 = zero fill
+    if constexpr (WG) {
+#pragma unroll
+        for (int i = 0; i < NCOL; ++i) {
+            const int e = tid + NTH * i;
+            const int p = e / F4P, c4 = (e % F4P) * 4;
+            wg_hw[i] = -1; wg_soff[i] = 0;
+            if (p < HHp * HW_USED) {
+                const int pw = p % HW_USED, ph = p / HW_USED;
+                int ih = h0 + ph + g.off, iw = w0 + pw + g.off;
+                bool ok = true;
+                if (g.replicate) { ih = min(max(ih, 0), g.S_in - 1); iw = min(max(iw, 0), g.S_in - 1); }
+                else ok = ih >= 0 && ih < g.S_in && iw >= 0 && iw < g.S_in;
+                wg_soff[i] = (ph * HWp + pw) * SP + c4;
+                wg_hw[i] = ok ? ih * Vin + iw : -2;
+                if (HALF == 1 && (edge_h ? ph : pw) >= 6) wg_hw[i] = -1;
+            }
+        }
+#pragma unroll
+        for (int pd = 0; pd < HDp; ++pd) {
+            int id = d0 + pd + g.off;
+            if (g.replicate) id = min(max(id, 0), g.S_in - 1);
+            wg_d[pd] = (id >= 0 && id < g.S_in) ? id * Vin * Vin : -2;
+        }
+    }
 
     // Weight tiles travel global -> registers -> LDS two taps ahead of their use (two register sets, two LDS buffers),
     // so an L2 round trip has two taps of MFMAs to hide behind; the A fragments of the next tap are read from the halo
@@ -340,12 +398,12 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     bf16x8 bqr[BD + 1][NT][2];
     const int nchunk = Ct / CPC;
     int tapbase = 0, ntap = 27, taplist = 0;      // TL: first row of this chunk in wfrag, its tap count, lane n = n-th tap's LDS offset
-    const long long wf_rows = TL ? g.tap_total : (long long)nchunk * 27;
+    const long long wf_rows = TL ? g.tap_total : (long long)nchunk * NTAP;
 #define HD_LOADB(BQ, tap_)                                                                                           \
     if (!(g.dbg & 2) || (tap_) < 3)                                                                                   \
     _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                    \
     _Pragma("unroll") for (int f = 0; f < NF; ++f)                                                                    \
-        BQ[j][f] = *reinterpret_cast<const bf16x8*>(g.wfrag + (((long long)(n0 / N) * wf_rows + (TL ? tapbase : ch * 27) + (tap_)) * (NTG * NF) + (wn * NT + j) * NF + f) * 512 + lane * 8);
+        BQ[j][f] = *reinterpret_cast<const bf16x8*>(g.wfrag + (((long long)(n0 / N) * wf_rows + (TL ? tapbase : ch * NTAP) + (tap_)) * (NTG * NF) + (wn * NT + j) * NF + f) * 512 + lane * 8);
 #define HB_READ_A_OFF(AF, off_)                                                                                      \
     {                                                                                                                \
         const int toff_ = (off_);                                                                                    \
@@ -418,9 +476,10 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     // VGPRs in 'bf16x3', no spills -- is 3.6 % SLOWER.  The vector L1 returns data in request order for the whole CU, so HBM-latency
     // halo loads in the middle of a tap loop hold up the L2-hit B-fragment loads of both resident workgroups.)
     constexpr bool PF = false;
-    const float in_sc = (PM >= 2 && g.scale) ? g.scale[0] : 1.0f;
-    const float out_sc = (PM >= 2 && g.scale) ? g.scale[1] : 1.0f;
-    float4 hv[NLD];
+    // (WG: the transformed inputs are sums of two values -- one more bit of headroom under the largest half; a power of two, exact)
+    const float in_sc = ((PM >= 2 && g.scale) ? g.scale[0] : 1.0f) * ((WG && PM >= 2) ? 0.5f : 1.0f);
+    const float out_sc = ((PM >= 2 && g.scale) ? g.scale[1] : 1.0f) * ((WG && PM >= 2) ? 2.0f : 1.0f);
+    float4 hv[WG ? NCOL * HDp : NLD];
     auto halo_issue = [&](int ch_) {
         const int cb_ = ch_ * CPC;
         const bool second = cb_ >= g.C0;
@@ -428,6 +487,17 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
         int Cs = second ? g.C1 : g.C0;
         int c0 = second ? cb_ - g.C0 : cb_;
         long long vbase = bvox;
+        if constexpr (WG) {
+#pragma unroll
+            for (int i = 0; i < NCOL; ++i)
+#pragma unroll
+                for (int pd = 0; pd < HDp; ++pd) {
+                    hv[i * HDp + pd] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (wg_hw[i] >= 0 && wg_d[pd] >= 0)
+                        hv[i * HDp + pd] = *reinterpret_cast<const float4*>(src + (vbase + wg_d[pd] + wg_hw[i]) * Cs + c0 + (((tid + NTH * i) % F4P) * 4));
+                }
+            return;
+        }
         if (g.s2d_s > 0) {
             const int ph = cb_ / g.s2d_C;
             c0 = cb_ - ph * g.s2d_C;
@@ -484,8 +554,38 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
             }
             __syncthreads();                        // no per-tap barriers here: every wave must be done with the old halo
         }
+        if constexpr (WG) {
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
+            for (int i = 0; i < NCOL; ++i) {
+                if (wg_hw[i] == -1) continue;
+                float4* x = &hv[i * HDp];
+                if (PM >= 2) {
+#pragma unroll
+                    for (int pd = 0; pd < HDp; ++pd) { x[pd].x *= in_sc; x[pd].y *= in_sc; x[pd].z *= in_sc; x[pd].w *= in_sc; }
+                }
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const float4 x0 = x[2 * pr], x1 = x[2 * pr + 1], x2 = x[2 * pr + 2], x3 = x[2 * pr + 3];
+                    float4 t[4];
+                    t[0] = make_float4(x0.x - x2.x, x0.y - x2.y, x0.z - x2.z, x0.w - x2.w);
+                    t[1] = make_float4(x1.x + x2.x, x1.y + x2.y, x1.z + x2.z, x1.w + x2.w);
+                    t[2] = make_float4(x2.x - x1.x, x2.y - x1.y, x2.z - x1.z, x2.w - x1.w);
+                    t[3] = make_float4(x1.x - x3.x, x1.y - x3.y, x1.z - x3.z, x1.w - x3.w);
+#pragma unroll
+                    for (int xi = 0; xi < 4; ++xi) {
+                        uint2 pk, q;
+                        pk.x = hb_pack2<PM>(t[xi].x, t[xi].y); pk.y = hb_pack2<PM>(t[xi].z, t[xi].w);
+                        q.x = hb_pack2<PM>(t[xi].x - hb_unpack_lo<PM>(pk.x), t[xi].y - hb_unpack_hi<PM>(pk.x));
+                        q.y = hb_pack2<PM>(t[xi].z - hb_unpack_lo<PM>(pk.y), t[xi].w - hb_unpack_hi<PM>(pk.y));
+                        u16* dstp = &halo[wg_soff[i] + (4 * pr + xi) * PLANE];
+                        *reinterpret_cast<uint2*>(dstp) = pk;
+                        *reinterpret_cast<uint2*>(dstp + 16) = q;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < (WG ? 0 : NLD); ++i) {
             if (st_goff[i] != -1 && !dbg_skip_stage && !((g.dbg & 0x10) && ch > 0)) {       // (0x10: loads, but no conversion / LDS stores after the first chunk)
                 if (PM >= 2) { hv[i].x *= in_sc; hv[i].y *= in_sc; hv[i].z *= in_sc; hv[i].w *= in_sc; }
                 uint2 pk;
@@ -518,6 +618,41 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
                 HT_TAP(n, bq0, bq2, afa, afb)
                 HT_TAP(n + 1, bq1, bq0, afb, afa)
                 HT_TAP(n + 2, bq2, bq1, afa, afb)
+            }
+            continue;
+        }
+        if constexpr (WG) {
+            // tap = (xi, kh, kw): A from transformed plane 4 wm + xi at (kh, kw), accumulator m_xi; same pipeline as the BD = 4 loop below
+#define WG_READ_A(AF, tap_)                                                                                          \
+    {                                                                                                                \
+        const int tp_ = (tap_);                                                                                      \
+        const int toff_ = (tp_ / 9) * PLANE + (((tp_ / 3) % 3) * HWp + tp_ % 3) * SP;                                \
+        _Pragma("unroll") for (int wh = 0; wh < WLIM; ++wh) {                                                        \
+            AF[wh][0] = *reinterpret_cast<const bf16x8*>(&halo[wabase[wh] + toff_]);                                 \
+            AF[wh][1] = *reinterpret_cast<const bf16x8*>(&halo[wabase[wh] + toff_ + 16]);                            \
+        }                                                                                                            \
+    }
+#define WG_MFMA(AC, BC, XI)                                                                                          \
+    {                                                                                                                \
+        _Pragma("unroll") for (int wh = 0; wh < WLIM; ++wh) wacc[wh][XI] = hb_mfma<PM>(AC[wh][1], BC[0][0], wacc[wh][XI]); \
+        if (X3) {                                                                                                    \
+            _Pragma("unroll") for (int wh = 0; wh < WLIM; ++wh) wacc[wh][XI] = hb_mfma<PM>(AC[wh][0], BC[0][1], wacc[wh][XI]); \
+        }                                                                                                            \
+        _Pragma("unroll") for (int wh = 0; wh < WLIM; ++wh) wacc[wh][XI] = hb_mfma<PM>(AC[wh][0], BC[0][0], wacc[wh][XI]); \
+    }
+            WG_READ_A(afa, 0)
+#pragma unroll
+            for (int tp = 0; tp < 36; ++tp) {
+                if (tp + BD < 36) { HD_LOADB(bqr[(tp + BD) % (BD + 1)], tp + BD) }
+                if (tp & 1) {
+                    if (tp + 1 < 36) { WG_READ_A(afa, tp + 1) }
+                    __builtin_amdgcn_sched_barrier(0);
+                    WG_MFMA(afb, bqr[tp % (BD + 1)], tp / 9)
+                } else {
+                    if (tp + 1 < 36) { WG_READ_A(afb, tp + 1) }
+                    __builtin_amdgcn_sched_barrier(0);
+                    WG_MFMA(afa, bqr[tp % (BD + 1)], tp / 9)
+                }
             }
             continue;
         }
@@ -556,6 +691,16 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
                 }
             }
         }
+    }
+    if constexpr (WG) {
+        // output transform: M tile i = 2 (depth parity) + w half
+#pragma unroll
+        for (int wh = 0; wh < WLIM; ++wh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[wh][0][r] = (wacc[wh][0][r] + wacc[wh][1][r]) + wacc[wh][2][r];
+                acc[2 + wh][0][r] = (wacc[wh][1][r] - wacc[wh][2][r]) - wacc[wh][3][r];
+            }
     }
     if (g.fold_pad > 0) {
         // ---- fused adjoint of the replicate padding (vxb_fold_pad_f32 without the round trip through HBM): the tile goes
@@ -816,9 +961,21 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     }
 }
 
-template <int NTG, int PM, int NW, int WD, int TL = 0, int WN = 1>
+template <int NTG, int PM, int NW, int WD, int TL = 0, int WN = 1, int WG = 0>
 __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
     constexpr bool EDGE = WD && WN == 2 && NW == 4;
+    if constexpr (WG) {
+        // (the host checked S_out % 2 == 0: a depth tile holds two or four outputs -- the idle wave row of a two-deep tile only helps
+        // staging; a last row / column tile of 6 runs in full, of 4 or less as a half tile)
+        const int nwg = gridDim.x, lid = blockIdx.x;
+        const int xcd = lid & 7, slot = lid >> 3, q = nwg >> 3, r = nwg & 7;
+        int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        t /= g.N / (NTG * 32);
+        const int tw = t % g.ntw, th = (t / g.ntw) % g.nth;
+        if (min(g.S_out - tw * TW, g.S_out - th * TH) <= 4 && !g_dbg_all_waves(g)) conv3_halo_body<NTG, PM, NW, WD, TL, WN, 1, 1>(g);
+        else conv3_halo_body<NTG, PM, NW, WD, TL, WN, 0, 1>(g);
+        return;
+    } else
     if constexpr (EDGE) {
         // this workgroup's tile (the body decodes it again): how many of its 8 columns (else: rows) lie inside the output grid?
         const int nwg = gridDim.x, lid = blockIdx.x;
@@ -851,14 +1008,14 @@ int g_halo_wn = 0;         // experiment knob (vxb_debug_set_halo_wn): waves alo
                           // repetitions each, B = 16, S = 100): forward 20.23 -> 19.43 ms, data gradient + padding adjoint
                           // 21.89 -> 20.85 ms; the tap-list variant (up-conv data gradient) is unchanged, 11.0 ms either way        // experiment knob (vxb_debug_set_halo_waves): 4 waves x 2 M tiles or 8 waves x 1 M tile per workgroup
 
-template <int NT, int PM, int NW, int WD, int TL = 0, int WN = 1>
+template <int NT, int PM, int NW, int WD, int TL = 0, int WN = 1, int WG = 0>
 int hb_launch(const HaloArgs& g, long long nblk, hipStream_t st) {
     // (the fold epilogue re-uses the buffer as an fp32 [256][64] tile: keep the full size in every variant)
-    const size_t lds = (size_t)(HALO_SLOTS * SP + 2 * NT * 32 * LDW) * sizeof(u16);
+    const size_t lds = WG ? (size_t)8 * HHp * HWp * SP * sizeof(u16) : (size_t)(HALO_SLOTS * SP + 2 * NT * 32 * LDW) * sizeof(u16);
     if (TL && (size_t)(g.ncls * 32 + g.nphase * 2) * sizeof(int) > (size_t)2 * NT * 32 * LDW * sizeof(u16)) return VXB_ESIZE;
-    if (hipFuncSetAttribute((const void*)conv3_halo_kernel<NT, PM, NW, WD, TL, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv3_halo_kernel<NT, PM, NW, WD, TL, WN, WG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VXB_ELAUNCH;
-    hipLaunchKernelGGL((conv3_halo_kernel<NT, PM, NW, WD, TL, WN>), dim3((unsigned)(nblk * (g.N / (NT * 32)) * (TL ? g.ksplit : 1))), dim3(NW * 64), lds, st, g);
+    hipLaunchKernelGGL((conv3_halo_kernel<NT, PM, NW, WD, TL, WN, WG>), dim3((unsigned)(nblk * (g.N / (NT * 32)) * (TL ? g.ksplit : 1))), dim3(NW * 64), lds, st, g);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
@@ -867,7 +1024,10 @@ int hb_impl(int x3 /* product mode: 0 bf16, 1 bf16x3, 2 fp16 (WD kernels only, `
             const void* wt_bf16, int N, const float* bias, float* out, int act, float slope, int s2d_s, int s2d_C,
             int d2s_s, vxb_stream_t stream, const HaloArgs* fold = nullptr, const void* wfrag = nullptr,
             const int32_t* taptab = nullptr, int ncls = 0, int nphase = 0, int tap_total = 0, const float* scale = nullptr,
-            int ksplit = 1, const int32_t* kparts = nullptr, float* ss_part = nullptr, const float* ss_lin = nullptr) {
+            int ksplit = 1, const int32_t* kparts = nullptr, float* ss_part = nullptr, const float* ss_lin = nullptr, int wino = 0) {
+    // wino: Winograd F(2, 3) along depth (see conv3_halo_body): bf16x3, fragment-order weights of the 36 transformed taps, whole depth tiles
+    if (wino && ((x3 != 1 && x3 != 3) || !wfrag || taptab || s2d_s > 0 || d2s_s > 0 || N != 64 || (S_out & 1) || (g_halo_wn && g_halo_wn != 2)))
+        return VXB_EARG;
     if (x3 == 2 && (!wfrag || taptab)) return VXB_EARG;
     if (x3 == 3 && (!wfrag || !scale || src1 || replicate || d2s_s > 0)) return VXB_EARG;     // data gradients only
     if (!src0 || !wt_bf16 || (!out && !fold) || B < 1 || S_in < 1 || S_out < 1) return VXB_EARG;
@@ -903,6 +1063,7 @@ int hb_impl(int x3 /* product mode: 0 bf16, 1 bf16x3, 2 fp16 (WD kernels only, `
     hipStream_t st = (hipStream_t)stream;
     // 64 output channels per workgroup (162-225 VGPRs -> two workgroups per CU); N = 128 runs two column blocks that each
     // stage the halo -- cheaper than the register spills of a 128-wide accumulator tile.
+    if (wino) return x3 == 3 ? hb_launch<2, 3, 4, 1, 0, 2, 1>(g, nblk, st) : hb_launch<2, 1, 4, 1, 0, 2, 1>(g, nblk, st);
     if (x3 == 2) return hb_launch<2, 2, 4, 1>(g, nblk, st);
     if (x3 == 3) return g.taptab ? hb_launch<2, 3, 4, 1, 1, 2>(g, nblk, st) : hb_launch<2, 3, 4, 1, 0, 2>(g, nblk, st);
     const int wn = g_halo_wn ? g_halo_wn : (x3 ? 2 : 1);
@@ -960,6 +1121,22 @@ extern "C" int vxb_conv3_halo_ss3d_bf16x3_f32(const float* src0, const float* sr
     if (!wfrag || !lin || !part_ws || !out_ss || !out_max || !stats || !argmax) return VXB_EARG;
     const int rc = hb_impl(1, src0, src1, C0, C1, B, S, S, -1, 1, wt_bf16, 64, bias, out, act, slope, 0, 0, 0, stream, nullptr, wfrag,
                            nullptr, 0, 0, 0, nullptr, 1, nullptr, part_ws, lin);
+    if (rc) return rc;
+    return vxb_ss3d_final_tiles_launch(part_ws, vxb_cdiv(S, TD) * vxb_cdiv(S, TH) * vxb_cdiv(S, TW), B, 64, out_ss, out_max, stats, argmax,
+                                       (hipStream_t)stream);
+}
+
+// vxb_conv3_halo_ss3d_bf16x3_f32 with the depth axis of the 3x3x3 filter evaluated by Winograd's F(2, 3) (four products per two output
+// depths instead of six: 2/3 of the matrix work; conv3_halo_body, WG): wfrag_wg = ops.halo_wfrag_wg of the weights -- the 36 transformed
+// taps (xi, kh, kw) in fragment order.  S % 4 == 0.  The transforms are exact up to fp32 rounding of sums of two inputs / three
+// weights; results agree with the direct kernel to ~1e-6 relative (tests/test_halo_winograd_gpu.py), not bit for bit.
+extern "C" int vxb_conv3_halo_ss3d_wg_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S, const float* bias,
+                                                 float* out, int act, float slope, const void* wfrag_wg, const float* lin,
+                                                 float* part_ws, float* out_ss, float* out_max, float* stats, int32_t* argmax,
+                                                 vxb_stream_t stream) {
+    if (!wfrag_wg || !lin || !part_ws || !out_ss || !out_max || !stats || !argmax || (S & 3)) return VXB_EARG;
+    const int rc = hb_impl(1, src0, src1, C0, C1, B, S, S, -1, 1, wfrag_wg, 64, bias, out, act, slope, 0, 0, 0, stream, nullptr, wfrag_wg,
+                           nullptr, 0, 0, 0, nullptr, 1, nullptr, part_ws, lin, 1);
     if (rc) return rc;
     return vxb_ss3d_final_tiles_launch(part_ws, vxb_cdiv(S, TD) * vxb_cdiv(S, TH) * vxb_cdiv(S, TW), B, 64, out_ss, out_max, stats, argmax,
                                        (hipStream_t)stream);
@@ -1049,9 +1226,9 @@ extern "C" int vxb_conv3_dgrad_fold_f16_f32(const float* dy, int C0, int B, int 
 // PROPAGATE -- the d(u0) half of `final`'s data gradient (perceiver_lang_io.py:462) -- with the optional by-products of
 // vxb_conv3_dgrad_fold_f32 (operand scale of dst, column sums of dst).  Against the reference's gradients the weight rounding of a
 // data gradient moves no gate (tools/experiments/emu_precision.py --round5), and a third of the MFMAs is gone.
-extern "C" int vxb_conv3_dgrad_fold_f16x2_f32(const float* dy, int C0, int B, int S, const void* wfrag_f16x2, float* dst, const float* y,
-                                              int acc, float slope, const float* scale, float* dst_scale, float* scale_ws,
-                                              float* dst_colsum, float* colsum_ws, vxb_stream_t stream) {
+static int dgrad_fold_f16x2(const float* dy, int C0, int B, int S, const void* wfrag_f16x2, float* dst, const float* y,
+                            int acc, float slope, const float* scale, float* dst_scale, float* scale_ws,
+                            float* dst_colsum, float* colsum_ws, vxb_stream_t stream, int wino) {
     if (!dy || !wfrag_f16x2 || !dst || !scale || S < 2) return VXB_EARG;
     if ((dst_scale && !scale_ws) || (dst_colsum && !colsum_ws)) return VXB_EARG;
     const int pad = 1, S_out = S + 2 * pad;
@@ -1063,7 +1240,7 @@ extern "C" int vxb_conv3_dgrad_fold_f16x2_f32(const float* dy, int C0, int B, in
     f.amax_part = dst_scale ? reinterpret_cast<unsigned*>(scale_ws) : nullptr;
     f.colsum_part = dst_colsum ? colsum_ws : nullptr;
     int rc = hb_impl(3, dy, nullptr, C0, 0, B, S, S_out, -2 * pad, 0, wfrag_f16x2, 64, nullptr, nullptr, 0, slope, 0, 0, 0, stream, &f,
-                     wfrag_f16x2, nullptr, 0, 0, 0, scale);
+                     wfrag_f16x2, nullptr, 0, 0, 0, scale, 1, nullptr, nullptr, nullptr, wino);
     if (rc) return rc;
     const int nblk = (int)vxb_conv3_dgrad_fold_blocks(B, S, 64);
     if (dst_colsum) {
@@ -1072,6 +1249,20 @@ extern "C" int vxb_conv3_dgrad_fold_f16x2_f32(const float* dy, int C0, int B, in
     }
     if (!dst_scale) return VXB_OK;
     return vxb_absmax_finish_launch(f.amax_part, nblk, dst_scale, (hipStream_t)stream);
+}
+
+extern "C" int vxb_conv3_dgrad_fold_f16x2_f32(const float* dy, int C0, int B, int S, const void* wfrag_f16x2, float* dst, const float* y,
+                                              int acc, float slope, const float* scale, float* dst_scale, float* scale_ws,
+                                              float* dst_colsum, float* colsum_ws, vxb_stream_t stream) {
+    return dgrad_fold_f16x2(dy, C0, B, S, wfrag_f16x2, dst, y, acc, slope, scale, dst_scale, scale_ws, dst_colsum, colsum_ws, stream, 0);
+}
+// ... with the filter's depth axis by Winograd's F(2, 3) (see vxb_conv3_halo_ss3d_wg_bf16x3_f32): wfrag = ops.halo_wfrag_x2_wg, the 36
+// transformed taps rounded to fp16 AFTER the transform; S even.
+extern "C" int vxb_conv3_dgrad_fold_f16x2_wg_f32(const float* dy, int C0, int B, int S, const void* wfrag_f16x2_wg, float* dst,
+                                                 const float* y, int acc, float slope, const float* scale, float* dst_scale,
+                                                 float* scale_ws, float* dst_colsum, float* colsum_ws, vxb_stream_t stream) {
+    if (S & 1) return VXB_EARG;
+    return dgrad_fold_f16x2(dy, C0, B, S, wfrag_f16x2_wg, dst, y, acc, slope, scale, dst_scale, scale_ws, dst_colsum, colsum_ws, stream, 1);
 }
 
 // The same launch when the 64-column block is the data gradient of a 1x1x1 conv's OUTPUT y [B, S^3, 64] = lrelu(W_in x + b_in) whose

@@ -946,8 +946,12 @@ def conv3_dgrad_fold(dy, wt_dgrad, B, S, N, dsts, label=None, dy_scale=None, lea
                     if sc is None:
                         _lib.set_meta(lbl, 0.0)
                         sc = absmax_scale(dy)
-                    wf2 = halo_wfrag_x2(wt_dgrad[:, 64 * nb:64 * nb + 64].t().contiguous().half(), C0)
                     _lib.set_meta(lbl, flops / len(dsts))
+                    if DGRAD_WINOGRAD and S % 2 == 0:
+                        call('vxb_conv3_dgrad_fold_f16x2_wg_f32', dy, C0, B, S, halo_wfrag_x2_wg(wt_dgrad[:, 64 * nb:64 * nb + 64], C0), dst, yv,
+                             int(acc), LRELU_SLOPE, sc, dsc, sws, cs, cws)
+                        continue
+                    wf2 = halo_wfrag_x2(wt_dgrad[:, 64 * nb:64 * nb + 64].t().contiguous().half(), C0)
                     call('vxb_conv3_dgrad_fold_f16x2_f32', dy, C0, B, S, wf2, dst, yv, int(acc), LRELU_SLOPE, sc, dsc, sws, cs, cws)
                     continue
                 _lib.set_meta(lbl, flops / len(dsts))
@@ -1196,6 +1200,46 @@ def conv3_ss3d_ok(C0, C1, N, S):
             and os.environ.get('VOXACTB_HALO_WN', '2') == '2')
 
 
+# `final`'s forward with the depth taps by Winograd F(2, 3) (conv_halo_bf16.hip, WG: 2/3 of the MFMAs); needs whole 4-deep tiles
+FINAL_WINOGRAD = os.environ.get('VOXACTB_FINAL_WINOGRAD', '1') != '0'
+# ... and the propagating (fp16x2) half of its data gradient; even S
+DGRAD_WINOGRAD = os.environ.get('VOXACTB_DGRAD_WINOGRAD', '0') != '0'
+
+
+def halo_wfrag_wg(wt_kn, Ct):
+    """fp32 weights [(tap = kd*9 + kh*3 + kw, ci)][N = 64] -> the 36 Winograd taps (xi, kh, kw), xi over the depth taps
+    {g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2}, as bf16 hi/lo planes in the fragment order of halo_wfrag
+    [N/64][chunk of 16][36][column tile 2][plane 2][hi 2][lq 32][8].  Memoised per step like to_bf16_nk."""
+    keep = getattr(wt_kn, '_vxb_keep', False)
+    key = (wt_kn.data_ptr(), tuple(wt_kn.shape), 'wfrag_wg', PRECISION)
+    if keep:
+        hit = _WCACHE.get(key)
+        if hit is not None:
+            return hit[0]
+    N = wt_kn.shape[1]
+    g = wt_kn.view(3, 9 * Ct, N)
+    half = 0.5 * (g[0] + g[2])
+    t = torch.stack([g[0], half + 0.5 * g[1], half - 0.5 * g[1], g[2]], 0)          # [4][9 Ct][N]
+    wb = split_bf16(t.view(36 * Ct, N).t().contiguous())                             # planes [2][N][36 Ct]
+    v = wb.view(2, N // 64, 2, 32, 36, Ct // 16, 2, 8)                                # (p, nb, j, lq, tap, ch, hi, e)
+    out = v.permute(1, 5, 4, 2, 0, 6, 3, 7).contiguous()                              # (nb, ch, tap, j, p, hi, lq, e)
+    if keep:
+        _WCACHE[key] = (out, wt_kn)
+    return out
+
+
+def halo_wfrag_x2_wg(wt_kn, Ct):
+    """halo_wfrag_wg for the 'fp16x2' product mode: fp32 weights [(tap, ci)][64] -> the 36 Winograd taps, rounded to fp16 after the
+    transform, in the fragment order of halo_wfrag_x2 [1][chunk][36][column tile 2][hi][lq][8]."""
+    N = wt_kn.shape[1]
+    g = wt_kn.reshape(3, 9 * Ct, N)
+    half = 0.5 * (g[0] + g[2])
+    t = torch.stack([g[0], half + 0.5 * g[1], half - 0.5 * g[1], g[2]], 0)          # [4][9 Ct][N]
+    w16 = t.view(36 * Ct, N).t().contiguous().half()
+    v = w16.view(N // 64, 2, 32, 36, Ct // 16, 2, 8)                                # (nb, j, lq, tap, ch, hi, e)
+    return v.permute(0, 4, 3, 1, 5, 2, 6).contiguous()                              # (nb, ch, tap, j, hi, lq, e)
+
+
 def conv3_ss3d_fwd(src0, src1, wt, bias, B, S, act=ACT_LRELU, label=None):
     """conv3d(src0 | src1, 3x3x3, replicate padding, 64 columns) + ss3d_max_fwd of its output, the statistics taken in the conv's
     epilogue (vxb_conv3_halo_ss3d_bf16x3_f32): -> (out [B,S,S,S,64], (out_ss, out_max, stats, argmax)).  `out` is bit-identical to
@@ -1203,9 +1247,6 @@ def conv3_ss3d_fwd(src0, src1, wt, bias, B, S, act=ACT_LRELU, label=None):
     dev = src0.device
     C0 = src0.shape[-1]
     C1 = src1.shape[-1] if src1 is not None else 0
-    wb = to_bf16_nk(wt)
-    assert wb.dim() == 3
-    wf = halo_wfrag(wb, C0 + C1)
     out = torch.empty((B, S, S, S, 64), dtype=torch.float32, device=dev)
     ws = torch.empty(int(_lib.lib().vxb_conv3_halo_ss3d_ws(B, S)), dtype=torch.float32, device=dev)
     out_ss = torch.empty((B, 3 * 64), dtype=torch.float32, device=dev)
@@ -1213,6 +1254,13 @@ def conv3_ss3d_fwd(src0, src1, wt, bias, B, S, act=ACT_LRELU, label=None):
     stats = torch.empty((B, 64, 2), dtype=torch.float32, device=dev)
     argmax = torch.empty((B, 64), dtype=torch.int32, device=dev)
     _lib.set_meta(label or 'conv3d_bf16[k3 s1 %d->64 S%d]' % (C0 + C1, S), 2.0 * B * S ** 3 * 64 * 27 * (C0 + C1))
+    if FINAL_WINOGRAD and S % 4 == 0:
+        call('vxb_conv3_halo_ss3d_wg_bf16x3_f32', src0, src1, C0, C1, B, S, bias, out, act, LRELU_SLOPE, halo_wfrag_wg(wt, C0 + C1),
+             lin_table(S, dev), ws, out_ss, out_max, stats, argmax)
+        return out, (out_ss, out_max, stats, argmax)
+    wb = to_bf16_nk(wt)
+    assert wb.dim() == 3
+    wf = halo_wfrag(wb, C0 + C1)
     call('vxb_conv3_halo_ss3d_bf16x3_f32', src0, src1, C0, C1, B, S, wb, bias, out, act, LRELU_SLOPE, wf, lin_table(S, dev), ws,
          out_ss, out_max, stats, argmax)
     return out, (out_ss, out_max, stats, argmax)
