@@ -335,6 +335,10 @@ def main():
                 roofline['traffic'], roofline['traffic_note'] = tr
         if headline_mode == 'bf16x3':
             roofline['frac_of_x3_roof'] = tf / (PEAK_BF16_MFMA_TFLOPS / 3.0)
+        from voxactb_amd import ops as _ops
+        if dom_label.startswith('conv3d_bf16[k3 s1 128->64') and _ops.FINAL_WINOGRAD and V % 4 == 0:
+            roofline['arithmetic_note'] = ('achieved / frac count the DIRECT convolution\'s flops (2 x 27 x Cin x Cout per output voxel); the kernel '
+                                           'evaluates the depth taps by Winograd F(2, 3) and issues 2/3 of them as MFMA work (x 3 for bf16x3)')
         roofline['share_of_device_time'] = agg[dom_label]['ms'] / tot_ms
         extra = dict(roofs)
         if 'voxelize' in agg_head:
@@ -391,11 +395,11 @@ def main():
 # doubled as MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950, WRITE_SIZE as reported) -- timer label -> the kernels one call
 # of that C-ABI entry launches.  tests/test_bench_traffic_cpu.py checks that every mapped kernel is present in the newest profile.
 TRAFFIC_KERNELS = {
-    'conv3d_bf16[k3 s1 128->64 S100': (['conv3_halo_kernel<2, 1, 4, 1, 0, 2>'],
+    'conv3d_bf16[k3 s1 128->64 S100': (['conv3_halo_kernel<2, 1, 4, 1, 0, 2, 1>'],
                                        'final conv forward (+ the SpatialSoftmax3D partials of its epilogue): 12.3 GB compulsory (2 x 4.1 GB read, 4.1 GB written)'),
     'conv3d_wgrad[k3 s1 128->64 S100]': (['wgrad_halo_kernel<2, 4, 4, 2>'],
                                          'weight gradient of the final conv (single fp16 products): 12.3 GB compulsory (x 4.1 GB + the second source 4.1 GB + dY 4.1 GB)'),
-    'conv3d_bf16[k3 s1 64->128 S102': (['conv3_halo_kernel<2, 3, 4, 1, 0, 2>', 'conv3_halo_kernel<2, 2, 4, 1, 0, 1>'],
+    'conv3d_bf16[k3 s1 64->128 S102': (['conv3_halo_kernel<2, 3, 4, 1, 0, 2, 1>', 'conv3_halo_kernel<2, 2, 4, 1, 0, 1, 0>'],
                                        'the two launches of the data gradient + padding adjoint of the final conv: d(u0) fp16x2, d(d0) fp16'),
 }
 

@@ -106,8 +106,9 @@ def test_winograd_data_gradient_against_the_direct_kernel(S, B):
     mx = float(d_g.abs().max())
     e = float((w_g - d_g).abs().max()) / mx
     print('S=%d: winograd vs direct data gradient %.2e of the largest element' % (S, e))
-    assert e < 2e-5
-    assert float((w_cs - d_cs).abs().max()) <= 2e-5 * float(d_cs.abs().max()) + 1e-4
+    # (both round their weights to fp16, 2^-12 per product -- the direct one the taps, this one the transformed taps: they differ by that)
+    assert e < 1e-3
+    assert float((w_cs - d_cs).abs().max()) <= 1e-3 * float(d_cs.abs().max()) + 1e-3
     assert torch.equal(w_sc, d_sc) or float((w_sc[0] / d_sc[0])) in (0.5, 1.0, 2.0)       # the same power of two unless the maximum sits at a binade edge
     if S <= 20:
         # float64: dX_padded = conv_transpose3d(dy, W) on the (S + 2)^3 domain, folded back by the adjoint of the replicate padding,
@@ -124,4 +125,4 @@ def test_winograd_data_gradient_against_the_direct_kernel(S, B):
         ew = float((w_g.cpu().double() - ref).abs().max()) / float(ref.abs().max())
         ed = float((d_g.cpu().double() - ref).abs().max()) / float(ref.abs().max())
         print('      vs float64: winograd %.2e  direct %.2e' % (ew, ed))
-        assert ew < 1e-3            # (the fp16 rounding of the WEIGHTS, 2^-12 per product, bounds both)
+        assert ew < 1e-3 and ew < 1.5 * ed + 1e-5           # (the fp16 rounding of the WEIGHTS, 2^-12 per product, bounds both)

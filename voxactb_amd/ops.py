@@ -1203,7 +1203,7 @@ def conv3_ss3d_ok(C0, C1, N, S):
 # `final`'s forward with the depth taps by Winograd F(2, 3) (conv_halo_bf16.hip, WG: 2/3 of the MFMAs); needs whole 4-deep tiles
 FINAL_WINOGRAD = os.environ.get('VOXACTB_FINAL_WINOGRAD', '1') != '0'
 # ... and the propagating (fp16x2) half of its data gradient; even S
-DGRAD_WINOGRAD = os.environ.get('VOXACTB_DGRAD_WINOGRAD', '0') != '0'
+DGRAD_WINOGRAD = os.environ.get('VOXACTB_DGRAD_WINOGRAD', '1') != '0'
 
 
 def halo_wfrag_wg(wt_kn, Ct):
