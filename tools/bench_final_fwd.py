@@ -23,6 +23,9 @@ def timeit(fn, n=5):
 
 def main():
     B, S, dev = int(sys.argv[1]) if len(sys.argv) > 1 else 8, 100, 'cuda:0'
+    if os.environ.get('HALO_DBG'):      # timing experiments (results are wrong): vxb_debug_set_halo_experiment bits
+        from voxactb_amd import _lib
+        _lib.lib().vxb_debug_set_halo_experiment(int(os.environ['HALO_DBG']))
     d0 = torch.randn(B, S, S, S, 64, device=dev)
     u0 = torch.randn(B, S, S, S, 64, device=dev)
     wt = (torch.randn(27 * 128, 64, device=dev) * 0.05).contiguous()

@@ -393,7 +393,10 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     // fragment order: 1 KB per (tap, column tile, k half / plane), lane-contiguous -> fully coalesced, L1-shared by the
     // waves of the CU), two taps ahead in three rotating register sets.  No weight traffic through LDS and NO barrier
     // inside the 27-tap loop.
-    constexpr int BD = (WD && !TL && WN == 2) ? 4 : 2;      // B-fragment prefetch distance in taps
+#ifndef WG_BD
+#define WG_BD 4
+#endif
+    constexpr int BD = WG ? WG_BD : (WD && !TL && WN == 2) ? 4 : 2;      // B-fragment prefetch distance in taps
     bf16x8 bq0[NT][2], bq1[NT][2], bq2[NT][2];
     bf16x8 bqr[BD + 1][NT][2];
     const int nchunk = Ct / CPC;
@@ -493,7 +496,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
 #pragma unroll
                 for (int pd = 0; pd < HDp; ++pd) {
                     hv[i * HDp + pd] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (wg_hw[i] >= 0 && wg_d[pd] >= 0)
+                    if (wg_hw[i] >= 0 && wg_d[pd] >= 0 && !((g.dbg & 0x20) && ch_ > 0))
                         hv[i * HDp + pd] = *reinterpret_cast<const float4*>(src + (vbase + wg_d[pd] + wg_hw[i]) * Cs + c0 + (((tid + NTH * i) % F4P) * 4));
                 }
             return;
@@ -557,7 +560,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
         if constexpr (WG) {
 #pragma unroll
             for (int i = 0; i < NCOL; ++i) {
-                if (wg_hw[i] == -1) continue;
+                if (wg_hw[i] == -1 || ((g.dbg & 0x10) && ch > 0)) continue;
                 float4* x = &hv[i * HDp];
                 if (PM >= 2) {
 #pragma unroll

@@ -1253,14 +1253,17 @@ def conv3_ss3d_fwd(src0, src1, wt, bias, B, S, act=ACT_LRELU, label=None):
     out_max = torch.empty((B, 64), dtype=torch.float32, device=dev)
     stats = torch.empty((B, 64, 2), dtype=torch.float32, device=dev)
     argmax = torch.empty((B, 64), dtype=torch.int32, device=dev)
-    _lib.set_meta(label or 'conv3d_bf16[k3 s1 %d->64 S%d]' % (C0 + C1, S), 2.0 * B * S ** 3 * 64 * 27 * (C0 + C1))
+    lbl, flops = label or 'conv3d_bf16[k3 s1 %d->64 S%d]' % (C0 + C1, S), 2.0 * B * S ** 3 * 64 * 27 * (C0 + C1)
     if FINAL_WINOGRAD and S % 4 == 0:
-        call('vxb_conv3_halo_ss3d_wg_bf16x3_f32', src0, src1, C0, C1, B, S, bias, out, act, LRELU_SLOPE, halo_wfrag_wg(wt, C0 + C1),
-             lin_table(S, dev), ws, out_ss, out_max, stats, argmax)
+        wfw, lin = halo_wfrag_wg(wt, C0 + C1), lin_table(S, dev)        # (before the label: their own launches must not take it)
+        _lib.set_meta(lbl, flops)
+        call('vxb_conv3_halo_ss3d_wg_bf16x3_f32', src0, src1, C0, C1, B, S, bias, out, act, LRELU_SLOPE, wfw, lin, ws, out_ss, out_max,
+             stats, argmax)
         return out, (out_ss, out_max, stats, argmax)
     wb = to_bf16_nk(wt)
     assert wb.dim() == 3
     wf = halo_wfrag(wb, C0 + C1)
+    _lib.set_meta(lbl, flops)
     call('vxb_conv3_halo_ss3d_bf16x3_f32', src0, src1, C0, C1, B, S, wb, bias, out, act, LRELU_SLOPE, wf, lin_table(S, dev), ws,
          out_ss, out_max, stats, argmax)
     return out, (out_ss, out_max, stats, argmax)
