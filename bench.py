@@ -336,7 +336,7 @@ def main():
         if headline_mode == 'bf16x3':
             roofline['frac_of_x3_roof'] = tf / (PEAK_BF16_MFMA_TFLOPS / 3.0)
         from voxactb_amd import ops as _ops
-        if dom_label.startswith('conv3d_bf16[k3 s1 128->64') and _ops.FINAL_WINOGRAD and V % 4 == 0:
+        if dom_label.startswith('conv3d_bf16[k3 s1 128->64') and _ops.FINAL_WINOGRAD and V % 2 == 0:
             roofline['arithmetic_note'] = ('achieved / frac count the DIRECT convolution\'s flops (2 x 27 x Cin x Cout per output voxel); the kernel '
                                            'evaluates the depth taps by Winograd F(2, 3) and issues 2/3 of them as MFMA work (x 3 for bf16x3)')
         roofline['share_of_device_time'] = agg[dom_label]['ms'] / tot_ms

@@ -288,7 +288,7 @@ int vxb_conv3_halo_ss3d_bf16x3_f32(const float* src0, const float* src1, int C0,
 /* The same launch with the filter's depth axis evaluated by Winograd's F(2, 3): per (kh, kw) four products for two output depths
  * instead of six -- two thirds of the matrix work (helpers/network_utils.py:128-170 `final`, the step's largest kernel).  wfrag_wg: the
  * 36 transformed taps (xi, kh, kw), xi = {g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2} over the depth taps, as bf16 hi/lo planes in
- * fragment order [1][chunk][36][column tile 2][plane 2][lane 64][8] (ops.halo_wfrag_wg).  S % 4 == 0.  Agrees with the direct entry to
+ * fragment order [1][chunk][36][column tile 2][plane 2][lane 64][8] (ops.halo_wfrag_wg).  S even.  Agrees with the direct entry to
  * fp32 rounding of the transforms (~1e-6 relative), not bit for bit. */
 int vxb_conv3_halo_ss3d_wg_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S, const float* bias,
                                       float* out, int act, float slope, const void* wfrag_wg, const float* lin,
@@ -312,6 +312,10 @@ size_t vxb_conv3_dgrad_fold_blocks(int B, int S, int N);
  * device, vxb_absmax_scale_f32; weights in fragment order of the fp16 [64][27 C0] matrix): the d(d0) half of `final`'s data
  * gradient, which only feeds the weight gradient of the 1x1x1 input conv (a leaf of the backward pass). */
 int vxb_conv3_dgrad_fold_f16_f32(const float* dy, int C0, int B, int S, const void* wfrag_f16, float* dst, const float* y,
+                                 int acc, float slope, const float* scale, vxb_stream_t stream);
+/* ... with the filter's depth axis by Winograd's F(2, 3) (see vxb_conv3_dgrad_fold_f16x2_wg_f32): wfrag_f16_wg = ops.halo_wfrag_x2_wg; S even,
+ * scale required. */
+int vxb_conv3_dgrad_fold_f16_wg_f32(const float* dy, int C0, int B, int S, const void* wfrag_f16_wg, float* dst, const float* y,
                                  int acc, float slope, const float* scale, vxb_stream_t stream);
 /* ... on TWO fp16 products per term for a block that propagates (the d(u0) half): dy * scale[0] as an fp16 hi + lo pair, the weights
  * as one fp16 value (wfrag_f16x2: single-plane fragment order of the fp16 [64][27 C0] matrix); optional by-products as in

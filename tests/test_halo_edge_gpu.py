@@ -33,7 +33,7 @@ def test_forward_part_tiles(S, B):
         full, part = _both(lambda: ops.conv3d(d0, wt, C, B, S, S, 3, -1, bias=bias, act=ops.ACT_LRELU, src1=u0))
         assert torch.equal(full, part)
         if ops.conv3_ss3d_ok(C, C, C, S):
-            for wino in (False, True):              # the direct kernel, then the Winograd-along-depth one (S % 4 == 0: half tiles only)
+            for wino in (False, True):              # the direct kernel, then the Winograd-along-depth one (even S; half tiles and two-deep last depth tiles)
                 old = ops.FINAL_WINOGRAD
                 ops.FINAL_WINOGRAD = wino
                 try:

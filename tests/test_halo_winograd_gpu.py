@@ -24,7 +24,7 @@ def _run(d0, u0, W, bias, B, S, wino):
         ops.FINAL_WINOGRAD = old
 
 
-@pytest.mark.parametrize('S,B', [(16, 2), (20, 2), (28, 1), (36, 1)])       # 20, 28, 36: half tiles along h / w
+@pytest.mark.parametrize('S,B', [(16, 2), (18, 1), (20, 2), (22, 1), (28, 1), (36, 1), (50, 1)])       # 20, 28, 36: half tiles along h / w; 18, 22, 50: a two-deep last depth tile, 6- and 2-wide edges
 def test_winograd_forward_against_float64_and_the_direct_kernel(S, B):
     C = 64
     a, c = rnd(B, C, S, S, S, seed=1), rnd(B, C, S, S, S, seed=2)
@@ -69,7 +69,7 @@ def test_winograd_at_the_headline_grid():
 
 
 def test_unsupported_depths_fall_back_to_the_direct_kernel():
-    S, B, C = 22, 1, 64                     # S % 4 != 0: a depth tile of two
+    S, B, C = 21, 1, 64                     # odd S: a depth pair would straddle the grid's end
     d0 = cl(rnd(B, C, S, S, S, seed=1)).to(DEV)
     u0 = cl(rnd(B, C, S, S, S, seed=2)).to(DEV)
     W = rnd(C, 2 * C, 3, 3, 3, seed=3, scale=0.03).to(DEV)
@@ -87,22 +87,26 @@ def test_winograd_data_gradient_against_the_direct_kernel(S, B):
     dy = cl(rnd(B, C, S, S, S, seed=3)).to(DEV)
     W = rnd(C, N, 3, 3, 3, seed=1, scale=0.1).to(DEV)
     y1 = cl(rnd(B, 64, S, S, S, seed=5)).to(DEV)
-    state = (ops.PRECISION, ops.WGRAD_PRECISION, ops.DGRAD_PRECISION, ops.DGRAD_WINOGRAD)
+    state = (ops.PRECISION, ops.WGRAD_PRECISION, ops.DGRAD_PRECISION, ops.DGRAD_WINOGRAD, ops.LEAF_WINOGRAD)
     try:
         ops.PRECISION, ops.WGRAD_PRECISION, ops.DGRAD_PRECISION = 'bf16x3', 'fp16', 'fp16x2'
         wd = ops.conv_weight_dgrad(W)
 
         def run(wino):
-            ops.DGRAD_WINOGRAD = wino
+            ops.DGRAD_WINOGRAD = ops.LEAF_WINOGRAD = wino
             g0, g1 = torch.ones(B, S, S, S, 64, device=DEV), torch.empty(B, S, S, S, 64, device=DEV)
             cs = torch.zeros(64, device=DEV)
             sc = ops.conv3_dgrad_fold(dy, wd, B, S, N, [(g0, True, None), (g1, False, y1)], leaf_blocks=(0,), scale_blocks=(1,),
                                       colsum_into={1: cs})
-            return g1, cs, sc[1]
-        d_g, d_cs, d_sc = run(False)
-        w_g, w_cs, w_sc = run(True)
+            return g1, cs, sc[1], g0
+        d_g, d_cs, d_sc, d_leaf = run(False)
+        w_g, w_cs, w_sc, w_leaf = run(True)
     finally:
-        ops.PRECISION, ops.WGRAD_PRECISION, ops.DGRAD_PRECISION, ops.DGRAD_WINOGRAD = state
+        ops.PRECISION, ops.WGRAD_PRECISION, ops.DGRAD_PRECISION, ops.DGRAD_WINOGRAD, ops.LEAF_WINOGRAD = state
+    # the leaf block (channels 0..63, single fp16 products, accumulated onto ones): both round dy AND the weights to 11 bits
+    e_leaf = float((w_leaf - d_leaf).abs().max()) / float((d_leaf - 1.0).abs().max())
+    print('S=%d: leaf block, winograd vs direct %.2e of the largest element' % (S, e_leaf))
+    assert e_leaf < 2e-3
     mx = float(d_g.abs().max())
     e = float((w_g - d_g).abs().max()) / mx
     print('S=%d: winograd vs direct data gradient %.2e of the largest element' % (S, e))

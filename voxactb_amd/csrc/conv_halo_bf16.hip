@@ -144,14 +144,15 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     // instead of the 6 raw ones), the weight transform on the host (ops.halo_wfrag_wg: 36 "taps" (xi, kh, kw)), the output transform on
     // the accumulators (a wave's M tiles are (depth, w half), so y0 / y1 are its own registers).  36 x 2 instead of 27 x 4 MFMA groups
     // per wave and chunk: two thirds of the matrix work, which is what bounds the direct kernel (73 % of its time).
-    static_assert(!WG || (WD && !TL && WN == 2 && NW == 4 && NTG == 2 && (HALF == 0 || HALF == 1) && (PM == 1 || PM == 3)),
-                  "WG: the final conv's forward (bf16x3) and its propagating data gradient (fp16x2)");
+    static_assert(!WG || (WD && !TL && WN == 2 && NW == 4 && NTG == 2 && (HALF == 0 || HALF == 1) && PM >= 1),
+                  "WG: the final conv's forward (bf16x3) and its data gradients (fp16x2; fp16 with 16-channel chunks)");
     constexpr int NTAP = WG ? 36 : 27;
     constexpr int PLANE = HHp * HWp * SP;           // u16 per depth plane of the LDS image
     constexpr int X3 = PM == 1;                     // three products: input hi | lo, weight planes hi / lo
     constexpr int X2 = PM == 3;                     // two products: input hi | lo, one weight plane
     constexpr int HL = X3 || X2;                    // a chunk is 16 channels as hi | lo halves
-    constexpr int NF = X2 ? 1 : 2;                  // weight fragments per (tap, column tile): k halves (PM 0, 2) / planes (1) / one (3)
+    constexpr int W1 = WG && PM == 2;               // WG with single fp16 products: 16-channel chunks too (one plane, one MFMA per tap and tile)
+    constexpr int NF = (X2 || W1) ? 1 : 2;          // weight fragments per (tap, column tile): k halves (PM 0, 2) / planes (1) / one (3; W1)
     constexpr int ST = HALF == 1 ? 2 : 1;           // M-tile stride of the tap loops
     constexpr int MLIM = HALF == 2 ? 3 : (HALF == 3 ? 2 : 8 / (NW / WN));     // ... and their end: HALF = 2 runs three of a wave's four M tiles, 3 two
     constexpr int NTH = NW * 64, MTW = 8 / (NW / WN), NT = NTG / WN;
@@ -159,7 +160,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     u16* halo = smem;                               // [HALO_SLOTS][SP]
     u16* wsm = smem + (WG ? 8 : HDp) * PLANE;       // [2][N][LDW]   (WG: 8 planes, and no weight tiles -- WD)
     constexpr int N = NTG * 32;
-    constexpr int CPC = HL ? 16 : 32;               // channels per chunk
+    constexpr int CPC = (HL || W1) ? 16 : 32;       // channels per chunk
     constexpr int F4P = CPC / 4;                    // float4 per voxel per chunk
     constexpr int NLD = (NPOS * F4P + NTH - 1) / NTH;   // halo float4 loads per thread per chunk (10 / 19)
     constexpr int W_V8 = (N * 4 + NTH - 1) / NTH;              // 16-byte weight loads per thread per tap (1 / 2)
@@ -578,11 +579,13 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
                     for (int xi = 0; xi < 4; ++xi) {
                         uint2 pk, q;
                         pk.x = hb_pack2<PM>(t[xi].x, t[xi].y); pk.y = hb_pack2<PM>(t[xi].z, t[xi].w);
-                        q.x = hb_pack2<PM>(t[xi].x - hb_unpack_lo<PM>(pk.x), t[xi].y - hb_unpack_hi<PM>(pk.x));
-                        q.y = hb_pack2<PM>(t[xi].z - hb_unpack_lo<PM>(pk.y), t[xi].w - hb_unpack_hi<PM>(pk.y));
                         u16* dstp = &halo[wg_soff[i] + (4 * pr + xi) * PLANE];
                         *reinterpret_cast<uint2*>(dstp) = pk;
-                        *reinterpret_cast<uint2*>(dstp + 16) = q;
+                        if (HL) {
+                            q.x = hb_pack2<PM>(t[xi].x - hb_unpack_lo<PM>(pk.x), t[xi].y - hb_unpack_hi<PM>(pk.x));
+                            q.y = hb_pack2<PM>(t[xi].z - hb_unpack_lo<PM>(pk.y), t[xi].w - hb_unpack_hi<PM>(pk.y));
+                            *reinterpret_cast<uint2*>(dstp + 16) = q;
+                        }
                     }
                 }
             }
@@ -632,12 +635,14 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
         const int toff_ = (tp_ / 9) * PLANE + (((tp_ / 3) % 3) * HWp + tp_ % 3) * SP;                                \
         _Pragma("unroll") for (int wh = 0; wh < WLIM; ++wh) {                                                        \
             AF[wh][0] = *reinterpret_cast<const bf16x8*>(&halo[wabase[wh] + toff_]);                                 \
-            AF[wh][1] = *reinterpret_cast<const bf16x8*>(&halo[wabase[wh] + toff_ + 16]);                            \
+            if (HL) AF[wh][1] = *reinterpret_cast<const bf16x8*>(&halo[wabase[wh] + toff_ + 16]);                    \
         }                                                                                                            \
     }
 #define WG_MFMA(AC, BC, XI)                                                                                          \
     {                                                                                                                \
-        _Pragma("unroll") for (int wh = 0; wh < WLIM; ++wh) wacc[wh][XI] = hb_mfma<PM>(AC[wh][1], BC[0][0], wacc[wh][XI]); \
+        if (HL) {                                                                                                    \
+            _Pragma("unroll") for (int wh = 0; wh < WLIM; ++wh) wacc[wh][XI] = hb_mfma<PM>(AC[wh][1], BC[0][0], wacc[wh][XI]); \
+        }                                                                                                            \
         if (X3) {                                                                                                    \
             _Pragma("unroll") for (int wh = 0; wh < WLIM; ++wh) wacc[wh][XI] = hb_mfma<PM>(AC[wh][0], BC[0][1], wacc[wh][XI]); \
         }                                                                                                            \
@@ -1029,7 +1034,7 @@ int hb_impl(int x3 /* product mode: 0 bf16, 1 bf16x3, 2 fp16 (WD kernels only, `
             const int32_t* taptab = nullptr, int ncls = 0, int nphase = 0, int tap_total = 0, const float* scale = nullptr,
             int ksplit = 1, const int32_t* kparts = nullptr, float* ss_part = nullptr, const float* ss_lin = nullptr, int wino = 0) {
     // wino: Winograd F(2, 3) along depth (see conv3_halo_body): bf16x3, fragment-order weights of the 36 transformed taps, whole depth tiles
-    if (wino && ((x3 != 1 && x3 != 3) || !wfrag || taptab || s2d_s > 0 || d2s_s > 0 || N != 64 || (S_out & 1) || (g_halo_wn && g_halo_wn != 2)))
+    if (wino && (x3 < 1 || x3 > 3 || !wfrag || taptab || s2d_s > 0 || d2s_s > 0 || N != 64 || (S_out & 1) || (g_halo_wn && g_halo_wn != 2)))
         return VXB_EARG;
     if (x3 == 2 && (!wfrag || taptab)) return VXB_EARG;
     if (x3 == 3 && (!wfrag || !scale || src1 || replicate || d2s_s > 0)) return VXB_EARG;     // data gradients only
@@ -1066,7 +1071,8 @@ int hb_impl(int x3 /* product mode: 0 bf16, 1 bf16x3, 2 fp16 (WD kernels only, `
     hipStream_t st = (hipStream_t)stream;
     // 64 output channels per workgroup (162-225 VGPRs -> two workgroups per CU); N = 128 runs two column blocks that each
     // stage the halo -- cheaper than the register spills of a 128-wide accumulator tile.
-    if (wino) return x3 == 3 ? hb_launch<2, 3, 4, 1, 0, 2, 1>(g, nblk, st) : hb_launch<2, 1, 4, 1, 0, 2, 1>(g, nblk, st);
+    if (wino) return x3 == 3 ? hb_launch<2, 3, 4, 1, 0, 2, 1>(g, nblk, st) : x3 == 2 ? hb_launch<2, 2, 4, 1, 0, 2, 1>(g, nblk, st)
+                                                                               : hb_launch<2, 1, 4, 1, 0, 2, 1>(g, nblk, st);
     if (x3 == 2) return hb_launch<2, 2, 4, 1>(g, nblk, st);
     if (x3 == 3) return g.taptab ? hb_launch<2, 3, 4, 1, 1, 2>(g, nblk, st) : hb_launch<2, 3, 4, 1, 0, 2>(g, nblk, st);
     const int wn = g_halo_wn ? g_halo_wn : (x3 ? 2 : 1);
@@ -1131,13 +1137,13 @@ extern "C" int vxb_conv3_halo_ss3d_bf16x3_f32(const float* src0, const float* sr
 
 // vxb_conv3_halo_ss3d_bf16x3_f32 with the depth axis of the 3x3x3 filter evaluated by Winograd's F(2, 3) (four products per two output
 // depths instead of six: 2/3 of the matrix work; conv3_halo_body, WG): wfrag_wg = ops.halo_wfrag_wg of the weights -- the 36 transformed
-// taps (xi, kh, kw) in fragment order.  S % 4 == 0.  The transforms are exact up to fp32 rounding of sums of two inputs / three
+// taps (xi, kh, kw) in fragment order.  S even (a two-deep last depth tile idles one wave row).  The transforms are exact up to fp32 rounding of sums of two inputs / three
 // weights; results agree with the direct kernel to ~1e-6 relative (tests/test_halo_winograd_gpu.py), not bit for bit.
 extern "C" int vxb_conv3_halo_ss3d_wg_bf16x3_f32(const float* src0, const float* src1, int C0, int C1, int B, int S, const float* bias,
                                                  float* out, int act, float slope, const void* wfrag_wg, const float* lin,
                                                  float* part_ws, float* out_ss, float* out_max, float* stats, int32_t* argmax,
                                                  vxb_stream_t stream) {
-    if (!wfrag_wg || !lin || !part_ws || !out_ss || !out_max || !stats || !argmax || (S & 3)) return VXB_EARG;
+    if (!wfrag_wg || !lin || !part_ws || !out_ss || !out_max || !stats || !argmax || (S & 1)) return VXB_EARG;
     const int rc = hb_impl(1, src0, src1, C0, C1, B, S, S, -1, 1, wfrag_wg, 64, bias, out, act, slope, 0, 0, 0, stream, nullptr, wfrag_wg,
                            nullptr, 0, 0, 0, nullptr, 1, nullptr, part_ws, lin, 1);
     if (rc) return rc;
@@ -1210,8 +1216,8 @@ extern "C" size_t vxb_conv3_dgrad_fold_blocks(int B, int S, int N) {
 // (perceiver_lang_io.py:462): that tensor only feeds the weight gradient of the 1x1x1 input conv -- a leaf: against the reference's
 // gradients it is indistinguishable from the bf16x3 evaluation (tools/experiments/emu_precision.py --round4), while the d(u0)
 // half, which propagates through the whole decoder and trunk, stays bf16x3.
-extern "C" int vxb_conv3_dgrad_fold_f16_f32(const float* dy, int C0, int B, int S, const void* wfrag_f16, float* dst, const float* y,
-                                            int acc, float slope, const float* scale, vxb_stream_t stream) {
+static int dgrad_fold_f16(const float* dy, int C0, int B, int S, const void* wfrag_f16, float* dst, const float* y,
+                          int acc, float slope, const float* scale, vxb_stream_t stream, int wino) {
     if (!dy || !wfrag_f16 || !dst || S < 2) return VXB_EARG;
     const int pad = 1, S_out = S + 2 * pad;
     if ((S_out - 1 - pad) / TD != (S_out - 1) / TD || (S_out - 1 - pad) / TH != (S_out - 1) / TH || (S_out - 1 - pad) / TW != (S_out - 1) / TW)
@@ -1221,7 +1227,19 @@ extern "C" int vxb_conv3_dgrad_fold_f16_f32(const float* dy, int C0, int B, int 
     f.fold_acc[0] = acc; f.fold_acc[1] = 0;
     f.amax_part = nullptr; f.colsum_part = nullptr;
     return hb_impl(2, dy, nullptr, C0, 0, B, S, S_out, -2 * pad, 0, wfrag_f16, 64, nullptr, nullptr, 0, slope, 0, 0, 0, stream, &f,
-                   wfrag_f16, nullptr, 0, 0, 0, scale);
+                   wfrag_f16, nullptr, 0, 0, 0, scale, 1, nullptr, nullptr, nullptr, wino);
+}
+
+extern "C" int vxb_conv3_dgrad_fold_f16_f32(const float* dy, int C0, int B, int S, const void* wfrag_f16, float* dst, const float* y,
+                                            int acc, float slope, const float* scale, vxb_stream_t stream) {
+    return dgrad_fold_f16(dy, C0, B, S, wfrag_f16, dst, y, acc, slope, scale, stream, 0);
+}
+// ... with the depth axis by Winograd's F(2, 3): wfrag = ops.halo_wfrag_x2_wg (the 36 transformed taps in fp16, 16-channel chunks);
+// S even.  See vxb_conv3_dgrad_fold_f16x2_wg_f32.
+extern "C" int vxb_conv3_dgrad_fold_f16_wg_f32(const float* dy, int C0, int B, int S, const void* wfrag_f16_wg, float* dst, const float* y,
+                                               int acc, float slope, const float* scale, vxb_stream_t stream) {
+    if ((S & 1) || !scale) return VXB_EARG;
+    return dgrad_fold_f16(dy, C0, B, S, wfrag_f16_wg, dst, y, acc, slope, scale, stream, 1);
 }
 
 // One 64-column block of the data gradient + padding adjoint on TWO fp16 products per term ("fp16x2": dy * scale[0] as an fp16

@@ -924,6 +924,11 @@ def conv3_dgrad_fold(dy, wt_dgrad, B, S, N, dsts, label=None, dy_scale=None, lea
                 if sc is None:
                     _lib.set_meta(lbl, 0.0)
                     sc = absmax_scale(dy)
+                if LEAF_WINOGRAD and S % 2 == 0 and not (wgin and nb in wgin):
+                    _lib.set_meta(lbl, flops / len(dsts))
+                    call('vxb_conv3_dgrad_fold_f16_wg_f32', dy, C0, B, S, halo_wfrag_x2_wg(wt_dgrad[:, 64 * nb:64 * nb + 64], C0), dst, yv,
+                         int(acc), LRELU_SLOPE, sc)
+                    continue
                 w16 = wt_dgrad[:, 64 * nb:64 * nb + 64].t().contiguous().half()           # [64][27 C0]
                 wf16 = halo_wfrag(w16, C0)
                 _lib.set_meta(lbl, flops / len(dsts))
@@ -1200,10 +1205,12 @@ def conv3_ss3d_ok(C0, C1, N, S):
             and os.environ.get('VOXACTB_HALO_WN', '2') == '2')
 
 
-# `final`'s forward with the depth taps by Winograd F(2, 3) (conv_halo_bf16.hip, WG: 2/3 of the MFMAs); needs whole 4-deep tiles
+# `final`'s forward with the depth taps by Winograd F(2, 3) (conv_halo_bf16.hip, WG: 2/3 of the MFMAs); needs whole depth pairs (even S)
 FINAL_WINOGRAD = os.environ.get('VOXACTB_FINAL_WINOGRAD', '1') != '0'
 # ... and the propagating (fp16x2) half of its data gradient; even S
 DGRAD_WINOGRAD = os.environ.get('VOXACTB_DGRAD_WINOGRAD', '1') != '0'
+# ... and the leaf (single fp16 product) half, in 16-channel chunks
+LEAF_WINOGRAD = os.environ.get('VOXACTB_LEAF_WINOGRAD', '0') != '0'
 
 
 def halo_wfrag_wg(wt_kn, Ct):
@@ -1254,7 +1261,7 @@ def conv3_ss3d_fwd(src0, src1, wt, bias, B, S, act=ACT_LRELU, label=None):
     stats = torch.empty((B, 64, 2), dtype=torch.float32, device=dev)
     argmax = torch.empty((B, 64), dtype=torch.int32, device=dev)
     lbl, flops = label or 'conv3d_bf16[k3 s1 %d->64 S%d]' % (C0 + C1, S), 2.0 * B * S ** 3 * 64 * 27 * (C0 + C1)
-    if FINAL_WINOGRAD and S % 4 == 0:
+    if FINAL_WINOGRAD and S % 2 == 0:
         wfw, lin = halo_wfrag_wg(wt, C0 + C1), lin_table(S, dev)        # (before the label: their own launches must not take it)
         _lib.set_meta(lbl, flops)
         call('vxb_conv3_halo_ss3d_wg_bf16x3_f32', src0, src1, C0, C1, B, S, bias, out, act, LRELU_SLOPE, wfw, lin, ws, out_ss, out_max,
