@@ -79,7 +79,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend, rank=rank, world_size=world)      # backend "nccl" == RCCL on ROCm
 
-    from voxactb_amd import _lib, synthetic
+    from voxactb_amd import _lib, ops, synthetic
     from voxactb_amd.agents.peract_bc import launch_utils as lu
 
     V, B, HW = a.voxel_size, a.batch, a.image
@@ -182,6 +182,9 @@ def main():
         for e_ in engines:
             e_.precision, _, e_.bwd_precision = base_mode.partition('/')  # 'bf16x3/bf16' = forward bf16x3, backward products bf16
             e_.attn_kernel = 'auto' if attn == 'attn_f16' else headline_attn
+        wino = (ops.FINAL_WINOGRAD, ops.DGRAD_WINOGRAD)
+        if attn == 'direct_final':                                       # same-run A/B: `final` forward + d(u0) on the direct LDS-halo kernels
+            ops.FINAL_WINOGRAD = ops.DGRAD_WINOGRAD = False
         if stream:
             streams[0] = open_streams()
         for _ in range(warmup):
@@ -206,6 +209,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         for e_ in engines:
             e_.precision, e_.bwd_precision, e_.attn_kernel = headline_mode, headline_bwd, headline_attn
+        ops.FINAL_WINOGRAD, ops.DGRAD_WINOGRAD = wino
         if stream:
             for st_ in streams[0]:
                 st_.close()
@@ -244,10 +248,12 @@ def main():
     # secondary measurements of the same workload in the other precisions (never the headline `value`)
     others = {}
     if not a.no_other_modes:
-        for mode in ('fp32', 'bf16x3', 'bf16x3+attn_f16', 'bf16x3/bf16', 'bf16'):
+        for mode in ('fp32', 'bf16x3', 'bf16x3+attn_f16', 'bf16x3+direct_final', 'bf16x3/bf16', 'bf16'):
             if mode == headline_mode and not headline_bwd:
                 continue
             if mode == 'bf16x3+attn_f16' and (headline_mode != 'bf16x3' or headline_attn != 'r3'):
+                continue
+            if mode == 'bf16x3+direct_final' and (headline_mode != 'bf16x3' or not (ops.FINAL_WINOGRAD or ops.DGRAD_WINOGRAD) or V % 2):
                 continue
             dt2, _, agg2 = measure(mode, a.steps, 1)
             others[mode] = {'value': world * a.steps / dt2, 'unit': 'steps/s', 'ms_per_step': dt2 / a.steps * 1e3,
@@ -544,6 +550,7 @@ MODE_DTYPE = {         # (short: the driver's record truncates long strings; the
     'bf16': 'bf16 MFMA, f32 accumulate/storage',
     'bf16x3/bf16': 'fwd bf16x3, bwd products plain bf16',
     'bf16x3+attn_f16': 'as bf16x3, attention fwd on 1x fp16 products (VOXACTB_ATTN_KERNEL=auto)',
+    'bf16x3+direct_final': 'as bf16x3, final conv fwd + d(u0) on the direct kernels (no Winograd depth axis)',
 }
 MODE_NOTE = {
     'fp32': 'exact fp32 matrix cores: the reference-parity mode of the first measurements (tests/test_encoder_gpu.py, 1e-4)',
@@ -555,6 +562,9 @@ MODE_NOTE = {
     'bf16': 'throughput mode, NOT held to the 1e-4 Q-value bound (tests/test_bf16_mode_gpu.py: ~4e-3 on q_trans)',
     'bf16x3/bf16': 'mixed mode (VOXACTB_BWD_PRECISION=bf16): the forward keeps the 1e-4 Q-value bound, parameter gradients are '
                    'within 0.5 % of the reference (norms within 4e-3) instead of 0.2 % -- not the default',
+    'bf16x3+direct_final': 'same-run A/B of round 5\'s Winograd depth axis (DESIGN.md 4b / 5r5.8): the default precision with VOXACTB_FINAL_WINOGRAD=0 '
+                           'VOXACTB_DGRAD_WINOGRAD=0 -- the `final` conv\'s forward and its propagating data gradient on round 4\'s direct LDS-halo kernels '
+                           '(27 x 4 instead of 36 x 2 MFMA groups per wave and chunk)',
     'bf16x3+attn_f16': 'named mode, NOT the default (VOXACTB_ATTN_KERNEL=auto): the default precision with the attention FORWARD (QK^T, PV) on the '
                        'pipelined kernel with ONE fp16 product per term (csrc/flash2_fwd.hip) from 2^22 score elements on, instead of round 3\'s bf16x3 '
                        'triple.  Measured (DESIGN.md 5r5; profiles/r05_attn_f16_forward_gate.log): Q-values within 1e-4 of the reference on every fixture '
