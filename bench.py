@@ -398,15 +398,20 @@ def main():
 
 # HBM bytes per launch of the dominant kernel: read from the NEWEST committed PMC passes of this command at configs[1]
 # (profiles/rNN_vK_pmc_{FETCH,WRITE}_SIZE_summary.txt: separate rocprofv3 --pmc runs, tools/profile_round.sh; KiB per dispatch; FETCH_SIZE
-# doubled as MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950, WRITE_SIZE as reported) -- timer label -> the kernels one call
+# times the factor of TRAFFIC_KERNELS below -- MI355X_MICROARCH.md's x 2 for wide streaming reads on gfx950 unless calibrated otherwise --,
+# WRITE_SIZE as reported) -- timer label -> the kernels one call
 # of that C-ABI entry launches.  tests/test_bench_traffic_cpu.py checks that every mapped kernel is present in the newest profile.
 TRAFFIC_KERNELS = {
+    # label prefix -> (kernels of one call, what the compulsory traffic is, FETCH_SIZE factor).  Factor 2 = the guide's rule for wide
+    # coalesced streaming reads (128-byte requests tallied at 64 bytes); factor 1 for the LDS-halo conv kernels, whose loads are 64-byte
+    # segments (16 channels of a voxel row per chunk): calibrated as the guide asks for other access widths -- in both tile orders the RAW
+    # counter sits on the geometric halo amplification, doubled it would exceed the no-sharing bound (profiles/r05_final_conv_tile_order.log)
     'conv3d_bf16[k3 s1 128->64 S100': (['conv3_halo_kernel<2, 1, 4, 1, 0, 2, 1>'],
-                                       'final conv forward (+ the SpatialSoftmax3D partials of its epilogue): 12.3 GB compulsory (2 x 4.1 GB read, 4.1 GB written)'),
+                                       'final conv forward (+ the SpatialSoftmax3D partials of its epilogue): 12.3 GB compulsory (2 x 4.1 GB read, 4.1 GB written)', 1.0),
     'conv3d_wgrad[k3 s1 128->64 S100]': (['wgrad_halo_kernel<2, 4, 4, 2>'],
-                                         'weight gradient of the final conv (single fp16 products): 12.3 GB compulsory (x 4.1 GB + the second source 4.1 GB + dY 4.1 GB)'),
+                                         'weight gradient of the final conv (single fp16 products): 12.3 GB compulsory (x 4.1 GB + the second source 4.1 GB + dY 4.1 GB)', 2.0),
     'conv3d_bf16[k3 s1 64->128 S102': (['conv3_halo_kernel<2, 3, 4, 1, 0, 2, 1>', 'conv3_halo_kernel<2, 2, 4, 1, 0, 1, 0>'],
-                                       'the two launches of the data gradient + padding adjoint of the final conv: d(u0) fp16x2, d(d0) fp16'),
+                                       'the two launches of the data gradient + padding adjoint of the final conv: d(u0) fp16x2, d(d0) fp16', 1.0),
 }
 
 
@@ -453,8 +458,10 @@ def profile_traffic(label):
         w = next((v for k, v in write.items() if kern in k), None)
         if f is None:
             return None
-        total += (2.0 * f + (w or 0.0)) * 1024.0
-        parts.append('%s: FETCH_SIZE %.2f GB raw (x2), WRITE_SIZE %.2f GB' % (kern, f * 1024.0 / 1e9, (w or 0.0) * 1024.0 / 1e9))
+        total += (ent[2] * f + (w or 0.0)) * 1024.0
+        parts.append('%s: FETCH_SIZE %.2f GB raw (x %g%s), WRITE_SIZE %.2f GB' % (
+            kern, f * 1024.0 / 1e9, ent[2], '' if ent[2] == 2.0 else ': 64-byte segment loads, calibrated in profiles/r05_final_conv_tile_order.log',
+            (w or 0.0) * 1024.0 / 1e9))
     return total, '%s; %s; %s' % (ent[1], '; '.join(parts), os.path.basename(prof[0]).replace('_pmc_FETCH_SIZE_summary.txt', '_pmc_*'))
 
 

@@ -20,14 +20,16 @@ def test_dominant_kernel_traffic_comes_from_the_newest_profile():
     assert prof is not None
     fetch = b.pmc_mean_per_dispatch(prof[0])
     assert len(fetch) > 10
-    for label, (kernels, _) in b.TRAFFIC_KERNELS.items():
+    for label, (kernels, _, factor) in b.TRAFFIC_KERNELS.items():
+        assert factor in (1.0, 2.0)
         for k in kernels:
             assert any(k in name for name in fetch), (k, os.path.basename(prof[0]))
         nbytes, note = b.profile_traffic(label + ']')
         assert 1e9 < nbytes < 1e11 and os.path.basename(prof[0]).split('_pmc_')[0] in note
-    # the final conv's forward: ~24 GB per launch for 12.3 GB compulsory since round 3 (a change of the kernel must show up here)
-    nbytes, _ = b.profile_traffic('conv3d_bf16[k3 s1 128->64 S100]')
-    assert 1.2e10 < nbytes < 3.0e10
+    # the final conv's forward: 12.3 GB compulsory; 14 - 17 GB moved (raw FETCH_SIZE: this kernel's 64-byte segment loads are tallied at
+    # face value, profiles/r05_final_conv_tile_order.log) -- a change of the kernel must show up here
+    nbytes, note = b.profile_traffic('conv3d_bf16[k3 s1 128->64 S100]')
+    assert 1.23e10 < nbytes < 2.0e10 and 'calibrated' in note
 
 
 def test_voxelizer_traffic_comes_from_the_newest_profile():

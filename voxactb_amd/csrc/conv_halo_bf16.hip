@@ -128,6 +128,31 @@ __device__ __forceinline__ float hb_unpack_hi(unsigned pk) {
 
 __device__ __forceinline__ bool g_dbg_all_waves(const HaloArgs& g) { return (g.dbg & 4) != 0; }    // experiment bit 4: no wave skipping
 
+// Tile index (inside one sample) -> tile coordinates.  Launch order walks 4 x 4 x 4 BLOCKS of tiles (ragged at the far faces), not rows:
+// the ~64 workgroups that are resident on an XCD at one time then cover a compact 16 x 32 x 32 voxel block, whose halo overlaps meet in
+// that XCD's L2 -- in row order (w fastest) they were a 4 x 40 x 104 slab and depth neighbours, the largest overlap (2 of 6 planes),
+// ran 169 tiles apart.  Any bijection gives the same results; experiment bit 0x80 restores row order.
+__device__ __forceinline__ void halo_tile_coords(const HaloArgs& g, int t, int& td, int& th, int& tw) {
+    if (g.dbg & 0x80) { tw = t % g.ntw; t /= g.ntw; th = t % g.nth; td = t / g.nth; return; }
+    constexpr int BL = 4;
+    const int slab = BL * g.nth * g.ntw;                       // tiles in a full block layer along d
+    const int sbd = min(t / slab, (g.ntd - 1) / BL);
+    t -= sbd * slab;
+    const int sd = min(BL, g.ntd - sbd * BL);
+    const int rowsz = sd * BL * g.ntw;                         // ... in a full row of blocks along h inside that layer
+    const int sbh = min(t / rowsz, (g.nth - 1) / BL);
+    t -= sbh * rowsz;
+    const int sh = min(BL, g.nth - sbh * BL);
+    const int blksz = sd * sh * BL;
+    const int sbw = min(t / blksz, (g.ntw - 1) / BL);
+    t -= sbw * blksz;
+    const int sw = min(BL, g.ntw - sbw * BL);
+    const int lw = t % sw; t /= sw;
+    const int lh = t % sh;
+    const int ld = t / sh;
+    td = sbd * BL + ld; th = sbh * BL + lh; tw = sbw * BL + lw;
+}
+
 template <int NTG, int PM, int NW, int WD, int TL, int WN, int HALF, int WG = 0>
                                               // NTG = N / 32 column tiles per workgroup; the NW waves form a (NW / WN) x WN grid over
                                               // (8 M tiles) x (NTG column tiles): 4 x 1 -> 2 M tiles x 2 column tiles per wave,
@@ -187,10 +212,10 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
         const int ntile_ = g.B * g.ntd * g.nth * g.ntw;
         kpart = t / ntile_; t -= kpart * ntile_;
     }
-    const int tw = t % g.ntw; t /= g.ntw;
-    const int th = t % g.nth; t /= g.nth;
-    const int td = t % g.ntd; t /= g.ntd;
-    const int b = t;
+    const int per_b = g.ntd * g.nth * g.ntw;
+    const int b = t / per_b;
+    int td, th, tw;
+    halo_tile_coords(g, t - b * per_b, td, th, tw);
     const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
     const int Ct = g.C0 + g.C1;
     // A wave whose M tiles all lie beyond the last depth slice (the last depth tile of S_out = 22 or 102: two of its four depths
@@ -979,7 +1004,8 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
         const int xcd = lid & 7, slot = lid >> 3, q = nwg >> 3, r = nwg & 7;
         int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
         t /= g.N / (NTG * 32);
-        const int tw = t % g.ntw, th = (t / g.ntw) % g.nth;
+        int td, th, tw;
+        halo_tile_coords(g, t % (g.ntd * g.nth * g.ntw), td, th, tw);
         if (min(g.S_out - tw * TW, g.S_out - th * TH) <= 4 && !g_dbg_all_waves(g)) conv3_halo_body<NTG, PM, NW, WD, TL, WN, 1, 1>(g);
         else conv3_halo_body<NTG, PM, NW, WD, TL, WN, 0, 1>(g);
         return;
@@ -991,8 +1017,8 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
         int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
         t /= g.N / (NTG * 32);
         if (TL) t %= g.B * g.ntd * g.nth * g.ntw;
-        const int tw = t % g.ntw, th = (t / g.ntw) % g.nth;
-        const int td = (t / (g.ntw * g.nth)) % g.ntd;
+        int td, th, tw;
+        halo_tile_coords(g, t % (g.ntd * g.nth * g.ntw), td, th, tw);
         if (g.S_out - td * TD <= 2 && !g_dbg_all_waves(g)) {
             conv3_halo_body<NTG, PM, NW, WD, TL, WN, 3>(g);
             return;
