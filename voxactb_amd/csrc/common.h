@@ -150,3 +150,26 @@ __device__ __forceinline__ float exp_v(float d) {
     r = fmaf(d, 1.92596299e-8f, r);                          // log2 e - float(log2 e)
     return __builtin_amdgcn_exp2f(t) * fmaf(r, 0.693147180559945f, 1.0f);
 }
+
+// Index of a tile inside an ntd x nth x ntw grid of tiles -> its coordinates, walking 4 x 4 x 4 BLOCKS of tiles (ragged at the far faces)
+// instead of rows: the ~64 workgroups resident on one XCD then cover a compact block of the volume and their halo overlaps meet in that
+// XCD's L2 (conv_halo_bf16.hip: halo_tile_coords; profiles/r05_final_conv_tile_order.log: FETCH_SIZE -25 %).  A bijection for any extents.
+__device__ __forceinline__ void vxb_tile_block_coords(int t, int ntd, int nth, int ntw, int& td, int& th, int& tw) {
+    constexpr int BL = 4;
+    const int slab = BL * nth * ntw;                           // tiles in a full block layer along d
+    const int sbd = min(t / slab, (ntd - 1) / BL);
+    t -= sbd * slab;
+    const int sd = min(BL, ntd - sbd * BL);
+    const int rowsz = sd * BL * ntw;                           // ... in a full row of blocks along h inside that layer
+    const int sbh = min(t / rowsz, (nth - 1) / BL);
+    t -= sbh * rowsz;
+    const int sh = min(BL, nth - sbh * BL);
+    const int blksz = sd * sh * BL;
+    const int sbw = min(t / blksz, (ntw - 1) / BL);
+    t -= sbw * blksz;
+    const int sw = min(BL, ntw - sbw * BL);
+    const int lw = t % sw; t /= sw;
+    const int lh = t % sh;
+    const int ld = t / sh;
+    td = sbd * BL + ld; th = sbh * BL + lh; tw = sbw * BL + lw;
+}

@@ -134,23 +134,7 @@ __device__ __forceinline__ bool g_dbg_all_waves(const HaloArgs& g) { return (g.d
 // ran 169 tiles apart.  Any bijection gives the same results; experiment bit 0x80 restores row order.
 __device__ __forceinline__ void halo_tile_coords(const HaloArgs& g, int t, int& td, int& th, int& tw) {
     if (g.dbg & 0x80) { tw = t % g.ntw; t /= g.ntw; th = t % g.nth; td = t / g.nth; return; }
-    constexpr int BL = 4;
-    const int slab = BL * g.nth * g.ntw;                       // tiles in a full block layer along d
-    const int sbd = min(t / slab, (g.ntd - 1) / BL);
-    t -= sbd * slab;
-    const int sd = min(BL, g.ntd - sbd * BL);
-    const int rowsz = sd * BL * g.ntw;                         // ... in a full row of blocks along h inside that layer
-    const int sbh = min(t / rowsz, (g.nth - 1) / BL);
-    t -= sbh * rowsz;
-    const int sh = min(BL, g.nth - sbh * BL);
-    const int blksz = sd * sh * BL;
-    const int sbw = min(t / blksz, (g.ntw - 1) / BL);
-    t -= sbw * blksz;
-    const int sw = min(BL, g.ntw - sbw * BL);
-    const int lw = t % sw; t /= sw;
-    const int lh = t % sh;
-    const int ld = t / sh;
-    td = sbd * BL + ld; th = sbh * BL + lh; tw = sbw * BL + lw;
+    vxb_tile_block_coords(t, g.ntd, g.nth, g.ntw, td, th, tw);
 }
 
 template <int NTG, int PM, int NW, int WD, int TL, int WN, int HALF, int WG = 0>
