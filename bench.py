@@ -569,7 +569,7 @@ MODE_NOTE = {
     'bf16': 'throughput mode, NOT held to the 1e-4 Q-value bound (tests/test_bf16_mode_gpu.py: ~4e-3 on q_trans)',
     'bf16x3/bf16': 'mixed mode (VOXACTB_BWD_PRECISION=bf16): the forward keeps the 1e-4 Q-value bound, parameter gradients are '
                    'within 0.5 % of the reference (norms within 4e-3) instead of 0.2 % -- not the default',
-    'bf16x3+direct_final': 'same-run A/B of round 5\'s Winograd depth axis (DESIGN.md 4b / 5r5.8): the default precision with VOXACTB_FINAL_WINOGRAD=0 '
+    'bf16x3+direct_final': 'same-run A/B of round 5\'s Winograd depth axis (DESIGN.md 4b / 5r5.7): the default precision with VOXACTB_FINAL_WINOGRAD=0 '
                            'VOXACTB_DGRAD_WINOGRAD=0 -- the `final` conv\'s forward and its propagating data gradient on round 4\'s direct LDS-halo kernels '
                            '(27 x 4 instead of 36 x 2 MFMA groups per wave and chunk)',
     'bf16x3+attn_f16': 'named mode, NOT the default (VOXACTB_ATTN_KERNEL=auto): the default precision with the attention FORWARD (QK^T, PV) on the '
