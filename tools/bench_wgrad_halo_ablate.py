@@ -18,13 +18,16 @@ def main():
     fl = 2.0 * B * S ** 3 * 64 * 27 * 128
     L = _lib.lib()
     ops.WGRAD_PRECISION = 'fp16'
+    more = ((2 | 16, 'no MFMA, no loads after the prologue'), (2 | 4, 'no MFMA, no x conversion'), (2 | 8, 'no MFMA, no dY conversion'),
+            (2 | 4 | 8, 'no MFMA, no conversion'), (2 | 4 | 8 | 16, 'no MFMA, no conversion, no loads'), (16, 'no loads after the prologue'),
+            (4 | 8, 'no conversion'), (4 | 8 | 16, 'MFMA loop + barriers only')) if os.environ.get('WH_MORE') else ()
     for nch in (2, 1):
         L.vxb_debug_set_wgrad_halo_chunks(nch)
-        for bits, what in ((0, 'as shipped'), (1, 'first tile staged only'), (2, 'no MFMA loop')):
+        for bits, what in ((0, 'as shipped'), (1, 'first tile staged only'), (2, 'no MFMA loop')) + (more if nch == 2 else ()):
             L.vxb_debug_set_wgrad_halo_experiment(bits)
             ops.new_step()
             t = timeit(lambda: ops.conv3d_wgrad(x0, dy, 64, B, S, S, 3, -1, src1=x1, force_bf16='bf16x3'), n=5)
-            print('fp16 wgrad 128->64 S100 B=%d  chunks/workgroup %d  %-24s %.3f ms  %.1f TF/s' % (B, nch, what, t, fl / t * 1e-9), flush=True)
+            print('fp16 wgrad 128->64 S100 B=%d  chunks/workgroup %d  %-40s %.3f ms  %.1f TF/s' % (B, nch, what, t, fl / t * 1e-9), flush=True)
     L.vxb_debug_set_wgrad_halo_experiment(0)
 
 

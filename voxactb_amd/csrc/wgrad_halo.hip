@@ -192,11 +192,10 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
 #pragma unroll
         for (int i = 0; i < NXL; ++i) {
             const int e = tid + NTH * i;
-            const int lch = NCH == 1 ? 0 : min(e / XF4, NCH - 1);
-            const int e2 = e - lch * XF4;
-            int p = e2 >> 2;
-            const int c4 = (e2 & 3) * 4;
-            const bool ok = p < XSLOTS && e < NCH * XF4;
+            const int lch = (e >> 2) % NCH;             // (the NCH chunks of a voxel on adjacent lanes: 64 NCH contiguous bytes per voxel)
+            int p = e / (4 * NCH);
+            const int c4 = (e & 3) * 4;
+            const bool ok = p < XSLOTS;
             p = min(p, XSLOTS - 1);
             const int cbl = (bx * NCH + lch) * 16;
             const int c0 = src_second ? cbl - g.C0 : cbl;
@@ -215,11 +214,10 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
 #pragma unroll
         for (int i = 0; i < NXL; ++i) {
             const int e = tid + NTH * i;
-            const int lch = NCH == 1 ? 0 : min(e / XF4, NCH - 1);
-            const int e2 = e - lch * XF4;
-            int p = e2 >> 2;
-            const int c4 = (e2 & 3) * 4;
-            const bool ok = p < XSLOTS && e < NCH * XF4;
+            const int lch = (e >> 2) % NCH;             // (the NCH chunks of a voxel on adjacent lanes: 64 NCH contiguous bytes per voxel)
+            int p = e / (4 * NCH);
+            const int c4 = (e & 3) * 4;
+            const bool ok = p < XSLOTS;
             p = min(p, XSLOTS - 1);
             const int cbl = (bx * NCH + lch) * 16;
             const int c0 = src_second ? cbl - g.C0 : cbl;
@@ -318,10 +316,9 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
 #pragma unroll
         for (int i = 0; i < NXL; ++i) {
             const int e = tid_ + NTH * i;
-            const int lch = NCH == 1 ? 0 : min(e / XF4, NCH - 1);      // which chunk of the workgroup this slot belongs to
-            const int e2 = e - lch * XF4;
-            int p = e2 >> 2;
-            const int c4 = (e2 & 3) * 4;
+            const int lch = (e >> 2) % NCH;                              // which chunk of the workgroup this slot belongs to
+            int p = e / (4 * NCH);
+            const int c4 = (e & 3) * 4;
             bool ok = p < XSLOTS;
             p = min(p, XSLOTS - 1);
             const int cbl = (bx * NCH + lch) * 16;                       // first channel of that chunk: source 0 or source 1
@@ -363,9 +360,9 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
 #pragma unroll
         for (int i = 0; i < NXL; ++i) {
             const int e0 = tid_s + NTH * i;
-            if (e0 < NCH * XF4) {
-                const int lch = NCH == 1 ? 0 : e0 / XF4;
-                const int e = e0 - lch * XF4 + lch * (1 + X3) * XPL / 4;     // slot index inside the chunk's plane pair
+            if (e0 < NCH * XF4 && !(g.dbg & 4)) {          // (experiment bit 4: no x conversion / LDS stores)
+                const int lch = (e0 >> 2) % NCH;
+                const int e = (e0 / (4 * NCH)) * 4 + (e0 & 3) + lch * (1 + X3) * XPL / 4;     // slot index inside the chunk's plane pair
                 if (!((L.okm >> i) & 1u)) L.px[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 uint2 pk;
                 pk.x = wh_pack2<PM>(L.px[i].x, L.px[i].y); pk.y = wh_pack2<PM>(L.px[i].z, L.px[i].w);
@@ -379,7 +376,7 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
             }
         }
 #pragma unroll
-        for (int i = 0; i < NDL; ++i) {
+        for (int i = 0; i < (((g.dbg & 8) != 0) ? 0 : NDL); ++i) {      // (experiment bit 8: no dY conversion / LDS stores)
             const int e = tid_s + NTH * i;
             if (!((L.okm >> (8 + i)) & 1u)) L.pd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (PM == 2) { L.pd[i].x *= dysc; L.pd[i].y *= dysc; L.pd[i].z *= dysc; L.pd[i].w *= dysc; }
@@ -506,7 +503,7 @@ __global__ void __launch_bounds__(256 * NCH, NCH == 1 ? 2 : 1) wgrad_halo_kernel
             const int nt = tile + 1 + lead;
             if (nt < t_end && !(g.dbg & 1)) {
                 stage(X, ((par + 1 + lead) & 1) * BUFU);
-                if (nt + 2 < t_end) issue(X, nt + 2);
+                if (nt + 2 < t_end && !(g.dbg & 16)) issue(X, nt + 2);      // (experiment bit 16: no loads after the prologue's)
             }
             if (!lead) vxb_raw_barrier_lds();
         };
