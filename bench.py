@@ -56,6 +56,8 @@ def main():
     ap.add_argument('--no-other-modes', '--no-bf16-mode', dest='no_other_modes', action='store_true',
                     help='skip the secondary measurements in the other precisions and the parity probe')
     ap.add_argument('--cpu-voxel-size', type=int, default=0, help='debug: smaller grid for the CPU baseline leg')
+    ap.add_argument('--cpu-full-batch', action='store_true', help='cpu_baseline: also time ONE real B=16 step of the oracle (needs >= 64 GB '
+                    'of host RAM and minutes; SURVEY.md 8d "if RAM allows")')
     ap.add_argument('--kernel-table', action='store_true', help='print the per-kernel timing table to stderr')
     ap.add_argument('--replay-stream', action='store_true',
                     help='feed the HEADLINE region from the replay store: a fresh task-uniform batch per step through '
@@ -119,7 +121,7 @@ def main():
     eng = engines[0]
     headline_mode = eng.precision          # 'bf16x3' unless VOXACTB_PRECISION overrides it
     headline_bwd = eng.bwd_precision       # '' (= same as the forward) unless VOXACTB_BWD_PRECISION overrides it
-    headline_attn = eng.attn_kernel        # 'r3' (round 3's bf16x3 attention forward) unless VOXACTB_ATTN_KERNEL overrides it
+    headline_attn = eng.attn_kernel        # 'auto' (round 6: the pipelined single-fp16 attention forward from 2^22 scores on) unless VOXACTB_ATTN_KERNEL overrides it
     counter = [0]
     updates_per_step = len(agents) * a.aug_copies
 
@@ -178,10 +180,10 @@ def main():
     def measure(mode, steps, warmup, only=None, stream=False):
         """W untimed + exactly K timed steps in `mode`, bracketed by barrier + synchronize; max over ranks.  `only`: the timer
         labels whose launches are bracketed by HIP events (None = every launch).  stream: batches from the replay store."""
-        base_mode, _, attn = mode.partition('+')                         # 'bf16x3+attn_f16' = the pipelined single-fp16 attention forward (VOXACTB_ATTN_KERNEL=auto)
+        base_mode, _, attn = mode.partition('+')                         # 'bf16x3+attn_x3' = round 3's bf16x3 attention forward (VOXACTB_ATTN_KERNEL=r3)
         for e_ in engines:
             e_.precision, _, e_.bwd_precision = base_mode.partition('/')  # 'bf16x3/bf16' = forward bf16x3, backward products bf16
-            e_.attn_kernel = 'auto' if attn == 'attn_f16' else headline_attn
+            e_.attn_kernel = 'auto' if attn == 'attn_f16' else 'r3' if attn == 'attn_x3' else headline_attn
         wino = (ops.FINAL_WINOGRAD, ops.DGRAD_WINOGRAD)
         if attn == 'direct_final':                                       # same-run A/B: `final` forward + d(u0) on the direct LDS-halo kernels
             ops.FINAL_WINOGRAD = ops.DGRAD_WINOGRAD = False
@@ -248,10 +250,12 @@ def main():
     # secondary measurements of the same workload in the other precisions (never the headline `value`)
     others = {}
     if not a.no_other_modes:
-        for mode in ('fp32', 'bf16x3', 'bf16x3+attn_f16', 'bf16x3+direct_final', 'bf16x3/bf16', 'bf16'):
+        for mode in ('fp32', 'bf16x3', 'bf16x3+attn_f16', 'bf16x3+attn_x3', 'bf16x3+direct_final', 'bf16x3/bf16', 'bf16'):
             if mode == headline_mode and not headline_bwd:
                 continue
             if mode == 'bf16x3+attn_f16' and (headline_mode != 'bf16x3' or headline_attn != 'r3'):
+                continue
+            if mode == 'bf16x3+attn_x3' and (headline_mode != 'bf16x3' or headline_attn != 'auto'):
                 continue
             if mode == 'bf16x3+direct_final' and (headline_mode != 'bf16x3' or not (ops.FINAL_WINOGRAD or ops.DGRAD_WINOGRAD) or V % 2):
                 continue
@@ -345,14 +349,39 @@ def main():
         if dom_label.startswith('conv3d_bf16[k3 s1 128->64') and _ops.FINAL_WINOGRAD and V % 2 == 0:
             roofline['arithmetic_note'] = ('achieved / frac count the DIRECT convolution\'s flops (2 x 27 x Cin x Cout per output voxel); the kernel '
                                            'evaluates the depth taps by Winograd F(2, 3) and issues 2/3 of them as MFMA work (x 3 for bf16x3)')
+            # (round-5 advisor) the MFMA work the kernel EXECUTES next to the algorithmic figure: 36 x 2 instead of 27 x 4 MFMA groups per
+            # wave and chunk, three bf16 MFMAs per product
+            roofline['executed_mfma_flops_per_launch'] = roofline['algorithmic_flops_per_launch'] * (72.0 / 108.0) * (3.0 if headline_mode == 'bf16x3' else 1.0)
+            roofline['executed_mfma_frac_of_peak'] = roofline['executed_mfma_flops_per_launch'] / (roofline['avg_launch_ms'] * 1e-3) / 1e12 / MODE_PEAK[headline_mode]
         roofline['share_of_device_time'] = agg[dom_label]['ms'] / tot_ms
         extra = dict(roofs)
+        # BASELINE.json north_star's three numeric targets, nested in `roofline` so the driver's parsed record keeps them (round-5 review):
+        # attention >= 0.30 of the dense bf16 MFMA peak, voxel scatter >= 0.60 of the HBM peak, >= 6 x at 8 GPUs (not measurable on one GPU)
+        north = {'targets': {'attention_frac_of_bf16_mfma_peak': 0.30, 'voxel_scatter_frac_of_hbm_peak': 0.60, 'scaling_at_8_gpus': 6.0}}
+        att = roofs.get('attention (QK^T, PV and their gradients)')
+        if att is not None:
+            north['attention_in_step'] = {'frac': att['frac'], 'achieved_tflops': att['achieved'], 'ms_per_step': att['ms_per_step'],
+                                          'launches': att['launches'],
+                                          'basis': 'algorithmic flops of QK^T, PV and their gradients (4 / 10 Nq Nk d per batch and head) over the '
+                                                   'summed durations of the attention-core launches of the event-timed pass of THIS run, / 2500 TF/s'}
         if 'voxelize' in agg_head:
             v = agg_head['voxelize']
             extra['voxel_scatter'] = voxel_roofline(v['ms'] / v['calls'], v['bytes'] / v['calls'], V, B, True)
+            vs = extra['voxel_scatter']
+            north['voxel_scatter_in_step'] = {'avg_launch_ms': vs['avg_launch_ms'], 'algorithmic_equivalent_frac': vs['algorithmic_equivalent_gbps'] / PEAK_HBM_GBPS,
+                                              'real_traffic_frac': vs.get('frac'),
+                                              'basis': 'the training path\'s call (persistent grids updated in place), timed INSIDE the K-step region; '
+                                                       'algorithmic_equivalent_frac = (read N*6*4 + write V^3*10*4 bytes per sample) / time / 8 TB/s -- the call '
+                                                       'moves fewer bytes than that (real_traffic_frac, PMC)'}
             if not a.no_other_modes:
                 extra['voxel_scatter_stateless'] = voxel_stateless(agents[0], batches[0][0], cfg, V, B)
+                north['voxel_scatter_stateless'] = {'avg_launch_ms': extra['voxel_scatter_stateless']['avg_launch_ms'],
+                                                    'frac': extra['voxel_scatter_stateless']['frac'],
+                                                    'basis': 'fresh grid, every cell written (coords_to_bounding_voxel_grid / act()): algorithmic bytes / time / 8 TB/s'}
                 extra['attention_kernels_B16_H8_N2048_d64'] = attention_kernel_probe(dev)
+                north['attention_kernels_alone'] = {k.split(' ')[0]: round(x['frac'], 4) for k, x in extra['attention_kernels_B16_H8_N2048_d64'].items()}
+        north['scaling_at_8_gpus'] = None if world == 1 else {'n_gpus': world, 'note': 'the driver computes efficiency from the per-N values'}
+        roofline['north_star'] = north
         if a.kernel_table:
             for label, d in sorted(agg.items(), key=lambda kv: -kv[1]['ms']):
                 sys.stderr.write('%-44s calls %5d  %9.2f ms/step  %7.2f TF/s\n' % (
@@ -553,7 +582,8 @@ def voxel_stateless(agent, batch, cfg, V, B):
 
 MODE_DTYPE = {         # (short: the driver's record truncates long strings; the long form is `precision_note`)
     'fp32': 'f32 (exact fp32 MFMA everywhere)',
-    'bf16x3': 'f32 storage/accumulate; fwd products bf16x3 (3 bf16 MFMA); bwd: weight grads + attention 1x fp16, data grads 2x fp16 (scaled)',
+    'bf16x3': 'f32 storage/accumulate; fwd products bf16x3 (3 bf16 MFMA), attention core 1x fp16; bwd: weight grads + attention 1x fp16, data grads 2x fp16 (scaled)',
+    'bf16x3+attn_x3': 'as bf16x3, attention fwd on the bf16x3 triple (VOXACTB_ATTN_KERNEL=r3: the default of rounds 3 - 5)',
     'bf16': 'bf16 MFMA, f32 accumulate/storage',
     'bf16x3/bf16': 'fwd bf16x3, bwd products plain bf16',
     'bf16x3+attn_f16': 'as bf16x3, attention fwd on 1x fp16 products (VOXACTB_ATTN_KERNEL=auto)',
@@ -561,7 +591,9 @@ MODE_DTYPE = {         # (short: the driver's record truncates long strings; the
 }
 MODE_NOTE = {
     'fp32': 'exact fp32 matrix cores: the reference-parity mode of the first measurements (tests/test_encoder_gpu.py, 1e-4)',
-    'bf16x3': 'f32 storage / accumulate; forward products as the bf16x3 split (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16), held to the '
+    'bf16x3': 'f32 storage / accumulate; forward products as the bf16x3 split (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16) -- except the '
+              'attention core (QK^T, PV) from 2^22 score elements on, which runs ONE fp16 product per term on the pipelined kernel (round 6: its '
+              'round-5 "failure" on the F5c3 digest was one max-pool tie, not arithmetic; profiles/r06_attn_variants_*.log) -- held to the '
               '1e-4 Q-value bound of the exact-fp32 mode (tests/test_c2_reference_gpu.py, test_encoder_gpu.py); backward: weight gradients '
               '(leaves) and the attention backward (pipelined kernels, csrc/flash2_bwd.hip) as single fp16 products, propagating conv / '
               'wide-linear data gradients as two fp16 products (gradient hi + lo), all with device-side power-of-two operand scales; gradients '
@@ -572,6 +604,8 @@ MODE_NOTE = {
     'bf16x3+direct_final': 'same-run A/B of round 5\'s Winograd depth axis (DESIGN.md 4b / 5r5.7): the default precision with VOXACTB_FINAL_WINOGRAD=0 '
                            'VOXACTB_DGRAD_WINOGRAD=0 -- the `final` conv\'s forward and its propagating data gradient on round 4\'s direct LDS-halo kernels '
                            '(27 x 4 instead of 36 x 2 MFMA groups per wave and chunk)',
+    'bf16x3+attn_x3': 'same-run A/B of round 6\'s default change (VOXACTB_ATTN_KERNEL=r3): the attention forward on round 3\'s bf16x3 kernel (three bf16 MFMAs '
+                      'per product), everything else as the headline',
     'bf16x3+attn_f16': 'named mode, NOT the default (VOXACTB_ATTN_KERNEL=auto): the default precision with the attention FORWARD (QK^T, PV) on the '
                        'pipelined kernel with ONE fp16 product per term (csrc/flash2_fwd.hip) from 2^22 score elements on, instead of round 3\'s bf16x3 '
                        'triple.  Measured (DESIGN.md 5r5; profiles/r05_attn_f16_forward_gate.log): Q-values within 1e-4 of the reference on every fixture '
@@ -717,9 +751,22 @@ def _digest_check(dev, mode, V, depth, latents, HW, fixture, g, Bf, wide):
     return res
 
 
+def _host_ram_gb():
+    try:
+        with open('/proc/meminfo') as fh:
+            for line in fh:
+                if line.startswith('MemTotal:'):
+                    return float(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return None
+
+
 def cpu_baseline(a, cfg):
-    """The oracle (CPU restatement of the reference path, kind 'port') timed on this host: ONE sample (B=1) of the same
-    workload through voxelize + forward + losses + backward + LAMB; a B=16 step is 16x that."""
+    """The oracle (CPU restatement of the reference path, kind 'port') timed on this host.  Bounded sample: ONE replay
+    sample (B=1) of the same workload through voxelize + forward + losses + backward + LAMB, and the voxelizer alone at the full
+    batch; `value` extrapolates a B=16 step as 16 x the sample.  --cpu-full-batch (not in the default run: ~2 minutes and ~45 GB of
+    host RAM) also times ONE real B=16 step; the result of such a run is committed under profiles/."""
     import torch
     from oracle import agent as oagent, perceiver as operc, weights as ow
     from voxactb_amd import synthetic
@@ -730,26 +777,45 @@ def cpu_baseline(a, cfg):
     V = a.cpu_voxel_size or a.voxel_size
     s = 5 if V % 5 == 0 else 4
     shapes = operc.param_shapes(a.depth, V, 4, num_latents=a.latents, voxel_patch_size=5, voxel_patch_stride=s)
-    P = ow.hashed_state_dict(shapes, 0)
-    rs = synthetic.make_replay_sample(1, cfg.rlbench.cameras, (a.image, a.image), V, 4, seed=7)
-    r = {k: (v[:, 0] if v.dim() > 2 else v) for k, v in rs.items()}
-    r = {k: ((v.float() / 255.0) * 2.0 - 1.0 if 'rgb' in k else v.float()) for k, v in r.items()}
-    bt = dict(pcd=[r['%s_point_cloud' % c] for c in cfg.rlbench.cameras], rgb=[r['%s_rgb' % c] for c in cfg.rlbench.cameras],
-              proprio=r['low_dim_state'], lang_token_embs=r['lang_token_embs'], bounds=torch.tensor([synthetic.SCENE_BOUNDS]),
-              trans=r['trans_action_indicies'], rot_grip=r['rot_grip_action_indicies'], ignore_collisions=r['ignore_collisions'])
     from oracle import voxel_grid as ovox
+
+    def batch_of(n):
+        rs = synthetic.make_replay_sample(n, cfg.rlbench.cameras, (a.image, a.image), V, 4, seed=7)
+        r = {k: (v[:, 0] if v.dim() > 2 else v) for k, v in rs.items()}
+        r = {k: ((v.float() / 255.0) * 2.0 - 1.0 if 'rgb' in k else v.float()) for k, v in r.items()}
+        return dict(pcd=[r['%s_point_cloud' % c] for c in cfg.rlbench.cameras], rgb=[r['%s_rgb' % c] for c in cfg.rlbench.cameras],
+                    proprio=r['low_dim_state'], lang_token_embs=r['lang_token_embs'], bounds=torch.tensor([synthetic.SCENE_BOUNDS]),
+                    trans=r['trans_action_indicies'], rot_grip=r['rot_grip_action_indicies'], ignore_collisions=r['ignore_collisions'])
+    bt = batch_of(1)
     t0 = time.perf_counter()
     ovox.voxelize(*ovox.flatten_cameras(bt['pcd'], bt['rgb']), bt['bounds'], V)       # the voxelizer leg on its own
     dt_vox = time.perf_counter() - t0
     t0 = time.perf_counter()
-    oagent.train_steps(P, [bt], V, 1, depth=a.depth, voxel_patch_stride=s)
+    oagent.train_steps(ow.hashed_state_dict(shapes, 0), [bt], V, 1, depth=a.depth, voxel_patch_stride=s)
     dt = time.perf_counter() - t0
-    return {'value': 1.0 / (dt * a.batch), 'unit': 'steps/s', 'cores': ncores, 'kind': 'port', 'extrapolated': True,
-            'sample': 'one replay sample (B=1) of the same workload through the CPU oracle (voxelize + fwd + 6 CE + bwd + LAMB) '
-                      'took %.1f s; `value` EXTRAPOLATES a B=%d step as %dx that (the B=%d autograd graph needs ~40 GB and minutes)'
-                      % (dt, a.batch, a.batch, a.batch),
-            'seconds_per_sample': dt, 'voxelize_seconds_per_sample': dt_vox,
-            'voxelize_note': 'scatter-mean voxelization of one sample (4 x 128 x 128 points -> %d^3 grid) on the same threads' % V}
+    out = {'value': 1.0 / (dt * a.batch), 'unit': 'steps/s', 'cores': ncores, 'kind': 'port', 'extrapolated': True,
+           'sample': 'one replay sample (B=1) of the same workload through the CPU oracle (voxelize + fwd + 6 CE + bwd + LAMB) '
+                     'took %.1f s; `value` EXTRAPOLATES a B=%d step as %dx that (a real B=%d step: --cpu-full-batch, ~45 GB of host RAM and '
+                     'minutes; profiles/r06_cpu_full_batch.json)' % (dt, a.batch, a.batch, a.batch),
+           'seconds_per_sample': dt, 'voxelize_seconds_per_sample': dt_vox, 'host_ram_gb': _host_ram_gb(),
+           'voxelize_note': 'scatter-mean voxelization of one sample (4 x 128 x 128 points -> %d^3 grid) on the same threads' % V}
+    # the voxelizer at the FULL batch (cheap: ~B x the sample)
+    btB = batch_of(a.batch)
+    t0 = time.perf_counter()
+    ovox.voxelize(*ovox.flatten_cameras(btB['pcd'], btB['rgb']), btB['bounds'], V)
+    out['voxelize_seconds_per_batch'] = time.perf_counter() - t0
+    out['voxelize_batches_per_s'] = 1.0 / out['voxelize_seconds_per_batch']
+    if a.cpu_full_batch:
+        ram = out['host_ram_gb']
+        if ram is not None and ram < 64.0:
+            out['full_batch'] = 'skipped: host RAM %.0f GB < 64 GB' % ram
+        else:
+            t0 = time.perf_counter()
+            oagent.train_steps(ow.hashed_state_dict(shapes, 0), [btB], V, 1, depth=a.depth, voxel_patch_stride=s)
+            dtB = time.perf_counter() - t0
+            out['full_batch'] = {'seconds_per_step': dtB, 'value': 1.0 / dtB, 'unit': 'steps/s', 'batch': a.batch,
+                                 'note': 'ONE real B=%d step of the oracle (not extrapolated)' % a.batch}
+    return out
 
 
 if __name__ == '__main__':

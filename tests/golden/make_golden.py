@@ -280,6 +280,89 @@ def encoder_fixture(name, cfg, arm=False, with_grads=True, digest=False, crop=Fa
 
 
 
+def _pool_hook(enc, pools):
+    def hook(mod, inp, out):
+        top = inp[0].detach().flatten(2).topk(2, dim=-1)
+        pools.append((top.indices[..., 0].int(), (top.values[..., 0] - top.values[..., 1]).float()))
+    return enc.global_maxp.register_forward_hook(hook)
+
+
+def _save_pools(fixture, pools, lse_key, lse, extra=None):
+    base = np.load(os.path.join(HERE, fixture + '.npz'), allow_pickle=False)
+    assert np.array_equal(base[lse_key], lse.numpy()), 'not the forward the fixture holds'
+    arrs = dict(q_trans_lse=lse)
+    for i, (am, mg) in enumerate(pools):
+        arrs['pool_argmax_%d' % i] = am
+        arrs['pool_margin_%d' % i] = mg
+    arrs.update(extra or {})
+    print('%s: smallest top-2 margins of the global max pools: %s' % (fixture, [float(mg.min()) for _, mg in pools]), flush=True)
+    save(fixture + '_pools', **arrs)
+
+
+def pool_choices(fixture, cfg, arm=False, crop=False, seed=1, slabs=False):
+    """Supplement of an encoder digest (same encoder, same batch, fp32, forward only; round 6): the arg-max voxel of every (sample,
+    channel) of the three global max pools (perceiver_lang_io.py:360, :451, :470) and the margin between the largest and the second
+    largest value.  The loss is only piecewise smooth: a pool whose two largest voxels are closer than a forward arithmetic's rounding
+    (~1e-5) hands its whole gradient to the other voxel -- ONE such choice of 512 moves `decoder_cross_attn.fn.to_out.weight`'s gradient by
+    4 % on the F5c3 batch (tools/experiments/attn_fwd_variants.py: every single-fp16 attention forward "failed" that digest by exactly
+    this one flip, whatever the operand treatment; the two voxels are 1.1e-6 apart in the reference's run).  As for the LeakyReLU choices
+    (capture_kinks) a test evaluates the product's backward at the SAME choices as the run the fixture's gradients come from, after
+    checking that the product's own values tie there.  slabs: the stride-1 convs as _f5v200g evaluates them."""
+    enc, sd = make_ref_encoder(cfg, arm)
+    rs = batch_for(cfg, seed=seed, arm=arm, crop=crop)
+    pcd = [rs['%s_point_cloud' % c] for c in cfg['cams']]
+    rgb = [rs['%s_rgb' % c] for c in cfg['cams']]
+    bounds = rs['target_object_scene_bounds'] if crop else torch.tensor([synthetic.SCENE_BOUNDS])
+    coords, feats = ovox.flatten_cameras(pcd, rgb)
+    grid = ref_voxelize(coords, feats, bounds, cfg['V'], cfg['B'])
+    ins = grid.permute(0, 4, 1, 2, 3).detach()
+    pools = []
+    h = _pool_hook(enc, pools)
+    if slabs:
+        torch.set_num_threads(8)
+        torch.nn.functional.conv3d = _chunked_conv3d_f64
+    try:
+        with torch.no_grad():
+            outs = enc(ins, rs['low_dim_state'], rs['lang_goal_emb'], rs['lang_token_embs'], None, bounds, None)
+    finally:
+        torch.nn.functional.conv3d = _ORIG_CONV3D
+    h.remove()
+    assert len(pools) == 3
+    _save_pools(fixture, pools, 'q_trans_lse', torch.logsumexp(outs[0].reshape(cfg['B'], -1).double(), 1))
+
+
+def pool_choices_2robots(fixture, cfg):
+    """The same supplement for a 2Robots digest (encoder2_fixture's encoder and batch), plus the LeakyReLU choices near zero the F11
+    fixtures never carried (capture_kinks): the round-5 review asked for them so that a default-precision difference on that digest can
+    be told apart into kinks and arithmetic.  The left arm's ss_final pools the same tensor as the right arm's (perceiver :838-846)."""
+    enc = ref_pl.PerceiverVoxelLang2RobotsEncoder(
+        depth=cfg['depth'], iterations=1, voxel_size=cfg['V'], initial_dim=10, low_dim_size=cfg['low_dim'],
+        num_latents=cfg['latents'], voxel_patch_size=cfg['k'], voxel_patch_stride=cfg['s'],
+        activation='lrelu', input_dropout=0.0, attn_dropout=0.0, decoder_dropout=0.0)
+    enc.load_state_dict(ow.hashed_state_dict({n: tuple(p.shape) for n, p in enc.named_parameters()}, 0), strict=False)
+    enc.eval()
+    rs = batch_for(cfg, seed=1)
+    B, V = cfg['B'], cfg['V']
+    pcd = [rs['%s_point_cloud' % c] for c in cfg['cams']]
+    rgb = [rs['%s_rgb' % c] for c in cfg['cams']]
+    bounds = torch.tensor([synthetic.SCENE_BOUNDS])
+    coords, feats = ovox.flatten_cameras(pcd, rgb)
+    grid = ref_voxelize(coords, feats, bounds, V, B)
+    ins = grid.permute(0, 4, 1, 2, 3).detach()
+    proprio_left = ow.hashed_uniform('f11.proprio_left', (B, cfg['low_dim']), 0.0, 1.0)
+    pools, store = [], {}
+    hooks = [_pool_hook(enc, pools)] + capture_kinks(enc, store)
+    with torch.no_grad():
+        outs = enc(ins, rs['low_dim_state'], proprio_left, rs['lang_goal_emb'], rs['lang_token_embs'], None, bounds, None)
+    for h in hooks:
+        h.remove()
+    assert len(pools) in (3, 4), len(pools)
+    if len(pools) == 4:
+        assert torch.equal(pools[2][0], pools[3][0])          # ss_final and ss_final_left_arm pool the same tensor
+    print('%s: pre-activations within %.0e of zero: %s' % (fixture, KINK_TAU, {k.split('__')[1]: int(v.numel()) for k, v in store.items() if k.endswith('idx')}))
+    _save_pools(fixture, pools[:3], 'q_trans_right_lse', torch.logsumexp(outs[0].reshape(B, -1).double(), 1), dict(store, kink_tau=KINK_TAU))
+
+
 def _f5v200g():
     """configs[4] geometry, forward + backward of the reference in fp32: stride-1 convs evaluated in slabs of eight output depths
     (_chunked_conv3d_f64 below: the module code is untouched), a stack dump every ten minutes so that a stuck ATen op is named."""
@@ -1182,6 +1265,14 @@ SECTIONS = {
     'f5k_v50b': lambda: grad_noise_kinks('f5n_kinks_v50b_s1', CFG_V50B, 1, arm=True, crop=True),
     'f5n_v50a': lambda: grad_noise_fixture('f5n_noise_v50a_s1', CFG_V50, 1, arm=True, crop=True),
     'f5n_v50b': lambda: grad_noise_fixture('f5n_noise_v50b_s1', CFG_V50B, 1, arm=True, crop=True),
+    # the fp32 reference run's max-pool choices for the gradient digests (round 6, forward only)
+    'f5p_f5g': lambda: pool_choices('f5g_encoder_c2_grads', CFG_C2),
+    'f5p_f5c3': lambda: pool_choices('f5c3_encoder_c3_digest', CFG_C3, arm=True, crop=True),
+    'f5p_f5gb8': lambda: pool_choices('f5gb8_encoder_c2_b8_grads', dict(CFG_C2, B=8)),
+    'f5p_f5v50a': lambda: pool_choices('f5v50a_encoder_release_digest', CFG_V50, arm=True, crop=True),
+    'f5p_f5v50b': lambda: pool_choices('f5v50b_encoder_release_digest', CFG_V50B, arm=True, crop=True),
+    'f5p_f5v200g': lambda: pool_choices('f5v200g_encoder_c5_grads', CFG_C5, slabs=True),
+    'f5p_f11c2': lambda: pool_choices_2robots('f11c2_encoder_2robots_c2_digest', CFG_C2),
     'f11tiny': lambda: encoder2_fixture('f11_encoder_2robots_tiny', CFG_TINY),
     'f11c1': lambda: encoder2_fixture('f11_encoder_2robots_c1', CFG_C1),
     'f11c2': lambda: encoder2_fixture('f11c2_encoder_2robots_c2_digest', CFG_C2, digest=True),

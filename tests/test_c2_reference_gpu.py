@@ -84,14 +84,24 @@ def _check_forward(g, outs, arm, tag):
 KINK_KEYS = {'input_preprocess': 'd0', 'patchify': 'patch', 'up0.conv_up.0': 'z1', 'up0.conv_up.2': 'u0', 'final': 'u'}
 
 
+KINK_FLIP_FRACTION = 5e-5       # of a site's elements: measured <= 2.2e-5 (2 779 of u0's 1.28 x 10^8 at B = 2 behind the single-fp16 attention forward)
+KINK_FLIP_MARGIN = 3e-5         # a flipped element of the PRODUCT lies within tau + this of zero (forward difference to the reference <= ~2e-5)
+
+
 def force_kinks(cache, g):
     """The loss is piecewise smooth: LeakyReLU' jumps from 0.02 to 1 where a pre-activation crosses zero, and a forward arithmetic that is
     1e-5 away from the reference's moves ~100 of the 64 M elements of u0 across (tools/experiments/fwd_sensitivity_gpu.py; DESIGN.md 5r5:
     those elements alone carry the 3-8 % gradient differences of the 'forward-sensitive' batches -- parameter gradients are cancelling sums
     over 10^6 voxels).  Fixtures that carry the reference run's pre-activations within 3e-5 of zero (make_golden.py: capture_kinks) let the
     backward be evaluated at the SAME subgradient choices, exactly as the max-pool arg-maxima are: the saved activation is given the
-    reference's sign there (magnitude 1e-30: these values are < 3e-5 anyway).  Returns the number of choices that differed."""
+    reference's sign there (magnitude 1e-30: these values are < 3e-5 anyway).  Returns the number of choices that differed.
+
+    What the forcing may NOT hide (round-5 advisor): a real forward or mask error at near-zero elements.  Asserted per site: the elements
+    whose sign differs are a vanishing fraction of the tensor (KINK_FLIP_FRACTION) and the product's OWN value there is within
+    tau + KINK_FLIP_MARGIN of zero, i.e. the two forwards agree to ~1e-5 at every patched element; every listed element (flipped or not)
+    is within 1e-3 of zero (same layout, same elements)."""
     flips = 0
+    tau = float(g['kink_tau'])
     for site, key in KINK_KEYS.items():
         k = 'kink__%s__idx' % site
         if k not in g.files:
@@ -103,12 +113,91 @@ def force_kinks(cache, g):
         flat = t.view(-1)
         cur = flat[idx]
         assert idx.numel() == 0 or float(cur.abs().max()) < 1e-3, (site, float(cur.abs().max()))      # (same layout, same elements)
-        flips += int(((cur > 0) != pos).sum())
+        diff = (cur > 0) != pos
+        n = int(diff.sum())
+        if n:
+            assert n <= max(4, KINK_FLIP_FRACTION * flat.numel()), (site, n, flat.numel())
+            # LeakyReLU(x) = 0.02 x below zero: the saved activation of a negative pre-activation x is 0.02 x -- bound |x|
+            worst = float(torch.where(cur[diff] > 0, cur[diff], cur[diff] / 0.02).abs().max())
+            assert worst <= tau + KINK_FLIP_MARGIN, (site, n, worst)
+        flips += n
         flat[idx] = torch.where(pos, torch.full_like(cur, 1e-30), torch.full_like(cur, -1e-30))
     return flips
 
 
-def _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, tag, gate=1.0):
+POOL_KEYS = (('ss0', 'd0'), ('ss1', 'z'), ('ss2', 'u'))
+POOL_TIE = 5e-5                 # the product's value at the reference's arg-max voxel is within this of the product's own maximum
+POOL_MAX_FLIPS = 4              # per pool, of B x C choices (measured: at most 2)
+
+
+def force_pools(cache, gp, T0):
+    """Global max pools (perceiver_lang_io.py:360, :451, :470): the backward at the reference run's arg-max voxels (fixture supplement
+    *_pools.npz, make_golden.py: pool_choices), as tests/test_grad_noise_gpu.py does at the float64 run's.  A choice may only be replaced
+    where it IS a tie: the reference's top-2 margin there is below POOL_TIE and the product's own value at the reference's voxel is within
+    POOL_TIE of the product's maximum -- a forward error would fail these asserts instead of being patched over.  T0: language tokens in
+    front of the grid tokens of z.  Returns the flips per pool."""
+    out = []
+    for i, (key, src) in enumerate(POOL_KEYS):
+        ss, mx, st, am = cache[key]
+        ref = T(gp['pool_argmax_%d' % i]).to(DEV).int().reshape(am.shape).contiguous()
+        diff = am != ref
+        n = int(diff.sum())
+        if n:
+            assert n <= POOL_MAX_FLIPS, (key, n)
+            margin = T(gp['pool_margin_%d' % i]).to(DEV).reshape(am.shape)
+            assert float(margin[diff].max()) < POOL_TIE, (key, float(margin[diff].max()))       # the reference's own top two tie there
+            t = cache[src]
+            B, C = am.shape
+            x = t.reshape(B, -1, C)
+            if src == 'z':
+                x = x[:, T0:]
+            b, c = torch.nonzero(diff, as_tuple=True)
+            mine_at_ref = x[b, ref[b, c].long(), c]
+            gap = float((mx[b, c] - mine_at_ref).abs().max())
+            assert gap < POOL_TIE, (key, n, gap)
+            cache[key] = (ss, mx, st, ref)
+        out.append(n)
+    return out
+
+
+def align_choices(cache, ref_cache, T0, tie=1e-4):
+    """Evaluate `cache`'s backward at the LeakyReLU / max-pool choices of ANOTHER run of the product on the same batch (`ref_cache`, e.g. the
+    exact-fp32 kernels'): where the two saved activations have different signs and both are within `tie` of zero, `cache` takes the other
+    run's sign; where the pool arg-maxima differ and the values tie within `tie`, the other run's voxel.  Same asserts as force_kinks /
+    force_pools: a vanishing fraction of elements, every one a genuine near-tie.  Returns (LeakyReLU flips, pool flips)."""
+    flips = 0
+    for key in KINK_KEYS.values():
+        a, b = cache[key].view(-1), ref_cache[key].view(-1)
+        diff = (a > 0) != (b > 0)
+        idx = torch.nonzero(diff)[:, 0]
+        n = int(idx.numel())
+        if n:
+            assert n <= max(4, KINK_FLIP_FRACTION * a.numel()), (key, n, a.numel())
+            va, vb = a[idx], b[idx]
+            worst = max(float(torch.where(va > 0, va, va / 0.02).abs().max()), float(torch.where(vb > 0, vb, vb / 0.02).abs().max()))
+            assert worst <= tie, (key, n, worst)
+            a[idx] = torch.where(vb > 0, torch.full_like(va, 1e-30), torch.full_like(va, -1e-30))
+        flips += n
+    pools = []
+    for key, src in POOL_KEYS:
+        ss, mx, st, am = cache[key]
+        ref = ref_cache[key][3]
+        diff = am != ref
+        n = int(diff.sum())
+        if n:
+            assert n <= POOL_MAX_FLIPS, (key, n)
+            B, C = am.shape
+            x = cache[src].reshape(B, -1, C)
+            if src == 'z':
+                x = x[:, T0:]
+            b, c = torch.nonzero(diff, as_tuple=True)
+            assert float((mx[b, c] - x[b, ref[b, c].long(), c]).abs().max()) < tie, key
+            cache[key] = (ss, mx, st, ref)
+        pools.append(n)
+    return flips, pools
+
+
+def _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, tag, gate=1.0, gp=None, forced=True):
     at = rs['trans_action_indicies'].long()
     lab = ((at[:, 0] * V + at[:, 1]) * V + at[:, 2]).int().to(DEV)
     dq = torch.empty((B, V ** 3), device=DEV)
@@ -126,14 +215,22 @@ def _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, tag, gate=1.0):
     assert abs(loss - float(g['loss'])) < 1e-4, (tag, loss, float(g['loss']))
     for p in enc.parameters():
         p.grad = None
-    if 'kink_tau' in g.files:
+    if not forced:
+        gp = None
+    elif eng.precision == 'fp32' and not eng.bwd_precision:
+        # exact-fp32 kernels: no forcing at all (round-5 advisor) -- their forward is within ~1e-6 of the reference's and every digest
+        # holds its gates at the product's OWN LeakyReLU / max-pool choices (20 fixtures x modes, profiles/r06_unforced_fp32.log)
+        gp = None
+    elif 'kink_tau' in g.files:
         print('%s: LeakyReLU choices near zero that differ from the reference run\'s (backward evaluated at the reference\'s): %d' % (tag, force_kinks(cache, g)))
+    if gp is not None:
+        print('%s: max-pool choices that differ from the reference run\'s (ties; backward evaluated at the reference\'s): %s' % (tag, force_pools(cache, gp, eng.T0)))
     eng.backward(cache, dq, d_o, d_arm)
     P = dict(enc.named_parameters())
     for prm in P.values():            # (a block an ablation leaves unused has no gradient: the reference's .grad is None there, the fixture holds zeros)
         if prm.grad is None:
             prm.grad = torch.zeros_like(prm)
-    bad, worst = [], 0.0
+    bad, worst, ratio = [], 0.0, 0.0
     for n, rn in zip([str(n) for n in g['grad_names']], T(g['grad_norms'])):
         gn, rn = float(P[n].grad.norm()), float(rn)
         key64 = 'dysum64__' + n
@@ -152,11 +249,13 @@ def _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, tag, gate=1.0):
             # by up to 4.0e-3 (final; 5.8e-3 and 1.4e-2 on the V = 100 fixtures), ours by at most 2.0e-3 (input_preprocess -- the same
             # 2.0e-3 from the exact-fp32 kernels and from the fused default-precision ones, two unrelated kernel families; on the V = 100
             # fixtures that tensor is at 3.8e-4 / 1.3e-3 with the reference's fp32 at 1.2e-3 / 1.7e-3))
-            size = max(1.0, (V / 100.0) ** 1.5)
+            size = max(1.0, (V / 100.0) ** 1.5) * gate
+            ratio = max(ratio, e / (size * (2e-3 * float(ref.abs().max()) + 2e-5)) * gate)
             if e > size * (2e-3 * float(ref.abs().max()) + 2e-5):
                 bad.append((n, 'vs float64 dY sum', e, float(ref.abs().max())))
             continue
         rel = abs(gn - rn) / (rn + 1e-12)
+        ratio = max(ratio, abs(gn - rn) / (3e-3 * rn + 1e-5))
         if abs(gn - rn) > gate * 3e-3 * rn + 1e-5:
             bad.append((n, gn, rn))
         elif rn > 1e-4:
@@ -165,13 +264,27 @@ def _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, tag, gate=1.0):
         if key in g.files:
             ref = T(g[key])
             e = float((P[n].grad.float().cpu() - ref).abs().max())
+            ratio = max(ratio, e / (3e-3 * float(ref.abs().max()) + 1e-5))
             if e > gate * 3e-3 * float(ref.abs().max()) + 1e-5:
                 bad.append((n, 'full', e, float(ref.abs().max())))
-    print('%s: loss %.6f (reference %.6f), worst grad-norm rel. error %.2e' % (tag, loss, float(g['loss']), worst))
+    print('%s: loss %.6f (reference %.6f), worst grad-norm rel. error %.2e, worst tensor at %.2f x its gate%s' % (
+        tag, loss, float(g['loss']), worst, ratio, '' if forced else ' (UN-FORCED: the product\'s own LeakyReLU / max-pool choices)'))
     assert not bad, (tag, bad)
+    return ratio
 
 
-def _run(g, precision, tag, backward, bwd_precision='', wgrad_precision=None, gate=1.0):
+def _pools_of(g):
+    """the *_pools.npz supplement of a gradient digest (the reference run's max-pool choices), found by the forward it belongs to"""
+    import glob
+    import os
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', '*_pools.npz'))):
+        gp = np.load(f, allow_pickle=False)
+        if 'q_trans_lse' in g.files and gp['q_trans_lse'].shape == g['q_trans_lse'].shape and np.array_equal(gp['q_trans_lse'], g['q_trans_lse']):
+            return gp
+    return None
+
+
+def _run(g, precision, tag, backward, bwd_precision='', wgrad_precision=None, gate=1.0, forced=True):
     enc, rs, grid, arm, V, B = _setup(g)
     _check_grid(g, grid)
     eng = enc.engine()
@@ -184,7 +297,8 @@ def _run(g, precision, tag, backward, bwd_precision='', wgrad_precision=None, ga
                               lang_goal_emb=rs['lang_goal_emb'].to(DEV))
     errs = _check_forward(g, outs, arm, '%s/%s' % (tag, precision))
     if backward:
-        _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, '%s/%s' % (tag, precision), gate=gate)
+        errs['worst_x_gate'] = _loss_and_backward(g, enc, eng, rs, outs, cache, arm, V, B, '%s/%s' % (tag, precision), gate=gate,
+                                                  gp=_pools_of(g), forced=forced)
     del cache, outs
     torch.cuda.empty_cache()
     return errs
@@ -222,6 +336,20 @@ def test_c2_b8_forward_backward_digest_at_the_headline_dispatch(golden, precisio
     g = golden('f5gb8_encoder_c2_b8_grads')
     assert int(g['cfg_B']) * int(g['cfg_latents']) >= ops.WIDE_MIN_M
     _run(g, precision, 'f5gb8', backward=True)
+
+
+UNFORCED_GATE = 20.0         # x the 3e-3 gates = 6 %: what ONE max-pool tie costs (measured 14.5 x on F5c3; rounds 4 - 5 allowed 10 %)
+
+
+@pytest.mark.parametrize('fixture', ['f5g_encoder_c2_grads', 'f5c3_encoder_c3_digest', 'f5gb8_encoder_c2_b8_grads'])
+def test_unforced_choices_on_the_headline_fixtures(golden, fixture):
+    """On record (round-5 advisor: "keep one unforced reference-gate run per headline fixture"): the default precision's backward at the
+    product's OWN LeakyReLU / max-pool choices against the reference's gradients.  A forward that is ~2e-5 from the reference's lands a
+    few thousand of 10^8 near-zero pre-activations on the other side and, on F5c3, one of 512 pool arg-maxima on the other of two voxels
+    that are 1.1e-6 apart in the reference's own run -- that single choice is 4.4 % of `decoder_cross_attn.fn.to_out.weight`'s largest
+    element.  Bounded at UNFORCED_GATE x the regular gates; the forced runs above hold 1 x."""
+    r = _run(golden(fixture), 'bf16x3', fixture[:5] + '|unforced', backward=True, gate=UNFORCED_GATE, forced=False)
+    print('%s un-forced: worst tensor at %.2f x the regular gate' % (fixture, r['worst_x_gate']))
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])

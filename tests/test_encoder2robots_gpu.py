@@ -23,7 +23,7 @@ def maxerr(a, b):
     return float((a.detach().float().cpu() - b.detach().float().cpu()).abs().max())
 
 
-def run(g, cams, precision, norm_tol=3e-3, elem_tol=3e-3, flips=0):
+def run(g, cams, precision, norm_tol=3e-3, elem_tol=3e-3, flips=0, choices=None):
     V, B = int(g['cfg_V']), int(g['cfg_B'])
     enc = PerceiverVoxelLang2RobotsEncoder(
         depth=int(g['cfg_depth']), iterations=1, voxel_size=V, initial_dim=10, low_dim_size=int(g['cfg_low_dim']),
@@ -85,6 +85,12 @@ def run(g, cams, precision, norm_tol=3e-3, elem_tol=3e-3, flips=0):
     assert abs(loss - float(g['loss'])) < 1e-4, (loss, float(g['loss']))
     for p in enc.parameters():
         p.grad = None
+    if choices is not None and precision != 'fp32':
+        # the backward at the reference run's LeakyReLU / max-pool choices (fixture supplement *_pools.npz, round 6), as the single-arm digests
+        from tests.test_c2_reference_gpu import force_kinks, force_pools
+        assert np.array_equal(choices['q_trans_lse'], g['q_trans_right_lse'])             # (the supplement of THIS forward)
+        print('%s: LeakyReLU choices near zero that differ from the reference run\'s %d, max-pool ties %s' % (
+            precision, force_kinks(cache, choices), force_pools(cache, choices, eng.T0)))
     eng.backward(cache, dq_r, do_r, dq_trans_left=dq_l, d_o_left=do_l)
     P = dict(enc.named_parameters())
     bad, worst = [], 0.0
@@ -130,13 +136,10 @@ def test_2robots_c1(golden, precision):
 def test_2robots_headline_size_digest(golden, precision):
     """V=100, depth 6, 2048 latents (BASELINE.json configs[1] geometry) with the 192-wide context and both head sets:
     forward digests, summed two-arm loss, every parameter gradient."""
-    if precision == 'fp32':
-        run(golden('f11c2_encoder_2robots_c2_digest'), synthetic.CAMERAS4, precision)      # worst gradient norm 1.4e-4
-    else:
-        # bf16x3 backward at this size (measured): gradient norms within 4.2e-3, elements within 1.6 % of the tensor's largest
-        # (worst: the 64 x 10 weight of the first 1x1x1 conv, which collects the SpatialSoftmax gradient of all 10^6 voxels).
-        # The forward differs from fp32 by ~1e-5 on `u`; SpatialSoftmax3D divides by its temperature 0.01 (network_utils.py
-        # :797-809), so its softmax weights -- and every gradient behind them -- carry ~1e-3 relative.  One element of the
-        # B = 1 head MLP (|h0| = 2.5e-7) lands on the other side of LeakyReLU's kink: its gradient differs by the slope ratio.
-        run(golden('f11c2_encoder_2robots_c2_digest'), synthetic.CAMERAS4, precision, norm_tol=5e-3, elem_tol=2e-2, flips=1)
+    # round 6: the fixture's supplement carries the reference run's LeakyReLU choices near zero and its max-pool arg-maxima, and with the
+    # backward evaluated there the default precision holds the SAME gates as exact fp32 (3e-3 on norms and on the small tensors in full, no
+    # element exempted).  Rounds 2 - 5 ran this digest at 5e-3 / 2e-2 with one exempted element and read the differences as SpatialSoftmax3D's
+    # 1 / 0.01 temperature amplifying a 1e-5 forward difference; they were kinks (13 752 pre-activations of u0 lie within 3e-5 of zero) and
+    # one pool whose two largest voxels are 6e-7 apart.  fp32: un-forced.
+    run(golden('f11c2_encoder_2robots_c2_digest'), synthetic.CAMERAS4, precision, choices=golden('f11c2_encoder_2robots_c2_digest_pools'))
     torch.cuda.empty_cache()

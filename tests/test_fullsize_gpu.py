@@ -2,7 +2,7 @@
 size-independent properties of the whole path through the C ABI.  The reference cannot run here and the CPU oracle
 needs ~6 s per sample at this size, so the checks are (a) two independent kernel families agreeing -- the default
 'bf16x3' precision against the exact-fp32 matrix-core kernels -- inside the 1e-4 north-star bound on every Q head and
-inside 1e-2 (max and L2, relative) on every parameter gradient -- activation-mask flips, see below, (b) run-to-run determinism, (c) occupancy bookkeeping
+inside 4e-3 (max and L2, relative) on every parameter gradient with the backward evaluated at the exact-fp32 run's LeakyReLU / max-pool choices, see below, (b) run-to-run determinism, (c) occupancy bookkeeping
 of the voxel grid that feeds it."""
 import numpy as np
 import pytest
@@ -14,6 +14,7 @@ from voxactb_amd import synthetic
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 V, B, HW = 100, 2, 128
+GRAD_GATE = 4e-3          # measured 2.0e-3 max / 1.2e-3 L2 (round 6, backward at the exact-fp32 run's choices); rounds 1 - 5: 1e-2 un-aligned
 
 
 @pytest.fixture(scope='module')
@@ -51,11 +52,14 @@ def test_voxel_grid_bookkeeping(rig):
     assert torch.equal(again, g)                                    # deterministic, bit for bit
 
 
-def _run(eng, rig, mode, backward):
+def _run(eng, rig, mode, backward, choices_of=None, keep_cache=False):
     eng.precision = mode
     outs, cache = eng.forward(rig['grid'], rig['prop'], rig['lang'], training=False, save=backward)
     outs = [o.float().clone() for o in outs[:3]]
     grads = None
+    if backward and choices_of is not None:
+        from tests.test_c2_reference_gpu import align_choices
+        print('%s backward at the %s run\'s choices: LeakyReLU flips %d, max-pool ties %s' % ((mode, choices_of[0]) + align_choices(cache, choices_of[1], eng.T0)))
     if backward:
         arena = rig['qa']._arena
         arena.zero_grad()
@@ -64,6 +68,8 @@ def _run(eng, rig, mode, backward):
         d_o = torch.randn_like(cache['o']) * 1e-1
         eng.backward(cache, dq, d_o, None)
         grads = {n: p.grad.clone() for n, p in rig['qa']._q.named_parameters()}
+    if keep_cache:
+        return outs, grads, cache
     return outs, grads
 
 
@@ -71,9 +77,11 @@ def test_q_values_and_gradients_agree_across_kernel_families(rig):
     eng = rig['eng']
     keep = eng.precision
     try:
-        o3, g3 = _run(eng, rig, 'bf16x3', True)
+        o1, g1, c1 = _run(eng, rig, 'fp32', True, keep_cache=True)
+        o3, g3 = _run(eng, rig, 'bf16x3', True, choices_of=('fp32', c1))
+        del c1
+        torch.cuda.empty_cache()
         o3b, _ = _run(eng, rig, 'bf16x3', False)
-        o1, g1 = _run(eng, rig, 'fp32', True)
     finally:
         eng.precision = keep
     for a, b in zip(o3, o3b):
@@ -95,10 +103,11 @@ def test_q_values_and_gradients_agree_across_kernel_families(rig):
         report.append((err, l2, n))
     report.sort(reverse=True)
     print('\n'.join('%.2e max-rel  %.2e l2-rel  %s' % r for r in report[:12]))
-    # 1e-5 differences in the forward flip the LeakyReLU mask / max-pool winner of the ~1e-5 fraction of activations that sit
-    # that close to the kink; each flip changes a gradient term by O(1), i.e. ~sqrt(1e-5) = 3e-3 in relative L2 -- the same
-    # effect bounds the fixture-based gradient tests (tests/test_encoder_gpu.py, 3e-3 at small sizes)
-    assert report[0][0] < 1e-2 and max(r[1] for r in report) < 1e-2, report[0]
+    # 1e-5 differences in the forward flip the LeakyReLU mask / max-pool winner of the ~1e-5 fraction of activations that sit that close
+    # to the kink; each flip changes a gradient term by O(1).  Rounds 1 - 5 bounded that at 1e-2; since round 6 the default precision's
+    # backward is evaluated at the exact-fp32 run's choices (align_choices: every replaced choice is asserted to be a tie within 1e-4),
+    # which leaves the arithmetic alone
+    assert report[0][0] < GRAD_GATE and max(r[1] for r in report) < GRAD_GATE, report[0]
     assert worst > 0.0                                              # (two different kernel families really ran)
 
 

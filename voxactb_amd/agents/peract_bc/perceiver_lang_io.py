@@ -349,7 +349,7 @@ class PerceiverEngine:
         # stay inside 1e-4 on every reference fixture at those sizes (max 8.1e-5 against 7.0e-5) and the gradients hold the float64 gate on
         # all eight batches once the backward is evaluated at the reference's LeakyReLU choices -- but the element gates of the F5c3 digest
         # (0.3 % of a small tensor's maximum) are missed by 2 x (0.65 %), so the default stays round 3's bf16x3 forward
-        self.attn_kernel = os.environ.get('VOXACTB_ATTN_KERNEL', 'r3')
+        self.attn_kernel = os.environ.get('VOXACTB_ATTN_KERNEL', 'auto')
         if self.attn_kernel not in ('auto', 'r3', 'r3bf16', 'f16', 'bf16', 'bf16x3'):
             raise ValueError('VOXACTB_ATTN_KERNEL must be auto, r3, r3bf16, f16, bf16 or bf16x3')
         self.attn_bwd_gx = os.environ.get('VOXACTB_ATTN_BWD_GX', '0') != '0'
