@@ -517,6 +517,21 @@ int vxb_flash2_attn_bwd(const float* q, const float* kv, const float* o, const f
                         int mode, int gx, float* dq, float* dkv, void* ws, int B, int H, int Nq, int Nk, int head_dim, float scale,
                         float dropout_p, uint32_t seed, int which, vxb_stream_t stream);
 
+/* Round 6: the dropout mask as DATA.  The forward's threshold compares leave one 64-bit lane mask per score register in an SGPR pair; with
+ * dropout_p > 0 vxb_flash2_attn_fwd_mask also stores those pairs (scalar stores, no vector-ALU work) as "keep words" -- bit q of word
+ * [b * H + h][32-row block][64-key tile][kb][r][half] = query row 32 block + q keeps key 64 tile + 32 kb + (r & 3) + 8 (r >> 2) + 4 half --
+ * and vxb_flash2_attn_bwd_mask reads them (dQ kernel: scalar loads straight into v_cndmask; dK | dV kernel: one word per lane and 32 rows)
+ * instead of hashing (seed, row, key) again: the same mask bit for bit, 9 - 15 vector instructions per score pair less in the backward.
+ * drop_mask: vxb_flash2_drop_mask_bytes(B, H, Nq, Nk) bytes, 256-byte aligned, written by the forward call and read by the backward call of
+ * the same (B, H, Nq, Nk).  modes 0 / 1 only.  Everything else as vxb_flash2_attn_fwd / vxb_flash2_attn_bwd (Attention.forward's dropout,
+ * perceiver_lang_io.py:124-128). */
+size_t vxb_flash2_drop_mask_bytes(int B, int H, int Nq, int Nk);
+int vxb_flash2_attn_fwd_mask(const float* q, const void* kv_planes, int mode, float* o, float* lse, void* drop_mask, int B, int H, int Nq, int Nk,
+                             int head_dim, float scale, float dropout_p, uint32_t seed, int waves, vxb_stream_t stream);
+int vxb_flash2_attn_bwd_mask(const float* q, const float* kv, const float* o, const float* d_o, const float* lse, const void* kv_plane,
+                             const void* drop_mask, int mode, int gx, float* dq, float* dkv, void* ws, int B, int H, int Nq, int Nk, int head_dim,
+                             float scale, float dropout_p, uint32_t seed, int which, vxb_stream_t stream);
+
 /* Forward with k | v as bf16 planes [nplanes][B*Nk][2*H*64] (vxb_split_bf16_f32 of the to_kv output): K/V tiles go
  * global -> LDS directly (double-buffered, one barrier per 64-key tile).  Same outputs / dropout mask as the entries above. */
 int vxb_flash_attn_fwd_dl(const float* q, const void* kv_planes, int nplanes, float* o, float* lse, int B, int H, int Nq,

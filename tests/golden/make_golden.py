@@ -476,6 +476,58 @@ def grad_noise_fixture(name, cfg, seed, arm=False, crop=False, nproj=16):
     save(name, **arrs)
 
 
+def kink_statistics(name, cfg, seeds, nproj=16):
+    """Round 6 (round-5 review, item 7: "quantify the kink effect instead of only explaining it"): the reference encoder in fp32 AND in
+    float64 on MANY seeded batches of one geometry, slim per batch -- per parameter tensor ||g64||, ||g32 - g64|| (exact: the reference's
+    own un-forced fp32 error against float64) and `nproj` +-1 projections of g64, from which tools/experiments/kink_statistics_gpu.py
+    estimates ||g - g64|| of the PRODUCT's un-forced gradient in each arithmetic.  Resumable: one temporary file per seed."""
+    part_dir = os.path.join(HERE, '_' + name)
+    os.makedirs(part_dir, exist_ok=True)
+    for seed in seeds:
+        part = os.path.join(part_dir, 's%d.npz' % seed)
+        if os.path.exists(part):
+            continue
+        enc, sd = make_ref_encoder(cfg)
+        rs = batch_for(cfg, seed=seed)
+        pcd = [rs['%s_point_cloud' % c] for c in cfg['cams']]
+        rgb = [rs['%s_rgb' % c] for c in cfg['cams']]
+        bounds = torch.tensor([synthetic.SCENE_BOUNDS])
+        coords, feats = ovox.flatten_cameras(pcd, rgb)
+        grid = ref_voxelize(coords, feats, bounds, cfg['V'], cfg['B'])
+        ins = grid.permute(0, 4, 1, 2, 3).detach()
+        res = {}
+        t0 = time.time()
+        for dt in (torch.float32, torch.float64):
+            torch.nn.functional.conv3d = _chunked_conv3d_f64 if dt == torch.float64 else _ORIG_CONV3D
+            try:
+                enc = enc.to(dt)
+                for p in enc.parameters():
+                    p.requires_grad_(True)
+                    p.grad = None
+                outs = enc(ins.to(dt), rs['low_dim_state'].to(dt), rs['lang_goal_emb'].to(dt), rs['lang_token_embs'].to(dt), None, bounds, None)
+                total, _ = oagent.losses(outs[0], outs[1], outs[2], rs['trans_action_indicies'], rs['rot_grip_action_indicies'], rs['ignore_collisions'])
+                total.backward()
+            finally:
+                torch.nn.functional.conv3d = _ORIG_CONV3D
+            res[dt] = dict(loss=total.detach().double(), grads={n: p.grad.detach().double().clone() for n, p in enc.named_parameters()})
+            del outs, total
+        names = list(res[torch.float64]['grads'])
+        g64, g32 = res[torch.float64]['grads'], res[torch.float32]['grads']
+        np.savez_compressed(part, seed=seed, loss64=res[torch.float64]['loss'].numpy(), loss32=res[torch.float32]['loss'].numpy(),
+                            grad_names=np.array(names),
+                            grad_norm64=torch.stack([g64[n].norm() for n in names]).numpy(),
+                            grad_err32=torch.stack([(g32[n] - g64[n]).norm() for n in names]).numpy(),
+                            grad_proj64=torch.stack([ow.project(g64[n], n, nproj) for n in names]).numpy())
+        rel = sorted(((float((g32[n] - g64[n]).norm() / (g64[n].norm() + 1e-300)), n) for n in names if float(g64[n].norm()) > 1e-6), reverse=True)
+        print('%s seed %d: %.0fs; reference fp32 vs float64, worst tensors: %s' % (name, seed, time.time() - t0, ', '.join('%s %.1e' % (n, e) for e, n in rel[:3])), flush=True)
+    parts = [np.load(os.path.join(part_dir, 's%d.npz' % sd_), allow_pickle=False) for sd_ in seeds]
+    save(name, cfg_V=cfg['V'], cfg_k=cfg['k'], cfg_s=cfg['s'], cfg_depth=cfg['depth'], cfg_latents=cfg['latents'], cfg_low_dim=cfg['low_dim'],
+         cfg_B=cfg['B'], cfg_H=cfg['H'], cfg_W=cfg['W'], cfg_ncam=len(cfg['cams']), nproj=nproj, seeds=np.array(list(seeds)),
+         grad_names=parts[0]['grad_names'], loss64=np.stack([p['loss64'] for p in parts]), loss32=np.stack([p['loss32'] for p in parts]),
+         grad_norm64=np.stack([p['grad_norm64'] for p in parts]), grad_err32=np.stack([p['grad_err32'] for p in parts]),
+         grad_proj64=np.stack([p['grad_proj64'] for p in parts]))
+
+
 def grad_noise_kinks(name, cfg, seed, arm=False, crop=False):
     """Supplement of grad_noise_fixture (same encoder, same batch): the FLOAT64 forward's pre-activations within KINK_TAU of zero at every
     grid-sized LeakyReLU (capture_kinks) -- the subgradient choices of the run whose gradients f5n_noise_* holds.  Forward only."""
@@ -1273,6 +1325,8 @@ SECTIONS = {
     'f5p_f5v50b': lambda: pool_choices('f5v50b_encoder_release_digest', CFG_V50B, arm=True, crop=True),
     'f5p_f5v200g': lambda: pool_choices('f5v200g_encoder_c5_grads', CFG_C5, slabs=True),
     'f5p_f11c2': lambda: pool_choices_2robots('f11c2_encoder_2robots_c2_digest', CFG_C2),
+    # 32 seeded configs[1] batches, reference fp32 and float64, slim (round 6; ~5 minutes of the build container per batch)
+    'f5s_c2': lambda: kink_statistics('f5s_kink_statistics_c2', CFG_C2, range(1, 33)),
     'f11tiny': lambda: encoder2_fixture('f11_encoder_2robots_tiny', CFG_TINY),
     'f11c1': lambda: encoder2_fixture('f11_encoder_2robots_c1', CFG_C1),
     'f11c2': lambda: encoder2_fixture('f11c2_encoder_2robots_c2_digest', CFG_C2, digest=True),

@@ -94,3 +94,37 @@ def test_zero_gradient_and_which():
     _, b = flash.flash2_attn_bwd(q, kv, o, d_o, lse, pl, B, H, Nq, Nk, 0.125, 0.0, 1, mode='f16', gx=False, which=2)
     c, d = flash.flash2_attn_bwd(q, kv, o, d_o, lse, pl, B, H, Nq, Nk, 0.125, 0.0, 1, mode='f16', gx=False, which=3)
     assert torch.equal(a, c) and torch.equal(b, d)
+
+
+@pytest.mark.parametrize('shape', SHAPES + [(2, 8, 2048, 2048), (1, 1, 100, 77)])
+@pytest.mark.parametrize('mode,gx', [('f16', False), ('f16', True), ('bf16', False)])
+def test_stored_dropout_mask_equals_the_regenerated_one(shape, mode, gx, monkeypatch):
+    """Round 6: the forward stores the dropout keep words (scalar stores of the compare results), the backward reads them.  The mask is the
+    SAME function of (seed, row, key) either way, so with and without the stored words the forward outputs are identical and dQ, dK | dV are
+    bit-identical -- any wrong word, bit position or layout index of the dQ kernel's scalar loads or of the dK | dV kernel's per-lane words
+    would drop other scores and differ by O(1).  Ragged shapes: row blocks / key tiles past the end, 8077-long contexts."""
+    B, H, Nq, Nk = shape
+    q, kv = _data(B, H, Nq, Nk, 0)
+    d_o = torch.randn(B * Nq, H * 64, device=DEV) * 1e-3
+    pl = flash.kv_planes(kv, mode)
+    monkeypatch.setattr(flash, 'DROP_MASK', '2')            # (store the words at every size: the product only does where the grid fills the chip)
+    o0, lse0 = flash.flash2_attn_fwd(q, kv, B, H, Nq, Nk, 0.125, 0.1, 7, mode=mode, planes=pl)
+    o1, lse1, mask = flash.flash2_attn_fwd(q, kv, B, H, Nq, Nk, 0.125, 0.1, 7, mode=mode, planes=pl, return_mask=True)
+    assert mask is not None
+    assert torch.equal(o0, o1) and torch.equal(lse0, lse1)
+    dq0, dkv0 = flash.flash2_attn_bwd(q, kv, o0, d_o, lse0, pl, B, H, Nq, Nk, 0.125, 0.1, 7, mode=mode, gx=gx)
+    dq1, dkv1 = flash.flash2_attn_bwd(q, kv, o0, d_o, lse0, pl, B, H, Nq, Nk, 0.125, 0.1, 7, mode=mode, gx=gx, drop_mask=mask)
+    assert torch.isfinite(dq1).all() and torch.isfinite(dkv1).all()
+    assert torch.equal(dq0, dq1), float((dq0 - dq1).abs().max())
+    assert torch.equal(dkv0, dkv1), float((dkv0 - dkv1).abs().max())
+    # the keep rate of the stored words (valid rows x keys only) is 1 - p
+    nrb, ntile = (Nq + 255) // 256 * 8, (Nk + 63) // 64
+    w = mask[:B * H * nrb * ntile * 64].view(B * H, nrb, ntile, 2, 16, 2)
+    bits = ((w.unsqueeze(-1) >> torch.arange(32, device=DEV, dtype=torch.int32)) & 1).bool()           # [bh, rb, tile, kb, r, half, row]
+    r = torch.arange(16, device=DEV)
+    key = (torch.arange(ntile, device=DEV)[:, None, None, None] * 64 + torch.arange(2, device=DEV)[None, :, None, None] * 32
+           + ((r & 3) + 8 * (r >> 2))[None, None, :, None] + 4 * torch.arange(2, device=DEV)[None, None, None, :])         # [tile, kb, r, half]
+    row = torch.arange(nrb, device=DEV)[:, None] * 32 + torch.arange(32, device=DEV)[None, :]                              # [rb, row]
+    valid = (key < Nk)[None, None, :, :, :, :, None] & (row < Nq)[None, :, None, None, None, None, :]
+    rate = float(bits[valid.expand_as(bits)].float().mean())
+    assert abs(rate - (1.0 - 6553.0 / 65536.0)) < 4.0 * (0.09 / float(valid.sum() * B * H)) ** 0.5 + 1e-3, rate

@@ -1,0 +1,114 @@
+"""How often, and how far, does a forward arithmetic's choice of LeakyReLU / max-pool subgradients move the parameter gradients?  (GPU; round 6,
+round-5 review item 7.)
+
+tests/golden/f5s_kink_statistics_c2.npz (make_golden.py: kink_statistics) holds, for 32 seeded batches of BASELINE.json configs[1] geometry
+(B = 1), the reference's float64 gradients as 16 random projections per tensor and the reference's own fp32 error against them.  This script
+runs the product UN-FORCED (its own subgradient choices) on the same batches in every arithmetic it ships and estimates ||g - g64|| / ||g64||
+per tensor from the projections (+-18 %), then prints per arithmetic: the median over batches of the median / worst tensor, and the number of
+batches in which any tensor is more than 0.5 % / 2 % / 10 % from float64.
+
+    python tools/experiments/kink_statistics_gpu.py [--max-seeds N]
+"""
+import glob
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import weights as ow                               # noqa: E402
+from voxactb_amd import ops                                     # noqa: E402
+import tests.test_c2_reference_gpu as T                        # noqa: E402
+
+DEV = 'cuda:0'
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+class G(dict):
+    @property
+    def files(self):
+        return list(self.keys())
+
+
+def load():
+    full = os.path.join(GOLDEN, 'f5s_kink_statistics_c2.npz')
+    if os.path.exists(full):
+        g = np.load(full, allow_pickle=False)
+        return {k: g[k] for k in g.files}
+    parts = sorted(glob.glob(os.path.join(GOLDEN, '_f5s_kink_statistics_c2', 's*.npz')), key=lambda p: int(os.path.basename(p)[1:-4]))
+    assert parts, 'no fixture: python tests/golden/make_golden.py --only f5s_c2'
+    ps = [np.load(p, allow_pickle=False) for p in parts]
+    out = dict(cfg_V=100, cfg_k=5, cfg_s=5, cfg_depth=6, cfg_latents=2048, cfg_low_dim=4, cfg_B=1, cfg_H=128, cfg_W=128, cfg_ncam=4, nproj=16,
+               seeds=np.array([int(p['seed']) for p in ps]), grad_names=ps[0]['grad_names'])
+    for k in ('loss64', 'loss32', 'grad_norm64', 'grad_err32', 'grad_proj64'):
+        out[k] = np.stack([p[k] for p in ps])
+    return out
+
+
+def product_errors(d, si, precision, attn_kernel):
+    g = G({k: d[k] for k in d if k.startswith('cfg_')})
+    g['cfg_arm'] = np.array(0)
+    g['cfg_seed'] = np.array(int(d['seeds'][si]))
+    enc, rs, grid, arm, V, B = T._setup(g)
+    eng = enc.engine()
+    eng.precision = precision
+    eng.attn_kernel = attn_kernel
+    outs, cache = eng.forward(grid, rs['low_dim_state'].to(DEV), rs['lang_token_embs'].to(DEV), training=False, save=True)
+    at = rs['trans_action_indicies'].long()
+    lab = ((at[:, 0] * V + at[:, 1]) * V + at[:, 2]).int().to(DEV)
+    dq = torch.empty((B, V ** 3), device=DEV)
+    l_t, _, _ = ops.ce_big(outs[0].view(B, -1), lab, dq, 1.0 / B)
+    labs = torch.cat([rs['rot_grip_action_indicies'].int(), rs['ignore_collisions'].int()[:, :1]], 1).to(DEV).contiguous()
+    d_o = torch.empty_like(cache['o'])
+    l_h, _ = ops.ce_rows(cache['o'], [(0, 72), (72, 72), (144, 72), (216, 2), (218, 2)], labs, d_o, 1.0 / B)
+    loss = float((l_t + l_h.sum(1)).mean())
+    for p in enc.parameters():
+        p.grad = None
+    eng.backward(cache, dq, d_o, None)
+    P = dict(enc.named_parameters())
+    nproj = int(d['nproj'])
+    rel = []
+    n64 = d['grad_norm64'][si]
+    for i, n in enumerate([str(x) for x in d['grad_names']]):
+        if n64[i] <= 1e-6 * n64.max():
+            continue
+        est = float(ow.projection_error(ow.project(P[n].grad, n, nproj), torch.from_numpy(d['grad_proj64'][si][i])))
+        rel.append(est / n64[i])
+    del cache, outs
+    torch.cuda.empty_cache()
+    return np.array(rel), loss
+
+
+def main():
+    d = load()
+    ns = len(d['seeds'])
+    for a in sys.argv[1:]:
+        if a.startswith('--max-seeds='):
+            ns = min(ns, int(a.split('=')[1]))
+    rows = {'reference fp32 (CPU, exact)': []}
+    for si in range(ns):
+        n64 = d['grad_norm64'][si]
+        keep = n64 > 1e-6 * n64.max()
+        rows['reference fp32 (CPU, exact)'].append(d['grad_err32'][si][keep] / n64[keep])
+    modes = [('product exact fp32', 'fp32', 'r3'), ('product bf16x3, attention forward bf16x3 (default of rounds 3 - 5)', 'bf16x3', 'r3'),
+             ('product bf16x3, attention forward 1x fp16 (default)', 'bf16x3', 'auto')]
+    for name, prec, attn in modes:
+        rows[name] = []
+        for si in range(ns):
+            rel, loss = product_errors(d, si, prec, attn)
+            rows[name].append(rel)
+            print('seed %2d  %-72s loss %.6f (f64 %.6f)  median %.2e  worst %.2e' % (int(d['seeds'][si]), name, loss, float(d['loss64'][si]), float(np.median(rel)), float(rel.max())), flush=True)
+    print('\n%d batches of configs[1] geometry (B = 1), UN-FORCED, relative L2 error of every parameter gradient against the float64 reference' % ns)
+    print('%-74s %10s %10s %10s | batches with a tensor beyond 0.5 %% / 2 %% / 10 %%' % ('arithmetic', 'med(med)', 'med(worst)', 'max(worst)'))
+    for name, rr in rows.items():
+        med = np.array([np.median(r) for r in rr])
+        worst = np.array([r.max() for r in rr])
+        print('%-74s %10.2e %10.2e %10.2e | %d / %d / %d of %d' % (name, np.median(med), np.median(worst), worst.max(), int((worst > 5e-3).sum()),
+                                                                  int((worst > 2e-2).sum()), int((worst > 1e-1).sum()), ns))
+
+
+if __name__ == '__main__':
+    main()

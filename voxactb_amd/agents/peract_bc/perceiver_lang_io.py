@@ -437,9 +437,11 @@ class PerceiverEngine:
         if (self.precision in ('bf16', 'bf16x3') and d == 64 and self.fused_attention
                 and (kern not in ('r3', 'r3bf16') or (self.precision == 'bf16' and kern == 'r3'))):
             mode = 'bf16' if self.precision == 'bf16' else kern
-            O, lse, kvp = flash.flash2_attn_fwd(q, kv, B, H, Nq, Nk, d ** -0.5, p, seed, mode=mode, return_planes=True)
+            # (save: the forward also stores the dropout keep words for the backward -- same mask, no second hash of it; flash.py)
+            O, lse, kvp, dmask = flash.flash2_attn_fwd(q, kv, B, H, Nq, Nk, d ** -0.5, p, seed, mode=mode, return_planes=True,
+                                                       return_mask=True, store_mask=bool(save))
             out = ops.linear(O, Wo, bo, residual=residual)
-            cache = dict(q=q, kv=kv, kvp=kvp, O=O, lse=lse, flash=2, mode=mode, dims=(B, Nq, Nk, H, d, 0), p=p, seed=seed) if save else None
+            cache = dict(q=q, kv=kv, kvp=kvp, O=O, lse=lse, flash=2, mode=mode, dims=(B, Nq, Nk, H, d, 0), p=p, seed=seed, dmask=dmask) if save else None
             return out, cache
         if self.precision in ('bf16', 'bf16x3') and d == 64 and self.fused_attention:
             # fused attention on the bf16 matrix cores, no [B*h, i, j] tensor (csrc/flash_attn.hip); 'bf16x3' carries
@@ -475,7 +477,7 @@ class PerceiverEngine:
                 mode = self.attn_bwd_kernel if self.attn_bwd_kernel in ('f16', 'bf16') else 'f16'
                 planes = flash.kv_planes(c['kv'], mode)
             dq, dkv = flash.flash2_attn_bwd(c['q'], c['kv'], c['O'], dO, c['lse'], planes, B, H, Nq, Nk, d ** -0.5, c['p'], c['seed'],
-                                            mode=mode, gx=self.attn_bwd_gx or B * H * Nq * Nk < (1 << 22))
+                                            mode=mode, gx=self.attn_bwd_gx or B * H * Nq * Nk < (1 << 22), drop_mask=c.get('dmask'))
             return self._attn_bwd_proj(pre, dq, dkv, xq2d, ctx2d, same_src)
         if c.get('flash') and self.attn_bwd_kernel in ('f16', 'bf16') and (self.bwd_precision or self.precision) != 'fp32':
             mode = 'bf16' if self.precision == 'bf16' else self.attn_bwd_kernel

@@ -43,6 +43,8 @@ struct F2bArgs {
     const unsigned* rowslots;   // [B*H][Nq64][4]
     const float* negd;     // [B*H][Nq64]  -2^k D
     const float* scale_ws; // [0] = 2^k, [1] = 2^-k
+    const unsigned* mask;  // DROP == 2: the forward's dropout keep words (flash2_fwd.hip: f2_store_keep), else unused
+    int nrb, ntile;        // 32-row blocks per (batch, head) and 64-key tiles per row block of that layout
     float* dq;
     float* dkv;
     int B, H, Nq, Nk, Nq64, nblk;
@@ -115,6 +117,16 @@ __device__ __forceinline__ void fb_split3(float x, unsigned& w01, unsigned& w2) 
     fb_unpack<MODE>(pm, m, z);
     w01 = (ph & 0xffffu) | (pm << 16);
     w2 = fb_pack<MODE>(r1 - m, 0.f) & 0xffffu;
+}
+
+// DROP == 2: the forward's keep words instead of the hash.  dQ kernel (lane = query, as the forward): the two SGPR pairs of a score pair come
+// back by scalar loads (constant address space: the compiler selects s_load and tracks lgkmcnt) and go straight into v_cndmask as lane masks.
+typedef unsigned fb_u4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) fb_u4 fb_c4;
+__device__ __forceinline__ float fb_sel(float if_set, float if_clear, unsigned long long lanes) {
+    float d;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(if_clear), "v"(if_set), "s"(lanes));
+    return d;
 }
 
 // ------------------------------------------------------------------------------------------------ preparation
@@ -297,6 +309,8 @@ __global__ void __launch_bounds__(NW * 64, 2) f2b_dq_kernel(F2bArgs g) {
     const unsigned thr = (unsigned)(g.p_drop * 65536.0f);
     const unsigned row_id = (unsigned)bh * (unsigned)g.Nq + (unsigned)qrow;
     const unsigned rowh = row_id * 0x9E3779B1U + g.seed;
+    // keep words of this wave's 32 rows (DROP == 2): 64 words per key tile, [kb][r][half]
+    const unsigned long long mwave = DROP == 2 ? (unsigned long long)(uintptr_t)(g.mask + ((size_t)bh * g.nrb + (size_t)(qblk * NW + wid)) * (size_t)g.ntile * 64) : 0ull;
     int rbase[2], rkey[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) { const int row = kb * 32 + lq; rbase[kb] = row * 64; rkey[kb] = fb_swz(row); }
@@ -324,11 +338,15 @@ __global__ void __launch_bounds__(NW * 64, 2) f2b_dq_kernel(F2bArgs g) {
         return fb_from4(one2, w1, 0u, 0u);
     };
     // element pair t = 0..7 of a unit: dS' = exp2(S') * (keep ? T' : -D'), packed hi (| lo)
-    auto pair = [&](int colb, int kb, int t, const f32x16& s, const f32x16& tt, unsigned (&ds)[NG][8]) {
+    auto pair = [&](int colb, const fb_u4 (&munit)[8], int kb, int t, const f32x16& s, const f32x16& tt, unsigned (&ds)[NG][8]) {
         const int r = 2 * t;
         const float p0 = __builtin_amdgcn_exp2f(s[r]), p1 = __builtin_amdgcn_exp2f(s[r + 1]);
         float t0 = tt[r], t1 = tt[r + 1];
-        if (DROP) {
+        if (DROP == 2) {
+            const fb_u4 w = munit[t];                       // words 4 t .. 4 t + 3 of the unit: the lane masks of registers r, r + 1
+            t0 = fb_sel(t0, negd, (unsigned long long)w.x | ((unsigned long long)w.y << 32));
+            t1 = fb_sel(t1, negd, (unsigned long long)w.z | ((unsigned long long)w.w << 32));
+        } else if (DROP) {
             const unsigned cp = (unsigned)((kb * 32 + (r & 3) + 8 * (r >> 2)) >> 1) * 0x85EBCA77U;
             const unsigned hsh = fb_hash(rowh ^ ((unsigned)colb + cp));
             t0 = (hsh & 0xffffu) >= thr ? t0 : negd;
@@ -348,6 +366,12 @@ __global__ void __launch_bounds__(NW * 64, 2) f2b_dq_kernel(F2bArgs g) {
                     const f32x16& sc_, const f32x16& tc_, unsigned (&dsc)[NG][8], const unsigned (&dsp)[NG][8]) {
         constexpr bool HN = decltype(has_n)::value, HC = decltype(has_c)::value, HD_ = decltype(has_d)::value;
         const int colb = (int)((unsigned)((ktc * BT + 4 * hi) >> 1) * 0x85EBCA77U + 0xC2B2AE3DU);
+        fb_u4 munit[8];                                     // the unit's 32 keep words: requested here (two s_load_dwordx16), used pair by pair
+        if (DROP == 2 && HC) {
+            fb_c4* const mp = (fb_c4*)(mwave + ((unsigned long long)ktc * 64 + (unsigned long long)kbc * 32) * 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) munit[i] = mp[i];
+        }
         bf16x8 kf[4], vf[4], tf[4];
         auto load_group = [&](int i) {
             if (HN) { kf[i] = row_frag(0, ktn, kbn, i); vf[i] = row_frag(VOFF, ktn, kbn, i); }
@@ -371,14 +395,14 @@ __global__ void __launch_bounds__(NW * 64, 2) f2b_dq_kernel(F2bArgs g) {
                 for (int p = 0; p < NG; ++p)
                     dqacc[db] = fb_mma<MODE>(tf[i], fb_from4(dsp[p][4 * ks], dsp[p][4 * ks + 1], dsp[p][4 * ks + 2], dsp[p][4 * ks + 3]), dqacc[db]);
             }
-            if (HC) pair(colb, kbc, 2 * i, sc_, tc_, dsc);
+            if (HC) pair(colb, munit, kbc, 2 * i, sc_, tc_, dsc);
             __builtin_amdgcn_sched_barrier(0);
             if (HN) {
                 sn = fb_mma<MODE>(kf[i], qf[i], sn);
 #pragma unroll
                 for (int p = 0; p < NG; ++p) tn = fb_mma<MODE>(vf[i], dof[p][i], tn);
             }
-            if (HC) pair(colb, kbc, 2 * i + 1, sc_, tc_, dsc);
+            if (HC) pair(colb, munit, kbc, 2 * i + 1, sc_, tc_, dsc);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -427,6 +451,7 @@ __global__ void __launch_bounds__(NW * 64, GX ? 1 : 2) f2b_dkv_kernel(F2bArgs g)
     constexpr int LPW = 8 / NW;
     constexpr int QOFF = 0, DOFF = NS * TILE, ROFF = DOFF + NS * NG * TILE;       // u16 offsets: Q ring | dO' ring | row fragments | -D' | zeros
     constexpr int NOFF = ROFF + NS * 512, ZOFF = NOFF + NS * 128;
+    constexpr int MOFF = ZOFF + 16;                 // DROP == 2: keep words of the tile's two 32-row blocks x this workgroup's 128 keys, 1 KB per stage
     constexpr int PF = GX ? 1 : 2;                  // fragment groups requested ahead (registers)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -468,6 +493,9 @@ __global__ void __launch_bounds__(NW * 64, GX ? 1 : 2) f2b_dkv_kernel(F2bArgs g)
     const u16* dbase_g = g.dop + (long long)b * g.Nq * inner + h * HD;
     const unsigned* rs_g = g.rowslots + (long long)bh * g.Nq64 * 4;
     const float* nd_g = g.negd + (long long)bh * g.Nq64;
+    const unsigned* mk_g = DROP == 2 ? g.mask + ((size_t)bh * g.nrb * (size_t)g.ntile + (size_t)kblk * (NW * 32 / BT)) * 64 : nullptr;
+    // this lane's word inside a row block's 128: key kk = wid * 32 + lk of the workgroup -> [tile kk / 64][kb][r][half] (flash2_fwd.hip)
+    const int mword = (wid >> 1) * 64 + (wid & 1) * 32 + (((lk & 3) | ((lk >> 3) << 2)) << 1) + ((lk >> 2) & 1);
     const unsigned rowb = 2u * (unsigned)inner;
     const unsigned planeb = (unsigned)(g.do_plane * 2);
     const unsigned smem0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
@@ -492,6 +520,9 @@ __global__ void __launch_bounds__(NW * 64, GX ? 1 : 2) f2b_dkv_kernel(F2bArgs g)
         const int qc = min(qt, nqt - 1) * BT;
         if (wid == 0) fb_load16(rs_g, (unsigned)((qc + lane) * 16), smem0 + (unsigned)((ROFF + st * 512) * 2));
         if (wid == 1 % NW) fb_load4(nd_g, (unsigned)((qc + lane) * 4), smem0 + (unsigned)((NOFF + st * 128) * 2));
+        // keep words: row blocks 2 qt, 2 qt + 1 (lanes 0 - 31 | 32 - 63) x the 128 words of this workgroup's two key tiles
+        if (DROP == 2 && wid == 2 % NW)
+            fb_load16(mk_g, (unsigned)(((2 * min(qt, nqt - 1) + (lane >> 5)) * g.ntile) * 256 + (lane & 31) * 16), smem0 + (unsigned)((MOFF + st * 512) * 2));
     };
     if (tid < 8) reinterpret_cast<unsigned*>(smem + ZOFF)[tid] = 0u;          // 32 bytes of zeros: the offset fragment of the hi = 1 lanes
 
@@ -519,11 +550,20 @@ __global__ void __launch_bounds__(NW * 64, GX ? 1 : 2) f2b_dkv_kernel(F2bArgs g)
         return fb_join(fb_tr16(ad + tlane[i & 1][0]), fb_tr16(ad + tlane[i & 1][1] + 8 * 64));
     };
     // element pair t of unit (qt, qb): rows ql, ql + 1 of this lane's key
-    auto pair = [&](int qt, int qb, int t, const f32x16& s, const f32x16& tt, const float* nd_tile, unsigned (&pp)[8], unsigned (&ds)[NG][8]) {
+    auto pair = [&](int qt, int qb, int mw, int t, const f32x16& s, const f32x16& tt, const float* nd_tile, unsigned (&pp)[8], unsigned (&ds)[NG][8]) {
         const int r = 2 * t;
         const float p0 = __builtin_amdgcn_exp2f(s[r]), p1 = __builtin_amdgcn_exp2f(s[r + 1]);
         float t0 = tt[r], t1 = tt[r + 1], pd0 = p0, pd1 = p1;
-        if (DROP) {
+        if (DROP == 2) {
+            // mw: the keep word of (row block, this lane's key) shifted right by 4 hi -> bit (r & 3) + 8 (r >> 2) is row r of this lane
+            int m0 = __builtin_amdgcn_sbfe(mw, (r & 3) + 8 * (r >> 2), 1), m1 = __builtin_amdgcn_sbfe(mw, ((r + 1) & 3) + 8 * ((r + 1) >> 2), 1);
+            asm("" : "+v"(m0), "+v"(m1));                   // (opaque 0 / -1: otherwise the bit selects below become compare + v_cndmask pairs, six instructions per score)
+            const float2 nd = *reinterpret_cast<const float2*>(nd_tile + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
+            t0 = __int_as_float((m0 & __float_as_int(t0)) | (~m0 & __float_as_int(nd.x)));
+            t1 = __int_as_float((m1 & __float_as_int(t1)) | (~m1 & __float_as_int(nd.y)));
+            pd0 = __int_as_float(m0 & __float_as_int(p0));
+            pd1 = __int_as_float(m1 & __float_as_int(p1));
+        } else if (DROP) {
             const unsigned row0 = (unsigned)bh * (unsigned)g.Nq + (unsigned)(qt * BT + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
             // the mask word of (row, key pair) covers this lane's key and its neighbour's: the even lane hashes row0, the odd lane
             // row0 + 1, and the two swap words (one DPP move) instead of hashing both
@@ -565,6 +605,7 @@ __global__ void __launch_bounds__(NW * 64, GX ? 1 : 2) f2b_dkv_kernel(F2bArgs g)
 #pragma unroll
         for (int i = 0; i < PF; ++i) load_group(i);
         const float* nd = reinterpret_cast<const float*>(smem + NOFF + stc * 128);
+        const int mw = (DROP == 2 && HC) ? (int)(*reinterpret_cast<const unsigned*>(smem + MOFF + stc * 512 + qbc * 256 + mword * 2) >> (4 * hi)) : 0;
         if (HN) {
             const uint4 w = *reinterpret_cast<const uint4*>(hi ? smem + ZOFF : smem + ROFF + stn * 512 + (qbn * 32 + lk) * 8);
             f32x16 z;
@@ -582,7 +623,7 @@ __global__ void __launch_bounds__(NW * 64, GX ? 1 : 2) f2b_dkv_kernel(F2bArgs g)
 #pragma unroll
                 for (int p = 0; p < NG; ++p) dvacc[db] = fb_mma<MODE>(pf, td[p][i], dvacc[db]);
             }
-            if (HC) pair(qtc, qbc, 2 * i, sc_, tc_, nd, ppc, dsc);
+            if (HC) pair(qtc, qbc, mw, 2 * i, sc_, tc_, nd, ppc, dsc);
             __builtin_amdgcn_sched_barrier(0);
             if (HN) {
                 sn = fb_mma<MODE>(qa[i], kf[i], sn);
@@ -595,7 +636,7 @@ __global__ void __launch_bounds__(NW * 64, GX ? 1 : 2) f2b_dkv_kernel(F2bArgs g)
                 for (int p = 0; p < NG; ++p)
                     dkacc[db] = fb_mma<MODE>(fb_from4(dsp[p][4 * ks], dsp[p][4 * ks + 1], dsp[p][4 * ks + 2], dsp[p][4 * ks + 3]), tq[i], dkacc[db]);
             }
-            if (HC) pair(qtc, qbc, 2 * i + 1, sc_, tc_, nd, ppc, dsc);
+            if (HC) pair(qtc, qbc, mw, 2 * i + 1, sc_, tc_, nd, ppc, dsc);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -606,6 +647,7 @@ __global__ void __launch_bounds__(NW * 64, GX ? 1 : 2) f2b_dkv_kernel(F2bArgs g)
         constexpr bool HN = decltype(has_n)::value, HC = decltype(has_c)::value;
         const int stn = qtn % NS, stc = qtc % NS;
         const float* nd = reinterpret_cast<const float*>(smem + NOFF + stc * 128);
+        const int mw = (DROP == 2 && HC) ? (int)(*reinterpret_cast<const unsigned*>(smem + MOFF + stc * 512 + qbc * 256 + mword * 2) >> (4 * hi)) : 0;
         bf16x8 qa[4], da[NG][4], tq[4], td[NG][4];
         auto load_n = [&](int i) {
             if (HN) {
@@ -645,7 +687,7 @@ __global__ void __launch_bounds__(NW * 64, GX ? 1 : 2) f2b_dkv_kernel(F2bArgs g)
             if (i + 1 < 4) load_n(i + 1);
             if (i == 1) { load_d(0); load_d(1); }
             if (i == 3) { load_d(2); load_d(3); }
-            if (HC) pair(qtc, qbc, 2 * i, sc_, tc_, nd, pp, ds);
+            if (HC) pair(qtc, qbc, mw, 2 * i, sc_, tc_, nd, pp, ds);
             __builtin_amdgcn_sched_barrier(0);
             if (HN) {
                 sn = fb_mma<MODE>(qa[i], kf[i], sn);
@@ -654,7 +696,7 @@ __global__ void __launch_bounds__(NW * 64, GX ? 1 : 2) f2b_dkv_kernel(F2bArgs g)
             }
             if (i == 2) { dvdk(0); }
             if (i == 3) { dvdk(1); }
-            if (HC) pair(qtc, qbc, 2 * i + 1, sc_, tc_, nd, pp, ds);
+            if (HC) pair(qtc, qbc, mw, 2 * i + 1, sc_, tc_, nd, pp, ds);
             __builtin_amdgcn_sched_barrier(0);
         }
         dvdk(2); dvdk(3);
@@ -715,9 +757,12 @@ __global__ void __launch_bounds__(NW * 64, GX ? 1 : 2) f2b_dkv_kernel(F2bArgs g)
 template <int MODE, int GX, int NW>
 int f2b_dkv_launch(const F2bArgs& g, bool drop, hipStream_t st) {
     constexpr int NG = 1 + GX;
-    const size_t lds = (size_t)(3 * TILE + 3 * NG * TILE + 3 * 512 + 3 * 128 + 16) * sizeof(u16);
+    const size_t lds = (size_t)(3 * TILE + 3 * NG * TILE + 3 * 512 + 3 * 128 + 16 + 3 * 512) * sizeof(u16);
     const dim3 grid(g.nblk * g.B * g.H);
-    if (drop) {
+    if (drop && g.mask) {
+        if (hipFuncSetAttribute((const void*)f2b_dkv_kernel<MODE, GX, 2, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
+        hipLaunchKernelGGL((f2b_dkv_kernel<MODE, GX, 2, NW>), grid, dim3(NW * 64), lds, st, g);
+    } else if (drop) {
         if (hipFuncSetAttribute((const void*)f2b_dkv_kernel<MODE, GX, 1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
         hipLaunchKernelGGL((f2b_dkv_kernel<MODE, GX, 1, NW>), grid, dim3(NW * 64), lds, st, g);
     } else {
@@ -731,7 +776,10 @@ template <int MODE, int GX, int NW>
 int f2b_dq_launch(const F2bArgs& g, bool drop, hipStream_t st) {
     const size_t lds = (size_t)2 * NST * TILE * sizeof(u16);
     const dim3 grid(g.nblk * g.B * g.H);
-    if (drop) {
+    if (drop && g.mask) {
+        if (hipFuncSetAttribute((const void*)f2b_dq_kernel<MODE, GX, 2, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
+        hipLaunchKernelGGL((f2b_dq_kernel<MODE, GX, 2, NW>), grid, dim3(NW * 64), lds, st, g);
+    } else if (drop) {
         if (hipFuncSetAttribute((const void*)f2b_dq_kernel<MODE, GX, 1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
         hipLaunchKernelGGL((f2b_dq_kernel<MODE, GX, 1, NW>), grid, dim3(NW * 64), lds, st, g);
     } else {
@@ -752,9 +800,28 @@ extern "C" size_t vxb_flash2_attn_bwd_ws_bytes(int B, int H, int Nq, int gx) {
 // Backward of the fused attention, pipelined structure.  kv_plane: the forward's 16-bit plane of k | v (mode 0 bf16, 1 fp16);
 // gx = 1: dO and dS as hi + lo pairs.  which: 1 = dQ only, 2 = dK | dV only, 3 = both.  ws: vxb_flash2_attn_bwd_ws_bytes, 256-byte
 // aligned.  Same dropout mask as the forward entries.
+static int f2b_run(const float* q, const float* kv, const float* o, const float* d_o, const float* lse, const void* kv_plane, const void* drop_mask,
+                   int mode, int gx, float* dq, float* dkv, void* ws, int B, int H, int Nq, int Nk, int head_dim, float scale,
+                   float dropout_p, uint32_t seed, int which, vxb_stream_t stream);
+
 extern "C" int vxb_flash2_attn_bwd(const float* q, const float* kv, const float* o, const float* d_o, const float* lse, const void* kv_plane,
                                    int mode, int gx, float* dq, float* dkv, void* ws, int B, int H, int Nq, int Nk, int head_dim, float scale,
                                    float dropout_p, uint32_t seed, int which, vxb_stream_t stream) {
+    return f2b_run(q, kv, o, d_o, lse, kv_plane, nullptr, mode, gx, dq, dkv, ws, B, H, Nq, Nk, head_dim, scale, dropout_p, seed, which, stream);
+}
+
+// The same backward reading the dropout keep words the forward wrote (vxb_flash2_attn_fwd_mask, same B, H, Nq, Nk and dropout_p > 0)
+// instead of regenerating the mask: identical results, 9 - 15 fewer vector instructions per score pair.
+extern "C" int vxb_flash2_attn_bwd_mask(const float* q, const float* kv, const float* o, const float* d_o, const float* lse, const void* kv_plane,
+                                        const void* drop_mask, int mode, int gx, float* dq, float* dkv, void* ws, int B, int H, int Nq, int Nk,
+                                        int head_dim, float scale, float dropout_p, uint32_t seed, int which, vxb_stream_t stream) {
+    if (!drop_mask || (((uintptr_t)drop_mask) & 15)) return VXB_EARG;
+    return f2b_run(q, kv, o, d_o, lse, kv_plane, drop_mask, mode, gx, dq, dkv, ws, B, H, Nq, Nk, head_dim, scale, dropout_p, seed, which, stream);
+}
+
+static int f2b_run(const float* q, const float* kv, const float* o, const float* d_o, const float* lse, const void* kv_plane, const void* drop_mask,
+                   int mode, int gx, float* dq, float* dkv, void* ws, int B, int H, int Nq, int Nk, int head_dim, float scale,
+                   float dropout_p, uint32_t seed, int which, vxb_stream_t stream) {
     if (!q || !kv || !o || !d_o || !lse || !kv_plane || !ws || B < 1 || H < 1 || Nq < 1 || Nk < 1 || mode < 0 || mode > 1) return VXB_EARG;
     if (((which & 1) && !dq) || ((which & 2) && !dkv) || !(which & 3)) return VXB_EARG;
     if (head_dim != HD || dropout_p < 0.f || dropout_p >= 1.f || (((uintptr_t)kv_plane | (uintptr_t)ws) & 15)) return VXB_ESIZE;
@@ -783,6 +850,7 @@ extern "C" int vxb_flash2_attn_bwd(const float* q, const float* kv, const float*
     F2bArgs g;
     g.q = q; g.kv = kv; g.d_o = d_o; g.kvp = (const u16*)kv_plane; g.qp = qp; g.dop = dop; g.do_plane = do_plane;
     g.rowslots = rowslots; g.negd = negd; g.scale_ws = scale_ws; g.dq = dq; g.dkv = dkv;
+    g.mask = (const unsigned*)drop_mask; g.nrb = ((Nq + 255) / 256) * 8; g.ntile = (Nk + BT - 1) / BT;
     g.B = B; g.H = H; g.Nq = Nq; g.Nk = Nk; g.Nq64 = Nq64; g.scale = scale; g.p_drop = dropout_p; g.seed = seed;
     const bool drop = (unsigned)(dropout_p * 65536.0f) > 0u;
     int rc = VXB_OK;

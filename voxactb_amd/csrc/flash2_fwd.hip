@@ -57,6 +57,7 @@ struct F2Args {
     const u16* kv;        // [B*Nk][2*H*64] bf16 or fp16
     float* o;
     float* lse;
+    unsigned* mask;       // DROP == 2: the keep words of the dropout mask (layout: vxb_flash2_drop_mask_bytes), else unused
     int B, H, Nq, Nk, nqb;
     float scale, p_drop;
     unsigned seed;
@@ -118,6 +119,17 @@ __device__ __forceinline__ void f2_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)
 __device__ __forceinline__ void f2_acc(float& acc, float x) {
     acc += x;
     asm volatile("" : "+v"(acc));
+}
+
+// Dropout keep words (round 6).  The compare of a score's 16-bit hash field against the threshold leaves a 64-bit lane mask in an SGPR pair
+// anyway (lanes 0 - 31: the wave's 32 query rows for key k, lanes 32 - 63: the same rows for key k + 4); with DROP == 2 the forward stores
+// those pairs -- scalar stores: no vector ALU work -- and the backward kernels read the mask instead of hashing it again (csrc/flash2_bwd.hip:
+// 11 and 24 vector instructions per score pair in the dQ and the dK | dV kernel).  Word (bh, 32-row block, 64-key tile, kb, r, half) =
+// keep bits of rows 32 qb32 .. + 32 for key 64 tile + 32 kb + (r & 3) + 8 (r >> 2) + 4 half; 64 words per (row block, tile).
+typedef unsigned f2_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void f2_store_keep(unsigned long long m0, unsigned long long m1, unsigned* base, unsigned byte_off) {
+    const f2_v4u v = {(unsigned)m0, (unsigned)(m0 >> 32), (unsigned)m1, (unsigned)(m1 >> 32)};
+    asm volatile("s_store_dwordx4 %0, %1, %2" ::"s"(v), "s"(base), "s"(byte_off));
 }
 
 template <int MODE, int DROP, int NW>
@@ -209,6 +221,8 @@ __global__ void __launch_bounds__(NW * 64, 2) flash2_fwd_kernel(F2Args g) {
     const unsigned thr = (unsigned)(g.p_drop * 65536.0f);
     const unsigned row_id = (unsigned)bh * (unsigned)g.Nq + (unsigned)qrow;
     const unsigned rowh = row_id * 0x9E3779B1U + g.seed;
+    // keep words of this wave's 32 rows: 64 words per key tile (f2_store_keep)
+    unsigned* const mwave = DROP == 2 ? g.mask + ((size_t)bh * (size_t)(((g.Nq + 255) >> 8) << 3) + (size_t)(qblk * NW + wid)) * (size_t)((g.Nk + BKV - 1) / BKV) * 64 : nullptr;
     // K fragment (A operand of S^T): key row kb*32 + lq, chunk 2 ks + hi, swizzle key (row >> 1) & 7
     int kbase[2], kkey[2];
 #pragma unroll
@@ -240,7 +254,7 @@ __global__ void __launch_bounds__(NW * 64, 2) flash2_fwd_kernel(F2Args g) {
         return f2_from4(one2, tail, 0u, 0u);
     };
     // element pair t = 0..15 of tile kts: P = exp2(S') (dropout applied) packed into pc, row-sum contribution into ps[t & 3]
-    auto pair = [&](int kts_colb, int t, const f32x16 (&sa)[2], unsigned (&pc)[2][8], float (&ps)[4]) {
+    auto pair = [&](int kts_colb, unsigned* mtile, int t, const f32x16 (&sa)[2], unsigned (&pc)[2][8], float (&ps)[4]) {
         const int kb = t >> 3, r = 2 * (t & 7);
         if (F2_ABLATE & 4) { pc[kb][r >> 1] = __float_as_uint(sa[kb][r]); return; }
         float p0 = __builtin_amdgcn_exp2f(sa[kb][r]), p1 = __builtin_amdgcn_exp2f(sa[kb][r + 1]);
@@ -249,8 +263,10 @@ __global__ void __launch_bounds__(NW * 64, 2) flash2_fwd_kernel(F2Args g) {
         if (DROP) {
             const unsigned cp = (unsigned)((kb * 32 + (r & 3) + 8 * (r >> 2)) >> 1) * 0x85EBCA77U;
             const unsigned hsh = f2_hash(rowh ^ ((unsigned)kts_colb + cp));
-            p0 = (hsh & 0xffffu) >= thr ? p0 : 0.f;
-            p1 = (hsh >> 16) >= thr ? p1 : 0.f;
+            const bool k0 = (hsh & 0xffffu) >= thr, k1 = (hsh >> 16) >= thr;
+            if (DROP == 2) f2_store_keep(__builtin_amdgcn_ballot_w64(k0), __builtin_amdgcn_ballot_w64(k1), mtile, (unsigned)((kb * 32 + 2 * r) * 4));
+            p0 = k0 ? p0 : 0.f;
+            p1 = k1 ? p1 : 0.f;
         }
         pc[kb][r >> 1] = f2_pack<MODE>(p0, p1);
     };
@@ -267,6 +283,7 @@ __global__ void __launch_bounds__(NW * 64, 2) flash2_fwd_kernel(F2Args g) {
                       unsigned (&pc)[2][8]) -> float {
         constexpr bool HAS_PV = decltype(has_pv)::value;
         const int colb = (int)((unsigned)((kts * BKV + 4 * hi) >> 1) * 0x85EBCA77U + 0xC2B2AE3DU);
+        unsigned* const mtile = DROP == 2 ? mwave + (size_t)kts * 64 : nullptr;
         const bf16x8 msl = f2_from4(mslot, big2, 0u, 0u);
         float ps[4] = {0.f, 0.f, 0.f, 0.f};
         bf16x8 kf[10], vf[10];
@@ -290,10 +307,10 @@ __global__ void __launch_bounds__(NW * 64, 2) flash2_fwd_kernel(F2Args g) {
                 const int ks = i >> 1, db = (i & 1) ^ kb;
                 oacc[db] = f2_mma<MODE>(vf[gi], f2_from4(pp[kb][4 * ks], pp[kb][4 * ks + 1], pp[kb][4 * ks + 2], pp[kb][4 * ks + 3]), oacc[db]);
             }
-            pair(colb, 2 * gi, sa, pc, ps);
+            pair(colb, mtile, 2 * gi, sa, pc, ps);
             __builtin_amdgcn_sched_barrier(0);
             sb[kb] = f2_mma<MODE>(kf[gi], qf[i], sb[kb]);
-            pair(colb, 2 * gi + 1, sa, pc, ps);
+            pair(colb, mtile, 2 * gi + 1, sa, pc, ps);
             __builtin_amdgcn_sched_barrier(0);
         }
         kfc[0] = kf[8]; kfc[1] = kf[9]; vfc[0] = vf[8]; vfc[1] = vf[9];
@@ -302,9 +319,10 @@ __global__ void __launch_bounds__(NW * 64, 2) flash2_fwd_kernel(F2Args g) {
     // P of a tile without the pipeline (the rare fix-up path)
     auto softmax = [&](int kt, const f32x16 (&s)[2], unsigned (&pk)[2][8]) -> float {
         const int colb = (int)((unsigned)((kt * BKV + 4 * hi) >> 1) * 0x85EBCA77U + 0xC2B2AE3DU);
+        unsigned* const mtile = DROP == 2 ? mwave + (size_t)kt * 64 : nullptr;
         float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 16; ++t) pair(colb, t, s, pk, ps);
+        for (int t = 0; t < 16; ++t) pair(colb, mtile, t, s, pk, ps);
         return (ps[0] + ps[1]) + (ps[2] + ps[3]);
     };
     // rare: some P of tile kt (scores sa, already offset by the current m) may exceed P_LIMIT -> raise m by an integer, rescale
@@ -423,6 +441,7 @@ __global__ void __launch_bounds__(NW * 64, 2) flash2_fwd_kernel(F2Args g) {
         last_pv(pa);
     }
     f2_wait_vm<0>();                                        // the clamped loads of tiles >= nkt must not outlive the workgroup's LDS
+    if (DROP == 2) asm volatile("s_dcache_wb");             // the scalar stores of the keep words leave the scalar data cache
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     if (q_ok) {
@@ -727,7 +746,10 @@ template <int MODE, int NW>
 int f2_launch(const F2Args& g, bool drop, hipStream_t st) {
     const size_t lds = (size_t)2 * NST * TILE * sizeof(u16);
     const dim3 grid(g.nqb * g.B * g.H);
-    if (drop) {
+    if (drop && g.mask) {
+        if (hipFuncSetAttribute((const void*)flash2_fwd_kernel<MODE, 2, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
+        hipLaunchKernelGGL((flash2_fwd_kernel<MODE, 2, NW>), grid, dim3(NW * 64), lds, st, g);
+    } else if (drop) {
         if (hipFuncSetAttribute((const void*)flash2_fwd_kernel<MODE, 1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
         hipLaunchKernelGGL((flash2_fwd_kernel<MODE, 1, NW>), grid, dim3(NW * 64), lds, st, g);
     } else {
@@ -777,10 +799,33 @@ extern "C" int vxb_split_f16_f32(const float* src, int64_t ld, int64_t rows, int
     return VXB_OK;
 }
 
+// bytes of the dropout keep words one forward call with dropout writes (drop_mask of vxb_flash2_attn_fwd_mask; 256-byte aligned buffer):
+// [B*H][8 ceil(Nq / 256)][ceil(Nk / 64)][64] 32-bit words (32-row blocks, rounded up to whole 256-row workgroups)
+extern "C" size_t vxb_flash2_drop_mask_bytes(int B, int H, int Nq, int Nk) {
+    if (B < 1 || H < 1 || Nq < 1 || Nk < 1) return 0;
+    return (size_t)B * H * ((((size_t)Nq + 255) / 256) * 8) * (((size_t)Nk + BKV - 1) / BKV) * 64 * sizeof(unsigned) + 1024;      // (+ 1 KB: the dK | dV kernel fetches two key tiles at a time)
+}
+
+static int f2_fwd(const float* q, const void* kv_planes, int mode, float* o, float* lse, void* drop_mask, int B, int H, int Nq, int Nk,
+                  int head_dim, float scale, float dropout_p, uint32_t seed, int waves, vxb_stream_t stream);
+
 // Forward of the fused attention, pipelined structure.  mode 0: kv_planes = ONE bf16 plane [B*Nk][2*H*64]; mode 1: one fp16 plane.
 // waves: 4 or 8 per workgroup (0 = choose).  Same outputs (o, lse) and the same dropout mask as vxb_flash_attn_fwd_dl.
 extern "C" int vxb_flash2_attn_fwd(const float* q, const void* kv_planes, int mode, float* o, float* lse, int B, int H, int Nq, int Nk,
                                    int head_dim, float scale, float dropout_p, uint32_t seed, int waves, vxb_stream_t stream) {
+    return f2_fwd(q, kv_planes, mode, o, lse, nullptr, B, H, Nq, Nk, head_dim, scale, dropout_p, seed, waves, stream);
+}
+
+// The same call that also WRITES the dropout keep words (modes 0 / 1, dropout_p > 0): vxb_flash2_attn_bwd_mask reads them instead of
+// regenerating the mask from (seed, row, key) -- the same mask, bit for bit (tests/test_flash2_gpu.py).
+extern "C" int vxb_flash2_attn_fwd_mask(const float* q, const void* kv_planes, int mode, float* o, float* lse, void* drop_mask, int B, int H,
+                                        int Nq, int Nk, int head_dim, float scale, float dropout_p, uint32_t seed, int waves, vxb_stream_t stream) {
+    if (!drop_mask || (((uintptr_t)drop_mask) & 15) || mode == 2) return VXB_EARG;
+    return f2_fwd(q, kv_planes, mode, o, lse, drop_mask, B, H, Nq, Nk, head_dim, scale, dropout_p, seed, waves, stream);
+}
+
+static int f2_fwd(const float* q, const void* kv_planes, int mode, float* o, float* lse, void* drop_mask, int B, int H, int Nq, int Nk,
+                  int head_dim, float scale, float dropout_p, uint32_t seed, int waves, vxb_stream_t stream) {
     if (!q || !kv_planes || !o || !lse || B < 1 || H < 1 || Nq < 1 || Nk < 1 || mode < 0 || mode > 2) return VXB_EARG;
     if (head_dim != HD || dropout_p < 0.f || dropout_p >= 1.f || (((uintptr_t)kv_planes) & 15)) return VXB_ESIZE;
     if (mode == 2) {                    // 'bf16x3': kv_planes = the hi | lo bf16 planes of vxb_split_bf16_f32, 8 waves share the rings
@@ -796,7 +841,7 @@ extern "C" int vxb_flash2_attn_fwd(const float* q, const void* kv_planes, int mo
     if (waves == 0) waves = 4;          // two 4-wave workgroups per CU overlap each other's prologue / epilogue; 8 waves measured 3-30 % slower
     if (waves != 4 && waves != 8) return VXB_EARG;
     F2Args g;
-    g.q = q; g.kv = (const u16*)kv_planes; g.o = o; g.lse = lse;
+    g.q = q; g.kv = (const u16*)kv_planes; g.o = o; g.lse = lse; g.mask = (unsigned*)drop_mask;
     g.B = B; g.H = H; g.Nq = Nq; g.Nk = Nk; g.nqb = vxb_cdiv(Nq, waves * 32); g.scale = scale; g.p_drop = dropout_p; g.seed = seed;
     const bool drop = (unsigned)(dropout_p * 65536.0f) > 0u;
     hipStream_t st = (hipStream_t)stream;

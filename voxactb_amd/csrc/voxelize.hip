@@ -507,7 +507,7 @@ int vox_launch_reduce(const VoxSrc& src, const VoxGeom& g, const VoxWs& w, float
 
 }  // namespace
 
-extern "C" int vxb_abi_version(void) { return 2; }
+extern "C" int vxb_abi_version(void) { return 3; }      // 3 (round 6): vxb_patch_dgrad_input_wgrad_f32 gained dWp / ws_wp in round 5 (advisor); + the *_mask attention entries
 
 namespace {
 struct VoxStreams {
@@ -561,7 +561,7 @@ void vox_launch_fill(float* out, int B, int V, int C, hipStream_t fs) {
 }
 
 extern "C" int vxb_voxelize_select_chain(int which) {
-    if (which != 0 && which != 1 && which != 3 && which != 5) return VXB_EARG;
+    if (which != 0 && which != 1 && which != 3 && which != 5 && which != 7) return VXB_EARG;
     g_vox_chain = which;
     return VXB_OK;
 }
@@ -616,7 +616,8 @@ static int vox_run(const float* const* coord_src, const float* const* feat_src, 
         // runs the fill after the chain.
         // g_vox_chain 0 (default): round 5's merged tile launch (orders 6 / 7; they fall back to 2 / 4 where they do not apply);
         // 3: round 4's chain (fill, route, classify, heavy, light as separate launches: orders 2 / 4), 5: the fill on a side stream
-        const int order = out_state != 0 ? (g_vox_chain == 0 ? 7 : 4) : (g_vox_chain == 5 ? 0 : (g_vox_chain == 3 ? 2 : 6));
+        // 7 (A/B): round 5's incremental chain (unpatch as its own launch); since round 6 the default resets the old cells inside the route launch (order 9)
+        const int order = out_state != 0 ? (g_vox_chain == 0 ? 9 : g_vox_chain == 7 ? 7 : 4) : (g_vox_chain == 5 ? 0 : (g_vox_chain == 3 ? 2 : 6));
         // out_state 0 / 2 -> this call writes cell list 0, out_state 1 -> list 1 (and resets the cells of the other one)
         return vox_tiles_launch(src, g, bounds, out, workspace, st, fs, vs->ev_fork, vs->ev_placed, vs->ev_join, order,
                                 out_state == 1 ? 0 : (out_state == 2 ? 1 : -1), out_state == 1 ? 1 : 0);

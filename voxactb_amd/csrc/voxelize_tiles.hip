@@ -645,13 +645,11 @@ __global__ void __launch_bounds__(256) vt_heavy_kernel(Geom g, TileWs w, int all
 // previously occupied ones are reset to "empty" (zeros | idx/V | 0, voxel_grid.py:192-198 for count == 0) before the new
 // ones are patched in: ~2 x 40 bytes per occupied cell of traffic instead of 40 bytes per cell of the grid.
 template <int F>
-__global__ void __launch_bounds__(256) vt_unpatch_kernel(Geom g, TileWs w, float* __restrict__ out) {
+__device__ __forceinline__ void unpatch_cells(const Geom& g, const TileWs& w, float* __restrict__ out, int bx, int b) {
     constexpr int C = 3 + F + 4;
-    const int b = blockIdx.y, V = g.V;
-    if (blockIdx.x == 0 && b == 0)                       // this call's counters (the other set than ctr_prev): no memset node
-        for (int i = threadIdx.x; i < 64 + 32 * g.B; i += 256) w.ctr[i] = 0;
+    const int V = g.V;
     const int nocc = w.ctr_prev[64 + 32 * b];
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int j = bx * 256 + threadIdx.x;
     if (j >= nocc) return;
     const size_t V3 = (size_t)V * V * V;
     const float Vf = (float)V;
@@ -671,6 +669,31 @@ __global__ void __launch_bounds__(256) vt_unpatch_kernel(Geom g, TileWs w, float
 #pragma unroll
         for (int c = 0; c < C; ++c) o[c] = v[c];
     }
+}
+
+template <int F>
+__global__ void __launch_bounds__(256) vt_unpatch_kernel(Geom g, TileWs w, float* __restrict__ out) {
+    if (blockIdx.x == 0 && blockIdx.y == 0)              // this call's counters (the other set than ctr_prev): no memset node
+        for (int i = threadIdx.x; i < 64 + 32 * g.B; i += 256) w.ctr[i] = 0;
+    unpatch_cells<F>(g, w, out, blockIdx.x, blockIdx.y);
+}
+
+// Round 6: the reset of the previously occupied cells IN the route launch.  The two are independent (unpatch writes the grid, route the
+// record arrays; only the tile kernel needs both) and each is a chain of dependent round trips that leaves the memory system idle: the
+// route workgroups (blockIdx.x < NC) are dispatched first and all of them are resident at once (NC x B = 1024 of 2048 slots at
+// configs[1]), the unpatch workgroups take the free slots beside them -- one launch and one kernel boundary fewer, the 17 us of the
+// unpatch kernel off the critical path.  (Two streams for the same pair ended later than back to back in round 2: an event wait and a
+// join cost more than the pair overlaps.)
+template <int F>
+__global__ void __launch_bounds__(256) vt_unpatch_route_kernel(Src src, Geom g, const float* __restrict__ bounds, TileWs w, float* __restrict__ out) {
+    extern __shared__ unsigned short s_dyn[];
+    if ((int)blockIdx.x >= w.NC) {
+        if ((int)blockIdx.x == w.NC && blockIdx.y == 0)
+            for (int i = threadIdx.x; i < 64 + 32 * g.B; i += 256) w.ctr[i] = 0;
+        unpatch_cells<F>(g, w, out, (int)blockIdx.x - w.NC, blockIdx.y);
+        return;
+    }
+    route_chunk<F>(src, g, bounds, w, blockIdx.x, blockIdx.y, s_dyn);
 }
 
 // ------------------------------------------------------------------------------------------------------------ patch
@@ -749,11 +772,14 @@ int vt_launch(const Src& src, const Geom& g, const float* bounds, float* out, co
     // (fill, or the reset of the previously occupied cells) runs FIRST and there is no patch kernel
     // orders 6 / 7 (round 5, the shipped ones when a sample has at most 64 chunks): fresh buffer / incremental with heavy and light
     // tiles in ONE launch (vt_tiles_kernel): fill | unpatch, route, classify, tiles
+    // order 9 (round 6, the shipped incremental one): order 7 with the unpatch workgroups inside the route launch
     if (order == 6 && w.NC > 64) order = 2;
-    if (order == 7 && w.NC > 64) order = 4;
+    if ((order == 7 || order == 9) && w.NC > 64) order = 4;
+    const bool merged_unpatch = order == 9;
+    if (merged_unpatch) order = 7;
     const bool direct = order == 2 || order == 4 || order == 6 || order == 7;
     float* dout = direct ? out : nullptr;
-    if (order == 4 || order == 7) hipLaunchKernelGGL(vt_unpatch_kernel<F>, dim3((unsigned)((cap + 255) / 256), g.B), dim3(256), 0, st, g, w, out);
+    if ((order == 4 || order == 7) && !merged_unpatch) hipLaunchKernelGGL(vt_unpatch_kernel<F>, dim3((unsigned)((cap + 255) / 256), g.B), dim3(256), 0, st, g, w, out);
     if (order == 0) vox_launch_fill(out, g.B, g.V, C, side);
     if (order == 2 || order == 6) vox_launch_fill(out, g.B, g.V, C, st);
     const size_t lds = (size_t)4 * w.NT * sizeof(unsigned short);
@@ -762,7 +788,12 @@ int vt_launch(const Src& src, const Geom& g, const float* bounds, float* out, co
             return VXB_ELAUNCH;
     }
     // (this call's counters are cleared by the route kernel's first workgroup unless the unpatch kernel already did: no memset node)
-    hipLaunchKernelGGL(vt_route_kernel<F>, dim3(w.NC, g.B), dim3(256), lds, st, src, g, bounds, w, (order != 4 && order != 7) ? 1 : 0);
+    if (merged_unpatch) {
+        if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)vt_unpatch_route_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return VXB_ELAUNCH;
+        hipLaunchKernelGGL(vt_unpatch_route_kernel<F>, dim3((unsigned)(w.NC + (cap + 255) / 256), g.B), dim3(256), lds, st, src, g, bounds, w, out);
+    } else
+        hipLaunchKernelGGL(vt_route_kernel<F>, dim3(w.NC, g.B), dim3(256), lds, st, src, g, bounds, w, (order != 4 && order != 7) ? 1 : 0);
     const long long tiles = (long long)g.B * w.NT;
     const size_t heavy_lds = 0;
     if (order == 6 || order == 7) {
@@ -821,7 +852,7 @@ int vox_tiles_launch(const Src& src, const Geom& g, const float* bounds, float* 
     int bits = 1;
     while ((1 << bits) < L.NT) ++bits;
     w.tile_bits = bits;
-    if ((order == 4 || order == 7) && list_in < 0) return VXB_EARG;
+    if ((order == 4 || order == 7 || order == 9) && list_in < 0) return VXB_EARG;
     switch (g.F) {
         case 0: return vt_launch<0>(src, g, bounds, out, w, st, side, ev_fork, ev_mid, ev_join, order, C);
         case 1: return vt_launch<1>(src, g, bounds, out, w, st, side, ev_fork, ev_mid, ev_join, order, C);

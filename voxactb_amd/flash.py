@@ -1,4 +1,6 @@
 """Tensor-level wrappers of the fused-attention kernels (csrc/flash_attn.hip; 'bf16' and 'bf16x3' precisions)."""
+import os
+
 import torch
 
 from ._lib import call, set_meta
@@ -76,28 +78,56 @@ def kv_planes(kv, mode):
     return out
 
 
-def flash2_attn_fwd(q, kv, B, H, Nq, Nk, scale, p=0.0, seed=0, mode='f16', waves=0, planes=None, return_planes=False):
-    """Pipelined forward (csrc/flash2_fwd.hip).  Same contract as flash_attn_fwd_dl."""
+# Round 6: the forward stores the dropout keep words, the backward reads them instead of hashing (seed, row, key) again.  Measured (B = 16,
+# tools/experiments/attn_mask_probe.py, profiles/r06_attn_mask_probe.log): 8-head self-attention 2048 x 2048 forward 0.279 -> 0.263 ms,
+# dK | dV 0.498 -> 0.453 ms, dQ unchanged (its scalar loads of the lane masks wait out their latency where the hash kept the vector ALU busy);
+# the 1-head cross attentions (256 / 1024 workgroups: every wave's scalar stores sit on its critical path) lose in the forward what the
+# backward gains, so the words are stored only where the grid fills the chip twice over.  '0' = never, '2' = always (tests).
+DROP_MASK = os.environ.get('VOXACTB_ATTN_DROP_MASK', '1')
+DROP_MASK_MIN_WORKGROUPS = 2048
+
+
+def drop_mask_words(B, H, Nq, Nk, device):
+    """buffer of the dropout keep words of one attention call (include/voxactb_hip.h: vxb_flash2_attn_fwd_mask)"""
+    from ._lib import lib
+    return torch.empty((lib().vxb_flash2_drop_mask_bytes(B, H, Nq, Nk) + 3) // 4, dtype=torch.int32, device=device)
+
+
+def flash2_attn_fwd(q, kv, B, H, Nq, Nk, scale, p=0.0, seed=0, mode='f16', waves=0, planes=None, return_planes=False, return_mask=False,
+                    store_mask=True):
+    """Pipelined forward (csrc/flash2_fwd.hip).  Same contract as flash_attn_fwd_dl.  return_mask (single-product modes, p > 0): the forward
+    also stores the dropout keep words; appended to the result (None when there is no dropout) for flash2_attn_bwd(drop_mask=...)."""
     if planes is None:
         planes = kv_planes(kv, mode)
     o = torch.empty_like(q)
     lse = torch.empty((B * H, Nq), dtype=torch.float32, device=q.device)
+    mask = None
     set_meta('attn_core', 4.0 * B * H * Nq * Nk * 64)
-    call('vxb_flash2_attn_fwd', q, planes, MODES[mode], o, lse, B, H, Nq, Nk, 64, float(scale), float(p), int(seed) & 0xFFFFFFFF,
-         int(waves))
-    if return_planes:
-        return o, lse, planes
-    return o, lse
+    big = DROP_MASK == '2' or B * H * ((Nq + 127) // 128) >= DROP_MASK_MIN_WORKGROUPS
+    if return_mask and store_mask and DROP_MASK != '0' and big and mode != 'bf16x3' and int(float(p) * 65536.0) > 0:
+        mask = drop_mask_words(B, H, Nq, Nk, q.device)
+        call('vxb_flash2_attn_fwd_mask', q, planes, MODES[mode], o, lse, mask, B, H, Nq, Nk, 64, float(scale), float(p), int(seed) & 0xFFFFFFFF,
+             int(waves))
+    else:
+        call('vxb_flash2_attn_fwd', q, planes, MODES[mode], o, lse, B, H, Nq, Nk, 64, float(scale), float(p), int(seed) & 0xFFFFFFFF,
+             int(waves))
+    out = (o, lse) + ((planes,) if return_planes else ()) + ((mask,) if return_mask else ())
+    return out
 
 
-def flash2_attn_bwd(q, kv, o, d_o, lse, planes, B, H, Nq, Nk, scale, p=0.0, seed=0, mode='f16', gx=True, which=3):
-    """Pipelined backward (csrc/flash2_bwd.hip) -> (dq, dkv); planes: the forward's k | v plane (kv_planes(kv, mode))."""
+def flash2_attn_bwd(q, kv, o, d_o, lse, planes, B, H, Nq, Nk, scale, p=0.0, seed=0, mode='f16', gx=True, which=3, drop_mask=None):
+    """Pipelined backward (csrc/flash2_bwd.hip) -> (dq, dkv); planes: the forward's k | v plane (kv_planes(kv, mode)); drop_mask: the keep
+    words the forward call wrote (flash2_attn_fwd(return_mask=True)) -- None: the mask is regenerated from (seed, row, key)."""
     from ._lib import lib
     dq = torch.empty_like(q) if which & 1 else None
     dkv = torch.empty_like(kv) if which & 2 else None
     nws = lib().vxb_flash2_attn_bwd_ws_bytes(B, H, Nq, int(gx))
     ws = torch.empty(nws, dtype=torch.uint8, device=q.device)
     set_meta('attn_core', 10.0 * B * H * Nq * Nk * 64 * (0.4 if which == 1 else 0.6 if which == 2 else 1.0))
-    call('vxb_flash2_attn_bwd', q, kv, o, d_o, lse, planes, MODES[mode], int(gx), dq, dkv, ws, B, H, Nq, Nk, 64, float(scale), float(p),
-         int(seed) & 0xFFFFFFFF, int(which))
+    if drop_mask is not None:
+        call('vxb_flash2_attn_bwd_mask', q, kv, o, d_o, lse, planes, drop_mask, MODES[mode], int(gx), dq, dkv, ws, B, H, Nq, Nk, 64, float(scale),
+             float(p), int(seed) & 0xFFFFFFFF, int(which))
+    else:
+        call('vxb_flash2_attn_bwd', q, kv, o, d_o, lse, planes, MODES[mode], int(gx), dq, dkv, ws, B, H, Nq, Nk, 64, float(scale), float(p),
+             int(seed) & 0xFFFFFFFF, int(which))
     return dq, dkv
