@@ -433,8 +433,10 @@ def main():
 TRAFFIC_KERNELS = {
     # label prefix -> (kernels of one call, what the compulsory traffic is, FETCH_SIZE factor).  Factor 2 = the guide's rule for wide
     # coalesced streaming reads (128-byte requests tallied at 64 bytes); factor 1 for the LDS-halo conv kernels, whose loads are 64-byte
-    # segments (16 channels of a voxel row per chunk): calibrated as the guide asks for other access widths -- in both tile orders the RAW
-    # counter sits on the geometric halo amplification, doubled it would exceed the no-sharing bound (profiles/r05_final_conv_tile_order.log)
+    # segments (16 channels of a voxel row per chunk): calibrated as the guide asks for other access widths -- measured in round 6 on a known
+    # byte count in exactly that pattern (tools/ubench/fetch_calib.hip, profiles/r06_fetch_size_calibration.log: FETCH_SIZE x 1024 / bytes
+    # requested = 1.0000 for one 64-byte segment of a 256-byte row per pass, 0.5000 for wide reads); round 5 had inferred the same factor from
+    # the geometric halo amplification (profiles/r05_final_conv_tile_order.log)
     'conv3d_bf16[k3 s1 128->64 S100': (['conv3_halo_kernel<2, 1, 4, 1, 0, 2, 1>'],
                                        'final conv forward (+ the SpatialSoftmax3D partials of its epilogue): 12.3 GB compulsory (2 x 4.1 GB read, 4.1 GB written)', 1.0),
     'conv3d_wgrad[k3 s1 128->64 S100]': (['wgrad_halo_kernel<2, 4, 4, 2>'],
@@ -489,7 +491,7 @@ def profile_traffic(label):
             return None
         total += (ent[2] * f + (w or 0.0)) * 1024.0
         parts.append('%s: FETCH_SIZE %.2f GB raw (x %g%s), WRITE_SIZE %.2f GB' % (
-            kern, f * 1024.0 / 1e9, ent[2], '' if ent[2] == 2.0 else ': 64-byte segment loads, calibrated in profiles/r05_final_conv_tile_order.log',
+            kern, f * 1024.0 / 1e9, ent[2], '' if ent[2] == 2.0 else ': 64-byte segment loads, factor measured in profiles/r06_fetch_size_calibration.log',
             (w or 0.0) * 1024.0 / 1e9))
     return total, '%s; %s; %s' % (ent[1], '; '.join(parts), os.path.basename(prof[0]).replace('_pmc_FETCH_SIZE_summary.txt', '_pmc_*'))
 

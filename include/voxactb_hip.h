@@ -51,10 +51,13 @@ int vxb_abi_version(void);
  * Workspace: vxb_voxelize_workspace_bytes() bytes, contents arbitrary on entry for out_state 0 (nothing to pre-zero).
  */
 size_t vxb_voxelize_workspace_bytes(int B, int n_points, int V);
-/* Point chain used by vxb_voxelize_f32: 0 = automatic (tile-routed chain when F <= 4, V <= 200, N < 2^20, all kernels in
- * order on the caller's stream, heavy and light tiles in one launch; otherwise the table-based chain), 1 = always the table-based
+/* Point chain used by vxb_voxelize_f32: 0 = automatic (tile-routed chain when F <= 4, V <= 200 and N <= 2^19 points per sample (512 route
+ * chunks of 1024), all kernels in order on the caller's stream; heavy and light tiles in ONE launch and -- incremental calls, round 6 -- the
+ * reset of the old cells inside the route launch while N <= 65 536 (64 chunks: the headline's 4 x 128 x 128 exactly), every tile through the
+ * workgroup kernel above that: correct, ~1.5 x slower per point; otherwise the table-based chain), 1 = always the table-based
  * chain, 3 = the tile-routed chain of rounds 2-4 (fill, route, classify, heavy, light as separate launches), 5 = that chain with
- * the empty-grid fill on a side stream -- kept for A/B measurements.  All produce identical grids. */
+ * the empty-grid fill on a side stream, 7 = round 5's incremental chain (the reset as its own launch) -- kept for A/B measurements.  All
+ * produce identical grids. */
 int vxb_voxelize_select_chain(int which);
 int vxb_voxelize_f32(const float* const* coord_src, const float* const* feat_src, int n_src,
                      int B, int pts_per_src, int F,

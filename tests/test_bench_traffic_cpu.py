@@ -29,7 +29,7 @@ def test_dominant_kernel_traffic_comes_from_the_newest_profile():
     # the final conv's forward: 12.3 GB compulsory; 14 - 17 GB moved (raw FETCH_SIZE: this kernel's 64-byte segment loads are tallied at
     # face value, profiles/r05_final_conv_tile_order.log) -- a change of the kernel must show up here
     nbytes, note = b.profile_traffic('conv3d_bf16[k3 s1 128->64 S100]')
-    assert 1.23e10 < nbytes < 2.0e10 and 'calibrated' in note
+    assert 1.23e10 < nbytes < 2.0e10 and 'r06_fetch_size_calibration' in note
 
 
 def test_voxelizer_traffic_comes_from_the_newest_profile():

@@ -84,17 +84,20 @@ def test_fused_weight_gradient_with_padding_adjoint():
         assert e < 2e-5, (name, e)
 
 
-@pytest.mark.parametrize('B,V,gain', [(2, 10, 1.0), (1, 23, 3e-7), (3, 12, 2e5)])
-def test_patchify_data_gradient_folded_into_the_input_weight_gradient(B, V, gain):
+@pytest.mark.parametrize('B,V,gain,wscale', [(2, 10, 1.0, 0.05), (1, 23, 3e-7, 0.05), (3, 12, 2e5, 0.05), (2, 10, 1.0, 1.0), (2, 10, 4e3, 1.0)])
+def test_patchify_data_gradient_folded_into_the_input_weight_gradient(B, V, gain, wscale):
     """vxb_patch_dgrad_input_wgrad_f32: the patchify block's data gradient (k = stride = 5, replicate padding 2) never becomes a
     tensor -- its share of dW_in [64][10] / db_in [64] straight from dpatch, against torch autograd in float64: the gradient of the
     replicate-padded stride-5 conv w.r.t. d0, times LeakyReLU'(d0), times the voxel inputs.  Ragged grids (V = 23, 12: voxels the
-    patches never reach get nothing), tiny / huge gradients (device-side power-of-two scale), accumulation into non-zero dW / db."""
+    patches never reach get nothing), tiny / huge gradients (device-side power-of-two scale), accumulation into non-zero dW / db.
+    wscale = 1.0 (round-5 advisor): patchify weights 20 x the released scale -- the data gradient G = sum of 64 products of dpatch
+    (scaled to max 2^15) and weights goes through fp16 at 2^-4 of its scaled value: |G| 2^-4 < 65504 holds for max |W| < 0.5 in the worst
+    case and with Gaussian weights of unit scale in practice (patch_wgrad.hip); same 2e-3 bound."""
     k, pad, C, Cin = 5, 2, 64, 10
     G = (V + 2 * pad - k) // k + 1
     d0 = rnd(B, C, V, V, V, seed=1)
     vox = rnd(B, Cin, V, V, V, seed=2)
-    Wp = rnd(C, C, k, k, k, seed=3) * 0.05
+    Wp = rnd(C, C, k, k, k, seed=3) * wscale
     dpatch = rnd(B, C, G, G, G, seed=4) * gain
     x = d0.double().requires_grad_(True)
     out = F.conv3d(F.pad(x, (pad,) * 6, mode='replicate'), Wp.double(), stride=k)
@@ -126,3 +129,23 @@ def test_patchify_data_gradient_folded_into_the_input_weight_gradient(B, V, gain
     assert float((dW2 - (dW - 0.25 * gain)).abs().max()) <= 2e-6 * float(dW2.abs().max())
     ep = float((dWp.double().cpu() - 0.125 * gain - dWp_ref).abs().max() / dWp_ref.abs().max())
     assert ep < 2e-3, ep
+
+
+def test_patchify_weight_gradient_propagates_a_nan_of_d0():
+    """round-5 advisor: the d0 operand of the fused patchify weight gradient goes through vxb_sat_f16 (NaN / inf stay non-finite) -- a
+    plain v_med3 would turn a NaN activation into -65504 and hand the optimizer finite garbage where the reference's autograd hands on NaN."""
+    B, V, k, pad, C, Cin = 1, 10, 5, 2, 64, 10
+    G = (V + 2 * pad - k) // k + 1
+    d0 = rnd(B, C, V, V, V, seed=1)
+    d0[0, 7, 3, 4, 5] = float('nan')
+    vox, Wp, dpatch = rnd(B, Cin, V, V, V, seed=2), rnd(C, C, k, k, k, seed=3) * 0.05, rnd(B, C, G, G, G, seed=4)
+    cl = lambda t: t.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+    dW, db, dWp = torch.zeros((C, Cin), device=DEV), torch.zeros((C,), device=DEV), torch.zeros((C, C, k, k, k), device=DEV)
+    keep = ops.PRECISION, ops.WGRAD_PRECISION
+    ops.PRECISION, ops.WGRAD_PRECISION = 'bf16x3', 'fp16'
+    try:
+        ops.patch_dgrad_input_wgrad(cl(dpatch), Wp.to(DEV), cl(d0), cl(vox), dW, db, B, V, G, k, pad, dWp=dWp)
+    finally:
+        ops.PRECISION, ops.WGRAD_PRECISION = keep
+    assert bool(torch.isnan(dWp[:, 7]).any())                 # the weight gradient column of the NaN input channel
+    assert bool(torch.isfinite(dWp[:, 8]).all())              # (and nothing else)
