@@ -642,10 +642,13 @@ __global__ void __launch_bounds__(NW * 64, GX ? 1 : 2) f2b_dkv_kernel(F2bArgs g)
     };
     // LEAN step (GX = 0, two waves per SIMD): S'T'(next unit) | P, dS of the current unit | dV, dK of the CURRENT unit as soon as its
     // words exist (key-step 0 after the first four pairs, key-step 1 behind the loop): no second P / dS buffer, fragments one group ahead
-    auto step_lean = [&](auto has_n, auto has_c, int qtn, int qbn, int qtc, int qbc, f32x16& sn, f32x16& tn, const f32x16& sc_,
+    // (stn_, stc_: the ring stages of the tiles of units n and c as COMPILE-TIME constants -- the tile loop below is unrolled over the
+    // three stages.  With `qt % NS` at run time every one of a step's 33 LDS fragment reads cost two vector adds for its stage offset:
+    // 48 of the step's 154 vector instructions)
+    auto step_lean = [&](auto has_n, auto has_c, auto stn_, auto stc_, int qtn, int qbn, int qtc, int qbc, f32x16& sn, f32x16& tn, const f32x16& sc_,
                          const f32x16& tc_, unsigned (&pp)[8], unsigned (&ds)[NG][8]) {
         constexpr bool HN = decltype(has_n)::value, HC = decltype(has_c)::value;
-        const int stn = qtn % NS, stc = qtc % NS;
+        constexpr int stn = decltype(stn_)::value, stc = decltype(stc_)::value;
         const float* nd = reinterpret_cast<const float*>(smem + NOFF + stc * 128);
         const int mw = (DROP == 2 && HC) ? (int)(*reinterpret_cast<const unsigned*>(smem + MOFF + stc * 512 + qbc * 256 + mword * 2) >> (4 * hi)) : 0;
         bf16x8 qa[4], da[NG][4], tq[4], td[NG][4];
@@ -711,15 +714,22 @@ __global__ void __launch_bounds__(NW * 64, GX ? 1 : 2) f2b_dkv_kernel(F2bArgs g)
         __syncthreads();
         f32x16 s_[2], t_[2];
         unsigned pp1[8], ds1[NG][8];
-        step_lean(T_, F_, 0, 0, 0, 0, s_[0], t_[0], s_[0], t_[0], pp1, ds1);
-        for (int j = 0; j < nqt; ++j) {
-            // region j = units (j, 0), (j, 1): tiles j (current) and j + 1 (the next unit's scores)
-            step_lean(T_, T_, j, 1, j, 0, s_[1], t_[1], s_[0], t_[0], pp1, ds1);
+        typedef std::integral_constant<int, 0> S0;
+        typedef std::integral_constant<int, 1> S1;
+        typedef std::integral_constant<int, 2> S2;
+        step_lean(T_, F_, S0(), S0(), 0, 0, 0, 0, s_[0], t_[0], s_[0], t_[0], pp1, ds1);
+        // region j = units (j, 0), (j, 1): tiles j (current, stage j % 3) and j + 1 (the next unit's scores)
+        auto region = [&](auto sa, auto sb, int j) {
+            step_lean(T_, T_, sa, sa, j, 1, j, 0, s_[1], t_[1], s_[0], t_[0], pp1, ds1);
             fb_wait_vm<0>();                                // tile j + 1 (requested one region ago) landed
             vxb_raw_barrier();
             if (j + 2 < nqt + 1) issue(j + 2);              // stage (j + 2) % 3 held tile j - 1
-            step_lean(T_, T_, j + 1, 0, j, 1, s_[0], t_[0], s_[1], t_[1], pp1, ds1);
-        }
+            step_lean(T_, T_, sb, sa, j + 1, 0, j, 1, s_[0], t_[0], s_[1], t_[1], pp1, ds1);
+        };
+        int j = 0;
+        for (; j + 3 <= nqt; j += 3) { region(S0(), S1(), j); region(S1(), S2(), j + 1); region(S2(), S0(), j + 2); }
+        if (j < nqt) region(S0(), S1(), j);
+        if (j + 1 < nqt) region(S1(), S2(), j + 1);
         fb_wait_vm<0>();
     } else {
     issue(0); issue(1);
