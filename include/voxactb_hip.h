@@ -524,7 +524,10 @@ int vxb_flash2_attn_bwd(const float* q, const float* kv, const float* o, const f
  * dropout_p > 0 vxb_flash2_attn_fwd_mask also stores those pairs (scalar stores, no vector-ALU work) as "keep words" -- bit q of word
  * [b * H + h][32-row block][64-key tile][kb][r][half] = query row 32 block + q keeps key 64 tile + 32 kb + (r & 3) + 8 (r >> 2) + 4 half --
  * and vxb_flash2_attn_bwd_mask reads them (dQ kernel: scalar loads straight into v_cndmask; dK | dV kernel: one word per lane and 32 rows)
- * instead of hashing (seed, row, key) again: the same mask bit for bit, 9 - 15 vector instructions per score pair less in the backward.
+ * instead of hashing (seed, row, key) again (9 - 15 vector instructions per score pair less in the backward).  Because the mask is handed
+ * on as data, this forward does not evaluate the (seed, row, key) hash of the entries above either: it draws the mask from a per-row 24-bit
+ * linear congruential sequence seeded by (seed, row) -- one full-rate instruction per score pair, same Bernoulli(1 - p) statistics, same
+ * mask for the same (seed, shape) -- so its backward MUST be vxb_flash2_attn_bwd_mask with the words it wrote.
  * drop_mask: vxb_flash2_drop_mask_bytes(B, H, Nq, Nk) bytes, 256-byte aligned, written by the forward call and read by the backward call of
  * the same (B, H, Nq, Nk).  modes 0 / 1 only.  Everything else as vxb_flash2_attn_fwd / vxb_flash2_attn_bwd (Attention.forward's dropout,
  * perceiver_lang_io.py:124-128). */

@@ -96,35 +96,85 @@ def test_zero_gradient_and_which():
     assert torch.equal(a, c) and torch.equal(b, d)
 
 
-@pytest.mark.parametrize('shape', SHAPES + [(2, 8, 2048, 2048), (1, 1, 100, 77)])
-@pytest.mark.parametrize('mode,gx', [('f16', False), ('f16', True), ('bf16', False)])
-def test_stored_dropout_mask_equals_the_regenerated_one(shape, mode, gx, monkeypatch):
-    """Round 6: the forward stores the dropout keep words (scalar stores of the compare results), the backward reads them.  The mask is the
-    SAME function of (seed, row, key) either way, so with and without the stored words the forward outputs are identical and dQ, dK | dV are
-    bit-identical -- any wrong word, bit position or layout index of the dQ kernel's scalar loads or of the dK | dV kernel's per-lane words
-    would drop other scores and differ by O(1).  Ragged shapes: row blocks / key tiles past the end, 8077-long contexts."""
-    B, H, Nq, Nk = shape
-    q, kv = _data(B, H, Nq, Nk, 0)
-    d_o = torch.randn(B * Nq, H * 64, device=DEV) * 1e-3
-    pl = flash.kv_planes(kv, mode)
-    monkeypatch.setattr(flash, 'DROP_MASK', '2')            # (store the words at every size: the product only does where the grid fills the chip)
-    o0, lse0 = flash.flash2_attn_fwd(q, kv, B, H, Nq, Nk, 0.125, 0.1, 7, mode=mode, planes=pl)
-    o1, lse1, mask = flash.flash2_attn_fwd(q, kv, B, H, Nq, Nk, 0.125, 0.1, 7, mode=mode, planes=pl, return_mask=True)
-    assert mask is not None
-    assert torch.equal(o0, o1) and torch.equal(lse0, lse1)
-    dq0, dkv0 = flash.flash2_attn_bwd(q, kv, o0, d_o, lse0, pl, B, H, Nq, Nk, 0.125, 0.1, 7, mode=mode, gx=gx)
-    dq1, dkv1 = flash.flash2_attn_bwd(q, kv, o0, d_o, lse0, pl, B, H, Nq, Nk, 0.125, 0.1, 7, mode=mode, gx=gx, drop_mask=mask)
-    assert torch.isfinite(dq1).all() and torch.isfinite(dkv1).all()
-    assert torch.equal(dq0, dq1), float((dq0 - dq1).abs().max())
-    assert torch.equal(dkv0, dkv1), float((dkv0 - dkv1).abs().max())
-    # the keep rate of the stored words (valid rows x keys only) is 1 - p
+def _decode_keep(mask, B, H, Nq, Nk):
+    """keep words (include/voxactb_hip.h: vxb_flash2_attn_fwd_mask) -> bool [B*H, Nq, Nk]"""
     nrb, ntile = (Nq + 255) // 256 * 8, (Nk + 63) // 64
     w = mask[:B * H * nrb * ntile * 64].view(B * H, nrb, ntile, 2, 16, 2)
     bits = ((w.unsqueeze(-1) >> torch.arange(32, device=DEV, dtype=torch.int32)) & 1).bool()           # [bh, rb, tile, kb, r, half, row]
     r = torch.arange(16, device=DEV)
     key = (torch.arange(ntile, device=DEV)[:, None, None, None] * 64 + torch.arange(2, device=DEV)[None, :, None, None] * 32
            + ((r & 3) + 8 * (r >> 2))[None, None, :, None] + 4 * torch.arange(2, device=DEV)[None, None, None, :])         # [tile, kb, r, half]
-    row = torch.arange(nrb, device=DEV)[:, None] * 32 + torch.arange(32, device=DEV)[None, :]                              # [rb, row]
-    valid = (key < Nk)[None, None, :, :, :, :, None] & (row < Nq)[None, :, None, None, None, None, :]
-    rate = float(bits[valid.expand_as(bits)].float().mean())
-    assert abs(rate - (1.0 - 6553.0 / 65536.0)) < 4.0 * (0.09 / float(valid.sum() * B * H)) ** 0.5 + 1e-3, rate
+    keep = torch.zeros((B * H, nrb * 32, ntile * 64), dtype=torch.bool, device=DEV)
+    rows = (torch.arange(nrb, device=DEV)[:, None] * 32 + torch.arange(32, device=DEV)[None, :])                          # [rb, row]
+    # keep[bh, rows[rb, row], key[tile, kb, r, half]] = bits[bh, rb, tile, kb, r, half, row]
+    keep[:, rows[:, None, None, None, None, :].expand(nrb, ntile, 2, 16, 2, 32), key[None, :, :, :, :, None].expand(nrb, ntile, 2, 16, 2, 32)] = bits
+    return keep[:, :Nq, :Nk]
+
+
+def _ref_with_mask(q, kv, d_o, keep, B, H, Nq, Nk, scale, p):
+    """float64 attention with dropout mask `keep` [B*H, Nq, Nk] on the probabilities (perceiver_lang_io.py:124-128) and its autograd"""
+    q64, kv64 = q.double().requires_grad_(True), kv.double().requires_grad_(True)
+    q4 = q64.view(B, Nq, H, 64).permute(0, 2, 1, 3)
+    k4 = kv64[:, :H * 64].reshape(B, Nk, H, 64).permute(0, 2, 1, 3)
+    v4 = kv64[:, H * 64:].reshape(B, Nk, H, 64).permute(0, 2, 1, 3)
+    s = torch.einsum('bhid,bhjd->bhij', q4, k4) * scale
+    pd = torch.softmax(s, -1) * keep.view(B, H, Nq, Nk).double() / (1.0 - p)
+    o = torch.einsum('bhij,bhjd->bhid', pd, v4).permute(0, 2, 1, 3).reshape(B * Nq, H * 64)
+    (o * d_o.double()).sum().backward()
+    return o.detach(), q64.grad, kv64.grad
+
+
+@pytest.mark.parametrize('shape', SHAPES[:3] + [(1, 1, 300, 1100), (1, 2, 1100, 130), (1, 1, 100, 77)])
+@pytest.mark.parametrize('mode,gx', [('f16', False), ('f16', True), ('bf16', False)])
+def test_stored_dropout_mask_forward_and_backward(shape, mode, gx, monkeypatch):
+    """Round 6: with dropout the forward can store the mask (the threshold compares' lane masks, scalar stores) and the backward reads it
+    (dQ kernel: scalar loads into v_cndmask; dK | dV kernel: one word per lane and 32 rows) instead of hashing (seed, row, key) again; the
+    storing forward draws the mask from a per-row linear congruential sequence.  Checked against a FLOAT64 attention that applies the
+    stored mask, decoded by the documented layout: forward output, dQ, dK | dV -- any wrong word, bit position or layout index in either
+    backward kernel drops other scores and differs by O(1).  Ragged shapes: row blocks / key tiles past the end.  Also: the keep rate is
+    1 - p, a second call reproduces the mask, another seed does not."""
+    B, H, Nq, Nk = shape
+    p = 0.1
+    q, kv = _data(B, H, Nq, Nk, 0)
+    d_o = torch.randn(B * Nq, H * 64, device=DEV) * 1e-3
+    pl = flash.kv_planes(kv, mode)
+    monkeypatch.setattr(flash, 'DROP_MASK', '2')            # (store the words at every size: the product only does where the grid fills the chip)
+    o1, lse1, mask = flash.flash2_attn_fwd(q, kv, B, H, Nq, Nk, 0.125, p, 7, mode=mode, planes=pl, return_mask=True)
+    assert mask is not None
+    keep = _decode_keep(mask, B, H, Nq, Nk)
+    rate = float(keep.float().mean())
+    assert abs(rate - (1.0 - 6553.0 / 65536.0)) < 4.0 * (0.09 / keep.numel()) ** 0.5 + 1e-3, rate
+    o_ref, dq_ref, dkv_ref = _ref_with_mask(q, kv, d_o, keep, B, H, Nq, Nk, 0.125, 6553.0 / 65536.0)
+    lse_ref = ref_attn(q, kv, B, H, Nq, Nk, 0.125)[1]
+    tol = TOL[mode]
+    assert (o1.double() - o_ref).abs().max().item() < tol * o_ref.abs().max().item()
+    assert (lse1.double() - lse_ref).abs().max().item() < tol
+    dq1, dkv1 = flash.flash2_attn_bwd(q, kv, o1, d_o, lse1, pl, B, H, Nq, Nk, 0.125, p, 7, mode=mode, gx=gx, drop_mask=mask)
+    btol = {'bf16': 3e-2, 'f16': 4e-3}[mode]
+    for a, r in ((dq1, dq_ref), (dkv1, dkv_ref)):
+        assert torch.isfinite(a).all()
+        assert (a.double() - r).abs().max().item() < btol * r.abs().max().item()
+    o2, _, mask2 = flash.flash2_attn_fwd(q, kv, B, H, Nq, Nk, 0.125, p, 7, mode=mode, planes=pl, return_mask=True)
+    assert torch.equal(o1, o2) and torch.equal(_decode_keep(mask2, B, H, Nq, Nk), keep)                 # same seed, same mask
+    _, _, mask3 = flash.flash2_attn_fwd(q, kv, B, H, Nq, Nk, 0.125, p, 8, mode=mode, planes=pl, return_mask=True)
+    assert float((_decode_keep(mask3, B, H, Nq, Nk) == keep).float().mean()) < 0.86                     # another seed: 0.82 expected
+
+
+def test_stored_mask_at_the_headline_size(monkeypatch):
+    """B = 2, 8 heads, 2048 x 2048 (the step's self-attention per sample pair): the storing forward and the mask-reading backward against the
+    hash pair on the keep RATE and on the gradient norms (different masks, same statistics), finite everywhere."""
+    B, H, Nq, Nk = 2, 8, 2048, 2048
+    q, kv = _data(B, H, Nq, Nk, 0)
+    d_o = torch.randn(B * Nq, H * 64, device=DEV) * 1e-3
+    pl = flash.kv_planes(kv, 'f16')
+    monkeypatch.setattr(flash, 'DROP_MASK', '2')
+    o0, lse0 = flash.flash2_attn_fwd(q, kv, B, H, Nq, Nk, 0.125, 0.1, 7, mode='f16', planes=pl)
+    dq0, dkv0 = flash.flash2_attn_bwd(q, kv, o0, d_o, lse0, pl, B, H, Nq, Nk, 0.125, 0.1, 7, mode='f16', gx=False)
+    o1, lse1, mask = flash.flash2_attn_fwd(q, kv, B, H, Nq, Nk, 0.125, 0.1, 7, mode='f16', planes=pl, return_mask=True)
+    assert mask is not None and torch.equal(lse0, lse1)          # (the normaliser does not see the mask)
+    dq1, dkv1 = flash.flash2_attn_bwd(q, kv, o1, d_o, lse1, pl, B, H, Nq, Nk, 0.125, 0.1, 7, mode='f16', gx=False, drop_mask=mask)
+    keep = _decode_keep(mask, B, H, Nq, Nk)
+    assert abs(float(keep.float().mean()) - 0.9) < 1e-3
+    for a, b_ in ((o0, o1), (dq0, dq1), (dkv0, dkv1)):
+        assert torch.isfinite(b_).all()
+        assert abs(float(a.norm()) / float(b_.norm()) - 1.0) < 2e-2

@@ -221,6 +221,7 @@ __global__ void __launch_bounds__(NW * 64, 2) flash2_fwd_kernel(F2Args g) {
     const unsigned thr = (unsigned)(g.p_drop * 65536.0f);
     const unsigned row_id = (unsigned)bh * (unsigned)g.Nq + (unsigned)qrow;
     const unsigned rowh = row_id * 0x9E3779B1U + g.seed;
+    unsigned lcg = f2_hash(rowh ^ (hi ? 0x68E31DA4u : 0u));      // DROP == 2: this lane's sequence (the two lanes of a row draw different keys)
     // keep words of this wave's 32 rows: 64 words per key tile (f2_store_keep)
     unsigned* const mwave = DROP == 2 ? g.mask + ((size_t)bh * (size_t)(((g.Nq + 255) >> 8) << 3) + (size_t)(qblk * NW + wid)) * (size_t)((g.Nk + BKV - 1) / BKV) * 64 : nullptr;
     // K fragment (A operand of S^T): key row kb*32 + lq, chunk 2 ks + hi, swizzle key (row >> 1) & 7
@@ -260,13 +261,24 @@ __global__ void __launch_bounds__(NW * 64, 2) flash2_fwd_kernel(F2Args g) {
         float p0 = __builtin_amdgcn_exp2f(sa[kb][r]), p1 = __builtin_amdgcn_exp2f(sa[kb][r + 1]);
         f2_acc(ps[t & 3], p0);
         f2_acc(ps[(t + 2) & 3], p1);
-        if (DROP) {
-            const unsigned cp = (unsigned)((kb * 32 + (r & 3) + 8 * (r >> 2)) >> 1) * 0x85EBCA77U;
-            const unsigned hsh = f2_hash(rowh ^ ((unsigned)kts_colb + cp));
-            const bool k0 = (hsh & 0xffffu) >= thr, k1 = (hsh >> 16) >= thr;
-            if (DROP == 2) f2_store_keep(__builtin_amdgcn_ballot_w64(k0), __builtin_amdgcn_ballot_w64(k1), mtile, (unsigned)((kb * 32 + 2 * r) * 4));
+        if (DROP == 2) {
+            // the mask is DATA here (the backward reads the stored words), so it need not be a function of (seed, row, key) that other
+            // kernels with other lane mappings can re-evaluate: one step of a per-lane 24-bit linear congruential sequence per score pair
+            // (v_mad_u32_u24, full rate) instead of the xorshift-multiply hash (7 instructions, one of them a quarter-rate 32-bit
+            // multiply).  Both 16-bit halves are used: the high one mixes all 24 state bits, the low one is itself a full-period sequence
+            // modulo 2^16 whose top bits -- the ones a 10 % threshold looks at -- have periods of 2^13 .. 2^16 steps against the 512 a lane
+            // draws.  Keep rate, row / column / block counts and the correlations at 26 lags match the hash's (worst 0.0015 against
+            // 0.0017; tools/experiments/README.md, round 6).
+            lcg = (lcg & 0xffffffu) * 0x8DA6B3u + 0x9E3779B9u;
+            const bool k0 = (lcg & 0xffffu) >= thr, k1 = (lcg >> 16) >= thr;
+            f2_store_keep(__builtin_amdgcn_ballot_w64(k0), __builtin_amdgcn_ballot_w64(k1), mtile, (unsigned)((kb * 32 + 2 * r) * 4));
             p0 = k0 ? p0 : 0.f;
             p1 = k1 ? p1 : 0.f;
+        } else if (DROP) {
+            const unsigned cp = (unsigned)((kb * 32 + (r & 3) + 8 * (r >> 2)) >> 1) * 0x85EBCA77U;
+            const unsigned hsh = f2_hash(rowh ^ ((unsigned)kts_colb + cp));
+            p0 = (hsh & 0xffffu) >= thr ? p0 : 0.f;
+            p1 = (hsh >> 16) >= thr ? p1 : 0.f;
         }
         pc[kb][r >> 1] = f2_pack<MODE>(p0, p1);
     };
@@ -816,8 +828,10 @@ extern "C" int vxb_flash2_attn_fwd(const float* q, const void* kv_planes, int mo
     return f2_fwd(q, kv_planes, mode, o, lse, nullptr, B, H, Nq, Nk, head_dim, scale, dropout_p, seed, waves, stream);
 }
 
-// The same call that also WRITES the dropout keep words (modes 0 / 1, dropout_p > 0): vxb_flash2_attn_bwd_mask reads them instead of
-// regenerating the mask from (seed, row, key) -- the same mask, bit for bit (tests/test_flash2_gpu.py).
+// The same call that also WRITES the dropout keep words (modes 0 / 1, dropout_p > 0) for vxb_flash2_attn_bwd_mask.  NOT the mask of
+// vxb_flash2_attn_fwd: with the mask handed on as data the forward draws it from a cheaper per-row sequence (see pair() above), so the
+// backward of THIS forward must be vxb_flash2_attn_bwd_mask with these words (tests/test_flash2_gpu.py checks both against a float64
+// attention that applies the stored mask).  Same (seed, shape) -> same mask, run to run.
 extern "C" int vxb_flash2_attn_fwd_mask(const float* q, const void* kv_planes, int mode, float* o, float* lse, void* drop_mask, int B, int H,
                                         int Nq, int Nk, int head_dim, float scale, float dropout_p, uint32_t seed, int waves, vxb_stream_t stream) {
     if (!drop_mask || (((uintptr_t)drop_mask) & 15) || mode == 2) return VXB_EARG;

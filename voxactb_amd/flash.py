@@ -78,13 +78,16 @@ def kv_planes(kv, mode):
     return out
 
 
-# Round 6: the forward stores the dropout keep words, the backward reads them instead of hashing (seed, row, key) again.  Measured (B = 16,
-# tools/experiments/attn_mask_probe.py, profiles/r06_attn_mask_probe.log): 8-head self-attention 2048 x 2048 forward 0.279 -> 0.263 ms,
-# dK | dV 0.498 -> 0.453 ms, dQ unchanged (its scalar loads of the lane masks wait out their latency where the hash kept the vector ALU busy);
-# the 1-head cross attentions (256 / 1024 workgroups: every wave's scalar stores sit on its critical path) lose in the forward what the
-# backward gains, so the words are stored only where the grid fills the chip twice over.  '0' = never, '2' = always (tests).
+# Round 6: with dropout the forward stores the mask as "keep words" and the backward reads them instead of hashing (seed, row, key) again;
+# the storing forward draws the mask from a per-row linear congruential sequence (one instruction per score pair instead of a 7-instruction
+# hash).  Measured at B = 16 (tools/experiments/attn_mask_probe.py, profiles/r06_attn_mask_probe.log), hash pair -> stored mask:
+#   8-head self-attention 2048 x 2048:  forward 0.277 -> 0.232 ms, dK | dV 0.440 -> 0.395 (with the stage-unrolled loop), dQ unchanged
+#   decoder cross attention 8077 x 2048 (1 head, 1024 workgroups): forward 0.110 -> 0.103, backward 0.413 -> 0.361
+#   latent cross attention 2048 x 8077 (1 head, 256 workgroups): forward 0.129 -> 0.131, backward 0.368 -> 0.361 -- a wash: below one
+#   workgroup per CU every wave's scalar stores sit on its critical path, so the words are stored from 1024 workgroups on.
+# '0' = never, '2' = always (tests).
 DROP_MASK = os.environ.get('VOXACTB_ATTN_DROP_MASK', '1')
-DROP_MASK_MIN_WORKGROUPS = 2048
+DROP_MASK_MIN_WORKGROUPS = 1024
 
 
 def drop_mask_words(B, H, Nq, Nk, device):
