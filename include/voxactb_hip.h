@@ -523,7 +523,7 @@ int vxb_flash2_attn_bwd(const float* q, const float* kv, const float* o, const f
 /* Round 6: the dropout mask as DATA.  The forward's threshold compares leave one 64-bit lane mask per score register in an SGPR pair; with
  * dropout_p > 0 vxb_flash2_attn_fwd_mask also stores those pairs (scalar stores, no vector-ALU work) as "keep words" -- bit q of word
  * [b * H + h][32-row block][64-key tile][kb][r][half] = query row 32 block + q keeps key 64 tile + 32 kb + (r & 3) + 8 (r >> 2) + 4 half --
- * and vxb_flash2_attn_bwd_mask reads them (dQ kernel: scalar loads straight into v_cndmask; dK | dV kernel: one word per lane and 32 rows)
+ * and vxb_flash2_attn_bwd_mask reads them (through LDS with the tile loads; one bit test per score in both kernels)
  * instead of hashing (seed, row, key) again (9 - 15 vector instructions per score pair less in the backward).  Because the mask is handed
  * on as data, this forward does not evaluate the (seed, row, key) hash of the entries above either: it draws the mask from a per-row 24-bit
  * linear congruential sequence seeded by (seed, row) -- one full-rate instruction per score pair, same Bernoulli(1 - p) statistics, same

@@ -128,7 +128,7 @@ def _ref_with_mask(q, kv, d_o, keep, B, H, Nq, Nk, scale, p):
 @pytest.mark.parametrize('mode,gx', [('f16', False), ('f16', True), ('bf16', False)])
 def test_stored_dropout_mask_forward_and_backward(shape, mode, gx, monkeypatch):
     """Round 6: with dropout the forward can store the mask (the threshold compares' lane masks, scalar stores) and the backward reads it
-    (dQ kernel: scalar loads into v_cndmask; dK | dV kernel: one word per lane and 32 rows) instead of hashing (seed, row, key) again; the
+    (both kernels: through LDS with the tile loads, one bit test per score) instead of hashing (seed, row, key) again; the
     storing forward draws the mask from a per-row linear congruential sequence.  Checked against a FLOAT64 attention that applies the
     stored mask, decoded by the documented layout: forward output, dQ, dK | dV -- any wrong word, bit position or layout index in either
     backward kernel drops other scores and differs by O(1).  Ragged shapes: row blocks / key tiles past the end.  Also: the keep rate is

@@ -119,15 +119,11 @@ __device__ __forceinline__ void fb_split3(float x, unsigned& w01, unsigned& w2) 
     w2 = fb_pack<MODE>(r1 - m, 0.f) & 0xffffu;
 }
 
-// DROP == 2: the forward's keep words instead of the hash.  dQ kernel (lane = query, as the forward): the two SGPR pairs of a score pair come
-// back by scalar loads (constant address space: the compiler selects s_load and tracks lgkmcnt) and go straight into v_cndmask as lane masks.
-typedef unsigned fb_u4 __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(4))) fb_u4 fb_c4;
-__device__ __forceinline__ float fb_sel(float if_set, float if_clear, unsigned long long lanes) {
-    float d;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(if_clear), "v"(if_set), "s"(lanes));
-    return d;
-}
+// DROP == 2: the forward's keep words (flash2_fwd.hip: f2_store_keep) instead of the hash.  Both kernels take them through LDS with their
+// tile loads and test ONE bit per score: dQ (lane = query) word (key) bit (own row), dK | dV (lane = key) word (own key) bit (row).  (The
+// first version of the dQ kernel loaded the lane masks by scalar loads straight into v_cndmask -- one instruction per score instead of
+// two -- and was no faster than hashing: a scalar load can only be waited for with lgkmcnt(0), which drains the LDS fragment reads in
+// flight; 48.8 % of its time in s_waitcnt, profiles/r06_v1_sq_summary.txt.)
 
 // ------------------------------------------------------------------------------------------------ preparation
 // D[bh][q] = sum_d dO O, and the largest |dO| (magnitude bits, atomicMax) -- one 16-lane group per (row, head)
@@ -228,8 +224,9 @@ __global__ void __launch_bounds__(NW * 64, 2) f2b_dq_kernel(F2bArgs g) {
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     constexpr int NG = 1 + GX;
     constexpr int LPW = 8 / NW;
-    constexpr int NLOAD = 2 * LPW;                  // K and V tile pieces per wave
+    constexpr int NLOAD = 2 * LPW + (DROP == 2 ? 1 : 0);      // K and V tile pieces (+ this wave's 64 keep words of the tile) per wave
     constexpr int VOFF = NST * TILE;
+    constexpr int MOFF = 2 * NST * TILE;            // DROP == 2: keep words, [stage][wave][64 words] (u16 offset)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, lq = lane & 31;
@@ -298,6 +295,9 @@ __global__ void __launch_bounds__(NW * 64, 2) f2b_dq_kernel(F2bArgs g) {
         lkey[t] = (wid + NW * t) * 8 + (lane >> 3);
         chb[t] = (unsigned)(((lane & 7) ^ fb_swz(lkey[t])) * 16);
     }
+    // keep words of this wave's 32 rows (DROP == 2): 64 words per key tile, [kb][r][half]
+    const unsigned* mwave_g = DROP == 2 ? g.mask + ((size_t)bh * g.nrb + (size_t)(qblk * NW + wid)) * (size_t)g.ntile * 64 : nullptr;
+    const int nkt_ = (g.Nk + BT - 1) / BT;
     auto issue = [&](int kt) {
 #pragma unroll
         for (int t = 0; t < LPW; ++t) {
@@ -305,12 +305,14 @@ __global__ void __launch_bounds__(NW * 64, 2) f2b_dq_kernel(F2bArgs g) {
             fb_load16(kbase_g, key * rowb + chb[t], smem0 + (unsigned)(((kt & 3) * TILE + (wid + NW * t) * 512) * 2));
             fb_load16(vbase_g, key * rowb + chb[t], smem0 + (unsigned)((VOFF + (kt & 3) * TILE + (wid + NW * t) * 512) * 2));
         }
+        // this wave's keep words of the tile: 64 words, lane l -> word l (the words travel through LDS, not by scalar loads: a scalar
+        // load's result can only be waited for with lgkmcnt(0), which also drains the LDS fragment reads in flight -- measured: the dQ
+        // kernel with scalar-loaded lane masks spent 48.8 % of its time in s_waitcnt and was no faster than hashing the mask)
+        if (DROP == 2) fb_load4(mwave_g, (unsigned)((min(kt, nkt_ - 1) * 64 + lane) * 4), smem0 + (unsigned)((MOFF + ((kt & 3) * NW + wid) * 128) * 2));
     };
     const unsigned thr = (unsigned)(g.p_drop * 65536.0f);
     const unsigned row_id = (unsigned)bh * (unsigned)g.Nq + (unsigned)qrow;
     const unsigned rowh = row_id * 0x9E3779B1U + g.seed;
-    // keep words of this wave's 32 rows (DROP == 2): 64 words per key tile, [kb][r][half]
-    const unsigned long long mwave = DROP == 2 ? (unsigned long long)(uintptr_t)(g.mask + ((size_t)bh * g.nrb + (size_t)(qblk * NW + wid)) * (size_t)g.ntile * 64) : 0ull;
     int rbase[2], rkey[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) { const int row = kb * 32 + lq; rbase[kb] = row * 64; rkey[kb] = fb_swz(row); }
@@ -338,14 +340,16 @@ __global__ void __launch_bounds__(NW * 64, 2) f2b_dq_kernel(F2bArgs g) {
         return fb_from4(one2, w1, 0u, 0u);
     };
     // element pair t = 0..7 of a unit: dS' = exp2(S') * (keep ? T' : -D'), packed hi (| lo)
-    auto pair = [&](int colb, const fb_u4 (&munit)[8], int kb, int t, const f32x16& s, const f32x16& tt, unsigned (&ds)[NG][8]) {
+    auto pair = [&](int colb, const unsigned (&munit)[16], int kb, int t, const f32x16& s, const f32x16& tt, unsigned (&ds)[NG][8]) {
         const int r = 2 * t;
         const float p0 = __builtin_amdgcn_exp2f(s[r]), p1 = __builtin_amdgcn_exp2f(s[r + 1]);
         float t0 = tt[r], t1 = tt[r + 1];
         if (DROP == 2) {
-            const fb_u4 w = munit[t];                       // words 4 t .. 4 t + 3 of the unit: the lane masks of registers r, r + 1
-            t0 = fb_sel(t0, negd, (unsigned long long)w.x | ((unsigned long long)w.y << 32));
-            t1 = fb_sel(t1, negd, (unsigned long long)w.z | ((unsigned long long)w.w << 32));
+            // munit[k] (per lane) = word 2 k + hi of the unit: this lane half's key of register k; bit lq = this row
+            int m0 = __builtin_amdgcn_sbfe((int)munit[r], lq, 1), m1 = __builtin_amdgcn_sbfe((int)munit[r + 1], lq, 1);
+            asm("" : "+v"(m0), "+v"(m1));                   // (opaque 0 / -1: keeps the bit selects below as v_bfi)
+            t0 = __int_as_float((m0 & __float_as_int(t0)) | (~m0 & __float_as_int(negd)));
+            t1 = __int_as_float((m1 & __float_as_int(t1)) | (~m1 & __float_as_int(negd)));
         } else if (DROP) {
             const unsigned cp = (unsigned)((kb * 32 + (r & 3) + 8 * (r >> 2)) >> 1) * 0x85EBCA77U;
             const unsigned hsh = fb_hash(rowh ^ ((unsigned)colb + cp));
@@ -366,11 +370,11 @@ __global__ void __launch_bounds__(NW * 64, 2) f2b_dq_kernel(F2bArgs g) {
                     const f32x16& sc_, const f32x16& tc_, unsigned (&dsc)[NG][8], const unsigned (&dsp)[NG][8]) {
         constexpr bool HN = decltype(has_n)::value, HC = decltype(has_c)::value, HD_ = decltype(has_d)::value;
         const int colb = (int)((unsigned)((ktc * BT + 4 * hi) >> 1) * 0x85EBCA77U + 0xC2B2AE3DU);
-        fb_u4 munit[8];                                     // the unit's 32 keep words: requested here (two s_load_dwordx16), used pair by pair
+        unsigned munit[16];                                 // the unit's keep words of this lane half, read with the step's first fragments
         if (DROP == 2 && HC) {
-            fb_c4* const mp = (fb_c4*)(mwave + ((unsigned long long)ktc * 64 + (unsigned long long)kbc * 32) * 4);
+            const unsigned* const mp = reinterpret_cast<const unsigned*>(smem + MOFF + ((ktc & 3) * NW + wid) * 128) + kbc * 32 + hi;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) munit[i] = mp[i];
+            for (int k = 0; k < 16; ++k) munit[k] = mp[2 * k];
         }
         bf16x8 kf[4], vf[4], tf[4];
         auto load_group = [&](int i) {
@@ -787,8 +791,9 @@ int f2b_dq_launch(const F2bArgs& g, bool drop, hipStream_t st) {
     const size_t lds = (size_t)2 * NST * TILE * sizeof(u16);
     const dim3 grid(g.nblk * g.B * g.H);
     if (drop && g.mask) {
-        if (hipFuncSetAttribute((const void*)f2b_dq_kernel<MODE, GX, 2, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
-        hipLaunchKernelGGL((f2b_dq_kernel<MODE, GX, 2, NW>), grid, dim3(NW * 64), lds, st, g);
+        const size_t ldsm = lds + (size_t)NST * NW * 256;       // + the keep-word ring
+        if (hipFuncSetAttribute((const void*)f2b_dq_kernel<MODE, GX, 2, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm) != hipSuccess) return VXB_ELAUNCH;
+        hipLaunchKernelGGL((f2b_dq_kernel<MODE, GX, 2, NW>), grid, dim3(NW * 64), ldsm, st, g);
     } else if (drop) {
         if (hipFuncSetAttribute((const void*)f2b_dq_kernel<MODE, GX, 1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
         hipLaunchKernelGGL((f2b_dq_kernel<MODE, GX, 1, NW>), grid, dim3(NW * 64), lds, st, g);

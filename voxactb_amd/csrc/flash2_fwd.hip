@@ -124,7 +124,7 @@ __device__ __forceinline__ void f2_acc(float& acc, float x) {
 // Dropout keep words (round 6).  The compare of a score's 16-bit hash field against the threshold leaves a 64-bit lane mask in an SGPR pair
 // anyway (lanes 0 - 31: the wave's 32 query rows for key k, lanes 32 - 63: the same rows for key k + 4); with DROP == 2 the forward stores
 // those pairs -- scalar stores: no vector ALU work -- and the backward kernels read the mask instead of hashing it again (csrc/flash2_bwd.hip:
-// 11 and 24 vector instructions per score pair in the dQ and the dK | dV kernel).  Word (bh, 32-row block, 64-key tile, kb, r, half) =
+// 11 and 24 vector instructions per score pair in the dQ and the dK | dV kernel become 4 and 6).  Word (bh, 32-row block, 64-key tile, kb, r, half) =
 // keep bits of rows 32 qb32 .. + 32 for key 64 tile + 32 kb + (r & 3) + 8 (r >> 2) + 4 half; 64 words per (row block, tile).
 typedef unsigned f2_v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void f2_store_keep(unsigned long long m0, unsigned long long m1, unsigned* base, unsigned byte_off) {

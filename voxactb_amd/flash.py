@@ -81,13 +81,13 @@ def kv_planes(kv, mode):
 # Round 6: with dropout the forward stores the mask as "keep words" and the backward reads them instead of hashing (seed, row, key) again;
 # the storing forward draws the mask from a per-row linear congruential sequence (one instruction per score pair instead of a 7-instruction
 # hash).  Measured at B = 16 (tools/experiments/attn_mask_probe.py, profiles/r06_attn_mask_probe.log), hash pair -> stored mask:
-#   8-head self-attention 2048 x 2048:  forward 0.277 -> 0.232 ms, dK | dV 0.440 -> 0.395 (with the stage-unrolled loop), dQ unchanged
-#   decoder cross attention 8077 x 2048 (1 head, 1024 workgroups): forward 0.110 -> 0.103, backward 0.413 -> 0.361
-#   latent cross attention 2048 x 8077 (1 head, 256 workgroups): forward 0.129 -> 0.131, backward 0.368 -> 0.361 -- a wash: below one
-#   workgroup per CU every wave's scalar stores sit on its critical path, so the words are stored from 1024 workgroups on.
-# '0' = never, '2' = always (tests).
+#   8-head self-attention 2048 x 2048:  forward 0.277 -> 0.232 ms, backward (dQ + dK | dV + preparation) 0.727 -> 0.668
+#   decoder cross attention 8077 x 2048 (1 head, 1024 workgroups): forward 0.110 -> 0.103, backward 0.405 -> 0.365
+#   latent cross attention 2048 x 8077 (1 head, 256 workgroups): forward 0.129 -> 0.131 (every wave's scalar stores sit on its critical
+#   path below one workgroup per CU), backward 0.363 -> 0.333
+# Stored from 256 workgroups on (the step's three attention shapes); smaller problems keep the hash pair.  '0' = never, '2' = always (tests).
 DROP_MASK = os.environ.get('VOXACTB_ATTN_DROP_MASK', '1')
-DROP_MASK_MIN_WORKGROUPS = 1024
+DROP_MASK_MIN_WORKGROUPS = 256
 
 
 def drop_mask_words(B, H, Nq, Nk, device):
