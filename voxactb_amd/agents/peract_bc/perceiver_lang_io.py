@@ -375,6 +375,7 @@ class PerceiverEngine:
         self.freeze_weight_prep = False
         self._prep_sig = None
         self._weff_keep = None
+        self._prepared_for_step = False
 
     # -------------------------------------------------------------------------------------------------- helpers
     def _draw_seed(self):
@@ -544,6 +545,29 @@ class PerceiverEngine:
                           self.g(pre + '.norm.bias'), dx=dx, accumulate_dx=True)
         return dx
 
+    def prepare_step(self):
+        """The per-step forms of the linear layers' weights (bf16 planes / MFMA fragments: one 0.28 ms launch), made BEFORE the step's first
+        data-dependent kernel.  update() calls this ahead of the SE(3) relabel and the voxelizer's chain of dependent launches: the step
+        starts on an empty queue (the runner's `.item()` on the previous loss), where every launch waits for the host to enqueue it;
+        behind 0.28 ms of weight preparation the host is ahead when the chain runs.  (Round 6.  It does NOT change what bench.py's event
+        pair around the voxelizer call reads -- 0.150 - 0.158 ms before and after: that figure is the chain's kernels running on cold
+        caches, `vt_tiles` 74 us in the step against 67 stand-alone, plus its launch boundaries)
+        forward(training=True, save=True) of the same step skips its own preparation."""
+        ops.new_step()
+        self._weff_keep = None
+        ops.PRECISION = self.precision
+        try:
+            if self._lin_weights is None:
+                self._lin_weights = [n for n, prm in self.P.items() if prm.dim() == 2 and n.endswith('.weight') and prm.numel() >= 4096]
+            ops.prepare_linear_weights([self.p(n) for n in self._lin_weights],
+                                       geglu=[self.p(n) for n in self._lin_weights if n.endswith('.fn.net.0.weight')],
+                                       f16_dgrad=self.precision == 'bf16x3' and self.wgrad_precision == 'fp16')
+            self._prep_sig = None
+            ops.CACHE_OWNER = None
+        finally:
+            ops.PRECISION = 'fp32'
+        self._prepared_for_step = True
+
     # -------------------------------------------------------------------------------------------------- forward
     def forward(self, vox, proprio, lang_token_embs, training=False, save=True, seed=None, proprio_left=None, lang_goal_emb=None):
         """vox [B,V,V,V,10] channels-last.  Returns ((trans [B,1,V,V,V], rot_and_grip, collision[, arm]), cache); for the
@@ -557,6 +581,9 @@ class PerceiverEngine:
             first = next(iter(self.P.values()))
             sig = (self.precision, sum(prm._version for prm in self.P.values()), first.data_ptr(), len(self.P))
         reuse = sig is not None and sig == self._prep_sig and ops.CACHE_OWNER is self
+        if self._prepared_for_step and training and save and ops.CACHE_OWNER is None:
+            reuse = True                  # prepare_step() ran for this very step (update() calls it before the voxelizer)
+        self._prepared_for_step = False
         if not reuse:
             ops.new_step()
             self._weff_keep = None

@@ -325,6 +325,7 @@ class QAttentionPerActBCAgent(Agent):
         if self._layer > 0:
             cp = replay_sample['attention_coordinate_layer_%d' % (self._layer - 1)]
             bounds = torch.cat([cp - self._bounds_offset, cp + self._bounds_offset], dim=1)
+        self._q.encoder.engine().prepare_step()          # (weight forms of this step first: the GPU has work while the host enqueues the voxelizer chain)
         proprio = replay_sample['low_dim_state'] if self._include_low_dim_state else None
         obs, pcd = self._preprocess_inputs(replay_sample)
         bs = pcd[0].shape[0]
@@ -609,6 +610,7 @@ class QAttentionPerActBCAgent2Robots(QAttentionPerActBCAgent):
         if self._include_low_dim_state:
             proprio_right = replay_sample['low_dim_state_right_arm']
             proprio_left = replay_sample['low_dim_state_left_arm']
+        self._q.encoder.engine().prepare_step()          # (as the one-arm agent: weight forms first)
         obs, pcd = self._preprocess_inputs(replay_sample)
         bs = pcd[0].shape[0]
 
