@@ -27,6 +27,12 @@ DEV = 'cuda:0'
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
+# bias gradients of the grid-sized convs: sums of dY over 10^6 voxels -- the reference's OWN fp32 summation is 1 - 10 % from float64 there
+# (tests/test_c2_reference_gpu.py judges them against float64 sums for that reason); not a subgradient-choice effect, listed separately
+BIAS_SUMS = ('input_preprocess.conv3d.bias', 'patchify.conv3d.bias', 'up0.conv_up.0.conv3d.bias', 'up0.conv_up.2.conv3d.bias', 'final.conv3d.bias',
+             'trans_decoder.conv3d.bias')
+
+
 class G(dict):
     @property
     def files(self):
@@ -73,7 +79,7 @@ def product_errors(d, si, precision, attn_kernel):
     rel = []
     n64 = d['grad_norm64'][si]
     for i, n in enumerate([str(x) for x in d['grad_names']]):
-        if n64[i] <= 1e-6 * n64.max():
+        if n64[i] <= 1e-6 * n64.max() or n in BIAS_SUMS:
             continue
         est = float(ow.projection_error(ow.project(P[n].grad, n, nproj), torch.from_numpy(d['grad_proj64'][si][i])))
         rel.append(est / n64[i])
@@ -89,10 +95,15 @@ def main():
         if a.startswith('--max-seeds='):
             ns = min(ns, int(a.split('=')[1]))
     rows = {'reference fp32 (CPU, exact)': []}
+    names = [str(x) for x in d['grad_names']]
+    notbias = np.array([n not in BIAS_SUMS for n in names])
+    bias_rel = []
     for si in range(ns):
         n64 = d['grad_norm64'][si]
-        keep = n64 > 1e-6 * n64.max()
+        keep = (n64 > 1e-6 * n64.max()) & notbias
         rows['reference fp32 (CPU, exact)'].append(d['grad_err32'][si][keep] / n64[keep])
+        bias_rel.append((d['grad_err32'][si][~notbias] / (n64[~notbias] + 1e-300)).max())
+    print('(the six grid-conv bias gradients, excluded below: the reference\'s fp32 sums are %.1e .. %.1e from float64, median %.1e)' % (min(bias_rel), max(bias_rel), float(np.median(bias_rel))))
     modes = [('product exact fp32', 'fp32', 'r3'), ('product bf16x3, attention forward bf16x3 (default of rounds 3 - 5)', 'bf16x3', 'r3'),
              ('product bf16x3, attention forward 1x fp16 (default)', 'bf16x3', 'auto')]
     for name, prec, attn in modes:

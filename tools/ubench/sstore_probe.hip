@@ -22,7 +22,7 @@ __global__ void rd(const unsigned long long* p, unsigned long long* outv, unsign
     const unsigned long long* q = p + (size_t)__builtin_amdgcn_readfirstlane(wave) * n_words;
     unsigned long long sv = 0, ss = 0;
     for (int i = 0; i < n_words; ++i) {
-        sv += p[(size_t)wave * n_words + ((i + lane) % n_words)] * (unsigned long long)(2 * i + 1);       // vector loads
+        { const int w_ = (i + lane) % n_words; sv += p[(size_t)wave * n_words + w_] * (unsigned long long)(2 * w_ + 1); }      // vector loads
         ss += q[i] * (unsigned long long)(2 * i + 1);                                                    // uniform address: scalar loads
     }
     if (lane == 0) outs[wave] = ss;
