@@ -102,8 +102,9 @@ def main():
         n64 = d['grad_norm64'][si]
         keep = (n64 > 1e-6 * n64.max()) & notbias
         rows['reference fp32 (CPU, exact)'].append(d['grad_err32'][si][keep] / n64[keep])
-        bias_rel.append((d['grad_err32'][si][~notbias] / (n64[~notbias] + 1e-300)).max())
-    print('(the six grid-conv bias gradients, excluded below: the reference\'s fp32 sums are %.1e .. %.1e from float64, median %.1e)' % (min(bias_rel), max(bias_rel), float(np.median(bias_rel))))
+        big = (~notbias) & (n64 > 1e-6 * n64.max())          # (trans_decoder's bias gradient is zero mathematically)
+        bias_rel.append((d['grad_err32'][si][big] / n64[big]).max())
+    print('(the grid-conv bias gradients -- sums of dY over 10^6 voxels -- excluded below: the reference\'s own fp32 sums are %.1e .. %.1e from float64 (worst tensor per batch), median %.1e)' % (min(bias_rel), max(bias_rel), float(np.median(bias_rel))))
     modes = [('product exact fp32', 'fp32', 'r3'), ('product bf16x3, attention forward bf16x3 (default of rounds 3 - 5)', 'bf16x3', 'r3'),
              ('product bf16x3, attention forward 1x fp16 (default)', 'bf16x3', 'auto')]
     for name, prec, attn in modes:
