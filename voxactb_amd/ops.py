@@ -1249,8 +1249,10 @@ def halo_wfrag_x2_wg(wt_kn, Ct):
 
 def conv3_ss3d_fwd(src0, src1, wt, bias, B, S, act=ACT_LRELU, label=None):
     """conv3d(src0 | src1, 3x3x3, replicate padding, 64 columns) + ss3d_max_fwd of its output, the statistics taken in the conv's
-    epilogue (vxb_conv3_halo_ss3d_bf16x3_f32): -> (out [B,S,S,S,64], (out_ss, out_max, stats, argmax)).  `out` is bit-identical to
-    conv3d's; the pooled features equal ss3d_max_fwd's up to the association of the partial sums."""
+    epilogue (vxb_conv3_halo_ss3d_bf16x3_f32): -> (out [B,S,S,S,64], (out_ss, out_max, stats, argmax)).  With FINAL_WINOGRAD off (or an
+    odd grid) `out` is bit-identical to conv3d's; with the depth axis by Winograd's F(2, 3) (the default on even grids since round 5) it
+    agrees with it to ~1e-6 of the output maximum (tests/test_halo_winograd_gpu.py), not bit for bit.  The pooled features equal
+    ss3d_max_fwd's up to the association of the partial sums."""
     dev = src0.device
     C0 = src0.shape[-1]
     C1 = src1.shape[-1] if src1 is not None else 0
