@@ -58,8 +58,9 @@ def test_c1_matrix_core_forward_and_wgrad(B, S, mode):
         ops.conv3_c1_wgrad(ud, dq.to(DEV), dw, dbb, B, S)
         dw2, db2 = torch.zeros_like(dw), torch.zeros_like(dbb)
         ops.conv3_c1_wgrad(ud, dq.to(DEV), dw2, db2, B, S)
-        # the shipped arithmetic of the default precision: one fp16 product per term, dq scaled by a device-side power of two
-        ops.C1_WGRAD_F16, ops.WGRAD_PRECISION = True, 'fp16'
+        # the shipped arithmetic of the default precision from 2^19 voxels on (here: at every size): one fp16 product per term, dq scaled by
+        # a device-side power of two
+        ops.C1_WGRAD_F16, ops.WGRAD_PRECISION, ops.C1_WGRAD_F16_MIN_VOXELS = True, 'fp16', 0
         dw16, db16 = torch.zeros_like(dw), torch.zeros_like(dbb)
         ops.conv3_c1_wgrad(ud, dq.to(DEV), dw16, db16, B, S)
         dw16b = torch.zeros_like(dw)
@@ -67,7 +68,7 @@ def test_c1_matrix_core_forward_and_wgrad(B, S, mode):
         ops.C1_MFMA = False
         q_exact = ops.conv3_c1_fwd(ud, w1.detach().to(DEV), b1.detach().to(DEV), B, S)
     finally:
-        ops.PRECISION, ops.C1_MFMA, ops.C1_WGRAD_F16, ops.WGRAD_PRECISION = 'fp32', True, True, ''
+        ops.PRECISION, ops.C1_MFMA, ops.C1_WGRAD_F16, ops.WGRAD_PRECISION, ops.C1_WGRAD_F16_MIN_VOXELS = 'fp32', True, True, '', 1 << 19
     if mode == 'bf16x3':
         close(dw16, w1.grad.float(), 1e-3, 'c1 fp16 wgrad')
         close(dw16b * 1e7, w1.grad.float(), 1e-3, 'c1 fp16 wgrad, tiny dq')

@@ -1347,13 +1347,16 @@ def conv3_c1_dgrad_ss3d(dq, w, u, du, B, S, stats, out_ss, argmax, g_ss, g_max, 
 
 
 C1_WGRAD_F16 = os.environ.get('VOXACTB_C1_WGRAD_F16', '1') != '0'    # trans_decoder weight gradient on single fp16 products ('0': bf16x3)
+C1_WGRAD_F16_MIN_VOXELS = 1 << 19
 
 
 def conv3_c1_wgrad(u, dq, dw, db, B, S):
     if C1_MFMA and _mm() and u.shape[-1] == 64:
         nb = int(_lib.lib().vxb_conv3_c1_wgrad_mfma_blocks(B, S))
         ws = torch.empty(nb * (64 * 27 + 1), dtype=torch.float32, device=u.device)
-        if C1_WGRAD_F16 and PRECISION == 'bf16x3' and WGRAD_PRECISION == 'fp16' and dq.is_contiguous():
+        # (from 2^19 voxels on -- round 6: below that nothing averages the 2^-12 operand rounding of a 64 x 27 gradient summed over a few 10^4
+        # voxels, the one widened element gate of the suite (no_skip_connection at V = 32, 1.04 x) came from here; the bf16x3 kernel runs there)
+        if C1_WGRAD_F16 and PRECISION == 'bf16x3' and WGRAD_PRECISION == 'fp16' and dq.is_contiguous() and B * S ** 3 >= C1_WGRAD_F16_MIN_VOXELS:
             # a leaf of the backward pass: one fp16 product per term, dq scaled by a device-side power of two (max |dq| -> [2^14, 2^15))
             _lib.set_meta('vxb_conv3_c1_wgrad_mfma', 0.0)
             sc = absmax_scale(dq)
