@@ -138,3 +138,46 @@ def test_linear_weight_gradient_fp16_wide_and_pipelined_kernels(_wide_at_test_si
     finally:
         _lib.lib().vxb_debug_set_wgrad_lin(2)
         ops.PRECISION, ops.WGRAD_PRECISION, ops.GENERIC_WGRAD_F16, ops._GRAD_SCALE = 'fp32', '', False, {}
+
+
+@pytest.mark.parametrize('M,N,K', [(32768, 4096, 512), (32768, 512, 2048), (4096 + 16 * 5, 512, 512)])
+def test_wide_weight_gradient_main_loop_against_its_guarded_form(M, N, K):
+    """wgrad_wide_f16_kernel (round 6): the main loop -- unconditional loads and stores, flags at compile time, the conversion of the next tile
+    and the loads issued between the MFMAs, workgroups in XCD-aware order -- accumulates in the order of the guarded steps of rounds 3 - 5:
+    dW, db and the reported operand scale are bit-identical with every step through the guarded form (vxb_debug_set_wgrad_lin(2 + 64)) and
+    in the plain workgroup order (2 + 16); a NaN / an inf anywhere in dy reaches the reported scale in both (slices of 5 .. 128 tiles: the
+    main loop's rounds, the guarded remainder and slices shorter than a round are all taken)."""
+    from .test_ops_gpu import rnd, DEV
+    from voxactb_amd import _lib
+    x, W = rnd(M, K).to(DEV), rnd(N, K, seed=1).to(DEV)
+    dy = rnd(M, N, seed=2).to(DEV) * 3e-4
+    ops.PRECISION, ops.WGRAD_PRECISION, ops.GENERIC_WGRAD_F16 = 'bf16x3', 'fp16', True
+    ops.set_wide_min_rows(1024)
+    try:
+        def run(mode, *dys):
+            _lib.lib().vxb_debug_set_wgrad_lin(mode)
+            ops._GRAD_SCALE = {}
+            for dy_ in dys:                      # (the first call takes its scale from a pass over dy, the next ones from the launch before)
+                dW, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+                ops.begin_backward()
+                ops.linear_bwd(x, W, dy_, dW, db, None)
+            (st,) = ops._GRAD_SCALE.values()
+            return dW, db, st[0].clone()         # st[0]: the scale this launch reported for the next one
+        a = run(2, dy)
+        ref = dy.double().t() @ x.double()
+        assert float((a[0].double() - ref).abs().max() / ref.abs().max()) < 1e-3
+        for mode in (2 + 64, 2 + 16):
+            b = run(mode, dy)
+            for u, v in zip(a, b):
+                assert torch.equal(u, v), mode
+        for bad in (float('nan'), float('inf')):
+            dyb = dy.clone()
+            dyb[M - 7, N // 2 + 3] = bad
+            for mode in (2, 2 + 64):
+                assert bool(torch.isfinite(run(mode, dy, dy)[2]).all())
+                sc = run(mode, dy, dyb)[2]
+                assert not bool(torch.isfinite(sc).all()), (bad, mode, sc)
+    finally:
+        _lib.lib().vxb_debug_set_wgrad_lin(2)
+        ops.set_wide_min_rows(16384)
+        ops.PRECISION, ops.WGRAD_PRECISION, ops.GENERIC_WGRAD_F16, ops._GRAD_SCALE = 'fp32', '', False, {}

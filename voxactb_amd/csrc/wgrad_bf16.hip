@@ -573,68 +573,97 @@ struct WideArgs {
     float* possum;                         // optional: position sums of src0's channels: [z][channels of src0]
     int possum_is_u;                       // src0 is U (its 128 channels of this tile) or V (all 512, i-tile 0 only)
     int possum_stride;                     // channels of src0
+    int dbg_order;                         // experiment: 1 = workgroups in the plain (i tile fastest) launch order
+    int dbg_slow;                          // experiment: 1 = every step through the guarded form (rounds 3 - 5)
 };
 
+// WP = positions per tile: 16 (one MFMA k-step, three register sets of loads in flight: rounds 3 - 5) or 32 (round 6: two k-steps per tile and
+// barrier, two register sets -- the 16-position tile gives a wave 8 MFMAs between barriers, 16.4 % matrix-pipe duty and 53 % of its time in
+// s_waitcnt, profiles/r06_v2_sq_summary.txt: the LDS store -> barrier -> transposed read -> MFMA chain of a tile is not covered)
+template <int WP, int AFL, int PFL>
 __global__ void __launch_bounds__(512) wgrad_wide_f16_kernel(WideArgs g) {
-    constexpr int PM = 2, BI = 128, BJ = 512, WP = 16;   // WP positions per tile = one MFMA k-step
+    constexpr int PM = 2, BI = 128, BJ = 512;
+    constexpr int NSET = WP == 16 ? 3 : 2, NA = WP / 16, NB = WP / 4;         // register sets; A / B loads per thread and tile
     constexpr int LDA = BI + 32, LDB = BJ + 32;          // 80 / 272 dwords per position row: both = 16 (mod 64)
     extern __shared__ __attribute__((aligned(16))) u16 wsm[];
     u16* As0 = wsm;                                      // [2][WP * LDA]
     u16* Bs0 = wsm + 2 * WP * LDA;                       // [2][WP * LDB]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 2, wn = wid & 3;
-    const int i0 = blockIdx.x * BI;
+    // Workgroup -> (i tile bi, position slice bz).  Every i tile of a slice streams the SAME rows of V: hardware places linear workgroup id
+    // L on XCD L % 8 (each with a private L2), so the ids are permuted to give an XCD a contiguous run of (slice, i tile) pairs -- the i
+    // tiles of a slice run side by side behind ONE L2 and V comes out of it for all but the first (round 6; before, the 32 i tiles of the
+    // GEGLU up-projection's gradient were spread over all eight XCDs and V was re-read 32 x from beyond the L2: 2.1 GB per launch).
+    // Bijective for any grid; only speed depends on it.  g.dbg_order != 0: the plain order (A/B).
+    int bi = blockIdx.x, bz = blockIdx.y;
+    if (!g.dbg_order) {
+        const int nwg = gridDim.x * gridDim.y, lid = blockIdx.x + gridDim.x * blockIdx.y;
+        const int xcd = lid & 7, slot = lid >> 3;
+        const int q_ = nwg >> 3, r_ = nwg & 7;
+        const int t = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + slot;
+        bi = t % gridDim.x;
+        bz = t / gridDim.x;
+    }
+    const int i0 = bi * BI;
     // tile rows: A (U): pos = tid / 32 (16 rows x 32 quads); B (V): pos = tid / 128 + 4 i (4 rows per pass x 128 quads)
     long long nkt = g.P / WP;                            // (host: P % 16 == 0)
-    const long long kt_begin = (long long)blockIdx.y * g.tiles_per_split;
+    const long long kt_begin = (long long)bz * g.tiles_per_split;
     if (nkt > kt_begin + g.tiles_per_split) nkt = kt_begin + g.tiles_per_split;
     const int nt = nkt > kt_begin ? (int)(nkt - kt_begin) : 0;
     // running load pointers: tiles are loaded strictly in order (0, 1, 2, ...), each load advances them by one tile
     const float* __restrict__ up = g.U + i0 + (tid & 31) * 4 + (kt_begin * WP + (tid >> 5)) * g.ldu;
     const float* __restrict__ vp = g.V + (tid & 127) * 4 + (kt_begin * WP + (tid >> 7)) * g.ldv;
-    const long long ustep = WP * g.ldu, v4 = 4 * g.ldv;
+    const long long u16s = 16 * g.ldu, v4 = 4 * g.ldv;
 
     // three register sets: the loads of tiles t+2, t+3, t+4 are in flight while tile t is multiplied (a workgroup per CU: nothing
     // else hides the ~2.5 us a loaded tile takes to arrive)
-    float4 ra[3], rb[3][4];
+    float4 ra[NSET][NA], rb[NSET][NB];
 #define WW_LOAD(S, t_)                                                                                               \
     {                                                                                                                \
-        ra[S] = *reinterpret_cast<const float4*>(up);                                                                \
-        up += ustep;                                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) { rb[S][i] = *reinterpret_cast<const float4*>(vp); vp += v4; } \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) { ra[S][i] = *reinterpret_cast<const float4*>(up); up += u16s; } \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) { rb[S][i] = *reinterpret_cast<const float4*>(vp); vp += v4; } \
     }
     const float sc_a = (g.scale && g.grad_is_u) ? g.scale[0] : 1.0f;
     const float sc_b = (g.scale && !g.grad_is_u) ? g.scale[0] : 1.0f;
-    const bool psum_u = g.possum != nullptr && g.possum_is_u;
-    const bool psum_v = g.possum != nullptr && !g.possum_is_u && blockIdx.x == 0;
-    const bool amax_u = g.amax_part != nullptr && g.grad_is_u;
-    const bool amax_v = g.amax_part != nullptr && !g.grad_is_u && blockIdx.x == 0;
+    // AFL / PFL (host: which operand the |x| maximum / the position sums are taken of: 0 none, 1 U, 2 V).  The V-side work is the same
+    // in every i tile of a slice; all of them do it and the i tile 0 workgroup writes it -- one instruction stream per kernel (two loop
+    // bodies in one kernel, with and without the V-side work, spilled 50 - 60 registers), ~24 more VALU instructions per tile next to
+    // the 60 of the conversion, issued between the MFMAs
+    constexpr bool psum_u = PFL == 1, psum_v = PFL == 2, amax_u = AFL == 1, amax_v = AFL == 2;
+    constexpr int AF = AFL, PF = PFL;
     float4 ps = make_float4(0.f, 0.f, 0.f, 0.f);        // position sums: of this thread's U quad (psum_u) or V quad (psum_v), never both
-    float amxf = 0.f, nanw = 0.f;          // largest |gradient operand| seen; nanw: NaN once a NaN / inf was seen (fmaxf drops NaN)
+    float amxf = 0.f;                      // largest |gradient operand| seen
+    vxb_f32x2 nanw = {0.f, 0.f};               // NaN once a NaN / inf was seen (fmaxf drops NaN): x * 0 accumulated, two lanes at a time
     const int a_st = (tid >> 5) * LDA + (tid & 31) * 4;
     const int b_st = (tid >> 7) * LDB + (tid & 127) * 4;
+#define WW_AMAX4(v)                                                                                                  \
+    {                                                                                                                \
+        amxf = fmaxf(fmaxf(amxf, fabsf((v).x)), fmaxf(fmaxf(fabsf((v).y), fabsf((v).z)), fabsf((v).w)));             \
+        nanw = __builtin_elementwise_fma(vxb_f32x2{(v).x, (v).y}, vxb_f32x2{0.f, 0.f}, nanw);                                \
+        nanw = __builtin_elementwise_fma(vxb_f32x2{(v).z, (v).w}, vxb_f32x2{0.f, 0.f}, nanw);                                \
+    }
+#define WW_FLAGS_A(S, i)                                                                                             \
+    {                                                                                                                \
+        if (PF == 1) { ps.x += ra[S][i].x; ps.y += ra[S][i].y; ps.z += ra[S][i].z; ps.w += ra[S][i].w; }             \
+        if (AF == 1) WW_AMAX4(ra[S][i])                                                                              \
+    }
+#define WW_FLAGS_B(S, i)                                                                                             \
+    {                                                                                                                \
+        if (PF == 2) { ps.x += rb[S][i].x; ps.y += rb[S][i].y; ps.z += rb[S][i].z; ps.w += rb[S][i].w; }             \
+        if (AF == 2) WW_AMAX4(rb[S][i])                                                                              \
+    }
 #define WW_STORE(S, stage_)                                                                                          \
     {                                                                                                                \
-        if (psum_u) { ps.x += ra[S].x; ps.y += ra[S].y; ps.z += ra[S].z; ps.w += ra[S].w; }                          \
-        if (psum_v) {                                                                                                \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) { ps.x += rb[S][i].x; ps.y += rb[S][i].y; ps.z += rb[S][i].z; ps.w += rb[S][i].w; } \
-        }                                                                                                            \
-        if (amax_u) {                                                                                                \
-            amxf = fmaxf(fmaxf(amxf, fabsf(ra[S].x)), fmaxf(fmaxf(fabsf(ra[S].y), fabsf(ra[S].z)), fabsf(ra[S].w))); \
-            nanw = fmaf((ra[S].x + ra[S].y) + (ra[S].z + ra[S].w), 0.0f, nanw);                                      \
-        }                                                                                                            \
-        if (amax_v) {                                                                                                \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                           \
-                amxf = fmaxf(fmaxf(amxf, fabsf(rb[S][i].x)), fmaxf(fmaxf(fabsf(rb[S][i].y), fabsf(rb[S][i].z)), fabsf(rb[S][i].w))); \
-                nanw = fmaf((rb[S][i].x + rb[S][i].y) + (rb[S][i].z + rb[S][i].w), 0.0f, nanw);                      \
-            }                                                                                                        \
-        }                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) WW_FLAGS_A(S, i)                                               \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) WW_FLAGS_B(S, i)                                               \
         u16* as_ = As0 + (stage_) * WP * LDA;                                                                        \
         u16* bs_ = Bs0 + (stage_) * WP * LDB;                                                                        \
-        uint2 p_;                                                                                                    \
-        p_.x = pack_bf16_2<PM>(ra[S].x * sc_a, ra[S].y * sc_a); p_.y = pack_bf16_2<PM>(ra[S].z * sc_a, ra[S].w * sc_a); \
-        *reinterpret_cast<uint2*>(&as_[a_st]) = p_;                                                                  \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                               \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                              \
+            uint2 p_;                                                                                                \
+            p_.x = pack_bf16_2<PM>(ra[S][i].x * sc_a, ra[S][i].y * sc_a); p_.y = pack_bf16_2<PM>(ra[S][i].z * sc_a, ra[S][i].w * sc_a); \
+            *reinterpret_cast<uint2*>(&as_[a_st + 16 * i * LDA]) = p_;                                               \
+        }                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                              \
             uint2 q_;                                                                                                \
             q_.x = pack_bf16_2<PM>(rb[S][i].x * sc_b, rb[S][i].y * sc_b); q_.y = pack_bf16_2<PM>(rb[S][i].z * sc_b, rb[S][i].w * sc_b); \
             *reinterpret_cast<uint2*>(&bs_[b_st + 4 * i * LDB]) = q_;                                                \
@@ -663,9 +692,85 @@ __global__ void __launch_bounds__(512) wgrad_wide_f16_kernel(WideArgs g) {
         if (tt_ < nt) {                                                                                              \
             const int cur_ = tt_ & 1;                                                                                \
             if (tt_ + 1 < nt) WW_STORE(S1, cur_ ^ 1)                                                                 \
-            if (tt_ + 4 < nt) WW_LOAD(S1, tt_ + 4)                                                                   \
-            const u16* at_ = As0 + cur_ * WP * LDA + a_lane;                                                         \
-            const u16* bt_ = Bs0 + cur_ * WP * LDB + b_lane;                                                         \
+            if (tt_ + 1 + NSET < nt) WW_LOAD(S1, tt_ + 1 + NSET)                                                     \
+            _Pragma("unroll") for (int ks = 0; ks < NA; ++ks) {                                                       \
+                const u16* at_ = As0 + cur_ * WP * LDA + ks * 16 * LDA + a_lane;                                     \
+                const u16* bt_ = Bs0 + cur_ * WP * LDB + ks * 16 * LDB + b_lane;                                     \
+                union { unsigned long long u[2]; bf16x8 v; } fa_[2], fb_[4];                                         \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                       \
+                    fa_[i].u[0] = wl_tr16(at_ + i * 32);                                                             \
+                    fa_[i].u[1] = wl_tr16(at_ + 4 * LDA + i * 32);                                                   \
+                }                                                                                                    \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                       \
+                    fb_[j].u[0] = wl_tr16(bt_ + j * 32);                                                             \
+                    fb_[j].u[1] = wl_tr16(bt_ + 4 * LDB + j * 32);                                                   \
+                }                                                                                                    \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = wg_mfma<PM>(fa_[i].v, fb_[j].v, acc[i][j]); \
+            }                                                                                                        \
+            __syncthreads();                                                                                         \
+        }                                                                                                            \
+    }
+    if (nt > 0) {
+        WW_LOAD(0, 0)
+        WW_STORE(0, 0)
+        if (nt > 1) WW_LOAD(1, 1)
+        if (NSET == 3) {
+            if (nt > 2) WW_LOAD(2 % NSET, 2)
+            if (nt > 3) WW_LOAD(0, 3)
+        } else if (nt > 2) WW_LOAD(0, 2)
+    }
+    __syncthreads();
+
+    // ---- the main loop: steps whose loads and stores are all unconditional, the flag work chosen at compile time (round 6) ----------------
+    // In the guarded step above the compiler cannot count the loads in flight across the `if`s and waits for all but the last four
+    // (s_waitcnt vmcnt(4) at the top of every step): the set loaded ONE step ago has to arrive, not the one loaded three steps ago, and
+    // every tile pays a memory round trip.  Here a step is one basic block: exact vmcnt, and the conversion of tile t+1 is issued between
+    // the MFMAs of tile t (pinned with sched_barrier) instead of in front of them with every wave of the workgroup in the same phase.
+    int t0 = 0;
+    // (a register quad is reloaded -- with the tile NSET steps on -- right after its conversion: the loads of a step are spread between its
+    //  MFMAs, so that a load waiting to be accepted by the memory pipeline stalls the wave while matrix work is already in the pipe)
+#if VXB_ABL & 1
+#define WW_ABL_LOAD_A(S, i) { up += u16s; }
+#define WW_ABL_LOAD_B(S, i) { vp += v4; }
+#else
+#define WW_ABL_LOAD_A(S, i) { ra[S][i] = *reinterpret_cast<const float4*>(up); up += u16s; }
+#define WW_ABL_LOAD_B(S, i) { rb[S][i] = *reinterpret_cast<const float4*>(vp); vp += v4; }
+#endif
+#if VXB_ABL & 2
+#define WW_ABL_MFMA(a, b, c) ({ asm volatile("" :: "v"(a), "v"(b)); c; })
+#else
+#define WW_ABL_MFMA(a, b, c) wg_mfma<PM>(a, b, c)
+#endif
+#define WW_CVT_A(S, i, as_)                                                                                          \
+    {                                                                                                                \
+        WW_FLAGS_A(S, i)                                                                                             \
+        uint2 p_;                                                                                                    \
+        p_.x = pack_bf16_2<PM>(ra[S][i].x * sc_a, ra[S][i].y * sc_a); p_.y = pack_bf16_2<PM>(ra[S][i].z * sc_a, ra[S][i].w * sc_a); \
+        *reinterpret_cast<uint2*>(&(as_)[a_st + 16 * (i) * LDA]) = p_;                                               \
+    }
+#define WW_CVT_B(S, i, bs_)                                                                                          \
+    {                                                                                                                \
+        WW_FLAGS_B(S, i)                                                                                             \
+        uint2 q_;                                                                                                    \
+        q_.x = pack_bf16_2<PM>(rb[S][i].x * sc_b, rb[S][i].y * sc_b); q_.y = pack_bf16_2<PM>(rb[S][i].z * sc_b, rb[S][i].w * sc_b); \
+        *reinterpret_cast<uint2*>(&(bs_)[b_st + 4 * (i) * LDB]) = q_;                                                \
+    }
+#if VXB_ABL & 4
+#define WW_ABL_CVT_A(S, i, as_) { asm volatile("" :: "v"(ra[S][i].x), "v"(ra[S][i].y), "v"(ra[S][i].z), "v"(ra[S][i].w)); }
+#define WW_ABL_CVT_B(S, i, bs_) { asm volatile("" :: "v"(rb[S][i].x), "v"(rb[S][i].y), "v"(rb[S][i].z), "v"(rb[S][i].w)); }
+#else
+#define WW_ABL_CVT_A(S, i, as_) WW_CVT_A(S, i, as_)
+#define WW_ABL_CVT_B(S, i, bs_) WW_CVT_B(S, i, bs_)
+#endif
+#define WW_FSTEP(t_, S1)                                                                                             \
+    {                                                                                                                \
+        const int cur_ = (t_) & 1;                                                                                   \
+        u16* as_ = As0 + (cur_ ^ 1) * WP * LDA;                                                                      \
+        u16* bs_ = Bs0 + (cur_ ^ 1) * WP * LDB;                                                                      \
+        _Pragma("unroll") for (int ks = 0; ks < NA; ++ks) {                                                           \
+            const u16* at_ = As0 + cur_ * WP * LDA + ks * 16 * LDA + a_lane;                                         \
+            const u16* bt_ = Bs0 + cur_ * WP * LDB + ks * 16 * LDB + b_lane;                                         \
             union { unsigned long long u[2]; bf16x8 v; } fa_[2], fb_[4];                                             \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                           \
                 fa_[i].u[0] = wl_tr16(at_ + i * 32);                                                                 \
@@ -675,32 +780,66 @@ __global__ void __launch_bounds__(512) wgrad_wide_f16_kernel(WideArgs g) {
                 fb_[j].u[0] = wl_tr16(bt_ + j * 32);                                                                 \
                 fb_[j].u[1] = wl_tr16(bt_ + 4 * LDB + j * 32);                                                       \
             }                                                                                                        \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                             \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = wg_mfma<PM>(fa_[i].v, fb_[j].v, acc[i][j]);     \
-            __syncthreads();                                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+            WW_ABL_CVT_A(S1, ks, as_)                                                                                 \
+            WW_ABL_LOAD_A(S1, ks)                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                           \
+                acc[c >> 1][2 * (c & 1)] = WW_ABL_MFMA(fa_[c >> 1].v, fb_[2 * (c & 1)].v, acc[c >> 1][2 * (c & 1)]); \
+                __builtin_amdgcn_sched_barrier(0);                                                                   \
+                WW_ABL_CVT_B(S1, 4 * ks + c, bs_)                                                                     \
+                WW_ABL_LOAD_B(S1, 4 * ks + c)                                                                        \
+                __builtin_amdgcn_sched_barrier(0);                                                                   \
+                acc[c >> 1][2 * (c & 1) + 1] = WW_ABL_MFMA(fa_[c >> 1].v, fb_[2 * (c & 1) + 1].v, acc[c >> 1][2 * (c & 1) + 1]); \
+                __builtin_amdgcn_sched_barrier(0);                                                                   \
+            }                                                                                                        \
         }                                                                                                            \
+        __syncthreads();                                                                                             \
     }
-    if (nt > 0) {
-        WW_LOAD(0, 0)
-        WW_STORE(0, 0)
-        if (nt > 1) WW_LOAD(1, 1)
-        if (nt > 2) WW_LOAD(2, 2)
-        if (nt > 3) WW_LOAD(0, 3)
-    }
-    __syncthreads();
+    if (!g.dbg_slow) {
+        if (NSET == 3) {
 #pragma unroll 1
-    for (int t = 0; t < nt; t += 3) {
-        WW_STEP(t, 1)
-        WW_STEP(t + 1, 2)
-        WW_STEP(t + 2, 0)
+            for (; t0 + 3 + NSET < nt; t0 += 3) {          // (the last step of a round loads tile t0 + 3 + NSET)
+                WW_FSTEP(t0, 1)
+                WW_FSTEP(t0 + 1, 2 % NSET)
+                WW_FSTEP(t0 + 2, 0)
+            }
+        } else {
+#pragma unroll 1
+            for (; t0 + 2 + NSET < nt; t0 += 2) {
+                WW_FSTEP(t0, 1)
+                WW_FSTEP(t0 + 1, 0)
+            }
+        }
+    }
+#undef WW_FSTEP
+#undef WW_CVT_A
+#undef WW_CVT_B
+    // the remaining steps (and all of a short slice), guarded
+    if (NSET == 3) {
+#pragma unroll 1
+        for (int t = t0; t < nt; t += 3) {
+            WW_STEP(t, 1)
+            WW_STEP(t + 1, 2 % NSET)
+            WW_STEP(t + 2, 0)
+        }
+    } else {
+#pragma unroll 1
+        for (int t = t0; t < nt; t += 2) {
+            WW_STEP(t, 1)
+            WW_STEP(t + 1, 0)
+        }
     }
 #undef WW_LOAD
 #undef WW_STORE
 #undef WW_STEP
+#undef WW_FLAGS_A
+#undef WW_FLAGS_B
+#undef WW_AMAX4
 
-    if (amax_u || amax_v) {                   // (uniform per workgroup)
+    if (amax_u || amax_v) {
         __shared__ unsigned wamx[8];
-        unsigned amx = vxb_amax_word(amxf, nanw);
+        unsigned amx = vxb_amax_word(amxf, nanw[0] + nanw[1]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o, 64));
         if (lane == 0) wamx[wid] = amx;
@@ -708,8 +847,8 @@ __global__ void __launch_bounds__(512) wgrad_wide_f16_kernel(WideArgs g) {
         if (tid == 0) {
             unsigned m = 0;
             for (int w = 0; w < 8; ++w) m = max(m, wamx[w]);
-            if (amax_u) g.amax_part[(long long)blockIdx.y * gridDim.x + blockIdx.x] = m;
-            else g.amax_part[blockIdx.y] = m;
+            if (amax_u) g.amax_part[(long long)bz * gridDim.x + bi] = m;
+            else if (bi == 0) g.amax_part[bz] = m;
         }
     }
     if (psum_u || psum_v) {
@@ -722,16 +861,16 @@ __global__ void __launch_bounds__(512) wgrad_wide_f16_kernel(WideArgs g) {
             float4 a = red[tid];
 #pragma unroll
             for (int j = 1; j < 16; ++j) { const float4 b = red[tid + 32 * j]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
-            *reinterpret_cast<float4*>(g.possum + (long long)blockIdx.y * g.possum_stride + i0 + tid * 4) = a;
+            *reinterpret_cast<float4*>(g.possum + (long long)bz * g.possum_stride + i0 + tid * 4) = a;
         }
-        if (psum_v && tid < 128) {
+        if (psum_v && bi == 0 && tid < 128) {
             float4 a = red[tid];
 #pragma unroll
             for (int j = 1; j < 4; ++j) { const float4 b = red[tid + 128 * j]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
-            *reinterpret_cast<float4*>(g.possum + (long long)blockIdx.y * g.possum_stride + tid * 4) = a;
+            *reinterpret_cast<float4*>(g.possum + (long long)bz * g.possum_stride + tid * 4) = a;
         }
     }
-    float* __restrict__ C = g.part + (long long)blockIdx.y * g.part_stride;
+    float* __restrict__ C = g.part + (long long)bz * g.part_stride;
     if (g.so_i == 1) {
         // transposed tile (U is the `dy` argument): the 4 consecutive i of an accumulator register quad are contiguous in memory
 #pragma unroll
@@ -768,6 +907,9 @@ static int g_wg_bm256 = 0;        // experiment knob (vxb_debug_set_wgrad_bm256)
                                   // with 128-row tiles -- a quarter fewer LDS fragment reads per MFMA, but half the workgroups and 176 VGPRs: OFF
 
 static long long g_wide_min_rows = 16384;      // positions from which the wide kernel's tiles x slices fill the chip (ops.WIDE_MIN_M)
+static int g_wg_wide_wp = 16;     // positions per tile of the wide kernel (vxb_debug_set_wgrad_lin(mode + 32): 32 -- measured no faster, and it spills)
+static int g_wg_wide_slow = 0;    // vxb_debug_set_wgrad_lin(mode + 64): no unconditional main loop in the wide kernel (A/B)
+static int g_wg_wide_order = 0;   // vxb_debug_set_wgrad_lin(mode + 16): the wide kernel's workgroups in the plain launch order (A/B of round 6's XCD-aware order)
 static int g_wg_lin = 2;          // plain-GEMM form of the fp16 products: 2 = wide kernel where it applies, else the pipelined 128^2 one;
                                   // 1 = pipelined 128^2 only; 0 = the generic kernel (vxb_debug_set_wgrad_lin: A/B switch)
 
@@ -804,16 +946,25 @@ static int wgrad_bf16_impl(int x3, const float* src0, const float* src1, int C0,
             w.U = c1 ? src0 : dy; w.V = c1 ? dy : src0;
             w.ldu = c1 ? C0 : ldy; w.ldv = c1 ? ldy : C0;
             w.Ru = c1 ? (int)K : N;
-            w.P = g.P; w.tiles_per_split = (int)((g.P / 16 + nsplit - 1) / nsplit);
+            const int wp = (g_wg_wide_wp == 32 && (g.P & 31) == 0) ? 32 : 16;
+            w.P = g.P; w.tiles_per_split = (int)((g.P / wp + nsplit - 1) / nsplit);
             w.part = part; w.part_stride = K * N;
             w.so_i = c1 ? N : 1; w.so_j = c1 ? 1 : N;
             w.scale = scale; w.grad_is_u = c1 ? grad_is_src0 : !grad_is_src0;
             w.amax_part = g.amax_part; w.possum = possum; w.possum_is_u = c1 ? 1 : 0; w.possum_stride = (int)K;
-            const size_t lds = (size_t)2 * 16 * (160 + 544) * sizeof(u16);
-            if (hipFuncSetAttribute((const void*)wgrad_wide_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return VXB_ELAUNCH;
+            w.dbg_order = g_wg_wide_order; w.dbg_slow = g_wg_wide_slow;
+            const size_t lds = (size_t)2 * wp * (160 + 544) * sizeof(u16);
             const int tiles_i = w.Ru / 128;
-            hipLaunchKernelGGL(wgrad_wide_f16_kernel, dim3(tiles_i, nsplit), dim3(512), lds, st, w);
+            const int afl = w.amax_part ? (w.grad_is_u ? 1 : 2) : 0, pfl = w.possum ? (w.possum_is_u ? 1 : 2) : 0;
+            void (*kern)(WideArgs) = nullptr;
+#define VXB_WIDE_PICK(A_, P_)                                                                                        \
+    if (afl == A_ && pfl == P_) kern = wp == 32 ? wgrad_wide_f16_kernel<32, A_, P_> : wgrad_wide_f16_kernel<16, A_, P_>;
+            VXB_WIDE_PICK(0, 0) VXB_WIDE_PICK(1, 0) VXB_WIDE_PICK(2, 0)
+            VXB_WIDE_PICK(0, 1) VXB_WIDE_PICK(1, 1) VXB_WIDE_PICK(2, 1)
+            VXB_WIDE_PICK(0, 2) VXB_WIDE_PICK(1, 2) VXB_WIDE_PICK(2, 2)
+#undef VXB_WIDE_PICK
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VXB_ELAUNCH;
+            hipLaunchKernelGGL(kern, dim3(tiles_i, nsplit), dim3(512), lds, st, w);
             VXB_CHECK_LAUNCH();
             if (g.amax_part && sum_dst)
                 return vxb_wgrad_finish_launch(part, nsplit, K * N, sum_dst, sum_accumulate, scale + 1, g.amax_part,
@@ -859,7 +1010,12 @@ extern "C" size_t vxb_conv3d_wgrad_f16_amax_words(int C0, int C1, int kext, int 
 }
 extern "C" void vxb_debug_set_wgrad_bm256(int on) { g_wg_bm256 = on ? 1 : 0; }
 extern "C" void vxb_debug_set_wide_min_rows(int rows) { g_wide_min_rows = rows < 16 ? 16 : rows; }
-extern "C" void vxb_debug_set_wgrad_lin(int mode) { g_wg_lin = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
+extern "C" void vxb_debug_set_wgrad_lin(int mode) {
+    g_wg_wide_slow = (mode >= 64); if (mode >= 64) mode -= 64;
+    g_wg_wide_wp = (mode >= 32) ? 32 : 16; if (mode >= 32) mode -= 32;
+    g_wg_wide_order = (mode >= 16); if (mode >= 16) mode -= 16;
+    g_wg_lin = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+}
 
 // ONE fp16 product per term (fp32 accumulate), same contract and `part` layout as the entries below.  The GRADIENT operand (src0 when
 // grad_is_src0 != 0 -- the plain-GEMM form of a linear layer's weight gradient, src0 = its dY -- else dy) is multiplied by scale[0]
