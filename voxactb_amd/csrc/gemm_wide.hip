@@ -190,11 +190,27 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) gemm_wide_kernel(GwA
     GW_LOADA(2, 2)
     GW_LOADA(0, 3)
     __syncthreads();
+    // Whole rounds of three k-tiles in a loop body WITHOUT branches, the 0 - 2 tiles left over after it: with `if (kt + 1 < nkt)` inside
+    // the body the compiler cannot count the loads in flight at the loop header and drains them all there (s_waitcnt vmcnt(0) once per
+    // round: the newest A tile, issued half a k-tile earlier, had to land before the round could start -- round 6).
+    // The first round is peeled: at the loop header the state after the prologue (4 loads younger than the set converted first) would
+    // otherwise be merged with the steady state's (20 younger loads) into s_waitcnt vmcnt(4).
+    int kt = 0;
+    if (nkt >= 3) {
+        GW_TILE(0, 0)
+        GW_TILE(1, 1)
+        GW_TILE(2, 2)
+        kt = 3;
 #pragma unroll 1
-    for (int kt = 0; kt < nkt; kt += 3) {
+        for (; kt + 3 <= nkt; kt += 3) {
+            GW_TILE(kt, 0)
+            GW_TILE(kt + 1, 1)
+            GW_TILE(kt + 2, 2)
+        }
+    }
+    if (kt < nkt) {
         GW_TILE(kt, 0)
         if (kt + 1 < nkt) GW_TILE(kt + 1, 1)
-        if (kt + 2 < nkt) GW_TILE(kt + 2, 2)
     }
 #undef GW_LOADA
 #undef GW_STOREA
@@ -427,14 +443,23 @@ __global__ void __launch_bounds__(512) conv_poly_wide_x3_kernel(PwArgs g) {
     PW_LOADA(2)
     PW_LOADA(0)
     __syncthreads();
+    // (whole rounds without branches around the tiles, then the remainder: see gemm_wide_kernel)
+    int kt = 0;
 #pragma unroll 1
-    for (int kt = 0; kt < nkt; kt += 6) {
+    for (; kt + 6 <= nkt; kt += 6) {
+        PW_TILE(kt, 0, 0)
+        PW_TILE(kt + 1, 1, 1)
+        PW_TILE(kt + 2, 2, 0)
+        PW_TILE(kt + 3, 0, 1)
+        PW_TILE(kt + 4, 1, 0)
+        PW_TILE(kt + 5, 2, 1)
+    }
+    if (kt < nkt) {
         PW_TILE(kt, 0, 0)
         if (kt + 1 < nkt) PW_TILE(kt + 1, 1, 1)
         if (kt + 2 < nkt) PW_TILE(kt + 2, 2, 0)
         if (kt + 3 < nkt) PW_TILE(kt + 3, 0, 1)
         if (kt + 4 < nkt) PW_TILE(kt + 4, 1, 0)
-        if (kt + 5 < nkt) PW_TILE(kt + 5, 2, 1)
     }
 #undef PW_LOADA
 #undef PW_STOREA
