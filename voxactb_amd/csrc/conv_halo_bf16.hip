@@ -406,7 +406,16 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
 #ifndef WG_BD
 #define WG_BD 4
 #endif
-    constexpr int BD = WG ? WG_BD : (WD && !TL && WN == 2) ? 4 : 2;      // B-fragment prefetch distance in taps
+#ifndef WG_BD_X2
+#define WG_BD_X2 6
+#endif
+    // B-fragment prefetch distance in taps.  WG: as deep as the registers allow without spilling -- a set is 8 VGPRs with two weight
+    // planes (bf16x3: 4 sets; 5 spill 23 registers), 4 with one (fp16x2 / fp16: 6 sets; 8 spill)
+    constexpr int BD = WG ? (PM == 1 ? WG_BD : WG_BD_X2) : (WD && !TL && WN == 2) ? 4 : 2;
+#ifndef WG_BD_PRE
+#define WG_BD_PRE 4
+#endif
+    constexpr int BD_PRE = WG_BD_PRE;     // ... of which this many sets are requested BEFORE the halo is converted (the staging registers are live then)
     bf16x8 bq0[NT][2], bq1[NT][2], bq2[NT][2];
     bf16x8 bqr[BD + 1][NT][2];
     const int nchunk = Ct / CPC;
@@ -562,7 +571,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
                     HD_LOADB(bq1, 1)
                 } else {
 #pragma unroll
-                    for (int t0 = 0; t0 < BD; ++t0) { HD_LOADB(bqr[t0], t0) }
+                    for (int t0 = 0; t0 < (BD < BD_PRE ? BD : BD_PRE); ++t0) { HD_LOADB(bqr[t0], t0) }
                 }
             }
             __syncthreads();                        // no per-tap barriers here: every wave must be done with the old halo
@@ -617,6 +626,10 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
         if (!WD) { HB_STORE_W(rw0, 0) }
         __syncthreads();
         if (!wave_on) continue;                     // (WD only: the two barriers above are the chunk's only ones)
+        if constexpr (WG && BD > BD_PRE) {
+#pragma unroll
+            for (int t0 = BD_PRE; t0 < BD; ++t0) { HD_LOADB(bqr[t0], t0) }
+        }
         if (TL) {
             HB_READ_A_OFF(afa, __builtin_amdgcn_readlane(taplist, 0))
             int n = 0;
