@@ -193,13 +193,14 @@ def test_batched_weight_split_emits_fragment_order_for_the_wide_gemm():
         ops.new_step()
 
 
-@pytest.mark.parametrize('waves,grid_bits', [(8, 0), (8, 32), (4, 0)])
+@pytest.mark.parametrize('waves,grid_bits', [(8, 0), (8, 32), (4, 0), (8, 64)])
 @pytest.mark.parametrize('M,N,K', [(2048, 512, 256), (4096, 1024, 512), (2300, 512, 2048), (1024, 4096, 512)])
 def test_gemm_wide_is_bit_identical_to_the_register_staged_kernel(M, N, K, waves, grid_bits):
     """gemm_wide.hip (128 x 512 workgroup tiles, A three k-tiles ahead, weight fragments from global memory) in bf16x3: ragged M, every
     epilogue option; same products in the same order as the kernels it replaces -> equal bits; and against float64.  waves = 4: the
     128 x 256 workgroups of four waves (two per CU); grid_bits = 32: round 3's grid order (row blocks fastest) instead of the column
-    groups of a row block side by side on one XCD."""
+    groups of a row block side by side on one XCD; 64: the epilogue of rounds 3 - 5 (stores straight out of the accumulators) instead of
+    round 6's row-contiguous one through LDS."""
     from voxactb_amd import _lib
     x, W, b, r = rnd(M, K), rnd(N, K, seed=1), rnd(N, seed=2), rnd(M, N, seed=3)
     wb = ops.split_bf16(W.to(DEV), True)

@@ -221,6 +221,87 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) gemm_wide_kernel(GwA
     float* __restrict__ C = g.C;
     const float* __restrict__ R = g.residual;
     if ((dbg & 8) && acc[0][0][0] != 12345.f) return;
+    // ---- row-contiguous epilogue (NW = 8; round 6).  Straight out of the accumulators a store instruction writes two 128-byte pieces (32
+    // columns of two rows) and a 128 x 512 tile takes 1024 of them per workgroup: measured, the epilogue is 0.27 of the 0.59 ms of a
+    // 4096 x 512 launch (tools/bench_gemm_ablate.py) -- 7.7 GB/s per CU.  Here the tile goes through LDS (the operand stages are free),
+    // sixteen rows at a time, and leaves as 1 KB per wave instruction: whole 2 KB rows (1 KB row pieces of h's two halves and of gg with
+    // GEGLU).  Per element the same operations in the same order as below: identical bits.
+    if (NW == 8 && g.geglu != 2 && !(g.dbg & 64) && !(g.ldc & 3) && !((uintptr_t)C & 15) && (!R || !((uintptr_t)R & 15)) && !((uintptr_t)g.bias & 15) &&
+        (g.geglu != 1 || (!(g.F & 3) && !((uintptr_t)g.C2 & 15)))) {
+        constexpr int CLD = 512 + 8;
+        float* Cs = reinterpret_cast<float*>(&As[0][0][0]);                 // [16][CLD] fp32 = 33 KB of the 40 KB
+        const int lrow = 4 * (lane >> 5), lcol = lane & 31;
+        if (g.geglu == 1) {
+            const int F = g.F;
+            const int er = tid >> 6, ec = (tid & 63) * 4;                   // 8 rows x 64 column quads per pass of the read-out
+            const int c0 = cg * 256 + ec;                                   // value column; its gate is column F + c0
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bg = bv;
+            if (g.bias) { bv = *reinterpret_cast<const float4*>(g.bias + c0); bg = *reinterpret_cast<const float4*>(g.bias + F + c0); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int rr = 0; rr < 8; ++rr) {
+                            const int r = 8 * hf + rr;
+                            Cs[((r & 3) + 8 * ((r >> 2) & 1) + lrow) * CLD + j * 256 + wn * 32 + lcol] = acc[i][j][r];
+                        }
+                    __syncthreads();
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        const int row = er + 8 * st;
+                        const int m = m0 + i * 32 + 16 * hf + row;
+                        if (m >= g.M) continue;
+                        const float4 a = *reinterpret_cast<const float4*>(&Cs[row * CLD + ec]);
+                        const float4 b = *reinterpret_cast<const float4*>(&Cs[row * CLD + 256 + ec]);
+                        const float4 hv = make_float4(a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w);
+                        const float4 hg = make_float4(b.x + bg.x, b.y + bg.y, b.z + bg.z, b.w + bg.w);
+                        *reinterpret_cast<float4*>(C + (long long)m * g.ldc + c0) = hv;
+                        *reinterpret_cast<float4*>(C + (long long)m * g.ldc + F + c0) = hg;
+                        *reinterpret_cast<float4*>(g.C2 + (long long)m * F + c0) =
+                            make_float4(hv.x * gelu_erf(hg.x), hv.y * gelu_erf(hg.y), hv.z * gelu_erf(hg.z), hv.w * gelu_erf(hg.w));
+                    }
+                }
+            return;
+        }
+        const int er = tid >> 7, ec = (tid & 127) * 4;                      // 4 rows x 128 column quads per pass of the read-out
+        const int n4 = cg * 512 + ec;
+        const float4 bs = g.bias ? *reinterpret_cast<const float4*>(g.bias + n4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr) {
+                        const int r = 8 * hf + rr;
+                        Cs[((r & 3) + 8 * ((r >> 2) & 1) + lrow) * CLD + wn * 64 + j * 32 + lcol] = X2 ? acc[i][j][r] * out_sc : acc[i][j][r];
+                    }
+                __syncthreads();
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const int row = er + 4 * st;
+                    const int m = m0 + i * 32 + 16 * hf + row;
+                    if (m >= g.M) continue;
+                    float4 v = *reinterpret_cast<const float4*>(&Cs[row * CLD + ec]);
+                    v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
+                    if (g.act == 1) {
+                        v.x = v.x > 0.f ? v.x : v.x * g.slope; v.y = v.y > 0.f ? v.y : v.y * g.slope;
+                        v.z = v.z > 0.f ? v.z : v.z * g.slope; v.w = v.w > 0.f ? v.w : v.w * g.slope;
+                    }
+                    const long long off = (long long)m * g.ldc + n4;
+                    if (R) { const float4 q = *reinterpret_cast<const float4*>(R + off); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+                    if (g.accumulate) { const float4 q = *reinterpret_cast<const float4*>(C + off); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+                    *reinterpret_cast<float4*>(C + off) = v;
+                }
+            }
+        return;
+    }
     if (g.geglu == 1) {
         const int F = g.F, c = (cg * NW + wn) * 32 + (lane & 31);          // value column; its gate is column F + c
         const float bv = g.bias ? g.bias[c] : 0.f, bg = g.bias ? g.bias[F + c] : 0.f;
@@ -301,6 +382,7 @@ struct PwArgs {
     int N, s;
     int act;
     float slope;
+    int dbg;                 // vxb_debug_set_gemm_wide_experiment bit 64: the epilogue of rounds 4 - 5 (stores straight out of the accumulators)
 };
 
 __global__ void __launch_bounds__(512) conv_poly_wide_x3_kernel(PwArgs g) {
@@ -472,6 +554,49 @@ __global__ void __launch_bounds__(512) conv_poly_wide_x3_kernel(PwArgs g) {
     const int sfac = g.s, ph = g.perm ? g.perm[blk] : blk;
     const int rw = ph % sfac, rh = (ph / sfac) % sfac, rd = ph / (sfac * sfac);
     const long long Vf = (long long)g.S * sfac;
+    if (!(g.dbg & 64) && !((uintptr_t)g.out & 15) && !((uintptr_t)g.bias & 15)) {
+        // voxel-contiguous stores (round 6; see gemm_wide_kernel's epilogue): a wave's 128 x 64 tile goes through its OWN 4 KB of the
+        // (now free) operand stages, sixteen low-res voxels at a time, and leaves as whole 256-byte voxels, four per store instruction,
+        // instead of two 128-byte halves of two voxels.  Wave-local: no workgroup barrier (waves that were switched off have left).
+        float* Ws = reinterpret_cast<float*>(&As[0][0][0]) + wn * (16 * 64);
+        const int er = lane >> 4, ec = (lane & 15) * 4;
+        const float4 bs = g.bias ? *reinterpret_cast<const float4*>(g.bias + blk * 64 + ec) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr) {
+                        const int r = 8 * hf + rr;
+                        Ws[((r & 3) + 8 * ((r >> 2) & 1) + 4 * (lane >> 5)) * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const int row = er + 4 * st;
+                    const int m = m0 + i * 32 + 16 * hf + row;
+                    if (m >= M) continue;
+                    int q = m;
+                    const int qw = q % g.S; q /= g.S;
+                    const int qh = q % g.S; q /= g.S;
+                    const int qd = q % g.S; q /= g.S;
+                    float4 v = *reinterpret_cast<const float4*>(&Ws[row * 64 + ec]);
+                    v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
+                    if (g.act == 1) {
+                        v.x = v.x > 0.f ? v.x : v.x * g.slope; v.y = v.y > 0.f ? v.y : v.y * g.slope;
+                        v.z = v.z > 0.f ? v.z : v.z * g.slope; v.w = v.w > 0.f ? v.w : v.w * g.slope;
+                    }
+                    *reinterpret_cast<float4*>(g.out + ((((long long)q * Vf + qd * sfac + rd) * Vf + qh * sfac + rh) * Vf + qw * sfac + rw) * 64 + ec) = v;
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -598,7 +723,7 @@ extern "C" int vxb_conv3_poly_wide_bf16x3_f32(const float* z, int Cin, int B, in
     if (M >= INT32_MAX || M * Cin >= (1ll << 40)) return VXB_ESIZE;
     PwArgs g;
     g.z = z; g.Bfrag = (const u16*)wt_frag; g.bias = bias; g.out = out; g.perm = perm; g.blockmask = blockmask;
-    g.B = B; g.S = S; g.Cin = Cin; g.kext = kext; g.off = off; g.replicate = replicate; g.N = N; g.s = d2s_s; g.act = act; g.slope = slope;
+    g.B = B; g.S = S; g.Cin = Cin; g.kext = kext; g.off = off; g.replicate = replicate; g.N = N; g.s = d2s_s; g.act = act; g.slope = slope; g.dbg = g_wide_dbg;
     hipLaunchKernelGGL(conv_poly_wide_x3_kernel, dim3((unsigned)vxb_cdiv(M, WBM), vxb_cdiv(N, 512)), dim3(512), 0, (hipStream_t)stream, g);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
