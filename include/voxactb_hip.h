@@ -175,9 +175,9 @@ int vxb_conv3d_wgrad_f16_f32(const float* src0, const float* src1, int C0, int C
 size_t vxb_conv3d_wgrad_f16_amax_words(int C0, int C1, int kext, int N, int nsplit, int grad_is_src0);
 void vxb_debug_set_wgrad_bm256(int on);       /* experiment knob: 256-row tiles of the fp16 weight-gradient kernel (measured slower: default off) */
 void vxb_debug_set_gemm_wide_waves(int waves);  /* wide linear-layer GEMMs: 8 = one 128 x 512 workgroup of 8 waves per CU, 4 = two 128 x 256 workgroups of 4 waves per CU */
-void vxb_debug_set_gemm_wide_experiment(int bits);  /* timing experiments of gemm_wide.hip (WRONG results): 1 no weight-fragment loads in the loop, 2 no A loads, 4 no A staging / barrier, 8 no epilogue; 32 = row blocks fastest in the grid (right results) */
+void vxb_debug_set_gemm_wide_experiment(int bits);  /* timing experiments of gemm_wide.hip (WRONG results): 1 no weight-fragment loads in the loop, 2 no A loads, 4 no A staging / barrier, 8 no epilogue; 32 = row blocks fastest in the grid (right results); 64 = the epilogue of rounds 3 - 5 (stores straight out of the accumulators; correct results) in gemm_wide_kernel and conv_poly_wide_x3_kernel */
 void vxb_debug_set_wide_min_rows(int rows);  /* rows from which the wide weight-gradient kernel is dispatched (default 16384; tests lower it) */
-void vxb_debug_set_wgrad_lin(int mode);       /* A/B switch of the linear layers' fp16 weight gradients: 2 (default) wide kernel where one operand has 512 channels, 1 pipelined 128x128 kernel only, 0 generic kernel */
+void vxb_debug_set_wgrad_lin(int mode);       /* A/B switch of the linear layers' fp16 weight gradients: 2 (default) wide kernel where one operand has 512 channels, 1 pipelined 128x128 kernel only, 0 generic kernel; + 16: the wide kernel's workgroups in the plain launch order; + 32: 32-position tiles; + 64: every step through the guarded form of rounds 3 - 5 (all: correct results, A/B of round 6's changes) */
 /* experiment knobs of the LDS-halo conv kernels (conv_halo_bf16.hip, wgrad_halo.hip; tools/bench_halo.py, tools/bench_wgrad_halo*.py).
    Everything the library exports is declared in this header: libvoxactb_hip.so is linked with csrc/exports.map (vxb_* only). */
 void vxb_debug_set_halo_waves(int nw);              /* 4 (default) or 8 waves per workgroup */
