@@ -130,3 +130,37 @@ def test_winograd_data_gradient_against_the_direct_kernel(S, B):
         ed = float((d_g.cpu().double() - ref).abs().max()) / float(ref.abs().max())
         print('      vs float64: winograd %.2e  direct %.2e' % (ew, ed))
         assert ew < 1e-3 and ew < 1.5 * ed + 1e-5           # (the fp16 rounding of the WEIGHTS, 2^-12 per product, bounds both)
+
+
+@pytest.mark.parametrize('S,B', [(20, 2), (22, 1), (36, 1)])      # half tiles along h / w; a two-deep last depth tile (idle wave rows take the barriers)
+def test_weight_fragments_through_lds_are_bit_identical(S, B):
+    """Round 6: the Winograd variants (bf16x3 forward, fp16x2 data gradient) fetch a tap's weight fragments once per workgroup into an
+    LDS ring and read the halo out of a compact, slot-swizzled image (conv3_halo_body, BL); vxb_debug_set_halo_experiment(0x1000) keeps
+    the per-wave fragment loads and the padded image of rounds 5 - 6.  Same products in the same order: equal bits."""
+    from voxactb_amd import _lib
+    C = 64
+    d0, u0 = cl(rnd(B, C, S, S, S, seed=1)).to(DEV), cl(rnd(B, C, S, S, S, seed=2)).to(DEV)
+    W = rnd(C, 2 * C, 3, 3, 3, seed=3, scale=0.03).to(DEV)
+    bias = rnd(C, seed=4).to(DEV)
+    dy = cl(rnd(B, C, S, S, S, seed=5)).to(DEV)
+    y1 = cl(rnd(B, 64, S, S, S, seed=6)).to(DEV)
+    Wd = rnd(C, 2 * C, 3, 3, 3, seed=7, scale=0.1).to(DEV)
+    out = {}
+    try:
+        for bits in (0, 0x1000):
+            _lib.lib().vxb_debug_set_halo_experiment(bits)
+            fwd, st = _run(d0, u0, W, bias, B, S, True)
+            ops.PRECISION, ops.WGRAD_PRECISION = 'bf16x3', 'fp16'
+            try:
+                assert ops.DGRAD_PRECISION == 'fp16x2' and ops.DGRAD_WINOGRAD
+                g0 = torch.zeros(B, S, S, S, 64, device=DEV)
+                g1 = torch.full((B, S, S, S, 64), 3.0, device=DEV)
+                ops.begin_backward()
+                ops.conv3_dgrad_fold(dy, ops.conv_weight_dgrad(Wd), B, S, 2 * C, [(g0, False, None), (g1, False, y1)], leaf_blocks=(0,))
+            finally:
+                ops.PRECISION, ops.WGRAD_PRECISION = 'fp32', ''
+            out[bits] = (fwd, st[0], st[1], st[3], g1)
+    finally:
+        _lib.lib().vxb_debug_set_halo_experiment(0)
+    for a, b in zip(out[0], out[0x1000]):
+        assert torch.equal(a, b)

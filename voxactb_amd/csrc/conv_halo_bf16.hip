@@ -153,10 +153,27 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     // instead of the 6 raw ones), the weight transform on the host (ops.halo_wfrag_wg: 36 "taps" (xi, kh, kw)), the output transform on
     // the accumulators (a wave's M tiles are (depth, w half), so y0 / y1 are its own registers).  36 x 2 instead of 27 x 4 MFMA groups
     // per wave and chunk: two thirds of the matrix work, which is what bounds the direct kernel (73 % of its time).
+    static_assert(WG != 2 || PM == 1 || PM == 3, "BL: the two-halves-per-voxel variants");
     static_assert(!WG || (WD && !TL && WN == 2 && NW == 4 && NTG == 2 && (HALF == 0 || HALF == 1) && PM >= 1),
                   "WG: the final conv's forward (bf16x3) and its data gradients (fp16x2; fp16 with 16-channel chunks)");
     constexpr int NTAP = WG ? 36 : 27;
-    constexpr int PLANE = HHp * HWp * SP;           // u16 per depth plane of the LDS image
+    // ---- BL (WG = 2; round 6): the weight fragments of a tap reach the four waves through LDS instead of every wave fetching its own.
+    // Measured on the bf16x3 forward: the fragment loads cost 21 % of the launch and do not hide; two 1 KB fragments per
+    // wave and tap, fetched twice per workgroup (the two waves of a column tile), ~16 B / clk / CU through the vector L1.  Here a ROUND
+    // = the 4 KB of fragments of one tap (two weight planes) or two taps (one plane) is fetched ONCE per workgroup -- wave w brings
+    // fragment w with one `global_load_lds_dwordx4`, no VGPRs -- into a ring of BL_NR rounds; one s_barrier per round publishes it.
+    // The room comes from the halo image: 64-byte voxels and 10-voxel rows (51 KB) instead of 80-byte voxels and 12-voxel rows (77 KB),
+    // the bank conflicts of the fragment reads avoided by XOR-ing the 16-byte slot of a voxel (k half | hi / lo) with its row & 3
+    // instead of by padding: the 16 lanes of a ds_read_b128 service group are 4 rows x 4 voxels; the voxels of a row fall on the four
+    // 64-byte quarters of the bank space (10 voxels per row: (2 h + w) mod 4), the four rows {0, 3, 5, 6} / {1, 2, 4, 7} on different slots.
+    constexpr bool BL = WG == 2;
+    constexpr int SPW = BL ? 32 : SP;               // u16 per voxel of the WG image
+    constexpr int HWW = BL ? HW_USED : HWp;         // voxels per row
+    constexpr int PLANE = HHp * HWW * SPW;          // u16 per depth plane of the LDS image
+    constexpr int BL_NR = 6;                        // rounds in the ring (24 KB)
+    constexpr int BL_TPR = (PM == 1) ? 1 : 2;       // taps per round: a round is four 1 KB fragments
+    constexpr int BL_ROUNDS = 36 / BL_TPR;
+    constexpr int BL_RING = 8 * PLANE;              // u16 offset of the ring
     constexpr int X3 = PM == 1;                     // three products: input hi | lo, weight planes hi / lo
     constexpr int X2 = PM == 3;                     // two products: input hi | lo, one weight plane
     constexpr int HL = X3 || X2;                    // a chunk is 16 channels as hi | lo halves
@@ -262,6 +279,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     constexpr int WLIM = HALF == 1 ? 1 : 2;
     f32x16 wacc[WG ? 2 : 1][WG ? 4 : 1];
     int wabase[2] = {0, 0};
+    int wab[2][3] = {{0, 0, 0}, {0, 0, 0}};      // BL: the hi-half fragment address of tile wh at kernel row kh (the slot depends on the row)
     if constexpr (WG) {
 #pragma unroll
         for (int wh = 0; wh < 2; ++wh) {
@@ -272,6 +290,10 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
             int dd, hh, ww;
             rowmap(wh, lq, dd, hh, ww);
             wabase[wh] = ((4 * wm * HHp + hh) * HWp + ww) * SP + 8 * hi;
+            if (BL) {
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) wab[wh][kh] = 4 * wm * PLANE + ((hh + kh) * HWW + ww) * SPW + ((hi ^ ((hh + kh) & 3)) << 3);
+            }
         }
     }
 
@@ -326,7 +348,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
                 bool ok = true;
                 if (g.replicate) { ih = min(max(ih, 0), g.S_in - 1); iw = min(max(iw, 0), g.S_in - 1); }
                 else ok = ih >= 0 && ih < g.S_in && iw >= 0 && iw < g.S_in;
-                wg_soff[i] = (ph * HWp + pw) * SP + c4;
+                wg_soff[i] = BL ? (ph * HWW + pw) * SPW + (((c4 >> 3) ^ (ph & 3)) << 3) + (c4 & 4) : (ph * HWp + pw) * SP + c4;
                 wg_hw[i] = ok ? ih * Vin + iw : -2;
                 if (HALF == 1 && (edge_h ? ph : pw) >= 6) wg_hw[i] = -1;
             }
@@ -534,6 +556,26 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
                 hv[i] = *reinterpret_cast<const float4*>(src + (vbase + st_goff[i]) * Cs + c0 + (((tid + NTH * i) % F4P) * 4));
         }
     };
+    // BL: this wave's quarter (fragment `wid`) of round r_ of chunk ch_: 1 KB, lane l's 16 bytes to LDS[ring slot + wid KB + 16 l].  Issued as
+    // inline asm: the compiler's counter model does not see it (it would put s_waitcnt vmcnt(0) in front of every LDS read that may alias
+    // the destination); the counted waits are placed by hand (bl_wait).  A visible load's compiler-placed wait only gets stricter by it.
+    const int widu = __builtin_amdgcn_readfirstlane(wid);
+    auto bl_issue = [&](int ch_, int r_) __attribute__((always_inline)) {
+        const unsigned long long sp_ = (unsigned long long)(g.wfrag + (((long long)(n0 / N) * wf_rows + (long long)ch_ * NTAP) * (NTG * NF) + (long long)r_ * 4 + widu) * 512);
+        const unsigned slo_ = __builtin_amdgcn_readfirstlane((unsigned)sp_), shi_ = __builtin_amdgcn_readfirstlane((unsigned)(sp_ >> 32));
+        const u16* src_ = reinterpret_cast<const u16*>(((unsigned long long)shi_ << 32) | slo_);
+        const unsigned ldsb_ = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)(halo + BL_RING + (r_ % BL_NR) * 2048 + widu * 512));
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"((unsigned)(lane * 16)), "s"(src_), "s"(ldsb_) : "memory");
+    };
+    auto bl_wait = [&](int n_) __attribute__((always_inline)) {
+        switch (n_) {          // (n_ is a constant after unrolling)
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        }
+    };
     if (PF) halo_issue(0);
     if (g.dbg & 0xf00) {
         // start-up stagger (experiment bits 8-11, results stay correct): the two workgroups that share a CU start together, stage together
@@ -571,10 +613,15 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
                     HD_LOADB(bq1, 1)
                 } else {
 #pragma unroll
-                    for (int t0 = 0; t0 < (BD < BD_PRE ? BD : BD_PRE); ++t0) { HD_LOADB(bqr[t0], t0) }
+                    for (int t0 = 0; t0 < (BL ? 0 : (BD < BD_PRE ? BD : BD_PRE)); ++t0) { HD_LOADB(bqr[t0], t0) }
                 }
             }
             __syncthreads();                        // no per-tap barriers here: every wave must be done with the old halo
+            if constexpr (BL) {
+                // every wave has left the previous chunk's taps: the whole ring is free -- rounds 0 .. BL_NR - 1 of this chunk
+#pragma unroll
+                for (int r0 = 0; r0 < BL_NR; ++r0) bl_issue(ch, r0);
+            }
         }
         if constexpr (WG) {
 #pragma unroll
@@ -602,7 +649,8 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
                         if (HL) {
                             q.x = hb_pack2<PM>(t[xi].x - hb_unpack_lo<PM>(pk.x), t[xi].y - hb_unpack_hi<PM>(pk.x));
                             q.y = hb_pack2<PM>(t[xi].z - hb_unpack_lo<PM>(pk.y), t[xi].w - hb_unpack_hi<PM>(pk.y));
-                            *reinterpret_cast<uint2*>(dstp + 16) = q;
+                            if (BL) *reinterpret_cast<uint2*>(&halo[(wg_soff[i] ^ 16) + (4 * pr + xi) * PLANE]) = q;      // (slot ^ 2: the lo half)
+                            else *reinterpret_cast<uint2*>(dstp + 16) = q;
                         }
                     }
                 }
@@ -624,9 +672,12 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
             }
         }
         if (!WD) { HB_STORE_W(rw0, 0) }
-        __syncthreads();
-        if (!wave_on) continue;                     // (WD only: the two barriers above are the chunk's only ones)
-        if constexpr (WG && BD > BD_PRE) {
+        if constexpr (BL) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BL_NR - 1) : "memory");      // this wave's fragment of round 0 has landed
+            vxb_raw_barrier_lds();                  // (LDS stores of the staging done, then the barrier: no fence -- the rounds in flight stay in flight)
+        } else __syncthreads();
+        if (!BL && !wave_on) continue;              // (WD only: the two barriers above are the chunk's only ones; BL: every wave takes the rounds' barriers)
+        if constexpr (WG && !BL && BD > BD_PRE) {
 #pragma unroll
             for (int t0 = BD_PRE; t0 < BD; ++t0) { HD_LOADB(bqr[t0], t0) }
         }
@@ -670,6 +721,56 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
         }                                                                                                            \
         _Pragma("unroll") for (int wh = 0; wh < WLIM; ++wh) wacc[wh][XI] = hb_mfma<PM>(AC[wh][0], BC[0][0], wacc[wh][XI]); \
     }
+            if constexpr (BL) {
+                // A of tap tp: tile wh at (kh, kw) of transformed plane 4 wm + xi; B: fragments (wn, plane) of the tap's round out of the ring
+#define BL_READ_A(AF, tap_)                                                                                          \
+    {                                                                                                                \
+        const int tp_ = (tap_);                                                                                      \
+        const int c_ = (tp_ / 9) * PLANE + (tp_ % 3) * SPW;                                                          \
+        _Pragma("unroll") for (int wh = 0; wh < WLIM; ++wh) {                                                        \
+            AF[wh][0] = *reinterpret_cast<const bf16x8*>(&halo[wab[wh][(tp_ / 3) % 3] + c_]);                        \
+            AF[wh][1] = *reinterpret_cast<const bf16x8*>(&halo[(wab[wh][(tp_ / 3) % 3] ^ 16) + c_]);                 \
+        }                                                                                                            \
+    }
+#define BL_READ_B(BF, tap_)                                                                                          \
+    {                                                                                                                \
+        const int tp_ = (tap_);                                                                                      \
+        const u16* rb_ = halo + BL_RING + ((tp_ / BL_TPR) % BL_NR) * 2048 + lane * 8;                                \
+        if (PM == 1) {                                                                                               \
+            BF[0][0] = *reinterpret_cast<const bf16x8*>(rb_ + (wn * 2 + 0) * 512);                                   \
+            BF[0][1] = *reinterpret_cast<const bf16x8*>(rb_ + (wn * 2 + 1) * 512);                                   \
+        } else {                                                                                                     \
+            BF[0][0] = *reinterpret_cast<const bf16x8*>(rb_ + ((tp_ % BL_TPR) * 2 + wn) * 512);                      \
+        }                                                                                                            \
+    }
+                // Round r >= 1 is opened one tap BEFORE its first tap (its fragments are read a tap ahead, like A): at the top of tap
+                // r * BL_TPR - 1 every wave has issued -- and (lgkmcnt(0)) finished -- its reads of round r - 1, whose ring slot then
+                // takes round r - 1 + BL_NR.  A wave waits for ITS fragment of round r (the rounds r + 1 .. r + BL_NR - 2 stay in flight).
+                bf16x8 bfa[1][2], bfb[1][2];
+                BL_READ_A(afa, 0)
+                BL_READ_B(bfa, 0)
+#pragma unroll
+                for (int tp = 0; tp < 36; ++tp) {
+                    if ((tp + 1) % BL_TPR == 0 && tp + 1 < 36) {
+                        constexpr int dummy_ = 0; (void)dummy_;
+                        const int r = (tp + 1) / BL_TPR;
+                        const int young = (BL_ROUNDS - 1 - r) < (BL_NR - 2) ? (BL_ROUNDS - 1 - r) : (BL_NR - 2);
+                        bl_wait(young);
+                        vxb_raw_barrier_lds();
+                        if (r - 1 + BL_NR < BL_ROUNDS) bl_issue(ch, r - 1 + BL_NR);
+                    }
+                    if (tp & 1) {
+                        if (tp + 1 < 36) { BL_READ_A(afa, tp + 1) BL_READ_B(bfa, tp + 1) }
+                        __builtin_amdgcn_sched_barrier(0);
+                        WG_MFMA(afb, bfb, tp / 9)
+                    } else {
+                        if (tp + 1 < 36) { BL_READ_A(afb, tp + 1) BL_READ_B(bfb, tp + 1) }
+                        __builtin_amdgcn_sched_barrier(0);
+                        WG_MFMA(afa, bfa, tp / 9)
+                    }
+                }
+                continue;
+            }
             WG_READ_A(afa, 0)
 #pragma unroll
             for (int tp = 0; tp < 36; ++tp) {
@@ -1003,8 +1104,8 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
         t /= g.N / (NTG * 32);
         int td, th, tw;
         halo_tile_coords(g, t % (g.ntd * g.nth * g.ntw), td, th, tw);
-        if (min(g.S_out - tw * TW, g.S_out - th * TH) <= 4 && !g_dbg_all_waves(g)) conv3_halo_body<NTG, PM, NW, WD, TL, WN, 1, 1>(g);
-        else conv3_halo_body<NTG, PM, NW, WD, TL, WN, 0, 1>(g);
+        if (min(g.S_out - tw * TW, g.S_out - th * TH) <= 4 && !g_dbg_all_waves(g)) conv3_halo_body<NTG, PM, NW, WD, TL, WN, 1, WG>(g);
+        else conv3_halo_body<NTG, PM, NW, WD, TL, WN, 0, WG>(g);
         return;
     } else
     if constexpr (EDGE) {
@@ -1042,7 +1143,8 @@ int g_halo_wn = 0;         // experiment knob (vxb_debug_set_halo_wn): waves alo
 template <int NT, int PM, int NW, int WD, int TL = 0, int WN = 1, int WG = 0>
 int hb_launch(const HaloArgs& g, long long nblk, hipStream_t st) {
     // (the fold epilogue re-uses the buffer as an fp32 [256][64] tile: keep the full size in every variant)
-    const size_t lds = WG ? (size_t)8 * HHp * HWp * SP * sizeof(u16) : (size_t)(HALO_SLOTS * SP + 2 * NT * 32 * LDW) * sizeof(u16);
+    const size_t lds = WG == 2 ? (size_t)(8 * HHp * HW_USED * 32 + 6 * 2048) * sizeof(u16)      // compact image + the fragment ring (conv3_halo_body: BL)
+                     : WG ? (size_t)8 * HHp * HWp * SP * sizeof(u16) : (size_t)(HALO_SLOTS * SP + 2 * NT * 32 * LDW) * sizeof(u16);
     if (TL && (size_t)(g.ncls * 32 + g.nphase * 2) * sizeof(int) > (size_t)2 * NT * 32 * LDW * sizeof(u16)) return VXB_ESIZE;
     if (hipFuncSetAttribute((const void*)conv3_halo_kernel<NT, PM, NW, WD, TL, WN, WG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VXB_ELAUNCH;
@@ -1094,6 +1196,8 @@ int hb_impl(int x3 /* product mode: 0 bf16, 1 bf16x3, 2 fp16 (WD kernels only, `
     hipStream_t st = (hipStream_t)stream;
     // 64 output channels per workgroup (162-225 VGPRs -> two workgroups per CU); N = 128 runs two column blocks that each
     // stage the halo -- cheaper than the register spills of a 128-wide accumulator tile.
+    if (wino && x3 != 2 && !(g.dbg & 0x1000))          // (experiment bit 0x1000: the fragments from global memory per wave, rounds 5 - 6)
+        return x3 == 3 ? hb_launch<2, 3, 4, 1, 0, 2, 2>(g, nblk, st) : hb_launch<2, 1, 4, 1, 0, 2, 2>(g, nblk, st);
     if (wino) return x3 == 3 ? hb_launch<2, 3, 4, 1, 0, 2, 1>(g, nblk, st) : x3 == 2 ? hb_launch<2, 2, 4, 1, 0, 2, 1>(g, nblk, st)
                                                                                : hb_launch<2, 1, 4, 1, 0, 2, 1>(g, nblk, st);
     if (x3 == 2) return hb_launch<2, 2, 4, 1>(g, nblk, st);
