@@ -437,11 +437,11 @@ TRAFFIC_KERNELS = {
     # byte count in exactly that pattern (tools/ubench/fetch_calib.hip, profiles/r06_fetch_size_calibration.log: FETCH_SIZE x 1024 / bytes
     # requested = 1.0000 for one 64-byte segment of a 256-byte row per pass, 0.5000 for wide reads); round 5 had inferred the same factor from
     # the geometric halo amplification (profiles/r05_final_conv_tile_order.log)
-    'conv3d_bf16[k3 s1 128->64 S100': (['conv3_halo_kernel<2, 1, 4, 1, 0, 2, 1>'],
+    'conv3d_bf16[k3 s1 128->64 S100': (['conv3_halo_kernel<2, 1, 4, 1, 0, 2, 2, 0>'],
                                        'final conv forward (+ the SpatialSoftmax3D partials of its epilogue): 12.3 GB compulsory (2 x 4.1 GB read, 4.1 GB written)', 1.0),
     'conv3d_wgrad[k3 s1 128->64 S100]': (['wgrad_halo_kernel<2, 4, 4, 2>'],
                                          'weight gradient of the final conv (single fp16 products): 12.3 GB compulsory (x 4.1 GB + the second source 4.1 GB + dY 4.1 GB)', 2.0),
-    'conv3d_bf16[k3 s1 64->128 S102': (['conv3_halo_kernel<2, 3, 4, 1, 0, 2, 1>', 'conv3_halo_kernel<2, 2, 4, 1, 0, 1, 0>'],
+    'conv3d_bf16[k3 s1 64->128 S102': (['conv3_halo_kernel<2, 3, 4, 1, 0, 2, 2, 0>', 'conv3_halo_kernel<2, 2, 4, 1, 0, 1, 0, 1>'],
                                        'the two launches of the data gradient + padding adjoint of the final conv: d(u0) fp16x2, d(d0) fp16', 1.0),
 }
 

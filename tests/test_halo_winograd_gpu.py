@@ -164,3 +164,35 @@ def test_weight_fragments_through_lds_are_bit_identical(S, B):
         _lib.lib().vxb_debug_set_halo_experiment(0)
     for a, b in zip(out[0], out[0x1000]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('S,B', [(20, 1), (22, 1)])
+def test_direct_kernels_with_the_fragment_ring_are_bit_identical(S, B):
+    """The non-Winograd variants whose waves all multiply both column tiles (the direct bf16x3 forward, the fp16 d(d0) data gradient) take
+    their weight fragments through the same LDS ring (conv3_halo_body, BN): equal bits with vxb_debug_set_halo_experiment(0x1000)."""
+    from voxactb_amd import _lib
+    C = 64
+    d0, u0 = cl(rnd(B, C, S, S, S, seed=1)).to(DEV), cl(rnd(B, C, S, S, S, seed=2)).to(DEV)
+    W = rnd(C, 2 * C, 3, 3, 3, seed=3, scale=0.03).to(DEV)
+    bias = rnd(C, seed=4).to(DEV)
+    dy = cl(rnd(B, C, S, S, S, seed=5)).to(DEV)
+    y1 = cl(rnd(B, 64, S, S, S, seed=6)).to(DEV)
+    Wd = rnd(C, 2 * C, 3, 3, 3, seed=7, scale=0.1).to(DEV)
+    out = {}
+    try:
+        for bits in (0, 0x1000):
+            _lib.lib().vxb_debug_set_halo_experiment(bits)
+            fwd, st = _run(d0, u0, W, bias, B, S, False)                # the direct forward
+            ops.PRECISION, ops.WGRAD_PRECISION = 'bf16x3', 'fp16'
+            try:
+                g0 = torch.zeros(B, S, S, S, 64, device=DEV)
+                g1 = torch.full((B, S, S, S, 64), 3.0, device=DEV)
+                ops.begin_backward()
+                ops.conv3_dgrad_fold(dy, ops.conv_weight_dgrad(Wd), B, S, 2 * C, [(g0, False, None), (g1, False, y1)], leaf_blocks=(0,))
+            finally:
+                ops.PRECISION, ops.WGRAD_PRECISION = 'fp32', ''
+            out[bits] = (fwd, st[0], st[1], st[3], g0, g1)
+    finally:
+        _lib.lib().vxb_debug_set_halo_experiment(0)
+    for a, b in zip(out[0], out[0x1000]):
+        assert torch.equal(a, b)

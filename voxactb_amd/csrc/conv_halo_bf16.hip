@@ -137,7 +137,7 @@ __device__ __forceinline__ void halo_tile_coords(const HaloArgs& g, int t, int& 
     vxb_tile_block_coords(t, g.ntd, g.nth, g.ntw, td, th, tw);
 }
 
-template <int NTG, int PM, int NW, int WD, int TL, int WN, int HALF, int WG = 0>
+template <int NTG, int PM, int NW, int WD, int TL, int WN, int HALF, int WG = 0, int BLN = 0>
                                               // NTG = N / 32 column tiles per workgroup; the NW waves form a (NW / WN) x WN grid over
                                               // (8 M tiles) x (NTG column tiles): 4 x 1 -> 2 M tiles x 2 column tiles per wave,
                                               // 2 x 2 -> 4 x 1 (half the B-fragment traffic per MFMA, twice the A reads from LDS),
@@ -174,6 +174,14 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     constexpr int BL_TPR = (PM == 1) ? 1 : 2;       // taps per round: a round is four 1 KB fragments
     constexpr int BL_ROUNDS = 36 / BL_TPR;
     constexpr int BL_RING = 8 * PLANE;              // u16 offset of the ring
+    // BN (BLN = 1; no Winograd, every wave multiplies BOTH column tiles -- the d(d0) data gradient on fp16 products and the direct forward):
+    // there the four waves fetch the SAME four 1 KB fragments per tap (16 KB through the vector L1 for 4 KB of weights, at 8 MFMAs per
+    // wave and tap that is the L1's peak rate).  Same ring -- a round is a tap -- behind the padded halo image of this variant, in the
+    // space of the weight tiles the register-staged variant keeps there (5 rounds: 57.6 + 20 KB, two workgroups per CU).
+    constexpr bool BN = BLN != 0;
+    static_assert(!BN || (WD && !TL && !WG && WN == 1 && NW == 4 && NTG == 2 && (PM == 0 || PM == 1 || PM == 2)), "BN: four fragments per tap, no Winograd");
+    constexpr int RING_OFF = BL ? BL_RING : HALO_SLOTS * SP;
+    constexpr int RING_NR = BL ? BL_NR : 5;
     constexpr int X3 = PM == 1;                     // three products: input hi | lo, weight planes hi / lo
     constexpr int X2 = PM == 3;                     // two products: input hi | lo, one weight plane
     constexpr int HL = X3 || X2;                    // a chunk is 16 channels as hi | lo halves
@@ -564,7 +572,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
         const unsigned long long sp_ = (unsigned long long)(g.wfrag + (((long long)(n0 / N) * wf_rows + (long long)ch_ * NTAP) * (NTG * NF) + (long long)r_ * 4 + widu) * 512);
         const unsigned slo_ = __builtin_amdgcn_readfirstlane((unsigned)sp_), shi_ = __builtin_amdgcn_readfirstlane((unsigned)(sp_ >> 32));
         const u16* src_ = reinterpret_cast<const u16*>(((unsigned long long)shi_ << 32) | slo_);
-        const unsigned ldsb_ = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)(halo + BL_RING + (r_ % BL_NR) * 2048 + widu * 512));
+        const unsigned ldsb_ = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)(halo + RING_OFF + (r_ % RING_NR) * 2048 + widu * 512));
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"((unsigned)(lane * 16)), "s"(src_), "s"(ldsb_) : "memory");
     };
     auto bl_wait = [&](int n_) __attribute__((always_inline)) {
@@ -608,7 +616,8 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
             // (the barrier that ended the previous chunk's last tap already freed the halo and both weight buffers)
         } else {
             if (wave_on) {
-                if (BD == 2) {
+                if (BN) {
+                } else if (BD == 2) {
                     HD_LOADB(bq0, 0)
                     HD_LOADB(bq1, 1)
                 } else {
@@ -617,10 +626,10 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
                 }
             }
             __syncthreads();                        // no per-tap barriers here: every wave must be done with the old halo
-            if constexpr (BL) {
-                // every wave has left the previous chunk's taps: the whole ring is free -- rounds 0 .. BL_NR - 1 of this chunk
+            if constexpr (BL || BN) {
+                // every wave has left the previous chunk's taps: the whole ring is free -- rounds 0 .. RING_NR - 1 of this chunk
 #pragma unroll
-                for (int r0 = 0; r0 < BL_NR; ++r0) bl_issue(ch, r0);
+                for (int r0 = 0; r0 < RING_NR; ++r0) bl_issue(ch, r0);
             }
         }
         if constexpr (WG) {
@@ -672,11 +681,11 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
             }
         }
         if (!WD) { HB_STORE_W(rw0, 0) }
-        if constexpr (BL) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BL_NR - 1) : "memory");      // this wave's fragment of round 0 has landed
+        if constexpr (BL || BN) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RING_NR - 1) : "memory");      // this wave's fragment of round 0 has landed
             vxb_raw_barrier_lds();                  // (LDS stores of the staging done, then the barrier: no fence -- the rounds in flight stay in flight)
         } else __syncthreads();
-        if (!BL && !wave_on) continue;              // (WD only: the two barriers above are the chunk's only ones; BL: every wave takes the rounds' barriers)
+        if (!BL && !BN && !wave_on) continue;              // (WD only: the two barriers above are the chunk's only ones; BL: every wave takes the rounds' barriers)
         if constexpr (WG && !BL && BD > BD_PRE) {
 #pragma unroll
             for (int t0 = BD_PRE; t0 < BD; ++t0) { HD_LOADB(bqr[t0], t0) }
@@ -783,6 +792,37 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
                     if (tp + 1 < 36) { WG_READ_A(afb, tp + 1) }
                     __builtin_amdgcn_sched_barrier(0);
                     WG_MFMA(afa, bqr[tp % (BD + 1)], tp / 9)
+                }
+            }
+            continue;
+        }
+        if constexpr (BN) {
+#define BN_READ_B(BF, tap_)                                                                                          \
+    {                                                                                                                \
+        const u16* rb_ = halo + RING_OFF + ((tap_) % RING_NR) * 2048 + lane * 8;                                     \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                \
+        _Pragma("unroll") for (int f = 0; f < NF; ++f) BF[j][f] = *reinterpret_cast<const bf16x8*>(rb_ + (j * NF + f) * 512); \
+    }
+            bf16x8 bfa[NT][2], bfb[NT][2];
+            HB_READ_A(afa, 0)
+            BN_READ_B(bfa, 0)
+#pragma unroll
+            for (int tp = 0; tp < 27; ++tp) {
+                if (tp + 1 < 27) {          // open round tp + 1 (see the BL loop)
+                    const int r = tp + 1;
+                    const int young = (26 - r) < (RING_NR - 2) ? (26 - r) : (RING_NR - 2);
+                    bl_wait(young);
+                    vxb_raw_barrier_lds();
+                    if (r - 1 + RING_NR < 27) bl_issue(ch, r - 1 + RING_NR);
+                }
+                if (tp & 1) {
+                    if (tp + 1 < 27) { HB_READ_A(afa, tp + 1) BN_READ_B(bfa, tp + 1) }
+                    __builtin_amdgcn_sched_barrier(0);
+                    HD_MFMA(afb, bfb)
+                } else {
+                    if (tp + 1 < 27) { HB_READ_A(afb, tp + 1) BN_READ_B(bfb, tp + 1) }
+                    __builtin_amdgcn_sched_barrier(0);
+                    HD_MFMA(afa, bfa)
                 }
             }
             continue;
@@ -1092,7 +1132,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
     }
 }
 
-template <int NTG, int PM, int NW, int WD, int TL = 0, int WN = 1, int WG = 0>
+template <int NTG, int PM, int NW, int WD, int TL = 0, int WN = 1, int WG = 0, int BLN = 0>
 __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
     constexpr bool EDGE = WD && WN == 2 && NW == 4;
     if constexpr (WG) {
@@ -1128,7 +1168,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3_halo_kernel(HaloArgs g) {
             return;
         }
     }
-    conv3_halo_body<NTG, PM, NW, WD, TL, WN, 0>(g);
+    conv3_halo_body<NTG, PM, NW, WD, TL, WN, 0, 0, BLN>(g);
 }
 
 inline bool hb_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -1140,15 +1180,17 @@ int g_halo_wn = 0;         // experiment knob (vxb_debug_set_halo_wn): waves alo
                           // repetitions each, B = 16, S = 100): forward 20.23 -> 19.43 ms, data gradient + padding adjoint
                           // 21.89 -> 20.85 ms; the tap-list variant (up-conv data gradient) is unchanged, 11.0 ms either way        // experiment knob (vxb_debug_set_halo_waves): 4 waves x 2 M tiles or 8 waves x 1 M tile per workgroup
 
-template <int NT, int PM, int NW, int WD, int TL = 0, int WN = 1, int WG = 0>
+template <int NT, int PM, int NW, int WD, int TL = 0, int WN = 1, int WG = 0, int BLN = 0>
 int hb_launch(const HaloArgs& g, long long nblk, hipStream_t st) {
     // (the fold epilogue re-uses the buffer as an fp32 [256][64] tile: keep the full size in every variant)
     const size_t lds = WG == 2 ? (size_t)(8 * HHp * HW_USED * 32 + 6 * 2048) * sizeof(u16)      // compact image + the fragment ring (conv3_halo_body: BL)
-                     : WG ? (size_t)8 * HHp * HWp * SP * sizeof(u16) : (size_t)(HALO_SLOTS * SP + 2 * NT * 32 * LDW) * sizeof(u16);
+                     : WG ? (size_t)8 * HHp * HWp * SP * sizeof(u16)
+                     : BLN ? (size_t)(HALO_SLOTS * SP + 5 * 2048) * sizeof(u16)                   // padded image + the fragment ring (BN)
+                     : (size_t)(HALO_SLOTS * SP + 2 * NT * 32 * LDW) * sizeof(u16);
     if (TL && (size_t)(g.ncls * 32 + g.nphase * 2) * sizeof(int) > (size_t)2 * NT * 32 * LDW * sizeof(u16)) return VXB_ESIZE;
-    if (hipFuncSetAttribute((const void*)conv3_halo_kernel<NT, PM, NW, WD, TL, WN, WG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv3_halo_kernel<NT, PM, NW, WD, TL, WN, WG, BLN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VXB_ELAUNCH;
-    hipLaunchKernelGGL((conv3_halo_kernel<NT, PM, NW, WD, TL, WN, WG>), dim3((unsigned)(nblk * (g.N / (NT * 32)) * (TL ? g.ksplit : 1))), dim3(NW * 64), lds, st, g);
+    hipLaunchKernelGGL((conv3_halo_kernel<NT, PM, NW, WD, TL, WN, WG, BLN>), dim3((unsigned)(nblk * (g.N / (NT * 32)) * (TL ? g.ksplit : 1))), dim3(NW * 64), lds, st, g);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }
@@ -1200,12 +1242,13 @@ int hb_impl(int x3 /* product mode: 0 bf16, 1 bf16x3, 2 fp16 (WD kernels only, `
         return x3 == 3 ? hb_launch<2, 3, 4, 1, 0, 2, 2>(g, nblk, st) : hb_launch<2, 1, 4, 1, 0, 2, 2>(g, nblk, st);
     if (wino) return x3 == 3 ? hb_launch<2, 3, 4, 1, 0, 2, 1>(g, nblk, st) : x3 == 2 ? hb_launch<2, 2, 4, 1, 0, 2, 1>(g, nblk, st)
                                                                                : hb_launch<2, 1, 4, 1, 0, 2, 1>(g, nblk, st);
-    if (x3 == 2) return hb_launch<2, 2, 4, 1>(g, nblk, st);
+    if (x3 == 2) return (g.dbg & 0x1000) ? hb_launch<2, 2, 4, 1>(g, nblk, st) : hb_launch<2, 2, 4, 1, 0, 1, 0, 1>(g, nblk, st);
     if (x3 == 3) return g.taptab ? hb_launch<2, 3, 4, 1, 1, 2>(g, nblk, st) : hb_launch<2, 3, 4, 1, 0, 2>(g, nblk, st);
     const int wn = g_halo_wn ? g_halo_wn : (x3 ? 2 : 1);
     if (g.taptab && wn == 2) return x3 ? hb_launch<2, 1, 4, 1, 1, 2>(g, nblk, st) : hb_launch<2, 0, 4, 1, 1, 2>(g, nblk, st);
     if (g.taptab) return x3 ? hb_launch<2, 1, 4, 1, 1>(g, nblk, st) : hb_launch<2, 0, 4, 1, 1>(g, nblk, st);
     if (g.wfrag && wn == 2) return x3 ? hb_launch<2, 1, 4, 1, 0, 2>(g, nblk, st) : hb_launch<2, 0, 4, 1, 0, 2>(g, nblk, st);
+    if (g.wfrag && !(g.dbg & 0x1000)) return x3 ? hb_launch<2, 1, 4, 1, 0, 1, 0, 1>(g, nblk, st) : hb_launch<2, 0, 4, 1, 0, 1, 0, 1>(g, nblk, st);
     if (g.wfrag) return x3 ? hb_launch<2, 1, 4, 1>(g, nblk, st) : hb_launch<2, 0, 4, 1>(g, nblk, st);
     if (g_halo_waves == 8) return x3 ? hb_launch<2, 1, 8, 0>(g, nblk, st) : hb_launch<2, 0, 8, 0>(g, nblk, st);
     return x3 ? hb_launch<2, 1, 4, 0>(g, nblk, st) : hb_launch<2, 0, 4, 0>(g, nblk, st);
