@@ -573,7 +573,7 @@ __device__ __forceinline__ void conv3_halo_body(const HaloArgs& g) {
         const unsigned slo_ = __builtin_amdgcn_readfirstlane((unsigned)sp_), shi_ = __builtin_amdgcn_readfirstlane((unsigned)(sp_ >> 32));
         const u16* src_ = reinterpret_cast<const u16*>(((unsigned long long)shi_ << 32) | slo_);
         const unsigned ldsb_ = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)(halo + RING_OFF + (r_ % RING_NR) * 2048 + widu * 512));
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"((unsigned)(lane * 16)), "s"(src_), "s"(ldsb_) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"((unsigned)(lane * 16)), "s"(src_), "s"(ldsb_) : "memory", "m0");
     };
     auto bl_wait = [&](int n_) __attribute__((always_inline)) {
         switch (n_) {          // (n_ is a constant after unrolling)
