@@ -220,6 +220,11 @@ int vxb_gemm_wide_geglu_fwd_f32(const float* A, int64_t lda, const void* Bw_frag
                                 int K, vxb_stream_t stream);
 int vxb_gemm_wide_geglu_bwd_f32(const float* dY, int64_t lda, const void* Bw_frag, const float* h, float* dh, int M, int F, int K,
                                 vxb_stream_t stream);
+/* ... and the _bwd launch on the two-fp16-product arithmetic of vxb_gemm_wide_f16x2_f32 (Bw_frag16: ONE fp16 plane of the transposed weight
+ * in fragment order; scale: device {2^k, 2^-k}, the operand scale of dY): d(gg) has the bits of that entry, dh those of vxb_geglu_bwd_f32
+ * applied to it.  FeedForward's backward, perceiver_lang_io.py:74-78 / :100-106 through autograd. */
+int vxb_gemm_wide_geglu_bwd_f16x2_f32(const float* dY, int64_t lda, const void* Bw_frag16, const float* h, float* dh, int M, int F, int K,
+                                      const float* scale, vxb_stream_t stream);
 /* Forward of the polyphase up-conv (network_utils.py:245-250 as ops.conv3_polyphase_fwd evaluates it: the low-res kext^3 conv with
  * s^3 * 64 phase columns and a depth-to-space store) on the same 128 x 512 workgroup tiles: z [B, S^3, Cin] fp32 is gathered and split
  * in the kernel (no activation planes), wt_frag = the [N][kext^3 * Cin] weights (column blocks in `perm` order) as hi / lo planes in

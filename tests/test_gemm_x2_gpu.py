@@ -82,3 +82,42 @@ def test_linear_dgrad_accumulates_into_dx():
         ops.new_step()
         ops._GRAD_SCALE.clear()
     assert float((dx1 - (base + dx0)).abs().max()) < 2e-5 * float(dx0.abs().max())
+
+
+@pytest.mark.parametrize('M,F,K', [(2048, 512, 512), (2300, 2048, 512)])
+def test_geglu_backward_fused_into_the_two_product_data_gradient(M, F, K):
+    """FeedForward's backward (perceiver_lang_io.py:74-78 / :100-106 through autograd): d(gg) = dy @ W2 on two fp16 products with GEGLU's
+    backward in the wide kernel's row-contiguous epilogue (vxb_gemm_wide_geglu_bwd_f16x2_f32, ops.linear_dgrad_geglu_bwd) against the
+    two launches it replaces (vxb_gemm_wide_f16x2_f32 + vxb_geglu_bwd_f32): equal bits, first on the exact operand scale, then on the
+    delayed one.  Ragged M.  Also: the epilogue that stores straight out of the accumulators (vxb_debug_set_gemm_wide_experiment(64))."""
+    from voxactb_amd import _lib
+    gg = rnd(M, F, seed=1).to(DEV)
+    h = rnd(M, 2 * F, seed=5).to(DEV)
+    dy = (rnd(M, K, seed=2) * 3e-3).to(DEV)
+    W2 = rnd(K, F, seed=3, scale=0.05).to(DEV)
+    state = (ops.PRECISION, ops.WGRAD_PRECISION, ops.GENERIC_WGRAD_F16, ops.DGRAD_PRECISION, ops.FUSE_GEGLU_BWD)
+    try:
+        ops.PRECISION, ops.WGRAD_PRECISION, ops.GENERIC_WGRAD_F16, ops.DGRAD_PRECISION, ops.FUSE_GEGLU_BWD = 'bf16x3', 'fp16', True, 'fp16x2', 'x2'
+        ops.new_step()
+        ops._GRAD_SCALE.clear()
+        ops.prepare_linear_weights([W2], f16_dgrad=True)
+        assert ops.geglu_bwd_fusable(dy, W2, h)
+        for it in range(2):
+            dW, db = torch.zeros_like(W2), torch.zeros(K, device=DEV)
+            ops.begin_backward()
+            ops._LAST_LIN_DY_SCALE[0] = None
+            ops.linear_bwd(gg, W2, dy, dW, db, None)
+            sc = ops._LAST_LIN_DY_SCALE[0]
+            assert sc is not None
+            dgg = torch.full((M, F), float('nan'), device=DEV)
+            ops.linear_dgrad(dy, W2, dgg, False, sc)
+            ref = ops.geglu_bwd(h, dgg)
+            for bits in (0, 64):
+                _lib.lib().vxb_debug_set_gemm_wide_experiment(bits)
+                got = ops.linear_dgrad_geglu_bwd(dy, W2, h, sc)
+                assert got is not None and torch.equal(got, ref), (it, bits)
+    finally:
+        _lib.lib().vxb_debug_set_gemm_wide_experiment(0)
+        ops.PRECISION, ops.WGRAD_PRECISION, ops.GENERIC_WGRAD_F16, ops.DGRAD_PRECISION, ops.FUSE_GEGLU_BWD = state
+        ops.new_step()
+        ops._GRAD_SCALE.clear()

@@ -531,9 +531,17 @@ class PerceiverEngine:
     def _ff_bwd(self, pre, c, dx):
         """dx: gradient wrt the block output (also the residual path); updated in place to the input gradient."""
         W2 = self.p(pre + '.fn.net.2.weight')
-        dh = ops.linear_dgrad_geglu_bwd(dx, W2, c['h'])      # d(gg) = dx @ W2 and GEGLU's backward in one launch where it applies
-        if dh is not None:
+        # the weight gradient first (its launch reports the operand scale of dx that the two-product data gradient takes), then
+        # d(gg) = dx @ W2 and GEGLU's backward in one launch -- where that applies (ops.geglu_bwd_fusable)
+        dh = None
+        if ops.geglu_bwd_fusable(dx, W2, c['h']):
+            ops._LAST_LIN_DY_SCALE[0] = None
             ops.linear_bwd(c['gg'], W2, dx, self.g(pre + '.fn.net.2.weight'), self.g(pre + '.fn.net.2.bias'), None)
+            dh = ops.linear_dgrad_geglu_bwd(dx, W2, c['h'], ops._LAST_LIN_DY_SCALE[0])
+            if dh is None:                      # (no fused form after all: the plain data gradient, then GEGLU's backward)
+                dgg = torch.empty_like(c['gg'])
+                ops.linear_dgrad(dx, W2, dgg, False, ops._LAST_LIN_DY_SCALE[0])
+                dh = ops.geglu_bwd(c['h'], dgg)
         else:
             dgg = torch.empty_like(c['gg'])
             ops.linear_bwd(c['gg'], W2, dx, self.g(pre + '.fn.net.2.weight'), self.g(pre + '.fn.net.2.bias'), dgg)

@@ -226,8 +226,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) gemm_wide_kernel(GwA
     // 4096 x 512 launch (tools/bench_gemm_ablate.py) -- 7.7 GB/s per CU.  Here the tile goes through LDS (the operand stages are free),
     // sixteen rows at a time, and leaves as 1 KB per wave instruction: whole 2 KB rows (1 KB row pieces of h's two halves and of gg with
     // GEGLU).  Per element the same operations in the same order as below: identical bits.
-    if (NW == 8 && g.geglu != 2 && !(g.dbg & 64) && !(g.ldc & 3) && !((uintptr_t)C & 15) && (!R || !((uintptr_t)R & 15)) && !((uintptr_t)g.bias & 15) &&
-        (g.geglu != 1 || (!(g.F & 3) && !((uintptr_t)g.C2 & 15)))) {
+    if (NW == 8 && !(g.dbg & 64) && !(g.ldc & 3) && !((uintptr_t)C & 15) && (!R || !((uintptr_t)R & 15)) && !((uintptr_t)g.bias & 15) &&
+        (g.geglu != 1 || (!(g.F & 3) && !((uintptr_t)g.C2 & 15))) && (g.geglu != 2 || (!(g.F & 3) && !((uintptr_t)g.H & 15)))) {
         constexpr int CLD = 512 + 8;
         float* Cs = reinterpret_cast<float*>(&As[0][0][0]);                 // [16][CLD] fp32 = 33 KB of the 40 KB
         const int lrow = 4 * (lane >> 5), lcol = lane & 31;
@@ -269,6 +269,37 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) gemm_wide_kernel(GwA
         }
         const int er = tid >> 7, ec = (tid & 127) * 4;                      // 4 rows x 128 column quads per pass of the read-out
         const int n4 = cg * 512 + ec;
+        if (g.geglu == 2) {
+            // the tile is d(gg): dh = [d * gelu(h_gate) | d * h_value * gelu'(h_gate)], h read and dh written in whole row pieces
+            const int F = g.F;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int rr = 0; rr < 8; ++rr) {
+                            const int r = 8 * hf + rr;
+                            Cs[((r & 3) + 8 * ((r >> 2) & 1) + lrow) * CLD + wn * 64 + j * 32 + lcol] = X2 ? acc[i][j][r] * out_sc : acc[i][j][r];
+                        }
+                    __syncthreads();
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) {
+                        const int row = er + 4 * st;
+                        const int m = m0 + i * 32 + 16 * hf + row;
+                        if (m >= g.M) continue;
+                        const float4 d = *reinterpret_cast<const float4*>(&Cs[row * CLD + ec]);
+                        const long long o = (long long)m * 2 * F + n4;
+                        const float4 a = *reinterpret_cast<const float4*>(g.H + o), gt = *reinterpret_cast<const float4*>(g.H + o + F);
+                        *reinterpret_cast<float4*>(C + o) = make_float4(d.x * gelu_erf(gt.x), d.y * gelu_erf(gt.y), d.z * gelu_erf(gt.z), d.w * gelu_erf(gt.w));
+                        *reinterpret_cast<float4*>(C + o + F) = make_float4(d.x * a.x * gelu_erf_grad(gt.x), d.y * a.y * gelu_erf_grad(gt.y),
+                                                                            d.z * a.z * gelu_erf_grad(gt.z), d.w * a.w * gelu_erf_grad(gt.w));
+                    }
+                }
+            return;
+        }
         const float4 bs = g.bias ? *reinterpret_cast<const float4*>(g.bias + n4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -330,7 +361,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) gemm_wide_kernel(GwA
                     const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     if (m >= g.M) continue;
                     const long long o = (long long)m * 2 * F + c;
-                    const float a = g.H[o], gt = g.H[o + F], d = acc[i][j][r];
+                    const float a = g.H[o], gt = g.H[o + F], d = X2 ? acc[i][j][r] * out_sc : acc[i][j][r];
                     C[o] = d * gelu_erf(gt);
                     C[o + F] = d * a * gelu_erf_grad(gt);
                 }
@@ -706,6 +737,21 @@ extern "C" int vxb_gemm_wide_geglu_bwd_f32(const float* dY, int64_t lda, const v
     g.M = M; g.K = K; g.act = 0; g.slope = 0.f; g.accumulate = 0;
     g.geglu = 2; g.F = F; g.C2 = nullptr; g.H = h; g.scale = nullptr;
     gw_launch<0>(g, M, F, (hipStream_t)stream);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+// The same on two fp16 products (round 6): dY * scale[0] as an fp16 hi + lo pair, W2 as ONE fp16 plane in fragment order (the operand of
+// vxb_gemm_wide_f16x2_f32: same products, same order -> d(gg) has its bits), GEGLU's backward in the row-contiguous epilogue.
+extern "C" int vxb_gemm_wide_geglu_bwd_f16x2_f32(const float* dY, int64_t lda, const void* Bw_frag16, const float* h, float* dh, int M, int F,
+                                                 int K, const float* scale, vxb_stream_t stream) {
+    if (!dY || !Bw_frag16 || !h || !dh || !scale || M < 1 || K < 64 || F < 512) return VXB_EARG;
+    if ((F & 511) || (K & 31) || (lda & 3) || (((uintptr_t)dY | (uintptr_t)Bw_frag16 | (uintptr_t)h | (uintptr_t)dh) & 15)) return VXB_ESIZE;
+    GwArgs g;
+    g.A = dY; g.lda = lda; g.Bfrag = (const u16*)Bw_frag16; g.C = dh; g.ldc = 2 * (long long)F; g.bias = nullptr; g.residual = nullptr;
+    g.M = M; g.K = K; g.act = 0; g.slope = 0.f; g.accumulate = 0;
+    g.geglu = 2; g.F = F; g.C2 = nullptr; g.H = h; g.scale = scale;
+    gw_launch<1>(g, M, F, (hipStream_t)stream);
     VXB_CHECK_LAUNCH();
     return VXB_OK;
 }

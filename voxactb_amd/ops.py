@@ -39,6 +39,7 @@ _WCACHE = {}
 
 _FCACHE = {}
 _F16CACHE = {}       # transposed weight planes (address, shape) -> the same matrix as ONE fp16 plane in fragment order (fp16x2 data gradients)
+_LAST_LIN_DY_SCALE = [None]   # operand scale of dY the last linear_bwd's weight-gradient launch took (None: it took none)
 _LAST_GRAD_SCALE = [None]     # operand scale (device {2^k, 2^-k}) the last delayed-scaling weight-gradient launch applied to its gradient
 # rows from which the 128 x 512 workgroup tiles of the wide kernels fill the chip (M / 128 workgroups per 512 columns: 128 at M = 16384).
 # Below it -- the released VoxAct-B recipe trains with replay.batch_size = 1, M = 2048 -- the 128 x 64 / 128 x 128 tile kernels run
@@ -291,6 +292,26 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None):
     return out
 
 
+def linear_dgrad(dy, W, dx, dx_accumulate=False, sc_dy=None):
+    """dx[M,K] (+)= dy[M,N] @ W[N,K] for the non-small shapes of linear_bwd; sc_dy: the operand scale of dy its weight-gradient launch
+    reported (None: the bf16x3 / fp32 arithmetic)."""
+    M, N = dy.shape
+    K = W.shape[1]
+    if _mm() and N % 8 == 0 and W.is_contiguous():
+        Wt = _bf16_weight(W, True)
+        f16 = _F16CACHE.get((Wt.data_ptr(), tuple(Wt.shape))) if (LIN_DGRAD_X2 and DGRAD_PRECISION == 'fp16x2' and sc_dy is not None) else None
+        if (f16 is not None and K % 512 == 0 and N % 32 == 0 and N >= 256 and M >= WIDE_MIN_M and dy.stride(1) == 1 and dy.stride(0) % 4 == 0
+                and dy.data_ptr() % 16 == 0):
+            # dX = dY @ W on two fp16 products: dY * 2^k as an fp16 hi + lo pair, W as one fp16 value (gemm_wide.hip, X2)
+            _lib.set_meta('gemm_dgrad %dx%dx%d' % (M, K, N), 2.0 * M * N * K)
+            call('vxb_gemm_wide_f16x2_f32', dy, dy.stride(0), f16[0], dx, dx.stride(0), None, M, K, N, int(dx_accumulate), sc_dy)
+        else:
+            gemm_bf16w(dy, Wt, dx, accumulate=dx_accumulate, label='gemm_dgrad %dx%dx%d' % (M, K, N))
+    else:
+        gemm(dy, W, dx, M, K, N, dy.stride(0), 1, W.stride(0), 1, dx.stride(0), accumulate=dx_accumulate,
+             label='gemm_dgrad %dx%dx%d' % (M, K, N))
+
+
 def linear_bwd(x, W, dy, dW, db=None, dx=None, dx_accumulate=False, ws=None):
     """dW[N,K] += dy^T x ; db[N] += colsum(dy) ; dx[M,K] (+)= dy @ W   (dy already includes the activation')."""
     M, K = x.shape
@@ -323,6 +344,7 @@ def linear_bwd(x, W, dy, dW, db=None, dx=None, dx_accumulate=False, ws=None):
                 axpy_(dW, res)
             db = None                    # (the bias gradient came out of the same launch)
             sc_dy, _LAST_GRAD_SCALE[0] = _LAST_GRAD_SCALE[0], None
+            _LAST_LIN_DY_SCALE[0] = sc_dy     # (for a caller that runs the data gradient itself: linear_dgrad_geglu_bwd)
         elif ns > 1:
             rc = M // ns
             part = torch.empty((ns, N, K), dtype=torch.float32, device=x.device)
@@ -331,19 +353,8 @@ def linear_bwd(x, W, dy, dW, db=None, dx=None, dx_accumulate=False, ws=None):
             sum_splits(part, ns, N * K, dW, accumulate=True)
         else:
             gemm(dy, x, dW, N, K, M, 1, dy.stride(0), x.stride(0), 1, dW.stride(0), accumulate=True, label='gemm_wgrad %dx%dx%d' % (N, K, M))
-        if dx is not None and _mm() and N % 8 == 0 and W.is_contiguous():
-            Wt = _bf16_weight(W, True)
-            f16 = _F16CACHE.get((Wt.data_ptr(), tuple(Wt.shape))) if (LIN_DGRAD_X2 and DGRAD_PRECISION == 'fp16x2' and sc_dy is not None) else None
-            if (f16 is not None and K % 512 == 0 and N % 32 == 0 and N >= 256 and M >= WIDE_MIN_M and dy.stride(1) == 1 and dy.stride(0) % 4 == 0
-                    and dy.data_ptr() % 16 == 0):
-                # dX = dY @ W on two fp16 products: dY * 2^k as an fp16 hi + lo pair, W as one fp16 value (gemm_wide.hip, X2)
-                _lib.set_meta('gemm_dgrad %dx%dx%d' % (M, K, N), 2.0 * M * N * K)
-                call('vxb_gemm_wide_f16x2_f32', dy, dy.stride(0), f16[0], dx, dx.stride(0), None, M, K, N, int(dx_accumulate), sc_dy)
-            else:
-                gemm_bf16w(dy, Wt, dx, accumulate=dx_accumulate, label='gemm_dgrad %dx%dx%d' % (M, K, N))
-        elif dx is not None:
-            gemm(dy, W, dx, M, K, N, dy.stride(0), 1, W.stride(0), 1, dx.stride(0), accumulate=dx_accumulate,
-                 label='gemm_dgrad %dx%dx%d' % (M, K, N))
+        if dx is not None:
+            linear_dgrad(dy, W, dx, dx_accumulate, sc_dy)
     if db is not None:
         colsum(dy, db, accumulate=True)
 
@@ -423,7 +434,11 @@ FUSE_GEGLU = os.environ.get('VOXACTB_FUSE_GEGLU', '1') != '0'     # GEGLU inside
 # ... and its backward inside the down-projection's data gradient: OFF.  Measured in the step (same box): the fused launch takes 0.63 ms where
 # the wide GEMM (0.235 ms) + vxb_geglu_bwd_f32 (0.264 ms, a streaming pass at 5 TB/s) take 0.50 -- with one workgroup per CU the 1 MB of
 # epilogue traffic and the erf / exp arithmetic of a 128 x 512 tile are serial with its main loop instead of running at full HBM bandwidth.
-FUSE_GEGLU_BWD = os.environ.get('VOXACTB_FUSE_GEGLU_BWD', '0') != '0'
+# Round 6: with the row-contiguous epilogue and on the two-fp16-product arithmetic of the layer's plain data gradient the fused launch wins
+# (vxb_gemm_wide_geglu_bwd_f16x2_f32; the bf16x3 one -- '1' -- still only ties: a third more MFMAs than the separate fp16x2 launch).
+# 'x2' (default): fused where the fp16x2 data gradient applies; '1': fused on bf16x3 elsewhere too; '0': never.
+_fgb = os.environ.get('VOXACTB_FUSE_GEGLU_BWD', 'x2')
+FUSE_GEGLU_BWD = False if _fgb == '0' else ('x2' if _fgb == 'x2' else True)
 
 
 def _geglu_wide_ok(x, rows_out, K):
@@ -447,13 +462,38 @@ def linear_geglu(x, W, bias):
     return h, geglu_fwd(h)
 
 
-def linear_dgrad_geglu_bwd(dy, W2, h):
+def geglu_bwd_fusable(dy, W2, h):
+    """Will linear_dgrad_geglu_bwd take this layer?  ('x2', the default: only where the layer's data gradient runs on two fp16 products and
+    its weight-gradient launch reports the operand scale of dy.)"""
+    M, K = dy.shape
+    F = W2.shape[1]
+    if not (FUSE_GEGLU_BWD and _geglu_wide_ok(dy, F, K) and W2.is_contiguous() and h.is_contiguous()):
+        return False
+    if FUSE_GEGLU_BWD == 'x2':
+        if not (LIN_DGRAD_X2 and DGRAD_PRECISION == 'fp16x2' and WGRAD_PRECISION == 'fp16' and GENERIC_WGRAD_F16 and M >= WIDE_MIN_M):
+            return False
+        Wt = _bf16_weight(W2, True)
+        return _F16CACHE.get((Wt.data_ptr(), tuple(Wt.shape))) is not None
+    return True
+
+
+def linear_dgrad_geglu_bwd(dy, W2, h, sc_dy=None):
     """dh [M][2 F] = GEGLU'(h) applied to d(gg) = dy [M][K] @ W2 [K][F] (data gradient of FeedForward's down-projection + GEGLU's
-    backward): one launch on the wide kernel where it applies, else None (the caller takes the two-pass route)."""
+    backward): one launch on the wide kernel where it applies, else None (the caller takes the two-pass route).  sc_dy: the operand
+    scale of dy (the weight-gradient launch of the same dy reports it: _LAST_LIN_DY_SCALE) -> the two-fp16-product arithmetic of the
+    layer's plain data gradient (vxb_gemm_wide_f16x2_f32), same bits as that launch followed by geglu_bwd."""
     M, K = dy.shape
     F = W2.shape[1]
     if not (FUSE_GEGLU_BWD and _geglu_wide_ok(dy, F, K) and W2.is_contiguous() and h.is_contiguous()):
         return None
+    if sc_dy is not None and LIN_DGRAD_X2 and DGRAD_PRECISION == 'fp16x2':
+        Wt = _bf16_weight(W2, True)
+        f16 = _F16CACHE.get((Wt.data_ptr(), tuple(Wt.shape)))
+        if f16 is not None:
+            dh = torch.empty_like(h)
+            _lib.set_meta('gemm_dgrad %dx%dx%d' % (M, F, K), 2.0 * M * F * K)
+            call('vxb_gemm_wide_geglu_bwd_f16x2_f32', dy, dy.stride(0), f16[0], h, dh, M, F, K, sc_dy)
+            return dh
     wf = gemm_wfrag(_bf16_weight(W2, True))
     if wf is None:
         return None
