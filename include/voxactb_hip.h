@@ -206,6 +206,12 @@ int vxb_split_bf16_f32(const float* src, int64_t ld, int64_t rows, int cols, voi
 int vxb_gemm_wide_bf16x3_f32(const float* A, int64_t lda, const void* Bw_frag, float* C, int64_t ldc, const float* bias,
                              const float* residual, int M, int N, int K, int act, float slope, int accumulate,
                              vxb_stream_t stream);
+/* ... with the result also as ONE fp16 plane f16_out [M][N] (saturating round-to-nearest: the bits of vxb_split_f16_f32 applied to C): the
+ * k | v operand plane of vxb_flash2_attn_fwd / _bwd out of the to_kv projection's epilogue (perceiver_lang_io.py:112-113) instead of by a
+ * pass over kv. */
+int vxb_gemm_wide_bf16x3_f16out_f32(const float* A, int64_t lda, const void* Bw_frag, float* C, int64_t ldc, const float* bias,
+                                    const float* residual, int M, int N, int K, int act, float slope, int accumulate, void* f16_out,
+                                    vxb_stream_t stream);
 /* ... on TWO fp16 products per term for the data gradients of the linear layers (dX = dY @ W, perceiver_lang_io.py:74-132 backward):
  * A = dY times scale[0] / 16 as an fp16 hi + lo pair, the weights as one fp16 value (Bw_frag16: single-plane fragment order of the fp16
  * [N][K] matrix, vxb_split_bf16_batch_f32 flag bit 3), the sums times 16 scale[1]; scale = device {2^k, 2^-k}. */

@@ -274,3 +274,30 @@ def test_geglu_fused_into_the_wide_gemm_is_bit_identical(M, F, K, _wide_waves):
         ops.PRECISION = old
         ops.FUSE_GEGLU = keep
         ops.new_step()
+
+
+@pytest.mark.parametrize('M,N,K', [(2048, 1024, 512), (2300, 512, 512)])
+def test_wide_gemm_fp16_plane_of_its_result(M, N, K):
+    """vxb_gemm_wide_bf16x3_f16out_f32 (ops.linear(..., f16_out=)): the product as the plain entry writes it, and its fp16 plane -- the k | v
+    operand of the pipelined attention kernels, perceiver_lang_io.py:112-113 -- with the bits of vxb_split_f16_f32 applied to that result;
+    values beyond the largest half saturate.  Ragged M; both epilogues (vxb_debug_set_gemm_wide_experiment(64))."""
+    from voxactb_amd import _lib, flash
+    x, W, b = rnd(M, K).to(DEV), rnd(N, K, seed=1).to(DEV), rnd(N, seed=2).to(DEV)
+    x[5, :] *= 3e3                       # a row whose outputs overflow half
+    old = ops.PRECISION
+    ops.PRECISION = 'bf16x3'
+    try:
+        ops.new_step()
+        ref = ops.linear(x, W, b)
+        planes = flash.kv_planes(ref, 'f16')
+        assert float(ref.abs().max()) > 65504.0
+        for bits in (0, 64):
+            _lib.lib().vxb_debug_set_gemm_wide_experiment(bits)
+            f16 = torch.zeros((M, N), dtype=torch.float16, device=DEV)
+            got, filled = ops.linear(x, W, b, f16_out=f16)
+            assert filled and torch.equal(got, ref)
+            assert torch.equal(f16.view(torch.int16), planes[0].view(torch.int16)), bits
+    finally:
+        _lib.lib().vxb_debug_set_gemm_wide_experiment(0)
+        ops.PRECISION = old
+        ops.new_step()

@@ -284,6 +284,7 @@ def _r4(n):
     return (n + 3) & ~3
 
 
+KV_F16_FROM_EPILOGUE = _os.environ.get('VOXACTB_KV_F16_EPILOGUE', '1') != '0'     # to_kv's GEMM writes the attention kernels' fp16 k | v plane itself (round 6)
 ATTN_F16_MIN_SCORES = 1 << 22      # attn_kernel 'auto': score elements (B * H * Nq * Nk) from which the single-fp16 attention forward runs
 
 
@@ -430,7 +431,6 @@ class PerceiverEngine:
         Wo, bo = self.p(pre + '.fn.to_out.weight'), self.p(pre + '.fn.to_out.bias')
         inner = H * d
         q = ops.linear(xq.view(B * Nq, Dq), Wq)
-        kv = ops.linear(ctxn.reshape(B * Nk, ctxn.shape[2]), Wkv)
         # (the plain-bf16 throughput mode takes the pipelined forward by default: single bf16 products either way, VOXACTB_ATTN_KERNEL=r3bf16 keeps round 3's)
         kern = self.attn_kernel
         if kern == 'auto':
@@ -438,12 +438,22 @@ class PerceiverEngine:
         if (self.precision in ('bf16', 'bf16x3') and d == 64 and self.fused_attention
                 and (kern not in ('r3', 'r3bf16') or (self.precision == 'bf16' and kern == 'r3'))):
             mode = 'bf16' if self.precision == 'bf16' else kern
+            kvp = None
+            if mode == 'f16' and KV_F16_FROM_EPILOGUE:
+                # the fp16 k | v plane of the attention kernels out of to_kv's epilogue where the wide GEMM runs (else: a pass over kv, flash.py)
+                kvp = torch.empty((1, B * Nk, 2 * inner), dtype=torch.float16, device=xq.device)
+                kv, filled = ops.linear(ctxn.reshape(B * Nk, ctxn.shape[2]), Wkv, f16_out=kvp[0])
+                if not filled:
+                    kvp = None
+            else:
+                kv = ops.linear(ctxn.reshape(B * Nk, ctxn.shape[2]), Wkv)
             # (save: the forward also stores the dropout keep words for the backward -- same mask, no second hash of it; flash.py)
-            O, lse, kvp, dmask = flash.flash2_attn_fwd(q, kv, B, H, Nq, Nk, d ** -0.5, p, seed, mode=mode, return_planes=True,
+            O, lse, kvp, dmask = flash.flash2_attn_fwd(q, kv, B, H, Nq, Nk, d ** -0.5, p, seed, mode=mode, planes=kvp, return_planes=True,
                                                        return_mask=True, store_mask=bool(save))
             out = ops.linear(O, Wo, bo, residual=residual)
             cache = dict(q=q, kv=kv, kvp=kvp, O=O, lse=lse, flash=2, mode=mode, dims=(B, Nq, Nk, H, d, 0), p=p, seed=seed, dmask=dmask) if save else None
             return out, cache
+        kv = ops.linear(ctxn.reshape(B * Nk, ctxn.shape[2]), Wkv)
         if self.precision in ('bf16', 'bf16x3') and d == 64 and self.fused_attention:
             # fused attention on the bf16 matrix cores, no [B*h, i, j] tensor (csrc/flash_attn.hip); 'bf16x3' carries
             # q, k, v, dO, P and dS as hi + lo halves

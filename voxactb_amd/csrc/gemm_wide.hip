@@ -55,6 +55,8 @@ struct GwArgs {
     const float* scale;
     int dbg;                 // timing experiments (WRONG results): 1 no B loads in the loop, 2 no A loads, 4 no A store / barrier, 8 no epilogue; 32: 2-D grid (row blocks fastest) for N > 512
     int ncg;                 // NW = 4 launches: column groups per row block (1-D grid)
+    int N_total;             // columns of the whole product (row length of aux16)
+    u16* aux16 = nullptr;    // plain epilogue, optional: the result also as ONE fp16 plane [M][N] (saturating RNE: the bits of vxb_split_f16_f32 on C)
 };
 
 typedef _Float16 gw_f16x8 __attribute__((ext_vector_type(8)));
@@ -329,6 +331,12 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) gemm_wide_kernel(GwA
                     if (R) { const float4 q = *reinterpret_cast<const float4*>(R + off); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
                     if (g.accumulate) { const float4 q = *reinterpret_cast<const float4*>(C + off); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
                     *reinterpret_cast<float4*>(C + off) = v;
+                    if (g.aux16) {
+                        uint2 ph;
+                        ph.x = vxb_pack_f16(__builtin_amdgcn_fmed3f(v.x, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v.y, -65504.f, 65504.f));
+                        ph.y = vxb_pack_f16(__builtin_amdgcn_fmed3f(v.z, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v.w, -65504.f, 65504.f));
+                        *reinterpret_cast<uint2*>(g.aux16 + (long long)m * g.N_total + n4) = ph;
+                    }
                 }
             }
         return;
@@ -384,6 +392,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) gemm_wide_kernel(GwA
                 if (R) v += R[off];
                 if (g.accumulate) v += C[off];
                 C[off] = v;
+                if (g.aux16) g.aux16[(long long)m * g.N_total + n] = (u16)(vxb_pack_f16(__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f), 0.f) & 0xffffu);
             }
         }
     }
@@ -653,7 +662,7 @@ __global__ void __launch_bounds__(512) conv_poly_wide_x3_kernel(PwArgs g) {
 int g_wide_waves = 8, g_wide_dbg = 0;
 template <int X2>
 void gw_launch(GwArgs& g, int M, int N, hipStream_t stream) {
-    g.dbg = g_wide_dbg;
+    g.dbg = g_wide_dbg; g.N_total = N;
     if (g_wide_waves == 4) {
         g.ncg = N / 256;
         hipLaunchKernelGGL((gemm_wide_kernel<X2, 4>), dim3(vxb_cdiv(M, WBM) * g.ncg), dim3(256), 0, stream, g);
@@ -685,6 +694,22 @@ extern "C" int vxb_gemm_wide_bf16x3_f32(const float* A, int64_t lda, const void*
     g.A = A; g.lda = lda; g.Bfrag = (const u16*)Bw_frag; g.C = C; g.ldc = ldc; g.bias = bias; g.residual = residual;
     g.M = M; g.K = K; g.act = act; g.slope = slope; g.accumulate = accumulate;
     g.geglu = 0; g.F = 0; g.C2 = nullptr; g.H = nullptr; g.scale = nullptr;
+    gw_launch<0>(g, M, N, (hipStream_t)stream);
+    VXB_CHECK_LAUNCH();
+    return VXB_OK;
+}
+
+// The same product with the result ALSO written as one fp16 plane [M][N] (saturating round-to-nearest: the bits vxb_split_f16_f32 makes of
+// C) -- the k | v operand plane of the pipelined attention kernels out of to_kv's epilogue instead of by a pass over kv (round 6).
+extern "C" int vxb_gemm_wide_bf16x3_f16out_f32(const float* A, int64_t lda, const void* Bw_frag, float* C, int64_t ldc, const float* bias,
+                                               const float* residual, int M, int N, int K, int act, float slope, int accumulate,
+                                               void* f16_out, vxb_stream_t stream) {
+    if (!A || !Bw_frag || !C || !f16_out || M < 1 || K < 64) return VXB_EARG;
+    if (N < 512 || (N & 511) || (K & 31) || (lda & 3) || (((uintptr_t)A | (uintptr_t)Bw_frag | (uintptr_t)f16_out) & 15)) return VXB_ESIZE;
+    GwArgs g;
+    g.A = A; g.lda = lda; g.Bfrag = (const u16*)Bw_frag; g.C = C; g.ldc = ldc; g.bias = bias; g.residual = residual;
+    g.M = M; g.K = K; g.act = act; g.slope = slope; g.accumulate = accumulate;
+    g.geglu = 0; g.F = 0; g.C2 = nullptr; g.H = nullptr; g.scale = nullptr; g.aux16 = (u16*)f16_out;
     gw_launch<0>(g, M, N, (hipStream_t)stream);
     VXB_CHECK_LAUNCH();
     return VXB_OK;

@@ -507,7 +507,7 @@ int vox_launch_reduce(const VoxSrc& src, const VoxGeom& g, const VoxWs& w, float
 
 }  // namespace
 
-extern "C" int vxb_abi_version(void) { return 4; }      // 4 (round 6): + vxb_gemm_wide_geglu_bwd_f16x2_f32; 3: vxb_patch_dgrad_input_wgrad_f32 gained dWp / ws_wp in round 5 (advisor), + the *_mask attention entries
+extern "C" int vxb_abi_version(void) { return 4; }      // 4 (round 6): + vxb_gemm_wide_geglu_bwd_f16x2_f32, vxb_gemm_wide_bf16x3_f16out_f32; 3: vxb_patch_dgrad_input_wgrad_f32 gained dWp / ws_wp in round 5 (advisor), + the *_mask attention entries
 
 namespace {
 struct VoxStreams {

@@ -274,10 +274,15 @@ def _small(M, N, K):
     return M * N * K <= _NAIVE_MACS or (K % 4) or (N % 4)
 
 
-def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None):
-    """out[M,N] = act(x[M,K] @ W[N,K]^T + bias) (+ residual).  nn.Linear / DenseBlock forward."""
+def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, f16_out=None):
+    """out[M,N] = act(x[M,K] @ W[N,K]^T + bias) (+ residual).  nn.Linear / DenseBlock forward.  f16_out: see gemm_bf16w -- then the
+    return value is (out, filled)."""
     M, K = x.shape
     N = W.shape[0]
+    if f16_out is not None:
+        if not _small(M, N, K) and _mm() and K % 8 == 0 and W.is_contiguous():
+            return gemm_bf16w(x, _bf16_weight(W, False), out, bias, act, residual, label='gemm_fwd %dx%dx%d' % (M, N, K), f16_out=f16_out)
+        return linear(x, W, bias, act, residual, out), False
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
     if _small(M, N, K):
@@ -1482,8 +1487,24 @@ def split_planes(x2d, nplanes):
     return planes
 
 
-def gemm_bf16w(x, Wb, out=None, bias=None, act=ACT_NONE, residual=None, accumulate=False, label=None):
-    """out[M,N] = act(x[M,K] (fp32 -> bf16 on the fly) @ Wb[N,K]^T (bf16) + bias) (+ residual), fp32 accumulate."""
+def gemm_bf16w(x, Wb, out=None, bias=None, act=ACT_NONE, residual=None, accumulate=False, label=None, f16_out=None):
+    """out[M,N] = act(x[M,K] (fp32 -> bf16 on the fly) @ Wb[N,K]^T (bf16) + bias) (+ residual), fp32 accumulate.  f16_out (contiguous
+    half [M][N] view): filled with the fp16 plane of the result where the wide kernel runs (its epilogue); returns out, or (out, filled)
+    when f16_out is given."""
+    if f16_out is not None:
+        M_, K_ = x.shape
+        N_ = Wb.shape[-2]
+        if (WIDE_GEMM and Wb.dim() == 3 and N_ % 512 == 0 and K_ % 32 == 0 and K_ >= 256 and M_ >= WIDE_MIN_M and x.stride(1) == 1
+                and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and not accumulate and f16_out.is_contiguous() and f16_out.data_ptr() % 16 == 0):
+            wf = gemm_wfrag(Wb)
+            if wf is not None:
+                if out is None:
+                    out = torch.empty((M_, N_), dtype=torch.float32, device=x.device)
+                _lib.set_meta(label or 'gemm_bf16 %dx%dx%d' % (M_, N_, K_), 2.0 * M_ * N_ * K_)
+                call('vxb_gemm_wide_bf16x3_f16out_f32', x, x.stride(0), wf, out, out.stride(0), bias, residual, M_, N_, K_, act, LRELU_SLOPE, 0,
+                     f16_out)
+                return out, True
+        return gemm_bf16w(x, Wb, out, bias, act, residual, accumulate, label), False
     M, K = x.shape
     x3 = Wb.dim() == 3          # hi/lo planes of the bf16x3 split
     N = Wb.shape[-2]
